@@ -1,0 +1,151 @@
+/*
+ * r3dm.h -- C ABI of the MI355X-native compute-matches hot path (libr3dm.so).
+ *
+ * Drop-in boundary for Regard3D's "Compute matches" stage.  Each entry point replaces one
+ * interface of the reference (rhiestan/Regard3D, paths relative to /root/reference):
+ *
+ *   r3dm_set_image          <- Regions_Provider::load + regions_provider->get(I)
+ *                              (src/R3DComputeMatches.cpp:2040, 443-472): one call per view with the
+ *                              view's DescriptorRawData() / RegionCount() / DescriptorLength() and its
+ *                              feature positions (Features_Provider::load, :2094-2095)
+ *   r3dm_match_pairs        <- Matcher_Regions(fDistRatio, BRUTE_FORCE_L2).Match(regions_provider,
+ *                              pairs, map_PutativesMatches) (src/R3DComputeMatches.cpp:2037-2039,2048)
+ *                              and its in-tree clones kgraph_match / hnsw_match / mrpt_match
+ *                              (:808-902, :502-597, :423-491): a new "matchingAlgorithm == 9" arm
+ *   r3dm_filter_F           <- ImageCollectionGeometricFilter::Robust_model_estimation(
+ *                              GeometricFilter_FMatrix_AC(4.0, 2048), putative, false) +
+ *                              Get_geometric_matches() (src/R3DComputeMatches.cpp:2099,2113-2115)
+ *   r3dm_knn2               <- openMVG::matching::ArrayMatcher<Scalar,Metric>::Build +
+ *                              SearchNeighbours(query, nbQuery, &idx, &dist, NN=2)
+ *                              (plugin contract: src/utils/matcher_kgraph.h:120-125,205-211)
+ *   r3dm_save_matches /     <- openMVG::matching::Save / Load(PairWiseMatches, "matches.*.txt|.bin")
+ *   r3dm_load_matches          (src/R3DComputeMatches.cpp:2064,2120; names src/R3DProject.cpp:858-871)
+ *   r3dm_graph_*            <- openMVG::matching::PairWiseMatches accessors
+ *                              (R3DComputeMatchesStatistics, src/R3DComputeMatches.h:59-66)
+ *
+ * Conventions: every function returns 0 on success or a negative r3dm_status; nothing throws;
+ * all state lives in the opaque context; buffers passed in stay owned by the caller (they are
+ * copied -- host or device pointers are both accepted, the copy is hipMemcpyDefault); objects
+ * returned by the library are released only with the matching *_free.  One context per host
+ * thread (or serialise externally); one context drives one GPU (one process per GPU).
+ * There is NO CPU fallback: if no gfx950 device is visible r3dm_create fails with
+ * R3DM_ERR_NO_DEVICE.
+ */
+#ifndef R3DM_H
+#define R3DM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct r3dm_ctx r3dm_ctx;
+typedef struct r3dm_graph r3dm_graph;
+
+typedef enum {
+    R3DM_OK = 0,
+    R3DM_ERR_INVALID = -1,     /* bad argument                                   */
+    R3DM_ERR_NO_DEVICE = -2,   /* no usable gfx950 GPU / HIP runtime failure      */
+    R3DM_ERR_HIP = -3,         /* a HIP call failed (see r3dm_last_error)         */
+    R3DM_ERR_IO = -4,          /* file could not be read / written                */
+    R3DM_ERR_UNSUPPORTED = -5, /* descriptor type / metric combination            */
+    R3DM_ERR_NOMEM = -6
+} r3dm_status;
+
+typedef enum {
+    R3DM_F32 = 0,   /* Scalar_Regions<.., float, D>: D floats per row (SIFT-128 f32, LIOP-144) */
+    R3DM_U8 = 1,    /* Scalar_Regions<.., unsigned char, D>: D bytes per row, L2 metric        */
+    R3DM_BIN = 2    /* Binary_Regions<.., NB>: NB bytes per row, Hamming metric                 */
+} r3dm_dtype;
+
+typedef struct { uint32_t i, j; } r3dm_match;   /* IndMatch{i_, j_}: i_ = row in I, j_ = row in J */
+
+/* which squared epipolar error the AC kernel binds (default symmetric) */
+typedef enum { R3DM_ERR_SYMMETRIC_EPIPOLAR = 0, R3DM_ERR_SAMPSON = 1, R3DM_ERR_EPIPOLAR_ONE_SIDED = 2 } r3dm_ferror;
+
+/* ---- context ---- */
+int  r3dm_create(int device_id, r3dm_ctx** out);
+void r3dm_destroy(r3dm_ctx* ctx);
+const char* r3dm_last_error(const r3dm_ctx* ctx);
+/* "gfx950", CU count, bytes of HBM -- for reports */
+int  r3dm_device_info(const r3dm_ctx* ctx, char* arch, size_t arch_cap, int* n_cu, uint64_t* hbm_bytes);
+
+/* ---- views ----
+ * Register (or replace) view `view_id`: n descriptors of `dim` elements (floats for F32, bytes for
+ * U8/BIN), row-major, plus optional feature positions xy (n x 2 floats, pixel coordinates; NULL if
+ * no coordinate de-duplication / geometric filter is wanted).  The data is copied to HBM and
+ * re-laid-out there (MFMA fragment-order tiles + row norms). */
+int r3dm_set_image(r3dm_ctx* ctx, uint32_t view_id, uint32_t width, uint32_t height,
+                   const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);
+int r3dm_clear_images(r3dm_ctx* ctx);
+
+/* ---- putative matching ----
+ * pairs_ij: n_pairs x 2 view ids (I, J); J's rows are the queries, I's rows the dataset.
+ * dist_ratio: Lowe ratio (0.6 default in the reference, src/Regard3DFeatures.cpp:129);
+ * squared_metric != 0 applies ratio^2 (RegionsMatcherT ctor flag, true for L2).
+ * The result holds only non-empty pairs, ordered by (I, J), matches ordered by (i_, j_). */
+int r3dm_match_pairs(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs,
+                     float dist_ratio, int squared_metric, r3dm_graph** out);
+
+/* ---- geometric filter ----
+ * AC-RANSAC fundamental-matrix filter over every pair of `putative`.  F_out (may be NULL) receives
+ * 9 doubles (row-major F) per KEPT pair, in the order of the returned graph. */
+int r3dm_filter_F(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                  uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out);
+
+/* Per-pair outcome of the last r3dm_filter_F call -- what OpenMVG's ACRANSAC returns besides the inliers
+ * (std::pair<errorMax, minNFA>) plus work counters.  One entry per pair of the putative graph, in its
+ * order; pairs with <= 7 putatives are all-zero.  Returns the number of entries available. */
+typedef struct {
+    double   threshold_px;   /* AC-RANSAC inlier threshold (pixels); 0 when no meaningful model     */
+    double   nfa;            /* minimum log10 NFA (+inf when nothing was evaluated)                  */
+    uint32_t iterations;     /* iterations executed                                                  */
+    uint32_t models;         /* models evaluated                                                     */
+    uint32_t inliers;        /* inliers found (before the > 2.5*7 acceptance rule)                   */
+    uint32_t reserved;
+} r3dm_pair_report;
+int r3dm_filter_report(const r3dm_ctx* ctx, r3dm_pair_report* out, uint64_t cap);
+
+/* ---- ArrayMatcher-shaped low level call: 2-NN of each query row among the dataset rows ----
+ * out_idx / out_dist: 2 entries per query, ascending distance (dist: float squared L2 for F32/U8,
+ * Hamming distance converted to float for BIN).  Fails (R3DM_ERR_INVALID) when n_query < 1 or
+ * n_dataset < 2, like ArrayMatcherBruteForce::SearchNeighbours with NN = 2. */
+int r3dm_knn2(r3dm_ctx* ctx, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
+              uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist);
+
+/* ---- match graph (PairWiseMatches) ---- */
+uint64_t          r3dm_graph_num_pairs(const r3dm_graph* g);
+uint64_t          r3dm_graph_num_matches(const r3dm_graph* g);
+const uint32_t*   r3dm_graph_pairs(const r3dm_graph* g);     /* n_pairs x 2                        */
+const uint64_t*   r3dm_graph_offsets(const r3dm_graph* g);   /* n_pairs + 1 (CSR into matches)     */
+const r3dm_match* r3dm_graph_matches(const r3dm_graph* g);
+void              r3dm_graph_free(r3dm_graph* g);
+/* build a graph from host CSR arrays (copied); used to re-assemble shards after the all-gather */
+int r3dm_graph_from_csr(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64_t* offsets,
+                        const r3dm_match* matches, r3dm_graph** out);
+/* merge several graphs (e.g. one per rank) into one ordered by (I, J) */
+int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out);
+
+/* ---- files: ".txt" (what Regard3D's consumers read) or ".bin" (cereal portable binary) ---- */
+int r3dm_save_matches(const r3dm_graph* g, const char* path);
+int r3dm_load_matches(const char* path, r3dm_graph** out);
+
+/* ---- run statistics of the last r3dm_match_pairs / r3dm_filter_F call ---- */
+typedef struct {
+    double   ms_match_kernels;     /* HIP-event time of the 2-NN kernels (dominant kernel)        */
+    uint64_t n_match_launches;     /* launches of the dominant kernel                              */
+    double   ms_filter_kernels;    /* HIP-event time of the AC-RANSAC kernel                       */
+    uint64_t n_pairs;              /* pairs processed                                              */
+    uint64_t n_queries;            /* query rows processed                                         */
+    uint64_t n_exact_fallback;     /* queries re-done by the exact scan (uncertified top-2)        */
+    double   algorithmic_flops;    /* 2 * nI * nJ * D summed over pairs (L2) / lane-ops (Hamming)   */
+    double   algorithmic_bytes;    /* compulsory HBM bytes: both descriptor sets once + results     */
+} r3dm_stats;
+int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

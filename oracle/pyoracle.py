@@ -1,0 +1,251 @@
+"""ctypes binding of oracle/liboracle.so (the CPU restatement) and oracle/_ref/libref_hnsw.so.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (regard3d_amd/) must never import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+
+class Match(C.Structure):
+    _fields_ = [("i", C.c_uint32), ("j", C.c_uint32)]
+
+
+class FResult(C.Structure):
+    _fields_ = [("F", C.c_double * 9), ("threshold", C.c_double), ("nfa", C.c_double),
+                ("n_inliers", C.c_uint32), ("n_iter", C.c_uint32), ("n_models", C.c_uint32),
+                ("accepted", C.c_int)]
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "r3d_oracle.h", "Makefile")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref = os.path.join(_HERE, "_ref", "libref_hnsw.so")
+    if os.path.isdir("/root/reference/src/thirdparty/hnswlib") and (force or not os.path.exists(ref)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_l2sq_f32.restype = C.c_float
+        L.orc_l2sq_u8.restype = C.c_float
+        L.orc_hamming.restype = C.c_uint32
+        L.orc_match_collection.restype = C.c_int64
+        L.orc_filter_F_collection.restype = C.c_int64
+        L.orc_rng_u64.restype = C.c_uint64
+        L.orc_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_sym_epipolar_err.restype = C.c_double
+        L.orc_sym_epipolar_err.argtypes = [C.c_void_p] + [C.c_double] * 4
+        _LIB = L
+    return _LIB
+
+
+def ref_lib():
+    """hnswlib::BruteforceSearch compiled from the reference tree (None if not built)."""
+    global _REF
+    if _REF is None:
+        so = os.path.join(_HERE, "_ref", "libref_hnsw.so")
+        if not os.path.exists(so):
+            return None
+        _REF = C.CDLL(so)
+    return _REF
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dtype_code(desc: np.ndarray, binary: bool) -> int:
+    if desc.dtype == np.float32:
+        return 0
+    if desc.dtype == np.uint8:
+        return 2 if binary else 1
+    raise TypeError(desc.dtype)
+
+
+def l2sq(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    if a.dtype == np.uint8:
+        return float(lib().orc_l2sq_u8(_p(a), _p(b), C.c_size_t(a.size)))
+    return float(lib().orc_l2sq_f32(_p(a.astype(np.float32)), _p(b.astype(np.float32)), C.c_size_t(a.size)))
+
+
+def hamming(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+    return int(lib().orc_hamming(_p(a), _p(b), C.c_size_t(a.size)))
+
+
+def knn2(dataset: np.ndarray, query: np.ndarray, binary: bool = False):
+    """Brute-force 2-NN of every query row among the dataset rows -> (idx [nJ,2], dist [nJ,2])."""
+    dataset = np.ascontiguousarray(dataset); query = np.ascontiguousarray(query)
+    nI, dim = dataset.shape; nJ = query.shape[0]
+    idx = np.full((nJ, 2), -1, np.int32)
+    code = _dtype_code(dataset, binary)
+    if code == 2:
+        dist = np.zeros((nJ, 2), np.uint32)
+        rc = lib().orc_knn2_hamming(_p(dataset), nI, _p(query), nJ, dim, _p(idx), _p(dist))
+    elif code == 1:
+        dist = np.zeros((nJ, 2), np.float32)
+        rc = lib().orc_knn2_l2_u8(_p(dataset), nI, _p(query), nJ, dim, _p(idx), _p(dist))
+    else:
+        dist = np.zeros((nJ, 2), np.float32)
+        rc = lib().orc_knn2_l2_f32(_p(dataset), nI, _p(query), nJ, dim, _p(idx), _p(dist))
+    if rc != 0:
+        raise ValueError("knn2 failed (nJ < 1 or nI < 2)")
+    return idx, dist
+
+
+def ref_knn(dataset: np.ndarray, query: np.ndarray, k: int = 2):
+    L = ref_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_hnsw.so not built")
+    dataset = np.ascontiguousarray(dataset, np.float32); query = np.ascontiguousarray(query, np.float32)
+    nI, dim = dataset.shape; nJ = query.shape[0]
+    idx = np.zeros((nJ, k), np.int32); dist = np.zeros((nJ, k), np.float32)
+    rc = L.ref_hnsw_knn_l2(_p(dataset), nI, _p(query), nJ, dim, k, _p(idx), _p(dist))
+    if rc != 0:
+        raise RuntimeError("ref_hnsw_knn_l2 failed")
+    return idx, dist
+
+
+def match_distance_ratio(descI, descJ, ratio: float, squared: bool = True, xyI=None, xyJ=None,
+                         binary: bool = False) -> np.ndarray:
+    descI = np.ascontiguousarray(descI); descJ = np.ascontiguousarray(descJ)
+    nI, dim = descI.shape; nJ = descJ.shape[0]
+    out = np.zeros((max(nJ, 1), 2), np.uint32)
+    xi = np.ascontiguousarray(xyI, np.float32) if xyI is not None else None
+    xj = np.ascontiguousarray(xyJ, np.float32) if xyJ is not None else None
+    m = lib().orc_match_distance_ratio(_dtype_code(descI, binary), _p(descI), nI,
+                                       _p(xi) if xi is not None else None,
+                                       _p(descJ), nJ, _p(xj) if xj is not None else None, dim,
+                                       C.c_float(ratio), int(squared), _p(out))
+    return out[:m].copy()
+
+
+def match_collection(descs, xys, pairs: np.ndarray, ratio: float, squared: bool = True, binary: bool = False):
+    """descs: list of [n_i, dim] arrays.  pairs: [P,2] uint32.  -> (counts [P], matches [M,2])."""
+    n = len(descs)
+    descs = [np.ascontiguousarray(d) for d in descs]
+    dim = descs[0].shape[1]
+    code = _dtype_code(descs[0], binary)
+    dptr = (C.c_void_p * n)(*[d.ctypes.data for d in descs])
+    nrows = np.array([d.shape[0] for d in descs], np.int32)
+    if xys is not None:
+        xys = [np.ascontiguousarray(x, np.float32) for x in xys]
+        xptr = (C.c_void_p * n)(*[x.ctypes.data for x in xys])
+    else:
+        xptr = None
+    pairs = np.ascontiguousarray(pairs, np.uint32)
+    P = pairs.shape[0]
+    counts = np.zeros(P, np.uint32)
+    cap = int(sum(int(nrows[j]) for j in pairs[:, 1])) + 1
+    out = np.zeros((cap, 2), np.uint32)
+    tot = lib().orc_match_collection(code, n, dptr, _p(nrows), xptr, dim, _p(pairs), C.c_int64(P),
+                                     C.c_float(ratio), int(squared), _p(counts), _p(out), C.c_int64(cap))
+    if tot < 0:
+        raise RuntimeError("capacity")
+    return counts, out[:tot].copy()
+
+
+def acransac_F(xI, xJ, wI, hI, wJ, hJ, precision_px=4.0, max_iter=2048, seed=5489, I=0, J=1):
+    xI = np.ascontiguousarray(xI, np.float64); xJ = np.ascontiguousarray(xJ, np.float64)
+    m = xI.shape[0]
+    inl = np.zeros(max(m, 1), np.uint32)
+    fr = FResult()
+    n = lib().orc_acransac_F(_p(xI), _p(xJ), m, wI, hI, wJ, hJ, C.c_double(precision_px), C.c_uint32(max_iter),
+                             C.c_uint64(seed), C.c_uint32(I), C.c_uint32(J), _p(inl), C.byref(fr))
+    return inl[:n].copy(), fr
+
+
+def acransac_F_traced(xI, xJ, wI, hI, wJ, hJ, precision_px=4.0, max_iter=2048, seed=5489, I=0, J=1, cap=16384):
+    buf = np.zeros((cap, 5), np.float64)
+    lib().orc_set_trace(_p(buf), cap)
+    inl, fr = acransac_F(xI, xJ, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J)
+    n = lib().orc_trace_rows()
+    lib().orc_set_trace(None, 0)
+    return inl, fr, buf[:n].copy()
+
+
+def filter_F_collection(xys, widths, heights, pairs, counts, matches, precision_px=4.0, max_iter=2048,
+                        seed=5489, want_F=False):
+    n = len(xys)
+    xys = [np.ascontiguousarray(x, np.float32) for x in xys]
+    xptr = (C.c_void_p * n)(*[x.ctypes.data for x in xys])
+    nrows = np.array([x.shape[0] for x in xys], np.int32)
+    widths = np.ascontiguousarray(widths, np.uint32); heights = np.ascontiguousarray(heights, np.uint32)
+    pairs = np.ascontiguousarray(pairs, np.uint32); counts = np.ascontiguousarray(counts, np.uint32)
+    matches = np.ascontiguousarray(matches, np.uint32).reshape(-1, 2)
+    P = pairs.shape[0]
+    oc = np.zeros(P, np.uint32)
+    out = np.zeros((max(matches.shape[0], 1), 2), np.uint32)
+    Fo = np.zeros((P, 9), np.float64) if want_F else None
+    tot = lib().orc_filter_F_collection(n, _p(nrows), xptr, _p(widths), _p(heights), _p(pairs), C.c_int64(P),
+                                        _p(counts), _p(matches), C.c_double(precision_px), C.c_uint32(max_iter),
+                                        C.c_uint64(seed), _p(oc), _p(out), _p(Fo) if want_F else None)
+    return (oc, out[:tot].copy(), Fo) if want_F else (oc, out[:tot].copy())
+
+
+def seven_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    Fs = np.zeros((3, 9), np.float64)
+    n = lib().orc_seven_point(_p(x1), _p(x2), _p(Fs))
+    return Fs[:n].reshape(n, 3, 3).copy()
+
+
+def solve_cubic(coeffs):
+    c = np.ascontiguousarray(coeffs, np.float64); r = np.zeros(3, np.float64)
+    n = lib().orc_solve_cubic(_p(c), _p(r))
+    return r[:n].copy()
+
+
+def sample7(seed, I, J, it, pool):
+    pool = np.ascontiguousarray(pool, np.uint32)
+    s = np.zeros(7, np.uint32)
+    lib().orc_sample7(C.c_uint64(seed), C.c_uint32(I), C.c_uint32(J), C.c_uint32(it), _p(pool),
+                      C.c_uint32(pool.size), _p(s))
+    return s
+
+
+def logcombi_tables(n, k=7):
+    a = np.zeros(n + 1, np.float32); b = np.zeros(n + 1, np.float32)
+    lib().orc_logcombi_tables(C.c_uint32(n), C.c_uint32(k), _p(a), _p(b))
+    return a, b
+
+
+def save_matches(path, pairs, counts, matches):
+    pairs = np.ascontiguousarray(pairs, np.uint32); counts = np.ascontiguousarray(counts, np.uint32)
+    matches = np.ascontiguousarray(matches, np.uint32).reshape(-1, 2)
+    rc = lib().orc_save_matches(path.encode(), C.c_int64(pairs.shape[0]), _p(pairs), _p(counts), _p(matches))
+    if rc != 0:
+        raise IOError(rc)
+
+
+def load_matches(path):
+    np_ = C.c_int64(0); nm = C.c_int64(0)
+    rc = lib().orc_load_matches(path.encode(), C.byref(np_), C.byref(nm), None, None, None)
+    if rc != 0:
+        raise IOError(rc)
+    pairs = np.zeros((np_.value, 2), np.uint32); counts = np.zeros(np_.value, np.uint32)
+    matches = np.zeros((max(nm.value, 1), 2), np.uint32)
+    rc = lib().orc_load_matches(path.encode(), C.byref(np_), C.byref(nm), _p(pairs), _p(counts), _p(matches))
+    if rc != 0:
+        raise IOError(rc)
+    return pairs, counts, matches[:nm.value].copy()

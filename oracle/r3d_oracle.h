@@ -1,0 +1,147 @@
+/*
+ * r3d_oracle.h -- CPU restatement ("oracle") of Regard3D's compute-matches hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and only as the checker / CPU baseline -- never as a fallback for the HIP path.
+ *
+ * What it restates (reference = /root/reference, rhiestan/Regard3D):
+ *   - the per-I / OpenMP-over-J / critical-insert loop nest of the matcher drivers
+ *     (src/R3DComputeMatches.cpp:423-491 mrpt_match, :502-597 hnsw_match, :808-902
+ *     kgraph_match -- all share the skeleton) and the dispatch + save + F-filter calls
+ *     (src/R3DComputeMatches.cpp:2035-2129);
+ *   - the ArrayMatcher plugin contract (src/utils/matcher_kgraph.h:120-251):
+ *     Build / SearchNeighbours, NN entries per query in ascending distance order;
+ *   - the file formats named in src/R3DProject.cpp:854-871 and src/keypointSet.hpp:49-67.
+ *
+ * The arithmetic itself (squared-L2 metric, brute-force 2-NN, distance-ratio test,
+ * AC-RANSAC with the 7-point fundamental solver, matches.*.txt/.bin writers) lives in
+ * OpenMVG 1.4, an EXTERNAL dependency that is NOT vendored under /root/reference
+ * (FIND_PACKAGE(OpenMVG REQUIRED), src/CMakeLists.txt:485; "OpenMVG 1.4", README.md:19).
+ * Those parts restate OpenMVG's published algorithm and anchor on
+ * the reference's own call sites.  The reference ships NO tests or golden vectors for this
+ * path, so:
+ *
+ *      >>>  PARITY UNPINNED by reference tests.  <<<
+ *
+ * The oracle is instead pinned by (a) analytic known-answer tests (tests/test_oracle_*.py),
+ * (b) hnswlib::BruteforceSearch compiled from the reference's vendored copy
+ * (oracle/_ref, built by oracle/Makefile; fixtures in tests/golden/), and
+ * (c) numpy/scipy second opinions (SVD null space, polynomial roots, exact rational L2).
+ *
+ * Restatement decisions where OpenMVG leaves behaviour unspecified (documented in DESIGN.md):
+ *   - equal distances: the lowest dataset row index wins (OpenMVG's partial sort is unstable);
+ *   - matches of a pair are emitted sorted by (i_, j_); coordinate de-duplication keeps the
+ *     smallest (i_, j_) of every group of matches with identical (xI,yI,xJ,yJ);
+ *   - squared L2 is evaluated without FMA contraction (build with -ffp-contract=off);
+ *   - AC-RANSAC draws its minimal samples from a counter-based generator keyed by
+ *     (seed, I, J, iteration, attempt) instead of std::mt19937, so the sample stream is
+ *     identical on any host or device and independent of how pairs are batched/sharded;
+ *   - the 7-point solver takes the 2-D null space from a Householder QR of A^T.
+ */
+#ifndef R3D_ORACLE_H
+#define R3D_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint32_t i, j; } orc_match;
+
+/* ---- metrics (OpenMVG matching/metric.hpp L2<T>, metric_hamming.hpp) ---- */
+float    orc_l2sq_f32(const float* a, const float* b, size_t n);
+float    orc_l2sq_u8(const uint8_t* a, const uint8_t* b, size_t n);
+uint32_t orc_hamming(const uint8_t* a, const uint8_t* b, size_t nbytes);
+
+/* ---- brute-force 2-NN (OpenMVG ArrayMatcherBruteForce::SearchNeighbours) ----
+ * dataset: nI rows, query: nJ rows, row-major.  idx/dist hold 2 entries per query, ascending.
+ * Returns 0, or -1 when the call would fail in OpenMVG (nJ < 1 or nI < 2). */
+int orc_knn2_l2_f32(const float* dataset, int nI, const float* query, int nJ, int dim,
+                    int32_t* idx, float* dist);
+int orc_knn2_l2_u8(const uint8_t* dataset, int nI, const uint8_t* query, int nJ, int dim,
+                   int32_t* idx, float* dist);
+int orc_knn2_hamming(const uint8_t* dataset, int nI, const uint8_t* query, int nJ, int nbytes,
+                     int32_t* idx, uint32_t* dist);
+
+/* ---- MatchDistanceRatio (OpenMVG RegionsMatcherT; call sites
+ * src/R3DComputeMatches.cpp:479,585,890).  dtype: 0 = f32 L2, 1 = u8 L2, 2 = binary Hamming.
+ * dim = floats / bytes per row.  xyI/xyJ (n x 2 floats) may be NULL (no coordinate dedup).
+ * out must hold nJ entries; returns the number of matches written (sorted by (i,j)). */
+int orc_match_distance_ratio(int dtype, const void* descI, int nI, const float* xyI,
+                             const void* descJ, int nJ, const float* xyJ, int dim,
+                             float dist_ratio, int squared_metric, orc_match* out);
+
+/* ---- collection matcher: the reference loop nest (src/R3DComputeMatches.cpp:428-489).
+ * images: arrays of length n_images.  pairs: n_pairs x 2 (I,J).  Results are returned in a
+ * CSR over the INPUT pair order: counts[p] matches for pair p, concatenated in `out`
+ * (capacity out_cap entries).  Returns total matches or -1 if out_cap is too small.
+ * OpenMP: serial over I, parallel-for schedule(dynamic) over the J's of one I. */
+int64_t orc_match_collection(int dtype, int n_images, const void* const* desc, const int* n_rows,
+                             const float* const* xy, int dim, const uint32_t* pairs, int64_t n_pairs,
+                             float dist_ratio, int squared_metric,
+                             uint32_t* counts, orc_match* out, int64_t out_cap);
+
+/* ---- AC-RANSAC fundamental-matrix filter (OpenMVG GeometricFilter_FMatrix_AC + ACRANSAC +
+ * SevenPointSolver + SymmetricEpipolarDistanceError; call site
+ * src/R3DComputeMatches.cpp:2113-2115 with precision 4.0, 2048 iterations). */
+typedef struct {
+    double F[9];        /* row-major, un-normalised (pixel) fundamental matrix             */
+    double threshold;   /* AC-RANSAC inlier threshold in pixels (unormalizeError(errorMax)) */
+    double nfa;         /* minimum log10 NFA                                                */
+    uint32_t n_inliers; /* inliers found by AC-RANSAC (before the > 2.5*7 acceptance test)   */
+    uint32_t n_iter;    /* iterations actually executed                                      */
+    uint32_t n_models;  /* models evaluated                                                  */
+    int accepted;       /* 1 iff n_inliers > 2.5 * 7                                         */
+} orc_fresult;
+
+/* xI, xJ: m x 2 pixel coordinates (row-major doubles) of the putative matches, in putative
+ * order.  inliers: capacity m; receives indices into the putative list in AC-RANSAC order
+ * (ascending residual).  Returns the number of inliers (0 when rejected by AC-RANSAC itself;
+ * check res->accepted for the 2.5*7 rule). */
+int orc_acransac_F(const double* xI, const double* xJ, int m,
+                   int wI, int hI, int wJ, int hJ,
+                   double precision_px, uint32_t max_iter,
+                   uint64_t seed, uint32_t I, uint32_t J,
+                   uint32_t* inliers, orc_fresult* res);
+
+/* Filter a whole putative graph (CSR as produced by orc_match_collection, pairs with count 0
+ * skipped).  OpenMP over pairs (OpenMVG Robust_model_estimation).  out_counts[p] = number of
+ * geometric matches kept for pair p (0 if rejected); matches concatenated in out. */
+int64_t orc_filter_F_collection(int n_images, const int* n_rows, const float* const* xy,
+                                const uint32_t* widths, const uint32_t* heights,
+                                const uint32_t* pairs, int64_t n_pairs,
+                                const uint32_t* counts, const orc_match* matches,
+                                double precision_px, uint32_t max_iter, uint64_t seed,
+                                uint32_t* out_counts, orc_match* out, double* F_out /* 9 per pair or NULL */);
+
+/* Debug trace of the next orc_acransac_F call(s): rows of (iter, model, #<=bound, NFA, improved). */
+void orc_set_trace(double* buf, int cap_rows);
+int  orc_trace_rows(void);
+
+/* Pieces exposed for known-answer tests. */
+uint64_t orc_rng_u64(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter, uint32_t attempt);
+void     orc_sample7(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter,
+                     const uint32_t* pool, uint32_t pool_size, uint32_t* sample7);
+int      orc_seven_point(const double* x1 /*7x2 normalised*/, const double* x2, double* Fs /*3x9*/);
+int      orc_solve_cubic(const double* coeffs /*c0..c3*/, double* roots);
+double   orc_sym_epipolar_err(const double* F, double x1, double y1, double x2, double y2);
+void     orc_logcombi_tables(uint32_t n, uint32_t k_sample, float* logc_n /*n+1*/, float* logc_k /*n+1*/);
+
+/* ---- file formats (src/keypointSet.hpp:49-67, src/R3DProject.cpp:854-871) ---- */
+int orc_save_matches(const char* path, int64_t n_pairs, const uint32_t* pairs,
+                     const uint32_t* counts, const orc_match* matches);   /* .txt or .bin by extension */
+/* Two-call load: first with pairs/counts/matches == NULL to get sizes. */
+int orc_load_matches(const char* path, int64_t* n_pairs, int64_t* n_matches,
+                     uint32_t* pairs, uint32_t* counts, orc_match* matches);
+int orc_save_feat(const char* path, int n, const float* xyso /* n x 4: x y scale orientation */);
+int orc_load_feat(const char* path, int* n, float* xyso, int cap);
+int orc_save_desc(const char* path, uint64_t n, size_t row_bytes, const void* data);
+int orc_load_desc(const char* path, uint64_t* n, size_t row_bytes, void* data, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,260 @@
+"""ctypes host binding of libr3dm.so -- the C ABI in include/r3dm.h.
+
+This is the Python face of the drop-in boundary used by tests/, bench.py and the multi-GPU
+driver.  It contains NO arithmetic: every call goes through the C ABI into the HIP kernels.
+If the shared library (or a gfx950 GPU) is missing the calls raise -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libr3dm.so")
+
+F32, U8, BIN = 0, 1, 2
+NONE = 0xFFFFFFFF
+
+EXPORTS = [
+    "r3dm_create", "r3dm_destroy", "r3dm_last_error", "r3dm_device_info", "r3dm_set_image", "r3dm_clear_images",
+    "r3dm_match_pairs", "r3dm_filter_F", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
+    "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
+    "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
+    "r3dm_compute_matches_dir",
+]
+
+
+class R3dmError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_match_kernels", C.c_double), ("n_match_launches", C.c_uint64),
+                ("ms_filter_kernels", C.c_double), ("n_pairs", C.c_uint64), ("n_queries", C.c_uint64),
+                ("n_exact_fallback", C.c_uint64), ("algorithmic_flops", C.c_double),
+                ("algorithmic_bytes", C.c_double)]
+
+
+class PairReport(C.Structure):
+    _fields_ = [("threshold_px", C.c_double), ("nfa", C.c_double), ("iterations", C.c_uint32),
+                ("models", C.c_uint32), ("inliers", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libr3dm.so and declare prototypes.  Raises if the extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise R3dmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.r3dm_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.r3dm_destroy.argtypes = [vp]; L.r3dm_destroy.restype = None
+    L.r3dm_last_error.argtypes = [vp]; L.r3dm_last_error.restype = C.c_char_p
+    L.r3dm_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(u64)]
+    L.r3dm_set_image.argtypes = [vp, u32, u32, u32, vp, u32, u32, C.c_int, vp]
+    L.r3dm_clear_images.argtypes = [vp]
+    L.r3dm_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
+    L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
+    L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
+    L.r3dm_graph_num_pairs.argtypes = [vp]; L.r3dm_graph_num_pairs.restype = u64
+    L.r3dm_graph_num_matches.argtypes = [vp]; L.r3dm_graph_num_matches.restype = u64
+    L.r3dm_graph_pairs.argtypes = [vp]; L.r3dm_graph_pairs.restype = vp
+    L.r3dm_graph_offsets.argtypes = [vp]; L.r3dm_graph_offsets.restype = vp
+    L.r3dm_graph_matches.argtypes = [vp]; L.r3dm_graph_matches.restype = vp
+    L.r3dm_graph_free.argtypes = [vp]; L.r3dm_graph_free.restype = None
+    L.r3dm_graph_from_csr.argtypes = [vp, u64, vp, vp, C.POINTER(vp)]
+    L.r3dm_graph_merge.argtypes = [vp, u32, C.POINTER(vp)]
+    L.r3dm_save_matches.argtypes = [vp, C.c_char_p]
+    L.r3dm_load_matches.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.r3dm_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.r3dm_filter_report.argtypes = [vp, vp, u64]
+    _lib = L
+    return L
+
+
+def _ptr(a) -> Optional[int]:
+    """address of a numpy array or torch tensor (host or device) -- the ABI takes plain pointers"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return int(a.data_ptr())           # torch tensor
+
+
+class Graph:
+    """PairWiseMatches: pairs [P,2] u32 ordered by (I,J); offsets [P+1] u64; matches [M,2] u32 (i_, j_)."""
+
+    def __init__(self, handle: int):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().r3dm_graph_free(self._h)
+            self._h = None
+
+    @property
+    def num_pairs(self) -> int:
+        return int(load_library().r3dm_graph_num_pairs(self._h))
+
+    @property
+    def num_matches(self) -> int:
+        return int(load_library().r3dm_graph_num_matches(self._h))
+
+    def _view(self, fn, n, dtype):
+        if n == 0:
+            return np.zeros(0, dtype)
+        addr = fn(self._h)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(addr)
+        return np.frombuffer(buf, dtype=dtype).copy()
+
+    @property
+    def pairs(self) -> np.ndarray:
+        return self._view(load_library().r3dm_graph_pairs, 2 * self.num_pairs, np.uint32).reshape(-1, 2)
+
+    @property
+    def offsets(self) -> np.ndarray:
+        if self.num_pairs == 0:
+            return np.zeros(1, np.uint64)
+        return self._view(load_library().r3dm_graph_offsets, self.num_pairs + 1, np.uint64)
+
+    @property
+    def matches(self) -> np.ndarray:
+        return self._view(load_library().r3dm_graph_matches, 2 * self.num_matches, np.uint32).reshape(-1, 2)
+
+    def as_dict(self):
+        """{(I, J): ndarray [m, 2]} -- the std::map view used by the parity tests"""
+        p, o, m = self.pairs, self.offsets, self.matches
+        return {(int(p[k, 0]), int(p[k, 1])): m[int(o[k]):int(o[k + 1])] for k in range(p.shape[0])}
+
+    def save(self, path: str) -> None:
+        rc = load_library().r3dm_save_matches(self._h, path.encode())
+        if rc != 0:
+            raise R3dmError(f"r3dm_save_matches({path}) -> {rc}")
+
+    @staticmethod
+    def load(path: str) -> "Graph":
+        h = C.c_void_p()
+        rc = load_library().r3dm_load_matches(path.encode(), C.byref(h))
+        if rc != 0:
+            raise R3dmError(f"r3dm_load_matches({path}) -> {rc}")
+        return Graph(h.value)
+
+    @staticmethod
+    def from_csr(pairs: np.ndarray, offsets: np.ndarray, matches: np.ndarray) -> "Graph":
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        matches = np.ascontiguousarray(matches, np.uint32).reshape(-1, 2)
+        h = C.c_void_p()
+        rc = load_library().r3dm_graph_from_csr(_ptr(pairs) if pairs.size else None, pairs.shape[0], _ptr(offsets),
+                                                 _ptr(matches) if matches.size else None, C.byref(h))
+        if rc != 0:
+            raise R3dmError(f"r3dm_graph_from_csr -> {rc}")
+        return Graph(h.value)
+
+    @staticmethod
+    def merge(parts: Sequence["Graph"]) -> "Graph":
+        arr = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        h = C.c_void_p()
+        rc = load_library().r3dm_graph_merge(arr, len(parts), C.byref(h))
+        if rc != 0:
+            raise R3dmError(f"r3dm_graph_merge -> {rc}")
+        return Graph(h.value)
+
+
+class Context:
+    """One GPU, one context (one process per GPU)."""
+
+    def __init__(self, device: int = 0):
+        L = load_library()
+        h = C.c_void_p()
+        rc = L.r3dm_create(device, C.byref(h))
+        if rc != 0:
+            raise R3dmError(f"r3dm_create(device={device}) -> {rc} (no gfx950 GPU visible? there is no CPU fallback)")
+        self._h = h.value
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.r3dm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise R3dmError(f"{what} -> {rc}: {self._L.r3dm_last_error(self._h).decode()}")
+
+    def device_info(self) -> Tuple[str, int, int]:
+        arch = C.create_string_buffer(64); cu = C.c_int(); hbm = C.c_uint64()
+        self._check(self._L.r3dm_device_info(self._h, arch, 64, C.byref(cu), C.byref(hbm)), "r3dm_device_info")
+        return arch.value.decode(), cu.value, hbm.value
+
+    def set_image(self, view_id: int, desc, xy=None, width: int = 0, height: int = 0, binary: bool = False):
+        """desc: [n, dim] float32 / uint8 numpy array or torch tensor (host or device memory)."""
+        if isinstance(desc, np.ndarray):
+            desc = np.ascontiguousarray(desc)
+            is_f32 = desc.dtype == np.float32
+            if not is_f32 and desc.dtype != np.uint8:
+                raise TypeError(desc.dtype)
+        else:
+            import torch
+            desc = desc.contiguous()
+            is_f32 = desc.dtype == torch.float32
+            if not is_f32 and desc.dtype != torch.uint8:
+                raise TypeError(desc.dtype)
+        n, dim = int(desc.shape[0]), int(desc.shape[1])
+        dt = F32 if is_f32 else (BIN if binary else U8)
+        if xy is not None:
+            xy = np.ascontiguousarray(xy, np.float32) if isinstance(xy, np.ndarray) else xy.contiguous().float()
+        self._check(self._L.r3dm_set_image(self._h, view_id, width, height, _ptr(desc), n, dim, dt, _ptr(xy)),
+                    "r3dm_set_image")
+
+    def clear_images(self):
+        self._check(self._L.r3dm_clear_images(self._h), "r3dm_clear_images")
+
+    def match_pairs(self, pairs, dist_ratio: float = 0.6, squared_metric: bool = True) -> Graph:
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        h = C.c_void_p()
+        self._check(self._L.r3dm_match_pairs(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0],
+                                             dist_ratio, int(squared_metric), C.byref(h)), "r3dm_match_pairs")
+        return Graph(h.value)
+
+    def filter_F(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489,
+                 want_F: bool = False):
+        h = C.c_void_p()
+        Fbuf = np.zeros((max(putative.num_pairs, 1), 9), np.float64) if want_F else None
+        self._check(self._L.r3dm_filter_F(self._h, putative._h, max_residual_px, max_iter, seed, 0, C.byref(h),
+                                          _ptr(Fbuf)), "r3dm_filter_F")
+        g = Graph(h.value)
+        return (g, Fbuf[:g.num_pairs].copy()) if want_F else g
+
+    def knn2(self, dataset: np.ndarray, query: np.ndarray, binary: bool = False):
+        dataset = np.ascontiguousarray(dataset); query = np.ascontiguousarray(query)
+        dt = F32 if dataset.dtype == np.float32 else (BIN if binary else U8)
+        nq = query.shape[0]
+        idx = np.full((max(nq, 1), 2), -1, np.int32); dist = np.zeros((max(nq, 1), 2), np.float32)
+        self._check(self._L.r3dm_knn2(self._h, _ptr(dataset), dataset.shape[0], _ptr(query), nq, dataset.shape[1], dt,
+                                      _ptr(idx), _ptr(dist)), "r3dm_knn2")
+        return idx[:nq], dist[:nq]
+
+    def filter_report(self):
+        """per putative pair of the last filter_F call: (threshold_px, nfa, iterations, models, inliers)"""
+        n = self._L.r3dm_filter_report(self._h, None, 0)
+        arr = (PairReport * max(n, 1))()
+        self._L.r3dm_filter_report(self._h, arr, n)
+        return [(r.threshold_px, r.nfa, r.iterations, r.models, r.inliers) for r in arr[:n]]
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._check(self._L.r3dm_get_stats(self._h, C.byref(s)), "r3dm_get_stats")
+        return s

@@ -1,0 +1,164 @@
+// compute_matches.cpp -- implementation of the R3DComputeMatches facade (include/r3d_compute_matches.hpp)
+// on top of the C ABI only.  Stage order follows /root/reference/src/R3DComputeMatches.cpp:1996-2129:
+// load regions -> exhaustive pairs -> match -> save matches.putative.txt -> F filter -> save matches.f.txt.
+#include "../../include/r3d_compute_matches.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <algorithm>
+
+namespace r3d_amd {
+
+namespace {
+
+// .feat: one "x y scale orientation" text line per feature; .desc: 8-byte count + raw rows
+// (/root/reference/src/keypointSet.hpp:49-67 -> OpenMVG loadFeatsFromFile / loadDescsFromBinFile)
+bool load_feat(const std::string& path, std::vector<float>& xy)
+{
+    std::ifstream f(path);
+    if (!f) return false;
+    float x, y, s, o;
+    xy.clear();
+    while (f >> x >> y >> s >> o) { xy.push_back(x); xy.push_back(y); }
+    return true;
+}
+
+bool load_desc(const std::string& path, size_t row_bytes, std::vector<unsigned char>& data, uint64_t& n)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = fread(&n, 8, 1, f) == 1;
+    if (ok) {
+        data.resize((size_t)n * row_bytes);
+        ok = n == 0 || fread(data.data(), row_bytes, n, f) == n;
+    }
+    fclose(f);
+    return ok;
+}
+
+void graph_to_map(const r3dm_graph* g, PairWiseMatches& out)
+{
+    out.clear();
+    const uint64_t np = r3dm_graph_num_pairs(g);
+    const uint32_t* p = r3dm_graph_pairs(g);
+    const uint64_t* o = r3dm_graph_offsets(g);
+    const r3dm_match* m = r3dm_graph_matches(g);
+    for (uint64_t k = 0; k < np; ++k)
+        out.emplace(std::make_pair(p[2 * k], p[2 * k + 1]), IndMatches(m + o[k], m + o[k + 1]));
+}
+
+std::string with_ext(const std::string& path, const char* ext)
+{
+    const size_t dot = path.find_last_of('.');
+    return (dot == std::string::npos ? path : path.substr(0, dot)) + ext;
+}
+
+}  // namespace
+
+R3DComputeMatches::R3DComputeMatches(int device_id)
+{
+    const int rc = r3dm_create(device_id, &ctx_);
+    if (rc != R3DM_OK) { ctx_ = nullptr; errorMessage_ = "r3dm_create failed (" + std::to_string(rc) + "): no gfx950 GPU"; }
+}
+
+R3DComputeMatches::~R3DComputeMatches() { if (ctx_) r3dm_destroy(ctx_); }
+
+void R3DComputeMatches::addViews(const std::vector<View>& views) { views_.insert(views_.end(), views.begin(), views.end()); }
+
+void R3DComputeMatches::setRegionsType(r3dm_dtype dtype, uint32_t dim) { dtype_ = dtype; dim_ = dim; }
+
+bool R3DComputeMatches::computeMatches(R3DFParams& params, bool /*svgOutput*/, const R3DProjectPaths& paths,
+                                       int /*cameraModel*/, int matchingAlgorithm)
+{
+    statistics_ = R3DComputeMatchesStatistics();
+    if (!ctx_) return false;
+    if (matchingAlgorithm != kMatchingAlgorithmGPU && matchingAlgorithm != 4) {
+        errorMessage_ = "matchingAlgorithm " + std::to_string(matchingAlgorithm) + " is not served by the GPU path (use 9 or 4)";
+        return false;
+    }
+    const std::string dir = paths.relativeMatchesPath_;
+    const size_t row_bytes = dtype_ == R3DM_F32 ? (size_t)dim_ * 4 : (size_t)dim_;
+
+    // ---- Regions_Provider::load + Features_Provider::load (src/R3DComputeMatches.cpp:2040,2094-2095)
+    if (r3dm_clear_images(ctx_) != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+    for (const View& v : views_) {
+        std::vector<float> xy;
+        std::vector<unsigned char> desc;
+        uint64_t n = 0;
+        if (!load_feat(dir + "/" + v.basename + ".feat", xy) || !load_desc(dir + "/" + v.basename + ".desc", row_bytes, desc, n)) {
+            errorMessage_ = "Invalid features: " + v.basename;       // reference: MLOG "Invalid features." + return false (:2096-2097)
+            return false;
+        }
+        if (xy.size() != 2 * n) { errorMessage_ = "feature/descriptor count mismatch: " + v.basename; return false; }
+        statistics_.numberOfKeypoints_.push_back((int)n);
+        const int rc = r3dm_set_image(ctx_, v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, dim_, dtype_, xy.data());
+        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+    }
+
+    // ---- exhaustivePairs(#views) (:2042): all (I, J) with I < J, in view-id order
+    std::vector<uint32_t> ids;
+    for (const View& v : views_) ids.push_back(v.id_view);
+    std::sort(ids.begin(), ids.end());
+    std::vector<uint32_t> pairs;
+    for (size_t a = 0; a < ids.size(); ++a)
+        for (size_t b = a + 1; b < ids.size(); ++b) { pairs.push_back(ids[a]); pairs.push_back(ids[b]); }
+
+    // ---- photometric matching (:2048) + Save(matches.putative.txt) (:2064)
+    r3dm_graph* putative = nullptr;
+    const int squared = dtype_ == R3DM_BIN ? 0 : 1;        // RegionsMatcherT squared flag: true for L2 metrics
+    int rc = r3dm_match_pairs(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, squared, &putative);
+    if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+    graph_to_map(putative, statistics_.putativeMatches_);
+    const std::string put_path = paths.matchesPutitativeFilename_.empty() ? dir + "/matches.putative.txt" : paths.matchesPutitativeFilename_;
+    if (r3dm_save_matches(putative, put_path.c_str()) != R3DM_OK ||
+        r3dm_save_matches(putative, with_ext(put_path, ".bin").c_str()) != R3DM_OK) {
+        // the reference returns EXIT_FAILURE (== true) from a bool function here (:2069); a real failure is reported instead
+        errorMessage_ = "Cannot save computed matches in: " + put_path;
+        r3dm_graph_free(putative);
+        return false;
+    }
+
+    // ---- geometric filtering, fundamental matrix (:2113-2120): AC-RANSAC, 4.0 px upper bound, 2048 iterations
+    if (params.computeFundalmentalMatrix_) {
+        r3dm_graph* geo = nullptr;
+        rc = r3dm_filter_F(ctx_, putative, 4.0, 2048, seed_, R3DM_ERR_SYMMETRIC_EPIPOLAR, &geo, nullptr);
+        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
+        graph_to_map(geo, statistics_.fundamentalMatches_);
+        const std::string f_path = paths.matchesFFilename_.empty() ? dir + "/matches.f.txt" : paths.matchesFFilename_;
+        const bool ok = r3dm_save_matches(geo, f_path.c_str()) == R3DM_OK &&
+                        r3dm_save_matches(geo, with_ext(f_path, ".bin").c_str()) == R3DM_OK;
+        r3dm_graph_free(geo);
+        if (!ok) { errorMessage_ = "Cannot save computed matches in: " + f_path; r3dm_graph_free(putative); return false; }
+    }
+    r3dm_graph_free(putative);
+    return true;
+}
+
+}  // namespace r3d_amd
+
+extern "C" int r3dm_compute_matches_dir(int device_id, const char* matches_dir, const r3dm_view* views, uint32_t n_views,
+                                        r3dm_dtype dtype, uint32_t dim, float dist_ratio, int compute_F, uint64_t seed,
+                                        uint64_t* n_putative_pairs, uint64_t* n_geometric_pairs, char* err, size_t err_cap)
+{
+    if (!matches_dir || (n_views && !views)) return R3DM_ERR_INVALID;
+    r3d_amd::R3DComputeMatches stage(device_id);
+    std::vector<r3d_amd::View> vs;
+    for (uint32_t k = 0; k < n_views; ++k) vs.push_back({views[k].id, views[k].width, views[k].height, views[k].basename});
+    stage.addViews(vs);
+    stage.setRegionsType(dtype, dim);
+    stage.setSeed(seed);
+    r3d_amd::R3DFParams params;
+    params.distRatio_ = dist_ratio;
+    params.computeFundalmentalMatrix_ = compute_F != 0;
+    params.computeEssentialMatrix_ = false;
+    params.computeHomographyMatrix_ = false;
+    r3d_amd::R3DProjectPaths paths;
+    paths.relativeMatchesPath_ = matches_dir;
+    const bool ok = stage.computeMatches(params, false, paths, 1, r3d_amd::R3DComputeMatches::kMatchingAlgorithmGPU);
+    if (n_putative_pairs) *n_putative_pairs = stage.getStatistics().putativeMatches_.size();
+    if (n_geometric_pairs) *n_geometric_pairs = stage.getStatistics().fundamentalMatches_.size();
+    if (err && err_cap) { strncpy(err, stage.errorMessage().c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+    return ok ? R3DM_OK : R3DM_ERR_IO;
+}

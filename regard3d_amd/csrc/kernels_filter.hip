@@ -1,0 +1,515 @@
+// kernels_filter.hip -- batched a-contrario RANSAC fundamental-matrix filter on gfx950.
+//
+// Replaces, behind r3dm_filter_F, the reference's
+//   ImageCollectionGeometricFilter::Robust_model_estimation(GeometricFilter_FMatrix_AC(4.0, 2048), ...)
+//   (/root/reference/src/R3DComputeMatches.cpp:2099,2113-2115), whose arithmetic is OpenMVG 1.4's
+//   ACRANSAC + ACKernelAdaptor<SevenPointSolver, SymmetricEpipolarDistanceError>.
+//
+// One workgroup per image pair.  AC-RANSAC is sequentially adaptive (the sampling pool shrinks to
+// the inlier set on every meaningful improvement and the iteration budget is cut once), so the
+// kernel keeps the reference's iteration ORDER and only parallelises inside it:
+//   * a chunk of 64 minimal samples is drawn from the counter-based sample stream and solved
+//     (7-point, f64, one lane per hypothesis, Householder QR null space + cubic);
+//   * the <= 3 models of each iteration are then evaluated one after the other by all 256 lanes:
+//     residuals of all m matches, wave-ballot compaction of those under the residual bound,
+//     LDS bitonic sort of (residual, index), parallel NFA scan + argmin;
+//   * when an iteration changes the pool, the rest of the chunk is discarded and re-drawn.
+// Residuals beyond the bound never enter bestNFA's scan (its loop stops at the first one), so
+// sorting only the sub-threshold set yields the same (NFA, k, inlier prefix) as the full sort.
+//
+// f64 throughout, compiled with -ffp-contract=off so residuals agree with the CPU restatement to
+// rounding of the transcendental calls (acos/cos/cbrt/log10) only.
+
+#include "r3dm_internal.hpp"
+
+namespace r3dm {
+
+#define FLT_EPS_D 1.1920928955078125e-07
+
+// ---- sample stream: identical integer arithmetic to oracle/acransac.c orc_rng_u64 ----
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ULL;
+    z ^= z >> 27; z *= 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return z;
+}
+
+__device__ __forceinline__ uint64_t rng_u64(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter, uint32_t attempt)
+{
+    const uint64_t G = 0x9E3779B97F4A7C15ULL;
+    const uint64_t a = mix64(seed + G * (1ULL + (((uint64_t)I << 32) | (uint64_t)J)));
+    return mix64(a + G * (1ULL + (((uint64_t)iter << 32) | (uint64_t)attempt)));
+}
+
+// ---- cubic: roots of c0 + c1 x + c2 x^2 + c3 x^3 (Cardano / trigonometric form) ----
+__device__ int solve_cubic(const double* c, double* roots)
+{
+    if (c[3] == 0.0) return 0;
+    const double a = c[2] / c[3], b = c[1] / c[3], cc = c[0] / c[3];
+    const double q = a * a - 3.0 * b;
+    const double r = 2.0 * a * a * a - 9.0 * a * b + 27.0 * cc;
+    const double Q = q / 9.0, R = r / 54.0;
+    const double Q3 = Q * Q * Q, R2 = R * R;
+    const double CR2 = 729.0 * r * r, CQ3 = 2916.0 * q * q * q;
+    const double a3 = a / 3.0;
+    if (R == 0.0 && Q == 0.0) {
+        roots[0] = roots[1] = roots[2] = -a3;
+        return 3;
+    }
+    if (CR2 == CQ3) {
+        const double sqrtQ = sqrt(Q);
+        if (R > 0.0) { roots[0] = -2.0 * sqrtQ - a3; roots[1] = sqrtQ - a3; roots[2] = sqrtQ - a3; }
+        else         { roots[0] = -sqrtQ - a3; roots[1] = -sqrtQ - a3; roots[2] = 2.0 * sqrtQ - a3; }
+        return 3;
+    }
+    if (CR2 < CQ3) {
+        const double sqrtQ = sqrt(Q);
+        const double sqrtQ3 = sqrtQ * sqrtQ * sqrtQ;
+        const double theta = acos(R / sqrtQ3);
+        const double norm = -2.0 * sqrtQ;
+        const double TWO_PI = 2.0 * 3.14159265358979323846;
+        double x0 = norm * cos(theta / 3.0) - a3;
+        double x1 = norm * cos((theta + TWO_PI) / 3.0) - a3;
+        double x2 = norm * cos((theta - TWO_PI) / 3.0) - a3;
+        double t;
+        if (x0 > x1) { t = x0; x0 = x1; x1 = t; }
+        if (x1 > x2) { t = x1; x1 = x2; x2 = t; if (x0 > x1) { t = x0; x0 = x1; x1 = t; } }
+        roots[0] = x0; roots[1] = x1; roots[2] = x2;
+        return 3;
+    }
+    const double sgnR = (R >= 0.0 ? 1.0 : -1.0);
+    const double A = -sgnR * cbrt(fabs(R) + sqrt(R2 - Q3));
+    const double B = Q / A;
+    roots[0] = A + B - a3;
+    return 1;
+}
+
+__device__ __forceinline__ double det3(const double* r0, const double* r1, const double* r2)
+{
+    return r0[0] * (r1[1] * r2[2] - r1[2] * r2[1])
+         - r0[1] * (r1[0] * r2[2] - r1[2] * r2[0])
+         + r0[2] * (r1[0] * r2[1] - r1[1] * r2[0]);
+}
+
+// 7-point solver: x1, x2 = 7 normalised correspondences.  Null space of the 7x9 system = last two
+// columns of Q in the Householder QR of A^T (9x7); all indices static -> registers.
+__device__ int seven_point(const double (&px1)[7][2], const double (&px2)[7][2], double* Fs /* 27 */)
+{
+    double M[9][7];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        const double ax = px1[p][0], ay = px1[p][1], bx = px2[p][0], by = px2[p][1];
+        M[0][p] = bx * ax; M[1][p] = bx * ay; M[2][p] = bx;
+        M[3][p] = by * ax; M[4][p] = by * ay; M[5][p] = by;
+        M[6][p] = ax;      M[7][p] = ay;      M[8][p] = 1.0;
+    }
+    double beta[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        double nrm2 = 0.0;
+#pragma unroll
+        for (int r = j; r < 9; ++r) nrm2 += M[r][j] * M[r][j];
+        const double nrm = sqrt(nrm2);
+        double bj = 0.0;
+        if (nrm != 0.0) {
+            const double alpha = (M[j][j] > 0.0) ? -nrm : nrm;
+            M[j][j] -= alpha;                       // column j now holds the reflector v_j (rows j..8)
+            double vn2 = 0.0;
+#pragma unroll
+            for (int r = j; r < 9; ++r) vn2 += M[r][j] * M[r][j];
+            if (vn2 != 0.0) bj = 2.0 / vn2;
+        } else {
+#pragma unroll
+            for (int r = j; r < 9; ++r) M[r][j] = 0.0;
+        }
+        beta[j] = bj;
+#pragma unroll
+        for (int c = j + 1; c < 7; ++c) {
+            double dot = 0.0;
+#pragma unroll
+            for (int r = j; r < 9; ++r) dot += M[r][j] * M[r][c];
+            const double s = bj * dot;
+#pragma unroll
+            for (int r = j; r < 9; ++r) M[r][c] -= s * M[r][j];
+        }
+    }
+    double f[2][9];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) f[e][r] = (r == 7 + e) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 6; j >= 0; --j) {
+            double dot = 0.0;
+#pragma unroll
+            for (int r = j; r < 9; ++r) dot += M[r][j] * f[e][r];
+            const double s = beta[j] * dot;
+#pragma unroll
+            for (int r = j; r < 9; ++r) f[e][r] -= s * M[r][j];
+        }
+    }
+    const double* A = f[0];
+    const double* B = f[1];
+    double P[4];
+    P[0] = det3(A, A + 3, A + 6);
+    P[1] = det3(B, A + 3, A + 6) + det3(A, B + 3, A + 6) + det3(A, A + 3, B + 6);
+    P[2] = det3(A, B + 3, B + 6) + det3(B, A + 3, B + 6) + det3(B, B + 3, A + 6);
+    P[3] = det3(B, B + 3, B + 6);
+    double roots[3];
+    const int n = solve_cubic(P, roots);
+    for (int k = 0; k < n; ++k)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Fs[9 * k + e] = A[e] + roots[k] * B[e];
+    return n;
+}
+
+// SymmetricEpipolarDistanceError (squared, /4)
+__device__ __forceinline__ double sym_epipolar_err(const double* F, double x1, double y1, double x2, double y2)
+{
+    const double Fx0 = F[0] * x1 + F[1] * y1 + F[2];
+    const double Fx1 = F[3] * x1 + F[4] * y1 + F[5];
+    const double Fx2 = F[6] * x1 + F[7] * y1 + F[8];
+    const double Fty0 = F[0] * x2 + F[3] * y2 + F[6];
+    const double Fty1 = F[1] * x2 + F[4] * y2 + F[7];
+    const double yFx = x2 * Fx0 + y2 * Fx1 + Fx2;
+    return (yFx * yFx) * (1.0 / (Fx0 * Fx0 + Fx1 * Fx1) + 1.0 / (Fty0 * Fty0 + Fty1 * Fty1)) / 4.0;
+}
+
+// ---- per-workgroup shared state (lives at the front of the dynamic LDS region) ----
+struct FState {
+    double minNFA, errorMax;
+    double bestF[9];
+    double cur_nfa;          // scratch: NFA of the model under evaluation
+    uint32_t nIter, reserve, iter, pool_size, n_inl, acMode, n_models, iters_done;
+    uint32_t cnt, cur_k, flag, chunk_n;
+    uint32_t wave_cnt[4];
+    double   red_v[4];
+    uint32_t red_k[4];
+    uint32_t nm[64];
+    uint32_t dbg_smp[64];    // debug trace: first sample index of each hypothesis of the chunk
+    uint32_t dbg_pool;       // debug trace: pool size the chunk was drawn from
+};
+
+constexpr int kChunk = 64;
+
+size_t filter_F_lds_bytes(uint32_t m_cap)
+{
+    // [FState, padded to 1024][Fs: 64 x 27 doubles][keys: m_cap x u64][idx: m_cap x u32]
+    return 1024 + (size_t)kChunk * 27 * 8 + (size_t)m_cap * 12;
+}
+
+__global__ __launch_bounds__(256)
+void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
+                       uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FState& S = *reinterpret_cast<FState*>(smem);
+    double* Fs = reinterpret_cast<double*>(smem + 1024);                                   // [64][27]
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * 27 * 8);
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
+
+    const uint32_t item = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t begin = P.offsets[2 * item], end = P.offsets[2 * item + 1];
+    const uint32_t m = (uint32_t)(end - begin);
+    const uint2 sl = P.pairs[item];
+    const uint2 id = P.pair_ids[item];
+    const ImgDev* __restrict__ Ip = P.imgs + sl.x;
+    const ImgDev* __restrict__ Jp = P.imgs + sl.y;
+    const r3dm_match* __restrict__ mm = P.matches + begin;
+    double* __restrict__ pt = pts + 4 * begin;
+    uint32_t* __restrict__ pool = pool_g + begin;
+    uint32_t* __restrict__ inl = P.inl_idx + begin;
+    float* __restrict__ logc_n = logc_g + begin + item;       // m + 1 entries
+
+    // ---- ACKernelAdaptor: normalisation N = [[s,0,-s w/2],[0,s,-s h/2],[0,0,1]], s = 1/sqrt(w h)
+    const int wI = (int)Ip->width, hI = (int)Ip->height, wJ = (int)Jp->width, hJ = (int)Jp->height;
+    const double s1 = 1.0 / sqrt((double)(wI * hI));
+    const double s2 = 1.0 / sqrt((double)(wJ * hJ));
+    const double t1x = -0.5 * wI * s1, t1y = -0.5 * hI * s1;
+    const double t2x = -0.5 * wJ * s2, t2y = -0.5 * hJ * s2;
+    for (uint32_t p = tid; p < m; p += 256) {
+        const r3dm_match q = mm[p];
+        const double xi = (double)Ip->xy[2 * (size_t)q.i], yi = (double)Ip->xy[2 * (size_t)q.i + 1];
+        const double xj = (double)Jp->xy[2 * (size_t)q.j], yj = (double)Jp->xy[2 * (size_t)q.j + 1];
+        pt[4 * p + 0] = s1 * xi + t1x; pt[4 * p + 1] = s1 * yi + t1y;
+        pt[4 * p + 2] = s2 * xj + t2x; pt[4 * p + 3] = s2 * yj + t2y;
+        pool[p] = p;
+    }
+    const double Dd = sqrt((double)wJ * (double)wJ + (double)hJ * (double)hJ);
+    const double Aa = (double)wJ * (double)hJ;
+    const double logalpha0 = log10(2.0 * Dd / Aa / s2);
+    const double maxThreshold = P.precision_px * P.precision_px * s2 * s2;
+    const double loge0 = log10(3.0 * (double)(m - 7));
+
+    if (tid == 0) {
+        // logcombi(k, m) as a running prefix in the reference's float accumulation order
+        // (makelogcombi_n): pre[i] = pre[i-1] + (l10[m-i+1] - l10[i]); mirrored for k > m/2
+        float pre = 0.0f;
+        logc_n[0] = 0.0f; logc_n[m] = 0.0f;
+        for (uint32_t i = 1; i <= m / 2; ++i) {
+            pre = pre + (P.log10_tab[m - i + 1] - P.log10_tab[i]);
+            logc_n[i] = pre;
+            if (m - i > i) logc_n[m - i] = pre;
+        }
+        S.minNFA = __builtin_huge_val(); S.errorMax = __builtin_huge_val();
+        for (int e = 0; e < 9; ++e) S.bestF[e] = 0.0;
+        const uint32_t reserve = P.max_iter / 10;
+        S.reserve = reserve; S.nIter = P.max_iter - reserve; S.iter = 0;
+        S.pool_size = m; S.n_inl = 0; S.acMode = !(P.precision_px < __builtin_huge_val());
+        S.n_models = 0; S.iters_done = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    while (true) {
+        __syncthreads();
+        const uint32_t iter0 = S.iter, nIter0 = S.nIter;
+        if (iter0 >= nIter0) break;
+        const uint32_t chunk_n = (nIter0 - iter0 < (uint32_t)kChunk) ? nIter0 - iter0 : (uint32_t)kChunk;
+        const uint32_t pool_size = S.pool_size;
+
+        // ---- draw + solve one chunk of minimal samples (lane c <-> iteration iter0 + c)
+        if (tid < chunk_n) {
+            uint32_t pos[7];
+            uint32_t cnt = 0, attempt = 0;
+            while (cnt < 7) {
+                const uint64_t r = rng_u64(P.seed, id.x, id.y, iter0 + tid, attempt++);
+                const uint32_t ps = (uint32_t)(((r >> 32) * (uint64_t)pool_size) >> 32);
+                bool dup = false;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) dup |= (k < (int)cnt) && (pos[k] == ps);
+                if (!dup) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) if (k == (int)cnt) pos[k] = ps;
+                    ++cnt;
+                }
+            }
+            double px1[7][2], px2[7][2];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const uint32_t sidx_ = pool[pos[k]];
+                px1[k][0] = pt[4 * (size_t)sidx_ + 0]; px1[k][1] = pt[4 * (size_t)sidx_ + 1];
+                px2[k][0] = pt[4 * (size_t)sidx_ + 2]; px2[k][1] = pt[4 * (size_t)sidx_ + 3];
+            }
+            double F3[27];
+            const int nm = seven_point(px1, px2, F3);
+            S.nm[tid] = (uint32_t)nm;
+            S.dbg_smp[tid] = pool[pos[0]];
+            if (P.trace && item == P.trace_item && iter0 + tid == P.trace_iter) {
+                double* t = P.trace + 5 * (size_t)(P.trace_cap - 4);
+                for (int k = 0; k < 7; ++k) t[k] = (double)pool[pos[k]];
+                t[7] = nm; t[8] = pool_size; t[9] = iter0 + tid;
+                for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k];
+            }
+            if (tid == 0) S.dbg_pool = pool_size;
+            for (int e = 0; e < 27; ++e) Fs[tid * 27 + e] = (e < 9 * nm) ? F3[e] : 0.0;
+        }
+        __syncthreads();
+
+        // ---- evaluate the chunk's iterations in order
+        bool pool_changed = false;
+        uint32_t c = 0;
+        for (; c < chunk_n && !pool_changed; ++c) {
+            const uint32_t it = iter0 + c;
+            const uint32_t nm = S.nm[c];
+            bool better = false;
+            for (uint32_t k = 0; k < nm; ++k) {
+                double F[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) F[e] = Fs[c * 27 + k * 9 + e];
+                // residuals + compaction of those within the bound
+                uint32_t total = 0;
+                for (uint32_t base = 0; base < m; base += 256) {
+                    const uint32_t p = base + tid;
+                    double r = 0.0; bool in = false;
+                    if (p < m) {
+                        r = sym_epipolar_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3]);
+                        in = (r <= maxThreshold);
+                    }
+                    const unsigned long long bal = __ballot(in);
+                    const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    if (lane == 0) S.wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+                    __syncthreads();
+                    uint32_t woff = 0, tot = 0;
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
+                    if (in) { keys[total + woff + before] = (unsigned long long)__double_as_longlong(r); sidx[total + woff + before] = p; }
+                    total += tot;
+                    __syncthreads();
+                }
+                // AC mode switches on with the first model that has > 2.5*7 points within the bound
+                bool ac = S.acMode != 0;
+                if (!ac && (double)total > 2.5 * 7) ac = true;
+                double nfa = __builtin_huge_val();
+                uint32_t kbest = 7;
+                if (ac && total > 7) {
+                    // sort (residual, index) ascending: residuals are >= 0 so the u64 bit pattern orders them
+                    uint32_t cap = 1; while (cap < total) cap <<= 1;
+                    for (uint32_t q = total + tid; q < cap; q += 256) { keys[q] = ~0ull; sidx[q] = 0xFFFFFFFFu; }
+                    __syncthreads();
+                    for (uint32_t size = 2; size <= cap; size <<= 1) {
+                        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                            for (uint32_t tI = tid; tI < (cap >> 1); tI += 256) {
+                                const uint32_t lo = 2 * tI - (tI & (stride - 1));
+                                const uint32_t hi = lo + stride;
+                                const bool up = ((lo & size) == 0);
+                                const unsigned long long x = keys[lo], y = keys[hi];
+                                const uint32_t xi = sidx[lo], yi = sidx[hi];
+                                const bool gt = (x > y) || (x == y && xi > yi);
+                                if (gt == up) { keys[lo] = y; keys[hi] = x; sidx[lo] = yi; sidx[hi] = xi; }
+                            }
+                            __syncthreads();
+                        }
+                    }
+                    // bestNFA: k = 8 .. total, first minimum wins
+                    double bv = __builtin_huge_val(); uint32_t bk = 0xFFFFFFFFu;
+                    for (uint32_t kk = 8 + tid; kk <= total; kk += 256) {
+                        const double e = __longlong_as_double((long long)keys[kk - 1]);
+                        const double logalpha = logalpha0 + 0.5 * log10(e + FLT_EPS_D);
+                        const double v = loge0 + logalpha * (double)(kk - 7) + (double)logc_n[kk] + (double)P.logc_k[kk];
+                        if (v < bv) { bv = v; bk = kk; }
+                    }
+                    // wave argmin (value, then smaller k), then across the 4 waves
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const double ov = __shfl_xor(bv, off);
+                        const uint32_t ok = __shfl_xor(bk, off);
+                        if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+                    }
+                    if (lane == 0) { S.red_v[wave] = bv; S.red_k[wave] = bk; }
+                    __syncthreads();
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; ++w) {
+                        const double ov = S.red_v[w]; const uint32_t ok = S.red_k[w];
+                        if (w == 0 || ov < nfa || (ov == nfa && ok < kbest)) { nfa = ov; kbest = ok; }
+                    }
+                    if (kbest == 0xFFFFFFFFu) { nfa = __builtin_huge_val(); kbest = 7; }
+                }
+                // commit (every lane evaluates the same condition on the same shared values)
+                const double minNFA = S.minNFA;
+                const bool improve = ac && (nfa < minNFA);
+                if (improve) {
+                    for (uint32_t q = tid; q < kbest; q += 256) inl[q] = sidx[q];
+                    better = true;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    if (P.trace && item == P.trace_item) {
+                        const uint32_t row = *P.trace_rows;
+                        if (row < P.trace_cap) {
+                            double* t = P.trace + 5 * (size_t)row;
+                            t[0] = it; t[1] = k + 10.0 * S.dbg_smp[c]; t[2] = total + 10000.0 * S.dbg_pool; t[3] = nfa; t[4] = (improve ? 1.0 : 0.0) + 2.0 * kbest;
+                            *P.trace_rows = row + 1;
+                        }
+                    }
+                    S.acMode = ac ? 1u : 0u;
+                    S.n_models += 1;
+                    if (improve) {
+                        S.minNFA = nfa;
+                        S.n_inl = kbest;
+                        S.errorMax = __longlong_as_double((long long)keys[kbest - 1]);
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) S.bestF[e] = F[e];
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- end of iteration `it`: ACRANSAC's pool / budget update
+            if (tid == 0) {
+                S.iters_done = it + 1;
+                S.flag = 0;
+                const bool trigger = (better && S.minNFA < 0.0) || (it + 1 == S.nIter && S.reserve != 0);
+                if (trigger) {
+                    if (S.n_inl == 0) { S.nIter += 1; S.reserve -= 1; }
+                    else {
+                        S.flag = 1;
+                        S.pool_size = S.n_inl;
+                        if (S.reserve) { S.nIter = it + 1 + S.reserve; S.reserve = 0; }
+                    }
+                }
+            }
+            __syncthreads();
+            if (S.flag) {
+                // new sampling pool = the inlier SET in ascending index order.  (The residual order of the
+                // inlier list is rounding noise among the 7 points the model was fitted to, so pool
+                // positions must not depend on it -- same rule in oracle/acransac.c.)
+                const uint32_t ni = S.n_inl;
+                uint32_t* flags = sidx;                                  // LDS scratch, free between models
+                for (uint32_t q = tid; q < m; q += 256) flags[q] = 0u;
+                __syncthreads();
+                for (uint32_t q = tid; q < ni; q += 256) flags[inl[q]] = 1u;
+                __syncthreads();
+                uint32_t filled = 0;
+                for (uint32_t base = 0; base < m; base += 256) {
+                    const uint32_t p = base + tid;
+                    const bool in = (p < m) && (flags[p] != 0u);
+                    const unsigned long long bal = __ballot(in);
+                    const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    if (lane == 0) S.wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+                    __syncthreads();
+                    uint32_t woff = 0, tot = 0;
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
+                    if (in) pool[filled + woff + before] = p;
+                    filled += tot;
+                    __syncthreads();
+                }
+                pool_changed = true;
+            }
+            __threadfence_block();
+            __syncthreads();
+            // the chunk was cut from the old budget: stop when the (possibly shrunk) budget is exhausted
+            if (it + 1 >= S.nIter) { ++c; break; }
+        }
+        if (tid == 0) S.iter = iter0 + c;
+        __threadfence_block();
+    }
+
+    // ---- result
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t n_inl = S.n_inl;
+        if (!(S.minNFA < 0.0)) n_inl = 0;
+        P.inl_count[item] = n_inl;
+        double Fo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double thr = 0.0;
+        if (n_inl > 0) {
+            // Unnormalize: F = N2^T * F * N1
+            const double N1[9] = {s1, 0, t1x, 0, s1, t1y, 0, 0, 1};
+            const double N2[9] = {s2, 0, t2x, 0, s2, t2y, 0, 0, 1};
+            double T[9];
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc) {
+                    double v = 0.0;
+                    for (int k = 0; k < 3; ++k) v += N2[3 * k + r] * S.bestF[3 * k + cc];
+                    T[3 * r + cc] = v;
+                }
+            for (int r = 0; r < 3; ++r)
+                for (int cc = 0; cc < 3; ++cc) {
+                    double v = 0.0;
+                    for (int k = 0; k < 3; ++k) v += T[3 * r + k] * N1[3 * k + cc];
+                    Fo[3 * r + cc] = v;
+                }
+            thr = sqrt(S.errorMax) / s2;
+        }
+        for (int e = 0; e < 9; ++e) P.F_out[9 * (size_t)item + e] = Fo[e];
+        P.thr_nfa[2 * (size_t)item] = thr;
+        P.thr_nfa[2 * (size_t)item + 1] = S.minNFA;
+        P.iters[2 * (size_t)item] = S.iters_done;
+        P.iters[2 * (size_t)item + 1] = S.n_models;
+    }
+}
+
+hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
+{
+    if (P.n_items == 0) return hipSuccess;
+    const size_t lds = filter_F_lds_bytes(P.m_cap);
+    hipError_t e = hipFuncSetAttribute((const void*)acransac_F_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(acransac_F_kernel, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+    return hipGetLastError();
+}
+
+}  // namespace r3dm

@@ -1,0 +1,592 @@
+// kernels_match.hip -- putative matching on gfx950 (MI355X): staging, fused squared-L2 2-NN on
+// FP32 MFMA tiles with exact re-scoring + ratio test, Hamming 2-NN on integer VALU, and the
+// per-pair finalisation (compaction, (i_,j_) ordering, coordinate de-duplication).
+//
+// What it replaces in the reference (rhiestan/Regard3D, /root/reference):
+//   Matcher_Regions(fDistRatio, BRUTE_FORCE_L2).Match()    src/R3DComputeMatches.cpp:2037-2039,2048
+//   per-I / OpenMP-over-J loop nest                          src/R3DComputeMatches.cpp:437-489
+//   ArrayMatcher::SearchNeighbours(NN=2) + MatchDistanceRatio  src/utils/matcher_kgraph.h:205-251,
+//                                                            src/R3DComputeMatches.cpp:479
+// Arithmetic contract (OpenMVG L2<float>): distances are the f32
+// 4-way-unrolled sum of squared differences, NO fused multiply-add; equal distances -> lowest
+// dataset row.  The MFMA pass only nominates candidates (||a||^2 - 2 a.b, any summation order); the
+// two best candidates are re-scored with the reference arithmetic, and a query whose runner-up is
+// not provably separated from every un-nominated row is redone by an exact scan (kFallback).
+//
+// This file is compiled with -ffp-contract=off; fused operations are spelled fmaf()/MFMA.
+
+#include "r3dm_internal.hpp"
+
+namespace r3dm {
+
+typedef float f32x4  __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// pointers read out of ImgDev are generic; the hot loops cast them to the global address space so
+// the compiler emits global_load (vmcnt only, SGPR base + lane offset) instead of flat_load
+typedef const __attribute__((address_space(1))) f32x4* gf4p;
+typedef const __attribute__((address_space(1))) float* gf1p;
+
+#define R3DM_INF __builtin_huge_valf()
+
+// ------------------------------------------------------------------------------------------------
+// staging: raw row-major descriptors -> rows (f32) + MFMA fragment-order tiles + norms
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256)
+void stage_rows_kernel(const void* __restrict__ raw, int raw_is_u8, uint32_t n, uint32_t dim,
+                       float* __restrict__ rows)
+{
+    const size_t total = (size_t)n * dim;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256)
+        rows[e] = raw_is_u8 ? (float)((const uint8_t*)raw)[e] : ((const float*)raw)[e];
+}
+
+// one workgroup per 32-row tile
+__global__ __launch_bounds__(256)
+void stage_tiles_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim, uint32_t G,
+                        float* __restrict__ tiled, float* __restrict__ norms, uint32_t* __restrict__ max_norm_bits)
+{
+    const uint32_t t = blockIdx.x;
+    const uint32_t per_tile = G * 256;                 // floats per tile = G * 2 * 32 * 4
+    float* dst = tiled + (size_t)t * per_tile;
+    for (uint32_t e = threadIdx.x; e < per_tile; e += 256) {
+        const uint32_t c = e & 3, r = (e >> 2) & 31, h = (e >> 7) & 1, g = e >> 8;
+        const uint32_t row = t * 32 + r, k = 8 * g + 4 * h + c;
+        dst[e] = (row < n && k < dim) ? rows[(size_t)row * dim + k] : 0.0f;
+    }
+    if (threadIdx.x < 32) {
+        const uint32_t row = t * 32 + threadIdx.x;
+        float s = R3DM_INF;
+        if (row < n) {
+            s = 0.0f;
+            const float* p = rows + (size_t)row * dim;
+            for (uint32_t k = 0; k < dim; ++k) s = fmaf(p[k], p[k], s);
+            atomicMax(max_norm_bits, __float_as_uint(s));   // s >= 0: float order == uint order
+        }
+        norms[(size_t)t * 32 + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void stage_bin_kernel(const uint8_t* __restrict__ raw, uint32_t n, uint32_t nbytes,
+                      uint32_t* __restrict__ bin, uint32_t words, uint32_t n_pad)
+{
+    const size_t total = (size_t)n_pad * words;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const uint32_t row = (uint32_t)(e / words), w = (uint32_t)(e % words);
+        uint32_t v = 0;
+        if (row < n)
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t byte = 4 * w + b;
+                if (byte < nbytes) v |= (uint32_t)raw[(size_t)row * nbytes + byte] << (8 * b);
+            }
+        bin[e] = v;
+    }
+}
+
+hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
+                            float* rows, float* tiled, float* norms, uint32_t G, uint32_t n_tiles,
+                            uint32_t* max_norm_bits_dev)
+{
+    if (n == 0) return hipSuccess;
+    const size_t total = (size_t)n * dim;
+    uint32_t grid = (uint32_t)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(stage_rows_kernel, dim3(grid), dim3(256), 0, st, raw, raw_is_u8, n, dim, rows);
+    hipLaunchKernelGGL(stage_tiles_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, G, tiled, norms, max_norm_bits_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint32_t nbytes,
+                            uint32_t* bin, uint32_t words, uint32_t n_pad)
+{
+    if (n_pad == 0) return hipSuccess;
+    const size_t total = (size_t)n_pad * words;
+    uint32_t grid = (uint32_t)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(stage_bin_kernel, dim3(grid), dim3(256), 0, st, raw, n, nbytes, bin, words, n_pad);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact squared L2 in the reference's arithmetic (OpenMVG L2<float>): 4-way unrolled, float
+// accumulator, ((d0^2 + d1^2) + d2^2) + d3^2 added to the running result, scalar tail, no FMA.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float exact_l2sq(const float* __restrict__ a, const float* __restrict__ b, uint32_t dim)
+{
+    float result = 0.0f;
+    uint32_t k = 0;
+    if ((dim & 3u) == 0) {
+        const f32x4* a4 = (const f32x4*)a;
+        const f32x4* b4 = (const f32x4*)b;
+        for (; k < dim; k += 4) {
+            const f32x4 x = a4[k >> 2], y = b4[k >> 2];
+            const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
+            result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        return result;
+    }
+    for (; k + 3 < dim; k += 4) {
+        const float d0 = a[k] - b[k], d1 = a[k + 1] - b[k + 1], d2 = a[k + 2] - b[k + 2], d3 = a[k + 3] - b[k + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    for (; k < dim; ++k) { const float d0 = a[k] - b[k]; result += d0 * d0; }
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// running (best, runner-up, bound) list of one query column held by one lane
+// ------------------------------------------------------------------------------------------------
+struct Top2 {
+    float d0, d1, d2;      // d0 <= d1 <= d2 ; d2 = smallest key NOT nominated (certification bound)
+    uint32_t i0, i1;
+};
+
+__device__ __forceinline__ void top2_init(Top2& s)
+{
+    s.d0 = s.d1 = s.d2 = R3DM_INF; s.i0 = s.i1 = kNone;
+}
+
+__device__ __forceinline__ void top2_push(Top2& s, float key, uint32_t idx)
+{
+    // branch-free: locals first so every ?: is a plain select (v_cndmask), never control flow
+    const float od0 = s.d0, od1 = s.d1, od2 = s.d2;
+    const uint32_t oi0 = s.i0, oi1 = s.i1;
+    const bool c0 = key < od0;
+    const bool c1 = key < od1;
+    const uint32_t t1 = c1 ? idx : oi1;
+    s.d2 = __builtin_amdgcn_fmed3f(od1, od2, key);     // min(d2, max(d1, key))
+    s.d1 = __builtin_amdgcn_fmed3f(od0, od1, key);     // min(d1, max(d0, key))
+    s.d0 = __builtin_amdgcn_fmed3f(-R3DM_INF, od0, key);   // min(d0, key) as one v_med3_f32 (no canonicalising v_max)
+    s.i1 = c0 ? oi0 : t1;
+    s.i0 = c0 ? idx : oi0;
+}
+
+// write the verdict for one query: ratio test, optional 2-NN dump
+__device__ __forceinline__ void emit_result(const MatchParams& P, uint32_t pair, uint32_t q,
+                                            float ea, uint32_t ia, float eb, uint32_t ib)
+{
+    const size_t o = (size_t)pair * P.q_stride + q;
+    P.nn_idx[o] = (ib != kNone && ea < P.ratio_R * eb) ? ia : kNone;
+    if (P.knn_idx) {
+        P.knn_idx[2 * o] = (int32_t)ia; P.knn_idx[2 * o + 1] = (int32_t)ib;
+        P.knn_dist[2 * o] = ea;         P.knn_dist[2 * o + 1] = eb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused squared-L2 2-NN: one workgroup = 4 waves; each wave keeps NJ query tiles (32 queries each,
+// pre-scaled by -2) in registers as MFMA B fragments and streams every 32-row dataset tile of
+// image I as the A fragment, straight from the fragment-ordered HBM/L2 image (1 KiB coalesced
+// line per load, rolling PF-deep register window).  D = C + A*B with C initialised to ||a||^2
+// gives key = ||a||^2 - 2 a.b per (row, query) in the accumulator; lane (h, c) then owns query
+// column c and the 16 rows {e + 8*qd + 4h} of the tile.
+//   v_mfma_f32_32x32x2_f32: A lane l = A[i = l&31][k = l>>5], B lane l = B[k = l>>5][j = l&31],
+//   D lane l reg r = D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
+// The k axis is permuted identically on both operands (lane half h supplies dims 8g+4h+cc at
+// step 4g+cc), which a dot product does not notice.
+// ------------------------------------------------------------------------------------------------
+template <int G, int NJ, int PF>
+__global__ __launch_bounds__(256, 2)
+void l2_knn2_mfma_kernel(const MatchParams P)
+{
+    static_assert(G % PF == 0, "prefetch window must divide the group count");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t h = lane >> 5, c = lane & 31u;
+    const uint32_t pair = blockIdx.x / P.qb_per_pair;
+    const uint32_t qb = blockIdx.x % P.qb_per_pair;
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, nJ = Jp->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles;
+    const uint32_t qt0 = (qb * 4u + wave) * NJ;
+    if (qt0 >= ntJ) return;                           // wave-uniform; no barriers in this kernel
+
+    // ---- query fragments (B operand), scaled by -2
+    f32x4 bq[NJ][G];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;          // clamp: results discarded below
+        const gf4p src = (gf4p)Jp->tiled + (size_t)qt * (G * 64) + lane;
+#pragma unroll
+        for (int g = 0; g < G; ++g) bq[nj][g] = src[g * 64] * -2.0f;
+    }
+
+    Top2 st[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);
+
+    if (nI >= 2) {
+        // ---- dataset stream (A operand): float4 index = (t*G + g)*64 + lane.  abase/nbase are
+        // wave-uniform (SGPR) bases; only `lane` / `h` are per-lane.
+        const gf4p abase = (gf4p)Ip->tiled;
+        const gf4p nbase = (gf4p)Ip->norms;               // tile t, quad qd -> float4 index t*8 + 2*qd + h
+        f32x4 abuf[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) abuf[s] = abase[s * 64 + lane];
+        f32x4 nrm[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) nrm[qd] = nbase[2 * qd + h];
+
+        for (uint32_t t = 0; t < ntI; ++t) {
+            f32x16 acc[NJ];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nj][r] = nrm[r >> 2][r & 3];
+            const gf4p atile = abase + (size_t)(t * G + PF) * 64;    // PF groups ahead (slack-padded)
+            const gf4p ntile = nbase + (size_t)(t + 1) * 8;          // next tile's norms (slack-padded)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const f32x4 a = abuf[g % PF];
+                abuf[g % PF] = atile[g * 64 + lane];
+                if (g == G - 1) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) nrm[qd] = ntile[2 * qd + h];
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj)
+                        acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cc], bq[nj][g][cc], acc[nj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);        // keep each prefetch in its own step
+            }
+            const uint32_t rowbase = t * 32u + 4u * h;
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    top2_push(st[nj], acc[nj][r], rowbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        }
+    }
+
+    // ---- per query: merge the two lane halves, re-score exactly, certify, ratio-test
+    const float maxnorm = __uint_as_float(Ip->max_norm_bits);
+    const uint32_t dim = Ip->dim;
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        Top2 s = st[nj];
+        // partner half (same query column, the other 16 rows of every tile)
+        const float pd0 = __shfl_xor(s.d0, 32), pd1 = __shfl_xor(s.d1, 32), pd2 = __shfl_xor(s.d2, 32);
+        const uint32_t pi0 = __shfl_xor(s.i0, 32), pi1 = __shfl_xor(s.i1, 32);
+        top2_push(s, pd0, pi0);
+        top2_push(s, pd1, pi1);
+        s.d2 = fminf(s.d2, pd2);
+        // make both halves agree on the nominated pair (lane c's view)
+        const uint32_t ci0 = __shfl(s.i0, (int)c), ci1 = __shfl(s.i1, (int)c);
+        const float bound = __shfl(s.d2, (int)c);
+
+        const uint32_t qt = qt0 + nj;
+        const uint32_t q = qt * 32u + c;
+        const bool valid = (qt < ntJ) && (q < nJ);
+        const uint32_t cand = h ? ci1 : ci0;
+        float e = R3DM_INF;
+        if (valid && cand != kNone)
+            e = exact_l2sq(Ip->rows + (size_t)cand * dim, Jp->rows + (size_t)q * dim, dim);
+        const float eo = __shfl_xor(e, 32);
+        float ea = h ? eo : e, eb = h ? e : eo;          // ea <-> ci0, eb <-> ci1
+        uint32_t ia = ci0, ib = ci1;
+        if (eb < ea || (eb == ea && ib < ia)) { const float tf = ea; ea = eb; eb = tf; const uint32_t tu = ia; ia = ib; ib = tu; }
+        if (valid && h == 0) {
+            if (nI < 2) {
+                emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
+            } else {
+                const float nb = Jp->norms[q];
+                const float slack = P.err_scale * (maxnorm + nb);
+                const bool certified = eb < (bound + nb) - slack;   // every un-nominated row is farther than eb
+                if (certified) {
+                    emit_result(P, pair, q, ea, ia, eb, ib);
+                } else {
+                    P.nn_idx[(size_t)pair * P.q_stride + q] = kFallback;
+                    const uint32_t pos = atomicAdd(P.fb_count, 1u);
+                    if (pos < P.fb_cap) P.fb_items[pos] = make_uint2(pair, q);
+                }
+            }
+        }
+    }
+}
+
+template <int G, int NJ, int PF>
+static hipError_t launch_l2_t(hipStream_t st, const MatchParams& P)
+{
+    const uint32_t grid = P.n_pairs * P.qb_per_pair;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF>), dim3(grid), dim3(256), 0, st, P);
+    return hipGetLastError();
+}
+
+// queries per workgroup for a given G (4 waves x NJ tiles x 32)
+static inline int nj_for(uint32_t G) { return G <= 18 ? 2 : 1; }
+
+hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& Pin, uint32_t G, uint32_t max_nj_tiles)
+{
+    MatchParams P = Pin;
+    const uint32_t tiles_per_wg = 4u * (uint32_t)nj_for(G);
+    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
+    switch (G) {
+        case 8:  return launch_l2_t<8, 2, 4>(st, P);
+        case 16: return launch_l2_t<16, 2, 4>(st, P);
+        case 18: return launch_l2_t<18, 2, 3>(st, P);
+        case 32: return launch_l2_t<32, 1, 4>(st, P);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact scan of single (pair, query) items: the reference arithmetic over every dataset row.
+// Used for un-certified queries (rare), descriptor lengths without a tensor kernel, and as the
+// independent on-device cross-check of the MFMA path.  One workgroup per item.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lex_less(float da, uint32_t ia, float db, uint32_t ib)
+{
+    return da < db || (da == db && ia < ib);
+}
+
+__global__ __launch_bounds__(256)
+void l2_exact_items_kernel(const MatchParams P, uint32_t count, int scan_all)
+{
+    __shared__ float sd0[256], sd1[256];
+    __shared__ uint32_t si0[256], si1[256];
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        uint32_t pair, q;
+        if (scan_all) { pair = it / P.q_stride; q = it % P.q_stride; }
+        else { const uint2 item = P.fb_items[it]; pair = item.x; q = item.y; }
+        const uint2 pr = P.pairs[pair];
+        const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+        const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+        if (q >= Jp->n) continue;                                 // block-uniform
+        if (scan_all == 2 && P.nn_idx[(size_t)pair * P.q_stride + q] != kFallback) continue;
+        const uint32_t dim = Ip->dim, nI = Ip->n;
+        const float* qv = Jp->rows + (size_t)q * dim;
+        float d0 = R3DM_INF, d1 = R3DM_INF; uint32_t i0 = kNone, i1 = kNone;
+        for (uint32_t r = threadIdx.x; r < nI; r += 256) {
+            const float d = exact_l2sq(Ip->rows + (size_t)r * dim, qv, dim);
+            if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = r; }
+            else if (d < d1) { d1 = d; i1 = r; }
+        }
+        sd0[threadIdx.x] = d0; sd1[threadIdx.x] = d1; si0[threadIdx.x] = i0; si1[threadIdx.x] = i1;
+        __syncthreads();
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+                // merge two sorted pairs under the (distance, index) order
+                float a0 = sd0[threadIdx.x], a1 = sd1[threadIdx.x]; uint32_t x0 = si0[threadIdx.x], x1 = si1[threadIdx.x];
+                const float b0 = sd0[threadIdx.x + s], b1 = sd1[threadIdx.x + s];
+                const uint32_t y0 = si0[threadIdx.x + s], y1 = si1[threadIdx.x + s];
+                float r0, r1; uint32_t j0, j1;
+                if (lex_less(b0, y0, a0, x0)) {
+                    r0 = b0; j0 = y0;
+                    if (lex_less(b1, y1, a0, x0)) { r1 = b1; j1 = y1; } else { r1 = a0; j1 = x0; }
+                } else {
+                    r0 = a0; j0 = x0;
+                    if (lex_less(b0, y0, a1, x1)) { r1 = b0; j1 = y0; } else { r1 = a1; j1 = x1; }
+                }
+                sd0[threadIdx.x] = r0; sd1[threadIdx.x] = r1; si0[threadIdx.x] = j0; si1[threadIdx.x] = j1;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (nI < 2) emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
+            else emit_result(P, pair, q, sd0[0], si0[0], sd1[0], si1[0]);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t count, int scan_all)
+{
+    if (count == 0) return hipSuccess;
+    uint32_t grid = count < 16384u ? count : 16384u;
+    hipLaunchKernelGGL(l2_exact_items_kernel, dim3(grid), dim3(256), 0, st, P, count, scan_all);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hamming 2-NN (binary descriptors, e.g. 486-bit A-KAZE MLDB stored in 16 words): integer VALU only.
+// Each lane owns QL query rows in registers; dataset rows arrive wave-uniformly through the scalar
+// cache (s_load), so a row costs W x (v_xor + v_bcnt-accumulate) per query and no LDS/vector memory.
+// The running top-2 is kept on packed keys (distance << 22 | row): unsigned min / med3 then break
+// ties towards the lowest row, exactly the oracle's rule.
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) uint32_t* cu32p;   // constant address space -> SMEM loads
+
+template <int W, int QL>
+__global__ __launch_bounds__(256)
+void hamming_knn2_kernel(const MatchParams P)
+{
+    const uint32_t pair = blockIdx.x / P.qb_per_pair;
+    const uint32_t qb = blockIdx.x % P.qb_per_pair;
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, nJ = Jp->n;
+    const uint32_t q0 = (qb * 256u + threadIdx.x) * QL;
+    const uint32_t wave_q0 = (qb * 256u + (threadIdx.x & ~63u)) * QL;
+    if (wave_q0 >= nJ) return;
+
+    uint32_t qw[QL][W];
+#pragma unroll
+    for (int k = 0; k < QL; ++k) {
+        uint32_t q = q0 + k; if (q >= nJ) q = nJ - 1;
+        const uint32_t* src = Jp->bin + (size_t)q * W;
+#pragma unroll
+        for (int w = 0; w < W; ++w) qw[k][w] = src[w];
+    }
+    uint32_t k0[QL], k1[QL];
+#pragma unroll
+    for (int k = 0; k < QL; ++k) { k0[k] = 0xFFFFFFFFu; k1[k] = 0xFFFFFFFFu; }
+
+    const cu32p base = (cu32p)(uintptr_t)Ip->bin;
+#pragma unroll 2
+    for (uint32_t r = 0; r < nI; ++r) {
+        const cu32p row = base + (size_t)r * W;
+        uint32_t a[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) a[w] = row[w];
+#pragma unroll
+        for (int k = 0; k < QL; ++k) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) d += (uint32_t)__builtin_popcount(qw[k][w] ^ a[w]);
+            const uint32_t key = (d << 22) | r;
+            const uint32_t hi = k0[k] > key ? k0[k] : key;       // max(k0, key)
+            k1[k] = k1[k] < hi ? k1[k] : hi;                     // min(k1, max(k0, key))  (v_med3_u32)
+            k0[k] = k0[k] < key ? k0[k] : key;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QL; ++k) {
+        const uint32_t q = q0 + k;
+        if (q >= nJ) continue;
+        const size_t o = (size_t)pair * P.q_stride + q;
+        if (nI < 2) { P.nn_idx[o] = kNone; if (P.knn_idx) { P.knn_idx[2*o] = -1; P.knn_idx[2*o+1] = -1; P.knn_dist[2*o] = R3DM_INF; P.knn_dist[2*o+1] = R3DM_INF; } continue; }
+        const uint32_t d0 = k0[k] >> 22, d1 = k1[k] >> 22;
+        const uint32_t i0 = k0[k] & 0x3FFFFFu, i1 = k1[k] & 0x3FFFFFu;
+        // NNdistanceRatio on unsigned distances converted to float
+        P.nn_idx[o] = ((float)d0 < P.ratio_R * (float)d1) ? i0 : kNone;
+        if (P.knn_idx) {
+            P.knn_idx[2 * o] = (int32_t)i0; P.knn_idx[2 * o + 1] = (int32_t)i1;
+            P.knn_dist[2 * o] = (float)d0;  P.knn_dist[2 * o + 1] = (float)d1;
+        }
+    }
+}
+
+hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& Pin, uint32_t words, uint32_t max_n)
+{
+    MatchParams P = Pin;
+    constexpr int QL = 4;
+    P.qb_per_pair = (max_n + 256u * QL - 1) / (256u * QL);
+    const uint32_t grid = P.n_pairs * P.qb_per_pair;
+    if (grid == 0) return hipSuccess;
+    switch (words) {
+        case 8:  hipLaunchKernelGGL((hamming_knn2_kernel<8, QL>), dim3(grid), dim3(256), 0, st, P); break;
+        case 16: hipLaunchKernelGGL((hamming_knn2_kernel<16, QL>), dim3(grid), dim3(256), 0, st, P); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalisation: one workgroup per pair.  Compacts nn_idx[pair][*] into (i_, j_) keys, sorts them
+// (IndMatch::getDeduplicated order), drops matches whose (xI,yI,xJ,yJ) repeat an earlier one
+// (IndMatchDecorator), appends the list to the batch output and records (offset, count).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void finalize_pairs_kernel(const FinalizeParams P)
+{
+    // all LDS comes from the dynamic region (keeps the base 16-byte aligned):
+    // [keys: sort_cap x u64][drop: sort_cap x u8][s_off u64][wave_cnt 4 x u32][s_total u32]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* keys = (unsigned long long*)smem_raw;
+    unsigned char* drop = smem_raw + (size_t)P.sort_cap * 8;
+    unsigned long long* s_off_p = (unsigned long long*)(smem_raw + (size_t)P.sort_cap * 9);
+    uint32_t* wave_cnt = (uint32_t*)(s_off_p + 1);
+    uint32_t* s_total_p = wave_cnt + 4;
+
+    const uint32_t pair = blockIdx.x;
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nJ = Jp->n;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t* src = P.nn_idx + (size_t)pair * P.q_stride;
+
+    uint32_t m = 0;                                  // block-uniform running count
+    for (uint32_t base = 0; base < nJ; base += 256) {
+        const uint32_t q = base + threadIdx.x;
+        const uint32_t v = (q < nJ) ? src[q] : kNone;
+        const bool keep = (v < kFallback);
+        const unsigned long long bal = __ballot(keep);
+        const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
+        if (keep) keys[m + woff + before] = ((unsigned long long)v << 32) | q;
+        m += tot;
+        __syncthreads();
+    }
+
+    if (m > 1) {
+        // pad to a power of two and bitonic-sort ascending
+        uint32_t cap = 1; while (cap < m) cap <<= 1;
+        for (uint32_t k = m + threadIdx.x; k < cap; k += 256) keys[k] = ~0ull;
+        __syncthreads();
+        for (uint32_t size = 2; size <= cap; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t tId = threadIdx.x; tId < (cap >> 1); tId += 256) {
+                    const uint32_t lo = 2 * tId - (tId & (stride - 1));
+                    const uint32_t hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned long long x = keys[lo], y = keys[hi];
+                    if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        // coordinate de-duplication: only possible when both views contain repeated positions
+        if (Ip->canon && Jp->canon) {
+            for (uint32_t k = threadIdx.x; k < m; k += 256) {
+                const uint32_t ci = Ip->canon[(uint32_t)(keys[k] >> 32)], cj = Jp->canon[(uint32_t)keys[k]];
+                unsigned char d = 0;
+                for (uint32_t e = 0; e < k && !d; ++e)
+                    d = (Ip->canon[(uint32_t)(keys[e] >> 32)] == ci) && (Jp->canon[(uint32_t)keys[e]] == cj);
+                drop[k] = d;
+            }
+            __syncthreads();
+            // stable in-place compaction by a single wave-serial pass (rare path)
+            if (threadIdx.x == 0) {
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < m; ++k) if (!drop[k]) keys[w++] = keys[k];
+                *s_total_p = w;
+            }
+            __syncthreads();
+            m = *s_total_p;
+        }
+    }
+
+    if (threadIdx.x == 0) {
+        const unsigned long long off = m ? atomicAdd(P.total, (unsigned long long)m) : 0ull;
+        *s_off_p = off;
+        P.pair_off[pair] = off;
+        P.pair_cnt[pair] = m;
+    }
+    __syncthreads();
+    const unsigned long long off = *s_off_p;
+    if (off + m <= P.out_cap)
+        for (uint32_t k = threadIdx.x; k < m; k += 256) {
+            r3dm_match mm; mm.i = (uint32_t)(keys[k] >> 32); mm.j = (uint32_t)keys[k];
+            P.out[off + k] = mm;
+        }
+}
+
+hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P)
+{
+    if (P.n_pairs == 0) return hipSuccess;
+    const size_t lds = (size_t)P.sort_cap * 9 + 32;                     // keys + drop flags + scalars (sort_cap is a power of two >= 8)
+    hipError_t e = hipFuncSetAttribute((const void*)finalize_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(finalize_pairs_kernel, dim3(P.n_pairs), dim3(256), lds, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace r3dm

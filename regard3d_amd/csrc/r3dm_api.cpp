@@ -1,0 +1,851 @@
+// r3dm_api.cpp -- host side of libr3dm.so: the C ABI declared in include/r3dm.h.
+//
+// Mirrors, for the compute-matches hot path only, what the reference does in
+// /root/reference/src/R3DComputeMatches.cpp:2035-2129 (load regions, exhaustive pairs, match,
+// save putative, AC-RANSAC F filter, save) -- with every arithmetic stage running as HIP kernels
+// on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
+#include "r3dm_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace r3dm;
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct HostImage {
+    uint32_t view_id = 0, n = 0, dim = 0, width = 0, height = 0;
+    r3dm_dtype dtype = R3DM_F32;
+    uint32_t G = 0, n_tiles = 0, words = 0;
+    bool has_xy = false, has_dup = false, live = false;
+    DevBuf rows, tiled, norms, bin, xy, canon;
+    void release() { rows.release(); tiled.release(); norms.release(); bin.release(); xy.release(); canon.release(); live = false; }
+};
+
+uint32_t kernel_G_for(uint32_t dim)
+{
+    const uint32_t g = (dim + 7) / 8;
+    if (g <= 8) return 8;
+    if (g <= 16) return 16;
+    if (g <= 18) return 18;
+    if (g <= 32) return 32;
+    return g;               // no tensor kernel: exact scan only
+}
+bool has_tensor_kernel(uint32_t G) { return G == 8 || G == 16 || G == 18 || G == 32; }
+
+uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+bool has_ext(const char* path, const char* ext)
+{
+    const size_t lp = strlen(path), le = strlen(ext);
+    return lp >= le && strcmp(path + lp - le, ext) == 0;
+}
+
+}  // namespace
+
+struct r3dm_graph {
+    std::vector<uint32_t> pairs;      // 2 per pair
+    std::vector<uint64_t> offsets;    // n_pairs + 1
+    std::vector<r3dm_match> matches;
+};
+
+struct r3dm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::string arch;
+    int n_cu = 0;
+    uint64_t hbm = 0;
+    std::vector<std::unique_ptr<HostImage>> imgs;           // slot -> image
+    std::unordered_map<uint32_t, uint32_t> slot_of;         // view id -> slot
+    DevBuf d_imgs;                                           // ImgDev[slots]
+    // scratch (grown on demand, reused across calls)
+    DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
+    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
+    r3dm_stats stats{};
+    std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
+};
+
+#define R3DM_HIP(ctx, call)                                                            \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);          \
+            return R3DM_ERR_HIP;                                                       \
+        }                                                                              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int r3dm_create(int device_id, r3dm_ctx** out)
+{
+    if (!out) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return R3DM_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n_dev) return R3DM_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return R3DM_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return R3DM_ERR_NO_DEVICE;
+    std::string arch = prop.gcnArchName;
+    if (arch.find("gfx950") == std::string::npos) return R3DM_ERR_NO_DEVICE;   // the kernels are gfx950-only
+    auto* c = new (std::nothrow) r3dm_ctx();
+    if (!c) return R3DM_ERR_NOMEM;
+    c->device = device_id;
+    c->arch = arch;
+    c->n_cu = prop.multiProcessorCount;
+    c->hbm = prop.totalGlobalMem;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return R3DM_ERR_HIP;
+    }
+    *out = c;
+    return R3DM_OK;
+}
+
+extern "C" void r3dm_destroy(r3dm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& im : c->imgs) if (im) im->release();
+    DevBuf* bufs[] = {&c->d_imgs, &c->d_pairs, &c->d_nn, &c->d_knn_idx, &c->d_knn_dist, &c->d_fb, &c->d_cnt, &c->d_out,
+                      &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
+                      &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch};
+    for (DevBuf* b : bufs) b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* r3dm_last_error(const r3dm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int r3dm_device_info(const r3dm_ctx* c, char* arch, size_t arch_cap, int* n_cu, uint64_t* hbm_bytes)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    if (arch && arch_cap) { strncpy(arch, c->arch.c_str(), arch_cap - 1); arch[arch_cap - 1] = 0; }
+    if (n_cu) *n_cu = c->n_cu;
+    if (hbm_bytes) *hbm_bytes = c->hbm;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_get_stats(const r3dm_ctx* c, r3dm_stats* out)
+{
+    if (!c || !out) return R3DM_ERR_INVALID;
+    *out = c->stats;
+    return R3DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// views
+// ------------------------------------------------------------------------------------------------
+static int upload_imgdev(r3dm_ctx* c, uint32_t slot)
+{
+    const size_t need = sizeof(ImgDev) * c->imgs.size();
+    if (need > c->d_imgs.cap) {
+        // grow and re-upload every live slot; max_norm_bits must survive -> read the old table back first
+        std::vector<ImgDev> old(c->d_imgs.cap / sizeof(ImgDev));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        if (!old.empty()) {
+            R3DM_HIP(c, hipMemcpyAsync(old.data(), c->d_imgs.p, old.size() * sizeof(ImgDev), hipMemcpyDeviceToHost, c->stream));
+            R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        DevBuf nb;
+        R3DM_HIP(c, nb.ensure(sizeof(ImgDev) * std::max<size_t>(64, c->imgs.size() * 2)));
+        R3DM_HIP(c, hipMemsetAsync(nb.p, 0, nb.cap, c->stream));
+        const size_t keep = std::min(old.size(), c->imgs.size());
+        if (keep) R3DM_HIP(c, hipMemcpyAsync(nb.p, old.data(), keep * sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        c->d_imgs.release();
+        c->d_imgs = nb;
+    }
+    const HostImage& h = *c->imgs[slot];
+    ImgDev d{};
+    d.rows = h.rows.as<float>(); d.tiled = h.tiled.as<float>(); d.norms = h.norms.as<float>();
+    d.bin = h.bin.as<uint32_t>(); d.xy = h.has_xy ? h.xy.as<float>() : nullptr;
+    d.canon = h.has_dup ? h.canon.as<uint32_t>() : nullptr;
+    d.n = h.n; d.n_tiles = h.n_tiles; d.dim = h.dim; d.G = h.G; d.words = h.words;
+    d.width = h.width; d.height = h.height; d.max_norm_bits = 0;
+    R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    return R3DM_OK;
+}
+
+// copy + re-layout one view into slot `slot`
+static int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width, uint32_t height,
+                           const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
+{
+    HostImage& h = *c->imgs[slot];
+    h.view_id = view_id; h.n = n; h.dim = dim; h.dtype = dtype; h.width = width; h.height = height;
+    h.has_xy = (xy != nullptr); h.has_dup = false; h.live = true;
+    h.G = 0; h.n_tiles = 0; h.words = 0;
+    if (dtype == R3DM_BIN) {
+        h.words = (dim + 3) / 4;
+        const uint32_t n_pad = n + 8;
+        R3DM_HIP(c, h.bin.ensure((size_t)n_pad * h.words * 4 + kSlackBytes));
+        if (n) {
+            R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
+            R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
+        }
+        R3DM_HIP(c, launch_stage_bin(c->stream, c->d_raw.as<uint8_t>(), n, dim, h.bin.as<uint32_t>(), h.words, n_pad));
+    } else {
+        h.G = kernel_G_for(dim);
+        h.n_tiles = (n + kTileRows - 1) / kTileRows;
+        const size_t tiled_bytes = (size_t)h.n_tiles * h.G * 1024 + kSlackBytes;
+        const size_t norm_bytes = (size_t)h.n_tiles * 32 * 4 + kSlackBytes;
+        R3DM_HIP(c, h.rows.ensure((size_t)std::max<uint32_t>(n, 1) * dim * 4 + 256));
+        R3DM_HIP(c, h.tiled.ensure(tiled_bytes));
+        R3DM_HIP(c, h.norms.ensure(norm_bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiled.p, 0, tiled_bytes, c->stream));
+        R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0, norm_bytes, c->stream));
+        const void* raw = nullptr;
+        if (n) {
+            if (dtype == R3DM_F32) {
+                R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim * 4));
+                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim * 4, hipMemcpyDefault, c->stream));
+            } else {
+                R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
+                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
+            }
+            raw = c->d_raw.p;
+        }
+        (void)raw;
+    }
+    if (xy && n) {
+        R3DM_HIP(c, h.xy.ensure((size_t)n * 8));
+        R3DM_HIP(c, hipMemcpyAsync(h.xy.p, xy, (size_t)n * 8, hipMemcpyDefault, c->stream));
+    }
+    // position classes (IndMatchDecorator de-duplication needs to know which features share a position)
+    if (xy && n > 1) {
+        std::vector<float> hxy((size_t)n * 2);
+        R3DM_HIP(c, hipMemcpyAsync(hxy.data(), h.xy.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> ord(n);
+        std::iota(ord.begin(), ord.end(), 0u);
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+            if (hxy[2 * a] != hxy[2 * b]) return hxy[2 * a] < hxy[2 * b];
+            if (hxy[2 * a + 1] != hxy[2 * b + 1]) return hxy[2 * a + 1] < hxy[2 * b + 1];
+            return a < b;
+        });
+        std::vector<uint32_t> canon(n);
+        bool dup = false;
+        for (uint32_t k = 0; k < n;) {
+            uint32_t e = k + 1;
+            while (e < n && hxy[2 * ord[e]] == hxy[2 * ord[k]] && hxy[2 * ord[e] + 1] == hxy[2 * ord[k] + 1]) ++e;
+            for (uint32_t q = k; q < e; ++q) canon[ord[q]] = ord[k];     // ord[k] is the smallest index of the group
+            if (e - k > 1) dup = true;
+            k = e;
+        }
+        if (dup) {
+            h.has_dup = true;
+            R3DM_HIP(c, h.canon.ensure((size_t)n * 4));
+            R3DM_HIP(c, hipMemcpyAsync(h.canon.p, canon.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    int rc = upload_imgdev(c, slot);
+    if (rc != R3DM_OK) return rc;
+    if (dtype != R3DM_BIN) {
+        uint32_t* mx = &(c->d_imgs.as<ImgDev>() + slot)->max_norm_bits;
+        R3DM_HIP(c, launch_stage_f32(c->stream, n ? c->d_raw.p : nullptr, dtype == R3DM_U8, n, dim, h.rows.as<float>(),
+                                     h.tiled.as<float>(), h.norms.as<float>(), h.G, h.n_tiles, mx));
+    }
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));     // d_raw is reused by the next call
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_set_image(r3dm_ctx* c, uint32_t view_id, uint32_t width, uint32_t height,
+                              const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
+{
+    if (!c || dim == 0 || (n && !desc)) return R3DM_ERR_INVALID;
+    if (dtype != R3DM_F32 && dtype != R3DM_U8 && dtype != R3DM_BIN) return R3DM_ERR_INVALID;
+    if (n >= (1u << 22)) { c->err = "more than 4M features in one view"; return R3DM_ERR_UNSUPPORTED; }
+    if (dtype == R3DM_BIN && !(((dim + 3) / 4) == 8 || ((dim + 3) / 4) == 16)) {
+        c->err = "binary descriptors must be 29..32 or 61..64 bytes"; return R3DM_ERR_UNSUPPORTED;
+    }
+    R3DM_HIP(c, hipSetDevice(c->device));
+    uint32_t slot;
+    auto it = c->slot_of.find(view_id);
+    if (it == c->slot_of.end()) {
+        slot = (uint32_t)c->imgs.size();
+        c->imgs.emplace_back(new HostImage());
+        c->slot_of[view_id] = slot;
+    } else slot = it->second;
+    return stage_into_slot(c, slot, view_id, width, height, desc, n, dim, dtype, xy);
+}
+
+extern "C" int r3dm_clear_images(r3dm_ctx* c)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& im : c->imgs) if (im) im->release();
+    c->imgs.clear();
+    c->slot_of.clear();
+    return R3DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// putative matching
+// ------------------------------------------------------------------------------------------------
+struct PairJob { uint32_t I, J, sI, sJ; };
+
+// runs the 2-NN + ratio kernels over `jobs` (slot pairs, all of one dtype/dim) and appends the
+// non-empty results to `g` in job order.  knn_idx/knn_dist (host, optional) receive the raw 2-NN.
+static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
+                           int32_t* knn_idx_host, float* knn_dist_host)
+{
+    const uint32_t P = (uint32_t)jobs.size();
+    if (P == 0) return R3DM_OK;
+    const HostImage& first = *c->imgs[jobs[0].sI];
+    const r3dm_dtype dtype = first.dtype;
+    uint32_t max_nJ = 0, max_tiles = 0;
+    uint64_t n_queries = 0;
+    double flops = 0, bytes = 0;
+    for (const PairJob& j : jobs) {
+        const HostImage& A = *c->imgs[j.sI];
+        const HostImage& B = *c->imgs[j.sJ];
+        max_nJ = std::max(max_nJ, B.n);
+        max_tiles = std::max(max_tiles, B.n_tiles);
+        n_queries += B.n;
+        if (dtype == R3DM_BIN) {
+            flops += 2.0 * A.n * (double)B.n * A.words;
+            bytes += ((double)A.n + B.n) * A.words * 4 + (double)B.n * 16;
+        } else {
+            flops += 2.0 * A.n * (double)B.n * A.dim;
+            bytes += ((double)A.n + B.n) * A.dim * 4 + (double)B.n * 16;
+        }
+    }
+    const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
+    const uint32_t sort_cap = std::max<uint32_t>(8, next_pow2(q_stride));
+    if ((size_t)sort_cap * 9 + 32 > 160 * 1024) { c->err = "more than 16384 features per view in the finalisation kernel"; return R3DM_ERR_UNSUPPORTED; }
+
+    std::vector<uint2> hp(P);
+    for (uint32_t p = 0; p < P; ++p) hp[p] = make_uint2(jobs[p].sI, jobs[p].sJ);
+    R3DM_HIP(c, c->d_pairs.ensure(sizeof(uint2) * P));
+    R3DM_HIP(c, hipMemcpyAsync(c->d_pairs.p, hp.data(), sizeof(uint2) * P, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, c->d_nn.ensure((size_t)P * q_stride * 4));
+    const uint64_t total_slots = (uint64_t)P * q_stride;
+    const uint32_t fb_cap = (uint32_t)std::min<uint64_t>(total_slots, 1u << 22);
+    R3DM_HIP(c, c->d_fb.ensure((size_t)fb_cap * sizeof(uint2)));
+    R3DM_HIP(c, c->d_cnt.ensure(64));
+    R3DM_HIP(c, hipMemsetAsync(c->d_cnt.p, 0, 64, c->stream));
+    if (knn_idx_host) {
+        R3DM_HIP(c, c->d_knn_idx.ensure((size_t)total_slots * 8));
+        R3DM_HIP(c, c->d_knn_dist.ensure((size_t)total_slots * 8));
+    }
+
+    MatchParams mp{};
+    mp.imgs = c->d_imgs.as<ImgDev>();
+    mp.pairs = c->d_pairs.as<uint2>();
+    mp.n_pairs = P; mp.qb_per_pair = 0; mp.q_stride = q_stride;
+    mp.ratio_R = ratio_R;
+    mp.err_scale = 8.0f * (float)(first.G * 8) * 5.9604645e-08f;
+    mp.nn_idx = c->d_nn.as<uint32_t>();
+    mp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
+    mp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
+    mp.fb_items = c->d_fb.as<uint2>();
+    mp.fb_count = c->d_cnt.as<uint32_t>();
+    mp.fb_cap = fb_cap;
+
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    uint64_t n_fallback = 0;
+    if (dtype == R3DM_BIN) {
+        R3DM_HIP(c, launch_hamming_knn2(c->stream, mp, first.words, max_nJ));
+        R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    } else if (has_tensor_kernel(first.G)) {
+        R3DM_HIP(c, launch_l2_knn2(c->stream, mp, first.G, max_tiles));
+        R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+        uint32_t fbc = 0;
+        R3DM_HIP(c, hipMemcpyAsync(&fbc, c->d_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        n_fallback = fbc;
+        if (fbc > 0) {
+            if (fbc <= fb_cap) R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, fbc, 0));
+            else {
+                if (total_slots > 0xFFFFFFFFull) { c->err = "batch too large for the exact rescan"; return R3DM_ERR_UNSUPPORTED; }
+                R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, (uint32_t)total_slots, 2));
+            }
+        }
+    } else {
+        // descriptor length without a tensor kernel: exact scan of every query (slow, still on the GPU)
+        if (total_slots > 0xFFFFFFFFull) { c->err = "batch too large for the exact scan"; return R3DM_ERR_UNSUPPORTED; }
+        R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, (uint32_t)total_slots, 1));
+        R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+        n_fallback = n_queries;
+    }
+
+    // ---- finalisation: compact + order + de-duplicate, per pair
+    R3DM_HIP(c, c->d_pair_off.ensure((size_t)P * 8));
+    R3DM_HIP(c, c->d_pair_cnt.ensure((size_t)P * 4));
+    uint64_t out_cap = std::max<uint64_t>(1u << 20, n_queries / 4);
+    std::vector<uint64_t> h_off(P);
+    std::vector<uint32_t> h_cnt(P);
+    unsigned long long total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        R3DM_HIP(c, c->d_out.ensure(out_cap * sizeof(r3dm_match)));
+        R3DM_HIP(c, hipMemsetAsync(c->d_cnt.as<uint32_t>() + 8, 0, 8, c->stream));
+        FinalizeParams fp{};
+        fp.imgs = c->d_imgs.as<ImgDev>(); fp.pairs = c->d_pairs.as<uint2>(); fp.n_pairs = P; fp.q_stride = q_stride;
+        fp.nn_idx = c->d_nn.as<uint32_t>(); fp.sort_cap = sort_cap;
+        fp.out = c->d_out.as<r3dm_match>(); fp.out_cap = out_cap;
+        fp.total = reinterpret_cast<unsigned long long*>(c->d_cnt.as<uint32_t>() + 8);
+        fp.pair_off = c->d_pair_off.as<uint64_t>(); fp.pair_cnt = c->d_pair_cnt.as<uint32_t>();
+        R3DM_HIP(c, launch_finalize(c->stream, fp));
+        R3DM_HIP(c, hipMemcpyAsync(&total, fp.total, 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(h_off.data(), fp.pair_off, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(h_cnt.data(), fp.pair_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        if (total <= out_cap) break;
+        out_cap = total;                                   // overflow: nothing was lost, run it again with room
+    }
+    std::vector<r3dm_match> h_m((size_t)total);
+    if (total) R3DM_HIP(c, hipMemcpy(h_m.data(), c->d_out.p, (size_t)total * sizeof(r3dm_match), hipMemcpyDeviceToHost));
+    if (knn_idx_host) {
+        // single-pair use (r3dm_knn2): copy the raw 2-NN of pair 0
+        R3DM_HIP(c, hipMemcpy(knn_idx_host, c->d_knn_idx.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost));
+        R3DM_HIP(c, hipMemcpy(knn_dist_host, c->d_knn_dist.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost));
+    }
+
+    if (g) {
+        for (uint32_t p = 0; p < P; ++p) {
+            if (h_cnt[p] == 0) continue;                   // empty vectors never enter the map
+            g->pairs.push_back(jobs[p].I); g->pairs.push_back(jobs[p].J);
+            g->matches.insert(g->matches.end(), h_m.begin() + h_off[p], h_m.begin() + h_off[p] + h_cnt[p]);
+            g->offsets.push_back(g->matches.size());
+        }
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_match_kernels += ms;
+    c->stats.n_match_launches += 1;
+    c->stats.n_pairs += P;
+    c->stats.n_queries += n_queries;
+    c->stats.n_exact_fallback += n_fallback;
+    c->stats.algorithmic_flops += flops;
+    c->stats.algorithmic_bytes += bytes;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs,
+                                float dist_ratio, int squared_metric, r3dm_graph** out)
+{
+    if (!c || !out || (n_pairs && !pairs_ij)) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    c->stats = r3dm_stats{};
+    // Matcher_Regions::Match: pairs whose views are missing, empty or of different region types are skipped
+    std::vector<PairJob> jobs;
+    jobs.reserve(n_pairs);
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        const uint32_t I = pairs_ij[2 * p], J = pairs_ij[2 * p + 1];
+        auto a = c->slot_of.find(I), b = c->slot_of.find(J);
+        if (a == c->slot_of.end() || b == c->slot_of.end()) { c->err = "pair references an unregistered view"; return R3DM_ERR_INVALID; }
+        const HostImage& A = *c->imgs[a->second];
+        const HostImage& B = *c->imgs[b->second];
+        if (A.n == 0 || B.n == 0 || A.dtype != B.dtype || A.dim != B.dim) continue;
+        jobs.push_back({I, J, a->second, b->second});
+    }
+    std::sort(jobs.begin(), jobs.end(), [](const PairJob& x, const PairJob& y) { return x.I != y.I ? x.I < y.I : x.J < y.J; });
+    jobs.erase(std::unique(jobs.begin(), jobs.end(), [](const PairJob& x, const PairJob& y) { return x.I == y.I && x.J == y.J; }), jobs.end());
+
+    auto g = std::unique_ptr<r3dm_graph>(new r3dm_graph());
+    g->offsets.push_back(0);
+    const float R = squared_metric ? dist_ratio * dist_ratio : dist_ratio;
+
+    // batches: same (dtype, dim) and a bounded nn_idx footprint
+    size_t start = 0;
+    while (start < jobs.size()) {
+        const HostImage& F = *c->imgs[jobs[start].sI];
+        size_t end = start;
+        uint64_t slots = 0;
+        uint32_t max_n = 0;
+        while (end < jobs.size()) {
+            const HostImage& A = *c->imgs[jobs[end].sI];
+            if (A.dtype != F.dtype || A.dim != F.dim) break;
+            const uint32_t mn = std::max(max_n, c->imgs[jobs[end].sJ]->n);
+            const uint64_t s = (uint64_t)(end - start + 1) * ((mn + 31) / 32 * 32);
+            if (end > start && s * 4 > (3ull << 30)) break;       // <= 3 GiB of nn_idx per batch
+            max_n = mn; slots = s; ++end;
+        }
+        (void)slots;
+        std::vector<PairJob> batch(jobs.begin() + start, jobs.begin() + end);
+        int rc = run_match_batch(c, batch, R, g.get(), nullptr, nullptr);
+        if (rc != R3DM_OK) return rc;
+        start = end;
+    }
+    *out = g.release();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
+                         uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist)
+{
+    if (!c || !dataset || !query || !out_idx || !out_dist || dim == 0) return R3DM_ERR_INVALID;
+    if (n_query < 1 || n_dataset < 2) return R3DM_ERR_INVALID;      // ArrayMatcherBruteForce: NN > nbRows / nbQuery < 1
+    if (dtype == R3DM_BIN && !(((dim + 3) / 4) == 8 || ((dim + 3) / 4) == 16)) return R3DM_ERR_UNSUPPORTED;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    // two private slots at the end of the table (never visible through view ids)
+    const uint32_t s0 = (uint32_t)c->imgs.size();
+    c->imgs.emplace_back(new HostImage());
+    c->imgs.emplace_back(new HostImage());
+    int rc = stage_into_slot(c, s0, 0, 0, 0, dataset, n_dataset, dim, dtype, nullptr);
+    if (rc == R3DM_OK) rc = stage_into_slot(c, s0 + 1, 0, 0, 0, query, n_query, dim, dtype, nullptr);
+    if (rc == R3DM_OK) {
+        std::vector<PairJob> jobs{{0, 1, s0, s0 + 1}};
+        const r3dm_stats keep = c->stats;
+        rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
+        c->stats = keep;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
+    c->imgs.pop_back(); c->imgs.pop_back();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometric filter
+// ------------------------------------------------------------------------------------------------
+extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out)
+{
+    if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    const uint64_t NP = putative->pairs.size() / 2;
+    // work items: pairs with more than 7 putatives (ACRANSAC returns nothing for n <= 7)
+    std::vector<uint32_t> item_pair;
+    std::vector<uint2> slots, ids;
+    uint32_t max_m = 0;
+    uint64_t sum_m = 0;
+    for (uint64_t p = 0; p < NP; ++p) {
+        const uint64_t m = putative->offsets[p + 1] - putative->offsets[p];
+        if (m <= 7) continue;
+        const uint32_t I = putative->pairs[2 * p], J = putative->pairs[2 * p + 1];
+        auto a = c->slot_of.find(I), b = c->slot_of.find(J);
+        if (a == c->slot_of.end() || b == c->slot_of.end()) { c->err = "filter: pair references an unregistered view"; return R3DM_ERR_INVALID; }
+        const HostImage& A = *c->imgs[a->second];
+        const HostImage& B = *c->imgs[b->second];
+        if (!A.has_xy || !B.has_xy) { c->err = "filter: view registered without feature positions"; return R3DM_ERR_INVALID; }
+        if (m > 8192) { c->err = "filter: more than 8192 putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
+        item_pair.push_back((uint32_t)p);
+        slots.push_back(make_uint2(a->second, b->second));
+        ids.push_back(make_uint2(I, J));
+        max_m = std::max<uint32_t>(max_m, (uint32_t)m);
+        sum_m += m;
+    }
+    auto g = std::unique_ptr<r3dm_graph>(new r3dm_graph());
+    g->offsets.push_back(0);
+    const uint32_t NI = (uint32_t)item_pair.size();
+    c->stats.ms_filter_kernels = 0;
+    if (NI == 0) { *out = g.release(); return R3DM_OK; }
+    (void)sum_m;
+    // [begin, end) of every item's putative list inside the full match array
+    std::vector<uint64_t> begin_end(2 * (size_t)NI);
+    for (uint32_t k = 0; k < NI; ++k) {
+        const uint32_t p = item_pair[k];
+        begin_end[2 * k] = putative->offsets[p];
+        begin_end[2 * k + 1] = putative->offsets[p + 1];
+    }
+    if (err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { c->err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
+    // host tables in the reference's own float arithmetic (glibc log10f), see kernels_filter.hip
+    std::vector<float> l10(max_m + 2), lck(max_m + 2);
+    for (uint32_t k = 0; k <= max_m + 1; ++k) l10[k] = std::log10((float)k);
+    for (uint32_t n = 0; n <= max_m + 1; ++n) {
+        const uint32_t ks = 7;
+        if (ks >= n) { lck[n] = 0.f; continue; }
+        const uint32_t kk = (n - ks < ks) ? n - ks : ks;
+        float r = 0.f;
+        for (uint32_t i = 1; i <= kk; ++i) r += l10[n - i + 1] - l10[i];
+        lck[n] = r;
+    }
+    const uint64_t n_match_total = putative->matches.size();
+    R3DM_HIP(c, c->f_pairs.ensure(sizeof(uint2) * NI));
+    R3DM_HIP(c, c->f_ids.ensure(sizeof(uint2) * NI));
+    R3DM_HIP(c, c->f_offs.ensure(sizeof(uint64_t) * 2 * NI));
+    R3DM_HIP(c, c->f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
+    R3DM_HIP(c, c->f_inl_cnt.ensure(4 * (size_t)NI));
+    R3DM_HIP(c, c->f_inl_idx.ensure(4 * (size_t)n_match_total + 64));
+    R3DM_HIP(c, c->f_F.ensure(72 * (size_t)NI));
+    R3DM_HIP(c, c->f_thr.ensure(16 * (size_t)NI));
+    R3DM_HIP(c, c->f_iters.ensure(8 * (size_t)NI));
+    R3DM_HIP(c, c->f_log10.ensure(4 * l10.size()));
+    R3DM_HIP(c, c->f_logck.ensure(4 * lck.size()));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_pairs.p, slots.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_ids.p, ids.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_offs.p, begin_end.data(), sizeof(uint64_t) * 2 * NI, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_log10.p, l10.data(), 4 * l10.size(), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_logck.p, lck.data(), 4 * lck.size(), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemsetAsync(c->f_inl_cnt.p, 0, 4 * (size_t)NI, c->stream));
+
+    FilterParams fp{};
+    fp.imgs = c->d_imgs.as<ImgDev>();
+    fp.pairs = c->f_pairs.as<uint2>(); fp.pair_ids = c->f_ids.as<uint2>();
+    fp.offsets = c->f_offs.as<uint64_t>(); fp.matches = c->f_matches.as<r3dm_match>();
+    fp.n_items = NI; fp.m_cap = std::max<uint32_t>(64, next_pow2(max_m));
+    fp.precision_px = max_residual_px; fp.max_iter = max_iter; fp.seed = seed; fp.err_kind = (int)err_kind;
+    fp.log10_tab = c->f_log10.as<float>(); fp.logc_k = c->f_logck.as<float>();
+    fp.inl_count = c->f_inl_cnt.as<uint32_t>(); fp.inl_idx = c->f_inl_idx.as<uint32_t>();
+    fp.F_out = c->f_F.as<double>(); fp.thr_nfa = c->f_thr.as<double>(); fp.iters = c->f_iters.as<uint32_t>();
+    R3DM_HIP(c, c->f_scratch.ensure(32 * (size_t)n_match_total + 4 * (size_t)n_match_total + 4 * ((size_t)n_match_total + NI + 1) + 256));
+    fp.pts_scratch = c->f_scratch.as<double>();
+    fp.pool_scratch = reinterpret_cast<uint32_t*>(c->f_scratch.as<unsigned char>() + 32 * (size_t)n_match_total);
+    fp.scratch_logc = reinterpret_cast<float*>(c->f_scratch.as<unsigned char>() + 36 * (size_t)n_match_total);
+    if (filter_F_lds_bytes(fp.m_cap) > 160 * 1024) { c->err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
+    // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
+    DevBuf trace_buf;
+    const uint32_t trace_cap = 16384;
+    const char* tp = getenv("R3DM_TRACE_PAIR");
+    const char* tf = getenv("R3DM_TRACE_FILE");
+    fp.trace = nullptr; fp.trace_item = 0xFFFFFFFFu; fp.trace_cap = trace_cap; fp.trace_rows = nullptr;
+    fp.trace_iter = getenv("R3DM_TRACE_ITER") ? (uint32_t)atoi(getenv("R3DM_TRACE_ITER")) : 0xFFFFFFFFu;
+    if (tp && tf) {
+        unsigned tI = 0, tJ = 0;
+        if (sscanf(tp, "%u,%u", &tI, &tJ) == 2)
+            for (uint32_t k = 0; k < NI; ++k)
+                if (ids[k].x == tI && ids[k].y == tJ) fp.trace_item = k;
+        if (fp.trace_item != 0xFFFFFFFFu) {
+            R3DM_HIP(c, trace_buf.ensure(40 * (size_t)trace_cap + 64));
+            R3DM_HIP(c, hipMemsetAsync(trace_buf.p, 0, 40 * (size_t)trace_cap + 64, c->stream));
+            fp.trace = trace_buf.as<double>() + 8;
+            fp.trace_rows = trace_buf.as<uint32_t>();
+        }
+    }
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    R3DM_HIP(c, launch_filter_F(c->stream, fp));
+    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+
+    std::vector<uint32_t> h_cnt(NI);
+    std::vector<uint32_t> h_idx(n_match_total);
+    std::vector<double> h_F(9 * (size_t)NI);
+    R3DM_HIP(c, hipMemcpyAsync(h_cnt.data(), c->f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(h_idx.data(), c->f_inl_idx.p, 4 * (size_t)n_match_total, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(h_F.data(), c->f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_filter_kernels = ms;
+    if (fp.trace) {
+        std::vector<double> tr(5 * (size_t)trace_cap + 8);
+        R3DM_HIP(c, hipMemcpy(tr.data(), trace_buf.p, tr.size() * 8, hipMemcpyDeviceToHost));
+        const uint32_t rows = std::min<uint32_t>(*reinterpret_cast<uint32_t*>(tr.data()), trace_cap);
+        if (FILE* f = fopen(tf, "w")) {
+            for (uint32_t r = 0; r < rows; ++r)
+                fprintf(f, "%.0f %.0f %.0f %.17g %.0f\n", tr[8 + 5 * r], tr[9 + 5 * r], tr[10 + 5 * r], tr[11 + 5 * r], tr[12 + 5 * r]);
+            if (fp.trace_iter != 0xFFFFFFFFu) {
+                fprintf(f, "# sample");
+                for (int k = 0; k < 20; ++k) fprintf(f, " %.0f", tr[8 + 5 * (size_t)(trace_cap - 4) + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        trace_buf.release();
+    }
+    // per-item diagnostics of this call (threshold px, NFA, iterations, models), in putative-pair order
+    {
+        std::vector<double> h_thr(2 * (size_t)NI);
+        std::vector<uint32_t> h_it(2 * (size_t)NI);
+        R3DM_HIP(c, hipMemcpy(h_thr.data(), c->f_thr.p, 16 * (size_t)NI, hipMemcpyDeviceToHost));
+        R3DM_HIP(c, hipMemcpy(h_it.data(), c->f_iters.p, 8 * (size_t)NI, hipMemcpyDeviceToHost));
+        c->report.assign(NP, r3dm_pair_report{});
+        for (uint32_t k = 0; k < NI; ++k) {
+            r3dm_pair_report& r = c->report[item_pair[k]];
+            r.threshold_px = h_thr[2 * k]; r.nfa = h_thr[2 * k + 1];
+            r.iterations = h_it[2 * k]; r.models = h_it[2 * k + 1]; r.inliers = h_cnt[k];
+        }
+    }
+
+    uint64_t kept = 0;
+    for (uint32_t k = 0; k < NI; ++k) {
+        // GeometricFilter_FMatrix_AC: accept iff #inliers > 2.5 * 7
+        if ((double)h_cnt[k] <= 2.5 * 7) continue;
+        const uint32_t p = item_pair[k];
+        const uint64_t base = putative->offsets[p];
+        g->pairs.push_back(putative->pairs[2 * p]); g->pairs.push_back(putative->pairs[2 * p + 1]);
+        for (uint32_t q = 0; q < h_cnt[k]; ++q) g->matches.push_back(putative->matches[base + h_idx[base + q]]);
+        g->offsets.push_back(g->matches.size());
+        if (F_out) memcpy(F_out + 9 * kept, h_F.data() + 9 * (size_t)k, 72);
+        ++kept;
+    }
+    *out = g.release();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint64_t cap)
+{
+    if (!c || (cap && !out)) return R3DM_ERR_INVALID;
+    const uint64_t n = std::min<uint64_t>(cap, c->report.size());
+    if (n) memcpy(out, c->report.data(), n * sizeof(r3dm_pair_report));
+    return (int)std::min<uint64_t>(c->report.size(), 0x7FFFFFFF);
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph accessors, merge, files
+// ------------------------------------------------------------------------------------------------
+extern "C" uint64_t r3dm_graph_num_pairs(const r3dm_graph* g) { return g ? g->pairs.size() / 2 : 0; }
+extern "C" uint64_t r3dm_graph_num_matches(const r3dm_graph* g) { return g ? g->matches.size() : 0; }
+extern "C" const uint32_t* r3dm_graph_pairs(const r3dm_graph* g) { return g ? g->pairs.data() : nullptr; }
+extern "C" const uint64_t* r3dm_graph_offsets(const r3dm_graph* g) { return g ? g->offsets.data() : nullptr; }
+extern "C" const r3dm_match* r3dm_graph_matches(const r3dm_graph* g) { return g ? g->matches.data() : nullptr; }
+extern "C" void r3dm_graph_free(r3dm_graph* g) { delete g; }
+
+extern "C" int r3dm_graph_from_csr(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64_t* offsets,
+                                   const r3dm_match* matches, r3dm_graph** out)
+{
+    if (!out || (n_pairs && (!pairs_ij || !offsets))) return R3DM_ERR_INVALID;
+    auto g = std::unique_ptr<r3dm_graph>(new (std::nothrow) r3dm_graph());
+    if (!g) return R3DM_ERR_NOMEM;
+    g->offsets.push_back(0);
+    // keep the PairWiseMatches invariants: ordered by (I, J), no empty entries
+    std::vector<uint64_t> ord(n_pairs);
+    std::iota(ord.begin(), ord.end(), 0ull);
+    std::sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) {
+        if (pairs_ij[2 * a] != pairs_ij[2 * b]) return pairs_ij[2 * a] < pairs_ij[2 * b];
+        return pairs_ij[2 * a + 1] < pairs_ij[2 * b + 1];
+    });
+    for (uint64_t k = 0; k < n_pairs; ++k) {
+        const uint64_t p = ord[k];
+        const uint64_t b = offsets[p], e = offsets[p + 1];
+        if (e <= b) continue;
+        if (!matches) return R3DM_ERR_INVALID;
+        g->pairs.push_back(pairs_ij[2 * p]); g->pairs.push_back(pairs_ij[2 * p + 1]);
+        g->matches.insert(g->matches.end(), matches + b, matches + e);
+        g->offsets.push_back(g->matches.size());
+    }
+    *out = g.release();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out)
+{
+    if (!out || (n_parts && !parts)) return R3DM_ERR_INVALID;
+    std::vector<uint32_t> pairs;
+    std::vector<uint64_t> offs{0};
+    std::vector<r3dm_match> m;
+    for (uint32_t k = 0; k < n_parts; ++k) {
+        const r3dm_graph* g = parts[k];
+        if (!g) continue;
+        const uint64_t np = g->pairs.size() / 2;
+        for (uint64_t p = 0; p < np; ++p) {
+            pairs.push_back(g->pairs[2 * p]); pairs.push_back(g->pairs[2 * p + 1]);
+            m.insert(m.end(), g->matches.begin() + g->offsets[p], g->matches.begin() + g->offsets[p + 1]);
+            offs.push_back(m.size());
+        }
+    }
+    return r3dm_graph_from_csr(pairs.data(), pairs.size() / 2, offs.data(), m.data(), out);
+}
+
+// matches.*.txt / matches.*.bin -- OpenMVG Save/Load(PairWiseMatches)
+extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
+{
+    if (!g || !path) return R3DM_ERR_INVALID;
+    const bool bin = has_ext(path, ".bin");
+    if (!bin && !has_ext(path, ".txt")) return R3DM_ERR_INVALID;
+    FILE* f = fopen(path, bin ? "wb" : "w");
+    if (!f) return R3DM_ERR_IO;
+    const uint64_t np = g->pairs.size() / 2;
+    bool ok = true;
+    if (bin) {
+        // cereal PortableBinaryOutputArchive: endianness flag, then the std::map as size + (key, value) items
+        const uint8_t le = 1;
+        ok &= fwrite(&le, 1, 1, f) == 1;
+        ok &= fwrite(&np, 8, 1, f) == 1;
+        for (uint64_t p = 0; p < np && ok; ++p) {
+            const uint64_t cnt = g->offsets[p + 1] - g->offsets[p];
+            ok &= fwrite(&g->pairs[2 * p], 4, 2, f) == 2;
+            ok &= fwrite(&cnt, 8, 1, f) == 1;
+            ok &= fwrite(g->matches.data() + g->offsets[p], sizeof(r3dm_match), cnt, f) == cnt;
+        }
+    } else {
+        std::string buf;
+        buf.reserve(1 << 20);
+        char tmp[64];
+        for (uint64_t p = 0; p < np && ok; ++p) {
+            const uint64_t cnt = g->offsets[p + 1] - g->offsets[p];
+            int len = snprintf(tmp, sizeof(tmp), "%u %u\n%llu\n", g->pairs[2 * p], g->pairs[2 * p + 1], (unsigned long long)cnt);
+            buf.append(tmp, len);
+            for (uint64_t k = g->offsets[p]; k < g->offsets[p + 1]; ++k) {
+                len = snprintf(tmp, sizeof(tmp), "%u %u\n", g->matches[k].i, g->matches[k].j);
+                buf.append(tmp, len);
+            }
+            if (buf.size() > (1 << 20) - 4096) { ok &= fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
+        }
+        if (ok && !buf.empty()) ok &= fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    }
+    ok &= (fclose(f) == 0);
+    return ok ? R3DM_OK : R3DM_ERR_IO;
+}
+
+extern "C" int r3dm_load_matches(const char* path, r3dm_graph** out)
+{
+    if (!path || !out) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    const bool bin = has_ext(path, ".bin");
+    if (!bin && !has_ext(path, ".txt")) return R3DM_ERR_INVALID;
+    FILE* f = fopen(path, bin ? "rb" : "r");
+    if (!f) return R3DM_ERR_IO;
+    std::vector<uint32_t> pairs;
+    std::vector<uint64_t> offs{0};
+    std::vector<r3dm_match> m;
+    bool ok = true;
+    if (bin) {
+        uint8_t le = 0; uint64_t np = 0;
+        ok = fread(&le, 1, 1, f) == 1 && le == 1 && fread(&np, 8, 1, f) == 1;
+        for (uint64_t p = 0; p < np && ok; ++p) {
+            uint32_t ij[2]; uint64_t cnt = 0;
+            ok = fread(ij, 4, 2, f) == 2 && fread(&cnt, 8, 1, f) == 1 && cnt < (1ull << 32);
+            if (!ok) break;
+            const size_t at = m.size();
+            m.resize(at + cnt);
+            ok = fread(m.data() + at, sizeof(r3dm_match), cnt, f) == cnt;
+            pairs.push_back(ij[0]); pairs.push_back(ij[1]); offs.push_back(m.size());
+        }
+    } else {
+        unsigned I, J; unsigned long long cnt;
+        while (fscanf(f, "%u %u %llu", &I, &J, &cnt) == 3) {
+            for (unsigned long long k = 0; k < cnt; ++k) {
+                unsigned a, b;
+                if (fscanf(f, "%u %u", &a, &b) != 2) { ok = false; break; }
+                m.push_back({a, b});
+            }
+            if (!ok) break;
+            pairs.push_back(I); pairs.push_back(J); offs.push_back(m.size());
+        }
+    }
+    fclose(f);
+    if (!ok) return R3DM_ERR_IO;
+    return r3dm_graph_from_csr(pairs.data(), pairs.size() / 2, offs.data(), m.data(), out);
+}

@@ -1,0 +1,113 @@
+// r3dm_internal.hpp -- structures shared by the host library (r3dm_api.cpp) and the HIP kernels
+// (kernels_*.hip).  Not part of the public ABI (include/r3dm.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/r3dm.h"
+
+namespace r3dm {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;       // "no match" / invalid row
+constexpr uint32_t kTileRows = 32;            // rows per MFMA tile (32x32x2 f32)
+constexpr uint32_t kSlackBytes = 32768;       // zero slack behind every tiled / norm array (prefetch runs past the end)
+
+// One registered view, resident in HBM.  Layouts (DESIGN.md "Data layout in HBM"):
+//   rows  : row-major f32 [n][dim]            -- exact re-scoring in the reference's summation order
+//   tiled : [n_tiles][G][2][32][4] f32        -- MFMA fragment order: float4 (g, h, r) = row 32t+r,
+//                                                dims 8g+4h .. 8g+4h+3; one 1 KiB line per wave load
+//   norms : f32 [n_tiles*32], ||row||^2, +inf for padding rows
+//   bin   : row-major u32 [n_pad][words]      -- binary descriptors, zero padded
+struct ImgDev {
+    const float*    rows;
+    const float*    tiled;
+    const float*    norms;
+    const uint32_t* bin;
+    const float*    xy;        // [n][2] pixel coordinates or nullptr
+    const uint32_t* canon;     // position-class id per feature (smallest index with identical xy) or nullptr
+    uint32_t n;
+    uint32_t n_tiles;
+    uint32_t dim;              // floats per row (F32/U8) or bytes per row (BIN)
+    uint32_t G;                // dim padded to 8, / 8   (F32/U8)
+    uint32_t words;            // u32 words per row (BIN)
+    uint32_t width, height;
+    uint32_t max_norm_bits;    // float bits of max ||row||^2 (filled by the staging kernel)
+};
+
+struct MatchParams {
+    const ImgDev* imgs;
+    const uint2*  pairs;          // slot indices (I, J)
+    uint32_t      n_pairs;
+    uint32_t      qb_per_pair;    // workgroups per pair
+    uint32_t      q_stride;       // entries per pair in nn_idx / knn_* (>= max n_J)
+    float         ratio_R;        // ratio^2 (squared metric) or ratio
+    float         err_scale;      // certification slack factor: 8 * Dpad * 2^-24
+    uint32_t*     nn_idx;         // [n_pairs][q_stride] matched I row, kNone, or kFallback
+    int32_t*      knn_idx;        // optional [n_pairs][q_stride][2]
+    float*        knn_dist;       // optional [n_pairs][q_stride][2]
+    uint2*        fb_items;       // (pair, q) needing the exact scan
+    uint32_t*     fb_count;
+    uint32_t      fb_cap;
+};
+constexpr uint32_t kFallback = 0xFFFFFFFEu;
+
+struct FinalizeParams {
+    const ImgDev* imgs;
+    const uint2*  pairs;
+    uint32_t      n_pairs;
+    uint32_t      q_stride;
+    const uint32_t* nn_idx;
+    uint32_t      sort_cap;       // power of two >= q_stride (LDS keys)
+    r3dm_match*   out;            // compacted matches
+    uint64_t      out_cap;
+    unsigned long long* total;    // running total (atomic)
+    uint64_t*     pair_off;       // [n_pairs]
+    uint32_t*     pair_cnt;       // [n_pairs]
+};
+
+struct FilterParams {
+    const ImgDev* imgs;
+    const uint2*  pairs;          // slot indices, one per work item
+    const uint2*  pair_ids;       // view ids (I, J): keys of the sample stream
+    const uint64_t* offsets;      // per work item: [2k] = begin, [2k+1] = end of its putative list inside `matches`
+    const r3dm_match* matches;
+    uint32_t      n_items;
+    uint32_t      m_cap;          // power of two >= max m (LDS sort capacity)
+    double        precision_px;
+    uint32_t      max_iter;
+    uint64_t      seed;
+    int           err_kind;
+    const float*  log10_tab;      // log10f(k), k = 0..max_m  (host-computed: same libm as the reference build)
+    const float*  logc_k;         // logcombi(7, n), n = 0..max_m (host-computed)
+    // outputs
+    uint32_t*     inl_count;      // [n_items] inliers kept (0 if rejected)
+    uint32_t*     inl_idx;        // [sum m] inlier positions into the pair's putative list, AC-RANSAC order
+    double*       F_out;          // [n_items][9]
+    double*       thr_nfa;        // [n_items][2]  threshold px, nfa
+    uint32_t*     iters;          // [n_items][2]  iterations, models
+    // scratch (global memory, sliced per item by its `begin` offset)
+    double*       pts_scratch;    // [n_matches][4] normalised (x1, y1, x2, y2)
+    uint32_t*     pool_scratch;   // [n_matches]    current sampling pool
+    float*        scratch_logc;   // [n_matches + n_items + 1] logcombi(k, m) table of each item
+    // debug trace (R3DM_TRACE_PAIR): rows of (iter, model, #<=bound, NFA, improved) for one item
+    double*       trace;
+    uint32_t      trace_item, trace_cap, trace_iter;
+    uint32_t*     trace_rows;
+};
+
+// ---- launchers implemented in the .hip files (host side) ----
+hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
+                            float* rows, float* tiled, float* norms, uint32_t G, uint32_t n_tiles,
+                            uint32_t* max_norm_bits_dev);
+hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint32_t nbytes,
+                            uint32_t* bin, uint32_t words, uint32_t n_pad);
+// returns hipErrorInvalidValue when (G, dtype) has no tensor kernel; caller falls back to the exact scan
+hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
+hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t count, int scan_all);
+hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_n);
+hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
+hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
+size_t     filter_F_lds_bytes(uint32_t m_cap);
+
+}  // namespace r3dm

@@ -1,0 +1,206 @@
+"""Deterministic synthetic multi-view scenes for the compute-matches hot path.
+
+BASELINE.json's configs are synthetic workloads of the reference's operator family (the reference
+ships no data).  The generator builds a scene in which the F-matrix filter
+has real work to do:
+
+  * a long relief "wall" of world points ordered along X; image i observes the window
+    [i*s, i*s + Wd) of world points (Wd = 0.6 n, s = Wd/4), so images 1/2/3 steps apart share
+    45 % / 30 % / 15 % of their features and images >= 4 steps apart share none
+    (~3 % of the exhaustive pairs of a 200-image set carry true correspondences);
+  * the remaining 0.4 n features of every image are distractors (uniform positions, independent
+    descriptors);
+  * cameras translate along the wall with a small random rotation; keypoints are pinhole
+    projections (f = 1.2 W, 4000 x 3000) + N(0, 0.5 px); 15 % of the observations get a uniformly
+    random position instead (descriptor matches, geometry does not -> RANSAC outliers);
+  * descriptors: "sift" = 128 gamma(0.5) bins, L2-normalised, x512, clipped to 255, observation noise
+    N(0, 6), rounded to integers (stored f32 or u8); "liop" = the same without rounding,
+    re-normalised to unit length, 144-D f32 (the reference's live descriptor, LIOP,
+    /root/reference/src/Regard3DFeatures.h:44,48); "akaze" = 486 random bits, 8 % flips per
+    observation, packed LSB-first into 61 bytes and zero-padded to 64
+    (/root/reference/src/thirdparty/fast-akaze/AKAZEFeatures.cpp:1069-1072).
+
+Everything is numpy default_rng streams keyed by (seed, image) so any rank can regenerate any image.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+WIDTH, HEIGHT = 4000, 3000
+
+
+@dataclass
+class Scene:
+    kind: str
+    dim: int                      # floats (sift/liop) or bytes (akaze, 64 incl. padding)
+    descs: List[np.ndarray]       # [n, dim] float32 / uint8
+    xys: List[np.ndarray]         # [n, 2] float32 pixel coordinates
+    world_ids: List[np.ndarray]   # [n] int64, -1 for distractors
+    widths: np.ndarray = field(default=None)
+    heights: np.ndarray = field(default=None)
+
+    @property
+    def n_images(self) -> int:
+        return len(self.descs)
+
+    def exhaustive_pairs(self) -> np.ndarray:
+        """openMVG exhaustivePairs(N): all (I, J), I < J, in (I, J) order
+        (/root/reference/src/R3DComputeMatches.cpp:2042)."""
+        n = self.n_images
+        i, j = np.triu_indices(n, k=1)
+        return np.stack([i, j], axis=1).astype(np.uint32)
+
+
+def _sift_from_base(base: np.ndarray, rng, sigma: float, integer: bool) -> np.ndarray:
+    d = base + sigma * rng.standard_normal(base.shape, dtype=np.float32)
+    np.clip(d, 0.0, 255.0, out=d)
+    if integer:
+        np.rint(d, out=d)
+    return d
+
+
+def _sift_base(rng, n: int, dim: int) -> np.ndarray:
+    g = rng.standard_gamma(0.5, size=(n, dim)).astype(np.float32)
+    g /= np.maximum(np.linalg.norm(g, axis=1, keepdims=True), 1e-12)
+    g *= 512.0
+    np.clip(g, 0.0, 255.0, out=g)
+    return g
+
+
+def make_scene(n_images: int, n_feat: int, kind: str = "sift", seed: int = 2002,
+               dtype: str = "f32", outlier_frac: float = 0.15, dim: int | None = None) -> Scene:
+    assert kind in ("sift", "liop", "akaze")
+    if dim is None:
+        dim = {"sift": 128, "liop": 144, "akaze": 64}[kind]
+    n_shared = int(round(0.6 * n_feat))
+    step = max(n_shared // 4, 1)
+    n_world = (n_images - 1) * step + n_shared
+
+    rw = np.random.default_rng([seed, 0x57])
+    # world geometry: wall along X with relief in Z
+    f = 1.2 * WIDTH
+    Z0 = 10.0
+    win_width = 0.8 * WIDTH * Z0 / f              # world-space width of one window
+    delta = win_width / n_shared
+    wx = (np.arange(n_world) + rw.uniform(-0.3, 0.3, n_world)) * delta
+    wy = rw.uniform(-0.4 * HEIGHT * Z0 / f, 0.4 * HEIGHT * Z0 / f, n_world)
+    wz = Z0 * rw.uniform(0.75, 1.25, n_world)
+    # world appearance
+    if kind == "akaze":
+        wbits = rw.integers(0, 2, size=(n_world, 486), dtype=np.uint8)
+    else:
+        wbase = _sift_base(rw, n_world, dim)
+
+    descs, xys, wids = [], [], []
+    for i in range(n_images):
+        r = np.random.default_rng([seed, 0x1A6E, i])
+        lo = i * step
+        ids = np.arange(lo, lo + n_shared)
+        n_dis = n_feat - n_shared
+        # camera: centre above the window, small yaw/pitch/roll
+        cx = (lo + 0.5 * n_shared) * delta
+        ang = r.normal(0.0, 0.02, 3)
+        ca, sa = np.cos(ang), np.sin(ang)
+        Rx = np.array([[1, 0, 0], [0, ca[0], -sa[0]], [0, sa[0], ca[0]]])
+        Ry = np.array([[ca[1], 0, sa[1]], [0, 1, 0], [-sa[1], 0, ca[1]]])
+        Rz = np.array([[ca[2], -sa[2], 0], [sa[2], ca[2], 0], [0, 0, 1]])
+        R = Rz @ Ry @ Rx
+        P = np.stack([wx[ids] - cx, wy[ids], wz[ids]], axis=1) @ R.T
+        u = f * P[:, 0] / P[:, 2] + 0.5 * WIDTH + r.normal(0.0, 0.5, n_shared)
+        v = f * P[:, 1] / P[:, 2] + 0.5 * HEIGHT + r.normal(0.0, 0.5, n_shared)
+        bad = r.random(n_shared) < outlier_frac
+        u[bad] = r.uniform(0, WIDTH, int(bad.sum()))
+        v[bad] = r.uniform(0, HEIGHT, int(bad.sum()))
+        xy = np.empty((n_feat, 2), np.float32)
+        xy[:n_shared, 0] = u; xy[:n_shared, 1] = v
+        xy[n_shared:, 0] = r.uniform(0, WIDTH, n_dis); xy[n_shared:, 1] = r.uniform(0, HEIGHT, n_dis)
+
+        if kind == "akaze":
+            bits = np.empty((n_feat, 486), np.uint8)
+            flips = (r.random((n_shared, 486)) < 0.08).astype(np.uint8)
+            bits[:n_shared] = wbits[ids] ^ flips
+            bits[n_shared:] = r.integers(0, 2, size=(n_dis, 486), dtype=np.uint8)
+            padded = np.zeros((n_feat, 488), np.uint8); padded[:, :486] = bits
+            packed = np.packbits(padded, axis=1, bitorder="little")          # 61 bytes, LSB first
+            d = np.zeros((n_feat, dim), np.uint8); d[:, :61] = packed
+        else:
+            integer = (kind == "sift")
+            sigma = 6.0
+            d = np.empty((n_feat, dim), np.float32)
+            d[:n_shared] = _sift_from_base(wbase[ids], r, sigma, integer)
+            d[n_shared:] = _sift_from_base(_sift_base(r, n_dis, dim), r, sigma, integer)
+            if kind == "liop":
+                d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12)
+            if dtype == "u8":
+                assert integer
+                d = d.astype(np.uint8)
+        wid = np.concatenate([ids, -np.ones(n_dis, np.int64)])
+        perm = r.permutation(n_feat)
+        descs.append(np.ascontiguousarray(d[perm])); xys.append(np.ascontiguousarray(xy[perm])); wids.append(wid[perm])
+
+    return Scene(kind=kind, dim=dim, descs=descs, xys=xys, world_ids=wids,
+                 widths=np.full(n_images, WIDTH, np.uint32), heights=np.full(n_images, HEIGHT, np.uint32))
+
+
+def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda", dim: int = 128,
+                     outlier_frac: float = 0.15):
+    """The "sift" scene of make_scene(), sampled with torch's device RNG so that bench.py can build
+    the 200 x 8192 x 128 workload (and its weak-scaling siblings) in about a second, directly in HBM.
+    Every rank that calls it with the same seed on the same GPU model gets the same tensors.
+    Returns (descs [N, n, dim] f32, xys [N, n, 2] f32, world_ids [N, n] int64) on `device`."""
+    import torch
+
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    n_shared = int(round(0.6 * n_feat)); step = max(n_shared // 4, 1)
+    n_world = (n_images - 1) * step + n_shared
+    n_dis = n_feat - n_shared
+    f = 1.2 * WIDTH; Z0 = 10.0
+    delta = (0.8 * WIDTH * Z0 / f) / n_shared
+    U = lambda *s: torch.rand(*s, generator=g, device=device, dtype=torch.float64)
+    Nn = lambda *s: torch.randn(*s, generator=g, device=device, dtype=torch.float64)
+    wx = (torch.arange(n_world, device=device, dtype=torch.float64) + (U(n_world) * 0.6 - 0.3)) * delta
+    wy = (U(n_world) * 2 - 1) * (0.4 * HEIGHT * Z0 / f)
+    wz = Z0 * (0.75 + 0.5 * U(n_world))
+
+    def sift_base(n):
+        gam = torch.distributions.Gamma(torch.tensor(0.5, device=device), torch.tensor(1.0, device=device))
+        # torch's gamma sampler has no generator argument: derive it from the seeded global state instead
+        b = torch._standard_gamma(torch.full((n, dim), 0.5, device=device, dtype=torch.float32))
+        b = b / b.norm(dim=1, keepdim=True).clamp_min(1e-12) * 512.0
+        return b.clamp_(0.0, 255.0)
+
+    torch.manual_seed(seed); torch.cuda.manual_seed(seed) if str(device).startswith("cuda") else None
+    wbase = sift_base(n_world)
+    descs = torch.empty((n_images, n_feat, dim), device=device, dtype=torch.float32)
+    xys = torch.empty((n_images, n_feat, 2), device=device, dtype=torch.float32)
+    wids = torch.full((n_images, n_feat), -1, device=device, dtype=torch.int64)
+    for i in range(n_images):
+        lo = i * step
+        ids = torch.arange(lo, lo + n_shared, device=device)
+        cx = (lo + 0.5 * n_shared) * delta
+        ang = (Nn(3) * 0.02).tolist()
+        ca, sa = [np.cos(a) for a in ang], [np.sin(a) for a in ang]
+        Rx = np.array([[1, 0, 0], [0, ca[0], -sa[0]], [0, sa[0], ca[0]]])
+        Ry = np.array([[ca[1], 0, sa[1]], [0, 1, 0], [-sa[1], 0, ca[1]]])
+        Rz = np.array([[ca[2], -sa[2], 0], [sa[2], ca[2], 0], [0, 0, 1]])
+        R = torch.tensor(Rz @ Ry @ Rx, device=device, dtype=torch.float64)
+        Pc = torch.stack([wx[ids] - cx, wy[ids], wz[ids]], dim=1) @ R.T
+        u = f * Pc[:, 0] / Pc[:, 2] + 0.5 * WIDTH + 0.5 * Nn(n_shared)
+        v = f * Pc[:, 1] / Pc[:, 2] + 0.5 * HEIGHT + 0.5 * Nn(n_shared)
+        bad = U(n_shared) < outlier_frac
+        u = torch.where(bad, U(n_shared) * WIDTH, u); v = torch.where(bad, U(n_shared) * HEIGHT, v)
+        xy = torch.empty((n_feat, 2), device=device, dtype=torch.float64)
+        xy[:n_shared, 0] = u; xy[:n_shared, 1] = v
+        xy[n_shared:, 0] = U(n_dis) * WIDTH; xy[n_shared:, 1] = U(n_dis) * HEIGHT
+        d = torch.empty((n_feat, dim), device=device, dtype=torch.float32)
+        d[:n_shared] = wbase[ids]; d[n_shared:] = sift_base(n_dis)
+        d += 6.0 * torch.randn((n_feat, dim), generator=g, device=device, dtype=torch.float32)
+        d.clamp_(0.0, 255.0).round_()
+        perm = torch.randperm(n_feat, generator=g, device=device)
+        descs[i] = d[perm]; xys[i] = xy[perm].float()
+        w = torch.full((n_feat,), -1, device=device, dtype=torch.int64); w[:n_shared] = ids
+        wids[i] = w[perm]
+    return descs, xys, wids

@@ -1,0 +1,43 @@
+"""Quick GPU performance probe (not the bench contract): match + filter on a synthetic scene."""
+import argparse, json, sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from regard3d_amd import api, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--images", type=int, default=24)
+ap.add_argument("--feat", type=int, default=8192)
+ap.add_argument("--kind", default="sift")
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--check", type=int, default=0, help="verify this many pairs against the oracle")
+a = ap.parse_args()
+
+t = time.time(); sc = synth.make_scene(a.images, a.feat, a.kind, seed=2002); print("gen %.1fs" % (time.time() - t), flush=True)
+c = api.Context(0)
+print(c.device_info())
+binary = a.kind == "akaze"
+t = time.time()
+for i in range(sc.n_images):
+    c.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000, binary=binary)
+print("set_image %.2fs" % (time.time() - t), flush=True)
+pairs = sc.exhaustive_pairs()
+ratio, sq = (0.8, False) if binary else (0.6, True)
+for rep in range(a.reps):
+    t = time.time(); g = c.match_pairs(pairs, ratio, sq); tm = time.time() - t
+    s = c.stats()
+    t = time.time(); gf = c.filter_F(g); tf = time.time() - t
+    s2 = c.stats()
+    print(json.dumps(dict(rep=rep, pairs=len(pairs), t_match=tm, t_filter=tf, pairs_per_s=len(pairs) / (tm + tf),
+                          ms_kernel=s.ms_match_kernels, tflops=s.algorithmic_flops / (s.ms_match_kernels * 1e-3) / 1e12,
+                          fallback=s.n_exact_fallback, queries=s.n_queries, put_pairs=g.num_pairs, put_matches=g.num_matches,
+                          f_pairs=gf.num_pairs, f_matches=gf.num_matches, ms_filter_kernel=s2.ms_filter_kernels)), flush=True)
+if a.check:
+    from oracle import pyoracle as O
+    sub = pairs[: a.check]
+    t = time.time(); counts, matches = O.match_collection(sc.descs, sc.xys, sub, ratio, sq, binary=binary); print("oracle %.1fs" % (time.time() - t))
+    d = g.as_dict(); off = 0; bad = 0
+    for p, (I, J) in enumerate(sub):
+        exp = matches[off:off + counts[p]]; off += counts[p]
+        got = d.get((int(I), int(J)), np.zeros((0, 2), np.uint32))
+        if not np.array_equal(got, exp): bad += 1
+    print("checked", len(sub), "pairs, mismatching:", bad)
