@@ -52,8 +52,8 @@ struct View {
     std::string basename;                      // <matches dir>/<basename>.feat|.desc
 };
 
-using IndMatches = std::vector<r3dm_match>;
-using PairWiseMatches = std::map<std::pair<uint32_t, uint32_t>, IndMatches>;
+using MatchList = std::vector<r3dm_match>;          // IndMatches (IndMatch{i_, j_} == r3dm_match{i, j})
+using PairWiseMatches = std::map<std::pair<uint32_t, uint32_t>, MatchList>;
 
 class R3DComputeMatches {
 public:

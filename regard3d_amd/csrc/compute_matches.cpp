@@ -46,7 +46,7 @@ void graph_to_map(const r3dm_graph* g, PairWiseMatches& out)
     const uint64_t* o = r3dm_graph_offsets(g);
     const r3dm_match* m = r3dm_graph_matches(g);
     for (uint64_t k = 0; k < np; ++k)
-        out.emplace(std::make_pair(p[2 * k], p[2 * k + 1]), IndMatches(m + o[k], m + o[k + 1]));
+        out.emplace(std::make_pair(p[2 * k], p[2 * k + 1]), MatchList(m + o[k], m + o[k + 1]));
 }
 
 std::string with_ext(const std::string& path, const char* ext)

@@ -10,7 +10,7 @@ padded payload) over torch.distributed -- backend "nccl" is RCCL over xGMI on th
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -48,16 +48,19 @@ def _unpack(buf: np.ndarray) -> api.Graph:
     return api.Graph.from_csr(p, o, m)
 
 
-def all_gather_graph(local: api.Graph, device=None, group=None) -> api.Graph:
-    """Every rank ends up with the union of all ranks' graphs, ordered by (I, J)."""
+def all_gather_graphs(local: Sequence[api.Graph], device=None, group=None) -> List[api.Graph]:
+    """ONE exchange step for several graphs of this rank (e.g. putative + F-filtered): every rank ends
+    up with the union over ranks of each graph, ordered by (I, J)."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
+        return list(local)
     world = dist.get_world_size(group)
     dev = torch.device(device) if device is not None else torch.device("cpu")
-    payload = torch.from_numpy(_pack(local)).to(dev)
+    packs = [_pack(g) for g in local]
+    head = np.array([len(packs)] + [p.size for p in packs], np.int64)
+    payload = torch.from_numpy(np.concatenate([head] + packs)).to(dev)
     n = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)                       # 8 bytes per rank
@@ -65,8 +68,15 @@ def all_gather_graph(local: api.Graph, device=None, group=None) -> api.Graph:
     padded = torch.zeros(mx, dtype=torch.int64, device=dev)
     padded[:payload.numel()] = payload
     bufs = [torch.empty(mx, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)                   # the one payload exchange
-    parts: List[api.Graph] = []
+    dist.all_gather(bufs, padded, group=group)                   # the one payload exchange (RCCL over xGMI)
+    per_graph: List[List[api.Graph]] = [[] for _ in local]
     for r in range(world):
-        parts.append(_unpack(bufs[r][: int(sizes[r].item())].cpu().numpy()))
-    return api.Graph.merge(parts)
+        buf = bufs[r][: int(sizes[r].item())].cpu().numpy()
+        k = int(buf[0]); lens = buf[1:1 + k]; at = 1 + k
+        for gi in range(k):
+            per_graph[gi].append(_unpack(buf[at:at + int(lens[gi])])); at += int(lens[gi])
+    return [api.Graph.merge(parts) for parts in per_graph]
+
+
+def all_gather_graph(local: api.Graph, device=None, group=None) -> api.Graph:
+    return all_gather_graphs([local], device=device, group=group)[0]

@@ -1,0 +1,119 @@
+"""CPU-side checks: on-disk formats (oracle writer vs library writer/reader), the C-ABI surface of
+libr3dm.so (every symbol include/*.h declares is exported; no compute without a GPU), host-only
+graph utilities, and the "fails loudly without a GPU" rule.  No GPU needed.
+"""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PAIRS = np.array([[0, 1], [0, 3], [2, 5]], np.uint32)
+COUNTS = np.array([2, 0, 3], np.uint32)
+MATCHES = np.array([[4, 7], [9, 1], [0, 0], [5, 6], [8, 2]], np.uint32)
+
+GOLDEN_TXT = "0 1\n2\n4 7\n9 1\n2 5\n3\n0 0\n5 6\n8 2\n"
+# cereal PortableBinaryOutputArchive of std::map<pair<u32,u32>, vector<IndMatch>>:
+# endianness flag, u64 map size, then (u32 I, u32 J, u64 count, count x (u32 i, u32 j)) per entry
+GOLDEN_BIN = (b"\x01" + struct.pack("<Q", 2)
+              + struct.pack("<IIQ", 0, 1, 2) + struct.pack("<IIII", 4, 7, 9, 1)
+              + struct.pack("<IIQ", 2, 5, 3) + struct.pack("<IIIIII", 0, 0, 5, 6, 8, 2))
+
+
+def test_oracle_txt_bin_golden(oracle, tmp_path):
+    t = str(tmp_path / "matches.putative.txt"); b = str(tmp_path / "matches.putative.bin")
+    oracle.save_matches(t, PAIRS, COUNTS, MATCHES)
+    oracle.save_matches(b, PAIRS, COUNTS, MATCHES)
+    assert open(t).read() == GOLDEN_TXT                      # empty pair (0,3) never enters the map
+    assert open(b, "rb").read() == GOLDEN_BIN
+    for path in (t, b):
+        p, c, m = oracle.load_matches(path)
+        assert p.tolist() == [[0, 1], [2, 5]] and c.tolist() == [2, 3] and np.array_equal(m, MATCHES)
+
+
+def test_library_writer_reader_match_the_goldens(tmp_path):
+    from regard3d_amd import api
+    offs = np.concatenate([[0], np.cumsum(COUNTS)]).astype(np.uint64)
+    g = api.Graph.from_csr(PAIRS, offs, MATCHES)
+    assert g.num_pairs == 2 and g.num_matches == 5            # from_csr drops the empty entry
+    t = str(tmp_path / "matches.f.txt"); b = str(tmp_path / "matches.f.bin")
+    g.save(t); g.save(b)
+    assert open(t).read() == GOLDEN_TXT
+    assert open(b, "rb").read() == GOLDEN_BIN
+    for path in (t, b):
+        g2 = api.Graph.load(path)
+        assert g2.pairs.tolist() == [[0, 1], [2, 5]] and np.array_equal(g2.matches, MATCHES)
+    with pytest.raises(api.R3dmError):
+        g.save(str(tmp_path / "matches.xyz"))                 # Save() dispatches on the extension
+    with pytest.raises(api.R3dmError):
+        api.Graph.load(str(tmp_path / "missing.txt"))
+
+
+def test_graph_from_csr_orders_pairs_and_merge():
+    from regard3d_amd import api
+    a = api.Graph.from_csr(np.array([[2, 5], [0, 1]], np.uint32), np.array([0, 3, 5], np.uint64),
+                           np.array([[0, 0], [5, 6], [8, 2], [4, 7], [9, 1]], np.uint32))
+    assert a.pairs.tolist() == [[0, 1], [2, 5]] and a.matches.tolist() == MATCHES.tolist()
+    b = api.Graph.from_csr(np.array([[1, 4]], np.uint32), np.array([0, 1], np.uint64), np.array([[3, 3]], np.uint32))
+    m = api.Graph.merge([b, a])
+    assert m.pairs.tolist() == [[0, 1], [1, 4], [2, 5]]
+    assert m.as_dict()[(1, 4)].tolist() == [[3, 3]]
+    e = api.Graph.merge([])
+    assert e.num_pairs == 0 and e.num_matches == 0
+
+
+def test_desc_and_feat_formats(oracle, tmp_path):
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=(5, 144)).astype(np.float32)
+    p = str(tmp_path / "img.desc")
+    assert oracle.lib().orc_save_desc(p.encode(), ctypes.c_uint64(5), ctypes.c_size_t(144 * 4), d.ctypes.data_as(ctypes.c_void_p)) == 0
+    raw = open(p, "rb").read()
+    assert len(raw) == 8 + 5 * 144 * 4 and struct.unpack("<Q", raw[:8])[0] == 5      # 8-byte count header
+    assert np.array_equal(np.frombuffer(raw[8:], np.float32).reshape(5, 144), d)
+    f = str(tmp_path / "img.feat")
+    xyso = np.array([[1.5, 2.25, 3.0, 0.5], [100.125, 7.0, 1.0, -1.0]], np.float32)
+    assert oracle.lib().orc_save_feat(f.encode(), 2, xyso.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert open(f).read() == "1.5 2.25 3 0.5\n100.125 7 1 -1\n"
+
+
+def _declared_symbols():
+    names = set()
+    for hdr in os.listdir(os.path.join(ROOT, "include")):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"//.*", "", txt)
+        names |= set(re.findall(r"\b(r3dm_[A-Za-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from regard3d_amd import api
+    L = api.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, f"libr3dm.so lacks: {missing}"
+    assert set(api.EXPORTS) <= declared
+
+
+def test_no_cpu_fallback_without_gpu():
+    """r3dm_create must fail (not silently degrade) when no gfx950 GPU is visible."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from regard3d_amd import api
+    with pytest.raises(api.R3dmError):
+        api.Context(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "regard3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "r3d_oracle.h" not in txt, fn

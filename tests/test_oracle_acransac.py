@@ -140,7 +140,16 @@ def test_acransac_known_scene(oracle):
     assert len(inl - set(range(200))) <= 0.02 * 200 + 2       # <= ~2 % outliers slip in
     assert 0 < fr.threshold < 4.0
     F = np.array(fr.F).reshape(3, 3); F /= np.linalg.norm(F); Ft = Ft / np.linalg.norm(Ft)
-    assert min(np.linalg.norm(F - Ft), np.linalg.norm(F + Ft)) < 1e-2
+    # AC-RANSAC returns the best MINIMAL-sample model (no refit): close to the truth in Frobenius terms
+    # and as good as the true F on the true inliers (median symmetric epipolar distance, pixels)
+    assert min(np.linalg.norm(F - Ft), np.linalg.norm(F + Ft)) < 0.1
+
+    def med_err(Fm):
+        a = np.c_[x1[:200], np.ones(200)]; b = np.c_[x2[:200], np.ones(200)]
+        Fa = a @ Fm.T; Fb = b @ Fm
+        num = np.sum(b * Fa, 1) ** 2
+        return np.median(np.sqrt(num * (1 / (Fa[:, 0] ** 2 + Fa[:, 1] ** 2) + 1 / (Fb[:, 0] ** 2 + Fb[:, 1] ** 2)) / 4))
+    assert med_err(F) < 2.0 * med_err(Ft) + 0.1
     assert fr.nfa < 0 and fr.n_iter <= 2048 + 204
 
 
