@@ -44,7 +44,7 @@ void stage_rows_kernel(const void* __restrict__ raw, int raw_is_u8, uint32_t n, 
 // one workgroup per 32-row tile
 __global__ __launch_bounds__(256)
 void stage_tiles_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim, uint32_t G,
-                        float* __restrict__ tiled, float* __restrict__ norms, uint32_t* __restrict__ max_norm_bits)
+                        float* __restrict__ tiled, float* __restrict__ norms, uint32_t* __restrict__ img_stats)
 {
     const uint32_t t = blockIdx.x;
     const uint32_t per_tile = G * 256;                 // floats per tile = G * 2 * 32 * 4
@@ -60,8 +60,17 @@ void stage_tiles_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim
         if (row < n) {
             s = 0.0f;
             const float* p = rows + (size_t)row * dim;
-            for (uint32_t k = 0; k < dim; ++k) s = fmaf(p[k], p[k], s);
-            atomicMax(max_norm_bits, __float_as_uint(s));   // s >= 0: float order == uint order
+            float mx = 0.0f; bool nonint = false;
+            for (uint32_t k = 0; k < dim; ++k) {
+                const float v = p[k];
+                s = fmaf(v, v, s);
+                mx = fmaxf(mx, fabsf(v));
+                nonint |= !(v == rintf(v));                  // also true for NaN
+            }
+            // img_stats = &ImgDev::max_norm_bits, max_abs_bits, not_integer (non-negative floats order like uints)
+            atomicMax(img_stats + 0, __float_as_uint(s));
+            atomicMax(img_stats + 1, __float_as_uint(mx));
+            if (nonint) atomicOr(img_stats + 2, 1u);
         }
         norms[(size_t)t * 32 + threadIdx.x] = s;
     }
@@ -86,13 +95,13 @@ void stage_bin_kernel(const uint8_t* __restrict__ raw, uint32_t n, uint32_t nbyt
 
 hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
                             float* rows, float* tiled, float* norms, uint32_t G, uint32_t n_tiles,
-                            uint32_t* max_norm_bits_dev)
+                            uint32_t* img_stats_dev)
 {
     if (n == 0) return hipSuccess;
     const size_t total = (size_t)n * dim;
     uint32_t grid = (uint32_t)((total + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(stage_rows_kernel, dim3(grid), dim3(256), 0, st, raw, raw_is_u8, n, dim, rows);
-    hipLaunchKernelGGL(stage_tiles_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, G, tiled, norms, max_norm_bits_dev);
+    hipLaunchKernelGGL(stage_tiles_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, G, tiled, norms, img_stats_dev);
     return hipGetLastError();
 }
 
@@ -262,6 +271,14 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     // ---- per query: merge the two lane halves, re-score exactly, certify, ratio-test
     const float maxnorm = __uint_as_float(Ip->max_norm_bits);
     const uint32_t dim = Ip->dim;
+    // Exactness proof for integer-valued descriptors (e.g. SIFT bins 0..255): when every element of
+    // both views is an integer and all partial sums stay below 2^24, the MFMA pass (norm init, fma
+    // chain, + ||q||^2) and the reference's sum of squared differences are BOTH exact, hence equal:
+    // no rounding slack is needed and only true ties with an un-nominated row need the exact scan.
+    const float mI = __uint_as_float(Ip->max_abs_bits), mJ = __uint_as_float(Jp->max_abs_bits);
+    const float dpad = (float)(G * 8);
+    const bool exact_pair = !Ip->not_integer && !Jp->not_integer &&
+                            2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f;
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         Top2 s = st[nj];
@@ -291,14 +308,16 @@ void l2_knn2_mfma_kernel(const MatchParams P)
                 emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
             } else {
                 const float nb = Jp->norms[q];
-                const float slack = P.err_scale * (maxnorm + nb);
+                const float slack = exact_pair ? 0.0f : P.err_scale * (maxnorm + nb);
                 const bool certified = eb < (bound + nb) - slack;   // every un-nominated row is farther than eb
                 if (certified) {
                     emit_result(P, pair, q, ea, ia, eb, ib);
                 } else {
                     P.nn_idx[(size_t)pair * P.q_stride + q] = kFallback;
-                    const uint32_t pos = atomicAdd(P.fb_count, 1u);
-                    if (pos < P.fb_cap) P.fb_items[pos] = make_uint2(pair, q);
+                    const uint32_t pos = atomicAdd(P.fb_cnt + pair, 1u);
+                    atomicAdd(P.fb_total, 1u);
+                    if (pos < kFbPerPair) P.fb_q[(size_t)pair * kFbPerPair + pos] = q;
+                    else atomicAdd(P.fb_total + 1, 1u);
                 }
             }
         }
@@ -348,8 +367,7 @@ void l2_exact_items_kernel(const MatchParams P, uint32_t count, int scan_all)
     __shared__ uint32_t si0[256], si1[256];
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         uint32_t pair, q;
-        if (scan_all) { pair = it / P.q_stride; q = it % P.q_stride; }
-        else { const uint2 item = P.fb_items[it]; pair = item.x; q = item.y; }
+        pair = it / P.q_stride; q = it % P.q_stride;
         const uint2 pr = P.pairs[pair];
         const ImgDev* __restrict__ Ip = P.imgs + pr.x;
         const ImgDev* __restrict__ Jp = P.imgs + pr.y;
@@ -396,6 +414,100 @@ hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t 
     if (count == 0) return hipSuccess;
     uint32_t grid = count < 16384u ? count : 16384u;
     hipLaunchKernelGGL(l2_exact_items_kernel, dim3(grid), dim3(256), 0, st, P, count, scan_all);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact scan of the per-pair fallback lists: one workgroup per pair, lane = one uncertified query
+// (its row in registers), wave w = rows {8w .. 8w+7} of every 32-row tile of image I staged through
+// LDS (row reads are wave-uniform -> LDS broadcast).  Reference arithmetic, (distance, row) order.
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256)
+void l2_exact_batch_kernel(const MatchParams P)
+{
+    constexpr int D4 = G * 2;                        // float4 per (padded) row
+    __shared__ f32x4 tile[32 * D4];                  // 32 rows x Dpad floats
+    __shared__ float md0[256], md1[256];
+    __shared__ uint32_t mi0[256], mi1[256];
+    const uint32_t pair = blockIdx.x;
+    const uint32_t cnt_all = P.fb_cnt[pair];
+    if (cnt_all == 0) return;
+    const uint32_t cnt = cnt_all < kFbPerPair ? cnt_all : kFbPerPair;
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, dim = Ip->dim, d4 = dim >> 2;      // dim % 4 == 0 guaranteed by the launcher
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const gf4p irows = (gf4p)Ip->rows;
+    for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
+        const bool active = b0 + lane < cnt;
+        const uint32_t q = P.fb_q[(size_t)pair * kFbPerPair + (active ? b0 + lane : b0)];
+        f32x4 qv[D4];
+        const gf4p qrow = (gf4p)Jp->rows + (size_t)q * d4;
+#pragma unroll
+        for (int k = 0; k < D4; ++k) qv[k] = (k < (int)d4) ? qrow[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        float d0 = R3DM_INF, d1 = R3DM_INF; uint32_t i0 = kNone, i1 = kNone;
+        for (uint32_t t0 = 0; t0 < nI; t0 += 32) {
+            __syncthreads();
+            const uint32_t rows_here = (nI - t0 < 32u) ? nI - t0 : 32u;
+            for (uint32_t e = threadIdx.x; e < rows_here * d4; e += 256) {
+                const uint32_t r = e / d4, k = e % d4;
+                tile[r * D4 + k] = irows[(size_t)(t0 + r) * d4 + k];
+            }
+            __syncthreads();
+            for (uint32_t rr = 0; rr < 8; ++rr) {
+                const uint32_t r = wave * 8 + rr;
+                if (r >= rows_here) break;                         // wave-uniform
+                float result = 0.0f;
+#pragma unroll
+                for (int k = 0; k < D4; ++k) {
+                    if (k < (int)d4) {
+                        const f32x4 a = tile[r * D4 + k];
+                        const float e0 = a[0] - qv[k][0], e1 = a[1] - qv[k][1], e2 = a[2] - qv[k][2], e3 = a[3] - qv[k][3];
+                        result += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+                    }
+                }
+                const uint32_t row = t0 + r;
+                if (result < d0) { d1 = d0; i1 = i0; d0 = result; i0 = row; }
+                else if (result < d1) { d1 = result; i1 = row; }
+            }
+        }
+        // merge the four waves' (best, runner-up) per lane under the (distance, row) order
+        __syncthreads();
+        md0[threadIdx.x] = d0; md1[threadIdx.x] = d1; mi0[threadIdx.x] = i0; mi1[threadIdx.x] = i1;
+        __syncthreads();
+        if (wave == 0 && active) {
+            float a0 = md0[lane], a1 = md1[lane]; uint32_t x0 = mi0[lane], x1 = mi1[lane];
+            for (uint32_t w = 1; w < 4; ++w) {
+                const float b0_ = md0[w * 64 + lane], b1_ = md1[w * 64 + lane];
+                const uint32_t y0 = mi0[w * 64 + lane], y1 = mi1[w * 64 + lane];
+                float r0, r1; uint32_t j0, j1;
+                if (lex_less(b0_, y0, a0, x0)) {
+                    r0 = b0_; j0 = y0;
+                    if (lex_less(b1_, y1, a0, x0)) { r1 = b1_; j1 = y1; } else { r1 = a0; j1 = x0; }
+                } else {
+                    r0 = a0; j0 = x0;
+                    if (lex_less(b0_, y0, a1, x1)) { r1 = b0_; j1 = y0; } else { r1 = a1; j1 = x1; }
+                }
+                a0 = r0; a1 = r1; x0 = j0; x1 = j1;
+            }
+            if (nI < 2) emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
+            else emit_result(P, pair, q, a0, x0, a1, x1);
+        }
+    }
+}
+
+hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t G)
+{
+    if (P.n_pairs == 0) return hipSuccess;
+    switch (G) {
+        case 8:  hipLaunchKernelGGL((l2_exact_batch_kernel<8>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
+        case 16: hipLaunchKernelGGL((l2_exact_batch_kernel<16>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
+        case 18: hipLaunchKernelGGL((l2_exact_batch_kernel<18>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
+        case 32: hipLaunchKernelGGL((l2_exact_batch_kernel<32>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

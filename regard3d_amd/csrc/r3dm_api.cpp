@@ -197,7 +197,7 @@ static int upload_imgdev(r3dm_ctx* c, uint32_t slot)
     d.bin = h.bin.as<uint32_t>(); d.xy = h.has_xy ? h.xy.as<float>() : nullptr;
     d.canon = h.has_dup ? h.canon.as<uint32_t>() : nullptr;
     d.n = h.n; d.n_tiles = h.n_tiles; d.dim = h.dim; d.G = h.G; d.words = h.words;
-    d.width = h.width; d.height = h.height; d.max_norm_bits = 0;
+    d.width = h.width; d.height = h.height; d.max_norm_bits = 0; d.max_abs_bits = 0; d.not_integer = 0;
     R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
     return R3DM_OK;
@@ -358,8 +358,10 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
     R3DM_HIP(c, hipMemcpyAsync(c->d_pairs.p, hp.data(), sizeof(uint2) * P, hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, c->d_nn.ensure((size_t)P * q_stride * 4));
     const uint64_t total_slots = (uint64_t)P * q_stride;
-    const uint32_t fb_cap = (uint32_t)std::min<uint64_t>(total_slots, 1u << 22);
-    R3DM_HIP(c, c->d_fb.ensure((size_t)fb_cap * sizeof(uint2)));
+    // per-pair lists of uncertified queries: [fb_total(2 words) | pad][fb_cnt: P][fb_q: P x kFbPerPair]
+    const size_t fb_words = 16 + (size_t)P + (size_t)P * kFbPerPair;
+    R3DM_HIP(c, c->d_fb.ensure(fb_words * 4));
+    R3DM_HIP(c, hipMemsetAsync(c->d_fb.p, 0, (16 + (size_t)P) * 4, c->stream));
     R3DM_HIP(c, c->d_cnt.ensure(64));
     R3DM_HIP(c, hipMemsetAsync(c->d_cnt.p, 0, 64, c->stream));
     if (knn_idx_host) {
@@ -372,13 +374,15 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
     mp.pairs = c->d_pairs.as<uint2>();
     mp.n_pairs = P; mp.qb_per_pair = 0; mp.q_stride = q_stride;
     mp.ratio_R = ratio_R;
-    mp.err_scale = 8.0f * (float)(first.G * 8) * 5.9604645e-08f;
+    // certification slack factor: |MFMA-path distance - reference distance| <= (3.5 D + 14) u (max||a||^2 + ||q||^2),
+    // u = 2^-24 (DESIGN.md "Certification"); 4.25 D u covers it for every padded D >= 64
+    mp.err_scale = 4.25f * (float)(first.G * 8) * 5.9604645e-08f;
     mp.nn_idx = c->d_nn.as<uint32_t>();
     mp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
     mp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
-    mp.fb_items = c->d_fb.as<uint2>();
-    mp.fb_count = c->d_cnt.as<uint32_t>();
-    mp.fb_cap = fb_cap;
+    mp.fb_total = c->d_fb.as<uint32_t>();
+    mp.fb_cnt = c->d_fb.as<uint32_t>() + 16;
+    mp.fb_q = c->d_fb.as<uint32_t>() + 16 + P;
 
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     uint64_t n_fallback = 0;
@@ -388,13 +392,15 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
     } else if (has_tensor_kernel(first.G)) {
         R3DM_HIP(c, launch_l2_knn2(c->stream, mp, first.G, max_tiles));
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
-        uint32_t fbc = 0;
-        R3DM_HIP(c, hipMemcpyAsync(&fbc, c->d_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+        uint32_t fbt[2] = {0, 0};
+        R3DM_HIP(c, hipMemcpyAsync(fbt, mp.fb_total, 8, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));
-        n_fallback = fbc;
-        if (fbc > 0) {
-            if (fbc <= fb_cap) R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, fbc, 0));
-            else {
+        n_fallback = fbt[0];
+        if (fbt[0] > 0) {
+            bool rescan = fbt[1] > 0;                      // some pair overflowed its list
+            if ((first.dim & 3u) == 0) R3DM_HIP(c, launch_l2_exact_batch(c->stream, mp, first.G));
+            else rescan = true;                            // scalar-tail dims: generic exact kernel
+            if (rescan) {
                 if (total_slots > 0xFFFFFFFFull) { c->err = "batch too large for the exact rescan"; return R3DM_ERR_UNSUPPORTED; }
                 R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, (uint32_t)total_slots, 2));
             }

@@ -33,6 +33,8 @@ struct ImgDev {
     uint32_t words;            // u32 words per row (BIN)
     uint32_t width, height;
     uint32_t max_norm_bits;    // float bits of max ||row||^2 (filled by the staging kernel)
+    uint32_t max_abs_bits;     // float bits of max |element|   (filled by the staging kernel)
+    uint32_t not_integer;      // != 0 if some element is not an integer (filled by the staging kernel)
 };
 
 struct MatchParams {
@@ -46,10 +48,13 @@ struct MatchParams {
     uint32_t*     nn_idx;         // [n_pairs][q_stride] matched I row, kNone, or kFallback
     int32_t*      knn_idx;        // optional [n_pairs][q_stride][2]
     float*        knn_dist;       // optional [n_pairs][q_stride][2]
-    uint2*        fb_items;       // (pair, q) needing the exact scan
-    uint32_t*     fb_count;
-    uint32_t      fb_cap;
+    // queries whose nominated pair could not be certified are redone exactly; they are collected per
+    // pair (fb_q[pair][0..kFbPerPair)) so one workgroup can stream image I once for all of them
+    uint32_t*     fb_q;           // [n_pairs][kFbPerPair] query rows
+    uint32_t*     fb_cnt;         // [n_pairs] number collected (may exceed kFbPerPair: overflow -> global rescan)
+    uint32_t*     fb_total;       // [2]: total uncertified queries, number that overflowed their pair's list
 };
+constexpr uint32_t kFbPerPair = 128;
 constexpr uint32_t kFallback = 0xFFFFFFFEu;
 
 struct FinalizeParams {
@@ -99,12 +104,14 @@ struct FilterParams {
 // ---- launchers implemented in the .hip files (host side) ----
 hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
                             float* rows, float* tiled, float* norms, uint32_t G, uint32_t n_tiles,
-                            uint32_t* max_norm_bits_dev);
+                            uint32_t* img_stats_dev /* &ImgDev::max_norm_bits: 3 consecutive words */);
 hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint32_t nbytes,
                             uint32_t* bin, uint32_t words, uint32_t n_pad);
 // returns hipErrorInvalidValue when (G, dtype) has no tensor kernel; caller falls back to the exact scan
 hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
 hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t count, int scan_all);
+// exact scan of the per-pair fallback lists (one workgroup per pair); false return -> no kernel for this G
+hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t G);
 hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_n);
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);

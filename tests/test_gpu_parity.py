@@ -181,3 +181,33 @@ def test_save_load_roundtrip(ctx, oracle, tmp_path):
         # the oracle's reader agrees with the library's writer
         p, c, m = oracle.load_matches(path)
         assert np.array_equal(p, g.pairs) and np.array_equal(m, g.matches)
+
+
+def test_uncertified_queries_take_the_exact_paths(ctx, oracle):
+    """Near-duplicate real-valued rows: the MFMA nomination cannot be certified, so every query goes
+    through the per-pair batched exact scan (first 128) and the overflow rescan (the rest)."""
+    rng = np.random.default_rng(21)
+    base = rng.gamma(0.5, 1.0, 128).astype(np.float32); base /= np.linalg.norm(base)
+    a = (base[None, :] * (1 + 1e-6 * rng.normal(size=(600, 128)))).astype(np.float32)
+    b = (base[None, :] * (1 + 1e-6 * rng.normal(size=(333, 128)))).astype(np.float32)
+    idx, dist = ctx.knn2(a, b)
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    # same through the collection API (stats expose how many queries needed the exact scan)
+    ctx.clear_images()
+    ctx.set_image(0, a); ctx.set_image(1, b); ctx.set_image(2, a[:100])
+    g = ctx.match_pairs(np.array([[0, 1], [0, 2], [1, 2]], np.uint32), 0.999, True)
+    assert ctx.stats().n_exact_fallback > 300
+    counts, matches = oracle.match_collection([a, b, a[:100]], None, np.array([[0, 1], [0, 2], [1, 2]], np.uint32), 0.999, True)
+    _graph_equal(g, np.array([[0, 1], [0, 2], [1, 2]]), counts, matches)
+
+
+def test_integer_descriptors_need_no_rounding_slack(ctx):
+    """SIFT-like integer bins: the exactness proof applies, (almost) nothing falls back."""
+    sc = synth.make_scene(3, 2048, "sift", seed=5)
+    ctx.clear_images()
+    for i in range(3):
+        ctx.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000)
+    ctx.match_pairs(sc.exhaustive_pairs(), 0.6, True)
+    s = ctx.stats()
+    assert s.n_exact_fallback <= s.n_queries // 1000
