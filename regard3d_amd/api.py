@@ -97,9 +97,12 @@ class Graph:
         self._h = handle
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            load_library().r3dm_graph_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                load_library().r3dm_graph_free(self._h)
+                self._h = None
+        except Exception:          # interpreter shutdown
+            pass
 
     @property
     def num_pairs(self) -> int:
@@ -188,7 +191,10 @@ class Context:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:          # interpreter shutdown: ctypes globals may already be gone
+            pass
 
     def _check(self, rc: int, what: str):
         if rc != 0:

@@ -17,6 +17,8 @@
 
 #include "r3dm_internal.hpp"
 
+#include <cstdlib>
+
 namespace r3dm {
 
 typedef float f32x4  __attribute__((ext_vector_type(4)));
@@ -193,8 +195,86 @@ __device__ __forceinline__ void emit_result(const MatchParams& P, uint32_t pair,
 // The k axis is permuted identically on both operands (lane half h supplies dims 8g+4h+cc at
 // step 4g+cc), which a dot product does not notice.
 // ------------------------------------------------------------------------------------------------
-template <int G, int NJ, int PF>
-__global__ __launch_bounds__(256, 2)
+// 16-byte buffer load: wave-uniform descriptor + SGPR byte offset + per-lane 32-bit offset -- no 64-bit
+// per-lane address registers in the hot loop (the pointer form spilled at 256 VGPRs)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bload16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
+// One dataset tile: MFMAs of tile t into `cur`, while the VALU folds the finished accumulators of
+// tile t-1 (`prev`) into the running top-2 lists -- software pipelining inside the wave, so the
+// epilogue issues in the shadow of the 64-cycle MFMAs instead of after them.
+template <int G, int NJ, int PF, int PIPE>
+__device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rn, uint32_t voffA, uint32_t voffN,
+                                             uint32_t soffA, uint32_t soffN, f32x4 (&abuf)[PF], f32x4 (&nrm)[4],
+                                             const f32x4 (&bq)[NJ][G], f32x16 (&cur)[NJ], const f32x16 (&prev)[NJ],
+                                             Top2 (&st)[NJ], uint32_t prev_rowbase)
+{
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[nj][r] = nrm[r >> 2][r & 3];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const f32x4 a = abuf[g % PF];
+        if constexpr (PIPE != 7 && PIPE != 8) abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
+        if ((PIPE != 7 && PIPE != 8) && g == 2) {   // next tile's norms: early, so the wait at the tile boundary finds them landed
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) nrm[qd] = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
+        }
+        if constexpr (PIPE == 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+                cur[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cc], bq[nj][g][cc], cur[nj], 0, 0, 0);
+        if constexpr (PIPE == 4) __builtin_amdgcn_s_setprio(0);
+        // this group's share of the previous tile's 16 accumulator values per query tile
+        if constexpr (PIPE == 9 || PIPE == 7) {
+            // ablation (timing only, results meaningless): keep the accumulators alive, skip the epilogue
+#pragma unroll
+            for (int r = (g * 16) / G; r < ((g + 1) * 16) / G; ++r)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) asm volatile("" ::"v"(prev[nj][r]));
+        } else if constexpr (PIPE == 3 || PIPE == 8) {
+            // test-and-skip: a value can only change a list if it is below that lane's bound d2; once the
+            // lists have warmed up that is rare, so one wave-wide test guards the whole slice
+            bool any = false;
+#pragma unroll
+            for (int r = (g * 16) / G; r < ((g + 1) * 16) / G; ++r)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) any |= prev[nj][r] < st[nj].d2;
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+                for (int r = (g * 16) / G; r < ((g + 1) * 16) / G; ++r)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj)
+                        top2_push(st[nj], prev[nj][r], prev_rowbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+            }
+        } else {
+#pragma unroll
+            for (int r = (g * 16) / G; r < ((g + 1) * 16) / G; ++r)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    top2_push(st[nj], prev[nj][r], prev_rowbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        }
+        if constexpr (PIPE == 2) {
+            // issue order inside the step: MFMA, 3 VALU, MFMA, 3 VALU, ... so the epilogue slice hides
+            // behind the 64-cycle matrix instructions instead of in front of them
+#pragma unroll
+            for (int i = 0; i < 4 * NJ; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                // keep each prefetch / epilogue slice in its own step
+    }
+}
+
+template <int G, int NJ, int PF, int PIPE, int WPS>
+__global__ __launch_bounds__(256, WPS)
 void l2_knn2_mfma_kernel(const MatchParams P)
 {
     static_assert(G % PF == 0, "prefetch window must divide the group count");
@@ -236,6 +316,41 @@ void l2_knn2_mfma_kernel(const MatchParams P)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) nrm[qd] = nbase[2 * qd + h];
 
+        if constexpr (PIPE != 0) {
+            f32x16 accA[NJ], accB[NJ];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accB[nj][r] = R3DM_INF;          // "tile -1": keys that never win
+            // descriptors from wave-uniform values only (readfirstlane) so no waterfall loop is emitted
+            const uint64_t pa = (uint64_t)Ip->tiled, pn = (uint64_t)Ip->norms;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
+                0, 0x7FFFFFFF, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pn >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pn)),
+                0, 0x7FFFFFFF, 0x00020000);
+            const uint32_t voffA = lane * 16u, voffN = h * 16u;
+            const uint32_t tileB = (uint32_t)G * 1024u;                // bytes per tile
+            const uint32_t hb = 4u * h;
+            uint32_t t = 0;
+            for (; t + 1 < ntI; t += 2) {
+                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
+                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 2) * 128u, abuf, nrm, bq, accB, accA, st, t * 32u + hb);
+            }
+            if (t < ntI) {
+                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) top2_push(st[nj], accA[nj][r], t * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+            } else {
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) top2_push(st[nj], accB[nj][r], (ntI - 1) * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+            }
+        } else {
         for (uint32_t t = 0; t < ntI; ++t) {
             f32x16 acc[NJ];
 #pragma unroll
@@ -248,7 +363,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
             for (int g = 0; g < G; ++g) {
                 const f32x4 a = abuf[g % PF];
                 abuf[g % PF] = atile[g * 64 + lane];
-                if (g == G - 1) {
+                if (g == 2) {   // next tile's norms: early, so the wait at the tile boundary finds them landed
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) nrm[qd] = ntile[2 * qd + h];
                 }
@@ -266,6 +381,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
                 for (int r = 0; r < 16; ++r)
                     top2_push(st[nj], acc[nj][r], rowbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
         }
+        }   // !PIPE
     }
 
     // ---- per query: merge the two lane halves, re-score exactly, certify, ratio-test
@@ -324,28 +440,42 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     }
 }
 
-template <int G, int NJ, int PF>
-static hipError_t launch_l2_t(hipStream_t st, const MatchParams& P)
+template <int G, int NJ, int PF, int PIPE, int WPS>
+static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
+    MatchParams P = Pin;
+    const uint32_t tiles_per_wg = 4u * NJ;                 // 4 waves x NJ query tiles x 32 queries
+    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
     const uint32_t grid = P.n_pairs * P.qb_per_pair;
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF>), dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF, PIPE, WPS>), dim3(grid), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 
-// queries per workgroup for a given G (4 waves x NJ tiles x 32)
-static inline int nj_for(uint32_t G) { return G <= 18 ? 2 : 1; }
-
-hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& Pin, uint32_t G, uint32_t max_nj_tiles)
+hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles)
 {
-    MatchParams P = Pin;
-    const uint32_t tiles_per_wg = 4u * (uint32_t)nj_for(G);
-    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
+    // R3DM_L2_VARIANT selects a build of the kernel for A/B measurements (tools/ab_l2.py):
+    //   0 epilogue after the MFMAs | 1 software-pipelined epilogue | 3 pipelined + wave-wide test-and-skip
+    //   (default) | 9 ablation without epilogue (timing only) | 13 / 43: NJ = 1 x 3 waves/SIMD, NJ = 4 x 1 wave/SIMD
+    static const int variant = [] { const char* v = getenv("R3DM_L2_VARIANT"); return v ? atoi(v) : 3; }();
+    if (G == 16) {
+        switch (variant) {
+            case 0:  return launch_l2_t<16, 2, 4, 0, 2>(st, P, max_nj_tiles);
+            case 1:  return launch_l2_t<16, 2, 4, 1, 2>(st, P, max_nj_tiles);
+            case 9:  return launch_l2_t<16, 2, 4, 9, 2>(st, P, max_nj_tiles);
+            case 7:  return launch_l2_t<16, 2, 4, 7, 2>(st, P, max_nj_tiles);
+            case 8:  return launch_l2_t<16, 2, 4, 8, 2>(st, P, max_nj_tiles);
+            case 13: return launch_l2_t<16, 1, 4, 3, 3>(st, P, max_nj_tiles);
+            case 18: return launch_l2_t<16, 1, 8, 3, 3>(st, P, max_nj_tiles);
+            case 19: return launch_l2_t<16, 1, 16, 3, 2>(st, P, max_nj_tiles);
+            case 43: return launch_l2_t<16, 4, 4, 3, 1>(st, P, max_nj_tiles);
+            default: return launch_l2_t<16, 2, 4, 3, 2>(st, P, max_nj_tiles);
+        }
+    }
     switch (G) {
-        case 8:  return launch_l2_t<8, 2, 4>(st, P);
-        case 16: return launch_l2_t<16, 2, 4>(st, P);
-        case 18: return launch_l2_t<18, 2, 3>(st, P);
-        case 32: return launch_l2_t<32, 1, 4>(st, P);
+        case 8:  return launch_l2_t<8, 2, 4, 3, 2>(st, P, max_nj_tiles);
+        case 18: return launch_l2_t<18, 2, 3, 0, 2>(st, P, max_nj_tiles);     // pipelined form spills at G = 18
+        case 32: return launch_l2_t<32, 1, 4, 3, 2>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,88 @@
+"""The C++ faces of the boundary (include/r3dm_array_matcher.hpp, include/r3d_compute_matches.hpp):
+compile check on CPU; on the GPU box the small C++ host program is run and compared with the oracle.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from regard3d_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("cpp") / "adapter_main")
+    lib = os.path.join(ROOT, "regard3d_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp"), "-o", out,
+                           "-L" + lib, "-lr3dm", "-Wl,-rpath," + lib])
+    return out
+
+
+def _write_views(oracle, d, sc):
+    import ctypes
+    names = []
+    for i in range(sc.n_images):
+        name = f"img{i:03d}"
+        desc = np.ascontiguousarray(sc.descs[i], np.float32)
+        assert oracle.lib().orc_save_desc(os.path.join(d, name + ".desc").encode(), ctypes.c_uint64(desc.shape[0]),
+                                          ctypes.c_size_t(desc.shape[1] * 4), desc.ctypes.data_as(ctypes.c_void_p)) == 0
+        xyso = np.zeros((desc.shape[0], 4), np.float32); xyso[:, :2] = sc.xys[i]; xyso[:, 2] = 1.0
+        with open(os.path.join(d, name + ".feat"), "w") as f:       # full-precision text so positions round-trip exactly
+            for r in xyso:
+                f.write("%.9g %.9g %.9g %.9g\n" % tuple(r))
+        names.append(name)
+    return names
+
+
+def test_cpp_headers_compile_and_link(host_exe):
+    assert os.path.exists(host_exe)
+    # without arguments the program only reports usage (exit code 2); it must at least load libr3dm.so
+    assert subprocess.run([host_exe]).returncode == 2
+
+
+def test_facade_reports_failure_without_gpu_or_files(host_exe, tmp_path):
+    import torch
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "128", "missing_view"], capture_output=True, text=True)
+    assert r.returncode == 7                                   # computeMatches() returned false, did not crash
+    if not torch.cuda.is_available():
+        assert "computeMatches failed" in r.stderr
+
+
+@pytest.mark.gpu
+def test_array_matcher_adapter_matches_oracle(host_exe, oracle, tmp_path):
+    sc = synth.make_scene(2, 700, "liop", seed=17)
+    names = _write_views(oracle, str(tmp_path), sc)
+    out = str(tmp_path / "knn.txt")
+    subprocess.check_call([host_exe, "knn", str(tmp_path / (names[0] + ".desc")), str(tmp_path / (names[1] + ".desc")), "144", out])
+    got = np.loadtxt(out)
+    oidx, odist = oracle.knn2(sc.descs[0], sc.descs[1])
+    assert np.array_equal(got[:, 0].astype(int), np.arange(700))           # IndMatch(i_ = query row, j_ = dataset row)
+    assert np.array_equal(got[:, 1].astype(int), oidx[:, 0]) and np.array_equal(got[:, 3].astype(int), oidx[:, 1])
+    assert np.array_equal(got[:, 2].astype(np.float32), odist[:, 0]) and np.array_equal(got[:, 4].astype(np.float32), odist[:, 1])
+
+
+@pytest.mark.gpu
+def test_stage_facade_writes_the_reference_files(host_exe, oracle, tmp_path):
+    sc = synth.make_scene(5, 900, "liop", seed=23)
+    names = _write_views(oracle, str(tmp_path), sc)
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n_put, n_f = map(int, r.stdout.split())
+    pairs = sc.exhaustive_pairs()
+    counts, matches = oracle.match_collection(sc.descs, sc.xys, pairs, 0.6, True)
+    for ext in ("txt", "bin"):
+        p, c, m = oracle.load_matches(str(tmp_path / f"matches.putative.{ext}"))
+        assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
+    assert n_put == int((counts > 0).sum())
+    oc, om = oracle.filter_F_collection(sc.xys, sc.widths, sc.heights, pairs, counts, matches, 4.0, 2048, 5489)
+    p, c, m = oracle.load_matches(str(tmp_path / "matches.f.txt"))
+    assert np.array_equal(p, pairs[oc > 0]) and np.array_equal(c, oc[oc > 0]) and n_f == int((oc > 0).sum())
+    off = 0
+    for k, cnt in enumerate(c):                                   # same inlier set per pair (order: ascending residual)
+        seg = m[off:off + cnt]; off += cnt
+        exp = om[int(oc[:np.flatnonzero(oc > 0)[k]].sum()):][:cnt]
+        assert set(map(tuple, seg.tolist())) == set(map(tuple, exp.tolist()))
