@@ -93,11 +93,13 @@ def main():
     fence()
     t0 = time.perf_counter()
     kernel_ms = 0.0; kernel_flops = 0.0; launches = 0; filter_ms = 0.0; fallback = 0; queries = 0
+    wall = {"match": 0.0, "match_post": 0.0, "filter": 0.0}
     for _ in range(a.steps):
         g, gf, full, s_match, s_all = step()
         kernel_ms += s_match.ms_match_kernels; kernel_flops += s_match.algorithmic_flops
         launches += s_match.n_match_launches; filter_ms += s_all.ms_filter_kernels
         fallback += s_match.n_exact_fallback; queries += s_match.n_queries
+        wall["match"] += s_all.ms_wall_match; wall["match_post"] += s_all.ms_wall_match_post; wall["filter"] += s_all.ms_wall_filter
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -123,6 +125,7 @@ def main():
                      "traffic": None, "avg_launch_ms": kernel_ms / max(launches, 1),
                      "flops_per_launch": kernel_flops / max(launches, 1), "launches": int(launches)},
         "detail": {"filter_kernel_ms_per_step": filter_ms / a.steps, "match_kernel_ms_per_step": kernel_ms / a.steps,
+                   "wall_ms_per_step": {k: v / a.steps for k, v in wall.items()},
                    "exact_fallback_queries_per_step": fallback / a.steps, "queries_per_step": queries / a.steps,
                    "putative_pairs": int(full[0].num_pairs), "putative_matches": int(full[0].num_matches),
                    "F_pairs": int(full[1].num_pairs), "F_matches": int(full[1].num_matches)},

@@ -142,6 +142,10 @@ typedef struct {
     uint64_t n_exact_fallback;     /* queries re-done by the exact scan (uncertified top-2)        */
     double   algorithmic_flops;    /* 2 * nI * nJ * D summed over pairs (L2) / lane-ops (Hamming)   */
     double   algorithmic_bytes;    /* compulsory HBM bytes: both descriptor sets once + results     */
+    /* host wall-clock breakdown of the last calls (milliseconds) */
+    double   ms_wall_match;        /* whole r3dm_match_pairs call                                   */
+    double   ms_wall_match_post;   /* of which: exact scans + finalisation + copies back + assembly */
+    double   ms_wall_filter;       /* whole r3dm_filter_F call                                      */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -35,7 +35,8 @@ class Stats(C.Structure):
     _fields_ = [("ms_match_kernels", C.c_double), ("n_match_launches", C.c_uint64),
                 ("ms_filter_kernels", C.c_double), ("n_pairs", C.c_uint64), ("n_queries", C.c_uint64),
                 ("n_exact_fallback", C.c_uint64), ("algorithmic_flops", C.c_double),
-                ("algorithmic_bytes", C.c_double)]
+                ("algorithmic_bytes", C.c_double), ("ms_wall_match", C.c_double),
+                ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double)]
 
 
 class PairReport(C.Structure):

@@ -425,7 +425,12 @@ void l2_knn2_mfma_kernel(const MatchParams P)
             } else {
                 const float nb = Jp->norms[q];
                 const float slack = exact_pair ? 0.0f : P.err_scale * (maxnorm + nb);
-                const bool certified = eb < (bound + nb) - slack;   // every un-nominated row is farther than eb
+                const float A3 = bound + nb;                        // distance of the best un-nominated row (exact if exact_pair)
+                // certified: every un-nominated row is strictly farther than the runner-up.  With exact
+                // arithmetic a runner-up that merely TIES an un-nominated row still fixes the best row (ea < eb)
+                // and the runner-up DISTANCE, which is all the ratio test needs; only the raw 2-NN dump
+                // (r3dm_knn2) needs the tie's index resolved by the exact scan.
+                const bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
                 if (certified) {
                     emit_result(P, pair, q, ea, ia, eb, ib);
                 } else {

@@ -7,6 +7,7 @@
 #include "r3dm_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +63,11 @@ uint32_t kernel_G_for(uint32_t dim)
 bool has_tensor_kernel(uint32_t G) { return G == 8 || G == 16 || G == 18 || G == 32; }
 
 uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 bool has_ext(const char* path, const char* ext)
 {
@@ -414,6 +420,7 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
     }
 
     // ---- finalisation: compact + order + de-duplicate, per pair
+    const double t_post = now_ms();            // (the stream is idle here only on the tensor path; good enough for a breakdown)
     R3DM_HIP(c, c->d_pair_off.ensure((size_t)P * 8));
     R3DM_HIP(c, c->d_pair_cnt.ensure((size_t)P * 4));
     uint64_t out_cap = std::max<uint64_t>(1u << 20, n_queries / 4);
@@ -453,6 +460,7 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
             g->offsets.push_back(g->matches.size());
         }
     }
+    c->stats.ms_wall_match_post += now_ms() - t_post;
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_match_kernels += ms;
@@ -472,6 +480,7 @@ extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t 
     *out = nullptr;
     R3DM_HIP(c, hipSetDevice(c->device));
     c->stats = r3dm_stats{};
+    const double t_call = now_ms();
     // Matcher_Regions::Match: pairs whose views are missing, empty or of different region types are skipped
     std::vector<PairJob> jobs;
     jobs.reserve(n_pairs);
@@ -512,6 +521,7 @@ extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t 
         if (rc != R3DM_OK) return rc;
         start = end;
     }
+    c->stats.ms_wall_match = now_ms() - t_call;
     *out = g.release();
     return R3DM_OK;
 }
@@ -550,6 +560,7 @@ extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max
     if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
     *out = nullptr;
     R3DM_HIP(c, hipSetDevice(c->device));
+    const double t_call = now_ms();
     const uint64_t NP = putative->pairs.size() / 2;
     // work items: pairs with more than 7 putatives (ACRANSAC returns nothing for n <= 7)
     std::vector<uint32_t> item_pair;
@@ -706,6 +717,7 @@ extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max
         if (F_out) memcpy(F_out + 9 * kept, h_F.data() + 9 * (size_t)k, 72);
         ++kept;
     }
+    c->stats.ms_wall_filter = now_ms() - t_call;
     *out = g.release();
     return R3DM_OK;
 }
