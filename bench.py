@@ -131,6 +131,14 @@ def main():
                    "F_pairs": int(full[1].num_pairs), "F_matches": int(full[1].num_matches)},
     }
 
+    # HBM traffic of one launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
+    # command (a process cannot profile itself): profiles/r01_pmc_traffic.json, valid for the default workload only
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("workload_pairs") == int(total_pairs) and a.feat == 8192:
+            out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; algorithmic %.4g)" % tj["algorithmic_bytes_per_launch"]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(descs, xys, g, gf, a.cpu_seconds)
     if rank == 0:
