@@ -77,8 +77,8 @@ public:
         std::vector<int> numberOfKeypoints_;
         PairWiseMatches putativeMatches_;
         PairWiseMatches fundamentalMatches_;
-        PairWiseMatches essentialMatches_;     // not computed this round
-        PairWiseMatches homographyMatches_;    // not computed this round
+        PairWiseMatches essentialMatches_;     // not computed this round: 5-point solver pending
+        PairWiseMatches homographyMatches_;    // GeometricFilter_HMatrix_AC (r3dm_filter_H)
     };
     const R3DComputeMatchesStatistics& getStatistics() const { return statistics_; }
     const std::string& errorMessage() const { return errorMessage_; }

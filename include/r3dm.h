@@ -95,9 +95,16 @@ int r3dm_match_pairs(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs,
 int r3dm_filter_F(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                   uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out);
 
-/* Per-pair outcome of the last r3dm_filter_F call -- what OpenMVG's ACRANSAC returns besides the inliers
+/* Homography AC-RANSAC filter: ImageCollectionGeometricFilter::Robust_model_estimation(
+ * GeometricFilter_HMatrix_AC(4.0, 2048), putative, false) (src/R3DComputeMatches.cpp:2216-2221; run by default,
+ * src/Regard3DFeatures.cpp:129-131) -- 4-point DLT, asymmetric transfer error, point-to-point NFA scale,
+ * accept iff #inliers > 2.5 * 4.  H_out: 9 doubles (row-major H, x_J ~ H x_I) per KEPT pair. */
+int r3dm_filter_H(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                  uint64_t seed, r3dm_graph** out, double* H_out);
+
+/* Per-pair outcome of the last r3dm_filter_F / r3dm_filter_H call -- what OpenMVG's ACRANSAC returns besides the inliers
  * (std::pair<errorMax, minNFA>) plus work counters.  One entry per pair of the putative graph, in its
- * order; pairs with <= 7 putatives are all-zero.  Returns the number of entries available. */
+ * order; pairs with too few putatives (<= 7 for F, <= 4 for H) are all-zero.  Returns the number of entries available. */
 typedef struct {
     double   threshold_px;   /* AC-RANSAC inlier threshold (pixels); 0 when no meaningful model     */
     double   nfa;            /* minimum log10 NFA (+inf when nothing was evaluated)                  */

@@ -44,20 +44,26 @@ uint64_t orc_rng_u64(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter, uint3
     return mix64(a + G * (1ULL + (((uint64_t)iter << 32) | (uint64_t)attempt)));
 }
 
-/* UniformSample(7, pool): distinct positions in the pool, drawn by rejection. */
-void orc_sample7(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter,
-                 const uint32_t* pool, uint32_t pool_size, uint32_t* sample7)
+/* UniformSample(n, pool): n <= 7 distinct positions in the pool, drawn by rejection. */
+void orc_sample_n(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter,
+                  const uint32_t* pool, uint32_t pool_size, uint32_t n, uint32_t* sample)
 {
     uint32_t pos[7];
     uint32_t cnt = 0, attempt = 0;
-    while (cnt < 7) {
+    while (cnt < n) {
         const uint64_t r = orc_rng_u64(seed, I, J, iter, attempt++);
         const uint32_t p = (uint32_t)(((r >> 32) * (uint64_t)pool_size) >> 32);
         int dup = 0;
         for (uint32_t k = 0; k < cnt; ++k) dup |= (pos[k] == p);
         if (!dup) pos[cnt++] = p;
     }
-    for (uint32_t k = 0; k < 7; ++k) sample7[k] = pool ? pool[pos[k]] : pos[k];
+    for (uint32_t k = 0; k < n; ++k) sample[k] = pool ? pool[pos[k]] : pos[k];
+}
+
+void orc_sample7(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter,
+                 const uint32_t* pool, uint32_t pool_size, uint32_t* sample7)
+{
+    orc_sample_n(seed, I, J, iter, pool, pool_size, 7, sample7);
 }
 
 /* ---------------------------------------------------------------- cubic */
@@ -182,6 +188,65 @@ double orc_sym_epipolar_err(const double* F, double x1, double y1, double x2, do
     return (yFx * yFx) * (1.0 / (Fx0 * Fx0 + Fx1 * Fx1) + 1.0 / (Fty0 * Fty0 + Fty1 * Fty1)) / 4.0;
 }
 
+/* ---------------------------------------------------------------- four-point homography */
+
+/* OpenMVG homography::kernel::FourPointSolver (DLT; SURVEY.md A.5 skeleton, f-2): per correspondence
+ *   [x y 1 0 0 0 -x'x -x'y -x'] and [0 0 0 x y 1 -y'x -y'y -y'];  h = null vector of the 8x9 system
+ * (restatement: last column of Q in the Householder QR of L^T).  x1, x2: 4 x 2.  H: row-major 3x3. */
+int orc_four_point_h(const double* x1, const double* x2, double* H)
+{
+    double M[9][8];
+    for (int p = 0; p < 4; ++p) {
+        const double x = x1[2 * p], y = x1[2 * p + 1], u = x2[2 * p], v = x2[2 * p + 1];
+        const int c0 = 2 * p, c1 = 2 * p + 1;
+        M[0][c0] = x; M[1][c0] = y; M[2][c0] = 1.0; M[3][c0] = 0.0; M[4][c0] = 0.0; M[5][c0] = 0.0;
+        M[6][c0] = -u * x; M[7][c0] = -u * y; M[8][c0] = -u;
+        M[0][c1] = 0.0; M[1][c1] = 0.0; M[2][c1] = 0.0; M[3][c1] = x; M[4][c1] = y; M[5][c1] = 1.0;
+        M[6][c1] = -v * x; M[7][c1] = -v * y; M[8][c1] = -v;
+    }
+    double V[8][9], beta[8];
+    for (int j = 0; j < 8; ++j) {
+        double nrm2 = 0.0;
+        for (int r = j; r < 9; ++r) nrm2 += M[r][j] * M[r][j];
+        const double nrm = sqrt(nrm2);
+        for (int r = 0; r < 9; ++r) V[j][r] = 0.0;
+        beta[j] = 0.0;
+        if (nrm == 0.0) continue;
+        const double alpha = (M[j][j] > 0.0) ? -nrm : nrm;
+        double vn2 = 0.0;
+        for (int r = j; r < 9; ++r) V[j][r] = M[r][j];
+        V[j][j] -= alpha;
+        for (int r = j; r < 9; ++r) vn2 += V[j][r] * V[j][r];
+        if (vn2 == 0.0) continue;
+        beta[j] = 2.0 / vn2;
+        for (int c = j + 1; c < 8; ++c) {
+            double dot = 0.0;
+            for (int r = j; r < 9; ++r) dot += V[j][r] * M[r][c];
+            const double s = beta[j] * dot;
+            for (int r = j; r < 9; ++r) M[r][c] -= s * V[j][r];
+        }
+    }
+    double f[9];
+    for (int r = 0; r < 9; ++r) f[r] = (r == 8) ? 1.0 : 0.0;
+    for (int j = 7; j >= 0; --j) {
+        double dot = 0.0;
+        for (int r = j; r < 9; ++r) dot += V[j][r] * f[r];
+        const double s = beta[j] * dot;
+        for (int r = j; r < 9; ++r) f[r] -= s * V[j][r];
+    }
+    memcpy(H, f, sizeof(f));
+    return 1;
+}
+
+/* homography::kernel::AsymmetricError: || x2 - hnormalized(H x1) ||^2 */
+double orc_h_asym_err(const double* H, double x1, double y1, double x2, double y2)
+{
+    const double w = H[6] * x1 + H[7] * y1 + H[8];
+    const double ex = x2 - (H[0] * x1 + H[1] * y1 + H[2]) / w;
+    const double ey = y2 - (H[3] * x1 + H[4] * y1 + H[5]) / w;
+    return ex * ex + ey * ey;
+}
+
 /* ---------------------------------------------------------------- log-combinatorial tables */
 
 void orc_logcombi_tables(uint32_t n, uint32_t ks, float* logc_n, float* logc_k)
@@ -237,14 +302,17 @@ static int cmp_err(const void* pa, const void* pb)
     return a->idx < b->idx ? -1 : (a->idx > b->idx ? 1 : 0);
 }
 
-int orc_acransac_F(const double* xI, const double* xJ, int m,
-                   int wI, int hI, int wJ, int hJ,
-                   double precision_px, uint32_t max_iter,
-                   uint64_t seed, uint32_t I, uint32_t J,
-                   uint32_t* inliers_out, orc_fresult* res)
+/* kind 0: fundamental matrix (ACKernelAdaptor<SevenPointSolver, SymmetricEpipolarDistanceError, UnnormalizerT>,
+ *         point-to-line); kind 1: homography (ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI>,
+ *         point-to-point: logalpha0 = log10(pi / A / N2(0,0)^2), multError = 1). */
+static int acransac_core(int kind, const double* xI, const double* xJ, int m,
+                         int wI, int hI, int wJ, int hJ,
+                         double precision_px, uint32_t max_iter,
+                         uint64_t seed, uint32_t I, uint32_t J,
+                         uint32_t* inliers_out, orc_fresult* res)
 {
-    const int SS = 7;            /* MINIMUM_SAMPLES */
-    const int MAX_MODELS = 3;
+    const int SS = kind == 0 ? 7 : 4;            /* MINIMUM_SAMPLES */
+    const int MAX_MODELS = kind == 0 ? 3 : 1;
     memset(res, 0, sizeof(*res));
     res->nfa = INFINITY;
     if (m <= SS) return 0;
@@ -264,8 +332,8 @@ int orc_acransac_F(const double* xI, const double* xJ, int m,
     /* point-to-line: logalpha0 = log10(2 D / A / N2(0,0)), multError = 0.5 */
     const double Dd = sqrt((double)wJ * (double)wJ + (double)hJ * (double)hJ);
     const double Aa = (double)wJ * (double)hJ;
-    const double logalpha0 = log10(2.0 * Dd / Aa / s2);
-    const double multError = 0.5;
+    const double logalpha0 = kind == 0 ? log10(2.0 * Dd / Aa / s2) : log10(M_PI / Aa / (s2 * s2));
+    const double multError = kind == 0 ? 0.5 : 1.0;
     const double maxThreshold = precision_px * precision_px * s2 * s2;   /* precision = 4.0^2, in N2 units */
 
     const double loge0 = log10((double)MAX_MODELS * (double)(n - SS));
@@ -291,14 +359,14 @@ int orc_acransac_F(const double* xI, const double* xJ, int m,
 
     for (uint32_t iter = 0; iter < nIter; ++iter) {
         uint32_t smp[7];
-        orc_sample7(seed, I, J, iter, pool, pool_size, smp);
+        orc_sample_n(seed, I, J, iter, pool, pool_size, (uint32_t)SS, smp);
         double sx1[14], sx2[14];
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < SS; ++k) {
             sx1[2 * k] = x1[2 * smp[k]]; sx1[2 * k + 1] = x1[2 * smp[k] + 1];
             sx2[2 * k] = x2[2 * smp[k]]; sx2[2 * k + 1] = x2[2 * smp[k] + 1];
         }
         double Fs[27];
-        const int nm = orc_seven_point(sx1, sx2, Fs);
+        const int nm = kind == 0 ? orc_seven_point(sx1, sx2, Fs) : orc_four_point_h(sx1, sx2, Fs);
         if ((int)iter == g_dbg_iter) {
             for (int k = 0; k < 7; ++k) g_dbg[k] = smp[k];
             g_dbg[7] = nm; g_dbg[8] = pool_size; g_dbg[9] = iter;
@@ -309,7 +377,8 @@ int orc_acransac_F(const double* xI, const double* xJ, int m,
             const double* F = Fs + 9 * k;
             ++n_models_total;
             for (uint32_t p = 0; p < n; ++p)
-                rs[p] = orc_sym_epipolar_err(F, x1[2 * p], x1[2 * p + 1], x2[2 * p], x2[2 * p + 1]);
+                rs[p] = kind == 0 ? orc_sym_epipolar_err(F, x1[2 * p], x1[2 * p + 1], x2[2 * p], x2[2 * p + 1])
+                                  : orc_h_asym_err(F, x1[2 * p], x1[2 * p + 1], x2[2 * p], x2[2 * p + 1]);
             if (!acMode) {
                 uint32_t nInlier = 0;
                 for (uint32_t p = 0; p < n; ++p) if (rs[p] <= maxThreshold) ++nInlier;
@@ -374,14 +443,16 @@ int orc_acransac_F(const double* xI, const double* xJ, int m,
     res->n_models = n_models_total;
     res->n_inliers = n_inl;
     if (n_inl > 0) {
-        /* Unnormalize: F = N2^T * F * N1 ; threshold = sqrt(errorMax) / N2(0,0) */
+        /* Unnormalize: F = N2^T * F * N1 (UnnormalizerT) ; H = N2^-1 * H * N1 (UnnormalizerI);
+         * threshold = sqrt(errorMax) / N2(0,0) */
         const double N1[9] = { s1, 0, t1x, 0, s1, t1y, 0, 0, 1 };
         const double N2[9] = { s2, 0, t2x, 0, s2, t2y, 0, 0, 1 };
+        const double N2i[9] = { 1.0 / s2, 0, -t2x / s2, 0, 1.0 / s2, -t2y / s2, 0, 0, 1 };
         double T[9];
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) {
                 double v = 0.0;
-                for (int k = 0; k < 3; ++k) v += N2[3 * k + r] * bestF[3 * k + c];   /* N2^T * F */
+                for (int k = 0; k < 3; ++k) v += (kind == 0 ? N2[3 * k + r] : N2i[3 * r + k]) * bestF[3 * k + c];
                 T[3 * r + c] = v;
             }
         for (int r = 0; r < 3; ++r)
@@ -393,15 +464,29 @@ int orc_acransac_F(const double* xI, const double* xJ, int m,
         res->threshold = sqrt(errorMax) / s2;
         memcpy(inliers_out, inl, sizeof(uint32_t) * n_inl);
     }
-    res->accepted = ((double)n_inl > 2.5 * SS) ? 1 : 0;
+    res->accepted = ((double)n_inl > 2.5 * SS) ? 1 : 0;   /* F_ACRobust / H_ACRobust acceptance */
 
     free(rs); free(er); free(inl); free(pool); free(logc_k); free(logc_n); free(x2); free(x1);
     return (int)n_inl;
 }
 
+int orc_acransac_F(const double* xI, const double* xJ, int m, int wI, int hI, int wJ, int hJ,
+                   double precision_px, uint32_t max_iter, uint64_t seed, uint32_t I, uint32_t J,
+                   uint32_t* inliers_out, orc_fresult* res)
+{
+    return acransac_core(0, xI, xJ, m, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J, inliers_out, res);
+}
+
+int orc_acransac_H(const double* xI, const double* xJ, int m, int wI, int hI, int wJ, int hJ,
+                   double precision_px, uint32_t max_iter, uint64_t seed, uint32_t I, uint32_t J,
+                   uint32_t* inliers_out, orc_fresult* res)
+{
+    return acransac_core(1, xI, xJ, m, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J, inliers_out, res);
+}
+
 /* ---------------------------------------------------------------- collection filter */
 
-int64_t orc_filter_F_collection(int n_images, const int* n_rows, const float* const* xy,
+static int64_t filter_collection(int kind, int n_images, const int* n_rows, const float* const* xy,
                                 const uint32_t* widths, const uint32_t* heights,
                                 const uint32_t* pairs, int64_t n_pairs,
                                 const uint32_t* counts, const orc_match* matches,
@@ -429,8 +514,8 @@ int64_t orc_filter_F_collection(int n_images, const int* n_rows, const float* co
         }
         uint32_t* inl = (uint32_t*)malloc(sizeof(uint32_t) * m);
         orc_fresult fr;
-        const int ni = orc_acransac_F(xI, xJ, (int)m, (int)widths[I], (int)heights[I], (int)widths[J], (int)heights[J],
-                                      precision_px, max_iter, seed, I, J, inl, &fr);
+        const int ni = acransac_core(kind, xI, xJ, (int)m, (int)widths[I], (int)heights[I], (int)widths[J], (int)heights[J],
+                                     precision_px, max_iter, seed, I, J, inl, &fr);
         if (fr.accepted) {
             orc_match* r = (orc_match*)malloc(sizeof(orc_match) * (size_t)ni);
             for (int k = 0; k < ni; ++k) r[k] = pm[inl[k]];
@@ -446,4 +531,26 @@ int64_t orc_filter_F_collection(int n_images, const int* n_rows, const float* co
     }
     free(res); free(offs);
     return w;
+}
+
+int64_t orc_filter_F_collection(int n_images, const int* n_rows, const float* const* xy,
+                                const uint32_t* widths, const uint32_t* heights,
+                                const uint32_t* pairs, int64_t n_pairs,
+                                const uint32_t* counts, const orc_match* matches,
+                                double precision_px, uint32_t max_iter, uint64_t seed,
+                                uint32_t* out_counts, orc_match* out, double* F_out)
+{
+    return filter_collection(0, n_images, n_rows, xy, widths, heights, pairs, n_pairs, counts, matches,
+                             precision_px, max_iter, seed, out_counts, out, F_out);
+}
+
+int64_t orc_filter_H_collection(int n_images, const int* n_rows, const float* const* xy,
+                                const uint32_t* widths, const uint32_t* heights,
+                                const uint32_t* pairs, int64_t n_pairs,
+                                const uint32_t* counts, const orc_match* matches,
+                                double precision_px, uint32_t max_iter, uint64_t seed,
+                                uint32_t* out_counts, orc_match* out, double* H_out)
+{
+    return filter_collection(1, n_images, n_rows, xy, widths, heights, pairs, n_pairs, counts, matches,
+                             precision_px, max_iter, seed, out_counts, out, H_out);
 }

@@ -175,6 +175,23 @@ def acransac_F(xI, xJ, wI, hI, wJ, hJ, precision_px=4.0, max_iter=2048, seed=548
     return inl[:n].copy(), fr
 
 
+def acransac_H(xI, xJ, wI, hI, wJ, hJ, precision_px=4.0, max_iter=2048, seed=5489, I=0, J=1):
+    xI = np.ascontiguousarray(xI, np.float64); xJ = np.ascontiguousarray(xJ, np.float64)
+    m = xI.shape[0]
+    inl = np.zeros(max(m, 1), np.uint32)
+    fr = FResult()
+    n = lib().orc_acransac_H(_p(xI), _p(xJ), m, wI, hI, wJ, hJ, C.c_double(precision_px), C.c_uint32(max_iter),
+                             C.c_uint64(seed), C.c_uint32(I), C.c_uint32(J), _p(inl), C.byref(fr))
+    return inl[:n].copy(), fr
+
+
+def four_point_h(x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    H = np.zeros(9, np.float64)
+    lib().orc_four_point_h(_p(x1), _p(x2), _p(H))
+    return H.reshape(3, 3)
+
+
 def acransac_F_traced(xI, xJ, wI, hI, wJ, hJ, precision_px=4.0, max_iter=2048, seed=5489, I=0, J=1, cap=16384):
     buf = np.zeros((cap, 5), np.float64)
     lib().orc_set_trace(_p(buf), cap)
@@ -184,8 +201,14 @@ def acransac_F_traced(xI, xJ, wI, hI, wJ, hJ, precision_px=4.0, max_iter=2048, s
     return inl, fr, buf[:n].copy()
 
 
-def filter_F_collection(xys, widths, heights, pairs, counts, matches, precision_px=4.0, max_iter=2048,
+def filter_H_collection(xys, widths, heights, pairs, counts, matches, precision_px=4.0, max_iter=2048,
                         seed=5489, want_F=False):
+    return filter_F_collection(xys, widths, heights, pairs, counts, matches, precision_px, max_iter, seed, want_F,
+                               _fn="orc_filter_H_collection")
+
+
+def filter_F_collection(xys, widths, heights, pairs, counts, matches, precision_px=4.0, max_iter=2048,
+                        seed=5489, want_F=False, _fn="orc_filter_F_collection"):
     n = len(xys)
     xys = [np.ascontiguousarray(x, np.float32) for x in xys]
     xptr = (C.c_void_p * n)(*[x.ctypes.data for x in xys])
@@ -197,7 +220,8 @@ def filter_F_collection(xys, widths, heights, pairs, counts, matches, precision_
     oc = np.zeros(P, np.uint32)
     out = np.zeros((max(matches.shape[0], 1), 2), np.uint32)
     Fo = np.zeros((P, 9), np.float64) if want_F else None
-    tot = lib().orc_filter_F_collection(n, _p(nrows), xptr, _p(widths), _p(heights), _p(pairs), C.c_int64(P),
+    fn = getattr(lib(), _fn); fn.restype = C.c_int64
+    tot = fn(n, _p(nrows), xptr, _p(widths), _p(heights), _p(pairs), C.c_int64(P),
                                         _p(counts), _p(matches), C.c_double(precision_px), C.c_uint32(max_iter),
                                         C.c_uint64(seed), _p(oc), _p(out), _p(Fo) if want_F else None)
     return (oc, out[:tot].copy(), Fo) if want_F else (oc, out[:tot].copy())

@@ -117,6 +117,22 @@ int64_t orc_filter_F_collection(int n_images, const int* n_rows, const float* co
                                 double precision_px, uint32_t max_iter, uint64_t seed,
                                 uint32_t* out_counts, orc_match* out, double* F_out /* 9 per pair or NULL */);
 
+/* Homography variant (GeometricFilter_HMatrix_AC, src/R3DComputeMatches.cpp:2216-2221): same result struct,
+ * F[] holds the un-normalised H (x_J ~ H x_I), accepted iff n_inliers > 2.5 * 4. */
+int orc_acransac_H(const double* xI, const double* xJ, int m, int wI, int hI, int wJ, int hJ,
+                   double precision_px, uint32_t max_iter, uint64_t seed, uint32_t I, uint32_t J,
+                   uint32_t* inliers, orc_fresult* res);
+int64_t orc_filter_H_collection(int n_images, const int* n_rows, const float* const* xy,
+                                const uint32_t* widths, const uint32_t* heights,
+                                const uint32_t* pairs, int64_t n_pairs,
+                                const uint32_t* counts, const orc_match* matches,
+                                double precision_px, uint32_t max_iter, uint64_t seed,
+                                uint32_t* out_counts, orc_match* out, double* H_out);
+int      orc_four_point_h(const double* x1 /*4x2*/, const double* x2, double* H /*9*/);
+double   orc_h_asym_err(const double* H, double x1, double y1, double x2, double y2);
+void     orc_sample_n(uint64_t seed, uint32_t I, uint32_t J, uint32_t iter,
+                      const uint32_t* pool, uint32_t pool_size, uint32_t n, uint32_t* sample);
+
 /* Debug trace of the next orc_acransac_F call(s): rows of (iter, model, #<=bound, NFA, improved). */
 void orc_set_trace(double* buf, int cap_rows);
 int  orc_trace_rows(void);

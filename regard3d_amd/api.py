@@ -20,7 +20,7 @@ NONE = 0xFFFFFFFF
 
 EXPORTS = [
     "r3dm_create", "r3dm_destroy", "r3dm_last_error", "r3dm_device_info", "r3dm_set_image", "r3dm_clear_images",
-    "r3dm_match_pairs", "r3dm_filter_F", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
+    "r3dm_match_pairs", "r3dm_filter_F", "r3dm_filter_H", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir",
@@ -65,6 +65,7 @@ def load_library():
     L.r3dm_clear_images.argtypes = [vp]
     L.r3dm_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
     L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
+    L.r3dm_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
     L.r3dm_graph_num_pairs.argtypes = [vp]; L.r3dm_graph_num_pairs.restype = u64
     L.r3dm_graph_num_matches.argtypes = [vp]; L.r3dm_graph_num_matches.restype = u64
@@ -244,6 +245,15 @@ class Context:
                                           _ptr(Fbuf)), "r3dm_filter_F")
         g = Graph(h.value)
         return (g, Fbuf[:g.num_pairs].copy()) if want_F else g
+
+    def filter_H(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489,
+                 want_H: bool = False):
+        h = C.c_void_p()
+        Hbuf = np.zeros((max(putative.num_pairs, 1), 9), np.float64) if want_H else None
+        self._check(self._L.r3dm_filter_H(self._h, putative._h, max_residual_px, max_iter, seed, C.byref(h), _ptr(Hbuf)),
+                    "r3dm_filter_H")
+        g = Graph(h.value)
+        return (g, Hbuf[:g.num_pairs].copy()) if want_H else g
 
     def knn2(self, dataset: np.ndarray, query: np.ndarray, binary: bool = False):
         dataset = np.ascontiguousarray(dataset); query = np.ascontiguousarray(query)

@@ -132,6 +132,21 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool /*svgOutput*/, c
         r3dm_graph_free(geo);
         if (!ok) { errorMessage_ = "Cannot save computed matches in: " + f_path; r3dm_graph_free(putative); return false; }
     }
+    // ---- homography filter (:2216-2233): same skeleton, 4-point solver; matches.h.txt
+    if (params.computeHomographyMatrix_) {
+        r3dm_graph* geo = nullptr;
+        rc = r3dm_filter_H(ctx_, putative, 4.0, 2048, seed_, &geo, nullptr);
+        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
+        graph_to_map(geo, statistics_.homographyMatches_);
+        const std::string h_path = paths.matchesHFilename_.empty() ? dir + "/matches.h.txt" : paths.matchesHFilename_;
+        const bool ok = r3dm_save_matches(geo, h_path.c_str()) == R3DM_OK &&
+                        r3dm_save_matches(geo, with_ext(h_path, ".bin").c_str()) == R3DM_OK;
+        r3dm_graph_free(geo);
+        if (!ok) { errorMessage_ = "Cannot save computed matches in: " + h_path; r3dm_graph_free(putative); return false; }
+    }
+    // essential-matrix filter (:2130-2204): not implemented this round -- computeEssentialMatrix_ is ignored and
+    // statistics_.essentialMatches_ stays empty; OpenMVG's CPU filter can still be run on
+    // the putative graph by the caller.
     r3dm_graph_free(putative);
     return true;
 }

@@ -176,6 +176,76 @@ __device__ __forceinline__ double sym_epipolar_err(const double* F, double x1, d
     return (yFx * yFx) * (1.0 / (Fx0 * Fx0 + Fx1 * Fx1) + 1.0 / (Fty0 * Fty0 + Fty1 * Fty1)) / 4.0;
 }
 
+// 4-point homography (OpenMVG homography::kernel::FourPointSolver, DLT): rows of L per correspondence
+//   [x y 1 0 0 0 -x'x -x'y -x'] and [0 0 0 x y 1 -y'x -y'y -y'];  h = null vector of the 8x9 system,
+// taken as the last column of Q in the Householder QR of L^T (9x8), all indices static.
+__device__ int four_point_h(const double (&px1)[7][2], const double (&px2)[7][2], double* Hs)
+{
+    double M[9][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double x = px1[p][0], y = px1[p][1], u = px2[p][0], v = px2[p][1];
+        M[0][2 * p] = x;  M[1][2 * p] = y;  M[2][2 * p] = 1.0; M[3][2 * p] = 0.0; M[4][2 * p] = 0.0; M[5][2 * p] = 0.0;
+        M[6][2 * p] = -u * x; M[7][2 * p] = -u * y; M[8][2 * p] = -u;
+        M[0][2 * p + 1] = 0.0; M[1][2 * p + 1] = 0.0; M[2][2 * p + 1] = 0.0; M[3][2 * p + 1] = x; M[4][2 * p + 1] = y; M[5][2 * p + 1] = 1.0;
+        M[6][2 * p + 1] = -v * x; M[7][2 * p + 1] = -v * y; M[8][2 * p + 1] = -v;
+    }
+    double beta[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double nrm2 = 0.0;
+#pragma unroll
+        for (int r = j; r < 9; ++r) nrm2 += M[r][j] * M[r][j];
+        const double nrm = sqrt(nrm2);
+        double bj = 0.0;
+        if (nrm != 0.0) {
+            const double alpha = (M[j][j] > 0.0) ? -nrm : nrm;
+            M[j][j] -= alpha;
+            double vn2 = 0.0;
+#pragma unroll
+            for (int r = j; r < 9; ++r) vn2 += M[r][j] * M[r][j];
+            if (vn2 != 0.0) bj = 2.0 / vn2;
+        } else {
+#pragma unroll
+            for (int r = j; r < 9; ++r) M[r][j] = 0.0;
+        }
+        beta[j] = bj;
+#pragma unroll
+        for (int c = j + 1; c < 8; ++c) {
+            double dot = 0.0;
+#pragma unroll
+            for (int r = j; r < 9; ++r) dot += M[r][j] * M[r][c];
+            const double s = bj * dot;
+#pragma unroll
+            for (int r = j; r < 9; ++r) M[r][c] -= s * M[r][j];
+        }
+    }
+    double f[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) f[r] = (r == 8) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+        double dot = 0.0;
+#pragma unroll
+        for (int r = j; r < 9; ++r) dot += M[r][j] * f[r];
+        const double s = beta[j] * dot;
+#pragma unroll
+        for (int r = j; r < 9; ++r) f[r] -= s * M[r][j];
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Hs[e] = f[e];
+    return 1;
+}
+
+// homography AsymmetricError: || x2 - hnormalized(H x1) ||^2
+__device__ __forceinline__ double h_asym_err(const double* H, double x1, double y1, double x2, double y2)
+{
+    const double w = H[6] * x1 + H[7] * y1 + H[8];
+    const double ex = x2 - (H[0] * x1 + H[1] * y1 + H[2]) / w;
+    const double ey = y2 - (H[3] * x1 + H[4] * y1 + H[5]) / w;
+    return ex * ex + ey * ey;
+}
+
 // ---- per-workgroup shared state (lives at the front of the dynamic LDS region) ----
 struct FState {
     double minNFA, errorMax;
@@ -199,8 +269,11 @@ size_t filter_F_lds_bytes(uint32_t m_cap)
     return 1024 + (size_t)kChunk * 27 * 8 + (size_t)m_cap * 12;
 }
 
+// KIND 0: fundamental matrix (7-point, <= 3 models, symmetric epipolar error, point-to-line NFA scale)
+// KIND 1: homography (4-point DLT, 1 model, asymmetric transfer error, point-to-point NFA scale)
+template <int KIND>
 __global__ __launch_bounds__(256)
-void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
+void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
                        uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -209,6 +282,9 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * 27 * 8);
     uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
 
+    constexpr uint32_t SS = (KIND == 0) ? 7u : 4u;             // Kernel::MINIMUM_SAMPLES
+    constexpr double MAXM = (KIND == 0) ? 3.0 : 1.0;           // Kernel::MAX_MODELS
+    constexpr double MULT_ERR = (KIND == 0) ? 0.5 : 1.0;       // multError(): point-to-line vs point-to-point
     const uint32_t item = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t begin = P.offsets[2 * item], end = P.offsets[2 * item + 1];
@@ -239,9 +315,10 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
     }
     const double Dd = sqrt((double)wJ * (double)wJ + (double)hJ * (double)hJ);
     const double Aa = (double)wJ * (double)hJ;
-    const double logalpha0 = log10(2.0 * Dd / Aa / s2);
+    const double logalpha0 = (KIND == 0) ? log10(2.0 * Dd / Aa / s2)                       // 2 D / A / N2(0,0)
+                                         : log10(3.14159265358979323846 / Aa / (s2 * s2));   // pi / A / N2(0,0)^2
     const double maxThreshold = P.precision_px * P.precision_px * s2 * s2;
-    const double loge0 = log10(3.0 * (double)(m - 7));
+    const double loge0 = log10(MAXM * (double)(m - SS));
 
     if (tid == 0) {
         // logcombi(k, m) as a running prefix in the reference's float accumulation order
@@ -274,7 +351,7 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
         if (tid < chunk_n) {
             uint32_t pos[7];
             uint32_t cnt = 0, attempt = 0;
-            while (cnt < 7) {
+            while (cnt < SS) {
                 const uint64_t r = rng_u64(P.seed, id.x, id.y, iter0 + tid, attempt++);
                 const uint32_t ps = (uint32_t)(((r >> 32) * (uint64_t)pool_size) >> 32);
                 bool dup = false;
@@ -289,12 +366,12 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
             double px1[7][2], px2[7][2];
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
-                const uint32_t sidx_ = pool[pos[k]];
+                const uint32_t sidx_ = pool[pos[k < (int)SS ? k : 0]];
                 px1[k][0] = pt[4 * (size_t)sidx_ + 0]; px1[k][1] = pt[4 * (size_t)sidx_ + 1];
                 px2[k][0] = pt[4 * (size_t)sidx_ + 2]; px2[k][1] = pt[4 * (size_t)sidx_ + 3];
             }
             double F3[27];
-            const int nm = seven_point(px1, px2, F3);
+            const int nm = (KIND == 0) ? seven_point(px1, px2, F3) : four_point_h(px1, px2, F3);
             S.nm[tid] = (uint32_t)nm;
             S.dbg_smp[tid] = pool[pos[0]];
             if (P.trace && item == P.trace_item && iter0 + tid == P.trace_iter) {
@@ -325,7 +402,8 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
                     const uint32_t p = base + tid;
                     double r = 0.0; bool in = false;
                     if (p < m) {
-                        r = sym_epipolar_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3]);
+                        r = (KIND == 0) ? sym_epipolar_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3])
+                                        : h_asym_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3]);
                         in = (r <= maxThreshold);
                     }
                     const unsigned long long bal = __ballot(in);
@@ -341,10 +419,10 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
                 }
                 // AC mode switches on with the first model that has > 2.5*7 points within the bound
                 bool ac = S.acMode != 0;
-                if (!ac && (double)total > 2.5 * 7) ac = true;
+                if (!ac && (double)total > 2.5 * SS) ac = true;
                 double nfa = __builtin_huge_val();
-                uint32_t kbest = 7;
-                if (ac && total > 7) {
+                uint32_t kbest = SS;
+                if (ac && total > SS) {
                     // sort (residual, index) ascending: residuals are >= 0 so the u64 bit pattern orders them
                     uint32_t cap = 1; while (cap < total) cap <<= 1;
                     for (uint32_t q = total + tid; q < cap; q += 256) { keys[q] = ~0ull; sidx[q] = 0xFFFFFFFFu; }
@@ -365,10 +443,10 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
                     }
                     // bestNFA: k = 8 .. total, first minimum wins
                     double bv = __builtin_huge_val(); uint32_t bk = 0xFFFFFFFFu;
-                    for (uint32_t kk = 8 + tid; kk <= total; kk += 256) {
+                    for (uint32_t kk = SS + 1 + tid; kk <= total; kk += 256) {
                         const double e = __longlong_as_double((long long)keys[kk - 1]);
-                        const double logalpha = logalpha0 + 0.5 * log10(e + FLT_EPS_D);
-                        const double v = loge0 + logalpha * (double)(kk - 7) + (double)logc_n[kk] + (double)P.logc_k[kk];
+                        const double logalpha = logalpha0 + MULT_ERR * log10(e + FLT_EPS_D);
+                        const double v = loge0 + logalpha * (double)(kk - SS) + (double)logc_n[kk] + (double)P.logc_k[kk];
                         if (v < bv) { bv = v; bk = kk; }
                     }
                     // wave argmin (value, then smaller k), then across the 4 waves
@@ -385,7 +463,7 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
                         const double ov = S.red_v[w]; const uint32_t ok = S.red_k[w];
                         if (w == 0 || ov < nfa || (ov == nfa && ok < kbest)) { nfa = ov; kbest = ok; }
                     }
-                    if (kbest == 0xFFFFFFFFu) { nfa = __builtin_huge_val(); kbest = 7; }
+                    if (kbest == 0xFFFFFFFFu) { nfa = __builtin_huge_val(); kbest = SS; }
                 }
                 // commit (every lane evaluates the same condition on the same shared values)
                 const double minNFA = S.minNFA;
@@ -476,14 +554,15 @@ void acransac_F_kernel(const FilterParams P, double* __restrict__ pts /* [sum m]
         double Fo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double thr = 0.0;
         if (n_inl > 0) {
-            // Unnormalize: F = N2^T * F * N1
+            // Unnormalize: F = N2^T * F * N1 (UnnormalizerT) ; H = N2^-1 * H * N1 (UnnormalizerI)
             const double N1[9] = {s1, 0, t1x, 0, s1, t1y, 0, 0, 1};
             const double N2[9] = {s2, 0, t2x, 0, s2, t2y, 0, 0, 1};
+            const double N2i[9] = {1.0 / s2, 0, -t2x / s2, 0, 1.0 / s2, -t2y / s2, 0, 0, 1};
             double T[9];
             for (int r = 0; r < 3; ++r)
                 for (int cc = 0; cc < 3; ++cc) {
                     double v = 0.0;
-                    for (int k = 0; k < 3; ++k) v += N2[3 * k + r] * S.bestF[3 * k + cc];
+                    for (int k = 0; k < 3; ++k) v += ((KIND == 0) ? N2[3 * k + r] : N2i[3 * r + k]) * S.bestF[3 * k + cc];
                     T[3 * r + cc] = v;
                 }
             for (int r = 0; r < 3; ++r)
@@ -506,9 +585,13 @@ hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
 {
     if (P.n_items == 0) return hipSuccess;
     const size_t lds = filter_F_lds_bytes(P.m_cap);
-    hipError_t e = hipFuncSetAttribute((const void*)acransac_F_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void* fn = (P.model_kind == 0) ? (const void*)acransac_kernel<0> : (const void*)acransac_kernel<1>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(acransac_F_kernel, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+    if (P.model_kind == 0)
+        hipLaunchKernelGGL(acransac_kernel<0>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+    else
+        hipLaunchKernelGGL(acransac_kernel<1>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
     return hipGetLastError();
 }
 

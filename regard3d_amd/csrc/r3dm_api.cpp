@@ -554,22 +554,24 @@ extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, c
 // ------------------------------------------------------------------------------------------------
 // geometric filter
 // ------------------------------------------------------------------------------------------------
-extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
-                             uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out)
+// model_kind 0 = fundamental matrix (GeometricFilter_FMatrix_AC), 1 = homography (GeometricFilter_HMatrix_AC)
+static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                         uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out)
 {
     if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
+    const uint32_t SS = model_kind == 0 ? 7u : 4u;          // Kernel::MINIMUM_SAMPLES
     *out = nullptr;
     R3DM_HIP(c, hipSetDevice(c->device));
     const double t_call = now_ms();
     const uint64_t NP = putative->pairs.size() / 2;
-    // work items: pairs with more than 7 putatives (ACRANSAC returns nothing for n <= 7)
+    // work items: pairs with more than SS putatives (ACRANSAC returns nothing for n <= MINIMUM_SAMPLES)
     std::vector<uint32_t> item_pair;
     std::vector<uint2> slots, ids;
     uint32_t max_m = 0;
     uint64_t sum_m = 0;
     for (uint64_t p = 0; p < NP; ++p) {
         const uint64_t m = putative->offsets[p + 1] - putative->offsets[p];
-        if (m <= 7) continue;
+        if (m <= SS) continue;
         const uint32_t I = putative->pairs[2 * p], J = putative->pairs[2 * p + 1];
         auto a = c->slot_of.find(I), b = c->slot_of.find(J);
         if (a == c->slot_of.end() || b == c->slot_of.end()) { c->err = "filter: pair references an unregistered view"; return R3DM_ERR_INVALID; }
@@ -596,12 +598,12 @@ extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max
         begin_end[2 * k] = putative->offsets[p];
         begin_end[2 * k + 1] = putative->offsets[p + 1];
     }
-    if (err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { c->err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
+    if (model_kind == 0 && err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { c->err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
     // host tables in the reference's own float arithmetic (glibc log10f), see kernels_filter.hip
     std::vector<float> l10(max_m + 2), lck(max_m + 2);
     for (uint32_t k = 0; k <= max_m + 1; ++k) l10[k] = std::log10((float)k);
     for (uint32_t n = 0; n <= max_m + 1; ++n) {
-        const uint32_t ks = 7;
+        const uint32_t ks = SS;
         if (ks >= n) { lck[n] = 0.f; continue; }
         const uint32_t kk = (n - ks < ks) ? n - ks : ks;
         float r = 0.f;
@@ -634,6 +636,7 @@ extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max
     fp.offsets = c->f_offs.as<uint64_t>(); fp.matches = c->f_matches.as<r3dm_match>();
     fp.n_items = NI; fp.m_cap = std::max<uint32_t>(64, next_pow2(max_m));
     fp.precision_px = max_residual_px; fp.max_iter = max_iter; fp.seed = seed; fp.err_kind = (int)err_kind;
+    fp.model_kind = model_kind;
     fp.log10_tab = c->f_log10.as<float>(); fp.logc_k = c->f_logck.as<float>();
     fp.inl_count = c->f_inl_cnt.as<uint32_t>(); fp.inl_idx = c->f_inl_idx.as<uint32_t>();
     fp.F_out = c->f_F.as<double>(); fp.thr_nfa = c->f_thr.as<double>(); fp.iters = c->f_iters.as<uint32_t>();
@@ -707,8 +710,8 @@ extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max
 
     uint64_t kept = 0;
     for (uint32_t k = 0; k < NI; ++k) {
-        // GeometricFilter_FMatrix_AC: accept iff #inliers > 2.5 * 7
-        if ((double)h_cnt[k] <= 2.5 * 7) continue;
+        // GeometricFilter_{F,H}Matrix_AC: accept iff #inliers > 2.5 * MINIMUM_SAMPLES
+        if ((double)h_cnt[k] <= 2.5 * SS) continue;
         const uint32_t p = item_pair[k];
         const uint64_t base = putative->offsets[p];
         g->pairs.push_back(putative->pairs[2 * p]); g->pairs.push_back(putative->pairs[2 * p + 1]);
@@ -720,6 +723,18 @@ extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max
     c->stats.ms_wall_filter = now_ms() - t_call;
     *out = g.release();
     return R3DM_OK;
+}
+
+extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out)
+{
+    return filter_common(c, putative, max_residual_px, max_iter, seed, err_kind, 0, out, F_out);
+}
+
+extern "C" int r3dm_filter_H(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, r3dm_graph** out, double* H_out)
+{
+    return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 1, out, H_out);
 }
 
 extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint64_t cap)

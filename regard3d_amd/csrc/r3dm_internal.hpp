@@ -83,8 +83,9 @@ struct FilterParams {
     uint32_t      max_iter;
     uint64_t      seed;
     int           err_kind;
+    int           model_kind;     // 0 = fundamental matrix (7-point), 1 = homography (4-point)
     const float*  log10_tab;      // log10f(k), k = 0..max_m  (host-computed: same libm as the reference build)
-    const float*  logc_k;         // logcombi(7, n), n = 0..max_m (host-computed)
+    const float*  logc_k;         // logcombi(sample size, n), n = 0..max_m (host-computed)
     // outputs
     uint32_t*     inl_count;      // [n_items] inliers kept (0 if rejected)
     uint32_t*     inl_idx;        // [sum m] inlier positions into the pair's putative list, AC-RANSAC order

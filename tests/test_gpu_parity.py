@@ -211,3 +211,40 @@ def test_integer_descriptors_need_no_rounding_slack(ctx):
     ctx.match_pairs(sc.exhaustive_pairs(), 0.6, True)
     s = ctx.stats()
     assert s.n_exact_fallback <= s.n_queries // 1000
+
+
+def test_filter_H_matches_oracle(ctx, oracle):
+    """Homography AC-RANSAC (GeometricFilter_HMatrix_AC): planar scene so that H has real support."""
+    rng = np.random.default_rng(12)
+    n = 900
+    Ht = np.array([[0.97, 0.05, 60.0], [-0.04, 1.01, 30.0], [2e-5, 1e-5, 1.0]])
+    base = np.rint(np.clip(rng.gamma(0.5, 60.0, (n, 128)), 0, 255)).astype(np.float32)
+    xy0 = np.stack([rng.uniform(200, 3800, n), rng.uniform(200, 2800, n)], 1)
+    descs, xys = [], []
+    for v in range(3):
+        Hv = np.linalg.matrix_power(Ht, v)
+        p = (Hv @ np.c_[xy0, np.ones(n)].T).T; p = p[:, :2] / p[:, 2:] + rng.normal(0, 0.4, (n, 2))
+        bad = rng.random(n) < 0.2
+        p[bad] = np.stack([rng.uniform(0, 4000, bad.sum()), rng.uniform(0, 3000, bad.sum())], 1)
+        d = np.rint(np.clip(base + rng.normal(0, 4, base.shape), 0, 255)).astype(np.float32)
+        perm = rng.permutation(n)
+        descs.append(d[perm]); xys.append(p[perm].astype(np.float32))
+    ctx.clear_images()
+    for i in range(3):
+        ctx.set_image(i, descs[i], xys[i], 4000, 3000)
+    pairs = np.array([[0, 1], [0, 2], [1, 2]], np.uint32)
+    g = ctx.match_pairs(pairs, 0.6, True)
+    gh, Hm = ctx.filter_H(g, 4.0, 2048, seed=5489, want_H=True)
+    counts = np.diff(g.offsets.astype(np.int64)).astype(np.uint32)
+    oc, om, oH = oracle.filter_H_collection(xys, [4000] * 3, [3000] * 3, g.pairs, counts, g.matches, 4.0, 2048, 5489, want_F=True)
+    d = gh.as_dict(); off = 0; kept = 0
+    for p, (I, J) in enumerate(g.pairs):
+        exp = om[off:off + oc[p]]; off += oc[p]
+        got = d.get((int(I), int(J)), np.zeros((0, 2), np.uint32))
+        assert set(map(tuple, got.tolist())) == set(map(tuple, exp.tolist())), (I, J)
+        if oc[p]:
+            a = Hm[kept] / np.linalg.norm(Hm[kept]); b = oH[p] / np.linalg.norm(oH[p])
+            if np.dot(a, b) < 0: a = -a
+            assert np.linalg.norm(a - b) < 1e-9
+            kept += 1
+    assert kept == 3 and gh.num_matches > 1200

@@ -183,3 +183,39 @@ def test_filter_collection_acceptance_rule(oracle):
     assert oc[0] > 17 and set(map(tuple, om.tolist())) <= set(map(tuple, m.tolist()))
     oc, om = oracle.filter_F_collection(xy, [W, W], [H, H], pairs, [12], m[:12])
     assert oc[0] == 0 and len(om) == 0
+
+
+# ---------------------------------------------------------------- homography variant
+
+def _h_scene(n_in, n_out, sigma, seed):
+    rng = np.random.default_rng(seed)
+    Ht = np.array([[1.02, 0.03, 40.0], [-0.02, 0.98, -25.0], [1e-5, -2e-5, 1.0]])
+    x1 = np.stack([rng.uniform(0, W, n_in + n_out), rng.uniform(0, H, n_in + n_out)], 1)
+    x2h = (Ht @ np.c_[x1, np.ones(len(x1))].T).T
+    x2 = x2h[:, :2] / x2h[:, 2:]
+    x2[:n_in] += rng.normal(0, sigma, (n_in, 2))
+    x2[n_in:] = np.stack([rng.uniform(0, W, n_out), rng.uniform(0, H, n_out)], 1)
+    return x1, x2, Ht
+
+
+def test_four_point_dlt_exact(oracle):
+    x1, x2, Ht = _h_scene(4, 0, 0.0, 1)
+    Hh = oracle.four_point_h(x1, x2)
+    # raw pixel coordinates (no pre-conditioning in this direct call): DLT is exact up to its conditioning
+    assert np.allclose(Hh / Hh[2, 2], Ht, rtol=1e-5, atol=1e-6)
+    x2h = (Hh @ np.c_[x1, np.ones(4)].T).T
+    assert np.allclose(x2h[:, :2] / x2h[:, 2:], x2, atol=1e-6)
+
+
+def test_acransac_H_known_scene(oracle):
+    x1, x2, Ht = _h_scene(200, 100, 0.4, 2)
+    inl, fr = oracle.acransac_H(x1, x2, W, H, W, H)
+    assert fr.accepted == 1 and fr.nfa < 0 and 0 < fr.threshold < 4.0
+    s = set(inl.tolist())
+    assert len(s & set(range(200))) >= 190 and len(s - set(range(200))) <= 3
+    Hh = np.array(fr.F).reshape(3, 3); Hh /= Hh[2, 2]
+    assert np.allclose(Hh[:2, :2], Ht[:2, :2], atol=5e-3) and np.allclose(Hh[:2, 2], Ht[:2, 2], atol=3.0)
+    # n <= 4 returns at once; pure outliers are rejected; acceptance needs > 2.5 * 4 inliers
+    assert len(oracle.acransac_H(x1[:4], x2[:4], W, H, W, H)[0]) == 0
+    _, fo = oracle.acransac_H(x1[200:260], x2[200:260], W, H, W, H)
+    assert fo.accepted == 0
