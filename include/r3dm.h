@@ -122,6 +122,16 @@ int r3dm_filter_report(const r3dm_ctx* ctx, r3dm_pair_report* out, uint64_t cap)
 int r3dm_knn2(r3dm_ctx* ctx, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
               uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist);
 
+/* ---- descriptor extraction: LIOP on pre-extracted patches ----
+ * r3d_vl_liopdesc_process of the vendored VLFeat copy (src/thirdparty/liop/vl_liop.c:465-580) as Regard3D
+ * calls it per keypoint (src/Regard3DFeatures.cpp:727-752,827: new_basic(41) -> 4 neighbours, 6 bins, radius 6):
+ * patches = n x 41 x 41 floats (the warped + blurred patch of every keypoint, row-major), desc_out = n x 144
+ * floats, non-negative, unit L2 norm (all-zero for a constant patch).  Host or device pointers.
+ * n_resorted (optional) receives the number of patches with equal intensities that went through the exact
+ * re-sort.  Results are bit-identical to the reference routine. */
+int r3dm_liop_describe_patches(r3dm_ctx* ctx, const float* patches, uint32_t n, uint32_t side, float* desc_out,
+                               uint32_t* n_resorted);
+
 /* ---- match graph (PairWiseMatches) ---- */
 uint64_t          r3dm_graph_num_pairs(const r3dm_graph* g);
 uint64_t          r3dm_graph_num_matches(const r3dm_graph* g);
@@ -153,6 +163,7 @@ typedef struct {
     double   ms_wall_match;        /* whole r3dm_match_pairs call                                   */
     double   ms_wall_match_post;   /* of which: exact scans + finalisation + copies back + assembly */
     double   ms_wall_filter;       /* whole r3dm_filter_F call                                      */
+    double   ms_liop_kernel;       /* HIP-event time of the last r3dm_liop_describe_patches kernel  */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

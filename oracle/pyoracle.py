@@ -29,12 +29,13 @@ class FResult(C.Structure):
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "r3d_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "r3d_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     ref = os.path.join(_HERE, "_ref", "libref_hnsw.so")
-    if os.path.isdir("/root/reference/src/thirdparty/hnswlib") and (force or not os.path.exists(ref)):
+    ref2 = os.path.join(_HERE, "_ref", "libref_liop.so")
+    if os.path.isdir("/root/reference/src/thirdparty/hnswlib") and (force or not os.path.exists(ref) or not os.path.exists(ref2)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -67,6 +68,47 @@ def ref_lib():
             return None
         _REF = C.CDLL(so)
     return _REF
+
+
+_REF_LIOP = None
+
+
+def ref_liop_lib():
+    """the reference's own vl_liop.c compiled stand-alone (None if not built)"""
+    global _REF_LIOP
+    if _REF_LIOP is None:
+        so = os.path.join(_HERE, "_ref", "libref_liop.so")
+        if not os.path.exists(so):
+            return None
+        L = C.CDLL(so)
+        L.r3d_vl_liopdesc_new_basic.restype = C.c_void_p
+        L.r3d_vl_liopdesc_new_basic.argtypes = [C.c_size_t]
+        L.r3d_vl_liopdesc_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.r3d_vl_liopdesc_delete.argtypes = [C.c_void_p]
+        _REF_LIOP = L
+    return _REF_LIOP
+
+
+def ref_liop(patches: np.ndarray) -> np.ndarray:
+    L = ref_liop_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_liop.so not built")
+    patches = np.ascontiguousarray(patches, np.float32)
+    n, side = patches.shape[0], patches.shape[1]
+    out = np.zeros((n, 144), np.float32)
+    h = L.r3d_vl_liopdesc_new_basic(side)
+    for k in range(n):
+        L.r3d_vl_liopdesc_process(h, out[k].ctypes.data_as(C.c_void_p), patches[k].ctypes.data_as(C.c_void_p))
+    L.r3d_vl_liopdesc_delete(h)
+    return out
+
+
+def liop_describe(patches: np.ndarray) -> np.ndarray:
+    patches = np.ascontiguousarray(patches, np.float32)
+    n, side = patches.shape[0], patches.shape[1]
+    out = np.zeros((n, 144), np.float32)
+    lib().orc_liop_describe(_p(patches), n, side, _p(out))
+    return out
 
 
 def _p(a):

@@ -146,6 +146,11 @@ int      orc_solve_cubic(const double* coeffs /*c0..c3*/, double* roots);
 double   orc_sym_epipolar_err(const double* F, double x1, double y1, double x2, double y2);
 void     orc_logcombi_tables(uint32_t n, uint32_t k_sample, float* logc_n /*n+1*/, float* logc_k /*n+1*/);
 
+/* ---- LIOP descriptor (vendored VLFeat copy src/thirdparty/liop/vl_liop.c; call site
+ * src/Regard3DFeatures.cpp:827).  patches: n x side x side floats, desc: n x 144 floats. */
+int orc_liop_describe(const float* patches, int n, int side, float* desc);
+int orc_liop_geometry(int side, int* n_pix, int* pix, double* sx, double* sy);
+
 /* ---- file formats (src/keypointSet.hpp:49-67, src/R3DProject.cpp:854-871) ---- */
 int orc_save_matches(const char* path, int64_t n_pairs, const uint32_t* pairs,
                      const uint32_t* counts, const orc_match* matches);   /* .txt or .bin by extension */

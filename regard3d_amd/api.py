@@ -23,7 +23,7 @@ EXPORTS = [
     "r3dm_match_pairs", "r3dm_filter_F", "r3dm_filter_H", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
-    "r3dm_compute_matches_dir",
+    "r3dm_compute_matches_dir", "r3dm_liop_describe_patches",
 ]
 
 
@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("ms_filter_kernels", C.c_double), ("n_pairs", C.c_uint64), ("n_queries", C.c_uint64),
                 ("n_exact_fallback", C.c_uint64), ("algorithmic_flops", C.c_double),
                 ("algorithmic_bytes", C.c_double), ("ms_wall_match", C.c_double),
-                ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double)]
+                ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double), ("ms_liop_kernel", C.c_double)]
 
 
 class PairReport(C.Structure):
@@ -66,6 +66,7 @@ def load_library():
     L.r3dm_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
     L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
     L.r3dm_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
+    L.r3dm_liop_describe_patches.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32)]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
     L.r3dm_graph_num_pairs.argtypes = [vp]; L.r3dm_graph_num_pairs.restype = u64
     L.r3dm_graph_num_matches.argtypes = [vp]; L.r3dm_graph_num_matches.restype = u64
@@ -263,6 +264,17 @@ class Context:
         self._check(self._L.r3dm_knn2(self._h, _ptr(dataset), dataset.shape[0], _ptr(query), nq, dataset.shape[1], dt,
                                       _ptr(idx), _ptr(dist)), "r3dm_knn2")
         return idx[:nq], dist[:nq]
+
+    def liop_describe_patches(self, patches):
+        """patches: [n, 41, 41] float32 (numpy or torch, host or device) -> (desc [n, 144] float32, n_resorted)"""
+        if isinstance(patches, np.ndarray):
+            patches = np.ascontiguousarray(patches, np.float32)
+        n, side = int(patches.shape[0]), int(patches.shape[1])
+        out = np.zeros((max(n, 1), 144), np.float32)
+        nt = C.c_uint32(0)
+        self._check(self._L.r3dm_liop_describe_patches(self._h, _ptr(patches), n, side, _ptr(out), C.byref(nt)),
+                    "r3dm_liop_describe_patches")
+        return out[:n], int(nt.value)
 
     def filter_report(self):
         """per putative pair of the last filter_F call: (threshold_px, nfa, iterations, models, inliers)"""

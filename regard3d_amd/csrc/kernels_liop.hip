@@ -1,0 +1,222 @@
+// kernels_liop.hip -- LIOP descriptor (Regard3D's live descriptor, 144 x f32) on gfx950.
+//
+// Replaces the per-keypoint loop of Regard3DFeatures::extractLIOPFeatures
+// (/root/reference/src/Regard3DFeatures.cpp:719-861, serial in the reference: the OpenMP/TBB pragmas are
+// compiled out at :35-37) whose arithmetic is the vendored VLFeat routine r3d_vl_liopdesc_process
+// (/root/reference/src/thirdparty/liop/vl_liop.c:465-580) with new_basic(41): 4 neighbours, 6 ordinal
+// bins, radius 6, threshold 5/255 of the patch's intensity range.
+//
+// One wave per 41x41 patch, everything in LDS:
+//   1. the 669 pixels of the circular support are ranked by intensity: bitonic sort of (order-preserving
+//      float bits << 32 | scan position).  The reference sorts with its own quick sort, whose result differs
+//      from any other sort only in the order of EQUAL intensities; patches with ties are therefore re-sorted
+//      by one lane with that exact procedure (middle pivot, Lomuto pass, "<= 0") -- rare, and constant
+//      patches short-cut to the all-zero descriptor they produce;
+//   2. each rank gets its ordinal bin, 4 bilinear samples (f64, positions from host tables computed with the
+//      host libm exactly as vl_liopdesc_new does), the permutation index of the sample order and the weight
+//      (#pairs differing by more than the threshold); weights are small integers -> integer LDS histogram;
+//   3. normalisation with the reference's float running sum (sequential) and float-stored sqrt.
+// HBM traffic: 6.7 KB patch in, 576 B out per keypoint -> bound by LDS latency / sort, not HBM.
+
+#include "r3dm_internal.hpp"
+
+namespace r3dm {
+
+constexpr int kLiopSide = 41;
+constexpr int kLiopPix = kLiopSide * kLiopSide;   // 1681
+constexpr int kLiopSortCap = 1024;
+
+__device__ __forceinline__ uint32_t float_order_bits(float v)
+{
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// exact emulation of the reference's quick sort over perm[0..n) ordered by val[perm[.]] (lane 0 only)
+__device__ void liop_ref_qsort(const float* __restrict__ val, uint16_t* __restrict__ perm, int n, int* __restrict__ stack)
+{
+    int sp = 0;
+    stack[sp++] = 0; stack[sp++] = n - 1;
+    while (sp > 0) {
+        const int end = stack[--sp], begin = stack[--sp];
+        const int pivot = (end + begin) / 2;
+        uint16_t t = perm[pivot]; perm[pivot] = perm[end]; perm[end] = t;
+        const float pv = val[perm[end]];
+        int low = begin;
+        for (int i = begin; i < end; ++i) {
+            const uint16_t pi = perm[i];
+            if (val[pi] - pv <= 0.0f) { perm[i] = perm[low]; perm[low] = pi; ++low; }
+        }
+        t = perm[low]; perm[low] = perm[end]; perm[end] = t;
+        // the reference recurses into the low part first, then the high part: push high first (LIFO)
+        if (low < end) { stack[sp++] = low + 1; stack[sp++] = end; }
+        if (low > begin) { stack[sp++] = begin; stack[sp++] = low - 1; }
+    }
+}
+
+// 4-element version of the same quick sort (neighbour samples with equal intensities)
+__device__ void liop_ref_qsort4(const float (&v)[4], int (&p)[4])
+{
+    int stack[8]; int sp = 0;
+    stack[sp++] = 0; stack[sp++] = 3;
+    while (sp > 0) {
+        const int end = stack[--sp], begin = stack[--sp];
+        const int pivot = (end + begin) / 2;
+        int t = p[pivot]; p[pivot] = p[end]; p[end] = t;
+        int low = begin;
+        for (int i = begin; i < end; ++i)
+            if (v[p[i]] - v[p[end]] <= 0.0f) { t = p[low]; p[low] = p[i]; p[i] = t; ++low; }
+        t = p[low]; p[low] = p[end]; p[end] = t;
+        if (low < end) { stack[sp++] = low + 1; stack[sp++] = end; }
+        if (low > begin) { stack[sp++] = begin; stack[sp++] = low - 1; }
+    }
+}
+
+struct LiopParams {
+    const float* patches;      // [n][41*41]
+    const int*   pix;          // [n_pix] offsets of the circular support (scan order)
+    const double* sx;          // [n_pix][4]
+    const double* sy;          // [n_pix][4]
+    uint32_t n, n_pix;
+    float* desc;               // [n][144]
+    uint32_t* n_tie_patches;   // statistics: patches that needed the exact re-sort
+};
+
+__global__ __launch_bounds__(64)
+void liop_kernel(const LiopParams P)
+{
+    __shared__ float patch[kLiopPix + 3];
+    __shared__ unsigned long long keys[kLiopSortCap];
+    __shared__ float inten[kLiopSortCap];            // intensities in scan order (for the exact re-sort)
+    __shared__ uint16_t perm[kLiopSortCap];
+    __shared__ int qstack[2 * kLiopSortCap + 8];
+    __shared__ uint32_t hist[144];
+    __shared__ float s_norm;
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t N = P.n_pix;
+    for (uint32_t item = blockIdx.x; item < P.n; item += gridDim.x) {
+        const float* src = P.patches + (size_t)item * kLiopPix;
+        for (uint32_t e = lane; e < (uint32_t)kLiopPix; e += 64) patch[e] = src[e];
+        for (uint32_t e = lane; e < 144; e += 64) hist[e] = 0;
+        __syncthreads();
+
+        // ---- 1. rank the support pixels by intensity
+        for (uint32_t i = lane; i < (uint32_t)kLiopSortCap; i += 64) {
+            if (i < N) { const float v = patch[P.pix[i]]; inten[i] = v; keys[i] = ((unsigned long long)float_order_bits(v) << 32) | i; }
+            else keys[i] = ~0ull;
+        }
+        __syncthreads();
+        for (uint32_t size = 2; size <= (uint32_t)kLiopSortCap; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = lane; t < (uint32_t)kLiopSortCap / 2; t += 64) {
+                    const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned long long x = keys[lo], y = keys[hi];
+                    if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+                }
+                __syncthreads();
+            }
+        bool tie = false;
+        for (uint32_t i = lane; i < N; i += 64) {
+            perm[i] = (uint16_t)(keys[i] & 0xFFFFu);
+            if (i + 1 < N) tie |= ((keys[i] >> 32) == (keys[i + 1] >> 32));
+        }
+        const bool any_tie = __ballot(tie) != 0ull;
+        __syncthreads();
+        const float vmin = inten[perm[0]], vmax = inten[perm[N - 1]];
+        if (vmin == vmax) {
+            // constant support: every weight is 0, the descriptor is 0 / max(0, 1e-12) = 0
+            for (uint32_t e = lane; e < 144; e += 64) P.desc[(size_t)item * 144 + e] = 0.0f;
+            __syncthreads();
+            continue;
+        }
+        if (any_tie) {
+            if (lane == 0) {
+                for (uint32_t i = 0; i < N; ++i) perm[i] = (uint16_t)i;
+                liop_ref_qsort(inten, perm, (int)N, qstack);
+                atomicAdd(P.n_tie_patches, 1u);
+            }
+            __syncthreads();
+        }
+        // threshold = -intensityThreshold * (max - min), all float (vl_liop.c:497-503)
+        const float thr = (float)(5.0 / 255) * (inten[perm[N - 1]] - inten[perm[0]]);
+
+        // ---- 2. per rank: bin, 4 bilinear samples, permutation index, weight
+        const uint32_t area = N / 6u;
+        for (uint32_t i = lane; i < N; i += 64) {
+            uint32_t bin = i / area; if (bin > 5u) bin = 5u;
+            const uint32_t p = perm[i];
+            float nv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double x = P.sx[4 * p + k], y = P.sy[4 * p + k];
+                const long xi = (long)x, yi = (long)y;
+                const long ix = (x >= 0 || (double)xi == x) ? xi : xi - 1;
+                const long iy = (y >= 0 || (double)yi == y) ? yi : yi - 1;
+                const double wx = x - ix, wy = y - iy;
+                double a = 0, b = 0, c = 0, d = 0;
+                const int L = kLiopSide;
+                if (ix >= 0 && iy >= 0) a = patch[ix + iy * L];
+                if (ix < L - 1 && iy >= 0) b = patch[ix + 1 + iy * L];
+                if (ix >= 0 && iy < L - 1) c = patch[ix + (iy + 1) * L];
+                if (ix < L - 1 && iy < L - 1) d = patch[ix + 1 + (iy + 1) * L];
+                nv[k] = (float)((1.0 - wy) * (a + (b - a) * wx) + wy * (c + (d - c) * wx));
+            }
+            // order of the 4 samples; without ties it is the unique ascending order
+            int np[4];
+            const bool ntie = nv[0] == nv[1] || nv[0] == nv[2] || nv[0] == nv[3] || nv[1] == nv[2] || nv[1] == nv[3] || nv[2] == nv[3];
+            if (!ntie) {
+                int rk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int r = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) r += (nv[u] < nv[k]);
+                    rk[k] = r;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) np[r] = (rk[0] == r) ? 0 : (rk[1] == r) ? 1 : (rk[2] == r) ? 2 : 3;
+            } else {
+                np[0] = 0; np[1] = 1; np[2] = 2; np[3] = 3;
+                liop_ref_qsort4(nv, np);
+            }
+            // lexicographic index of the permutation (Lehmer code)
+            const int c0 = (np[1] < np[0]) + (np[2] < np[0]) + (np[3] < np[0]);
+            const int c1 = (np[2] < np[1]) + (np[3] < np[1]);
+            const int c2 = (np[3] < np[2]);
+            const int index = c0 * 6 + c1 * 2 + c2;
+            uint32_t weight = 0;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a + 1; b < 4; ++b) weight += (nv[a] > nv[b] + thr || nv[b] > nv[a] + thr) ? 1u : 0u;
+            if (weight) atomicAdd(&hist[bin * 24u + (uint32_t)index], weight);
+        }
+        __syncthreads();
+
+        // ---- 3. normalisation: float running sum in index order, norm stored to float (vl_liop.c:567-575)
+        if (lane == 0) {
+            float norm = 0.0f;
+            for (int e = 0; e < 144; ++e) { const float v = (float)hist[e]; norm += v * v; }
+            const double r = sqrt((double)norm);
+            s_norm = (float)(r > 1e-12 ? r : 1e-12);
+        }
+        __syncthreads();
+        const float nrm = s_norm;
+        for (uint32_t e = lane; e < 144; e += 64) P.desc[(size_t)item * 144 + e] = (float)hist[e] / nrm;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
+                       uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches)
+{
+    if (n == 0) return hipSuccess;
+    LiopParams P{patches, pix, sx, sy, n, n_pix, desc, n_tie_patches};
+    const uint32_t grid = n < 65536u ? n : 65536u;
+    hipLaunchKernelGGL(liop_kernel, dim3(grid), dim3(64), 0, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace r3dm

@@ -97,6 +97,8 @@ struct r3dm_ctx {
     // scratch (grown on demand, reused across calls)
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
+    DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt;
+    uint32_t liop_npix = 0;
     r3dm_stats stats{};
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
 };
@@ -148,7 +150,8 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     for (auto& im : c->imgs) if (im) im->release();
     DevBuf* bufs[] = {&c->d_imgs, &c->d_pairs, &c->d_nn, &c->d_knn_idx, &c->d_knn_dist, &c->d_fb, &c->d_cnt, &c->d_out,
                       &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
-                      &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch};
+                      &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch,
+                      &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -743,6 +746,78 @@ extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint
     const uint64_t n = std::min<uint64_t>(cap, c->report.size());
     if (n) memcpy(out, c->report.data(), n * sizeof(r3dm_pair_report));
     return (int)std::min<uint64_t>(c->report.size(), 0x7FFFFFFF);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LIOP descriptor on patches
+// ------------------------------------------------------------------------------------------------
+// geometry of the 41x41 patch exactly as vl_liopdesc_new builds it (vl_liop.c:371-421): circular support
+// dx^2+dy^2 <= (long)((center - radius + 0.6)^2), 4 samples per pixel on a circle of radius 6 starting at
+// atan2(y, x); computed once on the host with the host libm (like the reference) and kept in HBM
+static int liop_prepare(r3dm_ctx* c)
+{
+    if (c->liop_npix) return R3DM_OK;
+    const int side = 41, center = (side - 1) / 2;
+    const double radius = 6.0, t = center - radius + 0.6;
+    const long t2 = (long)(t * t);
+    std::vector<int> pix;
+    for (int y = 0; y < side; ++y)
+        for (int x = 0; x < side; ++x) {
+            const long dx = x - center, dy = y - center;
+            if (x == 0 && y == 0) continue;
+            if (dx * dx + dy * dy <= t2) pix.push_back(x + y * side);
+        }
+    std::vector<double> sx(4 * pix.size()), sy(4 * pix.size());
+    const double dangle = 2 * M_PI / 4.0;
+    for (size_t i = 0; i < pix.size(); ++i) {
+        const double x = (pix[i] % side) - center, y = (pix[i] / side) - center;
+        const double angle0 = std::atan2(y, x);
+        for (int k = 0; k < 4; ++k) {
+            sx[4 * i + k] = x + radius * std::cos(angle0 + dangle * k) + center;
+            sy[4 * i + k] = y + radius * std::sin(angle0 + dangle * k) + center;
+        }
+    }
+    if (pix.size() > 1024) { c->err = "liop: support larger than the sort capacity"; return R3DM_ERR_UNSUPPORTED; }
+    R3DM_HIP(c, c->liop_pix.ensure(pix.size() * 4));
+    R3DM_HIP(c, c->liop_sx.ensure(sx.size() * 8));
+    R3DM_HIP(c, c->liop_sy.ensure(sy.size() * 8));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_pix.p, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_sx.p, sx.data(), sx.size() * 8, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_sy.p, sy.data(), sy.size() * 8, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    c->liop_npix = (uint32_t)pix.size();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_liop_describe_patches(r3dm_ctx* c, const float* patches, uint32_t n, uint32_t side, float* desc_out,
+                                          uint32_t* n_resorted)
+{
+    if (!c || (n && (!patches || !desc_out))) return R3DM_ERR_INVALID;
+    if (side != 41) { c->err = "liop: only the 41x41 patch of Regard3D (patchResolution 20) is supported"; return R3DM_ERR_UNSUPPORTED; }
+    R3DM_HIP(c, hipSetDevice(c->device));
+    int rc = liop_prepare(c);
+    if (rc != R3DM_OK) return rc;
+    if (n_resorted) *n_resorted = 0;
+    if (n == 0) return R3DM_OK;
+    const size_t in_bytes = (size_t)n * 41 * 41 * 4, out_bytes = (size_t)n * 144 * 4;
+    R3DM_HIP(c, c->liop_in.ensure(in_bytes));
+    R3DM_HIP(c, c->liop_out.ensure(out_bytes));
+    R3DM_HIP(c, c->liop_cnt.ensure(64));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_in.p, patches, in_bytes, hipMemcpyDefault, c->stream));
+    R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
+                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>()));
+    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(desc_out, c->liop_out.p, out_bytes, hipMemcpyDefault, c->stream));
+    uint32_t nt = 0;
+    R3DM_HIP(c, hipMemcpyAsync(&nt, c->liop_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_resorted) *n_resorted = nt;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_liop_kernel = ms;
+    return R3DM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -248,3 +248,21 @@ def test_filter_H_matches_oracle(ctx, oracle):
             assert np.linalg.norm(a - b) < 1e-9
             kept += 1
     assert kept == 3 and gh.num_matches > 1200
+
+
+def test_liop_kernel_bit_exact(ctx, oracle):
+    """LIOP on the GPU vs the reference routine (committed golden = output of the reference's own vl_liop.c;
+    live reference build when oracle/_ref travelled; restatement otherwise)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "liop_patches.npz"))
+    d, n_resorted = ctx.liop_describe_patches(z["patches"])
+    assert np.array_equal(d, z["ref_desc"])
+    assert n_resorted >= 3                                       # the quantised / half-flat patches took the exact re-sort
+    rng = np.random.default_rng(9)
+    from scipy.ndimage import gaussian_filter
+    P = np.stack([gaussian_filter(rng.random((41, 41)), 1.2).astype(np.float32) for _ in range(2000)])
+    P[:64] = np.round(P[:64] * 64) / 64
+    d, _ = ctx.liop_describe_patches(P)
+    exp = oracle.ref_liop(P) if oracle.ref_liop_lib() is not None else oracle.liop_describe(P)
+    assert np.array_equal(d, exp)
+    assert ctx.liop_describe_patches(P[:0])[0].shape == (0, 144)

@@ -37,3 +37,17 @@ vals = np.array([O.lib().orc_rng_u64(5489, I, J, it, at) for (I, J, it, at) in
 smp = np.stack([O.sample7(5489, 3, 5, it, np.arange(100, dtype=np.uint32)) for it in range(4)])
 np.savez_compressed(os.path.join(out, "rng_stream.npz"), u64=vals, sample7_pool100=smp)
 print("rng", vals, smp.tolist())
+
+# liop_patches.npz : 41x41 patches (smooth, textured, quantised with many equal intensities, half-flat, constant)
+# + the descriptors produced by the REFERENCE's own vl_liop.c (oracle/_ref/libref_liop.so).  Data only.
+from scipy.ndimage import gaussian_filter
+rng = np.random.default_rng(7)
+P = np.stack([gaussian_filter(rng.random((41, 41)), s).astype(np.float32) for s in (0.8, 1.2, 2.0, 3.0) for _ in range(6)])
+P[3] = np.round(P[3] * 16) / 16            # heavy ties
+P[9] = np.round(P[9] * 4) / 4
+P[14, :, :18] = 0.25                        # half flat
+P[20] = 0.5                                 # constant -> all-zero descriptor
+P[21] = np.float32(np.arange(41)[None, :] / 40.0) * np.ones((41, 1), np.float32)   # linear ramp
+ref = O.ref_liop(P)
+np.savez_compressed(os.path.join(out, "liop_patches.npz"), patches=P, ref_desc=ref)
+print("liop_patches.npz", P.shape, "norms", np.round(np.linalg.norm(ref, axis=1), 6)[[0, 3, 14, 20, 21]])
