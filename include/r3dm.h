@@ -132,6 +132,16 @@ int r3dm_knn2(r3dm_ctx* ctx, const void* dataset, uint32_t n_dataset, const void
 int r3dm_liop_describe_patches(r3dm_ctx* ctx, const float* patches, uint32_t n, uint32_t side, float* desc_out,
                                uint32_t* n_resorted);
 
+/* ---- descriptor extraction: keypoints -> LIOP descriptors ----
+ * The per-keypoint loop of Regard3DFeatures::extractLIOPFeatures (src/Regard3DFeatures.cpp:719-861; serial in the
+ * reference): for every keypoint a 41x41 patch by inverse affine warp (scale = size/41 * kpSizeFactor,
+ * angle = -90 - kp.angle, :768-803) + Gaussian blur sigma 1.2 (:807), then LIOP.  image: h x w floats (gray / 255,
+ * as R3DFeaturesThread.cpp:163-191 prepares it); keypoints: n x 4 floats (x, y, size, angle in degrees) as left by
+ * detectKeypoints (:574-684); kp_size_factor: getKpSizeFactor(detector) (:691-717, 8.0 for A-KAZE).
+ * desc_out: n x 144 floats.  patches_out (optional): n x 41 x 41 floats.  Host or device pointers. */
+int r3dm_extract_liop(r3dm_ctx* ctx, const float* image, uint32_t width, uint32_t height,
+                      const float* keypoints, uint32_t n, float kp_size_factor, float* desc_out, float* patches_out);
+
 /* ---- match graph (PairWiseMatches) ---- */
 uint64_t          r3dm_graph_num_pairs(const r3dm_graph* g);
 uint64_t          r3dm_graph_num_matches(const r3dm_graph* g);

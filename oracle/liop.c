@@ -158,3 +158,92 @@ int orc_liop_describe(const float* patches, int n, int side, float* desc)
     geom_free(g);
     return 0;
 }
+
+/* ---------------------------------------------------------------- patch extraction
+ * Regard3DFeatures::extractLIOPFeatures, /root/reference/src/Regard3DFeatures.cpp:768-808: per keypoint
+ * a 41x41 patch = cv::warpAffine(img, M, Size(41,41), INTER_LINEAR | WARP_INVERSE_MAP) followed by
+ * cv::GaussianBlur(patch, patch, Size(0,0), 1.2).  OpenCV 4.0 is an external dependency that is not in
+ * /root/reference and not in this image, so this sub-stage restates OpenCV's documented scalar code paths and
+ * its parity is UNPINNED:
+ *   warpAffine: M (float) -> double; fixed point with AB_BITS = 10, INTER_BITS = 5: adelta[x] = rint(M0*x*1024),
+ *     bdelta[x] = rint(M3*x*1024), X0 = rint((M1*y + M2)*1024) + 16, Y0 likewise; X = (X0 + adelta[x]) >> 5;
+ *     integer part X >> 5, fraction (X & 31)/32; bilinear weights from the 32x32 float table
+ *     {(1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy fx}; value = ((S00*w0 + S01*w1) + S10*w2) + S11*w3 in float;
+ *     BORDER_CONSTANT 0 for taps outside the image;
+ *   GaussianBlur: ksize = cvRound(1.2*4*2+1)|1 = 11, kernel k[i] = (float)exp(-0.5/sigma^2 * (i-5)^2) normalised
+ *     with a double sum of the float taps, row pass s = sum_{k=0..10} k[k]*S[x+k-5] in k order, column pass in the
+ *     symmetric form s = k[5]*S0 + sum_{j=1..5} k[5+j]*(S[+j] + S[-j]), BORDER_REFLECT_101, float throughout, no FMA.
+ * kps: n x 4 floats (x, y, size = diameter, angle in degrees) -- cv::KeyPoint as detectKeypoints leaves it. */
+
+static int reflect101(int p, int len)
+{
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+
+void orc_liop_affine(const float* kp, float kp_size_factor, float* M6)
+{
+    const int patchResolution = 20, patchSize = 41;
+    const float x = kp[0], y = kp[1];
+    const float angle = -90.0f - kp[3];
+    const float scale = kp[2] / (float)patchSize * kp_size_factor;
+    const float alpha = (float)(scale * cos(angle * M_PI / 180.0f));
+    const float beta = (float)(scale * sin(angle * M_PI / 180.0f));
+    const float trans_x = x - (float)patchResolution, trans_y = y - (float)patchResolution;
+    M6[0] = alpha; M6[1] = beta;
+    M6[2] = beta * trans_y + alpha * trans_x - beta * y + (1.0f - alpha) * x;
+    M6[3] = -beta; M6[4] = alpha;
+    M6[5] = alpha * trans_y - beta * trans_x + beta * x + (1.0f - alpha) * y;
+}
+
+int orc_liop_extract_patches(const float* image, int w, int h, const float* kps, int n, float kp_size_factor, float* patches)
+{
+    const int S = 41;
+    float kern[11];
+    {
+        const double scale2X = -0.5 / (1.2 * 1.2);
+        double sum = 0;
+        for (int i = 0; i < 11; ++i) { const double x = i - 5.0; kern[i] = (float)exp(scale2X * x * x); sum += kern[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 11; ++i) kern[i] = (float)(kern[i] * sum);
+    }
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < n; ++p) {
+        float Mf[6]; double M[6];
+        orc_liop_affine(kps + 4 * (size_t)p, kp_size_factor, Mf);
+        for (int k = 0; k < 6; ++k) M[k] = Mf[k];
+        float warped[41 * 41], rowp[41 * 41];
+        for (int y = 0; y < S; ++y) {
+            const int X0 = (int)lrint((M[1] * y + M[2]) * 1024) + 16;
+            const int Y0 = (int)lrint((M[4] * y + M[5]) * 1024) + 16;
+            for (int x = 0; x < S; ++x) {
+                const int X = (X0 + (int)lrint(M[0] * x * 1024)) >> 5;
+                const int Y = (Y0 + (int)lrint(M[3] * x * 1024)) >> 5;
+                int sx = X >> 5, sy = Y >> 5;
+                sx = sx > 32767 ? 32767 : (sx < -32768 ? -32768 : sx);            /* saturate_cast<short> */
+                sy = sy > 32767 ? 32767 : (sy < -32768 ? -32768 : sy);
+                const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+                const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                const float v0 = (sx >= 0 && sx < w && sy >= 0 && sy < h) ? image[(size_t)sy * w + sx] : 0.f;
+                const float v1 = (sx + 1 >= 0 && sx + 1 < w && sy >= 0 && sy < h) ? image[(size_t)sy * w + sx + 1] : 0.f;
+                const float v2 = (sx >= 0 && sx < w && sy + 1 >= 0 && sy + 1 < h) ? image[(size_t)(sy + 1) * w + sx] : 0.f;
+                const float v3 = (sx + 1 >= 0 && sx + 1 < w && sy + 1 >= 0 && sy + 1 < h) ? image[(size_t)(sy + 1) * w + sx + 1] : 0.f;
+                warped[y * S + x] = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+            }
+        }
+        for (int y = 0; y < S; ++y)
+            for (int x = 0; x < S; ++x) {
+                float s = kern[0] * warped[y * S + reflect101(x - 5, S)];
+                for (int k = 1; k < 11; ++k) s += kern[k] * warped[y * S + reflect101(x + k - 5, S)];
+                rowp[y * S + x] = s;
+            }
+        float* out = patches + (size_t)p * S * S;
+        for (int y = 0; y < S; ++y)
+            for (int x = 0; x < S; ++x) {
+                float s = kern[5] * rowp[y * S + x];
+                for (int j = 1; j <= 5; ++j) s += kern[5 + j] * (rowp[reflect101(y + j, S) * S + x] + rowp[reflect101(y - j, S) * S + x]);
+                out[y * S + x] = s;
+            }
+    }
+    return 0;
+}

@@ -103,6 +103,14 @@ def ref_liop(patches: np.ndarray) -> np.ndarray:
     return out
 
 
+def liop_extract_patches(image: np.ndarray, kps: np.ndarray, kp_size_factor: float = 8.0) -> np.ndarray:
+    image = np.ascontiguousarray(image, np.float32); kps = np.ascontiguousarray(kps, np.float32)
+    n = kps.shape[0]
+    out = np.zeros((n, 41, 41), np.float32)
+    lib().orc_liop_extract_patches(_p(image), image.shape[1], image.shape[0], _p(kps), n, C.c_float(kp_size_factor), _p(out))
+    return out
+
+
 def liop_describe(patches: np.ndarray) -> np.ndarray:
     patches = np.ascontiguousarray(patches, np.float32)
     n, side = patches.shape[0], patches.shape[1]

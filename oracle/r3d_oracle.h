@@ -150,6 +150,9 @@ void     orc_logcombi_tables(uint32_t n, uint32_t k_sample, float* logc_n /*n+1*
  * src/Regard3DFeatures.cpp:827).  patches: n x side x side floats, desc: n x 144 floats. */
 int orc_liop_describe(const float* patches, int n, int side, float* desc);
 int orc_liop_geometry(int side, int* n_pix, int* pix, double* sx, double* sy);
+/* patch extraction of extractLIOPFeatures (src/Regard3DFeatures.cpp:768-808): kps = n x (x, y, size, angle_deg) */
+void orc_liop_affine(const float* kp, float kp_size_factor, float* M6);
+int orc_liop_extract_patches(const float* image, int w, int h, const float* kps, int n, float kp_size_factor, float* patches);
 
 /* ---- file formats (src/keypointSet.hpp:49-67, src/R3DProject.cpp:854-871) ---- */
 int orc_save_matches(const char* path, int64_t n_pairs, const uint32_t* pairs,

@@ -23,7 +23,7 @@ EXPORTS = [
     "r3dm_match_pairs", "r3dm_filter_F", "r3dm_filter_H", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
-    "r3dm_compute_matches_dir", "r3dm_liop_describe_patches",
+    "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
 ]
 
 
@@ -67,6 +67,7 @@ def load_library():
     L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
     L.r3dm_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
     L.r3dm_liop_describe_patches.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32)]
+    L.r3dm_extract_liop.argtypes = [vp, vp, u32, u32, vp, u32, C.c_float, vp, vp]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
     L.r3dm_graph_num_pairs.argtypes = [vp]; L.r3dm_graph_num_pairs.restype = u64
     L.r3dm_graph_num_matches.argtypes = [vp]; L.r3dm_graph_num_matches.restype = u64
@@ -275,6 +276,17 @@ class Context:
         self._check(self._L.r3dm_liop_describe_patches(self._h, _ptr(patches), n, side, _ptr(out), C.byref(nt)),
                     "r3dm_liop_describe_patches")
         return out[:n], int(nt.value)
+
+    def extract_liop(self, image, keypoints, kp_size_factor: float = 8.0, want_patches: bool = False):
+        """image: [h, w] float32 gray/255; keypoints: [n, 4] float32 (x, y, size, angle_deg) -> desc [n, 144]"""
+        image = np.ascontiguousarray(image, np.float32) if isinstance(image, np.ndarray) else image.contiguous()
+        keypoints = np.ascontiguousarray(keypoints, np.float32)
+        n = keypoints.shape[0]
+        desc = np.zeros((max(n, 1), 144), np.float32)
+        patches = np.zeros((max(n, 1), 41, 41), np.float32) if want_patches else None
+        self._check(self._L.r3dm_extract_liop(self._h, _ptr(image), int(image.shape[1]), int(image.shape[0]), _ptr(keypoints), n,
+                                              kp_size_factor, _ptr(desc), _ptr(patches)), "r3dm_extract_liop")
+        return (desc[:n], patches[:n]) if want_patches else desc[:n]
 
     def filter_report(self):
         """per putative pair of the last filter_F call: (threshold_px, nfa, iterations, models, inliers)"""

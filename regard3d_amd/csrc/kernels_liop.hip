@@ -209,6 +209,79 @@ void liop_kernel(const LiopParams P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// patch extraction: cv::warpAffine(INTER_LINEAR | WARP_INVERSE_MAP, BORDER_CONSTANT 0) + cv::GaussianBlur(sigma 1.2,
+// 11 taps, BORDER_REFLECT_101) of extractLIOPFeatures (/root/reference/src/Regard3DFeatures.cpp:768-808), restated
+// from OpenCV 4.0's scalar code paths (OpenCV is external: this sub-stage is parity-unpinned).
+// One workgroup per keypoint; the 2x3 matrices are built on the host (float/double libm arithmetic of the
+// reference, lines 790-799).  Fixed-point source coordinates exactly like hal::warpAffine: 10 fractional bits,
+// rounded to 1/32 pixel, 32x32 table of float bilinear weights.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+
+__global__ __launch_bounds__(256)
+void liop_extract_patches_kernel(const float* __restrict__ image, int w, int h, const float* __restrict__ M6,
+                                 const float* __restrict__ kern /* 11 taps */, uint32_t n, float* __restrict__ patches)
+{
+    __shared__ float warped[kLiopPix];
+    __shared__ float rowp[kLiopPix];
+    const int S = kLiopSide;
+    for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        double M[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) M[k] = (double)M6[6 * (size_t)item + k];
+        for (int e = threadIdx.x; e < kLiopPix; e += 256) {
+            const int y = e / S, x = e % S;
+            const int X0 = (int)rint((M[1] * y + M[2]) * 1024) + 16;
+            const int Y0 = (int)rint((M[4] * y + M[5]) * 1024) + 16;
+            const int X = (X0 + (int)rint(M[0] * x * 1024)) >> 5;
+            const int Y = (Y0 + (int)rint(M[3] * x * 1024)) >> 5;
+            int sx = X >> 5, sy = Y >> 5;
+            sx = sx > 32767 ? 32767 : (sx < -32768 ? -32768 : sx);
+            sy = sy > 32767 ? 32767 : (sy < -32768 ? -32768 : sy);
+            const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+            const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+            const bool x0 = sx >= 0 && sx < w, x1 = sx + 1 >= 0 && sx + 1 < w, y0 = sy >= 0 && sy < h, y1 = sy + 1 >= 0 && sy + 1 < h;
+            const float v0 = (x0 && y0) ? image[(size_t)sy * w + sx] : 0.f;
+            const float v1 = (x1 && y0) ? image[(size_t)sy * w + sx + 1] : 0.f;
+            const float v2 = (x0 && y1) ? image[(size_t)(sy + 1) * w + sx] : 0.f;
+            const float v3 = (x1 && y1) ? image[(size_t)(sy + 1) * w + sx + 1] : 0.f;
+            warped[e] = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kLiopPix; e += 256) {
+            const int y = e / S, x = e % S;
+            float s = kern[0] * warped[y * S + reflect101(x - 5, S)];
+#pragma unroll
+            for (int k = 1; k < 11; ++k) s += kern[k] * warped[y * S + reflect101(x + k - 5, S)];
+            rowp[e] = s;
+        }
+        __syncthreads();
+        float* out = patches + (size_t)item * kLiopPix;
+        for (int e = threadIdx.x; e < kLiopPix; e += 256) {
+            const int y = e / S, x = e % S;
+            float s = kern[5] * rowp[e];
+#pragma unroll
+            for (int j = 1; j <= 5; ++j) s += kern[5 + j] * (rowp[reflect101(y + j, S) * S + x] + rowp[reflect101(y - j, S) * S + x]);
+            out[e] = s;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
+                               uint32_t n, float* patches)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = n < 65536u ? n : 65536u;
+    hipLaunchKernelGGL(liop_extract_patches_kernel, dim3(grid), dim3(256), 0, st, image, w, h, M6, kern, n, patches);
+    return hipGetLastError();
+}
+
 hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
                        uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches)
 {

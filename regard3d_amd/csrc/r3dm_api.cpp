@@ -97,7 +97,7 @@ struct r3dm_ctx {
     // scratch (grown on demand, reused across calls)
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
-    DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt;
+    DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     uint32_t liop_npix = 0;
     r3dm_stats stats{};
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
@@ -151,7 +151,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     DevBuf* bufs[] = {&c->d_imgs, &c->d_pairs, &c->d_nn, &c->d_knn_idx, &c->d_knn_dist, &c->d_fb, &c->d_cnt, &c->d_out,
                       &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
                       &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch,
-                      &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt};
+                      &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -814,6 +814,65 @@ extern "C" int r3dm_liop_describe_patches(r3dm_ctx* c, const float* patches, uin
     R3DM_HIP(c, hipMemcpyAsync(&nt, c->liop_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
     if (n_resorted) *n_resorted = nt;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_liop_kernel = ms;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_extract_liop(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height,
+                                 const float* keypoints, uint32_t n, float kp_size_factor, float* desc_out, float* patches_out)
+{
+    if (!c || !image || width == 0 || height == 0 || (n && (!keypoints || !desc_out))) return R3DM_ERR_INVALID;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    int rc = liop_prepare(c);
+    if (rc != R3DM_OK) return rc;
+    if (n == 0) return R3DM_OK;
+    // keypoints to the host (they may live in device memory), 2x3 inverse maps exactly as :786-799 computes them
+    std::vector<float> kp(4 * (size_t)n), M6(6 * (size_t)n);
+    R3DM_HIP(c, hipMemcpyAsync(kp.data(), keypoints, kp.size() * 4, hipMemcpyDefault, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    const int patchResolution = 20, patchSize = 41;
+    for (uint32_t k = 0; k < n; ++k) {
+        const float x = kp[4 * k], y = kp[4 * k + 1];
+        const float angle = -90.0f - kp[4 * k + 3];
+        const float scale = kp[4 * k + 2] / static_cast<float>(patchSize) * kp_size_factor;
+        const float alpha = scale * std::cos(angle * M_PI / 180.0f);
+        const float beta = scale * std::sin(angle * M_PI / 180.0f);
+        const float trans_x = x - static_cast<float>(patchResolution), trans_y = y - static_cast<float>(patchResolution);
+        float* m = &M6[6 * (size_t)k];
+        m[0] = alpha; m[1] = beta;  m[2] = beta * trans_y + alpha * trans_x - beta * y + (1.0f - alpha) * x;
+        m[3] = -beta; m[4] = alpha; m[5] = alpha * trans_y - beta * trans_x + beta * x + (1.0f - alpha) * y;
+    }
+    // cv::getGaussianKernel(11, 1.2, CV_32F)
+    float kern[11];
+    {
+        const double scale2X = -0.5 / (1.2 * 1.2);
+        double sum = 0;
+        for (int i = 0; i < 11; ++i) { const double xx = i - 5.0; kern[i] = (float)std::exp(scale2X * xx * xx); sum += kern[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 11; ++i) kern[i] = (float)(kern[i] * sum);
+    }
+    const size_t img_bytes = (size_t)width * height * 4, patch_bytes = (size_t)n * 41 * 41 * 4, out_bytes = (size_t)n * 144 * 4;
+    R3DM_HIP(c, c->liop_img.ensure(img_bytes));
+    R3DM_HIP(c, c->liop_M.ensure(M6.size() * 4));
+    R3DM_HIP(c, c->liop_kern.ensure(64));
+    R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
+    R3DM_HIP(c, c->liop_out.ensure(out_bytes));
+    R3DM_HIP(c, c->liop_cnt.ensure(64));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_img.p, image, img_bytes, hipMemcpyDefault, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_M.p, M6.data(), M6.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_kern.p, kern, sizeof(kern), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    R3DM_HIP(c, launch_liop_extract(c->stream, c->liop_img.as<float>(), (int)width, (int)height, c->liop_M.as<float>(),
+                                    c->liop_kern.as<float>(), n, c->liop_in.as<float>()));
+    R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
+                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>()));
+    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(desc_out, c->liop_out.p, out_bytes, hipMemcpyDefault, c->stream));
+    if (patches_out) R3DM_HIP(c, hipMemcpyAsync(patches_out, c->liop_in.p, patch_bytes, hipMemcpyDefault, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_liop_kernel = ms;

@@ -117,6 +117,8 @@ hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t wo
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
 size_t     filter_F_lds_bytes(uint32_t m_cap);
+hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
+                               uint32_t n, float* patches);
 hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
                        uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches);
 

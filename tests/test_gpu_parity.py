@@ -266,3 +266,22 @@ def test_liop_kernel_bit_exact(ctx, oracle):
     exp = oracle.ref_liop(P) if oracle.ref_liop_lib() is not None else oracle.liop_describe(P)
     assert np.array_equal(d, exp)
     assert ctx.liop_describe_patches(P[:0])[0].shape == (0, 144)
+
+
+def test_extract_liop_patches_and_descriptors(ctx, oracle):
+    """keypoints -> 41x41 warped + blurred patches -> LIOP: GPU vs the restatement (patch stage) and vs the
+    reference routine (LIOP stage), bit-exact, incl. keypoints whose patch leaves the image."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(31)
+    img = gaussian_filter(rng.random((600, 800)), 1.5).astype(np.float32)
+    img[200:260, 300:380] = 1.0                                             # saturated region -> equal intensities
+    n = 1500
+    kps = np.stack([rng.uniform(-5, 805, n), rng.uniform(-5, 605, n), rng.uniform(1.5, 12, n), rng.uniform(0, 360, n)], 1).astype(np.float32)
+    kps[:50, 0] = rng.uniform(310, 370, 50); kps[:50, 1] = rng.uniform(210, 250, 50); kps[:50, 2] = 2.0
+    desc, patches = ctx.extract_liop(img, kps, 8.0, want_patches=True)
+    exp_p = oracle.liop_extract_patches(img, kps, 8.0)
+    assert np.array_equal(patches, exp_p)
+    exp_d = oracle.ref_liop(exp_p) if oracle.ref_liop_lib() is not None else oracle.liop_describe(exp_p)
+    assert np.array_equal(desc, exp_d)
+    nrm = np.linalg.norm(desc.astype(np.float64), axis=1)
+    assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))

@@ -39,3 +39,22 @@ def test_liop_rotation_invariance_property(oracle):
     d0 = oracle.liop_describe(P)
     d1 = oracle.liop_describe(np.ascontiguousarray(np.rot90(P, 1, axes=(1, 2))))
     assert np.allclose(d0, d1, atol=2e-2)
+
+
+def test_patch_extraction_restatement_properties(oracle):
+    """OpenCV is not available, so the warp+blur restatement is checked by properties: identity-like warp
+    reproduces a Gaussian-blurred crop; out-of-image taps read 0; the Gaussian kernel sums to 1."""
+    from scipy.ndimage import correlate1d
+    rng = np.random.default_rng(2)
+    img = rng.random((200, 300)).astype(np.float32)
+    # size/41*factor = 1 and kp.angle = -90 -> angle 0: alpha = 1, beta = 0 -> pure translation by (x-20, y-20)
+    kps = np.array([[150.0, 100.0, 41.0 / 8.0, -90.0]], np.float32)
+    p = oracle.liop_extract_patches(img, kps, 8.0)[0]
+    crop = img[80:121, 130:171]
+    x = np.arange(11) - 5.0
+    k = np.exp(-0.5 / 1.44 * x * x).astype(np.float32); k = (k * (1.0 / k.astype(np.float64).sum())).astype(np.float32)
+    ref = correlate1d(correlate1d(crop.astype(np.float64), k.astype(np.float64), axis=1, mode="mirror"), k.astype(np.float64), axis=0, mode="mirror")
+    assert np.allclose(p, ref, atol=2e-6)
+    assert abs(float(k.sum()) - 1.0) < 1e-6
+    far = oracle.liop_extract_patches(img, np.array([[-500.0, -500.0, 5.0, 0.0]], np.float32), 8.0)[0]
+    assert np.all(far == 0)
