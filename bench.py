@@ -58,11 +58,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(a.gpus, 1) and rank == 0:
         print(f"# note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    # test hooks (CI on a 1-GPU box): R3DM_SHARE_GPU=1 maps every rank to cuda:0, R3DM_DIST_BACKEND=gloo exchanges
+    # the graphs through host tensors; the defaults are one GPU per rank and RCCL
+    if os.environ.get("R3DM_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("R3DM_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)          # RCCL
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        else:
+            td.init_process_group(backend)
 
     n_images = images_for(world, a.images)
     descs, xys, _ = synth.make_scene_torch(n_images, a.feat, seed=2002, device=dev)
@@ -79,7 +88,7 @@ def main():
         s_match = ctx.stats()
         gf = ctx.filter_F(g, 4.0, 2048, seed=5489)
         s_all = ctx.stats()
-        full = r3dist.all_gather_graphs([g, gf], device=dev)
+        full = r3dist.all_gather_graphs([g, gf], device=xdev)
         return g, gf, full, s_match, s_all
 
     def fence():
@@ -103,7 +112,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
 

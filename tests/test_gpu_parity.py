@@ -285,3 +285,25 @@ def test_extract_liop_patches_and_descriptors(ctx, oracle):
     assert np.array_equal(desc, exp_d)
     nrm = np.linalg.norm(desc.astype(np.float64), axis=1)
     assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))
+
+
+def test_knn2_random_shapes_sweep(ctx, oracle):
+    """Randomised sweep over sizes / descriptor lengths / value ranges (all tensor-kernel variants, the scalar-tail
+    exact path, integer and real-valued data, exact duplicates)."""
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        dim = int(rng.choice([3, 8, 31, 32, 61, 64, 65, 100, 127, 128, 129, 140, 144, 150, 200, 256, 300]))
+        nI = int(rng.integers(2, 700)); nJ = int(rng.integers(1, 500))
+        if trial % 3 == 0:
+            a = np.rint(rng.uniform(0, 255, (nI, dim))).astype(np.float32); b = np.rint(rng.uniform(0, 255, (nJ, dim))).astype(np.float32)
+        elif trial % 3 == 1:
+            a = rng.normal(0, 1, (nI, dim)).astype(np.float32); b = rng.normal(0, 1, (nJ, dim)).astype(np.float32)
+        else:
+            a = (rng.random((nI, dim)) * 1000).astype(np.float32); b = (rng.random((nJ, dim)) * 1000).astype(np.float32)
+        k = min(nI, nJ) // 3
+        if k:
+            b[:k] = a[rng.integers(0, nI, k)]                       # exact copies -> distance 0 and likely ties
+        idx, dist = ctx.knn2(a, b)
+        oidx, odist = oracle.knn2(a, b)
+        assert np.array_equal(dist, odist), (trial, dim, nI, nJ)
+        assert np.array_equal(idx, oidx), (trial, dim, nI, nJ)
