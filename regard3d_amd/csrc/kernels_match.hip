@@ -479,7 +479,9 @@ hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint
     }
     switch (G) {
         case 8:  return launch_l2_t<8, 2, 4, 3, 2>(st, P, max_nj_tiles);
-        case 18: return launch_l2_t<18, 2, 3, 0, 2>(st, P, max_nj_tiles);     // pipelined form spills at G = 18
+        case 18: return variant == 0 ? launch_l2_t<18, 2, 3, 0, 2>(st, P, max_nj_tiles)
+                       : variant == 2 ? launch_l2_t<18, 2, 2, 3, 2>(st, P, max_nj_tiles)
+                                      : launch_l2_t<18, 2, 3, 3, 2>(st, P, max_nj_tiles);
         case 32: return launch_l2_t<32, 1, 4, 3, 2>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }

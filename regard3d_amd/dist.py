@@ -35,16 +35,20 @@ def shard_pairs(pairs: np.ndarray, rank: int, world: int) -> np.ndarray:
 
 
 def _pack(g: api.Graph) -> np.ndarray:
+    """uint32 wire format: [P, M_lo, M_hi, pairs (2P), counts (P), matches (2M)] -- 8 B per match on the wire"""
     p, o, m = g.pairs, g.offsets, g.matches
-    head = np.array([p.shape[0], m.shape[0]], np.int64)
-    return np.concatenate([head, p.astype(np.int64).ravel(), o.astype(np.int64), m.astype(np.int64).ravel()])
+    M = int(m.shape[0])
+    head = np.array([p.shape[0], M & 0xFFFFFFFF, M >> 32], np.uint32)
+    counts = np.diff(o.astype(np.int64)).astype(np.uint32)
+    return np.concatenate([head, p.ravel(), counts, m.ravel()])
 
 
 def _unpack(buf: np.ndarray) -> api.Graph:
-    P, M = int(buf[0]), int(buf[1])
-    p = buf[2:2 + 2 * P].astype(np.uint32).reshape(-1, 2)
-    o = buf[2 + 2 * P:2 + 2 * P + P + 1].astype(np.uint64)
-    m = buf[3 + 3 * P:3 + 3 * P + 2 * M].astype(np.uint32).reshape(-1, 2)
+    P = int(buf[0]); M = int(buf[1]) | (int(buf[2]) << 32)
+    p = buf[3:3 + 2 * P].reshape(-1, 2)
+    counts = buf[3 + 2 * P:3 + 3 * P]
+    o = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
+    m = buf[3 + 3 * P:3 + 3 * P + 2 * M].reshape(-1, 2)
     return api.Graph.from_csr(p, o, m)
 
 
@@ -59,19 +63,20 @@ def all_gather_graphs(local: Sequence[api.Graph], device=None, group=None) -> Li
     world = dist.get_world_size(group)
     dev = torch.device(device) if device is not None else torch.device("cpu")
     packs = [_pack(g) for g in local]
-    head = np.array([len(packs)] + [p.size for p in packs], np.int64)
-    payload = torch.from_numpy(np.concatenate([head] + packs)).to(dev)
+    head = np.array([len(packs)] + [p.size for p in packs], np.uint32)
+    # torch has no uint32 collectives: ship the same bytes as int32
+    payload = torch.from_numpy(np.concatenate([head] + packs).view(np.int32)).to(dev)
     n = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)                       # 8 bytes per rank
     mx = int(max(int(s.item()) for s in sizes))
-    padded = torch.zeros(mx, dtype=torch.int64, device=dev)
+    padded = torch.zeros(mx, dtype=torch.int32, device=dev)
     padded[:payload.numel()] = payload
-    bufs = [torch.empty(mx, dtype=torch.int64, device=dev) for _ in range(world)]
+    bufs = [torch.empty(mx, dtype=torch.int32, device=dev) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)                   # the one payload exchange (RCCL over xGMI)
     per_graph: List[List[api.Graph]] = [[] for _ in local]
     for r in range(world):
-        buf = bufs[r][: int(sizes[r].item())].cpu().numpy()
+        buf = bufs[r][: int(sizes[r].item())].cpu().numpy().view(np.uint32)
         k = int(buf[0]); lens = buf[1:1 + k]; at = 1 + k
         for gi in range(k):
             per_graph[gi].append(_unpack(buf[at:at + int(lens[gi])])); at += int(lens[gi])

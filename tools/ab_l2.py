@@ -5,7 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from regard3d_amd import api, synth
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 48
-descs, xys, _ = synth.make_scene_torch(n_img, 8192, seed=2002, device="cuda")
+kind = sys.argv[2] if len(sys.argv) > 2 else "sift"
+if kind == "sift":
+    descs, xys, _ = synth.make_scene_torch(n_img, 8192, seed=2002, device="cuda")
+else:
+    sc = synth.make_scene(n_img, 8192, kind, seed=2002)
+    descs = [torch.from_numpy(d).cuda() for d in sc.descs]; xys = [torch.from_numpy(x).cuda() for x in sc.xys]
 c = api.Context(0)
 for i in range(n_img): c.set_image(i, descs[i], xys[i], 4000, 3000)
 ii, jj = np.triu_indices(n_img, k=1); pairs = np.stack([ii, jj], 1).astype(np.uint32)
@@ -13,4 +18,4 @@ res = []
 for rep in range(4):
     g = c.match_pairs(pairs, 0.6, True); s = c.stats()
     res.append(s.algorithmic_flops / (s.ms_match_kernels * 1e-3) / 1e12)
-print(json.dumps({"variant": os.environ.get("R3DM_L2_VARIANT", "default"), "pairs": len(pairs), "tflops": [round(x, 2) for x in res], "matches": g.num_matches, "fallback": s.n_exact_fallback}))
+print(json.dumps({"variant": os.environ.get("R3DM_L2_VARIANT", "default"), "pairs": len(pairs), "tflops": [round(x, 2) for x in res], "kind": kind, "matches": g.num_matches, "queries": s.n_queries, "fallback": s.n_exact_fallback}))
