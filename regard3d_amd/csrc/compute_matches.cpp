@@ -49,6 +49,32 @@ void graph_to_map(const r3dm_graph* g, PairWiseMatches& out)
         out.emplace(std::make_pair(p[2 * k], p[2 * k + 1]), MatchList(m + o[k], m + o[k + 1]));
 }
 
+// PairWiseMatchingToAdjacencyMatrixSVG (/root/reference/src/R3DComputeMatches.cpp:2074,2238; OpenMVG, external):
+// an N x N grid, 5 px per view, a blue square at (J, I) for every pair that kept matches, axis labels 0 / N.
+// Same geometry as upstream; the markup is not byte-identical to OpenMVG's svgDrawer output.
+bool write_adjacency_svg(const std::string& path, size_t n_views, const PairWiseMatches& m)
+{
+    if (m.empty()) return true;                             // upstream writes nothing for an empty map
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) return false;
+    const double s = 5.0;
+    const double wh = (n_views + 3) * s;
+    fprintf(f, "<?xml version=\"1.0\" standalone=\"yes\"?>\n<svg width=\"%g\" height=\"%g\" version=\"1.1\" "
+               "xmlns=\"http://www.w3.org/2000/svg\">\n", wh, wh);
+    for (const auto& kv : m) {
+        if (kv.second.empty()) continue;
+        fprintf(f, "<rect x=\"%g\" y=\"%g\" width=\"%g\" height=\"%g\" fill=\"blue\" stroke=\"none\">"
+                   "<title>(%u,%u %zu)</title></rect>\n",
+                kv.first.second * s, kv.first.first * s, s / 2.0, s / 2.0, kv.first.second, kv.first.first, kv.second.size());
+    }
+    fprintf(f, "<text x=\"%g\" y=\"%g\" font-size=\"%g\" fill=\"black\">0</text>\n", (n_views + 1) * s, s, s);
+    fprintf(f, "<text x=\"%g\" y=\"%g\" font-size=\"%g\" fill=\"black\">%zu</text>\n", (n_views + 1) * s, n_views * s - s, s, n_views);
+    fprintf(f, "<polyline points=\"%g,0 %g,%g 0,%g\" fill=\"none\" stroke=\"black\" stroke-width=\"1\"/>\n",
+            n_views * s, n_views * s, n_views * s, n_views * s);
+    fprintf(f, "</svg>\n");
+    return fclose(f) == 0;
+}
+
 std::string with_ext(const std::string& path, const char* ext)
 {
     const size_t dot = path.find_last_of('.');
@@ -69,7 +95,7 @@ void R3DComputeMatches::addViews(const std::vector<View>& views) { views_.insert
 
 void R3DComputeMatches::setRegionsType(r3dm_dtype dtype, uint32_t dim) { dtype_ = dtype; dim_ = dim; }
 
-bool R3DComputeMatches::computeMatches(R3DFParams& params, bool /*svgOutput*/, const R3DProjectPaths& paths,
+bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,
                                        int /*cameraModel*/, int matchingAlgorithm)
 {
     statistics_ = R3DComputeMatchesStatistics();
@@ -120,6 +146,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool /*svgOutput*/, c
         return false;
     }
 
+    if (svgOutput) write_adjacency_svg(dir + "/PutativeAdjacencyMatrix.svg", views_.size(), statistics_.putativeMatches_);   // :2074
+
     // ---- geometric filtering, fundamental matrix (:2113-2120): AC-RANSAC, 4.0 px upper bound, 2048 iterations
     if (params.computeFundalmentalMatrix_) {
         r3dm_graph* geo = nullptr;
@@ -143,6 +171,11 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool /*svgOutput*/, c
                         r3dm_save_matches(geo, with_ext(h_path, ".bin").c_str()) == R3DM_OK;
         r3dm_graph_free(geo);
         if (!ok) { errorMessage_ = "Cannot save computed matches in: " + h_path; r3dm_graph_free(putative); return false; }
+    }
+    // GeometricAdjacencyMatrix.svg (:2238): the reference draws whichever filter ran last (H, else F)
+    if (svgOutput) {
+        const PairWiseMatches& last = params.computeHomographyMatrix_ ? statistics_.homographyMatches_ : statistics_.fundamentalMatches_;
+        write_adjacency_svg(dir + "/GeometricAdjacencyMatrix.svg", views_.size(), last);
     }
     // essential-matrix filter (:2130-2204): not implemented this round -- computeEssentialMatrix_ is ignored and
     // statistics_.essentialMatches_ stays empty; OpenMVG's CPU filter can still be run on

@@ -78,6 +78,16 @@ def test_stage_facade_writes_the_reference_files(host_exe, oracle, tmp_path):
         p, c, m = oracle.load_matches(str(tmp_path / f"matches.putative.{ext}"))
         assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
     assert n_put == int((counts > 0).sum())
+    p_h, c_h, m_h = oracle.load_matches(str(tmp_path / "matches.h.txt"))          # homography filter ran too
+    oh, omh = oracle.filter_H_collection(sc.xys, sc.widths, sc.heights, pairs, counts, matches, 4.0, 2048, 5489)
+    assert np.array_equal(p_h, pairs[oh > 0]) and np.array_equal(c_h, oh[oh > 0])
+    # adjacency SVGs: putative always; the geometric one shows the LAST filter (H) and, like upstream, is not
+    # written for an empty map (a relief scene has no dominant plane, so H may keep nothing)
+    svgs = ["PutativeAdjacencyMatrix.svg"] + (["GeometricAdjacencyMatrix.svg"] if (oh > 0).any() else [])
+    for svg in svgs:
+        txt = open(str(tmp_path / svg)).read()
+        assert txt.startswith("<?xml") and txt.count("<rect") >= 1 and txt.rstrip().endswith("</svg>")
+    assert os.path.exists(str(tmp_path / "GeometricAdjacencyMatrix.svg")) == bool((oh > 0).any())
     oc, om = oracle.filter_F_collection(sc.xys, sc.widths, sc.heights, pairs, counts, matches, 4.0, 2048, 5489)
     p, c, m = oracle.load_matches(str(tmp_path / "matches.f.txt"))
     assert np.array_equal(p, pairs[oc > 0]) and np.array_equal(c, oc[oc > 0]) and n_f == int((oc > 0).sum())
