@@ -122,6 +122,36 @@ int r3dm_filter_report(const r3dm_ctx* ctx, r3dm_pair_report* out, uint64_t cap)
 int r3dm_knn2(r3dm_ctx* ctx, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
               uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist);
 
+/* ---- approximate matching: the KGraph plugin path (BASELINE config C5) ----
+ * Replaces kgraph_match (src/R3DComputeMatches.cpp:808-902): per first view I an index over its descriptors
+ * (ArrayMatcher_kgraph::Build, src/utils/matcher_kgraph.h:138-153), per query row of J a graph search for its 2
+ * nearest rows (SearchNeighbours, :204-251 -> KGraphImpl::search, src/thirdparty/kgraph/kgraph.cpp:411-552), then
+ * the same ratio test / de-duplication / pair rules as r3dm_match_pairs.  F32 (and U8) descriptors with
+ * dim % 4 == 0 only, squared-L2 metric (kgraph_match constructs its matcher with b_squared_metric = true, :842).
+ * The index is the exact index_K-nearest-neighbour graph completed with reverse edges (DESIGN.md "ANN"); it is
+ * built on first use and cached with the view.  Views with fewer than 128 rows are matched exhaustively.
+ * Results are deterministic: they depend on (descriptors, parameters, view ids) only. */
+typedef struct {
+    uint32_t index_K;    /* forward neighbours per row, 1..32  (reference: IndexParams K/L, presets 2/20 .. 16/24) */
+    uint32_t search_P;   /* random start rows per query, 2..61 (reference: SearchParams P, presets 2 / 6 / 12 / 10) */
+    uint32_t search_S;   /* neighbours expanded per step, 1..16 (reference: SearchParams S, default 10)              */
+    uint32_t reserved;
+    uint64_t seed;       /* start-row stream (reference: SearchParams seed, 1998)                                    */
+} r3dm_kgraph_params;
+/* preset = matchingAlgorithm of the reference: 0 "KGraph fast", 1 "medium", 2 "precise", anything else its default
+ * block (src/R3DComputeMatches.cpp:844-873) */
+int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out);
+int r3dm_match_pairs_kgraph(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                            const r3dm_kgraph_params* params, r3dm_graph** out);
+/* ArrayMatcher_kgraph-shaped call: index `dataset`, 2 approximate nearest rows of every query row.  pair_i / pair_j
+ * key the start-row stream (view ids in r3dm_match_pairs_kgraph).  out_idx -1 / out_dist +inf where the search
+ * found fewer than two rows. */
+int r3dm_kgraph_knn2(r3dm_ctx* ctx, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
+                     uint32_t dim, const r3dm_kgraph_params* params, uint32_t pair_i, uint32_t pair_j,
+                     int32_t* out_idx, float* out_dist);
+/* the index of a registered view (built if necessary): adj_out = n x 64 rows (0xFFFFFFFF padded), deg_out = n */
+int r3dm_kgraph_index(r3dm_ctx* ctx, uint32_t view_id, uint32_t index_K, uint32_t* adj_out, uint32_t* deg_out);
+
 /* ---- descriptor extraction: LIOP on pre-extracted patches ----
  * r3d_vl_liopdesc_process of the vendored VLFeat copy (src/thirdparty/liop/vl_liop.c:465-580) as Regard3D
  * calls it per keypoint (src/Regard3DFeatures.cpp:727-752,827: new_basic(41) -> 4 neighbours, 6 bins, radius 6):
@@ -174,6 +204,11 @@ typedef struct {
     double   ms_wall_match_post;   /* of which: exact scans + finalisation + copies back + assembly */
     double   ms_wall_filter;       /* whole r3dm_filter_F call                                      */
     double   ms_liop_kernel;       /* HIP-event time of the last r3dm_liop_describe_patches kernel  */
+    /* r3dm_match_pairs_kgraph */
+    double   ms_ann_build;         /* HIP-event time of the index builds triggered by the call      */
+    double   ms_ann_search;        /* HIP-event time of the search kernel                           */
+    uint64_t n_ann_built;          /* indices built by the call                                     */
+    uint64_t n_ann_dist;           /* descriptor distances evaluated by the searches                */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -154,37 +154,23 @@ static int cmp_coord(const void* pa, const void* pb)
     return a->pos < b->pos ? -1 : (a->pos > b->pos ? 1 : 0);
 }
 
-int orc_match_distance_ratio(int dtype, const void* descI, int nI, const float* xyI,
-                             const void* descJ, int nJ, const float* xyJ, int dim,
-                             float dist_ratio, int squared_metric, orc_match* out)
+/* NNdistanceRatio + both de-duplications on a precomputed 2-NN table (shared by the brute-force and the ANN drivers).
+ * dist_is_u32: Hamming distances (converted to float first). */
+static int ratio_and_dedup(const int32_t* idx, const void* dist, int dist_is_u32, int nJ,
+                           const float* xyI, const float* xyJ, float R, orc_match* out)
 {
-    /* RegionsMatcherT::MatchDistanceRatio returns at once when either side is empty; the
-     * brute-force SearchNeighbours fails (-> no matches) when NN=2 > nI. */
-    if (nI < 2 || nJ < 1) return 0;
-
-    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nJ);
-    void* dist = malloc(sizeof(float) * 2 * (size_t)nJ);
-    int rc;
-    if (dtype == 0)      rc = orc_knn2_l2_f32((const float*)descI, nI, (const float*)descJ, nJ, dim, idx, (float*)dist);
-    else if (dtype == 1) rc = orc_knn2_l2_u8((const uint8_t*)descI, nI, (const uint8_t*)descJ, nJ, dim, idx, (float*)dist);
-    else                 rc = orc_knn2_hamming((const uint8_t*)descI, nI, (const uint8_t*)descJ, nJ, dim, idx, (uint32_t*)dist);
-    if (rc != 0) { free(idx); free(dist); return 0; }
-
-    /* NNdistanceRatio: keep q iff dist[2q] < R * dist[2q+1], R = ratio^2 for squared metrics.
-     * All arithmetic in float (Hamming distances are converted to float first). */
-    const float R = squared_metric ? dist_ratio * dist_ratio : dist_ratio;
+    /* keep q iff dist[2q] < R * dist[2q+1], R = ratio^2 for squared metrics.  All arithmetic in float. */
     int m = 0;
     for (int q = 0; q < nJ; ++q) {
         float a, b;
-        if (dtype == 2) { a = (float)((uint32_t*)dist)[2 * q]; b = (float)((uint32_t*)dist)[2 * q + 1]; }
-        else            { a = ((float*)dist)[2 * q];           b = ((float*)dist)[2 * q + 1]; }
+        if (dist_is_u32) { a = (float)((const uint32_t*)dist)[2 * q]; b = (float)((const uint32_t*)dist)[2 * q + 1]; }
+        else             { a = ((const float*)dist)[2 * q];           b = ((const float*)dist)[2 * q + 1]; }
         if (a < R * b) {
             out[m].i = (uint32_t)idx[2 * q];   /* row of I (dataset) */
             out[m].j = (uint32_t)q;            /* row of J (query)   */
             ++m;
         }
     }
-    free(idx); free(dist);
 
     /* IndMatch::getDeduplicated: sort by (i_, j_) + unique (q is unique, so nothing drops). */
     qsort(out, (size_t)m, sizeof(orc_match), cmp_match);
@@ -210,6 +196,33 @@ int orc_match_distance_ratio(int dtype, const void* descI, int nI, const float* 
         m = w;
         free(drop); free(ck);
     }
+    return m;
+}
+
+int orc_ratio_dedup_f32(const int32_t* idx, const float* dist, int nJ, const float* xyI, const float* xyJ,
+                        float dist_ratio, int squared_metric, orc_match* out)
+{
+    return ratio_and_dedup(idx, dist, 0, nJ, xyI, xyJ, squared_metric ? dist_ratio * dist_ratio : dist_ratio, out);
+}
+
+int orc_match_distance_ratio(int dtype, const void* descI, int nI, const float* xyI,
+                             const void* descJ, int nJ, const float* xyJ, int dim,
+                             float dist_ratio, int squared_metric, orc_match* out)
+{
+    /* RegionsMatcherT::MatchDistanceRatio returns at once when either side is empty; the
+     * brute-force SearchNeighbours fails (-> no matches) when NN=2 > nI. */
+    if (nI < 2 || nJ < 1) return 0;
+
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nJ);
+    void* dist = malloc(sizeof(float) * 2 * (size_t)nJ);
+    int rc;
+    if (dtype == 0)      rc = orc_knn2_l2_f32((const float*)descI, nI, (const float*)descJ, nJ, dim, idx, (float*)dist);
+    else if (dtype == 1) rc = orc_knn2_l2_u8((const uint8_t*)descI, nI, (const uint8_t*)descJ, nJ, dim, idx, (float*)dist);
+    else                 rc = orc_knn2_hamming((const uint8_t*)descI, nI, (const uint8_t*)descJ, nJ, dim, idx, (uint32_t*)dist);
+    if (rc != 0) { free(idx); free(dist); return 0; }
+    const float R = squared_metric ? dist_ratio * dist_ratio : dist_ratio;
+    const int m = ratio_and_dedup(idx, dist, dtype == 2, nJ, xyI, xyJ, R, out);
+    free(idx); free(dist);
     return m;
 }
 

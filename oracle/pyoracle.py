@@ -29,7 +29,7 @@ class FResult(C.Structure):
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "r3d_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "kgraph.c", "r3d_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -54,6 +54,13 @@ def lib():
         L.orc_rng_u64.restype = C.c_uint64
         L.orc_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_sym_epipolar_err.restype = C.c_double
+        L.orc_kgraph_build_exact.restype = C.c_void_p
+        L.orc_kgraph_build_nndescent.restype = C.c_void_p
+        L.orc_kgraph_free.argtypes = [C.c_void_p]
+        L.orc_kgraph_size.argtypes = [C.c_void_p]; L.orc_kgraph_size.restype = C.c_uint32
+        L.orc_kgraph_edges.argtypes = [C.c_void_p]; L.orc_kgraph_edges.restype = C.c_uint64
+        L.orc_kgraph_export.argtypes = [C.c_void_p] * 4
+        L.orc_match_collection_kgraph.restype = C.c_int64
         L.orc_sym_epipolar_err.argtypes = [C.c_void_p] + [C.c_double] * 4
         _LIB = L
     return _LIB
@@ -323,3 +330,88 @@ def load_matches(path):
     if rc != 0:
         raise IOError(rc)
     return pairs, counts, matches[:nm.value].copy()
+
+
+# ---- KGraph plugin path (oracle/kgraph.c) -------------------------------------------------------
+KGRAPH_PRESETS = {          # src/R3DComputeMatches.cpp:844-873: (K, L, recall, P)
+    "fast": (2, 20, 0.6, 2), "medium": (16, 24, 0.2, 6), "precise": (16, 24, 0.8, 12), "default": (16, 24, 0.99, 10),
+}
+
+
+class KGraphIndex:
+    """owning handle of an orc_kgraph (CSR: off[n+1], ids, dist)"""
+
+    def __init__(self, handle, data):
+        if not handle:
+            raise RuntimeError("index build failed (too few rows?)")
+        self.h = C.c_void_p(handle)
+        self.data = data
+
+    def __del__(self):
+        try:
+            lib().orc_kgraph_free(self.h)
+        except Exception:
+            pass
+
+    def csr(self):
+        n = lib().orc_kgraph_size(self.h); e = lib().orc_kgraph_edges(self.h)
+        off = np.zeros(n + 1, np.uint64); ids = np.zeros(max(e, 1), np.uint32); dist = np.zeros(max(e, 1), np.float32)
+        lib().orc_kgraph_export(self.h, _p(off), _p(ids), _p(dist))
+        return off, ids[:e], dist[:e]
+
+    def knn2(self, query, P=10, S=10, seed=1998, I=0, J=1, min_rows=0):
+        query = np.ascontiguousarray(query, np.float32)
+        nq = query.shape[0]
+        idx = np.zeros((nq, 2), np.int32); dist = np.zeros((nq, 2), np.float32); comps = C.c_uint64(0)
+        rc = lib().orc_kgraph_knn2(self.h, _p(self.data), self.data.shape[1], _p(query), nq, P, S, C.c_uint64(seed), I, J,
+                                   min_rows, _p(idx), _p(dist), C.byref(comps))
+        if rc != 0:
+            raise RuntimeError("orc_kgraph_knn2 failed")
+        return idx, dist, comps.value
+
+
+def kgraph_build_exact(data, K=16, cap=64) -> KGraphIndex:
+    data = np.ascontiguousarray(data, np.float32)
+    return KGraphIndex(lib().orc_kgraph_build_exact(_p(data), data.shape[0], data.shape[1], K, cap), data)
+
+
+def kgraph_build_nndescent(data, K=16, L=24, recall=0.99, S=10, R=100, iterations=30, delta=0.002, controls=100, seed=1998):
+    data = np.ascontiguousarray(data, np.float32)
+    info = np.zeros(4, np.float32)
+    h = lib().orc_kgraph_build_nndescent(_p(data), data.shape[0], data.shape[1], K, L, S, R, iterations,
+                                         C.c_float(recall), C.c_float(delta), controls, seed, _p(info))
+    g = KGraphIndex(h, data)
+    g.info = dict(iterations=int(info[0]), recall=float(info[1]), delta=float(info[2]), cost=float(info[3]))
+    return g
+
+
+def kgraph_seeds(seed, I, J, q, n, P):
+    out = np.zeros(P, np.uint32)
+    lib().orc_kgraph_seeds(C.c_uint64(seed), I, J, q, n, P, _p(out))
+    return out
+
+
+def match_collection_kgraph(descs, xys, pairs, ratio, builder="exact", K=16, L=24, recall=0.99, cap=64, P=10, S=10,
+                            seed=1998, min_rows=0):
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    n_img = len(descs)
+    descs = [np.ascontiguousarray(d, np.float32) for d in descs]
+    dim = descs[0].shape[1]
+    desc_p = (C.c_void_p * n_img)(*[d.ctypes.data for d in descs])
+    n_rows = np.array([d.shape[0] for d in descs], np.int32)
+    if xys is not None:
+        xys = [np.ascontiguousarray(x, np.float32) for x in xys]
+        xy_p = (C.c_void_p * n_img)(*[x.ctypes.data for x in xys])
+    else:
+        xy_p = None
+    counts = np.zeros(len(pairs), np.uint32)
+    cap_out = int(sum(int(n_rows[j]) for j in pairs[:, 1])) + 1
+    out = np.zeros((cap_out, 2), np.uint32)
+    comps = C.c_uint64(0)
+    tot = lib().orc_match_collection_kgraph(n_img, desc_p, _p(n_rows), xy_p, dim, _p(pairs), C.c_int64(len(pairs)),
+                                            C.c_float(ratio), 0 if builder == "exact" else 1, K, L, C.c_float(recall), cap,
+                                            P, S, C.c_uint64(seed), min_rows, _p(counts), _p(out), C.c_int64(cap_out),
+                                            C.byref(comps))
+    if tot < 0:
+        raise RuntimeError("orc_match_collection_kgraph: output capacity")
+    return counts, out[:tot].copy(), comps.value

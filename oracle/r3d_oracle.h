@@ -74,6 +74,10 @@ int orc_match_distance_ratio(int dtype, const void* descI, int nI, const float* 
                              const void* descJ, int nJ, const float* xyJ, int dim,
                              float dist_ratio, int squared_metric, orc_match* out);
 
+/* The ratio test + de-duplications alone, on a 2-NN table computed elsewhere (the ANN drivers). */
+int orc_ratio_dedup_f32(const int32_t* idx, const float* dist, int nJ, const float* xyI, const float* xyJ,
+                        float dist_ratio, int squared_metric, orc_match* out);
+
 /* ---- collection matcher: the reference loop nest (src/R3DComputeMatches.cpp:428-489).
  * images: arrays of length n_images.  pairs: n_pairs x 2 (I,J).  Results are returned in a
  * CSR over the INPUT pair order: counts[p] matches for pair p, concatenated in `out`
@@ -164,6 +168,33 @@ int orc_save_feat(const char* path, int n, const float* xyso /* n x 4: x y scale
 int orc_load_feat(const char* path, int* n, float* xyso, int cap);
 int orc_save_desc(const char* path, uint64_t n, size_t row_bytes, const void* data);
 int orc_load_desc(const char* path, uint64_t* n, size_t row_bytes, void* data, uint64_t cap);
+
+/* ---- KGraph plugin path (config C5): oracle/kgraph.c.  src/thirdparty/kgraph/kgraph.cpp:411-552 (search),
+ * :703-997 (NN-descent), :660-700 (reverse), src/utils/matcher_kgraph.h, src/R3DComputeMatches.cpp:808-902. */
+typedef struct orc_kgraph orc_kgraph;
+orc_kgraph* orc_kgraph_build_nndescent(const float* data, uint32_t n, uint32_t dim,
+                                       uint32_t K, uint32_t L, uint32_t S, uint32_t R, uint32_t iterations,
+                                       float recall_target, float delta_target, uint32_t n_controls, uint32_t seed,
+                                       float* info);
+orc_kgraph* orc_kgraph_build_exact(const float* data, uint32_t n, uint32_t dim, uint32_t K, uint32_t cap);
+void     orc_kgraph_free(orc_kgraph* g);
+uint32_t orc_kgraph_size(const orc_kgraph* g);
+uint64_t orc_kgraph_edges(const orc_kgraph* g);
+void     orc_kgraph_export(const orc_kgraph* g, uint64_t* off, uint32_t* ids, float* dist);
+void     orc_kgraph_seeds(uint64_t seed, uint32_t I, uint32_t J, uint32_t q, uint32_t n, uint32_t P, uint32_t* out);
+uint32_t orc_kgraph_search(const orc_kgraph* g, const float* data, uint32_t dim, const float* query,
+                           uint32_t K, uint32_t P, uint32_t S, const uint32_t* seeds, uint32_t min_rows,
+                           uint32_t* ids, float* dists, uint32_t* n_comps_out);
+int      orc_kgraph_knn2(const orc_kgraph* g, const float* data, uint32_t dim, const float* query, uint32_t nq,
+                         uint32_t P, uint32_t S, uint64_t seed, uint32_t I, uint32_t J, uint32_t min_rows,
+                         int32_t* idx, float* dist, uint64_t* n_comps);
+/* kgraph_match (src/R3DComputeMatches.cpp:808-902): f32 descriptors; builder 0 = exact index (cap closest edges),
+ * 1 = NN-descent with (K, L, recall) of a preset.  Same CSR convention as orc_match_collection. */
+int64_t  orc_match_collection_kgraph(int n_images, const float* const* desc, const int* n_rows,
+                                     const float* const* xy, int dim, const uint32_t* pairs, int64_t n_pairs,
+                                     float dist_ratio, int builder, uint32_t K, uint32_t L, float recall, uint32_t cap,
+                                     uint32_t P, uint32_t S, uint64_t seed, uint32_t min_rows,
+                                     uint32_t* counts, orc_match* out, int64_t out_cap, uint64_t* n_comps);
 
 #ifdef __cplusplus
 }

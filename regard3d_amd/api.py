@@ -24,6 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
+    "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
 ]
 
 
@@ -36,7 +37,24 @@ class Stats(C.Structure):
                 ("ms_filter_kernels", C.c_double), ("n_pairs", C.c_uint64), ("n_queries", C.c_uint64),
                 ("n_exact_fallback", C.c_uint64), ("algorithmic_flops", C.c_double),
                 ("algorithmic_bytes", C.c_double), ("ms_wall_match", C.c_double),
-                ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double), ("ms_liop_kernel", C.c_double)]
+                ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double), ("ms_liop_kernel", C.c_double),
+                ("ms_ann_build", C.c_double), ("ms_ann_search", C.c_double), ("n_ann_built", C.c_uint64),
+                ("n_ann_dist", C.c_uint64)]
+
+
+class KGraphParams(C.Structure):
+    """r3dm_kgraph_params: index_K forward neighbours per row, search_P start rows, search_S neighbours per step."""
+    _fields_ = [("index_K", C.c_uint32), ("search_P", C.c_uint32), ("search_S", C.c_uint32), ("reserved", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+    @staticmethod
+    def preset(which) -> "KGraphParams":
+        """which: 0 / "fast", 1 / "medium", 2 / "precise", anything else the reference's default block"""
+        code = {"fast": 0, "medium": 1, "precise": 2}.get(which, which if isinstance(which, int) else 3)
+        kp = KGraphParams()
+        if load_library().r3dm_kgraph_preset(int(code), C.byref(kp)) != 0:
+            raise R3dmError("r3dm_kgraph_preset failed")
+        return kp
 
 
 class PairReport(C.Structure):
@@ -69,6 +87,10 @@ def load_library():
     L.r3dm_liop_describe_patches.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32)]
     L.r3dm_extract_liop.argtypes = [vp, vp, u32, u32, vp, u32, C.c_float, vp, vp]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
+    L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]
+    L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
+    L.r3dm_kgraph_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, u32, u32, vp, vp]
+    L.r3dm_kgraph_index.argtypes = [vp, u32, u32, vp, vp]
     L.r3dm_graph_num_pairs.argtypes = [vp]; L.r3dm_graph_num_pairs.restype = u64
     L.r3dm_graph_num_matches.argtypes = [vp]; L.r3dm_graph_num_matches.restype = u64
     L.r3dm_graph_pairs.argtypes = [vp]; L.r3dm_graph_pairs.restype = vp
@@ -238,6 +260,30 @@ class Context:
         self._check(self._L.r3dm_match_pairs(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0],
                                              dist_ratio, int(squared_metric), C.byref(h)), "r3dm_match_pairs")
         return Graph(h.value)
+
+    def match_pairs_kgraph(self, pairs, dist_ratio: float = 0.6, params: "KGraphParams" = None) -> Graph:
+        """kgraph_match: approximate 2-NN through a per-view graph index (config C5)"""
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        kp = params if params is not None else KGraphParams.preset(3)
+        h = C.c_void_p()
+        self._check(self._L.r3dm_match_pairs_kgraph(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0], dist_ratio,
+                                                    C.addressof(kp), C.byref(h)), "r3dm_match_pairs_kgraph")
+        return Graph(h.value)
+
+    def kgraph_knn2(self, dataset, query, params: "KGraphParams" = None, pair=(0, 1)):
+        dataset = np.ascontiguousarray(dataset, np.float32); query = np.ascontiguousarray(query, np.float32)
+        kp = params if params is not None else KGraphParams.preset(3)
+        nq = query.shape[0]
+        idx = np.full((max(nq, 1), 2), -1, np.int32); dist = np.zeros((max(nq, 1), 2), np.float32)
+        self._check(self._L.r3dm_kgraph_knn2(self._h, _ptr(dataset), dataset.shape[0], _ptr(query), nq, dataset.shape[1],
+                                             C.addressof(kp), pair[0], pair[1], _ptr(idx), _ptr(dist)), "r3dm_kgraph_knn2")
+        return idx[:nq], dist[:nq]
+
+    def kgraph_index(self, view_id: int, n_rows: int, index_K: int = 24):
+        """-> (adj [n, 64] uint32 padded with 0xFFFFFFFF, deg [n] uint32) of a registered view"""
+        adj = np.zeros((n_rows, 64), np.uint32); deg = np.zeros(n_rows, np.uint32)
+        self._check(self._L.r3dm_kgraph_index(self._h, view_id, index_K, _ptr(adj), _ptr(deg)), "r3dm_kgraph_index")
+        return adj, deg
 
     def filter_F(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489,
                  want_F: bool = False):

@@ -28,7 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(1))) f32x4* gf4p;
 typedef const __attribute__((address_space(1))) float* gf1p;
 
-#define R3DM_INF __builtin_huge_valf()
 
 // ------------------------------------------------------------------------------------------------
 // staging: raw row-major descriptors -> rows (f32) + MFMA fragment-order tiles + norms

@@ -35,6 +35,47 @@ struct ImgDev {
     uint32_t max_norm_bits;    // float bits of max ||row||^2 (filled by the staging kernel)
     uint32_t max_abs_bits;     // float bits of max |element|   (filled by the staging kernel)
     uint32_t not_integer;      // != 0 if some element is not an integer (filled by the staging kernel)
+    // graph index of the view (kernels_ann.hip), nullptr until r3dm_match_pairs_kgraph builds it
+    const uint32_t* ann_adj;   // [n][kAnnDeg] neighbour rows ordered by (distance, id), kNone padded
+    const uint32_t* ann_deg;   // [n] valid entries of each adjacency row
+};
+#ifndef R3DM_INF
+#define R3DM_INF __builtin_huge_valf()
+#endif
+constexpr uint32_t kAnnDeg = 64;        // adjacency slots per row
+constexpr uint32_t kAnnMaxK = 32;       // forward (exact nearest) neighbours per row
+constexpr uint32_t kAnnMinRows = 128;   // views with fewer rows are matched exhaustively
+
+struct AnnBuildJob {
+    uint32_t slot;
+    unsigned long long* fwd;      // [n][K] keys (distance bits << 32 | row), ascending, ~0 padded
+    uint32_t* rev_cnt;            // [n]   reverse edges received
+    uint32_t* rev_cur;            // [n]   fill cursor
+    uint32_t* rev_off;            // [n+1] exclusive scan of rev_cnt
+    unsigned long long* rev;      // [<= n*K] reverse keys, grouped by receiving row
+    uint32_t* adj;                // -> ImgDev::ann_adj
+    uint32_t* deg;                // -> ImgDev::ann_deg
+};
+struct AnnBuildParams {
+    const ImgDev* imgs;
+    const AnnBuildJob* jobs;
+    uint32_t K;
+};
+struct AnnSearchParams {
+    const ImgDev* imgs;
+    const uint2*  pairs;          // slot indices (I, J)
+    const uint2*  pair_ids;       // view ids (I, J): keys of the start-row stream
+    uint32_t      n_pairs;
+    uint32_t      qb_per_pair;    // workgroups (4 queries each) per pair
+    uint32_t      q_stride;
+    uint32_t      flag_words;     // u32 words of the visited bitset of one query
+    uint32_t      P, S, pool_cap; // start rows, neighbours expanded per step, K + P
+    uint64_t      seed;
+    float         ratio_R;
+    uint32_t*     nn_idx;
+    int32_t*      knn_idx;        // optional
+    float*        knn_dist;       // optional
+    unsigned long long* n_comps;  // distance evaluations (atomic)
 };
 
 struct MatchParams {
@@ -117,6 +158,8 @@ hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t wo
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
 size_t     filter_F_lds_bytes(uint32_t m_cap);
+hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim);
+hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim);
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
                                uint32_t n, float* patches);
 hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
