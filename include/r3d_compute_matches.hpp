@@ -50,6 +50,9 @@ struct View {
     uint32_t id_view = 0;
     uint32_t ui_width = 0, ui_height = 0;
     std::string basename;                      // <matches dir>/<basename>.feat|.desc
+    // pinhole intrinsics of the view (sfm_data.bin: Pinhole_Intrinsic focal / principal point); focal_px <= 0 = unknown,
+    // such views are skipped by the essential-matrix filter exactly as E_ACRobust.hpp skips views without intrinsics
+    double focal_px = -1.0, ppx = 0.0, ppy = 0.0;
 };
 
 using MatchList = std::vector<r3dm_match>;          // IndMatches (IndMatch{i_, j_} == r3dm_match{i, j})
@@ -58,7 +61,8 @@ using PairWiseMatches = std::map<std::pair<uint32_t, uint32_t>, MatchList>;
 class R3DComputeMatches {
 public:
     // matchingAlgorithm value of the new dispatch arm next to src/R3DComputeMatches.cpp:2054-2062;
-    // 4 ("Brute Force", src/Regard3DMainFrameBase.cpp:1020) is served by the same GPU path.
+    // 4 ("Brute Force", src/Regard3DMainFrameBase.cpp:1020) is served by the same GPU path; 1..3 (the KGraph presets,
+    // kgraph_match at :2051-2054) run the graph-based approximate matcher (r3dm_match_pairs_kgraph).
     static constexpr int kMatchingAlgorithmGPU = 9;
 
     explicit R3DComputeMatches(int device_id = 0);
@@ -77,7 +81,7 @@ public:
         std::vector<int> numberOfKeypoints_;
         PairWiseMatches putativeMatches_;
         PairWiseMatches fundamentalMatches_;
-        PairWiseMatches essentialMatches_;     // not computed this round: 5-point solver pending
+        PairWiseMatches essentialMatches_;     // GeometricFilter_EMatrix_AC + overlap rule (r3dm_filter_E)
         PairWiseMatches homographyMatches_;    // GeometricFilter_HMatrix_AC (r3dm_filter_H)
     };
     const R3DComputeMatchesStatistics& getStatistics() const { return statistics_; }

@@ -102,6 +102,17 @@ int r3dm_filter_F(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual
 int r3dm_filter_H(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                   uint64_t seed, r3dm_graph** out, double* H_out);
 
+/* Essential-matrix variant (GeometricFilter_EMatrix_AC(4.0, imax_iteration), src/R3DComputeMatches.cpp:2169, default on
+ * via computeEssentialMatrix_) -- 5-point solver on K^-1 x, epipolar distance in pixels through F = K2^-T E K1^-1,
+ * accept iff #inliers > 2.5 * 5 -- followed by Regard3D's own overlap rule (:2175-2192): a pair is dropped when it keeps
+ * fewer than min_count (50) matches or less than min_ratio (0.3) of its putative matches; pass 0 / 0 for the bare
+ * OpenMVG filter.  Needs r3dm_set_intrinsics for both views of a pair; pairs without are not estimated, as in
+ * E_ACRobust.hpp.  E_out: 9 doubles (row-major E, x_J^T E x_I = 0 in camera coordinates) per KEPT pair.
+ * K: row-major 3x3 pinhole matrix of the view (Pinhole_Intrinsic::K()), NULL to remove; call after r3dm_set_image. */
+int r3dm_set_intrinsics(r3dm_ctx* ctx, uint32_t view_id, const double* K);
+int r3dm_filter_E(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                  uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out);
+
 /* Per-pair outcome of the last r3dm_filter_F / r3dm_filter_H call -- what OpenMVG's ACRANSAC returns besides the inliers
  * (std::pair<errorMax, minNFA>) plus work counters.  One entry per pair of the putative graph, in its
  * order; pairs with too few putatives (<= 7 for F, <= 4 for H) are all-zero.  Returns the number of entries available. */

@@ -305,24 +305,29 @@ static int cmp_err(const void* pa, const void* pb)
 /* kind 0: fundamental matrix (ACKernelAdaptor<SevenPointSolver, SymmetricEpipolarDistanceError, UnnormalizerT>,
  *         point-to-line); kind 1: homography (ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI>,
  *         point-to-point: logalpha0 = log10(pi / A / N2(0,0)^2), multError = 1). */
+/* kind 2: essential matrix (ACKernelAdaptorEssential<FivePointKernel, EpipolarDistanceError>): samples are fitted in
+ *         camera coordinates (K^-1 x), residuals are taken in PIXELS through F = K2^-T E K1^-1, no normalisation:
+ *         logalpha0 = log10(2 D / A * 0.5), multError = 0.5, threshold = precision^2, unormalizeError(e) = e. */
 static int acransac_core(int kind, const double* xI, const double* xJ, int m,
                          int wI, int hI, int wJ, int hJ,
                          double precision_px, uint32_t max_iter,
                          uint64_t seed, uint32_t I, uint32_t J,
-                         uint32_t* inliers_out, orc_fresult* res)
+                         uint32_t* inliers_out, orc_fresult* res, const double* K1, const double* K2)
 {
-    const int SS = kind == 0 ? 7 : 4;            /* MINIMUM_SAMPLES */
-    const int MAX_MODELS = kind == 0 ? 3 : 1;
+    const int SS = kind == 0 ? 7 : (kind == 1 ? 4 : 5);            /* MINIMUM_SAMPLES */
+    const int MAX_MODELS = kind == 0 ? 3 : (kind == 1 ? 1 : 10);
     memset(res, 0, sizeof(*res));
     res->nfa = INFINITY;
     if (m <= SS) return 0;
     const uint32_t n = (uint32_t)m;
 
     /* ACKernelAdaptor: normalise with N = diag(s, s, 1) + translation, s = 1/sqrt(w*h) */
-    const double s1 = 1.0 / sqrt((double)(wI * hI));   /* static_cast<double>(width*height): int product */
-    const double s2 = 1.0 / sqrt((double)(wJ * hJ));
-    const double t1x = -0.5 * wI * s1, t1y = -0.5 * hI * s1;
-    const double t2x = -0.5 * wJ * s2, t2y = -0.5 * hJ * s2;
+    double s1 = 1.0 / sqrt((double)(wI * hI));   /* static_cast<double>(width*height): int product */
+    double s2 = 1.0 / sqrt((double)(wJ * hJ));
+    double t1x = -0.5 * wI * s1, t1y = -0.5 * hI * s1;
+    double t2x = -0.5 * wJ * s2, t2y = -0.5 * hJ * s2;
+    double K1i[9] = {0}, K2i[9] = {0};
+    if (kind == 2) { s1 = s2 = 1.0; t1x = t1y = t2x = t2y = 0.0; orc_inv3(K1, K1i); orc_inv3(K2, K2i); }
     double* x1 = (double*)malloc(sizeof(double) * 2 * n);
     double* x2 = (double*)malloc(sizeof(double) * 2 * n);
     for (uint32_t k = 0; k < n; ++k) {
@@ -332,8 +337,21 @@ static int acransac_core(int kind, const double* xI, const double* xJ, int m,
     /* point-to-line: logalpha0 = log10(2 D / A / N2(0,0)), multError = 0.5 */
     const double Dd = sqrt((double)wJ * (double)wJ + (double)hJ * (double)hJ);
     const double Aa = (double)wJ * (double)hJ;
-    const double logalpha0 = kind == 0 ? log10(2.0 * Dd / Aa / s2) : log10(M_PI / Aa / (s2 * s2));
-    const double multError = kind == 0 ? 0.5 : 1.0;
+    const double logalpha0 = kind == 0 ? log10(2.0 * Dd / Aa / s2) : (kind == 1 ? log10(M_PI / Aa / (s2 * s2)) : log10(2.0 * Dd / Aa * 0.5));
+    const double multError = kind == 1 ? 1.0 : 0.5;
+    /* camera coordinates of every point for the 5-point fits: hnormalized(K^-1 (x, y, 1)) */
+    double* xk1 = NULL; double* xk2 = NULL;
+    if (kind == 2) {
+        xk1 = (double*)malloc(sizeof(double) * 2 * n); xk2 = (double*)malloc(sizeof(double) * 2 * n);
+        for (uint32_t k = 0; k < n; ++k) {
+            const double w1 = K1i[6] * xI[2 * k] + K1i[7] * xI[2 * k + 1] + K1i[8];
+            xk1[2 * k] = (K1i[0] * xI[2 * k] + K1i[1] * xI[2 * k + 1] + K1i[2]) / w1;
+            xk1[2 * k + 1] = (K1i[3] * xI[2 * k] + K1i[4] * xI[2 * k + 1] + K1i[5]) / w1;
+            const double w2 = K2i[6] * xJ[2 * k] + K2i[7] * xJ[2 * k + 1] + K2i[8];
+            xk2[2 * k] = (K2i[0] * xJ[2 * k] + K2i[1] * xJ[2 * k + 1] + K2i[2]) / w2;
+            xk2[2 * k + 1] = (K2i[3] * xJ[2 * k] + K2i[4] * xJ[2 * k + 1] + K2i[5]) / w2;
+        }
+    }
     const double maxThreshold = precision_px * precision_px * s2 * s2;   /* precision = 4.0^2, in N2 units */
 
     const double loge0 = log10((double)MAX_MODELS * (double)(n - SS));
@@ -361,12 +379,14 @@ static int acransac_core(int kind, const double* xI, const double* xJ, int m,
         uint32_t smp[7];
         orc_sample_n(seed, I, J, iter, pool, pool_size, (uint32_t)SS, smp);
         double sx1[14], sx2[14];
+        const double* fx1 = kind == 2 ? xk1 : x1;
+        const double* fx2 = kind == 2 ? xk2 : x2;
         for (int k = 0; k < SS; ++k) {
-            sx1[2 * k] = x1[2 * smp[k]]; sx1[2 * k + 1] = x1[2 * smp[k] + 1];
-            sx2[2 * k] = x2[2 * smp[k]]; sx2[2 * k + 1] = x2[2 * smp[k] + 1];
+            sx1[2 * k] = fx1[2 * smp[k]]; sx1[2 * k + 1] = fx1[2 * smp[k] + 1];
+            sx2[2 * k] = fx2[2 * smp[k]]; sx2[2 * k + 1] = fx2[2 * smp[k] + 1];
         }
-        double Fs[27];
-        const int nm = kind == 0 ? orc_seven_point(sx1, sx2, Fs) : orc_four_point_h(sx1, sx2, Fs);
+        double Fs[90];
+        const int nm = kind == 0 ? orc_seven_point(sx1, sx2, Fs) : (kind == 1 ? orc_four_point_h(sx1, sx2, Fs) : orc_five_point(sx1, sx2, Fs));
         if ((int)iter == g_dbg_iter) {
             for (int k = 0; k < 7; ++k) g_dbg[k] = smp[k];
             g_dbg[7] = nm; g_dbg[8] = pool_size; g_dbg[9] = iter;
@@ -376,9 +396,12 @@ static int acransac_core(int kind, const double* xI, const double* xJ, int m,
         for (int k = 0; k < nm; ++k) {
             const double* F = Fs + 9 * k;
             ++n_models_total;
+            double FE[9];
+            if (kind == 2) orc_f_from_e(F, K1i, K2i, FE);
             for (uint32_t p = 0; p < n; ++p)
                 rs[p] = kind == 0 ? orc_sym_epipolar_err(F, x1[2 * p], x1[2 * p + 1], x2[2 * p], x2[2 * p + 1])
-                                  : orc_h_asym_err(F, x1[2 * p], x1[2 * p + 1], x2[2 * p], x2[2 * p + 1]);
+                      : kind == 1 ? orc_h_asym_err(F, x1[2 * p], x1[2 * p + 1], x2[2 * p], x2[2 * p + 1])
+                                  : orc_epipolar_dist_err(FE, x1[2 * p], x1[2 * p + 1], x2[2 * p], x2[2 * p + 1]);
             if (!acMode) {
                 uint32_t nInlier = 0;
                 for (uint32_t p = 0; p < n; ++p) if (rs[p] <= maxThreshold) ++nInlier;
@@ -462,11 +485,12 @@ static int acransac_core(int kind, const double* xI, const double* xJ, int m,
                 res->F[3 * r + c] = v;
             }
         res->threshold = sqrt(errorMax) / s2;
+        if (kind == 2) { memcpy(res->F, bestF, sizeof(bestF)); res->threshold = errorMax; }   /* E itself; unormalizeError(e) = e */
         memcpy(inliers_out, inl, sizeof(uint32_t) * n_inl);
     }
     res->accepted = ((double)n_inl > 2.5 * SS) ? 1 : 0;   /* F_ACRobust / H_ACRobust acceptance */
 
-    free(rs); free(er); free(inl); free(pool); free(logc_k); free(logc_n); free(x2); free(x1);
+    free(rs); free(er); free(inl); free(pool); free(logc_k); free(logc_n); free(x2); free(x1); free(xk1); free(xk2);
     return (int)n_inl;
 }
 
@@ -474,14 +498,22 @@ int orc_acransac_F(const double* xI, const double* xJ, int m, int wI, int hI, in
                    double precision_px, uint32_t max_iter, uint64_t seed, uint32_t I, uint32_t J,
                    uint32_t* inliers_out, orc_fresult* res)
 {
-    return acransac_core(0, xI, xJ, m, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J, inliers_out, res);
+    return acransac_core(0, xI, xJ, m, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J, inliers_out, res, NULL, NULL);
 }
 
 int orc_acransac_H(const double* xI, const double* xJ, int m, int wI, int hI, int wJ, int hJ,
                    double precision_px, uint32_t max_iter, uint64_t seed, uint32_t I, uint32_t J,
                    uint32_t* inliers_out, orc_fresult* res)
 {
-    return acransac_core(1, xI, xJ, m, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J, inliers_out, res);
+    return acransac_core(1, xI, xJ, m, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J, inliers_out, res, NULL, NULL);
+}
+
+int orc_acransac_E(const double* xI, const double* xJ, int m, int wI, int hI, int wJ, int hJ,
+                   const double* K1, const double* K2,
+                   double precision_px, uint32_t max_iter, uint64_t seed, uint32_t I, uint32_t J,
+                   uint32_t* inliers_out, orc_fresult* res)
+{
+    return acransac_core(2, xI, xJ, m, wI, hI, wJ, hJ, precision_px, max_iter, seed, I, J, inliers_out, res, K1, K2);
 }
 
 /* ---------------------------------------------------------------- collection filter */
@@ -491,7 +523,9 @@ static int64_t filter_collection(int kind, int n_images, const int* n_rows, cons
                                 const uint32_t* pairs, int64_t n_pairs,
                                 const uint32_t* counts, const orc_match* matches,
                                 double precision_px, uint32_t max_iter, uint64_t seed,
-                                uint32_t* out_counts, orc_match* out, double* F_out)
+                                uint32_t* out_counts, orc_match* out, double* F_out,
+                                const double* Ks /* 9 per image, K[8] == 0 marks "no intrinsics" */,
+                                uint32_t prune_min_count, float prune_min_ratio)
 {
     (void)n_images; (void)n_rows;
     int64_t* offs = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_pairs + 1));
@@ -514,8 +548,14 @@ static int64_t filter_collection(int kind, int n_images, const int* n_rows, cons
         }
         uint32_t* inl = (uint32_t*)malloc(sizeof(uint32_t) * m);
         orc_fresult fr;
-        const int ni = acransac_core(kind, xI, xJ, (int)m, (int)widths[I], (int)heights[I], (int)widths[J], (int)heights[J],
-                                     precision_px, max_iter, seed, I, J, inl, &fr);
+        int ni = 0;
+        memset(&fr, 0, sizeof(fr));
+        /* E_ACRobust: both views need valid pinhole intrinsics, otherwise the pair is not estimated */
+        if (kind != 2 || (Ks[9 * I + 8] != 0.0 && Ks[9 * J + 8] != 0.0))
+            ni = acransac_core(kind, xI, xJ, (int)m, (int)widths[I], (int)heights[I], (int)widths[J], (int)heights[J],
+                               precision_px, max_iter, seed, I, J, inl, &fr, Ks ? Ks + 9 * I : NULL, Ks ? Ks + 9 * J : NULL);
+        /* Regard3D's extra check after the E filter (src/R3DComputeMatches.cpp:2175-2192): drop pairs with poor overlap */
+        if (fr.accepted && kind == 2 && ((uint32_t)ni < prune_min_count || (float)ni / (float)m < prune_min_ratio)) fr.accepted = 0;
         if (fr.accepted) {
             orc_match* r = (orc_match*)malloc(sizeof(orc_match) * (size_t)ni);
             for (int k = 0; k < ni; ++k) r[k] = pm[inl[k]];
@@ -541,7 +581,7 @@ int64_t orc_filter_F_collection(int n_images, const int* n_rows, const float* co
                                 uint32_t* out_counts, orc_match* out, double* F_out)
 {
     return filter_collection(0, n_images, n_rows, xy, widths, heights, pairs, n_pairs, counts, matches,
-                             precision_px, max_iter, seed, out_counts, out, F_out);
+                             precision_px, max_iter, seed, out_counts, out, F_out, NULL, 0, 0.f);
 }
 
 int64_t orc_filter_H_collection(int n_images, const int* n_rows, const float* const* xy,
@@ -552,5 +592,19 @@ int64_t orc_filter_H_collection(int n_images, const int* n_rows, const float* co
                                 uint32_t* out_counts, orc_match* out, double* H_out)
 {
     return filter_collection(1, n_images, n_rows, xy, widths, heights, pairs, n_pairs, counts, matches,
-                             precision_px, max_iter, seed, out_counts, out, H_out);
+                             precision_px, max_iter, seed, out_counts, out, H_out, NULL, 0, 0.f);
+}
+
+/* GeometricFilter_EMatrix_AC over the collection + Regard3D's overlap check (src/R3DComputeMatches.cpp:2169-2192):
+ * a kept pair needs >= prune_min_count (50) geometric matches and a geometric/putative ratio >= prune_min_ratio (0.3). */
+int64_t orc_filter_E_collection(int n_images, const int* n_rows, const float* const* xy,
+                                const uint32_t* widths, const uint32_t* heights, const double* Ks,
+                                const uint32_t* pairs, int64_t n_pairs,
+                                const uint32_t* counts, const orc_match* matches,
+                                double precision_px, uint32_t max_iter, uint64_t seed,
+                                uint32_t prune_min_count, float prune_min_ratio,
+                                uint32_t* out_counts, orc_match* out, double* E_out)
+{
+    return filter_collection(2, n_images, n_rows, xy, widths, heights, pairs, n_pairs, counts, matches,
+                             precision_px, max_iter, seed, out_counts, out, E_out, Ks, prune_min_count, prune_min_ratio);
 }

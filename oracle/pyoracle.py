@@ -29,7 +29,7 @@ class FResult(C.Structure):
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "kgraph.c", "r3d_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "kgraph.c", "essential.c", "r3d_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -54,6 +54,10 @@ def lib():
         L.orc_rng_u64.restype = C.c_uint64
         L.orc_rng_u64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_sym_epipolar_err.restype = C.c_double
+        L.orc_filter_E_collection.restype = C.c_int64
+        L.orc_filter_H_collection.restype = C.c_int64
+        L.orc_epipolar_dist_err.restype = C.c_double
+        L.orc_epipolar_dist_err.argtypes = [C.c_void_p] + [C.c_double] * 4
         L.orc_kgraph_build_exact.restype = C.c_void_p
         L.orc_kgraph_build_nndescent.restype = C.c_void_p
         L.orc_kgraph_free.argtypes = [C.c_void_p]
@@ -415,3 +419,48 @@ def match_collection_kgraph(descs, xys, pairs, ratio, builder="exact", K=16, L=2
     if tot < 0:
         raise RuntimeError("orc_match_collection_kgraph: output capacity")
     return counts, out[:tot].copy(), comps.value
+
+
+# ---- essential matrix (oracle/essential.c) ----------------------------------------------------------
+def five_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64); x2 = np.ascontiguousarray(x2, np.float64)
+    Es = np.zeros((10, 3, 3), np.float64)
+    n = lib().orc_five_point(_p(x1), _p(x2), _p(Es))
+    return Es[:n].copy()
+
+
+def real_roots(coeffs_ascending):
+    c = np.ascontiguousarray(coeffs_ascending, np.float64)
+    r = np.zeros(10, np.float64)
+    n = lib().orc_real_roots10(_p(c), len(c) - 1, _p(r))
+    return r[:n].copy()
+
+
+def acransac_E(xI, xJ, wI, hI, wJ, hJ, K1, K2, precision_px=4.0, max_iter=2048, seed=5489, I=0, J=1):
+    xI = np.ascontiguousarray(xI, np.float64); xJ = np.ascontiguousarray(xJ, np.float64)
+    K1 = np.ascontiguousarray(K1, np.float64); K2 = np.ascontiguousarray(K2, np.float64)
+    m = xI.shape[0]
+    inl = np.zeros(max(m, 1), np.uint32)
+    res = FResult()
+    n = lib().orc_acransac_E(_p(xI), _p(xJ), m, wI, hI, wJ, hJ, _p(K1), _p(K2), C.c_double(precision_px), max_iter,
+                             C.c_uint64(seed), I, J, _p(inl), C.byref(res))
+    return inl[:n].copy(), res
+
+
+def filter_E_collection(xys, widths, heights, Ks, pairs, counts, matches, precision_px=4.0, max_iter=2048, seed=5489,
+                        prune_min_count=50, prune_min_ratio=0.3, want_E=False):
+    """Ks: [n_images, 3, 3] float64; an all-zero K marks a view without intrinsics"""
+    n = len(xys)
+    xys = [np.ascontiguousarray(x, np.float32) for x in xys]
+    xptr = (C.c_void_p * n)(*[x.ctypes.data for x in xys])
+    nrows = np.array([x.shape[0] for x in xys], np.int32)
+    widths = np.ascontiguousarray(widths, np.uint32); heights = np.ascontiguousarray(heights, np.uint32)
+    Ks = np.ascontiguousarray(Ks, np.float64)
+    pairs = np.ascontiguousarray(pairs, np.uint32); counts = np.ascontiguousarray(counts, np.uint32)
+    matches = np.ascontiguousarray(matches, np.uint32)
+    oc = np.zeros(len(pairs), np.uint32); out = np.zeros((max(len(matches), 1), 2), np.uint32)
+    Eo = np.zeros((len(pairs), 9), np.float64)
+    tot = lib().orc_filter_E_collection(n, _p(nrows), xptr, _p(widths), _p(heights), _p(Ks), _p(pairs), C.c_int64(len(pairs)),
+                                        _p(counts), _p(matches), C.c_double(precision_px), max_iter, C.c_uint64(seed),
+                                        prune_min_count, C.c_float(prune_min_ratio), _p(oc), _p(out), _p(Eo))
+    return (oc, out[:tot].copy(), Eo) if want_E else (oc, out[:tot].copy())

@@ -169,6 +169,26 @@ int orc_load_feat(const char* path, int* n, float* xyso, int cap);
 int orc_save_desc(const char* path, uint64_t n, size_t row_bytes, const void* data);
 int orc_load_desc(const char* path, uint64_t* n, size_t row_bytes, void* data, uint64_t cap);
 
+/* ---- essential-matrix variant (GeometricFilter_EMatrix_AC, src/R3DComputeMatches.cpp:2169; oracle/essential.c):
+ * 5-point solver on K^-1 x, EpipolarDistanceError in pixels through F = K2^-T E K1^-1, accepted iff n_inliers > 2.5 * 5.
+ * res->F holds E, res->threshold the squared pixel bound (ACKernelAdaptorEssential::unormalizeError is the identity). */
+int      orc_five_point(const double* x1 /*5x2*/, const double* x2, double* Es /*<= 10 x 9*/);
+int      orc_real_roots10(const double* p, int deg, double* roots);
+double   orc_epipolar_dist_err(const double* F, double x1, double y1, double x2, double y2);
+void     orc_inv3(const double* K, double* Ki);
+void     orc_f_from_e(const double* E, const double* K1i, const double* K2i, double* F);
+int      orc_acransac_E(const double* xI, const double* xJ, int m, int wI, int hI, int wJ, int hJ,
+                        const double* K1, const double* K2,
+                        double precision_px, uint32_t max_iter, uint64_t seed, uint32_t I, uint32_t J,
+                        uint32_t* inliers, orc_fresult* res);
+int64_t  orc_filter_E_collection(int n_images, const int* n_rows, const float* const* xy,
+                                 const uint32_t* widths, const uint32_t* heights, const double* Ks,
+                                 const uint32_t* pairs, int64_t n_pairs,
+                                 const uint32_t* counts, const orc_match* matches,
+                                 double precision_px, uint32_t max_iter, uint64_t seed,
+                                 uint32_t prune_min_count, float prune_min_ratio,
+                                 uint32_t* out_counts, orc_match* out, double* E_out);
+
 /* ---- KGraph plugin path (config C5): oracle/kgraph.c.  src/thirdparty/kgraph/kgraph.cpp:411-552 (search),
  * :703-997 (NN-descent), :660-700 (reverse), src/utils/matcher_kgraph.h, src/R3DComputeMatches.cpp:808-902. */
 typedef struct orc_kgraph orc_kgraph;

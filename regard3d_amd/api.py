@@ -24,7 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
 ]
 
 
@@ -84,6 +84,8 @@ def load_library():
     L.r3dm_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
     L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
     L.r3dm_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
+    L.r3dm_filter_E.argtypes = [vp, vp, C.c_double, u32, u64, u32, C.c_float, C.POINTER(vp), vp]
+    L.r3dm_set_intrinsics.argtypes = [vp, u32, vp]
     L.r3dm_liop_describe_patches.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32)]
     L.r3dm_extract_liop.argtypes = [vp, vp, u32, u32, vp, u32, C.c_float, vp, vp]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
@@ -302,6 +304,19 @@ class Context:
                     "r3dm_filter_H")
         g = Graph(h.value)
         return (g, Hbuf[:g.num_pairs].copy()) if want_H else g
+
+    def set_intrinsics(self, view_id: int, K):
+        K = None if K is None else np.ascontiguousarray(K, np.float64).reshape(9)
+        self._check(self._L.r3dm_set_intrinsics(self._h, view_id, _ptr(K)), "r3dm_set_intrinsics")
+
+    def filter_E(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489,
+                 min_count: int = 50, min_ratio: float = 0.3, want_E: bool = False):
+        h = C.c_void_p()
+        Ebuf = np.zeros((max(putative.num_pairs, 1), 9), np.float64) if want_E else None
+        self._check(self._L.r3dm_filter_E(self._h, putative._h, max_residual_px, max_iter, seed, min_count, min_ratio,
+                                          C.byref(h), _ptr(Ebuf)), "r3dm_filter_E")
+        g = Graph(h.value)
+        return (g, Ebuf[:g.num_pairs].copy()) if want_E else g
 
     def knn2(self, dataset: np.ndarray, query: np.ndarray, binary: bool = False):
         dataset = np.ascontiguousarray(dataset); query = np.ascontiguousarray(query)

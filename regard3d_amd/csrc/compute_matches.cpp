@@ -100,8 +100,11 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
 {
     statistics_ = R3DComputeMatchesStatistics();
     if (!ctx_) return false;
-    if (matchingAlgorithm != kMatchingAlgorithmGPU && matchingAlgorithm != 4) {
-        errorMessage_ = "matchingAlgorithm " + std::to_string(matchingAlgorithm) + " is not served by the GPU path (use 9 or 4)";
+    // dispatch of src/R3DComputeMatches.cpp:2035-2062: 1..3 = kgraph_match presets (fast / medium / precise), 4 = brute force;
+    // 9 = the new arm.  0 (FLANN kd-trees), 5 (MRPT) and 6..8 (HNSW) have no GPU counterpart: refuse rather than substitute.
+    const bool use_kgraph = matchingAlgorithm >= 1 && matchingAlgorithm <= 3;
+    if (matchingAlgorithm != kMatchingAlgorithmGPU && matchingAlgorithm != 4 && !use_kgraph) {
+        errorMessage_ = "matchingAlgorithm " + std::to_string(matchingAlgorithm) + " is not served by the GPU path (use 9, 4 or 1..3)";
         return false;
     }
     const std::string dir = paths.relativeMatchesPath_;
@@ -121,6 +124,10 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         statistics_.numberOfKeypoints_.push_back((int)n);
         const int rc = r3dm_set_image(ctx_, v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, dim_, dtype_, xy.data());
         if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+        if (v.focal_px > 0.0) {
+            const double K[9] = {v.focal_px, 0.0, v.ppx, 0.0, v.focal_px, v.ppy, 0.0, 0.0, 1.0};      // Pinhole_Intrinsic::K()
+            if (r3dm_set_intrinsics(ctx_, v.id_view, K) != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+        }
     }
 
     // ---- exhaustivePairs(#views) (:2042): all (I, J) with I < J, in view-id order
@@ -134,7 +141,14 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     // ---- photometric matching (:2048) + Save(matches.putative.txt) (:2064)
     r3dm_graph* putative = nullptr;
     const int squared = dtype_ == R3DM_BIN ? 0 : 1;        // RegionsMatcherT squared flag: true for L2 metrics
-    int rc = r3dm_match_pairs(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, squared, &putative);
+    int rc;
+    if (use_kgraph) {
+        r3dm_kgraph_params kp;
+        r3dm_kgraph_preset(matchingAlgorithm - 1, &kp);          // kgraph_match(..., matchingAlgorithm-1) (:2053)
+        rc = r3dm_match_pairs_kgraph(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, &kp, &putative);
+    } else {
+        rc = r3dm_match_pairs(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, squared, &putative);
+    }
     if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
     graph_to_map(putative, statistics_.putativeMatches_);
     const std::string put_path = paths.matchesPutitativeFilename_.empty() ? dir + "/matches.putative.txt" : paths.matchesPutitativeFilename_;
@@ -160,6 +174,19 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         r3dm_graph_free(geo);
         if (!ok) { errorMessage_ = "Cannot save computed matches in: " + f_path; r3dm_graph_free(putative); return false; }
     }
+    // ---- essential-matrix filter (:2130-2204): 5-point solver on K^-1 x, then the overlap rule (>= 50 matches and
+    //      >= 30 % of the putative matches, :2175-2192); matches.e.txt feeds the global SfM engine
+    if (params.computeEssentialMatrix_) {
+        r3dm_graph* geo = nullptr;
+        rc = r3dm_filter_E(ctx_, putative, 4.0, 2048, seed_, 50, 0.3f, &geo, nullptr);
+        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
+        graph_to_map(geo, statistics_.essentialMatches_);
+        const std::string e_path = paths.matchesEFilename_.empty() ? dir + "/matches.e.txt" : paths.matchesEFilename_;
+        const bool ok = r3dm_save_matches(geo, e_path.c_str()) == R3DM_OK &&
+                        r3dm_save_matches(geo, with_ext(e_path, ".bin").c_str()) == R3DM_OK;
+        r3dm_graph_free(geo);
+        if (!ok) { errorMessage_ = "Cannot save computed matches in: " + e_path; r3dm_graph_free(putative); return false; }
+    }
     // ---- homography filter (:2216-2233): same skeleton, 4-point solver; matches.h.txt
     if (params.computeHomographyMatrix_) {
         r3dm_graph* geo = nullptr;
@@ -172,14 +199,12 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         r3dm_graph_free(geo);
         if (!ok) { errorMessage_ = "Cannot save computed matches in: " + h_path; r3dm_graph_free(putative); return false; }
     }
-    // GeometricAdjacencyMatrix.svg (:2238): the reference draws whichever filter ran last (H, else F)
+    // GeometricAdjacencyMatrix.svg (:2238): the reference draws whichever filter ran last (H, else E, else F)
     if (svgOutput) {
-        const PairWiseMatches& last = params.computeHomographyMatrix_ ? statistics_.homographyMatches_ : statistics_.fundamentalMatches_;
+        const PairWiseMatches& last = params.computeHomographyMatrix_ ? statistics_.homographyMatches_
+                                    : (params.computeEssentialMatrix_ ? statistics_.essentialMatches_ : statistics_.fundamentalMatches_);
         write_adjacency_svg(dir + "/GeometricAdjacencyMatrix.svg", views_.size(), last);
     }
-    // essential-matrix filter (:2130-2204): not implemented this round -- computeEssentialMatrix_ is ignored and
-    // statistics_.essentialMatches_ stays empty; OpenMVG's CPU filter can still be run on
-    // the putative graph by the caller.
     r3dm_graph_free(putative);
     return true;
 }

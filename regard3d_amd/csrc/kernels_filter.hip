@@ -246,6 +246,263 @@ __device__ __forceinline__ double h_asym_err(const double* H, double x1, double 
     return ex * ex + ey * ey;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 5-point essential matrix (OpenMVG essential::kernel::FivePointKernel behind GeometricFilter_EMatrix_AC,
+// /root/reference/src/R3DComputeMatches.cpp:2169).  Same polynomial system as OpenMVG's FivePointsRelativePose,
+// solved with Nister's hidden-variable elimination + a Sturm sequence; operation for operation the arithmetic of
+// oracle/essential.c (only + - * / after the QR), so both produce the same bits.  One lane per minimal sample; the
+// 10x20 elimination matrix lives in scratch memory (the other 192 lanes of the workgroup wait at the barrier anyway).
+// ------------------------------------------------------------------------------------------------
+__device__ const unsigned char kT11[4][4] = {{0, 2, 3, 4}, {2, 1, 5, 6}, {3, 5, 7, 8}, {4, 6, 8, 9}};
+__device__ const unsigned char kT21[10][4] = {{0, 2, 4, 5}, {3, 1, 6, 7}, {2, 3, 8, 9}, {4, 8, 10, 11}, {5, 9, 11, 12},
+                                              {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+
+__device__ __noinline__ void e_mul11(const double* a, const double* b, double* out)
+{
+    for (int k = 0; k < 10; ++k) out[k] = 0.0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[kT11[i][j]] += a[i] * b[j];
+}
+__device__ __noinline__ void e_mul21_acc(const double* a, const double* b, double* out)
+{
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 4; ++j) out[kT21[i][j]] += a[i] * b[j];
+}
+__device__ __noinline__ void e_pmul(const double* a, int da, const double* b, int db, double* out)
+{
+    for (int k = 0; k <= da + db; ++k) out[k] = 0.0;
+    for (int i = 0; i <= da; ++i)
+        for (int j = 0; j <= db; ++j) out[i + j] += a[i] * b[j];
+}
+__device__ __forceinline__ double e_peval(const double* p, int d, double t)
+{
+    double v = p[d];
+    for (int k = d - 1; k >= 0; --k) v = v * t + p[k];
+    return v;
+}
+__device__ __noinline__ int e_sturm_changes(const double (*f)[11], const int* deg, int nf, double t)
+{
+    int changes = 0, last = 0;
+    for (int k = 0; k < nf; ++k) {
+        const double v = e_peval(f[k], deg[k], t);
+        const int s = (v > 0.0) - (v < 0.0);
+        if (s != 0) { if (last != 0 && s != last) ++changes; last = s; }
+    }
+    return changes;
+}
+
+// real roots of a polynomial of degree <= 10 (ascending coefficients), ascending, distinct
+__device__ __noinline__ int real_roots10(const double* p_in, int deg_in, double* roots)
+{
+    double f[12][11];
+    int deg[12];
+    int d = deg_in;
+    while (d > 0 && p_in[d] == 0.0) --d;
+    if (d <= 0) return 0;
+    for (int k = 0; k <= d; ++k) f[0][k] = p_in[k] / p_in[d];
+    deg[0] = d;
+    for (int k = 1; k <= d; ++k) f[1][k - 1] = (double)k * f[0][k];
+    deg[1] = d - 1;
+    int nf = 2;
+    while (deg[nf - 1] > 0) {
+        const double* b = f[nf - 1];
+        const int db = deg[nf - 1];
+        double r[11];
+        int dr = deg[nf - 2];
+        for (int k = 0; k <= dr; ++k) r[k] = f[nf - 2][k];
+        while (dr >= db) {
+            const double q = r[dr] / b[db];
+            for (int k = 0; k < db; ++k) r[dr - db + k] -= q * b[k];
+            r[dr] = 0.0;
+            --dr;
+        }
+        while (dr >= 0 && r[dr] == 0.0) --dr;
+        if (dr < 0) break;
+        const double sc = fabs(r[dr]);
+        for (int k = 0; k <= dr; ++k) f[nf][k] = -r[k] / sc;
+        deg[nf] = dr;
+        ++nf;
+    }
+    double bound = 0.0;
+    for (int k = 0; k < d; ++k) { const double a = fabs(f[0][k]); if (a > bound) bound = a; }
+    bound += 1.0;
+    const int va = e_sturm_changes(f, deg, nf, -bound);
+    const int nr = va - e_sturm_changes(f, deg, nf, bound);
+    int n_out = 0;
+    for (int r = 1; r <= nr && n_out < 10; ++r) {
+        double lo = -bound, hi = bound;
+        for (int it = 0; it < 64; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (va - e_sturm_changes(f, deg, nf, mid) >= r) hi = mid; else lo = mid;
+        }
+        roots[n_out++] = 0.5 * (lo + hi);
+    }
+    return n_out;
+}
+
+__device__ __noinline__ int five_point(const double (&px1)[7][2], const double (&px2)[7][2], double* Es /* 90 */)
+{
+    double M[9][5];
+    for (int p = 0; p < 5; ++p) {
+        const double ax = px1[p][0], ay = px1[p][1], bx = px2[p][0], by = px2[p][1];
+        M[0][p] = bx * ax; M[1][p] = bx * ay; M[2][p] = bx;
+        M[3][p] = by * ax; M[4][p] = by * ay; M[5][p] = by;
+        M[6][p] = ax;      M[7][p] = ay;      M[8][p] = 1.0;
+    }
+    double beta[5];
+    for (int j = 0; j < 5; ++j) {
+        double nrm2 = 0.0;
+        for (int r = j; r < 9; ++r) nrm2 += M[r][j] * M[r][j];
+        const double nrm = sqrt(nrm2);
+        double bj = 0.0;
+        if (nrm != 0.0) {
+            const double alpha = (M[j][j] > 0.0) ? -nrm : nrm;
+            M[j][j] -= alpha;
+            double vn2 = 0.0;
+            for (int r = j; r < 9; ++r) vn2 += M[r][j] * M[r][j];
+            if (vn2 != 0.0) bj = 2.0 / vn2;
+        } else {
+            for (int r = j; r < 9; ++r) M[r][j] = 0.0;
+        }
+        beta[j] = bj;
+        for (int c = j + 1; c < 5; ++c) {
+            double dot = 0.0;
+            for (int r = j; r < 9; ++r) dot += M[r][j] * M[r][c];
+            const double s = bj * dot;
+            for (int r = j; r < 9; ++r) M[r][c] -= s * M[r][j];
+        }
+    }
+    double N[4][9];
+    for (int e = 0; e < 4; ++e) {
+        for (int r = 0; r < 9; ++r) N[e][r] = (r == 5 + e) ? 1.0 : 0.0;
+        for (int j = 4; j >= 0; --j) {
+            double dot = 0.0;
+            for (int r = j; r < 9; ++r) dot += M[r][j] * N[e][r];
+            const double s = beta[j] * dot;
+            for (int r = j; r < 9; ++r) N[e][r] -= s * M[r][j];
+        }
+    }
+    double E1[9][4];
+    for (int r = 0; r < 9; ++r) for (int e = 0; e < 4; ++e) E1[r][e] = N[e][r];
+    double A[10][20];
+    for (int r = 0; r < 10; ++r) for (int c = 0; c < 20; ++c) A[r][c] = 0.0;
+    double t1[10], t2[10], d2[10];
+    e_mul11(E1[1], E1[5], t1); e_mul11(E1[2], E1[4], t2); for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
+    e_mul21_acc(d2, E1[6], A[0]);
+    e_mul11(E1[2], E1[3], t1); e_mul11(E1[0], E1[5], t2); for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
+    e_mul21_acc(d2, E1[7], A[0]);
+    e_mul11(E1[0], E1[4], t1); e_mul11(E1[1], E1[3], t2); for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
+    e_mul21_acc(d2, E1[8], A[0]);
+    double EET[3][3][10];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a0[10], a1[10], a2[10];
+            e_mul11(E1[3 * i], E1[3 * j], a0); e_mul11(E1[3 * i + 1], E1[3 * j + 1], a1); e_mul11(E1[3 * i + 2], E1[3 * j + 2], a2);
+            for (int k = 0; k < 10; ++k) EET[i][j][k] = a0[k] + a1[k] + a2[k];
+        }
+    double tr[10];
+    for (int k = 0; k < 10; ++k) tr[k] = 0.5 * (EET[0][0][k] + EET[1][1][k] + EET[2][2][k]);
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 10; ++k) EET[i][i][k] -= tr[k];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double* row = A[1 + 3 * i + j];
+            e_mul21_acc(EET[i][0], E1[j], row); e_mul21_acc(EET[i][1], E1[3 + j], row); e_mul21_acc(EET[i][2], E1[6 + j], row);
+        }
+    for (int c = 0; c < 10; ++c) {
+        int piv = c;
+        double best = fabs(A[c][c]);
+        for (int r = c + 1; r < 10; ++r) { const double v = fabs(A[r][c]); if (v > best) { best = v; piv = r; } }
+        if (best == 0.0) return 0;
+        if (piv != c) for (int k = 0; k < 20; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
+        const double inv = 1.0 / A[c][c];
+        for (int k = c; k < 20; ++k) A[c][k] *= inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == c) continue;
+            const double fct = A[r][c];
+            if (fct == 0.0) continue;
+            for (int k = c; k < 20; ++k) A[r][k] -= fct * A[c][k];
+        }
+    }
+    double B[3][3][5];
+    for (int q = 0; q < 3; ++q) {
+        const double* lo = A[4 + 2 * q];
+        const double* hi = A[5 + 2 * q];
+        for (int v = 0; v < 2; ++v) {
+            const int o = 10 + 3 * v;
+            B[q][v][0] = lo[o + 2];
+            B[q][v][1] = lo[o + 1] - hi[o + 2];
+            B[q][v][2] = lo[o] - hi[o + 1];
+            B[q][v][3] = -hi[o];
+            B[q][v][4] = 0.0;
+        }
+        B[q][2][0] = lo[19];
+        B[q][2][1] = lo[18] - hi[19];
+        B[q][2][2] = lo[17] - hi[18];
+        B[q][2][3] = lo[16] - hi[17];
+        B[q][2][4] = -hi[16];
+    }
+    double P[11];
+    for (int k = 0; k <= 10; ++k) P[k] = 0.0;
+    for (int q = 0; q < 3; ++q) {
+        const int r1 = (q + 1) % 3, r2 = (q + 2) % 3;
+        double m1[7], m2[7], mn[7], term[11];
+        e_pmul(B[r1][0], 3, B[r2][1], 3, m1);
+        e_pmul(B[r1][1], 3, B[r2][0], 3, m2);
+        for (int k = 0; k <= 6; ++k) mn[k] = m1[k] - m2[k];
+        e_pmul(mn, 6, B[q][2], 4, term);
+        for (int k = 0; k <= 10; ++k) P[k] += term[k];
+    }
+    double roots[10];
+    const int nr = real_roots10(P, 10, roots);
+    int n_out = 0;
+    for (int s = 0; s < nr; ++s) {
+        const double z = roots[s];
+        double b[3][3];
+        for (int q = 0; q < 3; ++q) { b[q][0] = e_peval(B[q][0], 3, z); b[q][1] = e_peval(B[q][1], 3, z); b[q][2] = e_peval(B[q][2], 4, z); }
+        double bx = 0.0, by = 0.0, bw = 0.0;
+        for (int q = 0; q < 3; ++q) {
+            const int r1 = q, r2 = (q + 1) % 3;
+            const double cx = b[r1][1] * b[r2][2] - b[r1][2] * b[r2][1];
+            const double cy = b[r1][2] * b[r2][0] - b[r1][0] * b[r2][2];
+            const double cw = b[r1][0] * b[r2][1] - b[r1][1] * b[r2][0];
+            if (fabs(cw) > fabs(bw)) { bx = cx; by = cy; bw = cw; }
+        }
+        if (bw == 0.0) continue;
+        const double x = bx / bw, y = by / bw;
+        for (int r = 0; r < 9; ++r) Es[9 * n_out + r] = x * N[0][r] + y * N[1][r] + z * N[2][r] + N[3][r];
+        ++n_out;
+    }
+    return n_out;
+}
+
+// fundamental::kernel::EpipolarDistanceError: squared distance of x2 to the epipolar line F x1
+__device__ __forceinline__ double epipolar_dist_err(const double* F, double x1, double y1, double x2, double y2)
+{
+    const double l0 = F[0] * x1 + F[1] * y1 + F[2];
+    const double l1 = F[3] * x1 + F[4] * y1 + F[5];
+    const double l2 = F[6] * x1 + F[7] * y1 + F[8];
+    const double d = l0 * x2 + l1 * y2 + l2;
+    return (d * d) / (l0 * l0 + l1 * l1);
+}
+
+// FundamentalFromEssential: F = K2^-T E K1^-1
+__device__ __forceinline__ void f_from_e(const double* E, const double* K1i, const double* K2i, double* F)
+{
+    double T[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            for (int k = 0; k < 3; ++k) v += K2i[3 * k + r] * E[3 * k + c];
+            T[3 * r + c] = v;
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            for (int k = 0; k < 3; ++k) v += T[3 * r + k] * K1i[3 * k + c];
+            F[3 * r + c] = v;
+        }
+}
+
 // ---- per-workgroup shared state (lives at the front of the dynamic LDS region) ----
 struct FState {
     double minNFA, errorMax;
@@ -263,14 +520,17 @@ struct FState {
 
 constexpr int kChunk = 64;
 
-size_t filter_F_lds_bytes(uint32_t m_cap)
+size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 {
-    // [FState, padded to 1024][Fs: 64 x 27 doubles][keys: m_cap x u64][idx: m_cap x u32]
-    return 1024 + (size_t)kChunk * 27 * 8 + (size_t)m_cap * 12;
+    // [FState, padded to 1024][Fs: 64 x (9 x MAX_MODELS) doubles][keys: m_cap x u64][idx: m_cap x u32]
+    const size_t ms = model_kind == 2 ? 90 : 27;
+    return 1024 + (size_t)kChunk * ms * 8 + (size_t)m_cap * 12;
 }
 
 // KIND 0: fundamental matrix (7-point, <= 3 models, symmetric epipolar error, point-to-line NFA scale)
 // KIND 1: homography (4-point DLT, 1 model, asymmetric transfer error, point-to-point NFA scale)
+// KIND 2: essential matrix (5-point on K^-1 x, <= 10 models, epipolar distance in pixels through F = K2^-T E K1^-1,
+//         no normalisation of the points: ACKernelAdaptorEssential)
 template <int KIND>
 __global__ __launch_bounds__(256)
 void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
@@ -278,13 +538,14 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FState& S = *reinterpret_cast<FState*>(smem);
-    double* Fs = reinterpret_cast<double*>(smem + 1024);                                   // [64][27]
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * 27 * 8);
+    constexpr int MS = (KIND == 2) ? 90 : 27;                  // doubles per hypothesis: 9 x MAX_MODELS (27 also for H)
+    double* Fs = reinterpret_cast<double*>(smem + 1024);                                   // [64][MS]
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * MS * 8);
     uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
 
-    constexpr uint32_t SS = (KIND == 0) ? 7u : 4u;             // Kernel::MINIMUM_SAMPLES
-    constexpr double MAXM = (KIND == 0) ? 3.0 : 1.0;           // Kernel::MAX_MODELS
-    constexpr double MULT_ERR = (KIND == 0) ? 0.5 : 1.0;       // multError(): point-to-line vs point-to-point
+    constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);    // Kernel::MINIMUM_SAMPLES
+    constexpr double MAXM = (KIND == 0) ? 3.0 : (KIND == 1 ? 1.0 : 10.0); // Kernel::MAX_MODELS
+    constexpr double MULT_ERR = (KIND == 1) ? 1.0 : 0.5;       // multError(): point-to-point vs point-to-line
     const uint32_t item = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t begin = P.offsets[2 * item], end = P.offsets[2 * item + 1];
@@ -301,10 +562,13 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
 
     // ---- ACKernelAdaptor: normalisation N = [[s,0,-s w/2],[0,s,-s h/2],[0,0,1]], s = 1/sqrt(w h)
     const int wI = (int)Ip->width, hI = (int)Ip->height, wJ = (int)Jp->width, hJ = (int)Jp->height;
-    const double s1 = 1.0 / sqrt((double)(wI * hI));
-    const double s2 = 1.0 / sqrt((double)(wJ * hJ));
-    const double t1x = -0.5 * wI * s1, t1y = -0.5 * hI * s1;
-    const double t2x = -0.5 * wJ * s2, t2y = -0.5 * hJ * s2;
+    const double s1 = (KIND == 2) ? 1.0 : 1.0 / sqrt((double)(wI * hI));
+    const double s2 = (KIND == 2) ? 1.0 : 1.0 / sqrt((double)(wJ * hJ));
+    const double t1x = (KIND == 2) ? 0.0 : -0.5 * wI * s1, t1y = (KIND == 2) ? 0.0 : -0.5 * hI * s1;
+    const double t2x = (KIND == 2) ? 0.0 : -0.5 * wJ * s2, t2y = (KIND == 2) ? 0.0 : -0.5 * hJ * s2;
+    double K1i[9], K2i[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { K1i[e] = (KIND == 2) ? P.kinv[9 * (size_t)sl.x + e] : 0.0; K2i[e] = (KIND == 2) ? P.kinv[9 * (size_t)sl.y + e] : 0.0; }
     for (uint32_t p = tid; p < m; p += 256) {
         const r3dm_match q = mm[p];
         const double xi = (double)Ip->xy[2 * (size_t)q.i], yi = (double)Ip->xy[2 * (size_t)q.i + 1];
@@ -316,7 +580,8 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
     const double Dd = sqrt((double)wJ * (double)wJ + (double)hJ * (double)hJ);
     const double Aa = (double)wJ * (double)hJ;
     const double logalpha0 = (KIND == 0) ? log10(2.0 * Dd / Aa / s2)                       // 2 D / A / N2(0,0)
-                                         : log10(3.14159265358979323846 / Aa / (s2 * s2));   // pi / A / N2(0,0)^2
+                           : (KIND == 1) ? log10(3.14159265358979323846 / Aa / (s2 * s2))   // pi / A / N2(0,0)^2
+                                         : log10(2.0 * Dd / Aa * 0.5);                        // ACKernelAdaptorEssential
     const double maxThreshold = P.precision_px * P.precision_px * s2 * s2;
     const double loge0 = log10(MAXM * (double)(m - SS));
 
@@ -369,9 +634,21 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                 const uint32_t sidx_ = pool[pos[k < (int)SS ? k : 0]];
                 px1[k][0] = pt[4 * (size_t)sidx_ + 0]; px1[k][1] = pt[4 * (size_t)sidx_ + 1];
                 px2[k][0] = pt[4 * (size_t)sidx_ + 2]; px2[k][1] = pt[4 * (size_t)sidx_ + 3];
+                if (KIND == 2) {                 // camera coordinates: hnormalized(K^-1 (x, y, 1))
+                    const double xa = px1[k][0], ya = px1[k][1], xb = px2[k][0], yb = px2[k][1];
+                    const double w1 = K1i[6] * xa + K1i[7] * ya + K1i[8];
+                    px1[k][0] = (K1i[0] * xa + K1i[1] * ya + K1i[2]) / w1;
+                    px1[k][1] = (K1i[3] * xa + K1i[4] * ya + K1i[5]) / w1;
+                    const double w2 = K2i[6] * xb + K2i[7] * yb + K2i[8];
+                    px2[k][0] = (K2i[0] * xb + K2i[1] * yb + K2i[2]) / w2;
+                    px2[k][1] = (K2i[3] * xb + K2i[4] * yb + K2i[5]) / w2;
+                }
             }
-            double F3[27];
-            const int nm = (KIND == 0) ? seven_point(px1, px2, F3) : four_point_h(px1, px2, F3);
+            double F3[MS];
+            int nm;
+            if constexpr (KIND == 0) nm = seven_point(px1, px2, F3);
+            else if constexpr (KIND == 1) nm = four_point_h(px1, px2, F3);
+            else nm = five_point(px1, px2, F3);
             S.nm[tid] = (uint32_t)nm;
             S.dbg_smp[tid] = pool[pos[0]];
             if (P.trace && item == P.trace_item && iter0 + tid == P.trace_iter) {
@@ -381,7 +658,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                 for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k];
             }
             if (tid == 0) S.dbg_pool = pool_size;
-            for (int e = 0; e < 27; ++e) Fs[tid * 27 + e] = (e < 9 * nm) ? F3[e] : 0.0;
+            for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0;
         }
         __syncthreads();
 
@@ -395,7 +672,9 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
             for (uint32_t k = 0; k < nm; ++k) {
                 double F[9];
 #pragma unroll
-                for (int e = 0; e < 9; ++e) F[e] = Fs[c * 27 + k * 9 + e];
+                for (int e = 0; e < 9; ++e) F[e] = Fs[c * MS + k * 9 + e];
+                double FE[9];
+                if (KIND == 2) f_from_e(F, K1i, K2i, FE);
                 // residuals + compaction of those within the bound
                 uint32_t total = 0;
                 for (uint32_t base = 0; base < m; base += 256) {
@@ -403,7 +682,8 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                     double r = 0.0; bool in = false;
                     if (p < m) {
                         r = (KIND == 0) ? sym_epipolar_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3])
-                                        : h_asym_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3]);
+                          : (KIND == 1) ? h_asym_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3])
+                                        : epipolar_dist_err(FE, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3]);
                         in = (r <= maxThreshold);
                     }
                     const unsigned long long bal = __ballot(in);
@@ -572,6 +852,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                     Fo[3 * r + cc] = v;
                 }
             thr = sqrt(S.errorMax) / s2;
+            if (KIND == 2) { for (int e = 0; e < 9; ++e) Fo[e] = S.bestF[e]; thr = S.errorMax; }   // E itself; unormalizeError(e) = e
         }
         for (int e = 0; e < 9; ++e) P.F_out[9 * (size_t)item + e] = Fo[e];
         P.thr_nfa[2 * (size_t)item] = thr;
@@ -584,14 +865,17 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
 {
     if (P.n_items == 0) return hipSuccess;
-    const size_t lds = filter_F_lds_bytes(P.m_cap);
-    const void* fn = (P.model_kind == 0) ? (const void*)acransac_kernel<0> : (const void*)acransac_kernel<1>;
+    const size_t lds = filter_F_lds_bytes(P.m_cap, P.model_kind);
+    const void* fn = (P.model_kind == 0) ? (const void*)acransac_kernel<0>
+                   : (P.model_kind == 1) ? (const void*)acransac_kernel<1> : (const void*)acransac_kernel<2>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (P.model_kind == 0)
         hipLaunchKernelGGL(acransac_kernel<0>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
-    else
+    else if (P.model_kind == 1)
         hipLaunchKernelGGL(acransac_kernel<1>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+    else
+        hipLaunchKernelGGL(acransac_kernel<2>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
     return hipGetLastError();
 }
 

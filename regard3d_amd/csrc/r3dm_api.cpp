@@ -50,6 +50,8 @@ struct HostImage {
     DevBuf rows, tiled, norms, bin, xy, canon;
     DevBuf ann_adj, ann_deg;          // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0
     uint32_t ann_K = 0;
+    bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter
+    double Kinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     void release()
     {
         rows.release(); tiled.release(); norms.release(); bin.release(); xy.release(); canon.release();
@@ -104,7 +106,7 @@ struct r3dm_ctx {
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
-    DevBuf a_jobs, a_scratch, a_ids;
+    DevBuf a_jobs, a_scratch, a_ids, f_kinv;
     uint32_t liop_npix = 0;
     r3dm_stats stats{};
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
@@ -159,7 +161,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
                       &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
                       &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch,
                       &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
-                      &c->a_jobs, &c->a_scratch, &c->a_ids};
+                      &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -853,11 +855,13 @@ extern "C" int r3dm_kgraph_index(r3dm_ctx* c, uint32_t view_id, uint32_t index_K
 // geometric filter
 // ------------------------------------------------------------------------------------------------
 // model_kind 0 = fundamental matrix (GeometricFilter_FMatrix_AC), 1 = homography (GeometricFilter_HMatrix_AC)
+//            2 = essential matrix (GeometricFilter_EMatrix_AC) + Regard3D's overlap rule (min_count / min_ratio)
 static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
-                         uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out)
+                         uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out,
+                         uint32_t min_count = 0, float min_ratio = 0.f)
 {
     if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
-    const uint32_t SS = model_kind == 0 ? 7u : 4u;          // Kernel::MINIMUM_SAMPLES
+    const uint32_t SS = model_kind == 0 ? 7u : (model_kind == 1 ? 4u : 5u);          // Kernel::MINIMUM_SAMPLES
     *out = nullptr;
     R3DM_HIP(c, hipSetDevice(c->device));
     const double t_call = now_ms();
@@ -877,6 +881,8 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         const HostImage& B = *c->imgs[b->second];
         if (!A.has_xy || !B.has_xy) { c->err = "filter: view registered without feature positions"; return R3DM_ERR_INVALID; }
         if (m > 8192) { c->err = "filter: more than 8192 putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
+        // E_ACRobust: a pair whose views lack valid pinhole intrinsics is not estimated (and so not kept)
+        if (model_kind == 2 && (!A.has_K || !B.has_K)) continue;
         item_pair.push_back((uint32_t)p);
         slots.push_back(make_uint2(a->second, b->second));
         ids.push_back(make_uint2(I, J));
@@ -935,6 +941,15 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     fp.n_items = NI; fp.m_cap = std::max<uint32_t>(64, next_pow2(max_m));
     fp.precision_px = max_residual_px; fp.max_iter = max_iter; fp.seed = seed; fp.err_kind = (int)err_kind;
     fp.model_kind = model_kind;
+    fp.kinv = nullptr;
+    if (model_kind == 2) {
+        std::vector<double> kinv(9 * c->imgs.size(), 0.0);
+        for (size_t s = 0; s < c->imgs.size(); ++s)
+            if (c->imgs[s] && c->imgs[s]->has_K) memcpy(&kinv[9 * s], c->imgs[s]->Kinv, 72);
+        R3DM_HIP(c, c->f_kinv.ensure(kinv.size() * 8));
+        R3DM_HIP(c, hipMemcpy(c->f_kinv.p, kinv.data(), kinv.size() * 8, hipMemcpyHostToDevice));
+        fp.kinv = c->f_kinv.as<double>();
+    }
     fp.log10_tab = c->f_log10.as<float>(); fp.logc_k = c->f_logck.as<float>();
     fp.inl_count = c->f_inl_cnt.as<uint32_t>(); fp.inl_idx = c->f_inl_idx.as<uint32_t>();
     fp.F_out = c->f_F.as<double>(); fp.thr_nfa = c->f_thr.as<double>(); fp.iters = c->f_iters.as<uint32_t>();
@@ -942,7 +957,7 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     fp.pts_scratch = c->f_scratch.as<double>();
     fp.pool_scratch = reinterpret_cast<uint32_t*>(c->f_scratch.as<unsigned char>() + 32 * (size_t)n_match_total);
     fp.scratch_logc = reinterpret_cast<float*>(c->f_scratch.as<unsigned char>() + 36 * (size_t)n_match_total);
-    if (filter_F_lds_bytes(fp.m_cap) > 160 * 1024) { c->err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
+    if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { c->err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
     // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
     DevBuf trace_buf;
     const uint32_t trace_cap = 16384;
@@ -1012,6 +1027,9 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         if ((double)h_cnt[k] <= 2.5 * SS) continue;
         const uint32_t p = item_pair[k];
         const uint64_t base = putative->offsets[p];
+        // the reference's extra check after the E filter (src/R3DComputeMatches.cpp:2175-2192): pairs with poor overlap go
+        if (model_kind == 2 && (h_cnt[k] < min_count ||
+                                (float)h_cnt[k] / (float)(putative->offsets[p + 1] - base) < min_ratio)) continue;
         g->pairs.push_back(putative->pairs[2 * p]); g->pairs.push_back(putative->pairs[2 * p + 1]);
         for (uint32_t q = 0; q < h_cnt[k]; ++q) g->matches.push_back(putative->matches[base + h_idx[base + q]]);
         g->offsets.push_back(g->matches.size());
@@ -1033,6 +1051,31 @@ extern "C" int r3dm_filter_H(r3dm_ctx* c, const r3dm_graph* putative, double max
                              uint64_t seed, r3dm_graph** out, double* H_out)
 {
     return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 1, out, H_out);
+}
+
+extern "C" int r3dm_set_intrinsics(r3dm_ctx* c, uint32_t view_id, const double* K)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    auto it = c->slot_of.find(view_id);
+    if (it == c->slot_of.end()) { c->err = "r3dm_set_intrinsics: unregistered view"; return R3DM_ERR_INVALID; }
+    HostImage& h = *c->imgs[it->second];
+    if (!K) { h.has_K = false; return R3DM_OK; }
+    // inverse by the adjugate, operation for operation what oracle/essential.c orc_inv3 does
+    const double c00 = K[4] * K[8] - K[5] * K[7], c01 = K[5] * K[6] - K[3] * K[8], c02 = K[3] * K[7] - K[4] * K[6];
+    const double det = K[0] * c00 + K[1] * c01 + K[2] * c02;
+    if (!(det != 0.0) || !std::isfinite(det)) { c->err = "r3dm_set_intrinsics: singular K"; return R3DM_ERR_INVALID; }
+    const double id = 1.0 / det;
+    h.Kinv[0] = c00 * id; h.Kinv[1] = (K[2] * K[7] - K[1] * K[8]) * id; h.Kinv[2] = (K[1] * K[5] - K[2] * K[4]) * id;
+    h.Kinv[3] = c01 * id; h.Kinv[4] = (K[0] * K[8] - K[2] * K[6]) * id; h.Kinv[5] = (K[2] * K[3] - K[0] * K[5]) * id;
+    h.Kinv[6] = c02 * id; h.Kinv[7] = (K[1] * K[6] - K[0] * K[7]) * id; h.Kinv[8] = (K[0] * K[4] - K[1] * K[3]) * id;
+    h.has_K = true;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out)
+{
+    return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 2, out, E_out, min_count, min_ratio);
 }
 
 extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint64_t cap)

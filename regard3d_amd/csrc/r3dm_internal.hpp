@@ -124,7 +124,8 @@ struct FilterParams {
     uint32_t      max_iter;
     uint64_t      seed;
     int           err_kind;
-    int           model_kind;     // 0 = fundamental matrix (7-point), 1 = homography (4-point)
+    int           model_kind;     // 0 = fundamental matrix (7-point), 1 = homography (4-point), 2 = essential matrix (5-point)
+    const double* kinv;           // [slots][9] inverse intrinsics K^-1 of every view (essential matrix only)
     const float*  log10_tab;      // log10f(k), k = 0..max_m  (host-computed: same libm as the reference build)
     const float*  logc_k;         // logcombi(sample size, n), n = 0..max_m (host-computed)
     // outputs
@@ -157,7 +158,7 @@ hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t 
 hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_n);
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
-size_t     filter_F_lds_bytes(uint32_t m_cap);
+size_t     filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim);
 hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim);
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,

@@ -70,6 +70,12 @@ def _sift_base(rng, n: int, dim: int) -> np.ndarray:
     return g
 
 
+def intrinsics() -> np.ndarray:
+    """pinhole K of every synthetic view: f = 1.2 * width, principal point at the image centre"""
+    f = 1.2 * WIDTH
+    return np.array([[f, 0.0, 0.5 * WIDTH], [0.0, f, 0.5 * HEIGHT], [0.0, 0.0, 1.0]], np.float64)
+
+
 def make_scene(n_images: int, n_feat: int, kind: str = "sift", seed: int = 2002,
                dtype: str = "f32", outlier_frac: float = 0.15, dim: int | None = None) -> Scene:
     assert kind in ("sift", "liop", "akaze")

@@ -48,13 +48,17 @@ int main(int argc, char** argv)
         // stage <matches_dir> <dim> <basename...>
         r3d_amd::R3DComputeMatches stage(0);
         std::vector<r3d_amd::View> views;
-        for (int k = 4; k < argc; ++k) views.push_back({(uint32_t)(k - 4), 4000, 3000, argv[k]});
+        // synthetic views (regard3d_amd/synth.py): 4000 x 3000, f = 1.2 * width, principal point at the centre
+        for (int k = 4; k < argc; ++k) views.push_back({(uint32_t)(k - 4), 4000, 3000, argv[k], 4800.0, 2000.0, 1500.0});
         stage.addViews(views);
         stage.setRegionsType(R3DM_F32, (uint32_t)atoi(argv[3]));
         r3d_amd::R3DFParams params;
         r3d_amd::R3DProjectPaths paths;
         paths.relativeMatchesPath_ = argv[2];
-        const bool ok = stage.computeMatches(params, true, paths, 1, r3d_amd::R3DComputeMatches::kMatchingAlgorithmGPU);
+        // R3DM_TEST_ALGO selects the dispatch arm (default 9 = GPU brute force; 1..3 = KGraph presets)
+        const char* algo_env = getenv("R3DM_TEST_ALGO");
+        const int algo = algo_env ? atoi(algo_env) : r3d_amd::R3DComputeMatches::kMatchingAlgorithmGPU;
+        const bool ok = stage.computeMatches(params, true, paths, 1, algo);
         if (!ok) { fprintf(stderr, "computeMatches failed: %s\n", stage.errorMessage().c_str()); return 7; }
         printf("%zu %zu\n", stage.getStatistics().putativeMatches_.size(), stage.getStatistics().fundamentalMatches_.size());
         return 0;

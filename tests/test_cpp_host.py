@@ -81,6 +81,10 @@ def test_stage_facade_writes_the_reference_files(host_exe, oracle, tmp_path):
     p_h, c_h, m_h = oracle.load_matches(str(tmp_path / "matches.h.txt"))          # homography filter ran too
     oh, omh = oracle.filter_H_collection(sc.xys, sc.widths, sc.heights, pairs, counts, matches, 4.0, 2048, 5489)
     assert np.array_equal(p_h, pairs[oh > 0]) and np.array_equal(c_h, oh[oh > 0])
+    p_e, c_e, m_e = oracle.load_matches(str(tmp_path / "matches.e.txt"))          # essential-matrix filter + overlap rule
+    Ks = np.stack([synth.intrinsics()] * sc.n_images)
+    oe, ome = oracle.filter_E_collection(sc.xys, sc.widths, sc.heights, Ks, pairs, counts, matches, 4.0, 2048, 5489)
+    assert np.array_equal(p_e, pairs[oe > 0]) and np.array_equal(c_e, oe[oe > 0]) and (oe > 0).sum() >= 2
     # adjacency SVGs: putative always; the geometric one shows the LAST filter (H) and, like upstream, is not
     # written for an empty map (a relief scene has no dominant plane, so H may keep nothing)
     svgs = ["PutativeAdjacencyMatrix.svg"] + (["GeometricAdjacencyMatrix.svg"] if (oh > 0).any() else [])
@@ -96,3 +100,21 @@ def test_stage_facade_writes_the_reference_files(host_exe, oracle, tmp_path):
         seg = m[off:off + cnt]; off += cnt
         exp = om[int(oc[:np.flatnonzero(oc > 0)[k]].sum()):][:cnt]
         assert set(map(tuple, seg.tolist())) == set(map(tuple, exp.tolist()))
+
+
+@pytest.mark.gpu
+def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
+    """matchingAlgorithm 3 = "KGraph precise" (src/R3DComputeMatches.cpp:2051-2054): putative file == the CPU model"""
+    sc = synth.make_scene(4, 900, "liop", seed=29)
+    names = _write_views(oracle, str(tmp_path), sc)
+    env = dict(os.environ, R3DM_TEST_ALGO="3")
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    pairs = sc.exhaustive_pairs()
+    counts, matches, _ = oracle.match_collection_kgraph(sc.descs, sc.xys, pairs, 0.6, builder="exact", K=24, P=12, S=10,
+                                                        seed=1998, min_rows=128)
+    p, c, m = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
+    assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
+                       env=dict(os.environ, R3DM_TEST_ALGO="6"))
+    assert r.returncode == 7 and "not served" in r.stderr               # HNSW arm: refused, not substituted

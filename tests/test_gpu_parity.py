@@ -307,3 +307,38 @@ def test_knn2_random_shapes_sweep(ctx, oracle):
         oidx, odist = oracle.knn2(a, b)
         assert np.array_equal(dist, odist), (trial, dim, nI, nJ)
         assert np.array_equal(idx, oidx), (trial, dim, nI, nJ)
+
+
+def test_filter_E_matches_oracle(ctx, oracle):
+    """Essential-matrix AC-RANSAC (GeometricFilter_EMatrix_AC + the reference's overlap rule): same sample stream, the
+    5-point solver uses only + - * / after its QR, so inlier sets AND matrices agree with the CPU restatement."""
+    sc = synth.make_scene(5, 1400, "liop", seed=47)
+    ctx.clear_images()
+    K = synth.intrinsics()
+    for i in range(sc.n_images):
+        ctx.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000)
+        if i != 4:
+            ctx.set_intrinsics(i, K)                                  # view 4 has no intrinsics: its pairs are not estimated
+    pairs = sc.exhaustive_pairs()
+    g = ctx.match_pairs(pairs, 0.6, True)
+    counts = np.diff(g.offsets.astype(np.int64)).astype(np.uint32)
+    Ks = np.stack([K] * 5); Ks[4] = 0
+    for mc, mr in ((50, 0.3), (0, 0.0)):
+        ge, Em = ctx.filter_E(g, 4.0, 2048, seed=5489, min_count=mc, min_ratio=mr, want_E=True)
+        oc, om, oE = oracle.filter_E_collection(sc.xys, sc.widths, sc.heights, Ks, g.pairs, counts, g.matches, 4.0, 2048, 5489,
+                                                prune_min_count=mc, prune_min_ratio=mr, want_E=True)
+        d = ge.as_dict(); off = 0; kept = 0
+        for p, (I, J) in enumerate(g.pairs):
+            exp = om[off:off + oc[p]]; off += oc[p]
+            got = d.get((int(I), int(J)), np.zeros((0, 2), np.uint32))
+            assert set(map(tuple, got.tolist())) == set(map(tuple, exp.tolist())), (I, J, len(got), len(exp))
+            if oc[p]:
+                a = Em[kept] / np.linalg.norm(Em[kept]); b = oE[p] / np.linalg.norm(oE[p])
+                if np.dot(a, b) < 0: a = -a
+                assert np.linalg.norm(a - b) < 1e-9
+                sv = np.linalg.svd(Em[kept].reshape(3, 3), compute_uv=False)
+                assert abs(sv[0] - sv[1]) < 1e-6 * sv[0] and sv[2] < 1e-6 * sv[0]
+                kept += 1
+        assert kept >= 3 and all(4 not in k for k in d)
+    rep = ctx.filter_report()
+    assert any(r[3] > r[2] for r in rep if r[2])                          # (.., iterations, models, ..): several E per minimal sample
