@@ -10,6 +10,7 @@ ap.add_argument("--feat", type=int, default=8192)
 ap.add_argument("--kind", default="sift")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--check", type=int, default=0, help="verify this many pairs against the oracle")
+ap.add_argument("--all-filters", action="store_true", help="also time the essential-matrix and homography filters")
 a = ap.parse_args()
 
 t = time.time(); sc = synth.make_scene(a.images, a.feat, a.kind, seed=2002); print("gen %.1fs" % (time.time() - t), flush=True)
@@ -19,6 +20,7 @@ binary = a.kind == "akaze"
 t = time.time()
 for i in range(sc.n_images):
     c.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000, binary=binary)
+    c.set_intrinsics(i, synth.intrinsics())
 print("set_image %.2fs" % (time.time() - t), flush=True)
 pairs = sc.exhaustive_pairs()
 ratio, sq = (0.8, False) if binary else (0.6, True)
@@ -31,6 +33,11 @@ for rep in range(a.reps):
                           ms_kernel=s.ms_match_kernels, tflops=s.algorithmic_flops / (s.ms_match_kernels * 1e-3) / 1e12,
                           fallback=s.n_exact_fallback, queries=s.n_queries, put_pairs=g.num_pairs, put_matches=g.num_matches,
                           f_pairs=gf.num_pairs, f_matches=gf.num_matches, ms_filter_kernel=s2.ms_filter_kernels)), flush=True)
+    if a.all_filters:
+        t = time.time(); ge = c.filter_E(g); te = time.time() - t; se = c.stats()
+        t = time.time(); gh = c.filter_H(g); th = time.time() - t; sh = c.stats()
+        print(json.dumps(dict(rep=rep, t_filter_E=te, ms_E_kernel=se.ms_filter_kernels, e_pairs=ge.num_pairs, e_matches=ge.num_matches,
+                              t_filter_H=th, ms_H_kernel=sh.ms_filter_kernels, h_pairs=gh.num_pairs)), flush=True)
 if a.check:
     from oracle import pyoracle as O
     sub = pairs[: a.check]
