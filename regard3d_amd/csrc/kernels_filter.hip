@@ -531,22 +531,23 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 // KIND 1: homography (4-point DLT, 1 model, asymmetric transfer error, point-to-point NFA scale)
 // KIND 2: essential matrix (5-point on K^-1 x, <= 10 models, epipolar distance in pixels through F = K2^-T E K1^-1,
 //         no normalisation of the points: ACKernelAdaptorEssential)
-template <int KIND>
-__global__ __launch_bounds__(256)
-void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
-                       uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
+// KeyT / IdxT: the (residual, index) sort buffers live in LDS, or -- for the rare pair with more putative matches than
+// the LDS budget holds (near-duplicate views with > 8192 matches) -- in a slice of global scratch.
+// workgroup barrier that also orders this workgroup's global-memory traffic (pool / inlier lists / spilled sort
+// buffers live in global memory; HIP's __syncthreads only fences LDS)
+__device__ __forceinline__ void wg_sync() { __threadfence_block(); __syncthreads(); }
+
+template <int KIND, class KeyT, class IdxT>
+__device__ __forceinline__ void acransac_body(const FilterParams& P, double* __restrict__ pts, uint32_t* __restrict__ pool_g,
+                                              float* __restrict__ logc_g, unsigned char* smem, KeyT keys, IdxT sidx, uint32_t item)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FState& S = *reinterpret_cast<FState*>(smem);
     constexpr int MS = (KIND == 2) ? 90 : 27;                  // doubles per hypothesis: 9 x MAX_MODELS (27 also for H)
     double* Fs = reinterpret_cast<double*>(smem + 1024);                                   // [64][MS]
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * MS * 8);
-    uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
 
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);    // Kernel::MINIMUM_SAMPLES
     constexpr double MAXM = (KIND == 0) ? 3.0 : (KIND == 1 ? 1.0 : 10.0); // Kernel::MAX_MODELS
     constexpr double MULT_ERR = (KIND == 1) ? 1.0 : 0.5;       // multError(): point-to-point vs point-to-line
-    const uint32_t item = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t begin = P.offsets[2 * item], end = P.offsets[2 * item + 1];
     const uint32_t m = (uint32_t)(end - begin);
@@ -602,11 +603,10 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
         S.pool_size = m; S.n_inl = 0; S.acMode = !(P.precision_px < __builtin_huge_val());
         S.n_models = 0; S.iters_done = 0;
     }
-    __threadfence_block();
-    __syncthreads();
+        wg_sync();
 
     while (true) {
-        __syncthreads();
+        wg_sync();
         const uint32_t iter0 = S.iter, nIter0 = S.nIter;
         if (iter0 >= nIter0) break;
         const uint32_t chunk_n = (nIter0 - iter0 < (uint32_t)kChunk) ? nIter0 - iter0 : (uint32_t)kChunk;
@@ -660,7 +660,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
             if (tid == 0) S.dbg_pool = pool_size;
             for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0;
         }
-        __syncthreads();
+        wg_sync();
 
         // ---- evaluate the chunk's iterations in order
         bool pool_changed = false;
@@ -689,13 +689,13 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                     const unsigned long long bal = __ballot(in);
                     const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
                     if (lane == 0) S.wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-                    __syncthreads();
+                    wg_sync();
                     uint32_t woff = 0, tot = 0;
 #pragma unroll
                     for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
                     if (in) { keys[total + woff + before] = (unsigned long long)__double_as_longlong(r); sidx[total + woff + before] = p; }
                     total += tot;
-                    __syncthreads();
+                    wg_sync();
                 }
                 // AC mode switches on with the first model that has > 2.5*7 points within the bound
                 bool ac = S.acMode != 0;
@@ -706,7 +706,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                     // sort (residual, index) ascending: residuals are >= 0 so the u64 bit pattern orders them
                     uint32_t cap = 1; while (cap < total) cap <<= 1;
                     for (uint32_t q = total + tid; q < cap; q += 256) { keys[q] = ~0ull; sidx[q] = 0xFFFFFFFFu; }
-                    __syncthreads();
+                    wg_sync();
                     for (uint32_t size = 2; size <= cap; size <<= 1) {
                         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                             for (uint32_t tI = tid; tI < (cap >> 1); tI += 256) {
@@ -718,7 +718,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                                 const bool gt = (x > y) || (x == y && xi > yi);
                                 if (gt == up) { keys[lo] = y; keys[hi] = x; sidx[lo] = yi; sidx[hi] = xi; }
                             }
-                            __syncthreads();
+                            wg_sync();
                         }
                     }
                     // bestNFA: k = 8 .. total, first minimum wins
@@ -737,7 +737,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                         if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
                     }
                     if (lane == 0) { S.red_v[wave] = bv; S.red_k[wave] = bk; }
-                    __syncthreads();
+                    wg_sync();
 #pragma unroll
                     for (uint32_t w = 0; w < 4; ++w) {
                         const double ov = S.red_v[w]; const uint32_t ok = S.red_k[w];
@@ -752,7 +752,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                     for (uint32_t q = tid; q < kbest; q += 256) inl[q] = sidx[q];
                     better = true;
                 }
-                __syncthreads();
+                wg_sync();
                 if (tid == 0) {
                     if (P.trace && item == P.trace_item) {
                         const uint32_t row = *P.trace_rows;
@@ -772,7 +772,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                         for (int e = 0; e < 9; ++e) S.bestF[e] = F[e];
                     }
                 }
-                __syncthreads();
+                wg_sync();
             }
             // ---- end of iteration `it`: ACRANSAC's pool / budget update
             if (tid == 0) {
@@ -788,17 +788,17 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                     }
                 }
             }
-            __syncthreads();
+            wg_sync();
             if (S.flag) {
                 // new sampling pool = the inlier SET in ascending index order.  (The residual order of the
                 // inlier list is rounding noise among the 7 points the model was fitted to, so pool
                 // positions must not depend on it -- same rule in oracle/acransac.c.)
                 const uint32_t ni = S.n_inl;
-                uint32_t* flags = sidx;                                  // LDS scratch, free between models
+                IdxT flags = sidx;                                       // sort scratch, free between models
                 for (uint32_t q = tid; q < m; q += 256) flags[q] = 0u;
-                __syncthreads();
+                wg_sync();
                 for (uint32_t q = tid; q < ni; q += 256) flags[inl[q]] = 1u;
-                __syncthreads();
+                wg_sync();
                 uint32_t filled = 0;
                 for (uint32_t base = 0; base < m; base += 256) {
                     const uint32_t p = base + tid;
@@ -806,27 +806,25 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
                     const unsigned long long bal = __ballot(in);
                     const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
                     if (lane == 0) S.wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-                    __syncthreads();
+                    wg_sync();
                     uint32_t woff = 0, tot = 0;
 #pragma unroll
                     for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
                     if (in) pool[filled + woff + before] = p;
                     filled += tot;
-                    __syncthreads();
+                    wg_sync();
                 }
                 pool_changed = true;
             }
-            __threadfence_block();
-            __syncthreads();
+                        wg_sync();
             // the chunk was cut from the old budget: stop when the (possibly shrunk) budget is exhausted
             if (it + 1 >= S.nIter) { ++c; break; }
         }
         if (tid == 0) S.iter = iter0 + c;
-        __threadfence_block();
-    }
+            }
 
     // ---- result
-    __syncthreads();
+    wg_sync();
     if (tid == 0) {
         uint32_t n_inl = S.n_inl;
         if (!(S.minNFA < 0.0)) n_inl = 0;
@@ -859,6 +857,27 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
         P.thr_nfa[2 * (size_t)item + 1] = S.minNFA;
         P.iters[2 * (size_t)item] = S.iters_done;
         P.iters[2 * (size_t)item + 1] = S.n_models;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256)
+void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
+                     uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int MS = (KIND == 2) ? 90 : 27;
+    const uint32_t item = blockIdx.x;
+    const uint32_t m = (uint32_t)(P.offsets[2 * item + 1] - P.offsets[2 * item]);
+    if (m <= P.m_cap) {
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * MS * 8);
+        uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
+        acransac_body<KIND>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
+    } else {
+        // slice of the global spill buffer, sized for the next power of two of m (host: spill_off[item])
+        unsigned long long* keys = P.spill_keys + P.spill_off[item];
+        uint32_t* sidx = P.spill_idx + P.spill_off[item];
+        acransac_body<KIND>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
     }
 }
 

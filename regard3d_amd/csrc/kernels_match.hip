@@ -737,19 +737,12 @@ hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& Pin, uint32_t 
 // (IndMatch::getDeduplicated order), drops matches whose (xI,yI,xJ,yJ) repeat an earlier one
 // (IndMatchDecorator), appends the list to the batch output and records (offset, count).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
-void finalize_pairs_kernel(const FinalizeParams P)
+// body shared by the two storage classes of the sort buffer: `keys` / `drop` point into LDS (fast path) or into a
+// per-pair slice of global scratch (pairs that keep more matches than the LDS budget holds: views with > 16k features)
+template <class KeyT, class DropT>
+__device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys, DropT drop, unsigned long long* s_off_p,
+                                              uint32_t* wave_cnt, uint32_t* s_total_p, uint32_t pair)
 {
-    // all LDS comes from the dynamic region (keeps the base 16-byte aligned):
-    // [keys: sort_cap x u64][drop: sort_cap x u8][s_off u64][wave_cnt 4 x u32][s_total u32]
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* keys = (unsigned long long*)smem_raw;
-    unsigned char* drop = smem_raw + (size_t)P.sort_cap * 8;
-    unsigned long long* s_off_p = (unsigned long long*)(smem_raw + (size_t)P.sort_cap * 9);
-    uint32_t* wave_cnt = (uint32_t*)(s_off_p + 1);
-    uint32_t* s_total_p = wave_cnt + 4;
-
-    const uint32_t pair = blockIdx.x;
     const uint2 pr = P.pairs[pair];
     const ImgDev* __restrict__ Ip = P.imgs + pr.x;
     const ImgDev* __restrict__ Jp = P.imgs + pr.y;
@@ -778,6 +771,7 @@ void finalize_pairs_kernel(const FinalizeParams P)
         // pad to a power of two and bitonic-sort ascending
         uint32_t cap = 1; while (cap < m) cap <<= 1;
         for (uint32_t k = m + threadIdx.x; k < cap; k += 256) keys[k] = ~0ull;
+        __threadfence_block();
         __syncthreads();
         for (uint32_t size = 2; size <= cap; size <<= 1) {
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -788,6 +782,7 @@ void finalize_pairs_kernel(const FinalizeParams P)
                     const unsigned long long x = keys[lo], y = keys[hi];
                     if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
                 }
+                __threadfence_block();
                 __syncthreads();
             }
         }
@@ -800,6 +795,7 @@ void finalize_pairs_kernel(const FinalizeParams P)
                     d = (Ip->canon[(uint32_t)(keys[e] >> 32)] == ci) && (Jp->canon[(uint32_t)keys[e]] == cj);
                 drop[k] = d;
             }
+            __threadfence_block();
             __syncthreads();
             // stable in-place compaction by a single wave-serial pass (rare path)
             if (threadIdx.x == 0) {
@@ -807,6 +803,7 @@ void finalize_pairs_kernel(const FinalizeParams P)
                 for (uint32_t k = 0; k < m; ++k) if (!drop[k]) keys[w++] = keys[k];
                 *s_total_p = w;
             }
+            __threadfence_block();
             __syncthreads();
             m = *s_total_p;
         }
@@ -822,9 +819,41 @@ void finalize_pairs_kernel(const FinalizeParams P)
     const unsigned long long off = *s_off_p;
     if (off + m <= P.out_cap)
         for (uint32_t k = threadIdx.x; k < m; k += 256) {
-            r3dm_match mm; mm.i = (uint32_t)(keys[k] >> 32); mm.j = (uint32_t)keys[k];
+            const unsigned long long kk = keys[k];
+            r3dm_match mm; mm.i = (uint32_t)(kk >> 32); mm.j = (uint32_t)kk;
             P.out[off + k] = mm;
         }
+}
+
+__global__ __launch_bounds__(256)
+void finalize_pairs_kernel(const FinalizeParams P)
+{
+    // all LDS comes from the dynamic region (keeps the base 16-byte aligned):
+    // [keys: sort_cap x u64][drop: sort_cap x u8][s_off u64][wave_cnt 4 x u32][s_total u32]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* keys = (unsigned long long*)smem_raw;
+    unsigned char* drop = smem_raw + (size_t)P.sort_cap * 8;
+    unsigned long long* s_off_p = (unsigned long long*)(smem_raw + (size_t)P.sort_cap * 9);
+    uint32_t* wave_cnt = (uint32_t*)(s_off_p + 1);
+    uint32_t* s_total_p = wave_cnt + 4;
+    const uint32_t pair = blockIdx.x;
+
+    if (P.spill_keys == nullptr) { finalize_body(P, keys, drop, s_off_p, wave_cnt, s_total_p, pair); return; }
+
+    // views larger than the LDS budget: count what the pair keeps, spill only if it does not fit
+    const uint32_t nJ = P.imgs[P.pairs[pair].y].n;
+    const uint32_t* src = P.nn_idx + (size_t)pair * P.q_stride;
+    uint32_t cnt = 0;
+    for (uint32_t q = threadIdx.x; q < nJ; q += 256) cnt += (src[q] < kFallback) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    if ((threadIdx.x & 63u) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    const uint32_t kept = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+    if (kept <= P.sort_cap) finalize_body(P, keys, drop, s_off_p, wave_cnt, s_total_p, pair);
+    else finalize_body(P, P.spill_keys + (size_t)pair * P.spill_stride, P.spill_drop + (size_t)pair * P.spill_stride,
+                       s_off_p, wave_cnt, s_total_p, pair);
 }
 
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P)

@@ -106,7 +106,7 @@ struct r3dm_ctx {
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
-    DevBuf a_jobs, a_scratch, a_ids, f_kinv;
+    DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill;
     uint32_t liop_npix = 0;
     r3dm_stats stats{};
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
@@ -161,7 +161,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
                       &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
                       &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch,
                       &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
-                      &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv};
+                      &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill};
     for (DevBuf* b : bufs) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -362,6 +362,13 @@ static int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_
         FinalizeParams fp{};
         fp.imgs = c->d_imgs.as<ImgDev>(); fp.pairs = c->d_pairs.as<uint2>(); fp.n_pairs = P; fp.q_stride = q_stride;
         fp.nn_idx = c->d_nn.as<uint32_t>(); fp.sort_cap = sort_cap;
+        fp.spill_keys = nullptr; fp.spill_drop = nullptr; fp.spill_stride = 0;
+        if (q_stride > sort_cap) {                         // views with more rows than the LDS sort holds
+            fp.spill_stride = next_pow2(q_stride);
+            R3DM_HIP(c, c->d_spill.ensure((size_t)P * fp.spill_stride * 9));
+            fp.spill_keys = c->d_spill.as<unsigned long long>();
+            fp.spill_drop = c->d_spill.as<unsigned char>() + (size_t)P * fp.spill_stride * 8;
+        }
         fp.out = c->d_out.as<r3dm_match>(); fp.out_cap = out_cap;
         fp.total = reinterpret_cast<unsigned long long*>(c->d_cnt.as<uint32_t>() + 8);
         fp.pair_off = c->d_pair_off.as<uint64_t>(); fp.pair_cnt = c->d_pair_cnt.as<uint32_t>();
@@ -419,8 +426,7 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
         }
     }
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
-    const uint32_t sort_cap = std::max<uint32_t>(8, next_pow2(q_stride));
-    if ((size_t)sort_cap * 9 + 32 > 160 * 1024) { c->err = "more than 16384 features per view in the finalisation kernel"; return R3DM_ERR_UNSUPPORTED; }
+    const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
 
     std::vector<uint2> hp(P);
     for (uint32_t p = 0; p < P; ++p) hp[p] = make_uint2(jobs[p].sI, jobs[p].sJ);
@@ -690,8 +696,7 @@ static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ra
     }
     const uint32_t dim = c->imgs[jobs[0].sI]->dim;
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
-    const uint32_t sort_cap = std::max<uint32_t>(8, next_pow2(q_stride));
-    if ((size_t)sort_cap * 9 + 32 > 160 * 1024) { c->err = "more than 16384 features per view in the finalisation kernel"; return R3DM_ERR_UNSUPPORTED; }
+    const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
     std::vector<uint2> hp(P), hid(P);
     for (uint32_t p = 0; p < P; ++p) { hp[p] = make_uint2(jobs[p].sI, jobs[p].sJ); hid[p] = make_uint2(jobs[p].I, jobs[p].J); }
     R3DM_HIP(c, c->d_pairs.ensure(sizeof(uint2) * P));
@@ -880,7 +885,7 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         const HostImage& A = *c->imgs[a->second];
         const HostImage& B = *c->imgs[b->second];
         if (!A.has_xy || !B.has_xy) { c->err = "filter: view registered without feature positions"; return R3DM_ERR_INVALID; }
-        if (m > 8192) { c->err = "filter: more than 8192 putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
+        if (m > (1u << 22)) { c->err = "filter: more than 4M putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
         // E_ACRobust: a pair whose views lack valid pinhole intrinsics is not estimated (and so not kept)
         if (model_kind == 2 && (!A.has_K || !B.has_K)) continue;
         item_pair.push_back((uint32_t)p);
@@ -938,7 +943,24 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     fp.imgs = c->d_imgs.as<ImgDev>();
     fp.pairs = c->f_pairs.as<uint2>(); fp.pair_ids = c->f_ids.as<uint2>();
     fp.offsets = c->f_offs.as<uint64_t>(); fp.matches = c->f_matches.as<r3dm_match>();
-    fp.n_items = NI; fp.m_cap = std::max<uint32_t>(64, next_pow2(max_m));
+    // LDS sort capacity: 8192 (x 12 B) fits beside the hypothesis buffer; pairs with more putatives sort in global scratch
+    fp.n_items = NI; fp.m_cap = std::min<uint32_t>(8192, std::max<uint32_t>(64, next_pow2(max_m)));
+    fp.spill_keys = nullptr; fp.spill_idx = nullptr; fp.spill_off = nullptr;
+    if (max_m > fp.m_cap) {
+        std::vector<uint64_t> soff(NI, 0);
+        uint64_t tot = 0;
+        for (uint32_t k = 0; k < NI; ++k) {
+            const uint64_t mk = begin_end[2 * k + 1] - begin_end[2 * k];
+            soff[k] = tot;
+            if (mk > fp.m_cap) tot += next_pow2((uint32_t)mk);
+        }
+        R3DM_HIP(c, c->f_spill.ensure(tot * 12 + NI * 8 + 64));
+        unsigned char* base = c->f_spill.as<unsigned char>();
+        R3DM_HIP(c, hipMemcpy(base + tot * 12, soff.data(), NI * 8, hipMemcpyHostToDevice));
+        fp.spill_keys = reinterpret_cast<unsigned long long*>(base);
+        fp.spill_idx = reinterpret_cast<uint32_t*>(base + tot * 8);
+        fp.spill_off = reinterpret_cast<const uint64_t*>(base + tot * 12);
+    }
     fp.precision_px = max_residual_px; fp.max_iter = max_iter; fp.seed = seed; fp.err_kind = (int)err_kind;
     fp.model_kind = model_kind;
     fp.kinv = nullptr;

@@ -104,7 +104,10 @@ struct FinalizeParams {
     uint32_t      n_pairs;
     uint32_t      q_stride;
     const uint32_t* nn_idx;
-    uint32_t      sort_cap;       // power of two >= q_stride (LDS keys)
+    uint32_t      sort_cap;       // LDS sort capacity: power of two, >= q_stride unless the spill buffers are set
+    unsigned long long* spill_keys;   // optional [n_pairs][spill_stride]: sort buffer of pairs keeping more than sort_cap matches
+    unsigned char*      spill_drop;   // optional [n_pairs][spill_stride]
+    uint32_t      spill_stride;   // power of two >= q_stride
     r3dm_match*   out;            // compacted matches
     uint64_t      out_cap;
     unsigned long long* total;    // running total (atomic)
@@ -119,7 +122,10 @@ struct FilterParams {
     const uint64_t* offsets;      // per work item: [2k] = begin, [2k+1] = end of its putative list inside `matches`
     const r3dm_match* matches;
     uint32_t      n_items;
-    uint32_t      m_cap;          // power of two >= max m (LDS sort capacity)
+    uint32_t      m_cap;          // LDS sort capacity (power of two); items with more putatives use the spill buffers
+    unsigned long long* spill_keys;  // optional global sort buffers for those items
+    uint32_t*     spill_idx;
+    const uint64_t* spill_off;    // [n_items] element offset of the item's slice (next_pow2(m) elements)
     double        precision_px;
     uint32_t      max_iter;
     uint64_t      seed;

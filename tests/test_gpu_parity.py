@@ -342,3 +342,44 @@ def test_filter_E_matches_oracle(ctx, oracle):
         assert kept >= 3 and all(4 not in k for k in d)
     rep = ctx.filter_report()
     assert any(r[3] > r[2] for r in rep if r[2])                          # (.., iterations, models, ..): several E per minimal sample
+
+
+def _two_view_scene(rng, n, dim, frac_match=1.0):
+    """n features per view; the first frac_match*n of view 1 are noisy copies of view-0 rows (shuffled), seen by a second camera"""
+    A = np.rint(rng.uniform(0, 255, (n, dim))).astype(np.float32)
+    nm = int(frac_match * n)
+    B = np.rint(rng.uniform(0, 255, (n, dim))).astype(np.float32)
+    src = rng.permutation(n)[:nm]
+    B[:nm] = np.clip(A[src] + np.rint(rng.normal(0, 2, (nm, dim))), 0, 255)
+    X = np.c_[rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(8, 14, n)]
+    f = 4800.0
+    xyA = np.c_[f * X[:, 0] / X[:, 2] + 2000, f * X[:, 1] / X[:, 2] + 1500]
+    th = 0.05
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    Y = X @ R.T + np.array([0.8, 0.05, 0.1])
+    xyB_all = np.c_[f * Y[:, 0] / Y[:, 2] + 2000, f * Y[:, 1] / Y[:, 2] + 1500] + rng.normal(0, 0.4, (n, 2))
+    xyB = np.c_[rng.uniform(0, 4000, n), rng.uniform(0, 3000, n)]
+    xyB[:nm] = xyB_all[src]
+    perm = rng.permutation(n)
+    return A, xyA.astype(np.float32), B[perm], xyB[perm].astype(np.float32)
+
+
+@pytest.mark.parametrize("n,frac", [(20000, 1.0), (18000, 0.3)])
+def test_views_beyond_the_lds_sort_budget(ctx, oracle, n, frac):
+    """nFeatures_ defaults to 20000 (src/Regard3DFeatures.cpp:128): more rows than the 16384-key LDS sort of the finalisation
+    kernel -> pairs that keep more than 16384 matches sort in global scratch; more than 8192 putatives -> the filter spills too."""
+    rng = np.random.default_rng(n)
+    A, xyA, B, xyB = _two_view_scene(rng, n, 16, frac)
+    ctx.clear_images()
+    ctx.set_image(0, A, xyA, 4000, 3000); ctx.set_image(1, B, xyB, 4000, 3000)
+    pairs = np.array([[0, 1]], np.uint32)
+    g = ctx.match_pairs(pairs, 0.6, True)
+    counts, matches = oracle.match_collection([A, B], [xyA, xyB], pairs, 0.6, True)
+    assert counts[0] > (16384 if frac == 1.0 else 4000)
+    _graph_equal(g, pairs, counts, matches)
+    gf, F = ctx.filter_F(g, 4.0, 2048, seed=5489, want_F=True)
+    oc, om, oF = oracle.filter_F_collection([xyA, xyB], [4000, 4000], [3000, 3000], pairs, counts, matches, 4.0, 2048, 5489, want_F=True)
+    assert oc[0] > 0.9 * counts[0] and gf.num_pairs == 1
+    assert set(map(tuple, gf.matches.tolist())) == set(map(tuple, om.tolist()))
+    a = F[0] / np.linalg.norm(F[0]); b = oF[0] / np.linalg.norm(oF[0])
+    assert min(np.linalg.norm(a - b), np.linalg.norm(a + b)) < 1e-9
