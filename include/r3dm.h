@@ -163,6 +163,18 @@ int r3dm_kgraph_knn2(r3dm_ctx* ctx, const float* dataset, uint32_t n_dataset, co
 /* the index of a registered view (built if necessary): adj_out = n x 64 rows (0xFFFFFFFF padded), deg_out = n */
 int r3dm_kgraph_index(r3dm_ctx* ctx, uint32_t view_id, uint32_t index_K, uint32_t* adj_out, uint32_t* deg_out);
 
+/* ---- keypoint detection: Fast-A-KAZE ----
+ * The "Fast-AKAZE" arm of Regard3DFeatures::detectKeypoints (src/Regard3DFeatures.cpp:596-617): cv::AKAZE2::create() with its
+ * defaults (src/thirdparty/fast-akaze/AKAZEConfig.h:18-43: 4 octaves x 4 sublevels, PM_G2 diffusivity), setThreshold(threshold),
+ * detect() = nonlinear scale space by fast explicit diffusion + determinant-of-Hessian extrema + sub-pixel refinement + main
+ * orientation (src/thirdparty/fast-akaze/AKAZEFeatures.cpp:245-382), then the angle conversion of :604-613.
+ * image: height x width floats in [0, 1] (gray / 255, as R3DFeaturesThread.cpp:163-191 prepares it), host or device pointer.
+ * keypoints_out: cap x 4 floats (x, y, size, angle in degrees) -- exactly what r3dm_extract_liop takes; responses_out optional.
+ * *n_out = number detected (may exceed cap; only the first cap are written, in the reference's order: by evolution level, then
+ * by detection order).  The reference serialises this stage with a semaphore (one image at a time). */
+int r3dm_detect_akaze(r3dm_ctx* ctx, const float* image, uint32_t width, uint32_t height, float threshold,
+                      float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out);
+
 /* ---- descriptor extraction: LIOP on pre-extracted patches ----
  * r3d_vl_liopdesc_process of the vendored VLFeat copy (src/thirdparty/liop/vl_liop.c:465-580) as Regard3D
  * calls it per keypoint (src/Regard3DFeatures.cpp:727-752,827: new_basic(41) -> 4 neighbours, 6 bins, radius 6):
@@ -220,6 +232,7 @@ typedef struct {
     double   ms_ann_search;        /* HIP-event time of the search kernel                           */
     uint64_t n_ann_built;          /* indices built by the call                                     */
     uint64_t n_ann_dist;           /* descriptor distances evaluated by the searches                */
+    double   ms_detect;            /* wall time of the last r3dm_detect_akaze call                  */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -29,7 +29,7 @@ class FResult(C.Structure):
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "kgraph.c", "essential.c", "r3d_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "kgraph.c", "essential.c", "akaze.c", "r3d_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -58,6 +58,7 @@ def lib():
         L.orc_filter_H_collection.restype = C.c_int64
         L.orc_epipolar_dist_err.restype = C.c_double
         L.orc_epipolar_dist_err.argtypes = [C.c_void_p] + [C.c_double] * 4
+        L.orc_akaze_kcontrast.restype = C.c_float
         L.orc_kgraph_build_exact.restype = C.c_void_p
         L.orc_kgraph_build_nndescent.restype = C.c_void_p
         L.orc_kgraph_free.argtypes = [C.c_void_p]
@@ -464,3 +465,59 @@ def filter_E_collection(xys, widths, heights, Ks, pairs, counts, matches, precis
                                         _p(counts), _p(matches), C.c_double(precision_px), max_iter, C.c_uint64(seed),
                                         prune_min_count, C.c_float(prune_min_ratio), _p(oc), _p(out), _p(Eo))
     return (oc, out[:tot].copy(), Eo) if want_E else (oc, out[:tot].copy())
+
+
+# ---- Fast-A-KAZE detector (oracle/akaze.c) ------------------------------------------------------------
+def akaze_gaussian(img, sigma):
+    img = np.ascontiguousarray(img, np.float32); out = np.empty_like(img)
+    lib().orc_akaze_gaussian(_p(img), img.shape[1], img.shape[0], C.c_float(sigma), _p(out))
+    return out
+
+
+def akaze_scharr(img):
+    img = np.ascontiguousarray(img, np.float32); lx = np.empty_like(img); ly = np.empty_like(img)
+    lib().orc_akaze_scharr(_p(img), img.shape[1], img.shape[0], _p(lx), _p(ly))
+    return lx, ly
+
+
+def akaze_scaled_deriv(img, s, dx):
+    img = np.ascontiguousarray(img, np.float32); out = np.empty_like(img)
+    lib().orc_akaze_scaled_deriv(_p(img), img.shape[1], img.shape[0], s, int(dx), _p(out))
+    return out
+
+
+def akaze_kcontrast(lx, ly, perc=0.7, nbins=300):
+    lx = np.ascontiguousarray(lx, np.float32); ly = np.ascontiguousarray(ly, np.float32)
+    return float(lib().orc_akaze_kcontrast(_p(lx), _p(ly), lx.shape[1], lx.shape[0], C.c_float(perc), nbins))
+
+
+def akaze_halfsample(img):
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.empty((img.shape[0] // 2, img.shape[1] // 2), np.float32)
+    lib().orc_akaze_halfsample(_p(img), img.shape[1], img.shape[0], _p(out))
+    return out
+
+
+def akaze_fed_tau(T):
+    tau = np.zeros(256, np.float32)
+    n = lib().orc_akaze_fed_tau(C.c_float(T), _p(tau))
+    return tau[:n].copy()
+
+
+def akaze_detect(img, threshold=0.001, cap=200000, dbg_level=-1):
+    """-> dict(kps [n,4] (x, y, size, angle_deg), responses, levels, info[, ldet, lt of dbg_level])"""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape
+    kps = np.zeros((cap, 4), np.float32); resp = np.zeros(cap, np.float32); lev = np.zeros(cap, np.int32)
+    info = np.zeros(8, np.float32)
+    ldet = np.zeros((h, w), np.float32) if dbg_level >= 0 else None
+    lt = np.zeros((h, w), np.float32) if dbg_level >= 0 else None
+    n = lib().orc_akaze_detect(_p(img), w, h, C.c_float(threshold), _p(kps), cap, _p(resp), _p(lev), dbg_level,
+                               _p(ldet) if ldet is not None else None, _p(lt) if lt is not None else None, _p(info))
+    n = min(n, cap)
+    out = dict(kps=kps[:n].copy(), responses=resp[:n].copy(), levels=lev[:n].copy(), info=info)
+    if dbg_level >= 0:
+        lw, lh = int(info[2]), int(info[3])
+        out["ldet"] = ldet.ravel()[:lw * lh].reshape(lh, lw).copy()
+        out["lt"] = lt.ravel()[:lw * lh].reshape(lh, lw).copy()
+    return out

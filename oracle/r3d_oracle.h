@@ -189,6 +189,19 @@ int64_t  orc_filter_E_collection(int n_images, const int* n_rows, const float* c
                                  uint32_t prune_min_count, float prune_min_ratio,
                                  uint32_t* out_counts, orc_match* out, double* E_out);
 
+/* ---- Fast-A-KAZE keypoint detector (oracle/akaze.c; src/Regard3DFeatures.cpp:596-617, src/thirdparty/fast-akaze/).
+ * PARITY UNPINNED: the reference detector sits on OpenCV primitives (absent here); see the header of akaze.c. */
+int   orc_akaze_gauss_ksize(float sigma);
+void  orc_akaze_gaussian(const float* src, int w, int h, float sigma, float* dst);
+void  orc_akaze_scharr(const float* src, int w, int h, float* Lx, float* Ly);
+void  orc_akaze_scaled_deriv(const float* src, int w, int h, int s, int dx, float* dst);
+float orc_akaze_kcontrast(const float* Lx, const float* Ly, int w, int h, float perc, int nbins);
+void  orc_akaze_halfsample(const float* src, int w, int h, float* dst);
+int   orc_akaze_fed_tau(float T, float* tau);
+void  orc_akaze_orientation_vec(const float* Lx, const float* Ly, int cols, int x0, int y0, int scale, float* out_xy);
+int   orc_akaze_detect(const float* image, int w, int h, float dthreshold, float* kps, int cap, float* responses, int* levels,
+                       int dbg_level, float* dbg_ldet, float* dbg_lt, float* dbg_info);
+
 /* ---- KGraph plugin path (config C5): oracle/kgraph.c.  src/thirdparty/kgraph/kgraph.cpp:411-552 (search),
  * :703-997 (NN-descent), :660-700 (reverse), src/utils/matcher_kgraph.h, src/R3DComputeMatches.cpp:808-902. */
 typedef struct orc_kgraph orc_kgraph;

@@ -24,7 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_detect_akaze", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
 ]
 
 
@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("algorithmic_bytes", C.c_double), ("ms_wall_match", C.c_double),
                 ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double), ("ms_liop_kernel", C.c_double),
                 ("ms_ann_build", C.c_double), ("ms_ann_search", C.c_double), ("n_ann_built", C.c_uint64),
-                ("n_ann_dist", C.c_uint64)]
+                ("n_ann_dist", C.c_uint64), ("ms_detect", C.c_double)]
 
 
 class KGraphParams(C.Structure):
@@ -89,6 +89,7 @@ def load_library():
     L.r3dm_liop_describe_patches.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32)]
     L.r3dm_extract_liop.argtypes = [vp, vp, u32, u32, vp, u32, C.c_float, vp, vp]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
+    L.r3dm_detect_akaze.argtypes = [vp, vp, u32, u32, C.c_float, vp, vp, u32, C.POINTER(u32)]
     L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]
     L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_kgraph_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, u32, u32, vp, vp]
@@ -348,6 +349,18 @@ class Context:
         self._check(self._L.r3dm_extract_liop(self._h, _ptr(image), int(image.shape[1]), int(image.shape[0]), _ptr(keypoints), n,
                                               kp_size_factor, _ptr(desc), _ptr(patches)), "r3dm_extract_liop")
         return (desc[:n], patches[:n]) if want_patches else desc[:n]
+
+    def detect_akaze(self, image, threshold: float = 0.001, cap: int = 200000):
+        """image: [h, w] float32 in [0, 1] (numpy or torch, host or device) -> (keypoints [n, 4] (x, y, size, angle_deg), responses [n])"""
+        h, w = int(image.shape[0]), int(image.shape[1])
+        if isinstance(image, np.ndarray):
+            image = np.ascontiguousarray(image, np.float32)
+        kps = np.zeros((cap, 4), np.float32); resp = np.zeros(cap, np.float32)
+        n = C.c_uint32(0)
+        self._check(self._L.r3dm_detect_akaze(self._h, _ptr(image), w, h, threshold, _ptr(kps), _ptr(resp), cap, C.byref(n)),
+                    "r3dm_detect_akaze")
+        k = min(n.value, cap)
+        return kps[:k].copy(), resp[:k].copy()
 
     def filter_report(self):
         """per putative pair of the last filter_F call: (threshold_px, nfa, iterations, models, inliers)"""

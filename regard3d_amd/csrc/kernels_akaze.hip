@@ -1,0 +1,553 @@
+// kernels_akaze.hip -- Fast-A-KAZE keypoint detection for gfx950.
+//
+// Replaces the "Fast-AKAZE" arm of Regard3DFeatures::detectKeypoints (/root/reference/src/Regard3DFeatures.cpp:596-617):
+// cv::AKAZE2::detect = AKAZEFeaturesV2::Create_Nonlinear_Scale_Space + Feature_Detection
+// (src/thirdparty/fast-akaze/AKAZEFeatures.cpp:245-382; helpers in nldiffusion_functions.cpp, fed.cpp).  In the reference
+// this stage is serialised by a semaphore (one image at a time) and its image-sized stencils run on OpenCV's CPU filters.
+//
+// Here every stencil is one HBM-bound pass (a thread per pixel, neighbours through L1/L2), the arithmetic is the
+// restatement of OpenCV's scalar filter paths documented in oracle/akaze.c -- float, no contraction, only + - * / sqrt on
+// the device (Gaussian taps, FED step sizes, the k-contrast scan and atan2 are computed by the host library with libm)
+// -- so the keypoints equal the CPU restatement bit for bit.  Scale-space extrema are compacted in raster order and
+// pruned by one wavefront per level that keeps the reference's sequential "first neighbour in the list" rule, with the
+// live part of the list (rows within one radius of the scan line) held in LDS.
+#include "r3dm_internal.hpp"
+
+namespace r3dm {
+
+namespace {
+
+__device__ __forceinline__ int ak_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int ak_refl101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+
+}  // namespace
+
+// ---- GaussianBlur, BORDER_REPLICATE: row pass (SymmRowSmallFilter for 5 taps, RowFilter otherwise), column pass (SymmColumnFilter)
+__global__ __launch_bounds__(256)
+void ak_gauss_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, AkTaps kf)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float* S = src + (size_t)y * w;
+    const int n = kf.n, r = n / 2;
+    float s;
+    if (n == 5) {
+        s = S[x] * kf.k[2] + (S[ak_clamp(x - 1, 0, w - 1)] + S[ak_clamp(x + 1, 0, w - 1)]) * kf.k[3]
+            + (S[ak_clamp(x - 2, 0, w - 1)] + S[ak_clamp(x + 2, 0, w - 1)]) * kf.k[4];
+    } else {
+        s = kf.k[0] * S[ak_clamp(x - r, 0, w - 1)];
+        for (int k = 1; k < n; ++k) s += kf.k[k] * S[ak_clamp(x + k - r, 0, w - 1)];
+    }
+    dst[(size_t)y * w + x] = s;
+}
+__global__ __launch_bounds__(256)
+void ak_gauss_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, AkTaps kf)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int r = kf.n / 2;
+    float s = kf.k[r] * src[(size_t)y * w + x];
+    for (int k = 1; k <= r; ++k)
+        s += kf.k[r + k] * (src[(size_t)ak_clamp(y + k, 0, h - 1) * w + x] + src[(size_t)ak_clamp(y - k, 0, h - 1) * w + x]);
+    dst[(size_t)y * w + x] = s;
+}
+
+// ---- Scharr 3x3, BORDER_REFLECT_101: row pass writes the derivative and the smoothed row, column pass Lx and Ly
+__global__ __launch_bounds__(256)
+void ak_scharr_rows_kernel(const float* __restrict__ src, float* __restrict__ rd, float* __restrict__ rs, int w, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float* S = src + (size_t)y * w;
+    const float a = S[ak_refl101(x - 1, w)], b = S[ak_refl101(x + 1, w)];
+    rd[(size_t)y * w + x] = b - a;
+    rs[(size_t)y * w + x] = S[x] * 10.0f + (a + b) * 3.0f;
+}
+__global__ __launch_bounds__(256)
+void ak_scharr_cols_kernel(const float* __restrict__ rd, const float* __restrict__ rs, float* __restrict__ Lx, float* __restrict__ Ly,
+                           int w, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int yu = ak_refl101(y - 1, h), yd = ak_refl101(y + 1, h);
+    Lx[(size_t)y * w + x] = (rd[(size_t)yu * w + x] + rd[(size_t)yd * w + x]) * 3.0f + rd[(size_t)y * w + x] * 10.0f;
+    Ly[(size_t)y * w + x] = rs[(size_t)yd * w + x] - rs[(size_t)yu * w + x];
+}
+
+// ---- multiscale Scharr derivative (taps at -s, 0, +s), BORDER_REFLECT_101
+__global__ __launch_bounds__(256)
+void ak_sderiv_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (wgt + 2.0f));
+    const float kc = wgt * norm;
+    const float* S = src + (size_t)y * w;
+    const float a = S[ak_refl101(x - s, w)], b = S[ak_refl101(x + s, w)];
+    float v;
+    if (dx) v = (-a) + b;
+    else if (s == 2) v = S[x] * kc + (a + b) * norm;
+    else v = (norm * a + kc * S[x]) + norm * b;
+    dst[(size_t)y * w + x] = v;
+}
+__global__ __launch_bounds__(256)
+void ak_sderiv_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (wgt + 2.0f));
+    const float kc = wgt * norm;
+    const float u = src[(size_t)ak_refl101(y - s, h) * w + x], d = src[(size_t)ak_refl101(y + s, h) * w + x], c = src[(size_t)y * w + x];
+    dst[(size_t)y * w + x] = dx ? (kc * c + norm * (d + u)) : (d - u);
+}
+
+__global__ __launch_bounds__(256)
+void ak_det_kernel(const float* __restrict__ lxx, const float* __restrict__ lyy, const float* __restrict__ lxy, float* __restrict__ ldet, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ldet[i] = lxx[i] * lyy[i] - lxy[i] * lxy[i];
+}
+
+// ---- k-contrast: maximum of the gradient modulus over the interior, then its histogram
+__global__ __launch_bounds__(256)
+void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, uint32_t* __restrict__ out_max)
+{
+    const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63), y = 1 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    float m = 0.0f;
+    if (x < w - 1 && y < h - 1) { const float lx = Lx[(size_t)y * w + x], ly = Ly[(size_t)y * w + x]; m = sqrtf(lx * lx + ly * ly); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_max, __float_as_uint(m));      // m >= 0: bit order = value order
+}
+__global__ __launch_bounds__(256)
+void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, float sc, int nbins, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t lh[512];
+    for (int k = threadIdx.x; k < nbins; k += 256) lh[k] = 0;
+    __syncthreads();
+    const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
+    for (int yy = 0; yy < 16; ++yy) {
+        const int y = 1 + (blockIdx.y * 16 + yy) * 4 + (threadIdx.x >> 6);
+        if (x < w - 1 && y < h - 1) {
+            const float lx = Lx[(size_t)y * w + x], ly = Ly[(size_t)y * w + x];
+            const float m = sqrtf(lx * lx + ly * ly);
+            atomicAdd(&lh[(int)(m * sc)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += 256) if (lh[k]) atomicAdd(hist + k, lh[k]);
+}
+
+__global__ __launch_bounds__(256)
+void ak_pm_g2_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, float* __restrict__ dst, size_t n, float inv_k2)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = 1.0f / (1.0f + ((Lx[i] * Lx[i] + Ly[i] * Ly[i]) * inv_k2));
+}
+
+// ---- one FED step: Lstep (nld_step_scalar_one_lane; corners 0) and out = Lt + Lstep * 0.5 * step
+__global__ __launch_bounds__(256)
+void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, float step_size)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t p = (size_t)y * w + x;
+    const bool has_l = x > 0, has_r = x < w - 1, has_a = y > 0, has_b = y < h - 1;
+    const float tc = Lt[p], fc = Lf[p];
+    float v;
+    if (!has_a) {
+        if (!has_l || !has_r) v = 0.0f;
+        else v = (fc + Lf[p + 1]) * (Lt[p + 1] - tc) + (fc + Lf[p - 1]) * (Lt[p - 1] - tc) + (fc + Lf[p + w]) * (Lt[p + w] - tc);
+    } else if (!has_b) {
+        if (!has_l || !has_r) v = 0.0f;
+        else v = (fc + Lf[p + 1]) * (Lt[p + 1] - tc) + (fc + Lf[p - 1]) * (Lt[p - 1] - tc) + (fc + Lf[p - w]) * (Lt[p - w] - tc);
+    } else if (!has_l) {
+        v = (fc + Lf[p + 1]) * (Lt[p + 1] - tc) + (fc + Lf[p + w]) * (Lt[p + w] - tc) + (fc + Lf[p - w]) * (Lt[p - w] - tc);
+    } else if (!has_r) {
+        v = (fc + Lf[p - 1]) * (Lt[p - 1] - tc) + (fc + Lf[p + w]) * (Lt[p + w] - tc) + (fc + Lf[p - w]) * (Lt[p - w] - tc);
+    } else {
+        v = (fc + Lf[p + 1]) * (Lt[p + 1] - tc) + (fc + Lf[p - 1]) * (Lt[p - 1] - tc) +
+            (fc + Lf[p + w]) * (Lt[p + w] - tc) + (fc + Lf[p - w]) * (Lt[p - w] - tc);
+    }
+    out[p] = tc + v * 0.5f * step_size;
+}
+
+// ---- halfsample: INTER_AREA, exact 2x (resizeAreaFast_) or fractional cells (ResizeArea_, tables from the host)
+__global__ __launch_bounds__(256)
+void ak_half_fast_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int dw, int dh)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const float* S = src + (size_t)(2 * y) * w + 2 * x;
+    float sum = 0; sum += S[0]; sum += S[1]; sum += S[w]; sum += S[w + 1];
+    dst[(size_t)y * dw + x] = sum * 0.25f;
+}
+__global__ __launch_bounds__(256)
+void ak_half_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int dw, int dh,
+                         const AkAreaTab* __restrict__ xt, const int* __restrict__ xb, const AkAreaTab* __restrict__ yt, const int* __restrict__ yb)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    float sum = 0.0f;
+    for (int j = yb[y]; j < yb[y + 1]; ++j) {
+        const float* S = src + (size_t)yt[j].si * w;
+        float buf = 0.0f;
+        for (int k = xb[x]; k < xb[x + 1]; ++k) buf += S[xt[k].si] * xt[k].alpha;
+        if (j == yb[y]) sum = yt[j].alpha * buf; else sum += yt[j].alpha * buf;
+    }
+    dst[(size_t)y * dw + x] = sum;
+}
+
+// ---- scale-space extrema of one level: per-row counts, then raster-ordered compaction
+__device__ __forceinline__ bool ak_is_extremum(const float* __restrict__ ldet, int w, int x, int y, float thr)
+{
+    const float* curr = ldet + (size_t)y * w; const float* prev = curr - w; const float* next = curr + w;
+    const float v = curr[x];
+    if (v <= thr) return false;
+    if (v <= curr[x - 1] || v <= curr[x + 1]) return false;
+    if (v <= prev[x - 1] || v <= prev[x] || v <= prev[x + 1]) return false;
+    if (v <= next[x - 1] || v <= next[x] || v <= next[x + 1]) return false;
+    return true;
+}
+// one workgroup per image row (border .. h - border)
+__global__ __launch_bounds__(256)
+void ak_extrema_kernel(const AkLevelDev L, float thr, int pass /* 0 = count, 1 = emit */)
+{
+    __shared__ uint32_t wave_cnt[4];
+    const int y = L.border + blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t base = pass ? L.row_off[blockIdx.x] : 0u;
+    uint32_t total = 0;
+    for (int x0 = L.border; x0 < L.w - L.border; x0 += 256) {
+        const int x = x0 + (int)threadIdx.x;
+        const bool is = (x < L.w - L.border) && ak_is_extremum(L.Ldet, L.w, x, y, thr);
+        const unsigned long long bal = __ballot(is);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t cw = wave_cnt[q]; if (q < wave) woff += cw; tot += cw; }
+        if (pass && is) {
+            const uint32_t o = base + total + woff + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            L.cand[o] = make_float4((float)(x * L.ratio), (float)(y * L.ratio), L.Ldet[(size_t)y * L.w + x], 0.0f);
+        }
+        total += tot;
+        __syncthreads();
+    }
+    if (!pass && threadIdx.x == 0) L.row_cnt[blockIdx.x] = total;
+}
+// exclusive scan of the row counts of every level (one workgroup per level)
+__global__ __launch_bounds__(1024)
+void ak_scan_rows_kernel(const AkLevelDev* __restrict__ levels)
+{
+    __shared__ uint32_t part[1024];
+    const AkLevelDev L = levels[blockIdx.x];
+    const int n = L.h - 2 * L.border;
+    const int per = (n + 1023) / 1024;
+    const int b = threadIdx.x * per, e = b + per < n ? b + per : n;
+    uint32_t s = 0;
+    for (int k = b; k < e; ++k) s += L.row_cnt[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int t = 0; t < 1024; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; } L.counts[0] = run; }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (int k = b; k < e; ++k) { L.row_off[k] = run; run += L.row_cnt[k]; }
+}
+
+// ---- in-level pruning (Find_Scale_Space_Extrema, first loop): candidates in raster order; a candidate within `size` of
+// a kept point replaces it if stronger (the slot keeps its place), else is dropped; otherwise it is appended.  "The"
+// kept point = the first one in list order.  A slot's row never decreases, so only slots within one radius of the scan
+// line can still match: that live set is kept in LDS, in list order.  One wavefront per level.
+constexpr int kAkLive = 3072;
+template <class FP, class UP>
+__device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_cand, FP lx, FP ly, FP lr, UP lslot)
+{
+    const int lane = threadIdx.x;
+    const float size = L.psize, size2 = size * size;
+    uint32_t n_list = 0, n_live = 0;
+    float cur_row = -1.0f;
+    for (uint32_t c0 = 0; c0 < n_cand; c0 += 64) {
+        const float4 mine = (c0 + lane < n_cand) ? L.cand[c0 + lane] : make_float4(0, 0, 0, 0);
+        const uint32_t nb = (n_cand - c0 < 64u) ? n_cand - c0 : 64u;
+        for (uint32_t k = 0; k < nb; ++k) {
+            const float px = __shfl(mine.x, (int)k), py = __shfl(mine.y, (int)k), pr = __shfl(mine.z, (int)k);
+            if (py != cur_row) {
+                // new scan line: drop live entries that no later candidate can reach
+                cur_row = py;
+                uint32_t w = 0;
+                for (uint32_t b = 0; b < n_live; b += 64) {
+                    const uint32_t i = b + lane;
+                    float ex = 0, ey = 0, er = 0; uint32_t es = 0; bool keep = false;
+                    if (i < n_live) { ex = lx[i]; ey = ly[i]; er = lr[i]; es = lslot[i]; const float dy = py - ey; keep = dy * dy <= size2; }
+                    const unsigned long long bal = __ballot(keep);
+                    const uint32_t o = w + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    __threadfence_block();
+                    if (keep) { lx[o] = ex; ly[o] = ey; lr[o] = er; lslot[o] = es; }
+                    w += (uint32_t)__builtin_popcountll(bal);
+                }
+                __threadfence_block();
+                n_live = w;
+            }
+            // first live entry within the radius
+            int found = -1;
+            for (uint32_t b = 0; b < n_live && found < 0; b += 64) {
+                const uint32_t i = b + lane;
+                bool hit = false;
+                if (i < n_live) { const float dx = px - lx[i], dy = py - ly[i]; hit = dx * dx + dy * dy <= size2; }
+                const unsigned long long bal = __ballot(hit);
+                if (bal) found = (int)b + __builtin_ctzll(bal);
+            }
+            if (found >= 0) {
+                if (pr > lr[found]) {
+                    if (lane == 0) { lx[found] = px; ly[found] = py; lr[found] = pr; L.list[lslot[found]] = make_float4(px, py, pr, 1.0f); }
+                }
+            } else {
+                if (lane == 0) { lx[n_live] = px; ly[n_live] = py; lr[n_live] = pr; lslot[n_live] = n_list; L.list[n_list] = make_float4(px, py, pr, 1.0f); }
+                ++n_live; ++n_list;
+            }
+            __threadfence_block();
+        }
+    }
+    if (lane == 0) L.counts[1] = n_list;
+}
+
+__global__ __launch_bounds__(64)
+void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels)
+{
+    __shared__ float lx[kAkLive], ly[kAkLive], lr[kAkLive];
+    __shared__ uint32_t lslot[kAkLive];
+    const AkLevelDev L = levels[blockIdx.x];
+    const uint32_t n_cand = L.counts[0];
+    // the live set never holds more entries than there are candidates: small levels stay in LDS, the rest use scratch
+    if (n_cand <= (uint32_t)kAkLive) ak_prune_body(L, n_cand, lx, ly, lr, lslot);
+    else ak_prune_body(L, n_cand, L.live, L.live + n_cand, L.live + 2 * (size_t)n_cand, (uint32_t*)(L.live + 3 * (size_t)n_cand));
+}
+
+// ---- cross-level pruning.  mode 0 ("lower"): a point q of level i-1 dies when some point p of level i lies within
+// p.size of it with a larger response.  mode 1 ("upper"): a point v of level i+1 dies when some point p of level i that
+// survived mode 0 lies within v.size of it with a larger response.  One thread per victim.
+__global__ __launch_bounds__(256)
+void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mode)
+{
+    const int vi = blockIdx.y;                                   // victim level
+    const int ki = mode == 0 ? vi + 1 : vi - 1;                  // killer level
+    if (ki < 0 || ki >= n_levels) return;
+    const AkLevelDev V = levels[vi], K = levels[ki];
+    const uint32_t nv = V.counts[1], nk = K.counts[1];
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nv) return;
+    const float4 v = V.list[q];
+    const float r = mode == 0 ? K.psize : V.psize, r2 = r * r;
+    bool dead = false;
+    for (uint32_t j = 0; j < nk && !dead; ++j) {
+        const float4 p = K.list[j];
+        if (mode == 1 && K.dead_lower[j]) continue;
+        const float dx = p.x - v.x, dy = p.y - v.y;
+        dead = (dx * dx + dy * dy <= r2) && (p.z > v.z);
+    }
+    (mode == 0 ? V.dead_lower : V.dead_upper)[q] = dead ? 1 : 0;
+}
+
+// ---- sub-pixel refinement + dominant gradient direction (Do_Subpixel_Refinement, Compute_Main_Orientation up to the
+// vector whose angle the host takes).  One thread per list entry; out: (x, y, size, response), (maxX, maxY), valid.
+__device__ const float kGauss25[7][7] = {
+    { 0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f },
+    { 0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f },
+    { 0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f },
+    { 0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f },
+    { 0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f },
+    { 0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f },
+    { 0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f } };
+
+__device__ __forceinline__ float ak_fast_atan2(float y, float x)
+{
+    const float kR = 0x1.ca5dc2p+5f;                              // (float)(180 / CV_PI)
+    const float p1 = 0.9997878412794807f * kR, p3 = -0.3258083974640975f * kR, p5 = 0.1555786518463281f * kR, p7 = -0.04432655554792128f * kR;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + 0x1p-52f); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + 0x1p-52f); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a * 0x1.1df46ap-6f;                                    // (float)(CV_PI / 180)
+}
+
+__global__ __launch_bounds__(64)
+void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
+{
+    const AkLevelDev L = levels[blockIdx.y];
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= L.counts[1]) return;
+    float4 kp = L.list[j];
+    float4 o0 = make_float4(0, 0, 0, 0);
+    float2 o1 = make_float2(0, 0);
+    uint32_t valid = 0;
+    if (!L.dead_lower[j] && !L.dead_upper[j]) {
+        const float* __restrict__ ldet = L.Ldet;
+        const int cols = L.w;
+        const float ratio = L.ratio;
+        const int x = (int)(kp.x / ratio), y = (int)(kp.y / ratio);
+        const float Dx = 0.5f * (ldet[y * cols + x + 1] - ldet[y * cols + x - 1]);
+        const float Dy = 0.5f * (ldet[(y + 1) * cols + x] - ldet[(y - 1) * cols + x]);
+        const float Dxx = ldet[y * cols + x + 1] + ldet[y * cols + x - 1] - 2.0f * ldet[y * cols + x];
+        const float Dyy = ldet[(y + 1) * cols + x] + ldet[(y - 1) * cols + x] - 2.0f * ldet[y * cols + x];
+        const float Dxy = 0.25f * (ldet[(y + 1) * cols + x + 1] + ldet[(y - 1) * cols + x - 1] -
+                                   ldet[(y - 1) * cols + x + 1] - ldet[(y + 1) * cols + x - 1]);
+        float dx = 0.0f, dy = 0.0f;
+        {
+            const float b0 = -Dx, b1 = -Dy;
+            double d = (double)Dxx * Dyy - (double)Dxy * Dxy;
+            if (d != 0.) {
+                d = 1. / d;
+                const double t = (float)(((double)b0 * Dyy - (double)b1 * Dxy) * d);
+                dy = (float)(((double)b1 * Dxx - (double)b0 * Dxy) * d);
+                dx = (float)t;
+            }
+        }
+        if (!(fabsf(dx) > 1.0f || fabsf(dy) > 1.0f)) {
+            valid = 1;
+            kp.x += dx * ratio; kp.y += dy * ratio;
+            const float size = L.psize * 2.0f;
+            const int scale = (int)(0.5f * size / ratio + 0.5f);
+            const int x0 = (int)(kp.x / ratio + 0.5f), y0 = (int)(kp.y / ratio + 0.5f);
+            float resX[109], resY[109], Ang[109];
+            int k = 0;
+            for (int i = -6; i <= 6; ++i)
+                for (int jj = -6; jj <= 6; ++jj)
+                    if (i * i + jj * jj < 36) {
+                        const float wgt = kGauss25[i < 0 ? -i : i][jj < 0 ? -jj : jj];
+                        const size_t p = (size_t)(y0 + i * scale) * cols + (x0 + jj * scale);
+                        resX[k] = wgt * L.Lx[p]; resY[k] = wgt * L.Ly[p];
+                        ++k;
+                    }
+            for (int i = 0; i < 109; ++i) Ang[i] = ak_fast_atan2(resY[i], resX[i]);
+            constexpr int slices = 42, win = 7;
+            const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
+            unsigned char slice[slices + 1], sorted_idx[109];
+            const int nkeys = (int)(0x1.921fb6p+2f / ang_step);   // (float)(2 pi) / ang_step = 42
+            for (int i = 0; i <= nkeys; ++i) slice[i] = 0;
+            for (int i = 0; i < 109; ++i) slice[(int)(Ang[i] / ang_step)]++;
+            for (int i = 1; i <= nkeys; ++i) slice[i] += slice[i - 1];
+            for (int i = 0; i < 109; ++i) sorted_idx[--slice[(int)(Ang[i] / ang_step)]] = (unsigned char)i;
+            float maxX = 0.0f, maxY = 0.0f;
+            for (int i = slice[0]; i < slice[win]; ++i) { maxX += resX[sorted_idx[i]]; maxY += resY[sorted_idx[i]]; }
+            float maxNorm = maxX * maxX + maxY * maxY;
+            for (int sn = 1; sn <= slices - win; ++sn) {
+                if (slice[sn] == slice[sn - 1] && slice[sn + win] == slice[sn + win - 1]) continue;
+                float sumX = 0.0f, sumY = 0.0f;
+                for (int i = slice[sn]; i < slice[sn + win]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+                const float nrm = sumX * sumX + sumY * sumY;
+                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
+            }
+            for (int sn = slices - win + 1; sn < slices; ++sn) {
+                const int remain = sn + win - slices;
+                if (slice[sn] == slice[sn - 1] && slice[remain] == slice[remain - 1]) continue;
+                float sumX = 0.0f, sumY = 0.0f;
+                for (int i = slice[sn]; i < slice[slices]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+                for (int i = slice[0]; i < slice[remain]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+                const float nrm = sumX * sumX + sumY * sumY;
+                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
+            }
+            o0 = make_float4(kp.x, kp.y, size, kp.z);
+            o1 = make_float2(maxX, maxY);
+        }
+    }
+    L.out0[j] = o0; L.out1[j] = o1; L.out_valid[j] = valid;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static dim3 ak_grid(int w, int h) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4)); }
+
+hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf)
+{
+    hipLaunchKernelGGL(ak_gauss_rows_kernel, ak_grid(w, h), dim3(256), 0, st, src, tmp, w, h, kf);
+    hipLaunchKernelGGL(ak_gauss_cols_kernel, ak_grid(w, h), dim3(256), 0, st, tmp, dst, w, h, kf);
+    return hipGetLastError();
+}
+hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h)
+{
+    hipLaunchKernelGGL(ak_scharr_rows_kernel, ak_grid(w, h), dim3(256), 0, st, src, rd, rs, w, h);
+    hipLaunchKernelGGL(ak_scharr_cols_kernel, ak_grid(w, h), dim3(256), 0, st, rd, rs, Lx, Ly, w, h);
+    return hipGetLastError();
+}
+hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int s, int dx)
+{
+    hipLaunchKernelGGL(ak_sderiv_rows_kernel, ak_grid(w, h), dim3(256), 0, st, src, tmp, w, h, s, dx);
+    hipLaunchKernelGGL(ak_sderiv_cols_kernel, ak_grid(w, h), dim3(256), 0, st, tmp, dst, w, h, s, dx);
+    return hipGetLastError();
+}
+hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const float* lxy, float* ldet, size_t n)
+{
+    hipLaunchKernelGGL(ak_det_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lxx, lyy, lxy, ldet, n);
+    return hipGetLastError();
+}
+hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max)
+{
+    hipLaunchKernelGGL(ak_modg_max_kernel, ak_grid(w - 2, h - 2), dim3(256), 0, st, Lx, Ly, w, h, out_max);
+    return hipGetLastError();
+}
+hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, float sc, int nbins, uint32_t* hist)
+{
+    if (nbins > 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)((h - 2 + 63) / 64)), dim3(256), 0, st, Lx, Ly, w, h, sc, nbins, hist);
+    return hipGetLastError();
+}
+hipError_t ak_pm_g2(hipStream_t st, const float* Lx, const float* Ly, float* dst, size_t n, float inv_k2)
+{
+    hipLaunchKernelGGL(ak_pm_g2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Lx, Ly, dst, n, inv_k2);
+    return hipGetLastError();
+}
+hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size)
+{
+    hipLaunchKernelGGL(ak_fed_step_kernel, ak_grid(w, h), dim3(256), 0, st, Lt, Lf, out, w, h, step_size);
+    return hipGetLastError();
+}
+hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
+                         const AkAreaTab* yt, const int* yb)
+{
+    const int dw = w / 2, dh = h / 2;
+    if (dw * 2 == w && dh * 2 == h) hipLaunchKernelGGL(ak_half_fast_kernel, ak_grid(dw, dh), dim3(256), 0, st, src, dst, w, dw, dh);
+    else hipLaunchKernelGGL(ak_half_area_kernel, ak_grid(dw, dh), dim3(256), 0, st, src, dst, w, dw, dh, xt, xb, yt, yb);
+    return hipGetLastError();
+}
+hipError_t ak_extrema(hipStream_t st, const AkLevelDev& L, float thr, int pass)
+{
+    const int rows = L.h - 2 * L.border;
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ak_extrema_kernel, dim3((unsigned)rows), dim3(256), 0, st, L, thr, pass);
+    return hipGetLastError();
+}
+hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels)
+{
+    hipLaunchKernelGGL(ak_scan_rows_kernel, dim3((unsigned)n_levels), dim3(1024), 0, st, levels);
+    return hipGetLastError();
+}
+hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels)
+{
+    hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)n_levels), dim3(64), 0, st, levels);
+    return hipGetLastError();
+}
+hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list, int mode)
+{
+    if (max_list == 0) return hipSuccess;
+    hipLaunchKernelGGL(ak_cross_kernel, dim3((max_list + 255) / 256, (unsigned)n_levels), dim3(256), 0, st, levels, n_levels, mode);
+    return hipGetLastError();
+}
+hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list)
+{
+    if (max_list == 0) return hipSuccess;
+    hipLaunchKernelGGL(ak_refine_kernel, dim3((max_list + 63) / 64, (unsigned)n_levels), dim3(64), 0, st, levels);
+    return hipGetLastError();
+}
+
+}  // namespace r3dm

@@ -150,6 +150,37 @@ struct FilterParams {
     uint32_t*     trace_rows;
 };
 
+// ---- Fast-A-KAZE detector (kernels_akaze.hip) ----
+struct AkTaps { int n; float k[31]; };                  // Gaussian taps (host: getGaussianKernel restated), n <= 31
+struct AkAreaTab { int si; float alpha; };              // one source cell of an INTER_AREA destination cell
+struct AkLevelDev {
+    int w, h, border;
+    float ratio, psize;                                  // octave ratio; keypoint size before the final doubling (esigma * 1.5)
+    const float* Ldet; const float* Lx; const float* Ly;
+    uint32_t* row_cnt; uint32_t* row_off;                // [h - 2 border] extrema per image row / exclusive scan
+    uint32_t* counts;                                    // [0] candidates, [1] list entries after the in-level pruning
+    float4* cand;                                        // raster-ordered candidates (x, y, response, -)
+    float4* list;                                        // kept points (x, y, response, -), in insertion order
+    float*  live;                                        // scratch for the live set of large levels (4 x capacity)
+    unsigned char* dead_lower; unsigned char* dead_upper;
+    float4* out0; float2* out1; uint32_t* out_valid;     // refined (x, y, size, response), dominant gradient vector, kept?
+};
+hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf);
+hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h);
+hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int s, int dx);
+hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const float* lxy, float* ldet, size_t n);
+hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max);
+hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, float sc, int nbins, uint32_t* hist);
+hipError_t ak_pm_g2(hipStream_t st, const float* Lx, const float* Ly, float* dst, size_t n, float inv_k2);
+hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size);
+hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
+                         const AkAreaTab* yt, const int* yb);
+hipError_t ak_extrema(hipStream_t st, const AkLevelDev& L, float thr, int pass);
+hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels);
+hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels);
+hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list, int mode);
+hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list);
+
 // ---- launchers implemented in the .hip files (host side) ----
 hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
                             float* rows, float* tiled, float* norms, uint32_t G, uint32_t n_tiles,

@@ -1,0 +1,64 @@
+"""GPU parity of the Fast-A-KAZE detector (r3dm_detect_akaze) against oracle/akaze.c: the device uses only + - * / sqrt in
+float without contraction and the host library shares libm with the oracle, so keypoints, sizes, angles and responses are
+compared BIT-EXACTLY.  (The oracle itself is parity-unpinned against the reference: see its header.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(h, w, seed, n_blobs=40, noise=0.01):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 0.5 + 0.1 * np.sin(xx / 17.0) * np.cos(yy / 23.0)
+    for _ in range(n_blobs):
+        mg = min(40, h // 4)
+        cx, cy = rng.uniform(mg, w - mg), rng.uniform(mg, h - mg)
+        s = rng.uniform(2, 12); a = rng.uniform(0.15, 0.45) * rng.choice([-1, 1])
+        th = rng.uniform(0, np.pi); e = rng.uniform(1.0, 2.5)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        img = img + a * np.exp(-(u * u / (2 * s * s * e) + v * v / (2 * s * s / e)))
+    img = img + rng.normal(0, noise, img.shape)
+    return np.clip(img, 0, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("h,w,thr,seed", [(480, 640, 0.001, 1), (757, 999, 0.001, 2), (600, 800, 0.0001, 3), (1500, 2000, 0.001, 4),
+                                           (120, 160, 0.001, 5), (60, 90, 0.001, 6)])
+def test_detector_equals_the_cpu_restatement(ctx, oracle, h, w, thr, seed):
+    img = _scene(h, w, seed, n_blobs=max(4, h * w // 8000))
+    kps, resp = ctx.detect_akaze(img, thr)
+    ref = oracle.akaze_detect(img, thr)
+    assert len(kps) == len(ref["kps"])
+    assert np.array_equal(resp, ref["responses"])
+    assert np.array_equal(kps[:, :3], ref["kps"][:, :3])
+    assert np.array_equal(kps[:, 3], ref["kps"][:, 3])
+    if h >= 400:
+        assert len(kps) > 50
+
+
+def test_detect_then_describe_is_the_reference_pipeline(ctx, oracle):
+    """detectKeypoints -> extractLIOPFeatures (src/Regard3DFeatures.cpp:206-222) entirely on the GPU == the CPU restatement"""
+    img = _scene(600, 800, 11)
+    kps, _ = ctx.detect_akaze(img, 0.001)
+    desc = ctx.extract_liop(img, kps, 8.0)
+    okp = oracle.akaze_detect(img, 0.001)["kps"]
+    patches = oracle.liop_extract_patches(img, okp, 8.0)
+    odesc = oracle.liop_describe(patches)
+    assert np.array_equal(kps, okp) and np.array_equal(desc, odesc) and len(kps) > 50
+
+
+def test_many_extrema_take_the_scratch_path(ctx, oracle):
+    """white noise at a tiny threshold: more candidates per level than the LDS live set holds"""
+    rng = np.random.default_rng(8)
+    img = np.clip(0.5 + rng.normal(0, 0.2, (700, 900)), 0, 1).astype(np.float32)
+    kps, resp = ctx.detect_akaze(img, 1e-7)
+    ref = oracle.akaze_detect(img, 1e-7)
+    assert len(kps) == len(ref["kps"]) and len(kps) > 4000
+    assert np.array_equal(kps, ref["kps"]) and np.array_equal(resp, ref["responses"])
+
+
+def test_blank_and_tiny_images(ctx):
+    kps, _ = ctx.detect_akaze(np.full((300, 400), 0.3, np.float32))
+    assert len(kps) == 0
+    kps, _ = ctx.detect_akaze(np.random.default_rng(0).random((20, 30)).astype(np.float32))   # too small for one evolution level
+    assert len(kps) == 0

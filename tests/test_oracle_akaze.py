@@ -1,0 +1,134 @@
+"""CPU tests of oracle/akaze.c (Fast-A-KAZE detector restatement).  PARITY UNPINNED: neither the reference detector nor
+OpenCV can be built here, so these are property tests -- every primitive against an independent numpy formulation, the
+detector against scenes with known structure."""
+import numpy as np
+import pytest
+
+
+def _blobs(h, w, n, seed, smin=2.5, smax=9.0):
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 0.5, np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    pts = []
+    for _ in range(n):
+        cx, cy = rng.uniform(90, w - 90), rng.uniform(90, h - 90)
+        s = rng.uniform(smin, smax); a = rng.uniform(0.2, 0.45) * rng.choice([-1, 1])
+        img += (a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))).astype(np.float32)
+        pts.append((cx, cy, s))
+    return np.clip(img, 0, 1).astype(np.float32), pts
+
+
+def test_fed_step_sizes(oracle):
+    for T in (0.1, 0.69, 2.0, 7.5, 40.0, 66.0):
+        tau = oracle.akaze_fed_tau(T)
+        n = int(np.ceil(np.sqrt(3 * T / 0.25 + 0.25) - 0.5 - 1e-8) + 0.5)
+        assert len(tau) == n and np.all(tau > 0)
+        assert abs(float(tau.sum(dtype=np.float64)) - T) < 1e-4 * max(T, 1)       # a FED cycle integrates exactly T
+        assert tau.max() > 0.25 or n == 1                                           # super-steps beyond the stability limit
+        un = 0.5 * (3 * T / (0.25 * n * (n + 1))) * 0.25 / np.cos(np.pi * (2 * np.arange(n) + 1) / (4 * n + 2)) ** 2
+        assert np.allclose(np.sort(tau), np.sort(un), rtol=1e-5)                    # a permutation of the analytic steps
+
+
+def test_gaussian_is_a_normalised_separable_convolution(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.random((37, 53)).astype(np.float32)
+    for sigma, n in ((1.0, 5), (1.6, 9)):
+        out = oracle.akaze_gaussian(img, sigma)
+        x = np.arange(n) - (n - 1) / 2
+        k = np.exp(-0.5 * x * x / sigma ** 2); k /= k.sum()
+        pad = np.pad(img.astype(np.float64), n // 2, mode="edge")                   # BORDER_REPLICATE
+        rows = sum(k[i] * pad[:, i:i + img.shape[1]] for i in range(n))
+        ref = sum(k[i] * rows[i:i + img.shape[0], :] for i in range(n))
+        assert np.abs(out - ref).max() < 2e-6
+        assert np.allclose(oracle.akaze_gaussian(np.full((20, 30), 0.37, np.float32), sigma), 0.37, atol=1e-6)
+
+
+def test_derivative_filters_on_ramps(oracle):
+    yy, xx = np.mgrid[0:40, 0:60].astype(np.float32)
+    img = (0.01 * xx + 0.02 * yy).astype(np.float32)
+    lx, ly = oracle.akaze_scharr(img)
+    assert np.allclose(lx[5:-5, 5:-5], 32 * 0.01, rtol=1e-4) and np.allclose(ly[5:-5, 5:-5], 32 * 0.02, rtol=1e-4)
+    for s in (2, 3, 4):
+        dx = oracle.akaze_scaled_deriv(img, s, True); dy = oracle.akaze_scaled_deriv(img, s, False)
+        assert np.allclose(dx[12:-12, 12:-12], s * 0.01, rtol=1e-4)                # taps at +-s, smoothing weights sum to 1/2
+        assert np.allclose(dy[12:-12, 12:-12], s * 0.02, rtol=1e-4)
+    q = (xx * xx).astype(np.float32) * 1e-3                                          # second derivative of x^2/1000: 2e-3 * s^2
+    dxx = oracle.akaze_scaled_deriv(oracle.akaze_scaled_deriv(q, 2, True), 2, True)
+    assert np.allclose(dxx[12:-12, 12:-12], 2e-3 * 4, rtol=1e-3)
+
+
+def test_halfsample_even_and_odd(oracle):
+    rng = np.random.default_rng(1)
+    a = rng.random((40, 64)).astype(np.float32)
+    assert np.allclose(oracle.akaze_halfsample(a), a.reshape(20, 2, 32, 2).mean(axis=(1, 3)), atol=1e-6)
+    b = rng.random((375, 501)).astype(np.float32)                                    # odd: fractional INTER_AREA cells
+    out = oracle.akaze_halfsample(b)
+    assert out.shape == (187, 250)
+    sx, sy = 501 / 250, 375 / 187
+    def cover(lo, hi, n):
+        w = np.zeros(n)
+        for s in range(int(np.floor(lo)), min(int(np.ceil(hi)), n)):
+            w[s] = max(0.0, min(hi, s + 1) - max(lo, s))
+        return w / w.sum()
+    for (dy, dx) in ((0, 0), (100, 133), (186, 249), (17, 5)):
+        wy = cover(dy * sy, (dy + 1) * sy, 375); wx = cover(dx * sx, (dx + 1) * sx, 501)
+        assert abs(out[dy, dx] - wy @ b.astype(np.float64) @ wx) < 1e-5
+    assert np.allclose(oracle.akaze_halfsample(np.full((375, 501), 0.25, np.float32)), 0.25, atol=1e-6)
+
+
+def test_kcontrast_is_the_percentile_of_the_gradient_histogram(oracle):
+    rng = np.random.default_rng(2)
+    lx = rng.normal(0, 0.02, (80, 90)).astype(np.float32); ly = rng.normal(0, 0.02, (80, 90)).astype(np.float32)
+    k = oracle.akaze_kcontrast(lx, ly)
+    m = np.sqrt(lx[1:-1, 1:-1] ** 2 + ly[1:-1, 1:-1] ** 2).ravel()
+    frac = (m[m >= m.max() / 300] < k).mean()                                       # ~70 % of the non-background moduli lie below k
+    assert 0.66 < frac < 0.74
+    assert oracle.akaze_kcontrast(np.zeros((10, 10), np.float32), np.zeros((10, 10), np.float32)) == pytest.approx(0.03)
+
+
+def test_detector_finds_blobs_and_nothing_else(oracle):
+    img, pts = _blobs(480, 640, 30, seed=5)
+    r = oracle.akaze_detect(img, 0.001)
+    kp = r["kps"]
+    assert 20 <= len(kp) <= 400 and int(r["info"][0]) == 13
+    found = sum(np.hypot(kp[:, 0] - cx, kp[:, 1] - cy).min() < 2.0 for cx, cy, s in pts)
+    assert found >= 0.8 * len(pts)
+    # every keypoint sits on a blob (no detections in the flat background) and bigger blobs give bigger keypoints
+    d = np.array([min(np.hypot(x - cx, y - cy) / s for cx, cy, s in pts) for x, y in kp[:, :2]])
+    assert (d < 3.0).mean() > 0.95
+    near = []
+    for cx, cy, s in pts:                                           # the strongest keypoint on each blob carries its scale
+        m = np.hypot(kp[:, 0] - cx, kp[:, 1] - cy) < 2.5
+        if m.any():
+            near.append((kp[np.flatnonzero(m)[r["responses"][m].argmax()], 2], s))
+    sz, sg = np.array(near).T
+    assert np.corrcoef(sz, sg)[0, 1] > 0.6
+    assert np.all((kp[:, 3] >= 0) & (kp[:, 3] <= 360)) and np.all(r["responses"] > 0.001)
+    assert len(oracle.akaze_detect(np.full((300, 400), 0.4, np.float32))["kps"]) == 0   # blank image: nothing
+    assert len(oracle.akaze_detect(img, 0.05)["kps"]) < len(kp)                         # threshold is monotone
+
+
+def test_detector_is_covariant_with_quarter_turns(oracle):
+    """rot90 maps the pixel grid onto itself, so keypoints must map with it and orientations turn by 90 degrees"""
+    img, _ = _blobs(420, 420, 25, seed=9, smin=3, smax=7)
+    yy, xx = np.mgrid[0:420, 0:420]
+    img = np.clip(img + 0.08 * np.sin(xx / 9.0) * np.cos(yy / 13.0), 0, 1).astype(np.float32)   # break the rotational symmetry of blobs
+    a = oracle.akaze_detect(img, 0.001)["kps"]
+    b = oracle.akaze_detect(np.ascontiguousarray(np.rot90(img)), 0.001)["kps"]      # counter-clockwise: (x, y) -> (y, W-1-x)
+    assert len(a) > 15 and abs(len(a) - len(b)) <= max(2, len(a) // 10)
+    das = []
+    for x, y, s, ang in a:
+        xr, yr = y, 419 - x
+        same = np.flatnonzero(np.abs(b[:, 2] - s) < 1e-3)             # a blob carries keypoints of several scales
+        if len(same) == 0:
+            continue
+        d = np.full(len(b), np.inf); d[same] = np.hypot(b[same, 0] - xr, b[same, 1] - yr)
+        j = d.argmin()
+        # coarser octaves place keypoints at x * ratio (no half-pixel centre), so the quarter turn maps them up to ratio - 1 pixels
+        if d[j] < max(0.5, s / 6.0) and abs(b[j, 2] - s) < 1e-3:
+            das.append(abs((b[j, 3] - (ang - 90.0) + 180.0) % 360.0 - 180.0))
+    das = np.array(das)
+    assert len(das) >= 0.9 * len(a)                                   # positions and sizes map
+    # the orientation histogram has 42 slices (a quarter turn is 10.5 of them), so angles turn by 90 degrees only up to the
+    # slice quantisation of the sliding window
+    assert np.median(das) < 3.0 and (das < 30.0).mean() > 0.9

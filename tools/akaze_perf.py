@@ -1,0 +1,25 @@
+"""Detector probe: r3dm_detect_akaze on a synthetic 4000 x 3000 image (the reference's semaphore-serialised stage)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from regard3d_amd import api
+
+h, w = 3000, 4000
+rng = np.random.default_rng(0)
+yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+img = 0.5 + 0.1 * np.sin(xx / 17.0) * np.cos(yy / 23.0)
+for _ in range(1500):
+    cx, cy = rng.uniform(40, w - 40), rng.uniform(40, h - 40); s = rng.uniform(2, 12); a = rng.uniform(0.15, 0.45) * rng.choice([-1, 1])
+    x0, x1, y0, y1 = int(max(cx - 5 * s, 0)), int(min(cx + 5 * s, w)), int(max(cy - 5 * s, 0)), int(min(cy + 5 * s, h))
+    img[y0:y1, x0:x1] += a * np.exp(-((xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2) / (2 * s * s))
+img = np.clip(img + rng.normal(0, 0.01, img.shape), 0, 1).astype(np.float32)
+c = api.Context(0)
+for thr in (0.001, 0.0001):
+    for rep in range(3):
+        t = time.time(); kps, resp = c.detect_akaze(img, thr); dt = time.time() - t
+    t = time.time(); desc = c.extract_liop(img, kps, 8.0); dl = time.time() - t
+    print(json.dumps(dict(image=[h, w], threshold=thr, keypoints=len(kps), s_detect=dt, s_liop=dl, mpix_per_s=h * w / dt / 1e6)), flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "cpu":
+    from oracle import pyoracle as o
+    t = time.time(); r = o.akaze_detect(img, 0.001); print("oracle (OpenMP port) %.2fs, %d keypoints" % (time.time() - t, len(r["kps"])))
+    print("equal:", np.array_equal(r["kps"], c.detect_akaze(img, 0.001)[0]))
