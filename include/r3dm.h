@@ -175,6 +175,17 @@ int r3dm_kgraph_index(r3dm_ctx* ctx, uint32_t view_id, uint32_t index_K, uint32_
 int r3dm_detect_akaze(r3dm_ctx* ctx, const float* image, uint32_t width, uint32_t height, float threshold,
                       float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out);
 
+/* ---- the per-image work item of the features stage ----
+ * R3DFeaturesThread::processWorkItem (src/threads/R3DFeaturesThread.cpp:123-210) after cv::imread: 8-bit BGR -> float / 255 ->
+ * BGR2GRAY (r3dm_gray_from_bgr8; bgr = height x width x 3 bytes, gray_out = height x width floats, host or device), then
+ * Regard3DFeatures::detectAndExtract with the "Fast-AKAZE" detector + LIOP and KeypointSet::saveToBinFile
+ * (src/keypointSet.hpp:61-67): <feat_path> gets one "x y scale orientation" line per feature (scale = size / 2), <desc_path>
+ * an 8-byte count followed by count x 144 floats -- the files r3dm_compute_matches_dir / the facade read back.
+ * Image decoding (cv::imread) stays with the caller. */
+int r3dm_gray_from_bgr8(r3dm_ctx* ctx, const unsigned char* bgr, uint32_t width, uint32_t height, float* gray_out);
+int r3dm_extract_features_to_files(r3dm_ctx* ctx, const float* gray, uint32_t width, uint32_t height, float threshold,
+                                   const char* feat_path, const char* desc_path, uint32_t* n_features);
+
 /* ---- descriptor extraction: LIOP on pre-extracted patches ----
  * r3d_vl_liopdesc_process of the vendored VLFeat copy (src/thirdparty/liop/vl_liop.c:465-580) as Regard3D
  * calls it per keypoint (src/Regard3DFeatures.cpp:727-752,827: new_basic(41) -> 4 neighbours, 6 bins, radius 6):

@@ -24,7 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_detect_akaze", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_detect_akaze", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
 ]
 
 
@@ -90,6 +90,8 @@ def load_library():
     L.r3dm_extract_liop.argtypes = [vp, vp, u32, u32, vp, u32, C.c_float, vp, vp]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
     L.r3dm_detect_akaze.argtypes = [vp, vp, u32, u32, C.c_float, vp, vp, u32, C.POINTER(u32)]
+    L.r3dm_gray_from_bgr8.argtypes = [vp, vp, u32, u32, vp]
+    L.r3dm_extract_features_to_files.argtypes = [vp, vp, u32, u32, C.c_float, C.c_char_p, C.c_char_p, C.POINTER(u32)]
     L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]
     L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_kgraph_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, u32, u32, vp, vp]
@@ -361,6 +363,19 @@ class Context:
                     "r3dm_detect_akaze")
         k = min(n.value, cap)
         return kps[:k].copy(), resp[:k].copy()
+
+    def gray_from_bgr8(self, bgr: np.ndarray) -> np.ndarray:
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        out = np.zeros(bgr.shape[:2], np.float32)
+        self._check(self._L.r3dm_gray_from_bgr8(self._h, _ptr(bgr), bgr.shape[1], bgr.shape[0], _ptr(out)), "r3dm_gray_from_bgr8")
+        return out
+
+    def extract_features_to_files(self, gray, feat_path: str, desc_path: str, threshold: float = 0.001) -> int:
+        gray = np.ascontiguousarray(gray, np.float32)
+        n = C.c_uint32(0)
+        self._check(self._L.r3dm_extract_features_to_files(self._h, _ptr(gray), gray.shape[1], gray.shape[0], threshold,
+                                                           feat_path.encode(), desc_path.encode(), C.byref(n)), "r3dm_extract_features_to_files")
+        return n.value
 
     def filter_report(self):
         """per putative pair of the last filter_F call: (threshold_px, nfa, iterations, models, inliers)"""

@@ -463,9 +463,27 @@ void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
     L.out0[j] = o0; L.out1[j] = o1; L.out_valid[j] = valid;
 }
 
+// ---- image preparation of R3DFeaturesThread::processWorkItem (src/threads/R3DFeaturesThread.cpp:163-191): 8-bit BGR ->
+// float (convertTo, scale 1/255) -> gray (cvtColor BGR2GRAY on floats: 0.114 B + 0.587 G + 0.299 R)
+__global__ __launch_bounds__(256)
+void ak_bgr_to_gray_kernel(const unsigned char* __restrict__ bgr, float* __restrict__ gray, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float sc = (float)(1.0 / 255.0);
+    const float b = (float)bgr[3 * i] * sc, g = (float)bgr[3 * i + 1] * sc, r = (float)bgr[3 * i + 2] * sc;
+    gray[i] = b * 0.114f + g * 0.587f + r * 0.299f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray, size_t n)
+{
+    hipLaunchKernelGGL(ak_bgr_to_gray_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bgr, gray, n);
+    return hipGetLastError();
+}
+
 static dim3 ak_grid(int w, int h) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4)); }
 
 hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf)

@@ -1571,6 +1571,63 @@ extern "C" int r3dm_extract_liop(r3dm_ctx* c, const float* image, uint32_t width
 }
 
 // ------------------------------------------------------------------------------------------------
+// the per-image work item of the features stage
+// ------------------------------------------------------------------------------------------------
+extern "C" int r3dm_gray_from_bgr8(r3dm_ctx* c, const unsigned char* bgr, uint32_t width, uint32_t height, float* gray_out)
+{
+    if (!c || !bgr || !gray_out || !width || !height) return R3DM_ERR_INVALID;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)width * height;
+    DevBuf in, out;
+    R3DM_HIP(c, in.ensure(n * 3));
+    R3DM_HIP(c, out.ensure(n * 4));
+    R3DM_HIP(c, hipMemcpyAsync(in.p, bgr, n * 3, hipMemcpyDefault, c->stream));
+    R3DM_HIP(c, ak_bgr_to_gray(c->stream, in.as<unsigned char>(), out.as<float>(), n));
+    R3DM_HIP(c, hipMemcpyAsync(gray_out, out.p, n * 4, hipMemcpyDefault, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    in.release(); out.release();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, uint32_t width, uint32_t height, float threshold,
+                                              const char* feat_path, const char* desc_path, uint32_t* n_features)
+{
+    if (!c || !gray || !feat_path || !desc_path) return R3DM_ERR_INVALID;
+    if (n_features) *n_features = 0;
+    // detectAndExtract (src/Regard3DFeatures.cpp:206-222) for keypointDetectorList_ = {"Fast-AKAZE"}
+    uint32_t n = 0;
+    std::vector<float> kps(4 * 65536);
+    int rc = r3dm_detect_akaze(c, gray, width, height, threshold, kps.data(), nullptr, 65536, &n);
+    if (rc != R3DM_OK) return rc;
+    if (n > 65536) {
+        kps.resize(4 * (size_t)n);
+        const uint32_t cap = n;
+        rc = r3dm_detect_akaze(c, gray, width, height, threshold, kps.data(), nullptr, cap, &n);
+        if (rc != R3DM_OK) return rc;
+    }
+    std::vector<float> desc(144 * (size_t)std::max<uint32_t>(n, 1));
+    if (n) {
+        rc = r3dm_extract_liop(c, gray, width, height, kps.data(), n, 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, desc.data(), nullptr);
+        if (rc != R3DM_OK) return rc;
+    }
+    // KeypointSet::saveToBinFile (src/keypointSet.hpp:61-67): .feat = one "x y scale orientation" line per feature
+    // (SIOPointFeature::operator<<, default float formatting; scale = size / 2, :835-836), .desc = count + raw rows
+    FILE* f = fopen(feat_path, "w");
+    if (!f) { c->err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
+    for (uint32_t k = 0; k < n; ++k)
+        fprintf(f, "%g %g %g %g\n", kps[4 * (size_t)k], kps[4 * (size_t)k + 1], kps[4 * (size_t)k + 2] / 2.0f, kps[4 * (size_t)k + 3]);
+    if (fclose(f) != 0) return R3DM_ERR_IO;
+    f = fopen(desc_path, "wb");
+    if (!f) { c->err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
+    const uint64_t cnt = n;
+    bool ok = fwrite(&cnt, 8, 1, f) == 1 && (n == 0 || fwrite(desc.data(), 144 * 4, n, f) == n);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return R3DM_ERR_IO;
+    if (n_features) *n_features = n;
+    return R3DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // graph accessors, merge, files
 // ------------------------------------------------------------------------------------------------
 extern "C" uint64_t r3dm_graph_num_pairs(const r3dm_graph* g) { return g ? g->pairs.size() / 2 : 0; }

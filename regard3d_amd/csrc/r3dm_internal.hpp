@@ -165,6 +165,7 @@ struct AkLevelDev {
     unsigned char* dead_lower; unsigned char* dead_upper;
     float4* out0; float2* out1; uint32_t* out_valid;     // refined (x, y, size, response), dominant gradient vector, kept?
 };
+hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray, size_t n);
 hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf);
 hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h);
 hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int s, int dx);

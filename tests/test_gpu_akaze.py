@@ -62,3 +62,28 @@ def test_blank_and_tiny_images(ctx):
     assert len(kps) == 0
     kps, _ = ctx.detect_akaze(np.random.default_rng(0).random((20, 30)).astype(np.float32))   # too small for one evolution level
     assert len(kps) == 0
+
+
+def test_features_stage_work_item_writes_the_reference_files(ctx, oracle, tmp_path):
+    """R3DFeaturesThread::processWorkItem after imread: BGR8 -> gray float -> Fast-AKAZE + LIOP -> <name>.feat / <name>.desc"""
+    import ctypes
+    rng = np.random.default_rng(21)
+    g = (_scene(480, 640, 21) * 255).astype(np.uint8)
+    bgr = np.stack([np.clip(g.astype(np.int32) + rng.integers(-20, 20, g.shape), 0, 255).astype(np.uint8) for _ in range(3)], axis=2)
+    gray = ctx.gray_from_bgr8(bgr)
+    sc = np.float32(1.0 / 255.0)
+    exp = (bgr[..., 0].astype(np.float32) * sc) * np.float32(0.114) + (bgr[..., 1].astype(np.float32) * sc) * np.float32(0.587) \
+        + (bgr[..., 2].astype(np.float32) * sc) * np.float32(0.299)
+    assert np.array_equal(gray, exp.astype(np.float32))
+    feat, desc = str(tmp_path / "img.feat"), str(tmp_path / "img.desc")
+    n = ctx.extract_features_to_files(gray, feat, desc, 0.001)
+    okp = oracle.akaze_detect(gray, 0.001)["kps"]
+    odesc = oracle.liop_describe(oracle.liop_extract_patches(gray, okp, 8.0))
+    assert n == len(okp) > 30
+    xyso = np.zeros((n, 4), np.float32); cnt = ctypes.c_int(0)
+    assert oracle.lib().orc_load_feat(feat.encode(), ctypes.byref(cnt), xyso.ctypes.data_as(ctypes.c_void_p), n) == 0 and cnt.value == n
+    want = okp.copy(); want[:, 2] /= 2.0                               # SIOPointFeature.scale = keypoint size / 2
+    assert np.allclose(xyso, want, rtol=1e-5, atol=0)                  # the text format keeps 6 significant digits
+    raw = np.fromfile(desc, np.uint8)
+    assert int(np.frombuffer(raw[:8].tobytes(), np.uint64)[0]) == n
+    assert np.array_equal(np.frombuffer(raw[8:].tobytes(), np.float32).reshape(n, 144), odesc)
