@@ -175,6 +175,13 @@ int r3dm_kgraph_index(r3dm_ctx* ctx, uint32_t view_id, uint32_t index_K, uint32_
 int r3dm_detect_akaze(r3dm_ctx* ctx, const float* image, uint32_t width, uint32_t height, float threshold,
                       float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out);
 
+/* cv::AKAZE2::detectAndCompute with DESCRIPTOR_MLDB (src/thirdparty/fast-akaze/akaze.cpp:171-221; the binary descriptors of
+ * BASELINE config C3): keypoints as above plus the full MLDB descriptor of each -- 3 grids (2x2, 3x3, 4x4) x 3 channels, all
+ * pairwise comparisons = 486 bits packed LSB first into 61 bytes (AKAZEFeatures.cpp:1790-1909).  descriptors_out: cap x 61
+ * bytes, ready for r3dm_set_image(..., dim 61, R3DM_BIN). */
+int r3dm_detect_akaze_mldb(r3dm_ctx* ctx, const float* image, uint32_t width, uint32_t height, float threshold,
+                           float* keypoints_out, unsigned char* descriptors_out, uint32_t cap, uint32_t* n_out);
+
 /* ---- the per-image work item of the features stage ----
  * R3DFeaturesThread::processWorkItem (src/threads/R3DFeaturesThread.cpp:123-210) after cv::imread: 8-bit BGR -> float / 255 ->
  * BGR2GRAY (r3dm_gray_from_bgr8; bgr = height x width x 3 bytes, gray_out = height x width floats, host or device), then

@@ -408,11 +408,64 @@ void orc_akaze_orientation_vec(const float* Lx, const float* Ly, int cols, int x
     out_xy[0] = maxX; out_xy[1] = maxY;
 }
 
+/* MLDB_Full_Descriptor_InvokerV2::Get_MLDB_Full_Descriptor (AKAZEFeatures.cpp:1877-1909) with MLDB_Fill_Values (:1790-1844) and
+ * MLDB_Binary_Comparisons (:1846-1868): 3 grids (2x2, 3x3, 4x4 cells over a 20 sigma window rotated to the keypoint angle), 3
+ * channels (mean intensity, mean rotated dx, dy), all pairwise comparisons per channel -> 486 bits, LSB first, 61 bytes. */
+void orc_akaze_mldb(const float* Lt, const float* Lx, const float* Ly, int cols, float xf, float yf, float co, float si,
+                    float scale, unsigned char* desc /* 61 */)
+{
+    const int pattern_size = 10, chan = 3;
+    const double size_mult[3] = { 1, 2.0 / 3.0, 1.0 / 2.0 };
+    float values[16 * 3];
+    int dpos = 0;
+    memset(desc, 0, 61);
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        const int val_count = (lvl + 2) * (lvl + 2);
+        const int sample_step = (int)ceil(pattern_size * size_mult[lvl]);
+        int valpos = 0;
+        for (int i = -pattern_size; i < pattern_size; i += sample_step)
+            for (int j = -pattern_size; j < pattern_size; j += sample_step) {
+                float di = 0.0f, dx = 0.0f, dy = 0.0f;
+                int nsamples = 0;
+                for (int k = i; k < i + sample_step; ++k)
+                    for (int l = j; l < j + sample_step; ++l) {
+                        const float sample_y = yf + (l * co * scale + k * si * scale);
+                        const float sample_x = xf + (-l * si * scale + k * co * scale);
+                        const int y1 = fround(sample_y), x1 = fround(sample_x);
+                        const float ri = Lt[(size_t)y1 * cols + x1];
+                        di += ri;
+                        const float rx = Lx[(size_t)y1 * cols + x1], ry = Ly[(size_t)y1 * cols + x1];
+                        const float rry = rx * co + ry * si;
+                        const float rrx = -rx * si + ry * co;
+                        dx += rrx; dy += rry;
+                        nsamples++;
+                    }
+                di /= nsamples; dx /= nsamples; dy /= nsamples;
+                values[valpos] = di; values[valpos + 1] = dx; values[valpos + 2] = dy;
+                valpos += chan;
+            }
+        int32_t iv[16 * 3];
+        memcpy(iv, values, sizeof(float) * (size_t)(val_count * chan));
+        for (int q = 0; q < val_count * chan; ++q) iv[q] = iv[q] ^ (iv[q] < 0 ? 0x7fffffff : 0);      /* CV_TOGGLE_FLT */
+        for (int pos = 0; pos < chan; ++pos)
+            for (int i = 0; i < val_count; ++i) {
+                const int32_t ival = iv[chan * i + pos];
+                for (int j = i + 1; j < val_count; ++j) {
+                    if (ival > iv[chan * j + pos]) desc[dpos >> 3] |= (unsigned char)(1 << (dpos & 7));
+                    else desc[dpos >> 3] &= (unsigned char)~(1 << (dpos & 7));
+                    dpos++;
+                }
+            }
+    }
+    const int remain = dpos % 8;
+    if (remain > 0) desc[dpos >> 3] &= (unsigned char)(0xff >> (8 - remain));
+}
+
 /* Regard3DFeatures::detectKeypoints, "Fast-AKAZE" arm: image = h x w floats in [0, 1].
  * keypoints out: (x, y, size, angle_degrees) x cap; responses/levels optional.  Returns the number detected (may exceed cap:
  * only the first cap are written).  dbg_level >= 0: copies that level's Ldet (and Lt) into dbg_ldet / dbg_lt if non-NULL. */
-int orc_akaze_detect(const float* image, int w, int h, float dthreshold, float* kps, int cap, float* responses, int* levels,
-                     int dbg_level, float* dbg_ldet, float* dbg_lt, float* dbg_info /* [8]: n_levels, kcontrast, ... */)
+static int akaze_detect_impl(const float* image, int w, int h, float dthreshold, float* kps, int cap, float* responses, int* levels,
+                             int dbg_level, float* dbg_ldet, float* dbg_lt, float* dbg_info, unsigned char* mldb /* cap x 61 or NULL */)
 {
     const int omax = 4, nsub = 4;
     const float soffset = 1.6f, dfac = 1.5f;
@@ -587,6 +640,8 @@ int orc_akaze_detect(const float* image, int w, int h, float dthreshold, float* 
             ang += 90.0f;
             while (ang < 0) ang += 360.0f;
             while (ang > 360.0f) ang -= 360.0f;
+            if (n_out < cap && mldb)      /* AKAZE2::detectAndCompute: descriptors from the raw (radian) orientation */
+                orc_akaze_mldb(e->Lt, e->Lx, e->Ly, cols, kp.x / ratio, kp.y / ratio, cosf(theta), sinf(theta), (float)e->sigma_size, mldb + 61 * (size_t)n_out);
             if (n_out < cap) {
                 kps[4 * n_out] = kp.x; kps[4 * n_out + 1] = kp.y; kps[4 * n_out + 2] = kp.size; kps[4 * n_out + 3] = ang;
                 if (responses) responses[n_out] = kp.response;
@@ -598,4 +653,16 @@ int orc_akaze_detect(const float* image, int w, int h, float dthreshold, float* 
     for (int i = 0; i < nl; ++i) { free(kl[i].v); free(lv[i].Lt); }
     free(kl); free(wx); free(wy); free(wflow); free(wstep);
     return n_out;
+}
+
+int orc_akaze_detect(const float* image, int w, int h, float dthreshold, float* kps, int cap, float* responses, int* levels,
+                     int dbg_level, float* dbg_ldet, float* dbg_lt, float* dbg_info /* [8]: n_levels, kcontrast, ... */)
+{
+    return akaze_detect_impl(image, w, h, dthreshold, kps, cap, responses, levels, dbg_level, dbg_ldet, dbg_lt, dbg_info, NULL);
+}
+
+/* cv::AKAZE2::detectAndCompute with DESCRIPTOR_MLDB (akaze.cpp:171-221): keypoints as above + 61-byte MLDB-486 descriptors */
+int orc_akaze_detect_mldb(const float* image, int w, int h, float dthreshold, float* kps, unsigned char* desc, int cap, float* responses)
+{
+    return akaze_detect_impl(image, w, h, dthreshold, kps, cap, responses, NULL, -1, NULL, NULL, NULL, desc);
 }

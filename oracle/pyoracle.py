@@ -521,3 +521,12 @@ def akaze_detect(img, threshold=0.001, cap=200000, dbg_level=-1):
         out["ldet"] = ldet.ravel()[:lw * lh].reshape(lh, lw).copy()
         out["lt"] = lt.ravel()[:lw * lh].reshape(lh, lw).copy()
     return out
+
+
+def akaze_detect_mldb(img, threshold=0.001, cap=200000):
+    """AKAZE2::detectAndCompute(DESCRIPTOR_MLDB): -> (kps [n,4], desc [n,61] uint8, responses)"""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape
+    kps = np.zeros((cap, 4), np.float32); resp = np.zeros(cap, np.float32); desc = np.zeros((cap, 61), np.uint8)
+    n = min(lib().orc_akaze_detect_mldb(_p(img), w, h, C.c_float(threshold), _p(kps), _p(desc), cap, _p(resp)), cap)
+    return kps[:n].copy(), desc[:n].copy(), resp[:n].copy()

@@ -199,6 +199,9 @@ float orc_akaze_kcontrast(const float* Lx, const float* Ly, int w, int h, float 
 void  orc_akaze_halfsample(const float* src, int w, int h, float* dst);
 int   orc_akaze_fed_tau(float T, float* tau);
 void  orc_akaze_orientation_vec(const float* Lx, const float* Ly, int cols, int x0, int y0, int scale, float* out_xy);
+void  orc_akaze_mldb(const float* Lt, const float* Lx, const float* Ly, int cols, float xf, float yf, float co, float si,
+                     float scale, unsigned char* desc);
+int   orc_akaze_detect_mldb(const float* image, int w, int h, float dthreshold, float* kps, unsigned char* desc, int cap, float* responses);
 int   orc_akaze_detect(const float* image, int w, int h, float dthreshold, float* kps, int cap, float* responses, int* levels,
                        int dbg_level, float* dbg_ldet, float* dbg_lt, float* dbg_info);
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_detect_akaze", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
 ]
 
 
@@ -90,6 +90,7 @@ def load_library():
     L.r3dm_extract_liop.argtypes = [vp, vp, u32, u32, vp, u32, C.c_float, vp, vp]
     L.r3dm_knn2.argtypes = [vp, vp, u32, vp, u32, u32, C.c_int, vp, vp]
     L.r3dm_detect_akaze.argtypes = [vp, vp, u32, u32, C.c_float, vp, vp, u32, C.POINTER(u32)]
+    L.r3dm_detect_akaze_mldb.argtypes = [vp, vp, u32, u32, C.c_float, vp, vp, u32, C.POINTER(u32)]
     L.r3dm_gray_from_bgr8.argtypes = [vp, vp, u32, u32, vp]
     L.r3dm_extract_features_to_files.argtypes = [vp, vp, u32, u32, C.c_float, C.c_char_p, C.c_char_p, C.POINTER(u32)]
     L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]
@@ -363,6 +364,18 @@ class Context:
                     "r3dm_detect_akaze")
         k = min(n.value, cap)
         return kps[:k].copy(), resp[:k].copy()
+
+    def detect_akaze_mldb(self, image, threshold: float = 0.001, cap: int = 200000):
+        """AKAZE2::detectAndCompute(DESCRIPTOR_MLDB) -> (keypoints [n, 4], descriptors [n, 61] uint8)"""
+        h, w = int(image.shape[0]), int(image.shape[1])
+        if isinstance(image, np.ndarray):
+            image = np.ascontiguousarray(image, np.float32)
+        kps = np.zeros((cap, 4), np.float32); desc = np.zeros((cap, 61), np.uint8)
+        n = C.c_uint32(0)
+        self._check(self._L.r3dm_detect_akaze_mldb(self._h, _ptr(image), w, h, threshold, _ptr(kps), _ptr(desc), cap, C.byref(n)),
+                    "r3dm_detect_akaze_mldb")
+        k = min(n.value, cap)
+        return kps[:k].copy(), desc[:k].copy()
 
     def gray_from_bgr8(self, bgr: np.ndarray) -> np.ndarray:
         bgr = np.ascontiguousarray(bgr, np.uint8)

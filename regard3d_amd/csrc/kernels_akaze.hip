@@ -463,6 +463,59 @@ void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
     L.out0[j] = o0; L.out1[j] = o1; L.out_valid[j] = valid;
 }
 
+// ---- MLDB-486 descriptor (MLDB_Full_Descriptor_InvokerV2, AKAZEFeatures.cpp:1790-1909): 2 keypoints per wavefront, one lane per
+// grid cell (4 + 9 + 16 cells of the 2x2 / 3x3 / 4x4 grids) accumulating its samples in the reference's order; the 486
+// comparisons are then read off a (value a, value b) table, one output byte per lane.
+__global__ __launch_bounds__(64)
+void ak_mldb_kernel(const AkLevelDev* __restrict__ levels, const AkMldbItem* __restrict__ items, uint32_t n,
+                    const unsigned char* __restrict__ pairs /* [486][2] */, unsigned char* __restrict__ out /* [n][61] */)
+{
+    __shared__ int32_t vals[2][96];
+    const uint32_t half = threadIdx.x >> 5, lane = threadIdx.x & 31u;
+    const uint32_t kp = blockIdx.x * 2 + half;
+    const bool live = kp < n;
+    if (live && lane < 29) {
+        const AkMldbItem it = items[kp];
+        const AkLevelDev L = levels[it.level];
+        int step, ncell, base, c = (int)lane;
+        if (c < 4) { step = 10; ncell = 2; base = 0; }
+        else if (c < 13) { step = 7; ncell = 3; base = 12; c -= 4; }
+        else { step = 5; ncell = 4; base = 39; c -= 13; }
+        const int i0 = -10 + (c / ncell) * step, j0 = -10 + (c % ncell) * step;
+        const float co = it.co, si = it.si, scale = it.scale, xf = it.xf, yf = it.yf;
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        int nsamples = 0;
+        for (int k = i0; k < i0 + step; ++k)
+            for (int l = j0; l < j0 + step; ++l) {
+                const float sample_y = yf + (l * co * scale + k * si * scale);
+                const float sample_x = xf + (-l * si * scale + k * co * scale);
+                const int y1 = (int)(sample_y + 0.5f), x1 = (int)(sample_x + 0.5f);
+                const size_t p = (size_t)y1 * L.w + x1;
+                di += L.Lt[p];
+                const float rx = L.Lx[p], ry = L.Ly[p];
+                const float rry = rx * co + ry * si;
+                const float rrx = -rx * si + ry * co;
+                dx += rrx; dy += rry;
+                nsamples++;
+            }
+        di /= nsamples; dx /= nsamples; dy /= nsamples;
+        const int32_t a = (int32_t)__float_as_uint(di), b = (int32_t)__float_as_uint(dx), d = (int32_t)__float_as_uint(dy);
+        vals[half][base + 3 * c] = a ^ (a < 0 ? 0x7fffffff : 0);            // CV_TOGGLE_FLT
+        vals[half][base + 3 * c + 1] = b ^ (b < 0 ? 0x7fffffff : 0);
+        vals[half][base + 3 * c + 2] = d ^ (d < 0 ? 0x7fffffff : 0);
+    }
+    __syncthreads();
+    if (!live) return;
+    for (uint32_t byte = lane; byte < 61; byte += 32) {
+        uint32_t v = 0;
+        for (uint32_t bit = 0; bit < 8; ++bit) {
+            const uint32_t dpos = byte * 8 + bit;
+            if (dpos < 486 && vals[half][pairs[2 * dpos]] > vals[half][pairs[2 * dpos + 1]]) v |= 1u << bit;
+        }
+        out[(size_t)kp * 61 + byte] = (unsigned char)v;
+    }
+}
+
 // ---- image preparation of R3DFeaturesThread::processWorkItem (src/threads/R3DFeaturesThread.cpp:163-191): 8-bit BGR ->
 // float (convertTo, scale 1/255) -> gray (cvtColor BGR2GRAY on floats: 0.114 B + 0.587 G + 0.299 R)
 __global__ __launch_bounds__(256)
@@ -481,6 +534,13 @@ void ak_bgr_to_gray_kernel(const unsigned char* __restrict__ bgr, float* __restr
 hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray, size_t n)
 {
     hipLaunchKernelGGL(ak_bgr_to_gray_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bgr, gray, n);
+    return hipGetLastError();
+}
+
+hipError_t ak_mldb(hipStream_t st, const AkLevelDev* levels, const AkMldbItem* items, uint32_t n, const unsigned char* pairs, unsigned char* out)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ak_mldb_kernel, dim3((n + 1) / 2), dim3(64), 0, st, levels, items, n, pairs, out);
     return hipGetLastError();
 }
 

@@ -1225,8 +1225,8 @@ void ak_area_tab(int ssize, int dsize, std::vector<AkAreaTab>& tab, std::vector<
 
 }  // namespace
 
-extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
-                                 float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out)
+static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+                             float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out, unsigned char* mldb_out)
 {
     if (!c || !image || !n_out || (cap && !keypoints_out)) return R3DM_ERR_INVALID;
     *n_out = 0;
@@ -1361,7 +1361,7 @@ extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width
             AkLevelDev& L = ld[i];
             L = AkLevelDev{};
             L.w = lv[i].w; L.h = lv[i].h; L.border = lv[i].border; L.ratio = lv[i].ratio; L.psize = lv[i].esigma * 1.5f;
-            L.Ldet = Ldet(i); L.Lx = Lx(i); L.Ly = Ly(i);
+            L.Ldet = Ldet(i); L.Lx = Lx(i); L.Ly = Ly(i); L.Lt = Lt(i);
             L.row_cnt = rc + ro; L.row_off = rc + rows_total + ro; L.counts = cnt + 4 * i;
             ro += (size_t)std::max(0, lv[i].h - 2 * lv[i].border);
         }
@@ -1408,6 +1408,7 @@ extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width
 
     // ---- gather in (level, list) order; angle = getAngleV2(maxX, maxY) then the detectKeypoints conversion (:604-613)
     uint32_t n_kp = 0;
+    std::vector<AkMldbItem> items;
     for (int i = 0; i < nl; ++i) {
         const uint32_t n = counts[4 * i + 1];
         if (!n) continue;
@@ -1421,6 +1422,8 @@ extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width
             if (n_kp < cap) {
                 float theta = atan2f(o1[j].y, o1[j].x);
                 if (!(theta >= 0)) theta = theta + (float)(2.0f * 3.1415926535897932384626433832795);
+                if (mldb_out)          // Get_MLDB_Full_Descriptor: level coordinates, cos / sin of the raw (radian) angle
+                    items.push_back({(uint32_t)i, o0[j].x / lv[i].ratio, o0[j].y / lv[i].ratio, cosf(theta), sinf(theta), (float)lv[i].sigma_size});
                 float ang = theta;
                 ang *= 180.0 / 3.1415926535897932384626433832795;
                 ang += 90.0f;
@@ -1433,10 +1436,42 @@ extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width
             ++n_kp;
         }
     }
+    if (mldb_out && !items.empty()) {
+        // comparison table of MLDB_Binary_Comparisons: per grid, per channel, all value pairs i < j
+        std::vector<unsigned char> pairs;
+        const int bases[3] = {0, 12, 39}, cnts[3] = {4, 9, 16};
+        for (int g = 0; g < 3; ++g)
+            for (int pos = 0; pos < 3; ++pos)
+                for (int i = 0; i < cnts[g]; ++i)
+                    for (int j = i + 1; j < cnts[g]; ++j) { pairs.push_back((unsigned char)(bases[g] + 3 * i + pos)); pairs.push_back((unsigned char)(bases[g] + 3 * j + pos)); }
+        DevBuf& mb = buf(B_LEVEL0 + 4 * nl + 2);
+        const size_t ni = items.size();
+        R3DM_HIP(c, mb.ensure(ni * sizeof(AkMldbItem) + 1024 + ni * 61 + 64));
+        unsigned char* base = mb.as<unsigned char>();
+        R3DM_HIP(c, hipMemcpyAsync(base, items.data(), ni * sizeof(AkMldbItem), hipMemcpyHostToDevice, st));
+        R3DM_HIP(c, hipMemcpyAsync(base + ni * sizeof(AkMldbItem), pairs.data(), pairs.size(), hipMemcpyHostToDevice, st));
+        unsigned char* d_out = base + ni * sizeof(AkMldbItem) + 1024;
+        R3DM_HIP(c, ak_mldb(st, d_levels, (const AkMldbItem*)base, (uint32_t)ni, base + ni * sizeof(AkMldbItem), d_out));
+        R3DM_HIP(c, hipMemcpyAsync(mldb_out, d_out, ni * 61, hipMemcpyDeviceToHost, st));
+        R3DM_HIP(c, hipStreamSynchronize(st));
+    }
     tab_buf.release();
     *n_out = n_kp;
     c->stats.ms_detect = now_ms() - t_call;
     return R3DM_OK;
+}
+
+extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+                                 float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out)
+{
+    return detect_akaze_impl(c, image, width, height, threshold, keypoints_out, responses_out, cap, n_out, nullptr);
+}
+
+extern "C" int r3dm_detect_akaze_mldb(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+                                      float* keypoints_out, unsigned char* descriptors_out, uint32_t cap, uint32_t* n_out)
+{
+    if (!descriptors_out && cap) return R3DM_ERR_INVALID;
+    return detect_akaze_impl(c, image, width, height, threshold, keypoints_out, nullptr, cap, n_out, descriptors_out);
 }
 
 // ------------------------------------------------------------------------------------------------

