@@ -119,12 +119,23 @@ void ak_det_kernel(const float* __restrict__ lxx, const float* __restrict__ lyy,
 __global__ __launch_bounds__(256)
 void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, uint32_t* __restrict__ out_max)
 {
-    const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63), y = 1 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    // grid-stride over the interior rows: one atomic per workgroup (the maximum is order-independent)
+    __shared__ float part[4];
     float m = 0.0f;
-    if (x < w - 1 && y < h - 1) { const float lx = Lx[(size_t)y * w + x], ly = Ly[(size_t)y * w + x]; m = sqrtf(lx * lx + ly * ly); }
+    for (int y = 1 + (int)blockIdx.x; y < h - 1; y += (int)gridDim.x)
+        for (int x = 1 + (int)threadIdx.x; x < w - 1; x += 256) {
+            const float lx = Lx[(size_t)y * w + x], ly = Ly[(size_t)y * w + x];
+            const float v = sqrtf(lx * lx + ly * ly);
+            m = v > m ? v : m;
+        }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_max, __float_as_uint(m));      // m >= 0: bit order = value order
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q) m = part[q] > m ? part[q] : m;
+        if (m > 0.0f) atomicMax(out_max, __float_as_uint(m));          // m >= 0: bit order = value order
+    }
 }
 __global__ __launch_bounds__(256)
 void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, float sc, int nbins, uint32_t* __restrict__ hist)
@@ -380,87 +391,92 @@ __device__ __forceinline__ float ak_fast_atan2(float y, float x)
     return a * 0x1.1df46ap-6f;                                    // (float)(CV_PI / 180)
 }
 
+// sample offsets (dy, dx) of Sample_Derivative_Response_Radius6 in its loop order: i, j in [-6, 6], i*i + j*j < 36
+__device__ const signed char kRad6[109][2] = { {-5, -3}, {-5, -2}, {-5, -1}, {-5, 0}, {-5, 1}, {-5, 2}, {-5, 3}, {-4, -4}, {-4, -3}, {-4, -2}, {-4, -1}, {-4, 0}, {-4, 1}, {-4, 2}, {-4, 3}, {-4, 4}, {-3, -5}, {-3, -4}, {-3, -3}, {-3, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-3, 2}, {-3, 3}, {-3, 4}, {-3, 5}, {-2, -5}, {-2, -4}, {-2, -3}, {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2}, {-2, 3}, {-2, 4}, {-2, 5}, {-1, -5}, {-1, -4}, {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3}, {-1, 4}, {-1, 5}, {0, -5}, {0, -4}, {0, -3}, {0, -2}, {0, -1}, {0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {1, -5}, {1, -4}, {1, -3}, {1, -2}, {1, -1}, {1, 0}, {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {2, -5}, {2, -4}, {2, -3}, {2, -2}, {2, -1}, {2, 0}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {2, 5}, {3, -5}, {3, -4}, {3, -3}, {3, -2}, {3, -1}, {3, 0}, {3, 1}, {3, 2}, {3, 3}, {3, 4}, {3, 5}, {4, -4}, {4, -3}, {4, -2}, {4, -1}, {4, 0}, {4, 1}, {4, 2}, {4, 3}, {4, 4}, {5, -3}, {5, -2}, {5, -1}, {5, 0}, {5, 1}, {5, 2}, {5, 3} };
+
+// one wavefront per list entry: lanes sample and take the angles in parallel, lane 0 runs the order-sensitive parts
+// (counting sort, sliding-window sums) out of LDS
 __global__ __launch_bounds__(64)
 void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
 {
+    __shared__ float resX[112], resY[112], Ang[112];
+    __shared__ unsigned char sorted_idx[112], slice[48];
     const AkLevelDev L = levels[blockIdx.y];
-    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t j = blockIdx.x;
     if (j >= L.counts[1]) return;
+    const int lane = threadIdx.x;
     float4 kp = L.list[j];
-    float4 o0 = make_float4(0, 0, 0, 0);
-    float2 o1 = make_float2(0, 0);
-    uint32_t valid = 0;
-    if (!L.dead_lower[j] && !L.dead_upper[j]) {
-        const float* __restrict__ ldet = L.Ldet;
-        const int cols = L.w;
-        const float ratio = L.ratio;
-        const int x = (int)(kp.x / ratio), y = (int)(kp.y / ratio);
-        const float Dx = 0.5f * (ldet[y * cols + x + 1] - ldet[y * cols + x - 1]);
-        const float Dy = 0.5f * (ldet[(y + 1) * cols + x] - ldet[(y - 1) * cols + x]);
-        const float Dxx = ldet[y * cols + x + 1] + ldet[y * cols + x - 1] - 2.0f * ldet[y * cols + x];
-        const float Dyy = ldet[(y + 1) * cols + x] + ldet[(y - 1) * cols + x] - 2.0f * ldet[y * cols + x];
-        const float Dxy = 0.25f * (ldet[(y + 1) * cols + x + 1] + ldet[(y - 1) * cols + x - 1] -
-                                   ldet[(y - 1) * cols + x + 1] - ldet[(y + 1) * cols + x - 1]);
-        float dx = 0.0f, dy = 0.0f;
-        {
-            const float b0 = -Dx, b1 = -Dy;
-            double d = (double)Dxx * Dyy - (double)Dxy * Dxy;
-            if (d != 0.) {
-                d = 1. / d;
-                const double t = (float)(((double)b0 * Dyy - (double)b1 * Dxy) * d);
-                dy = (float)(((double)b1 * Dxx - (double)b0 * Dxy) * d);
-                dx = (float)t;
-            }
-        }
-        if (!(fabsf(dx) > 1.0f || fabsf(dy) > 1.0f)) {
-            valid = 1;
-            kp.x += dx * ratio; kp.y += dy * ratio;
-            const float size = L.psize * 2.0f;
-            const int scale = (int)(0.5f * size / ratio + 0.5f);
-            const int x0 = (int)(kp.x / ratio + 0.5f), y0 = (int)(kp.y / ratio + 0.5f);
-            float resX[109], resY[109], Ang[109];
-            int k = 0;
-            for (int i = -6; i <= 6; ++i)
-                for (int jj = -6; jj <= 6; ++jj)
-                    if (i * i + jj * jj < 36) {
-                        const float wgt = kGauss25[i < 0 ? -i : i][jj < 0 ? -jj : jj];
-                        const size_t p = (size_t)(y0 + i * scale) * cols + (x0 + jj * scale);
-                        resX[k] = wgt * L.Lx[p]; resY[k] = wgt * L.Ly[p];
-                        ++k;
-                    }
-            for (int i = 0; i < 109; ++i) Ang[i] = ak_fast_atan2(resY[i], resX[i]);
-            constexpr int slices = 42, win = 7;
-            const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
-            unsigned char slice[slices + 1], sorted_idx[109];
-            const int nkeys = (int)(0x1.921fb6p+2f / ang_step);   // (float)(2 pi) / ang_step = 42
-            for (int i = 0; i <= nkeys; ++i) slice[i] = 0;
-            for (int i = 0; i < 109; ++i) slice[(int)(Ang[i] / ang_step)]++;
-            for (int i = 1; i <= nkeys; ++i) slice[i] += slice[i - 1];
-            for (int i = 0; i < 109; ++i) sorted_idx[--slice[(int)(Ang[i] / ang_step)]] = (unsigned char)i;
-            float maxX = 0.0f, maxY = 0.0f;
-            for (int i = slice[0]; i < slice[win]; ++i) { maxX += resX[sorted_idx[i]]; maxY += resY[sorted_idx[i]]; }
-            float maxNorm = maxX * maxX + maxY * maxY;
-            for (int sn = 1; sn <= slices - win; ++sn) {
-                if (slice[sn] == slice[sn - 1] && slice[sn + win] == slice[sn + win - 1]) continue;
-                float sumX = 0.0f, sumY = 0.0f;
-                for (int i = slice[sn]; i < slice[sn + win]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-                const float nrm = sumX * sumX + sumY * sumY;
-                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
-            }
-            for (int sn = slices - win + 1; sn < slices; ++sn) {
-                const int remain = sn + win - slices;
-                if (slice[sn] == slice[sn - 1] && slice[remain] == slice[remain - 1]) continue;
-                float sumX = 0.0f, sumY = 0.0f;
-                for (int i = slice[sn]; i < slice[slices]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-                for (int i = slice[0]; i < slice[remain]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-                const float nrm = sumX * sumX + sumY * sumY;
-                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
-            }
-            o0 = make_float4(kp.x, kp.y, size, kp.z);
-            o1 = make_float2(maxX, maxY);
+    if (L.dead_lower[j] || L.dead_upper[j]) {
+        if (lane == 0) { L.out0[j] = make_float4(0, 0, 0, 0); L.out1[j] = make_float2(0, 0); L.out_valid[j] = 0; }
+        return;
+    }
+    const float* __restrict__ ldet = L.Ldet;
+    const int cols = L.w;
+    const float ratio = L.ratio;
+    const int x = (int)(kp.x / ratio), y = (int)(kp.y / ratio);
+    const float Dx = 0.5f * (ldet[y * cols + x + 1] - ldet[y * cols + x - 1]);
+    const float Dy = 0.5f * (ldet[(y + 1) * cols + x] - ldet[(y - 1) * cols + x]);
+    const float Dxx = ldet[y * cols + x + 1] + ldet[y * cols + x - 1] - 2.0f * ldet[y * cols + x];
+    const float Dyy = ldet[(y + 1) * cols + x] + ldet[(y - 1) * cols + x] - 2.0f * ldet[y * cols + x];
+    const float Dxy = 0.25f * (ldet[(y + 1) * cols + x + 1] + ldet[(y - 1) * cols + x - 1] -
+                               ldet[(y - 1) * cols + x + 1] - ldet[(y + 1) * cols + x - 1]);
+    float dx = 0.0f, dy = 0.0f;
+    {
+        const float b0 = -Dx, b1 = -Dy;
+        double d = (double)Dxx * Dyy - (double)Dxy * Dxy;
+        if (d != 0.) {
+            d = 1. / d;
+            const double t = (float)(((double)b0 * Dyy - (double)b1 * Dxy) * d);
+            dy = (float)(((double)b1 * Dxx - (double)b0 * Dxy) * d);
+            dx = (float)t;
         }
     }
-    L.out0[j] = o0; L.out1[j] = o1; L.out_valid[j] = valid;
+    if (fabsf(dx) > 1.0f || fabsf(dy) > 1.0f) {                   // wave-uniform: every lane computed the same values
+        if (lane == 0) { L.out0[j] = make_float4(0, 0, 0, 0); L.out1[j] = make_float2(0, 0); L.out_valid[j] = 0; }
+        return;
+    }
+    kp.x += dx * ratio; kp.y += dy * ratio;
+    const float size = L.psize * 2.0f;
+    const int scale = (int)(0.5f * size / ratio + 0.5f);
+    const int x0 = (int)(kp.x / ratio + 0.5f), y0 = (int)(kp.y / ratio + 0.5f);
+    for (int k = lane; k < 109; k += 64) {
+        const int i = kRad6[k][0], jj = kRad6[k][1];
+        const float wgt = kGauss25[i < 0 ? -i : i][jj < 0 ? -jj : jj];
+        const size_t p = (size_t)(y0 + i * scale) * cols + (x0 + jj * scale);
+        const float rx = wgt * L.Lx[p], ry = wgt * L.Ly[p];
+        resX[k] = rx; resY[k] = ry; Ang[k] = ak_fast_atan2(ry, rx);
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    constexpr int slices = 42, win = 7;
+    const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
+    const int nkeys = (int)(0x1.921fb6p+2f / ang_step);   // (float)(2 pi) / ang_step = 42
+    for (int i = 0; i <= nkeys; ++i) slice[i] = 0;
+    for (int i = 0; i < 109; ++i) slice[(int)(Ang[i] / ang_step)]++;
+    for (int i = 1; i <= nkeys; ++i) slice[i] += slice[i - 1];
+    for (int i = 0; i < 109; ++i) sorted_idx[--slice[(int)(Ang[i] / ang_step)]] = (unsigned char)i;
+    float maxX = 0.0f, maxY = 0.0f;
+    for (int i = slice[0]; i < slice[win]; ++i) { maxX += resX[sorted_idx[i]]; maxY += resY[sorted_idx[i]]; }
+    float maxNorm = maxX * maxX + maxY * maxY;
+    for (int sn = 1; sn <= slices - win; ++sn) {
+        if (slice[sn] == slice[sn - 1] && slice[sn + win] == slice[sn + win - 1]) continue;
+        float sumX = 0.0f, sumY = 0.0f;
+        for (int i = slice[sn]; i < slice[sn + win]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+        const float nrm = sumX * sumX + sumY * sumY;
+        if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
+    }
+    for (int sn = slices - win + 1; sn < slices; ++sn) {
+        const int remain = sn + win - slices;
+        if (slice[sn] == slice[sn - 1] && slice[remain] == slice[remain - 1]) continue;
+        float sumX = 0.0f, sumY = 0.0f;
+        for (int i = slice[sn]; i < slice[slices]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+        for (int i = slice[0]; i < slice[remain]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+        const float nrm = sumX * sumX + sumY * sumY;
+        if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
+    }
+    L.out0[j] = make_float4(kp.x, kp.y, size, kp.z);
+    L.out1[j] = make_float2(maxX, maxY);
+    L.out_valid[j] = 1;
 }
 
 // ---- MLDB-486 descriptor (MLDB_Full_Descriptor_InvokerV2, AKAZEFeatures.cpp:1790-1909): 2 keypoints per wavefront, one lane per
@@ -571,7 +587,8 @@ hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const floa
 }
 hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max)
 {
-    hipLaunchKernelGGL(ak_modg_max_kernel, ak_grid(w - 2, h - 2), dim3(256), 0, st, Lx, Ly, w, h, out_max);
+    const int rows = h - 2 < 1024 ? (h - 2 < 1 ? 1 : h - 2) : 1024;
+    hipLaunchKernelGGL(ak_modg_max_kernel, dim3((unsigned)rows), dim3(256), 0, st, Lx, Ly, w, h, out_max);
     return hipGetLastError();
 }
 hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, float sc, int nbins, uint32_t* hist)
@@ -624,7 +641,7 @@ hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint
 hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list)
 {
     if (max_list == 0) return hipSuccess;
-    hipLaunchKernelGGL(ak_refine_kernel, dim3((max_list + 63) / 64, (unsigned)n_levels), dim3(64), 0, st, levels);
+    hipLaunchKernelGGL(ak_refine_kernel, dim3(max_list, (unsigned)n_levels), dim3(64), 0, st, levels);
     return hipGetLastError();
 }
 
