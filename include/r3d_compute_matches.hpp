@@ -73,6 +73,10 @@ public:
     void addViews(const std::vector<View>& views);                 // stands in for addImages + sfm_data.bin
     void setRegionsType(r3dm_dtype dtype, uint32_t dim);           // default: float x 144 (R3D_AKAZE_LIOP_Regions)
     void setSeed(uint64_t seed) { seed_ = seed; }
+    // updateProgress(float, const wxString&) (src/R3DComputeMatches.cpp:2664): the GUI hook, called with the reference's own
+    // fractions and messages (0.7 "Find putative matches", 0.8 / 0.9 / 0.95 "Calculate ... matrix", :2000,2107,2133,2209)
+    using ProgressFn = void (*)(float progress, const char* msg, void* user);
+    void setProgressCallback(ProgressFn fn, void* user) { progress_ = fn; progress_user_ = user; }
 
     bool computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,
                         int cameraModel, int matchingAlgorithm);
@@ -92,6 +96,8 @@ private:
     std::vector<View> views_;
     r3dm_dtype dtype_ = R3DM_F32;
     uint32_t dim_ = 144;
+    ProgressFn progress_ = nullptr;
+    void* progress_user_ = nullptr;
     uint64_t seed_ = 5489;
     R3DComputeMatchesStatistics statistics_;
     std::string errorMessage_;

@@ -138,6 +138,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     for (size_t a = 0; a < ids.size(); ++a)
         for (size_t b = a + 1; b < ids.size(); ++b) { pairs.push_back(ids[a]); pairs.push_back(ids[b]); }
 
+    if (progress_) progress_(0.7f, "Find putative matches", progress_user_);
     // ---- photometric matching (:2048) + Save(matches.putative.txt) (:2064)
     r3dm_graph* putative = nullptr;
     const int squared = dtype_ == R3DM_BIN ? 0 : 1;        // RegionsMatcherT squared flag: true for L2 metrics
@@ -164,6 +165,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
 
     // ---- geometric filtering, fundamental matrix (:2113-2120): AC-RANSAC, 4.0 px upper bound, 2048 iterations
     if (params.computeFundalmentalMatrix_) {
+        if (progress_) progress_(0.8f, "Calculate fundamental matrix", progress_user_);
         r3dm_graph* geo = nullptr;
         rc = r3dm_filter_F(ctx_, putative, 4.0, 2048, seed_, R3DM_ERR_SYMMETRIC_EPIPOLAR, &geo, nullptr);
         if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
@@ -177,6 +179,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     // ---- essential-matrix filter (:2130-2204): 5-point solver on K^-1 x, then the overlap rule (>= 50 matches and
     //      >= 30 % of the putative matches, :2175-2192); matches.e.txt feeds the global SfM engine
     if (params.computeEssentialMatrix_) {
+        if (progress_) progress_(0.9f, "Calculate essential matrix", progress_user_);
         r3dm_graph* geo = nullptr;
         rc = r3dm_filter_E(ctx_, putative, 4.0, 2048, seed_, 50, 0.3f, &geo, nullptr);
         if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
@@ -189,6 +192,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     }
     // ---- homography filter (:2216-2233): same skeleton, 4-point solver; matches.h.txt
     if (params.computeHomographyMatrix_) {
+        if (progress_) progress_(0.95f, "Calculate homography matrix", progress_user_);
         r3dm_graph* geo = nullptr;
         rc = r3dm_filter_H(ctx_, putative, 4.0, 2048, seed_, &geo, nullptr);
         if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }

@@ -52,6 +52,7 @@ int main(int argc, char** argv)
         for (int k = 4; k < argc; ++k) views.push_back({(uint32_t)(k - 4), 4000, 3000, argv[k], 4800.0, 2000.0, 1500.0});
         stage.addViews(views);
         stage.setRegionsType(R3DM_F32, (uint32_t)atoi(argv[3]));
+        stage.setProgressCallback([](float p, const char* msg, void*) { fprintf(stderr, "progress %.2f %s\n", p, msg); }, nullptr);
         r3d_amd::R3DFParams params;
         r3d_amd::R3DProjectPaths paths;
         paths.relativeMatchesPath_ = argv[2];

@@ -72,6 +72,9 @@ def test_stage_facade_writes_the_reference_files(host_exe, oracle, tmp_path):
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     n_put, n_f = map(int, r.stdout.split())
+    prog = [l for l in r.stderr.splitlines() if l.startswith("progress")]          # updateProgress hook, the reference's messages
+    assert prog == ["progress 0.70 Find putative matches", "progress 0.80 Calculate fundamental matrix",
+                    "progress 0.90 Calculate essential matrix", "progress 0.95 Calculate homography matrix"]
     pairs = sc.exhaustive_pairs()
     counts, matches = oracle.match_collection(sc.descs, sc.xys, pairs, 0.6, True)
     for ext in ("txt", "bin"):
