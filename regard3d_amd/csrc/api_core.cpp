@@ -1,0 +1,362 @@
+// api_core.cpp -- part of the host side of libr3dm.so: the C ABI declared in include/r3dm.h (see r3dm_ctx.hpp for the file map).
+//
+// Mirrors, for the compute-matches hot path only, what the reference does in
+// /root/reference/src/R3DComputeMatches.cpp:2035-2129 and src/Regard3DFeatures.cpp -- with every arithmetic stage running as
+// HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
+#include "r3dm_ctx.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int r3dm_create(int device_id, r3dm_ctx** out)
+{
+    if (!out) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return R3DM_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n_dev) return R3DM_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return R3DM_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return R3DM_ERR_NO_DEVICE;
+    std::string arch = prop.gcnArchName;
+    if (arch.find("gfx950") == std::string::npos) return R3DM_ERR_NO_DEVICE;   // the kernels are gfx950-only
+    auto* c = new (std::nothrow) r3dm_ctx();
+    if (!c) return R3DM_ERR_NOMEM;
+    c->device = device_id;
+    c->arch = arch;
+    c->n_cu = prop.multiProcessorCount;
+    c->hbm = prop.totalGlobalMem;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return R3DM_ERR_HIP;
+    }
+    *out = c;
+    return R3DM_OK;
+}
+
+extern "C" void r3dm_destroy(r3dm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& im : c->imgs) if (im) im->release();
+    DevBuf* bufs[] = {&c->d_imgs, &c->d_pairs, &c->d_nn, &c->d_knn_idx, &c->d_knn_dist, &c->d_fb, &c->d_cnt, &c->d_out,
+                      &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
+                      &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch,
+                      &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
+                      &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill};
+    for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : c->ak_bufs) b.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* r3dm_last_error(const r3dm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int r3dm_device_info(const r3dm_ctx* c, char* arch, size_t arch_cap, int* n_cu, uint64_t* hbm_bytes)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    if (arch && arch_cap) { strncpy(arch, c->arch.c_str(), arch_cap - 1); arch[arch_cap - 1] = 0; }
+    if (n_cu) *n_cu = c->n_cu;
+    if (hbm_bytes) *hbm_bytes = c->hbm;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_get_stats(const r3dm_ctx* c, r3dm_stats* out)
+{
+    if (!c || !out) return R3DM_ERR_INVALID;
+    *out = c->stats;
+    return R3DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// views
+// ------------------------------------------------------------------------------------------------
+static int upload_imgdev(r3dm_ctx* c, uint32_t slot)
+{
+    const size_t need = sizeof(ImgDev) * c->imgs.size();
+    if (need > c->d_imgs.cap) {
+        // grow and re-upload every live slot; max_norm_bits must survive -> read the old table back first
+        std::vector<ImgDev> old(c->d_imgs.cap / sizeof(ImgDev));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        if (!old.empty()) {
+            R3DM_HIP(c, hipMemcpyAsync(old.data(), c->d_imgs.p, old.size() * sizeof(ImgDev), hipMemcpyDeviceToHost, c->stream));
+            R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        DevBuf nb;
+        R3DM_HIP(c, nb.ensure(sizeof(ImgDev) * std::max<size_t>(64, c->imgs.size() * 2)));
+        R3DM_HIP(c, hipMemsetAsync(nb.p, 0, nb.cap, c->stream));
+        const size_t keep = std::min(old.size(), c->imgs.size());
+        if (keep) R3DM_HIP(c, hipMemcpyAsync(nb.p, old.data(), keep * sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        c->d_imgs.release();
+        c->d_imgs = nb;
+    }
+    const HostImage& h = *c->imgs[slot];
+    ImgDev d{};
+    d.rows = h.rows.as<float>(); d.tiled = h.tiled.as<float>(); d.norms = h.norms.as<float>();
+    d.bin = h.bin.as<uint32_t>(); d.xy = h.has_xy ? h.xy.as<float>() : nullptr;
+    d.canon = h.has_dup ? h.canon.as<uint32_t>() : nullptr;
+    d.n = h.n; d.n_tiles = h.n_tiles; d.dim = h.dim; d.G = h.G; d.words = h.words;
+    d.width = h.width; d.height = h.height; d.max_norm_bits = 0; d.max_abs_bits = 0; d.not_integer = 0;
+    d.ann_adj = nullptr; d.ann_deg = nullptr;          // staging invalidates the graph index
+    R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    return R3DM_OK;
+}
+
+// copy + re-layout one view into slot `slot`
+int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width, uint32_t height,
+                    const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
+{
+    HostImage& h = *c->imgs[slot];
+    h.view_id = view_id; h.n = n; h.dim = dim; h.dtype = dtype; h.width = width; h.height = height;
+    h.has_xy = (xy != nullptr); h.has_dup = false; h.live = true;
+    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0;
+    if (dtype == R3DM_BIN) {
+        h.words = (dim + 3) / 4;
+        const uint32_t n_pad = n + 8;
+        R3DM_HIP(c, h.bin.ensure((size_t)n_pad * h.words * 4 + kSlackBytes));
+        if (n) {
+            R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
+            R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
+        }
+        R3DM_HIP(c, launch_stage_bin(c->stream, c->d_raw.as<uint8_t>(), n, dim, h.bin.as<uint32_t>(), h.words, n_pad));
+    } else {
+        h.G = kernel_G_for(dim);
+        h.n_tiles = (n + kTileRows - 1) / kTileRows;
+        const size_t tiled_bytes = (size_t)h.n_tiles * h.G * 1024 + kSlackBytes;
+        const size_t norm_bytes = (size_t)h.n_tiles * 32 * 4 + kSlackBytes;
+        R3DM_HIP(c, h.rows.ensure((size_t)std::max<uint32_t>(n, 1) * dim * 4 + 256));
+        R3DM_HIP(c, h.tiled.ensure(tiled_bytes));
+        R3DM_HIP(c, h.norms.ensure(norm_bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiled.p, 0, tiled_bytes, c->stream));
+        R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0, norm_bytes, c->stream));
+        const void* raw = nullptr;
+        if (n) {
+            if (dtype == R3DM_F32) {
+                R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim * 4));
+                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim * 4, hipMemcpyDefault, c->stream));
+            } else {
+                R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
+                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
+            }
+            raw = c->d_raw.p;
+        }
+        (void)raw;
+    }
+    if (xy && n) {
+        R3DM_HIP(c, h.xy.ensure((size_t)n * 8));
+        R3DM_HIP(c, hipMemcpyAsync(h.xy.p, xy, (size_t)n * 8, hipMemcpyDefault, c->stream));
+    }
+    // position classes (IndMatchDecorator de-duplication needs to know which features share a position)
+    if (xy && n > 1) {
+        std::vector<float> hxy((size_t)n * 2);
+        R3DM_HIP(c, hipMemcpyAsync(hxy.data(), h.xy.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        std::vector<uint32_t> ord(n);
+        std::iota(ord.begin(), ord.end(), 0u);
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+            if (hxy[2 * a] != hxy[2 * b]) return hxy[2 * a] < hxy[2 * b];
+            if (hxy[2 * a + 1] != hxy[2 * b + 1]) return hxy[2 * a + 1] < hxy[2 * b + 1];
+            return a < b;
+        });
+        std::vector<uint32_t> canon(n);
+        bool dup = false;
+        for (uint32_t k = 0; k < n;) {
+            uint32_t e = k + 1;
+            while (e < n && hxy[2 * ord[e]] == hxy[2 * ord[k]] && hxy[2 * ord[e] + 1] == hxy[2 * ord[k] + 1]) ++e;
+            for (uint32_t q = k; q < e; ++q) canon[ord[q]] = ord[k];     // ord[k] is the smallest index of the group
+            if (e - k > 1) dup = true;
+            k = e;
+        }
+        if (dup) {
+            h.has_dup = true;
+            R3DM_HIP(c, h.canon.ensure((size_t)n * 4));
+            R3DM_HIP(c, hipMemcpyAsync(h.canon.p, canon.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+            R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    int rc = upload_imgdev(c, slot);
+    if (rc != R3DM_OK) return rc;
+    if (dtype != R3DM_BIN) {
+        uint32_t* mx = &(c->d_imgs.as<ImgDev>() + slot)->max_norm_bits;
+        R3DM_HIP(c, launch_stage_f32(c->stream, n ? c->d_raw.p : nullptr, dtype == R3DM_U8, n, dim, h.rows.as<float>(),
+                                     h.tiled.as<float>(), h.norms.as<float>(), h.G, h.n_tiles, mx));
+    }
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));     // d_raw is reused by the next call
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_set_image(r3dm_ctx* c, uint32_t view_id, uint32_t width, uint32_t height,
+                              const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
+{
+    if (!c || dim == 0 || (n && !desc)) return R3DM_ERR_INVALID;
+    if (dtype != R3DM_F32 && dtype != R3DM_U8 && dtype != R3DM_BIN) return R3DM_ERR_INVALID;
+    if (n >= (1u << 22)) { c->err = "more than 4M features in one view"; return R3DM_ERR_UNSUPPORTED; }
+    if (dtype == R3DM_BIN && !(((dim + 3) / 4) == 8 || ((dim + 3) / 4) == 16)) {
+        c->err = "binary descriptors must be 29..32 or 61..64 bytes"; return R3DM_ERR_UNSUPPORTED;
+    }
+    R3DM_HIP(c, hipSetDevice(c->device));
+    uint32_t slot;
+    auto it = c->slot_of.find(view_id);
+    if (it == c->slot_of.end()) {
+        slot = (uint32_t)c->imgs.size();
+        c->imgs.emplace_back(new HostImage());
+        c->slot_of[view_id] = slot;
+    } else slot = it->second;
+    return stage_into_slot(c, slot, view_id, width, height, desc, n, dim, dtype, xy);
+}
+
+extern "C" int r3dm_clear_images(r3dm_ctx* c)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& im : c->imgs) if (im) im->release();
+    c->imgs.clear();
+    c->slot_of.clear();
+    return R3DM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph accessors, merge, files
+// ------------------------------------------------------------------------------------------------
+extern "C" uint64_t r3dm_graph_num_pairs(const r3dm_graph* g) { return g ? g->pairs.size() / 2 : 0; }
+extern "C" uint64_t r3dm_graph_num_matches(const r3dm_graph* g) { return g ? g->matches.size() : 0; }
+extern "C" const uint32_t* r3dm_graph_pairs(const r3dm_graph* g) { return g ? g->pairs.data() : nullptr; }
+extern "C" const uint64_t* r3dm_graph_offsets(const r3dm_graph* g) { return g ? g->offsets.data() : nullptr; }
+extern "C" const r3dm_match* r3dm_graph_matches(const r3dm_graph* g) { return g ? g->matches.data() : nullptr; }
+extern "C" void r3dm_graph_free(r3dm_graph* g) { delete g; }
+
+extern "C" int r3dm_graph_from_csr(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64_t* offsets,
+                                   const r3dm_match* matches, r3dm_graph** out)
+{
+    if (!out || (n_pairs && (!pairs_ij || !offsets))) return R3DM_ERR_INVALID;
+    auto g = std::unique_ptr<r3dm_graph>(new (std::nothrow) r3dm_graph());
+    if (!g) return R3DM_ERR_NOMEM;
+    g->offsets.push_back(0);
+    // keep the PairWiseMatches invariants: ordered by (I, J), no empty entries
+    std::vector<uint64_t> ord(n_pairs);
+    std::iota(ord.begin(), ord.end(), 0ull);
+    std::sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) {
+        if (pairs_ij[2 * a] != pairs_ij[2 * b]) return pairs_ij[2 * a] < pairs_ij[2 * b];
+        return pairs_ij[2 * a + 1] < pairs_ij[2 * b + 1];
+    });
+    for (uint64_t k = 0; k < n_pairs; ++k) {
+        const uint64_t p = ord[k];
+        const uint64_t b = offsets[p], e = offsets[p + 1];
+        if (e <= b) continue;
+        if (!matches) return R3DM_ERR_INVALID;
+        g->pairs.push_back(pairs_ij[2 * p]); g->pairs.push_back(pairs_ij[2 * p + 1]);
+        g->matches.insert(g->matches.end(), matches + b, matches + e);
+        g->offsets.push_back(g->matches.size());
+    }
+    *out = g.release();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out)
+{
+    if (!out || (n_parts && !parts)) return R3DM_ERR_INVALID;
+    std::vector<uint32_t> pairs;
+    std::vector<uint64_t> offs{0};
+    std::vector<r3dm_match> m;
+    for (uint32_t k = 0; k < n_parts; ++k) {
+        const r3dm_graph* g = parts[k];
+        if (!g) continue;
+        const uint64_t np = g->pairs.size() / 2;
+        for (uint64_t p = 0; p < np; ++p) {
+            pairs.push_back(g->pairs[2 * p]); pairs.push_back(g->pairs[2 * p + 1]);
+            m.insert(m.end(), g->matches.begin() + g->offsets[p], g->matches.begin() + g->offsets[p + 1]);
+            offs.push_back(m.size());
+        }
+    }
+    return r3dm_graph_from_csr(pairs.data(), pairs.size() / 2, offs.data(), m.data(), out);
+}
+
+// matches.*.txt / matches.*.bin -- OpenMVG Save/Load(PairWiseMatches)
+extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
+{
+    if (!g || !path) return R3DM_ERR_INVALID;
+    const bool bin = has_ext(path, ".bin");
+    if (!bin && !has_ext(path, ".txt")) return R3DM_ERR_INVALID;
+    FILE* f = fopen(path, bin ? "wb" : "w");
+    if (!f) return R3DM_ERR_IO;
+    const uint64_t np = g->pairs.size() / 2;
+    bool ok = true;
+    if (bin) {
+        // cereal PortableBinaryOutputArchive: endianness flag, then the std::map as size + (key, value) items
+        const uint8_t le = 1;
+        ok &= fwrite(&le, 1, 1, f) == 1;
+        ok &= fwrite(&np, 8, 1, f) == 1;
+        for (uint64_t p = 0; p < np && ok; ++p) {
+            const uint64_t cnt = g->offsets[p + 1] - g->offsets[p];
+            ok &= fwrite(&g->pairs[2 * p], 4, 2, f) == 2;
+            ok &= fwrite(&cnt, 8, 1, f) == 1;
+            ok &= fwrite(g->matches.data() + g->offsets[p], sizeof(r3dm_match), cnt, f) == cnt;
+        }
+    } else {
+        std::string buf;
+        buf.reserve(1 << 20);
+        char tmp[64];
+        for (uint64_t p = 0; p < np && ok; ++p) {
+            const uint64_t cnt = g->offsets[p + 1] - g->offsets[p];
+            int len = snprintf(tmp, sizeof(tmp), "%u %u\n%llu\n", g->pairs[2 * p], g->pairs[2 * p + 1], (unsigned long long)cnt);
+            buf.append(tmp, len);
+            for (uint64_t k = g->offsets[p]; k < g->offsets[p + 1]; ++k) {
+                len = snprintf(tmp, sizeof(tmp), "%u %u\n", g->matches[k].i, g->matches[k].j);
+                buf.append(tmp, len);
+            }
+            if (buf.size() > (1 << 20) - 4096) { ok &= fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
+        }
+        if (ok && !buf.empty()) ok &= fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    }
+    ok &= (fclose(f) == 0);
+    return ok ? R3DM_OK : R3DM_ERR_IO;
+}
+
+extern "C" int r3dm_load_matches(const char* path, r3dm_graph** out)
+{
+    if (!path || !out) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    const bool bin = has_ext(path, ".bin");
+    if (!bin && !has_ext(path, ".txt")) return R3DM_ERR_INVALID;
+    FILE* f = fopen(path, bin ? "rb" : "r");
+    if (!f) return R3DM_ERR_IO;
+    std::vector<uint32_t> pairs;
+    std::vector<uint64_t> offs{0};
+    std::vector<r3dm_match> m;
+    bool ok = true;
+    if (bin) {
+        uint8_t le = 0; uint64_t np = 0;
+        ok = fread(&le, 1, 1, f) == 1 && le == 1 && fread(&np, 8, 1, f) == 1;
+        for (uint64_t p = 0; p < np && ok; ++p) {
+            uint32_t ij[2]; uint64_t cnt = 0;
+            ok = fread(ij, 4, 2, f) == 2 && fread(&cnt, 8, 1, f) == 1 && cnt < (1ull << 32);
+            if (!ok) break;
+            const size_t at = m.size();
+            m.resize(at + cnt);
+            ok = fread(m.data() + at, sizeof(r3dm_match), cnt, f) == cnt;
+            pairs.push_back(ij[0]); pairs.push_back(ij[1]); offs.push_back(m.size());
+        }
+    } else {
+        unsigned I, J; unsigned long long cnt;
+        while (fscanf(f, "%u %u %llu", &I, &J, &cnt) == 3) {
+            for (unsigned long long k = 0; k < cnt; ++k) {
+                unsigned a, b;
+                if (fscanf(f, "%u %u", &a, &b) != 2) { ok = false; break; }
+                m.push_back({a, b});
+            }
+            if (!ok) break;
+            pairs.push_back(I); pairs.push_back(J); offs.push_back(m.size());
+        }
+    }
+    fclose(f);
+    if (!ok) return R3DM_ERR_IO;
+    return r3dm_graph_from_csr(pairs.data(), pairs.size() / 2, offs.data(), m.data(), out);
+}
+

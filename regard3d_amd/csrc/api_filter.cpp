@@ -1,0 +1,259 @@
+// api_filter.cpp -- part of the host side of libr3dm.so: the C ABI declared in include/r3dm.h (see r3dm_ctx.hpp for the file map).
+//
+// Mirrors, for the compute-matches hot path only, what the reference does in
+// /root/reference/src/R3DComputeMatches.cpp:2035-2129 and src/Regard3DFeatures.cpp -- with every arithmetic stage running as
+// HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
+#include "r3dm_ctx.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// geometric filter
+// ------------------------------------------------------------------------------------------------
+// model_kind 0 = fundamental matrix (GeometricFilter_FMatrix_AC), 1 = homography (GeometricFilter_HMatrix_AC)
+//            2 = essential matrix (GeometricFilter_EMatrix_AC) + Regard3D's overlap rule (min_count / min_ratio)
+static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                         uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out,
+                         uint32_t min_count = 0, float min_ratio = 0.f)
+{
+    if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
+    const uint32_t SS = model_kind == 0 ? 7u : (model_kind == 1 ? 4u : 5u);          // Kernel::MINIMUM_SAMPLES
+    *out = nullptr;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    const double t_call = now_ms();
+    const uint64_t NP = putative->pairs.size() / 2;
+    // work items: pairs with more than SS putatives (ACRANSAC returns nothing for n <= MINIMUM_SAMPLES)
+    std::vector<uint32_t> item_pair;
+    std::vector<uint2> slots, ids;
+    uint32_t max_m = 0;
+    uint64_t sum_m = 0;
+    for (uint64_t p = 0; p < NP; ++p) {
+        const uint64_t m = putative->offsets[p + 1] - putative->offsets[p];
+        if (m <= SS) continue;
+        const uint32_t I = putative->pairs[2 * p], J = putative->pairs[2 * p + 1];
+        auto a = c->slot_of.find(I), b = c->slot_of.find(J);
+        if (a == c->slot_of.end() || b == c->slot_of.end()) { c->err = "filter: pair references an unregistered view"; return R3DM_ERR_INVALID; }
+        const HostImage& A = *c->imgs[a->second];
+        const HostImage& B = *c->imgs[b->second];
+        if (!A.has_xy || !B.has_xy) { c->err = "filter: view registered without feature positions"; return R3DM_ERR_INVALID; }
+        if (m > (1u << 22)) { c->err = "filter: more than 4M putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
+        // E_ACRobust: a pair whose views lack valid pinhole intrinsics is not estimated (and so not kept)
+        if (model_kind == 2 && (!A.has_K || !B.has_K)) continue;
+        item_pair.push_back((uint32_t)p);
+        slots.push_back(make_uint2(a->second, b->second));
+        ids.push_back(make_uint2(I, J));
+        max_m = std::max<uint32_t>(max_m, (uint32_t)m);
+        sum_m += m;
+    }
+    auto g = std::unique_ptr<r3dm_graph>(new r3dm_graph());
+    g->offsets.push_back(0);
+    const uint32_t NI = (uint32_t)item_pair.size();
+    c->stats.ms_filter_kernels = 0;
+    if (NI == 0) { *out = g.release(); return R3DM_OK; }
+    (void)sum_m;
+    // [begin, end) of every item's putative list inside the full match array
+    std::vector<uint64_t> begin_end(2 * (size_t)NI);
+    for (uint32_t k = 0; k < NI; ++k) {
+        const uint32_t p = item_pair[k];
+        begin_end[2 * k] = putative->offsets[p];
+        begin_end[2 * k + 1] = putative->offsets[p + 1];
+    }
+    if (model_kind == 0 && err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { c->err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
+    // host tables in the reference's own float arithmetic (glibc log10f), see kernels_filter.hip
+    std::vector<float> l10(max_m + 2), lck(max_m + 2);
+    for (uint32_t k = 0; k <= max_m + 1; ++k) l10[k] = std::log10((float)k);
+    for (uint32_t n = 0; n <= max_m + 1; ++n) {
+        const uint32_t ks = SS;
+        if (ks >= n) { lck[n] = 0.f; continue; }
+        const uint32_t kk = (n - ks < ks) ? n - ks : ks;
+        float r = 0.f;
+        for (uint32_t i = 1; i <= kk; ++i) r += l10[n - i + 1] - l10[i];
+        lck[n] = r;
+    }
+    const uint64_t n_match_total = putative->matches.size();
+    R3DM_HIP(c, c->f_pairs.ensure(sizeof(uint2) * NI));
+    R3DM_HIP(c, c->f_ids.ensure(sizeof(uint2) * NI));
+    R3DM_HIP(c, c->f_offs.ensure(sizeof(uint64_t) * 2 * NI));
+    R3DM_HIP(c, c->f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
+    R3DM_HIP(c, c->f_inl_cnt.ensure(4 * (size_t)NI));
+    R3DM_HIP(c, c->f_inl_idx.ensure(4 * (size_t)n_match_total + 64));
+    R3DM_HIP(c, c->f_F.ensure(72 * (size_t)NI));
+    R3DM_HIP(c, c->f_thr.ensure(16 * (size_t)NI));
+    R3DM_HIP(c, c->f_iters.ensure(8 * (size_t)NI));
+    R3DM_HIP(c, c->f_log10.ensure(4 * l10.size()));
+    R3DM_HIP(c, c->f_logck.ensure(4 * lck.size()));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_pairs.p, slots.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_ids.p, ids.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_offs.p, begin_end.data(), sizeof(uint64_t) * 2 * NI, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_log10.p, l10.data(), 4 * l10.size(), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_logck.p, lck.data(), 4 * lck.size(), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemsetAsync(c->f_inl_cnt.p, 0, 4 * (size_t)NI, c->stream));
+
+    FilterParams fp{};
+    fp.imgs = c->d_imgs.as<ImgDev>();
+    fp.pairs = c->f_pairs.as<uint2>(); fp.pair_ids = c->f_ids.as<uint2>();
+    fp.offsets = c->f_offs.as<uint64_t>(); fp.matches = c->f_matches.as<r3dm_match>();
+    // LDS sort capacity: 8192 (x 12 B) fits beside the hypothesis buffer; pairs with more putatives sort in global scratch
+    fp.n_items = NI; fp.m_cap = std::min<uint32_t>(8192, std::max<uint32_t>(64, next_pow2(max_m)));
+    fp.spill_keys = nullptr; fp.spill_idx = nullptr; fp.spill_off = nullptr;
+    if (max_m > fp.m_cap) {
+        std::vector<uint64_t> soff(NI, 0);
+        uint64_t tot = 0;
+        for (uint32_t k = 0; k < NI; ++k) {
+            const uint64_t mk = begin_end[2 * k + 1] - begin_end[2 * k];
+            soff[k] = tot;
+            if (mk > fp.m_cap) tot += next_pow2((uint32_t)mk);
+        }
+        R3DM_HIP(c, c->f_spill.ensure(tot * 12 + NI * 8 + 64));
+        unsigned char* base = c->f_spill.as<unsigned char>();
+        R3DM_HIP(c, hipMemcpy(base + tot * 12, soff.data(), NI * 8, hipMemcpyHostToDevice));
+        fp.spill_keys = reinterpret_cast<unsigned long long*>(base);
+        fp.spill_idx = reinterpret_cast<uint32_t*>(base + tot * 8);
+        fp.spill_off = reinterpret_cast<const uint64_t*>(base + tot * 12);
+    }
+    fp.precision_px = max_residual_px; fp.max_iter = max_iter; fp.seed = seed; fp.err_kind = (int)err_kind;
+    fp.model_kind = model_kind;
+    fp.kinv = nullptr;
+    if (model_kind == 2) {
+        std::vector<double> kinv(9 * c->imgs.size(), 0.0);
+        for (size_t s = 0; s < c->imgs.size(); ++s)
+            if (c->imgs[s] && c->imgs[s]->has_K) memcpy(&kinv[9 * s], c->imgs[s]->Kinv, 72);
+        R3DM_HIP(c, c->f_kinv.ensure(kinv.size() * 8));
+        R3DM_HIP(c, hipMemcpy(c->f_kinv.p, kinv.data(), kinv.size() * 8, hipMemcpyHostToDevice));
+        fp.kinv = c->f_kinv.as<double>();
+    }
+    fp.log10_tab = c->f_log10.as<float>(); fp.logc_k = c->f_logck.as<float>();
+    fp.inl_count = c->f_inl_cnt.as<uint32_t>(); fp.inl_idx = c->f_inl_idx.as<uint32_t>();
+    fp.F_out = c->f_F.as<double>(); fp.thr_nfa = c->f_thr.as<double>(); fp.iters = c->f_iters.as<uint32_t>();
+    R3DM_HIP(c, c->f_scratch.ensure(32 * (size_t)n_match_total + 4 * (size_t)n_match_total + 4 * ((size_t)n_match_total + NI + 1) + 256));
+    fp.pts_scratch = c->f_scratch.as<double>();
+    fp.pool_scratch = reinterpret_cast<uint32_t*>(c->f_scratch.as<unsigned char>() + 32 * (size_t)n_match_total);
+    fp.scratch_logc = reinterpret_cast<float*>(c->f_scratch.as<unsigned char>() + 36 * (size_t)n_match_total);
+    if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { c->err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
+    // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
+    DevBuf trace_buf;
+    const uint32_t trace_cap = 16384;
+    const char* tp = getenv("R3DM_TRACE_PAIR");
+    const char* tf = getenv("R3DM_TRACE_FILE");
+    fp.trace = nullptr; fp.trace_item = 0xFFFFFFFFu; fp.trace_cap = trace_cap; fp.trace_rows = nullptr;
+    fp.trace_iter = getenv("R3DM_TRACE_ITER") ? (uint32_t)atoi(getenv("R3DM_TRACE_ITER")) : 0xFFFFFFFFu;
+    if (tp && tf) {
+        unsigned tI = 0, tJ = 0;
+        if (sscanf(tp, "%u,%u", &tI, &tJ) == 2)
+            for (uint32_t k = 0; k < NI; ++k)
+                if (ids[k].x == tI && ids[k].y == tJ) fp.trace_item = k;
+        if (fp.trace_item != 0xFFFFFFFFu) {
+            R3DM_HIP(c, trace_buf.ensure(40 * (size_t)trace_cap + 64));
+            R3DM_HIP(c, hipMemsetAsync(trace_buf.p, 0, 40 * (size_t)trace_cap + 64, c->stream));
+            fp.trace = trace_buf.as<double>() + 8;
+            fp.trace_rows = trace_buf.as<uint32_t>();
+        }
+    }
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    R3DM_HIP(c, launch_filter_F(c->stream, fp));
+    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+
+    std::vector<uint32_t> h_cnt(NI);
+    std::vector<uint32_t> h_idx(n_match_total);
+    std::vector<double> h_F(9 * (size_t)NI);
+    R3DM_HIP(c, hipMemcpyAsync(h_cnt.data(), c->f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(h_idx.data(), c->f_inl_idx.p, 4 * (size_t)n_match_total, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(h_F.data(), c->f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_filter_kernels = ms;
+    if (fp.trace) {
+        std::vector<double> tr(5 * (size_t)trace_cap + 8);
+        R3DM_HIP(c, hipMemcpy(tr.data(), trace_buf.p, tr.size() * 8, hipMemcpyDeviceToHost));
+        const uint32_t rows = std::min<uint32_t>(*reinterpret_cast<uint32_t*>(tr.data()), trace_cap);
+        if (FILE* f = fopen(tf, "w")) {
+            for (uint32_t r = 0; r < rows; ++r)
+                fprintf(f, "%.0f %.0f %.0f %.17g %.0f\n", tr[8 + 5 * r], tr[9 + 5 * r], tr[10 + 5 * r], tr[11 + 5 * r], tr[12 + 5 * r]);
+            if (fp.trace_iter != 0xFFFFFFFFu) {
+                fprintf(f, "# sample");
+                for (int k = 0; k < 20; ++k) fprintf(f, " %.0f", tr[8 + 5 * (size_t)(trace_cap - 4) + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        trace_buf.release();
+    }
+    // per-item diagnostics of this call (threshold px, NFA, iterations, models), in putative-pair order
+    {
+        std::vector<double> h_thr(2 * (size_t)NI);
+        std::vector<uint32_t> h_it(2 * (size_t)NI);
+        R3DM_HIP(c, hipMemcpy(h_thr.data(), c->f_thr.p, 16 * (size_t)NI, hipMemcpyDeviceToHost));
+        R3DM_HIP(c, hipMemcpy(h_it.data(), c->f_iters.p, 8 * (size_t)NI, hipMemcpyDeviceToHost));
+        c->report.assign(NP, r3dm_pair_report{});
+        for (uint32_t k = 0; k < NI; ++k) {
+            r3dm_pair_report& r = c->report[item_pair[k]];
+            r.threshold_px = h_thr[2 * k]; r.nfa = h_thr[2 * k + 1];
+            r.iterations = h_it[2 * k]; r.models = h_it[2 * k + 1]; r.inliers = h_cnt[k];
+        }
+    }
+
+    uint64_t kept = 0;
+    for (uint32_t k = 0; k < NI; ++k) {
+        // GeometricFilter_{F,H}Matrix_AC: accept iff #inliers > 2.5 * MINIMUM_SAMPLES
+        if ((double)h_cnt[k] <= 2.5 * SS) continue;
+        const uint32_t p = item_pair[k];
+        const uint64_t base = putative->offsets[p];
+        // the reference's extra check after the E filter (src/R3DComputeMatches.cpp:2175-2192): pairs with poor overlap go
+        if (model_kind == 2 && (h_cnt[k] < min_count ||
+                                (float)h_cnt[k] / (float)(putative->offsets[p + 1] - base) < min_ratio)) continue;
+        g->pairs.push_back(putative->pairs[2 * p]); g->pairs.push_back(putative->pairs[2 * p + 1]);
+        for (uint32_t q = 0; q < h_cnt[k]; ++q) g->matches.push_back(putative->matches[base + h_idx[base + q]]);
+        g->offsets.push_back(g->matches.size());
+        if (F_out) memcpy(F_out + 9 * kept, h_F.data() + 9 * (size_t)k, 72);
+        ++kept;
+    }
+    c->stats.ms_wall_filter = now_ms() - t_call;
+    *out = g.release();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out)
+{
+    return filter_common(c, putative, max_residual_px, max_iter, seed, err_kind, 0, out, F_out);
+}
+
+extern "C" int r3dm_filter_H(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, r3dm_graph** out, double* H_out)
+{
+    return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 1, out, H_out);
+}
+
+extern "C" int r3dm_set_intrinsics(r3dm_ctx* c, uint32_t view_id, const double* K)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    auto it = c->slot_of.find(view_id);
+    if (it == c->slot_of.end()) { c->err = "r3dm_set_intrinsics: unregistered view"; return R3DM_ERR_INVALID; }
+    HostImage& h = *c->imgs[it->second];
+    if (!K) { h.has_K = false; return R3DM_OK; }
+    // inverse by the adjugate, operation for operation what oracle/essential.c orc_inv3 does
+    const double c00 = K[4] * K[8] - K[5] * K[7], c01 = K[5] * K[6] - K[3] * K[8], c02 = K[3] * K[7] - K[4] * K[6];
+    const double det = K[0] * c00 + K[1] * c01 + K[2] * c02;
+    if (!(det != 0.0) || !std::isfinite(det)) { c->err = "r3dm_set_intrinsics: singular K"; return R3DM_ERR_INVALID; }
+    const double id = 1.0 / det;
+    h.Kinv[0] = c00 * id; h.Kinv[1] = (K[2] * K[7] - K[1] * K[8]) * id; h.Kinv[2] = (K[1] * K[5] - K[2] * K[4]) * id;
+    h.Kinv[3] = c01 * id; h.Kinv[4] = (K[0] * K[8] - K[2] * K[6]) * id; h.Kinv[5] = (K[2] * K[3] - K[0] * K[5]) * id;
+    h.Kinv[6] = c02 * id; h.Kinv[7] = (K[1] * K[6] - K[0] * K[7]) * id; h.Kinv[8] = (K[0] * K[4] - K[1] * K[3]) * id;
+    h.has_K = true;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out)
+{
+    return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 2, out, E_out, min_count, min_ratio);
+}
+
+extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint64_t cap)
+{
+    if (!c || (cap && !out)) return R3DM_ERR_INVALID;
+    const uint64_t n = std::min<uint64_t>(cap, c->report.size());
+    if (n) memcpy(out, c->report.data(), n * sizeof(r3dm_pair_report));
+    return (int)std::min<uint64_t>(c->report.size(), 0x7FFFFFFF);
+}
+

@@ -1,0 +1,525 @@
+// api_match.cpp -- part of the host side of libr3dm.so: the C ABI declared in include/r3dm.h (see r3dm_ctx.hpp for the file map).
+//
+// Mirrors, for the compute-matches hot path only, what the reference does in
+// /root/reference/src/R3DComputeMatches.cpp:2035-2129 and src/Regard3DFeatures.cpp -- with every arithmetic stage running as
+// HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
+#include "r3dm_ctx.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// putative matching
+// ------------------------------------------------------------------------------------------------
+extern "C" int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out);
+
+// compaction + ordering + de-duplication of nn_idx[pair][*] (finalize_pairs_kernel), copy back, append the non-empty
+// pairs to `g` in job order.  Shared by the exhaustive and the graph-search drivers.
+static int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_stride, uint32_t sort_cap,
+                          uint64_t n_queries, uint32_t max_nJ, r3dm_graph* g, int32_t* knn_idx_host, float* knn_dist_host)
+{
+    const uint32_t P = (uint32_t)jobs.size();
+    // ---- finalisation: compact + order + de-duplicate, per pair
+    R3DM_HIP(c, c->d_pair_off.ensure((size_t)P * 8));
+    R3DM_HIP(c, c->d_pair_cnt.ensure((size_t)P * 4));
+    uint64_t out_cap = std::max<uint64_t>(1u << 20, n_queries / 4);
+    std::vector<uint64_t> h_off(P);
+    std::vector<uint32_t> h_cnt(P);
+    unsigned long long total = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        R3DM_HIP(c, c->d_out.ensure(out_cap * sizeof(r3dm_match)));
+        R3DM_HIP(c, hipMemsetAsync(c->d_cnt.as<uint32_t>() + 8, 0, 8, c->stream));
+        FinalizeParams fp{};
+        fp.imgs = c->d_imgs.as<ImgDev>(); fp.pairs = c->d_pairs.as<uint2>(); fp.n_pairs = P; fp.q_stride = q_stride;
+        fp.nn_idx = c->d_nn.as<uint32_t>(); fp.sort_cap = sort_cap;
+        fp.spill_keys = nullptr; fp.spill_drop = nullptr; fp.spill_stride = 0;
+        if (q_stride > sort_cap) {                         // views with more rows than the LDS sort holds
+            fp.spill_stride = next_pow2(q_stride);
+            R3DM_HIP(c, c->d_spill.ensure((size_t)P * fp.spill_stride * 9));
+            fp.spill_keys = c->d_spill.as<unsigned long long>();
+            fp.spill_drop = c->d_spill.as<unsigned char>() + (size_t)P * fp.spill_stride * 8;
+        }
+        fp.out = c->d_out.as<r3dm_match>(); fp.out_cap = out_cap;
+        fp.total = reinterpret_cast<unsigned long long*>(c->d_cnt.as<uint32_t>() + 8);
+        fp.pair_off = c->d_pair_off.as<uint64_t>(); fp.pair_cnt = c->d_pair_cnt.as<uint32_t>();
+        R3DM_HIP(c, launch_finalize(c->stream, fp));
+        R3DM_HIP(c, hipMemcpyAsync(&total, fp.total, 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(h_off.data(), fp.pair_off, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(h_cnt.data(), fp.pair_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        if (total <= out_cap) break;
+        out_cap = total;                                   // overflow: nothing was lost, run it again with room
+    }
+    std::vector<r3dm_match> h_m((size_t)total);
+    if (total) R3DM_HIP(c, hipMemcpy(h_m.data(), c->d_out.p, (size_t)total * sizeof(r3dm_match), hipMemcpyDeviceToHost));
+    if (knn_idx_host) {
+        // single-pair use (r3dm_knn2): copy the raw 2-NN of pair 0
+        R3DM_HIP(c, hipMemcpy(knn_idx_host, c->d_knn_idx.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost));
+        R3DM_HIP(c, hipMemcpy(knn_dist_host, c->d_knn_dist.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost));
+    }
+
+    if (g) {
+        for (uint32_t p = 0; p < P; ++p) {
+            if (h_cnt[p] == 0) continue;                   // empty vectors never enter the map
+            g->pairs.push_back(jobs[p].I); g->pairs.push_back(jobs[p].J);
+            g->matches.insert(g->matches.end(), h_m.begin() + h_off[p], h_m.begin() + h_off[p] + h_cnt[p]);
+            g->offsets.push_back(g->matches.size());
+        }
+    }
+    return R3DM_OK;
+}
+
+// runs the 2-NN + ratio kernels over `jobs` (slot pairs, all of one dtype/dim) and appends the
+// non-empty results to `g` in job order.  knn_idx/knn_dist (host, optional) receive the raw 2-NN.
+static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
+                           int32_t* knn_idx_host, float* knn_dist_host)
+{
+    const uint32_t P = (uint32_t)jobs.size();
+    if (P == 0) return R3DM_OK;
+    const HostImage& first = *c->imgs[jobs[0].sI];
+    const r3dm_dtype dtype = first.dtype;
+    uint32_t max_nJ = 0, max_tiles = 0;
+    uint64_t n_queries = 0;
+    double flops = 0, bytes = 0;
+    for (const PairJob& j : jobs) {
+        const HostImage& A = *c->imgs[j.sI];
+        const HostImage& B = *c->imgs[j.sJ];
+        max_nJ = std::max(max_nJ, B.n);
+        max_tiles = std::max(max_tiles, B.n_tiles);
+        n_queries += B.n;
+        if (dtype == R3DM_BIN) {
+            flops += 2.0 * A.n * (double)B.n * A.words;
+            bytes += ((double)A.n + B.n) * A.words * 4 + (double)B.n * 16;
+        } else {
+            flops += 2.0 * A.n * (double)B.n * A.dim;
+            bytes += ((double)A.n + B.n) * A.dim * 4 + (double)B.n * 16;
+        }
+    }
+    const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
+    const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
+
+    std::vector<uint2> hp(P);
+    for (uint32_t p = 0; p < P; ++p) hp[p] = make_uint2(jobs[p].sI, jobs[p].sJ);
+    R3DM_HIP(c, c->d_pairs.ensure(sizeof(uint2) * P));
+    R3DM_HIP(c, hipMemcpyAsync(c->d_pairs.p, hp.data(), sizeof(uint2) * P, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, c->d_nn.ensure((size_t)P * q_stride * 4));
+    const uint64_t total_slots = (uint64_t)P * q_stride;
+    // per-pair lists of uncertified queries: [fb_total(2 words) | pad][fb_cnt: P][fb_q: P x kFbPerPair]
+    const size_t fb_words = 16 + (size_t)P + (size_t)P * kFbPerPair;
+    R3DM_HIP(c, c->d_fb.ensure(fb_words * 4));
+    R3DM_HIP(c, hipMemsetAsync(c->d_fb.p, 0, (16 + (size_t)P) * 4, c->stream));
+    R3DM_HIP(c, c->d_cnt.ensure(64));
+    R3DM_HIP(c, hipMemsetAsync(c->d_cnt.p, 0, 64, c->stream));
+    if (knn_idx_host) {
+        R3DM_HIP(c, c->d_knn_idx.ensure((size_t)total_slots * 8));
+        R3DM_HIP(c, c->d_knn_dist.ensure((size_t)total_slots * 8));
+    }
+
+    MatchParams mp{};
+    mp.imgs = c->d_imgs.as<ImgDev>();
+    mp.pairs = c->d_pairs.as<uint2>();
+    mp.n_pairs = P; mp.qb_per_pair = 0; mp.q_stride = q_stride;
+    mp.ratio_R = ratio_R;
+    // certification slack factor: |MFMA-path distance - reference distance| <= (3.5 D + 14) u (max||a||^2 + ||q||^2),
+    // u = 2^-24 (DESIGN.md "Certification"); 4.25 D u covers it for every padded D >= 64
+    mp.err_scale = 4.25f * (float)(first.G * 8) * 5.9604645e-08f;
+    mp.nn_idx = c->d_nn.as<uint32_t>();
+    mp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
+    mp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
+    mp.fb_total = c->d_fb.as<uint32_t>();
+    mp.fb_cnt = c->d_fb.as<uint32_t>() + 16;
+    mp.fb_q = c->d_fb.as<uint32_t>() + 16 + P;
+
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    uint64_t n_fallback = 0;
+    if (dtype == R3DM_BIN) {
+        R3DM_HIP(c, launch_hamming_knn2(c->stream, mp, first.words, max_nJ));
+        R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    } else if (has_tensor_kernel(first.G)) {
+        R3DM_HIP(c, launch_l2_knn2(c->stream, mp, first.G, max_tiles));
+        R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+        uint32_t fbt[2] = {0, 0};
+        R3DM_HIP(c, hipMemcpyAsync(fbt, mp.fb_total, 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        n_fallback = fbt[0];
+        if (fbt[0] > 0) {
+            bool rescan = fbt[1] > 0;                      // some pair overflowed its list
+            if ((first.dim & 3u) == 0) R3DM_HIP(c, launch_l2_exact_batch(c->stream, mp, first.G));
+            else rescan = true;                            // scalar-tail dims: generic exact kernel
+            if (rescan) {
+                if (total_slots > 0xFFFFFFFFull) { c->err = "batch too large for the exact rescan"; return R3DM_ERR_UNSUPPORTED; }
+                R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, (uint32_t)total_slots, 2));
+            }
+        }
+    } else {
+        // descriptor length without a tensor kernel: exact scan of every query (slow, still on the GPU)
+        if (total_slots > 0xFFFFFFFFull) { c->err = "batch too large for the exact scan"; return R3DM_ERR_UNSUPPORTED; }
+        R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, (uint32_t)total_slots, 1));
+        R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+        n_fallback = n_queries;
+    }
+
+    const double t_post = now_ms();            // (the stream is idle here only on the tensor path; good enough for a breakdown)
+    int rcf = finalize_batch(c, jobs, q_stride, sort_cap, n_queries, max_nJ, g, knn_idx_host, knn_dist_host);
+    if (rcf != R3DM_OK) return rcf;
+    c->stats.ms_wall_match_post += now_ms() - t_post;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_match_kernels += ms;
+    c->stats.n_match_launches += 1;
+    c->stats.n_pairs += P;
+    c->stats.n_queries += n_queries;
+    c->stats.n_exact_fallback += n_fallback;
+    c->stats.algorithmic_flops += flops;
+    c->stats.algorithmic_bytes += bytes;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs,
+                                float dist_ratio, int squared_metric, r3dm_graph** out)
+{
+    if (!c || !out || (n_pairs && !pairs_ij)) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    c->stats = r3dm_stats{};
+    const double t_call = now_ms();
+    // Matcher_Regions::Match: pairs whose views are missing, empty or of different region types are skipped
+    std::vector<PairJob> jobs;
+    jobs.reserve(n_pairs);
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        const uint32_t I = pairs_ij[2 * p], J = pairs_ij[2 * p + 1];
+        auto a = c->slot_of.find(I), b = c->slot_of.find(J);
+        if (a == c->slot_of.end() || b == c->slot_of.end()) { c->err = "pair references an unregistered view"; return R3DM_ERR_INVALID; }
+        const HostImage& A = *c->imgs[a->second];
+        const HostImage& B = *c->imgs[b->second];
+        if (A.n == 0 || B.n == 0 || A.dtype != B.dtype || A.dim != B.dim) continue;
+        jobs.push_back({I, J, a->second, b->second});
+    }
+    std::sort(jobs.begin(), jobs.end(), [](const PairJob& x, const PairJob& y) { return x.I != y.I ? x.I < y.I : x.J < y.J; });
+    jobs.erase(std::unique(jobs.begin(), jobs.end(), [](const PairJob& x, const PairJob& y) { return x.I == y.I && x.J == y.J; }), jobs.end());
+
+    auto g = std::unique_ptr<r3dm_graph>(new r3dm_graph());
+    g->offsets.push_back(0);
+    const float R = squared_metric ? dist_ratio * dist_ratio : dist_ratio;
+
+    // batches: same (dtype, dim) and a bounded nn_idx footprint
+    size_t start = 0;
+    while (start < jobs.size()) {
+        const HostImage& F = *c->imgs[jobs[start].sI];
+        size_t end = start;
+        uint64_t slots = 0;
+        uint32_t max_n = 0;
+        while (end < jobs.size()) {
+            const HostImage& A = *c->imgs[jobs[end].sI];
+            if (A.dtype != F.dtype || A.dim != F.dim) break;
+            const uint32_t mn = std::max(max_n, c->imgs[jobs[end].sJ]->n);
+            const uint64_t s = (uint64_t)(end - start + 1) * ((mn + 31) / 32 * 32);
+            if (end > start && s * 4 > (3ull << 30)) break;       // <= 3 GiB of nn_idx per batch
+            max_n = mn; slots = s; ++end;
+        }
+        (void)slots;
+        std::vector<PairJob> batch(jobs.begin() + start, jobs.begin() + end);
+        int rc = run_match_batch(c, batch, R, g.get(), nullptr, nullptr);
+        if (rc != R3DM_OK) return rc;
+        start = end;
+    }
+    c->stats.ms_wall_match = now_ms() - t_call;
+    *out = g.release();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
+                         uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist)
+{
+    if (!c || !dataset || !query || !out_idx || !out_dist || dim == 0) return R3DM_ERR_INVALID;
+    if (n_query < 1 || n_dataset < 2) return R3DM_ERR_INVALID;      // ArrayMatcherBruteForce: NN > nbRows / nbQuery < 1
+    if (dtype == R3DM_BIN && !(((dim + 3) / 4) == 8 || ((dim + 3) / 4) == 16)) return R3DM_ERR_UNSUPPORTED;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    // two private slots at the end of the table (never visible through view ids)
+    const uint32_t s0 = (uint32_t)c->imgs.size();
+    c->imgs.emplace_back(new HostImage());
+    c->imgs.emplace_back(new HostImage());
+    int rc = stage_into_slot(c, s0, 0, 0, 0, dataset, n_dataset, dim, dtype, nullptr);
+    if (rc == R3DM_OK) rc = stage_into_slot(c, s0 + 1, 0, 0, 0, query, n_query, dim, dtype, nullptr);
+    if (rc == R3DM_OK) {
+        std::vector<PairJob> jobs{{0, 1, s0, s0 + 1}};
+        const r3dm_stats keep = c->stats;
+        rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
+        c->stats = keep;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
+    c->imgs.pop_back(); c->imgs.pop_back();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// approximate matching: graph index + graph search (kernels_ann.hip)
+// ------------------------------------------------------------------------------------------------
+extern "C" int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out)
+{
+    if (!out) return R3DM_ERR_INVALID;
+    // src/R3DComputeMatches.cpp:844-873: (K, L, recall, P) = default (16, 24, .99, 10); 0: (2, 20, .6, 2); 1: (16, 24, .2, 6);
+    // 2: (16, 24, .8, 12).  NN-descent keeps between S and L neighbours per row depending on how far it converged (its
+    // recall target); the exact index has no such knob, so index_K takes the pool length L of the preset.
+    r3dm_kgraph_params k{};
+    k.search_S = 10; k.seed = 1998;
+    switch (preset) {
+        case 0:  k.index_K = 20; k.search_P = 2;  break;
+        case 1:  k.index_K = 24; k.search_P = 6;  break;
+        case 2:  k.index_K = 24; k.search_P = 12; break;
+        default: k.index_K = 24; k.search_P = 10; break;
+    }
+    *out = k;
+    return R3DM_OK;
+}
+
+static int check_kgraph_params(r3dm_ctx* c, const r3dm_kgraph_params* kp)
+{
+    if (!kp) return R3DM_ERR_INVALID;
+    if (kp->index_K < 1 || kp->index_K > kAnnMaxK || kp->search_P < 2 || kp->search_P > 61 || kp->search_S < 1 || kp->search_S > 16) {
+        c->err = "kgraph parameters out of range (index_K 1..32, search_P 2..61, search_S 1..16)";
+        return R3DM_ERR_INVALID;
+    }
+    return R3DM_OK;
+}
+
+// builds the graph index of every listed slot that does not hold one for this K
+static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t K)
+{
+    std::sort(slots.begin(), slots.end());
+    slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+    std::vector<uint32_t> todo;
+    for (uint32_t s : slots) if (c->imgs[s]->ann_K != K) todo.push_back(s);
+    if (todo.empty()) return R3DM_OK;
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    size_t start = 0;
+    while (start < todo.size()) {
+        // chunk: bounded scratch (fwd + rev keys: 16 B per edge slot)
+        size_t end = start, bytes = 0;
+        uint32_t max_n = 0;
+        const uint32_t dim = c->imgs[todo[start]]->dim;
+        while (end < todo.size() && end - start < 256) {
+            const HostImage& h = *c->imgs[todo[end]];
+            if (h.dim != dim) break;
+            const size_t need = (size_t)h.n * K * 16 + (size_t)h.n * 12 + 64;
+            if (end > start && bytes + need > (4ull << 30)) break;
+            bytes += need; max_n = std::max(max_n, h.n); ++end;
+        }
+        R3DM_HIP(c, c->a_scratch.ensure(bytes));
+        R3DM_HIP(c, hipMemsetAsync(c->a_scratch.p, 0, bytes, c->stream));
+        std::vector<AnnBuildJob> jobs;
+        unsigned char* cur = c->a_scratch.as<unsigned char>();
+        for (size_t k = start; k < end; ++k) {
+            HostImage& h = *c->imgs[todo[k]];
+            R3DM_HIP(c, h.ann_adj.ensure((size_t)h.n * kAnnDeg * 4));
+            R3DM_HIP(c, h.ann_deg.ensure((size_t)h.n * 4));
+            AnnBuildJob j{};
+            j.slot = todo[k];
+            j.fwd = (unsigned long long*)cur; cur += (size_t)h.n * K * 8;
+            j.rev = (unsigned long long*)cur; cur += (size_t)h.n * K * 8;
+            j.rev_cnt = (uint32_t*)cur; cur += (size_t)h.n * 4;
+            j.rev_cur = (uint32_t*)cur; cur += (size_t)h.n * 4;
+            j.rev_off = (uint32_t*)cur; cur += (size_t)h.n * 4 + 64;
+            j.adj = h.ann_adj.as<uint32_t>(); j.deg = h.ann_deg.as<uint32_t>();
+            jobs.push_back(j);
+        }
+        R3DM_HIP(c, c->a_jobs.ensure(jobs.size() * sizeof(AnnBuildJob)));
+        R3DM_HIP(c, hipMemcpyAsync(c->a_jobs.p, jobs.data(), jobs.size() * sizeof(AnnBuildJob), hipMemcpyHostToDevice, c->stream));
+        AnnBuildParams bp{};
+        bp.imgs = c->d_imgs.as<ImgDev>(); bp.jobs = c->a_jobs.as<AnnBuildJob>(); bp.K = K;
+        hipError_t e = launch_ann_build(c->stream, bp, (uint32_t)jobs.size(), max_n, dim);
+        if (e == hipErrorInvalidValue) { c->err = "no graph-index kernel for this descriptor length (dim % 4 != 0 or too long)"; return R3DM_ERR_UNSUPPORTED; }
+        R3DM_HIP(c, e);
+        std::vector<const void*> ptrs(2 * (end - start));      // must outlive the asynchronous copies
+        for (size_t k = start; k < end; ++k) {
+            HostImage& h = *c->imgs[todo[k]];
+            ptrs[2 * (k - start)] = h.ann_adj.p; ptrs[2 * (k - start) + 1] = h.ann_deg.p;
+            R3DM_HIP(c, hipMemcpyAsync((void*)&(c->d_imgs.as<ImgDev>() + todo[k])->ann_adj, &ptrs[2 * (k - start)], 2 * sizeof(void*),
+                                       hipMemcpyHostToDevice, c->stream));
+            h.ann_K = K;
+        }
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));          // jobs / ptrs are host temporaries; scratch is reused
+        start = end;
+    }
+    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_ann_build += ms;
+    c->stats.n_ann_built += todo.size();
+    return R3DM_OK;
+}
+
+// graph search + ratio test over `jobs` (all of one dim; every sI holds an index), results appended to g in job order
+static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, const r3dm_kgraph_params& kp,
+                         r3dm_graph* g, int32_t* knn_idx_host, float* knn_dist_host)
+{
+    const uint32_t P = (uint32_t)jobs.size();
+    if (P == 0) return R3DM_OK;
+    uint32_t max_nJ = 0, max_nI = 0;
+    uint64_t n_queries = 0;
+    for (const PairJob& j : jobs) {
+        max_nI = std::max(max_nI, c->imgs[j.sI]->n);
+        max_nJ = std::max(max_nJ, c->imgs[j.sJ]->n);
+        n_queries += c->imgs[j.sJ]->n;
+    }
+    const uint32_t dim = c->imgs[jobs[0].sI]->dim;
+    const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
+    const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
+    std::vector<uint2> hp(P), hid(P);
+    for (uint32_t p = 0; p < P; ++p) { hp[p] = make_uint2(jobs[p].sI, jobs[p].sJ); hid[p] = make_uint2(jobs[p].I, jobs[p].J); }
+    R3DM_HIP(c, c->d_pairs.ensure(sizeof(uint2) * P));
+    R3DM_HIP(c, c->a_ids.ensure(sizeof(uint2) * P));
+    R3DM_HIP(c, hipMemcpyAsync(c->d_pairs.p, hp.data(), sizeof(uint2) * P, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->a_ids.p, hid.data(), sizeof(uint2) * P, hipMemcpyHostToDevice, c->stream));
+    const uint64_t total_slots = (uint64_t)P * q_stride;
+    R3DM_HIP(c, c->d_nn.ensure((size_t)total_slots * 4));
+    R3DM_HIP(c, c->d_cnt.ensure(64));
+    R3DM_HIP(c, hipMemsetAsync(c->d_cnt.p, 0, 64, c->stream));
+    if (knn_idx_host) {
+        R3DM_HIP(c, c->d_knn_idx.ensure((size_t)total_slots * 8));
+        R3DM_HIP(c, c->d_knn_dist.ensure((size_t)total_slots * 8));
+    }
+    AnnSearchParams sp{};
+    sp.imgs = c->d_imgs.as<ImgDev>(); sp.pairs = c->d_pairs.as<uint2>(); sp.pair_ids = c->a_ids.as<uint2>();
+    sp.n_pairs = P; sp.q_stride = q_stride;
+    sp.P = kp.search_P; sp.S = kp.search_S; sp.pool_cap = 2 + kp.search_P; sp.seed = kp.seed; sp.ratio_R = ratio_R;
+    sp.nn_idx = c->d_nn.as<uint32_t>();
+    sp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
+    sp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
+    sp.n_comps = reinterpret_cast<unsigned long long*>(c->d_cnt.as<uint32_t>() + 4);
+    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    hipError_t e = launch_ann_search(c->stream, sp, max_nJ, max_nI, dim);
+    if (e == hipErrorInvalidValue) { c->err = "graph search: unsupported descriptor length / view size / parameters"; return R3DM_ERR_UNSUPPORTED; }
+    R3DM_HIP(c, e);
+    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    unsigned long long comps = 0;
+    R3DM_HIP(c, hipMemcpyAsync(&comps, sp.n_comps, 8, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    const double t_post = now_ms();
+    int rc = finalize_batch(c, jobs, q_stride, sort_cap, n_queries, max_nJ, g, knn_idx_host, knn_dist_host);
+    if (rc != R3DM_OK) return rc;
+    c->stats.ms_wall_match_post += now_ms() - t_post;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_ann_search += ms;
+    c->stats.n_ann_dist += comps;
+    c->stats.n_pairs += P;
+    c->stats.n_queries += n_queries;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_match_pairs_kgraph(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                                       const r3dm_kgraph_params* kp, r3dm_graph** out)
+{
+    if (!c || !out || (n_pairs && !pairs_ij)) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    int rc = check_kgraph_params(c, kp);
+    if (rc != R3DM_OK) return rc;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    c->stats = r3dm_stats{};
+    const double t_call = now_ms();
+    std::vector<PairJob> ann_jobs, small_jobs;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        const uint32_t I = pairs_ij[2 * p], J = pairs_ij[2 * p + 1];
+        auto a = c->slot_of.find(I), b = c->slot_of.find(J);
+        if (a == c->slot_of.end() || b == c->slot_of.end()) { c->err = "pair references an unregistered view"; return R3DM_ERR_INVALID; }
+        const HostImage& A = *c->imgs[a->second];
+        const HostImage& B = *c->imgs[b->second];
+        if (A.n == 0 || B.n == 0 || A.dtype != B.dtype || A.dim != B.dim) continue;
+        if (A.dtype == R3DM_BIN || (A.dim & 3u)) { c->err = "kgraph matching needs F32/U8 descriptors with dim % 4 == 0"; return R3DM_ERR_UNSUPPORTED; }
+        // KGraphImpl::search scans linearly when P >= n (kgraph.cpp:415-421); here every small index is scanned
+        if (A.n < kAnnMinRows || kp->search_P >= A.n) small_jobs.push_back({I, J, a->second, b->second});
+        else ann_jobs.push_back({I, J, a->second, b->second});
+    }
+    auto by_pair = [](const PairJob& x, const PairJob& y) { return x.I != y.I ? x.I < y.I : x.J < y.J; };
+    auto same = [](const PairJob& x, const PairJob& y) { return x.I == y.I && x.J == y.J; };
+    for (auto* v : {&ann_jobs, &small_jobs}) { std::sort(v->begin(), v->end(), by_pair); v->erase(std::unique(v->begin(), v->end(), same), v->end()); }
+    const float R = dist_ratio * dist_ratio;
+
+    r3dm_graph ga, gs;
+    ga.offsets.push_back(0); gs.offsets.push_back(0);
+    if (!ann_jobs.empty()) {
+        std::vector<uint32_t> slots;
+        for (const PairJob& j : ann_jobs) slots.push_back(j.sI);
+        rc = ensure_ann_indices(c, slots, kp->index_K);
+        if (rc != R3DM_OK) return rc;
+    }
+    size_t start = 0;
+    while (start < ann_jobs.size()) {
+        const uint32_t dim = c->imgs[ann_jobs[start].sI]->dim;
+        size_t end = start;
+        uint32_t max_n = 0;
+        while (end < ann_jobs.size()) {
+            if (c->imgs[ann_jobs[end].sI]->dim != dim) break;
+            const uint32_t mn = std::max(max_n, c->imgs[ann_jobs[end].sJ]->n);
+            const uint64_t s = (uint64_t)(end - start + 1) * ((mn + 31) / 32 * 32);
+            if (end > start && (s * 4 > (3ull << 30) || s / 4 > 0x40000000ull)) break;
+            max_n = mn; ++end;
+        }
+        std::vector<PairJob> batch(ann_jobs.begin() + start, ann_jobs.begin() + end);
+        rc = run_ann_batch(c, batch, R, *kp, &ga, nullptr, nullptr);
+        if (rc != R3DM_OK) return rc;
+        start = end;
+    }
+    start = 0;
+    while (start < small_jobs.size()) {                      // few and tiny: one batch per (dtype, dim) run
+        size_t end = start;
+        const HostImage& F = *c->imgs[small_jobs[start].sI];
+        while (end < small_jobs.size() && c->imgs[small_jobs[end].sI]->dtype == F.dtype && c->imgs[small_jobs[end].sI]->dim == F.dim) ++end;
+        std::vector<PairJob> batch(small_jobs.begin() + start, small_jobs.begin() + end);
+        rc = run_match_batch(c, batch, R, &gs, nullptr, nullptr);
+        if (rc != R3DM_OK) return rc;
+        start = end;
+    }
+    const r3dm_graph* parts[2] = {&ga, &gs};
+    rc = r3dm_graph_merge(parts, 2, out);
+    c->stats.ms_wall_match = now_ms() - t_call;
+    return rc;
+}
+
+extern "C" int r3dm_kgraph_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
+                                uint32_t dim, const r3dm_kgraph_params* kp, uint32_t pair_i, uint32_t pair_j,
+                                int32_t* out_idx, float* out_dist)
+{
+    if (!c || !dataset || !query || !out_idx || !out_dist || dim == 0) return R3DM_ERR_INVALID;
+    if (n_query < 1 || n_dataset < 2) return R3DM_ERR_INVALID;
+    int rc = check_kgraph_params(c, kp);
+    if (rc != R3DM_OK) return rc;
+    if (dim & 3u) { c->err = "kgraph matching needs dim % 4 == 0"; return R3DM_ERR_UNSUPPORTED; }
+    R3DM_HIP(c, hipSetDevice(c->device));
+    const uint32_t s0 = (uint32_t)c->imgs.size();
+    c->imgs.emplace_back(new HostImage());
+    c->imgs.emplace_back(new HostImage());
+    rc = stage_into_slot(c, s0, pair_i, 0, 0, dataset, n_dataset, dim, R3DM_F32, nullptr);
+    if (rc == R3DM_OK) rc = stage_into_slot(c, s0 + 1, pair_j, 0, 0, query, n_query, dim, R3DM_F32, nullptr);
+    const r3dm_stats keep = c->stats;
+    if (rc == R3DM_OK) {
+        std::vector<PairJob> jobs{{pair_i, pair_j, s0, s0 + 1}};
+        if (n_dataset < kAnnMinRows || kp->search_P >= n_dataset) rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
+        else {
+            rc = ensure_ann_indices(c, {s0}, kp->index_K);
+            if (rc == R3DM_OK) rc = run_ann_batch(c, jobs, 1.0f, *kp, nullptr, out_idx, out_dist);
+        }
+    }
+    c->stats = keep;
+    (void)hipStreamSynchronize(c->stream);
+    c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
+    c->imgs.pop_back(); c->imgs.pop_back();
+    return rc;
+}
+
+extern "C" int r3dm_kgraph_index(r3dm_ctx* c, uint32_t view_id, uint32_t index_K, uint32_t* adj_out, uint32_t* deg_out)
+{
+    if (!c || !adj_out || !deg_out) return R3DM_ERR_INVALID;
+    auto it = c->slot_of.find(view_id);
+    if (it == c->slot_of.end()) { c->err = "unregistered view"; return R3DM_ERR_INVALID; }
+    if (index_K < 1 || index_K > kAnnMaxK) return R3DM_ERR_INVALID;
+    HostImage& h = *c->imgs[it->second];
+    if (h.dtype == R3DM_BIN || (h.dim & 3u) || h.n < 2) { c->err = "kgraph index needs >= 2 F32/U8 rows with dim % 4 == 0"; return R3DM_ERR_UNSUPPORTED; }
+    R3DM_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_ann_indices(c, {it->second}, index_K);
+    if (rc != R3DM_OK) return rc;
+    R3DM_HIP(c, hipMemcpy(adj_out, h.ann_adj.p, (size_t)h.n * kAnnDeg * 4, hipMemcpyDeviceToHost));
+    R3DM_HIP(c, hipMemcpy(deg_out, h.ann_deg.p, (size_t)h.n * 4, hipMemcpyDeviceToHost));
+    return R3DM_OK;
+}
+

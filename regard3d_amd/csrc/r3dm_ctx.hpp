@@ -1,0 +1,130 @@
+// r3dm_ctx.hpp -- host-side state shared by the translation units of libr3dm.so (not part of the public ABI).
+//   api_core.cpp      context, views (staging), match-graph objects, matches.* files
+//   api_match.cpp     exhaustive and graph-based putative matching
+//   api_filter.cpp    AC-RANSAC geometric filters (F, E, H)
+//   api_features.cpp  Fast-A-KAZE detection, MLDB / LIOP description, the features work item
+#pragma once
+
+#include "r3dm_internal.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace r3dm;
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct HostImage {
+    uint32_t view_id = 0, n = 0, dim = 0, width = 0, height = 0;
+    r3dm_dtype dtype = R3DM_F32;
+    uint32_t G = 0, n_tiles = 0, words = 0;
+    bool has_xy = false, has_dup = false, live = false;
+    DevBuf rows, tiled, norms, bin, xy, canon;
+    DevBuf ann_adj, ann_deg;          // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0
+    uint32_t ann_K = 0;
+    bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter
+    double Kinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void release()
+    {
+        rows.release(); tiled.release(); norms.release(); bin.release(); xy.release(); canon.release();
+        ann_adj.release(); ann_deg.release(); ann_K = 0; live = false;
+    }
+};
+
+inline uint32_t kernel_G_for(uint32_t dim)
+{
+    const uint32_t g = (dim + 7) / 8;
+    if (g <= 8) return 8;
+    if (g <= 16) return 16;
+    if (g <= 18) return 18;
+    if (g <= 32) return 32;
+    return g;               // no tensor kernel: exact scan only
+}
+inline bool has_tensor_kernel(uint32_t G) { return G == 8 || G == 16 || G == 18 || G == 32; }
+
+inline uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+inline double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline bool has_ext(const char* path, const char* ext)
+{
+    const size_t lp = strlen(path), le = strlen(ext);
+    return lp >= le && strcmp(path + lp - le, ext) == 0;
+}
+
+
+struct r3dm_graph {
+    std::vector<uint32_t> pairs;      // 2 per pair
+    std::vector<uint64_t> offsets;    // n_pairs + 1
+    std::vector<r3dm_match> matches;
+};
+
+struct r3dm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::string arch;
+    int n_cu = 0;
+    uint64_t hbm = 0;
+    std::vector<std::unique_ptr<HostImage>> imgs;           // slot -> image
+    std::unordered_map<uint32_t, uint32_t> slot_of;         // view id -> slot
+    DevBuf d_imgs;                                           // ImgDev[slots]
+    // scratch (grown on demand, reused across calls)
+    DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
+    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
+    DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
+    DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill;
+    std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size
+    int ak_w = 0, ak_h = 0;
+    uint32_t liop_npix = 0;
+    r3dm_stats stats{};
+    std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
+};
+
+#define R3DM_HIP(ctx, call)                                                            \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);          \
+            return R3DM_ERR_HIP;                                                       \
+        }                                                                              \
+    } while (0)
+
+
+struct PairJob { uint32_t I, J, sI, sJ; };
+
+// shared between the translation units
+int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width, uint32_t height,
+                    const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);

@@ -1,4 +1,4 @@
-// r3dm_internal.hpp -- structures shared by the host library (r3dm_api.cpp) and the HIP kernels
+// r3dm_internal.hpp -- structures shared by the host library (api_*.cpp, r3dm_ctx.hpp) and the HIP kernels
 // (kernels_*.hip).  Not part of the public ABI (include/r3dm.h is).
 #pragma once
 
