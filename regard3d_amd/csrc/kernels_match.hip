@@ -280,8 +280,19 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t h = lane >> 5, c = lane & 31u;
-    const uint32_t pair = blockIdx.x / P.qb_per_pair;
-    const uint32_t qb = blockIdx.x % P.qb_per_pair;
+    // workgroup -> (pair, query block).  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2; with
+    // xcd_map every workgroup of a pair runs on ONE XCD (pair p on XCD p % 8), so image I and the query tiles are pulled
+    // into one L2 instead of eight (pairs are sorted by I: an XCD's consecutive pairs mostly share their dataset image).
+    uint32_t pair, qb;
+    if (P.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        pair = (j / P.qb_per_pair) * 8u + xcd;
+        qb = j % P.qb_per_pair;
+        if (pair >= P.n_pairs) return;
+    } else {
+        pair = blockIdx.x / P.qb_per_pair;
+        qb = blockIdx.x % P.qb_per_pair;
+    }
     const uint2 pr = P.pairs[pair];
     const ImgDev* __restrict__ Ip = P.imgs + pr.x;
     const ImgDev* __restrict__ Jp = P.imgs + pr.y;
@@ -450,8 +461,12 @@ static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t m
     MatchParams P = Pin;
     const uint32_t tiles_per_wg = 4u * NJ;                 // 4 waves x NJ query tiles x 32 queries
     P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    const uint32_t grid = P.n_pairs * P.qb_per_pair;
-    if (grid == 0) return hipSuccess;
+    static const int xcd_map = [] { const char* v = getenv("R3DM_XCD_MAP"); return v ? atoi(v) : 1; }();
+    P.xcd_map = (uint32_t)xcd_map;
+    const uint64_t grid64 = (uint64_t)(xcd_map ? (P.n_pairs + 7u) / 8u * 8u : P.n_pairs) * P.qb_per_pair;
+    if (grid64 == 0) return hipSuccess;
+    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const uint32_t grid = (uint32_t)grid64;
     hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF, PIPE, WPS>), dim3(grid), dim3(256), 0, st, P);
     return hipGetLastError();
 }

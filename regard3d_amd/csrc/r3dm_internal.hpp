@@ -83,6 +83,7 @@ struct MatchParams {
     const uint2*  pairs;          // slot indices (I, J)
     uint32_t      n_pairs;
     uint32_t      qb_per_pair;    // workgroups per pair
+    uint32_t      xcd_map;        // != 0: all workgroups of a pair on one XCD (blockIdx & 7)
     uint32_t      q_stride;       // entries per pair in nn_idx / knn_* (>= max n_J)
     float         ratio_R;        // ratio^2 (squared metric) or ratio
     float         err_scale;      // certification slack factor: 8 * Dpad * 2^-24
