@@ -253,96 +253,154 @@ __device__ __forceinline__ double h_asym_err(const double* H, double x1, double 
 // oracle/essential.c (only + - * / after the QR), so both produce the same bits.  One lane per minimal sample; the
 // 10x20 elimination matrix lives in scratch memory (the other 192 lanes of the workgroup wait at the barrier anyway).
 // ------------------------------------------------------------------------------------------------
-__device__ const unsigned char kT11[4][4] = {{0, 2, 3, 4}, {2, 1, 5, 6}, {3, 5, 7, 8}, {4, 6, 8, 9}};
-__device__ const unsigned char kT21[10][4] = {{0, 2, 4, 5}, {3, 1, 6, 7}, {2, 3, 8, 9}, {4, 8, 10, 11}, {5, 9, 11, 12},
-                                              {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+constexpr unsigned char kT11[4][4] = {{0, 2, 3, 4}, {2, 1, 5, 6}, {3, 5, 7, 8}, {4, 6, 8, 9}};
+constexpr unsigned char kT21[10][4] = {{0, 2, 4, 5}, {3, 1, 6, 7}, {2, 3, 8, 9}, {4, 8, 10, 11}, {5, 9, 11, 12},
+                                       {8, 6, 13, 14}, {9, 7, 14, 15}, {10, 13, 16, 17}, {11, 14, 17, 18}, {12, 15, 18, 19}};
 
-__device__ __noinline__ void e_mul11(const double* a, const double* b, double* out)
+// products of small polynomials in (x, y, z); fully unrolled: the monomial tables are compile-time constants, so every
+// index is static and the operands stay in registers
+__device__ __forceinline__ void e_mul11(const double (&a)[4], const double (&b)[4], double (&out)[10])
 {
+#pragma unroll
     for (int k = 0; k < 10; ++k) out[k] = 0.0;
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) out[kT11[i][j]] += a[i] * b[j];
 }
-__device__ __noinline__ void e_mul21_acc(const double* a, const double* b, double* out)
+__device__ __forceinline__ void e_mul21_acc(const double (&a)[10], const double (&b)[4], double (&out)[20])
 {
+#pragma unroll
     for (int i = 0; i < 10; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) out[kT21[i][j]] += a[i] * b[j];
 }
-__device__ __noinline__ void e_pmul(const double* a, int da, const double* b, int db, double* out)
+template <int DA, int DB>
+__device__ __forceinline__ void e_pmul(const double (&a)[DA + 1], const double (&b)[DB + 1], double (&out)[DA + DB + 1])
 {
-    for (int k = 0; k <= da + db; ++k) out[k] = 0.0;
-    for (int i = 0; i <= da; ++i)
-        for (int j = 0; j <= db; ++j) out[i + j] += a[i] * b[j];
+#pragma unroll
+    for (int k = 0; k <= DA + DB; ++k) out[k] = 0.0;
+#pragma unroll
+    for (int i = 0; i <= DA; ++i)
+#pragma unroll
+        for (int j = 0; j <= DB; ++j) out[i + j] += a[i] * b[j];
 }
-__device__ __forceinline__ double e_peval(const double* p, int d, double t)
+template <int D>
+__device__ __forceinline__ double e_peval(const double (&p)[D + 1], double t)
 {
-    double v = p[d];
-    for (int k = d - 1; k >= 0; --k) v = v * t + p[k];
+    double v = p[D];
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) v = v * t + p[k];
     return v;
 }
-__device__ __noinline__ int e_sturm_changes(const double (*f)[11], const int* deg, int nf, double t)
+
+// per-lane workspace in LDS: element i of lane l lives at ws[i * 64] (ws already offset by l): conflict-free, and
+// dynamic indexing (pivot rows, Sturm chain) costs an LDS access instead of a scratch-memory round trip
+#define E_WS(i) ws[(size_t)(i) * 64]
+constexpr int kEwsChain = 0;        // Sturm chain f[k][c] at kEwsChain + 11 k + c   (k < 12)   -- reuses the matrix area
+constexpr int kEwsDeg = 140;        // degree of f[k]
+constexpr int kEwsRoots = 160;      // real roots
+constexpr int kEwsDoubles = 200;    // 10 x 20 elimination matrix = 200 doubles per lane
+
+__device__ __forceinline__ int e_sturm_changes(const double* ws, int nf, double t)
 {
     int changes = 0, last = 0;
     for (int k = 0; k < nf; ++k) {
-        const double v = e_peval(f[k], deg[k], t);
+        const int d = (int)E_WS(kEwsDeg + k);
+        double v = E_WS(kEwsChain + 11 * k + d);
+        for (int c = d - 1; c >= 0; --c) v = v * t + E_WS(kEwsChain + 11 * k + c);
         const int s = (v > 0.0) - (v < 0.0);
         if (s != 0) { if (last != 0 && s != last) ++changes; last = s; }
     }
     return changes;
 }
 
-// real roots of a polynomial of degree <= 10 (ascending coefficients), ascending, distinct
-__device__ __noinline__ int real_roots10(const double* p_in, int deg_in, double* roots)
+// real roots of a polynomial of degree <= 10 (ascending coefficients), ascending, distinct -> E_WS(kEwsRoots + ...)
+__device__ __noinline__ int real_roots10(const double (&p_in)[11], double* ws)
 {
-    double f[12][11];
-    int deg[12];
-    int d = deg_in;
+    int d = 10;
     while (d > 0 && p_in[d] == 0.0) --d;
     if (d <= 0) return 0;
-    for (int k = 0; k <= d; ++k) f[0][k] = p_in[k] / p_in[d];
-    deg[0] = d;
-    for (int k = 1; k <= d; ++k) f[1][k - 1] = (double)k * f[0][k];
-    deg[1] = d - 1;
+    {
+        double lead = 0.0;
+#pragma unroll
+        for (int k = 0; k <= 10; ++k) if (k == d) lead = p_in[k];
+#pragma unroll
+        for (int k = 0; k <= 10; ++k) if (k <= d) E_WS(kEwsChain + k) = p_in[k] / lead;
+    }
+    E_WS(kEwsDeg + 0) = (double)d;
+    for (int k = 1; k <= d; ++k) E_WS(kEwsChain + 11 + k - 1) = (double)k * E_WS(kEwsChain + k);
+    E_WS(kEwsDeg + 1) = (double)(d - 1);
     int nf = 2;
-    while (deg[nf - 1] > 0) {
-        const double* b = f[nf - 1];
-        const int db = deg[nf - 1];
-        double r[11];
-        int dr = deg[nf - 2];
-        for (int k = 0; k <= dr; ++k) r[k] = f[nf - 2][k];
+    int deg_prev = d, deg_cur = d - 1;
+    while (deg_cur > 0) {
+        // f[nf] = -rem(f[nf-2], f[nf-1]) / |leading coefficient|, remainder built in place in slot nf
+        const int bo = kEwsChain + 11 * (nf - 1), ro = kEwsChain + 11 * nf;
+        const int db = deg_cur;
+        int dr = deg_prev;
+        for (int k = 0; k <= dr; ++k) E_WS(ro + k) = E_WS(kEwsChain + 11 * (nf - 2) + k);
+        const double blead = E_WS(bo + db);
         while (dr >= db) {
-            const double q = r[dr] / b[db];
-            for (int k = 0; k < db; ++k) r[dr - db + k] -= q * b[k];
-            r[dr] = 0.0;
+            const double q = E_WS(ro + dr) / blead;
+            for (int k = 0; k < db; ++k) E_WS(ro + dr - db + k) -= q * E_WS(bo + k);
+            E_WS(ro + dr) = 0.0;
             --dr;
         }
-        while (dr >= 0 && r[dr] == 0.0) --dr;
+        while (dr >= 0 && E_WS(ro + dr) == 0.0) --dr;
         if (dr < 0) break;
-        const double sc = fabs(r[dr]);
-        for (int k = 0; k <= dr; ++k) f[nf][k] = -r[k] / sc;
-        deg[nf] = dr;
+        const double sc = fabs(E_WS(ro + dr));
+        for (int k = 0; k <= dr; ++k) E_WS(ro + k) = -E_WS(ro + k) / sc;
+        E_WS(kEwsDeg + nf) = (double)dr;
+        deg_prev = deg_cur; deg_cur = dr;
         ++nf;
     }
     double bound = 0.0;
-    for (int k = 0; k < d; ++k) { const double a = fabs(f[0][k]); if (a > bound) bound = a; }
+    for (int k = 0; k < d; ++k) { const double a = fabs(E_WS(kEwsChain + k)); if (a > bound) bound = a; }
     bound += 1.0;
-    const int va = e_sturm_changes(f, deg, nf, -bound);
-    const int nr = va - e_sturm_changes(f, deg, nf, bound);
-    int n_out = 0;
-    for (int r = 1; r <= nr && n_out < 10; ++r) {
-        double lo = -bound, hi = bound;
-        for (int it = 0; it < 64; ++it) {
-            const double mid = 0.5 * (lo + hi);
-            if (va - e_sturm_changes(f, deg, nf, mid) >= r) hi = mid; else lo = mid;
+    const int va = e_sturm_changes(ws, nf, -bound);
+    int nr = va - e_sturm_changes(ws, nf, bound);
+    if (nr > 10) nr = 10;
+    if (nr <= 0) return 0;
+    // the bisections of the nr roots are independent (root r follows only its own sign counts), so they advance in lockstep:
+    // every coefficient of the chain is read from LDS once per step and feeds all Horner recurrences.  Each root still sees
+    // exactly the midpoints and counts of the one-root-at-a-time loop of the CPU restatement.
+    double lo[10], hi[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { lo[r] = -bound; hi[r] = bound; }
+    for (int it = 0; it < 64; ++it) {
+        double mid[10], v[10];
+        int changes[10], last[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { mid[r] = 0.5 * (lo[r] + hi[r]); changes[r] = 0; last[r] = 0; }
+        for (int k = 0; k < nf; ++k) {
+            const int dk = (int)E_WS(kEwsDeg + k);
+            const double lead = E_WS(kEwsChain + 11 * k + dk);
+#pragma unroll
+            for (int r = 0; r < 10; ++r) v[r] = lead;
+            for (int c = dk - 1; c >= 0; --c) {
+                const double coef = E_WS(kEwsChain + 11 * k + c);
+#pragma unroll
+                for (int r = 0; r < 10; ++r) v[r] = v[r] * mid[r] + coef;
+            }
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const int s = (v[r] > 0.0) - (v[r] < 0.0);
+                if (s != 0) { if (last[r] != 0 && s != last[r]) ++changes[r]; last[r] = s; }
+            }
         }
-        roots[n_out++] = 0.5 * (lo + hi);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { if (va - changes[r] >= r + 1) hi[r] = mid[r]; else lo[r] = mid[r]; }
     }
-    return n_out;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) if (r < nr) E_WS(kEwsRoots + r) = 0.5 * (lo[r] + hi[r]);
+    return nr;
 }
 
-__device__ __noinline__ int five_point(const double (&px1)[7][2], const double (&px2)[7][2], double* Es /* 90 */)
+// Es: this lane's model slots (LDS), 9 doubles per model
+__device__ __noinline__ int five_point(const double (&px1)[7][2], const double (&px2)[7][2], double* __restrict__ Es, double* __restrict__ ws)
 {
     double M[9][5];
+#pragma unroll
     for (int p = 0; p < 5; ++p) {
         const double ax = px1[p][0], ay = px1[p][1], bx = px2[p][0], by = px2[p][1];
         M[0][p] = bx * ax; M[1][p] = bx * ay; M[2][p] = bx;
@@ -350,8 +408,10 @@ __device__ __noinline__ int five_point(const double (&px1)[7][2], const double (
         M[6][p] = ax;      M[7][p] = ay;      M[8][p] = 1.0;
     }
     double beta[5];
+#pragma unroll
     for (int j = 0; j < 5; ++j) {
         double nrm2 = 0.0;
+#pragma unroll
         for (int r = j; r < 9; ++r) nrm2 += M[r][j] * M[r][j];
         const double nrm = sqrt(nrm2);
         double bj = 0.0;
@@ -359,107 +419,173 @@ __device__ __noinline__ int five_point(const double (&px1)[7][2], const double (
             const double alpha = (M[j][j] > 0.0) ? -nrm : nrm;
             M[j][j] -= alpha;
             double vn2 = 0.0;
+#pragma unroll
             for (int r = j; r < 9; ++r) vn2 += M[r][j] * M[r][j];
             if (vn2 != 0.0) bj = 2.0 / vn2;
         } else {
+#pragma unroll
             for (int r = j; r < 9; ++r) M[r][j] = 0.0;
         }
         beta[j] = bj;
+#pragma unroll
         for (int c = j + 1; c < 5; ++c) {
             double dot = 0.0;
+#pragma unroll
             for (int r = j; r < 9; ++r) dot += M[r][j] * M[r][c];
             const double s = bj * dot;
+#pragma unroll
             for (int r = j; r < 9; ++r) M[r][c] -= s * M[r][j];
         }
     }
     double N[4][9];
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
+#pragma unroll
         for (int r = 0; r < 9; ++r) N[e][r] = (r == 5 + e) ? 1.0 : 0.0;
+#pragma unroll
         for (int j = 4; j >= 0; --j) {
             double dot = 0.0;
+#pragma unroll
             for (int r = j; r < 9; ++r) dot += M[r][j] * N[e][r];
             const double s = beta[j] * dot;
+#pragma unroll
             for (int r = j; r < 9; ++r) N[e][r] -= s * M[r][j];
         }
     }
-    double E1[9][4];
-    for (int r = 0; r < 9; ++r) for (int e = 0; e < 4; ++e) E1[r][e] = N[e][r];
-    double A[10][20];
-    for (int r = 0; r < 10; ++r) for (int c = 0; c < 20; ++c) A[r][c] = 0.0;
-    double t1[10], t2[10], d2[10];
-    e_mul11(E1[1], E1[5], t1); e_mul11(E1[2], E1[4], t2); for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
-    e_mul21_acc(d2, E1[6], A[0]);
-    e_mul11(E1[2], E1[3], t1); e_mul11(E1[0], E1[5], t2); for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
-    e_mul21_acc(d2, E1[7], A[0]);
-    e_mul11(E1[0], E1[4], t1); e_mul11(E1[1], E1[3], t2); for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
-    e_mul21_acc(d2, E1[8], A[0]);
-    double EET[3][3][10];
-    for (int i = 0; i < 3; ++i)
+    double E1[9][4];                                  // E_ij as a polynomial of degree 1: [x y z 1]
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) E1[r][e] = N[e][r];
+
+    // ---- the 10 cubic constraints: rows built in registers, stored to the per-lane LDS matrix A[r][k] = E_WS(20 r + k)
+    {
+        double row[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) row[k] = 0.0;
+        double t1[10], t2[10], d2[10];
+        e_mul11(E1[1], E1[5], t1); e_mul11(E1[2], E1[4], t2);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
+        e_mul21_acc(d2, E1[6], row);
+        e_mul11(E1[2], E1[3], t1); e_mul11(E1[0], E1[5], t2);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
+        e_mul21_acc(d2, E1[7], row);
+        e_mul11(E1[0], E1[4], t1); e_mul11(E1[1], E1[3], t2);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
+        e_mul21_acc(d2, E1[8], row);
+#pragma unroll
+        for (int k = 0; k < 20; ++k) E_WS(k) = row[k];
+    }
+    double tr[10];
+    {
+        double acc[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double a0[10], a1[10], a2[10];
+            e_mul11(E1[3 * i], E1[3 * i], a0); e_mul11(E1[3 * i + 1], E1[3 * i + 1], a1); e_mul11(E1[3 * i + 2], E1[3 * i + 2], a2);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { const double eii = a0[k] + a1[k] + a2[k]; acc[k] = (i == 0) ? eii : acc[k] + eii; }
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) tr[k] = 0.5 * acc[k];          // 0.5 * ((EET00 + EET11) + EET22)
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double L[3][10];
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             double a0[10], a1[10], a2[10];
             e_mul11(E1[3 * i], E1[3 * j], a0); e_mul11(E1[3 * i + 1], E1[3 * j + 1], a1); e_mul11(E1[3 * i + 2], E1[3 * j + 2], a2);
-            for (int k = 0; k < 10; ++k) EET[i][j][k] = a0[k] + a1[k] + a2[k];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { L[j][k] = a0[k] + a1[k] + a2[k]; if (i == j) L[j][k] -= tr[k]; }
         }
-    double tr[10];
-    for (int k = 0; k < 10; ++k) tr[k] = 0.5 * (EET[0][0][k] + EET[1][1][k] + EET[2][2][k]);
-    for (int i = 0; i < 3; ++i) for (int k = 0; k < 10; ++k) EET[i][i][k] -= tr[k];
-    for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
-            double* row = A[1 + 3 * i + j];
-            e_mul21_acc(EET[i][0], E1[j], row); e_mul21_acc(EET[i][1], E1[3 + j], row); e_mul21_acc(EET[i][2], E1[6 + j], row);
+            double row[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) row[k] = 0.0;
+            e_mul21_acc(L[0], E1[j], row); e_mul21_acc(L[1], E1[3 + j], row); e_mul21_acc(L[2], E1[6 + j], row);
+#pragma unroll
+            for (int k = 0; k < 20; ++k) E_WS(20 * (1 + 3 * i + j) + k) = row[k];
         }
+    }
+
+    // ---- Gauss-Jordan on the first 10 columns, partial pivoting (dynamic row indices: LDS)
     for (int c = 0; c < 10; ++c) {
         int piv = c;
-        double best = fabs(A[c][c]);
-        for (int r = c + 1; r < 10; ++r) { const double v = fabs(A[r][c]); if (v > best) { best = v; piv = r; } }
+        double best = fabs(E_WS(20 * c + c));
+        for (int r = c + 1; r < 10; ++r) { const double v = fabs(E_WS(20 * r + c)); if (v > best) { best = v; piv = r; } }
         if (best == 0.0) return 0;
-        if (piv != c) for (int k = 0; k < 20; ++k) { const double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
-        const double inv = 1.0 / A[c][c];
-        for (int k = c; k < 20; ++k) A[c][k] *= inv;
+        if (piv != c) for (int k = 0; k < 20; ++k) { const double t = E_WS(20 * c + k); E_WS(20 * c + k) = E_WS(20 * piv + k); E_WS(20 * piv + k) = t; }
+        const double inv = 1.0 / E_WS(20 * c + c);
+        for (int k = c; k < 20; ++k) E_WS(20 * c + k) *= inv;
         for (int r = 0; r < 10; ++r) {
             if (r == c) continue;
-            const double fct = A[r][c];
+            const double fct = E_WS(20 * r + c);
             if (fct == 0.0) continue;
-            for (int k = c; k < 20; ++k) A[r][k] -= fct * A[c][k];
+            for (int k = c; k < 20; ++k) E_WS(20 * r + k) -= fct * E_WS(20 * c + k);
         }
     }
     double B[3][3][5];
+#pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const double* lo = A[4 + 2 * q];
-        const double* hi = A[5 + 2 * q];
+        const int lo = 20 * (4 + 2 * q), hi = 20 * (5 + 2 * q);
+#pragma unroll
         for (int v = 0; v < 2; ++v) {
             const int o = 10 + 3 * v;
-            B[q][v][0] = lo[o + 2];
-            B[q][v][1] = lo[o + 1] - hi[o + 2];
-            B[q][v][2] = lo[o] - hi[o + 1];
-            B[q][v][3] = -hi[o];
+            B[q][v][0] = E_WS(lo + o + 2);
+            B[q][v][1] = E_WS(lo + o + 1) - E_WS(hi + o + 2);
+            B[q][v][2] = E_WS(lo + o) - E_WS(hi + o + 1);
+            B[q][v][3] = -E_WS(hi + o);
             B[q][v][4] = 0.0;
         }
-        B[q][2][0] = lo[19];
-        B[q][2][1] = lo[18] - hi[19];
-        B[q][2][2] = lo[17] - hi[18];
-        B[q][2][3] = lo[16] - hi[17];
-        B[q][2][4] = -hi[16];
+        B[q][2][0] = E_WS(lo + 19);
+        B[q][2][1] = E_WS(lo + 18) - E_WS(hi + 19);
+        B[q][2][2] = E_WS(lo + 17) - E_WS(hi + 18);
+        B[q][2][3] = E_WS(lo + 16) - E_WS(hi + 17);
+        B[q][2][4] = -E_WS(hi + 16);
     }
     double P[11];
+#pragma unroll
     for (int k = 0; k <= 10; ++k) P[k] = 0.0;
+#pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int r1 = (q + 1) % 3, r2 = (q + 2) % 3;
+        double a30[4], a31[4], b30[4], b31[4], c4[5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a30[k] = B[r1][0][k]; a31[k] = B[r1][1][k]; b30[k] = B[r2][0][k]; b31[k] = B[r2][1][k]; }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) c4[k] = B[q][2][k];
         double m1[7], m2[7], mn[7], term[11];
-        e_pmul(B[r1][0], 3, B[r2][1], 3, m1);
-        e_pmul(B[r1][1], 3, B[r2][0], 3, m2);
+        e_pmul<3, 3>(a30, b31, m1);
+        e_pmul<3, 3>(a31, b30, m2);
+#pragma unroll
         for (int k = 0; k <= 6; ++k) mn[k] = m1[k] - m2[k];
-        e_pmul(mn, 6, B[q][2], 4, term);
+        e_pmul<6, 4>(mn, c4, term);
+#pragma unroll
         for (int k = 0; k <= 10; ++k) P[k] += term[k];
     }
-    double roots[10];
-    const int nr = real_roots10(P, 10, roots);
+    const int nr = real_roots10(P, ws);               // overwrites the matrix area (no longer needed)
     int n_out = 0;
     for (int s = 0; s < nr; ++s) {
-        const double z = roots[s];
+        const double z = E_WS(kEwsRoots + s);
         double b[3][3];
-        for (int q = 0; q < 3; ++q) { b[q][0] = e_peval(B[q][0], 3, z); b[q][1] = e_peval(B[q][1], 3, z); b[q][2] = e_peval(B[q][2], 4, z); }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double p0[4], p1[4], p2[5];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { p0[k] = B[q][0][k]; p1[k] = B[q][1][k]; }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) p2[k] = B[q][2][k];
+            b[q][0] = e_peval<3>(p0, z); b[q][1] = e_peval<3>(p1, z); b[q][2] = e_peval<4>(p2, z);
+        }
         double bx = 0.0, by = 0.0, bw = 0.0;
+#pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int r1 = q, r2 = (q + 1) % 3;
             const double cx = b[r1][1] * b[r2][2] - b[r1][2] * b[r2][1];
@@ -469,11 +595,13 @@ __device__ __noinline__ int five_point(const double (&px1)[7][2], const double (
         }
         if (bw == 0.0) continue;
         const double x = bx / bw, y = by / bw;
+#pragma unroll
         for (int r = 0; r < 9; ++r) Es[9 * n_out + r] = x * N[0][r] + y * N[1][r] + z * N[2][r] + N[3][r];
         ++n_out;
     }
     return n_out;
 }
+#undef E_WS
 
 // fundamental::kernel::EpipolarDistanceError: squared distance of x2 to the epipolar line F x1
 __device__ __forceinline__ double epipolar_dist_err(const double* F, double x1, double y1, double x2, double y2)
@@ -524,7 +652,9 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 {
     // [FState, padded to 1024][Fs: 64 x (9 x MAX_MODELS) doubles][keys: m_cap x u64][idx: m_cap x u32]
     const size_t ms = model_kind == 2 ? 90 : 27;
-    return 1024 + (size_t)kChunk * ms * 8 + (size_t)m_cap * 12;
+    size_t sort_bytes = (size_t)m_cap * 12;
+    if (model_kind == 2 && sort_bytes < (size_t)kEwsDoubles * 64 * 8) sort_bytes = (size_t)kEwsDoubles * 64 * 8;   // 5-point workspace
+    return 1024 + (size_t)kChunk * ms * 8 + sort_bytes;
 }
 
 // KIND 0: fundamental matrix (7-point, <= 3 models, symmetric epipolar error, point-to-line NFA scale)
@@ -644,11 +774,16 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     px2[k][1] = (K2i[3] * xb + K2i[4] * yb + K2i[5]) / w2;
                 }
             }
-            double F3[MS];
+            double F3[(KIND == 2) ? 1 : MS];
             int nm;
             if constexpr (KIND == 0) nm = seven_point(px1, px2, F3);
             else if constexpr (KIND == 1) nm = four_point_h(px1, px2, F3);
-            else nm = five_point(px1, px2, F3);
+            else {
+                // the solver writes its models straight into this lane's LDS slots; its 200-double workspace is the
+                // region behind the hypothesis buffer (the sort buffers of the evaluation phase, idle during the solves)
+                double* ws = reinterpret_cast<double*>(smem + 1024 + kChunk * MS * 8) + tid;
+                nm = five_point(px1, px2, Fs + tid * MS, ws);
+            }
             S.nm[tid] = (uint32_t)nm;
             S.dbg_smp[tid] = pool[pos[0]];
             if (P.trace && item == P.trace_item && iter0 + tid == P.trace_iter) {
@@ -658,7 +793,8 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k];
             }
             if (tid == 0) S.dbg_pool = pool_size;
-            for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0;
+            if constexpr (KIND == 2) { for (int e = 9 * nm; e < MS; ++e) Fs[tid * MS + e] = 0.0; }
+            else { for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0; }
         }
         wg_sync();
 
