@@ -74,7 +74,13 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     R3DM_HIP(c, c->f_offs.ensure(sizeof(uint64_t) * 2 * NI));
     R3DM_HIP(c, c->f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
     R3DM_HIP(c, c->f_inl_cnt.ensure(4 * (size_t)NI));
-    R3DM_HIP(c, c->f_inl_idx.ensure(4 * (size_t)n_match_total + 64));
+    // slice offsets of the per-item work arrays: multiples of 32 elements, room for m + 1 (kernels_filter.hip explains why)
+    std::vector<uint64_t> soff(NI + 1, 0);
+    for (uint32_t k = 0; k < NI; ++k) soff[k + 1] = soff[k] + ((begin_end[2 * k + 1] - begin_end[2 * k] + 1 + 31) / 32) * 32;
+    const uint64_t n_slice = soff[NI];
+    R3DM_HIP(c, c->f_inl_idx.ensure(4 * (size_t)n_slice + 64));
+    R3DM_HIP(c, c->f_soff.ensure(8 * (size_t)(NI + 1)));
+    R3DM_HIP(c, hipMemcpyAsync(c->f_soff.p, soff.data(), 8 * (size_t)(NI + 1), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, c->f_F.ensure(72 * (size_t)NI));
     R3DM_HIP(c, c->f_thr.ensure(16 * (size_t)NI));
     R3DM_HIP(c, c->f_iters.ensure(8 * (size_t)NI));
@@ -124,10 +130,11 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     fp.log10_tab = c->f_log10.as<float>(); fp.logc_k = c->f_logck.as<float>();
     fp.inl_count = c->f_inl_cnt.as<uint32_t>(); fp.inl_idx = c->f_inl_idx.as<uint32_t>();
     fp.F_out = c->f_F.as<double>(); fp.thr_nfa = c->f_thr.as<double>(); fp.iters = c->f_iters.as<uint32_t>();
-    R3DM_HIP(c, c->f_scratch.ensure(32 * (size_t)n_match_total + 4 * (size_t)n_match_total + 4 * ((size_t)n_match_total + NI + 1) + 256));
+    R3DM_HIP(c, c->f_scratch.ensure(40 * (size_t)n_slice + 256));
     fp.pts_scratch = c->f_scratch.as<double>();
-    fp.pool_scratch = reinterpret_cast<uint32_t*>(c->f_scratch.as<unsigned char>() + 32 * (size_t)n_match_total);
-    fp.scratch_logc = reinterpret_cast<float*>(c->f_scratch.as<unsigned char>() + 36 * (size_t)n_match_total);
+    fp.pool_scratch = reinterpret_cast<uint32_t*>(c->f_scratch.as<unsigned char>() + 32 * (size_t)n_slice);
+    fp.scratch_logc = reinterpret_cast<float*>(c->f_scratch.as<unsigned char>() + 36 * (size_t)n_slice);
+    fp.soff = c->f_soff.as<uint64_t>();
     if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { c->err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
     // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
     DevBuf trace_buf;
@@ -148,15 +155,31 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
             fp.trace_rows = trace_buf.as<uint32_t>();
         }
     }
+    DevBuf dbg_buf;
+    fp.dbg = nullptr;
+    if (getenv("R3DM_FILTER_CHECK")) {
+        R3DM_HIP(c, dbg_buf.ensure(64));
+        R3DM_HIP(c, hipMemsetAsync(dbg_buf.p, 0, 64, c->stream));
+        fp.dbg = dbg_buf.as<uint32_t>();
+    }
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     R3DM_HIP(c, launch_filter_F(c->stream, fp));
+    if (fp.dbg) {
+        uint32_t d[4] = {0, 0, 0, 0};
+        R3DM_HIP(c, hipMemcpy(d, fp.dbg, 16, hipMemcpyDeviceToHost));
+        dbg_buf.release();
+        if (d[0]) {
+            c->err = "filter invariant " + std::to_string(d[0]) + " violated at item " + std::to_string(d[1]) + " (" + std::to_string(d[2]) + ", " + std::to_string(d[3]) + ")";
+            return R3DM_ERR_HIP;
+        }
+    }
     R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
 
     std::vector<uint32_t> h_cnt(NI);
-    std::vector<uint32_t> h_idx(n_match_total);
+    std::vector<uint32_t> h_idx(n_slice);
     std::vector<double> h_F(9 * (size_t)NI);
     R3DM_HIP(c, hipMemcpyAsync(h_cnt.data(), c->f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(h_idx.data(), c->f_inl_idx.p, 4 * (size_t)n_match_total, hipMemcpyDeviceToHost, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(h_idx.data(), c->f_inl_idx.p, 4 * (size_t)n_slice, hipMemcpyDeviceToHost, c->stream));
     R3DM_HIP(c, hipMemcpyAsync(h_F.data(), c->f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
@@ -202,7 +225,7 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         if (model_kind == 2 && (h_cnt[k] < min_count ||
                                 (float)h_cnt[k] / (float)(putative->offsets[p + 1] - base) < min_ratio)) continue;
         g->pairs.push_back(putative->pairs[2 * p]); g->pairs.push_back(putative->pairs[2 * p + 1]);
-        for (uint32_t q = 0; q < h_cnt[k]; ++q) g->matches.push_back(putative->matches[base + h_idx[base + q]]);
+        for (uint32_t q = 0; q < h_cnt[k]; ++q) g->matches.push_back(putative->matches[base + h_idx[soff[k] + q]]);
         g->offsets.push_back(g->matches.size());
         if (F_out) memcpy(F_out + 9 * kept, h_F.data() + 9 * (size_t)k, 72);
         ++kept;

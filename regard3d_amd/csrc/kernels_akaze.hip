@@ -131,7 +131,7 @@ void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
+    r3dm_syncthreads();
     if (threadIdx.x == 0) {
         for (int q = 1; q < 4; ++q) m = part[q] > m ? part[q] : m;
         if (m > 0.0f) atomicMax(out_max, __float_as_uint(m));          // m >= 0: bit order = value order
@@ -142,7 +142,7 @@ void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__
 {
     __shared__ uint32_t lh[512];
     for (int k = threadIdx.x; k < nbins; k += 256) lh[k] = 0;
-    __syncthreads();
+    r3dm_syncthreads();
     const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
     for (int yy = 0; yy < 16; ++yy) {
         const int y = 1 + (blockIdx.y * 16 + yy) * 4 + (threadIdx.x >> 6);
@@ -152,7 +152,7 @@ void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__
             atomicAdd(&lh[(int)(m * sc)], 1u);
         }
     }
-    __syncthreads();
+    r3dm_syncthreads();
     for (int k = threadIdx.x; k < nbins; k += 256) if (lh[k]) atomicAdd(hist + k, lh[k]);
 }
 
@@ -241,7 +241,7 @@ void ak_extrema_kernel(const AkLevelDev L, float thr, int pass /* 0 = count, 1 =
         const bool is = (x < L.w - L.border) && ak_is_extremum(L.Ldet, L.w, x, y, thr);
         const unsigned long long bal = __ballot(is);
         if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-        __syncthreads();
+        r3dm_syncthreads();
         uint32_t woff = 0, tot = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const uint32_t cw = wave_cnt[q]; if (q < wave) woff += cw; tot += cw; }
@@ -250,7 +250,7 @@ void ak_extrema_kernel(const AkLevelDev L, float thr, int pass /* 0 = count, 1 =
             L.cand[o] = make_float4((float)(x * L.ratio), (float)(y * L.ratio), L.Ldet[(size_t)y * L.w + x], 0.0f);
         }
         total += tot;
-        __syncthreads();
+        r3dm_syncthreads();
     }
     if (!pass && threadIdx.x == 0) L.row_cnt[blockIdx.x] = total;
 }
@@ -266,9 +266,9 @@ void ak_scan_rows_kernel(const AkLevelDev* __restrict__ levels)
     uint32_t s = 0;
     for (int k = b; k < e; ++k) s += L.row_cnt[k];
     part[threadIdx.x] = s;
-    __syncthreads();
+    r3dm_syncthreads();
     if (threadIdx.x == 0) { uint32_t run = 0; for (int t = 0; t < 1024; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; } L.counts[0] = run; }
-    __syncthreads();
+    r3dm_syncthreads();
     uint32_t run = part[threadIdx.x];
     for (int k = b; k < e; ++k) { L.row_off[k] = run; run += L.row_cnt[k]; }
 }
@@ -446,7 +446,7 @@ void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
         const float rx = wgt * L.Lx[p], ry = wgt * L.Ly[p];
         resX[k] = rx; resY[k] = ry; Ang[k] = ak_fast_atan2(ry, rx);
     }
-    __syncthreads();
+    r3dm_syncthreads();
     if (lane != 0) return;
     constexpr int slices = 42, win = 7;
     const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
@@ -520,7 +520,7 @@ void ak_mldb_kernel(const AkLevelDev* __restrict__ levels, const AkMldbItem* __r
         vals[half][base + 3 * c + 1] = b ^ (b < 0 ? 0x7fffffff : 0);
         vals[half][base + 3 * c + 2] = d ^ (d < 0 ? 0x7fffffff : 0);
     }
-    __syncthreads();
+    r3dm_syncthreads();
     if (!live) return;
     for (uint32_t byte = lane; byte < 61; byte += 32) {
         uint32_t v = 0;

@@ -166,9 +166,9 @@ void ann_scan_kernel(const AnnBuildParams P)
     uint32_t s = 0;
     for (uint32_t k = b; k < e; ++k) s += job.rev_cnt[k];
     part[threadIdx.x] = s;
-    __syncthreads();
+    r3dm_syncthreads();
     if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t t = 0; t < 1024; ++t) { const uint32_t v = part[t]; part[t] = run; run += v; } }
-    __syncthreads();
+    r3dm_syncthreads();
     uint32_t run = part[threadIdx.x];
     for (uint32_t k = b; k < e; ++k) { job.rev_off[k] = run; run += job.rev_cnt[k]; }
     if (threadIdx.x == 1023) job.rev_off[n] = run;

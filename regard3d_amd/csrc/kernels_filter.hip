@@ -21,6 +21,7 @@
 // rounding of the transcendental calls (acos/cos/cbrt/log10) only.
 
 #include "r3dm_internal.hpp"
+#include <cstdlib>
 
 namespace r3dm {
 
@@ -663,11 +664,30 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 //         no normalisation of the points: ACKernelAdaptorEssential)
 // KeyT / IdxT: the (residual, index) sort buffers live in LDS, or -- for the rare pair with more putative matches than
 // the LDS budget holds (near-duplicate views with > 8192 matches) -- in a slice of global scratch.
-// workgroup barrier that also orders this workgroup's global-memory traffic (pool / inlier lists / spilled sort
-// buffers live in global memory; HIP's __syncthreads only fences LDS)
-__device__ __forceinline__ void wg_sync() { __threadfence_block(); __syncthreads(); }
+// debug aid (R3DM_FILTER_CHECK=1): record the first violated invariant instead of running into a memory fault
+#define FCHECK(cond, code, a, b)                                                                          \
+    do {                                                                                                  \
+        if (P.dbg && !(cond)) {                                                                           \
+            if (atomicCAS(P.dbg, 0u, (uint32_t)(code)) == 0u) { P.dbg[1] = item; P.dbg[2] = (uint32_t)(a); P.dbg[3] = (uint32_t)(b); } \
+        }                                                                                                 \
+    } while (0)
 
-template <int KIND, class KeyT, class IdxT>
+// Workgroup barriers.  Waves of the workgroup exchange data through LDS almost everywhere (r3dm_syncthreads: barrier with an
+// explicit lgkmcnt(0), see r3dm_internal.hpp -- the missing wait at the top of the chunk loop below is what made the
+// homography kernel, the only one light enough for two workgroups per CU, return different results from run to run and
+// eventually fault).  Through GLOBAL memory they exchange data in three places: the normalised points / pool / log-combinatorial
+// table written at start-up, the pool rebuilt after an improvement, and -- spill variant only -- the sort buffers.  A
+// workgroup-scope fence compiles to no vmcnt wait on gfx950 (LLVM's memory model relies on same-CU ordering through the L1),
+// so those places use an agent-scope fence (vmcnt(0), L2 write-back, L1 invalidate) before the barrier: they are rare.
+__device__ __forceinline__ void wg_sync_global() { __threadfence(); __syncthreads(); }
+template <bool GLOBAL_BUFFERS>
+__device__ __forceinline__ void wg_sync_t()
+{
+    if (GLOBAL_BUFFERS) { __threadfence(); __syncthreads(); }
+    else r3dm_syncthreads();
+}
+
+template <int KIND, bool SPILL, class KeyT, class IdxT>
 __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __restrict__ pts, uint32_t* __restrict__ pool_g,
                                               float* __restrict__ logc_g, unsigned char* smem, KeyT keys, IdxT sidx, uint32_t item)
 {
@@ -686,10 +706,14 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     const ImgDev* __restrict__ Ip = P.imgs + sl.x;
     const ImgDev* __restrict__ Jp = P.imgs + sl.y;
     const r3dm_match* __restrict__ mm = P.matches + begin;
-    double* __restrict__ pt = pts + 4 * begin;
-    uint32_t* __restrict__ pool = pool_g + begin;
-    uint32_t* __restrict__ inl = P.inl_idx + begin;
-    float* __restrict__ logc_n = logc_g + begin + item;       // m + 1 entries
+    // per-item slices of the global work arrays start at multiples of 32 elements (>= one 128-byte line for the narrowest
+    // array): workgroups that share a CU -- and with it the vector L1 -- never share a cache line of data one of them is
+    // still writing
+    const uint64_t so = P.soff[item];
+    double* __restrict__ pt = pts + 4 * so;
+    uint32_t* __restrict__ pool = pool_g + so;
+    uint32_t* __restrict__ inl = P.inl_idx + so;
+    float* __restrict__ logc_n = logc_g + so;                 // m + 1 entries
 
     // ---- ACKernelAdaptor: normalisation N = [[s,0,-s w/2],[0,s,-s h/2],[0,0,1]], s = 1/sqrt(w h)
     const int wI = (int)Ip->width, hI = (int)Ip->height, wJ = (int)Jp->width, hJ = (int)Jp->height;
@@ -733,10 +757,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         S.pool_size = m; S.n_inl = 0; S.acMode = !(P.precision_px < __builtin_huge_val());
         S.n_models = 0; S.iters_done = 0;
     }
-        wg_sync();
+    wg_sync_global();          // points, pool and logcombi table go through global memory
 
     while (true) {
-        wg_sync();
+        wg_sync_t<SPILL>();
         const uint32_t iter0 = S.iter, nIter0 = S.nIter;
         if (iter0 >= nIter0) break;
         const uint32_t chunk_n = (nIter0 - iter0 < (uint32_t)kChunk) ? nIter0 - iter0 : (uint32_t)kChunk;
@@ -761,7 +785,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
             double px1[7][2], px2[7][2];
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
-                const uint32_t sidx_ = pool[pos[k < (int)SS ? k : 0]];
+                uint32_t sidx_ = pool[pos[k < (int)SS ? k : 0]];
+                FCHECK(pos[k < (int)SS ? k : 0] < pool_size, 1, pos[k < (int)SS ? k : 0], pool_size);
+                FCHECK(sidx_ < m, 2, sidx_, m);
+                if (P.dbg && sidx_ >= m) sidx_ = 0;
                 px1[k][0] = pt[4 * (size_t)sidx_ + 0]; px1[k][1] = pt[4 * (size_t)sidx_ + 1];
                 px2[k][0] = pt[4 * (size_t)sidx_ + 2]; px2[k][1] = pt[4 * (size_t)sidx_ + 3];
                 if (KIND == 2) {                 // camera coordinates: hnormalized(K^-1 (x, y, 1))
@@ -796,7 +823,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
             if constexpr (KIND == 2) { for (int e = 9 * nm; e < MS; ++e) Fs[tid * MS + e] = 0.0; }
             else { for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0; }
         }
-        wg_sync();
+        wg_sync_t<SPILL>();
 
         // ---- evaluate the chunk's iterations in order
         bool pool_changed = false;
@@ -825,13 +852,14 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     const unsigned long long bal = __ballot(in);
                     const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
                     if (lane == 0) S.wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-                    wg_sync();
+                    wg_sync_t<SPILL>();
                     uint32_t woff = 0, tot = 0;
 #pragma unroll
                     for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
+                    FCHECK(total + tot <= m, 3, total + tot, m);
                     if (in) { keys[total + woff + before] = (unsigned long long)__double_as_longlong(r); sidx[total + woff + before] = p; }
                     total += tot;
-                    wg_sync();
+                    wg_sync_t<SPILL>();
                 }
                 // AC mode switches on with the first model that has > 2.5*7 points within the bound
                 bool ac = S.acMode != 0;
@@ -842,7 +870,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     // sort (residual, index) ascending: residuals are >= 0 so the u64 bit pattern orders them
                     uint32_t cap = 1; while (cap < total) cap <<= 1;
                     for (uint32_t q = total + tid; q < cap; q += 256) { keys[q] = ~0ull; sidx[q] = 0xFFFFFFFFu; }
-                    wg_sync();
+                    wg_sync_t<SPILL>();
                     for (uint32_t size = 2; size <= cap; size <<= 1) {
                         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                             for (uint32_t tI = tid; tI < (cap >> 1); tI += 256) {
@@ -854,7 +882,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                                 const bool gt = (x > y) || (x == y && xi > yi);
                                 if (gt == up) { keys[lo] = y; keys[hi] = x; sidx[lo] = yi; sidx[hi] = xi; }
                             }
-                            wg_sync();
+                            wg_sync_t<SPILL>();
                         }
                     }
                     // bestNFA: k = 8 .. total, first minimum wins
@@ -873,7 +901,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                         if (ov < bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
                     }
                     if (lane == 0) { S.red_v[wave] = bv; S.red_k[wave] = bk; }
-                    wg_sync();
+                    wg_sync_t<SPILL>();
 #pragma unroll
                     for (uint32_t w = 0; w < 4; ++w) {
                         const double ov = S.red_v[w]; const uint32_t ok = S.red_k[w];
@@ -884,11 +912,12 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 // commit (every lane evaluates the same condition on the same shared values)
                 const double minNFA = S.minNFA;
                 const bool improve = ac && (nfa < minNFA);
+                FCHECK(!improve || (kbest <= total && kbest > SS), 4, kbest, total);
                 if (improve) {
                     for (uint32_t q = tid; q < kbest; q += 256) inl[q] = sidx[q];
                     better = true;
                 }
-                wg_sync();
+                wg_sync_t<SPILL>();
                 if (tid == 0) {
                     if (P.trace && item == P.trace_item) {
                         const uint32_t row = *P.trace_rows;
@@ -908,7 +937,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                         for (int e = 0; e < 9; ++e) S.bestF[e] = F[e];
                     }
                 }
-                wg_sync();
+                wg_sync_t<SPILL>();
             }
             // ---- end of iteration `it`: ACRANSAC's pool / budget update
             if (tid == 0) {
@@ -924,7 +953,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     }
                 }
             }
-            wg_sync();
+            wg_sync_t<SPILL>();
             if (S.flag) {
                 // new sampling pool = the inlier SET in ascending index order.  (The residual order of the
                 // inlier list is rounding noise among the 7 points the model was fitted to, so pool
@@ -932,9 +961,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 const uint32_t ni = S.n_inl;
                 IdxT flags = sidx;                                       // sort scratch, free between models
                 for (uint32_t q = tid; q < m; q += 256) flags[q] = 0u;
-                wg_sync();
-                for (uint32_t q = tid; q < ni; q += 256) flags[inl[q]] = 1u;
-                wg_sync();
+                wg_sync_t<SPILL>();
+                FCHECK(ni <= m, 5, ni, m);
+                for (uint32_t q = tid; q < ni; q += 256) { const uint32_t iq = inl[q]; FCHECK(iq < m, 6, iq, q); if (!P.dbg || iq < m) flags[iq] = 1u; }
+                wg_sync_t<SPILL>();
                 uint32_t filled = 0;
                 for (uint32_t base = 0; base < m; base += 256) {
                     const uint32_t p = base + tid;
@@ -942,17 +972,19 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     const unsigned long long bal = __ballot(in);
                     const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
                     if (lane == 0) S.wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-                    wg_sync();
+                    wg_sync_t<SPILL>();
                     uint32_t woff = 0, tot = 0;
 #pragma unroll
                     for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
                     if (in) pool[filled + woff + before] = p;
                     filled += tot;
-                    wg_sync();
+                    wg_sync_t<SPILL>();
                 }
+                FCHECK(filled == ni, 7, filled, ni);
                 pool_changed = true;
+                __threadfence();       // the rebuilt pool (global memory) is read by the sampling lanes of the next chunk
             }
-                        wg_sync();
+            wg_sync_t<SPILL>();
             // the chunk was cut from the old budget: stop when the (possibly shrunk) budget is exhausted
             if (it + 1 >= S.nIter) { ++c; break; }
         }
@@ -960,7 +992,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
             }
 
     // ---- result
-    wg_sync();
+    wg_sync_t<SPILL>();
     if (tid == 0) {
         uint32_t n_inl = S.n_inl;
         if (!(S.minNFA < 0.0)) n_inl = 0;
@@ -1008,12 +1040,12 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
     if (m <= P.m_cap) {
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * MS * 8);
         uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
-        acransac_body<KIND>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
+        acransac_body<KIND, false>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
     } else {
         // slice of the global spill buffer, sized for the next power of two of m (host: spill_off[item])
         unsigned long long* keys = P.spill_keys + P.spill_off[item];
         uint32_t* sidx = P.spill_idx + P.spill_off[item];
-        acransac_body<KIND>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
+        acransac_body<KIND, true>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
     }
 }
 

@@ -99,14 +99,14 @@ void liop_kernel(const LiopParams P)
         const float* src = P.patches + (size_t)item * kLiopPix;
         for (uint32_t e = lane; e < (uint32_t)kLiopPix; e += 64) patch[e] = src[e];
         for (uint32_t e = lane; e < 144; e += 64) hist[e] = 0;
-        __syncthreads();
+        r3dm_syncthreads();
 
         // ---- 1. rank the support pixels by intensity
         for (uint32_t i = lane; i < (uint32_t)kLiopSortCap; i += 64) {
             if (i < N) { const float v = patch[P.pix[i]]; inten[i] = v; keys[i] = ((unsigned long long)float_order_bits(v) << 32) | i; }
             else keys[i] = ~0ull;
         }
-        __syncthreads();
+        r3dm_syncthreads();
         for (uint32_t size = 2; size <= (uint32_t)kLiopSortCap; size <<= 1)
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                 for (uint32_t t = lane; t < (uint32_t)kLiopSortCap / 2; t += 64) {
@@ -115,7 +115,7 @@ void liop_kernel(const LiopParams P)
                     const unsigned long long x = keys[lo], y = keys[hi];
                     if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
                 }
-                __syncthreads();
+                r3dm_syncthreads();
             }
         bool tie = false;
         for (uint32_t i = lane; i < N; i += 64) {
@@ -123,12 +123,12 @@ void liop_kernel(const LiopParams P)
             if (i + 1 < N) tie |= ((keys[i] >> 32) == (keys[i + 1] >> 32));
         }
         const bool any_tie = __ballot(tie) != 0ull;
-        __syncthreads();
+        r3dm_syncthreads();
         const float vmin = inten[perm[0]], vmax = inten[perm[N - 1]];
         if (vmin == vmax) {
             // constant support: every weight is 0, the descriptor is 0 / max(0, 1e-12) = 0
             for (uint32_t e = lane; e < 144; e += 64) P.desc[(size_t)item * 144 + e] = 0.0f;
-            __syncthreads();
+            r3dm_syncthreads();
             continue;
         }
         if (any_tie) {
@@ -137,7 +137,7 @@ void liop_kernel(const LiopParams P)
                 liop_ref_qsort(inten, perm, (int)N, qstack);
                 atomicAdd(P.n_tie_patches, 1u);
             }
-            __syncthreads();
+            r3dm_syncthreads();
         }
         // threshold = -intensityThreshold * (max - min), all float (vl_liop.c:497-503)
         const float thr = (float)(5.0 / 255) * (inten[perm[N - 1]] - inten[perm[0]]);
@@ -193,7 +193,7 @@ void liop_kernel(const LiopParams P)
                 for (int b = a + 1; b < 4; ++b) weight += (nv[a] > nv[b] + thr || nv[b] > nv[a] + thr) ? 1u : 0u;
             if (weight) atomicAdd(&hist[bin * 24u + (uint32_t)index], weight);
         }
-        __syncthreads();
+        r3dm_syncthreads();
 
         // ---- 3. normalisation: float running sum in index order, norm stored to float (vl_liop.c:567-575)
         if (lane == 0) {
@@ -202,10 +202,10 @@ void liop_kernel(const LiopParams P)
             const double r = sqrt((double)norm);
             s_norm = (float)(r > 1e-12 ? r : 1e-12);
         }
-        __syncthreads();
+        r3dm_syncthreads();
         const float nrm = s_norm;
         for (uint32_t e = lane; e < 144; e += 64) P.desc[(size_t)item * 144 + e] = (float)hist[e] / nrm;
-        __syncthreads();
+        r3dm_syncthreads();
     }
 }
 
@@ -252,7 +252,7 @@ void liop_extract_patches_kernel(const float* __restrict__ image, int w, int h, 
             const float v3 = (x1 && y1) ? image[(size_t)(sy + 1) * w + sx + 1] : 0.f;
             warped[e] = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
         }
-        __syncthreads();
+        r3dm_syncthreads();
         for (int e = threadIdx.x; e < kLiopPix; e += 256) {
             const int y = e / S, x = e % S;
             float s = kern[0] * warped[y * S + reflect101(x - 5, S)];
@@ -260,7 +260,7 @@ void liop_extract_patches_kernel(const float* __restrict__ image, int w, int h, 
             for (int k = 1; k < 11; ++k) s += kern[k] * warped[y * S + reflect101(x + k - 5, S)];
             rowp[e] = s;
         }
-        __syncthreads();
+        r3dm_syncthreads();
         float* out = patches + (size_t)item * kLiopPix;
         for (int e = threadIdx.x; e < kLiopPix; e += 256) {
             const int y = e / S, x = e % S;
@@ -269,7 +269,7 @@ void liop_extract_patches_kernel(const float* __restrict__ image, int w, int h, 
             for (int j = 1; j <= 5; ++j) s += kern[5 + j] * (rowp[reflect101(y + j, S) * S + x] + rowp[reflect101(y - j, S) * S + x]);
             out[e] = s;
         }
-        __syncthreads();
+        r3dm_syncthreads();
     }
 }
 

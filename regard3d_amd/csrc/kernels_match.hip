@@ -533,7 +533,7 @@ void l2_exact_items_kernel(const MatchParams P, uint32_t count, int scan_all)
             else if (d < d1) { d1 = d; i1 = r; }
         }
         sd0[threadIdx.x] = d0; sd1[threadIdx.x] = d1; si0[threadIdx.x] = i0; si1[threadIdx.x] = i1;
-        __syncthreads();
+        r3dm_syncthreads();
         for (uint32_t s = 128; s > 0; s >>= 1) {
             if (threadIdx.x < s) {
                 // merge two sorted pairs under the (distance, index) order
@@ -550,13 +550,13 @@ void l2_exact_items_kernel(const MatchParams P, uint32_t count, int scan_all)
                 }
                 sd0[threadIdx.x] = r0; sd1[threadIdx.x] = r1; si0[threadIdx.x] = j0; si1[threadIdx.x] = j1;
             }
-            __syncthreads();
+            r3dm_syncthreads();
         }
         if (threadIdx.x == 0) {
             if (nI < 2) emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
             else emit_result(P, pair, q, sd0[0], si0[0], sd1[0], si1[0]);
         }
-        __syncthreads();
+        r3dm_syncthreads();
     }
 }
 
@@ -600,13 +600,13 @@ void l2_exact_batch_kernel(const MatchParams P)
         for (int k = 0; k < D4; ++k) qv[k] = (k < (int)d4) ? qrow[k] : f32x4{0.f, 0.f, 0.f, 0.f};
         float d0 = R3DM_INF, d1 = R3DM_INF; uint32_t i0 = kNone, i1 = kNone;
         for (uint32_t t0 = 0; t0 < nI; t0 += 32) {
-            __syncthreads();
+            r3dm_syncthreads();
             const uint32_t rows_here = (nI - t0 < 32u) ? nI - t0 : 32u;
             for (uint32_t e = threadIdx.x; e < rows_here * d4; e += 256) {
                 const uint32_t r = e / d4, k = e % d4;
                 tile[r * D4 + k] = irows[(size_t)(t0 + r) * d4 + k];
             }
-            __syncthreads();
+            r3dm_syncthreads();
             for (uint32_t rr = 0; rr < 8; ++rr) {
                 const uint32_t r = wave * 8 + rr;
                 if (r >= rows_here) break;                         // wave-uniform
@@ -625,9 +625,9 @@ void l2_exact_batch_kernel(const MatchParams P)
             }
         }
         // merge the four waves' (best, runner-up) per lane under the (distance, row) order
-        __syncthreads();
+        r3dm_syncthreads();
         md0[threadIdx.x] = d0; md1[threadIdx.x] = d1; mi0[threadIdx.x] = i0; mi1[threadIdx.x] = i1;
-        __syncthreads();
+        r3dm_syncthreads();
         if (wave == 0 && active) {
             float a0 = md0[lane], a1 = md1[lane]; uint32_t x0 = mi0[lane], x1 = mi1[lane];
             for (uint32_t w = 1; w < 4; ++w) {
@@ -754,7 +754,7 @@ hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& Pin, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // body shared by the two storage classes of the sort buffer: `keys` / `drop` point into LDS (fast path) or into a
 // per-pair slice of global scratch (pairs that keep more matches than the LDS budget holds: views with > 16k features)
-template <class KeyT, class DropT>
+template <bool GLOBAL_BUFFERS, class KeyT, class DropT>
 __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys, DropT drop, unsigned long long* s_off_p,
                                               uint32_t* wave_cnt, uint32_t* s_total_p, uint32_t pair)
 {
@@ -773,21 +773,21 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
         const unsigned long long bal = __ballot(keep);
         const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-        __syncthreads();
+        r3dm_syncthreads();
         uint32_t woff = 0, tot = 0;
 #pragma unroll
         for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
         if (keep) keys[m + woff + before] = ((unsigned long long)v << 32) | q;
         m += tot;
-        __syncthreads();
+        r3dm_syncthreads();
     }
 
     if (m > 1) {
         // pad to a power of two and bitonic-sort ascending
         uint32_t cap = 1; while (cap < m) cap <<= 1;
         for (uint32_t k = m + threadIdx.x; k < cap; k += 256) keys[k] = ~0ull;
-        __threadfence_block();
-        __syncthreads();
+        if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
+        r3dm_syncthreads();
         for (uint32_t size = 2; size <= cap; size <<= 1) {
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                 for (uint32_t tId = threadIdx.x; tId < (cap >> 1); tId += 256) {
@@ -797,8 +797,8 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
                     const unsigned long long x = keys[lo], y = keys[hi];
                     if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
                 }
-                __threadfence_block();
-                __syncthreads();
+                if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
+                r3dm_syncthreads();
             }
         }
         // coordinate de-duplication: only possible when both views contain repeated positions
@@ -810,16 +810,16 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
                     d = (Ip->canon[(uint32_t)(keys[e] >> 32)] == ci) && (Jp->canon[(uint32_t)keys[e]] == cj);
                 drop[k] = d;
             }
-            __threadfence_block();
-            __syncthreads();
+            if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
+            r3dm_syncthreads();
             // stable in-place compaction by a single wave-serial pass (rare path)
             if (threadIdx.x == 0) {
                 uint32_t w = 0;
                 for (uint32_t k = 0; k < m; ++k) if (!drop[k]) keys[w++] = keys[k];
                 *s_total_p = w;
             }
-            __threadfence_block();
-            __syncthreads();
+            if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
+            r3dm_syncthreads();
             m = *s_total_p;
         }
     }
@@ -830,7 +830,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
         P.pair_off[pair] = off;
         P.pair_cnt[pair] = m;
     }
-    __syncthreads();
+    r3dm_syncthreads();
     const unsigned long long off = *s_off_p;
     if (off + m <= P.out_cap)
         for (uint32_t k = threadIdx.x; k < m; k += 256) {
@@ -853,7 +853,7 @@ void finalize_pairs_kernel(const FinalizeParams P)
     uint32_t* s_total_p = wave_cnt + 4;
     const uint32_t pair = blockIdx.x;
 
-    if (P.spill_keys == nullptr) { finalize_body(P, keys, drop, s_off_p, wave_cnt, s_total_p, pair); return; }
+    if (P.spill_keys == nullptr) { finalize_body<false>(P, keys, drop, s_off_p, wave_cnt, s_total_p, pair); return; }
 
     // views larger than the LDS budget: count what the pair keeps, spill only if it does not fit
     const uint32_t nJ = P.imgs[P.pairs[pair].y].n;
@@ -863,11 +863,11 @@ void finalize_pairs_kernel(const FinalizeParams P)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
     if ((threadIdx.x & 63u) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
+    r3dm_syncthreads();
     const uint32_t kept = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
-    if (kept <= P.sort_cap) finalize_body(P, keys, drop, s_off_p, wave_cnt, s_total_p, pair);
-    else finalize_body(P, P.spill_keys + (size_t)pair * P.spill_stride, P.spill_drop + (size_t)pair * P.spill_stride,
+    r3dm_syncthreads();
+    if (kept <= P.sort_cap) finalize_body<false>(P, keys, drop, s_off_p, wave_cnt, s_total_p, pair);
+    else finalize_body<true>(P, P.spill_keys + (size_t)pair * P.spill_stride, P.spill_drop + (size_t)pair * P.spill_stride,
                        s_off_p, wave_cnt, s_total_p, pair);
 }
 

@@ -121,6 +121,7 @@ struct FilterParams {
     const uint2*  pairs;          // slot indices, one per work item
     const uint2*  pair_ids;       // view ids (I, J): keys of the sample stream
     const uint64_t* offsets;      // per work item: [2k] = begin, [2k+1] = end of its putative list inside `matches`
+    const uint64_t* soff;         // per work item: start of its slice in the work arrays (multiples of 32 elements, m + 1 <= slice)
     const r3dm_match* matches;
     uint32_t      n_items;
     uint32_t      m_cap;          // LDS sort capacity (power of two); items with more putatives use the spill buffers
@@ -132,17 +133,18 @@ struct FilterParams {
     uint64_t      seed;
     int           err_kind;
     int           model_kind;     // 0 = fundamental matrix (7-point), 1 = homography (4-point), 2 = essential matrix (5-point)
+    uint32_t*     dbg;            // optional [4]: first violated invariant (code, item, a, b); R3DM_FILTER_CHECK=1
     const double* kinv;           // [slots][9] inverse intrinsics K^-1 of every view (essential matrix only)
     const float*  log10_tab;      // log10f(k), k = 0..max_m  (host-computed: same libm as the reference build)
     const float*  logc_k;         // logcombi(sample size, n), n = 0..max_m (host-computed)
     // outputs
     uint32_t*     inl_count;      // [n_items] inliers kept (0 if rejected)
-    uint32_t*     inl_idx;        // [sum m] inlier positions into the pair's putative list, AC-RANSAC order
+    uint32_t*     inl_idx;        // [slices] inlier positions into the pair's putative list, AC-RANSAC order (indexed by soff)
     double*       F_out;          // [n_items][9]
     double*       thr_nfa;        // [n_items][2]  threshold px, nfa
     uint32_t*     iters;          // [n_items][2]  iterations, models
     // scratch (global memory, sliced per item by its `begin` offset)
-    double*       pts_scratch;    // [n_matches][4] normalised (x1, y1, x2, y2)
+    double*       pts_scratch;    // [slices][4] normalised (x1, y1, x2, y2)
     uint32_t*     pool_scratch;   // [n_matches]    current sampling pool
     float*        scratch_logc;   // [n_matches + n_items + 1] logcombi(k, m) table of each item
     // debug trace (R3DM_TRACE_PAIR): rows of (iter, model, #<=bound, NFA, improved) for one item
@@ -150,6 +152,18 @@ struct FilterParams {
     uint32_t      trace_item, trace_cap, trace_iter;
     uint32_t*     trace_rows;
 };
+
+// Workgroup barrier for waves that exchange data through LDS, with an EXPLICIT `s_waitcnt lgkmcnt(0)`.  hipcc (ROCm 7.2) was
+// seen to emit a bare s_barrier -- dropping the wait that __syncthreads' release fence implies -- when the barrier opens a loop
+// header and the pending ds_write sits in the latch block (kernels_filter.hip, chunk loop: other waves then read a stale loop
+// counter).  The builtin cannot be optimised away and costs nothing when nothing is pending.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+__device__ __forceinline__ void r3dm_syncthreads()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // vmcnt = max, expcnt = max, lgkmcnt = 0
+    __syncthreads();
+}
+#endif
 
 // ---- Fast-A-KAZE detector (kernels_akaze.hip) ----
 struct AkTaps { int n; float k[31]; };                  // Gaussian taps (host: getGaussianKernel restated), n <= 31

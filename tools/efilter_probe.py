@@ -3,14 +3,16 @@ import sys, os, json, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from regard3d_amd import api, synth
-sc = synth.make_scene(60, 8192, "sift", seed=2002)
+sc = synth.make_scene(int(sys.argv[1]) if len(sys.argv) > 1 else 60, 8192, "sift", seed=2002)
 c = api.Context(0)
 for i in range(sc.n_images):
     c.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000); c.set_intrinsics(i, synth.intrinsics())
 g = c.match_pairs(sc.exhaustive_pairs(), 0.6, True)
 print("putative pairs", g.num_pairs)
+only = sys.argv[2] if len(sys.argv) > 2 else "FEH"
 for name, fn in (("F", lambda it: c.filter_F(g, 4.0, it)), ("E", lambda it: c.filter_E(g, 4.0, it)), ("H", lambda it: c.filter_H(g, 4.0, it))):
-    for it in (2048, 512, 128):
+    if name not in only: continue
+    for it in (128, 512, 2048):
         fn(it); ms = c.stats().ms_filter_kernels
         rep = [r for r in c.filter_report() if r[2]]
         iters = np.array([r[2] for r in rep]); models = np.array([r[3] for r in rep])
