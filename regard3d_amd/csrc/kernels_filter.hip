@@ -939,7 +939,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 }
                 wg_sync_t<SPILL>();
             }
-            // ---- end of iteration `it`: ACRANSAC's pool / budget update
+            // ---- end of iteration `it`: ACRANSAC's pool / budget update.  Thread 0 is about to change the loop bounds that
+            // the other waves read right after the previous iteration's last barrier; every evaluated model ends with a
+            // barrier, a sample without real solutions (nm == 0, common for the 5-point solver) needs its own.
+            if (nm == 0) wg_sync_t<SPILL>();
             if (tid == 0) {
                 S.iters_done = it + 1;
                 S.flag = 0;

@@ -33,8 +33,9 @@ for name in a.presets.split(","):
     for i in range(sc.n_images):          # drop cached indices so the build is timed
         c.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000)
     t = time.time(); g = c.match_pairs_kgraph(pairs, 0.6, kp); t1 = time.time() - t
-    s1 = c.stats()
+    s1 = c.stats(); first = (g.pairs.tobytes(), g.matches.tobytes())
     t = time.time(); g = c.match_pairs_kgraph(pairs, 0.6, kp); t2 = time.time() - t
+    assert first == (g.pairs.tobytes(), g.matches.tobytes()), "graph matcher is not deterministic"
     s2 = c.stats()
     d = g.as_dict()
     hit = sum(len(set(map(tuple, d[k].tolist())) & set(map(tuple, bd[k].tolist()))) for k in d if k in bd)
