@@ -278,7 +278,7 @@ void ak_scan_rows_kernel(const AkLevelDev* __restrict__ levels)
 // kept point = the first one in list order.  A slot's row never decreases, so only slots within one radius of the scan
 // line can still match: that live set is kept in LDS, in list order.  One wavefront per level.
 constexpr int kAkLive = 3072;
-template <class FP, class UP>
+template <bool GLOBAL_LIVE, class FP, class UP>
 __device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_cand, FP lx, FP ly, FP lr, UP lslot)
 {
     const int lane = threadIdx.x;
@@ -300,11 +300,11 @@ __device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_ca
                     if (i < n_live) { ex = lx[i]; ey = ly[i]; er = lr[i]; es = lslot[i]; const float dy = py - ey; keep = dy * dy <= size2; }
                     const unsigned long long bal = __ballot(keep);
                     const uint32_t o = w + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                    __threadfence_block();
+                    if (GLOBAL_LIVE) __threadfence();    // live set in global scratch: make the wave's own stores visible to its later loads
                     if (keep) { lx[o] = ex; ly[o] = ey; lr[o] = er; lslot[o] = es; }
                     w += (uint32_t)__builtin_popcountll(bal);
                 }
-                __threadfence_block();
+                if (GLOBAL_LIVE) __threadfence();
                 n_live = w;
             }
             // first live entry within the radius
@@ -324,7 +324,7 @@ __device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_ca
                 if (lane == 0) { lx[n_live] = px; ly[n_live] = py; lr[n_live] = pr; lslot[n_live] = n_list; L.list[n_list] = make_float4(px, py, pr, 1.0f); }
                 ++n_live; ++n_list;
             }
-            __threadfence_block();
+            if (GLOBAL_LIVE) __threadfence();
         }
     }
     if (lane == 0) L.counts[1] = n_list;
@@ -338,8 +338,8 @@ void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels)
     const AkLevelDev L = levels[blockIdx.x];
     const uint32_t n_cand = L.counts[0];
     // the live set never holds more entries than there are candidates: small levels stay in LDS, the rest use scratch
-    if (n_cand <= (uint32_t)kAkLive) ak_prune_body(L, n_cand, lx, ly, lr, lslot);
-    else ak_prune_body(L, n_cand, L.live, L.live + n_cand, L.live + 2 * (size_t)n_cand, (uint32_t*)(L.live + 3 * (size_t)n_cand));
+    if (n_cand <= (uint32_t)kAkLive) ak_prune_body<false>(L, n_cand, lx, ly, lr, lslot);
+    else ak_prune_body<true>(L, n_cand, L.live, L.live + n_cand, L.live + 2 * (size_t)n_cand, (uint32_t*)(L.live + 3 * (size_t)n_cand));
 }
 
 // ---- cross-level pruning.  mode 0 ("lower"): a point q of level i-1 dies when some point p of level i lies within
