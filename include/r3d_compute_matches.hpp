@@ -61,8 +61,8 @@ using PairWiseMatches = std::map<std::pair<uint32_t, uint32_t>, MatchList>;
 class R3DComputeMatches {
 public:
     // matchingAlgorithm value of the new dispatch arm next to src/R3DComputeMatches.cpp:2054-2062;
-    // 4 ("Brute Force", src/Regard3DMainFrameBase.cpp:1020) is served by the same GPU path; 1..3 (the KGraph presets,
-    // kgraph_match at :2051-2054) run the graph-based approximate matcher (r3dm_match_pairs_kgraph).
+    // 4 ("Brute Force", src/Regard3DMainFrameBase.cpp:1020) is served by the same GPU path; the approximate arms (0 FLANN,
+    // 1..3 KGraph, 5 MRPT, 6..8 HNSW) run the graph-based approximate matcher with a preset of at least the arm's recall.
     static constexpr int kMatchingAlgorithmGPU = 9;
 
     explicit R3DComputeMatches(int device_id = 0);

@@ -152,6 +152,10 @@ typedef struct {
 /* preset = matchingAlgorithm of the reference: 0 "KGraph fast", 1 "medium", 2 "precise", anything else its default
  * block (src/R3DComputeMatches.cpp:844-873) */
 int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out);
+/* parameters that serve an approximate arm of the reference's dispatch (matchingAlgorithm, src/R3DComputeMatches.cpp:2035-2062:
+ * 0 FLANN kd-trees, 1..3 KGraph, 5 MRPT, 6..8 HNSW) with a recall at least that of the arm; R3DM_ERR_INVALID for the exhaustive
+ * arms 4 / 9 and unknown values.  See the table in api_match.cpp and DESIGN.md section 4.7. */
+int r3dm_ann_params_for_algorithm(int matching_algorithm, r3dm_kgraph_params* out);
 int r3dm_match_pairs_kgraph(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
                             const r3dm_kgraph_params* params, r3dm_graph** out);
 /* ArrayMatcher_kgraph-shaped call: index `dataset`, 2 approximate nearest rows of every query row.  pair_i / pair_j

@@ -24,7 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library():
     L.r3dm_gray_from_bgr8.argtypes = [vp, vp, u32, u32, vp]
     L.r3dm_extract_features_to_files.argtypes = [vp, vp, u32, u32, C.c_float, C.c_char_p, C.c_char_p, C.POINTER(u32)]
     L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]
+    L.r3dm_ann_params_for_algorithm.argtypes = [C.c_int, vp]
     L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_kgraph_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, u32, u32, vp, vp]
     L.r3dm_kgraph_index.argtypes = [vp, u32, u32, vp, vp]

@@ -271,6 +271,26 @@ extern "C" int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out)
     return R3DM_OK;
 }
 
+// The approximate arms of the reference's dispatch (src/R3DComputeMatches.cpp:2035-2062) all trade recall for speed with a
+// different index each (FLANN kd-trees, KGraph, MRPT random-projection trees, HNSW); none of them is reproducible bit for bit
+// (random trees / seeds / thread schedules), so parity with any of them is recall.  They are all served by the one deterministic
+// graph matcher here, with the preset whose measured recall is at least that of the reference's arm:
+//   1..3  kgraph_match presets                        -> fast / medium / precise
+//   6..8  hnsw_match presets (:533-565)               -> fast / medium / precise  (reference-built HNSW on tests/golden/
+//                                                        ann_hnsw_ref.npz: 0.573 / 0.933 / 0.975 recall@1; here 0.851 / 0.947 / 0.980)
+//   5     mrpt_match (:453-460, targetRecall_ 0.8)     -> medium (0.947)
+//   0     Matcher_Regions(ANN_L2): FLANN kd-trees     -> precise
+// 4 and 9 are the exhaustive arms (r3dm_match_pairs) and are not ANN.
+extern "C" int r3dm_ann_params_for_algorithm(int matching_algorithm, r3dm_kgraph_params* out)
+{
+    switch (matching_algorithm) {
+        case 1: case 6: return r3dm_kgraph_preset(0, out);
+        case 2: case 7: case 5: return r3dm_kgraph_preset(1, out);
+        case 3: case 8: case 0: return r3dm_kgraph_preset(2, out);
+        default: return R3DM_ERR_INVALID;
+    }
+}
+
 static int check_kgraph_params(r3dm_ctx* c, const r3dm_kgraph_params* kp)
 {
     if (!kp) return R3DM_ERR_INVALID;

@@ -100,11 +100,13 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
 {
     statistics_ = R3DComputeMatchesStatistics();
     if (!ctx_) return false;
-    // dispatch of src/R3DComputeMatches.cpp:2035-2062: 1..3 = kgraph_match presets (fast / medium / precise), 4 = brute force;
-    // 9 = the new arm.  0 (FLANN kd-trees), 5 (MRPT) and 6..8 (HNSW) have no GPU counterpart: refuse rather than substitute.
-    const bool use_kgraph = matchingAlgorithm >= 1 && matchingAlgorithm <= 3;
+    // dispatch of src/R3DComputeMatches.cpp:2035-2062: 4 = brute force and 9 = the new arm run the exhaustive matcher; every
+    // approximate arm (0 FLANN kd-trees, 1..3 KGraph, 5 MRPT, 6..8 HNSW) runs the graph matcher with a preset of at least the
+    // arm's recall (r3dm_ann_params_for_algorithm); anything else is refused.
+    r3dm_kgraph_params kp;
+    const bool use_kgraph = r3dm_ann_params_for_algorithm(matchingAlgorithm, &kp) == R3DM_OK;
     if (matchingAlgorithm != kMatchingAlgorithmGPU && matchingAlgorithm != 4 && !use_kgraph) {
-        errorMessage_ = "matchingAlgorithm " + std::to_string(matchingAlgorithm) + " is not served by the GPU path (use 9, 4 or 1..3)";
+        errorMessage_ = "matchingAlgorithm " + std::to_string(matchingAlgorithm) + " is not served by the GPU path (0..9 are)";
         return false;
     }
     const std::string dir = paths.relativeMatchesPath_;
@@ -144,8 +146,6 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     const int squared = dtype_ == R3DM_BIN ? 0 : 1;        // RegionsMatcherT squared flag: true for L2 metrics
     int rc;
     if (use_kgraph) {
-        r3dm_kgraph_params kp;
-        r3dm_kgraph_preset(matchingAlgorithm - 1, &kp);          // kgraph_match(..., matchingAlgorithm-1) (:2053)
         rc = r3dm_match_pairs_kgraph(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, &kp, &putative);
     } else {
         rc = r3dm_match_pairs(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, squared, &putative);

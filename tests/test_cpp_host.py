@@ -118,6 +118,12 @@ def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
                                                         seed=1998, min_rows=128)
     p, c, m = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
     assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
+    # the HNSW / MRPT / FLANN arms are served by the same matcher with the preset of matching recall: 8 ("HNSW precise") == 3
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
-                       env=dict(os.environ, R3DM_TEST_ALGO="6"))
-    assert r.returncode == 7 and "not served" in r.stderr               # HNSW arm: refused, not substituted
+                       env=dict(os.environ, R3DM_TEST_ALGO="8"))
+    assert r.returncode == 0, r.stderr
+    p8, c8, m8 = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
+    assert np.array_equal(p8, p) and np.array_equal(c8, c) and np.array_equal(m8, m)
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
+                       env=dict(os.environ, R3DM_TEST_ALGO="11"))
+    assert r.returncode == 7 and "not served" in r.stderr               # unknown arm: refused
