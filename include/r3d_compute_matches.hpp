@@ -9,10 +9,9 @@
 // /root/reference/src/R3DProject.h:39-65).  wxWidgets / OpenMVG types are replaced by std types:
 // the SfM_Data the stage reads is reduced to the fields it actually uses -- view id, image size and
 // the basename of the .feat/.desc files (/root/reference/src/R3DComputeMatches.cpp:1763-1777).
-// Feature EXTRACTION is outside this round's scope: the facade
-// matches views whose <basename>.feat / <basename>.desc already exist in the matches directory,
-// which is also the reference's behaviour when both files exist
-// (/root/reference/src/threads/R3DFeaturesThread.cpp:139-142).
+// The facade matches views whose <basename>.feat / <basename>.desc exist in the matches directory, which is the
+// reference's behaviour when both files exist (/root/reference/src/threads/R3DFeaturesThread.cpp:139-142); they are
+// produced by the feature stage (include/regard3d_features.hpp, r3dm_extract_features_to_files).
 #pragma once
 
 #include <cstdint>

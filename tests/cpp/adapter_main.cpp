@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "r3d_compute_matches.hpp"
+#include "regard3d_features.hpp"
 #include "r3dm_array_matcher.hpp"
 
 static bool read_desc(const char* path, int dim, std::vector<float>& out, int& n)
@@ -42,6 +43,29 @@ int main(int argc, char** argv)
         fclose(o);
         int one_idx = -1; float one_d = 0;
         if (!matcher.SearchNeighbour(b.data(), &one_idx, &one_d) || one_idx != (int)idx[0].j_) return 6;
+        return 0;
+    }
+    if (!strcmp(argv[1], "features") && argc >= 6) {
+        // features <raw float32 gray image> <width> <height> <out.txt>: Regard3DFeatures::detectAndExtract on the GPU
+        const uint32_t w = (uint32_t)atoi(argv[3]), h = (uint32_t)atoi(argv[4]);
+        std::vector<float> img((size_t)w * h);
+        FILE* f = fopen(argv[2], "rb");
+        if (!f || fread(img.data(), 4, img.size(), f) != img.size()) return 3;
+        fclose(f);
+        r3dm_ctx* ctx = nullptr;
+        if (r3dm_create(0, &ctx) != R3DM_OK) { fprintf(stderr, "no gfx950 device\n"); return 7; }
+        r3d_amd::FeatsR3D feats; r3d_amd::DescsR3D descs;
+        r3d_amd::R3DFParams params;
+        const bool ok = r3d_amd::Regard3DFeatures::detectAndExtract(ctx, {img.data(), w, h}, feats, descs, params);
+        if (!ok) { fprintf(stderr, "detectAndExtract failed: %s\n", r3dm_last_error(ctx)); r3dm_destroy(ctx); return 7; }
+        FILE* o = fopen(argv[5], "w");
+        for (size_t k = 0; k < feats.size(); ++k) {
+            fprintf(o, "%.9g %.9g %.9g %.9g", feats[k].x, feats[k].y, feats[k].scale, feats[k].orientation);
+            for (float v : descs[k]) fprintf(o, " %.9g", v);
+            fprintf(o, "\n");
+        }
+        fclose(o);
+        r3dm_destroy(ctx);
         return 0;
     }
     if (!strcmp(argv[1], "stage") && argc >= 5) {

@@ -127,3 +127,25 @@ def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
                        env=dict(os.environ, R3DM_TEST_ALGO="11"))
     assert r.returncode == 7 and "not served" in r.stderr               # unknown arm: refused
+
+
+@pytest.mark.gpu
+def test_features_facade_matches_oracle(host_exe, oracle, tmp_path):
+    """Regard3DFeatures::detectAndExtract (include/regard3d_features.hpp) == CPU restatement of detect + LIOP"""
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:400, 0:560]
+    img = 0.5 + 0.1 * np.sin(xx / 13.0) * np.cos(yy / 9.0)
+    for _ in range(40):
+        cx, cy, s, a = rng.uniform(40, 520), rng.uniform(40, 360), rng.uniform(2, 9), rng.uniform(0.2, 0.4) * rng.choice([-1, 1])
+        img = img + a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    img = np.clip(img, 0, 1).astype(np.float32)
+    raw = str(tmp_path / "img.f32"); out = str(tmp_path / "feats.txt")
+    img.tofile(raw)
+    r = subprocess.run([host_exe, "features", raw, "560", "400", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(out, dtype=np.float64).astype(np.float32)
+    okp = oracle.akaze_detect(img, 0.001)["kps"]
+    odesc = oracle.liop_describe(oracle.liop_extract_patches(img, okp, 8.0))
+    want = okp.copy(); want[:, 2] /= 2.0
+    assert got.shape == (len(okp), 148) and len(okp) > 30
+    assert np.array_equal(got[:, :4], want) and np.array_equal(got[:, 4:], odesc)
