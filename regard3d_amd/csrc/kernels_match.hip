@@ -422,9 +422,16 @@ void l2_knn2_mfma_kernel(const MatchParams P)
         const uint32_t q = qt * 32u + c;
         const bool valid = (qt < ntJ) && (q < nJ);
         const uint32_t cand = h ? ci1 : ci0;
+        const float cd0 = __shfl(s.d0, (int)c), cd1 = __shfl(s.d1, (int)c);     // (both shuffles outside the lane-dependent select)
+        const float ck = h ? cd1 : cd0;                                         // MFMA key ||a||^2 - 2 a.b of this lane's nominee
         float e = R3DM_INF;
-        if (valid && cand != kNone)
-            e = exact_l2sq(Ip->rows + (size_t)cand * dim, Jp->rows + (size_t)q * dim, dim);
+        if (valid && cand != kNone) {
+            // exact pairs (proof above): key + ||q||^2 IS the reference distance, bit for bit -- no need to fetch the two
+            // nominated rows again (that re-read was 60 % of the kernel's HBM-side traffic: 3 x 512 B per query).
+            // Otherwise re-score in the reference's summation order.
+            if (exact_pair) e = ck + Jp->norms[q];
+            else e = exact_l2sq(Ip->rows + (size_t)cand * dim, Jp->rows + (size_t)q * dim, dim);
+        }
         const float eo = __shfl_xor(e, 32);
         float ea = h ? eo : e, eb = h ? e : eo;          // ea <-> ci0, eb <-> ci1
         uint32_t ia = ci0, ib = ci1;
