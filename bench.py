@@ -33,6 +33,7 @@ import torch
 from regard3d_amd import api, dist as r3dist, synth
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16, dense (opt-in integer fast path only)
 
 
 def images_for(n_gpus: int, base_images: int) -> int:
@@ -51,6 +52,7 @@ def main():
     ap.add_argument("--feat", type=int, default=8192)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-opt-in", action="store_true", help="skip the extra (untimed-region) pass with r3dm_set_integer_mfma")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,6 +150,29 @@ def main():
         if tj.get("workload_pairs") == int(total_pairs) and a.feat == 8192:
             out["roofline"]["traffic"] = tj["traffic_bytes_per_launch"]
             out["roofline"]["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; algorithmic %.4g)" % tj["algorithmic_bytes_per_launch"]
+    # Outside the timed region, N = 1 only: the same step with the opt-in integer fast path (r3dm_set_integer_mfma:
+    # bf16-exact MFMA for integer-valued descriptors, bit-identical results -- DESIGN.md section 4.9).  Reported beside
+    # the headline, never as `value`: the headline stays on the f32 MFMA tiles the north star names.
+    if world == 1 and not a.no_opt_in:
+        ctx.set_integer_mfma(True)
+        try:
+            step(); fence()
+            t1 = time.perf_counter()
+            g2, gf2, _, sm2, sa2 = step()
+            fence()
+            el2 = time.perf_counter() - t1
+        finally:
+            ctx.set_integer_mfma(False)
+        same = all(np.array_equal(getattr(x, f), getattr(y, f)) for x, y in ((g, g2), (gf, gf2)) for f in ("pairs", "offsets", "matches"))
+        ach2 = sm2.algorithmic_flops / (sm2.ms_match_kernels * 1e-3) / 1e12 if sm2.ms_match_kernels > 0 else 0.0
+        out["opt_in_integer_mfma"] = {
+            "value": total_pairs / el2, "unit": "pairs/s", "ms_per_step": el2 * 1e3, "steps": 1,
+            "identical_to_headline_graphs": bool(same), "integer_mfma_launches": int(sm2.n_integer_mfma),
+            "dtype": "bf16 operands holding exact integers, f32 accumulate (exact below 2^24)",
+            "roofline": {"bound": "mfma", "kernel": "l2_knn2_mfma_kernel<G=8,NJ=2,BF=1>", "achieved": ach2, "peak": BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach2 / BF16_MFMA_PEAK_TFLOPS, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
+            "filter_kernel_ms": sa2.ms_filter_kernels,
+        }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(descs, xys, g, gf, a.cpu_seconds)
     if rank == 0:

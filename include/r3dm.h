@@ -81,6 +81,16 @@ int r3dm_set_image(r3dm_ctx* ctx, uint32_t view_id, uint32_t width, uint32_t hei
                    const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);
 int r3dm_clear_images(r3dm_ctx* ctx);
 
+/* Opt-in integer fast path of the L2 matcher (default off; no reference counterpart -- the reference has one L2 loop,
+ * openMVG/matching/metric.hpp L2_Vectorized via ArrayMatcherBruteForce).  When every view of a batch holds
+ * integer-valued descriptors of magnitude <= 256 (SIFT bins 0..255 stored as float or u8), the all-pairs contraction
+ * runs on v_mfma_f32_32x32x16_bf16 instead of v_mfma_f32_32x32x2_f32: every such value is a bf16, every product and
+ * partial sum an integer below 2^24, so the f32 accumulators -- and therefore the matches -- are bit-identical to the
+ * f32 path and to the reference; the kernel re-checks the condition per pair and sends anything else to the exact
+ * scan.  Batches with any other view (LIOP, normalised SIFT) keep the f32 tiles.  r3dm_stats.n_integer_mfma reports
+ * which path ran. */
+int r3dm_set_integer_mfma(r3dm_ctx* ctx, int enable);
+
 /* ---- putative matching ----
  * pairs_ij: n_pairs x 2 view ids (I, J); J's rows are the queries, I's rows the dataset.
  * dist_ratio: Lowe ratio (0.6 default in the reference, src/Regard3DFeatures.cpp:129);
@@ -255,6 +265,7 @@ typedef struct {
     uint64_t n_ann_built;          /* indices built by the call                                     */
     uint64_t n_ann_dist;           /* descriptor distances evaluated by the searches                */
     double   ms_detect;            /* wall time of the last r3dm_detect_akaze call                  */
+    uint64_t n_integer_mfma;       /* launches of the dominant kernel that ran as the integer fast path  */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -103,6 +103,7 @@ static int upload_imgdev(r3dm_ctx* c, uint32_t slot)
     d.n = h.n; d.n_tiles = h.n_tiles; d.dim = h.dim; d.G = h.G; d.words = h.words;
     d.width = h.width; d.height = h.height; d.max_norm_bits = 0; d.max_abs_bits = 0; d.not_integer = 0;
     d.ann_adj = nullptr; d.ann_deg = nullptr;          // staging invalidates the graph index
+    d.tiled16 = h.tiled16.as<uint16_t>();
     R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
     return R3DM_OK;
@@ -132,6 +133,9 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         const size_t norm_bytes = (size_t)h.n_tiles * 32 * 4 + kSlackBytes;
         R3DM_HIP(c, h.rows.ensure((size_t)std::max<uint32_t>(n, 1) * dim * 4 + 256));
         R3DM_HIP(c, h.tiled.ensure(tiled_bytes));
+        const size_t tiled16_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 1024 + kSlackBytes;
+        R3DM_HIP(c, h.tiled16.ensure(tiled16_bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiled16.p, 0, tiled16_bytes, c->stream));
         R3DM_HIP(c, h.norms.ensure(norm_bytes));
         R3DM_HIP(c, hipMemsetAsync(h.tiled.p, 0, tiled_bytes, c->stream));
         R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0, norm_bytes, c->stream));
@@ -185,7 +189,12 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
     if (dtype != R3DM_BIN) {
         uint32_t* mx = &(c->d_imgs.as<ImgDev>() + slot)->max_norm_bits;
         R3DM_HIP(c, launch_stage_f32(c->stream, n ? c->d_raw.p : nullptr, dtype == R3DM_U8, n, dim, h.rows.as<float>(),
-                                     h.tiled.as<float>(), h.norms.as<float>(), h.G, h.n_tiles, mx));
+                                     h.tiled.as<float>(), h.tiled16.as<uint16_t>(), h.norms.as<float>(), h.G, h.n_tiles, mx));
+        uint32_t st3[3] = {0, 0, 1};
+        R3DM_HIP(c, hipMemcpyAsync(st3, mx, 12, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(&h.max_abs, &st3[1], 4);
+        h.not_integer = (st3[2] != 0);
     }
     R3DM_HIP(c, hipStreamSynchronize(c->stream));     // d_raw is reused by the next call
     return R3DM_OK;
@@ -219,6 +228,13 @@ extern "C" int r3dm_clear_images(r3dm_ctx* c)
     for (auto& im : c->imgs) if (im) im->release();
     c->imgs.clear();
     c->slot_of.clear();
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_set_integer_mfma(r3dm_ctx* c, int enable)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    c->integer_mfma = (enable != 0);
     return R3DM_OK;
 }
 

@@ -92,6 +92,17 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
             bytes += ((double)A.n + B.n) * A.dim * 4 + (double)B.n * 16;
         }
     }
+    // integer fast path (r3dm_set_integer_mfma): every view of the batch must hold bf16-exact integers
+    bool int_mfma = c->integer_mfma && dtype != R3DM_BIN && first.G != 18;
+    if (int_mfma)
+        for (const PairJob& j : jobs) {
+            const HostImage& A = *c->imgs[j.sI];
+            const HostImage& B = *c->imgs[j.sJ];
+            const float dpad = (float)(first.G * 8), mI = A.max_abs, mJ = B.max_abs;      // same test as the kernel's exact_pair
+            const bool exact = !A.not_integer && !B.not_integer && mI <= 256.0f && mJ <= 256.0f &&
+                               2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f;
+            if (!exact) { int_mfma = false; break; }
+        }
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
     const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
 
@@ -133,7 +144,8 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
         R3DM_HIP(c, launch_hamming_knn2(c->stream, mp, first.words, max_nJ));
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
     } else if (has_tensor_kernel(first.G)) {
-        R3DM_HIP(c, launch_l2_knn2(c->stream, mp, first.G, max_tiles));
+        R3DM_HIP(c, launch_l2_knn2(c->stream, mp, first.G, max_tiles, int_mfma));
+        if (int_mfma) c->stats.n_integer_mfma += 1;
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         uint32_t fbt[2] = {0, 0};
         R3DM_HIP(c, hipMemcpyAsync(fbt, mp.fb_total, 8, hipMemcpyDeviceToHost, c->stream));
@@ -242,7 +254,9 @@ extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, c
         std::vector<PairJob> jobs{{0, 1, s0, s0 + 1}};
         const r3dm_stats keep = c->stats;
         rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
+        const uint64_t int_launches = c->stats.n_integer_mfma - keep.n_integer_mfma;
         c->stats = keep;
+        c->stats.n_integer_mfma = int_launches;           // which tiles this call ran on (r3dm_set_integer_mfma)
     }
     (void)hipStreamSynchronize(c->stream);
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();

@@ -45,7 +45,8 @@ void stage_rows_kernel(const void* __restrict__ raw, int raw_is_u8, uint32_t n, 
 // one workgroup per 32-row tile
 __global__ __launch_bounds__(256)
 void stage_tiles_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim, uint32_t G,
-                        float* __restrict__ tiled, float* __restrict__ norms, uint32_t* __restrict__ img_stats)
+                        float* __restrict__ tiled, uint16_t* __restrict__ tiled16, float* __restrict__ norms,
+                        uint32_t* __restrict__ img_stats)
 {
     const uint32_t t = blockIdx.x;
     const uint32_t per_tile = G * 256;                 // floats per tile = G * 2 * 32 * 4
@@ -54,6 +55,16 @@ void stage_tiles_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim
         const uint32_t c = e & 3, r = (e >> 2) & 31, h = (e >> 7) & 1, g = e >> 8;
         const uint32_t row = t * 32 + r, k = 8 * g + 4 * h + c;
         dst[e] = (row < n && k < dim) ? rows[(size_t)row * dim + k] : 0.0f;
+    }
+    // bf16 tiles of the integer fast path: the upper 16 bits of the float ARE the value when it is an integer of
+    // magnitude <= 256 (8 significant bits); for any other view these tiles are never read (kernel-side check)
+    const uint32_t GB = (G + 1) / 2, per_tile16 = GB * 512;
+    uint16_t* dst16 = tiled16 + (size_t)t * per_tile16;
+    for (uint32_t e = threadIdx.x; e < per_tile16; e += 256) {
+        const uint32_t c8 = e & 7, r = (e >> 3) & 31, h = (e >> 8) & 1, kb = e >> 9;
+        const uint32_t row = t * 32 + r, k = 16 * kb + 8 * h + c8;
+        const float v = (row < n && k < dim) ? rows[(size_t)row * dim + k] : 0.0f;
+        dst16[e] = (uint16_t)(__float_as_uint(v) >> 16);
     }
     if (threadIdx.x < 32) {
         const uint32_t row = t * 32 + threadIdx.x;
@@ -95,14 +106,14 @@ void stage_bin_kernel(const uint8_t* __restrict__ raw, uint32_t n, uint32_t nbyt
 }
 
 hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
-                            float* rows, float* tiled, float* norms, uint32_t G, uint32_t n_tiles,
+                            float* rows, float* tiled, uint16_t* tiled16, float* norms, uint32_t G, uint32_t n_tiles,
                             uint32_t* img_stats_dev)
 {
     if (n == 0) return hipSuccess;
     const size_t total = (size_t)n * dim;
     uint32_t grid = (uint32_t)((total + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(stage_rows_kernel, dim3(grid), dim3(256), 0, st, raw, raw_is_u8, n, dim, rows);
-    hipLaunchKernelGGL(stage_tiles_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, G, tiled, norms, img_stats_dev);
+    hipLaunchKernelGGL(stage_tiles_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, G, tiled, tiled16, norms, img_stats_dev);
     return hipGetLastError();
 }
 
@@ -205,7 +216,8 @@ __device__ __forceinline__ f32x4 bload16(__amdgpu_buffer_rsrc_t rsrc, uint32_t v
 // One dataset tile: MFMAs of tile t into `cur`, while the VALU folds the finished accumulators of
 // tile t-1 (`prev`) into the running top-2 lists -- software pipelining inside the wave, so the
 // epilogue issues in the shadow of the 64-cycle MFMAs instead of after them.
-template <int G, int NJ, int PF, int PIPE>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int G, int NJ, int PF, int PIPE, int BF = 0>
 __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rn, uint32_t voffA, uint32_t voffN,
                                              uint32_t soffA, uint32_t soffN, f32x4 (&abuf)[PF], f32x4 (&nrm)[4],
                                              const f32x4 (&bq)[NJ][G], f32x16 (&cur)[NJ], const f32x16 (&prev)[NJ],
@@ -224,11 +236,19 @@ __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu
             for (int qd = 0; qd < 4; ++qd) nrm[qd] = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
         }
         if constexpr (PIPE == 4) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
+        if constexpr (BF != 0) {
+            // integer fast path: the 16 bytes are 8 bf16 -- one 32x32x16 instruction covers 16 dims (two lane halves x 8)
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
-                cur[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cc], bq[nj][g][cc], cur[nj], 0, 0, 0);
+                cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[nj][g]),
+                                                                  cur[nj], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    cur[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cc], bq[nj][g][cc], cur[nj], 0, 0, 0);
+        }
         if constexpr (PIPE == 4) __builtin_amdgcn_s_setprio(0);
         // this group's share of the previous tile's 16 accumulator values per query tile
         if constexpr (PIPE == 9 || PIPE == 7) {
@@ -272,11 +292,16 @@ __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu
     }
 }
 
-template <int G, int NJ, int PF, int PIPE, int WPS>
+// BF = 1: integer fast path.  G then counts 16-dim bf16 blocks (16 bytes per lane, like an 8-dim f32 group), the tiles
+// come from ImgDev::tiled16 and one v_mfma_f32_32x32x16_bf16 replaces four v_mfma_f32_32x32x2_f32.  Every product and
+// partial sum is an integer below 2^24, so the accumulators hold the SAME values as on the f32 path (and as the
+// reference's sum of squared differences) -- see the exactness proof below; pairs that fail it go to the exact scan.
+template <int G, int NJ, int PF, int PIPE, int WPS, int BF = 0>
 __global__ __launch_bounds__(256, WPS)
 void l2_knn2_mfma_kernel(const MatchParams P)
 {
     static_assert(G % PF == 0, "prefetch window must divide the group count");
+    static_assert(BF == 0 || PIPE == 3 || PIPE == 9, "the integer fast path exists for the default pipeline only");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t h = lane >> 5, c = lane & 31u;
@@ -305,9 +330,23 @@ void l2_knn2_mfma_kernel(const MatchParams P)
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;          // clamp: results discarded below
-        const gf4p src = (gf4p)Jp->tiled + (size_t)qt * (G * 64) + lane;
+        const gf4p src = (gf4p)(BF ? (const void*)Jp->tiled16 : (const void*)Jp->tiled) + (size_t)qt * (G * 64) + lane;
 #pragma unroll
-        for (int g = 0; g < G; ++g) bq[nj][g] = src[g * 64] * -2.0f;
+        for (int g = 0; g < G; ++g) {
+            if constexpr (BF != 0) {
+                // -2 x an integer of magnitude <= 256 is a bf16 again: scale in f32, keep the upper halves
+                const u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float lo = __uint_as_float(w[k] << 16) * -2.0f, hi = __uint_as_float(w[k] & 0xFFFF0000u) * -2.0f;
+                    o[k] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+                }
+                bq[nj][g] = __builtin_bit_cast(f32x4, o);
+            } else {
+                bq[nj][g] = src[g * 64] * -2.0f;
+            }
+        }
     }
 
     Top2 st[NJ];
@@ -317,7 +356,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     if (nI >= 2) {
         // ---- dataset stream (A operand): float4 index = (t*G + g)*64 + lane.  abase/nbase are
         // wave-uniform (SGPR) bases; only `lane` / `h` are per-lane.
-        const gf4p abase = (gf4p)Ip->tiled;
+        const gf4p abase = (gf4p)(BF ? (const void*)Ip->tiled16 : (const void*)Ip->tiled);
         const gf4p nbase = (gf4p)Ip->norms;               // tile t, quad qd -> float4 index t*8 + 2*qd + h
         f32x4 abuf[PF];
 #pragma unroll
@@ -333,7 +372,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accB[nj][r] = R3DM_INF;          // "tile -1": keys that never win
             // descriptors from wave-uniform values only (readfirstlane) so no waterfall loop is emitted
-            const uint64_t pa = (uint64_t)Ip->tiled, pn = (uint64_t)Ip->norms;
+            const uint64_t pa = (uint64_t)abase, pn = (uint64_t)Ip->norms;
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
                 0, 0x7FFFFFFF, 0x00020000);
@@ -345,11 +384,11 @@ void l2_knn2_mfma_kernel(const MatchParams P)
             const uint32_t hb = 4u * h;
             uint32_t t = 0;
             for (; t + 1 < ntI; t += 2) {
-                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
-                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 2) * 128u, abuf, nrm, bq, accB, accA, st, t * 32u + hb);
+                l2_tile_step<G, NJ, PF, PIPE, BF>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
+                l2_tile_step<G, NJ, PF, PIPE, BF>(ra, rn, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 2) * 128u, abuf, nrm, bq, accB, accA, st, t * 32u + hb);
             }
             if (t < ntI) {
-                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
+                l2_tile_step<G, NJ, PF, PIPE, BF>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
 #pragma unroll
                 for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
@@ -402,9 +441,10 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     // chain, + ||q||^2) and the reference's sum of squared differences are BOTH exact, hence equal:
     // no rounding slack is needed and only true ties with an un-nominated row need the exact scan.
     const float mI = __uint_as_float(Ip->max_abs_bits), mJ = __uint_as_float(Jp->max_abs_bits);
-    const float dpad = (float)(G * 8);
+    const float dpad = (float)(BF ? G * 16 : G * 8);
     const bool exact_pair = !Ip->not_integer && !Jp->not_integer &&
-                            2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f;
+                            2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f &&
+                            (BF == 0 || (mI <= 256.0f && mJ <= 256.0f));      // bf16 tiles hold the values exactly
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         Top2 s = st[nj];
@@ -447,7 +487,8 @@ void l2_knn2_mfma_kernel(const MatchParams P)
                 // arithmetic a runner-up that merely TIES an un-nominated row still fixes the best row (ea < eb)
                 // and the runner-up DISTANCE, which is all the ratio test needs; only the raw 2-NN dump
                 // (r3dm_knn2) needs the tie's index resolved by the exact scan.
-                const bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
+                bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
+                if (BF != 0 && !exact_pair) certified = false;      // bf16 keys of a non-exact pair mean nothing: exact scan
                 if (certified) {
                     emit_result(P, pair, q, ea, ia, eb, ib);
                 } else {
@@ -462,7 +503,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     }
 }
 
-template <int G, int NJ, int PF, int PIPE, int WPS>
+template <int G, int NJ, int PF, int PIPE, int WPS, int BF = 0>
 static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
     MatchParams P = Pin;
@@ -474,12 +515,26 @@ static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t m
     if (grid64 == 0) return hipSuccess;
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint32_t grid = (uint32_t)grid64;
-    hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF, PIPE, WPS>), dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF, PIPE, WPS, BF>), dim3(grid), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 
-hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles)
+hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, bool integer_mfma)
 {
+    if (integer_mfma) {
+        // R3DM_L2_BF_VARIANT: 2 = NJ 2 x 2 waves/SIMD (default; 15.0 ms on 780 pairs of 8192 rows) | 4 = NJ 4 x 1 wave/SIMD (21.6 ms)
+        static const int bv = [] { const char* v = getenv("R3DM_L2_BF_VARIANT"); return v ? atoi(v) : 2; }();
+        switch (G) {
+            case 8:  return bv == 2 ? launch_l2_t<4, 2, 4, 3, 2, 1>(st, P, max_nj_tiles) : launch_l2_t<4, 4, 4, 3, 1, 1>(st, P, max_nj_tiles);
+            case 16: return bv == 2 ? launch_l2_t<8, 2, 4, 3, 2, 1>(st, P, max_nj_tiles)
+                          : bv == 9 ? launch_l2_t<8, 2, 4, 9, 2, 1>(st, P, max_nj_tiles)      // ablation: no epilogue (timing only)
+                          : bv == 3 ? launch_l2_t<8, 3, 4, 3, 2, 1>(st, P, max_nj_tiles)
+                          : bv == 28 ? launch_l2_t<8, 2, 8, 3, 2, 1>(st, P, max_nj_tiles)
+                          : bv == 8 ? launch_l2_t<8, 4, 8, 3, 1, 1>(st, P, max_nj_tiles) : launch_l2_t<8, 4, 4, 3, 1, 1>(st, P, max_nj_tiles);
+            case 32: return bv == 2 ? launch_l2_t<16, 2, 4, 3, 2, 1>(st, P, max_nj_tiles) : launch_l2_t<16, 4, 4, 3, 1, 1>(st, P, max_nj_tiles);
+            default: break;               // G = 18 (LIOP, never integer): f32 tiles
+        }
+    }
     // R3DM_L2_VARIANT selects a build of the kernel for A/B measurements (tools/ab_l2.py):
     //   0 epilogue after the MFMAs | 1 software-pipelined epilogue | 3 pipelined + wave-wide test-and-skip
     //   (default) | 9 ablation without epilogue (timing only) | 13 / 43: NJ = 1 x 3 waves/SIMD, NJ = 4 x 1 wave/SIMD

@@ -38,6 +38,10 @@ struct ImgDev {
     // graph index of the view (kernels_ann.hip), nullptr until r3dm_match_pairs_kgraph builds it
     const uint32_t* ann_adj;   // [n][kAnnDeg] neighbour rows ordered by (distance, id), kNone padded
     const uint32_t* ann_deg;   // [n] valid entries of each adjacency row
+    // bf16 fragment-order tiles for the integer fast path (r3dm_set_integer_mfma): [n_tiles][G/2][2][32][8] bf16,
+    // lane half h of 16-dim block kb holds dims 16 kb + 8 h .. + 7 of row 32 t + r.  Exact iff the view is
+    // integer-valued with |x| <= 256 (every such value is a bf16); the kernel checks that itself.
+    const uint16_t* tiled16;
 };
 #ifndef R3DM_INF
 #define R3DM_INF __builtin_huge_valf()
@@ -201,12 +205,12 @@ hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, uin
 
 // ---- launchers implemented in the .hip files (host side) ----
 hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
-                            float* rows, float* tiled, float* norms, uint32_t G, uint32_t n_tiles,
+                            float* rows, float* tiled, uint16_t* tiled16, float* norms, uint32_t G, uint32_t n_tiles,
                             uint32_t* img_stats_dev /* &ImgDev::max_norm_bits: 3 consecutive words */);
 hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint32_t nbytes,
                             uint32_t* bin, uint32_t words, uint32_t n_pad);
 // returns hipErrorInvalidValue when (G, dtype) has no tensor kernel; caller falls back to the exact scan
-hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
+hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, bool integer_mfma = false);
 hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t count, int scan_all);
 // exact scan of the per-pair fallback lists (one workgroup per pair); false return -> no kernel for this G
 hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t G);

@@ -1,0 +1,139 @@
+"""Opt-in integer fast path of the L2 matcher (r3dm_set_integer_mfma, include/r3dm.h): the all-pairs contraction on
+v_mfma_f32_32x32x16_bf16 for integer-valued descriptors of magnitude <= 256.
+
+Bar: BIT-EXACT -- the same 2-NN indices and float distances as the CPU restatement of the reference
+(openMVG ArrayMatcherBruteForce + L2_Vectorized) and as the default f32-MFMA path; every input the proof does not
+cover must keep running on the f32 tiles / the exact scan with unchanged results.
+"""
+import numpy as np
+import pytest
+
+from regard3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ictx(ctx):
+    ctx.set_integer_mfma(True)
+    yield ctx
+    ctx.set_integer_mfma(False)
+
+
+def _sift_like(rng, n, dim, lo=0, hi=255):
+    return np.rint(np.clip(rng.gamma(0.5, 60.0, (n, dim)) + lo, lo, hi)).astype(np.float32)
+
+
+@pytest.mark.parametrize("nI,nJ,dim", [(100, 70, 128), (257, 1000, 128), (2048, 2048, 128), (33, 31, 64), (1000, 777, 61),
+                                       (300, 200, 100), (300, 260, 256), (2, 5, 128), (4100, 130, 128)])
+def test_knn2_bit_exact_on_the_bf16_tiles(ictx, oracle, nI, nJ, dim):
+    rng = np.random.default_rng(nI * 104729 + nJ)
+    hi = 127 if dim > 128 else 255           # 2 * D * max^2 must stay below 2^24 for the proof (else: f32 tiles)
+    a = _sift_like(rng, nI, dim, hi=hi)
+    b = _sift_like(rng, nJ, dim, hi=hi)
+    m = min(nJ, nI) // 2
+    b[:m] = np.clip(a[:m] + np.rint(rng.normal(0, 4, (m, dim))), 0, hi)
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 1
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist)
+    assert np.array_equal(idx, oidx)
+
+
+def test_knn2_signed_and_extreme_bins(ictx, oracle):
+    """negative integers, the magnitude bound itself (256) and rows of all-255 bins (largest partial sums:
+    2 * 128 * 255 * 255 < 2^24) stay exact"""
+    rng = np.random.default_rng(8)
+    a = rng.integers(-128, 128, (700, 128)).astype(np.float32)
+    b = rng.integers(-128, 128, (500, 128)).astype(np.float32)
+    a[0, :] = -128; b[0, :] = 127
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 1
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    a = _sift_like(rng, 300, 128); b = _sift_like(rng, 200, 128)
+    a[:5] = 255; b[:3] = 255; a[5:8] = 0; b[3] = 0
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 1
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    a = rng.integers(0, 257, (400, 64)).astype(np.float32); b = rng.integers(0, 257, (300, 64)).astype(np.float32)
+    a[0, 0] = 256; b[0, 0] = 256
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 1
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+
+
+def test_exact_ties_and_duplicate_rows(ictx, oracle):
+    rng = np.random.default_rng(3)
+    a = _sift_like(rng, 640, 128)
+    a[100:200] = a[0:100]                    # duplicated dataset rows: ties between nominated and un-nominated rows
+    a[300:364] = a[200]
+    b = np.concatenate([a[50:150], _sift_like(rng, 100, 128)])
+    idx, dist = ictx.knn2(a, b)
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+
+
+def test_u8_views_and_match_graph_equal_f32_path_and_oracle(ctx, oracle):
+    sc = synth.make_scene(6, 1500, "sift", seed=77)
+    descs = [d.astype(np.uint8) for d in sc.descs]                  # R3DM_U8 storage (features of type unsigned char)
+    assert all(np.array_equal(d.astype(np.float32), s) for d, s in zip(descs, sc.descs))
+    pairs = sc.exhaustive_pairs()
+    ctx.clear_images()
+    for i in range(sc.n_images):
+        ctx.set_image(i, descs[i], sc.xys[i], 4000, 3000)
+    g0 = ctx.match_pairs(pairs, 0.6, True)
+    assert ctx.stats().n_integer_mfma == 0
+    ctx.set_integer_mfma(True)
+    try:
+        g1 = ctx.match_pairs(pairs, 0.6, True)
+        s = ctx.stats()
+    finally:
+        ctx.set_integer_mfma(False)
+    assert s.n_integer_mfma == 1
+    assert s.n_exact_fallback <= s.n_queries // 1000
+    assert np.array_equal(g0.pairs, g1.pairs) and np.array_equal(g0.offsets, g1.offsets)
+    assert np.array_equal(g0.matches, g1.matches)
+    counts, matches = oracle.match_collection(sc.descs, sc.xys, pairs, 0.6, True)
+    d = g1.as_dict(); off = 0
+    for p, (I, J) in enumerate(pairs):
+        exp = matches[off:off + counts[p]]; off += counts[p]
+        got = d.get((int(I), int(J)), np.zeros((0, 2), np.uint32))
+        assert np.array_equal(got, exp)
+
+
+def test_inputs_outside_the_proof_keep_the_f32_tiles(ictx, oracle):
+    rng = np.random.default_rng(12)
+    # real-valued (normalised) descriptors
+    a = rng.gamma(0.5, 1.0, (700, 128)).astype(np.float32); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = rng.gamma(0.5, 1.0, (400, 128)).astype(np.float32); b /= np.linalg.norm(b, axis=1, keepdims=True)
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 0
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    # integers beyond the bf16-exact range
+    a = rng.integers(0, 600, (500, 32)).astype(np.float32); b = rng.integers(0, 600, (300, 32)).astype(np.float32)
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 0
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    # one integer view against one real-valued view
+    a = _sift_like(rng, 500, 128); b = a[:300] + rng.normal(0, 0.25, (300, 128)).astype(np.float32)
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 0
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    # 256-D rows of full-range bins: partial sums may pass 2^24
+    a = _sift_like(rng, 300, 256); b = _sift_like(rng, 200, 256); a[0] = 255; b[0] = 255
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 0
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    # LIOP-length rows (144) have no bf16 kernel
+    a = _sift_like(rng, 300, 144); b = _sift_like(rng, 200, 144)
+    idx, dist = ictx.knn2(a, b)
+    assert ictx.stats().n_integer_mfma == 0
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)

@@ -11,6 +11,7 @@ ap.add_argument("--kind", default="sift")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--check", type=int, default=0, help="verify this many pairs against the oracle")
 ap.add_argument("--all-filters", action="store_true", help="also time the essential-matrix and homography filters")
+ap.add_argument("--integer-mfma", action="store_true", help="opt into the bf16-exact integer fast path and compare with the f32 path")
 a = ap.parse_args()
 
 t = time.time(); sc = synth.make_scene(a.images, a.feat, a.kind, seed=2002); print("gen %.1fs" % (time.time() - t), flush=True)
@@ -24,6 +25,14 @@ for i in range(sc.n_images):
 print("set_image %.2fs" % (time.time() - t), flush=True)
 pairs = sc.exhaustive_pairs()
 ratio, sq = (0.8, False) if binary else (0.6, True)
+if a.integer_mfma:
+    g0 = c.match_pairs(pairs, ratio, sq); s0 = c.stats()
+    c.set_integer_mfma(True)
+    g1 = c.match_pairs(pairs, ratio, sq); s1 = c.stats()
+    same = (np.array_equal(g0.pairs, g1.pairs) and np.array_equal(g0.offsets, g1.offsets)
+            and np.array_equal(g0.matches, g1.matches))
+    print(json.dumps(dict(integer_mfma_identical=bool(same), f32_ms_kernel=s0.ms_match_kernels, int_ms_kernel=s1.ms_match_kernels,
+                          int_launches=s1.n_integer_mfma, f32_fallback=s0.n_exact_fallback, int_fallback=s1.n_exact_fallback)), flush=True)
 for rep in range(a.reps):
     t = time.time(); g = c.match_pairs(pairs, ratio, sq); tm = time.time() - t
     s = c.stats()
