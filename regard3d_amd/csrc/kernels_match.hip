@@ -216,8 +216,7 @@ __device__ __forceinline__ f32x4 bload16(__amdgpu_buffer_rsrc_t rsrc, uint32_t v
 // One dataset tile: MFMAs of tile t into `cur`, while the VALU folds the finished accumulators of
 // tile t-1 (`prev`) into the running top-2 lists -- software pipelining inside the wave, so the
 // epilogue issues in the shadow of the 64-cycle MFMAs instead of after them.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <int G, int NJ, int PF, int PIPE, int BF = 0>
+template <int G, int NJ, int PF, int PIPE>
 __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rn, uint32_t voffA, uint32_t voffN,
                                              uint32_t soffA, uint32_t soffN, f32x4 (&abuf)[PF], f32x4 (&nrm)[4],
                                              const f32x4 (&bq)[NJ][G], f32x16 (&cur)[NJ], const f32x16 (&prev)[NJ],
@@ -236,19 +235,11 @@ __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu
             for (int qd = 0; qd < 4; ++qd) nrm[qd] = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
         }
         if constexpr (PIPE == 4) __builtin_amdgcn_s_setprio(1);
-        if constexpr (BF != 0) {
-            // integer fast path: the 16 bytes are 8 bf16 -- one 32x32x16 instruction covers 16 dims (two lane halves x 8)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
-                cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[nj][g]),
-                                                                  cur[nj], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                for (int nj = 0; nj < NJ; ++nj)
-                    cur[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cc], bq[nj][g][cc], cur[nj], 0, 0, 0);
-        }
+                cur[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cc], bq[nj][g][cc], cur[nj], 0, 0, 0);
         if constexpr (PIPE == 4) __builtin_amdgcn_s_setprio(0);
         // this group's share of the previous tile's 16 accumulator values per query tile
         if constexpr (PIPE == 9 || PIPE == 7) {
@@ -292,16 +283,106 @@ __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu
     }
 }
 
-// BF = 1: integer fast path.  G then counts 16-dim bf16 blocks (16 bytes per lane, like an 8-dim f32 group), the tiles
-// come from ImgDev::tiled16 and one v_mfma_f32_32x32x16_bf16 replaces four v_mfma_f32_32x32x2_f32.  Every product and
-// partial sum is an integer below 2^24, so the accumulators hold the SAME values as on the f32 path (and as the
-// reference's sum of squared differences) -- see the exactness proof below; pairs that fail it go to the exact scan.
-template <int G, int NJ, int PF, int PIPE, int WPS, int BF = 0>
+// ---- per query: merge the two lane halves, re-score exactly, certify, ratio-test (tail of both L2 kernels).
+// dpad = padded descriptor length, bf16_tiles = the keys come from the integer fast path
+__device__ __forceinline__ void lex_push(Top2& s, float key, uint32_t idx)
+{
+    const float od0 = s.d0, od1 = s.d1;
+    const uint32_t oi0 = s.i0, oi1 = s.i1;
+    const bool c0 = key < od0 || (key == od0 && idx < oi0);
+    const bool c1 = key < od1 || (key == od1 && idx < oi1);
+    s.d1 = c0 ? od0 : (c1 ? key : od1);
+    s.i1 = c0 ? oi0 : (c1 ? idx : oi1);
+    s.d0 = c0 ? key : od0;
+    s.i0 = c0 ? idx : oi0;
+}
+
+// LEX: the lists are exact lexicographic (distance, index) top-2 lists without a bound (l2_knn2_int_kernel)
+template <int NJ, bool LEX = false>
+__device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t pair, const ImgDev* __restrict__ Ip,
+                                                  const ImgDev* __restrict__ Jp, const Top2 (&st)[NJ], uint32_t qt0,
+                                                  uint32_t h, uint32_t c, float dpad, bool bf16_tiles)
+{
+    const uint32_t nI = Ip->n, nJ = Jp->n, ntJ = Jp->n_tiles;
+    const float maxnorm = __uint_as_float(Ip->max_norm_bits);
+    const uint32_t dim = Ip->dim;
+    // Exactness proof for integer-valued descriptors (e.g. SIFT bins 0..255): when every element of
+    // both views is an integer and all partial sums stay below 2^24, the MFMA pass (norm init, fma
+    // chain, + ||q||^2) and the reference's sum of squared differences are BOTH exact, hence equal:
+    // no rounding slack is needed and only true ties with an un-nominated row need the exact scan.
+    const float mI = __uint_as_float(Ip->max_abs_bits), mJ = __uint_as_float(Jp->max_abs_bits);
+    const bool exact_pair = !Ip->not_integer && !Jp->not_integer &&
+                            2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f &&
+                            (!bf16_tiles || (mI <= 256.0f && mJ <= 256.0f));      // bf16 tiles hold the values exactly
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        Top2 s = st[nj];
+        // partner half (same query column, the other 16 rows of every tile)
+        const float pd0 = __shfl_xor(s.d0, 32), pd1 = __shfl_xor(s.d1, 32), pd2 = __shfl_xor(s.d2, 32);
+        const uint32_t pi0 = __shfl_xor(s.i0, 32), pi1 = __shfl_xor(s.i1, 32);
+        if constexpr (LEX) {
+            lex_push(s, pd0, pi0);
+            lex_push(s, pd1, pi1);
+            s.d2 = R3DM_INF;                               // nothing un-nominated can tie or beat an exact top-2
+        } else {
+            top2_push(s, pd0, pi0);
+            top2_push(s, pd1, pi1);
+            s.d2 = fminf(s.d2, pd2);
+        }
+        // make both halves agree on the nominated pair (lane c's view)
+        const uint32_t ci0 = __shfl(s.i0, (int)c), ci1 = __shfl(s.i1, (int)c);
+        const float bound = __shfl(s.d2, (int)c);
+
+        const uint32_t qt = qt0 + nj;
+        const uint32_t q = qt * 32u + c;
+        const bool valid = (qt < ntJ) && (q < nJ);
+        const uint32_t cand = h ? ci1 : ci0;
+        const float cd0 = __shfl(s.d0, (int)c), cd1 = __shfl(s.d1, (int)c);     // (both shuffles outside the lane-dependent select)
+        const float ck = h ? cd1 : cd0;                                         // MFMA key ||a||^2 - 2 a.b of this lane's nominee
+        float e = R3DM_INF;
+        if (valid && cand != kNone) {
+            // exact pairs (proof above): key + ||q||^2 IS the reference distance, bit for bit -- no need to fetch the two
+            // nominated rows again (that re-read was 60 % of the kernel's HBM-side traffic: 3 x 512 B per query).
+            // Otherwise re-score in the reference's summation order.
+            if (exact_pair) e = ck + Jp->norms[q];
+            else e = exact_l2sq(Ip->rows + (size_t)cand * dim, Jp->rows + (size_t)q * dim, dim);
+        }
+        const float eo = __shfl_xor(e, 32);
+        float ea = h ? eo : e, eb = h ? e : eo;          // ea <-> ci0, eb <-> ci1
+        uint32_t ia = ci0, ib = ci1;
+        if (eb < ea || (eb == ea && ib < ia)) { const float tf = ea; ea = eb; eb = tf; const uint32_t tu = ia; ia = ib; ib = tu; }
+        if (valid && h == 0) {
+            if (nI < 2) {
+                emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
+            } else {
+                const float nb = Jp->norms[q];
+                const float slack = exact_pair ? 0.0f : P.err_scale * (maxnorm + nb);
+                const float A3 = bound + nb;                        // distance of the best un-nominated row (exact if exact_pair)
+                // certified: every un-nominated row is strictly farther than the runner-up.  With exact
+                // arithmetic a runner-up that merely TIES an un-nominated row still fixes the best row (ea < eb)
+                // and the runner-up DISTANCE, which is all the ratio test needs; only the raw 2-NN dump
+                // (r3dm_knn2) needs the tie's index resolved by the exact scan.
+                bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
+                if (bf16_tiles && !exact_pair) certified = false;      // bf16 keys of a non-exact pair mean nothing: exact scan
+                if (certified) {
+                    emit_result(P, pair, q, ea, ia, eb, ib);
+                } else {
+                    P.nn_idx[(size_t)pair * P.q_stride + q] = kFallback;
+                    const uint32_t pos = atomicAdd(P.fb_cnt + pair, 1u);
+                    atomicAdd(P.fb_total, 1u);
+                    if (pos < kFbPerPair) P.fb_q[(size_t)pair * kFbPerPair + pos] = q;
+                    else atomicAdd(P.fb_total + 1, 1u);
+                }
+            }
+        }
+    }
+}
+
+template <int G, int NJ, int PF, int PIPE, int WPS>
 __global__ __launch_bounds__(256, WPS)
 void l2_knn2_mfma_kernel(const MatchParams P)
 {
     static_assert(G % PF == 0, "prefetch window must divide the group count");
-    static_assert(BF == 0 || PIPE == 3 || PIPE == 9, "the integer fast path exists for the default pipeline only");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t h = lane >> 5, c = lane & 31u;
@@ -321,7 +402,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     const uint2 pr = P.pairs[pair];
     const ImgDev* __restrict__ Ip = P.imgs + pr.x;
     const ImgDev* __restrict__ Jp = P.imgs + pr.y;
-    const uint32_t nI = Ip->n, nJ = Jp->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles;
+    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles;
     const uint32_t qt0 = (qb * 4u + wave) * NJ;
     if (qt0 >= ntJ) return;                           // wave-uniform; no barriers in this kernel
 
@@ -330,23 +411,9 @@ void l2_knn2_mfma_kernel(const MatchParams P)
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;          // clamp: results discarded below
-        const gf4p src = (gf4p)(BF ? (const void*)Jp->tiled16 : (const void*)Jp->tiled) + (size_t)qt * (G * 64) + lane;
+        const gf4p src = (gf4p)Jp->tiled + (size_t)qt * (G * 64) + lane;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if constexpr (BF != 0) {
-                // -2 x an integer of magnitude <= 256 is a bf16 again: scale in f32, keep the upper halves
-                const u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);
-                u32x4 o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float lo = __uint_as_float(w[k] << 16) * -2.0f, hi = __uint_as_float(w[k] & 0xFFFF0000u) * -2.0f;
-                    o[k] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
-                }
-                bq[nj][g] = __builtin_bit_cast(f32x4, o);
-            } else {
-                bq[nj][g] = src[g * 64] * -2.0f;
-            }
-        }
+        for (int g = 0; g < G; ++g) bq[nj][g] = src[g * 64] * -2.0f;
     }
 
     Top2 st[NJ];
@@ -356,7 +423,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
     if (nI >= 2) {
         // ---- dataset stream (A operand): float4 index = (t*G + g)*64 + lane.  abase/nbase are
         // wave-uniform (SGPR) bases; only `lane` / `h` are per-lane.
-        const gf4p abase = (gf4p)(BF ? (const void*)Ip->tiled16 : (const void*)Ip->tiled);
+        const gf4p abase = (gf4p)Ip->tiled;
         const gf4p nbase = (gf4p)Ip->norms;               // tile t, quad qd -> float4 index t*8 + 2*qd + h
         f32x4 abuf[PF];
 #pragma unroll
@@ -372,7 +439,7 @@ void l2_knn2_mfma_kernel(const MatchParams P)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accB[nj][r] = R3DM_INF;          // "tile -1": keys that never win
             // descriptors from wave-uniform values only (readfirstlane) so no waterfall loop is emitted
-            const uint64_t pa = (uint64_t)abase, pn = (uint64_t)Ip->norms;
+            const uint64_t pa = (uint64_t)Ip->tiled, pn = (uint64_t)Ip->norms;
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
                 0, 0x7FFFFFFF, 0x00020000);
@@ -384,11 +451,11 @@ void l2_knn2_mfma_kernel(const MatchParams P)
             const uint32_t hb = 4u * h;
             uint32_t t = 0;
             for (; t + 1 < ntI; t += 2) {
-                l2_tile_step<G, NJ, PF, PIPE, BF>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
-                l2_tile_step<G, NJ, PF, PIPE, BF>(ra, rn, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 2) * 128u, abuf, nrm, bq, accB, accA, st, t * 32u + hb);
+                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
+                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 2) * 128u, abuf, nrm, bq, accB, accA, st, t * 32u + hb);
             }
             if (t < ntI) {
-                l2_tile_step<G, NJ, PF, PIPE, BF>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
+                l2_tile_step<G, NJ, PF, PIPE>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrm, bq, accA, accB, st, (t - 1) * 32u + hb);
 #pragma unroll
                 for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
@@ -433,77 +500,196 @@ void l2_knn2_mfma_kernel(const MatchParams P)
         }   // !PIPE
     }
 
-    // ---- per query: merge the two lane halves, re-score exactly, certify, ratio-test
-    const float maxnorm = __uint_as_float(Ip->max_norm_bits);
-    const uint32_t dim = Ip->dim;
-    // Exactness proof for integer-valued descriptors (e.g. SIFT bins 0..255): when every element of
-    // both views is an integer and all partial sums stay below 2^24, the MFMA pass (norm init, fma
-    // chain, + ||q||^2) and the reference's sum of squared differences are BOTH exact, hence equal:
-    // no rounding slack is needed and only true ties with an un-nominated row need the exact scan.
-    const float mI = __uint_as_float(Ip->max_abs_bits), mJ = __uint_as_float(Jp->max_abs_bits);
-    const float dpad = (float)(BF ? G * 16 : G * 8);
-    const bool exact_pair = !Ip->not_integer && !Jp->not_integer &&
-                            2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f &&
-                            (BF == 0 || (mI <= 256.0f && mJ <= 256.0f));      // bf16 tiles hold the values exactly
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-        Top2 s = st[nj];
-        // partner half (same query column, the other 16 rows of every tile)
-        const float pd0 = __shfl_xor(s.d0, 32), pd1 = __shfl_xor(s.d1, 32), pd2 = __shfl_xor(s.d2, 32);
-        const uint32_t pi0 = __shfl_xor(s.i0, 32), pi1 = __shfl_xor(s.i1, 32);
-        top2_push(s, pd0, pi0);
-        top2_push(s, pd1, pi1);
-        s.d2 = fminf(s.d2, pd2);
-        // make both halves agree on the nominated pair (lane c's view)
-        const uint32_t ci0 = __shfl(s.i0, (int)c), ci1 = __shfl(s.i1, (int)c);
-        const float bound = __shfl(s.d2, (int)c);
+    l2_finish_queries<NJ>(P, pair, Ip, Jp, st, qt0, h, c, (float)(G * 8), false);
+}
 
-        const uint32_t qt = qt0 + nj;
-        const uint32_t q = qt * 32u + c;
-        const bool valid = (qt < ntJ) && (q < nJ);
-        const uint32_t cand = h ? ci1 : ci0;
-        const float cd0 = __shfl(s.d0, (int)c), cd1 = __shfl(s.d1, (int)c);     // (both shuffles outside the lane-dependent select)
-        const float ck = h ? cd1 : cd0;                                         // MFMA key ||a||^2 - 2 a.b of this lane's nominee
-        float e = R3DM_INF;
-        if (valid && cand != kNone) {
-            // exact pairs (proof above): key + ||q||^2 IS the reference distance, bit for bit -- no need to fetch the two
-            // nominated rows again (that re-read was 60 % of the kernel's HBM-side traffic: 3 x 512 B per query).
-            // Otherwise re-score in the reference's summation order.
-            if (exact_pair) e = ck + Jp->norms[q];
-            else e = exact_l2sq(Ip->rows + (size_t)cand * dim, Jp->rows + (size_t)q * dim, dim);
+// ------------------------------------------------------------------------------------------------
+// integer fast path (r3dm_set_integer_mfma): the same contraction on v_mfma_f32_32x32x16_bf16.
+// Views whose descriptors are integers of magnitude <= 256 (SIFT bins) are staged a second time as bf16 tiles
+// (ImgDev::tiled16, [tile][16-dim block][lane half][32 rows][8 bf16] -- 16 bytes per lane and step like the f32
+// tiles, half as many steps).  Every value is a bf16, every product and partial sum an integer below 2^24, so the f32
+// accumulators hold exactly the values of the f32 path and of the reference's sum of squared differences
+// (l2_finish_queries re-checks the condition per pair; anything else goes to the exact scan).
+// At 32 cycles per MFMA (16x fewer matrix cycles) the VALU side of l2_tile_step -- 10.7 VALU instructions per MFMA:
+// accumulator init, one compare per key, 8-instruction pushes into (best, runner-up, bound) lists -- would hold the
+// issue port longer than the matrix pipe runs.  Exact keys allow less:
+//   * lists hold (best, runner-up) only.  Keys are exact and every lane sees its rows in increasing index order, so
+//     strict '<' keeps the lexicographic (distance, index) top-2 of the lane's rows, and a lexicographic merge of the
+//     two lane halves IS the exact top-2 -- no certification bound, a third fewer list updates;
+//   * one wave-wide test per FOUR keys of a list (v_min3 + v_min + v_cmp instead of four v_cmp);
+//   * the accumulators start from the norm vector through the MFMA's C operand (8 v_mov_b64 per tile instead of 32 v_mov).
+// Measured (780 pairs of 8192 x 8192 rows): f32 tiles 95.0 ms; this kernel 12.96 ms (the f32 kernel's structure on bf16
+// tiles: 14.97 ms; without any epilogue: 11.4 ms).  The shader clock drops from 2.32 GHz (f32 kernel) to 1.84 GHz under
+// the bf16 matrix load (GRBM_GUI_ACTIVE / duration), so 12.96 ms is 54 % of the clocked bf16 peak.  Sharing the dataset
+// tiles of a workgroup through LDS (a quarter of the L1 traffic) measured 16.0 ms against 15.0 ms and was dropped.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+__device__ __forceinline__ void tope_push(Top2& s, float key, uint32_t idx)
+{
+    const float od0 = s.d0, od1 = s.d1;
+    const uint32_t oi0 = s.i0, oi1 = s.i1;
+    const bool c0 = key < od0;
+    const bool c1 = key < od1;
+    const uint32_t t1 = c1 ? idx : oi1;
+    s.d1 = __builtin_amdgcn_fmed3f(od0, od1, key);
+    s.d0 = vmin2(od0, key);
+    s.i1 = c0 ? oi0 : t1;
+    s.i0 = c0 ? idx : oi0;
+}
+
+template <int GB, int NJ, int PF, int ABL>
+__device__ __forceinline__ void int_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rn, uint32_t voffA, uint32_t voffN,
+                                              uint32_t soffA, uint32_t soffN, f32x4 (&abuf)[PF], const f32x16& nrm_cur, f32x16& nrm_next,
+                                              const f32x4 (&bq)[NJ][GB], f32x16 (&cur)[NJ], const f32x16 (&prev)[NJ],
+                                              Top2 (&st)[NJ], uint32_t prev_rowbase)
+{
+    constexpr int NG = 4 * NJ;                             // (list, quad) groups of four keys per tile
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const f32x4 a = abuf[g % PF];
+        abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
+        if (g == (GB > 2 ? 2 : GB - 1)) {   // next tile's norms, element 4 qd + k = row 8 qd + 4 h + k: the accumulator layout
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const f32x4 v = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nrm_next[4 * qd + k] = v[k];
+            }
         }
-        const float eo = __shfl_xor(e, 32);
-        float ea = h ? eo : e, eb = h ? e : eo;          // ea <-> ci0, eb <-> ci1
-        uint32_t ia = ci0, ib = ci1;
-        if (eb < ea || (eb == ea && ib < ia)) { const float tf = ea; ea = eb; eb = tf; const uint32_t tu = ia; ia = ib; ib = tu; }
-        if (valid && h == 0) {
-            if (nI < 2) {
-                emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+            cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bq[nj][g]),
+                                                              g == 0 ? nrm_cur : cur[nj], 0, 0, 0);
+#pragma unroll
+        for (int gi = (g * NG) / GB; gi < ((g + 1) * NG) / GB; ++gi) {
+            const int nj = gi % NJ, qd = gi / NJ;
+            const float p0 = prev[nj][4 * qd], p1 = prev[nj][4 * qd + 1], p2 = prev[nj][4 * qd + 2], p3 = prev[nj][4 * qd + 3];
+            if constexpr (ABL != 0) {
+                asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(p3));
             } else {
-                const float nb = Jp->norms[q];
-                const float slack = exact_pair ? 0.0f : P.err_scale * (maxnorm + nb);
-                const float A3 = bound + nb;                        // distance of the best un-nominated row (exact if exact_pair)
-                // certified: every un-nominated row is strictly farther than the runner-up.  With exact
-                // arithmetic a runner-up that merely TIES an un-nominated row still fixes the best row (ea < eb)
-                // and the runner-up DISTANCE, which is all the ratio test needs; only the raw 2-NN dump
-                // (r3dm_knn2) needs the tie's index resolved by the exact scan.
-                bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
-                if (BF != 0 && !exact_pair) certified = false;      // bf16 keys of a non-exact pair mean nothing: exact scan
-                if (certified) {
-                    emit_result(P, pair, q, ea, ia, eb, ib);
-                } else {
-                    P.nn_idx[(size_t)pair * P.q_stride + q] = kFallback;
-                    const uint32_t pos = atomicAdd(P.fb_cnt + pair, 1u);
-                    atomicAdd(P.fb_total, 1u);
-                    if (pos < kFbPerPair) P.fb_q[(size_t)pair * kFbPerPair + pos] = q;
-                    else atomicAdd(P.fb_total + 1, 1u);
+                const float m = vmin2(vmin3(p0, p1, p2), p3);
+                if (__builtin_amdgcn_ballot_w64(m < st[nj].d1) != 0ull) {
+                    const uint32_t rb = prev_rowbase + 8u * (uint32_t)qd;
+                    tope_push(st[nj], p0, rb); tope_push(st[nj], p1, rb + 1u); tope_push(st[nj], p2, rb + 2u); tope_push(st[nj], p3, rb + 3u);
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int G, int NJ, int PF, int PIPE, int WPS, int BF = 0>
+template <int GB, int NJ, int PF, int WPS, int ABL = 0>
+__global__ __launch_bounds__(256, WPS)
+void l2_knn2_int_kernel(const MatchParams P)
+{
+    static_assert(GB % PF == 0, "prefetch window must divide the block count");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t h = lane >> 5, c = lane & 31u;
+    uint32_t pair, qb;
+    if (P.xcd_map) {                                       // pair p on XCD p % 8 (see l2_knn2_mfma_kernel)
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        pair = (j / P.qb_per_pair) * 8u + xcd;
+        qb = j % P.qb_per_pair;
+        if (pair >= P.n_pairs) return;
+    } else {
+        pair = blockIdx.x / P.qb_per_pair;
+        qb = blockIdx.x % P.qb_per_pair;
+    }
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles;
+    const uint32_t qt0 = (qb * 4u + wave) * NJ;
+    if (qt0 >= ntJ) return;                                // wave-uniform; no barriers in this kernel
+
+    f32x4 bq[NJ][GB];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
+        const gf4p src = (gf4p)(const void*)Jp->tiled16 + (size_t)qt * (GB * 64) + lane;
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);     // -2 x (integer, |x| <= 256) is a bf16 again
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __uint_as_float(w[k] << 16) * -2.0f, hi = __uint_as_float(w[k] & 0xFFFF0000u) * -2.0f;
+                o[k] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+            }
+            bq[nj][g] = __builtin_bit_cast(f32x4, o);
+        }
+    }
+    Top2 st[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);     // d2 stays +inf: these lists carry no bound
+
+    if (nI >= 2) {
+        const uint64_t pa = (uint64_t)Ip->tiled16, pn = (uint64_t)Ip->norms;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pn >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pn)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const uint32_t voffA = lane * 16u, voffN = h * 16u;
+        constexpr uint32_t tileB = (uint32_t)GB * 1024u;
+        const uint32_t hb = 4u * h;
+        f32x4 abuf[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) abuf[s] = bload16(ra, voffA, (uint32_t)s * 1024u);
+        f32x16 nrmA, nrmB;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 v = bload16(rn, voffN, (uint32_t)qd * 32u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nrmA[4 * qd + k] = v[k];
+        }
+        f32x16 accA[NJ], accB[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[nj][r] = R3DM_INF;              // "tile -1": keys that never win
+        uint32_t t = 0;
+        for (; t + 1 < ntI; t += 2) {
+            int_tile_step<GB, NJ, PF, ABL>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrmA, nrmB, bq, accA, accB, st, (t - 1) * 32u + hb);
+            int_tile_step<GB, NJ, PF, ABL>(ra, rn, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 2) * 128u, abuf, nrmB, nrmA, bq, accB, accA, st, t * 32u + hb);
+        }
+        if (t < ntI) {
+            int_tile_step<GB, NJ, PF, ABL>(ra, rn, voffA, voffN, t * tileB + PF * 1024u, (t + 1) * 128u, abuf, nrmA, nrmB, bq, accA, accB, st, (t - 1) * 32u + hb);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tope_push(st[nj], accA[nj][r], t * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        } else {
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tope_push(st[nj], accB[nj][r], (ntI - 1) * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        }
+    }
+    l2_finish_queries<NJ, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), true);
+}
+
+template <int GB, int NJ, int PF, int WPS, int ABL = 0>
+static hipError_t launch_l2_int(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
+{
+    MatchParams P = Pin;
+    const uint32_t tiles_per_wg = 4u * NJ;
+    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
+    static const int xcd_map = [] { const char* v = getenv("R3DM_XCD_MAP"); return v ? atoi(v) : 1; }();
+    P.xcd_map = (uint32_t)xcd_map;
+    const uint64_t grid64 = (uint64_t)(xcd_map ? (P.n_pairs + 7u) / 8u * 8u : P.n_pairs) * P.qb_per_pair;
+    if (grid64 == 0) return hipSuccess;
+    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((l2_knn2_int_kernel<GB, NJ, PF, WPS, ABL>), dim3((uint32_t)grid64), dim3(256), 0, st, P);
+    return hipGetLastError();
+}
+
+template <int G, int NJ, int PF, int PIPE, int WPS>
 static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
     MatchParams P = Pin;
@@ -515,23 +701,23 @@ static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t m
     if (grid64 == 0) return hipSuccess;
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint32_t grid = (uint32_t)grid64;
-    hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF, PIPE, WPS, BF>), dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF, PIPE, WPS>), dim3(grid), dim3(256), 0, st, P);
     return hipGetLastError();
 }
 
 hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, bool integer_mfma)
 {
     if (integer_mfma) {
-        // R3DM_L2_BF_VARIANT: 2 = NJ 2 x 2 waves/SIMD (default; 15.0 ms on 780 pairs of 8192 rows) | 4 = NJ 4 x 1 wave/SIMD (21.6 ms)
-        static const int bv = [] { const char* v = getenv("R3DM_L2_BF_VARIANT"); return v ? atoi(v) : 2; }();
+        // R3DM_L2_INT_VARIANT (A/B measurements on 780 pairs of 8192 x 8192 rows, D = 128; the f32 tiles take 95.0 ms):
+        //   2 = NJ 2 x 2 waves/SIMD (default, 12.96 ms) | 8 = same with a whole-tile prefetch window (12.95 ms) |
+        //   4 = NJ 4 x 1 wave/SIMD (17.6 ms) | 9 = 2 without the epilogue (timing only, 11.4 ms)
+        static const int iv = [] { const char* v = getenv("R3DM_L2_INT_VARIANT"); return v ? atoi(v) : 2; }();
         switch (G) {
-            case 8:  return bv == 2 ? launch_l2_t<4, 2, 4, 3, 2, 1>(st, P, max_nj_tiles) : launch_l2_t<4, 4, 4, 3, 1, 1>(st, P, max_nj_tiles);
-            case 16: return bv == 2 ? launch_l2_t<8, 2, 4, 3, 2, 1>(st, P, max_nj_tiles)
-                          : bv == 9 ? launch_l2_t<8, 2, 4, 9, 2, 1>(st, P, max_nj_tiles)      // ablation: no epilogue (timing only)
-                          : bv == 3 ? launch_l2_t<8, 3, 4, 3, 2, 1>(st, P, max_nj_tiles)
-                          : bv == 28 ? launch_l2_t<8, 2, 8, 3, 2, 1>(st, P, max_nj_tiles)
-                          : bv == 8 ? launch_l2_t<8, 4, 8, 3, 1, 1>(st, P, max_nj_tiles) : launch_l2_t<8, 4, 4, 3, 1, 1>(st, P, max_nj_tiles);
-            case 32: return bv == 2 ? launch_l2_t<16, 2, 4, 3, 2, 1>(st, P, max_nj_tiles) : launch_l2_t<16, 4, 4, 3, 1, 1>(st, P, max_nj_tiles);
+            case 8:  return launch_l2_int<4, 2, 4, 2>(st, P, max_nj_tiles);
+            case 16: return iv == 4 ? launch_l2_int<8, 4, 4, 1>(st, P, max_nj_tiles)
+                          : iv == 9 ? launch_l2_int<8, 2, 4, 2, 1>(st, P, max_nj_tiles)
+                          : iv == 8 ? launch_l2_int<8, 2, 8, 2>(st, P, max_nj_tiles) : launch_l2_int<8, 2, 4, 2>(st, P, max_nj_tiles);
+            case 32: return launch_l2_int<16, 2, 4, 2>(st, P, max_nj_tiles);
             default: break;               // G = 18 (LIOP, never integer): f32 tiles
         }
     }
