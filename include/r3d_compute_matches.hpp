@@ -72,6 +72,8 @@ public:
     void addViews(const std::vector<View>& views);                 // stands in for addImages + sfm_data.bin
     void setRegionsType(r3dm_dtype dtype, uint32_t dim);           // default: float x 144 (R3D_AKAZE_LIOP_Regions)
     void setSeed(uint64_t seed) { seed_ = seed; }
+    // no reference counterpart: forwards r3dm_set_integer_mfma (bit-identical results, integer-valued descriptors only)
+    void setIntegerFastPath(bool on);
     // updateProgress(float, const wxString&) (src/R3DComputeMatches.cpp:2664): the GUI hook, called with the reference's own
     // fractions and messages (0.7 "Find putative matches", 0.8 / 0.9 / 0.95 "Calculate ... matrix", :2000,2107,2133,2209)
     using ProgressFn = void (*)(float progress, const char* msg, void* user);

@@ -135,6 +135,22 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     fp.pool_scratch = reinterpret_cast<uint32_t*>(c->f_scratch.as<unsigned char>() + 32 * (size_t)n_slice);
     fp.scratch_logc = reinterpret_cast<float*>(c->f_scratch.as<unsigned char>() + 36 * (size_t)n_slice);
     fp.soff = c->f_soff.as<uint64_t>();
+    // launch order: the workgroup of a pair runs for a time roughly proportional to its putative count, and a C2 call has
+    // ~1.5 x as many pairs as resident workgroups -- start the long ones first so the tail of the launch is short ones
+    {
+        static const int lpt = [] { const char* v = getenv("R3DM_FILTER_LPT"); return v ? atoi(v) : 1; }();
+        fp.order = nullptr;
+        if (lpt && NI > 1) {
+            std::vector<uint32_t> order(NI);
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                return begin_end[2 * a + 1] - begin_end[2 * a] > begin_end[2 * b + 1] - begin_end[2 * b]; });
+            R3DM_HIP(c, c->f_order.ensure(4 * (size_t)NI));
+            R3DM_HIP(c, hipMemcpyAsync(c->f_order.p, order.data(), 4 * (size_t)NI, hipMemcpyHostToDevice, c->stream));
+            R3DM_HIP(c, hipStreamSynchronize(c->stream));       // `order` leaves scope
+            fp.order = c->f_order.as<uint32_t>();
+        }
+    }
     if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { c->err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
     // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
     DevBuf trace_buf;

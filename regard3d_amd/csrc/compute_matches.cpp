@@ -93,6 +93,11 @@ R3DComputeMatches::~R3DComputeMatches() { if (ctx_) r3dm_destroy(ctx_); }
 
 void R3DComputeMatches::addViews(const std::vector<View>& views) { views_.insert(views_.end(), views.begin(), views.end()); }
 
+void R3DComputeMatches::setIntegerFastPath(bool on)
+{
+    if (ctx_) (void)r3dm_set_integer_mfma(ctx_, on ? 1 : 0);
+}
+
 void R3DComputeMatches::setRegionsType(r3dm_dtype dtype, uint32_t dim) { dtype_ = dtype; dim_ = dim; }
 
 bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,

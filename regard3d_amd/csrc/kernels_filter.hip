@@ -1031,14 +1031,17 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     }
 }
 
+// Two workgroups per CU for F and H (256 registers per lane; the F kernel trades 42 spilled VGPRs of its cold solver path
+// for the second workgroup: 40.0 -> 24.8 ms on the 790 pairs of C2, three per CU at 168 registers gains nothing more);
+// the E kernel's 5-point workspace (102 KiB LDS) allows one.
 template <int KIND>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, KIND == 2 ? 1 : 2)
 void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
                      uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MS = (KIND == 2) ? 90 : 27;
-    const uint32_t item = blockIdx.x;
+    const uint32_t item = P.order ? P.order[blockIdx.x] : blockIdx.x;
     const uint32_t m = (uint32_t)(P.offsets[2 * item + 1] - P.offsets[2 * item]);
     if (m <= P.m_cap) {
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + 1024 + kChunk * MS * 8);

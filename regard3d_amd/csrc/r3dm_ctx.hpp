@@ -106,7 +106,7 @@ struct r3dm_ctx {
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
-    DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff;
+    DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff, f_order;
     std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size
     int ak_w = 0, ak_h = 0;
     bool integer_mfma = false;                              // r3dm_set_integer_mfma

@@ -125,6 +125,7 @@ struct FilterParams {
     const uint2*  pairs;          // slot indices, one per work item
     const uint2*  pair_ids;       // view ids (I, J): keys of the sample stream
     const uint64_t* offsets;      // per work item: [2k] = begin, [2k+1] = end of its putative list inside `matches`
+    const uint32_t* order;        // launch order: workgroup b runs item order[b] (longest putative lists first), nullptr = identity
     const uint64_t* soff;         // per work item: start of its slice in the work arrays (multiples of 32 elements, m + 1 <= slice)
     const r3dm_match* matches;
     uint32_t      n_items;

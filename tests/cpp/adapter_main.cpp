@@ -83,6 +83,7 @@ int main(int argc, char** argv)
         // R3DM_TEST_ALGO selects the dispatch arm (default 9 = GPU brute force; 1..3 = KGraph presets)
         const char* algo_env = getenv("R3DM_TEST_ALGO");
         const int algo = algo_env ? atoi(algo_env) : r3d_amd::R3DComputeMatches::kMatchingAlgorithmGPU;
+        if (getenv("R3DM_TEST_INTEGER_MFMA")) stage.setIntegerFastPath(true);
         const bool ok = stage.computeMatches(params, true, paths, 1, algo);
         if (!ok) { fprintf(stderr, "computeMatches failed: %s\n", stage.errorMessage().c_str()); return 7; }
         printf("%zu %zu\n", stage.getStatistics().putativeMatches_.size(), stage.getStatistics().fundamentalMatches_.size());

@@ -130,6 +130,26 @@ def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_stage_facade_integer_fast_path_writes_the_same_files(host_exe, oracle, tmp_path):
+    """R3DComputeMatches::setIntegerFastPath on SIFT-like integer descriptors: byte-identical matches.putative / matches.f"""
+    sc = synth.make_scene(5, 1200, "sift", seed=31)
+    names = _write_views(oracle, str(tmp_path), sc)
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "128"] + names, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ref = {f: open(str(tmp_path / f), "rb").read() for f in ("matches.putative.bin", "matches.putative.txt", "matches.f.bin")}
+    r2 = subprocess.run([host_exe, "stage", str(tmp_path), "128"] + names, capture_output=True, text=True,
+                        env=dict(os.environ, R3DM_TEST_INTEGER_MFMA="1"))
+    assert r2.returncode == 0, r2.stderr
+    assert r2.stdout == r.stdout
+    for f, blob in ref.items():
+        assert open(str(tmp_path / f), "rb").read() == blob, f
+    pairs = sc.exhaustive_pairs()
+    counts, matches = oracle.match_collection(sc.descs, sc.xys, pairs, 0.6, True)
+    p, c, m = oracle.load_matches(str(tmp_path / "matches.putative.bin"))
+    assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
+
+
+@pytest.mark.gpu
 def test_features_facade_matches_oracle(host_exe, oracle, tmp_path):
     """Regard3DFeatures::detectAndExtract (include/regard3d_features.hpp) == CPU restatement of detect + LIOP"""
     rng = np.random.default_rng(3)
