@@ -137,3 +137,42 @@ def test_inputs_outside_the_proof_keep_the_f32_tiles(ictx, oracle):
     assert ictx.stats().n_integer_mfma == 0
     oidx, odist = oracle.knn2(a, b)
     assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+
+
+# ---- the collection-level edge cases of test_gpu_parity.py, repeated with the fast path switched on ------------------
+def _parity_module():
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("_gpu_parity_cases", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_ragged_and_empty_views(ictx, oracle):
+    _parity_module().test_match_ragged_and_empty_views(ictx, oracle)          # views of 37, 0 and 1 rows
+    assert ictx.stats().n_integer_mfma >= 1
+
+
+def test_coordinate_dedup(ictx, oracle):
+    _parity_module().test_match_coordinate_dedup(ictx, oracle)
+    assert ictx.stats().n_integer_mfma >= 1
+
+
+def test_exact_ties_duplicates_and_random_shapes(ictx, oracle):
+    P = _parity_module()
+    P.test_knn2_l2_exact_ties_and_duplicates(ictx, oracle)
+    P.test_knn2_random_shapes_sweep(ictx, oracle)       # a third of the trials are integer-valued: those take the bf16 tiles
+
+
+def test_collection_graphs_of_every_descriptor_kind(ictx, oracle):
+    P = _parity_module()
+    P.test_match_collection_graph(ictx, oracle, "sift", 6, 1024)
+    assert ictx.stats().n_integer_mfma >= 1
+    P.test_match_collection_graph(ictx, oracle, "liop", 5, 700)               # real-valued: f32 tiles
+    assert ictx.stats().n_integer_mfma == 0
+    P.test_match_collection_graph(ictx, oracle, "akaze", 6, 1000)             # binary: Hamming kernel
+    assert ictx.stats().n_integer_mfma == 0
+
+
+def test_views_beyond_the_lds_sort_budget(ictx, oracle):
+    _parity_module().test_views_beyond_the_lds_sort_budget(ictx, oracle, 20000, 1.0)
