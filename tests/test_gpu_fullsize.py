@@ -120,3 +120,33 @@ def test_filters_are_deterministic_when_workgroups_share_a_cu(ctx, oracle):
         exp = omh[o:o + oh[k]]; o += oh[k]
         got = d.get((int(I), int(J)), np.zeros((0, 2), np.uint32))
         assert set(map(tuple, got.tolist())) == set(map(tuple, exp.tolist())), (I, J)
+
+
+def test_bench_contract_one_and_two_ranks(tmp_path):
+    """bench.py as the driver launches it: N = 1 directly, N = 2 through torch.distributed.run (two ranks on the one GPU
+    of this box, graphs exchanged through gloo -- the RCCL branch differs only in the tensors' device).  Checks the JSON
+    contract and that the sharded run reassembles the graph the single-rank run of the same collection produces."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "1", "--feat", "1024", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--images", "17"] + common,
+                         capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in j1, key
+    assert j1["n_gpus"] == 1 and j1["config"]["pairs"] == 17 * 16 // 2 and j1["roofline"]["achieved"] > 0
+    assert j1["opt_in_integer_mfma"]["identical_to_headline_graphs"] is True and j1["opt_in_integer_mfma"]["integer_mfma_launches"] == 1
+    env = dict(os.environ, R3DM_SHARE_GPU="1", R3DM_DIST_BACKEND="gloo")
+    port = 29600 + os.getpid() % 300
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--images", "12"] + common, capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    # weak scaling: 2 ranks x C(12,2) = 132 pairs -> 17 images (136 pairs), the same collection as the N = 1 run above
+    assert j2["n_gpus"] == 2 and j2["config"]["images"] == 17 and j2["config"]["pairs"] == 136 and j2["scaling"] == "weak"
+    assert 0 < j2["config"]["pairs_this_rank"] < 136
+    for k in ("putative_pairs", "putative_matches", "F_pairs", "F_matches"):
+        assert j2["detail"][k] == j1["detail"][k], k
