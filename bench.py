@@ -173,6 +173,10 @@ def main():
                          "unit": "TFLOP/s", "frac": ach2 / BF16_MFMA_PEAK_TFLOPS, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
             "filter_kernel_ms": sa2.ms_filter_kernels,
         }
+    if world == 1 and os.path.exists(tpath) and "opt_in_integer_mfma" in out:
+        ti = json.load(open(tpath)).get("integer_fast_path")
+        if ti and json.load(open(tpath)).get("workload_pairs") == int(total_pairs) and a.feat == 8192:
+            out["opt_in_integer_mfma"]["roofline"]["traffic"] = ti["traffic_bytes_per_launch"]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(descs, xys, g, gf, a.cpu_seconds)
     if rank == 0:
