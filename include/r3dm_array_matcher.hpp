@@ -63,6 +63,8 @@ public:
 
     explicit ArrayMatcher_r3dm(int device_id = 0) { if (r3dm_create(device_id, &ctx_) != R3DM_OK) ctx_ = nullptr; }
     virtual ~ArrayMatcher_r3dm() { if (ctx_) r3dm_destroy(ctx_); }
+    // not part of the ArrayMatcher interface: forwards r3dm_set_integer_mfma (same results, integer-valued float rows only)
+    void setIntegerFastPath(bool on) { if (ctx_) (void)r3dm_set_integer_mfma(ctx_, on ? 1 : 0); }
     ArrayMatcher_r3dm(const ArrayMatcher_r3dm&) = delete;
     ArrayMatcher_r3dm& operator=(const ArrayMatcher_r3dm&) = delete;
 
