@@ -137,6 +137,7 @@ def main():
                      "flops_per_launch": kernel_flops / max(launches, 1), "launches": int(launches)},
         "detail": {"filter_kernel_ms_per_step": filter_ms / a.steps, "match_kernel_ms_per_step": kernel_ms / a.steps,
                    "wall_ms_per_step": {k: v / a.steps for k, v in wall.items()},
+                   "match_only_pairs_per_s_this_rank": (mine.shape[0] * a.steps / (wall["match"] * 1e-3)) if wall["match"] > 0 else None,
                    "exact_fallback_queries_per_step": fallback / a.steps, "queries_per_step": queries / a.steps,
                    "putative_pairs": int(full[0].num_pairs), "putative_matches": int(full[0].num_matches),
                    "F_pairs": int(full[1].num_pairs), "F_matches": int(full[1].num_matches)},
