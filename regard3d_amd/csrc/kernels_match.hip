@@ -229,8 +229,8 @@ __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const f32x4 a = abuf[g % PF];
-        if constexpr (PIPE != 7 && PIPE != 8) abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
-        if ((PIPE != 7 && PIPE != 8) && g == 2) {   // next tile's norms: early, so the wait at the tile boundary finds them landed
+        abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
+        if (g == 2) {   // next tile's norms: early, so the wait at the tile boundary finds them landed
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) nrm[qd] = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
         }
@@ -242,13 +242,13 @@ __device__ __forceinline__ void l2_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu
                 cur[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cc], bq[nj][g][cc], cur[nj], 0, 0, 0);
         if constexpr (PIPE == 4) __builtin_amdgcn_s_setprio(0);
         // this group's share of the previous tile's 16 accumulator values per query tile
-        if constexpr (PIPE == 9 || PIPE == 7) {
+        if constexpr (PIPE == 9) {
             // ablation (timing only, results meaningless): keep the accumulators alive, skip the epilogue
 #pragma unroll
             for (int r = (g * 16) / G; r < ((g + 1) * 16) / G; ++r)
 #pragma unroll
                 for (int nj = 0; nj < NJ; ++nj) asm volatile("" ::"v"(prev[nj][r]));
-        } else if constexpr (PIPE == 3 || PIPE == 8) {
+        } else if constexpr (PIPE == 3) {
             // test-and-skip: a value can only change a list if it is below that lane's bound d2; once the
             // lists have warmed up that is rare, so one wave-wide test guards the whole slice
             bool any = false;
@@ -730,11 +730,7 @@ hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint
             case 0:  return launch_l2_t<16, 2, 4, 0, 2>(st, P, max_nj_tiles);
             case 1:  return launch_l2_t<16, 2, 4, 1, 2>(st, P, max_nj_tiles);
             case 9:  return launch_l2_t<16, 2, 4, 9, 2>(st, P, max_nj_tiles);
-            case 7:  return launch_l2_t<16, 2, 4, 7, 2>(st, P, max_nj_tiles);
-            case 8:  return launch_l2_t<16, 2, 4, 8, 2>(st, P, max_nj_tiles);
             case 13: return launch_l2_t<16, 1, 4, 3, 3>(st, P, max_nj_tiles);
-            case 18: return launch_l2_t<16, 1, 8, 3, 3>(st, P, max_nj_tiles);
-            case 19: return launch_l2_t<16, 1, 16, 3, 2>(st, P, max_nj_tiles);
             case 43: return launch_l2_t<16, 4, 4, 3, 1>(st, P, max_nj_tiles);
             default: return launch_l2_t<16, 2, 4, 3, 2>(st, P, max_nj_tiles);
         }

@@ -26,6 +26,15 @@ bd = gb.as_dict()
 nb = gb.num_matches
 print(json.dumps(dict(method="exhaustive", pairs=len(pairs), s=tb, pairs_per_s=len(pairs) / tb, ms_kernel=sb.ms_match_kernels,
                       matches=nb)), flush=True)
+# the same exhaustive matcher on the opt-in integer fast path (bf16-exact MFMA tiles, identical matches)
+c.set_integer_mfma(True)
+c.match_pairs(pairs[:4], 0.6, True)
+t = time.time(); gi = c.match_pairs(pairs, 0.6, True); ti = time.time() - t
+si = c.stats()
+c.set_integer_mfma(False)
+print(json.dumps(dict(method="exhaustive-integer-mfma", pairs=len(pairs), s=ti, pairs_per_s=len(pairs) / ti, ms_kernel=si.ms_match_kernels,
+                      ms_kernel_per_pair=si.ms_match_kernels / len(pairs), launches_on_bf16_tiles=si.n_integer_mfma,
+                      identical=bool(np.array_equal(gi.matches, gb.matches) and np.array_equal(gi.offsets, gb.offsets)))), flush=True)
 for name in a.presets.split(","):
     kp = api.KGraphParams.preset(name)
     if a.S: kp.search_S = a.S
