@@ -518,9 +518,10 @@ void l2_knn2_mfma_kernel(const MatchParams P)
 //     two lane halves IS the exact top-2 -- no certification bound, a third fewer list updates;
 //   * one wave-wide test per FOUR keys of a list (v_min3 + v_min + v_cmp instead of four v_cmp);
 //   * the accumulators start from the norm vector through the MFMA's C operand (8 v_mov_b64 per tile instead of 32 v_mov).
-// Measured (780 pairs of 8192 x 8192 rows): f32 tiles 95.0 ms; this kernel 12.96 ms (the f32 kernel's structure on bf16
+// Measured (780 pairs of 8192 x 8192 rows): f32 tiles 95.0 ms; this kernel 12.4 ms (12.96 before the per-key tests in the
+// update path) (the f32 kernel's structure on bf16
 // tiles: 14.97 ms; without any epilogue: 11.4 ms).  The shader clock drops from 2.32 GHz (f32 kernel) to 1.84 GHz under
-// the bf16 matrix load (GRBM_GUI_ACTIVE / duration), so 12.96 ms is 54 % of the clocked bf16 peak.  Sharing the dataset
+// the bf16 matrix load (GRBM_GUI_ACTIVE / duration), so 12.4 ms is 56 % of the clocked bf16 peak.  Sharing the dataset
 // tiles of a workgroup through LDS (a quarter of the L1 traffic) measured 16.0 ms against 15.0 ms and was dropped.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -572,8 +573,13 @@ __device__ __forceinline__ void int_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgp
             } else {
                 const float m = vmin2(vmin3(p0, p1, p2), p3);
                 if (__builtin_amdgcn_ballot_w64(m < st[nj].d1) != 0ull) {
+                    // some lane improves on one of the four keys: usually ONE key does, so test each before its 7-instruction push
+                    // (the 16-step body of D = 256 stays with unconditional pushes: the compiler gives up unrolling the larger one)
                     const uint32_t rb = prev_rowbase + 8u * (uint32_t)qd;
-                    tope_push(st[nj], p0, rb); tope_push(st[nj], p1, rb + 1u); tope_push(st[nj], p2, rb + 2u); tope_push(st[nj], p3, rb + 3u);
+                    if (GB > 8 || __builtin_amdgcn_ballot_w64(p0 < st[nj].d1) != 0ull) tope_push(st[nj], p0, rb);
+                    if (GB > 8 || __builtin_amdgcn_ballot_w64(p1 < st[nj].d1) != 0ull) tope_push(st[nj], p1, rb + 1u);
+                    if (GB > 8 || __builtin_amdgcn_ballot_w64(p2 < st[nj].d1) != 0ull) tope_push(st[nj], p2, rb + 2u);
+                    if (GB > 8 || __builtin_amdgcn_ballot_w64(p3 < st[nj].d1) != 0ull) tope_push(st[nj], p3, rb + 3u);
                 }
             }
         }
@@ -709,7 +715,7 @@ hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint
 {
     if (integer_mfma) {
         // R3DM_L2_INT_VARIANT (A/B measurements on 780 pairs of 8192 x 8192 rows, D = 128; the f32 tiles take 95.0 ms):
-        //   2 = NJ 2 x 2 waves/SIMD (default, 12.96 ms) | 8 = same with a whole-tile prefetch window (12.95 ms) |
+        //   2 = NJ 2 x 2 waves/SIMD (default, 12.4 ms) | 8 = same with a whole-tile prefetch window (12.95 ms) |
         //   4 = NJ 4 x 1 wave/SIMD (17.6 ms) | 9 = 2 without the epilogue (timing only, 11.4 ms)
         static const int iv = [] { const char* v = getenv("R3DM_L2_INT_VARIANT"); return v ? atoi(v) : 2; }();
         switch (G) {
