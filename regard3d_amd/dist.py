@@ -52,13 +52,16 @@ def _unpack(buf: np.ndarray) -> api.Graph:
     return api.Graph.from_csr(p, o, m)
 
 
-def all_gather_graphs(local: Sequence[api.Graph], device=None, group=None) -> List[api.Graph]:
+def all_gather_graphs(local: Sequence[api.Graph], device=None, group=None, force_collective: bool = False) -> List[api.Graph]:
     """ONE exchange step for several graphs of this rank (e.g. putative + F-filtered): every rank ends
-    up with the union over ranks of each graph, ordered by (I, J)."""
+    up with the union over ranks of each graph, ordered by (I, J).  force_collective runs the exchange even in a
+    one-rank group (test hook: exercises the RCCL tensor path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(local)
+    if dist.get_world_size(group) == 1 and not force_collective:
         return list(local)
     world = dist.get_world_size(group)
     dev = torch.device(device) if device is not None else torch.device("cpu")

@@ -150,3 +150,33 @@ def test_bench_contract_one_and_two_ranks(tmp_path):
     assert 0 < j2["config"]["pairs_this_rank"] < 136
     for k in ("putative_pairs", "putative_matches", "F_pairs", "F_matches"):
         assert j2["detail"][k] == j1["detail"][k], k
+
+
+def test_graph_exchange_over_rccl_single_rank(tmp_path):
+    """The exchange of regard3d_amd/dist.py with backend "nccl" (= RCCL) and device tensors, in a one-rank group on this
+    box's GPU: the same torch.distributed calls, dtypes and devices as the N > 1 bench path (the world_size-2 run of the
+    same code is tests/test_dist_gloo.py on CPU)."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {root!r})
+        import numpy as np, torch, torch.distributed as td
+        from regard3d_amd import api, dist, synth
+        torch.cuda.set_device(0)
+        td.init_process_group("nccl", init_method="tcp://127.0.0.1:{29700 + os.getpid() % 200}", rank=0, world_size=1,
+                              device_id=torch.device("cuda", 0))
+        sc = synth.make_scene(6, 700, "sift", seed=1001)
+        ctx = api.Context(0)
+        for i in range(sc.n_images):
+            ctx.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000)
+        g = ctx.match_pairs(sc.exhaustive_pairs(), 0.6, True)
+        gf = ctx.filter_F(g, 4.0, 2048, seed=5489)
+        out = dist.all_gather_graphs([g, gf], device=torch.device("cuda", 0), force_collective=True)
+        for a, b in zip((g, gf), out):
+            assert np.array_equal(a.pairs, b.pairs) and np.array_equal(a.offsets, b.offsets) and np.array_equal(a.matches, b.matches)
+        assert g.num_matches > 0 and gf.num_pairs > 0
+        td.barrier(); td.destroy_process_group()
+        print("rccl exchange ok", g.num_pairs, gf.num_pairs)
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl exchange ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
