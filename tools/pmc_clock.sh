@@ -1,6 +1,6 @@
 # effective shader clock during the L2 kernels: GRBM_GUI_ACTIVE cycles / kernel duration
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-rm -rf /tmp/pc; R3DM_L2_BF_VARIANT=${1:-202} timeout 90 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc -- python tools/gpu_perf.py --images 16 --feat 8192 --reps 0 --integer-mfma > /tmp/pc.log 2>&1
+rm -rf /tmp/pc; R3DM_L2_INT_VARIANT=${1:-2} timeout 90 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc -- python tools/gpu_perf.py --images 16 --feat 8192 --reps 0 --integer-mfma > /tmp/pc.log 2>&1
 python - <<'PY' | tee gpurun_out/pmc_clock.txt
 import csv, glob
 cc = glob.glob('/tmp/pc/**/*counter_collection.csv', recursive=True)[0]
