@@ -303,14 +303,21 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     // ---- gather in (level, list) order; angle = getAngleV2(maxX, maxY) then the detectKeypoints conversion (:604-613)
     uint32_t n_kp = 0;
     std::vector<AkMldbItem> items;
+    // all levels' results are copied back behind the refinement kernel with ONE stream synchronisation
+    std::vector<std::vector<float4>> all0(nl); std::vector<std::vector<float2>> all1(nl); std::vector<std::vector<uint32_t>> allv(nl);
     for (int i = 0; i < nl; ++i) {
         const uint32_t n = counts[4 * i + 1];
         if (!n) continue;
-        std::vector<float4> o0(n); std::vector<float2> o1(n); std::vector<uint32_t> ov(n);
-        R3DM_HIP(c, hipMemcpyAsync(o0.data(), ld[i].out0, n * 16, hipMemcpyDeviceToHost, st));
-        R3DM_HIP(c, hipMemcpyAsync(o1.data(), ld[i].out1, n * 8, hipMemcpyDeviceToHost, st));
-        R3DM_HIP(c, hipMemcpyAsync(ov.data(), ld[i].out_valid, n * 4, hipMemcpyDeviceToHost, st));
-        R3DM_HIP(c, hipStreamSynchronize(st));
+        all0[i].resize(n); all1[i].resize(n); allv[i].resize(n);
+        R3DM_HIP(c, hipMemcpyAsync(all0[i].data(), ld[i].out0, n * 16, hipMemcpyDeviceToHost, st));
+        R3DM_HIP(c, hipMemcpyAsync(all1[i].data(), ld[i].out1, n * 8, hipMemcpyDeviceToHost, st));
+        R3DM_HIP(c, hipMemcpyAsync(allv[i].data(), ld[i].out_valid, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    R3DM_HIP(c, hipStreamSynchronize(st));
+    for (int i = 0; i < nl; ++i) {
+        const uint32_t n = counts[4 * i + 1];
+        if (!n) continue;
+        const std::vector<float4>& o0 = all0[i]; const std::vector<float2>& o1 = all1[i]; const std::vector<uint32_t>& ov = allv[i];
         for (uint32_t j = 0; j < n; ++j) {
             if (!ov[j]) continue;
             if (n_kp < cap) {
