@@ -571,7 +571,10 @@ __device__ __forceinline__ void int_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgp
             if constexpr (ABL != 0) {
                 asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(p3));
             } else {
-                const float m = vmin2(vmin3(p0, p1, p2), p3);
+                // Step 0 may follow the previous tile's last MFMAs (the writers of p0..p3) closely: its minimum goes through
+                // ordinary fminf so that the compiler's MFMA -> VALU hazard pass sees the read; from step 1 on at least NJ
+                // MFMAs and a sched_barrier lie in between and the two-instruction asm form is safe.
+                const float m = g == 0 ? __builtin_fminf(__builtin_fminf(p0, p1), __builtin_fminf(p2, p3)) : vmin2(vmin3(p0, p1, p2), p3);
                 if (__builtin_amdgcn_ballot_w64(m < st[nj].d1) != 0ull) {
                     // some lane improves on one of the four keys: usually ONE key does, so test each before its 7-instruction push
                     // (the 16-step body of D = 256 stays with unconditional pushes: the compiler gives up unrolling the larger one)
