@@ -348,23 +348,33 @@ void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels)
 __global__ __launch_bounds__(256)
 void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mode)
 {
+    // killers are staged through LDS 256 at a time (one coalesced load per chunk instead of one dependent scalar load per
+    // killer and thread: the old loop was latency-bound, 0.52 ms per call on a 4000 x 3000 image)
+    __shared__ float4 sk[256];
+    __shared__ unsigned char sdead[256];
     const int vi = blockIdx.y;                                   // victim level
     const int ki = mode == 0 ? vi + 1 : vi - 1;                  // killer level
     if (ki < 0 || ki >= n_levels) return;
     const AkLevelDev V = levels[vi], K = levels[ki];
     const uint32_t nv = V.counts[1], nk = K.counts[1];
+    if (blockIdx.x * 256u >= nv) return;                         // workgroup-uniform: before any barrier
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nv) return;
-    const float4 v = V.list[q];
+    const float4 v = q < nv ? V.list[q] : make_float4(0, 0, 0, 0);
     const float r = mode == 0 ? K.psize : V.psize, r2 = r * r;
     bool dead = false;
-    for (uint32_t j = 0; j < nk && !dead; ++j) {
-        const float4 p = K.list[j];
-        if (mode == 1 && K.dead_lower[j]) continue;
-        const float dx = p.x - v.x, dy = p.y - v.y;
-        dead = (dx * dx + dy * dy <= r2) && (p.z > v.z);
+    for (uint32_t j0 = 0; j0 < nk; j0 += 256) {
+        const uint32_t j = j0 + threadIdx.x;
+        if (j < nk) { sk[threadIdx.x] = K.list[j]; sdead[threadIdx.x] = (mode == 1 && K.dead_lower[j]) ? 1 : 0; }
+        r3dm_syncthreads();
+        const uint32_t cnt = nk - j0 < 256u ? nk - j0 : 256u;
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const float4 p = sk[t];
+            const float dx = p.x - v.x, dy = p.y - v.y;
+            dead |= !sdead[t] && (dx * dx + dy * dy <= r2) && (p.z > v.z);
+        }
+        r3dm_syncthreads();
     }
-    (mode == 0 ? V.dead_lower : V.dead_upper)[q] = dead ? 1 : 0;
+    if (q < nv) (mode == 0 ? V.dead_lower : V.dead_upper)[q] = dead ? 1 : 0;
 }
 
 // ---- sub-pixel refinement + dominant gradient direction (Do_Subpixel_Refinement, Compute_Main_Orientation up to the
