@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256)
 void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mode)
 {
     // killers are staged through LDS 256 at a time (one coalesced load per chunk instead of one dependent scalar load per
-    // killer and thread: the old loop was latency-bound, 0.52 ms per call on a 4000 x 3000 image)
+    // killer and thread: the old loop was latency-bound, 0.52 ms per call on a 4000 x 3000 image); the chunks are dealt to
+    // gridDim.z workgroups, each of which only ever STORES a 1 into the (zero-initialised) flag array
     __shared__ float4 sk[256];
     __shared__ unsigned char sdead[256];
     const int vi = blockIdx.y;                                   // victim level
@@ -362,7 +363,7 @@ void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mo
     const float4 v = q < nv ? V.list[q] : make_float4(0, 0, 0, 0);
     const float r = mode == 0 ? K.psize : V.psize, r2 = r * r;
     bool dead = false;
-    for (uint32_t j0 = 0; j0 < nk; j0 += 256) {
+    for (uint32_t j0 = blockIdx.z * 256u; j0 < nk; j0 += 256u * gridDim.z) {
         const uint32_t j = j0 + threadIdx.x;
         if (j < nk) { sk[threadIdx.x] = K.list[j]; sdead[threadIdx.x] = (mode == 1 && K.dead_lower[j]) ? 1 : 0; }
         r3dm_syncthreads();
@@ -374,7 +375,7 @@ void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mo
         }
         r3dm_syncthreads();
     }
-    if (q < nv) (mode == 0 ? V.dead_lower : V.dead_upper)[q] = dead ? 1 : 0;
+    if (q < nv && dead) (mode == 0 ? V.dead_lower : V.dead_upper)[q] = 1;
 }
 
 // ---- sub-pixel refinement + dominant gradient direction (Do_Subpixel_Refinement, Compute_Main_Orientation up to the
@@ -645,7 +646,7 @@ hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_level
 hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list, int mode)
 {
     if (max_list == 0) return hipSuccess;
-    hipLaunchKernelGGL(ak_cross_kernel, dim3((max_list + 255) / 256, (unsigned)n_levels), dim3(256), 0, st, levels, n_levels, mode);
+    hipLaunchKernelGGL(ak_cross_kernel, dim3((max_list + 255) / 256, (unsigned)n_levels, 8), dim3(256), 0, st, levels, n_levels, mode);
     return hipGetLastError();
 }
 hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list)
