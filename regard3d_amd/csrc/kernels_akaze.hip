@@ -290,8 +290,10 @@ __device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_ca
         const uint32_t nb = (n_cand - c0 < 64u) ? n_cand - c0 : 64u;
         for (uint32_t k = 0; k < nb; ++k) {
             const float px = __shfl(mine.x, (int)k), py = __shfl(mine.y, (int)k), pr = __shfl(mine.z, (int)k);
-            if (py != cur_row) {
-                // new scan line: drop live entries that no later candidate can reach
+            if (py != cur_row && n_live >= 48u) {
+                // new scan line and the live set is about to need a second 64-entry scan: drop the entries that no later
+                // candidate can reach (they can never match -- their rows are more than one radius behind -- so leaving them
+                // in while the set is small changes nothing but saves this pass on most scan lines)
                 cur_row = py;
                 uint32_t w = 0;
                 for (uint32_t b = 0; b < n_live; b += 64) {
