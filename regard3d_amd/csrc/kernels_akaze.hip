@@ -278,8 +278,10 @@ void ak_scan_rows_kernel(const AkLevelDev* __restrict__ levels)
 // kept point = the first one in list order.  A slot's row never decreases, so only slots within one radius of the scan
 // line can still match: that live set is kept in LDS, in list order.  One wavefront per level.
 constexpr int kAkLive = 3072;
+// Returns false (LDS variant only) if the live set outgrows its kAkLive slots even right after a compaction; the caller then
+// redoes the level with the live set in global scratch (the list is rebuilt from its start, nothing else was written).
 template <bool GLOBAL_LIVE, class FP, class UP>
-__device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_cand, FP lx, FP ly, FP lr, UP lslot)
+__device__ __forceinline__ bool ak_prune_body(const AkLevelDev& L, uint32_t n_cand, FP lx, FP ly, FP lr, UP lslot, uint32_t live_cap)
 {
     const int lane = threadIdx.x;
     const float size = L.psize, size2 = size * size;
@@ -290,7 +292,7 @@ __device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_ca
         const uint32_t nb = (n_cand - c0 < 64u) ? n_cand - c0 : 64u;
         for (uint32_t k = 0; k < nb; ++k) {
             const float px = __shfl(mine.x, (int)k), py = __shfl(mine.y, (int)k), pr = __shfl(mine.z, (int)k);
-            if (py != cur_row && n_live >= 48u) {
+            if ((py != cur_row && n_live >= 48u) || (!GLOBAL_LIVE && n_live >= live_cap)) {
                 // new scan line and the live set is about to need a second 64-entry scan: drop the entries that no later
                 // candidate can reach (they can never match -- their rows are more than one radius behind -- so leaving them
                 // in while the set is small changes nothing but saves this pass on most scan lines)
@@ -323,6 +325,7 @@ __device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_ca
                     if (lane == 0) { lx[found] = px; ly[found] = py; lr[found] = pr; L.list[lslot[found]] = make_float4(px, py, pr, 1.0f); }
                 }
             } else {
+                if (!GLOBAL_LIVE && n_live >= live_cap) return false;       // (wave-uniform) still full after the compaction above
                 if (lane == 0) { lx[n_live] = px; ly[n_live] = py; lr[n_live] = pr; lslot[n_live] = n_list; L.list[n_list] = make_float4(px, py, pr, 1.0f); }
                 ++n_live; ++n_list;
             }
@@ -330,18 +333,20 @@ __device__ __forceinline__ void ak_prune_body(const AkLevelDev& L, uint32_t n_ca
         }
     }
     if (lane == 0) L.counts[1] = n_list;
+    return true;
 }
 
 __global__ __launch_bounds__(64)
-void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels)
+void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels, uint32_t live_cap)
 {
     __shared__ float lx[kAkLive], ly[kAkLive], lr[kAkLive];
     __shared__ uint32_t lslot[kAkLive];
     const AkLevelDev L = levels[blockIdx.x];
     const uint32_t n_cand = L.counts[0];
-    // the live set never holds more entries than there are candidates: small levels stay in LDS, the rest use scratch
-    if (n_cand <= (uint32_t)kAkLive) ak_prune_body<false>(L, n_cand, lx, ly, lr, lslot);
-    else ak_prune_body<true>(L, n_cand, L.live, L.live + n_cand, L.live + 2 * (size_t)n_cand, (uint32_t*)(L.live + 3 * (size_t)n_cand));
+    // The live set holds the kept points within one radius of the scan line: a few dozen in practice, so it lives in LDS;
+    // only if it ever outgrows kAkLive slots (bounded by the candidate count alone) is the level redone with it in scratch.
+    if (!ak_prune_body<false>(L, n_cand, lx, ly, lr, lslot, live_cap))
+        ak_prune_body<true>(L, n_cand, L.live, L.live + n_cand, L.live + 2 * (size_t)n_cand, (uint32_t*)(L.live + 3 * (size_t)n_cand), 0u);
 }
 
 // ---- cross-level pruning.  mode 0 ("lower"): a point q of level i-1 dies when some point p of level i lies within
@@ -642,7 +647,9 @@ hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels)
 }
 hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels)
 {
-    hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)n_levels), dim3(64), 0, st, levels);
+    // R3DM_AK_LIVE_CAP (test hook): a small LDS capacity forces the global-scratch fallback of the in-level pruning
+    static const uint32_t live_cap = [] { const char* v = getenv("R3DM_AK_LIVE_CAP"); const int c = v ? atoi(v) : kAkLive; return (uint32_t)(c < 1 ? 1 : c > kAkLive ? kAkLive : c); }();
+    hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)n_levels), dim3(64), 0, st, levels, live_cap);
     return hipGetLastError();
 }
 hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list, int mode)

@@ -48,13 +48,31 @@ def test_detect_then_describe_is_the_reference_pipeline(ctx, oracle):
 
 
 def test_many_extrema_take_the_scratch_path(ctx, oracle):
-    """white noise at a tiny threshold: more candidates per level than the LDS live set holds"""
+    """white noise at a tiny threshold: far more candidates per level than the 3072 live-set slots (the live set itself stays small)"""
     rng = np.random.default_rng(8)
     img = np.clip(0.5 + rng.normal(0, 0.2, (700, 900)), 0, 1).astype(np.float32)
     kps, resp = ctx.detect_akaze(img, 1e-7)
     ref = oracle.akaze_detect(img, 1e-7)
     assert len(kps) == len(ref["kps"]) and len(kps) > 4000
     assert np.array_equal(kps, ref["kps"]) and np.array_equal(resp, ref["responses"])
+
+
+def test_live_set_overflow_falls_back_to_scratch(ctx, tmp_path):
+    """R3DM_AK_LIVE_CAP=8 (test hook) makes the LDS live set of the in-level pruning overflow on every level, so each level is
+    redone with the live set in global scratch: the keypoints must not change."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(8)
+    img = np.clip(0.5 + rng.normal(0, 0.2, (500, 700)), 0, 1).astype(np.float32)
+    kps, resp = ctx.detect_akaze(img, 1e-6)
+    assert len(kps) > 2000
+    np.save(str(tmp_path / "img.npy"), img)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np; from regard3d_amd import api; "
+            f"c = api.Context(0); k, r = c.detect_akaze(np.load({str(tmp_path / 'img.npy')!r}), 1e-6); "
+            f"np.save({str(tmp_path / 'k.npy')!r}, k); np.save({str(tmp_path / 'r.npy')!r}, r)")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, R3DM_AK_LIVE_CAP="8"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(str(tmp_path / "k.npy")), kps) and np.array_equal(np.load(str(tmp_path / "r.npy")), resp)
 
 
 def test_blank_and_tiny_images(ctx):
