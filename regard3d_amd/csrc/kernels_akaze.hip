@@ -79,33 +79,34 @@ void ak_scharr_cols_kernel(const float* __restrict__ rd, const float* __restrict
     Ly[(size_t)y * w + x] = rs[(size_t)yd * w + x] - rs[(size_t)yu * w + x];
 }
 
-// ---- multiscale Scharr derivative (taps at -s, 0, +s), BORDER_REFLECT_101
-__global__ __launch_bounds__(256)
-void ak_sderiv_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
+// ---- multiscale Scharr derivative (taps at -s, 0, +s), BORDER_REFLECT_101: the reference's row pass and column pass
+// (sepFilter2D) in ONE kernel.  Every output pixel recomputes the row-filtered values it needs (2 or 3 rows x 2 or 3 taps,
+// served by L1/L2) with exactly the operations of the two-pass form, so the result is bit-identical while the intermediate
+// image and half of the launches disappear (160 -> 80 launches per 4000 x 3000 image).
+__device__ __forceinline__ float ak_sderiv_row(const float* __restrict__ S, int x, int w, int s, int dx)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
     const float wgt = 10.0f / 3.0f;
     const float norm = 1.0f / (2.0f * (wgt + 2.0f));
     const float kc = wgt * norm;
-    const float* S = src + (size_t)y * w;
     const float a = S[ak_refl101(x - s, w)], b = S[ak_refl101(x + s, w)];
-    float v;
-    if (dx) v = (-a) + b;
-    else if (s == 2) v = S[x] * kc + (a + b) * norm;
-    else v = (norm * a + kc * S[x]) + norm * b;
-    dst[(size_t)y * w + x] = v;
+    if (dx) return (-a) + b;
+    if (s == 2) return S[x] * kc + (a + b) * norm;
+    return (norm * a + kc * S[x]) + norm * b;
 }
 __global__ __launch_bounds__(256)
-void ak_sderiv_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
+void ak_sderiv_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const float wgt = 10.0f / 3.0f;
     const float norm = 1.0f / (2.0f * (wgt + 2.0f));
     const float kc = wgt * norm;
-    const float u = src[(size_t)ak_refl101(y - s, h) * w + x], d = src[(size_t)ak_refl101(y + s, h) * w + x], c = src[(size_t)y * w + x];
-    dst[(size_t)y * w + x] = dx ? (kc * c + norm * (d + u)) : (d - u);
+    const float u = ak_sderiv_row(src + (size_t)ak_refl101(y - s, h) * w, x, w, s, dx);
+    const float d = ak_sderiv_row(src + (size_t)ak_refl101(y + s, h) * w, x, w, s, dx);
+    float v;
+    if (dx) { const float c = ak_sderiv_row(src + (size_t)y * w, x, w, s, dx); v = kc * c + norm * (d + u); }
+    else v = d - u;
+    dst[(size_t)y * w + x] = v;
 }
 
 __global__ __launch_bounds__(256)
@@ -594,8 +595,8 @@ hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, flo
 }
 hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int s, int dx)
 {
-    hipLaunchKernelGGL(ak_sderiv_rows_kernel, ak_grid(w, h), dim3(256), 0, st, src, tmp, w, h, s, dx);
-    hipLaunchKernelGGL(ak_sderiv_cols_kernel, ak_grid(w, h), dim3(256), 0, st, tmp, dst, w, h, s, dx);
+    (void)tmp;
+    hipLaunchKernelGGL(ak_sderiv_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst, w, h, s, dx);
     return hipGetLastError();
 }
 hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const float* lxy, float* ldet, size_t n)
