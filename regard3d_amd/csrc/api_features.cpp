@@ -152,7 +152,7 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     auto Ldet = [&](int i) { return buf(B_LEVEL0 + 4 * i + 3).as<float>(); };
     float* img = buf(B_IMG).as<float>();
     float* smooth = buf(B_SMOOTH).as<float>();
-    float* lxx = buf(B_LXX).as<float>(); float* lxy = buf(B_LXY).as<float>(); float* lyy = buf(B_LYY).as<float>();
+    float* lxx = buf(B_LXX).as<float>(); float* lxy = buf(B_LXY).as<float>();
     float* tmp = buf(B_TMP).as<float>(); float* tmp2 = buf(B_TMP2).as<float>();
     float* wx = buf(B_WX).as<float>(); float* wy = buf(B_WY).as<float>();
     float* flow = buf(B_FLOW).as<float>(); float* lt2 = buf(B_LT2).as<float>();
@@ -165,12 +165,10 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     auto hessian = [&](int i) -> hipError_t {
         const int lw = lv[i].w, lh = lv[i].h, s = lv[i].sigma_size;
         hipError_t e;
-        if ((e = ak_scaled_deriv(st, smooth, tmp, Lx(i), lw, lh, s, 1)) != hipSuccess) return e;
-        if ((e = ak_scaled_deriv(st, Lx(i), tmp, lxx, lw, lh, s, 1)) != hipSuccess) return e;
-        if ((e = ak_scaled_deriv(st, Lx(i), tmp, lxy, lw, lh, s, 0)) != hipSuccess) return e;
-        if ((e = ak_scaled_deriv(st, smooth, tmp, Ly(i), lw, lh, s, 0)) != hipSuccess) return e;
-        if ((e = ak_scaled_deriv(st, Ly(i), tmp, lyy, lw, lh, s, 0)) != hipSuccess) return e;
-        return ak_det(st, lxx, lyy, lxy, Ldet(i), (size_t)lw * lh);
+        // three launches: smooth -> (Lx, Ly);  Lx -> (Lxx, Lxy);  Ly -> Lyy, folded into the determinant
+        if ((e = ak_scaled_deriv_xy(st, smooth, Lx(i), Ly(i), lw, lh, s)) != hipSuccess) return e;
+        if ((e = ak_scaled_deriv_xy(st, Lx(i), lxx, lxy, lw, lh, s)) != hipSuccess) return e;
+        return ak_scaled_deriv_det(st, Ly(i), lxx, lxy, Ldet(i), lw, lh, s);
     };
 
     // ---- Create_Nonlinear_Scale_Space (:245-369), Compute_Base_Evolution_Level (:199-237)

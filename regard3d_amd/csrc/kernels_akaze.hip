@@ -93,20 +93,42 @@ __device__ __forceinline__ float ak_sderiv_row(const float* __restrict__ S, int 
     if (s == 2) return S[x] * kc + (a + b) * norm;
     return (norm * a + kc * S[x]) + norm * b;
 }
-__global__ __launch_bounds__(256)
-void ak_sderiv_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
+__device__ __forceinline__ float ak_sderiv_at(const float* __restrict__ src, int x, int y, int w, int h, int s, int dx)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
     const float wgt = 10.0f / 3.0f;
     const float norm = 1.0f / (2.0f * (wgt + 2.0f));
     const float kc = wgt * norm;
     const float u = ak_sderiv_row(src + (size_t)ak_refl101(y - s, h) * w, x, w, s, dx);
     const float d = ak_sderiv_row(src + (size_t)ak_refl101(y + s, h) * w, x, w, s, dx);
-    float v;
-    if (dx) { const float c = ak_sderiv_row(src + (size_t)y * w, x, w, s, dx); v = kc * c + norm * (d + u); }
-    else v = d - u;
-    dst[(size_t)y * w + x] = v;
+    if (dx) { const float c = ak_sderiv_row(src + (size_t)y * w, x, w, s, dx); return kc * c + norm * (d + u); }
+    return d - u;
+}
+__global__ __launch_bounds__(256)
+void ak_sderiv_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    dst[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, dx);
+}
+// both derivatives of one source in one pass: d/dx -> dst_x, d/dy -> dst_y (smooth -> Lx, Ly;  Lx -> Lxx, Lxy)
+__global__ __launch_bounds__(256)
+void ak_sderiv_xy_kernel(const float* __restrict__ src, float* __restrict__ dst_x, float* __restrict__ dst_y, int w, int h, int s)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    dst_x[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, 1);
+    dst_y[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, 0);
+}
+// Lyy = d/dy of Ly, consumed on the spot: det = Lxx * Lyy - Lxy * Lxy
+__global__ __launch_bounds__(256)
+void ak_sderiv_det_kernel(const float* __restrict__ ly, const float* __restrict__ lxx, const float* __restrict__ lxy,
+                          float* __restrict__ ldet, int w, int h, int s)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t i = (size_t)y * w + x;
+    const float lyy = ak_sderiv_at(ly, x, y, w, h, s, 0);
+    ldet[i] = lxx[i] * lyy - lxy[i] * lxy[i];
 }
 
 __global__ __launch_bounds__(256)
@@ -597,6 +619,16 @@ hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* 
 {
     (void)tmp;
     hipLaunchKernelGGL(ak_sderiv_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst, w, h, s, dx);
+    return hipGetLastError();
+}
+hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int s)
+{
+    hipLaunchKernelGGL(ak_sderiv_xy_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst_x, dst_y, w, h, s);
+    return hipGetLastError();
+}
+hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int s)
+{
+    hipLaunchKernelGGL(ak_sderiv_det_kernel, ak_grid(w, h), dim3(256), 0, st, ly, lxx, lxy, ldet, w, h, s);
     return hipGetLastError();
 }
 hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const float* lxy, float* ldet, size_t n)
