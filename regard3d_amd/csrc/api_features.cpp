@@ -206,6 +206,8 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     for (int i = 1; i < nl; ++i) {
         const int lw = lv[i].w, lh = lv[i].h;
         const size_t n = (size_t)lw * lh;
+        const std::vector<float> tau = ak_fed_tau(lv[i].etime - lv[i - 1].etime);
+        const float* start = nullptr;
         if (lv[i].octave > lv[i - 1].octave) {
             const int sw = lv[i - 1].w, sh = lv[i - 1].h;
             const AkAreaTab* xt = nullptr; const AkAreaTab* yt = nullptr; const int* xb = nullptr; const int* yb = nullptr;
@@ -222,20 +224,29 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
                 R3DM_HIP(c, hipMemcpy(base + o, bx.data(), bx.size() * 4, hipMemcpyHostToDevice)); xb = (const int*)(base + o); o += bx.size() * 4;
                 R3DM_HIP(c, hipMemcpy(base + o, by.data(), by.size() * 4, hipMemcpyHostToDevice)); yb = (const int*)(base + o);
             }
-            R3DM_HIP(c, ak_halfsample(st, Lt(i - 1), Lt(i), sw, sh, xt, xb, yt, yb));
+            // the FED steps ping-pong between Lt(i) and the work image and must END in Lt(i): the half-sampled start image goes
+            // to whichever of the two the first step does not write
+            float* half = (tau.size() % 2 == 1) ? lt2 : Lt(i);
+            R3DM_HIP(c, ak_halfsample(st, Lt(i - 1), half, sw, sh, xt, xb, yt, yb));
+            start = half;
             kcontrast = kcontrast * 0.75f;
         } else {
-            R3DM_HIP(c, hipMemcpyAsync(Lt(i), Lt(i - 1), n * 4, hipMemcpyDeviceToDevice, st));
+            start = Lt(i - 1);                                  // same octave: the previous level IS the start image, no copy
         }
-        R3DM_HIP(c, ak_gaussian(st, Lt(i), tmp, smooth, lw, lh, taps_one));
-        R3DM_HIP(c, ak_scharr(st, smooth, tmp, tmp2, wx, wy, lw, lh));
+        if (tau.empty()) {                                      // (never for the reference's time steps) plain copy
+            if (start != Lt(i)) R3DM_HIP(c, hipMemcpyAsync(Lt(i), start, n * 4, hipMemcpyDeviceToDevice, st));
+            start = Lt(i);
+        }
+        R3DM_HIP(c, ak_gaussian(st, start, tmp, smooth, lw, lh, taps_one));
         R3DM_HIP(c, hessian(i));
-        R3DM_HIP(c, ak_pm_g2(st, wx, wy, flow, n, 1.0f / (kcontrast * kcontrast)));
-        // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j (ping-pong between the level's Lt and a work image)
-        const std::vector<float> tau = ak_fed_tau(lv[i].etime - lv[i - 1].etime);
-        float* cur = Lt(i); float* oth = lt2;
-        for (float step : tau) { R3DM_HIP(c, ak_fed_step(st, cur, flow, oth, lw, lh, step)); std::swap(cur, oth); }
-        if (cur != Lt(i)) R3DM_HIP(c, hipMemcpyAsync(Lt(i), cur, n * 4, hipMemcpyDeviceToDevice, st));
+        R3DM_HIP(c, ak_scharr_g2(st, smooth, flow, lw, lh, 1.0f / (kcontrast * kcontrast)));
+        // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; step k of n writes Lt(i) when n - k is even, else the work image
+        const float* cur = start;
+        for (size_t k = 1; k <= tau.size(); ++k) {
+            float* out = ((tau.size() - k) % 2 == 0) ? Lt(i) : lt2;
+            R3DM_HIP(c, ak_fed_step(st, cur, flow, out, lw, lh, tau[k - 1]));
+            cur = out;
+        }
     }
 
     // ---- Feature_Detection (:371-382): extrema -> in-level pruning -> cross-level pruning -> refinement + orientation

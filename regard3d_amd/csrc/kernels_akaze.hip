@@ -186,6 +186,25 @@ void ak_pm_g2_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly,
     if (i < n) dst[i] = 1.0f / (1.0f + ((Lx[i] * Lx[i] + Ly[i] * Ly[i]) * inv_k2));
 }
 
+// ---- Scharr 3x3 (row pass + column pass, as above) and the PM-G2 conductivity in one kernel: flow = 1 / (1 + |grad|^2 / k^2).
+// Same operations per pixel as ak_scharr_rows/cols + ak_pm_g2, without the four intermediate images.
+__global__ __launch_bounds__(256)
+void ak_scharr_g2_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, float inv_k2)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int xl = ak_refl101(x - 1, w), xr = ak_refl101(x + 1, w);
+    const float* Su = src + (size_t)ak_refl101(y - 1, h) * w;
+    const float* Sc = src + (size_t)y * w;
+    const float* Sd = src + (size_t)ak_refl101(y + 1, h) * w;
+    const float au = Su[xl], bu = Su[xr], ac = Sc[xl], bc = Sc[xr], ad = Sd[xl], bd = Sd[xr];
+    const float rdu = bu - au, rdc = bc - ac, rdd = bd - ad;                       // row pass, derivative
+    const float rsu = Su[x] * 10.0f + (au + bu) * 3.0f, rsd = Sd[x] * 10.0f + (ad + bd) * 3.0f;     // row pass, smoothing
+    const float lx = (rdu + rdd) * 3.0f + rdc * 10.0f;
+    const float ly = rsd - rsu;
+    dst[(size_t)y * w + x] = 1.0f / (1.0f + ((lx * lx + ly * ly) * inv_k2));
+}
+
 // ---- one FED step: Lstep (nld_step_scalar_one_lane; corners 0) and out = Lt + Lstep * 0.5 * step
 __global__ __launch_bounds__(256)
 void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, float step_size)
@@ -651,6 +670,11 @@ hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w,
 hipError_t ak_pm_g2(hipStream_t st, const float* Lx, const float* Ly, float* dst, size_t n, float inv_k2)
 {
     hipLaunchKernelGGL(ak_pm_g2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Lx, Ly, dst, n, inv_k2);
+    return hipGetLastError();
+}
+hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, float inv_k2)
+{
+    hipLaunchKernelGGL(ak_scharr_g2_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst, w, h, inv_k2);
     return hipGetLastError();
 }
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size)

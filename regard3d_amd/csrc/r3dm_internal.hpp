@@ -191,6 +191,7 @@ hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray,
 hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf);
 hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h);
 hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int s, int dx);
+hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, float inv_k2);
 hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int s);
 hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int s);
 hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const float* lxy, float* ldet, size_t n);
