@@ -103,13 +103,6 @@ __device__ __forceinline__ float ak_sderiv_at(const float* __restrict__ src, int
     if (dx) { const float c = ak_sderiv_row(src + (size_t)y * w, x, w, s, dx); return kc * c + norm * (d + u); }
     return d - u;
 }
-__global__ __launch_bounds__(256)
-void ak_sderiv_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int s, int dx)
-{
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    dst[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, dx);
-}
 // both derivatives of one source in one pass: d/dx -> dst_x, d/dy -> dst_y (smooth -> Lx, Ly;  Lx -> Lxx, Lxy)
 __global__ __launch_bounds__(256)
 void ak_sderiv_xy_kernel(const float* __restrict__ src, float* __restrict__ dst_x, float* __restrict__ dst_y, int w, int h, int s)
@@ -129,13 +122,6 @@ void ak_sderiv_det_kernel(const float* __restrict__ ly, const float* __restrict_
     const size_t i = (size_t)y * w + x;
     const float lyy = ak_sderiv_at(ly, x, y, w, h, s, 0);
     ldet[i] = lxx[i] * lyy - lxy[i] * lxy[i];
-}
-
-__global__ __launch_bounds__(256)
-void ak_det_kernel(const float* __restrict__ lxx, const float* __restrict__ lyy, const float* __restrict__ lxy, float* __restrict__ ldet, size_t n)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) ldet[i] = lxx[i] * lyy[i] - lxy[i] * lxy[i];
 }
 
 // ---- k-contrast: maximum of the gradient modulus over the interior, then its histogram
@@ -179,15 +165,8 @@ void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__
     for (int k = threadIdx.x; k < nbins; k += 256) if (lh[k]) atomicAdd(hist + k, lh[k]);
 }
 
-__global__ __launch_bounds__(256)
-void ak_pm_g2_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, float* __restrict__ dst, size_t n, float inv_k2)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = 1.0f / (1.0f + ((Lx[i] * Lx[i] + Ly[i] * Ly[i]) * inv_k2));
-}
-
 // ---- Scharr 3x3 (row pass + column pass, as above) and the PM-G2 conductivity in one kernel: flow = 1 / (1 + |grad|^2 / k^2).
-// Same operations per pixel as ak_scharr_rows/cols + ak_pm_g2, without the four intermediate images.
+// Same operations per pixel as the Scharr row + column pass followed by the conductivity, without the four intermediate images.
 __global__ __launch_bounds__(256)
 void ak_scharr_g2_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, float inv_k2)
 {
@@ -634,12 +613,6 @@ hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, flo
     hipLaunchKernelGGL(ak_scharr_cols_kernel, ak_grid(w, h), dim3(256), 0, st, rd, rs, Lx, Ly, w, h);
     return hipGetLastError();
 }
-hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int s, int dx)
-{
-    (void)tmp;
-    hipLaunchKernelGGL(ak_sderiv_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst, w, h, s, dx);
-    return hipGetLastError();
-}
 hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int s)
 {
     hipLaunchKernelGGL(ak_sderiv_xy_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst_x, dst_y, w, h, s);
@@ -648,11 +621,6 @@ hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, fl
 hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int s)
 {
     hipLaunchKernelGGL(ak_sderiv_det_kernel, ak_grid(w, h), dim3(256), 0, st, ly, lxx, lxy, ldet, w, h, s);
-    return hipGetLastError();
-}
-hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const float* lxy, float* ldet, size_t n)
-{
-    hipLaunchKernelGGL(ak_det_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lxx, lyy, lxy, ldet, n);
     return hipGetLastError();
 }
 hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max)
@@ -665,11 +633,6 @@ hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w,
 {
     if (nbins > 512) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)((h - 2 + 63) / 64)), dim3(256), 0, st, Lx, Ly, w, h, sc, nbins, hist);
-    return hipGetLastError();
-}
-hipError_t ak_pm_g2(hipStream_t st, const float* Lx, const float* Ly, float* dst, size_t n, float inv_k2)
-{
-    hipLaunchKernelGGL(ak_pm_g2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Lx, Ly, dst, n, inv_k2);
     return hipGetLastError();
 }
 hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, float inv_k2)

@@ -190,14 +190,11 @@ hipError_t ak_mldb(hipStream_t st, const AkLevelDev* levels, const AkMldbItem* i
 hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray, size_t n);
 hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf);
 hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h);
-hipError_t ak_scaled_deriv(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int s, int dx);
 hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, float inv_k2);
 hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int s);
 hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int s);
-hipError_t ak_det(hipStream_t st, const float* lxx, const float* lyy, const float* lxy, float* ldet, size_t n);
 hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max);
 hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, float sc, int nbins, uint32_t* hist);
-hipError_t ak_pm_g2(hipStream_t st, const float* Lx, const float* Ly, float* dst, size_t n, float inv_k2);
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size);
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);
