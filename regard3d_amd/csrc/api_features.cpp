@@ -270,8 +270,10 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
         }
     }
     AkLevelDev* d_levels = reinterpret_cast<AkLevelDev*>(meta.as<unsigned char>() + ((rows_total * 8 + (size_t)nl * 16 + 15) / 16) * 16);
-    for (int i = 0; i < nl; ++i) R3DM_HIP(c, ak_extrema(st, ld[i], threshold, 0));
+    int max_rows = 0;
+    for (int i = 0; i < nl; ++i) max_rows = std::max(max_rows, lv[i].h - 2 * lv[i].border);
     R3DM_HIP(c, hipMemcpyAsync(d_levels, ld.data(), nl * sizeof(AkLevelDev), hipMemcpyHostToDevice, st));
+    R3DM_HIP(c, ak_extrema(st, d_levels, nl, max_rows, threshold, 0));          // all levels in one launch
     R3DM_HIP(c, ak_scan_rows(st, d_levels, nl));
     std::vector<uint32_t> counts(4 * (size_t)nl);
     R3DM_HIP(c, hipMemcpyAsync(counts.data(), ld[0].counts, counts.size() * 4, hipMemcpyDeviceToHost, st));
@@ -299,7 +301,7 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     }
     R3DM_HIP(c, hipMemsetAsync(pts.as<unsigned char>() + 4 * cand_total * 16 + cand_total * 12, 0, cand_total * 2 + 64, st));
     R3DM_HIP(c, hipMemcpyAsync(d_levels, ld.data(), nl * sizeof(AkLevelDev), hipMemcpyHostToDevice, st));
-    for (int i = 0; i < nl; ++i) if (counts[4 * i]) R3DM_HIP(c, ak_extrema(st, ld[i], threshold, 1));
+    R3DM_HIP(c, ak_extrema(st, d_levels, nl, max_rows, threshold, 1));
     R3DM_HIP(c, ak_prune_levels(st, d_levels, nl));
     R3DM_HIP(c, hipMemcpyAsync(counts.data(), ld[0].counts, counts.size() * 4, hipMemcpyDeviceToHost, st));
     R3DM_HIP(c, hipStreamSynchronize(st));

@@ -248,11 +248,14 @@ __device__ __forceinline__ bool ak_is_extremum(const float* __restrict__ ldet, i
     if (v <= next[x - 1] || v <= next[x] || v <= next[x + 1]) return false;
     return true;
 }
-// one workgroup per image row (border .. h - border)
+// one workgroup per image row (border .. h - border) of every level: blockIdx.y = level, blockIdx.x = row
 __global__ __launch_bounds__(256)
-void ak_extrema_kernel(const AkLevelDev L, float thr, int pass /* 0 = count, 1 = emit */)
+void ak_extrema_kernel(const AkLevelDev* __restrict__ levels, float thr, int pass /* 0 = count, 1 = emit */)
 {
     __shared__ uint32_t wave_cnt[4];
+    const AkLevelDev L = levels[blockIdx.y];
+    if ((int)blockIdx.x >= L.h - 2 * L.border) return;                 // workgroup-uniform: this level has fewer rows
+    if (pass && L.counts[0] == 0) return;
     const int y = L.border + blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t base = pass ? L.row_off[blockIdx.x] : 0u;
@@ -653,11 +656,10 @@ hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, in
     else hipLaunchKernelGGL(ak_half_area_kernel, ak_grid(dw, dh), dim3(256), 0, st, src, dst, w, dw, dh, xt, xb, yt, yb);
     return hipGetLastError();
 }
-hipError_t ak_extrema(hipStream_t st, const AkLevelDev& L, float thr, int pass)
+hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int max_rows, float thr, int pass)
 {
-    const int rows = L.h - 2 * L.border;
-    if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ak_extrema_kernel, dim3((unsigned)rows), dim3(256), 0, st, L, thr, pass);
+    if (max_rows <= 0 || n_levels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ak_extrema_kernel, dim3((unsigned)max_rows, (unsigned)n_levels), dim3(256), 0, st, levels, thr, pass);
     return hipGetLastError();
 }
 hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels)

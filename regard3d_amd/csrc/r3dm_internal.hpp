@@ -198,7 +198,7 @@ hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w,
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size);
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);
-hipError_t ak_extrema(hipStream_t st, const AkLevelDev& L, float thr, int pass);
+hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int max_rows, float thr, int pass);
 hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels);
 hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels);
 hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list, int mode);
