@@ -142,7 +142,7 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
         c->ak_w = w; c->ak_h = h;
     }
     auto buf = [&](int k) -> DevBuf& { return c->ak_bufs[k]; };
-    for (int k = B_IMG; k <= B_LT2; ++k) R3DM_HIP(c, buf(k).ensure(n0 * 4));
+    for (int k = B_IMG; k <= B_LT2; ++k) if (k != B_LYY) R3DM_HIP(c, buf(k).ensure(n0 * 4));      // (Lyy is folded into the determinant kernel)
     R3DM_HIP(c, buf(B_SMALL).ensure(4096 * 4));
     for (int i = 0; i < nl; ++i)
         for (int q = 0; q < 4; ++q) R3DM_HIP(c, buf(B_LEVEL0 + 4 * i + q).ensure((size_t)lv[i].w * lv[i].h * 4));
