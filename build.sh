@@ -1,9 +1,38 @@
 #!/bin/bash
-# Builds regard3d_amd/libr3dm.so (HIP kernels + C ABI) for gfx950.  hipcc cross-compiles without a GPU.
+# Builds the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU):
+#   regard3d_amd/libr3dm.so      the product library -- no developer knobs, never reads the environment
+#   regard3d_amd/libr3dm_dev.so  the same sources with -DR3DM_DEVTOOLS + tools/devtools/dev_knobs.cpp: A/B kernel variants,
+#                                traces, invariant checks and test hooks for tools/ and the fallback-path tests
+# Usage: build.sh [product|dev|all]   (default: all).  Objects are cached under build/ and rebuilt when a source or header changes.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRC="regard3d_amd/csrc/kernels_match.hip regard3d_amd/csrc/kernels_filter.hip regard3d_amd/csrc/kernels_liop.hip regard3d_amd/csrc/kernels_ann.hip regard3d_amd/csrc/kernels_akaze.hip regard3d_amd/csrc/api_core.cpp regard3d_amd/csrc/api_match.cpp regard3d_amd/csrc/api_filter.cpp regard3d_amd/csrc/api_features.cpp regard3d_amd/csrc/compute_matches.cpp"
+WHAT=${1:-all}
+SRC="kernels_match.hip kernels_filter.hip kernels_liop.hip kernels_ann.hip kernels_akaze.hip api_core.cpp api_match.cpp api_filter.cpp api_features.cpp api_multi.cpp compute_matches.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
-$HIPCC $FLAGS -x hip -shared $SRC -o regard3d_amd/libr3dm.so
-echo "built regard3d_amd/libr3dm.so"
+HDRS="regard3d_amd/csrc/*.hpp include/*.h include/*.hpp"
+
+build_one() {   # $1 = variant dir, $2 = extra flags, $3 = output, $4 = extra sources
+  local dir=build/$1; mkdir -p $dir
+  local objs="" pids=""
+  for f in $SRC; do
+    local o=$dir/${f%.*}.o
+    objs="$objs $o"
+    local stale=0
+    if [ ! -f $o ]; then stale=1; else
+      for d in regard3d_amd/csrc/$f $HDRS build.sh; do [ $d -nt $o ] && stale=1; done
+    fi
+    if [ $stale = 1 ]; then ( $HIPCC $FLAGS $2 -x hip -c regard3d_amd/csrc/$f -o $o ) & pids="$pids $!"; fi
+  done
+  for f in $4; do
+    local o=$dir/$(basename ${f%.*}).o
+    objs="$objs $o"
+    ( $HIPCC $FLAGS $2 -x hip -c $f -o $o ) & pids="$pids $!"
+  done
+  for p in $pids; do wait $p; done
+  $HIPCC --offload-arch=gfx950 -fPIC -fopenmp -shared $objs -o $3
+  echo "built $3"
+}
+
+if [ "$WHAT" = product ] || [ "$WHAT" = all ]; then build_one product "" regard3d_amd/libr3dm.so ""; fi
+if [ "$WHAT" = dev ] || [ "$WHAT" = all ]; then build_one dev "-DR3DM_DEVTOOLS" regard3d_amd/libr3dm_dev.so "tools/devtools/dev_knobs.cpp"; fi

@@ -27,7 +27,8 @@
  * all state lives in the opaque context; buffers passed in stay owned by the caller (they are
  * copied -- host or device pointers are both accepted, the copy is hipMemcpyDefault); objects
  * returned by the library are released only with the matching *_free.  One context per host
- * thread (or serialise externally); one context drives one GPU (one process per GPU).
+ * thread (or serialise externally); one context drives one GPU (one process per GPU, or r3dm_multi_* below for one
+ * process driving several GPUs).
  * There is NO CPU fallback: if no gfx950 device is visible r3dm_create fails with
  * R3DM_ERR_NO_DEVICE.
  */
@@ -239,6 +240,38 @@ int r3dm_graph_from_csr(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64
                         const r3dm_match* matches, r3dm_graph** out);
 /* merge several graphs (e.g. one per rank) into one ordered by (I, J) */
 int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out);
+
+/* ---- multi-GPU, single process: one context per device, one host thread per device ----
+ * For a C++ host like Regard3D itself (one process, /root/reference/src/R3DComputeMatches.cpp:437-489 treats the pairs of the
+ * collection as independent OpenMP iterations; so does OpenMVG's filter loop, :2099).  r3dm_multi_create opens one context per
+ * entry of device_ids (an id may repeat: two contexts on one GPU); r3dm_multi_set_image replicates a view on every device;
+ * r3dm_multi_match_pairs deals the pair list to the devices by rows of I in snake order (r3dm_shard_pairs: rows sorted by
+ * decreasing pair count, dealt 0..W-1, W-1..0, ... -- cost-balanced, the pairs of one I stay on one device), runs
+ * r3dm_match_pairs on every device from its own host thread and merges the graphs; the filters deal the putative pairs
+ * longest list first.  No collective is involved (the graph is reassembled in host memory, where PairWiseMatches lives);
+ * the multi-PROCESS route -- one rank per GPU, one RCCL all-gather -- is regard3d_amd/dist.py.  Results are identical to a
+ * single-device run (every per-pair computation is independent of the device that runs it). */
+typedef struct r3dm_multi r3dm_multi;
+int  r3dm_multi_create(const int* device_ids, int n_dev, r3dm_multi** out);
+void r3dm_multi_destroy(r3dm_multi* m);
+int  r3dm_multi_num_devices(const r3dm_multi* m);
+r3dm_ctx* r3dm_multi_ctx(r3dm_multi* m, int k);            /* the k-th device's context (statistics, reports) */
+const char* r3dm_multi_last_error(const r3dm_multi* m);
+int r3dm_multi_set_image(r3dm_multi* m, uint32_t view_id, uint32_t width, uint32_t height,
+                         const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);
+int r3dm_multi_set_intrinsics(r3dm_multi* m, uint32_t view_id, const double* K);
+int r3dm_multi_clear_images(r3dm_multi* m);
+int r3dm_multi_set_integer_mfma(r3dm_multi* m, int enable);
+int r3dm_multi_match_pairs(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs,
+                           float dist_ratio, int squared_metric, r3dm_graph** out);
+int r3dm_multi_filter_F(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                        uint64_t seed, r3dm_graph** out, double* F_out);
+int r3dm_multi_filter_H(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                        uint64_t seed, r3dm_graph** out, double* H_out);
+int r3dm_multi_filter_E(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                        uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out);
+/* owner_out[p] = the device / rank (0..world-1) that the snake deal gives pair p.  Pure host code (no GPU needed). */
+int r3dm_shard_pairs(const uint32_t* pairs_ij, uint64_t n_pairs, uint32_t world, uint32_t* owner_out);
 
 /* ---- files: ".txt" (what Regard3D's consumers read) or ".bin" (cereal portable binary) ---- */
 int r3dm_save_matches(const r3dm_graph* g, const char* path);

@@ -26,6 +26,9 @@ EXPORTS = [
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
     "r3dm_set_integer_mfma",
+    "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
+    "r3dm_multi_set_image", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
+    "r3dm_multi_match_pairs", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
 ]
 
 
@@ -64,6 +67,17 @@ class PairReport(C.Structure):
 
 
 _lib = None
+DEV_LIB_PATH = os.path.join(_HERE, "libr3dm_dev.so")
+
+
+def use_developer_library():
+    """tools/ and the fallback-path tests: load the developer build (build.sh dev: -DR3DM_DEVTOOLS, the A/B kernel variants,
+    traces and test hooks that read R3DM_* environment variables) instead of the product library.  Must be called before the
+    first load_library(); the product library itself never reads the environment."""
+    global LIB_PATH
+    if _lib is not None:
+        raise R3dmError("the library is already loaded")
+    LIB_PATH = DEV_LIB_PATH
 
 
 def load_library():
@@ -112,6 +126,20 @@ def load_library():
     L.r3dm_load_matches.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.r3dm_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.r3dm_filter_report.argtypes = [vp, vp, u64]
+    L.r3dm_multi_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.r3dm_multi_destroy.argtypes = [vp]; L.r3dm_multi_destroy.restype = None
+    L.r3dm_multi_num_devices.argtypes = [vp]
+    L.r3dm_multi_ctx.argtypes = [vp, C.c_int]; L.r3dm_multi_ctx.restype = vp
+    L.r3dm_multi_last_error.argtypes = [vp]; L.r3dm_multi_last_error.restype = C.c_char_p
+    L.r3dm_multi_set_image.argtypes = [vp, u32, u32, u32, vp, u32, u32, C.c_int, vp]
+    L.r3dm_multi_set_intrinsics.argtypes = [vp, u32, vp]
+    L.r3dm_multi_clear_images.argtypes = [vp]
+    L.r3dm_multi_set_integer_mfma.argtypes = [vp, C.c_int]
+    L.r3dm_multi_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
+    L.r3dm_multi_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
+    L.r3dm_multi_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
+    L.r3dm_multi_filter_E.argtypes = [vp, vp, C.c_double, u32, u64, u32, C.c_float, C.POINTER(vp), vp]
+    L.r3dm_shard_pairs.argtypes = [vp, u64, u32, vp]
     _lib = L
     return L
 
@@ -408,3 +436,92 @@ class Context:
         s = Stats()
         self._check(self._L.r3dm_get_stats(self._h, C.byref(s)), "r3dm_get_stats")
         return s
+
+
+def shard_owner(pairs: np.ndarray, world: int) -> np.ndarray:
+    """r3dm_shard_pairs: the device / rank that the snake deal of rows I gives every pair (host code, no GPU needed)"""
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    owner = np.zeros(pairs.shape[0], np.uint32)
+    rc = load_library().r3dm_shard_pairs(_ptr(pairs) if pairs.size else None, pairs.shape[0], int(world), _ptr(owner) if pairs.size else None)
+    if rc != 0:
+        raise R3dmError(f"r3dm_shard_pairs -> {rc}")
+    return owner
+
+
+class MultiContext:
+    """r3dm_multi_*: one process driving several GPUs (one context + one host thread per device); device ids may repeat."""
+
+    def __init__(self, device_ids: Sequence[int]):
+        L = load_library()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = L.r3dm_multi_create(ids, len(device_ids), C.byref(h))
+        if rc != 0:
+            raise R3dmError(f"r3dm_multi_create({list(device_ids)}) -> {rc} (no gfx950 GPU visible? there is no CPU fallback)")
+        self._h = h.value
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.r3dm_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise R3dmError(f"{what} -> {rc}: {self._L.r3dm_multi_last_error(self._h).decode()}")
+
+    @property
+    def num_devices(self) -> int:
+        return int(self._L.r3dm_multi_num_devices(self._h))
+
+    def device_stats(self, k: int) -> Stats:
+        s = Stats()
+        rc = self._L.r3dm_get_stats(self._L.r3dm_multi_ctx(self._h, k), C.byref(s))
+        self._check(rc, "r3dm_get_stats")
+        return s
+
+    def set_image(self, view_id: int, desc, xy=None, width: int = 0, height: int = 0, binary: bool = False):
+        desc = np.ascontiguousarray(desc)
+        dt = F32 if desc.dtype == np.float32 else (BIN if binary else U8)
+        if xy is not None:
+            xy = np.ascontiguousarray(xy, np.float32)
+        self._check(self._L.r3dm_multi_set_image(self._h, view_id, width, height, _ptr(desc), desc.shape[0], desc.shape[1], dt, _ptr(xy)),
+                    "r3dm_multi_set_image")
+
+    def set_intrinsics(self, view_id: int, K):
+        K = None if K is None else np.ascontiguousarray(K, np.float64).reshape(9)
+        self._check(self._L.r3dm_multi_set_intrinsics(self._h, view_id, _ptr(K)), "r3dm_multi_set_intrinsics")
+
+    def set_integer_mfma(self, enable: bool = True):
+        self._check(self._L.r3dm_multi_set_integer_mfma(self._h, int(bool(enable))), "r3dm_multi_set_integer_mfma")
+
+    def match_pairs(self, pairs, dist_ratio: float = 0.6, squared_metric: bool = True) -> Graph:
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        h = C.c_void_p()
+        self._check(self._L.r3dm_multi_match_pairs(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0],
+                                                   dist_ratio, int(squared_metric), C.byref(h)), "r3dm_multi_match_pairs")
+        return Graph(h.value)
+
+    def _filter(self, fn, what, putative, args, want):
+        h = C.c_void_p()
+        buf = np.zeros((max(putative.num_pairs, 1), 9), np.float64) if want else None
+        self._check(fn(self._h, putative._h, *args, C.byref(h), _ptr(buf)), what)
+        g = Graph(h.value)
+        return (g, buf[:g.num_pairs].copy()) if want else g
+
+    def filter_F(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489, want_F: bool = False):
+        return self._filter(self._L.r3dm_multi_filter_F, "r3dm_multi_filter_F", putative, (max_residual_px, max_iter, seed), want_F)
+
+    def filter_H(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489, want_H: bool = False):
+        return self._filter(self._L.r3dm_multi_filter_H, "r3dm_multi_filter_H", putative, (max_residual_px, max_iter, seed), want_H)
+
+    def filter_E(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489,
+                 min_count: int = 50, min_ratio: float = 0.3, want_E: bool = False):
+        return self._filter(self._L.r3dm_multi_filter_E, "r3dm_multi_filter_E", putative,
+                            (max_residual_px, max_iter, seed, min_count, min_ratio), want_E)

@@ -194,7 +194,8 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         R3DM_HIP(c, hipMemcpyAsync(st3, mx, 12, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));
         std::memcpy(&h.max_abs, &st3[1], 4);
-        h.not_integer = (st3[2] != 0);
+        h.not_integer = (st3[2] & 1u) != 0;
+        h.has_negative = (st3[2] & 2u) != 0;
     }
     R3DM_HIP(c, hipStreamSynchronize(c->stream));     // d_raw is reused by the next call
     return R3DM_OK;

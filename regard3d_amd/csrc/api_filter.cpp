@@ -34,6 +34,12 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         const HostImage& A = *c->imgs[a->second];
         const HostImage& B = *c->imgs[b->second];
         if (!A.has_xy || !B.has_xy) { c->err = "filter: view registered without feature positions"; return R3DM_ERR_INVALID; }
+        // ACKernelAdaptor normalises with 1 / sqrt(w h) and the NFA scale is D / A of image J: a view registered with a zero
+        // width or height would turn every residual into NaN and the filter into a silent "no inliers"
+        if (A.width == 0 || A.height == 0 || B.width == 0 || B.height == 0) {
+            c->err = "filter: view " + std::to_string(A.width == 0 || A.height == 0 ? I : J) + " was registered without its image size (width / height = 0)";
+            return R3DM_ERR_INVALID;
+        }
         if (m > (1u << 22)) { c->err = "filter: more than 4M putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
         // E_ACRobust: a pair whose views lack valid pinhole intrinsics is not estimated (and so not kept)
         if (model_kind == 2 && (!A.has_K || !B.has_K)) continue;
@@ -138,7 +144,7 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     // launch order: the workgroup of a pair runs for a time roughly proportional to its putative count, and a C2 call has
     // ~1.5 x as many pairs as resident workgroups -- start the long ones first so the tail of the launch is short ones
     {
-        static const int lpt = [] { const char* v = getenv("R3DM_FILTER_LPT"); return v ? atoi(v) : 1; }();
+        static const int lpt = r3dm_dev_knob("R3DM_FILTER_LPT", 1);
         fp.order = nullptr;
         if (lpt && NI > 1) {
             std::vector<uint32_t> order(NI);
@@ -155,10 +161,10 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
     DevBuf trace_buf;
     const uint32_t trace_cap = 16384;
-    const char* tp = getenv("R3DM_TRACE_PAIR");
-    const char* tf = getenv("R3DM_TRACE_FILE");
+    const char* tp = r3dm_dev_str("R3DM_TRACE_PAIR");
+    const char* tf = r3dm_dev_str("R3DM_TRACE_FILE");
     fp.trace = nullptr; fp.trace_item = 0xFFFFFFFFu; fp.trace_cap = trace_cap; fp.trace_rows = nullptr;
-    fp.trace_iter = getenv("R3DM_TRACE_ITER") ? (uint32_t)atoi(getenv("R3DM_TRACE_ITER")) : 0xFFFFFFFFu;
+    fp.trace_iter = (uint32_t)r3dm_dev_knob("R3DM_TRACE_ITER", -1);
     if (tp && tf) {
         unsigned tI = 0, tJ = 0;
         if (sscanf(tp, "%u,%u", &tI, &tJ) == 2)
@@ -173,23 +179,26 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     }
     DevBuf dbg_buf;
     fp.dbg = nullptr;
-    if (getenv("R3DM_FILTER_CHECK")) {
+    if (r3dm_dev_knob("R3DM_FILTER_CHECK", 0)) {
         R3DM_HIP(c, dbg_buf.ensure(64));
         R3DM_HIP(c, hipMemsetAsync(dbg_buf.p, 0, 64, c->stream));
         fp.dbg = dbg_buf.as<uint32_t>();
     }
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     R3DM_HIP(c, launch_filter_F(c->stream, fp));
-    if (fp.dbg) {
+    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    if (fp.dbg) {                                          // developer build only
         uint32_t d[4] = {0, 0, 0, 0};
-        R3DM_HIP(c, hipMemcpy(d, fp.dbg, 16, hipMemcpyDeviceToHost));
+        hipError_t e = hipMemcpyAsync(d, fp.dbg, 16, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the kernel runs on c->stream (non-blocking): wait for it
         dbg_buf.release();
-        if (d[0]) {
-            c->err = "filter invariant " + std::to_string(d[0]) + " violated at item " + std::to_string(d[1]) + " (" + std::to_string(d[2]) + ", " + std::to_string(d[3]) + ")";
+        if (e != hipSuccess || d[0]) {
+            trace_buf.release();
+            c->err = e != hipSuccess ? std::string("filter check: ") + hipGetErrorString(e)
+                   : "filter invariant " + std::to_string(d[0]) + " violated at item " + std::to_string(d[1]) + " (" + std::to_string(d[2]) + ", " + std::to_string(d[3]) + ")";
             return R3DM_ERR_HIP;
         }
     }
-    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
 
     std::vector<uint32_t> h_cnt(NI);
     std::vector<uint32_t> h_idx(n_slice);

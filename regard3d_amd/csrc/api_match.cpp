@@ -100,7 +100,9 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
             const HostImage& B = *c->imgs[j.sJ];
             const float dpad = (float)(first.G * 8), mI = A.max_abs, mJ = B.max_abs;      // same test as the kernel's exact_pair
             const bool exact = !A.not_integer && !B.not_integer && mI <= 256.0f && mJ <= 256.0f &&
-                               2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f;
+                               ((A.has_negative || B.has_negative)
+                                    ? dpad * (mI + mJ) * (mI + mJ) < 16777216.0f
+                                    : (2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f));
             if (!exact) { int_mfma = false; break; }
         }
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);

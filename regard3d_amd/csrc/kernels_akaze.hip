@@ -670,7 +670,7 @@ hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels)
 hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels)
 {
     // R3DM_AK_LIVE_CAP (test hook): a small LDS capacity forces the global-scratch fallback of the in-level pruning
-    static const uint32_t live_cap = [] { const char* v = getenv("R3DM_AK_LIVE_CAP"); const int c = v ? atoi(v) : kAkLive; return (uint32_t)(c < 1 ? 1 : c > kAkLive ? kAkLive : c); }();
+    static const uint32_t live_cap = [] { const int c = r3dm_dev_knob("R3DM_AK_LIVE_CAP", kAkLive); return (uint32_t)(c < 1 ? 1 : c > kAkLive ? kAkLive : c); }();
     hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)n_levels), dim3(64), 0, st, levels, live_cap);
     return hipGetLastError();
 }

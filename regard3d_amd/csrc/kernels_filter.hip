@@ -664,10 +664,19 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 //         no normalisation of the points: ACKernelAdaptorEssential)
 // KeyT / IdxT: the (residual, index) sort buffers live in LDS, or -- for the rare pair with more putative matches than
 // the LDS budget holds (near-duplicate views with > 8192 matches) -- in a slice of global scratch.
-// debug aid (R3DM_FILTER_CHECK=1): record the first violated invariant instead of running into a memory fault
+// debug aids of the developer build (-DR3DM_DEVTOOLS; r3dm_internal.hpp): R3DM_FILTER_CHECK=1 records the first violated
+// invariant instead of running into a memory fault, R3DM_TRACE_PAIR dumps the per-model trace of one pair.  In the product
+// build both pointers are compile-time null and the code below them disappears.
+#ifdef R3DM_DEVTOOLS
+#define R3DM_DBG(P) ((P).dbg)
+#define R3DM_TRACE(P) ((P).trace)
+#else
+#define R3DM_DBG(P) ((uint32_t*)nullptr)
+#define R3DM_TRACE(P) ((double*)nullptr)
+#endif
 #define FCHECK(cond, code, a, b)                                                                          \
     do {                                                                                                  \
-        if (P.dbg && !(cond)) {                                                                           \
+        if (R3DM_DBG(P) && !(cond)) {                                                                           \
             if (atomicCAS(P.dbg, 0u, (uint32_t)(code)) == 0u) { P.dbg[1] = item; P.dbg[2] = (uint32_t)(a); P.dbg[3] = (uint32_t)(b); } \
         }                                                                                                 \
     } while (0)
@@ -788,7 +797,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 uint32_t sidx_ = pool[pos[k < (int)SS ? k : 0]];
                 FCHECK(pos[k < (int)SS ? k : 0] < pool_size, 1, pos[k < (int)SS ? k : 0], pool_size);
                 FCHECK(sidx_ < m, 2, sidx_, m);
-                if (P.dbg && sidx_ >= m) sidx_ = 0;
+                if (R3DM_DBG(P) && sidx_ >= m) sidx_ = 0;
                 px1[k][0] = pt[4 * (size_t)sidx_ + 0]; px1[k][1] = pt[4 * (size_t)sidx_ + 1];
                 px2[k][0] = pt[4 * (size_t)sidx_ + 2]; px2[k][1] = pt[4 * (size_t)sidx_ + 3];
                 if (KIND == 2) {                 // camera coordinates: hnormalized(K^-1 (x, y, 1))
@@ -812,14 +821,14 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 nm = five_point(px1, px2, Fs + tid * MS, ws);
             }
             S.nm[tid] = (uint32_t)nm;
-            S.dbg_smp[tid] = pool[pos[0]];
-            if (P.trace && item == P.trace_item && iter0 + tid == P.trace_iter) {
+            if (R3DM_TRACE(P)) S.dbg_smp[tid] = pool[pos[0]];
+            if (R3DM_TRACE(P) && item == P.trace_item && iter0 + tid == P.trace_iter) {
                 double* t = P.trace + 5 * (size_t)(P.trace_cap - 4);
                 for (int k = 0; k < 7; ++k) t[k] = (double)pool[pos[k]];
                 t[7] = nm; t[8] = pool_size; t[9] = iter0 + tid;
                 for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k];
             }
-            if (tid == 0) S.dbg_pool = pool_size;
+            if (R3DM_TRACE(P) && tid == 0) S.dbg_pool = pool_size;
             if constexpr (KIND == 2) { for (int e = 9 * nm; e < MS; ++e) Fs[tid * MS + e] = 0.0; }
             else { for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0; }
         }
@@ -919,7 +928,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 }
                 wg_sync_t<SPILL>();
                 if (tid == 0) {
-                    if (P.trace && item == P.trace_item) {
+                    if (R3DM_TRACE(P) && item == P.trace_item) {
                         const uint32_t row = *P.trace_rows;
                         if (row < P.trace_cap) {
                             double* t = P.trace + 5 * (size_t)row;
@@ -966,7 +975,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 for (uint32_t q = tid; q < m; q += 256) flags[q] = 0u;
                 wg_sync_t<SPILL>();
                 FCHECK(ni <= m, 5, ni, m);
-                for (uint32_t q = tid; q < ni; q += 256) { const uint32_t iq = inl[q]; FCHECK(iq < m, 6, iq, q); if (!P.dbg || iq < m) flags[iq] = 1u; }
+                for (uint32_t q = tid; q < ni; q += 256) { const uint32_t iq = inl[q]; FCHECK(iq < m, 6, iq, q); if (!R3DM_DBG(P) || iq < m) flags[iq] = 1u; }
                 wg_sync_t<SPILL>();
                 uint32_t filled = 0;
                 for (uint32_t base = 0; base < m; base += 256) {

@@ -17,8 +17,6 @@
 
 #include "r3dm_internal.hpp"
 
-#include <cstdlib>
-
 namespace r3dm {
 
 typedef float f32x4  __attribute__((ext_vector_type(4)));
@@ -72,17 +70,19 @@ void stage_tiles_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim
         if (row < n) {
             s = 0.0f;
             const float* p = rows + (size_t)row * dim;
-            float mx = 0.0f; bool nonint = false;
+            float mx = 0.0f; bool nonint = false, neg = false;
             for (uint32_t k = 0; k < dim; ++k) {
                 const float v = p[k];
                 s = fmaf(v, v, s);
                 mx = fmaxf(mx, fabsf(v));
                 nonint |= !(v == rintf(v));                  // also true for NaN
+                neg |= v < 0.0f;
             }
             // img_stats = &ImgDev::max_norm_bits, max_abs_bits, not_integer (non-negative floats order like uints)
             atomicMax(img_stats + 0, __float_as_uint(s));
             atomicMax(img_stats + 1, __float_as_uint(mx));
-            if (nonint) atomicOr(img_stats + 2, 1u);
+            if (nonint) atomicOr(img_stats + 2, 1u);       // ImgDev::not_integer: bit 0 = some non-integer, bit 1 = some negative
+            if (neg) atomicOr(img_stats + 2, 2u);
         }
         norms[(size_t)t * 32 + threadIdx.x] = s;
     }
@@ -310,9 +310,14 @@ __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t
     // both views is an integer and all partial sums stay below 2^24, the MFMA pass (norm init, fma
     // chain, + ||q||^2) and the reference's sum of squared differences are BOTH exact, hence equal:
     // no rounding slack is needed and only true ties with an un-nominated row need the exact scan.
+    // Non-negative data: ||a||^2 <= D mI^2 and the running ||a||^2 - 2 sum(a q) stays within [-2 D mI mJ, D mI^2]; the distance
+    // itself is at most D max(mI, mJ)^2.  With negative elements the partial sums reach D mI^2 + 2 D mI mJ and the distance
+    // D (mI + mJ)^2, where the reference's own sum starts to round: one bound on the latter covers both.
     const float mI = __uint_as_float(Ip->max_abs_bits), mJ = __uint_as_float(Jp->max_abs_bits);
-    const bool exact_pair = !Ip->not_integer && !Jp->not_integer &&
-                            2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f &&
+    const uint32_t fl = Ip->not_integer | Jp->not_integer;              // bit 0: non-integer, bit 1: negative elements
+    const bool exact_pair = (fl & 1u) == 0u &&
+                            ((fl & 2u) ? dpad * (mI + mJ) * (mI + mJ) < 16777216.0f
+                                       : (2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f)) &&
                             (!bf16_tiles || (mI <= 256.0f && mJ <= 256.0f));      // bf16 tiles hold the values exactly
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
@@ -689,7 +694,7 @@ static hipError_t launch_l2_int(hipStream_t st, const MatchParams& Pin, uint32_t
     MatchParams P = Pin;
     const uint32_t tiles_per_wg = 4u * NJ;
     P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    static const int xcd_map = [] { const char* v = getenv("R3DM_XCD_MAP"); return v ? atoi(v) : 1; }();
+    static const int xcd_map = r3dm_dev_knob("R3DM_XCD_MAP", 1);
     P.xcd_map = (uint32_t)xcd_map;
     const uint64_t grid64 = (uint64_t)(xcd_map ? (P.n_pairs + 7u) / 8u * 8u : P.n_pairs) * P.qb_per_pair;
     if (grid64 == 0) return hipSuccess;
@@ -704,7 +709,7 @@ static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t m
     MatchParams P = Pin;
     const uint32_t tiles_per_wg = 4u * NJ;                 // 4 waves x NJ query tiles x 32 queries
     P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    static const int xcd_map = [] { const char* v = getenv("R3DM_XCD_MAP"); return v ? atoi(v) : 1; }();
+    static const int xcd_map = r3dm_dev_knob("R3DM_XCD_MAP", 1);
     P.xcd_map = (uint32_t)xcd_map;
     const uint64_t grid64 = (uint64_t)(xcd_map ? (P.n_pairs + 7u) / 8u * 8u : P.n_pairs) * P.qb_per_pair;
     if (grid64 == 0) return hipSuccess;
@@ -714,26 +719,33 @@ static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t m
     return hipGetLastError();
 }
 
+// The A/B variants below (tools/ab_l2.py) -- including two ablations whose results are meaningless (timing only) -- exist
+// only in the developer build (-DR3DM_DEVTOOLS -> regard3d_amd/libr3dm_dev.so, build.sh dev); the product library compiles
+// one kernel per descriptor length and never reads the environment.
 hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, bool integer_mfma)
 {
     if (integer_mfma) {
+#ifdef R3DM_DEVTOOLS
         // R3DM_L2_INT_VARIANT (A/B measurements on 780 pairs of 8192 x 8192 rows, D = 128; the f32 tiles take 95.0 ms):
         //   2 = NJ 2 x 2 waves/SIMD (default, 12.4 ms) | 8 = same with a whole-tile prefetch window (12.95 ms) |
         //   4 = NJ 4 x 1 wave/SIMD (17.6 ms) | 9 = 2 without the epilogue (timing only, 11.4 ms)
-        static const int iv = [] { const char* v = getenv("R3DM_L2_INT_VARIANT"); return v ? atoi(v) : 2; }();
+        static const int iv = r3dm_dev_knob("R3DM_L2_INT_VARIANT", 2);
+        if (G == 16 && iv == 4) return launch_l2_int<8, 4, 4, 1>(st, P, max_nj_tiles);
+        if (G == 16 && iv == 9) return launch_l2_int<8, 2, 4, 2, 1>(st, P, max_nj_tiles);
+        if (G == 16 && iv == 8) return launch_l2_int<8, 2, 8, 2>(st, P, max_nj_tiles);
+#endif
         switch (G) {
             case 8:  return launch_l2_int<4, 2, 4, 2>(st, P, max_nj_tiles);
-            case 16: return iv == 4 ? launch_l2_int<8, 4, 4, 1>(st, P, max_nj_tiles)
-                          : iv == 9 ? launch_l2_int<8, 2, 4, 2, 1>(st, P, max_nj_tiles)
-                          : iv == 8 ? launch_l2_int<8, 2, 8, 2>(st, P, max_nj_tiles) : launch_l2_int<8, 2, 4, 2>(st, P, max_nj_tiles);
+            case 16: return launch_l2_int<8, 2, 4, 2>(st, P, max_nj_tiles);
             case 32: return launch_l2_int<16, 2, 4, 2>(st, P, max_nj_tiles);
             default: break;               // G = 18 (LIOP, never integer): f32 tiles
         }
     }
+#ifdef R3DM_DEVTOOLS
     // R3DM_L2_VARIANT selects a build of the kernel for A/B measurements (tools/ab_l2.py):
     //   0 epilogue after the MFMAs | 1 software-pipelined epilogue | 3 pipelined + wave-wide test-and-skip
     //   (default) | 9 ablation without epilogue (timing only) | 13 / 43: NJ = 1 x 3 waves/SIMD, NJ = 4 x 1 wave/SIMD
-    static const int variant = [] { const char* v = getenv("R3DM_L2_VARIANT"); return v ? atoi(v) : 3; }();
+    static const int variant = r3dm_dev_knob("R3DM_L2_VARIANT", 3);
     if (G == 16) {
         switch (variant) {
             case 0:  return launch_l2_t<16, 2, 4, 0, 2>(st, P, max_nj_tiles);
@@ -741,14 +753,16 @@ hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint
             case 9:  return launch_l2_t<16, 2, 4, 9, 2>(st, P, max_nj_tiles);
             case 13: return launch_l2_t<16, 1, 4, 3, 3>(st, P, max_nj_tiles);
             case 43: return launch_l2_t<16, 4, 4, 3, 1>(st, P, max_nj_tiles);
-            default: return launch_l2_t<16, 2, 4, 3, 2>(st, P, max_nj_tiles);
+            default: break;
         }
     }
+    if (G == 18 && variant == 0) return launch_l2_t<18, 2, 3, 0, 2>(st, P, max_nj_tiles);
+    if (G == 18 && variant == 2) return launch_l2_t<18, 2, 2, 3, 2>(st, P, max_nj_tiles);
+#endif
     switch (G) {
         case 8:  return launch_l2_t<8, 2, 4, 3, 2>(st, P, max_nj_tiles);
-        case 18: return variant == 0 ? launch_l2_t<18, 2, 3, 0, 2>(st, P, max_nj_tiles)
-                       : variant == 2 ? launch_l2_t<18, 2, 2, 3, 2>(st, P, max_nj_tiles)
-                                      : launch_l2_t<18, 2, 3, 3, 2>(st, P, max_nj_tiles);
+        case 16: return launch_l2_t<16, 2, 4, 3, 2>(st, P, max_nj_tiles);
+        case 18: return launch_l2_t<18, 2, 3, 3, 2>(st, P, max_nj_tiles);
         case 32: return launch_l2_t<32, 1, 4, 3, 2>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }

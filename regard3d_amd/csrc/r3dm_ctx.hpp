@@ -48,7 +48,7 @@ struct HostImage {
     uint32_t G = 0, n_tiles = 0, words = 0;
     bool has_xy = false, has_dup = false, live = false;
     DevBuf rows, tiled, tiled16, norms, bin, xy, canon;
-    float max_abs = 0.0f; bool not_integer = true;     // staging statistics (read back after the staging kernel)
+    float max_abs = 0.0f; bool not_integer = true, has_negative = true;     // staging statistics (read back after the staging kernel)
     DevBuf ann_adj, ann_deg;          // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0
     uint32_t ann_K = 0;
     bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter

@@ -7,6 +7,19 @@
 
 #include "../../include/r3dm.h"
 
+// Developer knobs -- A/B kernel variants (two of them ablations whose results are meaningless), traces, invariant checks, the
+// launch-order switches -- exist only in the developer build: `build.sh dev` compiles the same sources with -DR3DM_DEVTOOLS
+// plus tools/devtools/dev_knobs.cpp (the one place that calls getenv) into regard3d_amd/libr3dm_dev.so for tools/ and the
+// fallback-path tests.  The product library (libr3dm.so) resolves every knob to its default at compile time and never reads
+// the environment: a stray variable cannot change what a product call computes.
+#ifdef R3DM_DEVTOOLS
+int r3dm_dev_knob(const char* name, int dflt);
+const char* r3dm_dev_str(const char* name);
+#else
+constexpr int r3dm_dev_knob(const char*, int dflt) { return dflt; }
+constexpr const char* r3dm_dev_str(const char*) { return nullptr; }
+#endif
+
 namespace r3dm {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;       // "no match" / invalid row
@@ -34,7 +47,7 @@ struct ImgDev {
     uint32_t width, height;
     uint32_t max_norm_bits;    // float bits of max ||row||^2 (filled by the staging kernel)
     uint32_t max_abs_bits;     // float bits of max |element|   (filled by the staging kernel)
-    uint32_t not_integer;      // != 0 if some element is not an integer (filled by the staging kernel)
+    uint32_t not_integer;      // bit 0: some element is not an integer, bit 1: some element is negative (filled by the staging kernel)
     // graph index of the view (kernels_ann.hip), nullptr until r3dm_match_pairs_kgraph builds it
     const uint32_t* ann_adj;   // [n][kAnnDeg] neighbour rows ordered by (distance, id), kNone padded
     const uint32_t* ann_deg;   // [n] valid entries of each adjacency row

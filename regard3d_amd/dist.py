@@ -23,15 +23,8 @@ def shard_pairs(pairs: np.ndarray, rank: int, world: int) -> np.ndarray:
     pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
     if world <= 1:
         return pairs
-    rows, counts = np.unique(pairs[:, 0], return_counts=True)
-    order = np.argsort(-counts, kind="stable")
-    owner = np.empty(rows.size, np.int64)
-    for pos, k in enumerate(order):
-        rnd, off = divmod(pos, world)
-        owner[k] = off if rnd % 2 == 0 else world - 1 - off
-    lut = dict(zip(rows.tolist(), owner.tolist()))
-    mask = np.fromiter((lut[int(i)] == rank for i in pairs[:, 0]), dtype=bool, count=pairs.shape[0])
-    return pairs[mask]
+    # the deal itself is the library's (r3dm_shard_pairs: the same rule the single-process multi-GPU entry uses)
+    return pairs[api.shard_owner(pairs, world) == rank]
 
 
 def _pack(g: api.Graph) -> np.ndarray:

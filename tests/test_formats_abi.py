@@ -117,3 +117,45 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert "pyoracle" not in txt and "liboracle" not in txt and "r3d_oracle.h" not in txt, fn
+
+
+def test_product_library_never_reads_the_environment():
+    """The A/B kernel variants (two of them ablations that return garbage), traces and test hooks live in the developer build
+    only (build.sh dev -> libr3dm_dev.so, -DR3DM_DEVTOOLS): the product sources contain no getenv call outside the
+    #ifdef'd declaration and the product library does not import the symbol."""
+    import subprocess
+    csrc = os.path.join(ROOT, "regard3d_amd", "csrc")
+    for fn in os.listdir(csrc):
+        txt = open(os.path.join(csrc, fn)).read()
+        txt = re.sub(r"//.*", "", txt)
+        assert "getenv" not in txt, fn
+    so = os.path.join(ROOT, "regard3d_amd", "libr3dm.so")
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+    # the timing-only ablation kernels (PIPE == 9, ABL == 1) are not even compiled into the product library
+    names = subprocess.run(["nm", "-C", so], capture_output=True, text=True).stdout
+    assert "l2_knn2_mfma_kernel<16, 2, 4, 9, 2>" not in names and "l2_knn2_int_kernel<8, 2, 4, 2, 1>" not in names
+    assert "l2_knn2_mfma_kernel<16, 2, 4, 3, 2>" in names
+
+
+def test_shard_pairs_is_balanced_keeps_rows_together_and_is_a_partition():
+    from regard3d_amd import api, dist
+    for n, world in ((200, 8), (1000, 8), (37, 2), (10, 4), (5, 8)):
+        ii, jj = np.triu_indices(n, k=1)
+        pairs = np.stack([ii, jj], 1).astype(np.uint32)
+        owner = api.shard_owner(pairs, world)
+        # rows of I stay on one rank
+        for I in range(n - 1):
+            assert len(set(owner[pairs[:, 0] == I].tolist())) == 1
+        counts = np.bincount(owner, minlength=world)
+        if n >= 4 * world:
+            assert counts.max() - counts.min() <= n, (n, world, counts)
+        parts = [dist.shard_pairs(pairs, r, world) for r in range(world)]
+        allp = np.concatenate(parts)
+        assert allp.shape == pairs.shape
+        assert np.array_equal(allp[np.lexsort((allp[:, 1], allp[:, 0]))], pairs)
+    # the rule itself: rows by decreasing pair count (ascending I among equals), dealt 0..W-1, W-1..0, ...
+    pairs = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3], [7, 9], [7, 8]], np.uint32)
+    assert api.shard_owner(pairs, 2).tolist() == [0, 0, 0, 1, 1, 0, 1, 1]
+    assert api.shard_owner(pairs, 1).tolist() == [0] * 8
+    assert api.shard_owner(np.zeros((0, 2), np.uint32), 3).size == 0

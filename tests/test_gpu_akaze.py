@@ -58,8 +58,9 @@ def test_many_extrema_take_the_scratch_path(ctx, oracle):
 
 
 def test_live_set_overflow_falls_back_to_scratch(ctx, tmp_path):
-    """R3DM_AK_LIVE_CAP=8 (test hook) makes the LDS live set of the in-level pruning overflow on every level, so each level is
-    redone with the live set in global scratch: the keypoints must not change."""
+    """R3DM_AK_LIVE_CAP=8 (test hook of the DEVELOPER build, libr3dm_dev.so: the product library ignores the environment) makes
+    the LDS live set of the in-level pruning overflow on every level, so each level is redone with the live set in global
+    scratch: the keypoints must not change."""
     import os, subprocess, sys
     rng = np.random.default_rng(8)
     img = np.clip(0.5 + rng.normal(0, 0.2, (500, 700)), 0, 1).astype(np.float32)
@@ -67,7 +68,7 @@ def test_live_set_overflow_falls_back_to_scratch(ctx, tmp_path):
     assert len(kps) > 2000
     np.save(str(tmp_path / "img.npy"), img)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np; from regard3d_amd import api; "
+    code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np; from regard3d_amd import api; api.use_developer_library(); "
             f"c = api.Context(0); k, r = c.detect_akaze(np.load({str(tmp_path / 'img.npy')!r}), 1e-6); "
             f"np.save({str(tmp_path / 'k.npy')!r}, k); np.save({str(tmp_path / 'r.npy')!r}, r)")
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, R3DM_AK_LIVE_CAP="8"), capture_output=True, text=True, timeout=300)

@@ -4,6 +4,9 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from regard3d_amd import api, synth
+import os as _os
+if any(k.startswith("R3DM_") for k in _os.environ):
+    api.use_developer_library()      # R3DM_* knobs / traces exist only in the developer build (build.sh dev); otherwise measure the product
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 kind = sys.argv[2] if len(sys.argv) > 2 else "sift"
 if kind == "sift":

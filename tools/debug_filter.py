@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from regard3d_amd import api, synth
+api.use_developer_library()      # the per-model trace (R3DM_TRACE_*) exists only in the developer build (build.sh dev)
 from oracle import pyoracle as O
 
 n_img, n_feat, seed = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

@@ -4,6 +4,9 @@ import sys, os, collections
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from regard3d_amd import api, synth
+import os as _os
+if any(k.startswith("R3DM_") for k in _os.environ):
+    api.use_developer_library()      # R3DM_* knobs / traces exist only in the developer build (build.sh dev); otherwise measure the product
 sc = synth.make_scene(200, 8192, "sift", seed=2002)
 c = api.Context(0)
 for i in range(sc.n_images):

@@ -3,6 +3,9 @@ import argparse, json, sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from regard3d_amd import api, synth
+import os as _os
+if any(k.startswith("R3DM_") for k in _os.environ):
+    api.use_developer_library()      # R3DM_* knobs / traces exist only in the developer build (build.sh dev); otherwise measure the product
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--images", type=int, default=24)
