@@ -151,13 +151,18 @@ def make_scene(n_images: int, n_feat: int, kind: str = "sift", seed: int = 2002,
                  widths=np.full(n_images, WIDTH, np.uint32), heights=np.full(n_images, HEIGHT, np.uint32))
 
 
-def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda", dim: int = 128,
-                     outlier_frac: float = 0.15):
-    """The "sift" scene of make_scene(), sampled with torch's device RNG so that bench.py can build
-    the 200 x 8192 x 128 workload (and its weak-scaling siblings) in about a second, directly in HBM.
+def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda", dim: int | None = None,
+                     outlier_frac: float = 0.15, kind: str = "sift"):
+    """The scenes of make_scene() ("sift": integer-valued f32 bins; "liop": the same real-valued, unit length, 144-D;
+    "akaze": 486 random bits with 8 % flips per observation, packed LSB-first into 61 of 64 bytes), sampled with torch's
+    device RNG so that bench.py can build the 200 x 8192 workloads (and the 1000-view ones) in seconds, directly in HBM.
     Every rank that calls it with the same seed on the same GPU model gets the same tensors.
-    Returns (descs [N, n, dim] f32, xys [N, n, 2] f32, world_ids [N, n] int64) on `device`."""
+    Returns (descs [N, n, dim] f32 -- uint8 for "akaze" --, xys [N, n, 2] f32, world_ids [N, n] int64) on `device`."""
     import torch
+
+    assert kind in ("sift", "liop", "akaze")
+    if dim is None:
+        dim = {"sift": 128, "liop": 144, "akaze": 64}[kind]
 
     g = torch.Generator(device=device); g.manual_seed(seed)
     n_shared = int(round(0.6 * n_feat)); step = max(n_shared // 4, 1)
@@ -179,8 +184,19 @@ def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda"
         return b.clamp_(0.0, 255.0)
 
     torch.manual_seed(seed); torch.cuda.manual_seed(seed) if str(device).startswith("cuda") else None
-    wbase = sift_base(n_world)
-    descs = torch.empty((n_images, n_feat, dim), device=device, dtype=torch.float32)
+    if kind == "akaze":
+        wbits = torch.rand((n_world, 488), generator=g, device=device) < 0.5
+        wbits[:, 486:] = False
+        bitw = (2 ** torch.arange(8, device=device, dtype=torch.int32)).view(1, 1, 8)
+
+        def pack(bits):                                   # [n, 488] bool -> [n, 64] uint8, LSB first, bytes 61..63 zero
+            by = (bits.view(bits.shape[0], 61, 8).to(torch.int32) * bitw).sum(dim=2).to(torch.uint8)
+            out = torch.zeros((bits.shape[0], dim), device=device, dtype=torch.uint8)
+            out[:, :61] = by
+            return out
+    else:
+        wbase = sift_base(n_world)
+    descs = torch.empty((n_images, n_feat, dim), device=device, dtype=torch.uint8 if kind == "akaze" else torch.float32)
     xys = torch.empty((n_images, n_feat, 2), device=device, dtype=torch.float32)
     wids = torch.full((n_images, n_feat), -1, device=device, dtype=torch.int64)
     for i in range(n_images):
@@ -201,10 +217,22 @@ def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda"
         xy = torch.empty((n_feat, 2), device=device, dtype=torch.float64)
         xy[:n_shared, 0] = u; xy[:n_shared, 1] = v
         xy[n_shared:, 0] = U(n_dis) * WIDTH; xy[n_shared:, 1] = U(n_dis) * HEIGHT
-        d = torch.empty((n_feat, dim), device=device, dtype=torch.float32)
-        d[:n_shared] = wbase[ids]; d[n_shared:] = sift_base(n_dis)
-        d += 6.0 * torch.randn((n_feat, dim), generator=g, device=device, dtype=torch.float32)
-        d.clamp_(0.0, 255.0).round_()
+        if kind == "akaze":
+            bits = torch.empty((n_feat, 488), device=device, dtype=torch.bool)
+            flips = torch.rand((n_shared, 488), generator=g, device=device) < 0.08
+            bits[:n_shared] = wbits[ids] ^ flips
+            bits[n_shared:] = torch.rand((n_dis, 488), generator=g, device=device) < 0.5
+            bits[:, 486:] = False
+            d = pack(bits)
+        else:
+            d = torch.empty((n_feat, dim), device=device, dtype=torch.float32)
+            d[:n_shared] = wbase[ids]; d[n_shared:] = sift_base(n_dis)
+            d += 6.0 * torch.randn((n_feat, dim), generator=g, device=device, dtype=torch.float32)
+            d.clamp_(0.0, 255.0)
+            if kind == "sift":
+                d.round_()
+            else:
+                d /= d.norm(dim=1, keepdim=True).clamp_min(1e-12)
         perm = torch.randperm(n_feat, generator=g, device=device)
         descs[i] = d[perm]; xys[i] = xy[perm].float()
         w = torch.full((n_feat,), -1, device=device, dtype=torch.int64); w[:n_shared] = ids

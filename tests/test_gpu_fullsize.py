@@ -140,16 +140,46 @@ def test_bench_contract_one_and_two_ranks(tmp_path):
     assert j1["opt_in_integer_mfma"]["identical_to_headline_graphs"] is True and j1["opt_in_integer_mfma"]["integer_mfma_launches"] == 1
     env = dict(os.environ, R3DM_SHARE_GPU="1", R3DM_DIST_BACKEND="gloo")
     port = 29600 + os.getpid() % 300
+    # default N > 1 = STRONG scaling of the same collection (the metric's "200 img x 8k, 1/2/4/8 GPU"): 17 images, 136 pairs
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--images", "12"] + common, capture_output=True, text=True, timeout=300, env=env)
+                          "--gpus", "2", "--images", "17"] + common, capture_output=True, text=True, timeout=300, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     j2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
-    # weak scaling: 2 ranks x C(12,2) = 132 pairs -> 17 images (136 pairs), the same collection as the N = 1 run above
-    assert j2["n_gpus"] == 2 and j2["config"]["images"] == 17 and j2["config"]["pairs"] == 136 and j2["scaling"] == "weak"
+    assert j2["n_gpus"] == 2 and j2["config"]["images"] == 17 and j2["config"]["pairs"] == 136 and j2["scaling"] == "strong"
     assert 0 < j2["config"]["pairs_this_rank"] < 136
     for k in ("putative_pairs", "putative_matches", "F_pairs", "F_matches"):
         assert j2["detail"][k] == j1["detail"][k], k
+    # --scaling weak: 2 ranks x C(12,2) = 132 pairs -> 17 images (136 pairs), the same collection again
+    wk = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port + 1), os.path.join(root, "bench.py"),
+                         "--gpus", "2", "--images", "12", "--scaling", "weak"] + common, capture_output=True, text=True, timeout=300, env=env)
+    assert wk.returncode == 0, wk.stderr[-2000:]
+    j3 = json.loads([l for l in wk.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j3["config"]["images"] == 17 and j3["config"]["pairs"] == 136 and j3["scaling"] == "weak"
+    for k in ("putative_pairs", "putative_matches", "F_pairs", "F_matches"):
+        assert j3["detail"][k] == j1["detail"][k], k
+
+
+@pytest.mark.parametrize("config,extra", [("c3", ["--images", "10", "--feat", "2048"]), ("liop144", ["--images", "10", "--feat", "2048"]),
+                                          ("c5", ["--images", "6", "--feat", "4096"]), ("c4", ["--images", "24", "--feat", "1024", "--emulate-world", "8"])])
+def test_bench_config_legs(config, extra):
+    """every BASELINE config has a bench leg with its own roofline and a CPU baseline that doubles as a parity check"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", "1", "--warmup", "1",
+                        "--cpu-seconds", "0.5"] + extra, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["config"]["name"] == config and j["roofline"]["achieved"] > 0 and j["value"] > 0
+    assert j["roofline"]["bound"] == {"c3": "valu", "c5": "hbm"}.get(config, "mfma")
+    cb = j["cpu_baseline"]
+    assert cb["parity_pairs_checked"] >= 1 and cb["putative_mismatches"] == 0 and cb["F_inlier_set_mismatches"] == 0, cb
+    assert j["detail"]["putative_matches"] > 0
+    if config == "c4":
+        assert "shard 0 of 8" in j["config"]["workload"] and j["config"]["pairs"] < 24 * 23 // 2
+        assert cb["optimised_cpu"]["reference_built_index_mismatches"] == 0 and cb["optimised_cpu"]["reference_built_distance_mismatches"] == 0
+        assert cb["optimised_cpu"]["reference_built_rows_checked"] > 0
 
 
 def test_graph_exchange_over_rccl_single_rank(tmp_path):
