@@ -196,6 +196,8 @@ def main():
     if world == 1 and not a.no_opt_in and kp is None and kind == "sift":
         out["opt_in_integer_mfma"] = opt_in_integer(ctx, step, fence, g, gf, job_pairs)
         attach_traffic(out["opt_in_integer_mfma"]["roofline"], a.config, "l2_knn2_int_kernel", emu, base_images, n_feat)
+    if world == 1 and not a.no_opt_in and kp is None and kind == "liop":
+        out["opt_in_split_mfma"] = opt_in_split(ctx, step, fence, g, gf, job_pairs)
     if world == 1:
         attach_traffic(out["roofline"], a.config, out["roofline"]["kernel"].split("<")[0], emu, base_images, n_feat)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -278,6 +280,32 @@ def opt_in_integer(ctx, step, fence, g, gf, job_pairs):
             "roofline": {"bound": "mfma", "kernel": "l2_knn2_int_kernel<GB=8,NJ=2>", "achieved": ach2, "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach2 / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
+            "filter_kernel_ms": sa2.ms_filter_kernels,
+            "wall_ms": {"match": sa2.ms_wall_match, "match_post": sa2.ms_wall_match_post, "filter": sa2.ms_wall_filter}}
+
+
+def opt_in_split(ctx, step, fence, g, gf, job_pairs):
+    """the same step with the split-f16 nominator (r3dm_set_split_mfma): nomination on v_mfma_f32_32x32x16_f16, distances and
+    certification in the reference's f32 arithmetic as before -- bit-identical graphs, reported beside the headline"""
+    ctx.set_split_mfma(True)
+    try:
+        step(); fence()
+        t1 = time.perf_counter()
+        g2, gf2, _, sm2, sa2 = step()
+        fence()
+        el2 = time.perf_counter() - t1
+    finally:
+        ctx.set_split_mfma(False)
+    same = all(np.array_equal(getattr(x, f), getattr(y, f)) for x, y in ((g, g2), (gf, gf2)) for f in ("pairs", "offsets", "matches"))
+    # matrix work of the split kernel: 3 f16 MFMAs per 16 dims = 3 x the algorithmic 2 n^2 D flops
+    ach = 3.0 * sm2.algorithmic_flops / (sm2.ms_match_kernels * 1e-3) / 1e12 if sm2.ms_match_kernels > 0 else 0.0
+    return {"value": job_pairs / el2, "unit": "pairs/s", "ms_per_step": el2 * 1e3, "steps": 1,
+            "identical_to_headline_graphs": bool(same), "split_mfma_launches": int(sm2.n_split_mfma),
+            "dtype": "f16 hi/lo pieces nominate (3 MFMAs per 16 dims, f32 accumulate); distances re-scored in f32 as in the headline",
+            "exact_fallback_fraction": sm2.n_exact_fallback / max(sm2.n_queries, 1),
+            "roofline": {"bound": "mfma", "kernel": "l2_knn2_split_kernel<GB=9,NJ=2>", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s (executed f16 matrix flops = 3 x algorithmic)", "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_tflops": ach / 3.0, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
             "filter_kernel_ms": sa2.ms_filter_kernels,
             "wall_ms": {"match": sa2.ms_wall_match, "match_post": sa2.ms_wall_match_post, "filter": sa2.ms_wall_filter}}
 

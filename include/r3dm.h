@@ -92,6 +92,16 @@ int r3dm_clear_images(r3dm_ctx* ctx);
  * which path ran. */
 int r3dm_set_integer_mfma(r3dm_ctx* ctx, int enable);
 
+/* Opt-in split-f16 nominator of the L2 matcher for REAL-valued descriptors (default off; no reference counterpart) -- LIOP-144,
+ * normalised SIFT: what Regard3D actually matches (src/Regard3DFeatures.h:44-48).  Their matching is always "nominate on
+ * MFMA keys, re-score the nominees with the reference's own summation (L2_Vectorized order, no FMA), certify against a
+ * rounding slack, exact scan for what cannot be certified".  With this switch the nomination runs on
+ * v_mfma_f32_32x32x16_f16 with every value split into two f16 pieces (a.b ~ ah.bh + al.bh + ah.bl, 3/16 of the matrix
+ * cycles of the f32 tiles) and a slack that covers the split; the distances that are compared, ratio-tested and returned
+ * are still the reference's f32 sums, so results are bit-identical to the default path and to the CPU restatement.
+ * Batches of integer-valued views keep the f32 tiles (or r3dm_set_integer_mfma).  r3dm_stats.n_split_mfma reports which path ran. */
+int r3dm_set_split_mfma(r3dm_ctx* ctx, int enable);
+
 /* ---- putative matching ----
  * pairs_ij: n_pairs x 2 view ids (I, J); J's rows are the queries, I's rows the dataset.
  * dist_ratio: Lowe ratio (0.6 default in the reference, src/Regard3DFeatures.cpp:129);
@@ -299,6 +309,7 @@ typedef struct {
     uint64_t n_ann_dist;           /* descriptor distances evaluated by the searches                */
     double   ms_detect;            /* wall time of the last r3dm_detect_akaze call                  */
     uint64_t n_integer_mfma;       /* launches of the dominant kernel that ran as the integer fast path  */
+    uint64_t n_split_mfma;         /* launches of the dominant kernel that ran as the split-f16 nominator */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
-    "r3dm_set_integer_mfma",
+    "r3dm_set_integer_mfma", "r3dm_set_split_mfma",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
     "r3dm_multi_match_pairs", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("algorithmic_bytes", C.c_double), ("ms_wall_match", C.c_double),
                 ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double), ("ms_liop_kernel", C.c_double),
                 ("ms_ann_build", C.c_double), ("ms_ann_search", C.c_double), ("n_ann_built", C.c_uint64),
-                ("n_ann_dist", C.c_uint64), ("ms_detect", C.c_double), ("n_integer_mfma", C.c_uint64)]
+                ("n_ann_dist", C.c_uint64), ("ms_detect", C.c_double), ("n_integer_mfma", C.c_uint64),
+                ("n_split_mfma", C.c_uint64)]
 
 
 class KGraphParams(C.Structure):
@@ -97,6 +98,7 @@ def load_library():
     L.r3dm_set_image.argtypes = [vp, u32, u32, u32, vp, u32, u32, C.c_int, vp]
     L.r3dm_clear_images.argtypes = [vp]
     L.r3dm_set_integer_mfma.argtypes = [vp, C.c_int]
+    L.r3dm_set_split_mfma.argtypes = [vp, C.c_int]
     L.r3dm_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
     L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
     L.r3dm_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
@@ -343,6 +345,10 @@ class Context:
     def set_integer_mfma(self, enable: bool = True):
         """opt-in bf16-exact MFMA path for integer-valued descriptors (include/r3dm.h: r3dm_set_integer_mfma)"""
         self._check(self._L.r3dm_set_integer_mfma(self._h, int(bool(enable))), "r3dm_set_integer_mfma")
+
+    def set_split_mfma(self, enable: bool = True):
+        """opt-in split-f16 nominator for real-valued descriptors (include/r3dm.h: r3dm_set_split_mfma)"""
+        self._check(self._L.r3dm_set_split_mfma(self._h, int(bool(enable))), "r3dm_set_split_mfma")
 
     def set_intrinsics(self, view_id: int, K):
         K = None if K is None else np.ascontiguousarray(K, np.float64).reshape(9)

@@ -104,6 +104,7 @@ static int upload_imgdev(r3dm_ctx* c, uint32_t slot)
     d.width = h.width; d.height = h.height; d.max_norm_bits = 0; d.max_abs_bits = 0; d.not_integer = 0;
     d.ann_adj = nullptr; d.ann_deg = nullptr;          // staging invalidates the graph index
     d.tiled16 = h.tiled16.as<uint16_t>();
+    d.tiledh = h.tiledh.as<uint16_t>(); d.split_k = 0;
     R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
     return R3DM_OK;
@@ -136,6 +137,9 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         const size_t tiled16_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 1024 + kSlackBytes;
         R3DM_HIP(c, h.tiled16.ensure(tiled16_bytes));
         R3DM_HIP(c, hipMemsetAsync(h.tiled16.p, 0, tiled16_bytes, c->stream));
+        const size_t tiledh_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 2048 + kSlackBytes;      // f16 hi | lo planes (split nominator)
+        R3DM_HIP(c, h.tiledh.ensure(tiledh_bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiledh.p, 0, tiledh_bytes, c->stream));
         R3DM_HIP(c, h.norms.ensure(norm_bytes));
         R3DM_HIP(c, hipMemsetAsync(h.tiled.p, 0, tiled_bytes, c->stream));
         R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0, norm_bytes, c->stream));
@@ -190,8 +194,11 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         uint32_t* mx = &(c->d_imgs.as<ImgDev>() + slot)->max_norm_bits;
         R3DM_HIP(c, launch_stage_f32(c->stream, n ? c->d_raw.p : nullptr, dtype == R3DM_U8, n, dim, h.rows.as<float>(),
                                      h.tiled.as<float>(), h.tiled16.as<uint16_t>(), h.norms.as<float>(), h.G, h.n_tiles, mx));
+        int32_t* sk = &(c->d_imgs.as<ImgDev>() + slot)->split_k;
+        R3DM_HIP(c, launch_stage_split(c->stream, h.rows.as<float>(), n, dim, (h.G + 1) / 2, h.n_tiles, h.tiledh.as<uint16_t>(), mx, sk));
         uint32_t st3[3] = {0, 0, 1};
         R3DM_HIP(c, hipMemcpyAsync(st3, mx, 12, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(&h.split_k, sk, 4, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));
         std::memcpy(&h.max_abs, &st3[1], 4);
         h.not_integer = (st3[2] & 1u) != 0;
@@ -236,6 +243,13 @@ extern "C" int r3dm_set_integer_mfma(r3dm_ctx* c, int enable)
 {
     if (!c) return R3DM_ERR_INVALID;
     c->integer_mfma = (enable != 0);
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_set_split_mfma(r3dm_ctx* c, int enable)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    c->split_mfma = (enable != 0);
     return R3DM_OK;
 }
 

@@ -105,6 +105,20 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
                                     : (2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f));
             if (!exact) { int_mfma = false; break; }
         }
+    // split-f16 nominator (r3dm_set_split_mfma): batches with at least one real-valued view (integer-valued batches are exact
+    // on the f32 tiles already and have their own fast path); every view finite, scales within reach of one another
+    bool split = c->split_mfma && !int_mfma && dtype != R3DM_BIN && has_tensor_kernel(first.G);
+    if (split) {
+        bool any_real = false;
+        for (const PairJob& j : jobs) {
+            const HostImage& A = *c->imgs[j.sI];
+            const HostImage& B = *c->imgs[j.sJ];
+            any_real |= A.not_integer || B.not_integer;
+            if (!std::isfinite(A.max_abs) || !std::isfinite(B.max_abs) || !(A.max_abs > 0.0f) || !(B.max_abs > 0.0f) ||
+                std::abs(A.split_k - B.split_k) > 40 || std::abs(A.split_k + B.split_k) > 100) { split = false; break; }
+        }
+        split = split && any_real;
+    }
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
     const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
 
@@ -133,6 +147,10 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
     // certification slack factor: |MFMA-path distance - reference distance| <= (3.5 D + 14) u (max||a||^2 + ||q||^2),
     // u = 2^-24 (DESIGN.md "Certification"); 4.25 D u covers it for every padded D >= 64
     mp.err_scale = 4.25f * (float)(first.G * 8) * 5.9604645e-08f;
+    // split-f16 keys: residue of the two-piece split 3 x 2^-22 ||a|| ||b|| <= 1.5 x 2^-22 (||a||^2 + ||b||^2), f32 accumulation of
+    // 3 Dpad products + one C operand per MFMA with a one-sided 2^-23 per addition on partial sums <= 2 (||a||^2 + ||b||^2), plus the
+    // reference sum's own (D/2 + 12) 2^-24 -- together below (3 Dpad + 34) 2^-22 (kernels_match.hip, l2_knn2_split_kernel)
+    if (split) mp.err_scale = (3.0f * (float)(first.G * 8) + 34.0f) * 2.3841858e-07f;
     mp.nn_idx = c->d_nn.as<uint32_t>();
     mp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
     mp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
@@ -145,9 +163,15 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
     if (dtype == R3DM_BIN) {
         R3DM_HIP(c, launch_hamming_knn2(c->stream, mp, first.words, max_nJ));
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));      // (the finaliser would wait here anyway; keeps the wall breakdown honest)
     } else if (has_tensor_kernel(first.G)) {
-        R3DM_HIP(c, launch_l2_knn2(c->stream, mp, first.G, max_tiles, int_mfma));
-        if (int_mfma) c->stats.n_integer_mfma += 1;
+        if (split) {
+            R3DM_HIP(c, launch_l2_knn2_split(c->stream, mp, first.G, max_tiles));
+            c->stats.n_split_mfma += 1;
+        } else {
+            R3DM_HIP(c, launch_l2_knn2(c->stream, mp, first.G, max_tiles, int_mfma));
+            if (int_mfma) c->stats.n_integer_mfma += 1;
+        }
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         uint32_t fbt[2] = {0, 0};
         R3DM_HIP(c, hipMemcpyAsync(fbt, mp.fb_total, 8, hipMemcpyDeviceToHost, c->stream));
@@ -225,7 +249,9 @@ extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t 
             if (A.dtype != F.dtype || A.dim != F.dim) break;
             const uint32_t mn = std::max(max_n, c->imgs[jobs[end].sJ]->n);
             const uint64_t s = (uint64_t)(end - start + 1) * ((mn + 31) / 32 * 32);
-            if (end > start && s * 4 > (3ull << 30)) break;       // <= 3 GiB of nn_idx per batch
+            // <= 3 GiB of nn_idx per batch; one 256-thread workgroup per >= 128 queries keeps the dispatch below 2^32 work-items,
+            // one workgroup per pair in the finaliser / exact scan below kMaxBlocksOf256
+            if (end > start && (s * 4 > (3ull << 30) || end - start >= kMaxBlocksOf256 - 8)) break;
             max_n = mn; slots = s; ++end;
         }
         (void)slots;
@@ -257,8 +283,12 @@ extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, c
         const r3dm_stats keep = c->stats;
         rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
         const uint64_t int_launches = c->stats.n_integer_mfma - keep.n_integer_mfma;
+        const uint64_t split_launches = c->stats.n_split_mfma - keep.n_split_mfma;
+        const uint64_t fb = c->stats.n_exact_fallback - keep.n_exact_fallback;
         c->stats = keep;
-        c->stats.n_integer_mfma = int_launches;           // which tiles this call ran on (r3dm_set_integer_mfma)
+        c->stats.n_integer_mfma = int_launches;           // which tiles this call ran on (r3dm_set_integer_mfma / r3dm_set_split_mfma)
+        c->stats.n_split_mfma = split_launches;
+        c->stats.n_exact_fallback = fb;                   // ... and how many of its queries went through the exact scan
     }
     (void)hipStreamSynchronize(c->stream);
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
@@ -488,7 +518,8 @@ extern "C" int r3dm_match_pairs_kgraph(r3dm_ctx* c, const uint32_t* pairs_ij, ui
             if (c->imgs[ann_jobs[end].sI]->dim != dim) break;
             const uint32_t mn = std::max(max_n, c->imgs[ann_jobs[end].sJ]->n);
             const uint64_t s = (uint64_t)(end - start + 1) * ((mn + 31) / 32 * 32);
-            if (end > start && (s * 4 > (3ull << 30) || s / 4 > 0x40000000ull)) break;
+            // <= 3 GiB of nn_idx, and one workgroup per 4 queries: the dispatch must stay below 2^32 work-items (kMaxBlocksOf256)
+            if (end > start && (s * 4 > (3ull << 30) || s / 4 > kMaxBlocksOf256 - 4096)) break;
             max_n = mn; ++end;
         }
         std::vector<PairJob> batch(ann_jobs.begin() + start, ann_jobs.begin() + end);

@@ -405,7 +405,7 @@ hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& Pin, uint32_
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const uint64_t grid = (uint64_t)P.n_pairs * P.qb_per_pair;
     if (grid == 0) return hipSuccess;
-    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (grid > kMaxBlocksOf256) return hipErrorInvalidValue;
     const uint32_t nq = (dim / 4 + 3) / 4;
 #define R3DM_ANN_LAUNCH(NQ)                                                                                            \
     do {                                                                                                               \

@@ -298,10 +298,14 @@ __device__ __forceinline__ void lex_push(Top2& s, float key, uint32_t idx)
 }
 
 // LEX: the lists are exact lexicographic (distance, index) top-2 lists without a bound (l2_knn2_int_kernel)
-template <int NJ, bool LEX = false>
+// SPLIT: the keys come from the split-f16 nominator (l2_knn2_split_kernel) in units of key_inv^-1; a query whose merged
+//        top-2 cannot be certified gets a second chance with all four nominees of its two lane halves before it is sent to
+//        the exact scan
+template <int NJ, bool LEX = false, bool SPLIT = false>
 __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t pair, const ImgDev* __restrict__ Ip,
                                                   const ImgDev* __restrict__ Jp, const Top2 (&st)[NJ], uint32_t qt0,
-                                                  uint32_t h, uint32_t c, float dpad, bool bf16_tiles)
+                                                  uint32_t h, uint32_t c, float dpad, bool bf16_tiles,
+                                                  float key_inv = 1.0f, float slack_abs = 0.0f)
 {
     const uint32_t nI = Ip->n, nJ = Jp->n, ntJ = Jp->n_tiles;
     const float maxnorm = __uint_as_float(Ip->max_norm_bits);
@@ -315,13 +319,15 @@ __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t
     // D (mI + mJ)^2, where the reference's own sum starts to round: one bound on the latter covers both.
     const float mI = __uint_as_float(Ip->max_abs_bits), mJ = __uint_as_float(Jp->max_abs_bits);
     const uint32_t fl = Ip->not_integer | Jp->not_integer;              // bit 0: non-integer, bit 1: negative elements
-    const bool exact_pair = (fl & 1u) == 0u &&
+    const bool exact_pair = !SPLIT && (fl & 1u) == 0u &&
                             ((fl & 2u) ? dpad * (mI + mJ) * (mI + mJ) < 16777216.0f
                                        : (2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f)) &&
                             (!bf16_tiles || (mI <= 256.0f && mJ <= 256.0f));      // bf16 tiles hold the values exactly
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         Top2 s = st[nj];
+        if constexpr (SPLIT) { s.d0 *= key_inv; s.d1 *= key_inv; s.d2 *= key_inv; }     // power-of-two scale: order unchanged
+        const Top2 own = s;                              // this lane half's list (rows 8 qd + 4 h + k of every tile)
         // partner half (same query column, the other 16 rows of every tile)
         const float pd0 = __shfl_xor(s.d0, 32), pd1 = __shfl_xor(s.d1, 32), pd2 = __shfl_xor(s.d2, 32);
         const uint32_t pi0 = __shfl_xor(s.i0, 32), pi1 = __shfl_xor(s.i1, 32);
@@ -356,28 +362,50 @@ __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t
         float ea = h ? eo : e, eb = h ? e : eo;          // ea <-> ci0, eb <-> ci1
         uint32_t ia = ci0, ib = ci1;
         if (eb < ea || (eb == ea && ib < ia)) { const float tf = ea; ea = eb; eb = tf; const uint32_t tu = ia; ia = ib; ib = tu; }
+        // certification (evaluated identically by both lane halves of a query)
+        const float nb = valid ? Jp->norms[q] : 0.0f;
+        const float slack = exact_pair ? 0.0f : P.err_scale * (maxnorm + nb) + slack_abs;
+        const float A3 = bound + nb;                        // distance of the best un-nominated row (exact if exact_pair)
+        // certified: every un-nominated row is strictly farther than the runner-up.  With exact
+        // arithmetic a runner-up that merely TIES an un-nominated row still fixes the best row (ea < eb)
+        // and the runner-up DISTANCE, which is all the ratio test needs; only the raw 2-NN dump
+        // (r3dm_knn2) needs the tie's index resolved by the exact scan.
+        bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
+        if (bf16_tiles && !exact_pair) certified = false;      // bf16 keys of a non-exact pair mean nothing: exact scan
+        if constexpr (SPLIT) {
+            // second chance: the two lane halves of a query nominated up to four rows between them.  Re-score all four in the
+            // reference arithmetic and certify against the smallest key that NONE of them holds (each half's third key):
+            // the gap from the runner-up to the fifth-best row is what has to exceed the slack now, not the gap to the third.
+            const bool need = valid && nI >= 2 && !certified;
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                float f0 = R3DM_INF, f1 = R3DM_INF;
+                if (need) {
+                    const float* qrow = Jp->rows + (size_t)q * dim;
+                    if (own.i0 != kNone) f0 = exact_l2sq(Ip->rows + (size_t)own.i0 * dim, qrow, dim);
+                    if (own.i1 != kNone) f1 = exact_l2sq(Ip->rows + (size_t)own.i1 * dim, qrow, dim);
+                }
+                Top2 m4; top2_init(m4);
+                lex_push(m4, f0, own.i0); lex_push(m4, f1, own.i1);
+                const float g0 = __shfl_xor(f0, 32), g1 = __shfl_xor(f1, 32);
+                const uint32_t j0 = __shfl_xor(own.i0, 32), j1 = __shfl_xor(own.i1, 32);
+                lex_push(m4, g0, j0); lex_push(m4, g1, j1);
+                const float bound4 = fminf(own.d2, __shfl_xor(own.d2, 32));
+                if (need && m4.i1 != kNone && m4.d1 < (bound4 + nb) - slack) {
+                    ea = m4.d0; ia = m4.i0; eb = m4.d1; ib = m4.i1; certified = true;
+                }
+            }
+        }
         if (valid && h == 0) {
             if (nI < 2) {
                 emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
+            } else if (certified) {
+                emit_result(P, pair, q, ea, ia, eb, ib);
             } else {
-                const float nb = Jp->norms[q];
-                const float slack = exact_pair ? 0.0f : P.err_scale * (maxnorm + nb);
-                const float A3 = bound + nb;                        // distance of the best un-nominated row (exact if exact_pair)
-                // certified: every un-nominated row is strictly farther than the runner-up.  With exact
-                // arithmetic a runner-up that merely TIES an un-nominated row still fixes the best row (ea < eb)
-                // and the runner-up DISTANCE, which is all the ratio test needs; only the raw 2-NN dump
-                // (r3dm_knn2) needs the tie's index resolved by the exact scan.
-                bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
-                if (bf16_tiles && !exact_pair) certified = false;      // bf16 keys of a non-exact pair mean nothing: exact scan
-                if (certified) {
-                    emit_result(P, pair, q, ea, ia, eb, ib);
-                } else {
-                    P.nn_idx[(size_t)pair * P.q_stride + q] = kFallback;
-                    const uint32_t pos = atomicAdd(P.fb_cnt + pair, 1u);
-                    atomicAdd(P.fb_total, 1u);
-                    if (pos < kFbPerPair) P.fb_q[(size_t)pair * kFbPerPair + pos] = q;
-                    else atomicAdd(P.fb_total + 1, 1u);
-                }
+                P.nn_idx[(size_t)pair * P.q_stride + q] = kFallback;
+                const uint32_t pos = atomicAdd(P.fb_cnt + pair, 1u);
+                atomicAdd(P.fb_total, 1u);
+                if (pos < kFbPerPair) P.fb_q[(size_t)pair * kFbPerPair + pos] = q;
+                else atomicAdd(P.fb_total + 1, 1u);
             }
         }
     }
@@ -688,6 +716,237 @@ void l2_knn2_int_kernel(const MatchParams P)
     l2_finish_queries<NJ, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), true);
 }
 
+// ------------------------------------------------------------------------------------------------
+// split-f16 nomination for real-valued descriptors (r3dm_set_split_mfma): LIOP-144, normalised SIFT -- what Regard3D
+// actually matches (/root/reference/src/Regard3DFeatures.h:44-48).  Their path through l2_knn2_mfma_kernel is already
+// "nominate on MFMA keys -> re-score the nominees in the reference arithmetic -> certify against a rounding slack", so the
+// nominator need not run on f32 tiles.  Every value x of a view is scaled by the view's power of two s (max|x| s in
+// [2^13, 2^14)) and split into two f16 pieces x s = hi + lo + r with |r| <= 2^-22 |x s| (f16 carries 11 significant bits;
+// pieces below the f16 normal range lose at most 2^-25 absolutely), and
+//     a.b  ~  ah.bh + al.bh + ah.bl            (the dropped al.bl term is <= 2^-22 |a||b| too)
+// runs as three v_mfma_f32_32x32x16_f16 per 16 dimensions: 96 matrix cycles against 512 on the f32 tiles.  Products of f16
+// values are exact in f32, so the key differs from the exact one by the split residue (3 x 2^-22 ||a|| ||b||) plus the
+// f32 accumulation of 3 D products (bounded with a one-sided 2^-23 per addition, i.e. without assuming round-to-nearest
+// inside the matrix unit); host: MatchParams::err_scale = (3 Dpad + 34) 2^-22.  That is 3x the slack of the f32 tiles, which
+// is why the tail (l2_finish_queries<SPLIT>) gives an uncertified query a second chance with the four nominees of its two
+// lane halves.  Results stay bit-identical to the oracle: certification or exact scan, as on the f32 tiles.
+// Layout: ImgDev::tiledh = [tile][16-dim block][hi | lo][lane half][32 rows][8 f16] -- 2 KiB per block, one contiguous
+// stream per view.  The wave keeps the hi fragments of its NJ query tiles in registers and their lo fragments in LDS
+// (written once, read by the same wave only: no barrier in the loop); dataset hi / lo fragments stream through a PF-deep
+// register window like the f32 kernel's.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }    // -126 <= k <= 127
+
+// one workgroup per 32-row tile: the two f16 planes of the view, scaled by 2^split_k (read from the image table: the
+// statistics kernel ahead of this one on the stream produced max|x|)
+__global__ __launch_bounds__(256)
+void stage_split_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim, uint32_t GB, uint16_t* __restrict__ tiledh,
+                        const uint32_t* __restrict__ img_stats, int32_t* __restrict__ split_k_out)
+{
+    const float mx = __uint_as_float(img_stats[1]);
+    int k = 0;
+    if (mx > 0.0f && mx < R3DM_INF) {
+        k = 13 - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);           // max|x| 2^k in [2^13, 2^14)
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *split_k_out = k;
+    const float sc = pow2f(k);
+    const uint32_t t = blockIdx.x;
+    uint16_t* dst = tiledh + (size_t)t * GB * 1024;                              // halves per tile = GB * 2 planes * 512
+    for (uint32_t e = threadIdx.x; e < GB * 512; e += 256) {
+        const uint32_t c8 = e & 7, r = (e >> 3) & 31, h = (e >> 8) & 1, kb = e >> 9;
+        const uint32_t row = t * 32 + r, kk = 16 * kb + 8 * h + c8;
+        const float v = (row < n && kk < dim) ? rows[(size_t)row * dim + kk] * sc : 0.0f;
+        const _Float16 hi = (_Float16)v;                                         // round to nearest even
+        const _Float16 lo = (_Float16)(v - (float)hi);                           // the subtraction is exact in f32
+        const uint32_t o = kb * 1024 + (h * 32 + r) * 8 + c8;
+        dst[o] = __builtin_bit_cast(uint16_t, hi);
+        dst[o + 512] = __builtin_bit_cast(uint16_t, lo);
+    }
+}
+
+hipError_t launch_stage_split(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
+                              uint16_t* tiledh, const uint32_t* img_stats_dev, int32_t* split_k_dev)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_split_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, GB, tiledh, img_stats_dev, split_k_dev);
+    return hipGetLastError();
+}
+
+template <int GB, int NJ, int PF>
+__device__ __forceinline__ void split_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rn, uint32_t voffA, uint32_t voffN,
+                                                uint32_t soffA, uint32_t soffN, f32x4 (&ah)[PF], f32x4 (&al)[PF], f32x4 (&nrm)[4], float cscale,
+                                                const f32x4 (&bqh)[NJ][GB], const f32x4* __restrict__ bl_lds, f32x16 (&cur)[NJ],
+                                                const f32x16 (&prev)[NJ], Top2 (&st)[NJ], uint32_t prev_rowbase)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = nrm[r >> 2][r & 3] * cscale;       // ||a||^2 in key units (sI sJ); +inf for padding rows
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) cur[nj][r] = v;
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const f16x8 a_hi = __builtin_bit_cast(f16x8, ah[g % PF]);
+        const f16x8 a_lo = __builtin_bit_cast(f16x8, al[g % PF]);
+        ah[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 2048u);
+        al[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 2048u + 1024u);
+        if (g == 1) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) nrm[qd] = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
+        }
+        f32x4 bl[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) bl[nj] = bl_lds[(nj * GB + g) * 64];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+            cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, __builtin_bit_cast(f16x8, bqh[nj][g]), cur[nj], 0, 0, 0);
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+            cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, __builtin_bit_cast(f16x8, bl[nj]), cur[nj], 0, 0, 0);
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+            cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, __builtin_bit_cast(f16x8, bqh[nj][g]), cur[nj], 0, 0, 0);
+        // this block's share of the previous tile's keys: wave-wide test-and-skip, as in l2_tile_step<PIPE 3>
+        bool any = false;
+#pragma unroll
+        for (int r = (g * 16) / GB; r < ((g + 1) * 16) / GB; ++r)
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) any |= prev[nj][r] < st[nj].d2;
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+#pragma unroll
+            for (int r = (g * 16) / GB; r < ((g + 1) * 16) / GB; ++r)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    top2_push(st[nj], prev[nj][r], prev_rowbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int GB, int NJ, int PF>
+__global__ __launch_bounds__(256, 2)
+void l2_knn2_split_kernel(const MatchParams P)
+{
+    static_assert(GB % PF == 0, "prefetch window must divide the block count");
+    extern __shared__ __attribute__((aligned(16))) unsigned char split_smem[];     // [wave][NJ][GB][64 lanes] x 16 B: query lo fragments
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t h = lane >> 5, c = lane & 31u;
+    uint32_t pair, qb;
+    if (P.xcd_map) {                                       // pair p on XCD p % 8 (see l2_knn2_mfma_kernel)
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        pair = (j / P.qb_per_pair) * 8u + xcd;
+        qb = j % P.qb_per_pair;
+        if (pair >= P.n_pairs) return;
+    } else {
+        pair = blockIdx.x / P.qb_per_pair;
+        qb = blockIdx.x % P.qb_per_pair;
+    }
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles;
+    const uint32_t qt0 = (qb * 4u + wave) * NJ;
+    if (qt0 >= ntJ) return;                                // wave-uniform; no workgroup barriers in this kernel
+    const int kI = Ip->split_k, kJ = Jp->split_k;
+    const float cscale = pow2f(kI + kJ);                   // key units: sI sJ (||a||^2 - 2 a.b)
+    const float key_inv = pow2f(-(kI + kJ));
+
+    // ---- query fragments (B operand), scaled by -2 (exact in f16): hi in registers, lo in this wave's LDS slice
+    f32x4* bl_lds = reinterpret_cast<f32x4*>(split_smem) + (size_t)wave * (NJ * GB * 64) + lane;
+    f32x4 bqh[NJ][GB];
+    const f16x8 m2 = {(_Float16)-2.0f, (_Float16)-2.0f, (_Float16)-2.0f, (_Float16)-2.0f, (_Float16)-2.0f, (_Float16)-2.0f, (_Float16)-2.0f, (_Float16)-2.0f};
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;          // clamp: results discarded below
+        const gf4p src = (gf4p)(const void*)Jp->tiledh + (size_t)qt * (GB * 128) + lane;     // 128 float4 per block (hi | lo)
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            bqh[nj][g] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, src[g * 128]) * m2);
+            bl_lds[(nj * GB + g) * 64] = __builtin_bit_cast(f32x4, __builtin_bit_cast(f16x8, src[g * 128 + 64]) * m2);
+        }
+    }
+    Top2 st[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);
+
+    if (nI >= 2) {
+        const uint64_t pa = (uint64_t)Ip->tiledh, pn = (uint64_t)Ip->norms;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pn >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pn)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const uint32_t voffA = lane * 16u, voffN = h * 16u;
+        constexpr uint32_t tileB = (uint32_t)GB * 2048u;
+        const uint32_t hb = 4u * h;
+        f32x4 ah[PF], al[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) { ah[s] = bload16(ra, voffA, (uint32_t)s * 2048u); al[s] = bload16(ra, voffA, (uint32_t)s * 2048u + 1024u); }
+        f32x4 nrm[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) nrm[qd] = bload16(rn, voffN, (uint32_t)qd * 32u);
+        f32x16 accA[NJ], accB[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[nj][r] = R3DM_INF;              // "tile -1": keys that never win
+        uint32_t t = 0;
+        for (; t + 1 < ntI; t += 2) {
+            split_tile_step<GB, NJ, PF>(ra, rn, voffA, voffN, t * tileB + PF * 2048u, (t + 1) * 128u, ah, al, nrm, cscale, bqh, bl_lds, accA, accB, st, (t - 1) * 32u + hb);
+            split_tile_step<GB, NJ, PF>(ra, rn, voffA, voffN, (t + 1) * tileB + PF * 2048u, (t + 2) * 128u, ah, al, nrm, cscale, bqh, bl_lds, accB, accA, st, t * 32u + hb);
+        }
+        if (t < ntI) {
+            split_tile_step<GB, NJ, PF>(ra, rn, voffA, voffN, t * tileB + PF * 2048u, (t + 1) * 128u, ah, al, nrm, cscale, bqh, bl_lds, accA, accB, st, (t - 1) * 32u + hb);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) top2_push(st[nj], accA[nj][r], t * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        } else {
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) top2_push(st[nj], accB[nj][r], (ntI - 1) * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        }
+    }
+    // absolute part of the slack: pieces below the f16 normal range lose up to 2^-25 each (in scaled units), against an operand
+    // of magnitude < 2^14 on the other side, two sides, key = -2 a.b  ->  Dpad 2^-9 in key units
+    l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), false, key_inv, (float)(GB * 16) * 0.001953125f * key_inv);
+}
+
+template <int GB, int NJ, int PF>
+static hipError_t launch_l2_split_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
+{
+    MatchParams P = Pin;
+    const uint32_t tiles_per_wg = 4u * NJ;
+    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
+    P.xcd_map = 1u;
+    const uint64_t grid64 = (uint64_t)((P.n_pairs + 7u) / 8u * 8u) * P.qb_per_pair;
+    if (grid64 == 0) return hipSuccess;
+    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
+    const size_t lds = (size_t)4 * NJ * GB * 1024;
+    hipError_t e = hipFuncSetAttribute((const void*)l2_knn2_split_kernel<GB, NJ, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((l2_knn2_split_kernel<GB, NJ, PF>), dim3((uint32_t)grid64), dim3(256), lds, st, P);
+    return hipGetLastError();
+}
+
+// G = padded dim / 8 of the views (8, 16, 18, 32); hipErrorInvalidValue -> no split kernel, caller keeps the f32 tiles
+hipError_t launch_l2_knn2_split(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles)
+{
+    switch (G) {
+        case 8:  return launch_l2_split_t<4, 2, 4>(st, P, max_nj_tiles);
+        case 16: return launch_l2_split_t<8, 2, 4>(st, P, max_nj_tiles);
+        case 18: return launch_l2_split_t<9, 2, 3>(st, P, max_nj_tiles);
+        case 32: return launch_l2_split_t<16, 1, 4>(st, P, max_nj_tiles);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int GB, int NJ, int PF, int WPS, int ABL = 0>
 static hipError_t launch_l2_int(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
@@ -698,7 +957,7 @@ static hipError_t launch_l2_int(hipStream_t st, const MatchParams& Pin, uint32_t
     P.xcd_map = (uint32_t)xcd_map;
     const uint64_t grid64 = (uint64_t)(xcd_map ? (P.n_pairs + 7u) / 8u * 8u : P.n_pairs) * P.qb_per_pair;
     if (grid64 == 0) return hipSuccess;
-    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
     hipLaunchKernelGGL((l2_knn2_int_kernel<GB, NJ, PF, WPS, ABL>), dim3((uint32_t)grid64), dim3(256), 0, st, P);
     return hipGetLastError();
 }
@@ -713,7 +972,7 @@ static hipError_t launch_l2_t(hipStream_t st, const MatchParams& Pin, uint32_t m
     P.xcd_map = (uint32_t)xcd_map;
     const uint64_t grid64 = (uint64_t)(xcd_map ? (P.n_pairs + 7u) / 8u * 8u : P.n_pairs) * P.qb_per_pair;
     if (grid64 == 0) return hipSuccess;
-    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
     const uint32_t grid = (uint32_t)grid64;
     hipLaunchKernelGGL((l2_knn2_mfma_kernel<G, NJ, PF, PIPE, WPS>), dim3(grid), dim3(256), 0, st, P);
     return hipGetLastError();
@@ -919,6 +1178,7 @@ void l2_exact_batch_kernel(const MatchParams P)
 hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t G)
 {
     if (P.n_pairs == 0) return hipSuccess;
+    if (P.n_pairs > kMaxBlocksOf256) return hipErrorInvalidValue;
     switch (G) {
         case 8:  hipLaunchKernelGGL((l2_exact_batch_kernel<8>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
         case 16: hipLaunchKernelGGL((l2_exact_batch_kernel<16>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
@@ -1004,8 +1264,10 @@ hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& Pin, uint32_t 
     MatchParams P = Pin;
     constexpr int QL = 4;
     P.qb_per_pair = (max_n + 256u * QL - 1) / (256u * QL);
-    const uint32_t grid = P.n_pairs * P.qb_per_pair;
-    if (grid == 0) return hipSuccess;
+    const uint64_t grid64 = (uint64_t)P.n_pairs * P.qb_per_pair;
+    if (grid64 == 0) return hipSuccess;
+    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
+    const uint32_t grid = (uint32_t)grid64;
     switch (words) {
         case 8:  hipLaunchKernelGGL((hamming_knn2_kernel<8, QL>), dim3(grid), dim3(256), 0, st, P); break;
         case 16: hipLaunchKernelGGL((hamming_knn2_kernel<16, QL>), dim3(grid), dim3(256), 0, st, P); break;
@@ -1141,6 +1403,7 @@ void finalize_pairs_kernel(const FinalizeParams P)
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P)
 {
     if (P.n_pairs == 0) return hipSuccess;
+    if (P.n_pairs > kMaxBlocksOf256) return hipErrorInvalidValue;
     const size_t lds = (size_t)P.sort_cap * 9 + 32;                     // keys + drop flags + scalars (sort_cap is a power of two >= 8)
     hipError_t e = hipFuncSetAttribute((const void*)finalize_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

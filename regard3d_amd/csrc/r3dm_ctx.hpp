@@ -47,15 +47,16 @@ struct HostImage {
     r3dm_dtype dtype = R3DM_F32;
     uint32_t G = 0, n_tiles = 0, words = 0;
     bool has_xy = false, has_dup = false, live = false;
-    DevBuf rows, tiled, tiled16, norms, bin, xy, canon;
+    DevBuf rows, tiled, tiled16, tiledh, norms, bin, xy, canon;
     float max_abs = 0.0f; bool not_integer = true, has_negative = true;     // staging statistics (read back after the staging kernel)
+    int32_t split_k = 0;                                                    // scale exponent of the f16 split tiles
     DevBuf ann_adj, ann_deg;          // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0
     uint32_t ann_K = 0;
     bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter
     double Kinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     void release()
     {
-        rows.release(); tiled.release(); tiled16.release(); norms.release(); bin.release(); xy.release(); canon.release();
+        rows.release(); tiled.release(); tiled16.release(); tiledh.release(); norms.release(); bin.release(); xy.release(); canon.release();
         ann_adj.release(); ann_deg.release(); ann_K = 0; live = false;
     }
 };
@@ -110,6 +111,7 @@ struct r3dm_ctx {
     std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size
     int ak_w = 0, ak_h = 0;
     bool integer_mfma = false;                              // r3dm_set_integer_mfma
+    bool split_mfma = false;                                // r3dm_set_split_mfma
     uint32_t liop_npix = 0;
     r3dm_stats stats{};
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair

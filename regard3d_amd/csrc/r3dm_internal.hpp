@@ -24,7 +24,11 @@ namespace r3dm {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;       // "no match" / invalid row
 constexpr uint32_t kTileRows = 32;            // rows per MFMA tile (32x32x2 f32)
-constexpr uint32_t kSlackBytes = 32768;       // zero slack behind every tiled / norm array (prefetch runs past the end)
+constexpr uint32_t kSlackBytes = 32768;
+// A dispatch carries its global size (workgroups x threads per workgroup) as a 32-bit number of work-items: a launch of more
+// than 2^32 - 1 threads is not rejected by the runtime, it WRAPS (found on the first C5-sized graph search: 4560 pairs x 4096
+// workgroups x 256 threads ran only the first 464 pairs).  Launchers refuse such grids; callers batch below the limit.
+constexpr uint64_t kMaxBlocksOf256 = 0xFFFFFFFFull / 256ull;       // zero slack behind every tiled / norm array (prefetch runs past the end)
 
 // One registered view, resident in HBM.  Layouts (DESIGN.md "Data layout in HBM"):
 //   rows  : row-major f32 [n][dim]            -- exact re-scoring in the reference's summation order
@@ -55,6 +59,10 @@ struct ImgDev {
     // lane half h of 16-dim block kb holds dims 16 kb + 8 h .. + 7 of row 32 t + r.  Exact iff the view is
     // integer-valued with |x| <= 256 (every such value is a bf16); the kernel checks that itself.
     const uint16_t* tiled16;
+    // f16 hi / lo fragment-order tiles for the split nominator (r3dm_set_split_mfma): [n_tiles][G/2][hi | lo][2][32][8] f16 of the
+    // values scaled by 2^split_k (max|x| 2^split_k in [2^13, 2^14); both filled by stage_split_kernel)
+    const uint16_t* tiledh;
+    int32_t split_k;
 };
 #ifndef R3DM_INF
 #define R3DM_INF __builtin_huge_valf()
@@ -113,7 +121,7 @@ struct MatchParams {
     uint32_t*     fb_cnt;         // [n_pairs] number collected (may exceed kFbPerPair: overflow -> global rescan)
     uint32_t*     fb_total;       // [2]: total uncertified queries, number that overflowed their pair's list
 };
-constexpr uint32_t kFbPerPair = 128;
+constexpr uint32_t kFbPerPair = 256;
 constexpr uint32_t kFallback = 0xFFFFFFFEu;
 
 struct FinalizeParams {
@@ -225,6 +233,9 @@ hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint
                             uint32_t* bin, uint32_t words, uint32_t n_pad);
 // returns hipErrorInvalidValue when (G, dtype) has no tensor kernel; caller falls back to the exact scan
 hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, bool integer_mfma = false);
+hipError_t launch_l2_knn2_split(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
+hipError_t launch_stage_split(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
+                              uint16_t* tiledh, const uint32_t* img_stats_dev, int32_t* split_k_dev);
 hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t count, int scan_all);
 // exact scan of the per-pair fallback lists (one workgroup per pair); false return -> no kernel for this G
 hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t G);
