@@ -196,6 +196,8 @@ def main():
     if world == 1 and not a.no_opt_in and kp is None and kind == "sift":
         out["opt_in_integer_mfma"] = opt_in_integer(ctx, step, fence, g, gf, job_pairs)
         attach_traffic(out["opt_in_integer_mfma"]["roofline"], a.config, "l2_knn2_int_kernel", emu, base_images, n_feat)
+    if world == 1 and not a.no_opt_in and kp is None and kind == "akaze":
+        out["opt_in_hamming_mfma"] = opt_in_hamming(ctx, step, fence, g, gf, job_pairs)
     if world == 1 and not a.no_opt_in and kp is None and kind == "liop":
         out["opt_in_split_mfma"] = opt_in_split(ctx, step, fence, g, gf, job_pairs)
     if world == 1:
@@ -306,6 +308,31 @@ def opt_in_split(ctx, step, fence, g, gf, job_pairs):
             "roofline": {"bound": "mfma", "kernel": "l2_knn2_split_kernel<GB=9,NJ=2>", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s (executed f16 matrix flops = 3 x algorithmic)", "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                          "algorithmic_tflops": ach / 3.0, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
+            "filter_kernel_ms": sa2.ms_filter_kernels,
+            "wall_ms": {"match": sa2.ms_wall_match, "match_post": sa2.ms_wall_match_post, "filter": sa2.ms_wall_filter}}
+
+
+def opt_in_hamming(ctx, step, fence, g, gf, job_pairs):
+    """the same step with the exact MFMA formulation of the Hamming matcher (r3dm_set_hamming_mfma): bits as 0 / 1 bytes on
+    v_mfma_i32_32x32x32_i8, d = popcount(a) + popcount(b) - 2 a.b -- bit-identical graphs, reported beside the popcount headline"""
+    ctx.set_hamming_mfma(True)
+    try:
+        step(); fence()
+        t1 = time.perf_counter()
+        g2, gf2, _, sm2, sa2 = step()
+        fence()
+        el2 = time.perf_counter() - t1
+    finally:
+        ctx.set_hamming_mfma(False)
+    same = all(np.array_equal(getattr(x, f), getattr(y, f)) for x, y in ((g, g2), (gf, gf2)) for f in ("pairs", "offsets", "matches"))
+    # executed matrix work: 2 n^2 x 512 bit-products per pair (486 bits padded to 16 blocks of 32); algorithmic_flops counts 2 n^2 x 16 words
+    ach = 32.0 * sm2.algorithmic_flops / (sm2.ms_match_kernels * 1e-3) / 1e12 if sm2.ms_match_kernels > 0 else 0.0
+    return {"value": job_pairs / el2, "unit": "pairs/s", "ms_per_step": el2 * 1e3, "steps": 1,
+            "identical_to_headline_graphs": bool(same), "hamming_mfma_launches": int(sm2.n_hamming_mfma),
+            "dtype": "i8 operands holding bits 0/1, i32 accumulate (exact)",
+            "roofline": {"bound": "mfma", "kernel": "l2_knn2_int_lds_kernel<GB=16,NJ=2,OPS=i8>", "achieved": ach, "peak": 5000.0,
+                         "unit": "TOP/s (executed i8 matrix ops, 512 bits per row)", "frac": ach / 5000.0, "traffic": None,
+                         "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
             "filter_kernel_ms": sa2.ms_filter_kernels,
             "wall_ms": {"match": sa2.ms_wall_match, "match_post": sa2.ms_wall_match_post, "filter": sa2.ms_wall_filter}}
 

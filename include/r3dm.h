@@ -102,6 +102,14 @@ int r3dm_set_integer_mfma(r3dm_ctx* ctx, int enable);
  * Batches of integer-valued views keep the f32 tiles (or r3dm_set_integer_mfma).  r3dm_stats.n_split_mfma reports which path ran. */
 int r3dm_set_split_mfma(r3dm_ctx* ctx, int enable);
 
+/* Opt-in exact MFMA formulation of the Hamming matcher for binary descriptors (default off: the default is the plain
+ * xor + popcount kernel BASELINE config C3 names; no reference counterpart -- OpenMVG has one Hamming loop).  The bits of a
+ * row become bytes 0 / 1, Hamming(a, b) = popcount(a) + popcount(b) - 2 a.b, and a.b runs on v_mfma_i32_32x32x32_i8 with
+ * the dataset tiles shared by a workgroup through LDS; every quantity is a small integer, so indices, distances and
+ * matches are bit-identical to the popcount kernel and to the CPU restatement (ties -> lowest row).
+ * r3dm_stats.n_hamming_mfma reports which path ran. */
+int r3dm_set_hamming_mfma(r3dm_ctx* ctx, int enable);
+
 /* ---- putative matching ----
  * pairs_ij: n_pairs x 2 view ids (I, J); J's rows are the queries, I's rows the dataset.
  * dist_ratio: Lowe ratio (0.6 default in the reference, src/Regard3DFeatures.cpp:129);
@@ -153,6 +161,17 @@ int r3dm_filter_report(const r3dm_ctx* ctx, r3dm_pair_report* out, uint64_t cap)
  * n_dataset < 2, like ArrayMatcherBruteForce::SearchNeighbours with NN = 2. */
 int r3dm_knn2(r3dm_ctx* ctx, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
               uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist);
+
+/* The same with the dataset staged ONCE, the way the reference uses its plugins: Build per first view I, SearchNeighbours per
+ * J from an OpenMP loop (src/R3DComputeMatches.cpp:462-479; ArrayMatcher_kgraph::Build / SearchNeighbours,
+ * src/utils/matcher_kgraph.h:120-166,205-251).  r3dm_index_create copies and re-lays-out `dataset` (it need not outlive the
+ * call); the index belongs to the context's DEVICE, not to the context: r3dm_index_knn2 may be called with any context of
+ * that device, so a host can keep a small pool of contexts and run its searches concurrently (include/r3dm_array_matcher.hpp
+ * does).  Each search uploads the query rows only; r3dm_stats.n_views_staged counts the copies + re-layouts a context made. */
+typedef struct r3dm_index r3dm_index;
+int  r3dm_index_create(r3dm_ctx* ctx, const void* dataset, uint32_t n_dataset, uint32_t dim, r3dm_dtype dtype, r3dm_index** out);
+int  r3dm_index_knn2(r3dm_ctx* ctx, const r3dm_index* index, const void* query, uint32_t n_query, int32_t* out_idx, float* out_dist);
+void r3dm_index_destroy(r3dm_index* index);
 
 /* ---- approximate matching: the KGraph plugin path (BASELINE config C5) ----
  * Replaces kgraph_match (src/R3DComputeMatches.cpp:808-902): per first view I an index over its descriptors
@@ -310,6 +329,8 @@ typedef struct {
     double   ms_detect;            /* wall time of the last r3dm_detect_akaze call                  */
     uint64_t n_integer_mfma;       /* launches of the dominant kernel that ran as the integer fast path  */
     uint64_t n_split_mfma;         /* launches of the dominant kernel that ran as the split-f16 nominator */
+    uint64_t n_views_staged;       /* views / datasets / query sets copied + re-laid-out by this context since r3dm_create */
+    uint64_t n_hamming_mfma;       /* launches of the Hamming matcher that ran as the MFMA formulation */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

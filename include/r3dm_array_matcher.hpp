@@ -19,13 +19,19 @@
 // (/root/reference/src/R3DComputeMatches.cpp:838-842).  Without it (this repository: no OpenMVG in
 // the image) equivalent stand-in types are used so the adapter can be compiled and tested.
 //
-// Only NN <= 2 is served (MatchDistanceRatio asks for exactly 2).  Thread-safety: the reference calls
-// SearchNeighbours from many OpenMP threads; calls on one adapter are serialised by a mutex because
-// one r3dm context drives one GPU stream.  For whole-collection throughput use r3dm_match_pairs
-//  -- this adapter re-stages the query set on every call.
+// Only NN <= 2 is served (MatchDistanceRatio asks for exactly 2).
+// Build() stages the dataset ONCE (r3dm_index_create: copy to HBM + MFMA fragment tiles + norms); every SearchNeighbours
+// uploads only its query rows (r3dm_index_knn2) -- the amortisation the plugin contract is built around: the reference
+// builds per first view I and searches once per J (/root/reference/src/R3DComputeMatches.cpp:462-479).
+// Thread-safety: the reference calls SearchNeighbours from many OpenMP threads (`omp parallel for schedule(dynamic)` over J,
+// :465).  A context drives one HIP stream and owns its scratch, so the adapter leases a context per call from a small
+// process-wide pool (kPoolSize per device): concurrent searches run on different streams and overlap on the GPU; callers
+// beyond the pool size wait for a free context.  For whole-collection throughput use r3dm_match_pairs.
 #pragma once
 
+#include <condition_variable>
 #include <cstdint>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -56,23 +62,96 @@ template <typename Scalar> struct DefaultMetric { using ResultType = float; };
 #define R3DM_OVERRIDE
 #endif
 
+namespace detail {
+
+// Contexts of one device, shared by every adapter of the process.  Created on demand, never destroyed (a static destructor
+// would run after the HIP runtime's own teardown).
+class ContextPool {
+public:
+    static constexpr int kPoolSize = 4;
+    static ContextPool& of(int device)
+    {
+        static std::mutex mu;
+        static std::map<int, ContextPool*> pools;
+        std::lock_guard<std::mutex> lock(mu);
+        ContextPool*& p = pools[device];
+        if (!p) p = new ContextPool(device);
+        return *p;
+    }
+    r3dm_ctx* acquire()
+    {
+        std::unique_lock<std::mutex> lock(mu_);
+        for (;;) {
+            if (!free_.empty()) { r3dm_ctx* c = free_.back(); free_.pop_back(); return c; }
+            if (created_ < kPoolSize) {
+                r3dm_ctx* c = nullptr;
+                if (r3dm_create(device_, &c) == R3DM_OK) { ++created_; all_.push_back(c); return c; }
+                if (created_ == 0) return nullptr;             // no usable GPU: the adapter reports failure, it never falls back
+            }
+            cv_.wait(lock);
+        }
+    }
+    void release(r3dm_ctx* c)
+    {
+        { std::lock_guard<std::mutex> lock(mu_); free_.push_back(c); }
+        cv_.notify_one();
+    }
+    // copies + re-layouts made by all contexts of the pool (r3dm_stats.n_views_staged): Build = 1, every search = 1 (its queries)
+    uint64_t viewsStaged()
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        uint64_t n = 0;
+        for (r3dm_ctx* c : all_) { r3dm_stats s; if (r3dm_get_stats(c, &s) == R3DM_OK) n += s.n_views_staged; }
+        return n;
+    }
+    int created() { std::lock_guard<std::mutex> lock(mu_); return created_; }
+
+private:
+    explicit ContextPool(int device) : device_(device) {}
+    int device_;
+    int created_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<r3dm_ctx*> free_, all_;
+};
+
+struct ContextLease {
+    explicit ContextLease(ContextPool& p) : pool(p), ctx(p.acquire()) {}
+    ~ContextLease() { if (ctx) pool.release(ctx); }
+    ContextLease(const ContextLease&) = delete;
+    ContextLease& operator=(const ContextLease&) = delete;
+    ContextPool& pool;
+    r3dm_ctx* ctx;
+};
+
+}  // namespace detail
+
 template <typename Scalar = float, typename Metric = DefaultMetric<Scalar>>
 class ArrayMatcher_r3dm R3DM_ARRAY_MATCHER_BASE(Scalar, Metric) {
 public:
     using DistanceType = typename Metric::ResultType;
 
-    explicit ArrayMatcher_r3dm(int device_id = 0) { if (r3dm_create(device_id, &ctx_) != R3DM_OK) ctx_ = nullptr; }
-    virtual ~ArrayMatcher_r3dm() { if (ctx_) r3dm_destroy(ctx_); }
+    explicit ArrayMatcher_r3dm(int device_id = 0) : pool_(detail::ContextPool::of(device_id)) {}
+    virtual ~ArrayMatcher_r3dm() { if (index_) r3dm_index_destroy(index_); }
     // not part of the ArrayMatcher interface: forwards r3dm_set_integer_mfma (same results, integer-valued float rows only)
-    void setIntegerFastPath(bool on) { if (ctx_) (void)r3dm_set_integer_mfma(ctx_, on ? 1 : 0); }
+    void setIntegerFastPath(bool on) { integer_fast_path_ = on; }
+    // not part of the ArrayMatcher interface: forwards r3dm_set_split_mfma (same results, real-valued rows)
+    void setSplitFastPath(bool on) { split_fast_path_ = on; }
+    // copies + re-layouts made on this adapter's device by all adapters of the process (test / diagnostics hook)
+    uint64_t viewsStaged() const { return pool_.viewsStaged(); }
+    int contextsInUse() const { return pool_.created(); }
     ArrayMatcher_r3dm(const ArrayMatcher_r3dm&) = delete;
     ArrayMatcher_r3dm& operator=(const ArrayMatcher_r3dm&) = delete;
 
     bool Build(const Scalar* dataset, int nbRows, int dimension) R3DM_OVERRIDE
     {
-        if (nbRows < 1 || !ctx_) return false;              // matcher_kgraph.h:126-130
-        dataset_ = dataset; nbRows_ = nbRows; dimension_ = dimension;
-        return true;
+        if (nbRows < 1 || dimension < 1 || !dataset) return false;     // matcher_kgraph.h:126-130
+        detail::ContextLease lease(pool_);
+        if (!lease.ctx) return false;
+        if (index_) { r3dm_index_destroy(index_); index_ = nullptr; }
+        const r3dm_dtype dt = sizeof(Scalar) == 1 ? R3DM_U8 : R3DM_F32;
+        nbRows_ = nbRows; dimension_ = dimension;
+        return r3dm_index_create(lease.ctx, dataset, static_cast<uint32_t>(nbRows), static_cast<uint32_t>(dimension), dt, &index_) == R3DM_OK;
     }
 
     bool SearchNeighbour(const Scalar* query, int* indice, DistanceType* distance) R3DM_OVERRIDE
@@ -86,14 +165,15 @@ public:
     bool SearchNeighbours(const Scalar* query, int nbQuery, IndMatches* pvec_indices,
                           std::vector<DistanceType>* pvec_distances, size_t NN) R3DM_OVERRIDE
     {
-        if (!ctx_ || !dataset_ || nbQuery < 1 || NN < 1 || NN > 2 || nbRows_ < 2) return false;
+        if (!index_ || !query || nbQuery < 1 || NN < 1 || NN > 2 || nbRows_ < 2) return false;
         std::vector<int32_t> idx(2 * static_cast<size_t>(nbQuery));
         std::vector<float> dist(2 * static_cast<size_t>(nbQuery));
         {
-            std::lock_guard<std::mutex> lock(mu_);
-            const r3dm_dtype dt = sizeof(Scalar) == 1 ? R3DM_U8 : R3DM_F32;
-            if (r3dm_knn2(ctx_, dataset_, static_cast<uint32_t>(nbRows_), query, static_cast<uint32_t>(nbQuery),
-                          static_cast<uint32_t>(dimension_), dt, idx.data(), dist.data()) != R3DM_OK)
+            detail::ContextLease lease(pool_);                 // one stream + scratch per concurrent search
+            if (!lease.ctx) return false;
+            (void)r3dm_set_integer_mfma(lease.ctx, integer_fast_path_ ? 1 : 0);
+            (void)r3dm_set_split_mfma(lease.ctx, split_fast_path_ ? 1 : 0);
+            if (r3dm_index_knn2(lease.ctx, index_, query, static_cast<uint32_t>(nbQuery), idx.data(), dist.data()) != R3DM_OK)
                 return false;
         }
         pvec_indices->reserve(pvec_indices->size() + nbQuery * NN);
@@ -107,10 +187,10 @@ public:
     }
 
 private:
-    r3dm_ctx* ctx_ = nullptr;
-    const Scalar* dataset_ = nullptr;
+    detail::ContextPool& pool_;
+    r3dm_index* index_ = nullptr;
     int nbRows_ = 0, dimension_ = 0;
-    std::mutex mu_;
+    bool integer_fast_path_ = false, split_fast_path_ = false;
 };
 
 }  // namespace r3d_amd

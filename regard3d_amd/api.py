@@ -25,7 +25,7 @@ EXPORTS = [
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
-    "r3dm_set_integer_mfma", "r3dm_set_split_mfma",
+    "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
     "r3dm_multi_match_pairs", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
@@ -44,7 +44,8 @@ class Stats(C.Structure):
                 ("ms_wall_match_post", C.c_double), ("ms_wall_filter", C.c_double), ("ms_liop_kernel", C.c_double),
                 ("ms_ann_build", C.c_double), ("ms_ann_search", C.c_double), ("n_ann_built", C.c_uint64),
                 ("n_ann_dist", C.c_uint64), ("ms_detect", C.c_double), ("n_integer_mfma", C.c_uint64),
-                ("n_split_mfma", C.c_uint64)]
+                ("n_split_mfma", C.c_uint64), ("n_views_staged", C.c_uint64),
+                ("n_hamming_mfma", C.c_uint64)]
 
 
 class KGraphParams(C.Structure):
@@ -81,6 +82,14 @@ def use_developer_library():
     LIB_PATH = DEV_LIB_PATH
 
 
+def use_library(path: str):
+    """load a specific build of the library (bisecting tools); before the first load_library()"""
+    global LIB_PATH
+    if _lib is not None:
+        raise R3dmError("the library is already loaded")
+    LIB_PATH = path
+
+
 def load_library():
     """dlopen libr3dm.so and declare prototypes.  Raises if the extension was not built."""
     global _lib
@@ -99,6 +108,10 @@ def load_library():
     L.r3dm_clear_images.argtypes = [vp]
     L.r3dm_set_integer_mfma.argtypes = [vp, C.c_int]
     L.r3dm_set_split_mfma.argtypes = [vp, C.c_int]
+    L.r3dm_set_hamming_mfma.argtypes = [vp, C.c_int]
+    L.r3dm_index_create.argtypes = [vp, vp, u32, u32, C.c_int, C.POINTER(vp)]
+    L.r3dm_index_knn2.argtypes = [vp, vp, vp, u32, vp, vp]
+    L.r3dm_index_destroy.argtypes = [vp]; L.r3dm_index_destroy.restype = None
     L.r3dm_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
     L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
     L.r3dm_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
@@ -238,6 +251,24 @@ class Graph:
         return Graph(h.value)
 
 
+class Index:
+    """r3dm_index: a dataset staged once for many 2-NN searches"""
+
+    def __init__(self, handle: int):
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().r3dm_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One GPU, one context (one process per GPU)."""
 
@@ -346,6 +377,10 @@ class Context:
         """opt-in bf16-exact MFMA path for integer-valued descriptors (include/r3dm.h: r3dm_set_integer_mfma)"""
         self._check(self._L.r3dm_set_integer_mfma(self._h, int(bool(enable))), "r3dm_set_integer_mfma")
 
+    def set_hamming_mfma(self, enable: bool = True):
+        """opt-in exact MFMA formulation of the Hamming matcher (include/r3dm.h: r3dm_set_hamming_mfma)"""
+        self._check(self._L.r3dm_set_hamming_mfma(self._h, int(bool(enable))), "r3dm_set_hamming_mfma")
+
     def set_split_mfma(self, enable: bool = True):
         """opt-in split-f16 nominator for real-valued descriptors (include/r3dm.h: r3dm_set_split_mfma)"""
         self._check(self._L.r3dm_set_split_mfma(self._h, int(bool(enable))), "r3dm_set_split_mfma")
@@ -370,6 +405,22 @@ class Context:
         idx = np.full((max(nq, 1), 2), -1, np.int32); dist = np.zeros((max(nq, 1), 2), np.float32)
         self._check(self._L.r3dm_knn2(self._h, _ptr(dataset), dataset.shape[0], _ptr(query), nq, dataset.shape[1], dt,
                                       _ptr(idx), _ptr(dist)), "r3dm_knn2")
+        return idx[:nq], dist[:nq]
+
+    def index_create(self, dataset: np.ndarray, binary: bool = False) -> "Index":
+        """ArrayMatcher::Build: stage the dataset once (r3dm_index_create)"""
+        dataset = np.ascontiguousarray(dataset)
+        dt = F32 if dataset.dtype == np.float32 else (BIN if binary else U8)
+        h = C.c_void_p()
+        self._check(self._L.r3dm_index_create(self._h, _ptr(dataset), dataset.shape[0], dataset.shape[1], dt, C.byref(h)), "r3dm_index_create")
+        return Index(h.value)
+
+    def index_knn2(self, index: "Index", query: np.ndarray):
+        """ArrayMatcher::SearchNeighbours(NN = 2) against a staged dataset; any context of the index's device"""
+        query = np.ascontiguousarray(query)
+        nq = query.shape[0]
+        idx = np.full((max(nq, 1), 2), -1, np.int32); dist = np.zeros((max(nq, 1), 2), np.float32)
+        self._check(self._L.r3dm_index_knn2(self._h, index._h, _ptr(query), nq, _ptr(idx), _ptr(dist)), "r3dm_index_knn2")
         return idx[:nq], dist[:nq]
 
     def liop_describe_patches(self, patches):

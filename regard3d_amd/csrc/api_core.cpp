@@ -69,13 +69,16 @@ extern "C" int r3dm_get_stats(const r3dm_ctx* c, r3dm_stats* out)
 {
     if (!c || !out) return R3DM_ERR_INVALID;
     *out = c->stats;
+    out->n_views_staged = c->n_views_staged;
     return R3DM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
 // views
 // ------------------------------------------------------------------------------------------------
-static int upload_imgdev(r3dm_ctx* c, uint32_t slot)
+// writes the table entry of `slot`; stat_bits3 / split_k are given when the slot mounts an already staged r3dm_index (the
+// staging kernels fill them otherwise)
+int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_t split_k)
 {
     const size_t need = sizeof(ImgDev) * c->imgs.size();
     if (need > c->d_imgs.cap) {
@@ -101,10 +104,12 @@ static int upload_imgdev(r3dm_ctx* c, uint32_t slot)
     d.bin = h.bin.as<uint32_t>(); d.xy = h.has_xy ? h.xy.as<float>() : nullptr;
     d.canon = h.has_dup ? h.canon.as<uint32_t>() : nullptr;
     d.n = h.n; d.n_tiles = h.n_tiles; d.dim = h.dim; d.G = h.G; d.words = h.words;
-    d.width = h.width; d.height = h.height; d.max_norm_bits = 0; d.max_abs_bits = 0; d.not_integer = 0;
+    d.width = h.width; d.height = h.height;
+    d.max_norm_bits = stat_bits3 ? stat_bits3[0] : 0; d.max_abs_bits = stat_bits3 ? stat_bits3[1] : 0; d.not_integer = stat_bits3 ? stat_bits3[2] : 0;
     d.ann_adj = nullptr; d.ann_deg = nullptr;          // staging invalidates the graph index
     d.tiled16 = h.tiled16.as<uint16_t>();
-    d.tiledh = h.tiledh.as<uint16_t>(); d.split_k = 0;
+    d.tiledh = h.tiledh.as<uint16_t>(); d.split_k = split_k;
+    d.tiled8 = h.tiled8.as<uint8_t>();
     R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
     return R3DM_OK;
@@ -127,6 +132,15 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
             R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
         }
         R3DM_HIP(c, launch_stage_bin(c->stream, c->d_raw.as<uint8_t>(), n, dim, h.bin.as<uint32_t>(), h.words, n_pad));
+        // one byte per bit in i8 MFMA fragment order + biased popcounts: the tiles of the opt-in MFMA Hamming (r3dm_set_hamming_mfma)
+        h.n_tiles = (n + kTileRows - 1) / kTileRows;
+        const size_t t8_bytes = (size_t)h.n_tiles * h.words * 1024 + 2 * kSlackBytes;
+        const size_t nrm_bytes = (size_t)h.n_tiles * 32 * 4 + kSlackBytes;
+        R3DM_HIP(c, h.tiled8.ensure(t8_bytes));
+        R3DM_HIP(c, h.norms.ensure(nrm_bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiled8.p, 0, t8_bytes, c->stream));
+        R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0x7F, nrm_bytes, c->stream));
+        R3DM_HIP(c, launch_stage_bin8(c->stream, h.bin.as<uint32_t>(), n, h.words, h.n_tiles, h.tiled8.as<uint8_t>(), h.norms.as<float>()));
     } else {
         h.G = kernel_G_for(dim);
         h.n_tiles = (n + kTileRows - 1) / kTileRows;
@@ -205,6 +219,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         h.has_negative = (st3[2] & 2u) != 0;
     }
     R3DM_HIP(c, hipStreamSynchronize(c->stream));     // d_raw is reused by the next call
+    c->n_views_staged += 1;
     return R3DM_OK;
 }
 
@@ -250,6 +265,13 @@ extern "C" int r3dm_set_split_mfma(r3dm_ctx* c, int enable)
 {
     if (!c) return R3DM_ERR_INVALID;
     c->split_mfma = (enable != 0);
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_set_hamming_mfma(r3dm_ctx* c, int enable)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    c->hamming_mfma = (enable != 0);
     return R3DM_OK;
 }
 

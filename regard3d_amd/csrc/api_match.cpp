@@ -68,8 +68,8 @@ static int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_
 
 // runs the 2-NN + ratio kernels over `jobs` (slot pairs, all of one dtype/dim) and appends the
 // non-empty results to `g` in job order.  knn_idx/knn_dist (host, optional) receive the raw 2-NN.
-static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
-                           int32_t* knn_idx_host, float* knn_dist_host)
+int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
+                    int32_t* knn_idx_host, float* knn_dist_host)
 {
     const uint32_t P = (uint32_t)jobs.size();
     if (P == 0) return R3DM_OK;
@@ -161,7 +161,10 @@ static int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float 
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     uint64_t n_fallback = 0;
     if (dtype == R3DM_BIN) {
-        R3DM_HIP(c, launch_hamming_knn2(c->stream, mp, first.words, max_nJ));
+        if (c->hamming_mfma) {
+            R3DM_HIP(c, launch_hamming_mfma(c->stream, mp, first.words, max_tiles));
+            c->stats.n_hamming_mfma += 1;
+        } else R3DM_HIP(c, launch_hamming_knn2(c->stream, mp, first.words, max_nJ));
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));      // (the finaliser would wait here anyway; keeps the wall breakdown honest)
     } else if (has_tensor_kernel(first.G)) {
@@ -284,11 +287,82 @@ extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, c
         rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
         const uint64_t int_launches = c->stats.n_integer_mfma - keep.n_integer_mfma;
         const uint64_t split_launches = c->stats.n_split_mfma - keep.n_split_mfma;
+        const uint64_t ham_launches = c->stats.n_hamming_mfma - keep.n_hamming_mfma;
         const uint64_t fb = c->stats.n_exact_fallback - keep.n_exact_fallback;
         c->stats = keep;
         c->stats.n_integer_mfma = int_launches;           // which tiles this call ran on (r3dm_set_integer_mfma / r3dm_set_split_mfma)
-        c->stats.n_split_mfma = split_launches;
+        c->stats.n_split_mfma = split_launches; c->stats.n_hamming_mfma = ham_launches;
         c->stats.n_exact_fallback = fb;                   // ... and how many of its queries went through the exact scan
+    }
+    (void)hipStreamSynchronize(c->stream);
+    c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
+    c->imgs.pop_back(); c->imgs.pop_back();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ArrayMatcher::Build / SearchNeighbours with the dataset staged ONCE (the reference builds per I and searches per J:
+// /root/reference/src/R3DComputeMatches.cpp:462-479, plugin contract src/utils/matcher_kgraph.h:120-166,205-251)
+// ------------------------------------------------------------------------------------------------
+extern "C" int r3dm_index_create(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, uint32_t dim, r3dm_dtype dtype, r3dm_index** out)
+{
+    if (!c || !out || !dataset || dim == 0 || n_dataset < 1) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    if (dtype != R3DM_F32 && dtype != R3DM_U8 && dtype != R3DM_BIN) return R3DM_ERR_INVALID;
+    if (n_dataset >= (1u << 22)) { c->err = "more than 4M rows in one index"; return R3DM_ERR_UNSUPPORTED; }
+    if (dtype == R3DM_BIN && !(((dim + 3) / 4) == 8 || ((dim + 3) / 4) == 16)) return R3DM_ERR_UNSUPPORTED;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    auto ix = std::unique_ptr<r3dm_index>(new (std::nothrow) r3dm_index());
+    if (!ix) return R3DM_ERR_NOMEM;
+    const uint32_t s0 = (uint32_t)c->imgs.size();
+    c->imgs.emplace_back(new HostImage());
+    int rc = stage_into_slot(c, s0, 0, 0, 0, dataset, n_dataset, dim, dtype, nullptr);
+    if (rc == R3DM_OK && dtype != R3DM_BIN) {
+        hipError_t e = hipMemcpyAsync(ix->stat_bits, &(c->d_imgs.as<ImgDev>() + s0)->max_norm_bits, 12, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->err = std::string("r3dm_index_create: ") + hipGetErrorString(e); rc = R3DM_ERR_HIP; }
+    }
+    if (rc == R3DM_OK) {
+        ix->device = c->device;
+        ix->img = *c->imgs[s0];                   // the index takes the buffers over ...
+        *c->imgs[s0] = HostImage();               // ... and the private slot forgets them
+        *out = ix.release();
+    } else c->imgs[s0]->release();
+    c->imgs.pop_back();
+    return rc;
+}
+
+extern "C" void r3dm_index_destroy(r3dm_index* ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    ix->img.release();
+    delete ix;
+}
+
+extern "C" int r3dm_index_knn2(r3dm_ctx* c, const r3dm_index* ix, const void* query, uint32_t n_query, int32_t* out_idx, float* out_dist)
+{
+    if (!c || !ix || !query || !out_idx || !out_dist) return R3DM_ERR_INVALID;
+    if (n_query < 1 || ix->img.n < 2) return R3DM_ERR_INVALID;          // ArrayMatcherBruteForce: NN > nbRows / nbQuery < 1
+    if (ix->device != c->device) { c->err = "r3dm_index_knn2: the index lives on another device"; return R3DM_ERR_INVALID; }
+    R3DM_HIP(c, hipSetDevice(c->device));
+    const uint32_t s0 = (uint32_t)c->imgs.size();
+    c->imgs.emplace_back(new HostImage());
+    c->imgs.emplace_back(new HostImage());
+    *c->imgs[s0] = ix->img;                       // aliases of the index's buffers: mounted for this call only
+    c->imgs[s0]->borrowed = true;
+    int rc = upload_imgdev(c, s0, ix->stat_bits, ix->img.split_k);
+    if (rc == R3DM_OK) rc = stage_into_slot(c, s0 + 1, 0, 0, 0, query, n_query, ix->img.dim, ix->img.dtype, nullptr);
+    if (rc == R3DM_OK) {
+        std::vector<PairJob> jobs{{0, 1, s0, s0 + 1}};
+        const r3dm_stats keep = c->stats;
+        rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
+        const uint64_t int_launches = c->stats.n_integer_mfma - keep.n_integer_mfma;
+        const uint64_t split_launches = c->stats.n_split_mfma - keep.n_split_mfma;
+        const uint64_t ham_launches = c->stats.n_hamming_mfma - keep.n_hamming_mfma;
+        c->stats = keep;
+        c->stats.n_integer_mfma = int_launches; c->stats.n_split_mfma = split_launches; c->stats.n_hamming_mfma = ham_launches;
     }
     (void)hipStreamSynchronize(c->stream);
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();

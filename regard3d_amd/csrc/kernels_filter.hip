@@ -667,11 +667,14 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 // debug aids of the developer build (-DR3DM_DEVTOOLS; r3dm_internal.hpp): R3DM_FILTER_CHECK=1 records the first violated
 // invariant instead of running into a memory fault, R3DM_TRACE_PAIR dumps the per-model trace of one pair.  In the product
 // build both pointers are compile-time null and the code below them disappears.
-#ifdef R3DM_DEVTOOLS
+#if defined(R3DM_DEVTOOLS) || defined(R3DM_BISECT_DBG)
 #define R3DM_DBG(P) ((P).dbg)
-#define R3DM_TRACE(P) ((P).trace)
 #else
 #define R3DM_DBG(P) ((uint32_t*)nullptr)
+#endif
+#if defined(R3DM_DEVTOOLS) || defined(R3DM_BISECT_TRACE)
+#define R3DM_TRACE(P) ((P).trace)
+#else
 #define R3DM_TRACE(P) ((double*)nullptr)
 #endif
 #define FCHECK(cond, code, a, b)                                                                          \
@@ -832,6 +835,9 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
             if constexpr (KIND == 2) { for (int e = 9 * nm; e < MS; ++e) Fs[tid * MS + e] = 0.0; }
             else { for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0; }
         }
+#ifdef R3DM_BISECT_VMWAIT
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+#endif
         wg_sync_t<SPILL>();
 
         // ---- evaluate the chunk's iterations in order

@@ -47,7 +47,8 @@ struct HostImage {
     r3dm_dtype dtype = R3DM_F32;
     uint32_t G = 0, n_tiles = 0, words = 0;
     bool has_xy = false, has_dup = false, live = false;
-    DevBuf rows, tiled, tiled16, tiledh, norms, bin, xy, canon;
+    bool borrowed = false;            // the buffers belong to an r3dm_index mounted into this slot for one call: never freed here
+    DevBuf rows, tiled, tiled16, tiledh, tiled8, norms, bin, xy, canon;
     float max_abs = 0.0f; bool not_integer = true, has_negative = true;     // staging statistics (read back after the staging kernel)
     int32_t split_k = 0;                                                    // scale exponent of the f16 split tiles
     DevBuf ann_adj, ann_deg;          // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0
@@ -56,7 +57,8 @@ struct HostImage {
     double Kinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     void release()
     {
-        rows.release(); tiled.release(); tiled16.release(); tiledh.release(); norms.release(); bin.release(); xy.release(); canon.release();
+        if (borrowed) { *this = HostImage(); return; }     // drop the aliases, keep the index's memory
+        rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
         ann_adj.release(); ann_deg.release(); ann_K = 0; live = false;
     }
 };
@@ -112,7 +114,9 @@ struct r3dm_ctx {
     int ak_w = 0, ak_h = 0;
     bool integer_mfma = false;                              // r3dm_set_integer_mfma
     bool split_mfma = false;                                // r3dm_set_split_mfma
+    bool hamming_mfma = false;                              // r3dm_set_hamming_mfma
     uint32_t liop_npix = 0;
+    uint64_t n_views_staged = 0;                            // copies + re-layouts since r3dm_create (never reset)
     r3dm_stats stats{};
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
 };
@@ -129,6 +133,16 @@ struct r3dm_ctx {
 
 struct PairJob { uint32_t I, J, sI, sJ; };
 
+// A dataset staged once for many queries (ArrayMatcher::Build): owns its device buffers, belongs to a device, not to a context
+struct r3dm_index {
+    int device = 0;
+    HostImage img;
+    uint32_t stat_bits[3] = {0, 0, 0};          // ImgDev::max_norm_bits, max_abs_bits, not_integer as the staging kernel left them
+};
+
 // shared between the translation units
+int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3 = nullptr, int32_t split_k = 0);
+int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
+                    int32_t* knn_idx_host, float* knn_dist_host);
 int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width, uint32_t height,
                     const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);

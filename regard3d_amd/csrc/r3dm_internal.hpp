@@ -63,6 +63,9 @@ struct ImgDev {
     // values scaled by 2^split_k (max|x| 2^split_k in [2^13, 2^14); both filled by stage_split_kernel)
     const uint16_t* tiledh;
     int32_t split_k;
+    // binary views, opt-in MFMA Hamming (r3dm_set_hamming_mfma): one byte (0 / 1) per bit in i8 fragment order,
+    // [n_tiles][words][2][32][16]; `norms` then holds popcount + 0x3F800000 as float bits
+    const uint8_t* tiled8;
 };
 #ifndef R3DM_INF
 #define R3DM_INF __builtin_huge_valf()
@@ -233,6 +236,8 @@ hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint
                             uint32_t* bin, uint32_t words, uint32_t n_pad);
 // returns hipErrorInvalidValue when (G, dtype) has no tensor kernel; caller falls back to the exact scan
 hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, bool integer_mfma = false);
+hipError_t launch_hamming_mfma(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_nj_tiles);
+hipError_t launch_stage_bin8(hipStream_t st, const uint32_t* bin, uint32_t n, uint32_t words, uint32_t n_tiles, uint8_t* tiled8, float* norms);
 hipError_t launch_l2_knn2_split(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
 hipError_t launch_stage_split(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
                               uint16_t* tiledh, const uint32_t* img_stats_dev, int32_t* split_k_dev);

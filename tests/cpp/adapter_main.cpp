@@ -45,6 +45,35 @@ int main(int argc, char** argv)
         if (!matcher.SearchNeighbour(b.data(), &one_idx, &one_d) || one_idx != (int)idx[0].j_) return 6;
         return 0;
     }
+    if (!strcmp(argv[1], "loop") && argc == 7) {
+        // loop <I.desc> <J.desc> <dim> <n_searches> <out.txt>: the reference's use of a plugin (src/R3DComputeMatches.cpp:462-479):
+        // Build once, then SearchNeighbours from an OpenMP loop.  Prints "<datasets+queries staged> <contexts used> <all equal>".
+        const int dim = atoi(argv[4]), reps = atoi(argv[5]);
+        std::vector<float> a, b; int na = 0, nb = 0;
+        if (!read_desc(argv[2], dim, a, na) || !read_desc(argv[3], dim, b, nb)) return 3;
+        r3d_amd::ArrayMatcher_r3dm<float> matcher(0);
+        const uint64_t staged0 = matcher.viewsStaged();
+        if (!matcher.Build(a.data(), na, dim)) return 4;
+        std::vector<r3d_amd::IndMatches> idx(reps); std::vector<std::vector<float>> dist(reps);
+        int failed = 0;
+#pragma omp parallel for schedule(dynamic) num_threads(8)
+        for (int r = 0; r < reps; ++r)
+            if (!matcher.SearchNeighbours(b.data(), nb, &idx[r], &dist[r], 2)) {
+#pragma omp atomic
+                ++failed;
+            }
+        if (failed) return 5;
+        bool same = true;
+        for (int r = 1; r < reps; ++r)
+            for (size_t k = 0; k < idx[0].size(); ++k)
+                same = same && idx[r][k].j_ == idx[0][k].j_ && dist[r][k] == dist[0][k];
+        FILE* o = fopen(argv[6], "w");
+        for (int q = 0; q < nb; ++q)
+            fprintf(o, "%u %u %.9g %u %.9g\n", idx[0][2 * q].i_, idx[0][2 * q].j_, dist[0][2 * q], idx[0][2 * q + 1].j_, dist[0][2 * q + 1]);
+        fclose(o);
+        printf("%llu %d %d\n", (unsigned long long)(matcher.viewsStaged() - staged0), matcher.contextsInUse(), same ? 1 : 0);
+        return 0;
+    }
     if (!strcmp(argv[1], "features") && argc >= 6) {
         // features <raw float32 gray image> <width> <height> <out.txt>: Regard3DFeatures::detectAndExtract on the GPU
         const uint32_t w = (uint32_t)atoi(argv[3]), h = (uint32_t)atoi(argv[4]);

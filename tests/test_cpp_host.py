@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def host_exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("cpp") / "adapter_main")
     lib = os.path.join(ROOT, "regard3d_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp"), "-o", out,
                            "-L" + lib, "-lr3dm", "-Wl,-rpath," + lib])
     return out
@@ -63,6 +63,65 @@ def test_array_matcher_adapter_matches_oracle(host_exe, oracle, tmp_path):
     assert np.array_equal(got[:, 0].astype(int), np.arange(700))           # IndMatch(i_ = query row, j_ = dataset row)
     assert np.array_equal(got[:, 1].astype(int), oidx[:, 0]) and np.array_equal(got[:, 3].astype(int), oidx[:, 1])
     assert np.array_equal(got[:, 2].astype(np.float32), odist[:, 0]) and np.array_equal(got[:, 4].astype(np.float32), odist[:, 1])
+
+
+@pytest.mark.gpu
+def test_array_matcher_builds_once_and_searches_concurrently(host_exe, oracle, tmp_path):
+    """the plugin contract's amortisation: Build stages the dataset once, each of 50 SearchNeighbours
+    calls -- issued from 8 OpenMP threads like the reference's loop over J, src/R3DComputeMatches.cpp:465 -- uploads only its
+    queries, on one of the pool's contexts"""
+    sc = synth.make_scene(2, 1500, "sift", seed=19)
+    names = _write_views(oracle, str(tmp_path), sc)
+    out = str(tmp_path / "loop.txt")
+    r = subprocess.run([host_exe, "loop", str(tmp_path / (names[0] + ".desc")), str(tmp_path / (names[1] + ".desc")), "128", "50", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    staged, contexts, same = map(int, r.stdout.split())
+    assert staged == 1 + 50                                   # one dataset + fifty query sets: no dataset re-staging
+    assert 1 <= contexts <= 4 and same == 1
+    got = np.loadtxt(out)
+    oidx, odist = oracle.knn2(sc.descs[0], sc.descs[1])
+    assert np.array_equal(got[:, 1].astype(int), oidx[:, 0]) and np.array_equal(got[:, 3].astype(int), oidx[:, 1])
+    assert np.array_equal(got[:, 2].astype(np.float32), odist[:, 0]) and np.array_equal(got[:, 4].astype(np.float32), odist[:, 1])
+
+
+@pytest.mark.gpu
+def test_index_api_equals_knn2_and_serves_any_context_of_the_device(ctx, oracle):
+    from regard3d_amd import api
+    rng = np.random.default_rng(44)
+    a = np.rint(rng.uniform(0, 255, (900, 128))).astype(np.float32)
+    b = np.rint(rng.uniform(0, 255, (400, 128))).astype(np.float32)
+    ix = ctx.index_create(a)
+    staged0 = ctx.stats().n_views_staged
+    i1, d1 = ctx.index_knn2(ix, b)
+    other = api.Context(0)                                      # a second context on the same device searches the same index
+    i2, d2 = other.index_knn2(ix, b[:100])
+    other.set_integer_mfma(True)
+    i3, d3 = other.index_knn2(ix, b)
+    assert other.stats().n_integer_mfma == 1
+    other.close()
+    oidx, odist = oracle.knn2(a, b)
+    assert np.array_equal(i1, oidx) and np.array_equal(d1, odist) and np.array_equal(i3, oidx) and np.array_equal(d3, odist)
+    assert np.array_equal(i2, oidx[:100]) and np.array_equal(d2, odist[:100])
+    assert ctx.stats().n_views_staged == staged0 + 1            # the query set only
+    ix.close()
+    # binary rows and real-valued rows through the same entry points
+    a8 = rng.integers(0, 256, (300, 61), dtype=np.uint8); b8 = rng.integers(0, 256, (200, 61), dtype=np.uint8)
+    ix = ctx.index_create(a8, binary=True)
+    i, d = ctx.index_knn2(ix, b8)
+    oi, od = oracle.knn2(a8, b8, binary=True)
+    assert np.array_equal(i, oi) and np.array_equal(d, od.astype(np.float32))
+    ix.close()
+    ar = rng.normal(0, 1, (500, 144)).astype(np.float32); br = rng.normal(0, 1, (300, 144)).astype(np.float32)
+    ix = ctx.index_create(ar)
+    for split in (False, True):
+        ctx.set_split_mfma(split)
+        i, d = ctx.index_knn2(ix, br)
+        assert ctx.stats().n_split_mfma == int(split)
+        oi, od = oracle.knn2(ar, br)
+        assert np.array_equal(i, oi) and np.array_equal(d, od)
+    ctx.set_split_mfma(False)
+    ix.close()
 
 
 @pytest.mark.gpu

@@ -7,6 +7,8 @@ import numpy as np
 from regard3d_amd import api, synth
 if len(sys.argv) > 1 and sys.argv[1] == "dev":
     api.use_developer_library()
+elif len(sys.argv) > 1 and sys.argv[1].endswith(".so"):
+    api.use_library(os.path.abspath(sys.argv[1]))
 from oracle import pyoracle as O
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 O.build()
