@@ -352,6 +352,8 @@ def cpu_baseline(name, cfg, ctx, descs, xys, g, gf, budget_s, kp):
     if kp is not None:
         per_pair = 0.12 * (n / 16384.0)
     S = int(min(n_images - 1, max(min(cores, 16), int(cores * budget_s / per_pair))))
+    if kp is not None:
+        S = min(S, 96)                    # the index build of image 0 dominates; more searches add little
     hd = [descs[i].cpu().numpy() for i in range(S + 1)]
     hx = [xys[i].cpu().numpy() for i in range(S + 1)]
     sub = np.stack([np.zeros(S, np.uint32), np.arange(1, S + 1, dtype=np.uint32)], 1)

@@ -237,6 +237,17 @@ int r3dm_gray_from_bgr8(r3dm_ctx* ctx, const unsigned char* bgr, uint32_t width,
 int r3dm_extract_features_to_files(r3dm_ctx* ctx, const float* gray, uint32_t width, uint32_t height, float threshold,
                                    const char* feat_path, const char* desc_path, uint32_t* n_features);
 
+/* The features stage over an image list: R3DFeaturesThread::extractFeaturesAndDescriptors (src/threads/R3DFeaturesThread.cpp:38-121),
+ * whose worker pool pulls images off a work list and runs processWorkItem on each.  `concurrency` images (1..16) are in flight at
+ * once, each on its own context (stream + work buffers) of device `device_id` -- the reference serialises the A-KAZE scale space
+ * with a semaphore (src/Regard3DFeatures.cpp:71-125), the GPU need not.  Images whose <feat> AND <desc> files already exist are
+ * skipped like processWorkItem does (:139-142); skipped[i] (optional) says so and n_features[i] (optional) then carries the row
+ * count of the existing .desc.  grays[i]: height x width floats, host or device.  err (optional) receives the first failure. */
+int r3dm_extract_features_batch(int device_id, uint32_t n_images, const float* const* grays, const uint32_t* widths,
+                                const uint32_t* heights, float threshold, const char* const* feat_paths,
+                                const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped,
+                                uint32_t concurrency, char* err, size_t err_cap);
+
 /* ---- descriptor extraction: LIOP on pre-extracted patches ----
  * r3d_vl_liopdesc_process of the vendored VLFeat copy (src/thirdparty/liop/vl_liop.c:465-580) as Regard3D
  * calls it per keypoint (src/Regard3DFeatures.cpp:727-752,827: new_basic(41) -> 4 neighbours, 6 bins, radius 6):

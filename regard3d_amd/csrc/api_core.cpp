@@ -223,7 +223,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
     return R3DM_OK;
 }
 
-extern "C" int r3dm_set_image(r3dm_ctx* c, uint32_t view_id, uint32_t width, uint32_t height,
+static int r3dm_set_image_impl(r3dm_ctx* c, uint32_t view_id, uint32_t width, uint32_t height,
                               const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
 {
     if (!c || dim == 0 || (n && !desc)) return R3DM_ERR_INVALID;
@@ -241,6 +241,12 @@ extern "C" int r3dm_set_image(r3dm_ctx* c, uint32_t view_id, uint32_t width, uin
         c->slot_of[view_id] = slot;
     } else slot = it->second;
     return stage_into_slot(c, slot, view_id, width, height, desc, n, dim, dtype, xy);
+}
+
+extern "C" int r3dm_set_image(r3dm_ctx* c, uint32_t view_id, uint32_t width, uint32_t height,
+                              const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_set_image_impl(c, view_id, width, height, desc, n, dim, dtype, xy); });
 }
 
 extern "C" int r3dm_clear_images(r3dm_ctx* c)
@@ -285,7 +291,7 @@ extern "C" const uint64_t* r3dm_graph_offsets(const r3dm_graph* g) { return g ? 
 extern "C" const r3dm_match* r3dm_graph_matches(const r3dm_graph* g) { return g ? g->matches.data() : nullptr; }
 extern "C" void r3dm_graph_free(r3dm_graph* g) { delete g; }
 
-extern "C" int r3dm_graph_from_csr(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64_t* offsets,
+static int r3dm_graph_from_csr_impl(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64_t* offsets,
                                    const r3dm_match* matches, r3dm_graph** out)
 {
     if (!out || (n_pairs && (!pairs_ij || !offsets))) return R3DM_ERR_INVALID;
@@ -312,7 +318,13 @@ extern "C" int r3dm_graph_from_csr(const uint32_t* pairs_ij, uint64_t n_pairs, c
     return R3DM_OK;
 }
 
-extern "C" int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out)
+extern "C" int r3dm_graph_from_csr(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64_t* offsets,
+                                   const r3dm_match* matches, r3dm_graph** out)
+{
+    return r3dm_guarded(nullptr, [&]() -> int { return r3dm_graph_from_csr_impl(pairs_ij, n_pairs, offsets, matches, out); });
+}
+
+static int r3dm_graph_merge_impl(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out)
 {
     if (!out || (n_parts && !parts)) return R3DM_ERR_INVALID;
     std::vector<uint32_t> pairs;
@@ -329,6 +341,11 @@ extern "C" int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts
         }
     }
     return r3dm_graph_from_csr(pairs.data(), pairs.size() / 2, offs.data(), m.data(), out);
+}
+
+extern "C" int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts, r3dm_graph** out)
+{
+    return r3dm_guarded(nullptr, [&]() -> int { return r3dm_graph_merge_impl(parts, n_parts, out); });
 }
 
 // matches.*.txt / matches.*.bin -- OpenMVG Save/Load(PairWiseMatches)
@@ -372,7 +389,7 @@ extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
     return ok ? R3DM_OK : R3DM_ERR_IO;
 }
 
-extern "C" int r3dm_load_matches(const char* path, r3dm_graph** out)
+static int r3dm_load_matches_impl(const char* path, r3dm_graph** out)
 {
     if (!path || !out) return R3DM_ERR_INVALID;
     *out = nullptr;
@@ -387,9 +404,14 @@ extern "C" int r3dm_load_matches(const char* path, r3dm_graph** out)
     if (bin) {
         uint8_t le = 0; uint64_t np = 0;
         ok = fread(&le, 1, 1, f) == 1 && le == 1 && fread(&np, 8, 1, f) == 1;
+        // counts come from the file: never size anything by them beyond what the rest of the file can hold
+        long fsz = -1;
+        if (ok) { const long at = ftell(f); ok = at >= 0 && fseek(f, 0, SEEK_END) == 0; fsz = ok ? ftell(f) : -1; ok = ok && fseek(f, at, SEEK_SET) == 0; }
+        ok = ok && np <= (uint64_t)fsz / 16;                     // every entry takes at least 16 bytes
         for (uint64_t p = 0; p < np && ok; ++p) {
             uint32_t ij[2]; uint64_t cnt = 0;
             ok = fread(ij, 4, 2, f) == 2 && fread(&cnt, 8, 1, f) == 1 && cnt < (1ull << 32);
+            if (ok) { const long at = ftell(f); ok = at >= 0 && cnt <= (uint64_t)(fsz - at) / sizeof(r3dm_match); }
             if (!ok) break;
             const size_t at = m.size();
             m.resize(at + cnt);
@@ -399,6 +421,7 @@ extern "C" int r3dm_load_matches(const char* path, r3dm_graph** out)
     } else {
         unsigned I, J; unsigned long long cnt;
         while (fscanf(f, "%u %u %llu", &I, &J, &cnt) == 3) {
+            if (cnt >= (1ull << 32)) { ok = false; break; }
             for (unsigned long long k = 0; k < cnt; ++k) {
                 unsigned a, b;
                 if (fscanf(f, "%u %u", &a, &b) != 2) { ok = false; break; }
@@ -411,5 +434,10 @@ extern "C" int r3dm_load_matches(const char* path, r3dm_graph** out)
     fclose(f);
     if (!ok) return R3DM_ERR_IO;
     return r3dm_graph_from_csr(pairs.data(), pairs.size() / 2, offs.data(), m.data(), out);
+}
+
+extern "C" int r3dm_load_matches(const char* path, r3dm_graph** out)
+{
+    return r3dm_guarded(nullptr, [&]() -> int { return r3dm_load_matches_impl(path, out); });
 }
 

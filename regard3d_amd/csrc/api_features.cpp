@@ -373,17 +373,29 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     return R3DM_OK;
 }
 
-extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+static int r3dm_detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
                                  float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out)
 {
     return detect_akaze_impl(c, image, width, height, threshold, keypoints_out, responses_out, cap, n_out, nullptr);
 }
 
-extern "C" int r3dm_detect_akaze_mldb(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+extern "C" int r3dm_detect_akaze(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+                                 float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_detect_akaze_impl(c, image, width, height, threshold, keypoints_out, responses_out, cap, n_out); });
+}
+
+static int r3dm_detect_akaze_mldb_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
                                       float* keypoints_out, unsigned char* descriptors_out, uint32_t cap, uint32_t* n_out)
 {
     if (!descriptors_out && cap) return R3DM_ERR_INVALID;
     return detect_akaze_impl(c, image, width, height, threshold, keypoints_out, nullptr, cap, n_out, descriptors_out);
+}
+
+extern "C" int r3dm_detect_akaze_mldb(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+                                      float* keypoints_out, unsigned char* descriptors_out, uint32_t cap, uint32_t* n_out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_detect_akaze_mldb_impl(c, image, width, height, threshold, keypoints_out, descriptors_out, cap, n_out); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,7 +439,7 @@ static int liop_prepare(r3dm_ctx* c)
     return R3DM_OK;
 }
 
-extern "C" int r3dm_liop_describe_patches(r3dm_ctx* c, const float* patches, uint32_t n, uint32_t side, float* desc_out,
+static int r3dm_liop_describe_patches_impl(r3dm_ctx* c, const float* patches, uint32_t n, uint32_t side, float* desc_out,
                                           uint32_t* n_resorted)
 {
     if (!c || (n && (!patches || !desc_out))) return R3DM_ERR_INVALID;
@@ -458,7 +470,13 @@ extern "C" int r3dm_liop_describe_patches(r3dm_ctx* c, const float* patches, uin
     return R3DM_OK;
 }
 
-extern "C" int r3dm_extract_liop(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height,
+extern "C" int r3dm_liop_describe_patches(r3dm_ctx* c, const float* patches, uint32_t n, uint32_t side, float* desc_out,
+                                          uint32_t* n_resorted)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_liop_describe_patches_impl(c, patches, n, side, desc_out, n_resorted); });
+}
+
+static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height,
                                  const float* keypoints, uint32_t n, float kp_size_factor, float* desc_out, float* patches_out)
 {
     if (!c || !image || width == 0 || height == 0 || (n && (!keypoints || !desc_out))) return R3DM_ERR_INVALID;
@@ -517,6 +535,12 @@ extern "C" int r3dm_extract_liop(r3dm_ctx* c, const float* image, uint32_t width
     return R3DM_OK;
 }
 
+extern "C" int r3dm_extract_liop(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height,
+                                 const float* keypoints, uint32_t n, float kp_size_factor, float* desc_out, float* patches_out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_extract_liop_impl(c, image, width, height, keypoints, n, kp_size_factor, desc_out, patches_out); });
+}
+
 // ------------------------------------------------------------------------------------------------
 // the per-image work item of the features stage
 // ------------------------------------------------------------------------------------------------
@@ -536,7 +560,7 @@ extern "C" int r3dm_gray_from_bgr8(r3dm_ctx* c, const unsigned char* bgr, uint32
     return R3DM_OK;
 }
 
-extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, uint32_t width, uint32_t height, float threshold,
+static int r3dm_extract_features_to_files_impl(r3dm_ctx* c, const float* gray, uint32_t width, uint32_t height, float threshold,
                                               const char* feat_path, const char* desc_path, uint32_t* n_features)
 {
     if (!c || !gray || !feat_path || !desc_path) return R3DM_ERR_INVALID;
@@ -574,3 +598,78 @@ extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, ui
     return R3DM_OK;
 }
 
+extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, uint32_t width, uint32_t height, float threshold,
+                                              const char* feat_path, const char* desc_path, uint32_t* n_features)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_extract_features_to_files_impl(c, gray, width, height, threshold, feat_path, desc_path, n_features); });
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// the features stage over a whole image list: R3DFeaturesThread::extractFeaturesAndDescriptors
+// (src/threads/R3DFeaturesThread.cpp:38-89) -- a pool of CPUs + 1 worker threads pulling images off a work list (:93-121), each
+// running processWorkItem (:123-210).  The reference admits ONE image at a time into the A-KAZE scale space
+// (initAKAZESemaphore(1), src/R3DComputeMatches.cpp:1847; src/Regard3DFeatures.cpp:71-125) to bound host memory; HBM does not
+// need that: `concurrency` contexts (streams + work buffers) on the device run that many images at once, which fills the GPU
+// where a single image's ~600 small stencil launches cannot.  An image whose .feat AND .desc both exist is skipped, exactly
+// as processWorkItem does (:139-142: stale files of other parameters are reused; the reference wipes the matches directory
+// instead, src/threads/R3DComputeMatchesThread.cpp:84-86); n_features then reports the row count of the existing .desc.
+// ------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <thread>
+
+static bool file_exists(const char* p) { FILE* f = fopen(p, "rb"); if (!f) return false; fclose(f); return true; }
+
+extern "C" int r3dm_extract_features_batch(int device_id, uint32_t n_images, const float* const* grays, const uint32_t* widths,
+                                           const uint32_t* heights, float threshold, const char* const* feat_paths,
+                                           const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped,
+                                           uint32_t concurrency, char* err, size_t err_cap)
+{
+    if (n_images && (!grays || !widths || !heights || !feat_paths || !desc_paths)) return R3DM_ERR_INVALID;
+    if (err && err_cap) err[0] = 0;
+    if (concurrency < 1) concurrency = 1;
+    if (concurrency > 16) concurrency = 16;
+    if (concurrency > n_images) concurrency = n_images ? n_images : 1;
+    std::vector<r3dm_ctx*> ctxs;
+    int rc_all = R3DM_OK;
+    try {
+        for (uint32_t k = 0; k < concurrency; ++k) {
+            r3dm_ctx* c = nullptr;
+            const int rc = r3dm_create(device_id, &c);
+            if (rc != R3DM_OK) { for (r3dm_ctx* x : ctxs) r3dm_destroy(x); return rc; }
+            ctxs.push_back(c);
+        }
+        std::atomic<uint32_t> next{0};
+        std::vector<int> rcs(concurrency, R3DM_OK);
+        std::vector<std::string> errs(concurrency);
+        auto worker = [&](uint32_t k) {
+            for (;;) {
+                const uint32_t i = next.fetch_add(1);
+                if (i >= n_images || rcs[k] != R3DM_OK) return;
+                if (skipped) skipped[i] = 0;
+                if (file_exists(feat_paths[i]) && file_exists(desc_paths[i])) {           // processWorkItem: already computed
+                    uint64_t cnt = 0;
+                    if (FILE* f = fopen(desc_paths[i], "rb")) { if (fread(&cnt, 8, 1, f) != 1) cnt = 0; fclose(f); }
+                    if (n_features) n_features[i] = (uint32_t)cnt;
+                    if (skipped) skipped[i] = 1;
+                    continue;
+                }
+                uint32_t n = 0;
+                const int rc = r3dm_extract_features_to_files(ctxs[k], grays[i], widths[i], heights[i], threshold, feat_paths[i], desc_paths[i], &n);
+                if (n_features) n_features[i] = n;
+                if (rc != R3DM_OK) { rcs[k] = rc; errs[k] = std::string("image ") + std::to_string(i) + ": " + r3dm_last_error(ctxs[k]); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (uint32_t k = 1; k < concurrency; ++k) th.emplace_back(worker, k);
+        worker(0);
+        for (auto& t : th) t.join();
+        for (uint32_t k = 0; k < concurrency; ++k)
+            if (rcs[k] != R3DM_OK && rc_all == R3DM_OK) {
+                rc_all = rcs[k];
+                if (err && err_cap) { strncpy(err, errs[k].c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+            }
+    } catch (...) { rc_all = R3DM_ERR_NOMEM; }
+    for (r3dm_ctx* x : ctxs) r3dm_destroy(x);
+    return rc_all;
+}

@@ -260,16 +260,28 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     return R3DM_OK;
 }
 
-extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+static int r3dm_filter_F_impl(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                              uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out)
 {
     return filter_common(c, putative, max_residual_px, max_iter, seed, err_kind, 0, out, F_out);
 }
 
-extern "C" int r3dm_filter_H(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_filter_F_impl(c, putative, max_residual_px, max_iter, seed, err_kind, out, F_out); });
+}
+
+static int r3dm_filter_H_impl(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                              uint64_t seed, r3dm_graph** out, double* H_out)
 {
     return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 1, out, H_out);
+}
+
+extern "C" int r3dm_filter_H(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, r3dm_graph** out, double* H_out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_filter_H_impl(c, putative, max_residual_px, max_iter, seed, out, H_out); });
 }
 
 extern "C" int r3dm_set_intrinsics(r3dm_ctx* c, uint32_t view_id, const double* K)
@@ -291,10 +303,16 @@ extern "C" int r3dm_set_intrinsics(r3dm_ctx* c, uint32_t view_id, const double* 
     return R3DM_OK;
 }
 
-extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+static int r3dm_filter_E_impl(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                              uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out)
 {
     return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 2, out, E_out, min_count, min_ratio);
+}
+
+extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                             uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_filter_E_impl(c, putative, max_residual_px, max_iter, seed, min_count, min_ratio, out, E_out); });
 }
 
 extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint64_t cap)

@@ -213,7 +213,7 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
     return R3DM_OK;
 }
 
-extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs,
+static int r3dm_match_pairs_impl(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs,
                                 float dist_ratio, int squared_metric, r3dm_graph** out)
 {
     if (!c || !out || (n_pairs && !pairs_ij)) return R3DM_ERR_INVALID;
@@ -268,7 +268,13 @@ extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t 
     return R3DM_OK;
 }
 
-extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
+extern "C" int r3dm_match_pairs(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs,
+                                float dist_ratio, int squared_metric, r3dm_graph** out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_match_pairs_impl(c, pairs_ij, n_pairs, dist_ratio, squared_metric, out); });
+}
+
+static int r3dm_knn2_impl(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
                          uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist)
 {
     if (!c || !dataset || !query || !out_idx || !out_dist || dim == 0) return R3DM_ERR_INVALID;
@@ -300,11 +306,17 @@ extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, c
     return rc;
 }
 
+extern "C" int r3dm_knn2(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, const void* query, uint32_t n_query,
+                         uint32_t dim, r3dm_dtype dtype, int32_t* out_idx, float* out_dist)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_knn2_impl(c, dataset, n_dataset, query, n_query, dim, dtype, out_idx, out_dist); });
+}
+
 // ------------------------------------------------------------------------------------------------
 // ArrayMatcher::Build / SearchNeighbours with the dataset staged ONCE (the reference builds per I and searches per J:
 // /root/reference/src/R3DComputeMatches.cpp:462-479, plugin contract src/utils/matcher_kgraph.h:120-166,205-251)
 // ------------------------------------------------------------------------------------------------
-extern "C" int r3dm_index_create(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, uint32_t dim, r3dm_dtype dtype, r3dm_index** out)
+static int r3dm_index_create_impl(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, uint32_t dim, r3dm_dtype dtype, r3dm_index** out)
 {
     if (!c || !out || !dataset || dim == 0 || n_dataset < 1) return R3DM_ERR_INVALID;
     *out = nullptr;
@@ -332,6 +344,11 @@ extern "C" int r3dm_index_create(r3dm_ctx* c, const void* dataset, uint32_t n_da
     return rc;
 }
 
+extern "C" int r3dm_index_create(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, uint32_t dim, r3dm_dtype dtype, r3dm_index** out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_index_create_impl(c, dataset, n_dataset, dim, dtype, out); });
+}
+
 extern "C" void r3dm_index_destroy(r3dm_index* ix)
 {
     if (!ix) return;
@@ -341,7 +358,7 @@ extern "C" void r3dm_index_destroy(r3dm_index* ix)
     delete ix;
 }
 
-extern "C" int r3dm_index_knn2(r3dm_ctx* c, const r3dm_index* ix, const void* query, uint32_t n_query, int32_t* out_idx, float* out_dist)
+static int r3dm_index_knn2_impl(r3dm_ctx* c, const r3dm_index* ix, const void* query, uint32_t n_query, int32_t* out_idx, float* out_dist)
 {
     if (!c || !ix || !query || !out_idx || !out_dist) return R3DM_ERR_INVALID;
     if (n_query < 1 || ix->img.n < 2) return R3DM_ERR_INVALID;          // ArrayMatcherBruteForce: NN > nbRows / nbQuery < 1
@@ -368,6 +385,11 @@ extern "C" int r3dm_index_knn2(r3dm_ctx* c, const r3dm_index* ix, const void* qu
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
     c->imgs.pop_back(); c->imgs.pop_back();
     return rc;
+}
+
+extern "C" int r3dm_index_knn2(r3dm_ctx* c, const r3dm_index* ix, const void* query, uint32_t n_query, int32_t* out_idx, float* out_dist)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_index_knn2_impl(c, ix, query, n_query, out_idx, out_dist); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,7 +569,7 @@ static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ra
     return R3DM_OK;
 }
 
-extern "C" int r3dm_match_pairs_kgraph(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+static int r3dm_match_pairs_kgraph_impl(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
                                        const r3dm_kgraph_params* kp, r3dm_graph** out)
 {
     if (!c || !out || (n_pairs && !pairs_ij)) return R3DM_ERR_INVALID;
@@ -617,7 +639,13 @@ extern "C" int r3dm_match_pairs_kgraph(r3dm_ctx* c, const uint32_t* pairs_ij, ui
     return rc;
 }
 
-extern "C" int r3dm_kgraph_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
+extern "C" int r3dm_match_pairs_kgraph(r3dm_ctx* c, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                                       const r3dm_kgraph_params* kp, r3dm_graph** out)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_match_pairs_kgraph_impl(c, pairs_ij, n_pairs, dist_ratio, kp, out); });
+}
+
+static int r3dm_kgraph_knn2_impl(r3dm_ctx* c, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
                                 uint32_t dim, const r3dm_kgraph_params* kp, uint32_t pair_i, uint32_t pair_j,
                                 int32_t* out_idx, float* out_dist)
 {
@@ -646,6 +674,13 @@ extern "C" int r3dm_kgraph_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_da
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
     c->imgs.pop_back(); c->imgs.pop_back();
     return rc;
+}
+
+extern "C" int r3dm_kgraph_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
+                                uint32_t dim, const r3dm_kgraph_params* kp, uint32_t pair_i, uint32_t pair_j,
+                                int32_t* out_idx, float* out_dist)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_kgraph_knn2_impl(c, dataset, n_dataset, query, n_query, dim, kp, pair_i, pair_j, out_idx, out_dist); });
 }
 
 extern "C" int r3dm_kgraph_index(r3dm_ctx* c, uint32_t view_id, uint32_t index_K, uint32_t* adj_out, uint32_t* deg_out)

@@ -31,6 +31,12 @@ bool load_desc(const std::string& path, size_t row_bytes, std::vector<unsigned c
     if (!f) return false;
     bool ok = fread(&n, 8, 1, f) == 1;
     if (ok) {
+        // the count comes from the file: check it against what the file can hold before sizing anything by it
+        ok = fseek(f, 0, SEEK_END) == 0;
+        const long sz = ok ? ftell(f) : -1;
+        ok = ok && sz >= 8 && row_bytes > 0 && n <= (uint64_t)(sz - 8) / row_bytes && fseek(f, 8, SEEK_SET) == 0;
+    }
+    if (ok) {
         data.resize((size_t)n * row_bytes);
         ok = n == 0 || fread(data.data(), row_bytes, n, f) == n;
     }
@@ -225,6 +231,7 @@ extern "C" int r3dm_compute_matches_dir(int device_id, const char* matches_dir, 
                                         uint64_t* n_putative_pairs, uint64_t* n_geometric_pairs, char* err, size_t err_cap)
 {
     if (!matches_dir || (n_views && !views)) return R3DM_ERR_INVALID;
+    try {
     r3d_amd::R3DComputeMatches stage(device_id);
     std::vector<r3d_amd::View> vs;
     for (uint32_t k = 0; k < n_views; ++k) vs.push_back({views[k].id, views[k].width, views[k].height, views[k].basename});
@@ -243,4 +250,6 @@ extern "C" int r3dm_compute_matches_dir(int device_id, const char* matches_dir, 
     if (n_geometric_pairs) *n_geometric_pairs = stage.getStatistics().fundamentalMatches_.size();
     if (err && err_cap) { strncpy(err, stage.errorMessage().c_str(), err_cap - 1); err[err_cap - 1] = 0; }
     return ok ? R3DM_OK : R3DM_ERR_IO;
+    } catch (const std::bad_alloc&) { return R3DM_ERR_NOMEM; }          // nothing crosses the C boundary
+    catch (...) { return R3DM_ERR_INVALID; }
 }

@@ -677,6 +677,27 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 #else
 #define R3DM_TRACE(P) ((double*)nullptr)
 #endif
+// bisect builds (tools/build_bisect.sh): each of the four trace sites can be kept as a runtime-null test on its own
+#ifdef R3DM_BISECT_T1
+#define R3DM_TRACE1(P) ((P).trace)
+#else
+#define R3DM_TRACE1(P) R3DM_TRACE(P)
+#endif
+#ifdef R3DM_BISECT_T2
+#define R3DM_TRACE2(P) ((P).trace)
+#else
+#define R3DM_TRACE2(P) R3DM_TRACE(P)
+#endif
+#ifdef R3DM_BISECT_T3
+#define R3DM_TRACE3(P) ((P).trace)
+#else
+#define R3DM_TRACE3(P) R3DM_TRACE(P)
+#endif
+#ifdef R3DM_BISECT_T4
+#define R3DM_TRACE4(P) ((P).trace)
+#else
+#define R3DM_TRACE4(P) R3DM_TRACE(P)
+#endif
 #define FCHECK(cond, code, a, b)                                                                          \
     do {                                                                                                  \
         if (R3DM_DBG(P) && !(cond)) {                                                                           \
@@ -821,17 +842,21 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 // the solver writes its models straight into this lane's LDS slots; its 200-double workspace is the
                 // region behind the hypothesis buffer (the sort buffers of the evaluation phase, idle during the solves)
                 double* ws = reinterpret_cast<double*>(smem + 1024 + kChunk * MS * 8) + tid;
+#ifdef R3DM_BISECT_NANFILL
+                for (int e = 0; e < kEwsDoubles; ++e) ws[(size_t)e * 64] = __builtin_nan("");     // does the solver read workspace it did not write?
+                for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = __builtin_nan("");
+#endif
                 nm = five_point(px1, px2, Fs + tid * MS, ws);
             }
             S.nm[tid] = (uint32_t)nm;
-            if (R3DM_TRACE(P)) S.dbg_smp[tid] = pool[pos[0]];
-            if (R3DM_TRACE(P) && item == P.trace_item && iter0 + tid == P.trace_iter) {
+            if (R3DM_TRACE1(P)) S.dbg_smp[tid] = pool[pos[0]];
+            if (R3DM_TRACE2(P) && item == P.trace_item && iter0 + tid == P.trace_iter) {
                 double* t = P.trace + 5 * (size_t)(P.trace_cap - 4);
                 for (int k = 0; k < 7; ++k) t[k] = (double)pool[pos[k]];
                 t[7] = nm; t[8] = pool_size; t[9] = iter0 + tid;
                 for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k];
             }
-            if (R3DM_TRACE(P) && tid == 0) S.dbg_pool = pool_size;
+            if (R3DM_TRACE3(P) && tid == 0) S.dbg_pool = pool_size;
             if constexpr (KIND == 2) { for (int e = 9 * nm; e < MS; ++e) Fs[tid * MS + e] = 0.0; }
             else { for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0; }
         }
@@ -934,7 +959,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 }
                 wg_sync_t<SPILL>();
                 if (tid == 0) {
-                    if (R3DM_TRACE(P) && item == P.trace_item) {
+                    if (R3DM_TRACE4(P) && item == P.trace_item) {
                         const uint32_t row = *P.trace_rows;
                         if (row < P.trace_cap) {
                             double* t = P.trace + 5 * (size_t)row;

@@ -1634,26 +1634,44 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
                 r3dm_syncthreads();
             }
         }
-        // coordinate de-duplication: only possible when both views contain repeated positions
+        // coordinate de-duplication: only possible when both views contain repeated positions.  Element k is dropped when an
+        // EARLIER element of the (i, j)-sorted list has the same position classes (ci, cj).  canon[] is the smallest index of a
+        // class, so such an element has i >= ci: the scan starts at the first key with i >= ci (binary search) -- for a feature
+        // that is its own class representative (the usual case) that is the handful of earlier matches of the same i.
         if (Ip->canon && Jp->canon) {
             for (uint32_t k = threadIdx.x; k < m; k += 256) {
                 const uint32_t ci = Ip->canon[(uint32_t)(keys[k] >> 32)], cj = Jp->canon[(uint32_t)keys[k]];
+                uint32_t lo = 0, hi = k;
+                const unsigned long long want = (unsigned long long)ci << 32;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
                 unsigned char d = 0;
-                for (uint32_t e = 0; e < k && !d; ++e)
+                for (uint32_t e = lo; e < k && !d; ++e)
                     d = (Ip->canon[(uint32_t)(keys[e] >> 32)] == ci) && (Jp->canon[(uint32_t)keys[e]] == cj);
                 drop[k] = d;
             }
             if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
             r3dm_syncthreads();
-            // stable in-place compaction by a single wave-serial pass (rare path)
-            if (threadIdx.x == 0) {
-                uint32_t w = 0;
-                for (uint32_t k = 0; k < m; ++k) if (!drop[k]) keys[w++] = keys[k];
-                *s_total_p = w;
+            // stable in-place compaction, 256 elements per round: every element moves to a position <= its own, and a round
+            // reads its 256 keys before the barrier that precedes its writes
+            uint32_t w = 0;
+            for (uint32_t base = 0; base < m; base += 256) {
+                const uint32_t k = base + threadIdx.x;
+                const bool keep = (k < m) && !drop[k];
+                const unsigned long long kk = (k < m) ? keys[k] : 0ull;
+                const unsigned long long bal = __ballot(keep);
+                const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+                if (GLOBAL_BUFFERS) __threadfence();
+                r3dm_syncthreads();
+                uint32_t woff = 0, tot = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) { const uint32_t cw = wave_cnt[q]; if (q < wave) woff += cw; tot += cw; }
+                if (keep) keys[w + woff + before] = kk;
+                w += tot;
+                if (GLOBAL_BUFFERS) __threadfence();
+                r3dm_syncthreads();
             }
-            if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
-            r3dm_syncthreads();
-            m = *s_total_p;
+            m = w;
         }
     }
 

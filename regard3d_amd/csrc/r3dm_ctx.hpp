@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <numeric>
 #include <string>
 #include <unordered_map>
@@ -130,6 +131,18 @@ struct r3dm_ctx {
         }                                                                              \
     } while (0)
 
+
+
+// The C ABI never throws: entry points whose bodies size host containers from caller- or file-provided counts run behind this
+// guard (std::bad_alloc / std::length_error would otherwise cross the extern "C" boundary and terminate the host application).
+template <class F>
+static inline int r3dm_guarded(r3dm_ctx* c, F&& body) noexcept
+{
+    try { return body(); }
+    catch (const std::bad_alloc&) { if (c) { try { c->err = "out of host memory"; } catch (...) {} } return R3DM_ERR_NOMEM; }
+    catch (const std::exception& e) { if (c) { try { c->err = e.what(); } catch (...) {} } return R3DM_ERR_INVALID; }
+    catch (...) { return R3DM_ERR_INVALID; }
+}
 
 struct PairJob { uint32_t I, J, sI, sJ; };
 

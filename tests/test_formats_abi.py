@@ -159,3 +159,20 @@ def test_shard_pairs_is_balanced_keeps_rows_together_and_is_a_partition():
     assert api.shard_owner(pairs, 2).tolist() == [0, 0, 0, 1, 1, 0, 1, 1]
     assert api.shard_owner(pairs, 1).tolist() == [0] * 8
     assert api.shard_owner(np.zeros((0, 2), np.uint32), 3).size == 0
+
+
+def test_corrupt_match_and_descriptor_files_fail_cleanly(tmp_path):
+    """ADVICE r1: counts read from disk must not size allocations (std::bad_alloc through extern "C" = std::terminate in the host)"""
+    from regard3d_amd import api
+    good = tmp_path / "g.bin"
+    api.Graph.from_csr(PAIRS, np.concatenate([[0], np.cumsum(COUNTS)]).astype(np.uint64), MATCHES).save(str(good))
+    raw = open(good, "rb").read()
+    # a pair count / a match count far beyond the file size, and a truncated file
+    bad1 = tmp_path / "bad1.bin"; bad1.write_bytes(raw[:1] + struct.pack("<Q", 1 << 40) + raw[9:])
+    bad2 = tmp_path / "bad2.bin"; bad2.write_bytes(raw[:17] + struct.pack("<Q", (1 << 32) - 1) + raw[25:])
+    bad3 = tmp_path / "bad3.bin"; bad3.write_bytes(raw[:-5])
+    bad4 = tmp_path / "bad4.txt"; bad4.write_text("0 1\n99999999999\n0 0\n")
+    for p in (bad1, bad2, bad3, bad4):
+        with pytest.raises(api.R3dmError):
+            api.Graph.load(str(p))
+    assert api.Graph.load(str(good)).num_matches == len(MATCHES)

@@ -19,6 +19,17 @@ for thr in (0.001, 0.0001):
         t = time.time(); kps, resp = c.detect_akaze(img, thr); dt = time.time() - t
     t = time.time(); desc = c.extract_liop(img, kps, 8.0); dl = time.time() - t
     print(json.dumps(dict(image=[h, w], threshold=thr, keypoints=len(kps), s_detect=dt, s_liop=dl, mpix_per_s=h * w / dt / 1e6)), flush=True)
+# the features stage over an image list: 8 copies of the image, one at a time vs 4 in flight (files to /tmp)
+import tempfile, shutil
+d = tempfile.mkdtemp()
+try:
+    imgs = [img] * 8
+    for conc in (1, 2, 4, 8):
+        for f in os.listdir(d): os.remove(os.path.join(d, f))
+        t = time.time(); nf, sk = api.extract_features_batch(imgs, [f"{d}/i{k}.feat" for k in range(8)], [f"{d}/i{k}.desc" for k in range(8)], 0.001, concurrency=conc); dt = time.time() - t
+        print(json.dumps(dict(features_stage_images=8, concurrency=conc, s_total=dt, ms_per_image=dt / 8 * 1e3, keypoints=int(nf[0]))), flush=True)
+finally:
+    shutil.rmtree(d, ignore_errors=True)
 if len(sys.argv) > 1 and sys.argv[1] == "cpu":
     from oracle import pyoracle as o
     t = time.time(); r = o.akaze_detect(img, 0.001); print("oracle (OpenMP port) %.2fs, %d keypoints" % (time.time() - t, len(r["kps"])))

@@ -1,18 +1,23 @@
 #!/bin/bash
-# builds product-library variants that keep one of the two debug hooks of kernels_filter.hip as a RUNTIME-null pointer
-# (bisecting which compile-time removal exposes the nondeterministic essential-matrix filter): regard3d_amd/libr3dm_bisect_{dbg,trace,vmwait}.so
+# Product-library variants for bisecting the nondeterministic essential-matrix filter (kernels_filter.hip): each keeps ONE of
+# the debug hooks that the product build compiles out as a runtime-null test (dbg = the FCHECKs, t1..t4 = the four trace
+# sites), or adds a full vmcnt wait before the barrier behind the solves (vmwait), or poisons the solver's LDS workspace on
+# top of the passing developer configuration (nanfill).  -> regard3d_amd/libr3dm_bisect_<v>.so, linked from the current
+# product objects (run build.sh first).
 set -e
 cd "$(dirname "$0")/.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
 mkdir -p build/bisect
-for v in dbg trace vmwait; do
+VARS="dbg t1 t2 t3 t4 vmwait nanfill"
+for v in $VARS; do
   D=-DR3DM_BISECT_$(echo $v | tr a-z A-Z)
+  [ $v = nanfill ] && D="$D -DR3DM_BISECT_DBG -DR3DM_BISECT_TRACE"
   $HIPCC $FLAGS $D -x hip -c regard3d_amd/csrc/kernels_filter.hip -o build/bisect/kernels_filter_$v.o &
 done
 wait
-for v in dbg trace vmwait; do
+for v in $VARS; do
   objs=$(ls build/product/*.o | grep -v kernels_filter.o)
   $HIPCC --offload-arch=gfx950 -fPIC -fopenmp -shared $objs build/bisect/kernels_filter_$v.o -o regard3d_amd/libr3dm_bisect_$v.so
-  echo built regard3d_amd/libr3dm_bisect_$v.so
 done
+echo "built regard3d_amd/libr3dm_bisect_{$(echo $VARS | tr ' ' ',')}.so"
