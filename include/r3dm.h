@@ -237,17 +237,6 @@ int r3dm_gray_from_bgr8(r3dm_ctx* ctx, const unsigned char* bgr, uint32_t width,
 int r3dm_extract_features_to_files(r3dm_ctx* ctx, const float* gray, uint32_t width, uint32_t height, float threshold,
                                    const char* feat_path, const char* desc_path, uint32_t* n_features);
 
-/* The features stage over an image list: R3DFeaturesThread::extractFeaturesAndDescriptors (src/threads/R3DFeaturesThread.cpp:38-121),
- * whose worker pool pulls images off a work list and runs processWorkItem on each.  `concurrency` images (1..16) are in flight at
- * once, each on its own context (stream + work buffers) of device `device_id` -- the reference serialises the A-KAZE scale space
- * with a semaphore (src/Regard3DFeatures.cpp:71-125), the GPU need not.  Images whose <feat> AND <desc> files already exist are
- * skipped like processWorkItem does (:139-142); skipped[i] (optional) says so and n_features[i] (optional) then carries the row
- * count of the existing .desc.  grays[i]: height x width floats, host or device.  err (optional) receives the first failure. */
-int r3dm_extract_features_batch(int device_id, uint32_t n_images, const float* const* grays, const uint32_t* widths,
-                                const uint32_t* heights, float threshold, const char* const* feat_paths,
-                                const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped,
-                                uint32_t concurrency, char* err, size_t err_cap);
-
 /* ---- descriptor extraction: LIOP on pre-extracted patches ----
  * r3d_vl_liopdesc_process of the vendored VLFeat copy (src/thirdparty/liop/vl_liop.c:465-580) as Regard3D
  * calls it per keypoint (src/Regard3DFeatures.cpp:727-752,827: new_basic(41) -> 4 neighbours, 6 bins, radius 6):
@@ -310,6 +299,16 @@ int r3dm_multi_filter_H(r3dm_multi* m, const r3dm_graph* putative, double max_re
                         uint64_t seed, r3dm_graph** out, double* H_out);
 int r3dm_multi_filter_E(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                         uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out);
+/* The features stage over an image list: R3DFeaturesThread::extractFeaturesAndDescriptors (src/threads/R3DFeaturesThread.cpp:38-121),
+ * whose worker pool pulls images off a work list and runs processWorkItem on each.  Here every context of `m` is a worker: create
+ * the r3dm_multi with one device id repeated K times to keep K images in flight on that GPU (K streams + K sets of work buffers;
+ * the reference admits one image at a time into the A-KAZE scale space, src/Regard3DFeatures.cpp:71-125 -- HBM does not need that),
+ * or with several device ids to spread the list over the GPUs of a node.  Images whose <feat> AND <desc> files already exist are
+ * skipped like processWorkItem does (:139-142); skipped[i] (optional) says so and n_features[i] (optional) then carries the row
+ * count of the existing .desc.  grays[i]: height x width floats, host or device.  err (optional) receives the first failure. */
+int r3dm_multi_extract_features(r3dm_multi* m, uint32_t n_images, const float* const* grays, const uint32_t* widths,
+                                const uint32_t* heights, float threshold, const char* const* feat_paths,
+                                const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped, char* err, size_t err_cap);
 /* owner_out[p] = the device / rank (0..world-1) that the snake deal gives pair p.  Pure host code (no GPU needed). */
 int r3dm_shard_pairs(const uint32_t* pairs_ij, uint64_t n_pairs, uint32_t world, uint32_t* owner_out);
 
@@ -342,6 +341,7 @@ typedef struct {
     uint64_t n_split_mfma;         /* launches of the dominant kernel that ran as the split-f16 nominator */
     uint64_t n_views_staged;       /* views / datasets / query sets copied + re-laid-out by this context since r3dm_create */
     uint64_t n_hamming_mfma;       /* launches of the Hamming matcher that ran as the MFMA formulation */
+    uint64_t n_ak_graph_replays;   /* r3dm_detect_akaze calls whose scale space ran as one hipGraph launch (since r3dm_create) */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_extract_features_batch", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
@@ -45,7 +45,7 @@ class Stats(C.Structure):
                 ("ms_ann_build", C.c_double), ("ms_ann_search", C.c_double), ("n_ann_built", C.c_uint64),
                 ("n_ann_dist", C.c_uint64), ("ms_detect", C.c_double), ("n_integer_mfma", C.c_uint64),
                 ("n_split_mfma", C.c_uint64), ("n_views_staged", C.c_uint64),
-                ("n_hamming_mfma", C.c_uint64)]
+                ("n_hamming_mfma", C.c_uint64), ("n_ak_graph_replays", C.c_uint64)]
 
 
 class KGraphParams(C.Structure):
@@ -124,7 +124,7 @@ def load_library():
     L.r3dm_detect_akaze_mldb.argtypes = [vp, vp, u32, u32, C.c_float, vp, vp, u32, C.POINTER(u32)]
     L.r3dm_gray_from_bgr8.argtypes = [vp, vp, u32, u32, vp]
     L.r3dm_extract_features_to_files.argtypes = [vp, vp, u32, u32, C.c_float, C.c_char_p, C.c_char_p, C.POINTER(u32)]
-    L.r3dm_extract_features_batch.argtypes = [C.c_int, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, u32, C.c_char_p, C.c_size_t]
+    L.r3dm_multi_extract_features.argtypes = [vp, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
     L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]
     L.r3dm_ann_params_for_algorithm.argtypes = [C.c_int, vp]
     L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
@@ -559,6 +559,21 @@ class MultiContext:
     def set_integer_mfma(self, enable: bool = True):
         self._check(self._L.r3dm_multi_set_integer_mfma(self._h, int(bool(enable))), "r3dm_multi_set_integer_mfma")
 
+    def extract_features(self, images, feat_paths, desc_paths, threshold: float = 0.001):
+        """r3dm_multi_extract_features: the features stage over an image list, one image in flight per context.
+        images: list of [h, w] float32 arrays (gray / 255).  -> (n_features [N], skipped [N] bool)"""
+        imgs = [np.ascontiguousarray(im, np.float32) for im in images]
+        n = len(imgs)
+        gp = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        ws = np.array([im.shape[1] for im in imgs], np.uint32); hs = np.array([im.shape[0] for im in imgs], np.uint32)
+        fp = (C.c_char_p * n)(*[p.encode() for p in feat_paths]); dp = (C.c_char_p * n)(*[p.encode() for p in desc_paths])
+        nf = np.zeros(n, np.uint32); sk = np.zeros(n, np.uint32)
+        err = C.create_string_buffer(512)
+        rc = self._L.r3dm_multi_extract_features(self._h, n, gp, _ptr(ws), _ptr(hs), threshold, fp, dp, _ptr(nf), _ptr(sk), err, 512)
+        if rc != 0:
+            raise R3dmError(f"r3dm_multi_extract_features -> {rc}: {err.value.decode()}")
+        return nf, sk.astype(bool)
+
     def match_pairs(self, pairs, dist_ratio: float = 0.6, squared_metric: bool = True) -> Graph:
         pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
         h = C.c_void_p()
@@ -585,18 +600,3 @@ class MultiContext:
                             (max_residual_px, max_iter, seed, min_count, min_ratio), want_E)
 
 
-def extract_features_batch(images, feat_paths, desc_paths, threshold: float = 0.001, concurrency: int = 4, device: int = 0):
-    """r3dm_extract_features_batch: the features stage over an image list, `concurrency` images in flight on the device.
-    images: list of [h, w] float32 arrays (gray / 255).  -> (n_features [N], skipped [N] bool)"""
-    L = load_library()
-    imgs = [np.ascontiguousarray(im, np.float32) for im in images]
-    n = len(imgs)
-    gp = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
-    ws = np.array([im.shape[1] for im in imgs], np.uint32); hs = np.array([im.shape[0] for im in imgs], np.uint32)
-    fp = (C.c_char_p * n)(*[p.encode() for p in feat_paths]); dp = (C.c_char_p * n)(*[p.encode() for p in desc_paths])
-    nf = np.zeros(n, np.uint32); sk = np.zeros(n, np.uint32)
-    err = C.create_string_buffer(512)
-    rc = L.r3dm_extract_features_batch(device, n, gp, _ptr(ws), _ptr(hs), threshold, fp, dp, _ptr(nf), _ptr(sk), concurrency, err, 512)
-    if rc != 0:
-        raise R3dmError(f"r3dm_extract_features_batch -> {rc}: {err.value.decode()}")
-    return nf, sk.astype(bool)

@@ -161,6 +161,39 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     R3DM_HIP(c, hipMemcpyAsync(img, image, n0 * 4, hipMemcpyDefault, st));
     const AkTaps taps_off = ak_taps(1.6f), taps_one = ak_taps(1.0f);
 
+    // INTER_AREA tables of the octave transitions whose size is not an exact halving (they depend on the image size only):
+    // built and uploaded before the launch sequence so that the sequence itself never touches the host
+    struct HalfTabs { const AkAreaTab* xt = nullptr; const AkAreaTab* yt = nullptr; const int* xb = nullptr; const int* yb = nullptr; };
+    std::vector<HalfTabs> half_tabs(nl);
+    DevBuf& tab_buf = buf(B_LEVEL0 + 4 * nl + 3);
+    {
+        std::vector<unsigned char> blob;
+        std::vector<size_t> offs(4 * (size_t)nl, (size_t)-1);
+        auto put = [&](const void* p, size_t bytes) { const size_t at = (blob.size() + 15) / 16 * 16; blob.resize(at + bytes); memcpy(blob.data() + at, p, bytes); return at; };
+        for (int i = 1; i < nl; ++i) {
+            if (lv[i].octave == lv[i - 1].octave) continue;
+            const int sw = lv[i - 1].w, sh = lv[i - 1].h, lw = lv[i].w, lh = lv[i].h;
+            if (lw * 2 == sw && lh * 2 == sh) continue;
+            std::vector<AkAreaTab> tx, ty; std::vector<int> bx, by;
+            ak_area_tab(sw, lw, tx, bx); ak_area_tab(sh, lh, ty, by);
+            offs[4 * i] = put(tx.data(), tx.size() * sizeof(AkAreaTab)); offs[4 * i + 1] = put(ty.data(), ty.size() * sizeof(AkAreaTab));
+            offs[4 * i + 2] = put(bx.data(), bx.size() * 4); offs[4 * i + 3] = put(by.data(), by.size() * 4);
+        }
+        if (!blob.empty()) {
+            R3DM_HIP(c, tab_buf.ensure(blob.size() + 64));
+            R3DM_HIP(c, hipMemcpyAsync(tab_buf.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+            R3DM_HIP(c, hipStreamSynchronize(st));                 // `blob` leaves scope
+            const unsigned char* base = tab_buf.as<unsigned char>();
+            for (int i = 1; i < nl; ++i)
+                if (offs[4 * i] != (size_t)-1)
+                    half_tabs[i] = {(const AkAreaTab*)(base + offs[4 * i]), (const AkAreaTab*)(base + offs[4 * i + 1]),
+                                    (const int*)(base + offs[4 * i + 2]), (const int*)(base + offs[4 * i + 3])};
+        }
+    }
+    uint32_t* hmax_bits = small;                  // [0]      maximum of the gradient modulus (float bits)
+    uint32_t* hist = small + 16;                  // [16..)   300-bin histogram
+    float* inv_k2 = reinterpret_cast<float*>(small + 1024);     // [1024 + o] 1 / k^2 of octave o (ak_kcontrast_kernel)
+
     // Compute_Determinant_Hessian_Response_Single (AKAZEFeatures.cpp:389-410)
     auto hessian = [&](int i) -> hipError_t {
         const int lw = lv[i].w, lh = lv[i].h, s = lv[i].sigma_size;
@@ -171,83 +204,78 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
         return ak_scaled_deriv_det(st, Ly(i), lxx, lxy, Ldet(i), lw, lh, s);
     };
 
-    // ---- Create_Nonlinear_Scale_Space (:245-369), Compute_Base_Evolution_Level (:199-237)
-    R3DM_HIP(c, ak_gaussian(st, img, tmp, smooth, w, h, taps_off));
-    R3DM_HIP(c, hessian(0));
-    float kcontrast = 0.03f;
-    if (nl > 1) {
-        // compute_k_percentileV2 (nldiffusion_functions.cpp:212-262): maximum and 300-bin histogram on the device, the scan here
+    // ---- Create_Nonlinear_Scale_Space (:245-369), Compute_Base_Evolution_Level (:199-237): ~550 launches for a 12 Mpx image,
+    // none of which needs the host -- the k-contrast (compute_k_percentileV2: maximum, 300-bin histogram, percentile scan) stays
+    // on the device.  The sequence depends on the image SIZE only, so it is captured into a hipGraph the first time a size is
+    // seen and replayed as one launch for every later image of that size.
+    auto scale_space = [&]() -> hipError_t {
+        hipError_t e;
+#define AK_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
+        AK_TRY(ak_gaussian(st, img, tmp, smooth, w, h, taps_off));
+        AK_TRY(hessian(0));
+        AK_TRY(hipMemsetAsync(small, 0, 4096 * 4, st));
         const int nbins = 300;
-        R3DM_HIP(c, ak_gaussian(st, img, tmp, flow, w, h, taps_one));
-        R3DM_HIP(c, ak_scharr(st, flow, tmp, tmp2, wx, wy, w, h));
-        R3DM_HIP(c, hipMemsetAsync(small, 0, 4096 * 4, st));
-        R3DM_HIP(c, ak_modg_max(st, wx, wy, w, h, small));
-        uint32_t hbits = 0;
-        R3DM_HIP(c, hipMemcpyAsync(&hbits, small, 4, hipMemcpyDeviceToHost, st));
-        R3DM_HIP(c, hipStreamSynchronize(st));
-        float hmax; memcpy(&hmax, &hbits, 4);
-        if (hmax != 0.0f) {
-            const float sc = (nbins - 1) / hmax;
-            R3DM_HIP(c, ak_modg_hist(st, wx, wy, w, h, sc, nbins, small + 16));
-            std::vector<uint32_t> hist(nbins);
-            R3DM_HIP(c, hipMemcpyAsync(hist.data(), small + 16, nbins * 4, hipMemcpyDeviceToHost, st));
-            R3DM_HIP(c, hipStreamSynchronize(st));
-            const size_t total = (size_t)(w - 2) * (h - 2);
-            const int nthreshold = (int)((total - hist[0]) * 0.7f);
-            int nelements = 0;
-            for (int k = 1; k < nbins; ++k) {
-                if (nelements >= nthreshold) { kcontrast = (float)hmax * k / nbins; break; }
-                nelements = nelements + (int)hist[k];
+        if (nl > 1) {
+            AK_TRY(ak_gaussian(st, img, tmp, flow, w, h, taps_one));
+            AK_TRY(ak_scharr(st, flow, tmp, tmp2, wx, wy, w, h));
+            AK_TRY(ak_modg_max(st, wx, wy, w, h, hmax_bits));
+            AK_TRY(ak_modg_hist(st, wx, wy, w, h, hmax_bits, nbins, hist));
+        }
+        AK_TRY(ak_kcontrast(st, hmax_bits, hist, nbins, (uint32_t)((size_t)(w - 2) * (h - 2)), nl > 1 ? 1 : 0, inv_k2));
+        AK_TRY(hipMemcpyAsync(Lt(0), smooth, n0 * 4, hipMemcpyDeviceToDevice, st));
+        for (int i = 1; i < nl; ++i) {
+            const int lw = lv[i].w, lh = lv[i].h;
+            const size_t n = (size_t)lw * lh;
+            const std::vector<float> tau = ak_fed_tau(lv[i].etime - lv[i - 1].etime);
+            const float* start = nullptr;
+            if (lv[i].octave > lv[i - 1].octave) {
+                // the FED steps ping-pong between Lt(i) and the work image and must END in Lt(i): the half-sampled start image goes
+                // to whichever of the two the first step does not write
+                float* half = (tau.size() % 2 == 1) ? lt2 : Lt(i);
+                const HalfTabs& ht = half_tabs[i];
+                AK_TRY(ak_halfsample(st, Lt(i - 1), half, lv[i - 1].w, lv[i - 1].h, ht.xt, ht.xb, ht.yt, ht.yb));
+                start = half;
+            } else {
+                start = Lt(i - 1);                                  // same octave: the previous level IS the start image, no copy
+            }
+            if (tau.empty()) {                                      // (never for the reference's time steps) plain copy
+                if (start != Lt(i)) AK_TRY(hipMemcpyAsync(Lt(i), start, n * 4, hipMemcpyDeviceToDevice, st));
+                start = Lt(i);
+            }
+            AK_TRY(ak_gaussian(st, start, tmp, smooth, lw, lh, taps_one));
+            AK_TRY(hessian(i));
+            AK_TRY(ak_scharr_g2(st, smooth, flow, lw, lh, inv_k2 + lv[i].octave));      // kcontrast * 0.75^octave
+            // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; step k of n writes Lt(i) when n - k is even, else the work image
+            const float* cur = start;
+            for (size_t k = 1; k <= tau.size(); ++k) {
+                float* out = ((tau.size() - k) % 2 == 0) ? Lt(i) : lt2;
+                AK_TRY(ak_fed_step(st, cur, flow, out, lw, lh, tau[k - 1]));
+                cur = out;
             }
         }
-    }
-    R3DM_HIP(c, hipMemcpyAsync(Lt(0), smooth, n0 * 4, hipMemcpyDeviceToDevice, st));
-    DevBuf tab_buf;
-    for (int i = 1; i < nl; ++i) {
-        const int lw = lv[i].w, lh = lv[i].h;
-        const size_t n = (size_t)lw * lh;
-        const std::vector<float> tau = ak_fed_tau(lv[i].etime - lv[i - 1].etime);
-        const float* start = nullptr;
-        if (lv[i].octave > lv[i - 1].octave) {
-            const int sw = lv[i - 1].w, sh = lv[i - 1].h;
-            const AkAreaTab* xt = nullptr; const AkAreaTab* yt = nullptr; const int* xb = nullptr; const int* yb = nullptr;
-            if (lw * 2 != sw || lh * 2 != sh) {
-                std::vector<AkAreaTab> tx, ty; std::vector<int> bx, by;
-                ak_area_tab(sw, lw, tx, bx); ak_area_tab(sh, lh, ty, by);
-                const size_t bytes = (tx.size() + ty.size()) * sizeof(AkAreaTab) + (bx.size() + by.size()) * 4 + 64;
-                R3DM_HIP(c, hipStreamSynchronize(st));             // the previous table may still be in use
-                R3DM_HIP(c, tab_buf.ensure(bytes));
-                unsigned char* base = tab_buf.as<unsigned char>();
-                size_t o = 0;
-                R3DM_HIP(c, hipMemcpy(base + o, tx.data(), tx.size() * sizeof(AkAreaTab), hipMemcpyHostToDevice)); xt = (const AkAreaTab*)(base + o); o += tx.size() * sizeof(AkAreaTab);
-                R3DM_HIP(c, hipMemcpy(base + o, ty.data(), ty.size() * sizeof(AkAreaTab), hipMemcpyHostToDevice)); yt = (const AkAreaTab*)(base + o); o += ty.size() * sizeof(AkAreaTab);
-                R3DM_HIP(c, hipMemcpy(base + o, bx.data(), bx.size() * 4, hipMemcpyHostToDevice)); xb = (const int*)(base + o); o += bx.size() * 4;
-                R3DM_HIP(c, hipMemcpy(base + o, by.data(), by.size() * 4, hipMemcpyHostToDevice)); yb = (const int*)(base + o);
+#undef AK_TRY
+        return hipSuccess;
+    };
+    bool replayed = false;
+    if (!c->ak_graph_off) {
+        if (c->ak_graph && (c->ak_graph_w != w || c->ak_graph_h != h)) { (void)hipGraphExecDestroy(c->ak_graph); c->ak_graph = nullptr; }
+        if (!c->ak_graph) {
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+            if (e == hipSuccess) {
+                const hipError_t el = scale_space();
+                e = hipStreamEndCapture(st, &g);
+                if (e == hipSuccess) e = el;
             }
-            // the FED steps ping-pong between Lt(i) and the work image and must END in Lt(i): the half-sampled start image goes
-            // to whichever of the two the first step does not write
-            float* half = (tau.size() % 2 == 1) ? lt2 : Lt(i);
-            R3DM_HIP(c, ak_halfsample(st, Lt(i - 1), half, sw, sh, xt, xb, yt, yb));
-            start = half;
-            kcontrast = kcontrast * 0.75f;
-        } else {
-            start = Lt(i - 1);                                  // same octave: the previous level IS the start image, no copy
+            if (e == hipSuccess) e = hipGraphInstantiate(&c->ak_graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { c->ak_graph = nullptr; c->ak_graph_off = true; (void)hipGetLastError(); }
+            else { c->ak_graph_w = w; c->ak_graph_h = h; }
         }
-        if (tau.empty()) {                                      // (never for the reference's time steps) plain copy
-            if (start != Lt(i)) R3DM_HIP(c, hipMemcpyAsync(Lt(i), start, n * 4, hipMemcpyDeviceToDevice, st));
-            start = Lt(i);
-        }
-        R3DM_HIP(c, ak_gaussian(st, start, tmp, smooth, lw, lh, taps_one));
-        R3DM_HIP(c, hessian(i));
-        R3DM_HIP(c, ak_scharr_g2(st, smooth, flow, lw, lh, 1.0f / (kcontrast * kcontrast)));
-        // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; step k of n writes Lt(i) when n - k is even, else the work image
-        const float* cur = start;
-        for (size_t k = 1; k <= tau.size(); ++k) {
-            float* out = ((tau.size() - k) % 2 == 0) ? Lt(i) : lt2;
-            R3DM_HIP(c, ak_fed_step(st, cur, flow, out, lw, lh, tau[k - 1]));
-            cur = out;
-        }
+        if (c->ak_graph) { R3DM_HIP(c, hipGraphLaunch(c->ak_graph, st)); replayed = true; }
     }
+    if (!replayed) R3DM_HIP(c, scale_space());
+    c->n_ak_graph_replays += replayed ? 1 : 0;
 
     // ---- Feature_Detection (:371-382): extrema -> in-level pruning -> cross-level pruning -> refinement + orientation
     std::vector<AkLevelDev> ld(nl);
@@ -367,7 +395,6 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
         R3DM_HIP(c, hipMemcpyAsync(mldb_out, d_out, ni * 61, hipMemcpyDeviceToHost, st));
         R3DM_HIP(c, hipStreamSynchronize(st));
     }
-    tab_buf.release();
     *n_out = n_kp;
     c->stats.ms_detect = now_ms() - t_call;
     return R3DM_OK;
@@ -610,8 +637,8 @@ extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, ui
 // (src/threads/R3DFeaturesThread.cpp:38-89) -- a pool of CPUs + 1 worker threads pulling images off a work list (:93-121), each
 // running processWorkItem (:123-210).  The reference admits ONE image at a time into the A-KAZE scale space
 // (initAKAZESemaphore(1), src/R3DComputeMatches.cpp:1847; src/Regard3DFeatures.cpp:71-125) to bound host memory; HBM does not
-// need that: `concurrency` contexts (streams + work buffers) on the device run that many images at once, which fills the GPU
-// where a single image's ~600 small stencil launches cannot.  An image whose .feat AND .desc both exist is skipped, exactly
+// need that: every context of an r3dm_multi (r3dm_multi_create with a device id repeated K times = K streams + work buffers on
+// that device; or one per GPU) pulls images off the list from its own host thread, so K images are in flight at once.  An image whose .feat AND .desc both exist is skipped, exactly
 // as processWorkItem does (:139-142: stale files of other parameters are reused; the reference wipes the matches directory
 // instead, src/threads/R3DComputeMatchesThread.cpp:84-86); n_features then reports the row count of the existing .desc.
 // ------------------------------------------------------------------------------------------------
@@ -620,29 +647,27 @@ extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, ui
 
 static bool file_exists(const char* p) { FILE* f = fopen(p, "rb"); if (!f) return false; fclose(f); return true; }
 
-extern "C" int r3dm_extract_features_batch(int device_id, uint32_t n_images, const float* const* grays, const uint32_t* widths,
+extern "C" {
+int r3dm_multi_num_devices(const r3dm_multi* m);
+r3dm_ctx* r3dm_multi_ctx(r3dm_multi* m, int k);
+}
+
+extern "C" int r3dm_multi_extract_features(r3dm_multi* m, uint32_t n_images, const float* const* grays, const uint32_t* widths,
                                            const uint32_t* heights, float threshold, const char* const* feat_paths,
                                            const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped,
-                                           uint32_t concurrency, char* err, size_t err_cap)
+                                           char* err, size_t err_cap)
 {
-    if (n_images && (!grays || !widths || !heights || !feat_paths || !desc_paths)) return R3DM_ERR_INVALID;
+    if (!m || (n_images && (!grays || !widths || !heights || !feat_paths || !desc_paths))) return R3DM_ERR_INVALID;
     if (err && err_cap) err[0] = 0;
-    if (concurrency < 1) concurrency = 1;
-    if (concurrency > 16) concurrency = 16;
-    if (concurrency > n_images) concurrency = n_images ? n_images : 1;
-    std::vector<r3dm_ctx*> ctxs;
+    const uint32_t concurrency = (uint32_t)r3dm_multi_num_devices(m);
+    if (concurrency == 0) return R3DM_ERR_INVALID;
     int rc_all = R3DM_OK;
     try {
-        for (uint32_t k = 0; k < concurrency; ++k) {
-            r3dm_ctx* c = nullptr;
-            const int rc = r3dm_create(device_id, &c);
-            if (rc != R3DM_OK) { for (r3dm_ctx* x : ctxs) r3dm_destroy(x); return rc; }
-            ctxs.push_back(c);
-        }
         std::atomic<uint32_t> next{0};
         std::vector<int> rcs(concurrency, R3DM_OK);
         std::vector<std::string> errs(concurrency);
         auto worker = [&](uint32_t k) {
+            r3dm_ctx* c = r3dm_multi_ctx(m, (int)k);
             for (;;) {
                 const uint32_t i = next.fetch_add(1);
                 if (i >= n_images || rcs[k] != R3DM_OK) return;
@@ -655,9 +680,9 @@ extern "C" int r3dm_extract_features_batch(int device_id, uint32_t n_images, con
                     continue;
                 }
                 uint32_t n = 0;
-                const int rc = r3dm_extract_features_to_files(ctxs[k], grays[i], widths[i], heights[i], threshold, feat_paths[i], desc_paths[i], &n);
+                const int rc = r3dm_extract_features_to_files(c, grays[i], widths[i], heights[i], threshold, feat_paths[i], desc_paths[i], &n);
                 if (n_features) n_features[i] = n;
-                if (rc != R3DM_OK) { rcs[k] = rc; errs[k] = std::string("image ") + std::to_string(i) + ": " + r3dm_last_error(ctxs[k]); }
+                if (rc != R3DM_OK) { rcs[k] = rc; errs[k] = std::string("image ") + std::to_string(i) + ": " + r3dm_last_error(c); }
             }
         };
         std::vector<std::thread> th;
@@ -670,6 +695,5 @@ extern "C" int r3dm_extract_features_batch(int device_id, uint32_t n_images, con
                 if (err && err_cap) { strncpy(err, errs[k].c_str(), err_cap - 1); err[err_cap - 1] = 0; }
             }
     } catch (...) { rc_all = R3DM_ERR_NOMEM; }
-    for (r3dm_ctx* x : ctxs) r3dm_destroy(x);
     return rc_all;
 }

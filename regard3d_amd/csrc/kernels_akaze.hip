@@ -146,10 +146,14 @@ void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ 
         if (m > 0.0f) atomicMax(out_max, __float_as_uint(m));          // m >= 0: bit order = value order
     }
 }
+// hmax_bits: the maximum found by ak_modg_max_kernel, read on the device (no host round trip); bin scale = (nbins - 1) / hmax
 __global__ __launch_bounds__(256)
-void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, float sc, int nbins, uint32_t* __restrict__ hist)
+void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, const uint32_t* __restrict__ hmax_bits, int nbins, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t lh[512];
+    const float hmax = __uint_as_float(*hmax_bits);
+    if (hmax == 0.0f) return;                              // compute_k_percentileV2 keeps its default then (workgroup-uniform)
+    const float sc = (nbins - 1) / hmax;
     for (int k = threadIdx.x; k < nbins; k += 256) lh[k] = 0;
     r3dm_syncthreads();
     const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
@@ -165,13 +169,33 @@ void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__
     for (int k = threadIdx.x; k < nbins; k += 256) if (lh[k]) atomicAdd(hist + k, lh[k]);
 }
 
+// compute_k_percentileV2 (nldiffusion_functions.cpp:212-262), the scan over the 300 bins: one thread, the reference's own float
+// operations.  out[o] = 1 / k_o^2 for octave o, k_0 = the percentile (0.03 when the image is flat), k_o = k_{o-1} * 0.75
+// (Create_Nonlinear_Scale_Space: kcontrast *= 0.75 at every octave change).
+__global__ void ak_kcontrast_kernel(const uint32_t* __restrict__ hmax_bits, const uint32_t* __restrict__ hist, int nbins, uint32_t total,
+                                    int have_hist, float* __restrict__ inv_k2)
+{
+    float kcontrast = 0.03f;
+    const float hmax = __uint_as_float(*hmax_bits);
+    if (have_hist && hmax != 0.0f) {
+        const int nthreshold = (int)((float)(total - hist[0]) * 0.7f);
+        int nelements = 0;
+        for (int k = 1; k < nbins; ++k) {
+            if (nelements >= nthreshold) { kcontrast = hmax * (float)k / (float)nbins; break; }
+            nelements = nelements + (int)hist[k];
+        }
+    }
+    for (int o = 0; o < 8; ++o) { inv_k2[o] = 1.0f / (kcontrast * kcontrast); kcontrast = kcontrast * 0.75f; }
+}
+
 // ---- Scharr 3x3 (row pass + column pass, as above) and the PM-G2 conductivity in one kernel: flow = 1 / (1 + |grad|^2 / k^2).
 // Same operations per pixel as the Scharr row + column pass followed by the conductivity, without the four intermediate images.
 __global__ __launch_bounds__(256)
-void ak_scharr_g2_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, float inv_k2)
+void ak_scharr_g2_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, const float* __restrict__ inv_k2_p)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    const float inv_k2 = *inv_k2_p;                        // 1 / k^2 of this octave, left on the device by ak_kcontrast_kernel
     const int xl = ak_refl101(x - 1, w), xr = ak_refl101(x + 1, w);
     const float* Su = src + (size_t)ak_refl101(y - 1, h) * w;
     const float* Sc = src + (size_t)y * w;
@@ -360,6 +384,98 @@ __device__ __forceinline__ bool ak_prune_body(const AkLevelDev& L, uint32_t n_ca
     return true;
 }
 
+// The same rule, 64 candidates at a time.  A candidate can only interact with an EARLIER candidate of its batch if the two lie
+// within 2 size of each other: whatever the earlier one does -- append itself, or take over a slot (which moves that slot from a
+// place within `size` of it to its own place) -- changes the kept set only within `size` of itself or of the slot's old place.
+// So every lane first looks its candidate up in the live set as it stood BEFORE the batch (one pass over the live set for all
+// 64 candidates instead of one per candidate); the outcomes of the candidates without a close earlier batch-mate are final
+// and are applied block-wise (appends keep raster order through a prefix count); the few candidates WITH a close earlier
+// batch-mate are evaluated one by one, in order, exactly like ak_prune_body does.  Identical list, identical order.
+__device__ __forceinline__ bool ak_prune_body_batched(const AkLevelDev& L, uint32_t n_cand, float* lx, float* ly, float* lr, uint32_t* lslot, uint32_t live_cap)
+{
+    const uint32_t lane = threadIdx.x;
+    const float size = L.psize, size2 = size * size, box = 2.0f * size;
+    uint32_t n_list = 0, n_live = 0;
+    for (uint32_t c0 = 0; c0 < n_cand; c0 += 64) {
+        const uint32_t nb = (n_cand - c0 < 64u) ? n_cand - c0 : 64u;
+        const bool have = lane < nb;
+        const float4 mine = have ? L.cand[c0 + lane] : make_float4(0, 0, 0, 0);
+        const float px = mine.x, py = mine.y, pr = mine.z;
+        // ---- drop the live entries that no candidate from this batch on can reach (rows more than one radius behind the
+        // batch's first row; candidates come in raster order)
+        {
+            const float row0 = __shfl(py, 0);
+            uint32_t w = 0;
+            for (uint32_t b = 0; b < n_live; b += 64) {
+                const uint32_t i = b + lane;
+                float ex = 0, ey = 0, er = 0; uint32_t es = 0; bool keep = false;
+                if (i < n_live) { ex = lx[i]; ey = ly[i]; er = lr[i]; es = lslot[i]; const float dy = row0 - ey; keep = dy * dy <= size2; }
+                const unsigned long long bal = __ballot(keep);
+                const uint32_t o = w + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                if (keep) { lx[o] = ex; ly[o] = ey; lr[o] = er; lslot[o] = es; }
+                w += (uint32_t)__builtin_popcountll(bal);
+            }
+            n_live = w;
+        }
+        if (n_live + nb > live_cap) return false;           // (wave-uniform) the caller redoes the level with the live set in scratch
+        // ---- which candidates have an earlier batch-mate within the 2 size box?
+        bool dep = false;
+        for (uint32_t j = 1; j < nb; ++j) {
+            const float ox = __shfl_up(px, j), oy = __shfl_up(py, j);
+            const bool valid = have && lane >= j;
+            const bool near_row = valid && (py - oy) <= box;                 // raster order: py >= oy
+            dep |= near_row && fabsf(px - ox) <= box;
+            if (__ballot(near_row) == 0ull) break;                           // later j are even farther behind for every lane
+        }
+        // ---- look every candidate up in the pre-batch live set: first entry in list order within the radius
+        uint32_t found = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < n_live; ++i) {
+            const float dx = px - lx[i], dy = py - ly[i];
+            if (found == 0xFFFFFFFFu && dx * dx + dy * dy <= size2) found = i;
+        }
+        const unsigned long long dmask = __ballot(dep && have);
+        uint32_t p = 0;
+        while (p < nb) {
+            const unsigned long long rest = dmask >> p;
+            const uint32_t q = rest ? p + (uint32_t)__builtin_ctzll(rest) : nb;      // next candidate that must go one by one
+            // -- block [p, q): independent outcomes
+            const bool in_blk = have && lane >= p && lane < q;
+            const bool app = in_blk && found == 0xFFFFFFFFu;
+            const bool rep = in_blk && found != 0xFFFFFFFFu && pr > lr[found];
+            const unsigned long long amask = __ballot(app);
+            if (rep) { lx[found] = px; ly[found] = py; lr[found] = pr; L.list[lslot[found]] = make_float4(px, py, pr, 1.0f); }
+            if (app) {
+                const uint32_t r = (uint32_t)__builtin_popcountll(amask & ((1ull << lane) - 1ull));
+                lx[n_live + r] = px; ly[n_live + r] = py; lr[n_live + r] = pr; lslot[n_live + r] = n_list + r;
+                L.list[n_list + r] = make_float4(px, py, pr, 1.0f);
+            }
+            { const uint32_t na = (uint32_t)__builtin_popcountll(amask); n_live += na; n_list += na; }
+            p = q;
+            if (q < nb) {
+                // -- candidate q against the CURRENT live set, the whole wave scanning it (as ak_prune_body)
+                const float qx = __shfl(px, (int)q), qy = __shfl(py, (int)q), qr = __shfl(pr, (int)q);
+                int f = -1;
+                for (uint32_t b = 0; b < n_live && f < 0; b += 64) {
+                    const uint32_t i = b + lane;
+                    bool hit = false;
+                    if (i < n_live) { const float dx = qx - lx[i], dy = qy - ly[i]; hit = dx * dx + dy * dy <= size2; }
+                    const unsigned long long bal = __ballot(hit);
+                    if (bal) f = (int)b + __builtin_ctzll(bal);
+                }
+                if (f >= 0) {
+                    if (qr > lr[f]) { if (lane == 0) { lx[f] = qx; ly[f] = qy; lr[f] = qr; L.list[lslot[f]] = make_float4(qx, qy, qr, 1.0f); } }
+                } else {
+                    if (lane == 0) { lx[n_live] = qx; ly[n_live] = qy; lr[n_live] = qr; lslot[n_live] = n_list; L.list[n_list] = make_float4(qx, qy, qr, 1.0f); }
+                    ++n_live; ++n_list;
+                }
+                p = q + 1;
+            }
+        }
+    }
+    if (lane == 0) L.counts[1] = n_list;
+    return true;
+}
+
 __global__ __launch_bounds__(64)
 void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels, uint32_t live_cap)
 {
@@ -369,7 +485,7 @@ void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels, uint32_t live_
     const uint32_t n_cand = L.counts[0];
     // The live set holds the kept points within one radius of the scan line: a few dozen in practice, so it lives in LDS;
     // only if it ever outgrows kAkLive slots (bounded by the candidate count alone) is the level redone with it in scratch.
-    if (!ak_prune_body<false>(L, n_cand, lx, ly, lr, lslot, live_cap))
+    if (!ak_prune_body_batched(L, n_cand, lx, ly, lr, lslot, live_cap))
         ak_prune_body<true>(L, n_cand, L.live, L.live + n_cand, L.live + 2 * (size_t)n_cand, (uint32_t*)(L.live + 3 * (size_t)n_cand), 0u);
 }
 
@@ -632,13 +748,18 @@ hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, 
     hipLaunchKernelGGL(ak_modg_max_kernel, dim3((unsigned)rows), dim3(256), 0, st, Lx, Ly, w, h, out_max);
     return hipGetLastError();
 }
-hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, float sc, int nbins, uint32_t* hist)
+hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, const uint32_t* hmax_bits, int nbins, uint32_t* hist)
 {
     if (nbins > 512) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)((h - 2 + 63) / 64)), dim3(256), 0, st, Lx, Ly, w, h, sc, nbins, hist);
+    hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)((h - 2 + 63) / 64)), dim3(256), 0, st, Lx, Ly, w, h, hmax_bits, nbins, hist);
     return hipGetLastError();
 }
-hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, float inv_k2)
+hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2)
+{
+    hipLaunchKernelGGL(ak_kcontrast_kernel, dim3(1), dim3(1), 0, st, hmax_bits, hist, nbins, total, have_hist, inv_k2);
+    return hipGetLastError();
+}
+hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, const float* inv_k2)
 {
     hipLaunchKernelGGL(ak_scharr_g2_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst, w, h, inv_k2);
     return hipGetLastError();

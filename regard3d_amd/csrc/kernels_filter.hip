@@ -301,6 +301,7 @@ __device__ __forceinline__ double e_peval(const double (&p)[D + 1], double t)
 constexpr int kEwsChain = 0;        // Sturm chain f[k][c] at kEwsChain + 11 k + c   (k < 12)   -- reuses the matrix area
 constexpr int kEwsDeg = 140;        // degree of f[k]
 constexpr int kEwsRoots = 160;      // real roots
+constexpr int kEwsFree = 170;       // slots 170..199 of every lane are unused by the solver: 15,360 contiguous bytes behind slot 169
 constexpr int kEwsDoubles = 200;    // 10 x 20 elimination matrix = 200 doubles per lane
 
 __device__ __forceinline__ int e_sturm_changes(const double* ws, int nf, double t)
@@ -397,7 +398,10 @@ __device__ __noinline__ int real_roots10(const double (&p_in)[11], double* ws)
     return nr;
 }
 
-// Es: this lane's model slots (LDS), 9 doubles per model
+// Es: this lane's model slots (LDS), 9 doubles per model.  px1 / px2 must NOT be the caller's private arrays: the
+// essential-matrix kernel returned different inlier sets from run to run when this out-of-line function received pointers
+// into the caller's scratch frame (bisected in profiles/r02_d_efilter_bisect.txt: any edit that changed the code around the
+// call site hid it); the caller hands the sample over in LDS instead.
 __device__ __noinline__ int five_point(const double (&px1)[7][2], const double (&px2)[7][2], double* __restrict__ Es, double* __restrict__ ws)
 {
     double M[9][5];
@@ -846,7 +850,19 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 for (int e = 0; e < kEwsDoubles; ++e) ws[(size_t)e * 64] = __builtin_nan("");     // does the solver read workspace it did not write?
                 for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = __builtin_nan("");
 #endif
-                nm = five_point(px1, px2, Fs + tid * MS, ws);
+#if !defined(R3DM_E_SAMPLE_VIA_LDS) || R3DM_E_SAMPLE_VIA_LDS
+                // the sample goes to the callee through LDS: 28 contiguous doubles of this lane in the free tail of the workspace
+                typedef double Px72[7][2];
+                double* pbase = reinterpret_cast<double*>(smem + 1024 + kChunk * MS * 8 + kEwsFree * 512) + (size_t)tid * 28;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    pbase[2 * k] = px1[k][0]; pbase[2 * k + 1] = px1[k][1];
+                    pbase[14 + 2 * k] = px2[k][0]; pbase[14 + 2 * k + 1] = px2[k][1];
+                }
+                nm = five_point(*reinterpret_cast<const Px72*>(pbase), *reinterpret_cast<const Px72*>(pbase + 14), Fs + tid * MS, ws);
+#else
+                nm = five_point(px1, px2, Fs + tid * MS, ws);          // bisect builds only: the call shape that was nondeterministic
+#endif
             }
             S.nm[tid] = (uint32_t)nm;
             if (R3DM_TRACE1(P)) S.dbg_smp[tid] = pool[pos[0]];

@@ -372,11 +372,22 @@ __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t
         // (r3dm_knn2) needs the tie's index resolved by the exact scan.
         bool certified = (eb < A3 - slack) || (exact_pair && P.knn_idx == nullptr && ea < eb && eb <= A3);
         if (bf16_tiles && !exact_pair) certified = false;      // bf16 keys of a non-exact pair mean nothing: exact scan
+        // Match mode only needs the VERDICT of the ratio test.  The two re-scored nominees bound the true runner-up distance from
+        // above (d2 <= eb: two rows are no farther than eb) and, with the un-nominated rows' lower bound L = bound + ||q||^2 -
+        // slack, the true best distance from below (d1 >= min(ea, L)).  If min(ea, L) >= R eb then d1 >= R d2 whatever the exact
+        // top-2 is: the query has no match, exactly as the exact scan would find -- and that is the fate of nearly every
+        // uncertifiable query (descriptors without a counterpart sit at almost equal distances from their nearest rows).
+        bool no_match = false;
+        if (!certified && !exact_pair && !bf16_tiles && P.knn_idx == nullptr && valid && nI >= 2 && ib != kNone) {
+            float L = A3 - slack;
+            L -= fabsf(L) * 9.5367431640625e-07f;            // 2^-20: the float evaluation of L itself
+            no_match = fminf(ea, L) >= P.ratio_R * eb;
+        }
         if constexpr (SPLIT) {
             // second chance: the two lane halves of a query nominated up to four rows between them.  Re-score all four in the
             // reference arithmetic and certify against the smallest key that NONE of them holds (each half's third key):
             // the gap from the runner-up to the fifth-best row is what has to exceed the slack now, not the gap to the third.
-            const bool need = valid && nI >= 2 && !certified;
+            const bool need = valid && nI >= 2 && !certified && !no_match;
             if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
                 float f0 = R3DM_INF, f1 = R3DM_INF;
                 if (need) {
@@ -400,6 +411,8 @@ __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t
                 emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
             } else if (certified) {
                 emit_result(P, pair, q, ea, ia, eb, ib);
+            } else if (no_match) {
+                P.nn_idx[(size_t)pair * P.q_stride + q] = kNone;
             } else {
                 P.nn_idx[(size_t)pair * P.q_stride + q] = kFallback;
                 const uint32_t pos = atomicAdd(P.fb_cnt + pair, 1u);

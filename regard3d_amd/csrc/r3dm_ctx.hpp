@@ -113,11 +113,15 @@ struct r3dm_ctx {
     DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff, f_order;
     std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size
     int ak_w = 0, ak_h = 0;
+    hipGraphExec_t ak_graph = nullptr;                      // the scale-space launch sequence of the last image size, captured once
+    int ak_graph_w = 0, ak_graph_h = 0;
+    bool ak_graph_off = false;                              // capture failed once: plain stream launches from then on
     bool integer_mfma = false;                              // r3dm_set_integer_mfma
     bool split_mfma = false;                                // r3dm_set_split_mfma
     bool hamming_mfma = false;                              // r3dm_set_hamming_mfma
     uint32_t liop_npix = 0;
     uint64_t n_views_staged = 0;                            // copies + re-layouts since r3dm_create (never reset)
+    uint64_t n_ak_graph_replays = 0;                        // detector calls served by the captured launch sequence (never reset)
     r3dm_stats stats{};
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
 };

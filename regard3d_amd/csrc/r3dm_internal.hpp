@@ -214,11 +214,12 @@ hipError_t ak_mldb(hipStream_t st, const AkLevelDev* levels, const AkMldbItem* i
 hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray, size_t n);
 hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf);
 hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h);
-hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, float inv_k2);
+hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, const float* inv_k2);
+hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2);
 hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int s);
 hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int s);
 hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max);
-hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, float sc, int nbins, uint32_t* hist);
+hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size);
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);

@@ -109,7 +109,7 @@ def test_features_stage_work_item_writes_the_reference_files(ctx, oracle, tmp_pa
 
 
 def test_features_stage_over_an_image_list_runs_images_concurrently_and_skips_existing_files(ctx, tmp_path):
-    """r3dm_extract_features_batch = R3DFeaturesThread::extractFeaturesAndDescriptors: K images in flight on K contexts give
+    """r3dm_multi_extract_features = R3DFeaturesThread::extractFeaturesAndDescriptors: K images in flight on K contexts give
     byte-identical .feat / .desc files to the one-at-a-time work item; images whose two files exist are skipped
     (src/threads/R3DFeaturesThread.cpp:139-142)"""
     from regard3d_amd import api
@@ -117,7 +117,8 @@ def test_features_stage_over_an_image_list_runs_images_concurrently_and_skips_ex
     seq_dir = tmp_path / "seq"; par_dir = tmp_path / "par"; seq_dir.mkdir(); par_dir.mkdir()
     n_seq = [ctx.extract_features_to_files(im, str(seq_dir / f"i{k}.feat"), str(seq_dir / f"i{k}.desc"), 0.001) for k, im in enumerate(imgs)]
     feats = [str(par_dir / f"i{k}.feat") for k in range(7)]; descs = [str(par_dir / f"i{k}.desc") for k in range(7)]
-    nf, sk = api.extract_features_batch(imgs, feats, descs, 0.001, concurrency=4)
+    m = api.MultiContext([0, 0, 0, 0])
+    nf, sk = m.extract_features(imgs, feats, descs, 0.001)
     assert nf.tolist() == n_seq and not sk.any() and min(n_seq) > 10
     for k in range(7):
         assert open(feats[k], "rb").read() == open(str(seq_dir / f"i{k}.feat"), "rb").read()
@@ -125,7 +126,8 @@ def test_features_stage_over_an_image_list_runs_images_concurrently_and_skips_ex
     # second run: everything exists -> skipped, files untouched; remove one .desc -> only that image is recomputed
     os_mtime = [__import__("os").path.getmtime(p) for p in feats]
     __import__("os").remove(descs[3])
-    nf2, sk2 = api.extract_features_batch(imgs, feats, descs, 0.001, concurrency=3)
+    nf2, sk2 = m.extract_features(imgs, feats, descs, 0.001)
+    m.close()
     assert sk2.tolist() == [True, True, True, False, True, True, True] and nf2.tolist() == n_seq
     assert open(descs[3], "rb").read() == open(str(seq_dir / "i3.desc"), "rb").read()
     assert [__import__("os").path.getmtime(p) for p in feats[:3]] == os_mtime[:3]

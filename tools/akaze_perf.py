@@ -19,15 +19,22 @@ for thr in (0.001, 0.0001):
         t = time.time(); kps, resp = c.detect_akaze(img, thr); dt = time.time() - t
     t = time.time(); desc = c.extract_liop(img, kps, 8.0); dl = time.time() - t
     print(json.dumps(dict(image=[h, w], threshold=thr, keypoints=len(kps), s_detect=dt, s_liop=dl, mpix_per_s=h * w / dt / 1e6)), flush=True)
-# the features stage over an image list: 8 copies of the image, one at a time vs 4 in flight (files to /tmp)
+# the features stage over an image list: 16 copies of the image, K images in flight on K contexts of the one GPU (files to /tmp).
+# Every context has seen the image size once before the timed pass (work buffers allocated, launch sequence captured).
 import tempfile, shutil
+print(json.dumps(dict(scale_space_graph_replays=int(c.stats().n_ak_graph_replays))), flush=True)
 d = tempfile.mkdtemp()
 try:
-    imgs = [img] * 8
-    for conc in (1, 2, 4, 8):
+    imgs = [img] * 16
+    paths = lambda ext: [f"{d}/i{k}.{ext}" for k in range(16)]
+    for conc in (1, 2, 3, 4):
+        m = api.MultiContext([0] * conc)
+        m.extract_features(imgs[:conc], paths("feat")[:conc], paths("desc")[:conc], 0.001)          # warm-up: one image per context
         for f in os.listdir(d): os.remove(os.path.join(d, f))
-        t = time.time(); nf, sk = api.extract_features_batch(imgs, [f"{d}/i{k}.feat" for k in range(8)], [f"{d}/i{k}.desc" for k in range(8)], 0.001, concurrency=conc); dt = time.time() - t
-        print(json.dumps(dict(features_stage_images=8, concurrency=conc, s_total=dt, ms_per_image=dt / 8 * 1e3, keypoints=int(nf[0]))), flush=True)
+        t = time.time(); nf, sk = m.extract_features(imgs, paths("feat"), paths("desc"), 0.001); dt = time.time() - t
+        for f in os.listdir(d): os.remove(os.path.join(d, f))
+        m.close()
+        print(json.dumps(dict(features_stage_images=16, contexts=conc, s_total=dt, ms_per_image=dt / 16 * 1e3, keypoints=int(nf[0]))), flush=True)
 finally:
     shutil.rmtree(d, ignore_errors=True)
 if len(sys.argv) > 1 and sys.argv[1] == "cpu":

@@ -9,10 +9,11 @@ cd "$(dirname "$0")/.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
 mkdir -p build/bisect
-VARS="dbg t1 t2 t3 t4 vmwait nanfill"
+VARS="old olddbg"
 for v in $VARS; do
-  D=-DR3DM_BISECT_$(echo $v | tr a-z A-Z)
-  [ $v = nanfill ] && D="$D -DR3DM_BISECT_DBG -DR3DM_BISECT_TRACE"
+  # old = the by-reference call into the caller's scratch frame (failed); olddbg = the same with the FCHECKs kept as runtime-null
+  # tests (passed); the product itself hands the sample over in LDS.  Earlier variants (t1..t4, vmwait, nanfill): git history.
+  D="-DR3DM_E_SAMPLE_VIA_LDS=0"; [ $v = olddbg ] && D="$D -DR3DM_BISECT_DBG"
   $HIPCC $FLAGS $D -x hip -c regard3d_amd/csrc/kernels_filter.hip -o build/bisect/kernels_filter_$v.o &
 done
 wait
