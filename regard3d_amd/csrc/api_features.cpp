@@ -206,8 +206,7 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
 
     // ---- Create_Nonlinear_Scale_Space (:245-369), Compute_Base_Evolution_Level (:199-237): ~550 launches for a 12 Mpx image,
     // none of which needs the host -- the k-contrast (compute_k_percentileV2: maximum, 300-bin histogram, percentile scan) stays
-    // on the device.  The sequence depends on the image SIZE only, so it is captured into a hipGraph the first time a size is
-    // seen and replayed as one launch for every later image of that size.
+    // on the device.  The sequence depends on the image SIZE only, so it CAN be captured into a hipGraph and replayed (below).
     auto scale_space = [&]() -> hipError_t {
         hipError_t e;
 #define AK_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
@@ -256,8 +255,12 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
 #undef AK_TRY
         return hipSuccess;
     };
+    // Measured (profiles/r02_e_akaze_perf.txt): replaying the ~600-node graph costs MORE than issuing the launches -- 15.8 ms per
+    // 12 Mpx image against 7.5 ms with plain stream launches (the runtime walks the nodes one by one at ~20 us each) -- so the
+    // capture stays a developer option (R3DM_AK_GRAPH=1 in the developer build); the product issues the launches directly.
+    static const bool use_graph = r3dm_dev_knob("R3DM_AK_GRAPH", 0) != 0;
     bool replayed = false;
-    if (!c->ak_graph_off) {
+    if (use_graph && !c->ak_graph_off) {
         if (c->ak_graph && (c->ak_graph_w != w || c->ak_graph_h != h)) { (void)hipGraphExecDestroy(c->ak_graph); c->ak_graph = nullptr; }
         if (!c->ak_graph) {
             hipGraph_t g = nullptr;

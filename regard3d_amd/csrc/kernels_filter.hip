@@ -301,7 +301,7 @@ __device__ __forceinline__ double e_peval(const double (&p)[D + 1], double t)
 constexpr int kEwsChain = 0;        // Sturm chain f[k][c] at kEwsChain + 11 k + c   (k < 12)   -- reuses the matrix area
 constexpr int kEwsDeg = 140;        // degree of f[k]
 constexpr int kEwsRoots = 160;      // real roots
-constexpr int kEwsFree = 170;       // slots 170..199 of every lane are unused by the solver: 15,360 contiguous bytes behind slot 169
+[[maybe_unused]] constexpr int kEwsFree = 170;       // slots 170..199 of every lane are unused by the solver: 15,360 contiguous bytes behind slot 169
 constexpr int kEwsDoubles = 200;    // 10 x 20 elimination matrix = 200 doubles per lane
 
 __device__ __forceinline__ int e_sturm_changes(const double* ws, int nf, double t)
@@ -398,10 +398,8 @@ __device__ __noinline__ int real_roots10(const double (&p_in)[11], double* ws)
     return nr;
 }
 
-// Es: this lane's model slots (LDS), 9 doubles per model.  px1 / px2 must NOT be the caller's private arrays: the
-// essential-matrix kernel returned different inlier sets from run to run when this out-of-line function received pointers
-// into the caller's scratch frame (bisected in profiles/r02_d_efilter_bisect.txt: any edit that changed the code around the
-// call site hid it); the caller hands the sample over in LDS instead.
+// Es: this lane's model slots (LDS), 9 doubles per model.  Out of line on purpose (register pressure of the kernel around it);
+// see launch_filter_E for what that requires of the build.
 __device__ __noinline__ int five_point(const double (&px1)[7][2], const double (&px2)[7][2], double* __restrict__ Es, double* __restrict__ ws)
 {
     double M[9][5];
@@ -653,7 +651,12 @@ struct FState {
 
 constexpr int kChunk = 64;
 
+#ifdef R3DM_FILTER_ONLY_E
+size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind);
+static inline size_t filter_F_lds_bytes_unused_(uint32_t m_cap, int model_kind)
+#else
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
+#endif
 {
     // [FState, padded to 1024][Fs: 64 x (9 x MAX_MODELS) doubles][keys: m_cap x u64][idx: m_cap x u32]
     const size_t ms = model_kind == 2 ? 90 : 27;
@@ -804,7 +807,13 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         const uint32_t pool_size = S.pool_size;
 
         // ---- draw + solve one chunk of minimal samples (lane c <-> iteration iter0 + c)
+#ifdef R3DM_E_UNIFORM_SOLVE
+        // all 64 lanes of wave 0 draw and solve (the samples of lanes >= chunk_n belong to iterations beyond the budget and are
+        // never evaluated): the out-of-line solver is then called from wave-uniform control flow
+        if (tid < (uint32_t)kChunk) {
+#else
         if (tid < chunk_n) {
+#endif
             uint32_t pos[7];
             uint32_t cnt = 0, attempt = 0;
             while (cnt < SS) {
@@ -850,8 +859,8 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 for (int e = 0; e < kEwsDoubles; ++e) ws[(size_t)e * 64] = __builtin_nan("");     // does the solver read workspace it did not write?
                 for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = __builtin_nan("");
 #endif
-#if !defined(R3DM_E_SAMPLE_VIA_LDS) || R3DM_E_SAMPLE_VIA_LDS
-                // the sample goes to the callee through LDS: 28 contiguous doubles of this lane in the free tail of the workspace
+#if defined(R3DM_E_SAMPLE_VIA_LDS) && R3DM_E_SAMPLE_VIA_LDS
+                // bisect builds only (made no difference): the sample handed to the callee through LDS, 28 contiguous doubles of this lane
                 typedef double Px72[7][2];
                 double* pbase = reinterpret_cast<double*>(smem + 1024 + kChunk * MS * 8 + kEwsFree * 512) + (size_t)tid * 28;
 #pragma unroll
@@ -861,7 +870,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 }
                 nm = five_point(*reinterpret_cast<const Px72*>(pbase), *reinterpret_cast<const Px72*>(pbase + 14), Fs + tid * MS, ws);
 #else
-                nm = five_point(px1, px2, Fs + tid * MS, ws);          // bisect builds only: the call shape that was nondeterministic
+                nm = five_point(px1, px2, Fs + tid * MS, ws);
 #endif
             }
             S.nm[tid] = (uint32_t)nm;
@@ -1111,21 +1120,37 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
     }
 }
 
+// The essential-matrix instantiation lives in its own translation unit (kernels_filter_e.hip = this file with
+// R3DM_FILTER_ONLY_E, built with -mllvm -amdgpu-spill-sgpr-to-vgpr=0): it is the one kernel that calls out-of-line device
+// functions (five_point -> real_roots10) from divergent control flow, and with hipcc's default of parking spilled SGPRs in the
+// lanes of a VGPR across those calls it returned different inlier sets from run to run as soon as the debug hooks that happened
+// to reshape the code around the call site were compiled out (profiles/r02_d_efilter_bisect.txt, r02_f_efilter_variants.txt:
+// SGPR spills to memory -> 6 of 6 runs equal to the oracle; a full vmcnt wait, a wave-uniform call, the sample handed over in
+// LDS instead of the caller's scratch frame -> no effect).  F and H have no calls and keep the default.
+hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds);
+#ifdef R3DM_FILTER_ONLY_E
+hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds)
+{
+    hipError_t e = hipFuncSetAttribute((const void*)acransac_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(acransac_kernel<2>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+    return hipGetLastError();
+}
+#else
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
 {
     if (P.n_items == 0) return hipSuccess;
     const size_t lds = filter_F_lds_bytes(P.m_cap, P.model_kind);
-    const void* fn = (P.model_kind == 0) ? (const void*)acransac_kernel<0>
-                   : (P.model_kind == 1) ? (const void*)acransac_kernel<1> : (const void*)acransac_kernel<2>;
+    if (P.model_kind == 2) return launch_filter_E(st, P, lds);
+    const void* fn = (P.model_kind == 0) ? (const void*)acransac_kernel<0> : (const void*)acransac_kernel<1>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     if (P.model_kind == 0)
         hipLaunchKernelGGL(acransac_kernel<0>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
-    else if (P.model_kind == 1)
-        hipLaunchKernelGGL(acransac_kernel<1>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
     else
-        hipLaunchKernelGGL(acransac_kernel<2>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+        hipLaunchKernelGGL(acransac_kernel<1>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
     return hipGetLastError();
 }
+#endif
 
 }  // namespace r3dm

@@ -9,16 +9,15 @@ cd "$(dirname "$0")/.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
 mkdir -p build/bisect
-VARS="old olddbg"
+VARS="ldsflag"
+# ldsflag = the sample handed over in LDS + SGPR spills to memory (the combination that passed in profiles/r02_f_efilter_variants.txt
+# as "nosgprvgpr"); the product is the by-reference call + SGPR spills to memory.  Earlier variants: git history.
 for v in $VARS; do
-  # old = the by-reference call into the caller's scratch frame (failed); olddbg = the same with the FCHECKs kept as runtime-null
-  # tests (passed); the product itself hands the sample over in LDS.  Earlier variants (t1..t4, vmwait, nanfill): git history.
-  D="-DR3DM_E_SAMPLE_VIA_LDS=0"; [ $v = olddbg ] && D="$D -DR3DM_BISECT_DBG"
-  $HIPCC $FLAGS $D -x hip -c regard3d_amd/csrc/kernels_filter.hip -o build/bisect/kernels_filter_$v.o &
+  $HIPCC $FLAGS -DR3DM_E_SAMPLE_VIA_LDS=1 -mllvm -amdgpu-spill-sgpr-to-vgpr=0 -x hip -c regard3d_amd/csrc/kernels_filter_e.hip -o build/bisect/kernels_filter_e_$v.o &
 done
 wait
 for v in $VARS; do
-  objs=$(ls build/product/*.o | grep -v kernels_filter.o)
-  $HIPCC --offload-arch=gfx950 -fPIC -fopenmp -shared $objs build/bisect/kernels_filter_$v.o -o regard3d_amd/libr3dm_bisect_$v.so
+  objs=$(ls build/product/*.o | grep -v kernels_filter_e.o)
+  $HIPCC --offload-arch=gfx950 -fPIC -fopenmp -shared $objs build/bisect/kernels_filter_e_$v.o -o regard3d_amd/libr3dm_bisect_$v.so
 done
 echo "built regard3d_amd/libr3dm_bisect_{$(echo $VARS | tr ' ' ',')}.so"
