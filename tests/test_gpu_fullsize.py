@@ -210,3 +210,54 @@ def test_graph_exchange_over_rccl_single_rank(tmp_path):
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl exchange ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_c5_graph_matcher_at_16384_rows(ctx, oracle):
+    """BASELINE config C5 at its full per-view size (16,384 x 128) on a 4-view collection: the GPU graph matcher equals the CPU
+    model (exact index + pool search, same start-row stream) on a sampled pair bit for bit, recovers the exhaustive matcher's
+    putative matches, is idempotent, and evaluates two orders of magnitude fewer distances than brute force."""
+    from regard3d_amd import api
+    sc = synth.make_scene(4, 16384, "sift", seed=5005)
+    _load(ctx, sc, False)
+    pairs = sc.exhaustive_pairs()
+    kp = api.KGraphParams.preset(3)
+    g = ctx.match_pairs_kgraph(pairs, 0.6, kp)
+    s = ctx.stats()
+    assert s.n_ann_built == 3 and 100 < s.n_ann_dist / s.n_queries < 2000          # ~490 evaluations per query, not 16,384
+    gb = ctx.match_pairs(pairs, 0.6, True)                                          # exhaustive on the same views
+    d, db = g.as_dict(), gb.as_dict()
+    hit = sum(len(set(map(tuple, d[k].tolist())) & set(map(tuple, db[k].tolist()))) for k in d if k in db)
+    assert hit >= 0.99 * gb.num_matches and hit >= 0.999 * g.num_matches             # recall / precision of the putative matches
+    g2 = ctx.match_pairs_kgraph(pairs, 0.6, kp)
+    assert np.array_equal(g.pairs, g2.pairs) and np.array_equal(g.matches, g2.matches) and ctx.stats().n_ann_built == 0
+    # oracle model on one pair at full size (the exact K-NN graph of a 16k view on the CPU takes a few seconds)
+    sub = np.array([[0, 1]], np.uint32)
+    counts, matches, _ = oracle.match_collection_kgraph(sc.descs[:2], sc.xys[:2], sub, 0.6, builder="exact", K=kp.index_K, L=kp.index_K,
+                                                        cap=64, P=kp.search_P, S=kp.search_S, seed=kp.seed, min_rows=128)
+    assert np.array_equal(d[(0, 1)], matches) and counts[0] == len(matches) > 1000
+    ctx.clear_images()
+
+
+def test_c3_binary_collection_of_24_views(ctx, oracle):
+    """BASELINE config C3 as a collection: 24 views x 4,096 x 486-bit rows, 276 pairs, popcount and MFMA formulations against the
+    oracle on a sample of pairs and against each other on all of them; F filter on the result."""
+    sc = synth.make_scene(24, 4096, "akaze", seed=3003)
+    _load(ctx, sc, True)
+    pairs = sc.exhaustive_pairs()
+    g = ctx.match_pairs(pairs, 0.8, False)
+    ctx.set_hamming_mfma(True)
+    try:
+        g2 = ctx.match_pairs(pairs, 0.8, False)
+    finally:
+        ctx.set_hamming_mfma(False)
+    assert np.array_equal(g.pairs, g2.pairs) and np.array_equal(g.offsets, g2.offsets) and np.array_equal(g.matches, g2.matches)
+    sample = pairs[[0, 1, 2, 3, 22, 23, 45, 100, 200, 275]]
+    counts, matches = oracle.match_collection(sc.descs, sc.xys, sample, 0.8, False, binary=True)
+    d = g.as_dict(); off = 0
+    for p, (I, J) in enumerate(sample):
+        exp = matches[off:off + counts[p]]; off += counts[p]
+        assert np.array_equal(d.get((int(I), int(J)), np.zeros((0, 2), np.uint32)), exp), (I, J)
+    gf = ctx.filter_F(g)
+    # images more than three steps apart share nothing: every kept pair is a neighbouring one
+    assert gf.num_pairs >= 60 and all(int(J) - int(I) <= 3 for I, J in gf.pairs)
+    ctx.clear_images()
