@@ -198,9 +198,7 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     auto hessian = [&](int i) -> hipError_t {
         const int lw = lv[i].w, lh = lv[i].h, s = lv[i].sigma_size;
         hipError_t e;
-        // one launch through LDS tiles (ak_hessian_fused_kernel) for the reference's derivative scales ...
-        if (s <= 8) return ak_hessian(st, smooth, Lx(i), Ly(i), Ldet(i), lw, lh, s);
-        // ... three launches otherwise: smooth -> (Lx, Ly);  Lx -> (Lxx, Lxy);  Ly -> Lyy, folded into the determinant
+        // three launches: smooth -> (Lx, Ly);  Lx -> (Lxx, Lxy);  Ly -> Lyy, folded into the determinant
         if ((e = ak_scaled_deriv_xy(st, smooth, Lx(i), Ly(i), lw, lh, s)) != hipSuccess) return e;
         if ((e = ak_scaled_deriv_xy(st, Lx(i), lxx, lxy, lw, lh, s)) != hipSuccess) return e;
         return ak_scaled_deriv_det(st, Ly(i), lxx, lxy, Ldet(i), lw, lh, s);
@@ -230,9 +228,9 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
             const std::vector<float> tau = ak_fed_tau(lv[i].etime - lv[i - 1].etime);
             const float* start = nullptr;
             if (lv[i].octave > lv[i - 1].octave) {
-                // the FED launches (up to four steps each) ping-pong between Lt(i) and the work image and must END in Lt(i): the
-                // half-sampled start image goes to whichever of the two the first launch does not write
-                float* half = (((tau.size() + 3) / 4) % 2 == 1) ? lt2 : Lt(i);
+                // the FED steps ping-pong between Lt(i) and the work image and must END in Lt(i): the half-sampled start image goes
+                // to whichever of the two the first step does not write
+                float* half = (tau.size() % 2 == 1) ? lt2 : Lt(i);
                 const HalfTabs& ht = half_tabs[i];
                 AK_TRY(ak_halfsample(st, Lt(i - 1), half, lv[i - 1].w, lv[i - 1].h, ht.xt, ht.xb, ht.yt, ht.yb));
                 start = half;
@@ -246,14 +244,11 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
             AK_TRY(ak_gaussian(st, start, tmp, smooth, lw, lh, taps_one));
             AK_TRY(hessian(i));
             AK_TRY(ak_scharr_g2(st, smooth, flow, lw, lh, inv_k2 + lv[i].octave));      // kcontrast * 0.75^octave
-            // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j, up to four steps per launch (ak_fed_multi_kernel); launch j of L
-            // writes Lt(i) when L - j is even, else the work image
+            // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; step k of n writes Lt(i) when n - k is even, else the work image
             const float* cur = start;
-            const size_t L = (tau.size() + 3) / 4;
-            for (size_t j = 1; j <= L; ++j) {
-                float* out = ((L - j) % 2 == 0) ? Lt(i) : lt2;
-                const size_t k0 = (j - 1) * 4, nk = std::min<size_t>(4, tau.size() - k0);
-                AK_TRY(ak_fed_steps(st, cur, flow, out, lw, lh, tau.data() + k0, (int)nk));
+            for (size_t k = 1; k <= tau.size(); ++k) {
+                float* out = ((tau.size() - k) % 2 == 0) ? Lt(i) : lt2;
+                AK_TRY(ak_fed_step(st, cur, flow, out, lw, lh, tau[k - 1]));
                 cur = out;
             }
         }

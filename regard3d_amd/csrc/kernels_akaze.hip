@@ -124,74 +124,6 @@ void ak_sderiv_det_kernel(const float* __restrict__ ly, const float* __restrict_
     ldet[i] = lxx[i] * lyy - lxy[i] * lxy[i];
 }
 
-// ---- the determinant of the Hessian of one level in ONE launch (Compute_Determinant_Hessian_Response_Single: smooth -> (Lx, Ly),
-// Lx -> (Lxx, Lxy), Ly -> Lyy, det = Lxx Lyy - Lxy^2).  A 64 x 64 tile keeps `smooth` on a halo of 2 s and (Lx, Ly) on a halo of s
-// in LDS; BORDER_REFLECT_101 folds every tap back into the image before it is looked up, and a folded coordinate always lies
-// inside the tile's halo.  Same expressions, same operands as the three ak_sderiv_* launches it replaces (the accessor reads LDS
-// instead of L1/L2): bit-identical, one launch instead of three, 4.6 image-sized global transfers instead of 10.
-template <class Get>
-__device__ __forceinline__ float ak_sderiv_row_g(Get g, int yy, int x, int w, int s, int dx)
-{
-    const float wgt = 10.0f / 3.0f;
-    const float norm = 1.0f / (2.0f * (wgt + 2.0f));
-    const float kc = wgt * norm;
-    const float a = g(ak_refl101(x - s, w), yy), b = g(ak_refl101(x + s, w), yy);
-    if (dx) return (-a) + b;
-    if (s == 2) return g(x, yy) * kc + (a + b) * norm;
-    return (norm * a + kc * g(x, yy)) + norm * b;
-}
-template <class Get>
-__device__ __forceinline__ float ak_sderiv_at_g(Get g, int x, int y, int w, int h, int s, int dx)
-{
-    const float wgt = 10.0f / 3.0f;
-    const float norm = 1.0f / (2.0f * (wgt + 2.0f));
-    const float kc = wgt * norm;
-    const float u = ak_sderiv_row_g(g, ak_refl101(y - s, h), x, w, s, dx);
-    const float d = ak_sderiv_row_g(g, ak_refl101(y + s, h), x, w, s, dx);
-    if (dx) { const float c = ak_sderiv_row_g(g, y, x, w, s, dx); return kc * c + norm * (d + u); }
-    return d - u;
-}
-constexpr int kHessTile = 64;
-__global__ __launch_bounds__(256)
-void ak_hessian_fused_kernel(const float* __restrict__ smooth, float* __restrict__ Lx, float* __restrict__ Ly, float* __restrict__ Ldet,
-                             int w, int h, int s)
-{
-    extern __shared__ __attribute__((aligned(16))) float hess_smem[];
-    const int P1 = kHessTile + 4 * s, P2 = kHessTile + 2 * s;
-    float* Sm = hess_smem;                         // [P1][P1]  smooth, origin (x0 - 2 s, y0 - 2 s)
-    float* Dx = hess_smem + P1 * P1;               // [P2][P2]  Lx,     origin (x0 - s, y0 - s)
-    float* Dy = Dx + P2 * P2;                      // [P2][P2]  Ly
-    const int x0 = blockIdx.x * kHessTile, y0 = blockIdx.y * kHessTile;
-    const int ox1 = x0 - 2 * s, oy1 = y0 - 2 * s, ox2 = x0 - s, oy2 = y0 - s;
-    for (int e = threadIdx.x; e < P1 * P1; e += 256) {
-        const int ly = e / P1, lx = e - ly * P1;
-        const int gx = ox1 + lx, gy = oy1 + ly;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) Sm[e] = smooth[(size_t)gy * w + gx];
-    }
-    r3dm_syncthreads();
-    auto gS = [&](int xx, int yy) -> float { return Sm[(yy - oy1) * P1 + (xx - ox1)]; };
-    for (int e = threadIdx.x; e < P2 * P2; e += 256) {
-        const int ly = e / P2, lx = e - ly * P2;
-        const int x = ox2 + lx, y = oy2 + ly;
-        if (x < 0 || x >= w || y < 0 || y >= h) continue;
-        const float vx = ak_sderiv_at_g(gS, x, y, w, h, s, 1);
-        const float vy = ak_sderiv_at_g(gS, x, y, w, h, s, 0);
-        Dx[e] = vx; Dy[e] = vy;
-        if (lx >= s && lx < s + kHessTile && ly >= s && ly < s + kHessTile) { Lx[(size_t)y * w + x] = vx; Ly[(size_t)y * w + x] = vy; }
-    }
-    r3dm_syncthreads();
-    auto gX = [&](int xx, int yy) -> float { return Dx[(yy - oy2) * P2 + (xx - ox2)]; };
-    auto gY = [&](int xx, int yy) -> float { return Dy[(yy - oy2) * P2 + (xx - ox2)]; };
-    for (int e = threadIdx.x; e < kHessTile * kHessTile; e += 256) {
-        const int x = x0 + (e & (kHessTile - 1)), y = y0 + (e >> 6);
-        if (x >= w || y >= h) continue;
-        const float lxx = ak_sderiv_at_g(gX, x, y, w, h, s, 1);
-        const float lxy = ak_sderiv_at_g(gX, x, y, w, h, s, 0);
-        const float lyy = ak_sderiv_at_g(gY, x, y, w, h, s, 0);
-        Ldet[(size_t)y * w + x] = lxx * lyy - lxy * lxy;
-    }
-}
-
 // ---- k-contrast: maximum of the gradient modulus over the interior, then its histogram
 __global__ __launch_bounds__(256)
 void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, uint32_t* __restrict__ out_max)
@@ -301,72 +233,6 @@ void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ 
             (fc + Lf[p + w]) * (Lt[p + w] - tc) + (fc + Lf[p - w]) * (Lt[p - w] - tc);
     }
     out[p] = tc + v * 0.5f * step_size;
-}
-
-// ---- up to four FED steps in one launch (temporal blocking).  A 64 x 64 output tile needs the start image and the conductivity
-// on a halo of `ns` pixels; step k is evaluated on the tile grown by ns - k, entirely in LDS (two ping-pong images + the
-// conductivity: 62 KB for ns = 4), and only the last step is written out.  Every value is computed by the expression of
-// ak_fed_step_kernel from the same operands -- which workgroup evaluates an intermediate pixel does not change it -- so the
-// result is bit-identical to ns single-step launches at a quarter of the launches and about a third of the HBM traffic
-// (two reads with (72 / 64)^2 halo overhead + one write per FOUR steps instead of three passes per step).
-constexpr int kFedTile = 64, kFedMaxSteps = 4, kFedPitch = kFedTile + 2 * kFedMaxSteps;
-struct AkFedSteps { int n; float tau[kFedMaxSteps]; };
-
-__global__ __launch_bounds__(256)
-void ak_fed_multi_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, AkFedSteps st)
-{
-    extern __shared__ __attribute__((aligned(16))) float fed_smem[];      // [3][kFedPitch * kFedPitch]: A, B, flow
-    float* A = fed_smem;
-    float* B = fed_smem + kFedPitch * kFedPitch;
-    const float* F = fed_smem + 2 * kFedPitch * kFedPitch;
-    float* Fw = fed_smem + 2 * kFedPitch * kFedPitch;
-    const int ns = st.n;
-    const int x0 = blockIdx.x * kFedTile - ns, y0 = blockIdx.y * kFedTile - ns;      // image coordinates of LDS cell (0, 0)
-    const int RW0 = kFedTile + 2 * ns;
-    for (int e = threadIdx.x; e < RW0 * RW0; e += 256) {
-        const int ly = e / RW0, lx = e - ly * RW0;
-        const int gx = x0 + lx, gy = y0 + ly;
-        const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
-        const size_t p = (size_t)(in ? gy : 0) * w + (in ? gx : 0);
-        A[ly * kFedPitch + lx] = in ? Lt[p] : 0.0f;
-        Fw[ly * kFedPitch + lx] = in ? Lf[p] : 0.0f;
-    }
-    r3dm_syncthreads();
-    for (int k = 1; k <= ns; ++k) {
-        const int m = k;                                     // the region of step k starts m cells inside the loaded block
-        const int RW = kFedTile + 2 * (ns - k);
-        const float step_size = st.tau[k - 1];
-        const bool last = (k == ns);
-        for (int e = threadIdx.x; e < RW * RW; e += 256) {
-            const int ry = e / RW, rx = e - ry * RW;
-            const int lx = m + rx, ly = m + ry;
-            const int x = x0 + lx, y = y0 + ly;
-            if (x < 0 || x >= w || y < 0 || y >= h) continue;
-            const int c = ly * kFedPitch + lx;
-            const bool has_l = x > 0, has_r = x < w - 1, has_a = y > 0, has_b = y < h - 1;
-            const float tc = A[c], fc = F[c];
-            float v;
-            if (!has_a) {
-                if (!has_l || !has_r) v = 0.0f;
-                else v = (fc + F[c + 1]) * (A[c + 1] - tc) + (fc + F[c - 1]) * (A[c - 1] - tc) + (fc + F[c + kFedPitch]) * (A[c + kFedPitch] - tc);
-            } else if (!has_b) {
-                if (!has_l || !has_r) v = 0.0f;
-                else v = (fc + F[c + 1]) * (A[c + 1] - tc) + (fc + F[c - 1]) * (A[c - 1] - tc) + (fc + F[c - kFedPitch]) * (A[c - kFedPitch] - tc);
-            } else if (!has_l) {
-                v = (fc + F[c + 1]) * (A[c + 1] - tc) + (fc + F[c + kFedPitch]) * (A[c + kFedPitch] - tc) + (fc + F[c - kFedPitch]) * (A[c - kFedPitch] - tc);
-            } else if (!has_r) {
-                v = (fc + F[c - 1]) * (A[c - 1] - tc) + (fc + F[c + kFedPitch]) * (A[c + kFedPitch] - tc) + (fc + F[c - kFedPitch]) * (A[c - kFedPitch] - tc);
-            } else {
-                v = (fc + F[c + 1]) * (A[c + 1] - tc) + (fc + F[c - 1]) * (A[c - 1] - tc) +
-                    (fc + F[c + kFedPitch]) * (A[c + kFedPitch] - tc) + (fc + F[c - kFedPitch]) * (A[c - kFedPitch] - tc);
-            }
-            const float r = tc + v * 0.5f * step_size;
-            if (last) out[(size_t)y * w + x] = r;
-            else B[c] = r;
-        }
-        r3dm_syncthreads();
-        float* t = A; A = B; B = t;
-    }
 }
 
 // ---- halfsample: INTER_AREA, exact 2x (resizeAreaFast_) or fractional cells (ResizeArea_, tables from the host)
@@ -901,30 +767,6 @@ hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size)
 {
     hipLaunchKernelGGL(ak_fed_step_kernel, ak_grid(w, h), dim3(256), 0, st, Lt, Lf, out, w, h, step_size);
-    return hipGetLastError();
-}
-hipError_t ak_hessian(hipStream_t st, const float* smooth, float* Lx, float* Ly, float* Ldet, int w, int h, int s)
-{
-    if (s < 1 || s > 8) return hipErrorInvalidValue;         // LDS: (64 + 4 s)^2 + 2 (64 + 2 s)^2 floats, 88 KB at s = 8
-    const int P1 = kHessTile + 4 * s, P2 = kHessTile + 2 * s;
-    const size_t lds = ((size_t)P1 * P1 + 2 * (size_t)P2 * P2) * sizeof(float);
-    const hipError_t attr = hipFuncSetAttribute((const void*)ak_hessian_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(ak_hessian_fused_kernel, dim3((unsigned)((w + kHessTile - 1) / kHessTile), (unsigned)((h + kHessTile - 1) / kHessTile)), dim3(256), lds, st,
-                       smooth, Lx, Ly, Ldet, w, h, s);
-    return hipGetLastError();
-}
-hipError_t ak_fed_steps(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, const float* tau, int n)
-{
-    if (n < 1 || n > kFedMaxSteps) return hipErrorInvalidValue;
-    AkFedSteps s{};
-    s.n = n;
-    for (int k = 0; k < n; ++k) s.tau[k] = tau[k];
-    const size_t lds = (size_t)3 * kFedPitch * kFedPitch * sizeof(float);
-    const hipError_t attr = hipFuncSetAttribute((const void*)ak_fed_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return attr;                     // (per device: set on every launch, like the other large-LDS kernels)
-    hipLaunchKernelGGL(ak_fed_multi_kernel, dim3((unsigned)((w + kFedTile - 1) / kFedTile), (unsigned)((h + kFedTile - 1) / kFedTile)), dim3(256), lds, st,
-                       Lt, Lf, out, w, h, s);
     return hipGetLastError();
 }
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,

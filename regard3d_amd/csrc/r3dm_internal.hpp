@@ -221,8 +221,6 @@ hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx
 hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max);
 hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size);
-hipError_t ak_hessian(hipStream_t st, const float* smooth, float* Lx, float* Ly, float* Ldet, int w, int h, int s);          // fused, s <= 8
-hipError_t ak_fed_steps(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, const float* tau, int n);   // n <= 4 steps in one launch
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);
 hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int max_rows, float thr, int pass);
