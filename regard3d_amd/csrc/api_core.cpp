@@ -48,8 +48,6 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
                       &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill, &c->f_soff, &c->f_order};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
-    c->pin.release();
-    for (int k = 0; k < 2; ++k) if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]);
     if (c->ak_graph) (void)hipGraphExecDestroy(c->ak_graph);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -80,35 +78,6 @@ extern "C" int r3dm_get_stats(const r3dm_ctx* c, r3dm_stats* out)
 // ------------------------------------------------------------------------------------------------
 // views
 // ------------------------------------------------------------------------------------------------
-// Caller buffer -> device on c->stream.  Device and page-locked sources are copied directly; PAGEABLE host memory (what a
-// Regions object of the reference is) goes through two page-locked 4 MiB halves: memcpy into one half while the other is in flight.
-int copy_in(r3dm_ctx* c, void* dst_dev, const void* src, size_t bytes)
-{
-    if (bytes == 0) return R3DM_OK;
-    hipPointerAttribute_t at{};
-    bool pageable = false;
-    if (hipPointerGetAttributes(&at, src) != hipSuccess) { (void)hipGetLastError(); pageable = true; }     // unknown to the runtime: plain host memory
-    else pageable = (at.type == hipMemoryTypeUnregistered);
-    if (!pageable || bytes < (256u << 10)) {
-        R3DM_HIP(c, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDefault, c->stream));
-        return R3DM_OK;
-    }
-    constexpr size_t kHalf = 4u << 20;
-    R3DM_HIP(c, c->pin.ensure(2 * kHalf));
-    for (int k = 0; k < 2; ++k) if (!c->pin_ev[k]) R3DM_HIP(c, hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
-    size_t done = 0; int half = 0; bool used[2] = {false, false};
-    while (done < bytes) {
-        const size_t n = std::min(kHalf, bytes - done);
-        unsigned char* stage = static_cast<unsigned char*>(c->pin.p) + (size_t)half * kHalf;
-        if (used[half]) R3DM_HIP(c, hipEventSynchronize(c->pin_ev[half]));           // the copy that last read this half has finished
-        memcpy(stage, static_cast<const unsigned char*>(src) + done, n);
-        R3DM_HIP(c, hipMemcpyAsync(static_cast<unsigned char*>(dst_dev) + done, stage, n, hipMemcpyHostToDevice, c->stream));
-        R3DM_HIP(c, hipEventRecord(c->pin_ev[half], c->stream));
-        used[half] = true; half ^= 1; done += n;
-    }
-    return R3DM_OK;
-}
-
 // writes the table entry of `slot`; stat_bits3 / split_k are given when the slot mounts an already staged r3dm_index (the
 // staging kernels fill them otherwise)
 int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_t split_k)
@@ -162,7 +131,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         R3DM_HIP(c, h.bin.ensure((size_t)n_pad * h.words * 4 + kSlackBytes));
         if (n) {
             R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
-            if (int rc = copy_in(c, c->d_raw.p, desc, (size_t)n * dim)) return rc;
+            R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
         }
         R3DM_HIP(c, launch_stage_bin(c->stream, c->d_raw.as<uint8_t>(), n, dim, h.bin.as<uint32_t>(), h.words, n_pad));
         // one byte per bit in i8 MFMA fragment order + biased popcounts: the tiles of the opt-in MFMA Hamming (r3dm_set_hamming_mfma)
@@ -194,10 +163,10 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         if (n) {
             if (dtype == R3DM_F32) {
                 R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim * 4));
-                if (int rc = copy_in(c, c->d_raw.p, desc, (size_t)n * dim * 4)) return rc;
+                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim * 4, hipMemcpyDefault, c->stream));
             } else {
                 R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
-                if (int rc = copy_in(c, c->d_raw.p, desc, (size_t)n * dim)) return rc;
+                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
             }
             raw = c->d_raw.p;
         }

@@ -158,7 +158,7 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     float* flow = buf(B_FLOW).as<float>(); float* lt2 = buf(B_LT2).as<float>();
     uint32_t* small = buf(B_SMALL).as<uint32_t>();
 
-    if (int rc_in = copy_in(c, img, image, n0 * 4)) return rc_in;       // (pageable caller memory goes through the pinned staging halves)
+    R3DM_HIP(c, hipMemcpyAsync(img, image, n0 * 4, hipMemcpyDefault, st));
     const AkTaps taps_off = ak_taps(1.6f), taps_one = ak_taps(1.0f);
 
     // INTER_AREA tables of the octave transitions whose size is not an exact halving (they depend on the image size only):

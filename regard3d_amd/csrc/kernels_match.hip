@@ -1203,136 +1203,6 @@ void l2_knn2_int_lds_kernel(const MatchParams P)
     }
 }
 
-// Developer variant: the same pipeline with TWO tiles per barrier (three LDS buffers of two tiles each).  The waves of a
-// workgroup then meet half as often, so a wave that took the list-update path on one tile has a second tile to catch up on before
-// the others wait for it (the measured cost of the per-tile barrier: l2_knn2_int_lds_kernel's comment).
-template <int GB, int NJ, int PF, int WPS, int ABL = 0>
-__global__ __launch_bounds__(256, WPS)
-void l2_knn2_int_lds2_kernel(const MatchParams P)
-{
-    static_assert(GB % 4 == 0 && PF <= GB, "a tile is dealt to four waves in whole 1 KiB blocks");
-    extern __shared__ __attribute__((aligned(16))) unsigned char int_smem[];      // [3 groups][2 tiles][GB KiB] then [3][2][4 waves][256 B norms]
-    constexpr uint32_t tileB = (uint32_t)GB * 1024u, groupB = 2u * tileB;
-    constexpr uint32_t nrm0 = 3u * groupB;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t h = lane >> 5, c = lane & 31u;
-    const uint32_t xcd = blockIdx.x & 7u, jb = blockIdx.x >> 3;
-    const uint32_t pair = (jb / P.qb_per_pair) * 8u + xcd, qb = jb % P.qb_per_pair;
-    if (pair >= P.n_pairs) return;                         // whole workgroup
-    const uint2 pr = P.pairs[pair];
-    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
-    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
-    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles;
-    const uint32_t qt0 = (qb * 4u + wave) * NJ;
-    const bool has_queries = qt0 < ntJ;
-    f32x4 bq[NJ][GB];
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
-        const gf4p src = (gf4p)(const void*)Jp->tiled16 + (size_t)qt * (GB * 64) + lane;
-#pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            const u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);
-            u32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float lo = __uint_as_float(w[k] << 16) * -2.0f, hi = __uint_as_float(w[k] & 0xFFFF0000u) * -2.0f;
-                o[k] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
-            }
-            bq[nj][g] = __builtin_bit_cast(f32x4, o);
-        }
-    }
-    Top2 st[NJ];
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);
-    if (nI >= 2) {
-        const unsigned char* gA = reinterpret_cast<const unsigned char*>(Ip->tiled16) + (size_t)wave * (GB / 4) * 1024u + lane * 16u;
-        const unsigned char* gN = reinterpret_cast<const unsigned char*>(Ip->norms) + (lane & 31u) * 4u;
-        const uint32_t ldsA = wave * (GB / 4) * 1024u, ldsN = nrm0 + wave * 256u;
-        auto issue = [&](uint32_t group, uint32_t buf) {              // both tiles of a group: 2 x (GB / 4 + 1) loads per wave
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const uint32_t tile = 2u * group + (uint32_t)tt;
-#pragma unroll
-                for (int i = 0; i < GB / 4; ++i)
-                    __builtin_amdgcn_global_load_lds((glb_vp)(gA + (size_t)tile * tileB + i * 1024u), (lds_vp)(int_smem + buf * groupB + tt * tileB + ldsA + i * 1024u), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((glb_vp)(gN + (size_t)tile * 128u), (lds_vp)(int_smem + (buf * 2u + tt) * 1024u + ldsN), 4, 0, 0);
-            }
-        };
-        issue(0, 0);
-        issue(1, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue(2, 2);
-        const unsigned char* lane_lds = int_smem + lane * 16u;
-        const unsigned char* lane_nrm = int_smem + nrm0 + wave * 256u + h * 16u;        // tile tt of group buffer b: + (2 b + tt) * 1024
-        f32x4 abuf[PF];
-#pragma unroll
-        for (int s = 0; s < PF; ++s) abuf[s] = *reinterpret_cast<const f32x4*>(lane_lds + s * 1024);
-        f32x16 nrmA, nrmB;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(lane_nrm + qd * 32);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) nrmA[4 * qd + k] = v[k];
-        }
-        f32x16 accA[NJ], accB[NJ];
-#pragma unroll
-        for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accB[nj][r] = R3DM_INF;
-        const uint32_t hb = 4u * h;
-        uint32_t bc = 0, bn = 1, grp = 0;
-        uint32_t t = 0;
-        for (; t + 1 < ntI; t += 2, ++grp) {
-            if (t != 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                issue(grp + 2, bc == 0 ? 2u : bc - 1u);                      // the buffer group grp - 1 occupied
-            }
-            int_tile_step_lds<GB, NJ, PF, ABL>(lane_lds + bc * groupB, lane_lds + bc * groupB + tileB, lane_nrm + (2u * bc + 1u) * 1024u, abuf, nrmA, nrmB, bq, accA, accB, st, (t - 1) * 32u + hb);
-            int_tile_step_lds<GB, NJ, PF, ABL>(lane_lds + bc * groupB + tileB, lane_lds + bn * groupB, lane_nrm + (2u * bn) * 1024u, abuf, nrmB, nrmA, bq, accB, accA, st, t * 32u + hb);
-            bc = bn; bn = bn == 2 ? 0u : bn + 1u;
-        }
-        if (t < ntI) {
-            if (t != 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            int_tile_step_lds<GB, NJ, PF, ABL>(lane_lds + bc * groupB, lane_lds + bc * groupB + tileB, lane_nrm + (2u * bc + 1u) * 1024u, abuf, nrmA, nrmB, bq, accA, accB, st, (t - 1) * 32u + hb);
-#pragma unroll
-            for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tope_push(st[nj], accA[nj][r], t * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
-        } else {
-#pragma unroll
-            for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tope_push(st[nj], accB[nj][r], (ntI - 1) * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (has_queries) l2_finish_queries<NJ, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), true);
-}
-
-template <int GB, int NJ, int PF, int WPS, int ABL = 0>
-static hipError_t launch_l2_int_lds2(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
-{
-    MatchParams P = Pin;
-    const uint32_t tiles_per_wg = 4u * NJ;
-    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    P.xcd_map = 1u;
-    const uint64_t grid64 = (uint64_t)((P.n_pairs + 7u) / 8u * 8u) * P.qb_per_pair;
-    if (grid64 == 0) return hipSuccess;
-    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
-    const size_t lds = 6 * (size_t)GB * 1024 + 6 * 1024;
-    hipError_t e = hipFuncSetAttribute((const void*)l2_knn2_int_lds2_kernel<GB, NJ, PF, WPS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((l2_knn2_int_lds2_kernel<GB, NJ, PF, WPS, ABL>), dim3((uint32_t)grid64), dim3(256), lds, st, P);
-    return hipGetLastError();
-}
-
 template <int GB, int NJ, int PF, int WPS, int ABL = 0, int OPS = 0>
 static hipError_t launch_l2_int_lds(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
@@ -1436,8 +1306,6 @@ hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint
         if (G == 16 && iv == 5) return launch_l2_int_lds<8, 2, 4, 2>(st, P, max_nj_tiles);        // workgroup-shared tiles through LDS-DMA
         if (G == 16 && iv == 59) return launch_l2_int_lds<8, 2, 4, 2, 1>(st, P, max_nj_tiles);    // ... without the epilogue (timing only)
         if (G == 16 && iv == 6) return launch_l2_int_lds<8, 2, 8, 2>(st, P, max_nj_tiles);        // ... whole-tile fragment window
-        if (G == 16 && iv == 7) return launch_l2_int_lds2<8, 2, 4, 2>(st, P, max_nj_tiles);       // ... two tiles per barrier
-        if (G == 16 && iv == 79) return launch_l2_int_lds2<8, 2, 4, 2, 1>(st, P, max_nj_tiles);   // ... without the epilogue (timing only)
         if (G == 16 && iv == 4) return launch_l2_int<8, 4, 4, 1>(st, P, max_nj_tiles);
         if (G == 16 && iv == 9) return launch_l2_int<8, 2, 4, 2, 1>(st, P, max_nj_tiles);
         if (G == 16 && iv == 8) return launch_l2_int<8, 2, 8, 2>(st, P, max_nj_tiles);

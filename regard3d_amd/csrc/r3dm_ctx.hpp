@@ -43,22 +43,6 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// page-locked staging area for host -> device copies of caller buffers (pageable memory goes over PCIe at ~5 GB/s through the
-// runtime's own bounce buffers; two pinned halves filled by memcpy and sent asynchronously reach several times that)
-struct PinBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
-        if (e == hipSuccess) cap = bytes;
-        return e;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
 struct HostImage {
     uint32_t view_id = 0, n = 0, dim = 0, width = 0, height = 0;
     r3dm_dtype dtype = R3DM_F32;
@@ -124,8 +108,6 @@ struct r3dm_ctx {
     DevBuf d_imgs;                                           // ImgDev[slots]
     // scratch (grown on demand, reused across calls)
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
-    PinBuf pin;                                              // staging of caller buffers (copy_in)
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff, f_order;
@@ -176,7 +158,6 @@ struct r3dm_index {
 };
 
 // shared between the translation units
-int copy_in(r3dm_ctx* c, void* dst_dev, const void* src, size_t bytes);      // caller buffer (host or device) -> device, on c->stream
 int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3 = nullptr, int32_t split_k = 0);
 int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
                     int32_t* knn_idx_host, float* knn_dist_host);

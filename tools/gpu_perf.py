@@ -25,23 +25,7 @@ t = time.time()
 for i in range(sc.n_images):
     c.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000, binary=binary)
     c.set_intrinsics(i, synth.intrinsics())
-t_set = time.time() - t
-print("set_image %.2fs" % t_set, flush=True)
-try:
-    import torch
-    dd = [torch.from_numpy(d).cuda() for d in sc.descs[:32]]; dx = [torch.from_numpy(x).cuda() for x in sc.xys[:32]]
-    hp = [torch.from_numpy(d).pin_memory() for d in sc.descs[:32]]
-    torch.cuda.synchronize()
-    t = time.time()
-    for i in range(len(dd)): c.set_image(1000 + i, dd[i], dx[i], 4000, 3000, binary=binary)
-    t_dev = (time.time() - t) / len(dd)
-    t = time.time()
-    for i in range(len(hp)): c.set_image(1000 + i, hp[i], dx[i], 4000, 3000, binary=binary)
-    t_pin = (time.time() - t) / len(hp)
-    print(json.dumps(dict(set_image_ms_per_view=dict(pageable_host=t_set / sc.n_images * 1e3, pinned_host=t_pin * 1e3, device=t_dev * 1e3),
-                          bytes_per_view=int(sc.descs[0].nbytes))), flush=True)
-except Exception as e:
-    print("staging probe skipped:", e)
+print("set_image %.2fs" % (time.time() - t), flush=True)
 pairs = sc.exhaustive_pairs()
 ratio, sq = (0.8, False) if binary else (0.6, True)
 if a.integer_mfma:
