@@ -232,6 +232,7 @@ int r3dm_detect_akaze_mldb(r3dm_ctx* ctx, const float* image, uint32_t width, ui
  * Regard3DFeatures::detectAndExtract with the "Fast-AKAZE" detector + LIOP and KeypointSet::saveToBinFile
  * (src/keypointSet.hpp:61-67): <feat_path> gets one "x y scale orientation" line per feature (scale = size / 2), <desc_path>
  * an 8-byte count followed by count x 144 floats -- the files r3dm_compute_matches_dir / the facade read back.
+ * As in the reference (:139-142) the work item does nothing when BOTH files already exist (n_features = rows of the existing .desc).
  * Image decoding (cv::imread) stays with the caller. */
 int r3dm_gray_from_bgr8(r3dm_ctx* ctx, const unsigned char* bgr, uint32_t width, uint32_t height, float* gray_out);
 int r3dm_extract_features_to_files(r3dm_ctx* ctx, const float* gray, uint32_t width, uint32_t height, float threshold,

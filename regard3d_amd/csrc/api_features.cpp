@@ -595,6 +595,21 @@ static int r3dm_extract_features_to_files_impl(r3dm_ctx* c, const float* gray, u
 {
     if (!c || !gray || !feat_path || !desc_path) return R3DM_ERR_INVALID;
     if (n_features) *n_features = 0;
+    // "Test if descriptor and feature was already computed" (src/threads/R3DFeaturesThread.cpp:139-142): when BOTH files exist the
+    // work item does nothing -- files left by a run with other parameters are reused, the reference wipes the matches directory
+    // instead (src/threads/R3DComputeMatchesThread.cpp:84-86).  n_features then reports the row count of the existing .desc.
+    {
+        FILE* ff = fopen(feat_path, "rb");
+        FILE* fd = ff ? fopen(desc_path, "rb") : nullptr;
+        if (ff) fclose(ff);
+        if (fd) {
+            uint64_t cnt = 0;
+            if (fread(&cnt, 8, 1, fd) != 1) cnt = 0;
+            fclose(fd);
+            if (n_features) *n_features = (uint32_t)cnt;
+            return R3DM_OK;
+        }
+    }
     // detectAndExtract (src/Regard3DFeatures.cpp:206-222) for keypointDetectorList_ = {"Fast-AKAZE"}
     uint32_t n = 0;
     std::vector<float> kps(4 * 65536);
