@@ -61,7 +61,8 @@ class R3DComputeMatches {
 public:
     // matchingAlgorithm value of the new dispatch arm next to src/R3DComputeMatches.cpp:2054-2062;
     // 4 ("Brute Force", src/Regard3DMainFrameBase.cpp:1020) is served by the same GPU path; the approximate arms (0 FLANN,
-    // 1..3 KGraph, 5 MRPT, 6..8 HNSW) run the graph-based approximate matcher with a preset of at least the arm's recall.
+    // 1..3 KGraph, 5 MRPT, 6..8 HNSW) run the graph-based approximate matcher with a preset of at least the arm's recall
+    // (FLANN / MRPT / HNSW are substituted by it, not reimplemented: r3dm.h, r3dm_ann_params_for_algorithm).
     static constexpr int kMatchingAlgorithmGPU = 9;
 
     explicit R3DComputeMatches(int device_id = 0);
