@@ -437,3 +437,49 @@ def test_filters_on_degenerate_and_tiny_pairs(ctx, oracle):
                 bad.append((name, int(I), int(J), int(counts[p]), len(got), len(exp)))
     assert not bad, bad
     assert (0, 1) in ctx.filter_H(g).as_dict()                 # the translation is a perfect homography
+
+
+@pytest.mark.gpu
+def test_filters_skip_no_model_that_could_win(ctx):
+    """The AC-RANSAC kernels skip the sort of a model whose histogram bound on the NFA stays above the best NFA so far
+    (kernels_filter.hip).  The developer build with R3DM_FILTER_CHECK=1 skips nothing and checks `bound <= NFA` on every model it
+    evaluates (invariant 8 -> error); its inlier sets and models must equal the product's."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sc = synth.make_scene(7, 4000, "sift", seed=612)
+    K = synth.intrinsics()
+    ctx.clear_images()
+    for i in range(sc.n_images):
+        ctx.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000); ctx.set_intrinsics(i, K)
+    pairs = sc.exhaustive_pairs()
+    g = ctx.match_pairs(pairs, 0.6, True)
+    prod = {}
+    for name, fn, kw in (("F", ctx.filter_F, "want_F"), ("H", ctx.filter_H, "want_H"), ("E", ctx.filter_E, "want_E")):
+        out, M = fn(g, **{kw: True})
+        prod[name] = (np.array(out.pairs), np.array(out.offsets), np.array(out.matches), M, np.array(ctx.filter_report(), np.float64))
+    assert len(prod["F"][0]) > 0 and len(prod["E"][0]) > 0
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {root!r})
+        import numpy as np
+        from regard3d_amd import api, synth
+        api.use_developer_library()
+        sc = synth.make_scene(7, 4000, "sift", seed=612)
+        K = synth.intrinsics()
+        c = api.Context(0)
+        for i in range(sc.n_images):
+            c.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000); c.set_intrinsics(i, K)
+        g = c.match_pairs(sc.exhaustive_pairs(), 0.6, True)
+        for name, fn, kw in (("F", c.filter_F, "want_F"), ("H", c.filter_H, "want_H"), ("E", c.filter_E, "want_E")):
+            out, M = fn(g, **{{kw: True}})     # raises on a violated invariant
+            np.savez(sys.argv[1] + name + ".npz", pairs=np.array(out.pairs), offsets=np.array(out.offsets), matches=np.array(out.matches), models=M,
+                     report=np.array(c.filter_report(), np.float64))
+        print("checked")
+    """)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([sys.executable, "-c", code, d + "/"], env=dict(os.environ, R3DM_FILTER_CHECK="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "checked" in r.stdout, r.stdout[-800:] + r.stderr[-2500:]
+        for name in ("F", "H", "E"):
+            z = np.load(d + "/" + name + ".npz")
+            for k, ref in zip(("pairs", "offsets", "matches", "models", "report"), prod[name]):
+                assert np.array_equal(z[k], ref), (name, k)
