@@ -1021,27 +1021,45 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 #pragma unroll
                 for (int j = 0; j < kHistBins / 256; ++j) hist[tid + 256 * j] = 0u;
                 wg_sync_t<SPILL>();
-                for (uint32_t base = 0; base < m; base += 256) {
-                    const uint32_t p = base + tid;
-                    double r = 0.0; bool in = false;
-                    if (p < m) {
-                        r = (KIND == 0) ? sym_epipolar_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3])
-                          : (KIND == 1) ? h_asym_err(F, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3])
-                                        : epipolar_dist_err(FE, pt[4 * (size_t)p], pt[4 * (size_t)p + 1], pt[4 * (size_t)p + 2], pt[4 * (size_t)p + 3]);
-                        in = (r <= maxThreshold);
+                // four batches of 256 matches per trip: the point loads (global memory, 32 bytes per match) of all four are in
+                // flight before the first residual is needed
+                for (uint32_t base = 0; base < m; base += 1024) {
+                    double r[4]; bool in[4];
+                    double px[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t p = base + 256u * (uint32_t)u + tid;
+                        const size_t pp = 4 * (size_t)(p < m ? p : 0u);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) px[u][e] = pt[pp + e];
                     }
-                    const unsigned long long bal = __ballot(in);
-                    if (bal != 0ull) {
-                        const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                    unsigned long long bal[4];
+                    uint32_t n_new = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t p = base + 256u * (uint32_t)u + tid;
+                        r[u] = (KIND == 0) ? sym_epipolar_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
+                             : (KIND == 1) ? h_asym_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
+                                           : epipolar_dist_err(FE, px[u][0], px[u][1], px[u][2], px[u][3]);
+                        in[u] = (p < m) && (r[u] <= maxThreshold);
+                        bal[u] = __ballot(in[u]);
+                        n_new += (uint32_t)__builtin_popcountll(bal[u]);
+                    }
+                    if (n_new != 0u) {
                         uint32_t woff = 0;
-                        if (lane == (uint32_t)__builtin_ctzll(bal)) woff = atomicAdd(&S.cnt, (uint32_t)__builtin_popcountll(bal));
-                        woff = (uint32_t)__shfl((int)woff, __builtin_ctzll(bal));
-                        FCHECK(woff + before < m || !in, 3, woff + before, m);
-                        if (in) {
-                            keys[woff + before] = (unsigned long long)__double_as_longlong(r); sidx[woff + before] = p;
-                            long long bin = (__double_as_longlong(r) >> kHistShift) - hist_base;
-                            bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
-                            atomicAdd(&hist[bin], 1u);
+                        if (lane == 0) woff = atomicAdd(&S.cnt, n_new);
+                        woff = (uint32_t)__builtin_amdgcn_readfirstlane((int)woff);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t pos = woff + (uint32_t)__builtin_popcountll(bal[u] & ((1ull << lane) - 1ull));
+                            FCHECK(pos < m || !in[u], 3, pos, m);
+                            if (in[u]) {
+                                keys[pos] = (unsigned long long)__double_as_longlong(r[u]); sidx[pos] = base + 256u * (uint32_t)u + tid;
+                                long long bin = (__double_as_longlong(r[u]) >> kHistShift) - hist_base;
+                                bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
+                                atomicAdd(&hist[bin], 1u);
+                            }
+                            woff += (uint32_t)__builtin_popcountll(bal[u]);
                         }
                     }
                 }
