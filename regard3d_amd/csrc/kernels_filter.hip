@@ -647,7 +647,10 @@ struct FState {
     uint32_t nm[64];
     uint32_t dbg_smp[64];    // debug trace: first sample index of each hypothesis of the chunk
     uint32_t dbg_pool;       // debug trace: pool size the chunk was drawn from
+    double   kinv[18];       // essential matrix: K1^-1, K2^-1 of the pair (read from here at their two use sites: 36 wave-uniform
+                             // doubles held in scalar registers for the whole kernel were most of its SGPR spills)
 };
+static_assert(sizeof(FState) <= 1024, "FState must fit the first 1024 bytes of the dynamic LDS region");
 
 constexpr int kChunk = 64;
 // residual histogram of the model under evaluation (the sort-skipping bound below): 2^kHistSub bins per octave of the residual,
@@ -857,9 +860,9 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     const double s2 = (KIND == 2) ? 1.0 : 1.0 / sqrt((double)(wJ * hJ));
     const double t1x = (KIND == 2) ? 0.0 : -0.5 * wI * s1, t1y = (KIND == 2) ? 0.0 : -0.5 * hI * s1;
     const double t2x = (KIND == 2) ? 0.0 : -0.5 * wJ * s2, t2y = (KIND == 2) ? 0.0 : -0.5 * hJ * s2;
-    double K1i[9], K2i[9];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) { K1i[e] = (KIND == 2) ? P.kinv[9 * (size_t)sl.x + e] : 0.0; K2i[e] = (KIND == 2) ? P.kinv[9 * (size_t)sl.y + e] : 0.0; }
+    const double* K1i = S.kinv;
+    const double* K2i = S.kinv + 9;
+    if (KIND == 2 && tid < 18) S.kinv[tid] = P.kinv[9 * (size_t)(tid < 9 ? sl.x : sl.y) + (tid < 9 ? tid : tid - 9)];
     for (uint32_t p = tid; p < m; p += 256) {
         const r3dm_match q = mm[p];
         const double xi = (double)Ip->xy[2 * (size_t)q.i], yi = (double)Ip->xy[2 * (size_t)q.i + 1];
