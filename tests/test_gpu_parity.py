@@ -483,3 +483,34 @@ def test_filters_skip_no_model_that_could_win(ctx):
             z = np.load(d + "/" + name + ".npz")
             for k, ref in zip(("pairs", "offsets", "matches", "models", "report"), prod[name]):
                 assert np.array_equal(z[k], ref), (name, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["F", "H"])
+def test_filters_without_a_residual_bound(ctx, oracle, kind):
+    """max_residual_px = inf (ACRANSAC's default precision): a contrario mode from the first model, every residual is kept and
+    sorted -- the residual histogram of the sort-skipping bound then works with its clamped top bin.  Same inlier sets as the oracle."""
+    sc = synth.make_scene(5, 1200, "sift", seed=909)
+    ctx.clear_images()
+    for i in range(sc.n_images):
+        ctx.set_image(i, sc.descs[i], sc.xys[i], int(sc.widths[i]), int(sc.heights[i]))
+    g = ctx.match_pairs(sc.exhaustive_pairs(), 0.6, True)
+    gp, go, gm = g.pairs, g.offsets, g.matches
+    counts = np.diff(go.astype(np.int64)).astype(np.uint32)
+    inf = float("inf")
+    if kind == "F":
+        got = ctx.filter_F(g, inf, 512, seed=77).as_dict()
+        oc, om = oracle.filter_F_collection(sc.xys, sc.widths, sc.heights, gp, counts, gm, inf, 512, 77)
+    else:
+        got = ctx.filter_H(g, inf, 512, seed=77).as_dict()
+        oc, om = oracle.filter_H_collection(sc.xys, sc.widths, sc.heights, gp, counts, gm, inf, 512, 77)
+    off = 0; kept = 0
+    for p, (I, J) in enumerate(gp):
+        key = (int(I), int(J))
+        exp = om[off:off + oc[p]]; off += oc[p]
+        if oc[p]:
+            assert key in got and set(map(tuple, got[key].tolist())) == set(map(tuple, exp.tolist())), key
+            kept += 1
+        else:
+            assert key not in got
+    assert kept >= (6 if kind == "F" else 0)
