@@ -345,6 +345,8 @@ typedef struct {
     uint64_t n_views_staged;       /* views / datasets / query sets copied + re-laid-out by this context since r3dm_create */
     uint64_t n_hamming_mfma;       /* launches of the Hamming matcher that ran as the MFMA formulation */
     uint64_t n_ak_graph_replays;   /* r3dm_detect_akaze calls whose scale space ran as one hipGraph launch (since r3dm_create) */
+    uint64_t n_ann_rows16;         /* graph-search launches that gathered the bf16 row copy (integer-valued views: same distances, half the bytes) */
+    uint64_t n_ann_rows8;          /* ... the u8 row copy (integers 0 .. 255: a quarter of the bytes)                                          */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -108,7 +108,7 @@ int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_
     d.n = h.n; d.n_tiles = h.n_tiles; d.dim = h.dim; d.G = h.G; d.words = h.words;
     d.width = h.width; d.height = h.height;
     d.max_norm_bits = stat_bits3 ? stat_bits3[0] : 0; d.max_abs_bits = stat_bits3 ? stat_bits3[1] : 0; d.not_integer = stat_bits3 ? stat_bits3[2] : 0;
-    d.ann_adj = nullptr; d.ann_deg = nullptr;          // staging invalidates the graph index
+    d.ann_adj = nullptr; d.ann_deg = nullptr; d.ann_rows16 = nullptr; d.ann_rows8 = nullptr;          // staging invalidates the graph index
     d.tiled16 = h.tiled16.as<uint16_t>();
     d.tiledh = h.tiledh.as<uint16_t>(); d.split_k = split_k;
     d.tiled8 = h.tiled8.as<uint8_t>();

@@ -4,6 +4,7 @@
 // /root/reference/src/R3DComputeMatches.cpp:2035-2129 and src/Regard3DFeatures.cpp -- with every arithmetic stage running as
 // HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
 #include "r3dm_ctx.hpp"
+#include <cstddef>
 
 // ------------------------------------------------------------------------------------------------
 // putative matching
@@ -482,6 +483,19 @@ static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t
             j.rev_off = (uint32_t*)cur; cur += (size_t)h.n * 4 + 64;
             j.adj = h.ann_adj.as<uint32_t>(); j.deg = h.ann_deg.as<uint32_t>();
             jobs.push_back(j);
+            // bf16 copy of the rows for the search's gathers (ImgDev::ann_rows16): views whose every element is a bf16
+            // compact copy of the rows for the search's gathers: bytes for integers 0 .. 255 (ImgDev::ann_rows8), bf16 for other
+            // integers of magnitude <= 256 (ImgDev::ann_rows16); R3DM_ANN_ROWS16 (developer build): 0 = neither, 1 = bf16 only
+            const int compact = r3dm_dev_knob("R3DM_ANN_ROWS16", 2);
+            const bool ints = h.dtype != R3DM_BIN && !h.not_integer;
+            h.ann_rows16.release(); h.ann_rows8.release();
+            if (ints && !h.has_negative && h.max_abs <= 255.0f && (h.dim & 15u) == 0 && compact >= 2) {
+                R3DM_HIP(c, h.ann_rows8.ensure((size_t)h.n * h.dim + kSlackBytes));
+                R3DM_HIP(c, launch_ann_rows8(c->stream, h.rows.as<float>(), h.ann_rows8.as<uint8_t>(), (size_t)h.n * h.dim));
+            } else if (ints && h.max_abs <= 256.0f && (h.dim & 7u) == 0 && compact >= 1) {
+                R3DM_HIP(c, h.ann_rows16.ensure((size_t)h.n * h.dim * 2 + kSlackBytes));
+                R3DM_HIP(c, launch_ann_rows16(c->stream, h.rows.as<float>(), h.ann_rows16.as<uint16_t>(), (size_t)h.n * h.dim));
+            }
         }
         R3DM_HIP(c, c->a_jobs.ensure(jobs.size() * sizeof(AnnBuildJob)));
         R3DM_HIP(c, hipMemcpyAsync(c->a_jobs.p, jobs.data(), jobs.size() * sizeof(AnnBuildJob), hipMemcpyHostToDevice, c->stream));
@@ -490,11 +504,15 @@ static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t
         hipError_t e = launch_ann_build(c->stream, bp, (uint32_t)jobs.size(), max_n, dim);
         if (e == hipErrorInvalidValue) { c->err = "no graph-index kernel for this descriptor length (dim % 4 != 0 or too long)"; return R3DM_ERR_UNSUPPORTED; }
         R3DM_HIP(c, e);
-        std::vector<const void*> ptrs(2 * (end - start));      // must outlive the asynchronous copies
+        static_assert(offsetof(ImgDev, ann_deg) == offsetof(ImgDev, ann_adj) + sizeof(void*) &&
+                      offsetof(ImgDev, ann_rows16) == offsetof(ImgDev, ann_adj) + 2 * sizeof(void*) &&
+                      offsetof(ImgDev, ann_rows8) == offsetof(ImgDev, ann_adj) + 3 * sizeof(void*), "index pointers are set with one copy");
+        std::vector<const void*> ptrs(4 * (end - start));      // must outlive the asynchronous copies
         for (size_t k = start; k < end; ++k) {
             HostImage& h = *c->imgs[todo[k]];
-            ptrs[2 * (k - start)] = h.ann_adj.p; ptrs[2 * (k - start) + 1] = h.ann_deg.p;
-            R3DM_HIP(c, hipMemcpyAsync((void*)&(c->d_imgs.as<ImgDev>() + todo[k])->ann_adj, &ptrs[2 * (k - start)], 2 * sizeof(void*),
+            const void** q = &ptrs[4 * (k - start)];
+            q[0] = h.ann_adj.p; q[1] = h.ann_deg.p; q[2] = h.ann_rows16.p; q[3] = h.ann_rows8.p;
+            R3DM_HIP(c, hipMemcpyAsync((void*)&(c->d_imgs.as<ImgDev>() + todo[k])->ann_adj, q, 4 * sizeof(void*),
                                        hipMemcpyHostToDevice, c->stream));
             h.ann_K = K;
         }
@@ -549,7 +567,9 @@ static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ra
     sp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
     sp.n_comps = reinterpret_cast<unsigned long long*>(c->d_cnt.as<uint32_t>() + 4);
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
-    hipError_t e = launch_ann_search(c->stream, sp, max_nJ, max_nI, dim);
+    bool rows16 = true, rows8 = true;                     // every indexed view of the batch holds that compact row copy
+    for (const PairJob& j : jobs) { rows16 = rows16 && c->imgs[j.sI]->ann_rows16.p != nullptr; rows8 = rows8 && c->imgs[j.sI]->ann_rows8.p != nullptr; }
+    hipError_t e = launch_ann_search(c->stream, sp, max_nJ, max_nI, dim, rows8 ? 2 : (rows16 ? 1 : 0));
     if (e == hipErrorInvalidValue) { c->err = "graph search: unsupported descriptor length / view size / parameters"; return R3DM_ERR_UNSUPPORTED; }
     R3DM_HIP(c, e);
     R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -564,6 +584,9 @@ static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ra
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_ann_search += ms;
     c->stats.n_ann_dist += comps;
+    c->stats.n_ann_rows16 += (rows16 && !rows8) ? 1 : 0;
+    c->stats.n_ann_rows8 += rows8 ? 1 : 0;
+    c->stats.n_match_launches += 1;
     c->stats.n_pairs += P;
     c->stats.n_queries += n_queries;
     return R3DM_OK;
@@ -669,7 +692,9 @@ static int r3dm_kgraph_knn2_impl(r3dm_ctx* c, const float* dataset, uint32_t n_d
             if (rc == R3DM_OK) rc = run_ann_batch(c, jobs, 1.0f, *kp, nullptr, out_idx, out_dist);
         }
     }
+    const uint64_t r16 = c->stats.n_ann_rows16 - keep.n_ann_rows16, r8 = c->stats.n_ann_rows8 - keep.n_ann_rows8, evals = c->stats.n_ann_dist - keep.n_ann_dist;
     c->stats = keep;
+    c->stats.n_ann_rows16 = r16; c->stats.n_ann_rows8 = r8; c->stats.n_ann_dist = evals;   // like r3dm_knn2: which rows this call gathered, how many evaluations
     (void)hipStreamSynchronize(c->stream);
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
     c->imgs.pop_back(); c->imgs.pop_back();

@@ -20,6 +20,7 @@
 namespace r3dm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) float* cf32p;        // constant address space -> SMEM loads
 
 namespace {
@@ -240,8 +241,11 @@ void ann_merge_kernel(const AnnBuildParams P)
 // ------------------------------------------------------------------------------------------------
 // search: one wavefront per query row of J against the index of I
 // ------------------------------------------------------------------------------------------------
-template <int NQ>
-__global__ __launch_bounds__(256)
+// ROWS 1 / 2: the rows of I are gathered from their bf16 / u8 copy (ImgDev::ann_rows16 / ann_rows8: every element IS a bf16 /
+// a byte, so the f32 values -- and with them every distance, in the same operation order -- are those of the f32 rows at a half /
+// a quarter of the bytes per gather; a 128-dimensional u8 row is one 128-byte line).
+template <int NQ, int ROWS>
+__global__ __launch_bounds__(256)                          // (capping the registers at 64 for eight waves per SIMD measured no gain: 1,746 vs 1,780 pairs/s on C5)
 void ann_search_kernel(const AnnSearchParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ann_smem[];
@@ -259,6 +263,8 @@ void ann_search_kernel(const AnnSearchParams P)
     const uint32_t sub = lane & 3u, grp = lane >> 2;
     const uint32_t g_lo = sub * NQ;
     const float* __restrict__ rowsI = Ip->rows;
+    const uint16_t* __restrict__ rows16 = Ip->ann_rows16;
+    const uint8_t* __restrict__ rows8 = Ip->ann_rows8;
     const uint32_t* __restrict__ adj = Ip->ann_adj;
     const uint32_t* __restrict__ deg = Ip->ann_deg;
 
@@ -314,10 +320,41 @@ void ann_search_kernel(const AnnSearchParams P)
         float r = 0.0f;
         uint32_t cdeg = 0;
         if (fresh) {
-            const f32x4* a = (const f32x4*)(rowsI + (size_t)cid * dim) + g_lo;
             float gs[NQ];
+            if constexpr (ROWS == 2) {
+                static_assert(NQ % 4 == 0, "u8 rows are read 16 elements (four groups) at a time");
+                const u32x4* a8 = (const u32x4*)(rows8 + (size_t)cid * dim) + (g_lo >> 2);
 #pragma unroll
-            for (int g = 0; g < NQ; ++g) gs[g] = (g_lo + g < g4) ? group_sq(a[g], qv[g]) : 0.0f;
+                for (int g4i = 0; g4i < NQ / 4; ++g4i) {
+                    if (g_lo + 4 * g4i < g4) {                                 // dim % 16 == 0: groups come in fours
+                        const u32x4 w = a8[g4i];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 v = {(float)(w[k] & 0xFFu), (float)((w[k] >> 8) & 0xFFu), (float)((w[k] >> 16) & 0xFFu), (float)(w[k] >> 24)};
+                            gs[4 * g4i + k] = group_sq(v, qv[4 * g4i + k]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) gs[4 * g4i + k] = 0.0f;
+                    }
+                }
+            } else if constexpr (ROWS == 1) {
+                static_assert(NQ % 2 == 0, "bf16 rows are read 8 elements (two groups) at a time");
+                const u32x4* a16 = (const u32x4*)(rows16 + (size_t)cid * dim) + (g_lo >> 1);
+#pragma unroll
+                for (int g2 = 0; g2 < NQ / 2; ++g2) {
+                    if (g_lo + 2 * g2 < g4) {                                  // dim % 8 == 0: groups come in pairs
+                        const u32x4 w = a16[g2];
+                        const f32x4 lo4 = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u)};
+                        const f32x4 hi4 = {__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xFFFF0000u), __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xFFFF0000u)};
+                        gs[2 * g2] = group_sq(lo4, qv[2 * g2]); gs[2 * g2 + 1] = group_sq(hi4, qv[2 * g2 + 1]);
+                    } else { gs[2 * g2] = 0.0f; gs[2 * g2 + 1] = 0.0f; }
+                }
+            } else {
+                const f32x4* a = (const f32x4*)(rowsI + (size_t)cid * dim) + g_lo;
+#pragma unroll
+                for (int g = 0; g < NQ; ++g) gs[g] = (g_lo + g < g4) ? group_sq(a[g], qv[g]) : 0.0f;
+            }
             cdeg = deg[cid];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -395,7 +432,37 @@ hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_
     return hipGetLastError();
 }
 
-hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& Pin, uint32_t max_nJ, uint32_t max_nI, uint32_t dim)
+__global__ __launch_bounds__(256)
+void ann_rows16_kernel(const float* __restrict__ rows, uint16_t* __restrict__ rows16, size_t n_elems)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (size_t)gridDim.x * 256)
+        rows16[i] = (uint16_t)(__float_as_uint(rows[i]) >> 16);                // exact: the caller checked that every element is a bf16
+}
+
+hipError_t launch_ann_rows16(hipStream_t st, const float* rows, uint16_t* rows16, size_t n_elems)
+{
+    if (n_elems == 0) return hipSuccess;
+    const size_t blocks = std::min<size_t>((n_elems + 255) / 256, 8192);
+    hipLaunchKernelGGL(ann_rows16_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, rows, rows16, n_elems);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256)
+void ann_rows8_kernel(const float* __restrict__ rows, uint8_t* __restrict__ rows8, size_t n_elems)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (size_t)gridDim.x * 256)
+        rows8[i] = (uint8_t)rows[i];                                           // exact: the caller checked that every element is an integer in 0 .. 255
+}
+
+hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, size_t n_elems)
+{
+    if (n_elems == 0) return hipSuccess;
+    const size_t blocks = std::min<size_t>((n_elems + 255) / 256, 8192);
+    hipLaunchKernelGGL(ann_rows8_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, rows, rows8, n_elems);
+    return hipGetLastError();
+}
+
+hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& Pin, uint32_t max_nJ, uint32_t max_nI, uint32_t dim, int rows_mode)
 {
     AnnSearchParams P = Pin;
     if ((dim & 3u) || P.pool_cap > 63 || P.S < 1 || P.S > 16 || P.P < 2) return hipErrorInvalidValue;
@@ -407,19 +474,34 @@ hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& Pin, uint32_
     if (grid == 0) return hipSuccess;
     if (grid > kMaxBlocksOf256) return hipErrorInvalidValue;
     const uint32_t nq = (dim / 4 + 3) / 4;
-#define R3DM_ANN_LAUNCH(NQ)                                                                                            \
+#define R3DM_ANN_LAUNCH(NQ, ROWS)                                                                                      \
     do {                                                                                                               \
         if (lds > 64 * 1024) {                                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)ann_search_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e = hipFuncSetAttribute((const void*)ann_search_kernel<NQ, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((ann_search_kernel<NQ>), dim3((uint32_t)grid), dim3(256), lds, st, P);                      \
+        hipLaunchKernelGGL((ann_search_kernel<NQ, ROWS>), dim3((uint32_t)grid), dim3(256), lds, st, P);                 \
     } while (0)
-    if (nq <= 4) R3DM_ANN_LAUNCH(4);
-    else if (nq <= 8) R3DM_ANN_LAUNCH(8);
-    else if (nq == 9) R3DM_ANN_LAUNCH(9);
-    else if (nq <= 16) R3DM_ANN_LAUNCH(16);
-    else if (nq <= 32) R3DM_ANN_LAUNCH(32);
+    if (rows_mode == 2 && (dim & 15u) == 0 && nq != 9) {
+        if (nq <= 4) R3DM_ANN_LAUNCH(4, 2);
+        else if (nq <= 8) R3DM_ANN_LAUNCH(8, 2);
+        else if (nq <= 16) R3DM_ANN_LAUNCH(16, 2);
+        else if (nq <= 32) R3DM_ANN_LAUNCH(32, 2);
+        else return hipErrorInvalidValue;
+    }
+    else if (rows_mode == 1 && (dim & 7u) == 0 && nq != 9) {
+        if (nq <= 4) R3DM_ANN_LAUNCH(4, 1);
+        else if (nq <= 8) R3DM_ANN_LAUNCH(8, 1);
+        else if (nq <= 16) R3DM_ANN_LAUNCH(16, 1);
+        else if (nq <= 32) R3DM_ANN_LAUNCH(32, 1);
+        else return hipErrorInvalidValue;
+    }
+    else if (rows_mode != 0) return hipErrorInvalidValue;
+    else if (nq <= 4) R3DM_ANN_LAUNCH(4, 0);
+    else if (nq <= 8) R3DM_ANN_LAUNCH(8, 0);
+    else if (nq == 9) R3DM_ANN_LAUNCH(9, 0);
+    else if (nq <= 16) R3DM_ANN_LAUNCH(16, 0);
+    else if (nq <= 32) R3DM_ANN_LAUNCH(32, 0);
     else return hipErrorInvalidValue;
 #undef R3DM_ANN_LAUNCH
     return hipGetLastError();

@@ -55,6 +55,13 @@ struct ImgDev {
     // graph index of the view (kernels_ann.hip), nullptr until r3dm_match_pairs_kgraph builds it
     const uint32_t* ann_adj;   // [n][kAnnDeg] neighbour rows ordered by (distance, id), kNone padded
     const uint32_t* ann_deg;   // [n] valid entries of each adjacency row
+    // part of the index: the rows once more as bf16 ([n][dim], row-major) when every element is a bf16 (integers of magnitude
+    // <= 256: SIFT bins), else nullptr.  The graph search is bound by its row gathers; this halves their bytes and converts back to
+    // the SAME f32 values, so the search computes exactly what it computes on `rows`.  (Keep the three pointers adjacent: one copy sets them.)
+    const uint16_t* ann_rows16;
+    // ... or as bytes ([n][dim] u8) when every element is an integer in 0 .. 255 (what SIFT descriptors are on disk): one 128-byte
+    // line per 128-dimensional row.  A view has at most one of the two copies.
+    const uint8_t* ann_rows8;
     // bf16 fragment-order tiles for the integer fast path (r3dm_set_integer_mfma): [n_tiles][G/2][2][32][8] bf16,
     // lane half h of 16-dim block kb holds dims 16 kb + 8 h .. + 7 of row 32 t + r.  Exact iff the view is
     // integer-valued with |x| <= 256 (every such value is a bf16); the kernel checks that itself.
@@ -250,7 +257,10 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
 size_t     filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim);
-hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim);
+// rows_mode: 0 = f32 rows, 1 = ImgDev::ann_rows16 (bf16), 2 = ImgDev::ann_rows8 (u8) -- every indexed view of the batch must hold that copy
+hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim, int rows_mode);
+hipError_t launch_ann_rows16(hipStream_t st, const float* rows, uint16_t* rows16, size_t n_elems);
+hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, size_t n_elems);
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
                                uint32_t n, float* patches);
 hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,

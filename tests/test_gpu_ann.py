@@ -103,6 +103,8 @@ def test_collection_equals_the_cpu_model_and_recovers_the_exhaustive_matches(ctx
     _check_graph(g, pairs, counts, matches)
     st = ctx.stats()
     assert st.n_ann_dist > 0 and st.n_ann_built == 3                  # views 0, 1, 2 are first views of an indexed pair
+    # rows of integers 0 .. 255 are gathered from their u8 copy (same f32 values, a quarter of the bytes), real-valued ones from the f32 rows
+    assert (st.n_ann_rows8 > 0) == (kind == "sift") and st.n_ann_rows8 <= st.n_match_launches and st.n_ann_rows16 == 0
     assert st.n_ann_dist < 0.5 * sum(len(sc.descs[i]) * len(sc.descs[j]) for i, j in pairs)
     # against the exhaustive matcher: most matches recovered, few spurious
     bc, bm = oracle.match_collection(sc.descs, sc.xys, pairs, 0.6, True)
@@ -139,3 +141,38 @@ def test_kgraph_rejects_what_it_cannot_do(ctx):
     with pytest.raises(api.R3dmError):
         ctx.kgraph_knn2(rng.normal(size=(300, 32)).astype(np.float32), rng.normal(size=(10, 32)).astype(np.float32),
                         api.KGraphParams(index_K=64, search_P=10, search_S=10, seed=1))
+
+
+@pytest.mark.parametrize("negative", [False, True])
+def test_compact_row_copies_change_nothing(ctx, negative):
+    """The graph search on the u8 / bf16 row copy of integer-valued views (ImgDev::ann_rows8: integers 0 .. 255; ann_rows16: other
+    integers of magnitude <= 256) against the developer build told to keep the f32 rows (R3DM_ANN_ROWS16=0): identical 2-NN indices,
+    distances and evaluation counts."""
+    import os, subprocess, sys, tempfile, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sc = synth.make_scene(2, 3000, "sift", seed=88)
+    A, B = sc.descs[0].astype(np.float32), sc.descs[1].astype(np.float32)
+    if negative: A[5, 7] = -3.0                                # negative integers are bf16 values, not bytes
+    kp = api.KGraphParams.preset("default")
+    idx, dist = ctx.kgraph_knn2(A, B, kp, pair=(1, 2))
+    st = ctx.stats()
+    assert (st.n_ann_rows16, st.n_ann_rows8) == ((1, 0) if negative else (0, 1))
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {root!r})
+        import numpy as np
+        from regard3d_amd import api, synth
+        api.use_developer_library()
+        sc = synth.make_scene(2, 3000, "sift", seed=88)
+        A, B = sc.descs[0].astype(np.float32), sc.descs[1].astype(np.float32)
+        if {negative!r}: A[5, 7] = -3.0
+        c = api.Context(0)
+        idx, dist = c.kgraph_knn2(A, B, api.KGraphParams.preset("default"), pair=(1, 2))
+        assert c.stats().n_ann_rows16 == 0 and c.stats().n_ann_rows8 == 0
+        np.savez(sys.argv[1], idx=idx, dist=dist, evals=np.array([c.stats().n_ann_dist]))
+    """)
+    n_evals = st.n_ann_dist
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([sys.executable, "-c", code, d + "/f32.npz"], env=dict(os.environ, R3DM_ANN_ROWS16="0"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        z = np.load(d + "/f32.npz")
+    assert np.array_equal(z["idx"], idx) and np.array_equal(z["dist"], dist) and int(z["evals"][0]) == n_evals
