@@ -155,7 +155,7 @@ def main():
         acc["launches"] += s_match.n_match_launches; acc["filter_ms"] += s_all.ms_filter_kernels
         acc["fallback"] += s_match.n_exact_fallback; acc["queries"] += s_match.n_queries
         acc["ann_ms"] += s_match.ms_ann_search; acc["ann_dist"] += s_match.n_ann_dist; acc["ann_build_ms"] += s_match.ms_ann_build
-        acc["ann_rows16"] = acc.get("ann_rows16", 0) + int(s_match.n_ann_rows16); acc["ann_rows8"] = acc.get("ann_rows8", 0) + int(s_match.n_ann_rows8); acc["ann_launches"] = acc.get("ann_launches", 0) + int(s_match.n_match_launches)
+        acc["ann_rows16"] = acc.get("ann_rows16", 0) + int(s_match.n_ann_rows16); acc["ann_rows8"] = acc.get("ann_rows8", 0) + int(s_match.n_ann_rows8); acc["ann_dot8"] = acc.get("ann_dot8", 0) + int(s_match.n_ann_dot8); acc["ann_launches"] = acc.get("ann_launches", 0) + int(s_match.n_match_launches)
         wall["match"] += s_all.ms_wall_match; wall["match_post"] += s_all.ms_wall_match_post; wall["filter"] += s_all.ms_wall_filter
     fence()
     elapsed = time.perf_counter() - t0
@@ -225,7 +225,7 @@ def roofline(name, cfg, acc, dim, world):
         row_bytes = dim * (1.0 if rows8 else 2.0 if rows16 else 4.0)
         bytes_ = acc["ann_dist"] * row_bytes
         gbs = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "ann_search_kernel<u8 rows>" if rows8 else "ann_search_kernel<bf16 rows>" if rows16 else "ann_search_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"bound": "hbm", "kernel": ("ann_search_kernel<u8 rows, v_dot4>" if acc.get("ann_dot8", 0) == acc.get("ann_launches", -1) else "ann_search_kernel<u8 rows>") if rows8 else "ann_search_kernel<bf16 rows>" if rows16 else "ann_search_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                 "note": "algorithmic bytes = distance evaluations x row bytes (%d B gathers, mostly L2 / Infinity-Cache resident: "
                         "the HBM spec is the stated roof, not what these gathers can reach)" % int(row_bytes),

@@ -347,6 +347,7 @@ typedef struct {
     uint64_t n_ak_graph_replays;   /* r3dm_detect_akaze calls whose scale space ran as one hipGraph launch (since r3dm_create) */
     uint64_t n_ann_rows16;         /* graph-search launches that gathered the bf16 row copy (integer-valued views: same distances, half the bytes) */
     uint64_t n_ann_rows8;          /* ... the u8 row copy (integers 0 .. 255: a quarter of the bytes)                                          */
+    uint64_t n_ann_dot8;           /* ... of those, launches whose query views are bytes too: distances as exact integer dot products (v_dot4_u32_u8) */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -45,7 +45,7 @@ class Stats(C.Structure):
                 ("ms_ann_build", C.c_double), ("ms_ann_search", C.c_double), ("n_ann_built", C.c_uint64),
                 ("n_ann_dist", C.c_uint64), ("ms_detect", C.c_double), ("n_integer_mfma", C.c_uint64),
                 ("n_split_mfma", C.c_uint64), ("n_views_staged", C.c_uint64),
-                ("n_hamming_mfma", C.c_uint64), ("n_ak_graph_replays", C.c_uint64), ("n_ann_rows16", C.c_uint64), ("n_ann_rows8", C.c_uint64)]
+                ("n_hamming_mfma", C.c_uint64), ("n_ak_graph_replays", C.c_uint64), ("n_ann_rows16", C.c_uint64), ("n_ann_rows8", C.c_uint64), ("n_ann_dot8", C.c_uint64)]
 
 
 class KGraphParams(C.Structure):

@@ -124,7 +124,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
     HostImage& h = *c->imgs[slot];
     h.view_id = view_id; h.n = n; h.dim = dim; h.dtype = dtype; h.width = width; h.height = height;
     h.has_xy = (xy != nullptr); h.has_dup = false; h.live = true;
-    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0;
+    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0; h.compact_ready = false;
     if (dtype == R3DM_BIN) {
         h.words = (dim + 3) / 4;
         const uint32_t n_pad = n + 8;

@@ -444,6 +444,47 @@ static int check_kgraph_params(r3dm_ctx* c, const r3dm_kgraph_params* kp)
     return R3DM_OK;
 }
 
+// compact copy of a view's rows for the search's gathers: bytes for integers 0 .. 255 (ImgDev::ann_rows8), bf16 for other integers
+// of magnitude <= 256 (ImgDev::ann_rows16), nothing otherwise.  R3DM_ANN_ROWS16 (developer build): 0 = never, 1 = bf16 only,
+// 2 = bytes too, 3 (the product) = and integer dot products when both views of every pair are bytes.
+static int stage_compact_rows(r3dm_ctx* c, HostImage& h)
+{
+    const int compact = r3dm_dev_knob("R3DM_ANN_ROWS16", 3);
+    const bool ints = h.dtype != R3DM_BIN && !h.not_integer;
+    h.ann_rows16.release(); h.ann_rows8.release();
+    if (ints && !h.has_negative && h.max_abs <= 255.0f && (h.dim & 15u) == 0 && compact >= 2) {
+        R3DM_HIP(c, h.ann_rows8.ensure((size_t)h.n * h.dim + kSlackBytes));
+        R3DM_HIP(c, launch_ann_rows8(c->stream, h.rows.as<float>(), h.ann_rows8.as<uint8_t>(), (size_t)h.n * h.dim));
+    } else if (ints && h.max_abs <= 256.0f && (h.dim & 7u) == 0 && compact >= 1) {
+        R3DM_HIP(c, h.ann_rows16.ensure((size_t)h.n * h.dim * 2 + kSlackBytes));
+        R3DM_HIP(c, launch_ann_rows16(c->stream, h.rows.as<float>(), h.ann_rows16.as<uint16_t>(), (size_t)h.n * h.dim));
+    }
+    h.compact_ready = true;
+    return R3DM_OK;
+}
+
+// the query side of the integer-dot-product search: views that are only ever J hold no index, but may hold the byte copy
+static int ensure_compact_rows(r3dm_ctx* c, std::vector<uint32_t> slots)
+{
+    std::sort(slots.begin(), slots.end());
+    slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+    std::vector<const void*> ptrs;
+    ptrs.reserve(2 * slots.size());                          // must outlive the asynchronous copies: no reallocation below
+    bool any = false;
+    for (uint32_t s : slots) {
+        HostImage& h = *c->imgs[s];
+        if (h.compact_ready) continue;
+        int rc = stage_compact_rows(c, h);
+        if (rc != R3DM_OK) return rc;
+        ptrs.push_back(h.ann_rows16.p); ptrs.push_back(h.ann_rows8.p);
+        R3DM_HIP(c, hipMemcpyAsync((void*)&(c->d_imgs.as<ImgDev>() + s)->ann_rows16, &ptrs[ptrs.size() - 2], 2 * sizeof(void*),
+                                   hipMemcpyHostToDevice, c->stream));
+        any = true;
+    }
+    if (any) R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    return R3DM_OK;
+}
+
 // builds the graph index of every listed slot that does not hold one for this K
 static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t K)
 {
@@ -484,18 +525,7 @@ static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t
             j.adj = h.ann_adj.as<uint32_t>(); j.deg = h.ann_deg.as<uint32_t>();
             jobs.push_back(j);
             // bf16 copy of the rows for the search's gathers (ImgDev::ann_rows16): views whose every element is a bf16
-            // compact copy of the rows for the search's gathers: bytes for integers 0 .. 255 (ImgDev::ann_rows8), bf16 for other
-            // integers of magnitude <= 256 (ImgDev::ann_rows16); R3DM_ANN_ROWS16 (developer build): 0 = neither, 1 = bf16 only
-            const int compact = r3dm_dev_knob("R3DM_ANN_ROWS16", 2);
-            const bool ints = h.dtype != R3DM_BIN && !h.not_integer;
-            h.ann_rows16.release(); h.ann_rows8.release();
-            if (ints && !h.has_negative && h.max_abs <= 255.0f && (h.dim & 15u) == 0 && compact >= 2) {
-                R3DM_HIP(c, h.ann_rows8.ensure((size_t)h.n * h.dim + kSlackBytes));
-                R3DM_HIP(c, launch_ann_rows8(c->stream, h.rows.as<float>(), h.ann_rows8.as<uint8_t>(), (size_t)h.n * h.dim));
-            } else if (ints && h.max_abs <= 256.0f && (h.dim & 7u) == 0 && compact >= 1) {
-                R3DM_HIP(c, h.ann_rows16.ensure((size_t)h.n * h.dim * 2 + kSlackBytes));
-                R3DM_HIP(c, launch_ann_rows16(c->stream, h.rows.as<float>(), h.ann_rows16.as<uint16_t>(), (size_t)h.n * h.dim));
-            }
+            if (!h.compact_ready) { const int rcc = stage_compact_rows(c, h); if (rcc != R3DM_OK) return rcc; }
         }
         R3DM_HIP(c, c->a_jobs.ensure(jobs.size() * sizeof(AnnBuildJob)));
         R3DM_HIP(c, hipMemcpyAsync(c->a_jobs.p, jobs.data(), jobs.size() * sizeof(AnnBuildJob), hipMemcpyHostToDevice, c->stream));
@@ -567,9 +597,16 @@ static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ra
     sp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
     sp.n_comps = reinterpret_cast<unsigned long long*>(c->d_cnt.as<uint32_t>() + 4);
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
-    bool rows16 = true, rows8 = true;                     // every indexed view of the batch holds that compact row copy
-    for (const PairJob& j : jobs) { rows16 = rows16 && c->imgs[j.sI]->ann_rows16.p != nullptr; rows8 = rows8 && c->imgs[j.sI]->ann_rows8.p != nullptr; }
-    hipError_t e = launch_ann_search(c->stream, sp, max_nJ, max_nI, dim, rows8 ? 2 : (rows16 ? 1 : 0));
+    bool rows16 = true, rows8 = true, dot8 = r3dm_dev_knob("R3DM_ANN_ROWS16", 3) >= 3;   // every indexed view of the batch holds that compact row copy
+    for (const PairJob& j : jobs) {
+        const HostImage& A = *c->imgs[j.sI];
+        const HostImage& B = *c->imgs[j.sJ];
+        rows16 = rows16 && A.compact_ready && A.ann_rows16.p != nullptr;
+        rows8 = rows8 && A.compact_ready && A.ann_rows8.p != nullptr;
+        dot8 = dot8 && B.compact_ready && B.ann_rows8.p != nullptr;        // ... and every query view its byte copy
+    }
+    dot8 = dot8 && rows8 && dim <= 256 && (dim & 15u) == 0;
+    hipError_t e = launch_ann_search(c->stream, sp, max_nJ, max_nI, dim, dot8 ? 3 : rows8 ? 2 : (rows16 ? 1 : 0));
     if (e == hipErrorInvalidValue) { c->err = "graph search: unsupported descriptor length / view size / parameters"; return R3DM_ERR_UNSUPPORTED; }
     R3DM_HIP(c, e);
     R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -586,6 +623,7 @@ static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ra
     c->stats.n_ann_dist += comps;
     c->stats.n_ann_rows16 += (rows16 && !rows8) ? 1 : 0;
     c->stats.n_ann_rows8 += rows8 ? 1 : 0;
+    c->stats.n_ann_dot8 += dot8 ? 1 : 0;
     c->stats.n_match_launches += 1;
     c->stats.n_pairs += P;
     c->stats.n_queries += n_queries;
@@ -626,6 +664,10 @@ static int r3dm_match_pairs_kgraph_impl(r3dm_ctx* c, const uint32_t* pairs_ij, u
         std::vector<uint32_t> slots;
         for (const PairJob& j : ann_jobs) slots.push_back(j.sI);
         rc = ensure_ann_indices(c, slots, kp->index_K);
+        if (rc != R3DM_OK) return rc;
+        slots.clear();
+        for (const PairJob& j : ann_jobs) slots.push_back(j.sJ);
+        rc = ensure_compact_rows(c, slots);
         if (rc != R3DM_OK) return rc;
     }
     size_t start = 0;
@@ -689,12 +731,14 @@ static int r3dm_kgraph_knn2_impl(r3dm_ctx* c, const float* dataset, uint32_t n_d
         if (n_dataset < kAnnMinRows || kp->search_P >= n_dataset) rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
         else {
             rc = ensure_ann_indices(c, {s0}, kp->index_K);
+            if (rc == R3DM_OK) rc = ensure_compact_rows(c, {s0 + 1});
             if (rc == R3DM_OK) rc = run_ann_batch(c, jobs, 1.0f, *kp, nullptr, out_idx, out_dist);
         }
     }
-    const uint64_t r16 = c->stats.n_ann_rows16 - keep.n_ann_rows16, r8 = c->stats.n_ann_rows8 - keep.n_ann_rows8, evals = c->stats.n_ann_dist - keep.n_ann_dist;
+    const uint64_t r16 = c->stats.n_ann_rows16 - keep.n_ann_rows16, r8 = c->stats.n_ann_rows8 - keep.n_ann_rows8, d8 = c->stats.n_ann_dot8 - keep.n_ann_dot8,
+                   evals = c->stats.n_ann_dist - keep.n_ann_dist;
     c->stats = keep;
-    c->stats.n_ann_rows16 = r16; c->stats.n_ann_rows8 = r8; c->stats.n_ann_dist = evals;   // like r3dm_knn2: which rows this call gathered, how many evaluations
+    c->stats.n_ann_rows16 = r16; c->stats.n_ann_rows8 = r8; c->stats.n_ann_dot8 = d8; c->stats.n_ann_dist = evals;   // like r3dm_knn2: which rows this call gathered, how many evaluations
     (void)hipStreamSynchronize(c->stream);
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();
     c->imgs.pop_back(); c->imgs.pop_back();

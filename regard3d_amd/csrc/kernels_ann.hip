@@ -244,6 +244,10 @@ void ann_merge_kernel(const AnnBuildParams P)
 // ROWS 1 / 2: the rows of I are gathered from their bf16 / u8 copy (ImgDev::ann_rows16 / ann_rows8: every element IS a bf16 /
 // a byte, so the f32 values -- and with them every distance, in the same operation order -- are those of the f32 rows at a half /
 // a quarter of the bytes per gather; a 128-dimensional u8 row is one 128-byte line).
+// ROWS 3: the query view holds the byte copy too.  Then every (a - q)^2 and every partial sum of the reference's float accumulation is
+// an integer below 2^24 (D <= 256), i.e. exact in ANY order, and the distance is ||a||^2 - 2 a.q + ||q||^2 from two v_dot4_u32_u8
+// per four dimensions instead of ~6 f32 instructions per dimension -- the kernel is bound by VALU issue (86 % busy, 41 VALU
+// instructions per evaluation on f32 arithmetic: profiles/r02_r_pmc_ann_search.txt), not by its gathers.
 template <int NQ, int ROWS>
 __global__ __launch_bounds__(256)                          // (capping the registers at 64 for eight waves per SIMD measured no gain: 1,746 vs 1,780 pairs/s on C5)
 void ann_search_kernel(const AnnSearchParams P)
@@ -268,8 +272,19 @@ void ann_search_kernel(const AnnSearchParams P)
     const uint32_t* __restrict__ adj = Ip->ann_adj;
     const uint32_t* __restrict__ deg = Ip->ann_deg;
 
-    f32x4 qv[NQ];
-    {
+    f32x4 qv[ROWS == 3 ? 1 : NQ];
+    [[maybe_unused]] uint32_t q8[ROWS == 3 ? NQ : 1];
+    [[maybe_unused]] uint32_t qq_part = 0;                  // this lane's share of ||q||^2
+    if constexpr (ROWS == 3) {
+        static_assert(ROWS != 3 || NQ % 4 == 0, "byte rows are read 16 elements at a time");
+        const u32x4* src = (const u32x4*)(Jp->ann_rows8 + (size_t)q * dim) + (g_lo >> 2);
+#pragma unroll
+        for (int g4i = 0; g4i < NQ / 4; ++g4i) {
+            const u32x4 w = (g_lo + 4 * g4i < g4) ? src[g4i] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { q8[4 * g4i + k] = w[k]; qq_part = __builtin_amdgcn_udot4(w[k], w[k], qq_part, false); }
+        }
+    } else {
         const f32x4* src = (const f32x4*)(Jp->rows + (size_t)q * dim);
 #pragma unroll
         for (int g = 0; g < NQ; ++g) qv[g] = (g_lo + g < g4) ? src[g_lo + g] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -319,6 +334,25 @@ void ann_search_kernel(const AnnSearchParams P)
         // ---- distance of the group's candidate in the reference's summation order
         float r = 0.0f;
         uint32_t cdeg = 0;
+        if constexpr (ROWS == 3) {
+            if (fresh) {
+                const u32x4* a8 = (const u32x4*)(rows8 + (size_t)cid * dim) + (g_lo >> 2);
+                uint32_t aa = qq_part, aq = 0;
+#pragma unroll
+                for (int g4i = 0; g4i < NQ / 4; ++g4i) {
+                    if (g_lo + 4 * g4i < g4) {
+                        const u32x4 w = a8[g4i];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { aa = __builtin_amdgcn_udot4(w[k], w[k], aa, false); aq = __builtin_amdgcn_udot4(w[k], q8[4 * g4i + k], aq, false); }
+                    }
+                }
+                cdeg = deg[cid];
+                uint32_t part = aa - 2u * aq;                                  // = sum of (a - q)^2 over this lane's dimensions, >= 0
+                part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: all four lanes hold the sum
+                r = (float)part;
+            }
+        } else
         if (fresh) {
             float gs[NQ];
             if constexpr (ROWS == 2) {
@@ -482,7 +516,13 @@ hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& Pin, uint32_
         }                                                                                                              \
         hipLaunchKernelGGL((ann_search_kernel<NQ, ROWS>), dim3((uint32_t)grid), dim3(256), lds, st, P);                 \
     } while (0)
-    if (rows_mode == 2 && (dim & 15u) == 0 && nq != 9) {
+    if (rows_mode == 3 && (dim & 15u) == 0 && dim <= 256 && nq != 9) {
+        if (nq <= 4) R3DM_ANN_LAUNCH(4, 3);
+        else if (nq <= 8) R3DM_ANN_LAUNCH(8, 3);
+        else if (nq <= 16) R3DM_ANN_LAUNCH(16, 3);
+        else return hipErrorInvalidValue;
+    }
+    else if (rows_mode >= 2 && (dim & 15u) == 0 && nq != 9) {
         if (nq <= 4) R3DM_ANN_LAUNCH(4, 2);
         else if (nq <= 8) R3DM_ANN_LAUNCH(8, 2);
         else if (nq <= 16) R3DM_ANN_LAUNCH(16, 2);

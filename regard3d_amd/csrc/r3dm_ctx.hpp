@@ -52,6 +52,7 @@ struct HostImage {
     DevBuf rows, tiled, tiled16, tiledh, tiled8, norms, bin, xy, canon;
     float max_abs = 0.0f; bool not_integer = true, has_negative = true;     // staging statistics (read back after the staging kernel)
     int32_t split_k = 0;                                                    // scale exponent of the f16 split tiles
+    bool compact_ready = false;     // ann_rows16 / ann_rows8 reflect the staged rows (reset by staging)
     DevBuf ann_adj, ann_deg, ann_rows16, ann_rows8;   // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0; compact row copies only for bf16- / u8-exact views
     uint32_t ann_K = 0;
     bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter
@@ -60,7 +61,7 @@ struct HostImage {
     {
         if (borrowed) { *this = HostImage(); return; }     // drop the aliases, keep the index's memory
         rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
-        ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; live = false;
+        ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; compact_ready = false; live = false;
     }
 };
 

@@ -257,7 +257,8 @@ hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
 size_t     filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim);
-// rows_mode: 0 = f32 rows, 1 = ImgDev::ann_rows16 (bf16), 2 = ImgDev::ann_rows8 (u8) -- every indexed view of the batch must hold that copy
+// rows_mode: 0 = f32 rows, 1 = ImgDev::ann_rows16 (bf16), 2 = ImgDev::ann_rows8 (u8) -- every indexed view of the batch must hold that copy;
+// 3 = u8 rows on both sides (the query views hold ann_rows8 too): distances as integer dot products
 hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim, int rows_mode);
 hipError_t launch_ann_rows16(hipStream_t st, const float* rows, uint16_t* rows16, size_t n_elems);
 hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, size_t n_elems);

@@ -105,6 +105,7 @@ def test_collection_equals_the_cpu_model_and_recovers_the_exhaustive_matches(ctx
     assert st.n_ann_dist > 0 and st.n_ann_built == 3                  # views 0, 1, 2 are first views of an indexed pair
     # rows of integers 0 .. 255 are gathered from their u8 copy (same f32 values, a quarter of the bytes), real-valued ones from the f32 rows
     assert (st.n_ann_rows8 > 0) == (kind == "sift") and st.n_ann_rows8 <= st.n_match_launches and st.n_ann_rows16 == 0
+    assert st.n_ann_dot8 == st.n_ann_rows8                              # ... and the query views are bytes too: integer dot products
     assert st.n_ann_dist < 0.5 * sum(len(sc.descs[i]) * len(sc.descs[j]) for i, j in pairs)
     # against the exhaustive matcher: most matches recovered, few spurious
     bc, bm = oracle.match_collection(sc.descs, sc.xys, pairs, 0.6, True)
@@ -143,32 +144,32 @@ def test_kgraph_rejects_what_it_cannot_do(ctx):
                         api.KGraphParams(index_K=64, search_P=10, search_S=10, seed=1))
 
 
-@pytest.mark.parametrize("negative", [False, True])
-def test_compact_row_copies_change_nothing(ctx, negative):
-    """The graph search on the u8 / bf16 row copy of integer-valued views (ImgDev::ann_rows8: integers 0 .. 255; ann_rows16: other
-    integers of magnitude <= 256) against the developer build told to keep the f32 rows (R3DM_ANN_ROWS16=0): identical 2-NN indices,
-    distances and evaluation counts."""
+@pytest.mark.parametrize("variant", ["bytes", "negative", "real_queries"])
+def test_compact_row_copies_change_nothing(ctx, variant):
+    """The graph search on the compact row copies of integer-valued views -- ImgDev::ann_rows8 (integers 0 .. 255; with byte queries
+    the distances are integer dot products), ann_rows16 (other integers of magnitude <= 256) -- against the developer build told to
+    keep the f32 rows (R3DM_ANN_ROWS16=0): identical 2-NN indices, distances and evaluation counts."""
     import os, subprocess, sys, tempfile, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sc = synth.make_scene(2, 3000, "sift", seed=88)
-    A, B = sc.descs[0].astype(np.float32), sc.descs[1].astype(np.float32)
-    if negative: A[5, 7] = -3.0                                # negative integers are bf16 values, not bytes
+    prep = {"bytes": "", "negative": "A[5, 7] = -3.0", "real_queries": "B = B + np.float32(0.25)"}[variant]
+    setup = textwrap.dedent(f"""
+        sc = synth.make_scene(2, 3000, "sift", seed=88)
+        A, B = sc.descs[0].astype(np.float32), sc.descs[1].astype(np.float32)
+        {prep}
+    """)
+    ns = {"synth": synth, "np": np}
+    exec(setup, ns)
+    A, B = ns["A"], ns["B"]
     kp = api.KGraphParams.preset("default")
     idx, dist = ctx.kgraph_knn2(A, B, kp, pair=(1, 2))
     st = ctx.stats()
-    assert (st.n_ann_rows16, st.n_ann_rows8) == ((1, 0) if negative else (0, 1))
-    code = textwrap.dedent(f"""
-        import sys; sys.path.insert(0, {root!r})
-        import numpy as np
-        from regard3d_amd import api, synth
-        api.use_developer_library()
-        sc = synth.make_scene(2, 3000, "sift", seed=88)
-        A, B = sc.descs[0].astype(np.float32), sc.descs[1].astype(np.float32)
-        if {negative!r}: A[5, 7] = -3.0
+    assert (st.n_ann_rows16, st.n_ann_rows8, st.n_ann_dot8) == {"bytes": (0, 1, 1), "negative": (1, 0, 0), "real_queries": (0, 1, 0)}[variant]
+    code = "import sys; sys.path.insert(0, %r)\nimport numpy as np\nfrom regard3d_amd import api, synth\napi.use_developer_library()\n" % root + setup + textwrap.dedent("""
         c = api.Context(0)
         idx, dist = c.kgraph_knn2(A, B, api.KGraphParams.preset("default"), pair=(1, 2))
-        assert c.stats().n_ann_rows16 == 0 and c.stats().n_ann_rows8 == 0
-        np.savez(sys.argv[1], idx=idx, dist=dist, evals=np.array([c.stats().n_ann_dist]))
+        s = c.stats()
+        assert s.n_ann_rows16 == 0 and s.n_ann_rows8 == 0 and s.n_ann_dot8 == 0
+        np.savez(sys.argv[1], idx=idx, dist=dist, evals=np.array([s.n_ann_dist]))
     """)
     n_evals = st.n_ann_dist
     with tempfile.TemporaryDirectory() as d:
