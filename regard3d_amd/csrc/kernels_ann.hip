@@ -401,8 +401,12 @@ void ann_search_kernel(const AnnSearchParams P)
             }
         }
         // ---- sequential sorted inserts, candidate order = adjacency order (UpdateKnnList semantics)
-        unsigned long long todo = __ballot(fresh && sub == 3u);
-        comps += (uint32_t)__builtin_popcountll(todo);
+        // A full pool rejects every candidate at or beyond its last entry, and that entry only moves down while the step's
+        // candidates are inserted: those are dropped here, before the one-at-a-time loop (most of them, once the pool has settled)
+        const unsigned long long evaluated = __ballot(fresh && sub == 3u);
+        comps += (uint32_t)__builtin_popcountll(evaluated);
+        const float worst = (L >= cap) ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pdist), (int)(cap - 1u))) : R3DM_INF;
+        unsigned long long todo = __ballot(fresh && sub == 3u && (r < worst || L < cap));
         while (todo) {
             const int src = __builtin_ctzll(todo);
             todo &= todo - 1ull;
