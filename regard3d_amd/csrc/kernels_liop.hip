@@ -8,7 +8,9 @@
 //
 // One wave per 41x41 patch, everything in LDS:
 //   1. the 669 pixels of the circular support are ranked by intensity: bitonic sort of (order-preserving
-//      float bits << 32 | scan position).  The reference sorts with its own quick sort, whose result differs
+//      float bits << 32 | scan position), 16 keys per lane in registers -- exchanges at distance < 16 are register
+//      compare-exchanges, the others lane exchanges (ds_bpermute); no LDS round trips, no barriers (the LDS network this replaces
+//      took ~120 k of the ~330 k cycles of a patch and its 8 KiB held the kernel at five waves per CU).  The reference sorts with its own quick sort, whose result differs
 //      from any other sort only in the order of EQUAL intensities; patches with ties are therefore re-sorted
 //      by one lane with that exact procedure (middle pivot, Lomuto pass, "<= 0") -- rare, and constant
 //      patches short-cut to the all-zero descriptor they produce;
@@ -72,6 +74,40 @@ __device__ void liop_ref_qsort4(const float (&v)[4], int (&p)[4])
     }
 }
 
+// ascending bitonic sort of 1024 distinct u64 keys held 16 per lane (key i in lane i / 16, slot i % 16)
+__device__ __forceinline__ void liop_sort1024(unsigned long long (&k)[16], uint32_t lane)
+{
+    const uint32_t base = lane * 16u;
+    for (uint32_t size = 2; size <= 1024u; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride >= 16u; stride >>= 1) {           // partner in another lane
+            const int lane_xor = (int)(stride >> 4);
+            const bool keep_min = ((base & stride) == 0u) == ((base & size) == 0u);   // slot bits are below 16: the lane decides
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)k[s], lane_xor);
+                const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(k[s] >> 32), lane_xor);
+                const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+                k[s] = keep_min ? (o < k[s] ? o : k[s]) : (o > k[s] ? o : k[s]);
+            }
+        }
+#pragma unroll
+        for (int ST = 8; ST >= 1; ST >>= 1) {                                      // partner in this lane
+            if ((uint32_t)ST < size) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    if ((s & ST) == 0) {
+                        const bool up = ((base + (uint32_t)s) & size) == 0u;
+                        const unsigned long long a = k[s], b = k[s | ST];
+                        const bool gt = a > b;
+                        k[s] = (gt == up) ? b : a;
+                        k[s | ST] = (gt == up) ? a : b;
+                    }
+                }
+            }
+        }
+    }
+}
+
 struct LiopParams {
     const float* patches;      // [n][41*41]
     const int*   pix;          // [n_pix] offsets of the circular support (scan order)
@@ -85,8 +121,7 @@ struct LiopParams {
 __global__ __launch_bounds__(64)
 void liop_kernel(const LiopParams P)
 {
-    __shared__ float patch[kLiopPix + 3];
-    __shared__ unsigned long long keys[kLiopSortCap];
+    __shared__ __attribute__((aligned(16))) float patch[kLiopPix + 3 + 128];   // (+ slack: the patch is loaded in float4 pieces)
     __shared__ float inten[kLiopSortCap];            // intensities in scan order (for the exact re-sort)
     __shared__ uint16_t perm[kLiopSortCap];
     __shared__ int qstack[2 * kLiopSortCap + 8];
@@ -97,30 +132,38 @@ void liop_kernel(const LiopParams P)
     const uint32_t N = P.n_pix;
     for (uint32_t item = blockIdx.x; item < P.n; item += gridDim.x) {
         const float* src = P.patches + (size_t)item * kLiopPix;
-        for (uint32_t e = lane; e < (uint32_t)kLiopPix; e += 64) patch[e] = src[e];
+        {
+            // 1681 floats; a patch starts at a multiple of 4 bytes only, so the vector loads are of single floats, all in flight at once
+            float v[27];
+#pragma unroll
+            for (int j = 0; j < 27; ++j) { const uint32_t e = lane + 64u * (uint32_t)j; v[j] = e < (uint32_t)kLiopPix ? src[e] : 0.0f; }
+#pragma unroll
+            for (int j = 0; j < 27; ++j) { const uint32_t e = lane + 64u * (uint32_t)j; if (e < (uint32_t)kLiopPix) patch[e] = v[j]; }
+        }
         for (uint32_t e = lane; e < 144; e += 64) hist[e] = 0;
         r3dm_syncthreads();
 
-        // ---- 1. rank the support pixels by intensity
-        for (uint32_t i = lane; i < (uint32_t)kLiopSortCap; i += 64) {
-            if (i < N) { const float v = patch[P.pix[i]]; inten[i] = v; keys[i] = ((unsigned long long)float_order_bits(v) << 32) | i; }
-            else keys[i] = ~0ull;
+        // ---- 1. rank the support pixels by intensity (key i: lane i / 16, slot i % 16)
+        unsigned long long keys[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const uint32_t i = lane * 16u + (uint32_t)s;
+            if (i < N) { const float v = patch[P.pix[i]]; inten[i] = v; keys[s] = ((unsigned long long)float_order_bits(v) << 32) | i; }
+            else keys[s] = ~0ull;
         }
-        r3dm_syncthreads();
-        for (uint32_t size = 2; size <= (uint32_t)kLiopSortCap; size <<= 1)
-            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                for (uint32_t t = lane; t < (uint32_t)kLiopSortCap / 2; t += 64) {
-                    const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                    const bool up = ((lo & size) == 0);
-                    const unsigned long long x = keys[lo], y = keys[hi];
-                    if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
-                }
-                r3dm_syncthreads();
-            }
+        liop_sort1024(keys, lane);
         bool tie = false;
-        for (uint32_t i = lane; i < N; i += 64) {
-            perm[i] = (uint16_t)(keys[i] & 0xFFFFu);
-            if (i + 1 < N) tie |= ((keys[i] >> 32) == (keys[i + 1] >> 32));
+        {
+            // the first key of the next lane, for the pair that straddles two lanes
+            const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)keys[0], 1), nhi = (uint32_t)__shfl_down((int)(uint32_t)(keys[0] >> 32), 1);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const uint32_t i = lane * 16u + (uint32_t)s;
+                if (i < N) perm[i] = (uint16_t)(keys[s] & 0xFFFFu);
+                const uint32_t next_hi = (s < 15) ? (uint32_t)(keys[s < 15 ? s + 1 : 15] >> 32) : nhi;
+                if (i + 1 < N) tie |= ((uint32_t)(keys[s] >> 32) == next_hi);
+            }
+            (void)nlo;
         }
         const bool any_tie = __ballot(tie) != 0ull;
         r3dm_syncthreads();
