@@ -27,6 +27,7 @@ namespace r3dm {
 constexpr int kLiopSide = 41;
 constexpr int kLiopPix = kLiopSide * kLiopSide;   // 1681
 constexpr int kLiopSortCap = 1024;
+constexpr int kLiopMaxPix = 676;                   // support pixels the exact re-sort's LDS arrays hold (new_basic(41): 669)
 
 __device__ __forceinline__ uint32_t float_order_bits(float v)
 {
@@ -34,25 +35,35 @@ __device__ __forceinline__ uint32_t float_order_bits(float v)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// exact emulation of the reference's quick sort over perm[0..n) ordered by val[perm[.]] (lane 0 only)
-__device__ void liop_ref_qsort(const float* __restrict__ val, uint16_t* __restrict__ perm, int n, int* __restrict__ stack)
+// exact emulation of the reference's quick sort (lane 0 only) over arr[0..n) = (intensity bits, scan position), ordered by
+// intensity.  One LDS array of pairs instead of perm[] + val[perm[]] (no dependent second load), and the Lomuto pass reads four
+// positions ahead: a swap writes positions `low` <= i and i only, never one that is still to be read, so the look-ahead is exact.
+__device__ void liop_ref_qsort(uint2* __restrict__ arr, int n, uint16_t* __restrict__ stack)
 {
     int sp = 0;
-    stack[sp++] = 0; stack[sp++] = n - 1;
+    stack[sp++] = 0; stack[sp++] = (uint16_t)(n - 1);
     while (sp > 0) {
         const int end = stack[--sp], begin = stack[--sp];
         const int pivot = (end + begin) / 2;
-        uint16_t t = perm[pivot]; perm[pivot] = perm[end]; perm[end] = t;
-        const float pv = val[perm[end]];
+        uint2 t = arr[pivot]; arr[pivot] = arr[end]; arr[end] = t;
+        const float pv = __uint_as_float(arr[end].x);
         int low = begin;
-        for (int i = begin; i < end; ++i) {
-            const uint16_t pi = perm[i];
-            if (val[pi] - pv <= 0.0f) { perm[i] = perm[low]; perm[low] = pi; ++low; }
+        for (int i = begin; i < end; i += 4) {
+            uint2 e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = arr[i + j];                     // (arr carries 4 entries of slack)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (i + j < end && __uint_as_float(e[j].x) - pv <= 0.0f) {
+                    if (low != i + j) { const uint2 o = arr[low]; arr[i + j] = o; arr[low] = e[j]; }
+                    ++low;
+                }
+            }
         }
-        t = perm[low]; perm[low] = perm[end]; perm[end] = t;
+        t = arr[low]; arr[low] = arr[end]; arr[end] = t;
         // the reference recurses into the low part first, then the high part: push high first (LIFO)
-        if (low < end) { stack[sp++] = low + 1; stack[sp++] = end; }
-        if (low > begin) { stack[sp++] = begin; stack[sp++] = low - 1; }
+        if (low < end) { stack[sp++] = (uint16_t)(low + 1); stack[sp++] = (uint16_t)end; }
+        if (low > begin) { stack[sp++] = (uint16_t)begin; stack[sp++] = (uint16_t)(low - 1); }
     }
 }
 
@@ -124,7 +135,8 @@ void liop_kernel(const LiopParams P)
     __shared__ __attribute__((aligned(16))) float patch[kLiopPix + 3 + 128];   // (+ slack: the patch is loaded in float4 pieces)
     __shared__ float inten[kLiopSortCap];            // intensities in scan order (for the exact re-sort)
     __shared__ uint16_t perm[kLiopSortCap];
-    __shared__ int qstack[2 * kLiopSortCap + 8];
+    __shared__ uint2 qarr[kLiopMaxPix + 4];          // exact re-sort of patches with equal intensities: (intensity bits, position)
+    __shared__ uint16_t qstack[2 * kLiopMaxPix + 8];
     __shared__ uint32_t hist[144];
     __shared__ float s_norm;
 
@@ -175,11 +187,14 @@ void liop_kernel(const LiopParams P)
             continue;
         }
         if (any_tie) {
+            for (uint32_t i = lane; i < N + 4u; i += 64) qarr[i] = make_uint2(i < N ? __float_as_uint(inten[i]) : 0u, i);
+            r3dm_syncthreads();
             if (lane == 0) {
-                for (uint32_t i = 0; i < N; ++i) perm[i] = (uint16_t)i;
-                liop_ref_qsort(inten, perm, (int)N, qstack);
+                liop_ref_qsort(qarr, (int)N, qstack);
                 atomicAdd(P.n_tie_patches, 1u);
             }
+            r3dm_syncthreads();
+            for (uint32_t i = lane; i < N; i += 64) perm[i] = (uint16_t)qarr[i].y;
             r3dm_syncthreads();
         }
         // threshold = -intensityThreshold * (max - min), all float (vl_liop.c:497-503)
@@ -329,6 +344,7 @@ hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, con
                        uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches)
 {
     if (n == 0) return hipSuccess;
+    if (n_pix < 2 || n_pix > (uint32_t)kLiopMaxPix) return hipErrorInvalidValue;
     LiopParams P{patches, pix, sx, sy, n, n_pix, desc, n_tie_patches};
     const uint32_t grid = n < 65536u ? n : 65536u;
     hipLaunchKernelGGL(liop_kernel, dim3(grid), dim3(64), 0, st, P);
