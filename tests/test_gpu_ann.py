@@ -177,3 +177,23 @@ def test_compact_row_copies_change_nothing(ctx, variant):
         assert r.returncode == 0, r.stderr[-2000:]
         z = np.load(d + "/f32.npz")
     assert np.array_equal(z["idx"], idx) and np.array_equal(z["dist"], dist) and int(z["evals"][0]) == n_evals
+
+
+@pytest.mark.parametrize("dim,lo,hi,expect", [(40, -20, 200, "rows16"), (64, 0, 255, "dot8"), (96, 0, 180, "dot8"), (256, 0, 255, "dot8"),
+                                               (48, 0, 100, "dot8"), (72, 0, 100, "rows16"), (128, 0, 256, "rows16")])
+def test_compact_rows_at_other_lengths(ctx, oracle, dim, lo, hi, expect):
+    """Integer-valued descriptors of other lengths and ranges through the compact-row searches (partial 16- / 8-element blocks, the
+    2^24 bound of the integer dot products at D = 256, 256 as the one bf16 integer that is not a byte) against oracle/kgraph.c."""
+    rng = np.random.default_rng(dim + hi)
+    nI, nJ = 900, 400
+    A = np.rint(rng.uniform(lo, hi, (nI, dim))).astype(np.float32)
+    B = np.clip(np.rint(A[rng.integers(0, nI, nJ)] + rng.normal(0, 6, (nJ, dim))), lo, hi).astype(np.float32)
+    A[0, 0], B[0, 0] = hi, hi
+    A[1, 1] = lo
+    kp = api.KGraphParams(index_K=16, search_P=8, search_S=10, seed=5)
+    idx, dist = ctx.kgraph_knn2(A, B, kp, pair=(4, 6))
+    st = ctx.stats()
+    assert (st.n_ann_rows16, st.n_ann_rows8, st.n_ann_dot8) == {"rows16": (1, 0, 0), "dot8": (0, 1, 1)}[expect]
+    g = oracle.kgraph_build_exact(A, K=16, cap=64)
+    oidx, odist, _ = g.knn2(B, P=8, S=10, seed=5, I=4, J=6, min_rows=128)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
