@@ -208,6 +208,10 @@ int r3dm_kgraph_knn2(r3dm_ctx* ctx, const float* dataset, uint32_t n_dataset, co
                      int32_t* out_idx, float* out_dist);
 /* the index of a registered view (built if necessary): adj_out = n x 64 rows (0xFFFFFFFF padded), deg_out = n */
 int r3dm_kgraph_index(r3dm_ctx* ctx, uint32_t view_id, uint32_t index_K, uint32_t* adj_out, uint32_t* deg_out);
+/* forget the graph indices of all registered views (they are rebuilt on the next r3dm_match_pairs_kgraph); the reference builds
+ * the index of image I inside every kgraph_match call (src/R3DComputeMatches.cpp:826-841), so a measurement that wants the same
+ * accounting calls this between passes.  The registered descriptors stay. */
+int r3dm_drop_indices(r3dm_ctx* ctx);
 
 /* ---- keypoint detection: Fast-A-KAZE ----
  * The "Fast-AKAZE" arm of Regard3DFeatures::detectKeypoints (src/Regard3DFeatures.cpp:596-617): cv::AKAZE2::create() with its

@@ -24,7 +24,7 @@ EXPORTS = [
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
@@ -130,6 +130,7 @@ def load_library():
     L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_kgraph_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, u32, u32, vp, vp]
     L.r3dm_kgraph_index.argtypes = [vp, u32, u32, vp, vp]
+    L.r3dm_drop_indices.argtypes = [vp]
     L.r3dm_graph_num_pairs.argtypes = [vp]; L.r3dm_graph_num_pairs.restype = u64
     L.r3dm_graph_num_matches.argtypes = [vp]; L.r3dm_graph_num_matches.restype = u64
     L.r3dm_graph_pairs.argtypes = [vp]; L.r3dm_graph_pairs.restype = vp
@@ -349,6 +350,10 @@ class Context:
         self._check(self._L.r3dm_kgraph_knn2(self._h, _ptr(dataset), dataset.shape[0], _ptr(query), nq, dataset.shape[1],
                                              C.addressof(kp), pair[0], pair[1], _ptr(idx), _ptr(dist)), "r3dm_kgraph_knn2")
         return idx[:nq], dist[:nq]
+
+    def drop_indices(self):
+        """r3dm_drop_indices: the next match_pairs_kgraph rebuilds the graph index of every view it uses"""
+        self._check(self._L.r3dm_drop_indices(self._h), "r3dm_drop_indices")
 
     def kgraph_index(self, view_id: int, n_rows: int, index_K: int = 24):
         """-> (adj [n, 64] uint32 padded with 0xFFFFFFFF, deg [n] uint32) of a registered view"""

@@ -510,6 +510,7 @@ static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t
         R3DM_HIP(c, c->a_scratch.ensure(bytes));
         R3DM_HIP(c, hipMemsetAsync(c->a_scratch.p, 0, bytes, c->stream));
         std::vector<AnnBuildJob> jobs;
+        bool all_rows8 = r3dm_dev_knob("R3DM_ANN_ROWS16", 3) >= 3;
         unsigned char* cur = c->a_scratch.as<unsigned char>();
         for (size_t k = start; k < end; ++k) {
             HostImage& h = *c->imgs[todo[k]];
@@ -523,15 +524,16 @@ static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t
             j.rev_cur = (uint32_t*)cur; cur += (size_t)h.n * 4;
             j.rev_off = (uint32_t*)cur; cur += (size_t)h.n * 4 + 64;
             j.adj = h.ann_adj.as<uint32_t>(); j.deg = h.ann_deg.as<uint32_t>();
-            jobs.push_back(j);
-            // bf16 copy of the rows for the search's gathers (ImgDev::ann_rows16): views whose every element is a bf16
             if (!h.compact_ready) { const int rcc = stage_compact_rows(c, h); if (rcc != R3DM_OK) return rcc; }
+            j.rows8 = h.ann_rows8.as<uint8_t>();
+            all_rows8 = all_rows8 && j.rows8 != nullptr;
+            jobs.push_back(j);
         }
         R3DM_HIP(c, c->a_jobs.ensure(jobs.size() * sizeof(AnnBuildJob)));
         R3DM_HIP(c, hipMemcpyAsync(c->a_jobs.p, jobs.data(), jobs.size() * sizeof(AnnBuildJob), hipMemcpyHostToDevice, c->stream));
         AnnBuildParams bp{};
         bp.imgs = c->d_imgs.as<ImgDev>(); bp.jobs = c->a_jobs.as<AnnBuildJob>(); bp.K = K;
-        hipError_t e = launch_ann_build(c->stream, bp, (uint32_t)jobs.size(), max_n, dim);
+        hipError_t e = launch_ann_build(c->stream, bp, (uint32_t)jobs.size(), max_n, dim, all_rows8 && dim <= 256 && (dim & 15u) == 0);
         if (e == hipErrorInvalidValue) { c->err = "no graph-index kernel for this descriptor length (dim % 4 != 0 or too long)"; return R3DM_ERR_UNSUPPORTED; }
         R3DM_HIP(c, e);
         static_assert(offsetof(ImgDev, ann_deg) == offsetof(ImgDev, ann_adj) + sizeof(void*) &&
@@ -750,6 +752,13 @@ extern "C" int r3dm_kgraph_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_da
                                 int32_t* out_idx, float* out_dist)
 {
     return r3dm_guarded(c, [&]() -> int { return r3dm_kgraph_knn2_impl(c, dataset, n_dataset, query, n_query, dim, kp, pair_i, pair_j, out_idx, out_dist); });
+}
+
+extern "C" int r3dm_drop_indices(r3dm_ctx* c)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    for (auto& h : c->imgs) if (h) h->ann_K = 0;             // the device pointers stay valid until the rebuild replaces them
+    return R3DM_OK;
 }
 
 extern "C" int r3dm_kgraph_index(r3dm_ctx* c, uint32_t view_id, uint32_t index_K, uint32_t* adj_out, uint32_t* deg_out)

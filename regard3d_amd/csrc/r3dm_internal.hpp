@@ -90,6 +90,7 @@ struct AnnBuildJob {
     unsigned long long* rev;      // [<= n*K] reverse keys, grouped by receiving row
     uint32_t* adj;                // -> ImgDev::ann_adj
     uint32_t* deg;                // -> ImgDev::ann_deg
+    const uint8_t* rows8;         // the view's byte rows (ImgDev::ann_rows8 once the index is published) or nullptr
 };
 struct AnnBuildParams {
     const ImgDev* imgs;
@@ -256,7 +257,8 @@ hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t wo
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
 size_t     filter_F_lds_bytes(uint32_t m_cap, int model_kind);
-hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim);
+// rows8: every job carries byte rows -> the all-pairs scan runs on integer dot products (same keys)
+hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim, bool rows8);
 // rows_mode: 0 = f32 rows, 1 = ImgDev::ann_rows16 (bf16), 2 = ImgDev::ann_rows8 (u8) -- every indexed view of the batch must hold that copy;
 // 3 = u8 rows on both sides (the query views hold ann_rows8 too): distances as integer dot products
 hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim, int rows_mode);
