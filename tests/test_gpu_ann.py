@@ -197,3 +197,19 @@ def test_compact_rows_at_other_lengths(ctx, oracle, dim, lo, hi, expect):
     g = oracle.kgraph_build_exact(A, K=16, cap=64)
     oidx, odist, _ = g.knn2(B, P=8, S=10, seed=5, I=4, J=6, min_rows=128)
     assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+
+
+def test_drop_indices_forces_a_rebuild_with_the_same_result(ctx):
+    sc = synth.make_scene(4, 1200, "sift", seed=17)
+    ctx.clear_images()
+    for i in range(sc.n_images):
+        ctx.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000)
+    pairs = sc.exhaustive_pairs()
+    kp = api.KGraphParams.preset("default")
+    g0 = ctx.match_pairs_kgraph(pairs, 0.6, kp); built0 = ctx.stats().n_ann_built
+    g1 = ctx.match_pairs_kgraph(pairs, 0.6, kp); built1 = ctx.stats().n_ann_built
+    ctx.drop_indices()
+    g2 = ctx.match_pairs_kgraph(pairs, 0.6, kp); built2 = ctx.stats().n_ann_built
+    assert (built0, built1, built2) == (3, 0, 3)
+    for g in (g1, g2):
+        assert np.array_equal(g.pairs, g0.pairs) and np.array_equal(g.offsets, g0.offsets) and np.array_equal(g.matches, g0.matches)
