@@ -506,8 +506,11 @@ extern "C" int r3dm_liop_describe_patches(r3dm_ctx* c, const float* patches, uin
     return r3dm_guarded(c, [&]() -> int { return r3dm_liop_describe_patches_impl(c, patches, n, side, desc_out, n_resorted); });
 }
 
+// resident_image: the image is already on the device (the features stage: r3dm_detect_akaze has just uploaded it into its own
+// buffer, which it only reads) -- then `image` is not copied a second time
 static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height,
-                                 const float* keypoints, uint32_t n, float kp_size_factor, float* desc_out, float* patches_out)
+                                 const float* keypoints, uint32_t n, float kp_size_factor, float* desc_out, float* patches_out,
+                                 const float* resident_image = nullptr)
 {
     if (!c || !image || width == 0 || height == 0 || (n && (!keypoints || !desc_out))) return R3DM_ERR_INVALID;
     R3DM_HIP(c, hipSetDevice(c->device));
@@ -540,18 +543,19 @@ static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t widt
         for (int i = 0; i < 11; ++i) kern[i] = (float)(kern[i] * sum);
     }
     const size_t img_bytes = (size_t)width * height * 4, patch_bytes = (size_t)n * 41 * 41 * 4, out_bytes = (size_t)n * 144 * 4;
-    R3DM_HIP(c, c->liop_img.ensure(img_bytes));
+    if (!resident_image) R3DM_HIP(c, c->liop_img.ensure(img_bytes));
     R3DM_HIP(c, c->liop_M.ensure(M6.size() * 4));
     R3DM_HIP(c, c->liop_kern.ensure(64));
     R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
     R3DM_HIP(c, c->liop_out.ensure(out_bytes));
     R3DM_HIP(c, c->liop_cnt.ensure(64));
-    R3DM_HIP(c, hipMemcpyAsync(c->liop_img.p, image, img_bytes, hipMemcpyDefault, c->stream));
+    if (!resident_image) R3DM_HIP(c, hipMemcpyAsync(c->liop_img.p, image, img_bytes, hipMemcpyDefault, c->stream));
+    const float* dev_image = resident_image ? resident_image : c->liop_img.as<float>();
     R3DM_HIP(c, hipMemcpyAsync(c->liop_M.p, M6.data(), M6.size() * 4, hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipMemcpyAsync(c->liop_kern.p, kern, sizeof(kern), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
-    R3DM_HIP(c, launch_liop_extract(c->stream, c->liop_img.as<float>(), (int)width, (int)height, c->liop_M.as<float>(),
+    R3DM_HIP(c, launch_liop_extract(c->stream, dev_image, (int)width, (int)height, c->liop_M.as<float>(),
                                     c->liop_kern.as<float>(), n, c->liop_in.as<float>()));
     R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
                             c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>()));
@@ -623,7 +627,9 @@ static int r3dm_extract_features_to_files_impl(r3dm_ctx* c, const float* gray, u
     }
     std::vector<float> desc(144 * (size_t)std::max<uint32_t>(n, 1));
     if (n) {
-        rc = r3dm_extract_liop(c, gray, width, height, kps.data(), n, 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, desc.data(), nullptr);
+        // the detector has just uploaded `gray` into its image buffer (ak_bufs[0], read-only for it): no second 4 w h-byte copy
+        const float* resident = (c->ak_w == (int)width && c->ak_h == (int)height && !c->ak_bufs.empty()) ? c->ak_bufs[0].as<float>() : nullptr;
+        rc = r3dm_extract_liop_impl(c, gray, width, height, kps.data(), n, 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, desc.data(), nullptr, resident);
         if (rc != R3DM_OK) return rc;
     }
     // KeypointSet::saveToBinFile (src/keypointSet.hpp:61-67): .feat = one "x y scale orientation" line per feature
