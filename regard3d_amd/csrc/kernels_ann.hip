@@ -328,12 +328,13 @@ void ann_search_kernel(const AnnSearchParams P)
     const float* __restrict__ rowsI = Ip->rows;
     const uint16_t* __restrict__ rows16 = Ip->ann_rows16;
     const uint8_t* __restrict__ rows8 = Ip->ann_rows8;
+    [[maybe_unused]] const float* __restrict__ normsI = Ip->norms;
     const uint32_t* __restrict__ adj = Ip->ann_adj;
     const uint32_t* __restrict__ deg = Ip->ann_deg;
 
     f32x4 qv[ROWS == 3 ? 1 : NQ];
     [[maybe_unused]] uint32_t q8[ROWS == 3 ? NQ : 1];
-    [[maybe_unused]] uint32_t qq_part = 0;                  // this lane's share of ||q||^2
+    [[maybe_unused]] uint32_t qq_part = 0;                  // ||q||^2 (summed over the four lanes of the group below)
     if constexpr (ROWS == 3) {
         static_assert(ROWS != 3 || NQ % 4 == 0, "byte rows are read 16 elements at a time");
         const u32x4* src = (const u32x4*)(Jp->ann_rows8 + (size_t)q * dim) + (g_lo >> 2);
@@ -343,6 +344,8 @@ void ann_search_kernel(const AnnSearchParams P)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { q8[4 * g4i + k] = w[k]; qq_part = __builtin_amdgcn_udot4(w[k], w[k], qq_part, false); }
         }
+        qq_part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qq_part, 0xB1, 0xF, 0xF, true);
+        qq_part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qq_part, 0x4E, 0xF, 0xF, true);
     } else {
         const f32x4* src = (const f32x4*)(Jp->rows + (size_t)q * dim);
 #pragma unroll
@@ -396,20 +399,20 @@ void ann_search_kernel(const AnnSearchParams P)
         if constexpr (ROWS == 3) {
             if (fresh) {
                 const u32x4* a8 = (const u32x4*)(rows8 + (size_t)cid * dim) + (g_lo >> 2);
-                uint32_t aa = qq_part, aq = 0;
+                const float aa_f = normsI[cid];                                // ||a||^2 from the staging statistics (an integer)
+                uint32_t aq = 0;
 #pragma unroll
                 for (int g4i = 0; g4i < NQ / 4; ++g4i) {
                     if (g_lo + 4 * g4i < g4) {
                         const u32x4 w = a8[g4i];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { aa = __builtin_amdgcn_udot4(w[k], w[k], aa, false); aq = __builtin_amdgcn_udot4(w[k], q8[4 * g4i + k], aq, false); }
+                        for (int k = 0; k < 4; ++k) aq = __builtin_amdgcn_udot4(w[k], q8[4 * g4i + k], aq, false);
                     }
                 }
                 cdeg = deg[cid];
-                uint32_t part = aa - 2u * aq;                                  // = sum of (a - q)^2 over this lane's dimensions, >= 0
-                part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-                part += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)part, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: all four lanes hold the sum
-                r = (float)part;
+                aq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)aq, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+                aq += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)aq, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]: all four lanes hold a.q
+                r = (float)((uint32_t)aa_f + qq_part - 2u * aq);                    // sum of (a - q)^2 >= 0, below 2^24
             }
         } else
         if (fresh) {
