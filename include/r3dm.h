@@ -300,6 +300,9 @@ int r3dm_multi_clear_images(r3dm_multi* m);
 int r3dm_multi_set_integer_mfma(r3dm_multi* m, int enable);
 int r3dm_multi_match_pairs(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs,
                            float dist_ratio, int squared_metric, r3dm_graph** out);
+/* the same deal for the graph matcher (kgraph_match, config C5): a device builds the index of every image I whose row it owns */
+int r3dm_multi_match_pairs_kgraph(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                                  const r3dm_kgraph_params* params, r3dm_graph** out);
 int r3dm_multi_filter_F(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                         uint64_t seed, r3dm_graph** out, double* F_out);
 int r3dm_multi_filter_H(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,

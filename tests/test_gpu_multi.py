@@ -58,6 +58,12 @@ def test_two_contexts_reassemble_the_single_context_graphs(ctx, oracle, n_ctx):
         m.set_integer_mfma(True)
         g3 = m.match_pairs(pairs, 0.6, True)
         assert _same(g1, g3) and all(m.device_stats(k).n_integer_mfma >= 1 for k in range(n_ctx))
+        # the graph matcher over the same deal: every context builds the indices of its own rows of I only
+        kp = api.KGraphParams.preset("default")
+        a1 = ctx.match_pairs_kgraph(pairs, 0.6, kp)
+        a2 = m.match_pairs_kgraph(pairs, 0.6, kp)
+        assert _same(a1, a2) and a1.num_matches > 0
+        assert sum(m.device_stats(k).n_ann_built for k in range(n_ctx)) == sc.n_images - 1
     finally:
         m.close()
         ctx.clear_images()
