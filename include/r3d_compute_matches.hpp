@@ -66,6 +66,9 @@ public:
     static constexpr int kMatchingAlgorithmGPU = 9;
 
     explicit R3DComputeMatches(int device_id = 0);
+    // all GPUs of a node from this one process: the pair loop and the filter loop of the stage are dealt to the listed devices
+    // (r3dm_multi_*: one context + one host thread per device, results merged in the reference's map order)
+    explicit R3DComputeMatches(const std::vector<int>& device_ids);
     ~R3DComputeMatches();
     R3DComputeMatches(const R3DComputeMatches&) = delete;
     R3DComputeMatches& operator=(const R3DComputeMatches&) = delete;
@@ -95,6 +98,7 @@ public:
 
 private:
     r3dm_ctx* ctx_ = nullptr;
+    r3dm_multi* multi_ = nullptr;          // set instead of ctx_ by the device-list constructor
     std::vector<View> views_;
     r3dm_dtype dtype_ = R3DM_F32;
     uint32_t dim_ = 144;

@@ -95,13 +95,25 @@ R3DComputeMatches::R3DComputeMatches(int device_id)
     if (rc != R3DM_OK) { ctx_ = nullptr; errorMessage_ = "r3dm_create failed (" + std::to_string(rc) + "): no gfx950 GPU"; }
 }
 
-R3DComputeMatches::~R3DComputeMatches() { if (ctx_) r3dm_destroy(ctx_); }
+R3DComputeMatches::R3DComputeMatches(const std::vector<int>& device_ids)
+{
+    if (device_ids.size() == 1) {
+        const int rc = r3dm_create(device_ids[0], &ctx_);
+        if (rc != R3DM_OK) { ctx_ = nullptr; errorMessage_ = "r3dm_create failed (" + std::to_string(rc) + "): no gfx950 GPU"; }
+        return;
+    }
+    const int rc = r3dm_multi_create(device_ids.data(), (int)device_ids.size(), &multi_);
+    if (rc != R3DM_OK) { multi_ = nullptr; errorMessage_ = "r3dm_multi_create failed (" + std::to_string(rc) + ")"; }
+}
+
+R3DComputeMatches::~R3DComputeMatches() { if (ctx_) r3dm_destroy(ctx_); if (multi_) r3dm_multi_destroy(multi_); }
 
 void R3DComputeMatches::addViews(const std::vector<View>& views) { views_.insert(views_.end(), views.begin(), views.end()); }
 
 void R3DComputeMatches::setIntegerFastPath(bool on)
 {
     if (ctx_) (void)r3dm_set_integer_mfma(ctx_, on ? 1 : 0);
+    if (multi_) (void)r3dm_multi_set_integer_mfma(multi_, on ? 1 : 0);
 }
 
 void R3DComputeMatches::setRegionsType(r3dm_dtype dtype, uint32_t dim) { dtype_ = dtype; dim_ = dim; }
@@ -110,7 +122,23 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
                                        int /*cameraModel*/, int matchingAlgorithm)
 {
     statistics_ = R3DComputeMatchesStatistics();
-    if (!ctx_) return false;
+    if (!ctx_ && !multi_) return false;
+    // one device or the multi-device deal: the same calls either way
+    auto last_error = [&]() -> std::string { return ctx_ ? r3dm_last_error(ctx_) : r3dm_multi_last_error(multi_); };
+    auto clear_images = [&]() { return ctx_ ? r3dm_clear_images(ctx_) : r3dm_multi_clear_images(multi_); };
+    auto set_image = [&](uint32_t id, uint32_t w, uint32_t h, const void* d, uint32_t n, const float* xy) {
+        return ctx_ ? r3dm_set_image(ctx_, id, w, h, d, n, dim_, dtype_, xy) : r3dm_multi_set_image(multi_, id, w, h, d, n, dim_, dtype_, xy); };
+    auto set_intrinsics = [&](uint32_t id, const double* K) { return ctx_ ? r3dm_set_intrinsics(ctx_, id, K) : r3dm_multi_set_intrinsics(multi_, id, K); };
+    auto match = [&](const std::vector<uint32_t>& p, float ratio, int squared, r3dm_graph** out) {
+        return ctx_ ? r3dm_match_pairs(ctx_, p.data(), p.size() / 2, ratio, squared, out) : r3dm_multi_match_pairs(multi_, p.data(), p.size() / 2, ratio, squared, out); };
+    auto match_kgraph = [&](const std::vector<uint32_t>& p, float ratio, const r3dm_kgraph_params* kpp, r3dm_graph** out) {
+        return ctx_ ? r3dm_match_pairs_kgraph(ctx_, p.data(), p.size() / 2, ratio, kpp, out) : r3dm_multi_match_pairs_kgraph(multi_, p.data(), p.size() / 2, ratio, kpp, out); };
+    auto filter_F = [&](const r3dm_graph* g, r3dm_graph** out) {
+        return ctx_ ? r3dm_filter_F(ctx_, g, 4.0, 2048, seed_, R3DM_ERR_SYMMETRIC_EPIPOLAR, out, nullptr) : r3dm_multi_filter_F(multi_, g, 4.0, 2048, seed_, out, nullptr); };
+    auto filter_E = [&](const r3dm_graph* g, r3dm_graph** out) {
+        return ctx_ ? r3dm_filter_E(ctx_, g, 4.0, 2048, seed_, 50, 0.3f, out, nullptr) : r3dm_multi_filter_E(multi_, g, 4.0, 2048, seed_, 50, 0.3f, out, nullptr); };
+    auto filter_H = [&](const r3dm_graph* g, r3dm_graph** out) {
+        return ctx_ ? r3dm_filter_H(ctx_, g, 4.0, 2048, seed_, out, nullptr) : r3dm_multi_filter_H(multi_, g, 4.0, 2048, seed_, out, nullptr); };
     // dispatch of src/R3DComputeMatches.cpp:2035-2062: 4 = brute force and 9 = the new arm run the exhaustive matcher; every
     // approximate arm (0 FLANN kd-trees, 1..3 KGraph, 5 MRPT, 6..8 HNSW) runs the graph matcher with a preset of at least the
     // arm's recall (r3dm_ann_params_for_algorithm); anything else is refused.
@@ -124,7 +152,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     const size_t row_bytes = dtype_ == R3DM_F32 ? (size_t)dim_ * 4 : (size_t)dim_;
 
     // ---- Regions_Provider::load + Features_Provider::load (src/R3DComputeMatches.cpp:2040,2094-2095)
-    if (r3dm_clear_images(ctx_) != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+    if (clear_images() != R3DM_OK) { errorMessage_ = last_error(); return false; }
     for (const View& v : views_) {
         std::vector<float> xy;
         std::vector<unsigned char> desc;
@@ -135,11 +163,11 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         }
         if (xy.size() != 2 * n) { errorMessage_ = "feature/descriptor count mismatch: " + v.basename; return false; }
         statistics_.numberOfKeypoints_.push_back((int)n);
-        const int rc = r3dm_set_image(ctx_, v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, dim_, dtype_, xy.data());
-        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+        const int rc = set_image(v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, xy.data());
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
         if (v.focal_px > 0.0) {
             const double K[9] = {v.focal_px, 0.0, v.ppx, 0.0, v.focal_px, v.ppy, 0.0, 0.0, 1.0};      // Pinhole_Intrinsic::K()
-            if (r3dm_set_intrinsics(ctx_, v.id_view, K) != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+            if (set_intrinsics(v.id_view, K) != R3DM_OK) { errorMessage_ = last_error(); return false; }
         }
     }
 
@@ -157,11 +185,11 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     const int squared = dtype_ == R3DM_BIN ? 0 : 1;        // RegionsMatcherT squared flag: true for L2 metrics
     int rc;
     if (use_kgraph) {
-        rc = r3dm_match_pairs_kgraph(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, &kp, &putative);
+        rc = match_kgraph(pairs, params.distRatio_, &kp, &putative);
     } else {
-        rc = r3dm_match_pairs(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, squared, &putative);
+        rc = match(pairs, params.distRatio_, squared, &putative);
     }
-    if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); return false; }
+    if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
     graph_to_map(putative, statistics_.putativeMatches_);
     const std::string put_path = paths.matchesPutitativeFilename_.empty() ? dir + "/matches.putative.txt" : paths.matchesPutitativeFilename_;
     if (r3dm_save_matches(putative, put_path.c_str()) != R3DM_OK ||
@@ -178,8 +206,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     if (params.computeFundalmentalMatrix_) {
         if (progress_) progress_(0.8f, "Calculate fundamental matrix", progress_user_);
         r3dm_graph* geo = nullptr;
-        rc = r3dm_filter_F(ctx_, putative, 4.0, 2048, seed_, R3DM_ERR_SYMMETRIC_EPIPOLAR, &geo, nullptr);
-        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
+        rc = filter_F(putative, &geo);
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
         graph_to_map(geo, statistics_.fundamentalMatches_);
         const std::string f_path = paths.matchesFFilename_.empty() ? dir + "/matches.f.txt" : paths.matchesFFilename_;
         const bool ok = r3dm_save_matches(geo, f_path.c_str()) == R3DM_OK &&
@@ -192,8 +220,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     if (params.computeEssentialMatrix_) {
         if (progress_) progress_(0.9f, "Calculate essential matrix", progress_user_);
         r3dm_graph* geo = nullptr;
-        rc = r3dm_filter_E(ctx_, putative, 4.0, 2048, seed_, 50, 0.3f, &geo, nullptr);
-        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
+        rc = filter_E(putative, &geo);
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
         graph_to_map(geo, statistics_.essentialMatches_);
         const std::string e_path = paths.matchesEFilename_.empty() ? dir + "/matches.e.txt" : paths.matchesEFilename_;
         const bool ok = r3dm_save_matches(geo, e_path.c_str()) == R3DM_OK &&
@@ -205,8 +233,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     if (params.computeHomographyMatrix_) {
         if (progress_) progress_(0.95f, "Calculate homography matrix", progress_user_);
         r3dm_graph* geo = nullptr;
-        rc = r3dm_filter_H(ctx_, putative, 4.0, 2048, seed_, &geo, nullptr);
-        if (rc != R3DM_OK) { errorMessage_ = r3dm_last_error(ctx_); r3dm_graph_free(putative); return false; }
+        rc = filter_H(putative, &geo);
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
         graph_to_map(geo, statistics_.homographyMatches_);
         const std::string h_path = paths.matchesHFilename_.empty() ? dir + "/matches.h.txt" : paths.matchesHFilename_;
         const bool ok = r3dm_save_matches(geo, h_path.c_str()) == R3DM_OK &&

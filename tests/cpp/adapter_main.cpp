@@ -98,8 +98,10 @@ int main(int argc, char** argv)
         return 0;
     }
     if (!strcmp(argv[1], "stage") && argc >= 5) {
-        // stage <matches_dir> <dim> <basename...>
-        r3d_amd::R3DComputeMatches stage(0);
+        // stage <matches_dir> <dim> <basename...>;  R3DM_TEST_DEVICES=N: the device-list constructor with N entries of device 0
+        const char* ndev_env = getenv("R3DM_TEST_DEVICES");
+        const std::vector<int> devices((size_t)(ndev_env ? atoi(ndev_env) : 1), 0);
+        r3d_amd::R3DComputeMatches stage(devices);
         std::vector<r3d_amd::View> views;
         // synthetic views (regard3d_amd/synth.py): 4000 x 3000, f = 1.2 * width, principal point at the centre
         for (int k = 4; k < argc; ++k) views.push_back({(uint32_t)(k - 4), 4000, 3000, argv[k], 4800.0, 2000.0, 1500.0});

@@ -209,6 +209,26 @@ def test_stage_facade_integer_fast_path_writes_the_same_files(host_exe, oracle, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["9", "2"])
+def test_stage_facade_on_a_device_list_writes_the_same_files(host_exe, oracle, tmp_path, algo):
+    """R3DComputeMatches(device_ids): the stage dealt to several contexts (r3dm_multi_*; here three on the box's one GPU) writes
+    byte-identical putative / F / E / H files -- exhaustive arm 9 and the KGraph arm 2."""
+    sc = synth.make_scene(6, 1000, "sift", seed=37)
+    names = _write_views(oracle, str(tmp_path), sc)
+    files = ("matches.putative.bin", "matches.putative.txt", "matches.f.bin", "matches.e.bin", "matches.h.bin")
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "128"] + names, capture_output=True, text=True, env=dict(os.environ, R3DM_TEST_ALGO=algo))
+    assert r.returncode == 0, r.stderr
+    ref = {f: open(str(tmp_path / f), "rb").read() for f in files}
+    for f in files: os.remove(str(tmp_path / f))
+    r2 = subprocess.run([host_exe, "stage", str(tmp_path), "128"] + names, capture_output=True, text=True,
+                        env=dict(os.environ, R3DM_TEST_ALGO=algo, R3DM_TEST_DEVICES="3"))
+    assert r2.returncode == 0, r2.stderr
+    assert r2.stdout == r.stdout and int(r.stdout.split()[0]) > 3
+    for f, blob in ref.items():
+        assert open(str(tmp_path / f), "rb").read() == blob, f
+
+
+@pytest.mark.gpu
 def test_features_facade_matches_oracle(host_exe, oracle, tmp_path):
     """Regard3DFeatures::detectAndExtract (include/regard3d_features.hpp) == CPU restatement of detect + LIOP"""
     rng = np.random.default_rng(3)
