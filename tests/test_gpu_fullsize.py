@@ -161,6 +161,28 @@ def test_bench_contract_one_and_two_ranks(tmp_path):
         assert j3["detail"][k] == j1["detail"][k], k
 
 
+def test_bench_c5_two_ranks_reassemble_the_single_rank_graph():
+    """config C5 through the rank shard: every rank builds the graph indices of its own rows of I (dropped and rebuilt inside the
+    step) and searches its pairs; the gathered graphs equal the single-rank run's."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "c5", "--steps", "1", "--warmup", "1", "--images", "9", "--feat", "2048", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert j1["detail"]["ann_index_build_ms_per_step"] > 0 and j1["roofline"]["row_bytes"] == 128
+    env = dict(os.environ, R3DM_SHARE_GPU="1", R3DM_DIST_BACKEND="gloo")
+    port = 29900 + os.getpid() % 90
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j2 = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["config"]["pairs"] == 36 and 0 < j2["config"]["pairs_this_rank"] < 36
+    for k in ("putative_pairs", "putative_matches", "F_pairs", "F_matches"):
+        assert j2["detail"][k] == j1["detail"][k], k
+
+
 @pytest.mark.parametrize("config,extra", [("c3", ["--images", "10", "--feat", "2048"]), ("liop144", ["--images", "10", "--feat", "2048"]),
                                           ("c5", ["--images", "6", "--feat", "4096"]), ("c4", ["--images", "24", "--feat", "1024", "--emulate-world", "8"])])
 def test_bench_config_legs(config, extra):
