@@ -567,10 +567,11 @@ class MultiContext:
 
     def extract_features(self, images, feat_paths, desc_paths, threshold: float = 0.001):
         """r3dm_multi_extract_features: the features stage over an image list, one image in flight per context.
-        images: list of [h, w] float32 arrays (gray / 255).  -> (n_features [N], skipped [N] bool)"""
-        imgs = [np.ascontiguousarray(im, np.float32) for im in images]
+        images: list of [h, w] float32 arrays (gray / 255), host (numpy) or device (anything with data_ptr(): torch tensors).
+        -> (n_features [N], skipped [N] bool)"""
+        imgs = [im if hasattr(im, "data_ptr") else np.ascontiguousarray(im, np.float32) for im in images]
         n = len(imgs)
-        gp = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        gp = (C.c_void_p * n)(*[(im.data_ptr() if hasattr(im, "data_ptr") else im.ctypes.data) for im in imgs])
         ws = np.array([im.shape[1] for im in imgs], np.uint32); hs = np.array([im.shape[0] for im in imgs], np.uint32)
         fp = (C.c_char_p * n)(*[p.encode() for p in feat_paths]); dp = (C.c_char_p * n)(*[p.encode() for p in desc_paths])
         nf = np.zeros(n, np.uint32); sk = np.zeros(n, np.uint32)
