@@ -372,20 +372,26 @@ extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
             ok &= fwrite(g->matches.data() + g->offsets[p], sizeof(r3dm_match), cnt, f) == cnt;
         }
     } else {
-        std::string buf;
-        buf.reserve(1 << 20);
-        char tmp[64];
+        // "I J\ncount\n" then one "i j\n" line per match: decimal digits written by hand into a 1 MiB buffer (the same bytes
+        // as the "%u %u\n" this replaces, an order of magnitude faster: the stage writes four such files)
+        std::vector<char> buf((1 << 20) + 64);
+        size_t n = 0;
+        auto put_u64 = [&](uint64_t v, char sep) {
+            char d[20]; int k = 0;
+            do { d[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (k) buf[n++] = d[--k];
+            buf[n++] = sep;
+        };
         for (uint64_t p = 0; p < np && ok; ++p) {
             const uint64_t cnt = g->offsets[p + 1] - g->offsets[p];
-            int len = snprintf(tmp, sizeof(tmp), "%u %u\n%llu\n", g->pairs[2 * p], g->pairs[2 * p + 1], (unsigned long long)cnt);
-            buf.append(tmp, len);
+            put_u64(g->pairs[2 * p], ' '); put_u64(g->pairs[2 * p + 1], '\n'); put_u64(cnt, '\n');
             for (uint64_t k = g->offsets[p]; k < g->offsets[p + 1]; ++k) {
-                len = snprintf(tmp, sizeof(tmp), "%u %u\n", g->matches[k].i, g->matches[k].j);
-                buf.append(tmp, len);
+                put_u64(g->matches[k].i, ' '); put_u64(g->matches[k].j, '\n');
+                if (n > (1 << 20)) { ok &= fwrite(buf.data(), 1, n, f) == n; n = 0; }
             }
-            if (buf.size() > (1 << 20) - 4096) { ok &= fwrite(buf.data(), 1, buf.size(), f) == buf.size(); buf.clear(); }
+            if (n > (1 << 20)) { ok &= fwrite(buf.data(), 1, n, f) == n; n = 0; }
         }
-        if (ok && !buf.empty()) ok &= fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        if (ok && n) ok &= fwrite(buf.data(), 1, n, f) == n;
     }
     ok &= (fclose(f) == 0);
     return ok ? R3DM_OK : R3DM_ERR_IO;
@@ -421,16 +427,36 @@ static int r3dm_load_matches_impl(const char* path, r3dm_graph** out)
             pairs.push_back(ij[0]); pairs.push_back(ij[1]); offs.push_back(m.size());
         }
     } else {
-        unsigned I, J; unsigned long long cnt;
-        while (fscanf(f, "%u %u %llu", &I, &J, &cnt) == 3) {
-            if (cnt >= (1ull << 32)) { ok = false; break; }
-            for (unsigned long long k = 0; k < cnt; ++k) {
-                unsigned a, b;
-                if (fscanf(f, "%u %u", &a, &b) != 2) { ok = false; break; }
-                m.push_back({a, b});
+        // whitespace-separated unsigned decimals, read from one buffer holding the whole file (what fscanf("%u") accepts)
+        ok = fseek(f, 0, SEEK_END) == 0;
+        const long fsz = ok ? ftell(f) : -1;
+        ok = ok && fsz >= 0 && fseek(f, 0, SEEK_SET) == 0;
+        std::vector<char> txt(ok ? (size_t)fsz + 1 : 1);
+        ok = ok && fread(txt.data(), 1, (size_t)fsz, f) == (size_t)fsz;
+        const char* s = txt.data();
+        const char* e = s + (ok ? (size_t)fsz : 0);
+        // -> 1 number, 0 clean end of input, -1 something that is not a number (or one that does not fit `limit`)
+        auto next = [&](uint64_t limit, uint64_t& v) -> int {
+            while (s < e && (*s == ' ' || *s == '\n' || *s == '\r' || *s == '\t' || *s == '\v' || *s == '\f')) ++s;
+            if (s == e) return 0;
+            if (*s < '0' || *s > '9') return -1;
+            v = 0;
+            while (s < e && *s >= '0' && *s <= '9') { v = v * 10 + (uint64_t)(*s++ - '0'); if (v > limit) return -1; }
+            return 1;
+        };
+        while (ok) {
+            uint64_t I, J, cnt, a, b;
+            const int r = next(0xFFFFFFFFull, I);
+            if (r == 0) break;                                    // end of file between entries
+            if (r < 0 || next(0xFFFFFFFFull, J) != 1 || next(0xFFFFFFFFull, cnt) != 1 || cnt > (uint64_t)(e - s) / 4 + 1) { ok = false; break; }
+            const size_t at = m.size();
+            m.resize(at + cnt);
+            for (uint64_t k = 0; k < cnt; ++k) {
+                if (next(0xFFFFFFFFull, a) != 1 || next(0xFFFFFFFFull, b) != 1) { ok = false; break; }
+                m[at + k] = {(uint32_t)a, (uint32_t)b};
             }
             if (!ok) break;
-            pairs.push_back(I); pairs.push_back(J); offs.push_back(m.size());
+            pairs.push_back((uint32_t)I); pairs.push_back((uint32_t)J); offs.push_back(m.size());
         }
     }
     fclose(f);
