@@ -17,11 +17,31 @@ namespace {
 // (/root/reference/src/keypointSet.hpp:49-67 -> OpenMVG loadFeatsFromFile / loadDescsFromBinFile)
 bool load_feat(const std::string& path, std::vector<float>& xy)
 {
-    std::ifstream f(path);
+    // the whole file in one buffer, strtof per field (what `stream >> float` does underneath, without the stream): groups of four
+    // numbers until the first group that is not complete, like `while (f >> x >> y >> s >> o)`
+    FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    float x, y, s, o;
+    std::vector<char> txt;
+    bool ok = fseek(f, 0, SEEK_END) == 0;
+    const long sz = ok ? ftell(f) : -1;
+    ok = ok && sz >= 0 && fseek(f, 0, SEEK_SET) == 0;
+    if (ok) { txt.resize((size_t)sz + 1); ok = fread(txt.data(), 1, (size_t)sz, f) == (size_t)sz; txt[(size_t)sz] = 0; }
+    fclose(f);
+    if (!ok) return false;
     xy.clear();
-    while (f >> x >> y >> s >> o) { xy.push_back(x); xy.push_back(y); }
+    const char* s = txt.data();
+    for (;;) {
+        float v[4];
+        int k = 0;
+        for (; k < 4; ++k) {
+            char* end = nullptr;
+            v[k] = strtof(s, &end);
+            if (end == s) break;
+            s = end;
+        }
+        if (k < 4) break;
+        xy.push_back(v[0]); xy.push_back(v[1]);
+    }
     return true;
 }
 
@@ -153,11 +173,26 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
 
     // ---- Regions_Provider::load + Features_Provider::load (src/R3DComputeMatches.cpp:2040,2094-2095)
     if (clear_images() != R3DM_OK) { errorMessage_ = last_error(); return false; }
-    for (const View& v : views_) {
-        std::vector<float> xy;
-        std::vector<unsigned char> desc;
-        uint64_t n = 0;
-        if (!load_feat(dir + "/" + v.basename + ".feat", xy) || !load_desc(dir + "/" + v.basename + ".desc", row_bytes, desc, n)) {
+    // files are read and parsed by all host threads, 64 views at a time; registration (device copies) stays in view order
+    struct Loaded { std::vector<float> xy; std::vector<unsigned char> desc; uint64_t n = 0; bool ok = false; };
+    std::vector<Loaded> chunk;
+    for (size_t vi = 0; vi < views_.size(); ++vi) {
+        if (vi % 64 == 0) {
+            const size_t cn = std::min<size_t>(64, views_.size() - vi);
+            chunk.assign(cn, Loaded());
+#pragma omp parallel for schedule(dynamic)
+            for (long k = 0; k < (long)cn; ++k) {
+                const View& u = views_[vi + (size_t)k];
+                Loaded& L = chunk[(size_t)k];
+                L.ok = load_feat(dir + "/" + u.basename + ".feat", L.xy) && load_desc(dir + "/" + u.basename + ".desc", row_bytes, L.desc, L.n);
+            }
+        }
+        const View& v = views_[vi];
+        Loaded& L = chunk[vi % 64];
+        std::vector<float>& xy = L.xy;
+        std::vector<unsigned char>& desc = L.desc;
+        const uint64_t n = L.n;
+        if (!L.ok) {
             errorMessage_ = "Invalid features: " + v.basename;       // reference: MLOG "Invalid features." + return false (:2096-2097)
             return false;
         }
