@@ -374,7 +374,8 @@ extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
     } else {
         // "I J\ncount\n" then one "i j\n" line per match: decimal digits written by hand into a 1 MiB buffer (the same bytes
         // as the "%u %u\n" this replaces, an order of magnitude faster: the stage writes four such files)
-        std::vector<char> buf((1 << 20) + 64);
+        // flush threshold 1 MiB; behind it at most one pair header (11 + 11 + 21 bytes) and one match line (22 bytes) are written
+        std::vector<char> buf((1 << 20) + 256);
         size_t n = 0;
         auto put_u64 = [&](uint64_t v, char sep) {
             char d[20]; int k = 0;

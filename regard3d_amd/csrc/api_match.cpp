@@ -608,6 +608,9 @@ static int run_ann_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ra
         dot8 = dot8 && B.compact_ready && B.ann_rows8.p != nullptr;        // ... and every query view its byte copy
     }
     dot8 = dot8 && rows8 && dim <= 256 && (dim & 15u) == 0;
+    // descriptor lengths 132 .. 144 (nine float4 per lane: LIOP-144) have no compact-row instantiation of the search kernel
+    // (launch_ann_search): integer-valued views of that length gather the f32 rows
+    if ((dim / 4 + 3) / 4 == 9) { dot8 = false; rows8 = false; rows16 = false; }
     hipError_t e = launch_ann_search(c->stream, sp, max_nJ, max_nI, dim, dot8 ? 3 : rows8 ? 2 : (rows16 ? 1 : 0));
     if (e == hipErrorInvalidValue) { c->err = "graph search: unsupported descriptor length / view size / parameters"; return R3DM_ERR_UNSUPPORTED; }
     R3DM_HIP(c, e);

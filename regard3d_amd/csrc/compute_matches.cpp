@@ -3,6 +3,7 @@
 // load regions -> exhaustive pairs -> match -> save matches.putative.txt -> F filter -> save matches.f.txt.
 #include "../../include/r3d_compute_matches.hpp"
 
+#include <charconv>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -17,7 +18,7 @@ namespace {
 // (/root/reference/src/keypointSet.hpp:49-67 -> OpenMVG loadFeatsFromFile / loadDescsFromBinFile)
 bool load_feat(const std::string& path, std::vector<float>& xy)
 {
-    // the whole file in one buffer, strtof per field (what `stream >> float` does underneath, without the stream): groups of four
+    // the whole file in one buffer, one from_chars per field (what `stream >> float` does, without the stream): groups of four
     // numbers until the first group that is not complete, like `while (f >> x >> y >> s >> o)`
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -29,15 +30,25 @@ bool load_feat(const std::string& path, std::vector<float>& xy)
     fclose(f);
     if (!ok) return false;
     xy.clear();
+    // locale-independent, like the classic-locale `stream >> float` of OpenMVG's reader (the host application calls
+    // setlocale(LC_ALL, ""), so strtof would read "12.5" as 12 under a comma-decimal locale): std::from_chars, after the white
+    // space and the optional sign that operator>> accepts; hex / inf / nan tokens are not numbers for operator>> and end the file here too
     const char* s = txt.data();
+    const char* const end_txt = s + (size_t)sz;
     for (;;) {
         float v[4];
         int k = 0;
         for (; k < 4; ++k) {
-            char* end = nullptr;
-            v[k] = strtof(s, &end);
-            if (end == s) break;
-            s = end;
+            while (s < end_txt && (*s == ' ' || *s == '\n' || *s == '\t' || *s == '\r' || *s == '\f' || *s == '\v')) ++s;
+            const char* t = s;
+            bool neg = false;
+            if (t < end_txt && (*t == '+' || *t == '-')) { neg = *t == '-'; ++t; }
+            if (t >= end_txt || !((*t >= '0' && *t <= '9') || *t == '.')) break;
+            const std::from_chars_result r = std::from_chars(t, end_txt, v[k], std::chars_format::general);
+            if (r.ec == std::errc::invalid_argument) break;
+            if (r.ec == std::errc::result_out_of_range) v[k] = 0.0f;     // (never for pixel coordinates) operator>> sets failbit; keep going with 0
+            if (neg) v[k] = -v[k];
+            s = r.ptr;
         }
         if (k < 4) break;
         xy.push_back(v[0]); xy.push_back(v[1]);
@@ -184,7 +195,9 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
             for (long k = 0; k < (long)cn; ++k) {
                 const View& u = views_[vi + (size_t)k];
                 Loaded& L = chunk[(size_t)k];
-                L.ok = load_feat(dir + "/" + u.basename + ".feat", L.xy) && load_desc(dir + "/" + u.basename + ".desc", row_bytes, L.desc, L.n);
+                // nothing may leave an OpenMP region by exception (std::terminate): a failed allocation is a failed load
+                try { L.ok = load_feat(dir + "/" + u.basename + ".feat", L.xy) && load_desc(dir + "/" + u.basename + ".desc", row_bytes, L.desc, L.n); }
+                catch (...) { L.ok = false; }
             }
         }
         const View& v = views_[vi];

@@ -394,7 +394,10 @@ __device__ __forceinline__ bool ak_prune_body(const AkLevelDev& L, uint32_t n_ca
 __device__ __forceinline__ bool ak_prune_body_batched(const AkLevelDev& L, uint32_t n_cand, float* lx, float* ly, float* lr, uint32_t* lslot, uint32_t live_cap)
 {
     const uint32_t lane = threadIdx.x;
-    const float size = L.psize, size2 = size * size, box = 2.0f * size;
+    // the dependency box is a little wider than 2 size: the keep / replace rule compares dx*dx + dy*dy with size*size in floats, so
+    // a candidate may be `within size` of a slot at an axis distance a few ulps beyond size; classifying a few more candidates as
+    // dependent only sends them through the one-by-one path
+    const float size = L.psize, size2 = size * size, box = 2.0f * size * 1.0001f + 1.0f;
     uint32_t n_list = 0, n_live = 0;
     for (uint32_t c0 = 0; c0 < n_cand; c0 += 64) {
         const uint32_t nb = (n_cand - c0 < 64u) ? n_cand - c0 : 64u;

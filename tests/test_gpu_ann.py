@@ -180,10 +180,13 @@ def test_compact_row_copies_change_nothing(ctx, variant):
 
 
 @pytest.mark.parametrize("dim,lo,hi,expect", [(40, -20, 200, "rows16"), (64, 0, 255, "dot8"), (96, 0, 180, "dot8"), (256, 0, 255, "dot8"),
-                                               (48, 0, 100, "dot8"), (72, 0, 100, "rows16"), (128, 0, 256, "rows16")])
+                                               (48, 0, 100, "dot8"), (72, 0, 100, "rows16"), (128, 0, 256, "rows16"),
+                                               (144, 0, 255, "f32"), (136, -5, 250, "f32")])
 def test_compact_rows_at_other_lengths(ctx, oracle, dim, lo, hi, expect):
     """Integer-valued descriptors of other lengths and ranges through the compact-row searches (partial 16- / 8-element blocks, the
-    2^24 bound of the integer dot products at D = 256, 256 as the one bf16 integer that is not a byte) against oracle/kgraph.c."""
+    2^24 bound of the integer dot products at D = 256, 256 as the one bf16 integer that is not a byte) against oracle/kgraph.c.
+    Lengths 132 .. 144 (LIOP's 144: nine float4 per lane) have no compact-row kernel: integer-valued views of that length must
+    run on the f32 rows, not fail."""
     rng = np.random.default_rng(dim + hi)
     nI, nJ = 900, 400
     A = np.rint(rng.uniform(lo, hi, (nI, dim))).astype(np.float32)
@@ -193,7 +196,7 @@ def test_compact_rows_at_other_lengths(ctx, oracle, dim, lo, hi, expect):
     kp = api.KGraphParams(index_K=16, search_P=8, search_S=10, seed=5)
     idx, dist = ctx.kgraph_knn2(A, B, kp, pair=(4, 6))
     st = ctx.stats()
-    assert (st.n_ann_rows16, st.n_ann_rows8, st.n_ann_dot8) == {"rows16": (1, 0, 0), "dot8": (0, 1, 1)}[expect]
+    assert (st.n_ann_rows16, st.n_ann_rows8, st.n_ann_dot8) == {"rows16": (1, 0, 0), "dot8": (0, 1, 1), "f32": (0, 0, 0)}[expect]
     g = oracle.kgraph_build_exact(A, K=16, cap=64)
     oidx, odist, _ = g.knn2(B, P=8, S=10, seed=5, I=4, J=6, min_rows=128)
     assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
