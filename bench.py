@@ -14,6 +14,10 @@ them out).
   c4       configs[3]: 1000 x 8192 SIFT-128, 499,500 pairs, sharded over the GPUs + one all-gather.
   c5       configs[4]: 1000 x 16384 SIFT-128, KGraph-style approximate 2-NN (graph index + graph search) + F filter.
   liop144  what Regard3D actually matches (src/Regard3DFeatures.h:44-48): 200 x 8192 x f32[144], real-valued, unit length.
+  stage    the reference's DEFAULT stage end to end, one facade call per step (R3DComputeMatches::computeMatches): N synthetic
+           4000 x 3000 photographs resident in HBM -> Fast-A-KAZE + LIOP -> .feat/.desc -> LIOP-144 matching (arm 9, and arm 0 =
+           the GUI default) -> F + E + H AC-RANSAC -> matches.*.txt/.bin; per-phase times, a roofline for the detector and one
+           for the essential-matrix kernel (N = 1 only; --images sets N, default 32).
 N > 1 (one rank per GPU, torchrun): the SAME collection, pairs dealt to the ranks by rows of I (r3dm_shard_pairs), descriptors
 replicated -- "scaling": "strong", exactly the metric's "1/2/4/8 GPU" -- unless --scaling weak (image count grows so that
 the pair count is ~N x the base).  --emulate-world W at N = 1 runs shard 0 of a W-way job (what one GPU of a W-GPU node
@@ -73,7 +77,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + ["stage"], default="c2")
+    ap.add_argument("--stage-size", default="4000x3000", help="--config stage: image size WxH")
     ap.add_argument("--images", type=int, default=0, help="override the collection size of the config (stated in config.workload)")
     ap.add_argument("--feat", type=int, default=0, help="override the features per image of the config")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
@@ -82,6 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the extra (untimed-region) pass on the opt-in fast path of the config")
     a = ap.parse_args()
+    if a.config == "stage":
+        return stage_main(a)
     cfg = dict(CONFIGS[a.config])
     if a.feat:
         cfg["feat"] = a.feat
@@ -211,6 +218,165 @@ def main():
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+
+
+def stage_main(a):
+    """--config stage: the reference's default Compute-matches stage from pixels, through the one facade call."""
+    import shutil
+    import tempfile
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        raise SystemExit("--config stage is a single-GPU leg (the features and filter phases deal to devices inside the facade)")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    W, H = (int(x) for x in a.stage_size.lower().split("x"))
+    N = a.images or 32
+    imgs, K = synth.make_photo_set(N, H, W, seed=7007, device=dev)          # gray / 255 floats, resident in HBM
+    torch.cuda.synchronize()
+    views = [dict(id=k, width=W, height=H, basename=f"img{k:04d}", gray=imgs[k], focal_px=K[0, 0], ppx=K[0, 2], ppy=K[1, 2]) for k in range(N)]
+    bare = [dict(v, gray=None) for v in views]
+    n_pairs = N * (N - 1) // 2
+    d = tempfile.mkdtemp(prefix="r3dm_stage_")
+    conc, batch = 2, 8
+
+    def wipe(all_files=True):
+        for f in os.listdir(d):
+            if all_files or f.startswith("matches."):
+                os.remove(os.path.join(d, f))
+
+    def step(algo=9):
+        wipe()
+        return api.compute_matches_stage([0], d, views, 0.001, 0.6, algo, True, True, True, 5489, conc, batch)
+
+    try:
+        for _ in range(max(a.warmup, 1)):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = [step().as_dict() for _ in range(a.steps)]
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        mean = lambda k: sum(r[k] for r in reps) / len(reps)
+        last = reps[-1]
+        # the GUI's default arm (matchingAlgorithm 0 = FLANN kd-trees in the reference, src/Regard3DMainFrame.cpp:2405) on the files
+        # the step left: no extraction, matching + filters only; and arm 9 the same way for a like-for-like match phase
+        wipe(False); r9 = api.compute_matches_stage([0], d, bare, 0.001, 0.6, 9).as_dict()
+        f9 = open(os.path.join(d, "matches.f.bin"), "rb").read()
+        wipe(False); r0 = api.compute_matches_stage([0], d, bare, 0.001, 0.6, 0).as_dict()
+        f0 = open(os.path.join(d, "matches.f.bin"), "rb").read()
+        # detector roofline: a dedicated pass of the batch entry on B resident images, one context, nothing else on the GPU
+        ctx = api.Context(0)
+        B = min(8, N)
+        ctx.detect_akaze_batch(imgs[:B], 0.001)
+        ctx.detect_akaze_batch(imgs[:B], 0.001)
+        sd = ctx.stats()
+        det_gbs = sd.detect_algorithmic_bytes / (sd.ms_detect_kernels * 1e-3) / 1e9
+        out = {
+            "metric": "image-pairs matched/sec (+ F-inlier filter)", "value": n_pairs * a.steps / elapsed, "unit": "pairs/s", "n_gpus": 1,
+            "steps": a.steps, "warmup": max(a.warmup, 1), "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32 (detector, LIOP, L2) / f64 (AC-RANSAC)", "data": "synthetic",
+            "config": {"workload": f"stage: {N} synthetic {W}x{H} photographs (one textured plane, 78 % overlap between neighbours) resident in HBM -> "
+                                   f"R3DComputeMatches::computeMatches: Fast-A-KAZE + LIOP-144 ({conc} batches of {batch} in flight) -> .feat/.desc -> exhaustive {n_pairs} pairs, "
+                                   "brute-force L2 2-NN + ratio 0.6 (matchingAlgorithm 9) -> F + E + H AC-RANSAC (4 px, 2048 it) -> matches.*.txt/.bin",
+                       "name": "stage", "images": N, "pairs": n_pairs, "image_size": [W, H], "parallelism": "1 GPU"},
+            "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total")},
+            "kernels_ms": {"match": mean("ms_match_kernels"), "F": mean("ms_F_kernels"), "E": mean("ms_E_kernels"), "H": mean("ms_H_kernels"),
+                           "detector_sum_over_contexts": last["features"]["ms_detect_kernels"], "liop_sum_over_contexts": last["features"]["ms_liop_kernels"]},
+            "features": {"images_per_s": N / (mean("ms_features") * 1e-3), "ms_per_image": mean("ms_features") / N, "keypoints": int(last["n_keypoints"]),
+                         "keypoints_per_image": last["n_keypoints"] / N, "file_ms_sum_over_contexts": last["features"]["ms_files"],
+                         "detector_passes": int(last["features"]["n_passes"]), "regrows": int(last["features"]["n_regrows"])},
+            "graphs": {k: int(last[k]) for k in ("n_putative_pairs", "n_putative_matches", "n_F_pairs", "n_F_matches", "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches")},
+            "arm_9_on_existing_files": {"ms_match": r9["ms_match"], "ms_total": r9["ms_total"], "putative_matches": int(r9["n_putative_matches"])},
+            "arm_0_gui_default": {"ms_match": r0["ms_match"], "ms_total": r0["ms_total"], "putative_matches": int(r0["n_putative_matches"]),
+                                  "F_file_identical_to_arm_9": bool(f0 == f9),
+                                  "note": "the reference's arm 0 is FLANN kd-trees (approximate); the facade serves it with the matcher r3dm_ann_params_for_algorithm names (DESIGN.md section 4.7)"},
+            "roofline": {"bound": "hbm", "kernel": f"Fast-A-KAZE detector pass, B = {B} images (ak_* kernels, first scale-space launch .. keypoint compaction)",
+                         "achieved": det_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": det_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_image": sd.detect_algorithmic_bytes / B, "ms_per_image": sd.ms_detect_kernels / B,
+                         "note": "algorithmic bytes = every stencil pass of the launch sequence reads / writes whole image planes once (DESIGN.md section 4.8); "
+                                 "measured in a dedicated pass (one context, HIP events on the library's stream), the stage itself keeps "
+                                 f"{conc} such passes in flight"},
+        }
+        # essential-matrix kernel: f64 vector work of the models it evaluated (r3dm_filter_report) over its HIP-event time
+        out["roofline_E"] = stage_E_roofline(d, views, last)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = stage_cpu_baseline(ctx, imgs, d, K, W, H, a.cpu_seconds)
+        print(json.dumps(out))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def stage_E_roofline(d, views, last):
+    """achieved f64 flop/s of acransac_kernel<2> on the putative graph of the stage: per evaluated model m x 30 flops of residuals
+    (F = K2^-T E K1^-1 applied to every putative, SURVEY 8d's per-model figure) + per 5-point sample ~8e4 flops (null space, 10 x 20
+    elimination, degree-10 Sturm chain with 64 bisection steps: an estimate, stated as such)."""
+    g = api.Graph.load(os.path.join(d, "matches.putative.bin"))
+    ctx = api.Context(0)
+    import numpy as _np
+    kps = []
+    for v in views:
+        raw = _np.fromfile(os.path.join(d, v["basename"] + ".desc"), _np.uint8)
+        n = int(_np.frombuffer(raw[:8].tobytes(), _np.uint64)[0])
+        desc = _np.frombuffer(raw[8:].tobytes(), _np.float32).reshape(n, 144)
+        xy = _np.loadtxt(os.path.join(d, v["basename"] + ".feat"), dtype=_np.float32).reshape(-1, 4)[:, :2].copy()
+        ctx.set_image(v["id"], desc, xy, v["width"], v["height"])
+        ctx.set_intrinsics(v["id"], _np.array([[v["focal_px"], 0, v["ppx"]], [0, v["focal_px"], v["ppy"]], [0, 0, 1.0]]))
+    ge = ctx.filter_E(g, 4.0, 2048, seed=5489)
+    ms = ctx.stats().ms_filter_kernels
+    rep = ctx.filter_report()
+    counts = _np.diff(g.offsets.astype(_np.int64))
+    flops = sum(r[3] * float(m) * 30.0 + r[2] * 8.0e4 for r, m in zip(rep, counts))
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    ctx.close()
+    return {"bound": "valu", "kernel": "acransac_kernel<2> (essential matrix, 5-point)", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s (f64 vector)",
+            "frac": ach / 78.6, "traffic": None, "kernel_ms": ms, "pairs": int(g.num_pairs), "kept_pairs": int(ge.num_pairs),
+            "models_evaluated": int(sum(r[3] for r in rep)), "iterations": int(sum(r[2] for r in rep)),
+            "note": "latency-bound by construction (one workgroup per pair, sequential AC-RANSAC iterations): the f64 roof is the stated bound, the useful numbers are kernel_ms and iterations"}
+
+
+def stage_cpu_baseline(ctx, imgs, d, K, W, H, budget_s):
+    """the CPU restatement of the same chain on a bounded sample: Fast-A-KAZE + LIOP on the top-left crop of image 0 (cost is per pixel,
+    so images/s scales with the crop's share of the image), then matching + F / E / H of one pair with the descriptors the stage wrote.
+    The crop also goes through the GPU detector: same keypoints or the leg reports the mismatch."""
+    from oracle import pyoracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    cw, ch = W // 2, H // 2
+    crop = imgs[0][:ch, :cw].contiguous().cpu().numpy()
+    t0 = time.perf_counter()
+    ok = O.akaze_detect(crop, 0.001)["kps"]
+    t_det = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    od = O.liop_describe(O.liop_extract_patches(crop, ok, 8.0))
+    t_liop = time.perf_counter() - t0
+    gk, _ = ctx.detect_akaze(crop, 0.001)
+    gd = ctx.extract_liop(crop, gk, 8.0)
+    feats = []
+    for k in (0, 1):
+        raw = np.fromfile(os.path.join(d, f"img{k:04d}.desc"), np.uint8)
+        n = int(np.frombuffer(raw[:8].tobytes(), np.uint64)[0])
+        feats.append((np.loadtxt(os.path.join(d, f"img{k:04d}.feat"), dtype=np.float32).reshape(-1, 4)[:, :2].copy(),
+                      np.frombuffer(raw[8:].tobytes(), np.float32).reshape(n, 144).copy()))
+    pairs = np.array([[0, 1]], np.uint32)
+    xys = [feats[0][0], feats[1][0]]; descs = [feats[0][1], feats[1][1]]
+    t0 = time.perf_counter()
+    counts, matches = O.match_collection(descs, xys, pairs, 0.6, True)
+    t_match = time.perf_counter() - t0
+    Wd = np.full(2, W, np.uint32); Hd = np.full(2, H, np.uint32)
+    t0 = time.perf_counter()
+    oc, om = O.filter_F_collection(xys, Wd, Hd, pairs, counts, matches, 4.0, 2048, 5489)
+    O.filter_E_collection(xys, Wd, Hd, np.stack([K, K]), pairs, counts, matches, 4.0, 2048, 5489)
+    O.filter_H_collection(xys, Wd, Hd, pairs, counts, matches, 4.0, 2048, 5489)
+    t_filt = time.perf_counter() - t0
+    g = api.Graph.load(os.path.join(d, "matches.putative.bin")).as_dict()
+    gf = api.Graph.load(os.path.join(d, "matches.f.bin")).as_dict()
+    share = (cw * ch) / float(W * H)
+    return {"value": 1.0 / (t_match + t_filt), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"features: the {cw}x{ch} top-left crop of image 0 through oracle/akaze.c ({t_det:.1f} s) + liop.c ({t_liop:.1f} s), OpenMP on {cores} threads; "
+                      f"matching: pair (0,1) of the stage's own descriptors, brute-force L2 2-NN + ratio ({t_match:.1f} s) + F / E / H AC-RANSAC ({t_filt:.2f} s)",
+            "features_images_per_s_full_size_equivalent": share / (t_det + t_liop),
+            "crop_keypoints": int(len(ok)), "crop_keypoints_equal_gpu": bool(np.array_equal(ok, gk)), "crop_descriptors_equal_gpu": bool(np.array_equal(od, gd)),
+            "putative_pair_0_1_equal_gpu": bool(np.array_equal(g.get((0, 1), np.zeros((0, 2), np.uint32)), matches)),
+            "F_inlier_set_pair_0_1_equal_gpu": bool(set(map(tuple, gf.get((0, 1), np.zeros((0, 2), np.uint32)).tolist())) == set(map(tuple, om[:oc[0]].tolist())))}
 
 
 def roofline(name, cfg, acc, dim, world):

@@ -9,9 +9,12 @@
 // /root/reference/src/R3DProject.h:39-65).  wxWidgets / OpenMVG types are replaced by std types:
 // the SfM_Data the stage reads is reduced to the fields it actually uses -- view id, image size and
 // the basename of the .feat/.desc files (/root/reference/src/R3DComputeMatches.cpp:1763-1777).
-// The facade matches views whose <basename>.feat / <basename>.desc exist in the matches directory, which is the
-// reference's behaviour when both files exist (/root/reference/src/threads/R3DFeaturesThread.cpp:139-142); they are
-// produced by the feature stage (include/regard3d_features.hpp, r3dm_extract_features_to_files).
+// computeMatches runs the whole stage as the reference does (/root/reference/src/R3DComputeMatches.cpp:1994-2240): first the
+// features stage -- R3DFeaturesThread::extractFeaturesAndDescriptors, src/threads/R3DFeaturesThread.cpp:38-210 -- for every view
+// whose <basename>.feat / <basename>.desc are not BOTH in the matches directory (views that have both are reused as they are,
+// :139-142), then matching, the F / E / H filters and the match files.  Image DECODING (cv::imread) stays with the caller: a
+// view carries its decoded pixels (View::bgr8 as cv::imread returns them, or View::gray = gray / 255 floats), or the caller sets an
+// image provider that is asked for the pixels of exactly the views that need extraction.
 #pragma once
 
 #include <cstdint>
@@ -52,6 +55,10 @@ struct View {
     // pinhole intrinsics of the view (sfm_data.bin: Pinhole_Intrinsic focal / principal point); focal_px <= 0 = unknown,
     // such views are skipped by the essential-matrix filter exactly as E_ACRobust.hpp skips views without intrinsics
     double focal_px = -1.0, ppx = 0.0, ppy = 0.0;
+    // decoded pixels for the features stage (host or device memory, borrowed until computeMatches returns; either may be null):
+    // bgr8 = ui_height x ui_width x 3 bytes in cv::imread's BGR order, gray = ui_height x ui_width floats (gray / 255)
+    const unsigned char* bgr8 = nullptr;
+    const float* gray = nullptr;
 };
 
 using MatchList = std::vector<r3dm_match>;          // IndMatches (IndMatch{i_, j_} == r3dm_match{i, j})
@@ -82,9 +89,27 @@ public:
     // fractions and messages (0.7 "Find putative matches", 0.8 / 0.9 / 0.95 "Calculate ... matrix", :2000,2107,2133,2209)
     using ProgressFn = void (*)(float progress, const char* msg, void* user);
     void setProgressCallback(ProgressFn fn, void* user) { progress_ = fn; progress_user_ = user; }
+    // Pixels on demand: called (from the thread that runs computeMatches) for each view that needs the features stage and
+    // carries no pixels; fills bgr8 or gray of `out` (valid until the matching release call) and returns false if the image
+    // cannot be provided.  Lets a host decode 16 images at a time instead of holding the whole collection in memory.
+    struct Pixels { const unsigned char* bgr8 = nullptr; const float* gray = nullptr; };
+    using ImageProviderFn = bool (*)(const View& view, Pixels* out, void* user);
+    using ImageReleaseFn = void (*)(const View& view, void* user);
+    void setImageProvider(ImageProviderFn get, ImageReleaseFn release, void* user) { provider_ = get; provider_release_ = release; provider_user_ = user; }
+    // detector batches in flight per device and images per batch of the features stage (defaults 2 x 8)
+    void setFeaturesConcurrency(int batches_in_flight, int images_per_batch) { feat_conc_ = batches_in_flight; feat_batch_ = images_per_batch; }
 
     bool computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,
                         int cameraModel, int matchingAlgorithm);
+
+    // wall time of the phases of the last computeMatches call, milliseconds (no reference counterpart: the GUI shows progress only)
+    struct PhaseTimes {
+        double features = 0, load = 0, match = 0, filter_F = 0, filter_E = 0, filter_H = 0, files = 0, total = 0;
+        double match_kernels = 0, F_kernels = 0, E_kernels = 0, H_kernels = 0;     // HIP-event time of the dominant kernel of each phase
+        uint64_t images_extracted = 0;
+        r3dm_features_totals features_totals{};                                      // summed over the contexts of the features stage
+    };
+    const PhaseTimes& getPhaseTimes() const { return phases_; }
 
     struct R3DComputeMatchesStatistics {
         std::vector<int> numberOfKeypoints_;
@@ -105,6 +130,14 @@ private:
     ProgressFn progress_ = nullptr;
     void* progress_user_ = nullptr;
     uint64_t seed_ = 5489;
+    std::vector<int> devices_;             // the device list this facade was built with
+    r3dm_multi* feat_multi_ = nullptr;     // contexts of the features stage (feat_conc_ per device), created on first use
+    int feat_conc_ = 2, feat_batch_ = 8;
+    ImageProviderFn provider_ = nullptr;
+    ImageReleaseFn provider_release_ = nullptr;
+    void* provider_user_ = nullptr;
+    PhaseTimes phases_;
+    bool runFeaturesStage(const R3DFParams& params, const std::string& dir);
     R3DComputeMatchesStatistics statistics_;
     std::string errorMessage_;
 };
@@ -113,6 +146,26 @@ private:
 
 // C entry point over the facade (lets non-C++ hosts and the tests drive the directory-level stage)
 extern "C" {
+// the whole stage from pixels for non-C++ hosts, the tests and bench.py: views with decoded pixels (either pointer may be null
+// when the view's .feat / .desc exist), the device list, the reference's parameters, and a report of the phases
+typedef struct {
+    uint32_t id, width, height;
+    const char* basename;
+    const unsigned char* bgr8;       /* height x width x 3, BGR, host or device; or NULL */
+    const float* gray;               /* height x width floats, gray / 255, host or device; or NULL */
+    double focal_px, ppx, ppy;       /* focal_px <= 0: intrinsics unknown */
+} r3dm_view_image;
+typedef struct {
+    double ms_features, ms_load, ms_match, ms_filter_F, ms_filter_E, ms_filter_H, ms_files, ms_total;
+    double ms_match_kernels, ms_F_kernels, ms_E_kernels, ms_H_kernels;
+    uint64_t images_extracted, n_keypoints;
+    uint64_t n_putative_pairs, n_putative_matches, n_F_pairs, n_F_matches, n_E_pairs, n_E_matches, n_H_pairs, n_H_matches;
+    r3dm_features_totals features;
+} r3dm_stage_report;
+int r3dm_compute_matches_stage(const int* device_ids, int n_devices, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
+                               float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
+                               uint64_t seed, int features_batches_in_flight, int features_images_per_batch,
+                               r3dm_stage_report* report, char* err, size_t err_cap);
 typedef struct { uint32_t id, width, height; const char* basename; } r3dm_view;
 int r3dm_compute_matches_dir(int device_id, const char* matches_dir, const r3dm_view* views, uint32_t n_views,
                              r3dm_dtype dtype, uint32_t dim, float dist_ratio, int compute_F, uint64_t seed,

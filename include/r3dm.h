@@ -225,6 +225,15 @@ int r3dm_drop_indices(r3dm_ctx* ctx);
 int r3dm_detect_akaze(r3dm_ctx* ctx, const float* image, uint32_t width, uint32_t height, float threshold,
                       float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out);
 
+/* The same over a BATCH of n_images same-size images in ONE pass of the detector (no reference counterpart: the reference admits one
+ * image at a time into this stage, src/Regard3DFeatures.cpp:71-125).  The ~550 dependent launches of the scale space depend on the
+ * image size only, so they serve all images at once (one image alone waits for launch latency below the first octave), and nothing
+ * in the chain visits the host.  images[b]: height x width floats, host or device; keypoints_out[b]: cap x 4
+ * floats; responses_out: NULL, or n_images pointers (each may be NULL); n_out[b] as above.  Results per image are bit-identical
+ * to r3dm_detect_akaze on that image. */
+int r3dm_detect_akaze_batch(r3dm_ctx* ctx, uint32_t n_images, const float* const* images, uint32_t width, uint32_t height,
+                            float threshold, float* const* keypoints_out, float* const* responses_out, uint32_t cap, uint32_t* n_out);
+
 /* cv::AKAZE2::detectAndCompute with DESCRIPTOR_MLDB (src/thirdparty/fast-akaze/akaze.cpp:171-221; the binary descriptors of
  * BASELINE config C3): keypoints as above plus the full MLDB descriptor of each -- 3 grids (2x2, 3x3, 4x4) x 3 channels, all
  * pairwise comparisons = 486 bits packed LSB first into 61 bytes (AKAZEFeatures.cpp:1790-1909).  descriptors_out: cap x 61
@@ -243,6 +252,15 @@ int r3dm_detect_akaze_mldb(r3dm_ctx* ctx, const float* image, uint32_t width, ui
 int r3dm_gray_from_bgr8(r3dm_ctx* ctx, const unsigned char* bgr, uint32_t width, uint32_t height, float* gray_out);
 int r3dm_extract_features_to_files(r3dm_ctx* ctx, const float* gray, uint32_t width, uint32_t height, float threshold,
                                    const char* feat_path, const char* desc_path, uint32_t* n_features);
+
+/* n_images same-size images through the work item in one pass: detector batch (above) -> the angle and LIOP patch map of every
+ * keypoint on the host (atan2f / cos / sin of the host libm, as the reference; 32 bytes per keypoint up, 24 down) -> ONE patch
+ * extraction launch and ONE LIOP launch over the keypoints of all images -> files.  grays: n_images pointers to height x width
+ * floats, or NULL and bgrs: n_images pointers to height x width x 3 bytes (BGR as cv::imread decodes; converted on the device as
+ * r3dm_gray_from_bgr8 does); host or device.  No skip rule here: every image is computed and its two files (re)written. */
+int r3dm_extract_features_batch(r3dm_ctx* ctx, uint32_t n_images, const float* const* grays, const unsigned char* const* bgrs,
+                                uint32_t width, uint32_t height, float threshold, const char* const* feat_paths,
+                                const char* const* desc_paths, uint32_t* n_features);
 
 /* ---- descriptor extraction: LIOP on pre-extracted patches ----
  * r3d_vl_liopdesc_process of the vendored VLFeat copy (src/thirdparty/liop/vl_liop.c:465-580) as Regard3D
@@ -310,8 +328,9 @@ int r3dm_multi_filter_H(r3dm_multi* m, const r3dm_graph* putative, double max_re
 int r3dm_multi_filter_E(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                         uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out);
 /* The features stage over an image list: R3DFeaturesThread::extractFeaturesAndDescriptors (src/threads/R3DFeaturesThread.cpp:38-121),
- * whose worker pool pulls images off a work list and runs processWorkItem on each.  Here every context of `m` is a worker: create
- * the r3dm_multi with one device id repeated K times to keep K images in flight on that GPU (K streams + K sets of work buffers;
+ * whose worker pool pulls images off a work list and runs processWorkItem on each.  Here every context of `m` is a worker that pulls
+ * BATCHES of same-size images (r3dm_extract_features_batch: up to 8 per detector pass): create
+ * the r3dm_multi with one device id repeated K times to keep K batches in flight on that GPU (K streams + K sets of work buffers;
  * the reference admits one image at a time into the A-KAZE scale space, src/Regard3DFeatures.cpp:71-125 -- HBM does not need that),
  * or with several device ids to spread the list over the GPUs of a node.  Images whose <feat> AND <desc> files already exist are
  * skipped like processWorkItem does (:139-142); skipped[i] (optional) says so and n_features[i] (optional) then carries the row
@@ -319,6 +338,14 @@ int r3dm_multi_filter_E(r3dm_multi* m, const r3dm_graph* putative, double max_re
 int r3dm_multi_extract_features(r3dm_multi* m, uint32_t n_images, const float* const* grays, const uint32_t* widths,
                                 const uint32_t* heights, float threshold, const char* const* feat_paths,
                                 const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped, char* err, size_t err_cap);
+/* the general form: per image either grays[i] (gray / 255 floats) or bgrs[i] (decoded 8-bit BGR, what cv::imread hands
+ * processWorkItem, src/threads/R3DFeaturesThread.cpp:163-165: the float / 255 -> BGR2GRAY conversion then runs on the device);
+ * either array may be NULL as a whole.  batch: images per detector pass of a worker, 0 = the default (8; fewer when HBM or the list
+ * is short).  A worker's batch is a run of images of one size and one kind. */
+int r3dm_multi_extract_features_ex(r3dm_multi* m, uint32_t n_images, const float* const* grays, const unsigned char* const* bgrs,
+                                   const uint32_t* widths, const uint32_t* heights, float threshold, const char* const* feat_paths,
+                                   const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped, uint32_t batch,
+                                   char* err, size_t err_cap);
 /* owner_out[p] = the device / rank (0..world-1) that the snake deal gives pair p.  Pure host code (no GPU needed). */
 int r3dm_shard_pairs(const uint32_t* pairs_ij, uint64_t n_pairs, uint32_t world, uint32_t* owner_out);
 
@@ -351,12 +378,32 @@ typedef struct {
     uint64_t n_split_mfma;         /* launches of the dominant kernel that ran as the split-f16 nominator */
     uint64_t n_views_staged;       /* views / datasets / query sets copied + re-laid-out by this context since r3dm_create */
     uint64_t n_hamming_mfma;       /* launches of the Hamming matcher that ran as the MFMA formulation */
-    uint64_t n_ak_graph_replays;   /* r3dm_detect_akaze calls whose scale space ran as one hipGraph launch (since r3dm_create) */
+    uint64_t n_detect_images;      /* images of the last detector pass (r3dm_detect_akaze: 1; the batch entries: B)                   */
     uint64_t n_ann_rows16;         /* graph-search launches that gathered the bf16 row copy (integer-valued views: same distances, half the bytes) */
     uint64_t n_ann_rows8;          /* ... the u8 row copy (integers 0 .. 255: a quarter of the bytes)                                          */
     uint64_t n_ann_dot8;           /* ... of those, launches whose query views are bytes too: distances as exact integer dot products (v_dot4_u32_u8) */
+    /* the last detector pass (r3dm_detect_akaze*, r3dm_extract_features_*) */
+    double   ms_detect_kernels;    /* HIP-event time from the first scale-space launch to the keypoint compaction, all images of the pass */
+    double   detect_algorithmic_bytes; /* HBM bytes the pass structure implies: every stencil pass reads / writes whole image planes once */
+    double   ms_liop_wall;         /* host + device time of the LIOP half of the last features pass (patch maps, two launches, copy back) */
+    double   ms_feature_files;     /* time spent writing the .feat / .desc files of the last features pass                              */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
+
+/* ---- totals of the features work this context has done since r3dm_create (never reset: a stage that runs many batches on several
+ * contexts adds them up; R3DFeaturesThread keeps doneCount_ / numberOfKeypoints_ the same way, src/threads/R3DFeaturesThread.cpp:32-36) ---- */
+typedef struct {
+    uint64_t n_images;                 /* images through the detector                                                         */
+    uint64_t n_passes;                 /* detector passes (batches)                                                            */
+    uint64_t n_keypoints;              /* keypoints found                                                                      */
+    uint64_t n_regrows;                /* detection phases repeated because an image had more candidates than slots            */
+    double   ms_detect_kernels;        /* HIP-event time, first scale-space launch .. keypoint compaction                      */
+    double   detect_algorithmic_bytes; /* HBM bytes the pass structure implies (every stencil pass moves whole planes once)    */
+    double   ms_liop_kernels;          /* HIP-event time of the LIOP patch extraction + descriptor launches                     */
+    double   ms_wall;                  /* wall time inside the features entry points (detector + LIOP + copies + files)        */
+    double   ms_files;                 /* of which: writing .feat / .desc                                                      */
+} r3dm_features_totals;
+int r3dm_get_features_totals(const r3dm_ctx* ctx, r3dm_features_totals* out);
 
 #ifdef __cplusplus
 }

@@ -23,8 +23,9 @@ EXPORTS = [
     "r3dm_match_pairs", "r3dm_filter_F", "r3dm_filter_H", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
-    "r3dm_compute_matches_dir", "r3dm_liop_describe_patches", "r3dm_extract_liop",
-    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
+    "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_liop_describe_patches", "r3dm_extract_liop",
+    "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
+    "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
@@ -45,7 +46,66 @@ class Stats(C.Structure):
                 ("ms_ann_build", C.c_double), ("ms_ann_search", C.c_double), ("n_ann_built", C.c_uint64),
                 ("n_ann_dist", C.c_uint64), ("ms_detect", C.c_double), ("n_integer_mfma", C.c_uint64),
                 ("n_split_mfma", C.c_uint64), ("n_views_staged", C.c_uint64),
-                ("n_hamming_mfma", C.c_uint64), ("n_ak_graph_replays", C.c_uint64), ("n_ann_rows16", C.c_uint64), ("n_ann_rows8", C.c_uint64), ("n_ann_dot8", C.c_uint64)]
+                ("n_hamming_mfma", C.c_uint64), ("n_detect_images", C.c_uint64), ("n_ann_rows16", C.c_uint64), ("n_ann_rows8", C.c_uint64), ("n_ann_dot8", C.c_uint64),
+                ("ms_detect_kernels", C.c_double), ("detect_algorithmic_bytes", C.c_double),
+                ("ms_liop_wall", C.c_double), ("ms_feature_files", C.c_double)]
+
+
+class FeaturesTotals(C.Structure):
+    """r3dm_features_totals: the features work of one context since its creation"""
+    _fields_ = [("n_images", C.c_uint64), ("n_passes", C.c_uint64), ("n_keypoints", C.c_uint64), ("n_regrows", C.c_uint64),
+                ("ms_detect_kernels", C.c_double), ("detect_algorithmic_bytes", C.c_double), ("ms_liop_kernels", C.c_double),
+                ("ms_wall", C.c_double), ("ms_files", C.c_double)]
+
+
+class ViewImage(C.Structure):
+    """r3dm_view_image (include/r3d_compute_matches.hpp)"""
+    _fields_ = [("id", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("basename", C.c_char_p),
+                ("bgr8", C.c_void_p), ("gray", C.c_void_p), ("focal_px", C.c_double), ("ppx", C.c_double), ("ppy", C.c_double)]
+
+
+class StageReport(C.Structure):
+    """r3dm_stage_report: wall time of the phases of R3DComputeMatches::computeMatches (ms), kernel times, counts"""
+    _fields_ = [(k, C.c_double) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total",
+                                          "ms_match_kernels", "ms_F_kernels", "ms_E_kernels", "ms_H_kernels")] + \
+               [(k, C.c_uint64) for k in ("images_extracted", "n_keypoints", "n_putative_pairs", "n_putative_matches", "n_F_pairs", "n_F_matches",
+                                          "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches")] + [("features", FeaturesTotals)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "features"}
+        d["features"] = {k: getattr(self.features, k) for k, _ in FeaturesTotals._fields_}
+        return d
+
+
+def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6,
+                          matching_algorithm: int = 9, compute_F: bool = True, compute_E: bool = True, compute_H: bool = True,
+                          seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8) -> StageReport:
+    """R3DComputeMatches::computeMatches from pixels (r3dm_compute_matches_stage): features stage for the views whose .feat/.desc
+    are missing, matching, F / E / H filters, match files.  views: dicts with id, width, height, basename and optionally
+    gray ([h, w] float32) or bgr ([h, w, 3] uint8) -- numpy or torch (host or device) -- and focal_px / ppx / ppy."""
+    L = load_library()
+    keep = []
+    arr = (ViewImage * max(len(views), 1))()
+    for k, v in enumerate(views):
+        def ptr(a, dt):
+            if a is None:
+                return None
+            if not hasattr(a, "data_ptr"):
+                a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
+        arr[k] = ViewImage(int(v["id"]), int(v["width"]), int(v["height"]), v["basename"].encode(), ptr(v.get("bgr"), np.uint8),
+                           ptr(v.get("gray"), np.float32), float(v.get("focal_px", -1.0)), float(v.get("ppx", 0.0)), float(v.get("ppy", 0.0)))
+    ids = (C.c_int * len(device_ids))(*device_ids)
+    rep = StageReport(); err = C.create_string_buffer(1024)
+    L.r3dm_compute_matches_stage.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+    rc = L.r3dm_compute_matches_stage(ids, len(device_ids), matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm,
+                                      int(compute_F), int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
+                                      C.byref(rep), err, 1024)
+    if rc != 0:
+        raise R3dmError(f"r3dm_compute_matches_stage -> {rc}: {err.value.decode()}")
+    return rep
 
 
 class KGraphParams(C.Structure):
@@ -125,6 +185,9 @@ def load_library():
     L.r3dm_gray_from_bgr8.argtypes = [vp, vp, u32, u32, vp]
     L.r3dm_extract_features_to_files.argtypes = [vp, vp, u32, u32, C.c_float, C.c_char_p, C.c_char_p, C.POINTER(u32)]
     L.r3dm_multi_extract_features.argtypes = [vp, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
+    L.r3dm_multi_extract_features_ex.argtypes = [vp, u32, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, u32, C.c_char_p, C.c_size_t]
+    L.r3dm_detect_akaze_batch.argtypes = [vp, u32, vp, u32, u32, C.c_float, vp, vp, u32, vp]
+    L.r3dm_extract_features_batch.argtypes = [vp, u32, vp, vp, u32, u32, C.c_float, vp, vp, vp]
     L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]
     L.r3dm_ann_params_for_algorithm.argtypes = [C.c_int, vp]
     L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
@@ -476,6 +539,34 @@ class Context:
         k = min(n.value, cap)
         return kps[:k].copy(), desc[:k].copy()
 
+    def detect_akaze_batch(self, images, threshold: float = 0.001, cap: int = 200000):
+        """r3dm_detect_akaze_batch: B same-size images (numpy or torch, host or device) in one pass of the detector
+        -> list of (keypoints [n, 4], responses [n])"""
+        imgs = [im if hasattr(im, "data_ptr") else np.ascontiguousarray(im, np.float32) for im in images]
+        B = len(imgs); h, w = int(imgs[0].shape[0]), int(imgs[0].shape[1])
+        assert all(tuple(im.shape) == (h, w) for im in imgs), "a batch holds images of one size"
+        ip = (C.c_void_p * B)(*[(im.data_ptr() if hasattr(im, "data_ptr") else im.ctypes.data) for im in imgs])
+        kps = [np.zeros((cap, 4), np.float32) for _ in range(B)]; resp = [np.zeros(cap, np.float32) for _ in range(B)]
+        kp_p = (C.c_void_p * B)(*[k.ctypes.data for k in kps]); rp_p = (C.c_void_p * B)(*[r.ctypes.data for r in resp])
+        n = np.zeros(B, np.uint32)
+        self._check(self._L.r3dm_detect_akaze_batch(self._h, B, ip, w, h, threshold, kp_p, rp_p, cap, _ptr(n)), "r3dm_detect_akaze_batch")
+        return [(kps[b][:min(int(n[b]), cap)].copy(), resp[b][:min(int(n[b]), cap)].copy()) for b in range(B)]
+
+    def extract_features_batch(self, images, feat_paths, desc_paths, threshold: float = 0.001, bgr: bool = False):
+        """r3dm_extract_features_batch: detector + LIOP + .feat / .desc files of B same-size images in one pass.
+        images: [h, w] float32 gray / 255, or with bgr=True [h, w, 3] uint8 as cv::imread decodes -> n_features [B]"""
+        if bgr:
+            imgs = [im if hasattr(im, "data_ptr") else np.ascontiguousarray(im, np.uint8) for im in images]
+        else:
+            imgs = [im if hasattr(im, "data_ptr") else np.ascontiguousarray(im, np.float32) for im in images]
+        B = len(imgs); h, w = int(imgs[0].shape[0]), int(imgs[0].shape[1])
+        ip = (C.c_void_p * B)(*[(im.data_ptr() if hasattr(im, "data_ptr") else im.ctypes.data) for im in imgs])
+        fp = (C.c_char_p * B)(*[p.encode() for p in feat_paths]); dp = (C.c_char_p * B)(*[p.encode() for p in desc_paths])
+        nf = np.zeros(B, np.uint32)
+        self._check(self._L.r3dm_extract_features_batch(self._h, B, None if bgr else ip, ip if bgr else None, w, h, threshold, fp, dp, _ptr(nf)),
+                    "r3dm_extract_features_batch")
+        return nf
+
     def gray_from_bgr8(self, bgr: np.ndarray) -> np.ndarray:
         bgr = np.ascontiguousarray(bgr, np.uint8)
         out = np.zeros(bgr.shape[:2], np.float32)
@@ -495,6 +586,11 @@ class Context:
         arr = (PairReport * max(n, 1))()
         self._L.r3dm_filter_report(self._h, arr, n)
         return [(r.threshold_px, r.nfa, r.iterations, r.models, r.inliers) for r in arr[:n]]
+
+    def features_totals(self) -> FeaturesTotals:
+        t = FeaturesTotals()
+        self._check(self._L.r3dm_get_features_totals(self._h, C.byref(t)), "r3dm_get_features_totals")
+        return t
 
     def stats(self) -> Stats:
         s = Stats()
@@ -565,18 +661,23 @@ class MultiContext:
     def set_integer_mfma(self, enable: bool = True):
         self._check(self._L.r3dm_multi_set_integer_mfma(self._h, int(bool(enable))), "r3dm_multi_set_integer_mfma")
 
-    def extract_features(self, images, feat_paths, desc_paths, threshold: float = 0.001):
-        """r3dm_multi_extract_features: the features stage over an image list, one image in flight per context.
-        images: list of [h, w] float32 arrays (gray / 255), host (numpy) or device (anything with data_ptr(): torch tensors).
+    def extract_features(self, images, feat_paths, desc_paths, threshold: float = 0.001, bgr: bool = False, batch: int = 0):
+        """r3dm_multi_extract_features(_bgr8): the features stage over an image list, one BATCH of same-size images in flight per context.
+        images: list of [h, w] float32 arrays (gray / 255) -- or, with bgr=True, [h, w, 3] uint8 as cv::imread decodes --
+        host (numpy) or device (anything with data_ptr(): torch tensors).
         -> (n_features [N], skipped [N] bool)"""
-        imgs = [im if hasattr(im, "data_ptr") else np.ascontiguousarray(im, np.float32) for im in images]
+        imgs = [im if hasattr(im, "data_ptr") else np.ascontiguousarray(im, np.uint8 if bgr else np.float32) for im in images]
         n = len(imgs)
         gp = (C.c_void_p * n)(*[(im.data_ptr() if hasattr(im, "data_ptr") else im.ctypes.data) for im in imgs])
         ws = np.array([im.shape[1] for im in imgs], np.uint32); hs = np.array([im.shape[0] for im in imgs], np.uint32)
         fp = (C.c_char_p * n)(*[p.encode() for p in feat_paths]); dp = (C.c_char_p * n)(*[p.encode() for p in desc_paths])
         nf = np.zeros(n, np.uint32); sk = np.zeros(n, np.uint32)
         err = C.create_string_buffer(512)
-        rc = self._L.r3dm_multi_extract_features(self._h, n, gp, _ptr(ws), _ptr(hs), threshold, fp, dp, _ptr(nf), _ptr(sk), err, 512)
+        if bgr or batch:
+            rc = self._L.r3dm_multi_extract_features_ex(self._h, n, None if bgr else gp, gp if bgr else None, _ptr(ws), _ptr(hs), threshold, fp, dp,
+                                                        _ptr(nf), _ptr(sk), batch, err, 512)
+        else:
+            rc = self._L.r3dm_multi_extract_features(self._h, n, gp, _ptr(ws), _ptr(hs), threshold, fp, dp, _ptr(nf), _ptr(sk), err, 512)
         if rc != 0:
             raise R3dmError(f"r3dm_multi_extract_features -> {rc}: {err.value.decode()}")
         return nf, sk.astype(bool)

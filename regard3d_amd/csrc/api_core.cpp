@@ -48,7 +48,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
                       &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill, &c->f_soff, &c->f_order};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
-    if (c->ak_graph) (void)hipGraphExecDestroy(c->ak_graph);
+    c->pin_desc.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -71,7 +71,13 @@ extern "C" int r3dm_get_stats(const r3dm_ctx* c, r3dm_stats* out)
     if (!c || !out) return R3DM_ERR_INVALID;
     *out = c->stats;
     out->n_views_staged = c->n_views_staged;
-    out->n_ak_graph_replays = c->n_ak_graph_replays;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_get_features_totals(const r3dm_ctx* c, r3dm_features_totals* out)
+{
+    if (!c || !out) return R3DM_ERR_INVALID;
+    *out = c->feat_totals;
     return R3DM_OK;
 }
 

@@ -5,6 +5,8 @@
 // HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
 #include "r3dm_ctx.hpp"
 
+#include <charconv>
+
 // ------------------------------------------------------------------------------------------------
 // keypoint detection: Fast-A-KAZE (kernels_akaze.hip)
 // ------------------------------------------------------------------------------------------------
@@ -119,33 +121,72 @@ void ak_area_tab(int ssize, int dsize, std::vector<AkAreaTab>& tab, std::vector<
 
 }  // namespace
 
-static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
-                             float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out, unsigned char* mldb_out)
+// ------------------------------------------------------------------------------------------------
+// The detector over a BATCH of B same-size images.  One image alone cannot fill the chip below the first octave: its ~550
+// dependent launches are a few microseconds each (profiles/r02_e_akaze_kernel_stats.txt), so a single image waits for launch
+// latency, not for HBM.  The launch sequence depends on the image SIZE only, so the same ~550 launches serve B images
+// (blockIdx.z = image), and nothing in the chain goes to the host: the k-contrast stays on the device, the candidate slots are
+// laid out on the device from a capacity (ak_layout_kernel) instead of counts read back, list lengths are read by grid-stride
+// kernels, and the survivors of all levels are compacted into one 32-byte record per keypoint (ak_compact_kernel).  The host sees
+// the batch twice: the per-image counts, then the records.
+// ------------------------------------------------------------------------------------------------
+struct AkBatchOut {
+    std::vector<AkLevelHost> lv;                       // evolution levels of this image size
+    std::vector<std::vector<AkKpRec>> recs;            // per image: surviving keypoints in the reference's order (level, list)
+};
+
+// angle of a keypoint: getAngleV2(maxX, maxY) (fast-akaze utils.h:11-19: atan2f of the host libm, + 2 pi when negative)
+static inline float ak_theta(const AkKpRec& r)
 {
-    if (!c || !image || !n_out || (cap && !keypoints_out)) return R3DM_ERR_INVALID;
-    *n_out = 0;
-    if (width < 3 || height < 3 || (uint64_t)width * height > (1ull << 30)) return R3DM_ERR_INVALID;
+    float theta = atan2f(r.max_y, r.max_x);
+    if (!(theta >= 0)) theta = theta + (float)(2.0f * 3.1415926535897932384626433832795);
+    return theta;
+}
+// ... and the conversion of detectKeypoints (src/Regard3DFeatures.cpp:604-613): degrees, + 90, wrapped into [0, 360]
+static inline float ak_angle_deg(float theta)
+{
+    float ang = theta;
+    ang *= 180.0 / 3.1415926535897932384626433832795;
+    ang += 90.0f;
+    while (ang < 0) ang += 360.0f;
+    while (ang > 360.0f) ang -= 360.0f;
+    return ang;
+}
+
+// images: B pointers to height x width floats (host or device), or bgrs: B pointers to height x width x 3 bytes (cv::imread's
+// BGR order; converted on the device exactly as processWorkItem does, src/threads/R3DFeaturesThread.cpp:163-191).
+// Leaves the B gray images in ak_bufs[0] (B planes) for the LIOP patch extraction and the level images for MLDB.
+static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, const unsigned char* const* bgrs,
+                           uint32_t width, uint32_t height, float threshold, AkBatchOut& out)
+{
+    if (!c || B == 0 || (!images && !bgrs)) return R3DM_ERR_INVALID;
+    for (uint32_t b = 0; b < B; ++b) if (!(images ? (const void*)images[b] : (const void*)bgrs[b])) return R3DM_ERR_INVALID;
+    out.recs.assign(B, std::vector<AkKpRec>());
+    if (width < 3 || height < 3 || (uint64_t)width * height > (1ull << 30) || B > 4096) return R3DM_ERR_INVALID;
     R3DM_HIP(c, hipSetDevice(c->device));
     const double t_call = now_ms();
-    const int w = (int)width, h = (int)height;
-    const std::vector<AkLevelHost> lv = ak_levels(w, h);
+    const int w = (int)width, h = (int)height, iB = (int)B;
+    out.lv = ak_levels(w, h);
+    const std::vector<AkLevelHost>& lv = out.lv;
     const int nl = (int)lv.size();
-    if (nl == 0) return R3DM_OK;                                  // image too small for a single evolution level
+    c->stats.n_detect_images = B; c->stats.ms_detect_kernels = 0.0; c->stats.detect_algorithmic_bytes = 0.0;
+    if (nl == 0) { c->stats.ms_detect = now_ms() - t_call; return R3DM_OK; }     // image too small for a single evolution level
     hipStream_t st = c->stream;
     const size_t n0 = (size_t)w * h;
 
-    // ---- buffers: [0] image, [1..10] level-0 sized work images, then 4 per level (Lt, Lx, Ly, Ldet)
+    // ---- buffers, each B planes: [0] image, [1..10] level-0 sized work images, then 4 per level (Lt, Lx, Ly, Ldet)
     enum { B_IMG = 0, B_SMOOTH, B_LXX, B_LXY, B_LYY, B_TMP, B_TMP2, B_WX, B_WY, B_FLOW, B_LT2, B_SMALL, B_LEVEL0 };
-    if (c->ak_w != w || c->ak_h != h || c->ak_bufs.size() != (size_t)B_LEVEL0 + 4 * nl + 8) {
+    if (c->ak_w != w || c->ak_h != h || c->ak_B < iB || c->ak_bufs.size() != (size_t)B_LEVEL0 + 4 * nl + 8) {
         for (DevBuf& b : c->ak_bufs) b.release();
         c->ak_bufs.assign((size_t)B_LEVEL0 + 4 * nl + 8, DevBuf());
-        c->ak_w = w; c->ak_h = h;
+        c->ak_w = w; c->ak_h = h; c->ak_B = iB;
     }
+    const size_t PB = (size_t)c->ak_B;                            // planes per buffer (the largest batch of this size so far)
     auto buf = [&](int k) -> DevBuf& { return c->ak_bufs[k]; };
-    for (int k = B_IMG; k <= B_LT2; ++k) if (k != B_LYY) R3DM_HIP(c, buf(k).ensure(n0 * 4));      // (Lyy is folded into the determinant kernel)
-    R3DM_HIP(c, buf(B_SMALL).ensure(4096 * 4));
+    for (int k = B_IMG; k <= B_LT2; ++k) if (k != B_LYY) R3DM_HIP(c, buf(k).ensure(PB * n0 * 4));      // (Lyy is folded into the determinant kernel)
+    R3DM_HIP(c, buf(B_SMALL).ensure(PB * 4096 * 4));
     for (int i = 0; i < nl; ++i)
-        for (int q = 0; q < 4; ++q) R3DM_HIP(c, buf(B_LEVEL0 + 4 * i + q).ensure((size_t)lv[i].w * lv[i].h * 4));
+        for (int q = 0; q < 4; ++q) R3DM_HIP(c, buf(B_LEVEL0 + 4 * i + q).ensure(PB * (size_t)lv[i].w * lv[i].h * 4));
     auto Lt = [&](int i) { return buf(B_LEVEL0 + 4 * i).as<float>(); };
     auto Lx = [&](int i) { return buf(B_LEVEL0 + 4 * i + 1).as<float>(); };
     auto Ly = [&](int i) { return buf(B_LEVEL0 + 4 * i + 2).as<float>(); };
@@ -158,7 +199,14 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
     float* flow = buf(B_FLOW).as<float>(); float* lt2 = buf(B_LT2).as<float>();
     uint32_t* small = buf(B_SMALL).as<uint32_t>();
 
-    R3DM_HIP(c, hipMemcpyAsync(img, image, n0 * 4, hipMemcpyDefault, st));
+    if (images) {
+        for (uint32_t b = 0; b < B; ++b) R3DM_HIP(c, hipMemcpyAsync(img + b * n0, images[b], n0 * 4, hipMemcpyDefault, st));
+    } else {
+        // 8-bit BGR -> float / 255 -> gray: the bytes are staged in the (not yet used) work image tmp2
+        unsigned char* stage = reinterpret_cast<unsigned char*>(tmp2);
+        for (uint32_t b = 0; b < B; ++b) R3DM_HIP(c, hipMemcpyAsync(stage + b * n0 * 4, bgrs[b], n0 * 3, hipMemcpyDefault, st));
+        for (uint32_t b = 0; b < B; ++b) R3DM_HIP(c, ak_bgr_to_gray(st, stage + b * n0 * 4, img + b * n0, n0));
+    }
     const AkTaps taps_off = ak_taps(1.6f), taps_one = ak_taps(1.0f);
 
     // INTER_AREA tables of the octave transitions whose size is not an exact halving (they depend on the image size only):
@@ -190,38 +238,46 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
                                     (const int*)(base + offs[4 * i + 2]), (const int*)(base + offs[4 * i + 3])};
         }
     }
-    uint32_t* hmax_bits = small;                  // [0]      maximum of the gradient modulus (float bits)
-    uint32_t* hist = small + 16;                  // [16..)   300-bin histogram
-    float* inv_k2 = reinterpret_cast<float*>(small + 1024);     // [1024 + o] 1 / k^2 of octave o (ak_kcontrast_kernel)
+    // per image (4096 words apart, kernels_akaze.hip kAkSmallWords): [0] maximum of the gradient modulus (float bits),
+    // [16..) 300-bin histogram, [1024 + o] 1 / k^2 of octave o (ak_kcontrast_kernel)
+    uint32_t* hmax_bits = small;
+    uint32_t* hist = small + 16;
+    float* inv_k2 = reinterpret_cast<float*>(small + 1024);
+
+    // algorithmic HBM bytes of the launch sequence: every pass reads / writes whole image planes once
+    double planes_px = 0.0;
+    auto tally = [&](int lw, int lh, int n_planes) { planes_px += (double)lw * lh * n_planes; };
 
     // Compute_Determinant_Hessian_Response_Single (AKAZEFeatures.cpp:389-410)
     auto hessian = [&](int i) -> hipError_t {
         const int lw = lv[i].w, lh = lv[i].h, s = lv[i].sigma_size;
         hipError_t e;
         // three launches: smooth -> (Lx, Ly);  Lx -> (Lxx, Lxy);  Ly -> Lyy, folded into the determinant
-        if ((e = ak_scaled_deriv_xy(st, smooth, Lx(i), Ly(i), lw, lh, s)) != hipSuccess) return e;
-        if ((e = ak_scaled_deriv_xy(st, Lx(i), lxx, lxy, lw, lh, s)) != hipSuccess) return e;
-        return ak_scaled_deriv_det(st, Ly(i), lxx, lxy, Ldet(i), lw, lh, s);
+        if ((e = ak_scaled_deriv_xy(st, smooth, Lx(i), Ly(i), lw, lh, iB, s)) != hipSuccess) return e;
+        if ((e = ak_scaled_deriv_xy(st, Lx(i), lxx, lxy, lw, lh, iB, s)) != hipSuccess) return e;
+        tally(lw, lh, 3 + 3 + 4);
+        return ak_scaled_deriv_det(st, Ly(i), lxx, lxy, Ldet(i), lw, lh, iB, s);
     };
 
     // ---- Create_Nonlinear_Scale_Space (:245-369), Compute_Base_Evolution_Level (:199-237): ~550 launches for a 12 Mpx image,
     // none of which needs the host -- the k-contrast (compute_k_percentileV2: maximum, 300-bin histogram, percentile scan) stays
-    // on the device.  The sequence depends on the image SIZE only, so it CAN be captured into a hipGraph and replayed (below).
+    // on the device.  (Replaying the sequence as a hipGraph was measured SLOWER than issuing it, 15.8 vs 7.5 ms per image:
+    // DESIGN.md section 4.8 (c); the capture code is in the history.)
     auto scale_space = [&]() -> hipError_t {
         hipError_t e;
 #define AK_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
-        AK_TRY(ak_gaussian(st, img, tmp, smooth, w, h, taps_off));
+        AK_TRY(ak_gaussian(st, img, tmp, smooth, w, h, iB, taps_off)); tally(w, h, 4);
         AK_TRY(hessian(0));
-        AK_TRY(hipMemsetAsync(small, 0, 4096 * 4, st));
+        AK_TRY(hipMemsetAsync(small, 0, (size_t)B * 4096 * 4, st));
         const int nbins = 300;
         if (nl > 1) {
-            AK_TRY(ak_gaussian(st, img, tmp, flow, w, h, taps_one));
-            AK_TRY(ak_scharr(st, flow, tmp, tmp2, wx, wy, w, h));
-            AK_TRY(ak_modg_max(st, wx, wy, w, h, hmax_bits));
-            AK_TRY(ak_modg_hist(st, wx, wy, w, h, hmax_bits, nbins, hist));
+            AK_TRY(ak_gaussian(st, img, tmp, flow, w, h, iB, taps_one)); tally(w, h, 4);
+            AK_TRY(ak_scharr(st, flow, tmp, tmp2, wx, wy, w, h, iB)); tally(w, h, 3 + 4);
+            AK_TRY(ak_modg_max(st, wx, wy, w, h, iB, hmax_bits)); tally(w, h, 2);
+            AK_TRY(ak_modg_hist(st, wx, wy, w, h, iB, hmax_bits, nbins, hist)); tally(w, h, 2);
         }
-        AK_TRY(ak_kcontrast(st, hmax_bits, hist, nbins, (uint32_t)((size_t)(w - 2) * (h - 2)), nl > 1 ? 1 : 0, inv_k2));
-        AK_TRY(hipMemcpyAsync(Lt(0), smooth, n0 * 4, hipMemcpyDeviceToDevice, st));
+        AK_TRY(ak_kcontrast(st, hmax_bits, hist, nbins, (uint32_t)((size_t)(w - 2) * (h - 2)), nl > 1 ? 1 : 0, inv_k2, iB));
+        AK_TRY(hipMemcpyAsync(Lt(0), smooth, (size_t)B * n0 * 4, hipMemcpyDeviceToDevice, st)); tally(w, h, 2);
         for (int i = 1; i < nl; ++i) {
             const int lw = lv[i].w, lh = lv[i].h;
             const size_t n = (size_t)lw * lh;
@@ -232,152 +288,138 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
                 // to whichever of the two the first step does not write
                 float* half = (tau.size() % 2 == 1) ? lt2 : Lt(i);
                 const HalfTabs& ht = half_tabs[i];
-                AK_TRY(ak_halfsample(st, Lt(i - 1), half, lv[i - 1].w, lv[i - 1].h, ht.xt, ht.xb, ht.yt, ht.yb));
+                AK_TRY(ak_halfsample(st, Lt(i - 1), half, lv[i - 1].w, lv[i - 1].h, iB, ht.xt, ht.xb, ht.yt, ht.yb));
+                tally(lv[i - 1].w, lv[i - 1].h, 1); tally(lw, lh, 1);
                 start = half;
             } else {
                 start = Lt(i - 1);                                  // same octave: the previous level IS the start image, no copy
             }
             if (tau.empty()) {                                      // (never for the reference's time steps) plain copy
-                if (start != Lt(i)) AK_TRY(hipMemcpyAsync(Lt(i), start, n * 4, hipMemcpyDeviceToDevice, st));
+                if (start != Lt(i)) AK_TRY(hipMemcpyAsync(Lt(i), start, (size_t)B * n * 4, hipMemcpyDeviceToDevice, st));
                 start = Lt(i);
             }
-            AK_TRY(ak_gaussian(st, start, tmp, smooth, lw, lh, taps_one));
+            AK_TRY(ak_gaussian(st, start, tmp, smooth, lw, lh, iB, taps_one)); tally(lw, lh, 4);
             AK_TRY(hessian(i));
-            AK_TRY(ak_scharr_g2(st, smooth, flow, lw, lh, inv_k2 + lv[i].octave));      // kcontrast * 0.75^octave
+            AK_TRY(ak_scharr_g2(st, smooth, flow, lw, lh, iB, inv_k2 + lv[i].octave)); tally(lw, lh, 2);     // kcontrast * 0.75^octave
             // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; step k of n writes Lt(i) when n - k is even, else the work image
             const float* cur = start;
             for (size_t k = 1; k <= tau.size(); ++k) {
-                float* out = ((tau.size() - k) % 2 == 0) ? Lt(i) : lt2;
-                AK_TRY(ak_fed_step(st, cur, flow, out, lw, lh, tau[k - 1]));
-                cur = out;
+                float* o = ((tau.size() - k) % 2 == 0) ? Lt(i) : lt2;
+                AK_TRY(ak_fed_step(st, cur, flow, o, lw, lh, iB, tau[k - 1])); tally(lw, lh, 3);
+                cur = o;
             }
         }
 #undef AK_TRY
         return hipSuccess;
     };
-    // Measured (profiles/r02_e_akaze_perf.txt): replaying the ~600-node graph costs MORE than issuing the launches -- 15.8 ms per
-    // 12 Mpx image against 7.5 ms with plain stream launches (the runtime walks the nodes one by one at ~20 us each) -- so the
-    // capture stays a developer option (R3DM_AK_GRAPH=1 in the developer build); the product issues the launches directly.
-    static const bool use_graph = r3dm_dev_knob("R3DM_AK_GRAPH", 0) != 0;
-    bool replayed = false;
-    if (use_graph && !c->ak_graph_off) {
-        if (c->ak_graph && (c->ak_graph_w != w || c->ak_graph_h != h)) { (void)hipGraphExecDestroy(c->ak_graph); c->ak_graph = nullptr; }
-        if (!c->ak_graph) {
-            hipGraph_t g = nullptr;
-            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
-            if (e == hipSuccess) {
-                const hipError_t el = scale_space();
-                e = hipStreamEndCapture(st, &g);
-                if (e == hipSuccess) e = el;
-            }
-            if (e == hipSuccess) e = hipGraphInstantiate(&c->ak_graph, g, nullptr, nullptr, 0);
-            if (g) (void)hipGraphDestroy(g);
-            if (e != hipSuccess) { c->ak_graph = nullptr; c->ak_graph_off = true; (void)hipGetLastError(); }
-            else { c->ak_graph_w = w; c->ak_graph_h = h; }
-        }
-        if (c->ak_graph) { R3DM_HIP(c, hipGraphLaunch(c->ak_graph, st)); replayed = true; }
-    }
-    if (!replayed) R3DM_HIP(c, scale_space());
-    c->n_ak_graph_replays += replayed ? 1 : 0;
+    R3DM_HIP(c, hipEventRecord(c->ev0, st));
+    R3DM_HIP(c, scale_space());
 
     // ---- Feature_Detection (:371-382): extrema -> in-level pruning -> cross-level pruning -> refinement + orientation
-    std::vector<AkLevelDev> ld(nl);
-    size_t rows_total = 0;
-    for (int i = 0; i < nl; ++i) rows_total += (size_t)std::max(0, lv[i].h - 2 * lv[i].border);
-    DevBuf& meta = buf(B_LEVEL0 + 4 * nl);                        // row counts/offsets + per-level counters + level table
-    R3DM_HIP(c, meta.ensure(rows_total * 8 + (size_t)nl * 16 + (size_t)nl * sizeof(AkLevelDev) + 256));
-    R3DM_HIP(c, hipMemsetAsync(meta.p, 0, rows_total * 8 + (size_t)nl * 16, st));
+    std::vector<AkLevelDev> ld((size_t)nl * B);
+    size_t rows_img = 0;
+    for (int i = 0; i < nl; ++i) rows_img += (size_t)std::max(0, lv[i].h - 2 * lv[i].border);
+    const size_t rows_total = rows_img * B, n_lv = (size_t)nl * B;
+    // row counts + row offsets, per-level counters (4 words), level table, per-image meta
+    DevBuf& meta = buf(B_LEVEL0 + 4 * nl);
+    const size_t off_levels = ((rows_total * 8 + n_lv * 16 + 15) / 16) * 16;
+    const size_t off_bmeta = off_levels + ((n_lv * sizeof(AkLevelDev) + 15) / 16) * 16;
+    R3DM_HIP(c, meta.ensure(off_bmeta + (size_t)B * sizeof(AkBatchMeta) + 256));
+    uint32_t* rc = meta.as<uint32_t>();
+    uint32_t* cnt = rc + 2 * rows_total;
+    AkLevelDev* d_levels = reinterpret_cast<AkLevelDev*>(meta.as<unsigned char>() + off_levels);
+    AkBatchMeta* d_bmeta = reinterpret_cast<AkBatchMeta*>(meta.as<unsigned char>() + off_bmeta);
     {
-        uint32_t* rc = meta.as<uint32_t>();
-        uint32_t* cnt = rc + 2 * rows_total;
         size_t ro = 0;
-        for (int i = 0; i < nl; ++i) {
-            AkLevelDev& L = ld[i];
-            L = AkLevelDev{};
-            L.w = lv[i].w; L.h = lv[i].h; L.border = lv[i].border; L.ratio = lv[i].ratio; L.psize = lv[i].esigma * 1.5f;
-            L.Ldet = Ldet(i); L.Lx = Lx(i); L.Ly = Ly(i); L.Lt = Lt(i);
-            L.row_cnt = rc + ro; L.row_off = rc + rows_total + ro; L.counts = cnt + 4 * i;
-            ro += (size_t)std::max(0, lv[i].h - 2 * lv[i].border);
-        }
+        for (uint32_t b = 0; b < B; ++b)
+            for (int i = 0; i < nl; ++i) {
+                AkLevelDev& L = ld[(size_t)b * nl + i];
+                L = AkLevelDev{};
+                const size_t plane = (size_t)lv[i].w * lv[i].h;
+                L.w = lv[i].w; L.h = lv[i].h; L.border = lv[i].border; L.ratio = lv[i].ratio; L.psize = lv[i].esigma * 1.5f;
+                L.Ldet = Ldet(i) + b * plane; L.Lx = Lx(i) + b * plane; L.Ly = Ly(i) + b * plane; L.Lt = Lt(i) + b * plane;
+                L.row_cnt = rc + ro; L.row_off = rc + rows_total + ro; L.counts = cnt + 4 * ((size_t)b * nl + i);
+                ro += (size_t)std::max(0, lv[i].h - 2 * lv[i].border);
+            }
     }
-    AkLevelDev* d_levels = reinterpret_cast<AkLevelDev*>(meta.as<unsigned char>() + ((rows_total * 8 + (size_t)nl * 16 + 15) / 16) * 16);
     int max_rows = 0;
     for (int i = 0; i < nl; ++i) max_rows = std::max(max_rows, lv[i].h - 2 * lv[i].border);
-    R3DM_HIP(c, hipMemcpyAsync(d_levels, ld.data(), nl * sizeof(AkLevelDev), hipMemcpyHostToDevice, st));
-    R3DM_HIP(c, ak_extrema(st, d_levels, nl, max_rows, threshold, 0));          // all levels in one launch
-    R3DM_HIP(c, ak_scan_rows(st, d_levels, nl));
-    std::vector<uint32_t> counts(4 * (size_t)nl);
-    R3DM_HIP(c, hipMemcpyAsync(counts.data(), ld[0].counts, counts.size() * 4, hipMemcpyDeviceToHost, st));
-    R3DM_HIP(c, hipStreamSynchronize(st));
-    size_t cand_total = 0;
-    for (int i = 0; i < nl; ++i) cand_total += counts[4 * i];
-    DevBuf& pts = buf(B_LEVEL0 + 4 * nl + 1);
-    // per candidate slot: cand 16 + list 16 + live 16 + out0 16 + out1 8 + valid 4 + dead 2
-    R3DM_HIP(c, pts.ensure(cand_total * 80 + 256));
-    {
-        unsigned char* base = pts.as<unsigned char>();
-        size_t off = 0;
-        for (int i = 0; i < nl; ++i) {
-            const size_t n = counts[4 * i];
-            ld[i].cand = (float4*)(base + 0 * cand_total * 16) + off;
-            ld[i].list = (float4*)(base + 1 * cand_total * 16) + off;
-            ld[i].live = (float*)(base + 2 * cand_total * 16) + 4 * off;
-            ld[i].out0 = (float4*)(base + 3 * cand_total * 16) + off;
-            ld[i].out1 = (float2*)(base + 4 * cand_total * 16) + off;
-            ld[i].out_valid = (uint32_t*)(base + 4 * cand_total * 16 + cand_total * 8) + off;
-            ld[i].dead_lower = base + 4 * cand_total * 16 + cand_total * 12 + off;
-            ld[i].dead_upper = base + 4 * cand_total * 16 + cand_total * 13 + off;
-            off += n;
-        }
+    // slot capacity per image: a strict 3x3 maximum excludes its eight neighbours, so a level holds at most ceil(w/2) ceil(h/2)
+    // candidates; start from min(that bound, 256 k) and grow only if an image reports more (the bound itself never overflows)
+    uint64_t bound = 0;
+    for (int i = 0; i < nl; ++i) bound += (uint64_t)((lv[i].w + 1) / 2) * (uint64_t)((lv[i].h + 1) / 2);
+    // (R3DM_AK_CAP, developer build only: a tiny first capacity so that the tests reach the grow-and-repeat path)
+    static const uint32_t cap0 = (uint32_t)std::max(1, r3dm_dev_knob("R3DM_AK_CAP", 1 << 18));
+    uint32_t cap = (uint32_t)std::min<uint64_t>(bound, std::max<uint64_t>(c->ak_cap, cap0));
+    std::vector<AkBatchMeta> bm(B);
+    DevBuf& slots = buf(B_LEVEL0 + 4 * nl + 1);
+    DevBuf& recs = buf(B_LEVEL0 + 4 * nl + 4);
+    for (int attempt = 0;; ++attempt) {
+        const size_t field = (size_t)B * cap;
+        R3DM_HIP(c, slots.ensure(field * kAkSlotBytes + 256));
+        R3DM_HIP(c, recs.ensure(field * sizeof(AkKpRec) + 256));
+        R3DM_HIP(c, hipMemsetAsync(meta.p, 0, rows_total * 8 + n_lv * 16, st));
+        R3DM_HIP(c, hipMemcpyAsync(d_levels, ld.data(), n_lv * sizeof(AkLevelDev), hipMemcpyHostToDevice, st));
+        R3DM_HIP(c, ak_extrema(st, d_levels, nl, iB, max_rows, threshold, 0));          // all levels of all images in one launch
+        R3DM_HIP(c, ak_scan_rows(st, d_levels, nl, iB));
+        R3DM_HIP(c, ak_layout(st, d_levels, nl, iB, slots.as<unsigned char>(), cap, d_bmeta));
+        R3DM_HIP(c, hipMemsetAsync(slots.as<unsigned char>() + field * 76, 0, field * 2, st));   // dead_lower / dead_upper flags
+        R3DM_HIP(c, ak_extrema(st, d_levels, nl, iB, max_rows, threshold, 1));
+        R3DM_HIP(c, ak_prune_levels(st, d_levels, nl, iB));
+        R3DM_HIP(c, ak_cross(st, d_levels, nl, iB, 0));
+        R3DM_HIP(c, ak_cross(st, d_levels, nl, iB, 1));
+        R3DM_HIP(c, ak_refine(st, d_levels, nl, iB));
+        R3DM_HIP(c, ak_compact(st, d_levels, nl, iB, recs.as<AkKpRec>(), cap, d_bmeta));
+        R3DM_HIP(c, hipEventRecord(c->ev1, st));
+        R3DM_HIP(c, hipMemcpyAsync(bm.data(), d_bmeta, (size_t)B * sizeof(AkBatchMeta), hipMemcpyDeviceToHost, st));
+        R3DM_HIP(c, hipStreamSynchronize(st));                                            // host visit 1 of 2: the counts
+        uint32_t need = 0;
+        for (uint32_t b = 0; b < B; ++b) if (bm[b].overflow) need = std::max(need, bm[b].need);
+        if (!need) break;
+        if (attempt >= 2 || need > bound) { c->err = "detector: candidate count exceeds its own bound"; return R3DM_ERR_HIP; }
+        cap = (uint32_t)std::min<uint64_t>(bound, (uint64_t)need + need / 4 + 1024);       // grow and redo the detection phase (the scale space stays)
+        c->feat_totals.n_regrows += 1;
     }
-    R3DM_HIP(c, hipMemsetAsync(pts.as<unsigned char>() + 4 * cand_total * 16 + cand_total * 12, 0, cand_total * 2 + 64, st));
-    R3DM_HIP(c, hipMemcpyAsync(d_levels, ld.data(), nl * sizeof(AkLevelDev), hipMemcpyHostToDevice, st));
-    R3DM_HIP(c, ak_extrema(st, d_levels, nl, max_rows, threshold, 1));
-    R3DM_HIP(c, ak_prune_levels(st, d_levels, nl));
-    R3DM_HIP(c, hipMemcpyAsync(counts.data(), ld[0].counts, counts.size() * 4, hipMemcpyDeviceToHost, st));
-    R3DM_HIP(c, hipStreamSynchronize(st));
-    uint32_t max_list = 0;
-    for (int i = 0; i < nl; ++i) max_list = std::max(max_list, counts[4 * i + 1]);
-    R3DM_HIP(c, ak_cross(st, d_levels, nl, max_list, 0));
-    R3DM_HIP(c, ak_cross(st, d_levels, nl, max_list, 1));
-    R3DM_HIP(c, ak_refine(st, d_levels, nl, max_list));
+    c->ak_cap = cap;
+    c->ak_n_levels = nl;
+    c->ak_levels_dev = d_levels;
+    for (uint32_t b = 0; b < B; ++b) {
+        out.recs[b].resize(bm[b].n_kp);
+        if (bm[b].n_kp) R3DM_HIP(c, hipMemcpyAsync(out.recs[b].data(), recs.as<AkKpRec>() + (size_t)b * cap, (size_t)bm[b].n_kp * sizeof(AkKpRec), hipMemcpyDeviceToHost, st));
+    }
+    R3DM_HIP(c, hipStreamSynchronize(st));                                                // host visit 2 of 2: the records
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    c->stats.ms_detect_kernels = ms;
+    c->stats.detect_algorithmic_bytes = planes_px * 4.0 * B;
+    c->stats.ms_detect = now_ms() - t_call;
+    r3dm_features_totals& T = c->feat_totals;
+    T.n_images += B; T.n_passes += 1; T.ms_detect_kernels += ms; T.detect_algorithmic_bytes += planes_px * 4.0 * B; T.ms_wall += c->stats.ms_detect;
+    for (uint32_t b = 0; b < B; ++b) T.n_keypoints += bm[b].n_kp;
+    return R3DM_OK;
+}
 
-    // ---- gather in (level, list) order; angle = getAngleV2(maxX, maxY) then the detectKeypoints conversion (:604-613)
-    uint32_t n_kp = 0;
+static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height, float threshold,
+                             float* keypoints_out, float* responses_out, uint32_t cap, uint32_t* n_out, unsigned char* mldb_out)
+{
+    if (!c || !image || !n_out || (cap && !keypoints_out)) return R3DM_ERR_INVALID;
+    *n_out = 0;
+    AkBatchOut bo;
+    const int rc = ak_detect_batch(c, 1, &image, nullptr, width, height, threshold, bo);
+    if (rc != R3DM_OK) return rc;
+    const std::vector<AkKpRec>& recs = bo.recs[0];
+    const std::vector<AkLevelHost>& lv = bo.lv;
+    hipStream_t st = c->stream;
+    const uint32_t n_kp = (uint32_t)recs.size();
     std::vector<AkMldbItem> items;
-    // all levels' results are copied back behind the refinement kernel with ONE stream synchronisation
-    std::vector<std::vector<float4>> all0(nl); std::vector<std::vector<float2>> all1(nl); std::vector<std::vector<uint32_t>> allv(nl);
-    for (int i = 0; i < nl; ++i) {
-        const uint32_t n = counts[4 * i + 1];
-        if (!n) continue;
-        all0[i].resize(n); all1[i].resize(n); allv[i].resize(n);
-        R3DM_HIP(c, hipMemcpyAsync(all0[i].data(), ld[i].out0, n * 16, hipMemcpyDeviceToHost, st));
-        R3DM_HIP(c, hipMemcpyAsync(all1[i].data(), ld[i].out1, n * 8, hipMemcpyDeviceToHost, st));
-        R3DM_HIP(c, hipMemcpyAsync(allv[i].data(), ld[i].out_valid, n * 4, hipMemcpyDeviceToHost, st));
-    }
-    R3DM_HIP(c, hipStreamSynchronize(st));
-    for (int i = 0; i < nl; ++i) {
-        const uint32_t n = counts[4 * i + 1];
-        if (!n) continue;
-        const std::vector<float4>& o0 = all0[i]; const std::vector<float2>& o1 = all1[i]; const std::vector<uint32_t>& ov = allv[i];
-        for (uint32_t j = 0; j < n; ++j) {
-            if (!ov[j]) continue;
-            if (n_kp < cap) {
-                float theta = atan2f(o1[j].y, o1[j].x);
-                if (!(theta >= 0)) theta = theta + (float)(2.0f * 3.1415926535897932384626433832795);
-                if (mldb_out)          // Get_MLDB_Full_Descriptor: level coordinates, cos / sin of the raw (radian) angle
-                    items.push_back({(uint32_t)i, o0[j].x / lv[i].ratio, o0[j].y / lv[i].ratio, cosf(theta), sinf(theta), (float)lv[i].sigma_size});
-                float ang = theta;
-                ang *= 180.0 / 3.1415926535897932384626433832795;
-                ang += 90.0f;
-                while (ang < 0) ang += 360.0f;
-                while (ang > 360.0f) ang -= 360.0f;
-                keypoints_out[4 * (size_t)n_kp] = o0[j].x; keypoints_out[4 * (size_t)n_kp + 1] = o0[j].y;
-                keypoints_out[4 * (size_t)n_kp + 2] = o0[j].z; keypoints_out[4 * (size_t)n_kp + 3] = ang;
-                if (responses_out) responses_out[n_kp] = o0[j].w;
-            }
-            ++n_kp;
-        }
+    for (uint32_t k = 0; k < n_kp && k < cap; ++k) {
+        const AkKpRec& r = recs[k];
+        const float theta = ak_theta(r);
+        if (mldb_out)          // Get_MLDB_Full_Descriptor: level coordinates, cos / sin of the raw (radian) angle
+            items.push_back({r.level, r.x / lv[r.level].ratio, r.y / lv[r.level].ratio, cosf(theta), sinf(theta), (float)lv[r.level].sigma_size});
+        keypoints_out[4 * (size_t)k] = r.x; keypoints_out[4 * (size_t)k + 1] = r.y;
+        keypoints_out[4 * (size_t)k + 2] = r.size; keypoints_out[4 * (size_t)k + 3] = ak_angle_deg(theta);
+        if (responses_out) responses_out[k] = r.response;
     }
     if (mldb_out && !items.empty()) {
         // comparison table of MLDB_Binary_Comparisons: per grid, per channel, all value pairs i < j
@@ -387,19 +429,18 @@ static int detect_akaze_impl(r3dm_ctx* c, const float* image, uint32_t width, ui
             for (int pos = 0; pos < 3; ++pos)
                 for (int i = 0; i < cnts[g]; ++i)
                     for (int j = i + 1; j < cnts[g]; ++j) { pairs.push_back((unsigned char)(bases[g] + 3 * i + pos)); pairs.push_back((unsigned char)(bases[g] + 3 * j + pos)); }
-        DevBuf& mb = buf(B_LEVEL0 + 4 * nl + 2);
+        DevBuf& mb = c->ak_bufs[c->ak_bufs.size() - 6];          // B_LEVEL0 + 4 nl + 2
         const size_t ni = items.size();
         R3DM_HIP(c, mb.ensure(ni * sizeof(AkMldbItem) + 1024 + ni * 61 + 64));
         unsigned char* base = mb.as<unsigned char>();
         R3DM_HIP(c, hipMemcpyAsync(base, items.data(), ni * sizeof(AkMldbItem), hipMemcpyHostToDevice, st));
         R3DM_HIP(c, hipMemcpyAsync(base + ni * sizeof(AkMldbItem), pairs.data(), pairs.size(), hipMemcpyHostToDevice, st));
         unsigned char* d_out = base + ni * sizeof(AkMldbItem) + 1024;
-        R3DM_HIP(c, ak_mldb(st, d_levels, (const AkMldbItem*)base, (uint32_t)ni, base + ni * sizeof(AkMldbItem), d_out));
+        R3DM_HIP(c, ak_mldb(st, c->ak_levels_dev, (const AkMldbItem*)base, (uint32_t)ni, base + ni * sizeof(AkMldbItem), d_out));
         R3DM_HIP(c, hipMemcpyAsync(mldb_out, d_out, ni * 61, hipMemcpyDeviceToHost, st));
         R3DM_HIP(c, hipStreamSynchronize(st));
     }
     *n_out = n_kp;
-    c->stats.ms_detect = now_ms() - t_call;
     return R3DM_OK;
 }
 
@@ -426,6 +467,30 @@ extern "C" int r3dm_detect_akaze_mldb(r3dm_ctx* c, const float* image, uint32_t 
                                       float* keypoints_out, unsigned char* descriptors_out, uint32_t cap, uint32_t* n_out)
 {
     return r3dm_guarded(c, [&]() -> int { return r3dm_detect_akaze_mldb_impl(c, image, width, height, threshold, keypoints_out, descriptors_out, cap, n_out); });
+}
+
+// B same-size images in one pass of the detector.  keypoints_out[b]: cap x 4 floats (x, y, size, angle in degrees),
+// responses_out (optional, entries optional): cap floats, n_out[b] = number detected (may exceed cap).
+extern "C" int r3dm_detect_akaze_batch(r3dm_ctx* c, uint32_t n_images, const float* const* images, uint32_t width, uint32_t height,
+                                       float threshold, float* const* keypoints_out, float* const* responses_out, uint32_t cap,
+                                       uint32_t* n_out)
+{
+    return r3dm_guarded(c, [&]() -> int {
+        if (!c || !images || !n_out || (cap && !keypoints_out)) return R3DM_ERR_INVALID;
+        AkBatchOut bo;
+        const int rc = ak_detect_batch(c, n_images, images, nullptr, width, height, threshold, bo);
+        if (rc != R3DM_OK) return rc;
+        for (uint32_t b = 0; b < n_images; ++b) {
+            const std::vector<AkKpRec>& recs = bo.recs[b];
+            n_out[b] = (uint32_t)recs.size();
+            for (uint32_t k = 0; k < recs.size() && k < cap; ++k) {
+                float* o = keypoints_out[b] + 4 * (size_t)k;
+                o[0] = recs[k].x; o[1] = recs[k].y; o[2] = recs[k].size; o[3] = ak_angle_deg(ak_theta(recs[k]));
+                if (responses_out && responses_out[b]) responses_out[b][k] = recs[k].response;
+            }
+        }
+        return R3DM_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -506,6 +571,29 @@ extern "C" int r3dm_liop_describe_patches(r3dm_ctx* c, const float* patches, uin
     return r3dm_guarded(c, [&]() -> int { return r3dm_liop_describe_patches_impl(c, patches, n, side, desc_out, n_resorted); });
 }
 
+// cv::getGaussianKernel(11, 1.2, CV_32F): the blur of every LIOP patch (src/Regard3DFeatures.cpp:807)
+static void liop_blur_taps(float (&kern)[11])
+{
+    const double scale2X = -0.5 / (1.2 * 1.2);
+    double sum = 0;
+    for (int i = 0; i < 11; ++i) { const double xx = i - 5.0; kern[i] = (float)std::exp(scale2X * xx * xx); sum += kern[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < 11; ++i) kern[i] = (float)(kern[i] * sum);
+}
+
+// 2x3 inverse map of one keypoint's patch exactly as src/Regard3DFeatures.cpp:786-799 computes it
+static inline void liop_patch_map(float x, float y, float size, float angle_deg, float kp_size_factor, float* m)
+{
+    const int patchResolution = 20, patchSize = 41;
+    const float angle = -90.0f - angle_deg;
+    const float scale = size / static_cast<float>(patchSize) * kp_size_factor;
+    const float alpha = scale * std::cos(angle * M_PI / 180.0f);
+    const float beta = scale * std::sin(angle * M_PI / 180.0f);
+    const float trans_x = x - static_cast<float>(patchResolution), trans_y = y - static_cast<float>(patchResolution);
+    m[0] = alpha; m[1] = beta;  m[2] = beta * trans_y + alpha * trans_x - beta * y + (1.0f - alpha) * x;
+    m[3] = -beta; m[4] = alpha; m[5] = alpha * trans_y - beta * trans_x + beta * x + (1.0f - alpha) * y;
+}
+
 // resident_image: the image is already on the device (the features stage: r3dm_detect_akaze has just uploaded it into its own
 // buffer, which it only reads) -- then `image` is not copied a second time
 static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t width, uint32_t height,
@@ -521,27 +609,9 @@ static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t widt
     std::vector<float> kp(4 * (size_t)n), M6(6 * (size_t)n);
     R3DM_HIP(c, hipMemcpyAsync(kp.data(), keypoints, kp.size() * 4, hipMemcpyDefault, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
-    const int patchResolution = 20, patchSize = 41;
-    for (uint32_t k = 0; k < n; ++k) {
-        const float x = kp[4 * k], y = kp[4 * k + 1];
-        const float angle = -90.0f - kp[4 * k + 3];
-        const float scale = kp[4 * k + 2] / static_cast<float>(patchSize) * kp_size_factor;
-        const float alpha = scale * std::cos(angle * M_PI / 180.0f);
-        const float beta = scale * std::sin(angle * M_PI / 180.0f);
-        const float trans_x = x - static_cast<float>(patchResolution), trans_y = y - static_cast<float>(patchResolution);
-        float* m = &M6[6 * (size_t)k];
-        m[0] = alpha; m[1] = beta;  m[2] = beta * trans_y + alpha * trans_x - beta * y + (1.0f - alpha) * x;
-        m[3] = -beta; m[4] = alpha; m[5] = alpha * trans_y - beta * trans_x + beta * x + (1.0f - alpha) * y;
-    }
-    // cv::getGaussianKernel(11, 1.2, CV_32F)
+    for (uint32_t k = 0; k < n; ++k) liop_patch_map(kp[4 * k], kp[4 * k + 1], kp[4 * k + 2], kp[4 * k + 3], kp_size_factor, &M6[6 * (size_t)k]);
     float kern[11];
-    {
-        const double scale2X = -0.5 / (1.2 * 1.2);
-        double sum = 0;
-        for (int i = 0; i < 11; ++i) { const double xx = i - 5.0; kern[i] = (float)std::exp(scale2X * xx * xx); sum += kern[i]; }
-        sum = 1. / sum;
-        for (int i = 0; i < 11; ++i) kern[i] = (float)(kern[i] * sum);
-    }
+    liop_blur_taps(kern);
     const size_t img_bytes = (size_t)width * height * 4, patch_bytes = (size_t)n * 41 * 41 * 4, out_bytes = (size_t)n * 144 * 4;
     if (!resident_image) R3DM_HIP(c, c->liop_img.ensure(img_bytes));
     R3DM_HIP(c, c->liop_M.ensure(M6.size() * 4));
@@ -594,6 +664,135 @@ extern "C" int r3dm_gray_from_bgr8(r3dm_ctx* c, const unsigned char* bgr, uint32
     return R3DM_OK;
 }
 
+// "%g" of one float, locale-independent (the host application runs under setlocale(LC_ALL, "")): std::to_chars with the
+// general format and precision 6 is defined as printf("%.6g") in the "C" locale
+static inline char* put_g(char* p, char* end, float v)
+{
+    const std::to_chars_result r = std::to_chars(p, end, v, std::chars_format::general, 6);
+    return r.ptr;
+}
+
+// KeypointSet::saveToBinFile (src/keypointSet.hpp:61-67): .feat = one "x y scale orientation" line per feature
+// (SIOPointFeature::operator<<, default float formatting; scale = size / 2, :835-836), .desc = count + raw rows
+static int write_feat_desc(r3dm_ctx* c, const char* feat_path, const char* desc_path, const float* kps, const float* desc, uint32_t n)
+{
+    std::vector<char> txt((size_t)n * 64 + 64);
+    char* p = txt.data(); char* const end = p + txt.size();
+    for (uint32_t k = 0; k < n; ++k) {
+        p = put_g(p, end, kps[4 * (size_t)k]); *p++ = ' ';
+        p = put_g(p, end, kps[4 * (size_t)k + 1]); *p++ = ' ';
+        p = put_g(p, end, kps[4 * (size_t)k + 2] / 2.0f); *p++ = ' ';
+        p = put_g(p, end, kps[4 * (size_t)k + 3]); *p++ = '\n';
+    }
+    FILE* f = fopen(feat_path, "wb");
+    if (!f) { c->err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
+    bool ok = (p == txt.data()) || fwrite(txt.data(), 1, (size_t)(p - txt.data()), f) == (size_t)(p - txt.data());
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { c->err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
+    f = fopen(desc_path, "wb");
+    if (!f) { c->err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
+    const uint64_t cnt = n;
+    ok = fwrite(&cnt, 8, 1, f) == 1 && (n == 0 || fwrite(desc, 144 * 4, n, f) == n);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { c->err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
+    return R3DM_OK;
+}
+
+static bool both_files_exist(const char* feat_path, const char* desc_path, uint32_t* n_rows)
+{
+    FILE* ff = fopen(feat_path, "rb");
+    FILE* fd = ff ? fopen(desc_path, "rb") : nullptr;
+    if (ff) fclose(ff);
+    if (!fd) return false;
+    uint64_t cnt = 0;
+    if (fread(&cnt, 8, 1, fd) != 1) cnt = 0;
+    fclose(fd);
+    if (n_rows) *n_rows = (uint32_t)cnt;
+    return true;
+}
+
+// detectAndExtract (src/Regard3DFeatures.cpp:206-222) for keypointDetectorList_ = {"Fast-AKAZE"} over a batch of B same-size
+// images + KeypointSet::saveToBinFile of each: detector batch -> (host: angle and patch map of every keypoint, 24 bytes each back
+// to the device) -> one LIOP patch-extraction launch and one LIOP launch over the keypoints of ALL images -> descriptors to page-locked
+// host memory -> files.  Every image of the batch is computed (the skip rule is the caller's: it only batches images it wants).
+// kps_out / desc_out (optional): the keypoints (x, y, size, angle) and descriptors of every image, for callers that register the
+// views without reading the files back.
+static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* const* grays, const unsigned char* const* bgrs,
+                                       uint32_t width, uint32_t height, float threshold, const char* const* feat_paths,
+                                       const char* const* desc_paths, uint32_t* n_features,
+                                       std::vector<std::vector<float>>* kps_out = nullptr, std::vector<std::vector<float>>* desc_out = nullptr)
+{
+    if (!c || B == 0) return R3DM_ERR_INVALID;
+    AkBatchOut bo;
+    int rc = ak_detect_batch(c, B, grays, bgrs, width, height, threshold, bo);
+    if (rc != R3DM_OK) return rc;
+    const double t_liop = now_ms();
+    size_t n_total = 0;
+    std::vector<size_t> first(B + 1, 0);
+    for (uint32_t b = 0; b < B; ++b) { first[b] = n_total; n_total += bo.recs[b].size(); }
+    first[B] = n_total;
+    std::vector<float> kps(4 * n_total), M6(6 * n_total);
+    std::vector<uint32_t> img_of(n_total);
+    for (uint32_t b = 0; b < B; ++b)
+        for (size_t k = 0; k < bo.recs[b].size(); ++k) {
+            const AkKpRec& r = bo.recs[b][k];
+            const size_t g = first[b] + k;
+            float* o = &kps[4 * g];
+            o[0] = r.x; o[1] = r.y; o[2] = r.size; o[3] = ak_angle_deg(ak_theta(r));
+            liop_patch_map(o[0], o[1], o[2], o[3], 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, &M6[6 * g]);
+            img_of[g] = b;
+        }
+    const float* desc_host = nullptr;
+    if (n_total) {
+        rc = liop_prepare(c);
+        if (rc != R3DM_OK) return rc;
+        float kern[11];
+        liop_blur_taps(kern);
+        const size_t patch_bytes = n_total * 41 * 41 * 4, out_bytes = n_total * 144 * 4;
+        R3DM_HIP(c, c->liop_M.ensure(M6.size() * 4 + img_of.size() * 4));
+        R3DM_HIP(c, c->liop_kern.ensure(64));
+        R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
+        R3DM_HIP(c, c->liop_out.ensure(out_bytes));
+        R3DM_HIP(c, c->liop_cnt.ensure(64));
+        R3DM_HIP(c, c->pin_desc.ensure(out_bytes));
+        uint32_t* d_img_of = reinterpret_cast<uint32_t*>(c->liop_M.as<float>() + M6.size());
+        R3DM_HIP(c, hipMemcpyAsync(c->liop_M.p, M6.data(), M6.size() * 4, hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(d_img_of, img_of.data(), img_of.size() * 4, hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(c->liop_kern.p, kern, sizeof(kern), hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
+        R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
+        // the detector has left the B gray images in its image buffer (ak_bufs[0], B planes, read-only for it)
+        R3DM_HIP(c, launch_liop_extract(c->stream, c->ak_bufs[0].as<float>(), (int)width, (int)height, c->liop_M.as<float>(),
+                                        c->liop_kern.as<float>(), (uint32_t)n_total, c->liop_in.as<float>(), d_img_of));
+        R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
+                                c->liop_sy.as<double>(), (uint32_t)n_total, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>()));
+        R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(c->pin_desc.p, c->liop_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->stats.ms_liop_kernel = ms;
+        desc_host = c->pin_desc.as<float>();
+    }
+    c->stats.ms_liop_wall = now_ms() - t_liop;
+    const double t_io = now_ms();
+    for (uint32_t b = 0; b < B; ++b) {
+        const uint32_t n = (uint32_t)bo.recs[b].size();
+        if (feat_paths && desc_paths && feat_paths[b] && desc_paths[b]) {
+            rc = write_feat_desc(c, feat_paths[b], desc_paths[b], kps.data() + 4 * first[b], desc_host ? desc_host + 144 * first[b] : nullptr, n);
+            if (rc != R3DM_OK) return rc;
+        }
+        if (n_features) n_features[b] = n;
+        if (kps_out) (*kps_out)[b].assign(kps.begin() + 4 * first[b], kps.begin() + 4 * first[b + 1]);
+        if (desc_out) { if (n) (*desc_out)[b].assign(desc_host + 144 * first[b], desc_host + 144 * first[b + 1]); else (*desc_out)[b].clear(); }
+    }
+    c->stats.ms_feature_files = now_ms() - t_io;
+    c->feat_totals.ms_liop_kernels += n_total ? c->stats.ms_liop_kernel : 0.0;
+    c->feat_totals.ms_wall += c->stats.ms_liop_wall + c->stats.ms_feature_files;
+    c->feat_totals.ms_files += c->stats.ms_feature_files;
+    return R3DM_OK;
+}
+
 static int r3dm_extract_features_to_files_impl(r3dm_ctx* c, const float* gray, uint32_t width, uint32_t height, float threshold,
                                               const char* feat_path, const char* desc_path, uint32_t* n_features)
 {
@@ -602,57 +801,25 @@ static int r3dm_extract_features_to_files_impl(r3dm_ctx* c, const float* gray, u
     // "Test if descriptor and feature was already computed" (src/threads/R3DFeaturesThread.cpp:139-142): when BOTH files exist the
     // work item does nothing -- files left by a run with other parameters are reused, the reference wipes the matches directory
     // instead (src/threads/R3DComputeMatchesThread.cpp:84-86).  n_features then reports the row count of the existing .desc.
-    {
-        FILE* ff = fopen(feat_path, "rb");
-        FILE* fd = ff ? fopen(desc_path, "rb") : nullptr;
-        if (ff) fclose(ff);
-        if (fd) {
-            uint64_t cnt = 0;
-            if (fread(&cnt, 8, 1, fd) != 1) cnt = 0;
-            fclose(fd);
-            if (n_features) *n_features = (uint32_t)cnt;
-            return R3DM_OK;
-        }
-    }
-    // detectAndExtract (src/Regard3DFeatures.cpp:206-222) for keypointDetectorList_ = {"Fast-AKAZE"}
-    uint32_t n = 0;
-    std::vector<float> kps(4 * 65536);
-    int rc = r3dm_detect_akaze(c, gray, width, height, threshold, kps.data(), nullptr, 65536, &n);
-    if (rc != R3DM_OK) return rc;
-    if (n > 65536) {
-        kps.resize(4 * (size_t)n);
-        const uint32_t cap = n;
-        rc = r3dm_detect_akaze(c, gray, width, height, threshold, kps.data(), nullptr, cap, &n);
-        if (rc != R3DM_OK) return rc;
-    }
-    std::vector<float> desc(144 * (size_t)std::max<uint32_t>(n, 1));
-    if (n) {
-        // the detector has just uploaded `gray` into its image buffer (ak_bufs[0], read-only for it): no second 4 w h-byte copy
-        const float* resident = (c->ak_w == (int)width && c->ak_h == (int)height && !c->ak_bufs.empty()) ? c->ak_bufs[0].as<float>() : nullptr;
-        rc = r3dm_extract_liop_impl(c, gray, width, height, kps.data(), n, 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, desc.data(), nullptr, resident);
-        if (rc != R3DM_OK) return rc;
-    }
-    // KeypointSet::saveToBinFile (src/keypointSet.hpp:61-67): .feat = one "x y scale orientation" line per feature
-    // (SIOPointFeature::operator<<, default float formatting; scale = size / 2, :835-836), .desc = count + raw rows
-    FILE* f = fopen(feat_path, "w");
-    if (!f) { c->err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
-    for (uint32_t k = 0; k < n; ++k)
-        fprintf(f, "%g %g %g %g\n", kps[4 * (size_t)k], kps[4 * (size_t)k + 1], kps[4 * (size_t)k + 2] / 2.0f, kps[4 * (size_t)k + 3]);
-    if (fclose(f) != 0) return R3DM_ERR_IO;
-    f = fopen(desc_path, "wb");
-    if (!f) { c->err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
-    const uint64_t cnt = n;
-    bool ok = fwrite(&cnt, 8, 1, f) == 1 && (n == 0 || fwrite(desc.data(), 144 * 4, n, f) == n);
-    ok = (fclose(f) == 0) && ok;
-    if (!ok) return R3DM_ERR_IO;
-    if (n_features) *n_features = n;
-    return R3DM_OK;
+    if (both_files_exist(feat_path, desc_path, n_features)) return R3DM_OK;
+    return extract_features_batch_impl(c, 1, &gray, nullptr, width, height, threshold, &feat_path, &desc_path, n_features);
 }
 
 extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, uint32_t width, uint32_t height, float threshold,
                                               const char* feat_path, const char* desc_path, uint32_t* n_features)
 {
     return r3dm_guarded(c, [&]() -> int { return r3dm_extract_features_to_files_impl(c, gray, width, height, threshold, feat_path, desc_path, n_features); });
+}
+
+// B same-size images through detector + LIOP + files in one pass (no skip rule: the caller decides what to compute).
+// grays: B pointers to height x width floats, or NULL and bgrs: B pointers to height x width x 3 bytes (BGR, as cv::imread decodes).
+extern "C" int r3dm_extract_features_batch(r3dm_ctx* c, uint32_t n_images, const float* const* grays, const unsigned char* const* bgrs,
+                                           uint32_t width, uint32_t height, float threshold, const char* const* feat_paths,
+                                           const char* const* desc_paths, uint32_t* n_features)
+{
+    return r3dm_guarded(c, [&]() -> int {
+        if (!feat_paths || !desc_paths) return R3DM_ERR_INVALID;
+        return extract_features_batch_impl(c, n_images, grays, bgrs, width, height, threshold, feat_paths, desc_paths, n_features); });
 }
 
 
@@ -662,62 +829,127 @@ extern "C" int r3dm_extract_features_to_files(r3dm_ctx* c, const float* gray, ui
 // running processWorkItem (:123-210).  The reference admits ONE image at a time into the A-KAZE scale space
 // (initAKAZESemaphore(1), src/R3DComputeMatches.cpp:1847; src/Regard3DFeatures.cpp:71-125) to bound host memory; HBM does not
 // need that: every context of an r3dm_multi (r3dm_multi_create with a device id repeated K times = K streams + work buffers on
-// that device; or one per GPU) pulls images off the list from its own host thread, so K images are in flight at once.  An image whose .feat AND .desc both exist is skipped, exactly
-// as processWorkItem does (:139-142: stale files of other parameters are reused; the reference wipes the matches directory
-// instead, src/threads/R3DComputeMatchesThread.cpp:84-86); n_features then reports the row count of the existing .desc.
+// that device; or one per GPU) is a worker that pulls BATCHES of same-size images off the list from its own host thread -- B images
+// per pass of the detector, K passes in flight, the host part of one pass (angles, files) hidden behind the kernels of the others.
+// An image whose .feat AND .desc both exist is skipped, exactly as processWorkItem does (:139-142: stale files of other parameters
+// are reused; the reference wipes the matches directory instead, src/threads/R3DComputeMatchesThread.cpp:84-86); n_features then
+// reports the row count of the existing .desc.
 // ------------------------------------------------------------------------------------------------
 #include <atomic>
+#include <mutex>
 #include <thread>
-
-static bool file_exists(const char* p) { FILE* f = fopen(p, "rb"); if (!f) return false; fclose(f); return true; }
+#include <tuple>
 
 extern "C" {
 int r3dm_multi_num_devices(const r3dm_multi* m);
 r3dm_ctx* r3dm_multi_ctx(r3dm_multi* m, int k);
 }
 
-extern "C" int r3dm_multi_extract_features(r3dm_multi* m, uint32_t n_images, const float* const* grays, const uint32_t* widths,
-                                           const uint32_t* heights, float threshold, const char* const* feat_paths,
-                                           const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped,
-                                           char* err, size_t err_cap)
+namespace {
+
+// batch size for images of w x h on context c: 8 when HBM allows (the work buffers take ~125 bytes per pixel and image),
+// fewer for very large images or a nearly full device
+uint32_t ak_batch_for(r3dm_ctx* c, uint32_t w, uint32_t h, uint32_t want)
 {
-    if (!m || (n_images && (!grays || !widths || !heights || !feat_paths || !desc_paths))) return R3DM_ERR_INVALID;
+    size_t free_b = 0, total_b = 0;
+    (void)hipSetDevice(c->device);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1;
+    const double per_image = (double)w * h * 4.0 * 32.0 + 64e6;
+    const double budget = (double)free_b * 0.5 + (c->ak_w == (int)w && c->ak_h == (int)h ? (double)c->ak_B * per_image : 0.0);
+    uint32_t b = want;
+    while (b > 1 && b * per_image > budget) --b;
+    return b;
+}
+
+int multi_extract_impl(r3dm_multi* m, uint32_t n_images, const float* const* grays, const unsigned char* const* bgrs,
+                       const uint32_t* widths, const uint32_t* heights, float threshold, const char* const* feat_paths,
+                       const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped, uint32_t batch, char* err, size_t err_cap)
+{
+    if (!m || (n_images && ((!grays && !bgrs) || !widths || !heights || !feat_paths || !desc_paths))) return R3DM_ERR_INVALID;
+    // per image: gray floats if grays[i] is set, else 8-bit BGR
+    auto is_gray = [&](uint32_t i) { return grays && grays[i]; };
     if (err && err_cap) err[0] = 0;
     const uint32_t concurrency = (uint32_t)r3dm_multi_num_devices(m);
     if (concurrency == 0) return R3DM_ERR_INVALID;
+    if (batch == 0) batch = 8;
     int rc_all = R3DM_OK;
+    std::vector<std::thread> th;
     try {
-        std::atomic<uint32_t> next{0};
+        // work list: the images still to compute (the skip rule applied up front), grouped by size so that a worker's batch is
+        // a run of same-size images; the order inside a size class is the caller's
+        std::vector<uint32_t> todo;
+        for (uint32_t i = 0; i < n_images; ++i) {
+            if (skipped) skipped[i] = 0;
+            uint32_t rows = 0;
+            if (both_files_exist(feat_paths[i], desc_paths[i], &rows)) {            // processWorkItem: already computed
+                if (n_features) n_features[i] = rows;
+                if (skipped) skipped[i] = 1;
+            } else todo.push_back(i);
+        }
+        for (uint32_t i : todo) if (!is_gray(i) && !(bgrs && bgrs[i])) return R3DM_ERR_INVALID;      // an image to compute without pixels
+        std::stable_sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) {
+            return std::make_tuple(widths[a], heights[a], is_gray(a)) < std::make_tuple(widths[b], heights[b], is_gray(b)); });
+        std::mutex mu;
+        size_t next = 0;
         std::vector<int> rcs(concurrency, R3DM_OK);
         std::vector<std::string> errs(concurrency);
-        auto worker = [&](uint32_t k) {
-            r3dm_ctx* c = r3dm_multi_ctx(m, (int)k);
-            for (;;) {
-                const uint32_t i = next.fetch_add(1);
-                if (i >= n_images || rcs[k] != R3DM_OK) return;
-                if (skipped) skipped[i] = 0;
-                if (file_exists(feat_paths[i]) && file_exists(desc_paths[i])) {           // processWorkItem: already computed
-                    uint64_t cnt = 0;
-                    if (FILE* f = fopen(desc_paths[i], "rb")) { if (fread(&cnt, 8, 1, f) != 1) cnt = 0; fclose(f); }
-                    if (n_features) n_features[i] = (uint32_t)cnt;
-                    if (skipped) skipped[i] = 1;
-                    continue;
+        // small lists: shrink the batch so that every worker gets something to do
+        const uint32_t fair = (uint32_t)std::max<size_t>(1, (todo.size() + concurrency - 1) / concurrency);
+        auto worker = [&](uint32_t k) noexcept {
+            try {
+                r3dm_ctx* c = r3dm_multi_ctx(m, (int)k);
+                for (;;) {
+                    std::vector<uint32_t> mine;
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (next >= todo.size() || rcs[k] != R3DM_OK) return;
+                        const uint32_t w = widths[todo[next]], h = heights[todo[next]];
+                        const bool gk = is_gray(todo[next]);
+                        const uint32_t bmax = ak_batch_for(c, w, h, std::min(batch, fair));
+                        while (next < todo.size() && mine.size() < bmax && widths[todo[next]] == w && heights[todo[next]] == h && is_gray(todo[next]) == gk) mine.push_back(todo[next++]);
+                    }
+                    const uint32_t B = (uint32_t)mine.size();
+                    std::vector<const float*> g(B); std::vector<const unsigned char*> bg(B);
+                    std::vector<const char*> fp(B), dp(B); std::vector<uint32_t> nf(B, 0);
+                    const bool gk = is_gray(mine[0]);
+                    for (uint32_t j = 0; j < B; ++j) { if (gk) g[j] = grays[mine[j]]; else bg[j] = bgrs[mine[j]]; fp[j] = feat_paths[mine[j]]; dp[j] = desc_paths[mine[j]]; }
+                    const int rc = r3dm_extract_features_batch(c, B, gk ? g.data() : nullptr, gk ? nullptr : bg.data(), widths[mine[0]], heights[mine[0]],
+                                                               threshold, fp.data(), dp.data(), nf.data());
+                    if (n_features) for (uint32_t j = 0; j < B; ++j) n_features[mine[j]] = nf[j];
+                    if (rc != R3DM_OK) { rcs[k] = rc; errs[k] = std::string("image ") + std::to_string(mine[0]) + " (batch of " + std::to_string(B) + "): " + r3dm_last_error(c); }
                 }
-                uint32_t n = 0;
-                const int rc = r3dm_extract_features_to_files(c, grays[i], widths[i], heights[i], threshold, feat_paths[i], desc_paths[i], &n);
-                if (n_features) n_features[i] = n;
-                if (rc != R3DM_OK) { rcs[k] = rc; errs[k] = std::string("image ") + std::to_string(i) + ": " + r3dm_last_error(c); }
-            }
+            } catch (...) { rcs[k] = R3DM_ERR_NOMEM; }          // nothing leaves a worker thread by exception (std::terminate)
         };
-        std::vector<std::thread> th;
         for (uint32_t k = 1; k < concurrency; ++k) th.emplace_back(worker, k);
         worker(0);
         for (auto& t : th) t.join();
+        th.clear();
         for (uint32_t k = 0; k < concurrency; ++k)
             if (rcs[k] != R3DM_OK && rc_all == R3DM_OK) {
                 rc_all = rcs[k];
                 if (err && err_cap) { strncpy(err, errs[k].c_str(), err_cap - 1); err[err_cap - 1] = 0; }
             }
-    } catch (...) { rc_all = R3DM_ERR_NOMEM; }
+    } catch (...) {
+        for (auto& t : th) if (t.joinable()) t.join();          // thread creation failed half way: the started workers finish first
+        rc_all = R3DM_ERR_NOMEM;
+    }
     return rc_all;
+}
+
+}  // namespace
+
+extern "C" int r3dm_multi_extract_features(r3dm_multi* m, uint32_t n_images, const float* const* grays, const uint32_t* widths,
+                                           const uint32_t* heights, float threshold, const char* const* feat_paths,
+                                           const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped,
+                                           char* err, size_t err_cap)
+{
+    return multi_extract_impl(m, n_images, grays, nullptr, widths, heights, threshold, feat_paths, desc_paths, n_features, skipped, 0, err, err_cap);
+}
+
+extern "C" int r3dm_multi_extract_features_ex(r3dm_multi* m, uint32_t n_images, const float* const* grays, const unsigned char* const* bgrs,
+                                              const uint32_t* widths, const uint32_t* heights, float threshold, const char* const* feat_paths,
+                                              const char* const* desc_paths, uint32_t* n_features, uint32_t* skipped, uint32_t batch,
+                                              char* err, size_t err_cap)
+{
+    return multi_extract_impl(m, n_images, grays, bgrs, widths, heights, threshold, feat_paths, desc_paths, n_features, skipped, batch, err, err_cap);
 }

@@ -4,6 +4,7 @@
 #include "../../include/r3d_compute_matches.hpp"
 
 #include <charconv>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -112,6 +113,13 @@ bool write_adjacency_svg(const std::string& path, size_t n_views, const PairWise
     return fclose(f) == 0;
 }
 
+double wall_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+bool file_exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (!f) return false; fclose(f); return true; }
+
 std::string with_ext(const std::string& path, const char* ext)
 {
     const size_t dot = path.find_last_of('.');
@@ -122,12 +130,14 @@ std::string with_ext(const std::string& path, const char* ext)
 
 R3DComputeMatches::R3DComputeMatches(int device_id)
 {
+    devices_.assign(1, device_id);
     const int rc = r3dm_create(device_id, &ctx_);
     if (rc != R3DM_OK) { ctx_ = nullptr; errorMessage_ = "r3dm_create failed (" + std::to_string(rc) + "): no gfx950 GPU"; }
 }
 
 R3DComputeMatches::R3DComputeMatches(const std::vector<int>& device_ids)
 {
+    devices_ = device_ids;
     if (device_ids.size() == 1) {
         const int rc = r3dm_create(device_ids[0], &ctx_);
         if (rc != R3DM_OK) { ctx_ = nullptr; errorMessage_ = "r3dm_create failed (" + std::to_string(rc) + "): no gfx950 GPU"; }
@@ -137,7 +147,91 @@ R3DComputeMatches::R3DComputeMatches(const std::vector<int>& device_ids)
     if (rc != R3DM_OK) { multi_ = nullptr; errorMessage_ = "r3dm_multi_create failed (" + std::to_string(rc) + ")"; }
 }
 
-R3DComputeMatches::~R3DComputeMatches() { if (ctx_) r3dm_destroy(ctx_); if (multi_) r3dm_multi_destroy(multi_); }
+R3DComputeMatches::~R3DComputeMatches()
+{
+    if (feat_multi_) r3dm_multi_destroy(feat_multi_);
+    if (ctx_) r3dm_destroy(ctx_);
+    if (multi_) r3dm_multi_destroy(multi_);
+}
+
+// R3DFeaturesThread::extractFeaturesAndDescriptors(vec_fileNames, sOutDir, params) (/root/reference/src/R3DComputeMatches.cpp:1994-1995,
+// src/threads/R3DFeaturesThread.cpp:38-210) for the views whose two files are not both there.  The reference's worker threads
+// admit one image at a time into the detector; here feat_conc_ batches of feat_batch_ same-size images are in flight per device.
+bool R3DComputeMatches::runFeaturesStage(const R3DFParams& params, const std::string& dir)
+{
+    std::vector<size_t> need;
+    for (size_t vi = 0; vi < views_.size(); ++vi)
+        if (!(file_exists(dir + "/" + views_[vi].basename + ".feat") && file_exists(dir + "/" + views_[vi].basename + ".desc"))) need.push_back(vi);
+    if (need.empty()) return true;
+    // the detector list of the GUI: only the default arm runs on the GPU (include/regard3d_features.hpp says so too)
+    for (const std::string& d : params.keypointDetectorList_)
+        if (d != "Fast-AKAZE") { errorMessage_ = "keypoint detector \"" + d + "\" is not served by the GPU path (Fast-AKAZE is)"; return false; }
+    if (dtype_ != R3DM_F32 || dim_ != 144) { errorMessage_ = "the features stage writes LIOP regions (float x 144); setRegionsType disagrees"; return false; }
+    if (!feat_multi_) {
+        std::vector<int> ids;
+        for (int d : devices_) for (int k = 0; k < std::max(1, feat_conc_); ++k) ids.push_back(d);
+        const int rc = r3dm_multi_create(ids.data(), (int)ids.size(), &feat_multi_);
+        if (rc != R3DM_OK) { feat_multi_ = nullptr; errorMessage_ = "r3dm_multi_create (features stage) failed (" + std::to_string(rc) + ")"; return false; }
+    }
+    const int n_ctx = r3dm_multi_num_devices(feat_multi_);
+    r3dm_features_totals before{};
+    for (int k = 0; k < n_ctx; ++k) {
+        r3dm_features_totals t{};
+        (void)r3dm_get_features_totals(r3dm_multi_ctx(feat_multi_, k), &t);
+        before.n_images += t.n_images; before.n_passes += t.n_passes; before.n_keypoints += t.n_keypoints; before.n_regrows += t.n_regrows;
+        before.ms_detect_kernels += t.ms_detect_kernels; before.detect_algorithmic_bytes += t.detect_algorithmic_bytes;
+        before.ms_liop_kernels += t.ms_liop_kernels; before.ms_wall += t.ms_wall; before.ms_files += t.ms_files;
+    }
+    // with a provider, pixels are requested one chunk at a time (every context gets two batches per chunk), else all at once
+    const size_t chunk = provider_ ? (size_t)n_ctx * (size_t)std::max(1, feat_batch_) * 2 : need.size();
+    for (size_t c0 = 0; c0 < need.size(); c0 += chunk) {
+        const size_t cn = std::min(chunk, need.size() - c0);
+        std::vector<const float*> grays(cn, nullptr); std::vector<const unsigned char*> bgrs(cn, nullptr);
+        std::vector<uint32_t> ws(cn), hs(cn), nf(cn, 0), sk(cn, 0);
+        std::vector<std::string> fps(cn), dps(cn);
+        std::vector<const char*> fp(cn), dp(cn);
+        std::vector<char> provided(cn, 0);
+        bool ok = true;
+        for (size_t k = 0; k < cn && ok; ++k) {
+            const View& v = views_[need[c0 + k]];
+            grays[k] = v.gray; bgrs[k] = v.bgr8;
+            if (!grays[k] && !bgrs[k] && provider_) {
+                Pixels px;
+                if (provider_(v, &px, provider_user_)) { grays[k] = px.gray; bgrs[k] = px.bgr8; provided[k] = 1; }
+            }
+            if (!grays[k] && !bgrs[k]) {
+                // the reference would cv::imread the file here; decoding is the caller's, so a view without files AND pixels is an error
+                errorMessage_ = "Invalid features: " + v.basename + " (no .feat/.desc in the matches directory and no pixels for the features stage)";
+                ok = false;
+            }
+            ws[k] = v.ui_width; hs[k] = v.ui_height;
+            fps[k] = dir + "/" + v.basename + ".feat"; dps[k] = dir + "/" + v.basename + ".desc";
+            fp[k] = fps[k].c_str(); dp[k] = dps[k].c_str();
+        }
+        int rc = R3DM_OK;
+        char err[512] = {0};
+        if (ok) rc = r3dm_multi_extract_features_ex(feat_multi_, (uint32_t)cn, grays.data(), bgrs.data(), ws.data(), hs.data(), params.threshold_,
+                                                    fp.data(), dp.data(), nf.data(), sk.data(), (uint32_t)std::max(1, feat_batch_), err, sizeof(err));
+        if (provider_release_) for (size_t k = 0; k < cn; ++k) if (provided[k]) provider_release_(views_[need[c0 + k]], provider_user_);
+        if (!ok) return false;
+        if (rc != R3DM_OK) { errorMessage_ = std::string("features stage failed: ") + err; return false; }
+        phases_.images_extracted += cn;
+        if (progress_) progress_(0.7f * (float)(c0 + cn) / (float)need.size(), "Extracting features", progress_user_);   // sendMsgToMainFrame, :212-240
+    }
+    r3dm_features_totals& T = phases_.features_totals;
+    T = r3dm_features_totals{};
+    for (int k = 0; k < n_ctx; ++k) {
+        r3dm_features_totals t{};
+        (void)r3dm_get_features_totals(r3dm_multi_ctx(feat_multi_, k), &t);
+        T.n_images += t.n_images; T.n_passes += t.n_passes; T.n_keypoints += t.n_keypoints; T.n_regrows += t.n_regrows;
+        T.ms_detect_kernels += t.ms_detect_kernels; T.detect_algorithmic_bytes += t.detect_algorithmic_bytes;
+        T.ms_liop_kernels += t.ms_liop_kernels; T.ms_wall += t.ms_wall; T.ms_files += t.ms_files;
+    }
+    T.n_images -= before.n_images; T.n_passes -= before.n_passes; T.n_keypoints -= before.n_keypoints; T.n_regrows -= before.n_regrows;
+    T.ms_detect_kernels -= before.ms_detect_kernels; T.detect_algorithmic_bytes -= before.detect_algorithmic_bytes;
+    T.ms_liop_kernels -= before.ms_liop_kernels; T.ms_wall -= before.ms_wall; T.ms_files -= before.ms_files;
+    return true;
+}
 
 void R3DComputeMatches::addViews(const std::vector<View>& views) { views_.insert(views_.end(), views.begin(), views.end()); }
 
@@ -153,7 +247,19 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
                                        int /*cameraModel*/, int matchingAlgorithm)
 {
     statistics_ = R3DComputeMatchesStatistics();
+    phases_ = PhaseTimes();
     if (!ctx_ && !multi_) return false;
+    const double t_begin = wall_ms();
+    // HIP-event time of the dominant kernel of the last match / filter call (the slowest device of a multi-device deal)
+    auto kernel_ms = [&](bool filter) -> double {
+        double ms = 0;
+        const int n = ctx_ ? 1 : r3dm_multi_num_devices(multi_);
+        for (int k = 0; k < n; ++k) {
+            r3dm_stats st{};
+            if (r3dm_get_stats(ctx_ ? ctx_ : r3dm_multi_ctx(multi_, k), &st) == R3DM_OK) ms = std::max(ms, filter ? st.ms_filter_kernels : st.ms_match_kernels + st.ms_ann_search + st.ms_ann_build);
+        }
+        return ms;
+    };
     // one device or the multi-device deal: the same calls either way
     auto last_error = [&]() -> std::string { return ctx_ ? r3dm_last_error(ctx_) : r3dm_multi_last_error(multi_); };
     auto clear_images = [&]() { return ctx_ ? r3dm_clear_images(ctx_) : r3dm_multi_clear_images(multi_); };
@@ -181,6 +287,14 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     }
     const std::string dir = paths.relativeMatchesPath_;
     const size_t row_bytes = dtype_ == R3DM_F32 ? (size_t)dim_ * 4 : (size_t)dim_;
+
+    // ---- R3DFeaturesThread::extractFeaturesAndDescriptors(vec_fileNames, sOutDir, params) (:1994-1995)
+    {
+        const double t0 = wall_ms();
+        if (!runFeaturesStage(params, dir)) return false;
+        phases_.features = wall_ms() - t0;
+    }
+    const double t_load = wall_ms();
 
     // ---- Regions_Provider::load + Features_Provider::load (src/R3DComputeMatches.cpp:2040,2094-2095)
     if (clear_images() != R3DM_OK) { errorMessage_ = last_error(); return false; }
@@ -227,7 +341,9 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     for (size_t a = 0; a < ids.size(); ++a)
         for (size_t b = a + 1; b < ids.size(); ++b) { pairs.push_back(ids[a]); pairs.push_back(ids[b]); }
 
+    phases_.load = wall_ms() - t_load;
     if (progress_) progress_(0.7f, "Find putative matches", progress_user_);
+    double t_phase = wall_ms();
     // ---- photometric matching (:2048) + Save(matches.putative.txt) (:2064)
     r3dm_graph* putative = nullptr;
     const int squared = dtype_ == R3DM_BIN ? 0 : 1;        // RegionsMatcherT squared flag: true for L2 metrics
@@ -238,6 +354,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         rc = match(pairs, params.distRatio_, squared, &putative);
     }
     if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
+    phases_.match = wall_ms() - t_phase; phases_.match_kernels = kernel_ms(false);
+    t_phase = wall_ms();
     graph_to_map(putative, statistics_.putativeMatches_);
     const std::string put_path = paths.matchesPutitativeFilename_.empty() ? dir + "/matches.putative.txt" : paths.matchesPutitativeFilename_;
     if (r3dm_save_matches(putative, put_path.c_str()) != R3DM_OK ||
@@ -249,18 +367,23 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     }
 
     if (svgOutput) write_adjacency_svg(dir + "/PutativeAdjacencyMatrix.svg", views_.size(), statistics_.putativeMatches_);   // :2074
+    phases_.files += wall_ms() - t_phase;
 
     // ---- geometric filtering, fundamental matrix (:2113-2120): AC-RANSAC, 4.0 px upper bound, 2048 iterations
     if (params.computeFundalmentalMatrix_) {
         if (progress_) progress_(0.8f, "Calculate fundamental matrix", progress_user_);
         r3dm_graph* geo = nullptr;
+        t_phase = wall_ms();
         rc = filter_F(putative, &geo);
         if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
+        phases_.filter_F = wall_ms() - t_phase; phases_.F_kernels = kernel_ms(true);
+        t_phase = wall_ms();
         graph_to_map(geo, statistics_.fundamentalMatches_);
         const std::string f_path = paths.matchesFFilename_.empty() ? dir + "/matches.f.txt" : paths.matchesFFilename_;
         const bool ok = r3dm_save_matches(geo, f_path.c_str()) == R3DM_OK &&
                         r3dm_save_matches(geo, with_ext(f_path, ".bin").c_str()) == R3DM_OK;
         r3dm_graph_free(geo);
+        phases_.files += wall_ms() - t_phase;
         if (!ok) { errorMessage_ = "Cannot save computed matches in: " + f_path; r3dm_graph_free(putative); return false; }
     }
     // ---- essential-matrix filter (:2130-2204): 5-point solver on K^-1 x, then the overlap rule (>= 50 matches and
@@ -268,26 +391,34 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     if (params.computeEssentialMatrix_) {
         if (progress_) progress_(0.9f, "Calculate essential matrix", progress_user_);
         r3dm_graph* geo = nullptr;
+        t_phase = wall_ms();
         rc = filter_E(putative, &geo);
         if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
+        phases_.filter_E = wall_ms() - t_phase; phases_.E_kernels = kernel_ms(true);
+        t_phase = wall_ms();
         graph_to_map(geo, statistics_.essentialMatches_);
         const std::string e_path = paths.matchesEFilename_.empty() ? dir + "/matches.e.txt" : paths.matchesEFilename_;
         const bool ok = r3dm_save_matches(geo, e_path.c_str()) == R3DM_OK &&
                         r3dm_save_matches(geo, with_ext(e_path, ".bin").c_str()) == R3DM_OK;
         r3dm_graph_free(geo);
+        phases_.files += wall_ms() - t_phase;
         if (!ok) { errorMessage_ = "Cannot save computed matches in: " + e_path; r3dm_graph_free(putative); return false; }
     }
     // ---- homography filter (:2216-2233): same skeleton, 4-point solver; matches.h.txt
     if (params.computeHomographyMatrix_) {
         if (progress_) progress_(0.95f, "Calculate homography matrix", progress_user_);
         r3dm_graph* geo = nullptr;
+        t_phase = wall_ms();
         rc = filter_H(putative, &geo);
         if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
+        phases_.filter_H = wall_ms() - t_phase; phases_.H_kernels = kernel_ms(true);
+        t_phase = wall_ms();
         graph_to_map(geo, statistics_.homographyMatches_);
         const std::string h_path = paths.matchesHFilename_.empty() ? dir + "/matches.h.txt" : paths.matchesHFilename_;
         const bool ok = r3dm_save_matches(geo, h_path.c_str()) == R3DM_OK &&
                         r3dm_save_matches(geo, with_ext(h_path, ".bin").c_str()) == R3DM_OK;
         r3dm_graph_free(geo);
+        phases_.files += wall_ms() - t_phase;
         if (!ok) { errorMessage_ = "Cannot save computed matches in: " + h_path; r3dm_graph_free(putative); return false; }
     }
     // GeometricAdjacencyMatrix.svg (:2238): the reference draws whichever filter ran last (H, else E, else F)
@@ -297,10 +428,61 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         write_adjacency_svg(dir + "/GeometricAdjacencyMatrix.svg", views_.size(), last);
     }
     r3dm_graph_free(putative);
+    phases_.total = wall_ms() - t_begin;
     return true;
 }
 
 }  // namespace r3d_amd
+
+extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
+                                          float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
+                                          uint64_t seed, int features_batches_in_flight, int features_images_per_batch,
+                                          r3dm_stage_report* report, char* err, size_t err_cap)
+{
+    if (!matches_dir || !device_ids || n_devices < 1 || (n_views && !views)) return R3DM_ERR_INVALID;
+    if (err && err_cap) err[0] = 0;
+    try {
+        r3d_amd::R3DComputeMatches stage(std::vector<int>(device_ids, device_ids + n_devices));
+        std::vector<r3d_amd::View> vs(n_views);
+        for (uint32_t k = 0; k < n_views; ++k) {
+            r3d_amd::View& v = vs[k];
+            v.id_view = views[k].id; v.ui_width = views[k].width; v.ui_height = views[k].height; v.basename = views[k].basename ? views[k].basename : "";
+            v.focal_px = views[k].focal_px; v.ppx = views[k].ppx; v.ppy = views[k].ppy;
+            v.bgr8 = views[k].bgr8; v.gray = views[k].gray;
+        }
+        stage.addViews(vs);
+        stage.setSeed(seed);
+        if (features_batches_in_flight > 0 && features_images_per_batch > 0) stage.setFeaturesConcurrency(features_batches_in_flight, features_images_per_batch);
+        r3d_amd::R3DFParams params;
+        params.keypointDetectorList_ = {"Fast-AKAZE"};
+        params.threshold_ = threshold;
+        params.distRatio_ = dist_ratio;
+        params.computeFundalmentalMatrix_ = compute_F != 0;
+        params.computeEssentialMatrix_ = compute_E != 0;
+        params.computeHomographyMatrix_ = compute_H != 0;
+        r3d_amd::R3DProjectPaths paths;
+        paths.relativeMatchesPath_ = matches_dir;
+        const bool ok = stage.computeMatches(params, false, paths, 1, matching_algorithm);
+        if (err && err_cap) { strncpy(err, stage.errorMessage().c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+        if (report) {
+            const auto& P = stage.getPhaseTimes();
+            const auto& S = stage.getStatistics();
+            *report = r3dm_stage_report{};
+            report->ms_features = P.features; report->ms_load = P.load; report->ms_match = P.match; report->ms_filter_F = P.filter_F;
+            report->ms_filter_E = P.filter_E; report->ms_filter_H = P.filter_H; report->ms_files = P.files; report->ms_total = P.total;
+            report->ms_match_kernels = P.match_kernels; report->ms_F_kernels = P.F_kernels; report->ms_E_kernels = P.E_kernels; report->ms_H_kernels = P.H_kernels;
+            report->images_extracted = P.images_extracted; report->features = P.features_totals;
+            for (int n : S.numberOfKeypoints_) report->n_keypoints += (uint64_t)n;
+            auto count = [](const r3d_amd::PairWiseMatches& m, uint64_t& pairs, uint64_t& matches) { pairs = m.size(); matches = 0; for (const auto& kv : m) matches += kv.second.size(); };
+            count(S.putativeMatches_, report->n_putative_pairs, report->n_putative_matches);
+            count(S.fundamentalMatches_, report->n_F_pairs, report->n_F_matches);
+            count(S.essentialMatches_, report->n_E_pairs, report->n_E_matches);
+            count(S.homographyMatches_, report->n_H_pairs, report->n_H_matches);
+        }
+        return ok ? R3DM_OK : R3DM_ERR_IO;
+    } catch (const std::bad_alloc&) { return R3DM_ERR_NOMEM; }          // nothing crosses the C boundary
+    catch (...) { return R3DM_ERR_INVALID; }
+}
 
 extern "C" int r3dm_compute_matches_dir(int device_id, const char* matches_dir, const r3dm_view* views, uint32_t n_views,
                                         r3dm_dtype dtype, uint32_t dim, float dist_ratio, int compute_F, uint64_t seed,

@@ -17,6 +17,11 @@ namespace r3dm {
 
 namespace {
 
+// Batching: one launch serves B same-size images.  blockIdx.z = image; every image plane a launch touches has the launch's own
+// w x h, and the planes of image z start z * w * h floats into each buffer (api_features.cpp sizes every buffer for B planes).
+#define AK_PLANE(ptr, w, h) ((ptr) + (size_t)blockIdx.z * ((size_t)(w) * (size_t)(h)))
+constexpr uint32_t kAkSmallWords = 4096;            // per-image scalars: [0] max |grad| bits, [16..316) histogram, [1024..1032) 1 / k^2 per octave
+
 __device__ __forceinline__ int ak_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int ak_refl101(int p, int len)
 {
@@ -33,6 +38,7 @@ void ak_gauss_rows_kernel(const float* __restrict__ src, float* __restrict__ dst
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    src = AK_PLANE(src, w, h); dst = AK_PLANE(dst, w, h);
     const float* S = src + (size_t)y * w;
     const int n = kf.n, r = n / 2;
     float s;
@@ -50,6 +56,7 @@ void ak_gauss_cols_kernel(const float* __restrict__ src, float* __restrict__ dst
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    src = AK_PLANE(src, w, h); dst = AK_PLANE(dst, w, h);
     const int r = kf.n / 2;
     float s = kf.k[r] * src[(size_t)y * w + x];
     for (int k = 1; k <= r; ++k)
@@ -63,6 +70,7 @@ void ak_scharr_rows_kernel(const float* __restrict__ src, float* __restrict__ rd
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    src = AK_PLANE(src, w, h); rd = AK_PLANE(rd, w, h); rs = AK_PLANE(rs, w, h);
     const float* S = src + (size_t)y * w;
     const float a = S[ak_refl101(x - 1, w)], b = S[ak_refl101(x + 1, w)];
     rd[(size_t)y * w + x] = b - a;
@@ -74,6 +82,7 @@ void ak_scharr_cols_kernel(const float* __restrict__ rd, const float* __restrict
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    rd = AK_PLANE(rd, w, h); rs = AK_PLANE(rs, w, h); Lx = AK_PLANE(Lx, w, h); Ly = AK_PLANE(Ly, w, h);
     const int yu = ak_refl101(y - 1, h), yd = ak_refl101(y + 1, h);
     Lx[(size_t)y * w + x] = (rd[(size_t)yu * w + x] + rd[(size_t)yd * w + x]) * 3.0f + rd[(size_t)y * w + x] * 10.0f;
     Ly[(size_t)y * w + x] = rs[(size_t)yd * w + x] - rs[(size_t)yu * w + x];
@@ -109,6 +118,7 @@ void ak_sderiv_xy_kernel(const float* __restrict__ src, float* __restrict__ dst_
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    src = AK_PLANE(src, w, h); dst_x = AK_PLANE(dst_x, w, h); dst_y = AK_PLANE(dst_y, w, h);
     dst_x[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, 1);
     dst_y[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, 0);
 }
@@ -119,6 +129,7 @@ void ak_sderiv_det_kernel(const float* __restrict__ ly, const float* __restrict_
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    ly = AK_PLANE(ly, w, h); lxx = AK_PLANE(lxx, w, h); lxy = AK_PLANE(lxy, w, h); ldet = AK_PLANE(ldet, w, h);
     const size_t i = (size_t)y * w + x;
     const float lyy = ak_sderiv_at(ly, x, y, w, h, s, 0);
     ldet[i] = lxx[i] * lyy - lxy[i] * lxy[i];
@@ -130,6 +141,7 @@ void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ 
 {
     // grid-stride over the interior rows: one atomic per workgroup (the maximum is order-independent)
     __shared__ float part[4];
+    Lx = AK_PLANE(Lx, w, h); Ly = AK_PLANE(Ly, w, h); out_max += (size_t)blockIdx.z * kAkSmallWords;
     float m = 0.0f;
     for (int y = 1 + (int)blockIdx.x; y < h - 1; y += (int)gridDim.x)
         for (int x = 1 + (int)threadIdx.x; x < w - 1; x += 256) {
@@ -151,6 +163,7 @@ __global__ __launch_bounds__(256)
 void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, const uint32_t* __restrict__ hmax_bits, int nbins, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t lh[512];
+    Lx = AK_PLANE(Lx, w, h); Ly = AK_PLANE(Ly, w, h); hmax_bits += (size_t)blockIdx.z * kAkSmallWords; hist += (size_t)blockIdx.z * kAkSmallWords;
     const float hmax = __uint_as_float(*hmax_bits);
     if (hmax == 0.0f) return;                              // compute_k_percentileV2 keeps its default then (workgroup-uniform)
     const float sc = (nbins - 1) / hmax;
@@ -175,6 +188,7 @@ void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__
 __global__ void ak_kcontrast_kernel(const uint32_t* __restrict__ hmax_bits, const uint32_t* __restrict__ hist, int nbins, uint32_t total,
                                     int have_hist, float* __restrict__ inv_k2)
 {
+    hmax_bits += (size_t)blockIdx.x * kAkSmallWords; hist += (size_t)blockIdx.x * kAkSmallWords; inv_k2 += (size_t)blockIdx.x * kAkSmallWords;   // one thread per image
     float kcontrast = 0.03f;
     const float hmax = __uint_as_float(*hmax_bits);
     if (have_hist && hmax != 0.0f) {
@@ -195,6 +209,7 @@ void ak_scharr_g2_kernel(const float* __restrict__ src, float* __restrict__ dst,
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    src = AK_PLANE(src, w, h); dst = AK_PLANE(dst, w, h); inv_k2_p += (size_t)blockIdx.z * kAkSmallWords;
     const float inv_k2 = *inv_k2_p;                        // 1 / k^2 of this octave, left on the device by ak_kcontrast_kernel
     const int xl = ak_refl101(x - 1, w), xr = ak_refl101(x + 1, w);
     const float* Su = src + (size_t)ak_refl101(y - 1, h) * w;
@@ -214,6 +229,7 @@ void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ 
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    Lt = AK_PLANE(Lt, w, h); Lf = AK_PLANE(Lf, w, h); out = AK_PLANE(out, w, h);
     const size_t p = (size_t)y * w + x;
     const bool has_l = x > 0, has_r = x < w - 1, has_a = y > 0, has_b = y < h - 1;
     const float tc = Lt[p], fc = Lf[p];
@@ -237,20 +253,22 @@ void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ 
 
 // ---- halfsample: INTER_AREA, exact 2x (resizeAreaFast_) or fractional cells (ResizeArea_, tables from the host)
 __global__ __launch_bounds__(256)
-void ak_half_fast_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int dw, int dh)
+void ak_half_fast_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int sh, int dw, int dh)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
+    src = AK_PLANE(src, w, sh); dst = AK_PLANE(dst, dw, dh);
     const float* S = src + (size_t)(2 * y) * w + 2 * x;
     float sum = 0; sum += S[0]; sum += S[1]; sum += S[w]; sum += S[w + 1];
     dst[(size_t)y * dw + x] = sum * 0.25f;
 }
 __global__ __launch_bounds__(256)
-void ak_half_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int dw, int dh,
+void ak_half_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int sh, int dw, int dh,
                          const AkAreaTab* __restrict__ xt, const int* __restrict__ xb, const AkAreaTab* __restrict__ yt, const int* __restrict__ yb)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
+    src = AK_PLANE(src, w, sh); dst = AK_PLANE(dst, dw, dh);
     float sum = 0.0f;
     for (int j = yb[y]; j < yb[y + 1]; ++j) {
         const float* S = src + (size_t)yt[j].si * w;
@@ -272,12 +290,12 @@ __device__ __forceinline__ bool ak_is_extremum(const float* __restrict__ ldet, i
     if (v <= next[x - 1] || v <= next[x] || v <= next[x + 1]) return false;
     return true;
 }
-// one workgroup per image row (border .. h - border) of every level: blockIdx.y = level, blockIdx.x = row
+// one workgroup per image row (border .. h - border) of every level: blockIdx.z = image, blockIdx.y = level, blockIdx.x = row
 __global__ __launch_bounds__(256)
 void ak_extrema_kernel(const AkLevelDev* __restrict__ levels, float thr, int pass /* 0 = count, 1 = emit */)
 {
     __shared__ uint32_t wave_cnt[4];
-    const AkLevelDev L = levels[blockIdx.y];
+    const AkLevelDev L = levels[blockIdx.z * gridDim.y + blockIdx.y];
     if ((int)blockIdx.x >= L.h - 2 * L.border) return;                 // workgroup-uniform: this level has fewer rows
     if (pass && L.counts[0] == 0) return;
     const int y = L.border + blockIdx.x;
@@ -319,6 +337,40 @@ void ak_scan_rows_kernel(const AkLevelDev* __restrict__ levels)
     r3dm_syncthreads();
     uint32_t run = part[threadIdx.x];
     for (int k = b; k < e; ++k) { L.row_off[k] = run; run += L.row_cnt[k]; }
+}
+
+// Candidate slots of every level of every image, laid out ON THE DEVICE from the counts the count pass left (no host round trip
+// to size them): the slot arrays are field-major over the batch -- field f of image b starts at base_f + b * cap elements --
+// and the levels of an image follow each other inside its slice.  An image with more candidates than `cap` gets empty levels
+// (counts[0] = 0: every later kernel sees nothing to do for it) and reports its need; the host then grows the arrays and
+// repeats the detection phase (api_features.cpp).  One thread per image.
+__global__ void ak_layout_kernel(AkLevelDev* __restrict__ levels, int n_levels, unsigned char* __restrict__ slots, uint32_t cap,
+                                 uint32_t n_images, AkBatchMeta* __restrict__ meta)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_images) return;
+    AkLevelDev* L = levels + (size_t)b * n_levels;
+    uint32_t total = 0;
+    for (int i = 0; i < n_levels; ++i) total += L[i].counts[0];
+    const bool over = total > cap;
+    meta[b].need = total; meta[b].overflow = over ? 1u : 0u; meta[b].n_kp = 0u;
+    const size_t field = (size_t)n_images * cap;            // elements per field region
+    unsigned char* p = slots;
+    float4* cand = (float4*)p + (size_t)b * cap;            p += field * 16;
+    float4* list = (float4*)p + (size_t)b * cap;            p += field * 16;
+    float*  live = (float*)p + 4 * (size_t)b * cap;         p += field * 16;
+    float4* out0 = (float4*)p + (size_t)b * cap;            p += field * 16;
+    float2* out1 = (float2*)p + (size_t)b * cap;            p += field * 8;
+    uint32_t* valid = (uint32_t*)p + (size_t)b * cap;       p += field * 4;
+    unsigned char* dl = p + (size_t)b * cap;                p += field;
+    unsigned char* du = p + (size_t)b * cap;
+    size_t off = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        if (over) L[i].counts[0] = 0;
+        L[i].cand = cand + off; L[i].list = list + off; L[i].live = live + 4 * off; L[i].out0 = out0 + off; L[i].out1 = out1 + off;
+        L[i].out_valid = valid + off; L[i].dead_lower = dl + off; L[i].dead_upper = du + off;
+        off += L[i].counts[0];
+    }
 }
 
 // ---- in-level pruning (Find_Scale_Space_Extrema, first loop): candidates in raster order; a candidate within `size` of
@@ -503,29 +555,32 @@ void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mo
     // gridDim.z workgroups, each of which only ever STORES a 1 into the (zero-initialised) flag array
     __shared__ float4 sk[256];
     __shared__ unsigned char sdead[256];
-    const int vi = blockIdx.y;                                   // victim level
+    // blockIdx.y = image * n_levels + victim level; the list lengths live on the device, so the victims are covered by a
+    // grid-stride loop over chunks of 256 instead of a grid sized by the host
+    const int vi = (int)(blockIdx.y % (unsigned)n_levels);       // victim level
     const int ki = mode == 0 ? vi + 1 : vi - 1;                  // killer level
     if (ki < 0 || ki >= n_levels) return;
-    const AkLevelDev V = levels[vi], K = levels[ki];
+    const AkLevelDev V = levels[blockIdx.y], K = levels[(int)blockIdx.y + (ki - vi)];
     const uint32_t nv = V.counts[1], nk = K.counts[1];
-    if (blockIdx.x * 256u >= nv) return;                         // workgroup-uniform: before any barrier
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    const float4 v = q < nv ? V.list[q] : make_float4(0, 0, 0, 0);
     const float r = mode == 0 ? K.psize : V.psize, r2 = r * r;
-    bool dead = false;
-    for (uint32_t j0 = blockIdx.z * 256u; j0 < nk; j0 += 256u * gridDim.z) {
-        const uint32_t j = j0 + threadIdx.x;
-        if (j < nk) { sk[threadIdx.x] = K.list[j]; sdead[threadIdx.x] = (mode == 1 && K.dead_lower[j]) ? 1 : 0; }
-        r3dm_syncthreads();
-        const uint32_t cnt = nk - j0 < 256u ? nk - j0 : 256u;
-        for (uint32_t t = 0; t < cnt; ++t) {
-            const float4 p = sk[t];
-            const float dx = p.x - v.x, dy = p.y - v.y;
-            dead |= !sdead[t] && (dx * dx + dy * dy <= r2) && (p.z > v.z);
+    for (uint32_t q0 = blockIdx.x * 256u; q0 < nv; q0 += 256u * gridDim.x) {      // workgroup-uniform bounds
+        const uint32_t q = q0 + threadIdx.x;
+        const float4 v = q < nv ? V.list[q] : make_float4(0, 0, 0, 0);
+        bool dead = false;
+        for (uint32_t j0 = blockIdx.z * 256u; j0 < nk; j0 += 256u * gridDim.z) {
+            const uint32_t j = j0 + threadIdx.x;
+            if (j < nk) { sk[threadIdx.x] = K.list[j]; sdead[threadIdx.x] = (mode == 1 && K.dead_lower[j]) ? 1 : 0; }
+            r3dm_syncthreads();
+            const uint32_t cnt = nk - j0 < 256u ? nk - j0 : 256u;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                const float4 p = sk[t];
+                const float dx = p.x - v.x, dy = p.y - v.y;
+                dead |= !sdead[t] && (dx * dx + dy * dy <= r2) && (p.z > v.z);
+            }
+            r3dm_syncthreads();
         }
-        r3dm_syncthreads();
+        if (q < nv && dead) (mode == 0 ? V.dead_lower : V.dead_upper)[q] = 1;
     }
-    if (q < nv && dead) (mode == 0 ? V.dead_lower : V.dead_upper)[q] = 1;
 }
 
 // ---- sub-pixel refinement + dominant gradient direction (Do_Subpixel_Refinement, Compute_Main_Orientation up to the
@@ -556,88 +611,126 @@ __device__ __forceinline__ float ak_fast_atan2(float y, float x)
 __device__ const signed char kRad6[109][2] = { {-5, -3}, {-5, -2}, {-5, -1}, {-5, 0}, {-5, 1}, {-5, 2}, {-5, 3}, {-4, -4}, {-4, -3}, {-4, -2}, {-4, -1}, {-4, 0}, {-4, 1}, {-4, 2}, {-4, 3}, {-4, 4}, {-3, -5}, {-3, -4}, {-3, -3}, {-3, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-3, 2}, {-3, 3}, {-3, 4}, {-3, 5}, {-2, -5}, {-2, -4}, {-2, -3}, {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2}, {-2, 3}, {-2, 4}, {-2, 5}, {-1, -5}, {-1, -4}, {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3}, {-1, 4}, {-1, 5}, {0, -5}, {0, -4}, {0, -3}, {0, -2}, {0, -1}, {0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {1, -5}, {1, -4}, {1, -3}, {1, -2}, {1, -1}, {1, 0}, {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {2, -5}, {2, -4}, {2, -3}, {2, -2}, {2, -1}, {2, 0}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {2, 5}, {3, -5}, {3, -4}, {3, -3}, {3, -2}, {3, -1}, {3, 0}, {3, 1}, {3, 2}, {3, 3}, {3, 4}, {3, 5}, {4, -4}, {4, -3}, {4, -2}, {4, -1}, {4, 0}, {4, 1}, {4, 2}, {4, 3}, {4, 4}, {5, -3}, {5, -2}, {5, -1}, {5, 0}, {5, 1}, {5, 2}, {5, 3} };
 
 // one wavefront per list entry: lanes sample and take the angles in parallel, lane 0 runs the order-sensitive parts
-// (counting sort, sliding-window sums) out of LDS
+// (counting sort, sliding-window sums) out of LDS.  blockIdx.y = image * n_levels + level; the list lengths live on the
+// device, so the entries of a level are covered by a grid-stride loop (gridDim.x wavefronts per level).
 __global__ __launch_bounds__(64)
 void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
 {
     __shared__ float resX[112], resY[112], Ang[112];
     __shared__ unsigned char sorted_idx[112], slice[48];
     const AkLevelDev L = levels[blockIdx.y];
-    const uint32_t j = blockIdx.x;
-    if (j >= L.counts[1]) return;
+    const uint32_t n_list = L.counts[1];
     const int lane = threadIdx.x;
-    float4 kp = L.list[j];
-    if (L.dead_lower[j] || L.dead_upper[j]) {
-        if (lane == 0) { L.out0[j] = make_float4(0, 0, 0, 0); L.out1[j] = make_float2(0, 0); L.out_valid[j] = 0; }
-        return;
-    }
     const float* __restrict__ ldet = L.Ldet;
     const int cols = L.w;
     const float ratio = L.ratio;
-    const int x = (int)(kp.x / ratio), y = (int)(kp.y / ratio);
-    const float Dx = 0.5f * (ldet[y * cols + x + 1] - ldet[y * cols + x - 1]);
-    const float Dy = 0.5f * (ldet[(y + 1) * cols + x] - ldet[(y - 1) * cols + x]);
-    const float Dxx = ldet[y * cols + x + 1] + ldet[y * cols + x - 1] - 2.0f * ldet[y * cols + x];
-    const float Dyy = ldet[(y + 1) * cols + x] + ldet[(y - 1) * cols + x] - 2.0f * ldet[y * cols + x];
-    const float Dxy = 0.25f * (ldet[(y + 1) * cols + x + 1] + ldet[(y - 1) * cols + x - 1] -
-                               ldet[(y - 1) * cols + x + 1] - ldet[(y + 1) * cols + x - 1]);
-    float dx = 0.0f, dy = 0.0f;
-    {
-        const float b0 = -Dx, b1 = -Dy;
-        double d = (double)Dxx * Dyy - (double)Dxy * Dxy;
-        if (d != 0.) {
-            d = 1. / d;
-            const double t = (float)(((double)b0 * Dyy - (double)b1 * Dxy) * d);
-            dy = (float)(((double)b1 * Dxx - (double)b0 * Dxy) * d);
-            dx = (float)t;
+    for (uint32_t j = blockIdx.x; j < n_list; j += gridDim.x) {
+        float4 kp = L.list[j];
+        bool drop = L.dead_lower[j] || L.dead_upper[j];             // wave-uniform
+        float dx = 0.0f, dy = 0.0f;
+        if (!drop) {
+            const int x = (int)(kp.x / ratio), y = (int)(kp.y / ratio);
+            const float Dx = 0.5f * (ldet[y * cols + x + 1] - ldet[y * cols + x - 1]);
+            const float Dy = 0.5f * (ldet[(y + 1) * cols + x] - ldet[(y - 1) * cols + x]);
+            const float Dxx = ldet[y * cols + x + 1] + ldet[y * cols + x - 1] - 2.0f * ldet[y * cols + x];
+            const float Dyy = ldet[(y + 1) * cols + x] + ldet[(y - 1) * cols + x] - 2.0f * ldet[y * cols + x];
+            const float Dxy = 0.25f * (ldet[(y + 1) * cols + x + 1] + ldet[(y - 1) * cols + x - 1] -
+                                       ldet[(y - 1) * cols + x + 1] - ldet[(y + 1) * cols + x - 1]);
+            const float b0 = -Dx, b1 = -Dy;
+            double d = (double)Dxx * Dyy - (double)Dxy * Dxy;
+            if (d != 0.) {
+                d = 1. / d;
+                const double t = (float)(((double)b0 * Dyy - (double)b1 * Dxy) * d);
+                dy = (float)(((double)b1 * Dxx - (double)b0 * Dxy) * d);
+                dx = (float)t;
+            }
+            drop = fabsf(dx) > 1.0f || fabsf(dy) > 1.0f;            // wave-uniform: every lane computed the same values
+        }
+        if (drop) {
+            if (lane == 0) { L.out0[j] = make_float4(0, 0, 0, 0); L.out1[j] = make_float2(0, 0); L.out_valid[j] = 0; }
+            continue;
+        }
+        kp.x += dx * ratio; kp.y += dy * ratio;
+        const float size = L.psize * 2.0f;
+        const int scale = (int)(0.5f * size / ratio + 0.5f);
+        const int x0 = (int)(kp.x / ratio + 0.5f), y0 = (int)(kp.y / ratio + 0.5f);
+        for (int k = lane; k < 109; k += 64) {
+            const int i = kRad6[k][0], jj = kRad6[k][1];
+            const float wgt = kGauss25[i < 0 ? -i : i][jj < 0 ? -jj : jj];
+            const size_t p = (size_t)(y0 + i * scale) * cols + (x0 + jj * scale);
+            const float rx = wgt * L.Lx[p], ry = wgt * L.Ly[p];
+            resX[k] = rx; resY[k] = ry; Ang[k] = ak_fast_atan2(ry, rx);
+        }
+        r3dm_syncthreads();
+        if (lane == 0) {
+            constexpr int slices = 42, win = 7;
+            const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
+            const int nkeys = (int)(0x1.921fb6p+2f / ang_step);   // (float)(2 pi) / ang_step = 42
+            for (int i = 0; i <= nkeys; ++i) slice[i] = 0;
+            for (int i = 0; i < 109; ++i) slice[(int)(Ang[i] / ang_step)]++;
+            for (int i = 1; i <= nkeys; ++i) slice[i] += slice[i - 1];
+            for (int i = 0; i < 109; ++i) sorted_idx[--slice[(int)(Ang[i] / ang_step)]] = (unsigned char)i;
+            float maxX = 0.0f, maxY = 0.0f;
+            for (int i = slice[0]; i < slice[win]; ++i) { maxX += resX[sorted_idx[i]]; maxY += resY[sorted_idx[i]]; }
+            float maxNorm = maxX * maxX + maxY * maxY;
+            for (int sn = 1; sn <= slices - win; ++sn) {
+                if (slice[sn] == slice[sn - 1] && slice[sn + win] == slice[sn + win - 1]) continue;
+                float sumX = 0.0f, sumY = 0.0f;
+                for (int i = slice[sn]; i < slice[sn + win]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+                const float nrm = sumX * sumX + sumY * sumY;
+                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
+            }
+            for (int sn = slices - win + 1; sn < slices; ++sn) {
+                const int remain = sn + win - slices;
+                if (slice[sn] == slice[sn - 1] && slice[remain] == slice[remain - 1]) continue;
+                float sumX = 0.0f, sumY = 0.0f;
+                for (int i = slice[sn]; i < slice[slices]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+                for (int i = slice[0]; i < slice[remain]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
+                const float nrm = sumX * sumX + sumY * sumY;
+                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
+            }
+            L.out0[j] = make_float4(kp.x, kp.y, size, kp.z);
+            L.out1[j] = make_float2(maxX, maxY);
+            L.out_valid[j] = 1;
+        }
+        r3dm_syncthreads();                                       // the next entry overwrites resX / resY / Ang
+    }
+}
+
+// ---- the surviving keypoints of every image, compacted in the reference's order (evolution level, then list order) into one
+// record array per image: what crosses to the host for the angle (getAngleV2 = atan2 of the host libm, utils.h of fast-akaze)
+// and comes back as the LIOP warp -- 32 bytes per keypoint, one copy each way.  One workgroup per image.
+__global__ __launch_bounds__(256)
+void ak_compact_kernel(const AkLevelDev* __restrict__ levels, int n_levels, AkKpRec* __restrict__ recs, uint32_t cap,
+                       AkBatchMeta* __restrict__ meta)
+{
+    __shared__ uint32_t wave_cnt[4];
+    const uint32_t b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    AkKpRec* out = recs + (size_t)b * cap;
+    uint32_t base = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const AkLevelDev L = levels[(size_t)b * n_levels + i];
+        const uint32_t n = L.counts[1];
+        for (uint32_t j0 = 0; j0 < n; j0 += 256) {
+            const uint32_t j = j0 + threadIdx.x;
+            const bool v = j < n && L.out_valid[j] != 0;
+            const unsigned long long bal = __ballot(v);
+            if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+            r3dm_syncthreads();
+            uint32_t woff = 0, tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const uint32_t cw = wave_cnt[q]; if (q < wave) woff += cw; tot += cw; }
+            if (v) {
+                const float4 o0 = L.out0[j]; const float2 o1 = L.out1[j];
+                AkKpRec r; r.x = o0.x; r.y = o0.y; r.size = o0.z; r.response = o0.w; r.max_x = o1.x; r.max_y = o1.y; r.level = (uint32_t)i; r.pad = 0;
+                out[base + woff + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = r;
+            }
+            base += tot;
+            r3dm_syncthreads();
         }
     }
-    if (fabsf(dx) > 1.0f || fabsf(dy) > 1.0f) {                   // wave-uniform: every lane computed the same values
-        if (lane == 0) { L.out0[j] = make_float4(0, 0, 0, 0); L.out1[j] = make_float2(0, 0); L.out_valid[j] = 0; }
-        return;
-    }
-    kp.x += dx * ratio; kp.y += dy * ratio;
-    const float size = L.psize * 2.0f;
-    const int scale = (int)(0.5f * size / ratio + 0.5f);
-    const int x0 = (int)(kp.x / ratio + 0.5f), y0 = (int)(kp.y / ratio + 0.5f);
-    for (int k = lane; k < 109; k += 64) {
-        const int i = kRad6[k][0], jj = kRad6[k][1];
-        const float wgt = kGauss25[i < 0 ? -i : i][jj < 0 ? -jj : jj];
-        const size_t p = (size_t)(y0 + i * scale) * cols + (x0 + jj * scale);
-        const float rx = wgt * L.Lx[p], ry = wgt * L.Ly[p];
-        resX[k] = rx; resY[k] = ry; Ang[k] = ak_fast_atan2(ry, rx);
-    }
-    r3dm_syncthreads();
-    if (lane != 0) return;
-    constexpr int slices = 42, win = 7;
-    const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
-    const int nkeys = (int)(0x1.921fb6p+2f / ang_step);   // (float)(2 pi) / ang_step = 42
-    for (int i = 0; i <= nkeys; ++i) slice[i] = 0;
-    for (int i = 0; i < 109; ++i) slice[(int)(Ang[i] / ang_step)]++;
-    for (int i = 1; i <= nkeys; ++i) slice[i] += slice[i - 1];
-    for (int i = 0; i < 109; ++i) sorted_idx[--slice[(int)(Ang[i] / ang_step)]] = (unsigned char)i;
-    float maxX = 0.0f, maxY = 0.0f;
-    for (int i = slice[0]; i < slice[win]; ++i) { maxX += resX[sorted_idx[i]]; maxY += resY[sorted_idx[i]]; }
-    float maxNorm = maxX * maxX + maxY * maxY;
-    for (int sn = 1; sn <= slices - win; ++sn) {
-        if (slice[sn] == slice[sn - 1] && slice[sn + win] == slice[sn + win - 1]) continue;
-        float sumX = 0.0f, sumY = 0.0f;
-        for (int i = slice[sn]; i < slice[sn + win]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-        const float nrm = sumX * sumX + sumY * sumY;
-        if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
-    }
-    for (int sn = slices - win + 1; sn < slices; ++sn) {
-        const int remain = sn + win - slices;
-        if (slice[sn] == slice[sn - 1] && slice[remain] == slice[remain - 1]) continue;
-        float sumX = 0.0f, sumY = 0.0f;
-        for (int i = slice[sn]; i < slice[slices]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-        for (int i = slice[0]; i < slice[remain]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-        const float nrm = sumX * sumX + sumY * sumY;
-        if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
-    }
-    L.out0[j] = make_float4(kp.x, kp.y, size, kp.z);
-    L.out1[j] = make_float2(maxX, maxY);
-    L.out_valid[j] = 1;
+    if (threadIdx.x == 0) meta[b].n_kp = base;
 }
 
 // ---- MLDB-486 descriptor (MLDB_Full_Descriptor_InvokerV2, AKAZEFeatures.cpp:1790-1909): 2 keypoints per wavefront, one lane per
@@ -721,93 +814,106 @@ hipError_t ak_mldb(hipStream_t st, const AkLevelDev* levels, const AkMldbItem* i
     return hipGetLastError();
 }
 
-static dim3 ak_grid(int w, int h) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4)); }
+static dim3 ak_grid(int w, int h, int B) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)B); }
 
-hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf)
+// every launcher: B = images of the batch (same size), buffers hold B planes of the launch's w x h back to back
+hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int B, const AkTaps& kf)
 {
-    hipLaunchKernelGGL(ak_gauss_rows_kernel, ak_grid(w, h), dim3(256), 0, st, src, tmp, w, h, kf);
-    hipLaunchKernelGGL(ak_gauss_cols_kernel, ak_grid(w, h), dim3(256), 0, st, tmp, dst, w, h, kf);
+    hipLaunchKernelGGL(ak_gauss_rows_kernel, ak_grid(w, h, B), dim3(256), 0, st, src, tmp, w, h, kf);
+    hipLaunchKernelGGL(ak_gauss_cols_kernel, ak_grid(w, h, B), dim3(256), 0, st, tmp, dst, w, h, kf);
     return hipGetLastError();
 }
-hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h)
+hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h, int B)
 {
-    hipLaunchKernelGGL(ak_scharr_rows_kernel, ak_grid(w, h), dim3(256), 0, st, src, rd, rs, w, h);
-    hipLaunchKernelGGL(ak_scharr_cols_kernel, ak_grid(w, h), dim3(256), 0, st, rd, rs, Lx, Ly, w, h);
+    hipLaunchKernelGGL(ak_scharr_rows_kernel, ak_grid(w, h, B), dim3(256), 0, st, src, rd, rs, w, h);
+    hipLaunchKernelGGL(ak_scharr_cols_kernel, ak_grid(w, h, B), dim3(256), 0, st, rd, rs, Lx, Ly, w, h);
     return hipGetLastError();
 }
-hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int s)
+hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int B, int s)
 {
-    hipLaunchKernelGGL(ak_sderiv_xy_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst_x, dst_y, w, h, s);
+    hipLaunchKernelGGL(ak_sderiv_xy_kernel, ak_grid(w, h, B), dim3(256), 0, st, src, dst_x, dst_y, w, h, s);
     return hipGetLastError();
 }
-hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int s)
+hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int B, int s)
 {
-    hipLaunchKernelGGL(ak_sderiv_det_kernel, ak_grid(w, h), dim3(256), 0, st, ly, lxx, lxy, ldet, w, h, s);
+    hipLaunchKernelGGL(ak_sderiv_det_kernel, ak_grid(w, h, B), dim3(256), 0, st, ly, lxx, lxy, ldet, w, h, s);
     return hipGetLastError();
 }
-hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max)
+hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, uint32_t* out_max)
 {
     const int rows = h - 2 < 1024 ? (h - 2 < 1 ? 1 : h - 2) : 1024;
-    hipLaunchKernelGGL(ak_modg_max_kernel, dim3((unsigned)rows), dim3(256), 0, st, Lx, Ly, w, h, out_max);
+    hipLaunchKernelGGL(ak_modg_max_kernel, dim3((unsigned)rows, 1, (unsigned)B), dim3(256), 0, st, Lx, Ly, w, h, out_max);
     return hipGetLastError();
 }
-hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, const uint32_t* hmax_bits, int nbins, uint32_t* hist)
+hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist)
 {
     if (nbins > 512) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)((h - 2 + 63) / 64)), dim3(256), 0, st, Lx, Ly, w, h, hmax_bits, nbins, hist);
+    hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)((h - 2 + 63) / 64), (unsigned)B), dim3(256), 0, st, Lx, Ly, w, h, hmax_bits, nbins, hist);
     return hipGetLastError();
 }
-hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2)
+hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2, int B)
 {
-    hipLaunchKernelGGL(ak_kcontrast_kernel, dim3(1), dim3(1), 0, st, hmax_bits, hist, nbins, total, have_hist, inv_k2);
+    hipLaunchKernelGGL(ak_kcontrast_kernel, dim3((unsigned)B), dim3(1), 0, st, hmax_bits, hist, nbins, total, have_hist, inv_k2);
     return hipGetLastError();
 }
-hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, const float* inv_k2)
+hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, int B, const float* inv_k2)
 {
-    hipLaunchKernelGGL(ak_scharr_g2_kernel, ak_grid(w, h), dim3(256), 0, st, src, dst, w, h, inv_k2);
+    hipLaunchKernelGGL(ak_scharr_g2_kernel, ak_grid(w, h, B), dim3(256), 0, st, src, dst, w, h, inv_k2);
     return hipGetLastError();
 }
-hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size)
+hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, float step_size)
 {
-    hipLaunchKernelGGL(ak_fed_step_kernel, ak_grid(w, h), dim3(256), 0, st, Lt, Lf, out, w, h, step_size);
+    hipLaunchKernelGGL(ak_fed_step_kernel, ak_grid(w, h, B), dim3(256), 0, st, Lt, Lf, out, w, h, step_size);
     return hipGetLastError();
 }
-hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
+hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb)
 {
     const int dw = w / 2, dh = h / 2;
-    if (dw * 2 == w && dh * 2 == h) hipLaunchKernelGGL(ak_half_fast_kernel, ak_grid(dw, dh), dim3(256), 0, st, src, dst, w, dw, dh);
-    else hipLaunchKernelGGL(ak_half_area_kernel, ak_grid(dw, dh), dim3(256), 0, st, src, dst, w, dw, dh, xt, xb, yt, yb);
+    if (dw * 2 == w && dh * 2 == h) hipLaunchKernelGGL(ak_half_fast_kernel, ak_grid(dw, dh, B), dim3(256), 0, st, src, dst, w, h, dw, dh);
+    else hipLaunchKernelGGL(ak_half_area_kernel, ak_grid(dw, dh, B), dim3(256), 0, st, src, dst, w, h, dw, dh, xt, xb, yt, yb);
     return hipGetLastError();
 }
-hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int max_rows, float thr, int pass)
+// levels: [B][n_levels]
+hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int max_rows, float thr, int pass)
 {
     if (max_rows <= 0 || n_levels <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ak_extrema_kernel, dim3((unsigned)max_rows, (unsigned)n_levels), dim3(256), 0, st, levels, thr, pass);
+    hipLaunchKernelGGL(ak_extrema_kernel, dim3((unsigned)max_rows, (unsigned)n_levels, (unsigned)B), dim3(256), 0, st, levels, thr, pass);
     return hipGetLastError();
 }
-hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels)
+hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels, int B)
 {
-    hipLaunchKernelGGL(ak_scan_rows_kernel, dim3((unsigned)n_levels), dim3(1024), 0, st, levels);
+    hipLaunchKernelGGL(ak_scan_rows_kernel, dim3((unsigned)(n_levels * B)), dim3(1024), 0, st, levels);
     return hipGetLastError();
 }
-hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels)
+hipError_t ak_layout(hipStream_t st, AkLevelDev* levels, int n_levels, int B, unsigned char* slots, uint32_t cap, AkBatchMeta* meta)
+{
+    hipLaunchKernelGGL(ak_layout_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, levels, n_levels, slots, cap, (uint32_t)B, meta);
+    return hipGetLastError();
+}
+hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels, int B)
 {
     // R3DM_AK_LIVE_CAP (test hook): a small LDS capacity forces the global-scratch fallback of the in-level pruning
     static const uint32_t live_cap = [] { const int c = r3dm_dev_knob("R3DM_AK_LIVE_CAP", kAkLive); return (uint32_t)(c < 1 ? 1 : c > kAkLive ? kAkLive : c); }();
-    hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)n_levels), dim3(64), 0, st, levels, live_cap);
+    hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)(n_levels * B)), dim3(64), 0, st, levels, live_cap);
     return hipGetLastError();
 }
-hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list, int mode)
+hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int mode)
 {
-    if (max_list == 0) return hipSuccess;
-    hipLaunchKernelGGL(ak_cross_kernel, dim3((max_list + 255) / 256, (unsigned)n_levels, 8), dim3(256), 0, st, levels, n_levels, mode);
+    // 16 x 256 victims per pass of the grid-stride loop, the killers of a victim chunk dealt to 8 workgroups
+    hipLaunchKernelGGL(ak_cross_kernel, dim3(16, (unsigned)(n_levels * B), 8), dim3(256), 0, st, levels, n_levels, mode);
     return hipGetLastError();
 }
-hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list)
+hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, int B)
 {
-    if (max_list == 0) return hipSuccess;
-    hipLaunchKernelGGL(ak_refine_kernel, dim3(max_list, (unsigned)n_levels), dim3(64), 0, st, levels);
+    // gridDim.x wavefronts share the entries of a level: enough to fill the chip when one level holds most of the list
+    const unsigned per_level = (unsigned)std::max(64, 4096 / (n_levels * B));
+    hipLaunchKernelGGL(ak_refine_kernel, dim3(per_level, (unsigned)(n_levels * B)), dim3(64), 0, st, levels);
+    return hipGetLastError();
+}
+hipError_t ak_compact(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, AkKpRec* recs, uint32_t cap, AkBatchMeta* meta)
+{
+    hipLaunchKernelGGL(ak_compact_kernel, dim3((unsigned)B), dim3(256), 0, st, levels, n_levels, recs, cap, meta);
     return hipGetLastError();
 }
 

@@ -282,13 +282,16 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 __global__ __launch_bounds__(256)
-void liop_extract_patches_kernel(const float* __restrict__ image, int w, int h, const float* __restrict__ M6,
-                                 const float* __restrict__ kern /* 11 taps */, uint32_t n, float* __restrict__ patches)
+void liop_extract_patches_kernel(const float* __restrict__ image0, int w, int h, const float* __restrict__ M6,
+                                 const float* __restrict__ kern /* 11 taps */, uint32_t n, float* __restrict__ patches,
+                                 const uint32_t* __restrict__ img_of)
 {
     __shared__ float warped[kLiopPix];
     __shared__ float rowp[kLiopPix];
     const int S = kLiopSide;
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        // keypoints of a batch of same-size images in one launch: the keypoint's own image plane
+        const float* __restrict__ image = image0 + (img_of ? (size_t)img_of[item] * ((size_t)w * (size_t)h) : 0);
         double M[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) M[k] = (double)M6[6 * (size_t)item + k];
@@ -332,11 +335,11 @@ void liop_extract_patches_kernel(const float* __restrict__ image, int w, int h, 
 }
 
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
-                               uint32_t n, float* patches)
+                               uint32_t n, float* patches, const uint32_t* img_of)
 {
     if (n == 0) return hipSuccess;
     const uint32_t grid = n < 65536u ? n : 65536u;
-    hipLaunchKernelGGL(liop_extract_patches_kernel, dim3(grid), dim3(256), 0, st, image, w, h, M6, kern, n, patches);
+    hipLaunchKernelGGL(liop_extract_patches_kernel, dim3(grid), dim3(256), 0, st, image, w, h, M6, kern, n, patches, img_of);
     return hipGetLastError();
 }
 

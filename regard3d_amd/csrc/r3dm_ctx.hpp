@@ -43,6 +43,23 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// page-locked host memory (device-to-host copies into it run at link speed and are truly asynchronous)
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 struct HostImage {
     uint32_t view_id = 0, n = 0, dim = 0, width = 0, height = 0;
     r3dm_dtype dtype = R3DM_F32;
@@ -112,18 +129,19 @@ struct r3dm_ctx {
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff, f_order;
-    std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size
-    int ak_w = 0, ak_h = 0;
-    hipGraphExec_t ak_graph = nullptr;                      // the scale-space launch sequence of the last image size, captured once
-    int ak_graph_w = 0, ak_graph_h = 0;
-    bool ak_graph_off = false;                              // capture failed once: plain stream launches from then on
+    std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size, ak_B planes each
+    int ak_w = 0, ak_h = 0, ak_B = 0;
+    uint32_t ak_cap = 0;                                    // candidate slots per image the detector last needed (grows, never shrinks)
+    int ak_n_levels = 0;
+    AkLevelDev* ak_levels_dev = nullptr;                    // level table of the last detector pass (inside ak_bufs; read by the MLDB kernel)
+    PinBuf pin_desc;                                        // page-locked landing zone of the LIOP descriptors of a batch
     bool integer_mfma = false;                              // r3dm_set_integer_mfma
     bool split_mfma = false;                                // r3dm_set_split_mfma
     bool hamming_mfma = false;                              // r3dm_set_hamming_mfma
     uint32_t liop_npix = 0;
     uint64_t n_views_staged = 0;                            // copies + re-layouts since r3dm_create (never reset)
-    uint64_t n_ak_graph_replays = 0;                        // detector calls served by the captured launch sequence (never reset)
     r3dm_stats stats{};
+    r3dm_features_totals feat_totals{};                      // since r3dm_create (r3dm_get_features_totals)
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
 };
 

@@ -217,25 +217,34 @@ struct AkLevelDev {
     unsigned char* dead_lower; unsigned char* dead_upper;
     float4* out0; float2* out1; uint32_t* out_valid;     // refined (x, y, size, response), dominant gradient vector, kept?
 };
-struct AkMldbItem { uint32_t level; float xf, yf, co, si, scale; };   // keypoint in level coordinates, cos / sin of its angle, sigma_size
+struct AkMldbItem { uint32_t level; float xf, yf, co, si, scale; };   // keypoint in level coordinates (level = image * n_levels + level), cos / sin of its angle, sigma_size
+// per image of a batch, written by the device: candidates the count pass found, whether they exceeded the slot capacity (then the
+// image's lists were not built and the host repeats the detection phase with larger slot arrays), keypoints compacted
+struct AkBatchMeta { uint32_t need, overflow, n_kp, pad; };
+// one surviving keypoint as it crosses to the host: refined position, size (diameter), response, dominant gradient vector, level
+struct AkKpRec { float x, y, size, response, max_x, max_y; uint32_t level, pad; };
+// All launchers: B = images of the batch (same size); image buffers hold B planes back to back; levels = [B][n_levels].
 hipError_t ak_mldb(hipStream_t st, const AkLevelDev* levels, const AkMldbItem* items, uint32_t n, const unsigned char* pairs, unsigned char* out);
 hipError_t ak_bgr_to_gray(hipStream_t st, const unsigned char* bgr, float* gray, size_t n);
-hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, const AkTaps& kf);
-hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h);
-hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, const float* inv_k2);
-hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2);
-hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int s);
-hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int s);
-hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, uint32_t* out_max);
-hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
-hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, float step_size);
-hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, const AkAreaTab* xt, const int* xb,
+hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int B, const AkTaps& kf);
+hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, float* Lx, float* Ly, int w, int h, int B);
+hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, int B, const float* inv_k2);
+hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2, int B);
+hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int B, int s);
+hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int B, int s);
+hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, uint32_t* out_max);
+hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
+hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, float step_size);
+hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);
-hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int max_rows, float thr, int pass);
-hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels);
-hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels);
-hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list, int mode);
-hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, uint32_t max_list);
+hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int max_rows, float thr, int pass);
+hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels, int B);
+hipError_t ak_layout(hipStream_t st, AkLevelDev* levels, int n_levels, int B, unsigned char* slots, uint32_t cap, AkBatchMeta* meta);
+hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels, int B);
+hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int mode);
+hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, int B);
+hipError_t ak_compact(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, AkKpRec* recs, uint32_t cap, AkBatchMeta* meta);
+constexpr uint32_t kAkSlotBytes = 80;                  // per candidate slot: cand 16 + list 16 + live 16 + out0 16 + out1 8 + valid 4 + dead 2 (+ 2 spare)
 
 // ---- launchers implemented in the .hip files (host side) ----
 hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
@@ -264,8 +273,9 @@ hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_
 hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim, int rows_mode);
 hipError_t launch_ann_rows16(hipStream_t st, const float* rows, uint16_t* rows16, size_t n_elems);
 hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, size_t n_elems);
+// img_of (optional): image of the batch each keypoint belongs to -- its pixels start img_of[k] * w * h floats into `image`
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
-                               uint32_t n, float* patches);
+                               uint32_t n, float* patches, const uint32_t* img_of = nullptr);
 hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
                        uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches);
 

@@ -238,3 +238,70 @@ def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda"
         w = torch.full((n_feat,), -1, device=device, dtype=torch.int64); w[:n_shared] = ids
         wids[i] = w[perm]
     return descs, xys, wids
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic PHOTOGRAPHS (the features stage and the whole-stage bench: pixels -> matches.*.txt)
+# ------------------------------------------------------------------------------------------------
+def _texture(hh: int, ww: int, seed: int, device):
+    """A [hh, ww] float32 texture in [0, 1] with structure at every scale from 3 px to 200 px: band-limited noise octaves
+    (what a determinant-of-Hessian detector fires on) -- seeded, generated on `device` with torch."""
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    img = torch.full((1, 1, hh, ww), 0.5, device=device)
+    for cell, amp in ((192, 0.10), (96, 0.10), (48, 0.09), (24, 0.08), (12, 0.07), (6, 0.06), (3, 0.03)):
+        gh, gw = hh // cell + 3, ww // cell + 3
+        n = torch.randn((1, 1, gh, gw), generator=g, device=device)
+        up = F.interpolate(n, size=(gh * cell, gw * cell), mode="bicubic", align_corners=False)
+        img = img + amp * up[:, :, cell:cell + hh, cell:cell + ww]
+    return img.clamp_(0.0, 1.0)[0, 0]
+
+
+def make_photo(h: int = HEIGHT, w: int = WIDTH, seed: int = 0, device="cpu") -> np.ndarray:
+    """one [h, w] float32 gray image in [0, 1], 8-bit quantised (value / 255 as the reference's loader produces)"""
+    import torch
+    t = _texture(h, w, seed, device)
+    return (torch.round(t * 255.0) * np.float32(1.0 / 255.0)).cpu().numpy().astype(np.float32)
+
+
+def make_photo_set(n_images: int, h: int = HEIGHT, w: int = WIDTH, seed: int = 7, device="cpu", overlap_step: float = 0.22,
+                   bgr: bool = False, noise: float = 0.004):
+    """n_images photographs of ONE textured plane taken by a camera that moves along it: view i sees the window of the world
+    texture starting at i * overlap_step * w (so neighbours share 78 %, views 4 steps apart 12 %, 5 apart nothing) through its
+    own small homography (rotation, scale, perspective) with its own sensor noise, quantised to 8 bits -- the F / E / H filters
+    have true inliers on the overlapping pairs and nothing on the others.
+    Returns (images, K): images = list of torch tensors on `device`, [h, w] float32 (gray / 255) or, with bgr=True,
+    [h, w, 3] uint8 (a colour cast per channel, what cv::imread would decode); K = the 3x3 pinhole matrix used (f = 1.2 w)."""
+    import torch
+    import torch.nn.functional as F
+
+    step = overlap_step * w
+    ww = int(w + step * (n_images - 1) + 0.2 * w) + 8
+    hh = int(1.2 * h) + 8
+    world = _texture(hh, ww, seed, device)[None, None]
+    rng = np.random.default_rng(seed)
+    f = 1.2 * w
+    K = np.array([[f, 0, 0.5 * w], [0, f, 0.5 * h], [0, 0, 1.0]])
+    ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32), torch.arange(w, device=device, dtype=torch.float32), indexing="ij")
+    out = []
+    for i in range(n_images):
+        a = rng.normal(0, 0.02); s = 1.0 + rng.normal(0, 0.03)
+        px, py = rng.normal(0, 2e-6, 2)                                        # perspective terms
+        tx = 0.1 * w + i * step + rng.normal(0, 0.01 * w); ty = 0.1 * h + rng.normal(0, 0.01 * h)
+        ca, sa = np.cos(a) * s, np.sin(a) * s
+        xc, yc = xs - 0.5 * w, ys - 0.5 * h
+        den = 1.0 + px * xc + py * yc
+        wxp = (ca * xc - sa * yc) / den + 0.5 * w + tx
+        wyp = (sa * xc + ca * yc) / den + 0.5 * h + ty
+        grid = torch.stack([wxp / (ww - 1) * 2 - 1, wyp / (hh - 1) * 2 - 1], dim=-1)[None]
+        v = F.grid_sample(world, grid, mode="bilinear", padding_mode="border", align_corners=True)[0, 0]
+        g = torch.Generator(device=device); g.manual_seed(seed * 1000003 + i)
+        v = (v + noise * torch.randn((h, w), generator=g, device=device)).clamp_(0.0, 1.0)
+        if bgr:
+            cast = torch.tensor([0.96, 1.0, 0.93], device=device).view(1, 1, 3)
+            out.append(torch.round(v[..., None] * cast * 255.0).to(torch.uint8).contiguous())
+        else:
+            out.append((torch.round(v * 255.0) * np.float32(1.0 / 255.0)).contiguous())
+    return out, K

@@ -1,0 +1,179 @@
+"""The features stage in batches and the whole stage from pixels: `-m gpu`.
+
+* r3dm_detect_akaze_batch: B same-size images in ONE pass of the detector == oracle/akaze.c per image, bit for bit, including a
+  blank image in the batch, the slot-capacity regrow path and batches after a batch of another size.
+* r3dm_extract_features_batch / r3dm_multi_extract_features_ex: byte-identical .feat / .desc to the one-image work item, from gray
+  floats and from 8-bit BGR.
+* R3DComputeMatches::computeMatches from PIXELS (r3dm_compute_matches_stage): views without .feat/.desc go through the features
+  stage inside the call, views that have both files are reused as they are (src/threads/R3DFeaturesThread.cpp:139-142), and
+  matches.putative / f / e / h equal the CPU restatement of the whole chain (Fast-A-KAZE -> LIOP -> 2-NN + ratio -> AC-RANSAC)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from regard3d_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _photos(n, h, w, seed, **kw):
+    ims, K = synth.make_photo_set(n, h, w, seed=seed, device="cpu", **kw)
+    return [im.numpy() for im in ims], K
+
+
+def test_batch_detector_equals_the_cpu_restatement_per_image(ctx, oracle):
+    ims, _ = _photos(5, 480, 640, 3)
+    ims[2] = np.full((480, 640), 0.25, np.float32)                      # a blank image inside the batch: no keypoints, no effect on the others
+    ims[4] = np.clip(ims[4] * 0.2 + 0.4, 0, 1).astype(np.float32)       # low contrast: another k-contrast than its batch-mates
+    res = ctx.detect_akaze_batch(ims, 0.001)
+    s = ctx.stats()
+    assert s.n_detect_images == 5 and s.ms_detect_kernels > 0 and s.detect_algorithmic_bytes > 5 * 480 * 640 * 4 * 100
+    for b, (kps, resp) in enumerate(res):
+        ref = oracle.akaze_detect(ims[b], 0.001)
+        assert np.array_equal(kps, ref["kps"]) and np.array_equal(resp, ref["responses"]), b
+    assert len(res[2][0]) == 0 and len(res[0][0]) > 500
+    # the single-image entry is the batch of one; a smaller batch after a larger one reuses the buffers (plane stride = the image's own size)
+    k1, r1 = ctx.detect_akaze(ims[1], 0.001)
+    assert np.array_equal(k1, res[1][0]) and np.array_equal(r1, res[1][1])
+    res2 = ctx.detect_akaze_batch(ims[3:5], 0.0005)
+    for b in range(2):
+        ref = oracle.akaze_detect(ims[3 + b], 0.0005)
+        assert np.array_equal(res2[b][0], ref["kps"]) and np.array_equal(res2[b][1], ref["responses"])
+    # ... and another image size in between
+    other, _ = _photos(2, 300, 500, 5)
+    res3 = ctx.detect_akaze_batch(other, 0.001)
+    for b in range(2):
+        assert np.array_equal(res3[b][0], oracle.akaze_detect(other[b], 0.001)["kps"])
+    res4 = ctx.detect_akaze_batch(ims[:2], 0.001)
+    assert np.array_equal(res4[0][0], res[0][0]) and np.array_equal(res4[1][0], res[1][0])
+
+
+def test_slot_capacity_regrow_repeats_the_detection_phase(oracle, tmp_path):
+    """R3DM_AK_CAP=64 (developer build): every image overflows the first slot capacity, reports its need, and the detection phase
+    is repeated with larger arrays -- same keypoints, regrow counted."""
+    ims, _ = _photos(3, 360, 480, 9)
+    np.save(str(tmp_path / "ims.npy"), np.stack(ims))
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import numpy as np; from regard3d_amd import api; api.use_developer_library(); "
+            f"c = api.Context(0); ims = list(np.load({str(tmp_path / 'ims.npy')!r})); r = c.detect_akaze_batch(ims, 0.001); "
+            f"assert c.features_totals().n_regrows >= 1, c.features_totals().n_regrows; "
+            f"[np.save({str(tmp_path)!r} + '/k%d.npy' % b, r[b][0]) for b in range(3)]")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, R3DM_AK_CAP="64"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for b in range(3):
+        assert np.array_equal(np.load(str(tmp_path / f"k{b}.npy")), oracle.akaze_detect(ims[b], 0.001)["kps"])
+
+
+def test_features_batch_writes_the_files_of_the_single_work_item(ctx, tmp_path):
+    ims, _ = _photos(4, 420, 560, 13)
+    one = tmp_path / "one"; bat = tmp_path / "bat"; bgrd = tmp_path / "bgr"; one.mkdir(); bat.mkdir(); bgrd.mkdir()
+    n1 = [ctx.extract_features_to_files(im, str(one / f"v{k}.feat"), str(one / f"v{k}.desc"), 0.001) for k, im in enumerate(ims)]
+    nb = ctx.extract_features_batch(ims, [str(bat / f"v{k}.feat") for k in range(4)], [str(bat / f"v{k}.desc") for k in range(4)], 0.001)
+    assert nb.tolist() == n1 and min(n1) > 300
+    for k in range(4):
+        for ext in ("feat", "desc"):
+            assert open(str(bat / f"v{k}.{ext}"), "rb").read() == open(str(one / f"v{k}.{ext}"), "rb").read(), (k, ext)
+    # 8-bit BGR in (what cv::imread decodes): the device-side conversion == r3dm_gray_from_bgr8 == processWorkItem's convertTo + cvtColor
+    rng = np.random.default_rng(2)
+    bgr = [np.stack([np.clip(np.rint(im * 255) + rng.integers(-6, 7, im.shape), 0, 255).astype(np.uint8) for _ in range(3)], axis=2) for im in ims[:3]]
+    grays = [ctx.gray_from_bgr8(b) for b in bgr]
+    ng = ctx.extract_features_batch(bgr, [str(bgrd / f"b{k}.feat") for k in range(3)], [str(bgrd / f"b{k}.desc") for k in range(3)], 0.001, bgr=True)
+    for k in range(3):
+        n = ctx.extract_features_to_files(grays[k], str(bgrd / f"g{k}.feat"), str(bgrd / f"g{k}.desc"), 0.001)
+        assert n == ng[k] > 300
+        for ext in ("feat", "desc"):
+            assert open(str(bgrd / f"b{k}.{ext}"), "rb").read() == open(str(bgrd / f"g{k}.{ext}"), "rb").read()
+    # the list entry with mixed sizes and kinds, two contexts, batches of 3
+    m = api.MultiContext([0, 0])
+    mixed, _ = _photos(3, 300, 440, 17)
+    lst = ims + mixed
+    fp = [str(tmp_path / f"m{k}.feat") for k in range(7)]; dp = [str(tmp_path / f"m{k}.desc") for k in range(7)]
+    nf, sk = m.extract_features(lst, fp, dp, 0.001, batch=3)
+    m.close()
+    assert nf[:4].tolist() == n1 and not sk.any()
+    for k in range(4):
+        assert open(dp[k], "rb").read() == open(str(one / f"v{k}.desc"), "rb").read()
+    assert ctx.features_totals().n_images >= 4 + 4 + 3 + 3
+
+
+def _g(v):
+    """the value a "%g" line of a .feat file holds (6 significant digits), as the loaders parse it back"""
+    return np.array([np.float32(float("%g" % x)) for x in np.asarray(v, np.float32).ravel()], np.float32).reshape(np.shape(v))
+
+
+def _oracle_stage(oracle, ims, K, dist_ratio=0.6):
+    kps, descs, xys = [], [], []
+    for im in ims:
+        kp = oracle.akaze_detect(im, 0.001)["kps"]
+        d = oracle.liop_describe(oracle.liop_extract_patches(im, kp, 8.0))
+        kps.append(kp); descs.append(d); xys.append(_g(kp[:, :2]))                    # positions as the .feat text carries them
+    n = len(ims)
+    i, j = np.triu_indices(n, k=1)
+    pairs = np.stack([i, j], axis=1).astype(np.uint32)
+    counts, matches = oracle.match_collection(descs, xys, pairs, dist_ratio, True)
+    return kps, descs, xys, pairs, counts, matches
+
+
+def _check_filter(oracle, path, pairs, oc, om):
+    p, c, m = oracle.load_matches(path)
+    assert np.array_equal(p, pairs[oc > 0]) and np.array_equal(c, oc[oc > 0])
+    off = 0; ooff = np.concatenate([[0], np.cumsum(oc)])
+    for k, cnt in enumerate(c):
+        seg = m[off:off + cnt]; off += cnt
+        q = int(np.flatnonzero(oc > 0)[k])
+        exp = om[ooff[q]:ooff[q] + cnt]
+        assert set(map(tuple, seg.tolist())) == set(map(tuple, exp.tolist())), (path, k)
+    return int((oc > 0).sum())
+
+
+@pytest.mark.parametrize("kind", ["gray", "bgr"])
+def test_stage_from_pixels_equals_the_cpu_restatement(oracle, tmp_path, kind):
+    """ONE facade call: pixels -> .feat/.desc -> matches.putative / f / e / h, against oracle/akaze.c + liop.c + matching.c + acransac.c + essential.c"""
+    h, w = 480, 640
+    if kind == "bgr":
+        bgrs, K = synth.make_photo_set(5, h, w, seed=21, device="cpu", bgr=True)
+        bgrs = [b.numpy() for b in bgrs]
+        sc = np.float32(1.0 / 255.0)
+        ims = [((b[..., 0].astype(np.float32) * sc) * np.float32(0.114) + (b[..., 1].astype(np.float32) * sc) * np.float32(0.587)
+                + (b[..., 2].astype(np.float32) * sc) * np.float32(0.299)).astype(np.float32) for b in bgrs]
+        views = [dict(id=k, width=w, height=h, basename=f"img{k:03d}", bgr=bgrs[k], focal_px=K[0, 0], ppx=K[0, 2], ppy=K[1, 2]) for k in range(5)]
+    else:
+        ims, K = _photos(5, h, w, 21)
+        views = [dict(id=k, width=w, height=h, basename=f"img{k:03d}", gray=ims[k], focal_px=K[0, 0], ppx=K[0, 2], ppy=K[1, 2]) for k in range(5)]
+    d = str(tmp_path)
+    rep = api.compute_matches_stage([0], d, views, 0.001, 0.6, 9, True, True, True, 5489, 2, 2)
+    kps, descs, xys, pairs, counts, matches = _oracle_stage(oracle, ims, K)
+    assert rep.images_extracted == 5 and rep.n_keypoints == sum(len(k) for k in kps) and rep.features.n_images == 5
+    assert rep.ms_features > 0 and rep.ms_match > 0 and rep.ms_filter_E > 0 and rep.features.ms_detect_kernels > 0
+    for k in range(5):                                                               # the features stage wrote the reference's files
+        raw = np.fromfile(os.path.join(d, f"img{k:03d}.desc"), np.uint8)
+        assert int(np.frombuffer(raw[:8].tobytes(), np.uint64)[0]) == len(kps[k])
+        assert np.array_equal(np.frombuffer(raw[8:].tobytes(), np.float32).reshape(-1, 144), descs[k])
+        txt = np.loadtxt(os.path.join(d, f"img{k:03d}.feat"), dtype=np.float32).reshape(-1, 4)
+        want = kps[k].copy(); want[:, 2] /= 2.0
+        assert np.array_equal(txt, _g(want))
+    p, c, m = oracle.load_matches(os.path.join(d, "matches.putative.txt"))
+    assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
+    assert rep.n_putative_pairs == int((counts > 0).sum()) >= 6
+    W = np.full(5, w, np.uint32); H = np.full(5, h, np.uint32)
+    oc, om = oracle.filter_F_collection(xys, W, H, pairs, counts, matches, 4.0, 2048, 5489)
+    assert _check_filter(oracle, os.path.join(d, "matches.f.txt"), pairs, oc, om) == rep.n_F_pairs >= 4
+    oh, omh = oracle.filter_H_collection(xys, W, H, pairs, counts, matches, 4.0, 2048, 5489)
+    assert _check_filter(oracle, os.path.join(d, "matches.h.txt"), pairs, oh, omh) == rep.n_H_pairs >= 4      # a plane: H has inliers
+    oe, ome = oracle.filter_E_collection(xys, W, H, np.stack([K] * 5), pairs, counts, matches, 4.0, 2048, 5489)
+    assert _check_filter(oracle, os.path.join(d, "matches.e.txt"), pairs, oe, ome) == rep.n_E_pairs
+    # second call: every view has both files now -> no extraction, same match files (processWorkItem's skip rule)
+    blob = open(os.path.join(d, "matches.f.bin"), "rb").read()
+    rep2 = api.compute_matches_stage([0], d, [dict(v, gray=None, bgr=None) for v in views], 0.001, 0.6, 9, True, False, False)
+    assert rep2.images_extracted == 0 and open(os.path.join(d, "matches.f.bin"), "rb").read() == blob
+    # a view without files and without pixels is the reference's "Invalid features"
+    os.remove(os.path.join(d, "img002.desc"))
+    with pytest.raises(api.R3dmError, match="Invalid features"):
+        api.compute_matches_stage([0], d, [dict(v, gray=None, bgr=None) for v in views], 0.001, 0.6, 9, True, False, False)
+    # ... with pixels for that view only, exactly that view is recomputed
+    v2 = [dict(v, gray=None, bgr=None) for v in views]; v2[2] = views[2]
+    rep3 = api.compute_matches_stage([0, 0], d, v2, 0.001, 0.6, 9, True, False, False)
+    assert rep3.images_extracted == 1 and open(os.path.join(d, "matches.f.bin"), "rb").read() == blob

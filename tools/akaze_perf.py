@@ -1,56 +1,59 @@
-"""Detector probe: r3dm_detect_akaze on a synthetic 4000 x 3000 image (the reference's semaphore-serialised stage)."""
+"""Detector probe on synthetic 4000 x 3000 images: r3dm_detect_akaze_batch at B = 1, 2, 4, 8 with the images resident in HBM
+(per-image kernel time, fraction of the HBM roof of the pass structure), then the features stage (detect + LIOP + files) over an
+image list with K contexts x batches of B -- what the reference runs one image at a time behind a semaphore."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 torch.cuda.init()          # before the library: torch's HIP runtime has to come up first in a process that uses both
-from regard3d_amd import api
+from regard3d_amd import api, synth
 
 h, w = 3000, 4000
-rng = np.random.default_rng(0)
-yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-img = 0.5 + 0.1 * np.sin(xx / 17.0) * np.cos(yy / 23.0)
-for _ in range(1500):
-    cx, cy = rng.uniform(40, w - 40), rng.uniform(40, h - 40); s = rng.uniform(2, 12); a = rng.uniform(0.15, 0.45) * rng.choice([-1, 1])
-    x0, x1, y0, y1 = int(max(cx - 5 * s, 0)), int(min(cx + 5 * s, w)), int(max(cy - 5 * s, 0)), int(min(cy + 5 * s, h))
-    img[y0:y1, x0:x1] += a * np.exp(-((xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2) / (2 * s * s))
-img = np.clip(img + rng.normal(0, 0.01, img.shape), 0, 1).astype(np.float32)
+NIMG = int(os.environ.get("AK_IMAGES", "16"))
+imgs = [synth.make_photo(h, w, seed=100 + k) for k in range(min(NIMG, 8))]
+dimgs = [torch.from_numpy(im).cuda() for im in imgs]
+torch.cuda.synchronize()
 c = api.Context(0)
-for thr in (0.001, 0.0001):
-    for rep in range(3):
-        t = time.time(); kps, resp = c.detect_akaze(img, thr); dt = time.time() - t
-    t = time.time(); desc = c.extract_liop(img, kps, 8.0); dl = time.time() - t
-    print(json.dumps(dict(image=[h, w], threshold=thr, keypoints=len(kps), s_detect=dt, s_liop=dl, mpix_per_s=h * w / dt / 1e6)), flush=True)
-# the features stage over an image list: 16 copies of the image, K images in flight on K contexts of the one GPU (files to /tmp).
-# Every context has seen the image size once before the timed pass (work buffers allocated, launch sequence captured).
+for thr in (0.001,):
+    for B in (1, 2, 4, 8):
+        if B > len(dimgs): break
+        for rep in range(3):
+            t = time.time(); res = c.detect_akaze_batch(dimgs[:B], thr); dt = time.time() - t
+        s = c.stats()
+        print(json.dumps(dict(image=[h, w], threshold=thr, batch=B, keypoints=[len(r[0]) for r in res], ms_wall_per_image=dt / B * 1e3,
+                              ms_kernels_per_image=s.ms_detect_kernels / B, algorithmic_GB_per_image=s.detect_algorithmic_bytes / B / 1e9,
+                              hbm_frac=s.detect_algorithmic_bytes / (s.ms_detect_kernels * 1e-3) / 8e12, regrows=int(c.features_totals().n_regrows))), flush=True)
+    t = time.time(); kps, resp = c.detect_akaze(imgs[0], thr); dt = time.time() - t
+    t = time.time(); desc = c.extract_liop(imgs[0], kps, 8.0); dl = time.time() - t
+    print(json.dumps(dict(single_image_from_host=True, keypoints=len(kps), s_detect=dt, s_liop=dl)), flush=True)
+# the features stage over an image list (files to /tmp); every context has seen the image size once before the timed pass
 import tempfile, shutil
-print(json.dumps(dict(scale_space_graph_replays=int(c.stats().n_ak_graph_replays))), flush=True)
+
 d = tempfile.mkdtemp()
 try:
-    imgs = [img] * 16
-    paths = lambda ext: [f"{d}/i{k}.{ext}" for k in range(16)]
-    for conc in (1, 2, 3, 4):
+    lst = [dimgs[k % len(dimgs)] for k in range(NIMG)]
+    paths = lambda ext: [f"{d}/i{k}.{ext}" for k in range(NIMG)]
+    for conc, batch in ((1, 1), (1, 8), (2, 8), (2, 4), (3, 4), (4, 2)):
         m = api.MultiContext([0] * conc)
-        m.extract_features(imgs[:conc], paths("feat")[:conc], paths("desc")[:conc], 0.001)          # warm-up: one image per context
+        m.extract_features(lst, paths("feat"), paths("desc"), 0.001, batch=batch)          # warm-up: buffers of every context
         for f in os.listdir(d): os.remove(os.path.join(d, f))
-        t = time.time(); nf, sk = m.extract_features(imgs, paths("feat"), paths("desc"), 0.001); dt = time.time() - t
+        t = time.time(); nf, sk = m.extract_features(lst, paths("feat"), paths("desc"), 0.001, batch=batch); dt = time.time() - t
         for f in os.listdir(d): os.remove(os.path.join(d, f))
         m.close()
-        print(json.dumps(dict(features_stage_images=16, contexts=conc, s_total=dt, ms_per_image=dt / 16 * 1e3, keypoints=int(nf[0]))), flush=True)
-    # the same with the images already on the device (what is left when the 48 MB host-to-device copy per image is not in the way)
-    dimgs = [torch.from_numpy(np.ascontiguousarray(img)).cuda() for _ in range(4)] * 4
-    torch.cuda.synchronize()
-    for conc in (1, 4):
+        print(json.dumps(dict(features_stage_images=NIMG, contexts=conc, batch=batch, images="device-resident", s_total=dt,
+                              ms_per_image=dt / NIMG * 1e3, keypoints=int(nf[0]))), flush=True)
+    hl = [imgs[k % len(imgs)] for k in range(NIMG)]
+    for conc, batch in ((2, 4),):
         m = api.MultiContext([0] * conc)
-        m.extract_features(dimgs[:conc], paths("feat")[:conc], paths("desc")[:conc], 0.001)
+        m.extract_features(hl, paths("feat"), paths("desc"), 0.001, batch=batch)
         for f in os.listdir(d): os.remove(os.path.join(d, f))
-        t = time.time(); nf, sk = m.extract_features(dimgs, paths("feat"), paths("desc"), 0.001); dt = time.time() - t
-        for f in os.listdir(d): os.remove(os.path.join(d, f))
+        t = time.time(); nf, sk = m.extract_features(hl, paths("feat"), paths("desc"), 0.001, batch=batch); dt = time.time() - t
         m.close()
-        print(json.dumps(dict(features_stage_images=16, contexts=conc, images="device-resident", s_total=dt, ms_per_image=dt / 16 * 1e3)), flush=True)
+        print(json.dumps(dict(features_stage_images=NIMG, contexts=conc, batch=batch, images="pageable host float32 (48 MB each)", s_total=dt,
+                              ms_per_image=dt / NIMG * 1e3)), flush=True)
 finally:
     shutil.rmtree(d, ignore_errors=True)
 if len(sys.argv) > 1 and sys.argv[1] == "cpu":
     from oracle import pyoracle as o
-    t = time.time(); r = o.akaze_detect(img, 0.001); print("oracle (OpenMP port) %.2fs, %d keypoints" % (time.time() - t, len(r["kps"])))
-    print("equal:", np.array_equal(r["kps"], c.detect_akaze(img, 0.001)[0]))
+    t = time.time(); r = o.akaze_detect(imgs[0], 0.001); print("oracle (OpenMP port) %.2fs, %d keypoints" % (time.time() - t, len(r["kps"])))
+    print("equal:", np.array_equal(r["kps"], c.detect_akaze(imgs[0], 0.001)[0]))

@@ -1,0 +1,61 @@
+#!/bin/bash
+# One parameterised runner for the GPU sessions (replaces the per-session gpu_round2_*.sh scripts): every step writes under
+# gpurun_out/<tag>_*, the files worth judging are then copied into profiles/.
+#
+#   tools/gpu_session.sh <tag> <step> [<step> ...]
+#
+# steps:
+#   pytest[:<-k expression>]        python -m pytest tests -m gpu (-k ...)            -> <tag>_pytest.txt
+#   smoke                           __graft_entry__.smoke()                            -> <tag>_smoke.txt
+#   bench:<config>[:<extra args>]   python bench.py --config <config> <extra>          -> <tag>_bench_<config>.json / .err
+#   prof:<config>[:<extra args>]    the same under rocprofv3 --kernel-trace --stats    -> <tag>_bench_<config>.json + _kernel_stats.txt
+#   akaze                           tools/akaze_perf.py (+ kernel stats)              -> <tag>_akaze_perf.txt + _akaze_kernel_stats.txt
+#   tool:<script.py>[:<args>]       python tools/<script.py> <args>                   -> <tag>_<script>.txt
+#   proftool:<script.py>[:<args>]   the same under rocprofv3 --kernel-trace --stats    -> <tag>_<script>.txt + _<script>_kernel_stats.txt
+#   pmc:<counters>:<config>[:<extra args>]   separate rocprofv3 --pmc passes (one per comma-separated counter, --kernel-trace only)
+#                                                                                        -> <tag>_pmc_<config>.txt
+# Every step runs under its own `timeout`; nothing here kills by pattern.
+cd /tmp && export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
+T=$1; shift
+stats() {   # $1 = profile dir, $2 = output file
+  local db; db=$(find $1 -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocprof_summary.py $db > $2 2>&1 && head -${STATS_HEAD:-24} $2 | cut -c1-150
+}
+for step in "$@"; do
+  IFS=':' read -r kind a1 a2 a3 <<< "$step"
+  echo "=== [$T] $step"
+  case $kind in
+    pytest)
+      if [ -n "$a1" ]; then timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -x -k "$a1" 2>&1 | tail -${PYTEST_TAIL:-15} | tee gpurun_out/${T}_pytest.txt
+      else timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q 2>&1 | tail -${PYTEST_TAIL:-15} | tee gpurun_out/${T}_pytest.txt; fi ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/${T}_smoke.txt ;;
+    bench)
+      timeout ${BENCH_TIMEOUT:-1200} python bench.py --config $a1 $a2 > gpurun_out/${T}_bench_$a1.json 2> gpurun_out/${T}_bench_$a1.err
+      echo "rc=$?"; cut -c1-1500 gpurun_out/${T}_bench_$a1.json; tail -3 gpurun_out/${T}_bench_$a1.err ;;
+    prof)
+      rm -rf /tmp/prof_$a1
+      timeout ${BENCH_TIMEOUT:-1200} rocprofv3 --kernel-trace --stats -d /tmp/prof_$a1 -- python bench.py --config $a1 $a2 > gpurun_out/${T}_bench_$a1.json 2> gpurun_out/${T}_bench_$a1.err
+      echo "rc=$?"; cut -c1-1500 gpurun_out/${T}_bench_$a1.json; tail -3 gpurun_out/${T}_bench_$a1.err
+      stats /tmp/prof_$a1 gpurun_out/${T}_bench_${a1}_kernel_stats.txt ;;
+    akaze)
+      rm -rf /tmp/prof_ak
+      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ak -- python tools/akaze_perf.py > gpurun_out/${T}_akaze_perf_profiled.txt 2>&1
+      stats /tmp/prof_ak gpurun_out/${T}_akaze_kernel_stats.txt
+      timeout 600 python tools/akaze_perf.py 2>&1 | grep "^{" | cut -c1-400 | tee gpurun_out/${T}_akaze_perf.txt ;;
+    tool)
+      n=$(basename $a1 .py)
+      timeout ${TOOL_TIMEOUT:-900} python tools/$a1 $a2 2>&1 | tail -${TOOL_TAIL:-40} | cut -c1-400 | tee gpurun_out/${T}_$n.txt ;;
+    proftool)
+      n=$(basename $a1 .py); rm -rf /tmp/prof_$n
+      timeout ${TOOL_TIMEOUT:-900} rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -- python tools/$a1 $a2 2>&1 | grep -v "^W\|rocprofv3" | tail -${TOOL_TAIL:-40} | cut -c1-400 | tee gpurun_out/${T}_$n.txt
+      stats /tmp/prof_$n gpurun_out/${T}_${n}_kernel_stats.txt ;;
+    pmc)
+      for ctr in ${a1//,/ }; do
+        rm -rf /tmp/pmc_$ctr
+        timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- python bench.py --config $a2 $a3 --no-cpu-baseline > /tmp/pmc_$ctr.log 2>&1
+        echo "## pass: $ctr (rc=$?)"; python tools/pmc_summary.py /tmp/pmc_$ctr 2>&1 | grep -v "stage_" | head -${PMC_HEAD:-8}
+      done | tee gpurun_out/${T}_pmc_$a2.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
