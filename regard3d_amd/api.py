@@ -186,6 +186,7 @@ def load_library():
     L.r3dm_extract_features_to_files.argtypes = [vp, vp, u32, u32, C.c_float, C.c_char_p, C.c_char_p, C.POINTER(u32)]
     L.r3dm_multi_extract_features.argtypes = [vp, u32, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
     L.r3dm_multi_extract_features_ex.argtypes = [vp, u32, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, u32, C.c_char_p, C.c_size_t]
+    L.r3dm_get_features_totals.argtypes = [vp, vp]
     L.r3dm_detect_akaze_batch.argtypes = [vp, u32, vp, u32, u32, C.c_float, vp, vp, u32, vp]
     L.r3dm_extract_features_batch.argtypes = [vp, u32, vp, vp, u32, u32, C.c_float, vp, vp, vp]
     L.r3dm_kgraph_preset.argtypes = [C.c_int, vp]

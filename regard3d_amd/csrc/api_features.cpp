@@ -183,7 +183,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     }
     const size_t PB = (size_t)c->ak_B;                            // planes per buffer (the largest batch of this size so far)
     auto buf = [&](int k) -> DevBuf& { return c->ak_bufs[k]; };
-    for (int k = B_IMG; k <= B_LT2; ++k) if (k != B_LYY) R3DM_HIP(c, buf(k).ensure(PB * n0 * 4));      // (Lyy is folded into the determinant kernel)
+    for (int k = B_IMG; k <= B_LT2; ++k) if (k != B_LYY && k != B_LXX && k != B_LXY && k != B_WX && k != B_WY) R3DM_HIP(c, buf(k).ensure(PB * n0 * 4));      // (the second derivatives are folded into the determinant kernel)
     R3DM_HIP(c, buf(B_SMALL).ensure(PB * 4096 * 4));
     for (int i = 0; i < nl; ++i)
         for (int q = 0; q < 4; ++q) R3DM_HIP(c, buf(B_LEVEL0 + 4 * i + q).ensure(PB * (size_t)lv[i].w * lv[i].h * 4));
@@ -193,9 +193,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     auto Ldet = [&](int i) { return buf(B_LEVEL0 + 4 * i + 3).as<float>(); };
     float* img = buf(B_IMG).as<float>();
     float* smooth = buf(B_SMOOTH).as<float>();
-    float* lxx = buf(B_LXX).as<float>(); float* lxy = buf(B_LXY).as<float>();
     float* tmp = buf(B_TMP).as<float>(); float* tmp2 = buf(B_TMP2).as<float>();
-    float* wx = buf(B_WX).as<float>(); float* wy = buf(B_WY).as<float>();
     float* flow = buf(B_FLOW).as<float>(); float* lt2 = buf(B_LT2).as<float>();
     uint32_t* small = buf(B_SMALL).as<uint32_t>();
 
@@ -249,14 +247,13 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     auto tally = [&](int lw, int lh, int n_planes) { planes_px += (double)lw * lh * n_planes; };
 
     // Compute_Determinant_Hessian_Response_Single (AKAZEFeatures.cpp:389-410)
-    auto hessian = [&](int i) -> hipError_t {
+    auto hessian = [&](int i, const float* src) -> hipError_t {
         const int lw = lv[i].w, lh = lv[i].h, s = lv[i].sigma_size;
         hipError_t e;
-        // three launches: smooth -> (Lx, Ly);  Lx -> (Lxx, Lxy);  Ly -> Lyy, folded into the determinant
-        if ((e = ak_scaled_deriv_xy(st, smooth, Lx(i), Ly(i), lw, lh, iB, s)) != hipSuccess) return e;
-        if ((e = ak_scaled_deriv_xy(st, Lx(i), lxx, lxy, lw, lh, iB, s)) != hipSuccess) return e;
-        tally(lw, lh, 3 + 3 + 4);
-        return ak_scaled_deriv_det(st, Ly(i), lxx, lxy, Ldet(i), lw, lh, iB, s);
+        // two launches: smooth -> (Lx, Ly);  (Lx, Ly) -> Lxx, Lxy, Lyy on the spot -> the determinant
+        if ((e = ak_scaled_deriv_xy(st, src, Lx(i), Ly(i), lw, lh, iB, s)) != hipSuccess) return e;
+        tally(lw, lh, 3 + 3);
+        return ak_scaled_deriv_det(st, Lx(i), Ly(i), Ldet(i), lw, lh, iB, s);
     };
 
     // ---- Create_Nonlinear_Scale_Space (:245-369), Compute_Base_Evolution_Level (:199-237): ~550 launches for a 12 Mpx image,
@@ -266,48 +263,68 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     auto scale_space = [&]() -> hipError_t {
         hipError_t e;
 #define AK_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
-        AK_TRY(ak_gaussian(st, img, tmp, smooth, w, h, iB, taps_off)); tally(w, h, 4);
-        AK_TRY(hessian(0));
+        // (the base level's smoothed image IS evolution level 0: written straight into Lt(0), no copy)
+        AK_TRY(ak_gaussian(st, img, tmp, Lt(0), w, h, iB, taps_off)); tally(w, h, 2);
+        AK_TRY(hessian(0, Lt(0)));
         AK_TRY(hipMemsetAsync(small, 0, (size_t)B * 4096 * 4, st));
         const int nbins = 300;
         if (nl > 1) {
-            AK_TRY(ak_gaussian(st, img, tmp, flow, w, h, iB, taps_one)); tally(w, h, 4);
-            AK_TRY(ak_scharr(st, flow, tmp, tmp2, wx, wy, w, h, iB)); tally(w, h, 3 + 4);
-            AK_TRY(ak_modg_max(st, wx, wy, w, h, iB, hmax_bits)); tally(w, h, 2);
-            AK_TRY(ak_modg_hist(st, wx, wy, w, h, iB, hmax_bits, nbins, hist)); tally(w, h, 2);
+            AK_TRY(ak_gaussian(st, img, tmp, flow, w, h, iB, taps_one)); tally(w, h, 2);
+            // (the Scharr derivative images of the reference exist only inside these two kernels: DESIGN.md section 4.8)
+            AK_TRY(ak_modg_max(st, flow, w, h, iB, hmax_bits)); tally(w, h, 1);
+            AK_TRY(ak_modg_hist(st, flow, w, h, iB, hmax_bits, nbins, hist)); tally(w, h, 1);
         }
         AK_TRY(ak_kcontrast(st, hmax_bits, hist, nbins, (uint32_t)((size_t)(w - 2) * (h - 2)), nl > 1 ? 1 : 0, inv_k2, iB));
-        AK_TRY(hipMemcpyAsync(Lt(0), smooth, (size_t)B * n0 * 4, hipMemcpyDeviceToDevice, st)); tally(w, h, 2);
         for (int i = 1; i < nl; ++i) {
             const int lw = lv[i].w, lh = lv[i].h;
             const size_t n = (size_t)lw * lh;
             const std::vector<float> tau = ak_fed_tau(lv[i].etime - lv[i - 1].etime);
-            const float* start = nullptr;
-            if (lv[i].octave > lv[i - 1].octave) {
-                // the FED steps ping-pong between Lt(i) and the work image and must END in Lt(i): the half-sampled start image goes
-                // to whichever of the two the first step does not write
-                float* half = (tau.size() % 2 == 1) ? lt2 : Lt(i);
-                const HalfTabs& ht = half_tabs[i];
-                AK_TRY(ak_halfsample(st, Lt(i - 1), half, lv[i - 1].w, lv[i - 1].h, iB, ht.xt, ht.xb, ht.yt, ht.yb));
-                tally(lv[i - 1].w, lv[i - 1].h, 1); tally(lw, lh, 1);
-                start = half;
-            } else {
-                start = Lt(i - 1);                                  // same octave: the previous level IS the start image, no copy
+            // (Splitting the launches of the 3 Mpx octave into sub-batches whose planes fit the Infinity Cache was measured: 2.31-2.34 ms
+            // per image against 2.36 -- not worth a second launch order; profiles/r03_f_*.)
+            const uint32_t SUB = B;
+            for (uint32_t b0 = 0; b0 < B; b0 += SUB) {
+                const int nb = (int)std::min<uint32_t>(SUB, B - b0);
+                const size_t po = (size_t)b0 * n;                       // every plane of this level's launches is n floats
+                float* Lti = Lt(i) + po; float* lt2i = lt2 + po; float* tmpi = tmp + po; float* smoothi = smooth + po; float* flowi = flow + po;
+                // FED launches of this level: one step per launch on the large levels, up to four steps per launch where a step is
+                // mostly launch latency (<= 1.2 Mpx per image; R3DM_AK_FED_MULTI=0 in the developer build keeps one step per launch)
+                static const int multi_px = r3dm_dev_knob("R3DM_AK_FED_MULTI", 1) ? 1200000 : 0;
+                const size_t per = n <= (size_t)multi_px ? 4 : 1;
+                const size_t n_launch = (tau.size() + per - 1) / per;
+                const float* start = nullptr;
+                if (lv[i].octave > lv[i - 1].octave) {
+                    // the FED launches ping-pong between Lt(i) and the work image and must END in Lt(i): the half-sampled start image
+                    // goes to whichever of the two the first launch does not write
+                    float* half = (n_launch % 2 == 1) ? lt2i : Lti;
+                    const HalfTabs& ht = half_tabs[i];
+                    AK_TRY(ak_halfsample(st, Lt(i - 1) + (size_t)b0 * lv[i - 1].w * lv[i - 1].h, half, lv[i - 1].w, lv[i - 1].h, nb, ht.xt, ht.xb, ht.yt, ht.yb));
+                    start = half;
+                } else {
+                    start = Lt(i - 1) + po;                             // same octave: the previous level IS the start image, no copy
+                }
+                if (tau.empty()) {                                      // (never for the reference's time steps) plain copy
+                    if (start != Lti) AK_TRY(hipMemcpyAsync(Lti, start, (size_t)nb * n * 4, hipMemcpyDeviceToDevice, st));
+                    start = Lti;
+                }
+                AK_TRY(ak_gaussian(st, start, tmpi, smoothi, lw, lh, nb, taps_one));
+                {
+                    const int s_i = lv[i].sigma_size;
+                    AK_TRY(ak_scaled_deriv_xy(st, smoothi, Lx(i) + po, Ly(i) + po, lw, lh, nb, s_i));
+                    AK_TRY(ak_scaled_deriv_det(st, Lx(i) + po, Ly(i) + po, Ldet(i) + po, lw, lh, nb, s_i));
+                }
+                AK_TRY(ak_scharr_g2(st, smoothi, flowi, lw, lh, nb, inv_k2 + (size_t)b0 * 4096 + lv[i].octave));     // kcontrast * 0.75^octave
+                // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; launch m of M writes Lt(i) when M - m is even, else the work image
+                const float* cur = start;
+                for (size_t m = 1; m <= n_launch; ++m) {
+                    float* o = ((n_launch - m) % 2 == 0) ? Lti : lt2i;
+                    const size_t k0 = (m - 1) * per, kn = std::min(per, tau.size() - k0);
+                    if (per == 1) AK_TRY(ak_fed_step(st, cur, flowi, o, lw, lh, nb, tau[k0]));
+                    else AK_TRY(ak_fed_multi(st, cur, flowi, o, lw, lh, nb, tau.data() + k0, (int)kn));
+                    cur = o;
+                }
             }
-            if (tau.empty()) {                                      // (never for the reference's time steps) plain copy
-                if (start != Lt(i)) AK_TRY(hipMemcpyAsync(Lt(i), start, (size_t)B * n * 4, hipMemcpyDeviceToDevice, st));
-                start = Lt(i);
-            }
-            AK_TRY(ak_gaussian(st, start, tmp, smooth, lw, lh, iB, taps_one)); tally(lw, lh, 4);
-            AK_TRY(hessian(i));
-            AK_TRY(ak_scharr_g2(st, smooth, flow, lw, lh, iB, inv_k2 + lv[i].octave)); tally(lw, lh, 2);     // kcontrast * 0.75^octave
-            // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; step k of n writes Lt(i) when n - k is even, else the work image
-            const float* cur = start;
-            for (size_t k = 1; k <= tau.size(); ++k) {
-                float* o = ((tau.size() - k) % 2 == 0) ? Lt(i) : lt2;
-                AK_TRY(ak_fed_step(st, cur, flow, o, lw, lh, iB, tau[k - 1])); tally(lw, lh, 3);
-                cur = o;
-            }
+            if (lv[i].octave > lv[i - 1].octave) { tally(lv[i - 1].w, lv[i - 1].h, 1); tally(lw, lh, 1); }
+            tally(lw, lh, 2 + 6 + 2 + 3 * (int)tau.size());       // Gaussian (fused row + column pass) 2, derivatives + determinant 6, conductivity 2, 3 per FED step
         }
 #undef AK_TRY
         return hipSuccess;
@@ -330,6 +347,10 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     AkLevelDev* d_levels = reinterpret_cast<AkLevelDev*>(meta.as<unsigned char>() + off_levels);
     AkBatchMeta* d_bmeta = reinterpret_cast<AkBatchMeta*>(meta.as<unsigned char>() + off_bmeta);
     {
+        std::vector<size_t> mask_off(nl + 1, 0);                          // in 64-bit words, per level, inside an image's mask area
+        for (int i = 0; i < nl; ++i)
+            mask_off[i + 1] = mask_off[i] + (size_t)std::max(0, lv[i].h - 2 * lv[i].border) * (size_t)std::max(0, (lv[i].w - 2 * lv[i].border + 63) / 64);
+        if (mask_off[nl] * 8 + 8 > n0 * 4) { c->err = "detector: extremum masks do not fit the work image"; return R3DM_ERR_HIP; }
         size_t ro = 0;
         for (uint32_t b = 0; b < B; ++b)
             for (int i = 0; i < nl; ++i) {
@@ -339,11 +360,26 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
                 L.w = lv[i].w; L.h = lv[i].h; L.border = lv[i].border; L.ratio = lv[i].ratio; L.psize = lv[i].esigma * 1.5f;
                 L.Ldet = Ldet(i) + b * plane; L.Lx = Lx(i) + b * plane; L.Ly = Ly(i) + b * plane; L.Lt = Lt(i) + b * plane;
                 L.row_cnt = rc + ro; L.row_off = rc + rows_total + ro; L.counts = cnt + 4 * ((size_t)b * nl + i);
-                ro += (size_t)std::max(0, lv[i].h - 2 * lv[i].border);
+                // extremum bit masks: in the row-pass work image of the Gaussian (idle once the scale space is built), image b's
+                // plane, the levels one after another (1 bit per pixel + at most 8 bytes per row: far below the plane's 4 bytes per pixel)
+                const int rows_i = std::max(0, lv[i].h - 2 * lv[i].border);
+                L.mask_words = (uint32_t)std::max(0, (lv[i].w - 2 * lv[i].border + 63) / 64);
+                L.mask = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(tmp) + (((size_t)b * n0 * 4 + 7) / 8) * 8) + mask_off[i];   // (8-byte aligned also when w h is odd)
+                ro += (size_t)rows_i;
             }
     }
     int max_rows = 0;
     for (int i = 0; i < nl; ++i) max_rows = std::max(max_rows, lv[i].h - 2 * lv[i].border);
+    // tiles of the extremum count pass: 64 columns x 16 rows of a level's interior, the levels one after another
+    AkTileTable tiles;
+    uint32_t n_tiles = 0;
+    for (int i = 0; i < 17; ++i) tiles.begin[i] = 0xFFFFFFFFu;
+    if (nl > 16) { c->err = "detector: more than 16 evolution levels"; return R3DM_ERR_UNSUPPORTED; }
+    for (int i = 0; i < nl; ++i) {
+        tiles.begin[i] = n_tiles;
+        const int rows_i = std::max(0, lv[i].h - 2 * lv[i].border), words_i = std::max(0, (lv[i].w - 2 * lv[i].border + 63) / 64);
+        n_tiles += (uint32_t)words_i * (uint32_t)((rows_i + 15) / 16);
+    }
     // slot capacity per image: a strict 3x3 maximum excludes its eight neighbours, so a level holds at most ceil(w/2) ceil(h/2)
     // candidates; start from min(that bound, 256 k) and grow only if an image reports more (the bound itself never overflows)
     uint64_t bound = 0;
@@ -360,12 +396,13 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
         R3DM_HIP(c, recs.ensure(field * sizeof(AkKpRec) + 256));
         R3DM_HIP(c, hipMemsetAsync(meta.p, 0, rows_total * 8 + n_lv * 16, st));
         R3DM_HIP(c, hipMemcpyAsync(d_levels, ld.data(), n_lv * sizeof(AkLevelDev), hipMemcpyHostToDevice, st));
-        R3DM_HIP(c, ak_extrema(st, d_levels, nl, iB, max_rows, threshold, 0));          // all levels of all images in one launch
+        R3DM_HIP(c, ak_extrema_mask(st, d_levels, nl, iB, tiles, n_tiles, threshold));   // all levels of all images in one launch
         R3DM_HIP(c, ak_scan_rows(st, d_levels, nl, iB));
         R3DM_HIP(c, ak_layout(st, d_levels, nl, iB, slots.as<unsigned char>(), cap, d_bmeta));
         R3DM_HIP(c, hipMemsetAsync(slots.as<unsigned char>() + field * 76, 0, field * 2, st));   // dead_lower / dead_upper flags
         R3DM_HIP(c, ak_extrema(st, d_levels, nl, iB, max_rows, threshold, 1));
         R3DM_HIP(c, ak_prune_levels(st, d_levels, nl, iB));
+        R3DM_HIP(c, ak_list_ranges(st, d_levels, nl, iB));
         R3DM_HIP(c, ak_cross(st, d_levels, nl, iB, 0));
         R3DM_HIP(c, ak_cross(st, d_levels, nl, iB, 1));
         R3DM_HIP(c, ak_refine(st, d_levels, nl, iB));

@@ -32,14 +32,27 @@ __device__ __forceinline__ int ak_refl101(int p, int len)
 
 }  // namespace
 
-// ---- GaussianBlur, BORDER_REPLICATE: row pass (SymmRowSmallFilter for 5 taps, RowFilter otherwise), column pass (SymmColumnFilter)
-__global__ __launch_bounds__(256)
-void ak_gauss_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, AkTaps kf)
+// The stencil kernels of the launch sequence.  A workgroup owns a tile of 64 x (4 R) pixels: every lane a column, every wave R
+// consecutive rows.  Two bodies: the INTERIOR body for tiles whose every tap lies inside the image (a workgroup-uniform test
+// on blockIdx) loads everything the R rows of a lane need FIRST -- no border rule, addresses = a row pointer + a compile-time
+// offset -- and only then computes, so that a wave has R rows' worth of distinct cache lines in flight (with one row per wave
+// and dependent tap loops the passes were latency-bound at 2-3.4 TB/s with VALU, TA and HBM all under 60 % busy,
+// profiles/r03_d_pmc_akaze_perf.txt); the BORDER body applies the reference's border rule per tap, pixel by pixel.
+// Both perform the same float operations in the same order per pixel, so the split changes no bit.
+template <bool IN> __device__ __forceinline__ int ak_cl(int v, int hi) { return IN ? v : ak_clamp(v, 0, hi); }
+template <bool IN> __device__ __forceinline__ int ak_rf(int p, int len) { return IN ? p : ak_refl101(p, len); }
+template <int R> __device__ __forceinline__ bool ak_strip_interior(int w, int h, int rx, int ry)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    src = AK_PLANE(src, w, h); dst = AK_PLANE(dst, w, h);
-    const float* S = src + (size_t)y * w;
+    const int x0 = (int)blockIdx.x * 64, y0 = (int)blockIdx.y * (4 * R);
+    return x0 >= rx && x0 + 63 + rx < w && y0 >= ry && y0 + 4 * R - 1 + ry < h;
+}
+#define AK_STRIP(R) const int x = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63), y0 = (int)blockIdx.y * (4 * (R)) + (int)(threadIdx.x >> 6) * (R)
+
+// ---- GaussianBlur, BORDER_REPLICATE: row pass (SymmRowSmallFilter for 5 taps, RowFilter otherwise), column pass (SymmColumnFilter)
+__device__ __forceinline__ void ak_gauss_rows_px(const float* __restrict__ src, float* __restrict__ dst, int w, int x, int y, const AkTaps& kf)
+{
+    const uint32_t row = (uint32_t)y * (uint32_t)w;
+    const float* __restrict__ S = src + row;
     const int n = kf.n, r = n / 2;
     float s;
     if (n == 5) {
@@ -49,19 +62,93 @@ void ak_gauss_rows_kernel(const float* __restrict__ src, float* __restrict__ dst
         s = kf.k[0] * S[ak_clamp(x - r, 0, w - 1)];
         for (int k = 1; k < n; ++k) s += kf.k[k] * S[ak_clamp(x + k - r, 0, w - 1)];
     }
-    dst[(size_t)y * w + x] = s;
+    dst[row + (uint32_t)x] = s;
+}
+__device__ __forceinline__ void ak_gauss_cols_px(const float* __restrict__ src, float* __restrict__ dst, int w, int h, int x, int y, const AkTaps& kf)
+{
+    const int r = kf.n / 2;
+    const uint32_t p = (uint32_t)y * (uint32_t)w + (uint32_t)x;
+    float s = kf.k[r] * src[p];
+    for (int k = 1; k <= r; ++k)
+        s += kf.k[r + k] * (src[(uint32_t)ak_clamp(y + k, 0, h - 1) * (uint32_t)w + (uint32_t)x] + src[(uint32_t)ak_clamp(y - k, 0, h - 1) * (uint32_t)w + (uint32_t)x]);
+    dst[p] = s;
+}
+// Row pass and column pass in ONE kernel: a workgroup row-filters the 16 + 2 r rows its 64 x 16 output tile needs into LDS
+// (each wave 5-6 rows, all taps loaded before the first multiply) and column-filters them from there -- the row-filtered image
+// never goes to HBM (2 planes of traffic instead of 4; the halo rows are row-filtered twice, by this tile and its neighbour).
+// Per value exactly the operations of the two-pass form: row value = ak_gauss_rows_px's expression at (clamped) row y, output =
+// ak_gauss_cols_px's expression on those values.  IN = the tile and its halo lie inside the image (no clamps).
+template <int N, bool IN> __device__ __forceinline__ void ak_gauss_fused(const float* __restrict__ src, float* __restrict__ dst, int w, int h, const AkTaps& kf,
+                                                                         float (*mid)[64])
+{
+    constexpr int r = N / 2, RI = 16 + 2 * r, PER = (RI + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = (int)blockIdx.x * 64 + lane, y0 = (int)blockIdx.y * 16;
+    const uint32_t uw = (uint32_t)w;
+    float v[PER][N];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int jj = wave + 4 * q;
+        const int yy = ak_cl<IN>(y0 - r + (jj < RI ? jj : RI - 1), h - 1);
+        const float* __restrict__ S = src + (uint32_t)yy * uw;
+        if (IN) {
+            const float* __restrict__ P = S + (uint32_t)x;
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[q][k] = P[k - r];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[q][k] = S[ak_clamp(x + k - r, 0, w - 1)];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int jj = wave + 4 * q;
+        float s;
+        if (N == 5) {
+            s = v[q][2] * kf.k[2] + (v[q][1] + v[q][3]) * kf.k[3] + (v[q][0] + v[q][4]) * kf.k[4];
+        } else {
+            s = kf.k[0] * v[q][0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) s += kf.k[k] * v[q][k];
+        }
+        if (jj < RI) mid[jj][lane] = s;
+    }
+    r3dm_syncthreads();
+    if (!IN && x >= w) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = wave * 4 + q;
+        if (!IN && y0 + j >= h) break;
+        float s = kf.k[r] * mid[j + r][lane];
+#pragma unroll
+        for (int k = 1; k <= r; ++k) s += kf.k[r + k] * (mid[j + r + k][lane] + mid[j + r - k][lane]);
+        dst[(uint32_t)(y0 + j) * uw + (uint32_t)x] = s;
+    }
+}
+__global__ __launch_bounds__(256)
+void ak_gauss_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, AkTaps kf)
+{
+    __shared__ float mid[24][64];
+    src = AK_PLANE(src, w, h); dst = AK_PLANE(dst, w, h);
+    const int r = kf.n / 2;
+    const bool in = ak_strip_interior<4>(w, h, r, r);
+    if (kf.n == 5) { if (in) ak_gauss_fused<5, true>(src, dst, w, h, kf, mid); else ak_gauss_fused<5, false>(src, dst, w, h, kf, mid); }
+    else { if (in) ak_gauss_fused<9, true>(src, dst, w, h, kf, mid); else ak_gauss_fused<9, false>(src, dst, w, h, kf, mid); }
+}
+// tap counts other than 5 / 9 (no sigma of the detector produces them): the two-pass form, one pixel per thread
+__global__ __launch_bounds__(256)
+void ak_gauss_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, AkTaps kf)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    ak_gauss_rows_px(AK_PLANE(src, w, h), AK_PLANE(dst, w, h), w, x, y, kf);
 }
 __global__ __launch_bounds__(256)
 void ak_gauss_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, AkTaps kf)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    src = AK_PLANE(src, w, h); dst = AK_PLANE(dst, w, h);
-    const int r = kf.n / 2;
-    float s = kf.k[r] * src[(size_t)y * w + x];
-    for (int k = 1; k <= r; ++k)
-        s += kf.k[r + k] * (src[(size_t)ak_clamp(y + k, 0, h - 1) * w + x] + src[(size_t)ak_clamp(y - k, 0, h - 1) * w + x]);
-    dst[(size_t)y * w + x] = s;
+    ak_gauss_cols_px(AK_PLANE(src, w, h), AK_PLANE(dst, w, h), w, h, x, y, kf);
 }
 
 // ---- Scharr 3x3, BORDER_REFLECT_101: row pass writes the derivative and the smoothed row, column pass Lx and Ly
@@ -107,48 +194,173 @@ __device__ __forceinline__ float ak_sderiv_at(const float* __restrict__ src, int
     const float wgt = 10.0f / 3.0f;
     const float norm = 1.0f / (2.0f * (wgt + 2.0f));
     const float kc = wgt * norm;
-    const float u = ak_sderiv_row(src + (size_t)ak_refl101(y - s, h) * w, x, w, s, dx);
-    const float d = ak_sderiv_row(src + (size_t)ak_refl101(y + s, h) * w, x, w, s, dx);
-    if (dx) { const float c = ak_sderiv_row(src + (size_t)y * w, x, w, s, dx); return kc * c + norm * (d + u); }
+    const float u = ak_sderiv_row(src + (uint32_t)ak_refl101(y - s, h) * (uint32_t)w, x, w, s, dx);
+    const float d = ak_sderiv_row(src + (uint32_t)ak_refl101(y + s, h) * (uint32_t)w, x, w, s, dx);
+    if (dx) { const float c = ak_sderiv_row(src + (uint32_t)y * (uint32_t)w, x, w, s, dx); return kc * c + norm * (d + u); }
     return d - u;
 }
-// both derivatives of one source in one pass: d/dx -> dst_x, d/dy -> dst_y (smooth -> Lx, Ly;  Lx -> Lxx, Lxy)
+// the interior forms: the taps of one pixel, loaded by the caller.  u / m / d = rows y - S, y, y + S; a / c / b = columns x - S, x, x + S
+template <int S> __device__ __forceinline__ float ak_sd_smooth3(float a, float c, float b)      // ak_sderiv_row(dx = 0)
+{
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (wgt + 2.0f));
+    const float kc = wgt * norm;
+    if (S == 2) return c * kc + (a + b) * norm;
+    return (norm * a + kc * c) + norm * b;
+}
+template <int S> __device__ __forceinline__ float ak_sd_dx(float au, float bu, float am, float bm, float ad, float bd)   // ak_sderiv_at(dx = 1)
+{
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (wgt + 2.0f));
+    const float kc = wgt * norm;
+    const float u = (-au) + bu, d = (-ad) + bd, c = (-am) + bm;
+    return kc * c + norm * (d + u);
+}
+template <int S> __device__ __forceinline__ float ak_sd_dy(float au, float cu, float bu, float ad, float cd, float bd)   // ak_sderiv_at(dx = 0)
+{
+    const float u = ak_sd_smooth3<S>(au, cu, bu), d = ak_sd_smooth3<S>(ad, cd, bd);
+    return d - u;
+}
+// both derivatives of one source in one pass: d/dx -> dst_x, d/dy -> dst_y (smooth -> Lx, Ly)
+template <int S, int R> __device__ __forceinline__ void ak_sderiv_xy_strip(const float* __restrict__ src, float* __restrict__ dst_x, float* __restrict__ dst_y, int w, int x, int y0)
+{
+    const uint32_t uw = (uint32_t)w;
+    const float* __restrict__ P = src + ((uint32_t)y0 * uw + (uint32_t)x);
+    float u[R][3], m[R][2], d[R][3];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const float* __restrict__ U = P + (uint32_t)(j + 0) * uw - (uint32_t)S * uw;
+        const float* __restrict__ M = P + (uint32_t)j * uw;
+        const float* __restrict__ D = P + (uint32_t)j * uw + (uint32_t)S * uw;
+        u[j][0] = U[-S]; u[j][1] = U[0]; u[j][2] = U[S];
+        m[j][0] = M[-S]; m[j][1] = M[S];
+        d[j][0] = D[-S]; d[j][1] = D[0]; d[j][2] = D[S];
+    }
+    const uint32_t p = (uint32_t)y0 * uw + (uint32_t)x;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        dst_x[p + (uint32_t)j * uw] = ak_sd_dx<S>(u[j][0], u[j][2], m[j][0], m[j][1], d[j][0], d[j][2]);
+        dst_y[p + (uint32_t)j * uw] = ak_sd_dy<S>(u[j][0], u[j][1], u[j][2], d[j][0], d[j][1], d[j][2]);
+    }
+}
 __global__ __launch_bounds__(256)
 void ak_sderiv_xy_kernel(const float* __restrict__ src, float* __restrict__ dst_x, float* __restrict__ dst_y, int w, int h, int s)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    constexpr int R = 4;
+    AK_STRIP(R);
     src = AK_PLANE(src, w, h); dst_x = AK_PLANE(dst_x, w, h); dst_y = AK_PLANE(dst_y, w, h);
-    dst_x[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, 1);
-    dst_y[(size_t)y * w + x] = ak_sderiv_at(src, x, y, w, h, s, 0);
+    if (s >= 2 && s <= 4 && ak_strip_interior<R>(w, h, s, s)) {
+        if (s == 2) ak_sderiv_xy_strip<2, R>(src, dst_x, dst_y, w, x, y0);
+        else if (s == 3) ak_sderiv_xy_strip<3, R>(src, dst_x, dst_y, w, x, y0);
+        else ak_sderiv_xy_strip<4, R>(src, dst_x, dst_y, w, x, y0);
+        return;
+    }
+    if (x >= w) return;
+    for (int j = 0; j < R; ++j) {
+        const int y = y0 + j;
+        if (y >= h) break;
+        const uint32_t p = (uint32_t)y * (uint32_t)w + (uint32_t)x;
+        dst_x[p] = ak_sderiv_at(src, x, y, w, h, s, 1);
+        dst_y[p] = ak_sderiv_at(src, x, y, w, h, s, 0);
+    }
 }
-// Lyy = d/dy of Ly, consumed on the spot: det = Lxx * Lyy - Lxy * Lxy
-__global__ __launch_bounds__(256)
-void ak_sderiv_det_kernel(const float* __restrict__ ly, const float* __restrict__ lxx, const float* __restrict__ lxy,
-                          float* __restrict__ ldet, int w, int h, int s)
+// The second derivatives consumed on the spot: Lxx = d/dx of Lx, Lxy = d/dy of Lx, Lyy = d/dy of Ly, det = Lxx * Lyy - Lxy * Lxy.
+// Each is the very expression ak_sderiv_xy_kernel would have stored (same operations, same order), so the determinant is
+// bit-identical to the three-image form while two work images and four of the ten plane passes of a level's Hessian disappear
+// (reads Lx, Ly, writes Ldet: 3 planes instead of read Lx + write Lxx, Lxy + read Ly, Lxx, Lxy + write Ldet = 7).
+template <int S, int R> __device__ __forceinline__ void ak_sderiv_det_strip(const float* __restrict__ lx, const float* __restrict__ ly, float* __restrict__ ldet, int w, int x, int y0)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    ly = AK_PLANE(ly, w, h); lxx = AK_PLANE(lxx, w, h); lxy = AK_PLANE(lxy, w, h); ldet = AK_PLANE(ldet, w, h);
-    const size_t i = (size_t)y * w + x;
-    const float lyy = ak_sderiv_at(ly, x, y, w, h, s, 0);
-    ldet[i] = lxx[i] * lyy - lxy[i] * lxy[i];
+    const uint32_t uw = (uint32_t)w;
+    const uint32_t p = (uint32_t)y0 * uw + (uint32_t)x;
+    const float* __restrict__ PX = lx + p;
+    const float* __restrict__ PY = ly + p;
+    float u[R][3], m[R][2], d[R][3], yu[R][3], yd[R][3];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const float* __restrict__ U = PX + (uint32_t)j * uw - (uint32_t)S * uw;
+        const float* __restrict__ M = PX + (uint32_t)j * uw;
+        const float* __restrict__ D = PX + (uint32_t)j * uw + (uint32_t)S * uw;
+        const float* __restrict__ YU = PY + (uint32_t)j * uw - (uint32_t)S * uw;
+        const float* __restrict__ YD = PY + (uint32_t)j * uw + (uint32_t)S * uw;
+        u[j][0] = U[-S]; u[j][1] = U[0]; u[j][2] = U[S];
+        m[j][0] = M[-S]; m[j][1] = M[S];
+        d[j][0] = D[-S]; d[j][1] = D[0]; d[j][2] = D[S];
+        yu[j][0] = YU[-S]; yu[j][1] = YU[0]; yu[j][2] = YU[S];
+        yd[j][0] = YD[-S]; yd[j][1] = YD[0]; yd[j][2] = YD[S];
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const float lxx = ak_sd_dx<S>(u[j][0], u[j][2], m[j][0], m[j][1], d[j][0], d[j][2]);
+        const float lxy = ak_sd_dy<S>(u[j][0], u[j][1], u[j][2], d[j][0], d[j][1], d[j][2]);
+        const float lyy = ak_sd_dy<S>(yu[j][0], yu[j][1], yu[j][2], yd[j][0], yd[j][1], yd[j][2]);
+        ldet[p + (uint32_t)j * uw] = lxx * lyy - lxy * lxy;
+    }
+}
+__global__ __launch_bounds__(256)
+void ak_sderiv_det_kernel(const float* __restrict__ lx, const float* __restrict__ ly, float* __restrict__ ldet, int w, int h, int s)
+{
+    constexpr int R = 2;
+    AK_STRIP(R);
+    lx = AK_PLANE(lx, w, h); ly = AK_PLANE(ly, w, h); ldet = AK_PLANE(ldet, w, h);
+    if (s >= 2 && s <= 4 && ak_strip_interior<R>(w, h, s, s)) {
+        if (s == 2) ak_sderiv_det_strip<2, R>(lx, ly, ldet, w, x, y0);
+        else if (s == 3) ak_sderiv_det_strip<3, R>(lx, ly, ldet, w, x, y0);
+        else ak_sderiv_det_strip<4, R>(lx, ly, ldet, w, x, y0);
+        return;
+    }
+    if (x >= w) return;
+    for (int j = 0; j < R; ++j) {
+        const int y = y0 + j;
+        if (y >= h) break;
+        const float lxx = ak_sderiv_at(lx, x, y, w, h, s, 1);
+        const float lxy = ak_sderiv_at(lx, x, y, w, h, s, 0);
+        const float lyy = ak_sderiv_at(ly, x, y, w, h, s, 0);
+        ldet[(uint32_t)y * (uint32_t)w + (uint32_t)x] = lxx * lyy - lxy * lxy;
+    }
 }
 
-// ---- k-contrast: maximum of the gradient modulus over the interior, then its histogram
-__global__ __launch_bounds__(256)
-void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, uint32_t* __restrict__ out_max)
+// ---- k-contrast: maximum of the gradient modulus over the interior, then its histogram.  The modulus comes straight from the
+// smoothed image: for an interior pixel the Scharr row + column pass (ak_scharr_rows / _cols_kernel: Lx = (rd[y-1] + rd[y+1]) * 3 +
+// rd[y] * 10, Ly = rs[y+1] - rs[y-1]) touches no border, so both kernels recompute exactly those expressions from the 3 x 3
+// neighbourhood instead of reading two derivative images that four more plane passes would have to write first.
+// Tile = 64 columns x 16 rows of the interior [1, w-2] x [1, h-2]; every lane a column and 4 rows, 18 loads up front.
+__device__ __forceinline__ void ak_modg_strip(const float* __restrict__ src, int w, int h, int tile_y, float (&m)[4], bool (&ok)[4])
 {
-    // grid-stride over the interior rows: one atomic per workgroup (the maximum is order-independent)
+    const int x = 1 + (int)blockIdx.x * 64 + (int)(threadIdx.x & 63), y0 = 1 + tile_y * 16 + (int)(threadIdx.x >> 6) * 4;
+    const bool vx = x < w - 1;
+    const int xc = vx ? x : 1;
+    float v[6][3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        int yy = y0 - 1 + j;
+        yy = yy < h - 1 ? yy : h - 1;
+        const float* __restrict__ P = src + ((uint32_t)yy * (uint32_t)w + (uint32_t)xc);
+        v[j][0] = P[-1]; v[j][1] = P[0]; v[j][2] = P[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float au = v[j][0], cu = v[j][1], bu = v[j][2], ac = v[j + 1][0], bc = v[j + 1][2], ad = v[j + 2][0], cd = v[j + 2][1], bd = v[j + 2][2];
+        const float rdu = bu - au, rdc = bc - ac, rdd = bd - ad;
+        const float rsu = cu * 10.0f + (au + bu) * 3.0f, rsd = cd * 10.0f + (ad + bd) * 3.0f;
+        const float lx = (rdu + rdd) * 3.0f + rdc * 10.0f;
+        const float ly = rsd - rsu;
+        m[j] = sqrtf(lx * lx + ly * ly);
+        ok[j] = vx && (y0 + j < h - 1);
+    }
+}
+__global__ __launch_bounds__(256)
+void ak_modg_max_kernel(const float* __restrict__ src, int w, int h, uint32_t* __restrict__ out_max)
+{
     __shared__ float part[4];
-    Lx = AK_PLANE(Lx, w, h); Ly = AK_PLANE(Ly, w, h); out_max += (size_t)blockIdx.z * kAkSmallWords;
+    src = AK_PLANE(src, w, h); out_max += (size_t)blockIdx.z * kAkSmallWords;
     float m = 0.0f;
-    for (int y = 1 + (int)blockIdx.x; y < h - 1; y += (int)gridDim.x)
-        for (int x = 1 + (int)threadIdx.x; x < w - 1; x += 256) {
-            const float lx = Lx[(size_t)y * w + x], ly = Ly[(size_t)y * w + x];
-            const float v = sqrtf(lx * lx + ly * ly);
-            m = v > m ? v : m;
-        }
+    const int tiles_y = (h - 2 + 15) / 16;
+    for (int ty = (int)blockIdx.y; ty < tiles_y; ty += (int)gridDim.y) {          // one atomic per workgroup, not per tile
+        float mg[4]; bool ok[4];
+        ak_modg_strip(src, w, h, ty, mg, ok);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (ok[j]) m = mg[j] > m ? mg[j] : m;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off); m = o > m ? o : m; }
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
@@ -160,23 +372,21 @@ void ak_modg_max_kernel(const float* __restrict__ Lx, const float* __restrict__ 
 }
 // hmax_bits: the maximum found by ak_modg_max_kernel, read on the device (no host round trip); bin scale = (nbins - 1) / hmax
 __global__ __launch_bounds__(256)
-void ak_modg_hist_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, int w, int h, const uint32_t* __restrict__ hmax_bits, int nbins, uint32_t* __restrict__ hist)
+void ak_modg_hist_kernel(const float* __restrict__ src, int w, int h, const uint32_t* __restrict__ hmax_bits, int nbins, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t lh[512];
-    Lx = AK_PLANE(Lx, w, h); Ly = AK_PLANE(Ly, w, h); hmax_bits += (size_t)blockIdx.z * kAkSmallWords; hist += (size_t)blockIdx.z * kAkSmallWords;
+    src = AK_PLANE(src, w, h); hmax_bits += (size_t)blockIdx.z * kAkSmallWords; hist += (size_t)blockIdx.z * kAkSmallWords;
     const float hmax = __uint_as_float(*hmax_bits);
     if (hmax == 0.0f) return;                              // compute_k_percentileV2 keeps its default then (workgroup-uniform)
     const float sc = (nbins - 1) / hmax;
     for (int k = threadIdx.x; k < nbins; k += 256) lh[k] = 0;
     r3dm_syncthreads();
-    const int x = 1 + blockIdx.x * 64 + (threadIdx.x & 63);
-    for (int yy = 0; yy < 16; ++yy) {
-        const int y = 1 + (blockIdx.y * 16 + yy) * 4 + (threadIdx.x >> 6);
-        if (x < w - 1 && y < h - 1) {
-            const float lx = Lx[(size_t)y * w + x], ly = Ly[(size_t)y * w + x];
-            const float m = sqrtf(lx * lx + ly * ly);
-            atomicAdd(&lh[(int)(m * sc)], 1u);
-        }
+    const int tiles_y = (h - 2 + 15) / 16;
+    for (int ty = (int)blockIdx.y; ty < tiles_y; ty += (int)gridDim.y) {          // the 300 bins are flushed once per workgroup, not per tile
+        float mg[4]; bool ok[4];
+        ak_modg_strip(src, w, h, ty, mg, ok);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (ok[j]) atomicAdd(&lh[(int)(mg[j] * sc)], 1u);
     }
     r3dm_syncthreads();
     for (int k = threadIdx.x; k < nbins; k += 256) if (lh[k]) atomicAdd(hist + k, lh[k]);
@@ -204,32 +414,48 @@ __global__ void ak_kcontrast_kernel(const uint32_t* __restrict__ hmax_bits, cons
 
 // ---- Scharr 3x3 (row pass + column pass, as above) and the PM-G2 conductivity in one kernel: flow = 1 / (1 + |grad|^2 / k^2).
 // Same operations per pixel as the Scharr row + column pass followed by the conductivity, without the four intermediate images.
+__device__ __forceinline__ float ak_g2_from_taps(float au, float cu, float bu, float ac, float bc, float ad, float cd, float bd, float inv_k2)
+{
+    const float rdu = bu - au, rdc = bc - ac, rdd = bd - ad;                       // row pass, derivative
+    const float rsu = cu * 10.0f + (au + bu) * 3.0f, rsd = cd * 10.0f + (ad + bd) * 3.0f;     // row pass, smoothing
+    const float lx = (rdu + rdd) * 3.0f + rdc * 10.0f;
+    const float ly = rsd - rsu;
+    return 1.0f / (1.0f + ((lx * lx + ly * ly) * inv_k2));
+}
+__device__ __forceinline__ float ak_scharr_g2_px(const float* __restrict__ src, int w, int h, int x, int y, float inv_k2)
+{
+    const int xl = ak_refl101(x - 1, w), xr = ak_refl101(x + 1, w);
+    const float* __restrict__ Su = src + (uint32_t)ak_refl101(y - 1, h) * (uint32_t)w;
+    const float* __restrict__ Sc = src + (uint32_t)y * (uint32_t)w;
+    const float* __restrict__ Sd = src + (uint32_t)ak_refl101(y + 1, h) * (uint32_t)w;
+    return ak_g2_from_taps(Su[xl], Su[x], Su[xr], Sc[xl], Sc[xr], Sd[xl], Sd[x], Sd[xr], inv_k2);
+}
 __global__ __launch_bounds__(256)
 void ak_scharr_g2_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, const float* __restrict__ inv_k2_p)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    constexpr int R = 4;
+    AK_STRIP(R);
     src = AK_PLANE(src, w, h); dst = AK_PLANE(dst, w, h); inv_k2_p += (size_t)blockIdx.z * kAkSmallWords;
     const float inv_k2 = *inv_k2_p;                        // 1 / k^2 of this octave, left on the device by ak_kcontrast_kernel
-    const int xl = ak_refl101(x - 1, w), xr = ak_refl101(x + 1, w);
-    const float* Su = src + (size_t)ak_refl101(y - 1, h) * w;
-    const float* Sc = src + (size_t)y * w;
-    const float* Sd = src + (size_t)ak_refl101(y + 1, h) * w;
-    const float au = Su[xl], bu = Su[xr], ac = Sc[xl], bc = Sc[xr], ad = Sd[xl], bd = Sd[xr];
-    const float rdu = bu - au, rdc = bc - ac, rdd = bd - ad;                       // row pass, derivative
-    const float rsu = Su[x] * 10.0f + (au + bu) * 3.0f, rsd = Sd[x] * 10.0f + (ad + bd) * 3.0f;     // row pass, smoothing
-    const float lx = (rdu + rdd) * 3.0f + rdc * 10.0f;
-    const float ly = rsd - rsu;
-    dst[(size_t)y * w + x] = 1.0f / (1.0f + ((lx * lx + ly * ly) * inv_k2));
+    if (ak_strip_interior<R>(w, h, 1, 1)) {
+        const uint32_t uw = (uint32_t)w;
+        const float* __restrict__ P = src + ((uint32_t)(y0 - 1) * uw + (uint32_t)x);
+        float v[R + 2][3];
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) { const float* __restrict__ Pj = P + (uint32_t)j * uw; v[j][0] = Pj[-1]; v[j][1] = Pj[0]; v[j][2] = Pj[1]; }
+        float* __restrict__ D = dst + ((uint32_t)y0 * uw + (uint32_t)x);
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            D[(uint32_t)j * uw] = ak_g2_from_taps(v[j][0], v[j][1], v[j][2], v[j + 1][0], v[j + 1][2], v[j + 2][0], v[j + 2][1], v[j + 2][2], inv_k2);
+        return;
+    }
+    if (x >= w) return;
+    for (int j = 0; j < R; ++j) if (y0 + j < h) dst[(uint32_t)(y0 + j) * (uint32_t)w + (uint32_t)x] = ak_scharr_g2_px(src, w, h, x, y0 + j, inv_k2);
 }
 
 // ---- one FED step: Lstep (nld_step_scalar_one_lane; corners 0) and out = Lt + Lstep * 0.5 * step
-__global__ __launch_bounds__(256)
-void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, float step_size)
+__device__ __forceinline__ void ak_fed_px_border(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, int x, int y, float step_size)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    Lt = AK_PLANE(Lt, w, h); Lf = AK_PLANE(Lf, w, h); out = AK_PLANE(out, w, h);
     const size_t p = (size_t)y * w + x;
     const bool has_l = x > 0, has_r = x < w - 1, has_a = y > 0, has_b = y < h - 1;
     const float tc = Lt[p], fc = Lf[p];
@@ -249,6 +475,98 @@ void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ 
             (fc + Lf[p + w]) * (Lt[p + w] - tc) + (fc + Lf[p - w]) * (Lt[p - w] - tc);
     }
     out[p] = tc + v * 0.5f * step_size;
+}
+__global__ __launch_bounds__(256)
+void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, float step_size)
+{
+    constexpr int R = 4;
+    AK_STRIP(R);
+    Lt = AK_PLANE(Lt, w, h); Lf = AK_PLANE(Lf, w, h); out = AK_PLANE(out, w, h);
+    if (ak_strip_interior<R>(w, h, 1, 1)) {
+        const uint32_t uw = (uint32_t)w;
+        const uint32_t q = (uint32_t)(y0 - 1) * uw + (uint32_t)x;
+        const float* __restrict__ T = Lt + q;
+        const float* __restrict__ F = Lf + q;
+        float tc[R + 2], fc[R + 2], tl[R], tr[R], fl[R], fr[R];
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) { tc[j] = T[(uint32_t)j * uw]; fc[j] = F[(uint32_t)j * uw]; }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float* __restrict__ Tj = T + (uint32_t)(j + 1) * uw;
+            const float* __restrict__ Fj = F + (uint32_t)(j + 1) * uw;
+            tl[j] = Tj[-1]; tr[j] = Tj[1]; fl[j] = Fj[-1]; fr[j] = Fj[1];
+        }
+        float* __restrict__ O = out + ((uint32_t)y0 * uw + (uint32_t)x);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float t = tc[j + 1], f = fc[j + 1];
+            const float v = (f + fr[j]) * (tr[j] - t) + (f + fl[j]) * (tl[j] - t) + (f + fc[j + 2]) * (tc[j + 2] - t) + (f + fc[j]) * (tc[j] - t);
+            O[(uint32_t)j * uw] = t + v * 0.5f * step_size;
+        }
+        return;
+    }
+    if (x >= w) return;
+    for (int j = 0; j < R; ++j) if (y0 + j < h) ak_fed_px_border(Lt, Lf, out, w, h, x, y0 + j, step_size);
+}
+
+// ---- up to 4 FED steps in ONE launch, for the small octaves: there a step is a few microseconds of work behind a launch (8 us per
+// step for eight 500 x 375 images: the launch floor), and a level of those octaves takes 8 .. 28 steps.  A workgroup owns a
+// 32 x 32 tile: it loads the tile with a halo of 4 (Lt and the conductivity) into LDS, runs the steps there -- after step s the
+// cells at least s from the halo's edge are exact -- and writes its tile.  Every cell update is the expression of
+// ak_fed_step_kernel with the same border cases (decided by the cell's position in the IMAGE), so the result is bit-identical;
+// the halo cells are simply updated twice (here and by the neighbouring tile).
+struct AkFedSteps { float tau[4]; int n; };
+__global__ __launch_bounds__(256)
+void ak_fed_multi_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, AkFedSteps st)
+{
+    constexpr int K = 4, T = 32, HW = T + 2 * K;
+    __shared__ float a[2][HW * HW];
+    __shared__ float f[HW * HW];
+    Lt = AK_PLANE(Lt, w, h); Lf = AK_PLANE(Lf, w, h); out = AK_PLANE(out, w, h);
+    const int x0 = (int)blockIdx.x * T - K, y0 = (int)blockIdx.y * T - K;
+    for (int c = threadIdx.x; c < HW * HW; c += 256) {
+        const int lx = c % HW, ly = c / HW, gx = x0 + lx, gy = y0 + ly;
+        const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+        const uint32_t p = (uint32_t)(in ? gy : 0) * (uint32_t)w + (uint32_t)(in ? gx : 0);
+        const float tv = Lt[p], fv = Lf[p];
+        a[0][c] = in ? tv : 0.0f; f[c] = in ? fv : 0.0f;
+    }
+    r3dm_syncthreads();
+    for (int s = 0; s < st.n; ++s) {
+        const float* __restrict__ cur = a[s & 1];
+        float* __restrict__ nxt = a[(s + 1) & 1];
+        const int lo = s + 1, side = HW - 2 * (s + 1);                  // cells [lo, lo + side) x [lo, lo + side) are exact after this step
+        const float step_size = st.tau[s];
+        for (int c = threadIdx.x; c < side * side; c += 256) {
+            const int lx = lo + c % side, ly = lo + c / side, gx = x0 + lx, gy = y0 + ly;
+            if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
+            const int q = ly * HW + lx;
+            const bool has_l = gx > 0, has_r = gx < w - 1, has_a = gy > 0, has_b = gy < h - 1;
+            const float tc = cur[q], fc = f[q];
+            float v;
+            if (!has_a) {
+                if (!has_l || !has_r) v = 0.0f;
+                else v = (fc + f[q + 1]) * (cur[q + 1] - tc) + (fc + f[q - 1]) * (cur[q - 1] - tc) + (fc + f[q + HW]) * (cur[q + HW] - tc);
+            } else if (!has_b) {
+                if (!has_l || !has_r) v = 0.0f;
+                else v = (fc + f[q + 1]) * (cur[q + 1] - tc) + (fc + f[q - 1]) * (cur[q - 1] - tc) + (fc + f[q - HW]) * (cur[q - HW] - tc);
+            } else if (!has_l) {
+                v = (fc + f[q + 1]) * (cur[q + 1] - tc) + (fc + f[q + HW]) * (cur[q + HW] - tc) + (fc + f[q - HW]) * (cur[q - HW] - tc);
+            } else if (!has_r) {
+                v = (fc + f[q - 1]) * (cur[q - 1] - tc) + (fc + f[q + HW]) * (cur[q + HW] - tc) + (fc + f[q - HW]) * (cur[q - HW] - tc);
+            } else {
+                v = (fc + f[q + 1]) * (cur[q + 1] - tc) + (fc + f[q - 1]) * (cur[q - 1] - tc) +
+                    (fc + f[q + HW]) * (cur[q + HW] - tc) + (fc + f[q - HW]) * (cur[q - HW] - tc);
+            }
+            nxt[q] = tc + v * 0.5f * step_size;
+        }
+        r3dm_syncthreads();
+    }
+    const float* __restrict__ fin = a[st.n & 1];
+    for (int c = threadIdx.x; c < T * T; c += 256) {
+        const int lx = K + c % T, ly = K + c / T, gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) out[(uint32_t)gy * (uint32_t)w + (uint32_t)gx] = fin[ly * HW + lx];
+    }
 }
 
 // ---- halfsample: INTER_AREA, exact 2x (resizeAreaFast_) or fractional cells (ResizeArea_, tables from the host)
@@ -290,35 +608,77 @@ __device__ __forceinline__ bool ak_is_extremum(const float* __restrict__ ldet, i
     if (v <= next[x - 1] || v <= next[x] || v <= next[x + 1]) return false;
     return true;
 }
-// one workgroup per image row (border .. h - border) of every level: blockIdx.z = image, blockIdx.y = level, blockIdx.x = row
+// The count pass: a workgroup owns a tile of 64 columns x 16 rows of ONE level's interior (every lane a column, every wave 4 rows;
+// the 18 values a lane needs are loaded before anything is compared), blockIdx.x = tile over all levels (AkTileTable: where the
+// tiles of each level begin), blockIdx.y = image.  The outcome of the 3 x 3 test is kept as one bit per pixel (a 64-bit ballot per
+// 64 pixels, L.mask: 1/32 of the image) next to the per-row counts; after the scan of the counts and the device-side slot layout the
+// emit pass reads only the bit masks and the determinant at the set bits -- no second sweep over the image, no barrier anywhere
+// (the two-sweep, two-barriers-per-256-pixels form took 1.4 ms per call for eight 12 Mpx images, a wave-per-row sweep 1.0 ms).
 __global__ __launch_bounds__(256)
-void ak_extrema_kernel(const AkLevelDev* __restrict__ levels, float thr, int pass /* 0 = count, 1 = emit */)
+void ak_extrema_mask_kernel(const AkLevelDev* __restrict__ levels, int n_levels, AkTileTable tt, float thr)
 {
-    __shared__ uint32_t wave_cnt[4];
-    const AkLevelDev L = levels[blockIdx.z * gridDim.y + blockIdx.y];
-    if ((int)blockIdx.x >= L.h - 2 * L.border) return;                 // workgroup-uniform: this level has fewer rows
-    if (pass && L.counts[0] == 0) return;
-    const int y = L.border + blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t base = pass ? L.row_off[blockIdx.x] : 0u;
-    uint32_t total = 0;
-    for (int x0 = L.border; x0 < L.w - L.border; x0 += 256) {
-        const int x = x0 + (int)threadIdx.x;
-        const bool is = (x < L.w - L.border) && ak_is_extremum(L.Ldet, L.w, x, y, thr);
-        const unsigned long long bal = __ballot(is);
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-        r3dm_syncthreads();
-        uint32_t woff = 0, tot = 0;
+    const uint32_t t = blockIdx.x;
+    int li = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const uint32_t cw = wave_cnt[q]; if (q < wave) woff += cw; tot += cw; }
-        if (pass && is) {
-            const uint32_t o = base + total + woff + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-            L.cand[o] = make_float4((float)(x * L.ratio), (float)(y * L.ratio), L.Ldet[(size_t)y * L.w + x], 0.0f);
-        }
-        total += tot;
-        r3dm_syncthreads();
+    for (int i = 1; i < 16; ++i) li += (t >= tt.begin[i]) ? 1 : 0;             // begin[i] = 0xFFFFFFFF beyond the last level
+    const AkLevelDev L = levels[blockIdx.y * (unsigned)n_levels + (unsigned)li];
+    const uint32_t local = t - tt.begin[li];
+    const int tx = (int)(local % L.mask_words), ty = (int)(local / L.mask_words);
+    const int rows = L.h - 2 * L.border, lane = threadIdx.x & 63;
+    const int row0 = ty * 16 + (int)(threadIdx.x >> 6) * 4;
+    if (row0 >= rows) return;                                              // wave-uniform
+    const int x = L.border + tx * 64 + lane;
+    const bool valid_x = x < L.w - L.border;
+    const int xc = valid_x ? x : L.border;
+    const float* __restrict__ ldet = L.Ldet;
+    float v[6][3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        int yy = L.border + row0 - 1 + j;
+        yy = yy < L.h - 1 ? yy : L.h - 1;
+        const float* __restrict__ P = ldet + ((uint32_t)yy * (uint32_t)L.w + (uint32_t)xc);
+        v[j][0] = P[-1]; v[j][1] = P[0]; v[j][2] = P[1];
     }
-    if (!pass && threadIdx.x == 0) L.row_cnt[blockIdx.x] = total;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = row0 + j;
+        const float c = v[j + 1][1];
+        // ak_is_extremum: `if (v <= n) return false` for the threshold and the eight neighbours
+        const bool is = valid_x && row < rows && !(c <= thr) && !(c <= v[j + 1][0]) && !(c <= v[j + 1][2]) &&
+                        !(c <= v[j][0]) && !(c <= v[j][1]) && !(c <= v[j][2]) && !(c <= v[j + 2][0]) && !(c <= v[j + 2][1]) && !(c <= v[j + 2][2]);
+        const unsigned long long bal = __ballot(is);
+        if (row < rows && lane == 0) {
+            L.mask[(size_t)row * L.mask_words + (uint32_t)tx] = bal;
+            if (bal) atomicAdd(L.row_cnt + row, (uint32_t)__builtin_popcountll(bal));      // (zeroed by the host before the pass)
+        }
+    }
+}
+__global__ __launch_bounds__(256)
+void ak_extrema_emit_kernel(const AkLevelDev* __restrict__ levels)
+{
+    const AkLevelDev L = levels[blockIdx.z * gridDim.y + blockIdx.y];
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (row >= L.h - 2 * L.border || L.counts[0] == 0) return;          // wave-uniform
+    if (L.row_cnt[row] == 0) return;
+    const int y = L.border + row, lane = threadIdx.x & 63;
+    const unsigned long long* __restrict__ mrow = L.mask + (size_t)row * L.mask_words;
+    uint32_t base = L.row_off[row];
+    for (uint32_t c0 = 0; c0 < L.mask_words; c0 += 64) {
+        const uint32_t c = c0 + (uint32_t)lane;
+        unsigned long long m = c < L.mask_words ? mrow[c] : 0ull;
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        uint32_t o = base + incl - cnt;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int x = L.border + (int)c * 64 + bit;
+            L.cand[o++] = make_float4((float)(x * L.ratio), (float)(y * L.ratio), L.Ldet[(size_t)y * L.w + x], 0.0f);
+        }
+        base += (uint32_t)__shfl((int)incl, 63);
+    }
 }
 // exclusive scan of the row counts of every level (one workgroup per level)
 __global__ __launch_bounds__(1024)
@@ -547,12 +907,35 @@ void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels, uint32_t live_
 // ---- cross-level pruning.  mode 0 ("lower"): a point q of level i-1 dies when some point p of level i lies within
 // p.size of it with a larger response.  mode 1 ("upper"): a point v of level i+1 dies when some point p of level i that
 // survived mode 0 lies within v.size of it with a larger response.  One thread per victim.
+//
+// The test is "any killer within the radius", so the order in which killers are visited is free.  The lists are in insertion
+// order of a raster scan, i.e. almost sorted by row: ak_list_ranges_kernel records the row span (min y, max y) of every chunk of
+// 256 list entries, and a block of 256 victims only loads the killer chunks whose span comes within the radius of its own --
+// a few chunks instead of all of them (the all-pairs form was quadratic: 6.9 ms per call at 72 k keypoints per image).  The
+// spans are taken from the data, so nothing depends on the lists actually being sorted.
+__global__ __launch_bounds__(256)
+void ak_list_ranges_kernel(const AkLevelDev* __restrict__ levels)
+{
+    __shared__ float smin[4], smax[4];
+    const AkLevelDev L = levels[blockIdx.y];
+    const uint32_t n = L.counts[1];
+    float2* __restrict__ ranges = reinterpret_cast<float2*>(L.live);       // the in-level pruning is done with its scratch
+    for (uint32_t c = blockIdx.x; c * 256u < n; c += gridDim.x) {
+        const uint32_t j = c * 256u + threadIdx.x;
+        float lo = __builtin_inff(), hi = -__builtin_inff();
+        if (j < n) { const float y = L.list[j].y; lo = y; hi = y; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+        if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+        r3dm_syncthreads();
+        if (threadIdx.x == 0) ranges[c] = make_float2(fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3])), fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])));
+        r3dm_syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256)
 void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mode)
 {
-    // killers are staged through LDS 256 at a time (one coalesced load per chunk instead of one dependent scalar load per
-    // killer and thread: the old loop was latency-bound, 0.52 ms per call on a 4000 x 3000 image); the chunks are dealt to
-    // gridDim.z workgroups, each of which only ever STORES a 1 into the (zero-initialised) flag array
     __shared__ float4 sk[256];
     __shared__ unsigned char sdead[256];
     // blockIdx.y = image * n_levels + victim level; the list lengths live on the device, so the victims are covered by a
@@ -563,21 +946,36 @@ void ak_cross_kernel(const AkLevelDev* __restrict__ levels, int n_levels, int mo
     const AkLevelDev V = levels[blockIdx.y], K = levels[(int)blockIdx.y + (ki - vi)];
     const uint32_t nv = V.counts[1], nk = K.counts[1];
     const float r = mode == 0 ? K.psize : V.psize, r2 = r * r;
+    const float2* __restrict__ vr = reinterpret_cast<const float2*>(V.live);
+    const float2* __restrict__ kr = reinterpret_cast<const float2*>(K.live);
+    const uint32_t n_kchunks = (nk + 255u) / 256u;
+    __shared__ float2 sspan[256];
     for (uint32_t q0 = blockIdx.x * 256u; q0 < nv; q0 += 256u * gridDim.x) {      // workgroup-uniform bounds
         const uint32_t q = q0 + threadIdx.x;
         const float4 v = q < nv ? V.list[q] : make_float4(0, 0, 0, 0);
+        const float2 span = vr[q0 >> 8];                                          // rows of this victim block
+        const float lo = span.x - r - 1.0f, hi = span.y + r + 1.0f;               // (one row of slack: the comparison below is exact anyway)
         bool dead = false;
-        for (uint32_t j0 = blockIdx.z * 256u; j0 < nk; j0 += 256u * gridDim.z) {
-            const uint32_t j = j0 + threadIdx.x;
-            if (j < nk) { sk[threadIdx.x] = K.list[j]; sdead[threadIdx.x] = (mode == 1 && K.dead_lower[j]) ? 1 : 0; }
+        for (uint32_t kb = 0; kb < n_kchunks; kb += 256u) {                       // the spans of 256 killer chunks at a time, through LDS
             r3dm_syncthreads();
-            const uint32_t cnt = nk - j0 < 256u ? nk - j0 : 256u;
-            for (uint32_t t = 0; t < cnt; ++t) {
-                const float4 p = sk[t];
-                const float dx = p.x - v.x, dy = p.y - v.y;
-                dead |= !sdead[t] && (dx * dx + dy * dy <= r2) && (p.z > v.z);
+            if (kb + threadIdx.x < n_kchunks) sspan[threadIdx.x] = kr[kb + threadIdx.x];
+            r3dm_syncthreads();
+            const uint32_t nb = n_kchunks - kb < 256u ? n_kchunks - kb : 256u;
+            for (uint32_t kk = blockIdx.z; kk < nb; kk += gridDim.z) {           // the killer chunks are dealt to gridDim.z workgroups (they only ever store a 1)
+                const float2 ks = sspan[kk];
+                if (ks.y < lo || ks.x > hi) continue;                             // workgroup-uniform: no killer of this chunk can reach a victim of the block
+                const uint32_t j0 = (kb + kk) * 256u, j = j0 + threadIdx.x;
+                if (j < nk) { sk[threadIdx.x] = K.list[j]; sdead[threadIdx.x] = (mode == 1 && K.dead_lower[j]) ? 1 : 0; }
+                r3dm_syncthreads();
+                const uint32_t cnt = nk - j0 < 256u ? nk - j0 : 256u;
+#pragma unroll 8
+                for (uint32_t t = 0; t < cnt; ++t) {                              // (a dependent LDS read per killer made one chunk ~16 us)
+                    const float4 p = sk[t];
+                    const float dx = p.x - v.x, dy = p.y - v.y;
+                    dead |= !sdead[t] && (dx * dx + dy * dy <= r2) && (p.z > v.z);
+                }
+                r3dm_syncthreads();
             }
-            r3dm_syncthreads();
         }
         if (q < nv && dead) (mode == 0 ? V.dead_lower : V.dead_upper)[q] = 1;
     }
@@ -610,21 +1008,34 @@ __device__ __forceinline__ float ak_fast_atan2(float y, float x)
 // sample offsets (dy, dx) of Sample_Derivative_Response_Radius6 in its loop order: i, j in [-6, 6], i*i + j*j < 36
 __device__ const signed char kRad6[109][2] = { {-5, -3}, {-5, -2}, {-5, -1}, {-5, 0}, {-5, 1}, {-5, 2}, {-5, 3}, {-4, -4}, {-4, -3}, {-4, -2}, {-4, -1}, {-4, 0}, {-4, 1}, {-4, 2}, {-4, 3}, {-4, 4}, {-3, -5}, {-3, -4}, {-3, -3}, {-3, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-3, 2}, {-3, 3}, {-3, 4}, {-3, 5}, {-2, -5}, {-2, -4}, {-2, -3}, {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2}, {-2, 3}, {-2, 4}, {-2, 5}, {-1, -5}, {-1, -4}, {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3}, {-1, 4}, {-1, 5}, {0, -5}, {0, -4}, {0, -3}, {0, -2}, {0, -1}, {0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {1, -5}, {1, -4}, {1, -3}, {1, -2}, {1, -1}, {1, 0}, {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {2, -5}, {2, -4}, {2, -3}, {2, -2}, {2, -1}, {2, 0}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {2, 5}, {3, -5}, {3, -4}, {3, -3}, {3, -2}, {3, -1}, {3, 0}, {3, 1}, {3, 2}, {3, 3}, {3, 4}, {3, 5}, {4, -4}, {4, -3}, {4, -2}, {4, -1}, {4, 0}, {4, 1}, {4, 2}, {4, 3}, {4, 4}, {5, -3}, {5, -2}, {5, -1}, {5, 0}, {5, 1}, {5, 2}, {5, 3} };
 
-// one wavefront per list entry: lanes sample and take the angles in parallel, lane 0 runs the order-sensitive parts
-// (counting sort, sliding-window sums) out of LDS.  blockIdx.y = image * n_levels + level; the list lengths live on the
-// device, so the entries of a level are covered by a grid-stride loop (gridDim.x wavefronts per level).
+// One wavefront per list entry.  blockIdx.y = image; the entries of ALL levels of the image form one flat index range
+// (prefix sums of the list lengths, which live on the device), covered by a grid-stride loop -- every wavefront gets the same
+// share whatever the distribution over the levels.  Compute_Main_Orientation's order-sensitive parts run in parallel without
+// changing a single float: the counting sort places sample i at start[key] + count[key] - 1 - #{j < i, same key} (what the
+// reference's "--slice[key]" loop produces), every lane sums ONE of the 42 sliding windows in the sorted order, and the winner
+// is the earliest window with the largest norm (the reference replaces only on a strictly larger norm).
 __global__ __launch_bounds__(64)
-void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
+void ak_refine_kernel(const AkLevelDev* __restrict__ levels, int n_levels)
 {
-    __shared__ float resX[112], resY[112], Ang[112];
-    __shared__ unsigned char sorted_idx[112], slice[48];
-    const AkLevelDev L = levels[blockIdx.y];
-    const uint32_t n_list = L.counts[1];
+    __shared__ float resX[112], resY[112];
+    const AkLevelDev* __restrict__ Lb = levels + (size_t)blockIdx.y * n_levels;
     const int lane = threadIdx.x;
-    const float* __restrict__ ldet = L.Ldet;
-    const int cols = L.w;
-    const float ratio = L.ratio;
-    for (uint32_t j = blockIdx.x; j < n_list; j += gridDim.x) {
+    uint32_t pre[17];
+    pre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pre[i + 1] = pre[i] + (i < n_levels ? Lb[i].counts[1] : 0u);
+    const uint32_t total = pre[16];
+    constexpr int slices = 42, win = 7;
+    const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
+    for (uint32_t f = blockIdx.x; f < total; f += gridDim.x) {
+        int li = 0;
+#pragma unroll
+        for (int i = 1; i < 16; ++i) li += (f >= pre[i]) ? 1 : 0;
+        const AkLevelDev L = Lb[li];
+        const uint32_t j = f - pre[li];
+        const float* __restrict__ ldet = L.Ldet;
+        const int cols = L.w;
+        const float ratio = L.ratio;
         float4 kp = L.list[j];
         bool drop = L.dead_lower[j] || L.dead_upper[j];             // wave-uniform
         float dx = 0.0f, dy = 0.0f;
@@ -654,46 +1065,57 @@ void ak_refine_kernel(const AkLevelDev* __restrict__ levels)
         const float size = L.psize * 2.0f;
         const int scale = (int)(0.5f * size / ratio + 0.5f);
         const int x0 = (int)(kp.x / ratio + 0.5f), y0 = (int)(kp.y / ratio + 0.5f);
-        for (int k = lane; k < 109; k += 64) {
-            const int i = kRad6[k][0], jj = kRad6[k][1];
+        // two samples per lane (k = lane and k = lane + 64 < 109): weighted responses and the angle slice of each
+        float rxs[2], rys[2]; int key[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = lane + 64 * q;
+            const int kk = k < 109 ? k : 0;
+            const int i = kRad6[kk][0], jj = kRad6[kk][1];
             const float wgt = kGauss25[i < 0 ? -i : i][jj < 0 ? -jj : jj];
             const size_t p = (size_t)(y0 + i * scale) * cols + (x0 + jj * scale);
-            const float rx = wgt * L.Lx[p], ry = wgt * L.Ly[p];
-            resX[k] = rx; resY[k] = ry; Ang[k] = ak_fast_atan2(ry, rx);
+            rxs[q] = wgt * L.Lx[p]; rys[q] = wgt * L.Ly[p];
+            key[q] = k < 109 ? (int)(ak_fast_atan2(rys[q], rxs[q]) / ang_step) : -1;
         }
+        // counting sort by angle slice without touching LDS: for every slice one ballot per sample row gives its population, the
+        // start of the slice (running sum) and, for the lanes holding one of its samples, the sample's slot
+        // start + count - 1 - #{earlier samples of the slice} -- what the reference's "--slice[key]" loop produces
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        uint32_t pos0 = 0, pos1 = 0, my_start = 109, running = 0;
+        for (int kk = 0; kk <= slices; ++kk) {
+            const unsigned long long b0 = __ballot(key[0] == kk), b1 = __ballot(key[1] == kk);
+            const uint32_t c0 = (uint32_t)__builtin_popcountll(b0), c1 = (uint32_t)__builtin_popcountll(b1);
+            if (key[0] == kk) pos0 = running + (c0 + c1) - 1u - (uint32_t)__builtin_popcountll(b0 & lt);
+            if (key[1] == kk) pos1 = running + (c0 + c1) - 1u - (c0 + (uint32_t)__builtin_popcountll(b1 & lt));
+            if (lane == kk) my_start = running;
+            running += c0 + c1;
+        }
+        resX[pos0] = rxs[0]; resY[pos0] = rys[0];
+        if (key[1] >= 0) { resX[pos1] = rxs[1]; resY[pos1] = rys[1]; }
         r3dm_syncthreads();
+        // window sn = lane: slices [sn, sn + win) of the circle, summed in sorted order (resX / resY are in sorted order now)
+        float sumX = 0.0f, sumY = 0.0f, nrm = -1.0f;
+        const int sn = lane;
+        const int e_lo = (int)__shfl((int)my_start, sn + win <= slices ? sn + win : slices);        // start[sn + win], or start[42] = 109 - #{key 42}
+        const int e_wrap = (int)__shfl((int)my_start, sn + win > slices ? sn + win - slices : 0);  // start[remain]
+        if (lane < slices) {
+            for (int i = (int)my_start; i < e_lo; ++i) { sumX += resX[i]; sumY += resY[i]; }
+            if (sn > slices - win) for (int i = 0; i < e_wrap; ++i) { sumX += resX[i]; sumY += resY[i]; }
+            nrm = sumX * sumX + sumY * sumY;
+        }
+        int best = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float on = __shfl_xor(nrm, off); const int ob = __shfl_xor(best, off);
+            const float ox = __shfl_xor(sumX, off), oy = __shfl_xor(sumY, off);
+            if (on > nrm || (on == nrm && ob < best)) { nrm = on; best = ob; sumX = ox; sumY = oy; }
+        }
         if (lane == 0) {
-            constexpr int slices = 42, win = 7;
-            const float ang_step = 0x1.32614ep-3f;                // (float)(2.0 * CV_PI / 42)
-            const int nkeys = (int)(0x1.921fb6p+2f / ang_step);   // (float)(2 pi) / ang_step = 42
-            for (int i = 0; i <= nkeys; ++i) slice[i] = 0;
-            for (int i = 0; i < 109; ++i) slice[(int)(Ang[i] / ang_step)]++;
-            for (int i = 1; i <= nkeys; ++i) slice[i] += slice[i - 1];
-            for (int i = 0; i < 109; ++i) sorted_idx[--slice[(int)(Ang[i] / ang_step)]] = (unsigned char)i;
-            float maxX = 0.0f, maxY = 0.0f;
-            for (int i = slice[0]; i < slice[win]; ++i) { maxX += resX[sorted_idx[i]]; maxY += resY[sorted_idx[i]]; }
-            float maxNorm = maxX * maxX + maxY * maxY;
-            for (int sn = 1; sn <= slices - win; ++sn) {
-                if (slice[sn] == slice[sn - 1] && slice[sn + win] == slice[sn + win - 1]) continue;
-                float sumX = 0.0f, sumY = 0.0f;
-                for (int i = slice[sn]; i < slice[sn + win]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-                const float nrm = sumX * sumX + sumY * sumY;
-                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
-            }
-            for (int sn = slices - win + 1; sn < slices; ++sn) {
-                const int remain = sn + win - slices;
-                if (slice[sn] == slice[sn - 1] && slice[remain] == slice[remain - 1]) continue;
-                float sumX = 0.0f, sumY = 0.0f;
-                for (int i = slice[sn]; i < slice[slices]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-                for (int i = slice[0]; i < slice[remain]; ++i) { sumX += resX[sorted_idx[i]]; sumY += resY[sorted_idx[i]]; }
-                const float nrm = sumX * sumX + sumY * sumY;
-                if (nrm > maxNorm) { maxNorm = nrm; maxX = sumX; maxY = sumY; }
-            }
             L.out0[j] = make_float4(kp.x, kp.y, size, kp.z);
-            L.out1[j] = make_float2(maxX, maxY);
+            L.out1[j] = make_float2(sumX, sumY);
             L.out_valid[j] = 1;
         }
-        r3dm_syncthreads();                                       // the next entry overwrites resX / resY / Ang
+        r3dm_syncthreads();                                       // the next entry overwrites the LDS arrays
     }
 }
 
@@ -815,10 +1237,16 @@ hipError_t ak_mldb(hipStream_t st, const AkLevelDev* levels, const AkMldbItem* i
 }
 
 static dim3 ak_grid(int w, int h, int B) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)B); }
+// strip kernels: a workgroup owns 64 x (4 R) pixels (R rows per wave)
+static dim3 ak_strip_grid(int w, int h, int B, int R) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 4 * R - 1) / (4 * R)), (unsigned)B); }
 
 // every launcher: B = images of the batch (same size), buffers hold B planes of the launch's w x h back to back
 hipError_t ak_gaussian(hipStream_t st, const float* src, float* tmp, float* dst, int w, int h, int B, const AkTaps& kf)
 {
+    if (kf.n == 5 || kf.n == 9) {
+        hipLaunchKernelGGL(ak_gauss_kernel, ak_strip_grid(w, h, B, 4), dim3(256), 0, st, src, dst, w, h, kf);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(ak_gauss_rows_kernel, ak_grid(w, h, B), dim3(256), 0, st, src, tmp, w, h, kf);
     hipLaunchKernelGGL(ak_gauss_cols_kernel, ak_grid(w, h, B), dim3(256), 0, st, tmp, dst, w, h, kf);
     return hipGetLastError();
@@ -831,24 +1259,28 @@ hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, flo
 }
 hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int B, int s)
 {
-    hipLaunchKernelGGL(ak_sderiv_xy_kernel, ak_grid(w, h, B), dim3(256), 0, st, src, dst_x, dst_y, w, h, s);
+    hipLaunchKernelGGL(ak_sderiv_xy_kernel, ak_strip_grid(w, h, B, 4), dim3(256), 0, st, src, dst_x, dst_y, w, h, s);
     return hipGetLastError();
 }
-hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int B, int s)
+hipError_t ak_scaled_deriv_det(hipStream_t st, const float* lx, const float* ly, float* ldet, int w, int h, int B, int s)
 {
-    hipLaunchKernelGGL(ak_sderiv_det_kernel, ak_grid(w, h, B), dim3(256), 0, st, ly, lxx, lxy, ldet, w, h, s);
+    hipLaunchKernelGGL(ak_sderiv_det_kernel, ak_strip_grid(w, h, B, 2), dim3(256), 0, st, lx, ly, ldet, w, h, s);
     return hipGetLastError();
 }
-hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, uint32_t* out_max)
+// src = the smoothed image (Gaussian 1.0 of the input); both kernels cover the interior [1, w-2] x [1, h-2] in 64 x 16 tiles
+hipError_t ak_modg_max(hipStream_t st, const float* src, int w, int h, int B, uint32_t* out_max)
 {
-    const int rows = h - 2 < 1024 ? (h - 2 < 1 ? 1 : h - 2) : 1024;
-    hipLaunchKernelGGL(ak_modg_max_kernel, dim3((unsigned)rows, 1, (unsigned)B), dim3(256), 0, st, Lx, Ly, w, h, out_max);
+    if (w < 3 || h < 3) return hipSuccess;
+    const int tiles_y = (h - 2 + 15) / 16;
+    hipLaunchKernelGGL(ak_modg_max_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)std::min(tiles_y, 24), (unsigned)B), dim3(256), 0, st, src, w, h, out_max);
     return hipGetLastError();
 }
-hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist)
+hipError_t ak_modg_hist(hipStream_t st, const float* src, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist)
 {
     if (nbins > 512) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)((h - 2 + 63) / 64), (unsigned)B), dim3(256), 0, st, Lx, Ly, w, h, hmax_bits, nbins, hist);
+    if (w < 3 || h < 3) return hipSuccess;
+    const int tiles_y = (h - 2 + 15) / 16;
+    hipLaunchKernelGGL(ak_modg_hist_kernel, dim3((unsigned)((w - 2 + 63) / 64), (unsigned)std::min(tiles_y, 24), (unsigned)B), dim3(256), 0, st, src, w, h, hmax_bits, nbins, hist);
     return hipGetLastError();
 }
 hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2, int B)
@@ -858,12 +1290,22 @@ hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_
 }
 hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, int B, const float* inv_k2)
 {
-    hipLaunchKernelGGL(ak_scharr_g2_kernel, ak_grid(w, h, B), dim3(256), 0, st, src, dst, w, h, inv_k2);
+    hipLaunchKernelGGL(ak_scharr_g2_kernel, ak_strip_grid(w, h, B, 4), dim3(256), 0, st, src, dst, w, h, inv_k2);
     return hipGetLastError();
 }
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, float step_size)
 {
-    hipLaunchKernelGGL(ak_fed_step_kernel, ak_grid(w, h, B), dim3(256), 0, st, Lt, Lf, out, w, h, step_size);
+    hipLaunchKernelGGL(ak_fed_step_kernel, ak_strip_grid(w, h, B, 4), dim3(256), 0, st, Lt, Lf, out, w, h, step_size);
+    return hipGetLastError();
+}
+// n_steps <= 4 FED steps tau[0..n) in one launch (small levels: see ak_fed_multi_kernel)
+hipError_t ak_fed_multi(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps)
+{
+    if (n_steps < 1 || n_steps > 4) return hipErrorInvalidValue;
+    AkFedSteps fs{};
+    for (int k = 0; k < n_steps; ++k) fs.tau[k] = tau[k];
+    fs.n = n_steps;
+    hipLaunchKernelGGL(ak_fed_multi_kernel, dim3((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32), (unsigned)B), dim3(256), 0, st, Lt, Lf, out, w, h, fs);
     return hipGetLastError();
 }
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,
@@ -878,7 +1320,16 @@ hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, in
 hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int max_rows, float thr, int pass)
 {
     if (max_rows <= 0 || n_levels <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ak_extrema_kernel, dim3((unsigned)max_rows, (unsigned)n_levels, (unsigned)B), dim3(256), 0, st, levels, thr, pass);
+    const dim3 grid((unsigned)((max_rows + 3) / 4), (unsigned)n_levels, (unsigned)B);
+    if (pass == 0) return hipErrorInvalidValue;          // the count pass is ak_extrema_mask (it needs the tile table)
+    hipLaunchKernelGGL(ak_extrema_emit_kernel, grid, dim3(256), 0, st, levels);
+    return hipGetLastError();
+}
+hipError_t ak_extrema_mask(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, const AkTileTable& tt, uint32_t n_tiles, float thr)
+{
+    if (n_tiles == 0 || n_levels <= 0) return hipSuccess;
+    if (n_levels > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ak_extrema_mask_kernel, dim3(n_tiles, (unsigned)B), dim3(256), 0, st, levels, n_levels, tt, thr);
     return hipGetLastError();
 }
 hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels, int B)
@@ -898,17 +1349,23 @@ hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_level
     hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)(n_levels * B)), dim3(64), 0, st, levels, live_cap);
     return hipGetLastError();
 }
+hipError_t ak_list_ranges(hipStream_t st, const AkLevelDev* levels, int n_levels, int B)
+{
+    hipLaunchKernelGGL(ak_list_ranges_kernel, dim3(64, (unsigned)(n_levels * B)), dim3(256), 0, st, levels);
+    return hipGetLastError();
+}
 hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int mode)
 {
-    // 16 x 256 victims per pass of the grid-stride loop, the killers of a victim chunk dealt to 8 workgroups
-    hipLaunchKernelGGL(ak_cross_kernel, dim3(16, (unsigned)(n_levels * B), 8), dim3(256), 0, st, levels, n_levels, mode);
+    // 128 x 256 victims per pass of the grid-stride loop (ak_list_ranges must have run on the pruned lists)
+    hipLaunchKernelGGL(ak_cross_kernel, dim3(128, (unsigned)(n_levels * B), 4), dim3(256), 0, st, levels, n_levels, mode);
     return hipGetLastError();
 }
 hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, int B)
 {
-    // gridDim.x wavefronts share the entries of a level: enough to fill the chip when one level holds most of the list
-    const unsigned per_level = (unsigned)std::max(64, 4096 / (n_levels * B));
-    hipLaunchKernelGGL(ak_refine_kernel, dim3(per_level, (unsigned)(n_levels * B)), dim3(64), 0, st, levels);
+    if (n_levels > 16) return hipErrorInvalidValue;
+    // gridDim.x wavefronts share the flat entry range of an image
+    const unsigned per_image = (unsigned)std::max(256, 8192 / B);
+    hipLaunchKernelGGL(ak_refine_kernel, dim3(per_image, (unsigned)B), dim3(64), 0, st, levels, n_levels);
     return hipGetLastError();
 }
 hipError_t ak_compact(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, AkKpRec* recs, uint32_t cap, AkBatchMeta* meta)

@@ -210,6 +210,7 @@ struct AkLevelDev {
     float ratio, psize;                                  // octave ratio; keypoint size before the final doubling (esigma * 1.5)
     const float* Ldet; const float* Lx; const float* Ly; const float* Lt;
     uint32_t* row_cnt; uint32_t* row_off;                // [h - 2 border] extrema per image row / exclusive scan
+    unsigned long long* mask; uint32_t mask_words;       // [h - 2 border][mask_words] one bit per interior pixel: is a scale-space extremum (64-pixel ballots)
     uint32_t* counts;                                    // [0] candidates, [1] list entries after the in-level pruning
     float4* cand;                                        // raster-ordered candidates (x, y, response, -)
     float4* list;                                        // kept points (x, y, response, -), in insertion order
@@ -231,16 +232,20 @@ hipError_t ak_scharr(hipStream_t st, const float* src, float* rd, float* rs, flo
 hipError_t ak_scharr_g2(hipStream_t st, const float* src, float* dst, int w, int h, int B, const float* inv_k2);
 hipError_t ak_kcontrast(hipStream_t st, const uint32_t* hmax_bits, const uint32_t* hist, int nbins, uint32_t total, int have_hist, float* inv_k2, int B);
 hipError_t ak_scaled_deriv_xy(hipStream_t st, const float* src, float* dst_x, float* dst_y, int w, int h, int B, int s);
-hipError_t ak_scaled_deriv_det(hipStream_t st, const float* ly, const float* lxx, const float* lxy, float* ldet, int w, int h, int B, int s);
-hipError_t ak_modg_max(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, uint32_t* out_max);
-hipError_t ak_modg_hist(hipStream_t st, const float* Lx, const float* Ly, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
+hipError_t ak_scaled_deriv_det(hipStream_t st, const float* lx, const float* ly, float* ldet, int w, int h, int B, int s);
+hipError_t ak_modg_max(hipStream_t st, const float* src, int w, int h, int B, uint32_t* out_max);
+hipError_t ak_modg_hist(hipStream_t st, const float* src, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, float step_size);
+hipError_t ak_fed_multi(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps);
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);
 hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int max_rows, float thr, int pass);
+struct AkTileTable { uint32_t begin[17]; };            // first tile of every level in the extremum count pass (0xFFFFFFFF beyond the last level)
+hipError_t ak_extrema_mask(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, const AkTileTable& tt, uint32_t n_tiles, float thr);
 hipError_t ak_scan_rows(hipStream_t st, const AkLevelDev* levels, int n_levels, int B);
 hipError_t ak_layout(hipStream_t st, AkLevelDev* levels, int n_levels, int B, unsigned char* slots, uint32_t cap, AkBatchMeta* meta);
 hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_levels, int B);
+hipError_t ak_list_ranges(hipStream_t st, const AkLevelDev* levels, int n_levels, int B);
 hipError_t ak_cross(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int mode);
 hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, int B);
 hipError_t ak_compact(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, AkKpRec* recs, uint32_t cap, AkBatchMeta* meta);

@@ -251,7 +251,7 @@ def _texture(hh: int, ww: int, seed: int, device):
 
     g = torch.Generator(device=device); g.manual_seed(seed)
     img = torch.full((1, 1, hh, ww), 0.5, device=device)
-    for cell, amp in ((192, 0.10), (96, 0.10), (48, 0.09), (24, 0.08), (12, 0.07), (6, 0.06), (3, 0.03)):
+    for cell, amp in ((192, 0.11), (96, 0.10), (48, 0.09), (24, 0.075), (12, 0.055), (6, 0.035), (3, 0.012)):     # ~22 k A-KAZE keypoints per 12 Mpx at threshold 0.001
         gh, gw = hh // cell + 3, ww // cell + 3
         n = torch.randn((1, 1, gh, gw), generator=g, device=device)
         up = F.interpolate(n, size=(gh * cell, gw * cell), mode="bicubic", align_corners=False)

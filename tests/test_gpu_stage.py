@@ -35,7 +35,7 @@ def test_batch_detector_equals_the_cpu_restatement_per_image(ctx, oracle):
     for b, (kps, resp) in enumerate(res):
         ref = oracle.akaze_detect(ims[b], 0.001)
         assert np.array_equal(kps, ref["kps"]) and np.array_equal(resp, ref["responses"]), b
-    assert len(res[2][0]) == 0 and len(res[0][0]) > 500
+    assert len(res[2][0]) == 0 and len(res[0][0]) > 150
     # the single-image entry is the batch of one; a smaller batch after a larger one reuses the buffers (plane stride = the image's own size)
     k1, r1 = ctx.detect_akaze(ims[1], 0.001)
     assert np.array_equal(k1, res[1][0]) and np.array_equal(r1, res[1][1])
@@ -72,7 +72,7 @@ def test_features_batch_writes_the_files_of_the_single_work_item(ctx, tmp_path):
     one = tmp_path / "one"; bat = tmp_path / "bat"; bgrd = tmp_path / "bgr"; one.mkdir(); bat.mkdir(); bgrd.mkdir()
     n1 = [ctx.extract_features_to_files(im, str(one / f"v{k}.feat"), str(one / f"v{k}.desc"), 0.001) for k, im in enumerate(ims)]
     nb = ctx.extract_features_batch(ims, [str(bat / f"v{k}.feat") for k in range(4)], [str(bat / f"v{k}.desc") for k in range(4)], 0.001)
-    assert nb.tolist() == n1 and min(n1) > 300
+    assert nb.tolist() == n1 and min(n1) > 150
     for k in range(4):
         for ext in ("feat", "desc"):
             assert open(str(bat / f"v{k}.{ext}"), "rb").read() == open(str(one / f"v{k}.{ext}"), "rb").read(), (k, ext)
@@ -83,7 +83,7 @@ def test_features_batch_writes_the_files_of_the_single_work_item(ctx, tmp_path):
     ng = ctx.extract_features_batch(bgr, [str(bgrd / f"b{k}.feat") for k in range(3)], [str(bgrd / f"b{k}.desc") for k in range(3)], 0.001, bgr=True)
     for k in range(3):
         n = ctx.extract_features_to_files(grays[k], str(bgrd / f"g{k}.feat"), str(bgrd / f"g{k}.desc"), 0.001)
-        assert n == ng[k] > 300
+        assert n == ng[k] > 150
         for ext in ("feat", "desc"):
             assert open(str(bgrd / f"b{k}.{ext}"), "rb").read() == open(str(bgrd / f"g{k}.{ext}"), "rb").read()
     # the list entry with mixed sizes and kinds, two contexts, batches of 3
@@ -120,11 +120,11 @@ def _oracle_stage(oracle, ims, K, dist_ratio=0.6):
 def _check_filter(oracle, path, pairs, oc, om):
     p, c, m = oracle.load_matches(path)
     assert np.array_equal(p, pairs[oc > 0]) and np.array_equal(c, oc[oc > 0])
-    off = 0; ooff = np.concatenate([[0], np.cumsum(oc)])
+    off = 0; ooff = np.concatenate([[0], np.cumsum(np.asarray(oc, np.int64))]).astype(np.int64)
     for k, cnt in enumerate(c):
         seg = m[off:off + cnt]; off += cnt
         q = int(np.flatnonzero(oc > 0)[k])
-        exp = om[ooff[q]:ooff[q] + cnt]
+        exp = om[int(ooff[q]):int(ooff[q]) + int(cnt)]
         assert set(map(tuple, seg.tolist())) == set(map(tuple, exp.tolist())), (path, k)
     return int((oc > 0).sum())
 

@@ -7,6 +7,8 @@ import numpy as np
 import torch
 torch.cuda.init()          # before the library: torch's HIP runtime has to come up first in a process that uses both
 from regard3d_amd import api, synth
+if any(k.startswith("R3DM_") for k in os.environ):
+    api.use_developer_library()          # developer knobs (R3DM_*) only exist in libr3dm_dev.so
 
 h, w = 3000, 4000
 NIMG = int(os.environ.get("AK_IMAGES", "16"))
@@ -15,7 +17,7 @@ dimgs = [torch.from_numpy(im).cuda() for im in imgs]
 torch.cuda.synchronize()
 c = api.Context(0)
 for thr in (0.001,):
-    for B in (1, 2, 4, 8):
+    for B in [int(x) for x in os.environ.get("AK_BATCHES", "1,2,4,8").split(",")]:
         if B > len(dimgs): break
         for rep in range(3):
             t = time.time(); res = c.detect_akaze_batch(dimgs[:B], thr); dt = time.time() - t
@@ -26,6 +28,8 @@ for thr in (0.001,):
     t = time.time(); kps, resp = c.detect_akaze(imgs[0], thr); dt = time.time() - t
     t = time.time(); desc = c.extract_liop(imgs[0], kps, 8.0); dl = time.time() - t
     print(json.dumps(dict(single_image_from_host=True, keypoints=len(kps), s_detect=dt, s_liop=dl)), flush=True)
+if os.environ.get("AK_STAGE", "1") == "0":
+    sys.exit(0)
 # the features stage over an image list (files to /tmp); every context has seen the image size once before the timed pass
 import tempfile, shutil
 

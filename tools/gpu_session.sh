@@ -12,6 +12,7 @@
 #   akaze                           tools/akaze_perf.py (+ kernel stats)              -> <tag>_akaze_perf.txt + _akaze_kernel_stats.txt
 #   tool:<script.py>[:<args>]       python tools/<script.py> <args>                   -> <tag>_<script>.txt
 #   proftool:<script.py>[:<args>]   the same under rocprofv3 --kernel-trace --stats    -> <tag>_<script>.txt + _<script>_kernel_stats.txt
+#   gridtrace:<script.py>[:<args>] rocprofv3 --kernel-trace CSV of python tools/<script.py>, durations bucketed by (kernel, grid)
 #   pmc:<counters>:<config>[:<extra args>]   separate rocprofv3 --pmc passes (one per comma-separated counter, --kernel-trace only)
 #                                                                                        -> <tag>_pmc_<config>.txt
 # Every step runs under its own `timeout`; nothing here kills by pattern.
@@ -50,6 +51,18 @@ for step in "$@"; do
       n=$(basename $a1 .py); rm -rf /tmp/prof_$n
       timeout ${TOOL_TIMEOUT:-900} rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -- python tools/$a1 $a2 2>&1 | grep -v "^W\|rocprofv3" | tail -${TOOL_TAIL:-40} | cut -c1-400 | tee gpurun_out/${T}_$n.txt
       stats /tmp/prof_$n gpurun_out/${T}_${n}_kernel_stats.txt ;;
+    gridtrace)   # gridtrace:<script.py>[:<args>]: per-launch durations by (kernel, grid) -> <tag>_<script>_by_grid.txt
+      n=$(basename $a1 .py); rm -rf /tmp/tr_$n
+      timeout ${TOOL_TIMEOUT:-900} rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_$n -- python tools/$a1 $a2 > /tmp/tr_$n.log 2>&1
+      grep "^{" /tmp/tr_$n.log | cut -c1-300
+      python tools/trace_by_grid.py /tmp/tr_$n "r3dm::" ${GRID_MIN_US:-100} | tee gpurun_out/${T}_${n}_by_grid.txt | head -${GRID_HEAD:-70} ;;
+    pmctool)   # pmctool:<group+group+...>:<script.py>[:<args>]: one rocprofv3 --pmc pass per group (counters of a group comma-separated)
+      n=$(basename $a2 .py)
+      for grp in ${a1//+/ }; do
+        rm -rf /tmp/pmt_$n
+        timeout ${TOOL_TIMEOUT:-600} rocprofv3 --pmc ${grp//,/ } --kernel-trace --output-format csv -d /tmp/pmt_$n -- python tools/$a2 $a3 > /tmp/pmt_$n.log 2>&1
+        echo "## pass: ${grp//,/ } (rc=$?)"; python tools/pmc_summary.py /tmp/pmt_$n ${PMC_BY_GRID:+--by-grid} 2>&1 | grep -E "${PMC_FILTER:-r3dm}" | head -${PMC_HEAD:-12}
+      done | tee gpurun_out/${T}_pmc_$n.txt ;;
     pmc)
       for ctr in ${a1//,/ }; do
         rm -rf /tmp/pmc_$ctr
