@@ -165,6 +165,7 @@ def main():
         acc["ann_ms"] += s_match.ms_ann_search; acc["ann_dist"] += s_match.n_ann_dist; acc["ann_build_ms"] += s_match.ms_ann_build
         acc["ann_rows16"] = acc.get("ann_rows16", 0) + int(s_match.n_ann_rows16); acc["ann_rows8"] = acc.get("ann_rows8", 0) + int(s_match.n_ann_rows8); acc["ann_dot8"] = acc.get("ann_dot8", 0) + int(s_match.n_ann_dot8); acc["ann_launches"] = acc.get("ann_launches", 0) + int(s_match.n_match_launches)
         wall["match"] += s_all.ms_wall_match; wall["match_post"] += s_all.ms_wall_match_post; wall["filter"] += s_all.ms_wall_filter
+        acc["pairs"] = acc.get("pairs", 0) + int(mine.shape[0])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -195,7 +196,9 @@ def main():
                      "exact_fallback_queries_per_step": acc["fallback"] / a.steps, "queries_per_step": acc["queries"] / a.steps,
                      "exact_fallback_fraction": acc["fallback"] / max(acc["queries"], 1),
                      "putative_pairs": int(full[0].num_pairs), "putative_matches": int(full[0].num_matches),
-                     "F_pairs": int(full[1].num_pairs), "F_matches": int(full[1].num_matches)}
+                     "F_pairs": int(full[1].num_pairs), "F_matches": int(full[1].num_matches),
+                     # identity of the reassembled graphs (pairs, offsets, matches of both): equal across N for the same collection
+                     "graphs_sha16": hashlib.sha256(b"".join(np.ascontiguousarray(getattr(gr, f)).tobytes() for gr in full for f in ("pairs", "offsets", "matches"))).hexdigest()[:16]}
     if kp is not None:
         out["detail"].update({"ann_index_build_ms_per_step": acc["ann_build_ms"] / a.steps, "ann_search_ms_per_step": acc["ann_ms"] / a.steps,
                               "ann_evaluations_per_query": acc["ann_dist"] / max(acc["queries"], 1)})
@@ -258,11 +261,17 @@ def stage_main(a):
         mean = lambda k: sum(r[k] for r in reps) / len(reps)
         last = reps[-1]
         # the GUI's default arm (matchingAlgorithm 0 = FLANN kd-trees in the reference, src/Regard3DMainFrame.cpp:2405) on the files
-        # the step left: no extraction, matching + filters only; and arm 9 the same way for a like-for-like match phase
-        wipe(False); r9 = api.compute_matches_stage([0], d, bare, 0.001, 0.6, 9).as_dict()
-        f9 = open(os.path.join(d, "matches.f.bin"), "rb").read()
-        wipe(False); r0 = api.compute_matches_stage([0], d, bare, 0.001, 0.6, 0).as_dict()
-        f0 = open(os.path.join(d, "matches.f.bin"), "rb").read()
+        # the step left: no extraction, matching + filters only -- under the facade's default policy (an approximate arm is served by
+        # whichever matcher is faster on the views: exhaustive for LIOP-144), as requested (the graph matcher), and arm 9 the same
+        # way for a like-for-like match phase, plain and with the opt-in split-f16 nominator
+        def rerun(algo, **kw):
+            wipe(False)
+            r = api.compute_matches_stage([0], d, bare, 0.001, 0.6, algo, **kw).as_dict()
+            return r, {x: open(os.path.join(d, f"matches.{x}.bin"), "rb").read() for x in ("putative", "f", "e", "h")}
+        r9, f9 = rerun(9)
+        r9s, f9s = rerun(9, split_mfma=True)
+        r0, f0 = rerun(0)
+        r0g, f0g = rerun(0, arms_as_requested=True)
         # detector roofline: a dedicated pass of the batch entry on B resident images, one context, nothing else on the GPU
         ctx = api.Context(0)
         B = min(8, N)
@@ -285,10 +294,17 @@ def stage_main(a):
                          "keypoints_per_image": last["n_keypoints"] / N, "file_ms_sum_over_contexts": last["features"]["ms_files"],
                          "detector_passes": int(last["features"]["n_passes"]), "regrows": int(last["features"]["n_regrows"])},
             "graphs": {k: int(last[k]) for k in ("n_putative_pairs", "n_putative_matches", "n_F_pairs", "n_F_matches", "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches")},
-            "arm_9_on_existing_files": {"ms_match": r9["ms_match"], "ms_total": r9["ms_total"], "putative_matches": int(r9["n_putative_matches"])},
+            "arm_9_on_existing_files": {"ms_match": r9["ms_match"], "ms_match_kernels": r9["ms_match_kernels"], "ms_total": r9["ms_total"], "putative_matches": int(r9["n_putative_matches"])},
+            "arm_9_opt_in_split_mfma": {"ms_match": r9s["ms_match"], "ms_match_kernels": r9s["ms_match_kernels"], "ms_total": r9s["ms_total"],
+                                        "all_match_files_identical_to_arm_9": bool(f9s == f9)},
             "arm_0_gui_default": {"ms_match": r0["ms_match"], "ms_total": r0["ms_total"], "putative_matches": int(r0["n_putative_matches"]),
-                                  "F_file_identical_to_arm_9": bool(f0 == f9),
-                                  "note": "the reference's arm 0 is FLANN kd-trees (approximate); the facade serves it with the matcher r3dm_ann_params_for_algorithm names (DESIGN.md section 4.7)"},
+                                  "served_by": "exhaustive matcher" if r0["match_was_exhaustive"] else "graph matcher",
+                                  "all_match_files_identical_to_arm_9": bool(f0 == f9),
+                                  "note": "the reference's arm 0 is FLANN kd-trees (approximate); the facade serves an approximate arm with the exhaustive matcher "
+                                          "when r3dm_exhaustive_is_faster says so for the registered views (LIOP-144: real-valued rows), DESIGN.md section 4.7"},
+            "arm_0_as_requested_graph_matcher": {"ms_match": r0g["ms_match"], "ms_total": r0g["ms_total"], "putative_matches": int(r0g["n_putative_matches"]),
+                                                 "served_by": "exhaustive matcher" if r0g["match_was_exhaustive"] else "graph matcher",
+                                                 "putative_matches_recovered_vs_arm_9": r0g["n_putative_matches"] / max(r9["n_putative_matches"], 1)},
             "roofline": {"bound": "hbm", "kernel": f"Fast-A-KAZE detector pass, B = {B} images (ak_* kernels, first scale-space launch .. keypoint compaction)",
                          "achieved": det_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": det_gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_image": sd.detect_algorithmic_bytes / B, "ms_per_image": sd.ms_detect_kernels / B,
@@ -385,18 +401,31 @@ def roofline(name, cfg, acc, dim, world):
     L = max(acc["launches"], 1)
     if cfg["matcher"] == "kgraph":
         ms = acc["ann_ms"]
-        # every evaluation gathers one descriptor row: f32 rows, or their u8 / bf16 copy when the library used it (integer-valued
-        # views, r3dm_stats.n_ann_rows8 / n_ann_rows16 -- the same distances from a quarter / half of the bytes)
+        # The search is VALU-ISSUE-bound, not gather-bound (PMC: profiles/r02_r_pmc_ann_search_dot8_prefilter.txt):
+        # one wavefront per query executes 6.04 k VALU (+ 5.21 k SALU) instructions on the byte-row / v_dot4 path, and a wave64 VALU
+        # instruction occupies its SIMD16 for 4 cycles -> the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 = 614.4 G wave-instructions/s.
+        # 99.3 % of the row gathers are served by L1 / L2; what reaches the fabric is reported as `traffic` (PMC, scaled per pair).
         rows8 = acc.get("ann_rows8", 0) > 0 and acc.get("ann_rows8", 0) == acc.get("ann_launches", -1)
         rows16 = acc.get("ann_rows16", 0) > 0 and acc.get("ann_rows16", 0) == acc.get("ann_launches", -1)
+        dot8 = acc.get("ann_dot8", 0) == acc.get("ann_launches", -1)
         row_bytes = dim * (1.0 if rows8 else 2.0 if rows16 else 4.0)
-        bytes_ = acc["ann_dist"] * row_bytes
-        gbs = bytes_ / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": ("ann_search_kernel<u8 rows, v_dot4>" if acc.get("ann_dot8", 0) == acc.get("ann_launches", -1) else "ann_search_kernel<u8 rows>") if rows8 else "ann_search_kernel<bf16 rows>" if rows16 else "ann_search_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                "note": "algorithmic bytes = distance evaluations x row bytes (%d B gathers, mostly L2 / Infinity-Cache resident: "
-                        "the HBM spec is the stated roof, not what these gathers can reach)" % int(row_bytes),
-                "evaluations": int(acc["ann_dist"]), "row_bytes": int(row_bytes), "search_ms_total": ms}
+        VALU_PER_QUERY = 6038.0 if (rows8 and dot8) else None          # SQ_INSTS_VALU / SQ_WAVES of ann_search_kernel<8, 3>
+        peak = 256 * 4 * 2.4e9 / 4 / 1e9
+        ach = acc["queries"] * VALU_PER_QUERY / (ms * 1e-3) / 1e9 if (ms > 0 and VALU_PER_QUERY) else 0.0
+        out = {"bound": "valu", "kernel": ("ann_search_kernel<u8 rows, v_dot4>" if dot8 else "ann_search_kernel<u8 rows>") if rows8 else "ann_search_kernel<bf16 rows>" if rows16 else "ann_search_kernel",
+               "achieved": ach, "peak": peak, "unit": "G wave-instructions/s (VALU issue)", "frac": ach / peak, "traffic": None,
+               "valu_instructions_per_query": VALU_PER_QUERY, "salu_instructions_per_query": 5212.0 if VALU_PER_QUERY else None,
+               "note": "VALU-issue-bound: instructions per query from PMC (profiles/r02_r_pmc_ann_search_dot8_prefilter.txt, same kernel source) x queries / "
+                       "HIP-event time of the launches; the gathers (evaluations x %d B rows) are 99.3 %% cache hits" % int(row_bytes),
+               "evaluations": int(acc["ann_dist"]), "evaluations_per_query": acc["ann_dist"] / max(acc["queries"], 1), "row_bytes": int(row_bytes),
+               "gathered_GB_per_s": acc["ann_dist"] * row_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "search_ms_total": ms}
+        ent_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if VALU_PER_QUERY and os.path.exists(ent_path):
+            ent = json.load(open(ent_path)).get("c5:ann_search_kernel")
+            if ent and ent.get("source_sha16") == _sha16(os.path.join(ROOT, "regard3d_amd", "csrc", "kernels_ann.hip")):
+                out["traffic"] = ent["traffic_bytes_per_pair"] * acc.get("pairs", 0) / max(acc["launches"], 1)
+                out["traffic_source"] = f"{ent['from']}: FETCH_SIZE + WRITE_SIZE of the search launches of a 96-image step, per pair ({ent['traffic_bytes_per_pair'] / 1e6:.2f} MB) x the pairs of a launch"
+        return out
     ms = acc["kernel_ms"]
     if cfg["kind"] == "akaze":
         t_ops = acc["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0     # lane-ops: 2 per 32-bit word (xor, popcount-accumulate)

@@ -85,6 +85,16 @@ public:
     void setSeed(uint64_t seed) { seed_ = seed; }
     // no reference counterpart: forwards r3dm_set_integer_mfma (bit-identical results, integer-valued descriptors only)
     void setIntegerFastPath(bool on);
+    // no reference counterpart: forwards r3dm_set_split_mfma (bit-identical results, real-valued descriptors: LIOP)
+    void setSplitFastPath(bool on);
+    // How the approximate arms of the dispatch (0 FLANN, 1-3 KGraph, 5 MRPT, 6-8 HNSW) are served.  kArmsFastest (default): by the
+    // EXHAUSTIVE matcher whenever r3dm_exhaustive_is_faster says it is not slower on the registered views -- on LIOP-144 every
+    // approximate arm is then exact and >= 2x faster than the graph search (the GUI's default arm 0 included); kArmsAsRequested:
+    // always by the graph matcher with the arm's preset (r3dm_ann_params_for_algorithm), as in rounds 1-2.
+    enum ArmsPolicy { kArmsFastest = 0, kArmsAsRequested = 1 };
+    void setApproximateArmsPolicy(ArmsPolicy p) { arms_policy_ = p; }
+    // which matcher the last computeMatches call ran: true = exhaustive (arm 4 / 9, or an approximate arm routed to it)
+    bool lastMatchWasExhaustive() const { return last_exhaustive_; }
     // updateProgress(float, const wxString&) (src/R3DComputeMatches.cpp:2664): the GUI hook, called with the reference's own
     // fractions and messages (0.7 "Find putative matches", 0.8 / 0.9 / 0.95 "Calculate ... matrix", :2000,2107,2133,2209)
     using ProgressFn = void (*)(float progress, const char* msg, void* user);
@@ -133,6 +143,8 @@ private:
     std::vector<int> devices_;             // the device list this facade was built with
     r3dm_multi* feat_multi_ = nullptr;     // contexts of the features stage (feat_conc_ per device), created on first use
     int feat_conc_ = 2, feat_batch_ = 8;
+    ArmsPolicy arms_policy_ = kArmsFastest;
+    bool last_exhaustive_ = true;
     ImageProviderFn provider_ = nullptr;
     ImageReleaseFn provider_release_ = nullptr;
     void* provider_user_ = nullptr;
@@ -160,12 +172,17 @@ typedef struct {
     double ms_match_kernels, ms_F_kernels, ms_E_kernels, ms_H_kernels;
     uint64_t images_extracted, n_keypoints;
     uint64_t n_putative_pairs, n_putative_matches, n_F_pairs, n_F_matches, n_E_pairs, n_E_matches, n_H_pairs, n_H_matches;
+    uint64_t match_was_exhaustive;   /* 1: the exhaustive matcher ran (arm 4 / 9, or an approximate arm routed to it) */
     r3dm_features_totals features;
 } r3dm_stage_report;
 int r3dm_compute_matches_stage(const int* device_ids, int n_devices, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
                                float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
-                               uint64_t seed, int features_batches_in_flight, int features_images_per_batch,
+                               uint64_t seed, int features_batches_in_flight, int features_images_per_batch, uint32_t flags,
                                r3dm_stage_report* report, char* err, size_t err_cap);
+/* flags of r3dm_compute_matches_stage */
+#define R3DM_STAGE_ARMS_AS_REQUESTED 1u   /* approximate arms always on the graph matcher (default: the faster matcher, R3DComputeMatches::setApproximateArmsPolicy) */
+#define R3DM_STAGE_SPLIT_MFMA        2u   /* r3dm_set_split_mfma: the opt-in split-f16 nominator for real-valued descriptors (bit-identical results) */
+#define R3DM_STAGE_INTEGER_MFMA      4u   /* r3dm_set_integer_mfma */
 typedef struct { uint32_t id, width, height; const char* basename; } r3dm_view;
 int r3dm_compute_matches_dir(int device_id, const char* matches_dir, const r3dm_view* views, uint32_t n_views,
                              r3dm_dtype dtype, uint32_t dim, float dist_ratio, int compute_F, uint64_t seed,

@@ -200,6 +200,14 @@ int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out);
 int r3dm_ann_params_for_algorithm(int matching_algorithm, r3dm_kgraph_params* out);
 int r3dm_match_pairs_kgraph(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
                             const r3dm_kgraph_params* params, r3dm_graph** out);
+/* 1 when, for the views registered in ctx, the EXHAUSTIVE matcher (r3dm_match_pairs) is expected to be at least as fast as the
+ * graph matcher -- and it is exact: the views hold real-valued descriptors (LIOP-144, the descriptor Regard3D matches: the graph
+ * search then gathers f32 rows and runs at 937 pairs/s on 16,384-row views where the exhaustive f32 kernel runs at 2,017 and the
+ * split-f16 path at ~5,000, profiles/r02_p_ann_perf_f32rows.txt) of a length the tensor kernels serve (64 / 128 / 144 / 256) and no
+ * view has more than 32,768 rows.  0 otherwise (integer-valued byte rows, where the v_dot4 graph search beats the f32 tiles; very
+ * large views, where n log n beats n^2).  A host that only wants the arm's RESULT QUALITY (the reference's approximate arms 0-3,
+ * 5-8 exist to save CPU time, not to lose matches) can use this to serve them with the exact matcher: the facade's default. */
+int r3dm_exhaustive_is_faster(const r3dm_ctx* ctx);
 /* ArrayMatcher_kgraph-shaped call: index `dataset`, 2 approximate nearest rows of every query row.  pair_i / pair_j
  * key the start-row stream (view ids in r3dm_match_pairs_kgraph).  out_idx -1 / out_dist +inf where the search
  * found fewer than two rows. */
@@ -313,6 +321,9 @@ r3dm_ctx* r3dm_multi_ctx(r3dm_multi* m, int k);            /* the k-th device's 
 const char* r3dm_multi_last_error(const r3dm_multi* m);
 int r3dm_multi_set_image(r3dm_multi* m, uint32_t view_id, uint32_t width, uint32_t height,
                          const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);
+/* how the views registered so far travelled: a view crosses PCIe once (host -> the first context's device; not at all when the
+ * caller's buffers are device memory) and reaches the other devices by hipMemcpyPeerAsync (xGMI where peer access exists) */
+int r3dm_multi_transfer_counts(const r3dm_multi* m, uint64_t* host_uploads, uint64_t* peer_copies);
 int r3dm_multi_set_intrinsics(r3dm_multi* m, uint32_t view_id, const double* K);
 int r3dm_multi_clear_images(r3dm_multi* m);
 int r3dm_multi_set_integer_mfma(r3dm_multi* m, int enable);

@@ -25,10 +25,10 @@ EXPORTS = [
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
-    "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
+    "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
-    "r3dm_multi_set_image", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
+    "r3dm_multi_set_image", "r3dm_multi_transfer_counts", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
     "r3dm_multi_match_pairs", "r3dm_multi_match_pairs_kgraph", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
 ]
 
@@ -69,7 +69,7 @@ class StageReport(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total",
                                           "ms_match_kernels", "ms_F_kernels", "ms_E_kernels", "ms_H_kernels")] + \
                [(k, C.c_uint64) for k in ("images_extracted", "n_keypoints", "n_putative_pairs", "n_putative_matches", "n_F_pairs", "n_F_matches",
-                                          "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches")] + [("features", FeaturesTotals)]
+                                          "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches", "match_was_exhaustive")] + [("features", FeaturesTotals)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "features"}
@@ -79,7 +79,8 @@ class StageReport(C.Structure):
 
 def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6,
                           matching_algorithm: int = 9, compute_F: bool = True, compute_E: bool = True, compute_H: bool = True,
-                          seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8) -> StageReport:
+                          seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8, arms_as_requested: bool = False,
+                          split_mfma: bool = False, integer_mfma: bool = False) -> StageReport:
     """R3DComputeMatches::computeMatches from pixels (r3dm_compute_matches_stage): features stage for the views whose .feat/.desc
     are missing, matching, F / E / H filters, match files.  views: dicts with id, width, height, basename and optionally
     gray ([h, w] float32) or bgr ([h, w, 3] uint8) -- numpy or torch (host or device) -- and focal_px / ppx / ppy."""
@@ -99,10 +100,10 @@ def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float 
     ids = (C.c_int * len(device_ids))(*device_ids)
     rep = StageReport(); err = C.create_string_buffer(1024)
     L.r3dm_compute_matches_stage.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
-                                             C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+                                             C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_char_p, C.c_size_t]
     rc = L.r3dm_compute_matches_stage(ids, len(device_ids), matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm,
                                       int(compute_F), int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
-                                      C.byref(rep), err, 1024)
+                                      (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0), C.byref(rep), err, 1024)
     if rc != 0:
         raise R3dmError(f"r3dm_compute_matches_stage -> {rc}: {err.value.decode()}")
     return rep
@@ -654,6 +655,13 @@ class MultiContext:
             xy = np.ascontiguousarray(xy, np.float32)
         self._check(self._L.r3dm_multi_set_image(self._h, view_id, width, height, _ptr(desc), desc.shape[0], desc.shape[1], dt, _ptr(xy)),
                     "r3dm_multi_set_image")
+
+    def transfer_counts(self):
+        """(views uploaded from host memory, device-to-device copies) of the set_image calls so far"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._L.r3dm_multi_transfer_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self._check(self._L.r3dm_multi_transfer_counts(self._h, C.byref(a), C.byref(b)), "r3dm_multi_transfer_counts")
+        return int(a.value), int(b.value)
 
     def set_intrinsics(self, view_id: int, K):
         K = None if K is None else np.ascontiguousarray(K, np.float64).reshape(9)

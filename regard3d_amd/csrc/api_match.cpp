@@ -444,6 +444,22 @@ static int check_kgraph_params(r3dm_ctx* c, const r3dm_kgraph_params* kp)
     return R3DM_OK;
 }
 
+extern "C" int r3dm_exhaustive_is_faster(const r3dm_ctx* c)
+{
+    if (!c) return 0;
+    bool any = false;
+    for (const auto& up : c->imgs) {
+        if (!up || !up->live) continue;
+        const HostImage& h = *up;
+        any = true;
+        if (h.dtype == R3DM_BIN) return 0;                                   // no graph matcher for Hamming anyway
+        if (!h.not_integer) return 0;                                        // integer-valued rows: the byte-row graph search is the faster one
+        if (!has_tensor_kernel(kernel_G_for(h.dim))) return 0;               // other lengths run the one-workgroup-per-query exact scan
+        if (h.n > 32768u) return 0;
+    }
+    return any ? 1 : 0;
+}
+
 // compact copy of a view's rows for the search's gathers: bytes for integers 0 .. 255 (ImgDev::ann_rows8), bf16 for other integers
 // of magnitude <= 256 (ImgDev::ann_rows16), nothing otherwise.  R3DM_ANN_ROWS16 (developer build): 0 = never, 1 = bf16 only,
 // 2 = bytes too, 3 (the product) = and integer dot products when both views of every pair are bytes.

@@ -16,6 +16,7 @@
 struct r3dm_multi {
     std::vector<r3dm_ctx*> ctx;
     std::string err;
+    uint64_t n_host_uploads = 0, n_peer_copies = 0;       // r3dm_multi_set_image: views that crossed PCIe / copies device to device
 };
 
 extern "C" {
@@ -111,11 +112,74 @@ static int for_each_device(r3dm_multi* m, Fn fn)
     return R3DM_OK;
 }
 
+// A view is replicated on every device.  It crosses PCIe ONCE: the raw descriptors and positions go host -> the first context's
+// device (or are already device memory: then nothing crosses), and from there to every other context's device with
+// hipMemcpyPeerAsync -- over xGMI where peer access exists, through a staged copy where it does not; every device then runs its own
+// re-layout kernels on its local copy (r3dm_set_image takes device pointers).  C4 (1000 views, 4.2 GB) used to cross PCIe 8 times.
 extern "C" int r3dm_multi_set_image(r3dm_multi* m, uint32_t view_id, uint32_t width, uint32_t height,
                                     const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
 {
     if (!m) return R3DM_ERR_INVALID;
-    return for_each_device(m, [&](uint32_t, r3dm_ctx* c) { return r3dm_set_image(c, view_id, width, height, desc, n, dim, dtype, xy); });
+    const size_t W = m->ctx.size();
+    if (W == 1 || n == 0 || !desc)
+        return for_each_device(m, [&](uint32_t, r3dm_ctx* c) { return r3dm_set_image(c, view_id, width, height, desc, n, dim, dtype, xy); });
+    const size_t desc_bytes = (size_t)n * dim * (dtype == R3DM_F32 ? 4 : 1), xy_bytes = xy ? (size_t)n * 8 : 0;
+    const size_t xy_off = (desc_bytes + 255) / 256 * 256;
+    // where the caller's buffers live: device memory is the source of the fan-out as it is
+    auto device_of = [](const void* p) -> int {
+        hipPointerAttribute_t a{};
+        if (p && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice) return a.device;
+        (void)hipGetLastError();
+        return -1;
+    };
+    const int desc_dev = device_of(desc), xy_dev = xy ? device_of(xy) : -1;
+    r3dm_ctx* c0 = m->ctx[0];
+    const void* src_desc = desc; const void* src_xy = xy;
+    int src_desc_dev = desc_dev, src_xy_dev = xy_dev;
+    if (desc_dev < 0 || (xy && xy_dev < 0)) {
+        R3DM_HIP(c0, hipSetDevice(c0->device));
+        R3DM_HIP(c0, c0->m_raw.ensure(xy_off + xy_bytes + 256));
+        if (desc_dev < 0) {
+            R3DM_HIP(c0, hipMemcpyAsync(c0->m_raw.p, desc, desc_bytes, hipMemcpyHostToDevice, c0->stream));
+            src_desc = c0->m_raw.p; src_desc_dev = c0->device;
+        }
+        if (xy && xy_dev < 0) {
+            R3DM_HIP(c0, hipMemcpyAsync(c0->m_raw.as<unsigned char>() + xy_off, xy, xy_bytes, hipMemcpyHostToDevice, c0->stream));
+            src_xy = c0->m_raw.as<unsigned char>() + xy_off; src_xy_dev = c0->device;
+        }
+        R3DM_HIP(c0, hipStreamSynchronize(c0->stream));
+        m->n_host_uploads += 1;
+    }
+    std::vector<uint64_t> peer(W, 0);
+    const int rc = for_each_device(m, [&](uint32_t k, r3dm_ctx* c) -> int {
+        const void* d = src_desc; const void* x = src_xy;
+        R3DM_HIP(c, hipSetDevice(c->device));
+        if (k != 0 || src_desc_dev != c->device || (xy && src_xy_dev != c->device)) {
+            // this context's local copy (context 0 reads its own upload in place when it already sits on its device)
+            const bool own = (c == c0) && src_desc == c0->m_raw.p;
+            if (!own) {
+                R3DM_HIP(c, c->m_peer.ensure(xy_off + xy_bytes + 256));
+                R3DM_HIP(c, hipMemcpyPeerAsync(c->m_peer.p, c->device, src_desc, src_desc_dev, desc_bytes, c->stream));
+                if (xy) R3DM_HIP(c, hipMemcpyPeerAsync(c->m_peer.as<unsigned char>() + xy_off, c->device, src_xy, src_xy_dev, xy_bytes, c->stream));
+                R3DM_HIP(c, hipStreamSynchronize(c->stream));
+                d = c->m_peer.p; x = xy ? (const void*)(c->m_peer.as<unsigned char>() + xy_off) : nullptr;
+                peer[k] = 1;
+            }
+        }
+        return r3dm_set_image(c, view_id, width, height, d, n, dim, dtype, (const float*)x);
+    });
+    for (uint64_t v : peer) m->n_peer_copies += v;
+    return rc;
+}
+
+// how the views registered so far travelled: uploads from host memory (one per view, whatever the number of devices) and
+// device-to-device copies (one per view and further context)
+extern "C" int r3dm_multi_transfer_counts(const r3dm_multi* m, uint64_t* host_uploads, uint64_t* peer_copies)
+{
+    if (!m) return R3DM_ERR_INVALID;
+    if (host_uploads) *host_uploads = m->n_host_uploads;
+    if (peer_copies) *peer_copies = m->n_peer_copies;
+    return R3DM_OK;
 }
 
 extern "C" int r3dm_multi_set_intrinsics(r3dm_multi* m, uint32_t view_id, const double* K)

@@ -241,6 +241,12 @@ void R3DComputeMatches::setIntegerFastPath(bool on)
     if (multi_) (void)r3dm_multi_set_integer_mfma(multi_, on ? 1 : 0);
 }
 
+void R3DComputeMatches::setSplitFastPath(bool on)
+{
+    if (ctx_) (void)r3dm_set_split_mfma(ctx_, on ? 1 : 0);
+    if (multi_) for (int k = 0; k < r3dm_multi_num_devices(multi_); ++k) (void)r3dm_set_split_mfma(r3dm_multi_ctx(multi_, k), on ? 1 : 0);
+}
+
 void R3DComputeMatches::setRegionsType(r3dm_dtype dtype, uint32_t dim) { dtype_ = dtype; dim_ = dim; }
 
 bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,
@@ -280,7 +286,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     // approximate arm (0 FLANN kd-trees, 1..3 KGraph, 5 MRPT, 6..8 HNSW) runs the graph matcher with a preset of at least the
     // arm's recall (r3dm_ann_params_for_algorithm); anything else is refused.
     r3dm_kgraph_params kp;
-    const bool use_kgraph = r3dm_ann_params_for_algorithm(matchingAlgorithm, &kp) == R3DM_OK;
+    bool use_kgraph = r3dm_ann_params_for_algorithm(matchingAlgorithm, &kp) == R3DM_OK;
     if (matchingAlgorithm != kMatchingAlgorithmGPU && matchingAlgorithm != 4 && !use_kgraph) {
         errorMessage_ = "matchingAlgorithm " + std::to_string(matchingAlgorithm) + " is not served by the GPU path (0..9 are)";
         return false;
@@ -348,6 +354,9 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     r3dm_graph* putative = nullptr;
     const int squared = dtype_ == R3DM_BIN ? 0 : 1;        // RegionsMatcherT squared flag: true for L2 metrics
     int rc;
+    // an approximate arm whose job the exhaustive matcher does at least as fast -- and exactly -- is served by it (setApproximateArmsPolicy)
+    if (use_kgraph && arms_policy_ == kArmsFastest && r3dm_exhaustive_is_faster(ctx_ ? ctx_ : r3dm_multi_ctx(multi_, 0)) == 1) use_kgraph = false;
+    last_exhaustive_ = !use_kgraph;
     if (use_kgraph) {
         rc = match_kgraph(pairs, params.distRatio_, &kp, &putative);
     } else {
@@ -436,7 +445,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
 
 extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
                                           float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
-                                          uint64_t seed, int features_batches_in_flight, int features_images_per_batch,
+                                          uint64_t seed, int features_batches_in_flight, int features_images_per_batch, uint32_t flags,
                                           r3dm_stage_report* report, char* err, size_t err_cap)
 {
     if (!matches_dir || !device_ids || n_devices < 1 || (n_views && !views)) return R3DM_ERR_INVALID;
@@ -453,6 +462,9 @@ extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, 
         stage.addViews(vs);
         stage.setSeed(seed);
         if (features_batches_in_flight > 0 && features_images_per_batch > 0) stage.setFeaturesConcurrency(features_batches_in_flight, features_images_per_batch);
+        if (flags & R3DM_STAGE_ARMS_AS_REQUESTED) stage.setApproximateArmsPolicy(r3d_amd::R3DComputeMatches::kArmsAsRequested);
+        if (flags & R3DM_STAGE_SPLIT_MFMA) stage.setSplitFastPath(true);
+        if (flags & R3DM_STAGE_INTEGER_MFMA) stage.setIntegerFastPath(true);
         r3d_amd::R3DFParams params;
         params.keypointDetectorList_ = {"Fast-AKAZE"};
         params.threshold_ = threshold;
@@ -472,6 +484,7 @@ extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, 
             report->ms_filter_E = P.filter_E; report->ms_filter_H = P.filter_H; report->ms_files = P.files; report->ms_total = P.total;
             report->ms_match_kernels = P.match_kernels; report->ms_F_kernels = P.F_kernels; report->ms_E_kernels = P.E_kernels; report->ms_H_kernels = P.H_kernels;
             report->images_extracted = P.images_extracted; report->features = P.features_totals;
+            report->match_was_exhaustive = stage.lastMatchWasExhaustive() ? 1 : 0;
             for (int n : S.numberOfKeypoints_) report->n_keypoints += (uint64_t)n;
             auto count = [](const r3d_amd::PairWiseMatches& m, uint64_t& pairs, uint64_t& matches) { pairs = m.size(); matches = 0; for (const auto& kv : m) matches += kv.second.size(); };
             count(S.putativeMatches_, report->n_putative_pairs, report->n_putative_matches);

@@ -524,24 +524,32 @@ void ak_fed_multi_kernel(const float* __restrict__ Lt, const float* __restrict__
     __shared__ float f[HW * HW];
     Lt = AK_PLANE(Lt, w, h); Lf = AK_PLANE(Lf, w, h); out = AK_PLANE(out, w, h);
     const int x0 = (int)blockIdx.x * T - K, y0 = (int)blockIdx.y * T - K;
-    for (int c = threadIdx.x; c < HW * HW; c += 256) {
+    // a thread's cells c = tid + 256 i of the 40 x 40 tile: position, image coordinates and border case once, not per step
+    constexpr int NC = (HW * HW + 255) / 256;
+    int cq[NC]; unsigned char cl[NC], cy[NC], cm[NC];          // LDS index; column, row in the tile; bit 0..3 = has_l, has_r, has_a, has_b, bit 4 = inside the image
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (int)threadIdx.x + 256 * i;
         const int lx = c % HW, ly = c / HW, gx = x0 + lx, gy = y0 + ly;
-        const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+        const bool in = c < HW * HW && gx >= 0 && gx < w && gy >= 0 && gy < h;
+        cq[i] = c < HW * HW ? c : 0; cl[i] = (unsigned char)lx; cy[i] = (unsigned char)(c < HW * HW ? ly : 255);
+        cm[i] = (unsigned char)((gx > 0 ? 1 : 0) | (gx < w - 1 ? 2 : 0) | (gy > 0 ? 4 : 0) | (gy < h - 1 ? 8 : 0) | (in ? 16 : 0));
         const uint32_t p = (uint32_t)(in ? gy : 0) * (uint32_t)w + (uint32_t)(in ? gx : 0);
         const float tv = Lt[p], fv = Lf[p];
-        a[0][c] = in ? tv : 0.0f; f[c] = in ? fv : 0.0f;
+        if (c < HW * HW) { a[0][c] = in ? tv : 0.0f; f[c] = in ? fv : 0.0f; }
     }
     r3dm_syncthreads();
     for (int s = 0; s < st.n; ++s) {
         const float* __restrict__ cur = a[s & 1];
         float* __restrict__ nxt = a[(s + 1) & 1];
-        const int lo = s + 1, side = HW - 2 * (s + 1);                  // cells [lo, lo + side) x [lo, lo + side) are exact after this step
+        const int lo = s + 1, hi = HW - 1 - (s + 1);                    // cells [lo, hi] x [lo, hi] are exact after this step
         const float step_size = st.tau[s];
-        for (int c = threadIdx.x; c < side * side; c += 256) {
-            const int lx = lo + c % side, ly = lo + c / side, gx = x0 + lx, gy = y0 + ly;
-            if (gx < 0 || gx >= w || gy < 0 || gy >= h) continue;
-            const int q = ly * HW + lx;
-            const bool has_l = gx > 0, has_r = gx < w - 1, has_a = gy > 0, has_b = gy < h - 1;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int lx = cl[i], ly = cy[i];
+            if (!(cm[i] & 16) || lx < lo || lx > hi || ly < lo || ly > hi) continue;
+            const int q = cq[i];
+            const bool has_l = cm[i] & 1, has_r = cm[i] & 2, has_a = cm[i] & 4, has_b = cm[i] & 8;
             const float tc = cur[q], fc = f[q];
             float v;
             if (!has_a) {

@@ -129,6 +129,7 @@ struct r3dm_ctx {
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff, f_order;
+    DevBuf m_raw, m_peer;                                   // r3dm_multi_set_image: the one upload of a view / this device's copy of it
     std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size, ak_B planes each
     int ak_w = 0, ak_h = 0, ak_B = 0;
     uint32_t ak_cap = 0;                                    // candidate slots per image the detector last needed (grows, never shrinks)

@@ -115,8 +115,12 @@ int main(int argc, char** argv)
         const char* algo_env = getenv("R3DM_TEST_ALGO");
         const int algo = algo_env ? atoi(algo_env) : r3d_amd::R3DComputeMatches::kMatchingAlgorithmGPU;
         if (getenv("R3DM_TEST_INTEGER_MFMA")) stage.setIntegerFastPath(true);
+        // R3DM_TEST_ARMS=requested: approximate arms always on the graph matcher (default: on whichever matcher is faster for the views)
+        const char* arms_env = getenv("R3DM_TEST_ARMS");
+        if (arms_env && !strcmp(arms_env, "requested")) stage.setApproximateArmsPolicy(r3d_amd::R3DComputeMatches::kArmsAsRequested);
         const bool ok = stage.computeMatches(params, true, paths, 1, algo);
         if (!ok) { fprintf(stderr, "computeMatches failed: %s\n", stage.errorMessage().c_str()); return 7; }
+        fprintf(stderr, "matcher %s\n", stage.lastMatchWasExhaustive() ? "exhaustive" : "graph");
         printf("%zu %zu\n", stage.getStatistics().putativeMatches_.size(), stage.getStatistics().fundamentalMatches_.size());
         return 0;
     }

@@ -169,9 +169,10 @@ def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
     """matchingAlgorithm 3 = "KGraph precise" (src/R3DComputeMatches.cpp:2051-2054): putative file == the CPU model"""
     sc = synth.make_scene(4, 900, "liop", seed=29)
     names = _write_views(oracle, str(tmp_path), sc)
-    env = dict(os.environ, R3DM_TEST_ALGO="3")
+    env = dict(os.environ, R3DM_TEST_ALGO="3", R3DM_TEST_ARMS="requested")
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
+    assert "matcher graph" in r.stderr
     pairs = sc.exhaustive_pairs()
     counts, matches, _ = oracle.match_collection_kgraph(sc.descs, sc.xys, pairs, 0.6, builder="exact", K=24, P=12, S=10,
                                                         seed=1998, min_rows=128)
@@ -179,10 +180,17 @@ def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
     assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
     # the HNSW / MRPT / FLANN arms are served by the same matcher with the preset of matching recall: 8 ("HNSW precise") == 3
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
-                       env=dict(os.environ, R3DM_TEST_ALGO="8"))
+                       env=dict(os.environ, R3DM_TEST_ALGO="8", R3DM_TEST_ARMS="requested"))
     assert r.returncode == 0, r.stderr
     p8, c8, m8 = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
     assert np.array_equal(p8, p) and np.array_equal(c8, c) and np.array_equal(m8, m)
+    # the default policy serves an approximate arm with whichever matcher is faster for the views: LIOP-144 (real-valued) -> the
+    # exhaustive matcher, i.e. arm 0 (the GUI's default, FLANN in the reference) writes exactly what arm 9 writes
+    r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True, env=dict(os.environ, R3DM_TEST_ALGO="0"))
+    assert r.returncode == 0 and "matcher exhaustive" in r.stderr, r.stderr
+    pe, ce, me = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
+    cx, mx = oracle.match_collection(sc.descs, sc.xys, pairs, 0.6, True)
+    assert np.array_equal(pe, pairs[cx > 0]) and np.array_equal(ce, cx[cx > 0]) and np.array_equal(me, mx)
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
                        env=dict(os.environ, R3DM_TEST_ALGO="11"))
     assert r.returncode == 7 and "not served" in r.stderr               # unknown arm: refused

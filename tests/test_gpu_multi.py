@@ -20,7 +20,7 @@ def _same(a, b):
     return np.array_equal(a.pairs, b.pairs) and np.array_equal(a.offsets, b.offsets) and np.array_equal(a.matches, b.matches)
 
 
-@pytest.mark.parametrize("n_ctx", [2, 3])
+@pytest.mark.parametrize("n_ctx", [2, 3, 8])
 def test_two_contexts_reassemble_the_single_context_graphs(ctx, oracle, n_ctx):
     sc = synth.make_scene(9, 1500, "sift", seed=404)
     pairs = sc.exhaustive_pairs()
@@ -39,9 +39,11 @@ def test_two_contexts_reassemble_the_single_context_graphs(ctx, oracle, n_ctx):
         for i in range(sc.n_images):
             m.set_image(i, sc.descs[i], sc.xys[i], synth.WIDTH, synth.HEIGHT)
             m.set_intrinsics(i, K)
+        # a view crosses PCIe once, whatever the number of contexts; the others get it device to device
+        assert m.transfer_counts() == (sc.n_images, sc.n_images * (n_ctx - 1))
         g2 = m.match_pairs(pairs, 0.6, True)
         assert _same(g1, g2)
-        # every context really took its share of the rows of I
+        # every context really took its share of the rows of I (with 8 contexts and 9 views: one row each)
         owner = api.shard_owner(pairs, n_ctx)
         for k in range(n_ctx):
             assert m.device_stats(k).n_pairs == int((owner == k).sum())
