@@ -246,9 +246,11 @@ def stage_main(a):
             if all_files or f.startswith("matches."):
                 os.remove(os.path.join(d, f))
 
+    stage = api.Stage([0])             # the facade object of a long-lived host: contexts and work buffers survive between steps
+
     def step(algo=9):
         wipe()
-        return api.compute_matches_stage([0], d, views, 0.001, 0.6, algo, True, True, True, 5489, conc, batch)
+        return stage.run(d, views, 0.001, 0.6, algo, True, True, True, 5489, conc, batch)
 
     try:
         for _ in range(max(a.warmup, 1)):
@@ -266,12 +268,12 @@ def stage_main(a):
         # way for a like-for-like match phase, plain and with the opt-in split-f16 nominator
         def rerun(algo, **kw):
             wipe(False)
-            r = api.compute_matches_stage([0], d, bare, 0.001, 0.6, algo, **kw).as_dict()
+            r = stage.run(d, bare, 0.001, 0.6, algo, **kw).as_dict()
             return r, {x: open(os.path.join(d, f"matches.{x}.bin"), "rb").read() for x in ("putative", "f", "e", "h")}
-        r9, f9 = rerun(9)
+        r0g, f0g = rerun(0, arms_as_requested=True)
         r9s, f9s = rerun(9, split_mfma=True)
         r0, f0 = rerun(0)
-        r0g, f0g = rerun(0, arms_as_requested=True)
+        r9, f9 = rerun(9)                   # last: its files are what the CPU leg below compares with
         # detector roofline: a dedicated pass of the batch entry on B resident images, one context, nothing else on the GPU
         ctx = api.Context(0)
         B = min(8, N)
@@ -318,6 +320,7 @@ def stage_main(a):
             out["cpu_baseline"] = stage_cpu_baseline(ctx, imgs, d, K, W, H, a.cpu_seconds)
         print(json.dumps(out))
     finally:
+        stage.close()
         shutil.rmtree(d, ignore_errors=True)
 
 

@@ -22,8 +22,7 @@ build_one() {   # $1 = variant dir, $2 = extra flags, $3 = output, $4 = extra so
     if [ ! -f $o ]; then stale=1; else
       for d in regard3d_amd/csrc/$f $HDRS build.sh; do [ $d -nt $o ] && stale=1; done
     fi
-    # the one kernel with out-of-line device calls keeps its spilled SGPRs in memory, not in VGPR lanes (kernels_filter.hip: launch_filter_E)
-    local extra=""; [ $f = kernels_filter_e.hip ] && extra="-mllvm -amdgpu-spill-sgpr-to-vgpr=0"
+    local extra=""      # (no per-file compiler options: the essential-matrix kernel no longer needs -amdgpu-spill-sgpr-to-vgpr=0)
     [ $f = kernels_filter_e.hip ] && [ regard3d_amd/csrc/kernels_filter.hip -nt $o ] && stale=1
     if [ $stale = 1 ]; then ( $HIPCC $FLAGS $2 $extra -x hip -c regard3d_amd/csrc/$f -o $o ) & pids="$pids $!"; fi
   done

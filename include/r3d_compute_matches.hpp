@@ -81,6 +81,7 @@ public:
     R3DComputeMatches& operator=(const R3DComputeMatches&) = delete;
 
     void addViews(const std::vector<View>& views);                 // stands in for addImages + sfm_data.bin
+    void clearViews() { views_.clear(); }                            // a kept-alive stage object between two collections
     void setRegionsType(r3dm_dtype dtype, uint32_t dim);           // default: float x 144 (R3D_AKAZE_LIOP_Regions)
     void setSeed(uint64_t seed) { seed_ = seed; }
     // no reference counterpart: forwards r3dm_set_integer_mfma (bit-identical results, integer-valued descriptors only)
@@ -179,7 +180,17 @@ int r3dm_compute_matches_stage(const int* device_ids, int n_devices, const char*
                                float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
                                uint64_t seed, int features_batches_in_flight, int features_images_per_batch, uint32_t flags,
                                r3dm_stage_report* report, char* err, size_t err_cap);
-/* flags of r3dm_compute_matches_stage */
+/* The same with the stage object kept alive between calls, as a long-lived host (the Regard3D GUI process) would keep it: device
+ * contexts, work buffers of the detector and page-locked staging memory are allocated once, not per call (~12 GB of hipMalloc
+ * per features context at 12 Mpx and batches of 8). */
+typedef struct r3dm_stage r3dm_stage;
+int  r3dm_stage_create(const int* device_ids, int n_devices, r3dm_stage** out);
+void r3dm_stage_destroy(r3dm_stage* s);
+int  r3dm_stage_run(r3dm_stage* s, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
+                    float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
+                    uint64_t seed, int features_batches_in_flight, int features_images_per_batch, uint32_t flags,
+                    r3dm_stage_report* report, char* err, size_t err_cap);
+/* flags of r3dm_compute_matches_stage / r3dm_stage_run */
 #define R3DM_STAGE_ARMS_AS_REQUESTED 1u   /* approximate arms always on the graph matcher (default: the faster matcher, R3DComputeMatches::setApproximateArmsPolicy) */
 #define R3DM_STAGE_SPLIT_MFMA        2u   /* r3dm_set_split_mfma: the opt-in split-f16 nominator for real-valued descriptors (bit-identical results) */
 #define R3DM_STAGE_INTEGER_MFMA      4u   /* r3dm_set_integer_mfma */

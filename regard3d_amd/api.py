@@ -23,7 +23,7 @@ EXPORTS = [
     "r3dm_match_pairs", "r3dm_filter_F", "r3dm_filter_H", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
-    "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_liop_describe_patches", "r3dm_extract_liop",
+    "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_stage_create", "r3dm_stage_run", "r3dm_stage_destroy", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
     "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
@@ -77,15 +77,7 @@ class StageReport(C.Structure):
         return d
 
 
-def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6,
-                          matching_algorithm: int = 9, compute_F: bool = True, compute_E: bool = True, compute_H: bool = True,
-                          seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8, arms_as_requested: bool = False,
-                          split_mfma: bool = False, integer_mfma: bool = False) -> StageReport:
-    """R3DComputeMatches::computeMatches from pixels (r3dm_compute_matches_stage): features stage for the views whose .feat/.desc
-    are missing, matching, F / E / H filters, match files.  views: dicts with id, width, height, basename and optionally
-    gray ([h, w] float32) or bgr ([h, w, 3] uint8) -- numpy or torch (host or device) -- and focal_px / ppx / ppy."""
-    L = load_library()
-    keep = []
+def _stage_views(views, keep):
     arr = (ViewImage * max(len(views), 1))()
     for k, v in enumerate(views):
         def ptr(a, dt):
@@ -97,10 +89,68 @@ def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float 
             return a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
         arr[k] = ViewImage(int(v["id"]), int(v["width"]), int(v["height"]), v["basename"].encode(), ptr(v.get("bgr"), np.uint8),
                            ptr(v.get("gray"), np.float32), float(v.get("focal_px", -1.0)), float(v.get("ppx", 0.0)), float(v.get("ppy", 0.0)))
+    return arr
+
+
+_STAGE_ARGS = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+               C.c_uint32, C.c_void_p, C.c_char_p, C.c_size_t]
+
+
+class Stage:
+    """r3dm_stage_*: the R3DComputeMatches facade kept alive between calls (contexts, detector work buffers and page-locked memory
+    are allocated once), as a long-lived host process would keep it."""
+
+    def __init__(self, device_ids):
+        L = load_library()
+        L.r3dm_stage_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.r3dm_stage_run.argtypes = [C.c_void_p] + _STAGE_ARGS
+        L.r3dm_stage_destroy.argtypes = [C.c_void_p]
+        L.r3dm_stage_destroy.restype = None
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = L.r3dm_stage_create(ids, len(device_ids), C.byref(h))
+        if rc != 0:
+            raise R3dmError(f"r3dm_stage_create({list(device_ids)}) -> {rc} (no gfx950 GPU visible? there is no CPU fallback)")
+        self._h, self._L = h.value, L
+
+    def run(self, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6, matching_algorithm: int = 9, compute_F: bool = True,
+            compute_E: bool = True, compute_H: bool = True, seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8,
+            arms_as_requested: bool = False, split_mfma: bool = False, integer_mfma: bool = False) -> StageReport:
+        keep = []
+        arr = _stage_views(views, keep)
+        rep = StageReport(); err = C.create_string_buffer(1024)
+        rc = self._L.r3dm_stage_run(self._h, matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm, int(compute_F),
+                                    int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
+                                    (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0), C.byref(rep), err, 1024)
+        if rc != 0:
+            raise R3dmError(f"r3dm_stage_run -> {rc}: {err.value.decode()}")
+        return rep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.r3dm_stage_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6,
+                          matching_algorithm: int = 9, compute_F: bool = True, compute_E: bool = True, compute_H: bool = True,
+                          seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8, arms_as_requested: bool = False,
+                          split_mfma: bool = False, integer_mfma: bool = False) -> StageReport:
+    """R3DComputeMatches::computeMatches from pixels (r3dm_compute_matches_stage): features stage for the views whose .feat/.desc
+    are missing, matching, F / E / H filters, match files.  views: dicts with id, width, height, basename and optionally
+    gray ([h, w] float32) or bgr ([h, w, 3] uint8) -- numpy or torch (host or device) -- and focal_px / ppx / ppy."""
+    L = load_library()
+    keep = []
+    arr = _stage_views(views, keep)
     ids = (C.c_int * len(device_ids))(*device_ids)
     rep = StageReport(); err = C.create_string_buffer(1024)
-    L.r3dm_compute_matches_stage.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
-                                             C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.r3dm_compute_matches_stage.argtypes = [C.c_void_p, C.c_int] + _STAGE_ARGS
     rc = L.r3dm_compute_matches_stage(ids, len(device_ids), matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm,
                                       int(compute_F), int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
                                       (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0), C.byref(rep), err, 1024)

@@ -443,15 +443,39 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
 
 }  // namespace r3d_amd
 
-extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
-                                          float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
-                                          uint64_t seed, int features_batches_in_flight, int features_images_per_batch, uint32_t flags,
-                                          r3dm_stage_report* report, char* err, size_t err_cap)
+struct r3dm_stage { r3d_amd::R3DComputeMatches* stage = nullptr; };
+
+extern "C" int r3dm_stage_create(const int* device_ids, int n_devices, r3dm_stage** out)
 {
-    if (!matches_dir || !device_ids || n_devices < 1 || (n_views && !views)) return R3DM_ERR_INVALID;
+    if (!out || !device_ids || n_devices < 1) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    try {
+        auto* s = new r3dm_stage();
+        s->stage = new r3d_amd::R3DComputeMatches(std::vector<int>(device_ids, device_ids + n_devices));
+        if (!s->stage->errorMessage().empty()) { delete s->stage; delete s; return R3DM_ERR_NO_DEVICE; }
+        *out = s;
+        return R3DM_OK;
+    } catch (const std::bad_alloc&) { return R3DM_ERR_NOMEM; }
+    catch (...) { return R3DM_ERR_INVALID; }
+}
+
+extern "C" void r3dm_stage_destroy(r3dm_stage* s)
+{
+    if (!s) return;
+    delete s->stage;
+    delete s;
+}
+
+extern "C" int r3dm_stage_run(r3dm_stage* sp, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
+                              float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
+                              uint64_t seed, int features_batches_in_flight, int features_images_per_batch, uint32_t flags,
+                              r3dm_stage_report* report, char* err, size_t err_cap)
+{
+    if (!sp || !sp->stage || !matches_dir || (n_views && !views)) return R3DM_ERR_INVALID;
     if (err && err_cap) err[0] = 0;
     try {
-        r3d_amd::R3DComputeMatches stage(std::vector<int>(device_ids, device_ids + n_devices));
+        r3d_amd::R3DComputeMatches& stage = *sp->stage;
+        stage.clearViews();
         std::vector<r3d_amd::View> vs(n_views);
         for (uint32_t k = 0; k < n_views; ++k) {
             r3d_amd::View& v = vs[k];
@@ -462,9 +486,9 @@ extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, 
         stage.addViews(vs);
         stage.setSeed(seed);
         if (features_batches_in_flight > 0 && features_images_per_batch > 0) stage.setFeaturesConcurrency(features_batches_in_flight, features_images_per_batch);
-        if (flags & R3DM_STAGE_ARMS_AS_REQUESTED) stage.setApproximateArmsPolicy(r3d_amd::R3DComputeMatches::kArmsAsRequested);
-        if (flags & R3DM_STAGE_SPLIT_MFMA) stage.setSplitFastPath(true);
-        if (flags & R3DM_STAGE_INTEGER_MFMA) stage.setIntegerFastPath(true);
+        stage.setApproximateArmsPolicy((flags & R3DM_STAGE_ARMS_AS_REQUESTED) ? r3d_amd::R3DComputeMatches::kArmsAsRequested : r3d_amd::R3DComputeMatches::kArmsFastest);
+        stage.setSplitFastPath((flags & R3DM_STAGE_SPLIT_MFMA) != 0);
+        stage.setIntegerFastPath((flags & R3DM_STAGE_INTEGER_MFMA) != 0);
         r3d_amd::R3DFParams params;
         params.keypointDetectorList_ = {"Fast-AKAZE"};
         params.threshold_ = threshold;
@@ -495,6 +519,21 @@ extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, 
         return ok ? R3DM_OK : R3DM_ERR_IO;
     } catch (const std::bad_alloc&) { return R3DM_ERR_NOMEM; }          // nothing crosses the C boundary
     catch (...) { return R3DM_ERR_INVALID; }
+}
+
+extern "C" int r3dm_compute_matches_stage(const int* device_ids, int n_devices, const char* matches_dir, const r3dm_view_image* views, uint32_t n_views,
+                                          float threshold, float dist_ratio, int matching_algorithm, int compute_F, int compute_E, int compute_H,
+                                          uint64_t seed, int features_batches_in_flight, int features_images_per_batch, uint32_t flags,
+                                          r3dm_stage_report* report, char* err, size_t err_cap)
+{
+    if (err && err_cap) err[0] = 0;
+    r3dm_stage* s = nullptr;
+    int rc = r3dm_stage_create(device_ids, n_devices, &s);
+    if (rc != R3DM_OK) { if (err && err_cap) snprintf(err, err_cap, "r3dm_create failed (%d): no gfx950 GPU", rc); return rc; }
+    rc = r3dm_stage_run(s, matches_dir, views, n_views, threshold, dist_ratio, matching_algorithm, compute_F, compute_E, compute_H, seed,
+                        features_batches_in_flight, features_images_per_batch, flags, report, err, err_cap);
+    r3dm_stage_destroy(s);
+    return rc;
 }
 
 extern "C" int r3dm_compute_matches_dir(int device_id, const char* matches_dir, const r3dm_view* views, uint32_t n_views,

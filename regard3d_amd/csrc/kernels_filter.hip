@@ -251,8 +251,8 @@ __device__ __forceinline__ double h_asym_err(const double* H, double x1, double 
 // 5-point essential matrix (OpenMVG essential::kernel::FivePointKernel behind GeometricFilter_EMatrix_AC,
 // /root/reference/src/R3DComputeMatches.cpp:2169).  Same polynomial system as OpenMVG's FivePointsRelativePose,
 // solved with Nister's hidden-variable elimination + a Sturm sequence; operation for operation the arithmetic of
-// oracle/essential.c (only + - * / after the QR), so both produce the same bits.  One lane per minimal sample; the
-// 10x20 elimination matrix lives in scratch memory (the other 192 lanes of the workgroup wait at the barrier anyway).
+// oracle/essential.c (only + - * / after the QR), so both produce the same bits.  Sixteen lanes per minimal sample
+// (five_point_coop below), the sample's state in an LDS workspace.
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned char kT11[4][4] = {{0, 2, 3, 4}, {2, 1, 5, 6}, {3, 5, 7, 8}, {4, 6, 8, 9}};
 constexpr unsigned char kT21[10][4] = {{0, 2, 4, 5}, {3, 1, 6, 7}, {2, 3, 8, 9}, {4, 8, 10, 11}, {5, 9, 11, 12},
@@ -295,296 +295,267 @@ __device__ __forceinline__ double e_peval(const double (&p)[D + 1], double t)
     return v;
 }
 
-// per-lane workspace in LDS: element i of lane l lives at ws[i * 64] (ws already offset by l): conflict-free, and
-// dynamic indexing (pivot rows, Sturm chain) costs an LDS access instead of a scratch-memory round trip
-#define E_WS(i) ws[(size_t)(i) * 64]
-constexpr int kEwsChain = 0;        // Sturm chain f[k][c] at kEwsChain + 11 k + c   (k < 12)   -- reuses the matrix area
-constexpr int kEwsDeg = 140;        // degree of f[k]
-constexpr int kEwsRoots = 160;      // real roots
-[[maybe_unused]] constexpr int kEwsFree = 170;       // slots 170..199 of every lane are unused by the solver: 15,360 contiguous bytes behind slot 169
-constexpr int kEwsDoubles = 200;    // 10 x 20 elimination matrix = 200 doubles per lane
+// ------------------------------------------------------------------------------------------------
+// The 5-point solver as a COOPERATIVE routine: 16 lanes per minimal sample, 16 samples per workgroup pass.
+// (Round 2 ran one sample per lane of wave 0: 512 registers + 256 spilled, two out-of-line calls from divergent flow that were
+// only correct with SGPR spills forced to memory, 0.85 ms per chunk on one wave while 192 lanes waited, one workgroup per CU.)
+// Here every quantity with an index -- matrix columns, constraint rows, polynomial coefficients, Sturm-chain evaluations, roots,
+// models -- belongs to a lane of the sample's group, the sample's state lives in a 367-double LDS workspace, and the lanes of a
+// group meet at wave-level fences only (a group never leaves its wavefront, so LDS program order is all the synchronisation there
+// is; groups of one wave may diverge freely).  No register arrays with dynamic indices, no calls, nothing data-dependent crosses a
+// workgroup barrier.  Every value is produced by exactly the operation sequence of the one-lane form (and of oracle/essential.c):
+// the split is over INDEPENDENT outputs, sums keep their order.
+// ------------------------------------------------------------------------------------------------
+constexpr int kE5Lanes = 16;            // lanes per sample
+constexpr int kE5Samples = 16;          // samples per workgroup pass = the essential-matrix kernel's chunk of hypotheses
+constexpr int kE5Stride = 367;          // doubles per sample workspace (odd: the groups' accesses spread over the LDS banks)
+// workspace map (doubles)
+constexpr int kE5A = 0;                 // 10 x 20 elimination matrix A[r][k] at 20 r + k; later the Sturm chain f[k][c] at 11 k + c (k < 12)
+constexpr int kE5Deg = 140;             //   ... degree of f[k] (inside the dead matrix)
+constexpr int kE5Roots = 160;           //   ... real roots
+constexpr int kE5Sgn = 172;             //   ... signs of the chain at a point (12)
+constexpr int kE5N = 200;               // null space N[e][r] at 9 e + r (e < 4): E1[r][e] = N[e][r]
+constexpr int kE5M = 236;               // 9 x 5 design matrix M[r][j] at 5 r + j, Householder vectors in place      (dead after N)
+constexpr int kE5Beta = 281;            // beta[5]                                                                    (dead after N)
+constexpr int kE5Eii = 236;             // EE^T diagonal polynomials eii[i][10] at 10 i (i < 3)                         (over M)
+constexpr int kE5Tr = 266;              // trace polynomial [10]
+constexpr int kE5L = 276;               // L[i][j][10] at 10 (3 i + j)  (90 doubles)                                   (dead after the rows)
+constexpr int kE5B = 236;               // B[q][v][5] at 5 (3 q + v)   (45 doubles)                                    (over eii / tr / L)
+constexpr int kE5Term = 290;            // the three terms of det B, [3][11]
+constexpr int kE5P = 330;               // det B, degree 10 [11]
+constexpr int kE5Flag = 345;            // model validity flags [10]
+static_assert(kE5L + 90 <= kE5Stride && kE5Flag + 10 <= kE5Stride, "5-point workspace map");
 
-__device__ __forceinline__ int e_sturm_changes(const double* ws, int nf, double t)
+// lanes of one sample meet here: compiler fence + scheduling barrier (LDS operations of one wavefront execute in program order)
+#define E5_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+__device__ __forceinline__ void e5_row(const double* __restrict__ W, int r, double (&a)[4])     // E1[r][0..3]
 {
-    int changes = 0, last = 0;
-    for (int k = 0; k < nf; ++k) {
-        const int d = (int)E_WS(kEwsDeg + k);
-        double v = E_WS(kEwsChain + 11 * k + d);
-        for (int c = d - 1; c >= 0; --c) v = v * t + E_WS(kEwsChain + 11 * k + c);
-        const int s = (v > 0.0) - (v < 0.0);
-        if (s != 0) { if (last != 0 && s != last) ++changes; last = s; }
-    }
-    return changes;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = W[kE5N + 9 * e + r];
+}
+__device__ __forceinline__ void e5_mul11_rows(const double* __restrict__ W, int ra, int rb, double (&out)[10])
+{
+    double a[4], b[4];
+    e5_row(W, ra, a); e5_row(W, rb, b);
+    e_mul11(a, b, out);
 }
 
-// 64 bisection steps of roots 0 .. R-1 of the Sturm chain in the workspace (root r: the (r + 1)-th real root from below)
-template <int R>
-__device__ __forceinline__ void e_bisect_roots(double* ws, int nf, int va, int nr, double bound)
+// l = lane within the sample's group (0..15); W = the sample's workspace; Es = its model slots (9 doubles per model).
+// Returns the number of models (the same value in every lane of the group).
+__device__ __forceinline__ int five_point_coop(const double (&px1)[7][2], const double (&px2)[7][2], double* __restrict__ Es,
+                                               double* __restrict__ W, const int l)
 {
-    double lo[R], hi[R];
+    // ---- design matrix: lane p < 5 writes the column of point p
+    if (l < 5) {
+        double ax = 0, ay = 0, bx = 0, by = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) { lo[r] = -bound; hi[r] = bound; }
-    for (int it = 0; it < 64; ++it) {
-        double mid[R], v[R];
-        int changes[R], last[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { mid[r] = 0.5 * (lo[r] + hi[r]); changes[r] = 0; last[r] = 0; }
-        for (int k = 0; k < nf; ++k) {
-            const int dk = (int)E_WS(kEwsDeg + k);
-            const double lead = E_WS(kEwsChain + 11 * k + dk);
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = lead;
-            for (int c = dk - 1; c >= 0; --c) {
-                const double coef = E_WS(kEwsChain + 11 * k + c);
-#pragma unroll
-                for (int r = 0; r < R; ++r) v[r] = v[r] * mid[r] + coef;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = (v[r] > 0.0) - (v[r] < 0.0);
-                if (s != 0) { if (last[r] != 0 && s != last[r]) ++changes[r]; last[r] = s; }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) { if (va - changes[r] >= r + 1) hi[r] = mid[r]; else lo[r] = mid[r]; }
+        for (int p = 0; p < 5; ++p) if (p == l) { ax = px1[p][0]; ay = px1[p][1]; bx = px2[p][0]; by = px2[p][1]; }
+        double* M = W + kE5M + l;
+        M[0] = bx * ax; M[5] = bx * ay; M[10] = bx;
+        M[15] = by * ax; M[20] = by * ay; M[25] = by;
+        M[30] = ax;      M[35] = ay;      M[40] = 1.0;
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) if (r < nr) E_WS(kEwsRoots + r) = 0.5 * (lo[r] + hi[r]);
-}
-
-// real roots of a polynomial of degree <= 10 (ascending coefficients), ascending, distinct -> E_WS(kEwsRoots + ...)
-__device__ __noinline__ int real_roots10(const double (&p_in)[11], double* ws)
-{
-    int d = 10;
-    while (d > 0 && p_in[d] == 0.0) --d;
-    if (d <= 0) return 0;
-    {
-        double lead = 0.0;
-#pragma unroll
-        for (int k = 0; k <= 10; ++k) if (k == d) lead = p_in[k];
-#pragma unroll
-        for (int k = 0; k <= 10; ++k) if (k <= d) E_WS(kEwsChain + k) = p_in[k] / lead;
-    }
-    E_WS(kEwsDeg + 0) = (double)d;
-    for (int k = 1; k <= d; ++k) E_WS(kEwsChain + 11 + k - 1) = (double)k * E_WS(kEwsChain + k);
-    E_WS(kEwsDeg + 1) = (double)(d - 1);
-    int nf = 2;
-    int deg_prev = d, deg_cur = d - 1;
-    while (deg_cur > 0) {
-        // f[nf] = -rem(f[nf-2], f[nf-1]) / |leading coefficient|, remainder built in place in slot nf
-        const int bo = kEwsChain + 11 * (nf - 1), ro = kEwsChain + 11 * nf;
-        const int db = deg_cur;
-        int dr = deg_prev;
-        for (int k = 0; k <= dr; ++k) E_WS(ro + k) = E_WS(kEwsChain + 11 * (nf - 2) + k);
-        const double blead = E_WS(bo + db);
-        while (dr >= db) {
-            const double q = E_WS(ro + dr) / blead;
-            for (int k = 0; k < db; ++k) E_WS(ro + dr - db + k) -= q * E_WS(bo + k);
-            E_WS(ro + dr) = 0.0;
-            --dr;
-        }
-        while (dr >= 0 && E_WS(ro + dr) == 0.0) --dr;
-        if (dr < 0) break;
-        const double sc = fabs(E_WS(ro + dr));
-        for (int k = 0; k <= dr; ++k) E_WS(ro + k) = -E_WS(ro + k) / sc;
-        E_WS(kEwsDeg + nf) = (double)dr;
-        deg_prev = deg_cur; deg_cur = dr;
-        ++nf;
-    }
-    double bound = 0.0;
-    for (int k = 0; k < d; ++k) { const double a = fabs(E_WS(kEwsChain + k)); if (a > bound) bound = a; }
-    bound += 1.0;
-    const int va = e_sturm_changes(ws, nf, -bound);
-    int nr = va - e_sturm_changes(ws, nf, bound);
-    if (nr > 10) nr = 10;
-    if (nr <= 0) return 0;
-    // the bisections of the nr roots are independent (root r follows only its own sign counts), so they advance in lockstep:
-    // every coefficient of the chain is read from LDS once per step and feeds all Horner recurrences.  Each root still sees
-    // exactly the midpoints and counts of the one-root-at-a-time loop of the CPU restatement.  Only as many recurrences as the
-    // lane of the wave with the most real roots needs (typically 4 to 6 of the 10 a degree-10 polynomial can have) are carried.
-    int rmax = 2;
-    if (__ballot(nr > 2) != 0ull) rmax = 4;
-    if (__ballot(nr > 4) != 0ull) rmax = 6;
-    if (__ballot(nr > 6) != 0ull) rmax = 8;
-    if (__ballot(nr > 8) != 0ull) rmax = 10;
-    switch (rmax) {
-        case 2: e_bisect_roots<2>(ws, nf, va, nr, bound); break;
-        case 4: e_bisect_roots<4>(ws, nf, va, nr, bound); break;
-        case 6: e_bisect_roots<6>(ws, nf, va, nr, bound); break;
-        case 8: e_bisect_roots<8>(ws, nf, va, nr, bound); break;
-        default: e_bisect_roots<10>(ws, nf, va, nr, bound); break;
-    }
-    return nr;
-}
-
-// Es: this lane's model slots (LDS), 9 doubles per model.  Out of line on purpose (register pressure of the kernel around it);
-// see launch_filter_E for what that requires of the build.
-__device__ __noinline__ int five_point(const double (&px1)[7][2], const double (&px2)[7][2], double* __restrict__ Es, double* __restrict__ ws)
-{
-    double M[9][5];
-#pragma unroll
-    for (int p = 0; p < 5; ++p) {
-        const double ax = px1[p][0], ay = px1[p][1], bx = px2[p][0], by = px2[p][1];
-        M[0][p] = bx * ax; M[1][p] = bx * ay; M[2][p] = bx;
-        M[3][p] = by * ax; M[4][p] = by * ay; M[5][p] = by;
-        M[6][p] = ax;      M[7][p] = ay;      M[8][p] = 1.0;
-    }
-    double beta[5];
-#pragma unroll
+    E5_SYNC();
+    // ---- Householder QR of the 9 x 5 matrix: every lane derives the reflection of column j from the column itself (identical
+    // values everywhere), lane 0 stores the vector and beta, lanes c = j + 1 .. 4 apply it to their column
     for (int j = 0; j < 5; ++j) {
+        double v[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) v[r] = W[kE5M + 5 * r + j];
         double nrm2 = 0.0;
 #pragma unroll
-        for (int r = j; r < 9; ++r) nrm2 += M[r][j] * M[r][j];
+        for (int r = 0; r < 9; ++r) if (r >= j) nrm2 += v[r] * v[r];
         const double nrm = sqrt(nrm2);
         double bj = 0.0;
         if (nrm != 0.0) {
-            const double alpha = (M[j][j] > 0.0) ? -nrm : nrm;
-            M[j][j] -= alpha;
+            double vjj = 0.0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r == j) vjj = v[r];
+            const double alpha = (vjj > 0.0) ? -nrm : nrm;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r == j) v[r] = vjj - alpha;
             double vn2 = 0.0;
 #pragma unroll
-            for (int r = j; r < 9; ++r) vn2 += M[r][j] * M[r][j];
+            for (int r = 0; r < 9; ++r) if (r >= j) vn2 += v[r] * v[r];
             if (vn2 != 0.0) bj = 2.0 / vn2;
         } else {
 #pragma unroll
-            for (int r = j; r < 9; ++r) M[r][j] = 0.0;
+            for (int r = 0; r < 9; ++r) if (r >= j) v[r] = 0.0;
         }
-        beta[j] = bj;
+        E5_SYNC();                                                  // every lane has read column j
+        if (l == 0) {
 #pragma unroll
-        for (int c = j + 1; c < 5; ++c) {
+            for (int r = 0; r < 9; ++r) if (r >= j) W[kE5M + 5 * r + j] = v[r];
+            W[kE5Beta + j] = bj;
+        }
+        if (l > j && l < 5) {
+            double col[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) col[r] = W[kE5M + 5 * r + l];
             double dot = 0.0;
 #pragma unroll
-            for (int r = j; r < 9; ++r) dot += M[r][j] * M[r][c];
-            const double s = bj * dot;
+            for (int r = 0; r < 9; ++r) if (r >= j) dot += v[r] * col[r];
+            const double sc = bj * dot;
 #pragma unroll
-            for (int r = j; r < 9; ++r) M[r][c] -= s * M[r][j];
+            for (int r = 0; r < 9; ++r) if (r >= j) W[kE5M + 5 * r + l] = col[r] - sc * v[r];
         }
+        E5_SYNC();
     }
-    double N[4][9];
+    // ---- null space: lane e < 4 reflects the unit vector e_{5 + e} back through the five reflections
+    if (l < 4) {
+        double n[9];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int r = 0; r < 9; ++r) N[e][r] = (r == 5 + e) ? 1.0 : 0.0;
+        for (int r = 0; r < 9; ++r) n[r] = (r == 5 + l) ? 1.0 : 0.0;
 #pragma unroll
         for (int j = 4; j >= 0; --j) {
             double dot = 0.0;
 #pragma unroll
-            for (int r = j; r < 9; ++r) dot += M[r][j] * N[e][r];
-            const double s = beta[j] * dot;
+            for (int r = j; r < 9; ++r) dot += W[kE5M + 5 * r + j] * n[r];
+            const double sc = W[kE5Beta + j] * dot;
 #pragma unroll
-            for (int r = j; r < 9; ++r) N[e][r] -= s * M[r][j];
+            for (int r = j; r < 9; ++r) n[r] -= sc * W[kE5M + 5 * r + j];
         }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) W[kE5N + 9 * l + r] = n[r];
     }
-    double E1[9][4];                                  // E_ij as a polynomial of degree 1: [x y z 1]
+    E5_SYNC();
+    // ---- EE^T diagonal polynomials (lanes 0..2) and the determinant constraint, row 0 of A (lane 9)
+    if (l < 3) {
+        double a0[10], a1[10], a2[10];
+        e5_mul11_rows(W, 3 * l, 3 * l, a0); e5_mul11_rows(W, 3 * l + 1, 3 * l + 1, a1); e5_mul11_rows(W, 3 * l + 2, 3 * l + 2, a2);
 #pragma unroll
-    for (int r = 0; r < 9; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) E1[r][e] = N[e][r];
-
-    // ---- the 10 cubic constraints: rows built in registers, stored to the per-lane LDS matrix A[r][k] = E_WS(20 r + k)
-    {
+        for (int k = 0; k < 10; ++k) W[kE5Eii + 10 * l + k] = a0[k] + a1[k] + a2[k];
+    }
+    if (l == 9) {
         double row[20];
 #pragma unroll
         for (int k = 0; k < 20; ++k) row[k] = 0.0;
-        double t1[10], t2[10], d2[10];
-        e_mul11(E1[1], E1[5], t1); e_mul11(E1[2], E1[4], t2);
+        double t1[10], t2[10], d2[10], e4[4];
+        e5_mul11_rows(W, 1, 5, t1); e5_mul11_rows(W, 2, 4, t2);
 #pragma unroll
         for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
-        e_mul21_acc(d2, E1[6], row);
-        e_mul11(E1[2], E1[3], t1); e_mul11(E1[0], E1[5], t2);
+        e5_row(W, 6, e4); e_mul21_acc(d2, e4, row);
+        e5_mul11_rows(W, 2, 3, t1); e5_mul11_rows(W, 0, 5, t2);
 #pragma unroll
         for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
-        e_mul21_acc(d2, E1[7], row);
-        e_mul11(E1[0], E1[4], t1); e_mul11(E1[1], E1[3], t2);
+        e5_row(W, 7, e4); e_mul21_acc(d2, e4, row);
+        e5_mul11_rows(W, 0, 4, t1); e5_mul11_rows(W, 1, 3, t2);
 #pragma unroll
         for (int k = 0; k < 10; ++k) d2[k] = t1[k] - t2[k];
-        e_mul21_acc(d2, E1[8], row);
+        e5_row(W, 8, e4); e_mul21_acc(d2, e4, row);
 #pragma unroll
-        for (int k = 0; k < 20; ++k) E_WS(k) = row[k];
+        for (int k = 0; k < 20; ++k) W[kE5A + k] = row[k];
     }
-    double tr[10];
-    {
-        double acc[10];
+    E5_SYNC();
+    if (l < 10) W[kE5Tr + l] = 0.5 * ((W[kE5Eii + l] + W[kE5Eii + 10 + l]) + W[kE5Eii + 20 + l]);     // 0.5 * ((EET00 + EET11) + EET22)
+    E5_SYNC();
+    // ---- L[i][j] = (E E^T)_ij - delta_ij tr: lane 3 i + j
+    if (l < 9) {
+        const int i = l / 3, j = l % 3;
+        double a0[10], a1[10], a2[10];
+        e5_mul11_rows(W, 3 * i, 3 * j, a0); e5_mul11_rows(W, 3 * i + 1, 3 * j + 1, a1); e5_mul11_rows(W, 3 * i + 2, 3 * j + 2, a2);
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+        for (int k = 0; k < 10; ++k) { double v = a0[k] + a1[k] + a2[k]; if (i == j) v -= W[kE5Tr + k]; W[kE5L + 10 * l + k] = v; }
+    }
+    E5_SYNC();
+    // ---- the nine trace constraints: row 1 + 3 i + j of A = sum over j' of L[i][j'] * E1[3 j' + j], lane 3 i + j
+    if (l < 9) {
+        const int i = l / 3, j = l % 3;
+        double row[20];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double a0[10], a1[10], a2[10];
-            e_mul11(E1[3 * i], E1[3 * i], a0); e_mul11(E1[3 * i + 1], E1[3 * i + 1], a1); e_mul11(E1[3 * i + 2], E1[3 * i + 2], a2);
+        for (int k = 0; k < 20; ++k) row[k] = 0.0;
 #pragma unroll
-            for (int k = 0; k < 10; ++k) { const double eii = a0[k] + a1[k] + a2[k]; acc[k] = (i == 0) ? eii : acc[k] + eii; }
+        for (int jp = 0; jp < 3; ++jp) {
+            double Lp[10], e4[4];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) Lp[k] = W[kE5L + 10 * (3 * i + jp) + k];
+            e5_row(W, 3 * jp + j, e4);
+            e_mul21_acc(Lp, e4, row);
         }
 #pragma unroll
-        for (int k = 0; k < 10; ++k) tr[k] = 0.5 * acc[k];          // 0.5 * ((EET00 + EET11) + EET22)
+        for (int k = 0; k < 20; ++k) W[kE5A + 20 * (1 + l) + k] = row[k];
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double L[3][10];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double a0[10], a1[10], a2[10];
-            e_mul11(E1[3 * i], E1[3 * j], a0); e_mul11(E1[3 * i + 1], E1[3 * j + 1], a1); e_mul11(E1[3 * i + 2], E1[3 * j + 2], a2);
-#pragma unroll
-            for (int k = 0; k < 10; ++k) { L[j][k] = a0[k] + a1[k] + a2[k]; if (i == j) L[j][k] -= tr[k]; }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double row[20];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) row[k] = 0.0;
-            e_mul21_acc(L[0], E1[j], row); e_mul21_acc(L[1], E1[3 + j], row); e_mul21_acc(L[2], E1[6 + j], row);
-#pragma unroll
-            for (int k = 0; k < 20; ++k) E_WS(20 * (1 + 3 * i + j) + k) = row[k];
-        }
-    }
-
-    // ---- Gauss-Jordan on the first 10 columns, partial pivoting (dynamic row indices: LDS).  (Reading a row's entries together
-    // -- static column loop, pivot row in registers -- and unrolling the whole elimination were both measured and are slower in
-    // this register-starved function: E 74.6 / 60.8 ms against 51.8 for this entry-at-a-time form, identical results.)
+    E5_SYNC();
+    // ---- Gauss-Jordan on the first 10 columns, partial pivoting.  Lane l owns column l (and column 16 + l for l < 4).  Per
+    // pivot column c: every lane reads column c (the pivot search and all ten multipliers come from it), then updates its own
+    // columns: swap rows c / piv, scale the pivot row, eliminate -- the one-lane order of operations per entry.
+    bool alive = true;
     for (int c = 0; c < 10; ++c) {
+        double colc[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r) colc[r] = W[kE5A + 20 * r + c];
         int piv = c;
-        double best = fabs(E_WS(20 * c + c));
-        for (int r = c + 1; r < 10; ++r) { const double v = fabs(E_WS(20 * r + c)); if (v > best) { best = v; piv = r; } }
-        if (best == 0.0) return 0;
-        if (piv != c) for (int k = 0; k < 20; ++k) { const double t = E_WS(20 * c + k); E_WS(20 * c + k) = E_WS(20 * piv + k); E_WS(20 * piv + k) = t; }
-        const double inv = 1.0 / E_WS(20 * c + c);
-        for (int k = c; k < 20; ++k) E_WS(20 * c + k) *= inv;
-        for (int r = 0; r < 10; ++r) {
-            if (r == c) continue;
-            const double fct = E_WS(20 * r + c);
-            if (fct == 0.0) continue;
-            for (int k = c; k < 20; ++k) E_WS(20 * r + k) -= fct * E_WS(20 * c + k);
+        double best = 0.0, pval = 0.0, cval = 0.0;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) if (r == c) { best = fabs(colc[r]); pval = colc[r]; cval = colc[r]; }
+#pragma unroll
+        for (int r = 0; r < 10; ++r) if (r > c) { const double v = fabs(colc[r]); if (v > best) { best = v; piv = r; pval = colc[r]; } }
+        if (best == 0.0) alive = false;                             // (the same decision in every lane of the group)
+        E5_SYNC();                                                  // every lane has read column c
+        if (alive) {
+            const double inv = 1.0 / pval;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = l + 16 * h;
+                if (k < 20 && k >= c) {
+                    const double old_c = W[kE5A + 20 * c + k], old_p = W[kE5A + 20 * piv + k];
+                    const double prow = ((piv != c) ? old_p : old_c) * inv;       // pivot row after the swap, scaled
+                    W[kE5A + 20 * c + k] = prow;
+                    if (piv != c) W[kE5A + 20 * piv + k] = old_c;
+#pragma unroll
+                    for (int r = 0; r < 10; ++r) {
+                        if (r == c) continue;
+                        // row r after the swap: the old row c sits in row piv; its multiplier is its entry in column c
+                        const bool moved = (piv != c) && (r == piv);
+                        const double fct = moved ? cval : colc[r];
+                        if (fct == 0.0) continue;
+                        const double cur = moved ? old_c : W[kE5A + 20 * r + k];
+                        W[kE5A + 20 * r + k] = cur - fct * prow;
+                    }
+                }
+            }
         }
+        E5_SYNC();
     }
-    double B[3][3][5];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int lo = 20 * (4 + 2 * q), hi = 20 * (5 + 2 * q);
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
+    if (!alive) return 0;
+    // ---- B(z): lane 3 q + v
+    if (l < 9) {
+        const int q = l / 3, v = l % 3;
+        const int lo = kE5A + 20 * (4 + 2 * q), hi = kE5A + 20 * (5 + 2 * q);
+        double b[5];
+        if (v < 2) {
             const int o = 10 + 3 * v;
-            B[q][v][0] = E_WS(lo + o + 2);
-            B[q][v][1] = E_WS(lo + o + 1) - E_WS(hi + o + 2);
-            B[q][v][2] = E_WS(lo + o) - E_WS(hi + o + 1);
-            B[q][v][3] = -E_WS(hi + o);
-            B[q][v][4] = 0.0;
+            b[0] = W[lo + o + 2];
+            b[1] = W[lo + o + 1] - W[hi + o + 2];
+            b[2] = W[lo + o] - W[hi + o + 1];
+            b[3] = -W[hi + o];
+            b[4] = 0.0;
+        } else {
+            b[0] = W[lo + 19];
+            b[1] = W[lo + 18] - W[hi + 19];
+            b[2] = W[lo + 17] - W[hi + 18];
+            b[3] = W[lo + 16] - W[hi + 17];
+            b[4] = -W[hi + 16];
         }
-        B[q][2][0] = E_WS(lo + 19);
-        B[q][2][1] = E_WS(lo + 18) - E_WS(hi + 19);
-        B[q][2][2] = E_WS(lo + 17) - E_WS(hi + 18);
-        B[q][2][3] = E_WS(lo + 16) - E_WS(hi + 17);
-        B[q][2][4] = -E_WS(hi + 16);
+        E5_SYNC();                                                  // (B overlays nothing that is still read: eii / tr / L are dead)
+#pragma unroll
+        for (int e = 0; e < 5; ++e) W[kE5B + 5 * l + e] = b[e];
+    } else {
+        E5_SYNC();
     }
-    double P[11];
-#pragma unroll
-    for (int k = 0; k <= 10; ++k) P[k] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int r1 = (q + 1) % 3, r2 = (q + 2) % 3;
+    E5_SYNC();
+    // ---- det B(z) = sum of three products: lane q < 3 one term
+    if (l < 3) {
+        const int q = l, r1 = (q + 1) % 3, r2 = (q + 2) % 3;
         double a30[4], a31[4], b30[4], b31[4], c4[5];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { a30[k] = B[r1][0][k]; a31[k] = B[r1][1][k]; b30[k] = B[r2][0][k]; b31[k] = B[r2][1][k]; }
+        for (int k = 0; k < 4; ++k) {
+            a30[k] = W[kE5B + 5 * (3 * r1 + 0) + k]; a31[k] = W[kE5B + 5 * (3 * r1 + 1) + k];
+            b30[k] = W[kE5B + 5 * (3 * r2 + 0) + k]; b31[k] = W[kE5B + 5 * (3 * r2 + 1) + k];
+        }
 #pragma unroll
-        for (int k = 0; k < 5; ++k) c4[k] = B[q][2][k];
+        for (int k = 0; k < 5; ++k) c4[k] = W[kE5B + 5 * (3 * q + 2) + k];
         double m1[7], m2[7], mn[7], term[11];
         e_pmul<3, 3>(a30, b31, m1);
         e_pmul<3, 3>(a31, b30, m2);
@@ -592,20 +563,111 @@ __device__ __noinline__ int five_point(const double (&px1)[7][2], const double (
         for (int k = 0; k <= 6; ++k) mn[k] = m1[k] - m2[k];
         e_pmul<6, 4>(mn, c4, term);
 #pragma unroll
-        for (int k = 0; k <= 10; ++k) P[k] += term[k];
+        for (int k = 0; k <= 10; ++k) W[kE5Term + 11 * q + k] = term[k];
     }
-    const int nr = real_roots10(P, ws);               // overwrites the matrix area (no longer needed)
-    int n_out = 0;
-    for (int s = 0; s < nr; ++s) {
-        const double z = E_WS(kEwsRoots + s);
+    E5_SYNC();
+    if (l < 11) { double pk = 0.0; pk += W[kE5Term + l]; pk += W[kE5Term + 11 + l]; pk += W[kE5Term + 22 + l]; W[kE5P + l] = pk; }
+    E5_SYNC();
+    // ---- real roots of det B (degree <= 10): Sturm chain in the dead matrix area, built coefficient-parallel
+    int d = 10;
+    while (d > 0 && W[kE5P + d] == 0.0) --d;
+    if (d <= 0) return 0;
+    {
+        const double lead = W[kE5P + d];
+        if (l <= d) W[kE5A + l] = W[kE5P + l] / lead;
+        if (l == 15) W[kE5Deg + 0] = (double)d;
+    }
+    E5_SYNC();
+    if (l >= 1 && l <= d) W[kE5A + 11 + l - 1] = (double)l * W[kE5A + l];
+    if (l == 15) W[kE5Deg + 1] = (double)(d - 1);
+    E5_SYNC();
+    int nf = 2;
+    {
+        int deg_prev = d, deg_cur = d - 1;
+        while (deg_cur > 0) {
+            // f[nf] = -rem(f[nf-2], f[nf-1]) / |leading coefficient|, remainder built in place in slot nf
+            const int bo = kE5A + 11 * (nf - 1), ro = kE5A + 11 * nf;
+            const int db = deg_cur;
+            int dr = deg_prev;
+            if (l <= dr) W[ro + l] = W[kE5A + 11 * (nf - 2) + l];
+            E5_SYNC();
+            const double blead = W[bo + db];
+            while (dr >= db) {
+                const double q = W[ro + dr] / blead;
+                E5_SYNC();                                          // every lane has read the leading remainder coefficient
+                if (l < db) W[ro + dr - db + l] -= q * W[bo + l];
+                if (l == 15) W[ro + dr] = 0.0;
+                E5_SYNC();
+                --dr;
+            }
+            while (dr >= 0 && W[ro + dr] == 0.0) --dr;
+            if (dr < 0) break;
+            const double sc = fabs(W[ro + dr]);
+            E5_SYNC();
+            if (l <= dr) W[ro + l] = -W[ro + l] / sc;
+            if (l == 15) W[kE5Deg + nf] = (double)dr;
+            E5_SYNC();
+            deg_prev = deg_cur; deg_cur = dr;
+            ++nf;
+        }
+    }
+    double bound = 0.0;
+    for (int k = 0; k < d; ++k) { const double a = fabs(W[kE5A + k]); if (a > bound) bound = a; }
+    bound += 1.0;
+    // sign changes of the chain at -bound and +bound: lane k evaluates f[k], the count walks the signs in order
+    int va = 0, vb = 0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const double t = side == 0 ? -bound : bound;
+        if (l < nf) {
+            const int dk = (int)W[kE5Deg + l];
+            double v = W[kE5A + 11 * l + dk];
+            for (int c = dk - 1; c >= 0; --c) v = v * t + W[kE5A + 11 * l + c];
+            W[kE5Sgn + l] = (double)((v > 0.0) - (v < 0.0));
+        }
+        E5_SYNC();
+        int changes = 0, last = 0;
+        for (int k = 0; k < nf; ++k) {
+            const int sg = (int)W[kE5Sgn + k];
+            if (sg != 0) { if (last != 0 && sg != last) ++changes; last = sg; }
+        }
+        if (side == 0) va = changes; else vb = changes;
+        E5_SYNC();
+    }
+    int nr = va - vb;
+    if (nr > 10) nr = 10;
+    if (nr <= 0) return 0;
+    // ---- bisection: lane r < nr owns root r (the (r + 1)-th real root from below): its own midpoints and sign counts, 64 steps
+    if (l < nr) {
+        double lo = -bound, hi = bound;
+        for (int it = 0; it < 64; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            int changes = 0, last = 0;
+            for (int k = 0; k < nf; ++k) {
+                const int dk = (int)W[kE5Deg + k];
+                double v = W[kE5A + 11 * k + dk];
+                for (int c = dk - 1; c >= 0; --c) v = v * mid + W[kE5A + 11 * k + c];
+                const int sg = (v > 0.0) - (v < 0.0);
+                if (sg != 0) { if (last != 0 && sg != last) ++changes; last = sg; }
+            }
+            if (va - changes >= l + 1) hi = mid; else lo = mid;
+        }
+        W[kE5Roots + l] = 0.5 * (lo + hi);
+    }
+    E5_SYNC();
+    // ---- one model per root: lane s < nr; models with a vanishing minor are skipped, the others keep their order
+    double model[9];
+    bool valid = false;
+    if (l < nr) {
+        const double z = W[kE5Roots + l];
         double b[3][3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             double p0[4], p1[4], p2[5];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { p0[k] = B[q][0][k]; p1[k] = B[q][1][k]; }
+            for (int k = 0; k < 4; ++k) { p0[k] = W[kE5B + 5 * (3 * q) + k]; p1[k] = W[kE5B + 5 * (3 * q + 1) + k]; }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) p2[k] = B[q][2][k];
+            for (int k = 0; k < 5; ++k) p2[k] = W[kE5B + 5 * (3 * q + 2) + k];
             b[q][0] = e_peval<3>(p0, z); b[q][1] = e_peval<3>(p1, z); b[q][2] = e_peval<4>(p2, z);
         }
         double bx = 0.0, by = 0.0, bw = 0.0;
@@ -617,15 +679,24 @@ __device__ __noinline__ int five_point(const double (&px1)[7][2], const double (
             const double cw = b[r1][0] * b[r2][1] - b[r1][1] * b[r2][0];
             if (fabs(cw) > fabs(bw)) { bx = cx; by = cy; bw = cw; }
         }
-        if (bw == 0.0) continue;
-        const double x = bx / bw, y = by / bw;
+        if (bw != 0.0) {
+            valid = true;
+            const double x = bx / bw, y = by / bw;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) Es[9 * n_out + r] = x * N[0][r] + y * N[1][r] + z * N[2][r] + N[3][r];
-        ++n_out;
+            for (int r = 0; r < 9; ++r) model[r] = x * W[kE5N + r] + y * W[kE5N + 9 + r] + z * W[kE5N + 18 + r] + W[kE5N + 27 + r];
+        }
+    }
+    if (l < 10) W[kE5Flag + l] = (l < nr && valid) ? 1.0 : 0.0;
+    E5_SYNC();
+    int before = 0, n_out = 0;
+    for (int s2 = 0; s2 < nr; ++s2) { const int fl = (int)W[kE5Flag + s2]; if (s2 < l) before += fl; n_out += fl; }
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) Es[9 * before + r] = model[r];
     }
     return n_out;
 }
-#undef E_WS
+#undef E5_SYNC
 
 // fundamental::kernel::EpipolarDistanceError: squared distance of x2 to the epipolar line F x1
 __device__ __forceinline__ double epipolar_dist_err(const double* F, double x1, double y1, double x2, double y2)
@@ -673,7 +744,8 @@ struct FState {
 };
 static_assert(sizeof(FState) <= 1024, "FState must fit the first 1024 bytes of the dynamic LDS region");
 
-constexpr int kChunk = 64;
+constexpr int kChunk = 64;                          // hypotheses per chunk, F and H: one lane of wave 0 per minimal sample
+template <int KIND> struct ChunkOf { static constexpr int n = (KIND == 2) ? kE5Samples : kChunk; };   // E: 16 lanes per sample, 16 samples
 // residual histogram of the model under evaluation (the sort-skipping bound below): 2^kHistSub bins per octave of the residual,
 // kHistBins bins down from the bound on the residuals; LDS header = FState (padded to 1024) + the histogram
 constexpr int kHistBins = 1024, kHistSub = 5, kHistShift = 52 - kHistSub;
@@ -686,11 +758,12 @@ static inline size_t filter_F_lds_bytes_unused_(uint32_t m_cap, int model_kind)
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 #endif
 {
-    // [FState, padded to 1024][histogram: 1024 x u32][Fs: 64 x (9 x MAX_MODELS) doubles][keys: m_cap x u64][idx: m_cap x u32]
+    // [FState, padded to 1024][histogram: 1024 x u32][Fs: chunk x (9 x MAX_MODELS) doubles][keys: m_cap x u64][idx: m_cap x u32]
     const size_t ms = model_kind == 2 ? 90 : 27;
+    const size_t chunk = model_kind == 2 ? kE5Samples : kChunk;
     size_t sort_bytes = (size_t)m_cap * 12;
-    if (model_kind == 2 && sort_bytes < (size_t)kEwsDoubles * 64 * 8) sort_bytes = (size_t)kEwsDoubles * 64 * 8;   // 5-point workspace
-    return (size_t)kHdr + (size_t)kChunk * ms * 8 + sort_bytes;
+    if (model_kind == 2 && sort_bytes < (size_t)kE5Samples * kE5Stride * 8) sort_bytes = (size_t)kE5Samples * kE5Stride * 8;   // 5-point workspaces
+    return (size_t)kHdr + chunk * ms * 8 + sort_bytes;
 }
 
 // KIND 0: fundamental matrix (7-point, <= 3 models, symmetric epipolar error, point-to-line NFA scale)
@@ -932,21 +1005,18 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 #endif
         const uint32_t iter0 = S.iter, nIter0 = S.nIter;
         if (iter0 >= nIter0) break;
-        const uint32_t chunk_n = (nIter0 - iter0 < (uint32_t)kChunk) ? nIter0 - iter0 : (uint32_t)kChunk;
+        constexpr uint32_t CH = (uint32_t)ChunkOf<KIND>::n;
+        const uint32_t chunk_n = (nIter0 - iter0 < CH) ? nIter0 - iter0 : CH;
+        // the hypothesis of the chunk this lane works on: lane c of wave 0 for F / H, the 16-lane group tid / 16 for E
+        const uint32_t hyp = (KIND == 2) ? (tid >> 4) : tid;
         const uint32_t pool_size = S.pool_size;
 
-        // ---- draw + solve one chunk of minimal samples (lane c <-> iteration iter0 + c)
-#ifdef R3DM_E_UNIFORM_SOLVE
-        // all 64 lanes of wave 0 draw and solve (the samples of lanes >= chunk_n belong to iterations beyond the budget and are
-        // never evaluated): the out-of-line solver is then called from wave-uniform control flow
-        if (tid < (uint32_t)kChunk) {
-#else
-        if (tid < chunk_n) {
-#endif
+        // ---- draw + solve one chunk of minimal samples (hypothesis c <-> iteration iter0 + c)
+        if ((KIND == 2 || tid < (uint32_t)kChunk) && hyp < chunk_n) {
             uint32_t pos[7];
             uint32_t cnt = 0, attempt = 0;
             while (cnt < SS) {
-                const uint64_t r = rng_u64(P.seed, id.x, id.y, iter0 + tid, attempt++);
+                const uint64_t r = rng_u64(P.seed, id.x, id.y, iter0 + hyp, attempt++);
                 const uint32_t ps = (uint32_t)(((r >> 32) * (uint64_t)pool_size) >> 32);
                 bool dup = false;
 #pragma unroll
@@ -976,43 +1046,40 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     px2[k][1] = (K2i[3] * xb + K2i[4] * yb + K2i[5]) / w2;
                 }
             }
-            double F3[(KIND == 2) ? 1 : MS];
-            int nm;
-            if constexpr (KIND == 0) nm = seven_point(px1, px2, F3);
-            else if constexpr (KIND == 1) nm = four_point_h(px1, px2, F3);
-            else {
-                // the solver writes its models straight into this lane's LDS slots; its 200-double workspace is the
-                // region behind the hypothesis buffer (the sort buffers of the evaluation phase, idle during the solves)
-                double* ws = reinterpret_cast<double*>(smem + kHdr + kChunk * MS * 8) + tid;
-#ifdef R3DM_BISECT_NANFILL
-                for (int e = 0; e < kEwsDoubles; ++e) ws[(size_t)e * 64] = __builtin_nan("");     // does the solver read workspace it did not write?
-                for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = __builtin_nan("");
-#endif
-#if defined(R3DM_E_SAMPLE_VIA_LDS) && R3DM_E_SAMPLE_VIA_LDS
-                // bisect builds only (made no difference): the sample handed to the callee through LDS, 28 contiguous doubles of this lane
-                typedef double Px72[7][2];
-                double* pbase = reinterpret_cast<double*>(smem + kHdr + kChunk * MS * 8 + kEwsFree * 512) + (size_t)tid * 28;
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    pbase[2 * k] = px1[k][0]; pbase[2 * k + 1] = px1[k][1];
-                    pbase[14 + 2 * k] = px2[k][0]; pbase[14 + 2 * k + 1] = px2[k][1];
+            if constexpr (KIND == 2) {
+                // the 16 lanes of the group solve the sample together; the models go straight into the hypothesis' LDS slots, the
+                // workspaces are the region behind the hypothesis buffer (the sort buffers of the evaluation phase, idle during the solves)
+                double* W = reinterpret_cast<double*>(smem + kHdr + CH * MS * 8) + (size_t)hyp * kE5Stride;
+                const int l = (int)(tid & 15u);
+                const int nm = five_point_coop(px1, px2, Fs + hyp * MS, W, l);
+                for (int e = 9 * nm + l; e < MS; e += kE5Lanes) Fs[hyp * MS + e] = 0.0;
+                if (l == 0) {
+                    S.nm[hyp] = (uint32_t)nm;
+                    if (R3DM_TRACE1(P)) S.dbg_smp[hyp] = pool[pos[0]];
+                    if (R3DM_TRACE2(P) && item == P.trace_item && iter0 + hyp == P.trace_iter) {
+                        double* t = P.trace + 5 * (size_t)(P.trace_cap - 4);
+                        for (int k = 0; k < 7; ++k) t[k] = (double)pool[pos[k < (int)SS ? k : 0]];
+                        t[7] = nm; t[8] = pool_size; t[9] = iter0 + hyp;
+                        for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k < (int)SS ? k : 0];
+                    }
+                    if (R3DM_TRACE3(P) && hyp == 0) S.dbg_pool = pool_size;
                 }
-                nm = five_point(*reinterpret_cast<const Px72*>(pbase), *reinterpret_cast<const Px72*>(pbase + 14), Fs + tid * MS, ws);
-#else
-                nm = five_point(px1, px2, Fs + tid * MS, ws);
-#endif
+            } else {
+                double F3[MS];
+                int nm;
+                if constexpr (KIND == 0) nm = seven_point(px1, px2, F3);
+                else nm = four_point_h(px1, px2, F3);
+                S.nm[tid] = (uint32_t)nm;
+                if (R3DM_TRACE1(P)) S.dbg_smp[tid] = pool[pos[0]];
+                if (R3DM_TRACE2(P) && item == P.trace_item && iter0 + tid == P.trace_iter) {
+                    double* t = P.trace + 5 * (size_t)(P.trace_cap - 4);
+                    for (int k = 0; k < 7; ++k) t[k] = (double)pool[pos[k]];
+                    t[7] = nm; t[8] = pool_size; t[9] = iter0 + tid;
+                    for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k];
+                }
+                if (R3DM_TRACE3(P) && tid == 0) S.dbg_pool = pool_size;
+                for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0;
             }
-            S.nm[tid] = (uint32_t)nm;
-            if (R3DM_TRACE1(P)) S.dbg_smp[tid] = pool[pos[0]];
-            if (R3DM_TRACE2(P) && item == P.trace_item && iter0 + tid == P.trace_iter) {
-                double* t = P.trace + 5 * (size_t)(P.trace_cap - 4);
-                for (int k = 0; k < 7; ++k) t[k] = (double)pool[pos[k]];
-                t[7] = nm; t[8] = pool_size; t[9] = iter0 + tid;
-                for (int k = 0; k < 7; ++k) t[10 + k] = (double)pos[k];
-            }
-            if (R3DM_TRACE3(P) && tid == 0) S.dbg_pool = pool_size;
-            if constexpr (KIND == 2) { for (int e = 9 * nm; e < MS; ++e) Fs[tid * MS + e] = 0.0; }
-            else { for (int e = 0; e < MS; ++e) Fs[tid * MS + e] = (e < 9 * nm) ? F3[e] : 0.0; }
         }
 #ifdef R3DM_BISECT_VMWAIT
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
@@ -1343,7 +1410,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 // for the second workgroup: 40.0 -> 24.8 ms on the 790 pairs of C2, three per CU at 168 registers gains nothing more);
 // the E kernel's 5-point workspace (102 KiB LDS) allows one.
 template <int KIND>
-__global__ __launch_bounds__(256, KIND == 2 ? 1 : 2)
+__global__ __launch_bounds__(256, 2)
 void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
                      uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
 {
@@ -1352,7 +1419,7 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
     const uint32_t item = P.order ? P.order[blockIdx.x] : blockIdx.x;
     const uint32_t m = (uint32_t)(P.offsets[2 * item + 1] - P.offsets[2 * item]);
     if (m <= P.m_cap) {
-        unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + kHdr + kChunk * MS * 8);
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + kHdr + ChunkOf<KIND>::n * MS * 8);
         uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
         acransac_body<KIND, false>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
     } else {
@@ -1364,12 +1431,10 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
 }
 
 // The essential-matrix instantiation lives in its own translation unit (kernels_filter_e.hip = this file with
-// R3DM_FILTER_ONLY_E, built with -mllvm -amdgpu-spill-sgpr-to-vgpr=0): it is the one kernel that calls out-of-line device
-// functions (five_point -> real_roots10) from divergent control flow, and with hipcc's default of parking spilled SGPRs in the
-// lanes of a VGPR across those calls it returned different inlier sets from run to run as soon as the debug hooks that happened
-// to reshape the code around the call site were compiled out (profiles/r02_d_efilter_bisect.txt, r02_f_efilter_variants.txt:
-// SGPR spills to memory -> 6 of 6 runs equal to the oracle; a full vmcnt wait, a wave-uniform call, the sample handed over in
-// LDS instead of the caller's scratch frame -> no effect).  F and H have no calls and keep the default.
+// R3DM_FILTER_ONLY_E) only to compile in parallel with F / H.  (Round 2 needed -mllvm -amdgpu-spill-sgpr-to-vgpr=0 there: the
+// one-lane 5-point solver was called out of line from divergent control flow and SGPRs spilled into VGPR lanes across the calls
+// gave run-to-run different inlier sets.  The cooperative solver above has no calls and no spills; the option is gone, and
+// tests/test_gpu_fullsize.py::test_filters_are_deterministic_when_workgroups_share_a_cu runs against the default build.)
 hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds);
 #ifdef R3DM_FILTER_ONLY_E
 hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds)

@@ -177,3 +177,15 @@ def test_stage_from_pixels_equals_the_cpu_restatement(oracle, tmp_path, kind):
     v2 = [dict(v, gray=None, bgr=None) for v in views]; v2[2] = views[2]
     rep3 = api.compute_matches_stage([0, 0], d, v2, 0.001, 0.6, 9, True, False, False)
     assert rep3.images_extracted == 1 and open(os.path.join(d, "matches.f.bin"), "rb").read() == blob
+    # the kept-alive stage object (r3dm_stage_*): same files from a second and third collection run on the same object, an
+    # approximate arm under the default policy is served by the exhaustive matcher on these real-valued views
+    st = api.Stage([0])
+    for f in os.listdir(d):
+        os.remove(os.path.join(d, f))
+    r4 = st.run(d, views, 0.001, 0.6, 9, True, False, False, batches_in_flight=1, images_per_batch=3)
+    assert r4.images_extracted == 5 and open(os.path.join(d, "matches.f.bin"), "rb").read() == blob
+    r5 = st.run(d, [dict(v, gray=None, bgr=None) for v in views], 0.001, 0.6, 0, True, False, False)
+    assert r5.images_extracted == 0 and r5.match_was_exhaustive == 1 and open(os.path.join(d, "matches.f.bin"), "rb").read() == blob
+    r6 = st.run(d, [dict(v, gray=None, bgr=None) for v in views], 0.001, 0.6, 0, True, False, False, arms_as_requested=True)
+    assert r6.match_was_exhaustive == 0 and r6.n_putative_pairs >= 4
+    st.close()
