@@ -112,6 +112,12 @@ int r3dm_set_hamming_mfma(r3dm_ctx* ctx, int enable);
 
 /* ---- putative matching ----
  * pairs_ij: n_pairs x 2 view ids (I, J); J's rows are the queries, I's rows the dataset.
+ * Descriptor lengths and speed: the tensor kernels serve float / byte rows of up to 64, 128, 144 and 256 elements (rows are padded
+ * to the next of these: SIFT-128, LIOP-144, SURF-64, 256-D learned descriptors) and binary rows of 29..32 / 61..64 bytes.  Any other
+ * L2 length (> 256 elements) is matched by the exact scan alone -- one workgroup per query row streaming the dataset: the same
+ * results, two to three orders of magnitude slower; r3dm_stats.n_exact_fallback then equals n_queries.  Lengths that are not a
+ * multiple of 4 (37, 61 ...) run on the tensor kernels like any other; only their uncertified queries (a handful per million) are
+ * re-done by that per-query scan instead of the batched one, because the reference's 4-way unrolled sum ends in a scalar tail.
  * dist_ratio: Lowe ratio (0.6 default in the reference, src/Regard3DFeatures.cpp:129);
  * squared_metric != 0 applies ratio^2 (RegionsMatcherT ctor flag, true for L2).
  * The result holds only non-empty pairs, ordered by (I, J), matches ordered by (i_, j_). */

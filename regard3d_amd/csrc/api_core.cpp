@@ -48,6 +48,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
                       &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill, &c->f_soff, &c->f_order};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
+    for (auto& im : c->spare) if (im) im->release();
     c->pin_desc.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -182,26 +183,38 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         R3DM_HIP(c, h.xy.ensure((size_t)n * 8));
         R3DM_HIP(c, hipMemcpyAsync(h.xy.p, xy, (size_t)n * 8, hipMemcpyDefault, c->stream));
     }
-    // position classes (IndMatchDecorator de-duplication needs to know which features share a position)
+    // position classes (IndMatchDecorator de-duplication needs to know which features share a position): canon[k] = the smallest
+    // index among the features at k's position.  One hash pass (equal floats <-> equal bit patterns once -0 is folded into +0; a NaN
+    // equals nothing, itself included); host positions are read where they are.
     if (xy && n > 1) {
-        std::vector<float> hxy((size_t)n * 2);
-        R3DM_HIP(c, hipMemcpyAsync(hxy.data(), h.xy.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-        R3DM_HIP(c, hipStreamSynchronize(c->stream));
-        std::vector<uint32_t> ord(n);
-        std::iota(ord.begin(), ord.end(), 0u);
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
-            if (hxy[2 * a] != hxy[2 * b]) return hxy[2 * a] < hxy[2 * b];
-            if (hxy[2 * a + 1] != hxy[2 * b + 1]) return hxy[2 * a + 1] < hxy[2 * b + 1];
-            return a < b;
-        });
+        std::vector<float> hxy_copy;
+        const float* hxy = xy;
+        {
+            hipPointerAttribute_t at{};
+            const bool on_device = hipPointerGetAttributes(&at, xy) == hipSuccess && (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged);
+            (void)hipGetLastError();
+            if (on_device) {
+                hxy_copy.resize((size_t)n * 2);
+                R3DM_HIP(c, hipMemcpyAsync(hxy_copy.data(), h.xy.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+                R3DM_HIP(c, hipStreamSynchronize(c->stream));
+                hxy = hxy_copy.data();
+            }
+        }
         std::vector<uint32_t> canon(n);
         bool dup = false;
-        for (uint32_t k = 0; k < n;) {
-            uint32_t e = k + 1;
-            while (e < n && hxy[2 * ord[e]] == hxy[2 * ord[k]] && hxy[2 * ord[e] + 1] == hxy[2 * ord[k] + 1]) ++e;
-            for (uint32_t q = k; q < e; ++q) canon[ord[q]] = ord[k];     // ord[k] is the smallest index of the group
-            if (e - k > 1) dup = true;
-            k = e;
+        {
+            std::unordered_map<uint64_t, uint32_t> first;
+            first.reserve((size_t)n * 2);
+            for (uint32_t k = 0; k < n; ++k) {
+                const float fx = hxy[2 * (size_t)k], fy = hxy[2 * (size_t)k + 1];
+                canon[k] = k;
+                if (fx != fx || fy != fy) continue;                           // NaN: a class of its own
+                uint32_t bx, by;
+                const float zx = fx == 0.0f ? 0.0f : fx, zy = fy == 0.0f ? 0.0f : fy;
+                std::memcpy(&bx, &zx, 4); std::memcpy(&by, &zy, 4);
+                auto it = first.emplace(((uint64_t)bx << 32) | by, k);
+                if (!it.second) { canon[k] = it.first->second; dup = true; }  // ascending k: the stored index is the smallest of the class
+            }
         }
         if (dup) {
             h.has_dup = true;
@@ -245,7 +258,8 @@ static int r3dm_set_image_impl(r3dm_ctx* c, uint32_t view_id, uint32_t width, ui
     auto it = c->slot_of.find(view_id);
     if (it == c->slot_of.end()) {
         slot = (uint32_t)c->imgs.size();
-        c->imgs.emplace_back(new HostImage());
+        if (!c->spare.empty()) { c->imgs.emplace_back(std::move(c->spare.back())); c->spare.pop_back(); }      // buffers of a cleared view
+        else c->imgs.emplace_back(new HostImage());
         c->slot_of[view_id] = slot;
     } else slot = it->second;
     return stage_into_slot(c, slot, view_id, width, height, desc, n, dim, dtype, xy);
@@ -262,7 +276,14 @@ extern "C" int r3dm_clear_images(r3dm_ctx* c)
     if (!c) return R3DM_ERR_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (auto& im : c->imgs) if (im) im->release();
+    // the views are forgotten, their device buffers are kept for the next collection (a stage object that lives across runs, or a
+    // bench loop, registers views of the same sizes again and again: six hipMalloc per view were most of the registration time)
+    for (auto& im : c->imgs) {
+        if (!im) continue;
+        if (im->borrowed) { im->release(); continue; }
+        im->live = false; im->has_K = false; im->ann_K = 0; im->compact_ready = false; im->n = 0;
+        c->spare.push_back(std::move(im));
+    }
     c->imgs.clear();
     c->slot_of.clear();
     return R3DM_OK;

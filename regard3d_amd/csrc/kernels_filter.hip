@@ -735,6 +735,7 @@ struct FState {
     uint32_t cnt, cur_k, flag, chunk_n;
     uint32_t wave_cnt[4];
     double   red_v[4];
+    double   red_b[4];       // reduction slots of the sort-skipping bound
     uint32_t red_k[4];
     uint32_t nm[64];
     uint32_t dbg_smp[64];    // debug trace: first sample index of each hypothesis of the chunk
@@ -992,7 +993,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         S.reserve = reserve; S.nIter = P.max_iter - reserve; S.iter = 0;
         S.pool_size = m; S.n_inl = 0; S.acMode = !(P.precision_px < __builtin_huge_val());
         S.n_models = 0; S.iters_done = 0;
+        S.cnt = 0u;
     }
+#pragma unroll
+    for (int j = 0; j < kHistBins / 256; ++j) hist[tid + 256 * j] = 0u;
     wg_sync_global();          // points, pool and logcombi table go through global memory
 
 #ifdef R3DM_E_TIMING
@@ -1108,10 +1112,8 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 #endif
                 // (order of the compacted entries: whatever the atomics give -- the sort below fixes the order, `total` and the
                 // set do not depend on it)
-                if (tid == 0) S.cnt = 0u;
-#pragma unroll
-                for (int j = 0; j < kHistBins / 256; ++j) hist[tid + 256 * j] = 0u;
-                wg_sync_t<SPILL>();
+                // (S.cnt and the histogram are zero here: cleared once at kernel start and again at the end of every model, behind the
+                // barrier that closes it -- one barrier less per model than clearing them here)
                 // four batches of 256 matches per trip: the point loads (global memory, 32 bytes per match) of all four are in
                 // flight before the first residual is needed
                 for (uint32_t base = 0; base < m; base += 1024) {
@@ -1207,10 +1209,9 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     }
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wmin, off); wmin = o < wmin ? o : wmin; }
-                    if (lane == 0) S.red_v[wave] = wmin;
+                    if (lane == 0) S.red_b[wave] = wmin;
                     wg_sync_t<SPILL>();
-                    wmin = fmin(fmin(S.red_v[0], S.red_v[1]), fmin(S.red_v[2], S.red_v[3]));
-                    wg_sync_t<SPILL>();                           // red_v is reused by the NFA reduction below
+                    wmin = fmin(fmin(S.red_b[0], S.red_b[1]), fmin(S.red_b[2], S.red_b[3]));      // (own slots: the NFA reduction below uses red_v, no barrier in between)
                     hopeless = !R3DM_DBG(P) && (wmin - 1.0e-6 >= S.minNFA);
                     if (R3DM_DBG(P)) S_bound = wmin;              // developer build: nothing is skipped, the bound is checked against the NFA
                 }
@@ -1303,7 +1304,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 #pragma unroll
                         for (int e = 0; e < 9; ++e) S.bestF[e] = F[e];
                     }
+                    S.cnt = 0u;                                   // for the next model (every reader of this model's count is behind the barrier above)
                 }
+#pragma unroll
+                for (int j = 0; j < kHistBins / 256; ++j) hist[tid + 256 * j] = 0u;     // ... and its histogram: last read before the commit barrier
                 wg_sync_t<SPILL>();
             }
             // ---- end of iteration `it`: ACRANSAC's pool / budget update.  Thread 0 is about to change the loop bounds that

@@ -122,6 +122,7 @@ struct r3dm_ctx {
     int n_cu = 0;
     uint64_t hbm = 0;
     std::vector<std::unique_ptr<HostImage>> imgs;           // slot -> image
+    std::vector<std::unique_ptr<HostImage>> spare;          // views dropped by r3dm_clear_images: their device buffers serve the next ones
     std::unordered_map<uint32_t, uint32_t> slot_of;         // view id -> slot
     DevBuf d_imgs;                                           // ImgDev[slots]
     // scratch (grown on demand, reused across calls)

@@ -9,7 +9,7 @@ cd "$(dirname "$0")/.."
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
 mkdir -p build/bisect
-$HIPCC $FLAGS -DR3DM_E_TIMING -mllvm -amdgpu-spill-sgpr-to-vgpr=0 -x hip -c regard3d_amd/csrc/kernels_filter_e.hip -o build/bisect/kernels_filter_e_timing.o &
+$HIPCC $FLAGS -DR3DM_E_TIMING -x hip -c regard3d_amd/csrc/kernels_filter_e.hip -o build/bisect/kernels_filter_e_timing.o &
 $HIPCC $FLAGS -DR3DM_E_TIMING -x hip -c regard3d_amd/csrc/kernels_filter.hip -o build/bisect/kernels_filter_timing.o &
 wait
 objs=$(ls build/product/*.o | grep -v "kernels_filter_e.o\|kernels_filter.o")
