@@ -530,3 +530,81 @@ def akaze_detect_mldb(img, threshold=0.001, cap=200000):
     kps = np.zeros((cap, 4), np.float32); resp = np.zeros(cap, np.float32); desc = np.zeros((cap, 61), np.uint8)
     n = min(lib().orc_akaze_detect_mldb(_p(img), w, h, C.c_float(threshold), _p(kps), _p(desc), cap, _p(resp)), cap)
     return kps[:n].copy(), desc[:n].copy(), resp[:n].copy()
+
+
+# ---- HNSW plugin path: the restatement (hnsw.c) and the reference-built library (oracle/_ref) ----
+class HnswIndex:
+    """orc_hnsw: built by the restatement (hnswlib's single-thread insertion) or wrapped around exported arrays"""
+
+    def __init__(self, handle, data, M):
+        self._h, self._data, self.M = handle, data, M
+
+    def __del__(self):
+        try:
+            lib().orc_hnsw_free(C.c_void_p(self._h))
+        except Exception:
+            pass
+
+    def export(self):
+        n = self._data.shape[0]; M = self.M
+        L = lib(); L.orc_hnsw_up_rows.restype = C.c_uint32
+        rows = L.orc_hnsw_up_rows(C.c_void_p(self._h))
+        levels = np.zeros(n, np.int32); links0 = np.zeros((n, 1 + 2 * M), np.int32); up_off = np.zeros(n + 1, np.int32)
+        up = np.zeros((max(rows, 1), 1 + M), np.int32); ep = C.c_int32(0); ml = C.c_int32(0)
+        L.orc_hnsw_export(C.c_void_p(self._h), _p(levels), _p(links0), _p(up_off), _p(up), C.byref(ep), C.byref(ml))
+        return dict(levels=levels, links0=links0, up_off=up_off, up_links=up[:rows], enterpoint=ep.value, maxlevel=ml.value)
+
+    def knn2(self, query, ef):
+        query = np.ascontiguousarray(query, np.float32)
+        idx = np.zeros((len(query), 2), np.int32); dist = np.zeros((len(query), 2), np.float32)
+        rc = lib().orc_hnsw_knn2(C.c_void_p(self._h), _p(query), len(query), ef, _p(idx), _p(dist), None)
+        if rc != 0:
+            raise ValueError("orc_hnsw_knn2 failed")
+        return idx, dist
+
+
+HNSW_PRESETS = {"fast": (5, 112, 5), "medium": (15, 112, 10), "precise": (19, 100, 15)}      # M, efConstruction, ef (src/R3DComputeMatches.cpp:533-565)
+
+
+def hnsw_levels(n, M, seed=100):
+    out = np.zeros(n, np.int32)
+    lib().orc_hnsw_levels(n, M, seed, _p(out))
+    return out
+
+
+def hnsw_build(data, M, ef_construction, seed=100) -> HnswIndex:
+    data = np.ascontiguousarray(data, np.float32)
+    L = lib(); L.orc_hnsw_build.restype = C.c_void_p
+    h = L.orc_hnsw_build(_p(data), data.shape[0], data.shape[1], M, ef_construction, seed)
+    if not h:
+        raise ValueError("orc_hnsw_build: dim % 16 != 0 or M out of range")
+    return HnswIndex(h, data, M)
+
+
+def hnsw_from_arrays(data, M, ix) -> HnswIndex:
+    data = np.ascontiguousarray(data, np.float32)
+    L = lib(); L.orc_hnsw_from_arrays.restype = C.c_void_p
+    lv = np.ascontiguousarray(ix["levels"], np.int32); l0 = np.ascontiguousarray(ix["links0"], np.int32)
+    uo = np.ascontiguousarray(ix["up_off"], np.int32); ul = np.ascontiguousarray(ix["up_links"], np.int32).reshape(-1, 1 + M)
+    if ul.shape[0] == 0:
+        ul = np.zeros((1, 1 + M), np.int32)
+    h = L.orc_hnsw_from_arrays(_p(data), data.shape[0], data.shape[1], M, _p(lv), _p(l0), _p(uo), _p(ul), int(ix["enterpoint"]), int(ix["maxlevel"]))
+    return HnswIndex(h, data, M)
+
+
+def ref_hnsw_export(dataset, query, M, ef_construction, ef):
+    """the reference-built HierarchicalNSW (single-thread insertion) as arrays + its searchKnn(ef, 2) of `query`"""
+    R = ref_lib()
+    if R is None:
+        raise RuntimeError("oracle/_ref/libref_hnsw.so not built")
+    dataset = np.ascontiguousarray(dataset, np.float32); query = np.ascontiguousarray(query, np.float32)
+    n, dim = dataset.shape; nq = query.shape[0]
+    levels = np.zeros(n, np.int32); links0 = np.zeros((n, 1 + 2 * M), np.int32); up_off = np.zeros(n + 1, np.int32)
+    cap = n + 64
+    up = np.zeros((cap, 1 + M), np.int32); ep = C.c_int32(0); ml = C.c_int32(0)
+    idx = np.zeros((nq, 2), np.int32); dist = np.zeros((nq, 2), np.float32)
+    rc = R.ref_hnsw_export(_p(dataset), n, _p(query), nq, dim, M, ef_construction, ef, _p(levels), _p(links0), _p(up_off), _p(up), cap,
+                           C.byref(ep), C.byref(ml), _p(idx), _p(dist))
+    if rc != 0:
+        raise RuntimeError(f"ref_hnsw_export failed ({rc})")
+    return dict(levels=levels, links0=links0, up_off=up_off, up_links=up[:up_off[n]], enterpoint=ep.value, maxlevel=ml.value), idx, dist

@@ -207,6 +207,18 @@ int   orc_akaze_detect(const float* image, int w, int h, float dthreshold, float
 
 /* ---- KGraph plugin path (config C5): oracle/kgraph.c.  src/thirdparty/kgraph/kgraph.cpp:411-552 (search),
  * :703-997 (NN-descent), :660-700 (reverse), src/utils/matcher_kgraph.h, src/R3DComputeMatches.cpp:808-902. */
+/* ---- hnsw.c: the HNSW plugin path (hnswlib restated: levels, single-thread build, searchKnn; pinned by oracle/_ref) ---- */
+typedef struct orc_hnsw orc_hnsw;
+float     orc_hnsw_l2(const float* a, const float* b, uint32_t dim);
+void      orc_hnsw_levels(uint32_t n, uint32_t M, uint32_t seed, int32_t* out);
+orc_hnsw* orc_hnsw_build(const float* data, uint32_t n, uint32_t dim, uint32_t M, uint32_t ef_construction, uint32_t seed);
+orc_hnsw* orc_hnsw_from_arrays(const float* data, uint32_t n, uint32_t dim, uint32_t M, const int32_t* levels, const int32_t* links0,
+                               const int32_t* up_off, const int32_t* up_links, int32_t enterpoint, int32_t maxlevel);
+void      orc_hnsw_free(orc_hnsw* g);
+uint32_t  orc_hnsw_up_rows(const orc_hnsw* g);
+void      orc_hnsw_export(const orc_hnsw* g, int32_t* levels, int32_t* links0, int32_t* up_off, int32_t* up_links, int32_t* enterpoint, int32_t* maxlevel);
+int       orc_hnsw_knn2(const orc_hnsw* g, const float* query, uint32_t nq, uint32_t ef, int32_t* idx, float* dist, uint64_t* n_dist);
+
 typedef struct orc_kgraph orc_kgraph;
 orc_kgraph* orc_kgraph_build_nndescent(const float* data, uint32_t n, uint32_t dim,
                                        uint32_t K, uint32_t L, uint32_t S, uint32_t R, uint32_t iterations,
