@@ -91,11 +91,15 @@ public:
     // How the approximate arms of the dispatch (0 FLANN, 1-3 KGraph, 5 MRPT, 6-8 HNSW) are served.  kArmsFastest (default): by the
     // EXHAUSTIVE matcher whenever r3dm_exhaustive_is_faster says it is not slower on the registered views -- on LIOP-144 every
     // approximate arm is then exact and >= 2x faster than the graph search (the GUI's default arm 0 included); kArmsAsRequested:
-    // always by the graph matcher with the arm's preset (r3dm_ann_params_for_algorithm), as in rounds 1-2.
+    // arms 6-8 by hnsw_match itself (hnswlib's searchKnn on a batch-built HNSW index, r3dm_match_pairs_hnsw; descriptor lengths 64 /
+    // 128 / 144 / 256), arms 1-3 by kgraph_match, and the arms whose index is not built here (0 FLANN kd-trees, 5 MRPT, HNSW on other
+    // lengths) by the graph matcher with a preset of at least the arm's recall (r3dm_ann_params_for_algorithm).
     enum ArmsPolicy { kArmsFastest = 0, kArmsAsRequested = 1 };
     void setApproximateArmsPolicy(ArmsPolicy p) { arms_policy_ = p; }
     // which matcher the last computeMatches call ran: true = exhaustive (arm 4 / 9, or an approximate arm routed to it)
     bool lastMatchWasExhaustive() const { return last_exhaustive_; }
+    // ... true = hnsw_match (arms 6-8 under kArmsAsRequested)
+    bool lastMatchWasHnsw() const { return last_hnsw_; }
     // updateProgress(float, const wxString&) (src/R3DComputeMatches.cpp:2664): the GUI hook, called with the reference's own
     // fractions and messages (0.7 "Find putative matches", 0.8 / 0.9 / 0.95 "Calculate ... matrix", :2000,2107,2133,2209)
     using ProgressFn = void (*)(float progress, const char* msg, void* user);
@@ -145,7 +149,7 @@ private:
     r3dm_multi* feat_multi_ = nullptr;     // contexts of the features stage (feat_conc_ per device), created on first use
     int feat_conc_ = 2, feat_batch_ = 8;
     ArmsPolicy arms_policy_ = kArmsFastest;
-    bool last_exhaustive_ = true;
+    bool last_exhaustive_ = true, last_hnsw_ = false;
     ImageProviderFn provider_ = nullptr;
     ImageReleaseFn provider_release_ = nullptr;
     void* provider_user_ = nullptr;

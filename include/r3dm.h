@@ -227,6 +227,56 @@ int r3dm_kgraph_index(r3dm_ctx* ctx, uint32_t view_id, uint32_t index_K, uint32_
  * accounting calls this between passes.  The registered descriptors stay. */
 int r3dm_drop_indices(r3dm_ctx* ctx);
 
+/* ---- approximate matching: the HNSW plugin path (matchingAlgorithm 6 / 7 / 8) ----
+ * Replaces hnsw_match (src/R3DComputeMatches.cpp:497-593): per first view I an HNSW index over its descriptors
+ * (ArrayMatcher_hnsw::Build, src/utils/matcher_hnsw.h:53-83 -> hnswlib::HierarchicalNSW, src/thirdparty/hnswlib/hnswlib/hnswalg.h),
+ * per query row of J hnswlib's searchKnn(row, 2) with setEf(ef) (SearchNeighbours, matcher_hnsw.h:150-190), then the same ratio
+ * test / de-duplication / pair rules as r3dm_match_pairs.  F32 / U8 descriptors of length 64, 128, 144 or 256 (hnswlib's
+ * L2SqrSIMD16Ext, dim % 16 == 0), squared-L2 metric, at most 262,144 rows per view; views with fewer than 128 rows are scanned.
+ *
+ * SEARCH: hnswlib's algorithm step for step -- greedy descent through the upper layers, searchBaseLayerST on layer 0 with the two
+ * priority queues moved as libstdc++'s heaps move them (ties between equally distant rows included), distances summed in the order
+ * of hnswlib's AVX kernel.  On an index written by the reference-built library r3dm_hnsw_knn2_on_index returns hnswlib's own
+ * rows and distances BIT FOR BIT (tests/test_gpu_hnsw.py against tests/golden/hnsw_ref_index.npz).
+ * BUILD: hnswlib inserts rows one after another, each insertion searching the graph so far, and the reference adds rows 1 .. n-1
+ * from an OpenMP loop -- its index differs from run to run.  Here the index is built in one batch, deterministically: hnswlib's
+ * level draw (same engine and seed), per layer exact candidates (layer 0: the 64 closest of the exact 32-NN graph with reverse
+ * edges; above: the 32 nearest members), hnswlib's neighbour-selection heuristic over them (at most 2M links on layer 0, M above),
+ * free places refilled with the closest rejected candidates.  ef_construction has no role in it (accepted, ignored).  At the
+ * reference's ef the batch-built index finds the true nearest row at least as often as the reference-built one (same tests;
+ * CPU model: oracle/hnsw.c orc_hnsw_build_batch, GPU parity with it bit-exact). */
+typedef struct {
+    uint32_t M;                /* links per row above layer 0 (2M on layer 0), 2..32   (reference presets 5 / 15 / 19)        */
+    uint32_t ef_construction;  /* the reference's build beam (112 / 112 / 100): unused by the batch construction             */
+    uint32_t ef;               /* search beam, 1..512 (searchKnn uses max(ef, 2))      (reference presets 5 / 10 / 15)        */
+    uint32_t seed;             /* level draw (hnswlib: random_seed = 100)                                                    */
+} r3dm_hnsw_params;
+/* preset = matchingAlgorithm - 6 of the reference: 0 "HNSW fast", 1 "medium", anything else "precise" */
+int r3dm_hnsw_preset(int preset, r3dm_hnsw_params* out);
+int r3dm_match_pairs_hnsw(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                          const r3dm_hnsw_params* params, r3dm_graph** out);
+/* ArrayMatcher_hnsw-shaped call: index `dataset` (>= 128 rows), searchKnn(row, 2) of every query row.  out_idx -1 / out_dist +inf
+ * where the search found fewer than two rows. */
+int r3dm_hnsw_knn2(r3dm_ctx* ctx, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
+                   uint32_t dim, const r3dm_hnsw_params* params, int32_t* out_idx, float* out_dist);
+/* An HNSW index as arrays in hnswlib's own shape: links0 = n x (1 + 2M) ints (count, then links, -1 padded), up_off = n + 1 ints
+ * (first upper-layer row of a node; layer L >= 1 of node i is row up_off[i] + L - 1), up_links = up_rows x (1 + M) ints. */
+typedef struct {
+    uint32_t M;
+    const int32_t* links0;
+    const int32_t* up_off;
+    const int32_t* up_links;
+    uint32_t up_rows;
+    int32_t enterpoint, maxlevel;
+} r3dm_hnsw_arrays;
+/* searchKnn(row, 2) with setEf(ef) on an index handed over as arrays -- e.g. one written by hnswlib itself (any n_dataset >= 2).
+ * The arrays are validated (R3DM_ERR_INVALID when a link or an offset is out of range). */
+int r3dm_hnsw_knn2_on_index(r3dm_ctx* ctx, const float* dataset, uint32_t n_dataset, uint32_t dim, const r3dm_hnsw_arrays* index,
+                            const float* query, uint32_t n_query, uint32_t ef, int32_t* out_idx, float* out_dist);
+/* the index of a registered view (built if necessary) in that shape; up_links holds up_cap rows, *up_rows receives the number needed */
+int r3dm_hnsw_index(r3dm_ctx* ctx, uint32_t view_id, const r3dm_hnsw_params* params, int32_t* links0, int32_t* up_off,
+                    int32_t* up_links, uint32_t up_cap, uint32_t* up_rows, int32_t* enterpoint, int32_t* maxlevel);
+
 /* ---- keypoint detection: Fast-A-KAZE ----
  * The "Fast-AKAZE" arm of Regard3DFeatures::detectKeypoints (src/Regard3DFeatures.cpp:596-617): cv::AKAZE2::create() with its
  * defaults (src/thirdparty/fast-akaze/AKAZEConfig.h:18-43: 4 octaves x 4 sublevels, PM_G2 diffusivity), setThreshold(threshold),
@@ -338,6 +388,9 @@ int r3dm_multi_match_pairs(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_p
 /* the same deal for the graph matcher (kgraph_match, config C5): a device builds the index of every image I whose row it owns */
 int r3dm_multi_match_pairs_kgraph(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
                                   const r3dm_kgraph_params* params, r3dm_graph** out);
+/* ... and for the HNSW matcher (hnsw_match, matchingAlgorithm 6..8) */
+int r3dm_multi_match_pairs_hnsw(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                                const r3dm_hnsw_params* params, r3dm_graph** out);
 int r3dm_multi_filter_F(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                         uint64_t seed, r3dm_graph** out, double* F_out);
 int r3dm_multi_filter_H(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
@@ -404,6 +457,9 @@ typedef struct {
     double   detect_algorithmic_bytes; /* HBM bytes the pass structure implies: every stencil pass reads / writes whole image planes once */
     double   ms_liop_wall;         /* host + device time of the LIOP half of the last features pass (patch maps, two launches, copy back) */
     double   ms_feature_files;     /* time spent writing the .feat / .desc files of the last features pass                              */
+    /* r3dm_match_pairs_hnsw (ms_ann_build / ms_ann_search / n_ann_built / n_ann_dist are shared with the KGraph path) */
+    uint64_t n_hnsw_launches;      /* launches of the HNSW search kernel                                                                */
+    uint64_t n_hnsw_retries;       /* ... of those, repeats because a query's candidate heap outgrew its LDS room                       */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -247,6 +247,102 @@ orc_hnsw* orc_hnsw_build(const float* data, uint32_t n, uint32_t dim, uint32_t M
     return g;
 }
 
+/* ---------------------------------------------------------------- the index the HIP path builds (DESIGN.md "HNSW")
+ * hnswlib inserts rows one after another, every insertion searching the graph built so far: sequential by construction (and the
+ * reference's own index varies from run to run, rows 1 .. n-1 being added from an OpenMP loop).  The HIP path builds the same KIND of
+ * index in one batch, deterministically:
+ *   levels      the reference's own draw (orc_hnsw_levels); entry point = the first row of the highest level, as in hnswlib
+ *   layer 0     candidates of a row = its list in the exact 32-nearest-neighbour graph completed with reverse edges, 64 closest
+ *               (orc_kgraph_build_exact: the index of the KGraph path), re-measured with hnswlib's distance
+ *   layer L>0   candidates of a member = its min(32, members - 1) nearest members of the layer (exact scan)
+ *   selection   hnswlib's getNeighborsByHeuristic2 (hnswalg.h:282-322) over the candidates in ascending (distance, row) order, at most
+ *               2M links on layer 0 and M above; free places are then given to the closest rejected candidates (the paper's
+ *               keepPrunedConnections); a candidate list shorter than the limit is kept whole (hnswlib: size < M returns)
+ *   list order  farthest first, the order hnswlib's own lists come out of its max-heap
+ * Chosen among four variants by recall at the reference's ef on the fixture scenes (forward-M + back links as in
+ * mutuallyConnectNewElement, with / without refill: lower degree and LOWER recall than the reference-built index; this one: higher
+ * in all six preset x scene cases -- tests/test_oracle_hnsw.py holds that).  Searching is hnswlib's searchKnn, unchanged
+ * (orc_hnsw_knn2).  GPU parity against this model is bit-exact. */
+typedef struct { float d; uint32_t id; } hb_c;
+static int hb_cmp(const void* a, const void* b)
+{
+    const hb_c* x = (const hb_c*)a; const hb_c* y = (const hb_c*)b;
+    if (x->d < y->d) return -1;
+    if (x->d > y->d) return 1;
+    return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+/* cand (ascending, nc <= 64) -> list[0] = count, list[1..] = the kept rows farthest first */
+static void hb_select(const float* data, uint32_t dim, const hb_c* cand, uint32_t nc, uint32_t limit, int32_t* list)
+{
+    hb_c ret[64], pruned[64]; uint32_t nret = 0, np = 0;
+    if (nc < limit) { for (uint32_t k = 0; k < nc; ++k) ret[nret++] = cand[k]; }
+    else {
+        for (uint32_t k = 0; k < nc && nret < limit; ++k) {
+            int good = 1;
+            for (uint32_t s = 0; s < nret; ++s)
+                if (orc_hnsw_l2(data + (size_t)ret[s].id * dim, data + (size_t)cand[k].id * dim, dim) < cand[k].d) { good = 0; break; }
+            if (good) ret[nret++] = cand[k]; else pruned[np++] = cand[k];
+        }
+        for (uint32_t k = 0; k < np && nret < limit; ++k) ret[nret++] = pruned[k];
+        qsort(ret, nret, sizeof(hb_c), hb_cmp);
+    }
+    list[0] = (int32_t)nret;
+    for (uint32_t k = 0; k < nret; ++k) list[1 + k] = (int32_t)ret[nret - 1 - k].id;
+}
+
+orc_hnsw* orc_hnsw_build_batch(const float* data, uint32_t n, uint32_t dim, uint32_t M, uint32_t seed)
+{
+    if (!data || n < 2 || (dim & 15u) || M < 2 || M > 32) return NULL;
+    orc_hnsw* g = (orc_hnsw*)calloc(1, sizeof(orc_hnsw));
+    g->n = n; g->dim = dim; g->M = M; g->maxM0 = 2 * M; g->efc = 0; g->data = data;
+    g->level = (int32_t*)malloc((size_t)n * 4);
+    g->l0 = (int32_t*)calloc((size_t)n * (1 + g->maxM0), 4);
+    g->up = (int32_t**)calloc(n, sizeof(int32_t*));
+    orc_hnsw_levels(n, M, seed, g->level);
+    g->enter = 0; g->maxlevel = g->level[0];
+    for (uint32_t i = 1; i < n; ++i) if (g->level[i] > g->maxlevel) { g->maxlevel = g->level[i]; g->enter = (int32_t)i; }
+    for (uint32_t i = 0; i < n; ++i) if (g->level[i]) g->up[i] = (int32_t*)calloc((size_t)g->level[i] * (1 + M), 4);
+
+    orc_kgraph* kg = orc_kgraph_build_exact(data, n, dim, 32, 64);
+    if (!kg) { orc_hnsw_free(g); return NULL; }
+    uint64_t* off = (uint64_t*)malloc(((size_t)n + 1) * 8);
+    uint32_t* ids = (uint32_t*)malloc((size_t)orc_kgraph_edges(kg) * 4 + 4);
+    orc_kgraph_export(kg, off, ids, NULL);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long i = 0; i < (long)n; ++i) {
+        hb_c c[64]; uint32_t k = 0;
+        for (uint64_t e = off[i]; e < off[i + 1] && k < 64; ++e) { c[k].id = ids[e]; c[k].d = orc_hnsw_l2(data + (size_t)i * dim, data + (size_t)ids[e] * dim, dim); ++k; }
+        qsort(c, k, sizeof(hb_c), hb_cmp);
+        hb_select(data, dim, c, k, g->maxM0, g->l0 + (size_t)i * (1 + g->maxM0));
+    }
+    free(off); free(ids); orc_kgraph_free(kg);
+
+    uint32_t* mem = (uint32_t*)malloc((size_t)n * 4);
+    for (int L = 1; L <= g->maxlevel; ++L) {
+        uint32_t nm = 0;
+        for (uint32_t i = 0; i < n; ++i) if (g->level[i] >= L) mem[nm++] = i;
+        const uint32_t K = nm - 1 < 32 ? nm - 1 : 32;
+#pragma omp parallel for schedule(dynamic, 16)
+        for (long a = 0; a < (long)nm; ++a) {
+            hb_c c[33]; uint32_t k = 0;
+            const uint32_t i = mem[a];
+            for (uint32_t b = 0; b < nm && K; ++b) {
+                if (b == (uint32_t)a) continue;
+                hb_c e = { orc_hnsw_l2(data + (size_t)i * dim, data + (size_t)mem[b] * dim, dim), mem[b] };
+                uint32_t p = k;                                    /* insertion keeps ascending (distance, row): members come in row order */
+                while (p > 0 && e.d < c[p - 1].d) --p;
+                if (p >= K) continue;
+                for (uint32_t t = (k < K ? k : K - 1); t > p; --t) c[t] = c[t - 1];
+                c[p] = e;
+                if (k < K) ++k;
+            }
+            hb_select(data, dim, c, k, M, g->up[i] + (size_t)(L - 1) * (1 + M));
+        }
+    }
+    free(mem);
+    return g;
+}
+
 /* an index handed over as data (e.g. exported from the reference-built library): the arrays are borrowed, not copied */
 orc_hnsw* orc_hnsw_from_arrays(const float* data, uint32_t n, uint32_t dim, uint32_t M, const int32_t* levels, const int32_t* links0,
                                const int32_t* up_off, const int32_t* up_links, int32_t enterpoint, int32_t maxlevel)
@@ -341,4 +437,53 @@ int orc_hnsw_knn2(const orc_hnsw* g, const float* query, uint32_t nq, uint32_t e
     }
     if (n_dist) *n_dist = evals;       /* (upper levels only; the layer-0 evaluations are counted by the GPU side's own statistics) */
     return 0;
+}
+
+/* ---------------------------------------------------------------- hnsw_match (src/R3DComputeMatches.cpp:497-593)
+ * One index per first image (builder 0: the batch construction of the HIP path, 1: hnswlib's single-thread insertion), searchKnn(ef, 2)
+ * of every row of J, then RegionsMatcherT::MatchDistanceRatio's ratio test and de-duplication (orc_ratio_dedup_f32, squared metric).
+ * Views with fewer than min_rows rows are scanned exactly (what the HIP path does below 128 rows).  CSR convention of
+ * orc_match_collection. */
+int64_t orc_match_collection_hnsw(int n_images, const float* const* desc, const int* n_rows, const float* const* xy, int dim,
+                                  const uint32_t* pairs, int64_t n_pairs, float dist_ratio, int builder, uint32_t M,
+                                  uint32_t ef_construction, uint32_t ef, uint32_t seed, uint32_t min_rows,
+                                  uint32_t* counts, orc_match* out, int64_t out_cap)
+{
+    orc_match** res = (orc_match**)calloc((size_t)n_pairs, sizeof(orc_match*));
+    memset(counts, 0, sizeof(uint32_t) * (size_t)n_pairs);
+    for (int I = 0; I < n_images; ++I) {
+        orc_hnsw* g = NULL;
+        for (int64_t p = 0; p < n_pairs; ++p) {
+            if ((int)pairs[2 * p] != I) continue;
+            const uint32_t J = pairs[2 * p + 1];
+            if (n_rows[I] < 2 || n_rows[J] < 1) continue;
+            const int scan = (uint32_t)n_rows[I] < min_rows;
+            if (!g && !scan) {
+                g = builder == 0 ? orc_hnsw_build_batch(desc[I], (uint32_t)n_rows[I], (uint32_t)dim, M, seed)
+                                 : orc_hnsw_build(desc[I], (uint32_t)n_rows[I], (uint32_t)dim, M, ef_construction, seed);
+                if (!g) break;
+            }
+            int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)n_rows[J]);
+            float* dist = (float*)malloc(sizeof(float) * 2 * (size_t)n_rows[J]);
+            const int rc = scan ? orc_knn2_l2_f32(desc[I], n_rows[I], desc[J], n_rows[J], dim, idx, dist)
+                                : orc_hnsw_knn2(g, desc[J], (uint32_t)n_rows[J], ef, idx, dist, NULL);
+            if (rc == 0) {
+                orc_match* tmp = (orc_match*)malloc(sizeof(orc_match) * (size_t)n_rows[J]);
+                const int m = orc_ratio_dedup_f32(idx, dist, n_rows[J], xy ? xy[I] : NULL, xy ? xy[J] : NULL, dist_ratio, 1, tmp);
+                if (m > 0) { res[p] = tmp; counts[p] = (uint32_t)m; } else free(tmp);
+            }
+            free(idx); free(dist);
+        }
+        orc_hnsw_free(g);
+    }
+    int64_t total = 0;
+    for (int64_t p = 0; p < n_pairs; ++p) total += counts[p];
+    int64_t rc = total > out_cap ? -1 : total, w = 0;
+    for (int64_t p = 0; p < n_pairs; ++p)
+        if (res[p]) {
+            if (rc >= 0) { memcpy(out + w, res[p], sizeof(orc_match) * counts[p]); w += counts[p]; }
+            free(res[p]);
+        }
+    free(res);
+    return rc;
 }

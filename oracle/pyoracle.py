@@ -581,6 +581,16 @@ def hnsw_build(data, M, ef_construction, seed=100) -> HnswIndex:
     return HnswIndex(h, data, M)
 
 
+def hnsw_build_batch(data, M, seed=100) -> HnswIndex:
+    """the batch construction the HIP path uses (hnsw.c: orc_hnsw_build_batch)"""
+    data = np.ascontiguousarray(data, np.float32)
+    L = lib(); L.orc_hnsw_build_batch.restype = C.c_void_p
+    h = L.orc_hnsw_build_batch(_p(data), data.shape[0], data.shape[1], M, seed)
+    if not h:
+        raise ValueError("orc_hnsw_build_batch: dim % 16 != 0 or M out of range")
+    return HnswIndex(h, data, M)
+
+
 def hnsw_from_arrays(data, M, ix) -> HnswIndex:
     data = np.ascontiguousarray(data, np.float32)
     L = lib(); L.orc_hnsw_from_arrays.restype = C.c_void_p
@@ -590,6 +600,31 @@ def hnsw_from_arrays(data, M, ix) -> HnswIndex:
         ul = np.zeros((1, 1 + M), np.int32)
     h = L.orc_hnsw_from_arrays(_p(data), data.shape[0], data.shape[1], M, _p(lv), _p(l0), _p(uo), _p(ul), int(ix["enterpoint"]), int(ix["maxlevel"]))
     return HnswIndex(h, data, M)
+
+
+def match_collection_hnsw(descs, xys, pairs, ratio, preset="precise", builder="batch", min_rows=128, seed=100):
+    """hnsw_match over a collection (hnsw.c: orc_match_collection_hnsw); builder "batch" = the HIP path's index, "hnswlib" = the reference's"""
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    n_img = len(descs)
+    descs = [np.ascontiguousarray(d, np.float32) for d in descs]
+    dim = descs[0].shape[1]
+    desc_p = (C.c_void_p * n_img)(*[d.ctypes.data for d in descs])
+    n_rows = np.array([d.shape[0] for d in descs], np.int32)
+    if xys is not None:
+        xys = [np.ascontiguousarray(x, np.float32) for x in xys]
+        xy_p = (C.c_void_p * n_img)(*[x.ctypes.data for x in xys])
+    else:
+        xy_p = None
+    M, efc, ef = HNSW_PRESETS[preset] if isinstance(preset, str) else preset
+    counts = np.zeros(len(pairs), np.uint32)
+    cap_out = int(sum(int(n_rows[j]) for j in pairs[:, 1])) + 1
+    out = np.zeros((cap_out, 2), np.uint32)
+    L = lib(); L.orc_match_collection_hnsw.restype = C.c_int64
+    tot = L.orc_match_collection_hnsw(n_img, desc_p, _p(n_rows), xy_p, dim, _p(pairs), C.c_int64(len(pairs)), C.c_float(ratio),
+                                      0 if builder == "batch" else 1, M, efc, ef, seed, min_rows, _p(counts), _p(out), C.c_int64(cap_out))
+    if tot < 0:
+        raise RuntimeError("orc_match_collection_hnsw: output capacity")
+    return counts, out[:tot].copy()
 
 
 def ref_hnsw_export(dataset, query, M, ef_construction, ef):

@@ -212,11 +212,16 @@ typedef struct orc_hnsw orc_hnsw;
 float     orc_hnsw_l2(const float* a, const float* b, uint32_t dim);
 void      orc_hnsw_levels(uint32_t n, uint32_t M, uint32_t seed, int32_t* out);
 orc_hnsw* orc_hnsw_build(const float* data, uint32_t n, uint32_t dim, uint32_t M, uint32_t ef_construction, uint32_t seed);
+orc_hnsw* orc_hnsw_build_batch(const float* data, uint32_t n, uint32_t dim, uint32_t M, uint32_t seed);
 orc_hnsw* orc_hnsw_from_arrays(const float* data, uint32_t n, uint32_t dim, uint32_t M, const int32_t* levels, const int32_t* links0,
                                const int32_t* up_off, const int32_t* up_links, int32_t enterpoint, int32_t maxlevel);
 void      orc_hnsw_free(orc_hnsw* g);
 uint32_t  orc_hnsw_up_rows(const orc_hnsw* g);
 void      orc_hnsw_export(const orc_hnsw* g, int32_t* levels, int32_t* links0, int32_t* up_off, int32_t* up_links, int32_t* enterpoint, int32_t* maxlevel);
+int64_t   orc_match_collection_hnsw(int n_images, const float* const* desc, const int* n_rows, const float* const* xy, int dim,
+                                    const uint32_t* pairs, int64_t n_pairs, float dist_ratio, int builder, uint32_t M,
+                                    uint32_t ef_construction, uint32_t ef, uint32_t seed, uint32_t min_rows,
+                                    uint32_t* counts, orc_match* out, int64_t out_cap);
 int       orc_hnsw_knn2(const orc_hnsw* g, const float* query, uint32_t nq, uint32_t ef, int32_t* idx, float* dist, uint64_t* n_dist);
 
 typedef struct orc_kgraph orc_kgraph;

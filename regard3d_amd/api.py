@@ -26,6 +26,7 @@ EXPORTS = [
     "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_stage_create", "r3dm_stage_run", "r3dm_stage_destroy", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
     "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
+    "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_transfer_counts", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
@@ -48,7 +49,8 @@ class Stats(C.Structure):
                 ("n_split_mfma", C.c_uint64), ("n_views_staged", C.c_uint64),
                 ("n_hamming_mfma", C.c_uint64), ("n_detect_images", C.c_uint64), ("n_ann_rows16", C.c_uint64), ("n_ann_rows8", C.c_uint64), ("n_ann_dot8", C.c_uint64),
                 ("ms_detect_kernels", C.c_double), ("detect_algorithmic_bytes", C.c_double),
-                ("ms_liop_wall", C.c_double), ("ms_feature_files", C.c_double)]
+                ("ms_liop_wall", C.c_double), ("ms_feature_files", C.c_double),
+                ("n_hnsw_launches", C.c_uint64), ("n_hnsw_retries", C.c_uint64)]
 
 
 class FeaturesTotals(C.Structure):
@@ -174,6 +176,26 @@ class KGraphParams(C.Structure):
         return kp
 
 
+class HnswParams(C.Structure):
+    """r3dm_hnsw_params: M links per row (2M on layer 0), ef_construction (unused by the batch build), ef search beam, seed of the level draw"""
+    _fields_ = [("M", C.c_uint32), ("ef_construction", C.c_uint32), ("ef", C.c_uint32), ("seed", C.c_uint32)]
+
+    @staticmethod
+    def preset(which) -> "HnswParams":
+        """which: 0 / "fast", 1 / "medium", 2 / "precise" (matchingAlgorithm 6 / 7 / 8 of the reference)"""
+        code = {"fast": 0, "medium": 1, "precise": 2}.get(which, which if isinstance(which, int) else 2)
+        hp = HnswParams()
+        if load_library().r3dm_hnsw_preset(int(code), C.byref(hp)) != 0:
+            raise R3dmError("r3dm_hnsw_preset failed")
+        return hp
+
+
+class HnswArrays(C.Structure):
+    """r3dm_hnsw_arrays: an HNSW index in hnswlib's own shape"""
+    _fields_ = [("M", C.c_uint32), ("links0", C.c_void_p), ("up_off", C.c_void_p), ("up_links", C.c_void_p), ("up_rows", C.c_uint32),
+                ("enterpoint", C.c_int32), ("maxlevel", C.c_int32)]
+
+
 class PairReport(C.Structure):
     _fields_ = [("threshold_px", C.c_double), ("nfa", C.c_double), ("iterations", C.c_uint32),
                 ("models", C.c_uint32), ("inliers", C.c_uint32), ("reserved", C.c_uint32)]
@@ -245,6 +267,11 @@ def load_library():
     L.r3dm_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_kgraph_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, u32, u32, vp, vp]
     L.r3dm_kgraph_index.argtypes = [vp, u32, u32, vp, vp]
+    L.r3dm_hnsw_preset.argtypes = [C.c_int, vp]
+    L.r3dm_match_pairs_hnsw.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
+    L.r3dm_hnsw_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, vp]
+    L.r3dm_hnsw_knn2_on_index.argtypes = [vp, vp, u32, u32, vp, vp, u32, u32, vp, vp]
+    L.r3dm_hnsw_index.argtypes = [vp, u32, vp, vp, vp, vp, u32, vp, vp, vp]
     L.r3dm_drop_indices.argtypes = [vp]
     L.r3dm_graph_num_pairs.argtypes = [vp]; L.r3dm_graph_num_pairs.restype = u64
     L.r3dm_graph_num_matches.argtypes = [vp]; L.r3dm_graph_num_matches.restype = u64
@@ -476,6 +503,49 @@ class Context:
         adj = np.zeros((n_rows, 64), np.uint32); deg = np.zeros(n_rows, np.uint32)
         self._check(self._L.r3dm_kgraph_index(self._h, view_id, index_K, _ptr(adj), _ptr(deg)), "r3dm_kgraph_index")
         return adj, deg
+
+    def match_pairs_hnsw(self, pairs, dist_ratio: float = 0.6, params: "HnswParams" = None) -> Graph:
+        """hnsw_match: hnswlib's searchKnn on a batch-built HNSW index per first view (matchingAlgorithm 6 / 7 / 8)"""
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        hp = params if params is not None else HnswParams.preset(2)
+        h = C.c_void_p()
+        self._check(self._L.r3dm_match_pairs_hnsw(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0], dist_ratio,
+                                                  C.addressof(hp), C.byref(h)), "r3dm_match_pairs_hnsw")
+        return Graph(h.value)
+
+    def hnsw_knn2(self, dataset, query, params: "HnswParams" = None):
+        dataset = np.ascontiguousarray(dataset, np.float32); query = np.ascontiguousarray(query, np.float32)
+        hp = params if params is not None else HnswParams.preset(2)
+        nq = query.shape[0]
+        idx = np.full((max(nq, 1), 2), -1, np.int32); dist = np.zeros((max(nq, 1), 2), np.float32)
+        self._check(self._L.r3dm_hnsw_knn2(self._h, _ptr(dataset), dataset.shape[0], _ptr(query), nq, dataset.shape[1],
+                                           C.addressof(hp), _ptr(idx), _ptr(dist)), "r3dm_hnsw_knn2")
+        return idx[:nq], dist[:nq]
+
+    def hnsw_knn2_on_index(self, dataset, index: dict, M: int, query, ef: int):
+        """searchKnn(row, 2) with setEf(ef) on an index given as arrays (keys links0, up_off, up_links, enterpoint, maxlevel)"""
+        dataset = np.ascontiguousarray(dataset, np.float32); query = np.ascontiguousarray(query, np.float32)
+        l0 = np.ascontiguousarray(index["links0"], np.int32); uo = np.ascontiguousarray(index["up_off"], np.int32)
+        ul = np.ascontiguousarray(index["up_links"], np.int32).reshape(-1, 1 + M)
+        a = HnswArrays(M, l0.ctypes.data, uo.ctypes.data, ul.ctypes.data if ul.size else None, ul.shape[0], int(index["enterpoint"]), int(index["maxlevel"]))
+        nq = query.shape[0]
+        idx = np.full((max(nq, 1), 2), -1, np.int32); dist = np.zeros((max(nq, 1), 2), np.float32)
+        self._check(self._L.r3dm_hnsw_knn2_on_index(self._h, _ptr(dataset), dataset.shape[0], dataset.shape[1], C.addressof(a),
+                                                    _ptr(query), nq, ef, _ptr(idx), _ptr(dist)), "r3dm_hnsw_knn2_on_index")
+        return idx[:nq], dist[:nq]
+
+    def hnsw_index(self, view_id: int, n_rows: int, params: "HnswParams" = None) -> dict:
+        """the HNSW index of a registered view as arrays in hnswlib's shape (r3dm_hnsw_arrays)"""
+        hp = params if params is not None else HnswParams.preset(2)
+        M = hp.M
+        l0 = np.zeros((n_rows, 1 + 2 * M), np.int32); uo = np.zeros(n_rows + 1, np.int32)
+        cap = n_rows + 64
+        ul = np.zeros((cap, 1 + M), np.int32)
+        rows = C.c_uint32(0); ep = C.c_int32(0); ml = C.c_int32(0)
+        self._check(self._L.r3dm_hnsw_index(self._h, view_id, C.addressof(hp), _ptr(l0), _ptr(uo), _ptr(ul), cap, C.byref(rows), C.byref(ep), C.byref(ml)),
+                    "r3dm_hnsw_index")
+        return dict(links0=l0, up_off=uo, up_links=ul[:rows.value].copy(), enterpoint=ep.value, maxlevel=ml.value,
+                    levels=np.diff(uo).astype(np.int32))
 
     def filter_F(self, putative: Graph, max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489,
                  want_F: bool = False):

@@ -45,7 +45,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
                       &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->m_raw, &c->m_peer, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
                       &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch,
                       &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
-                      &c->a_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill, &c->f_soff, &c->f_order};
+                      &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill, &c->f_soff, &c->f_order};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
     for (auto& im : c->spare) if (im) im->release();
@@ -131,7 +131,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
     HostImage& h = *c->imgs[slot];
     h.view_id = view_id; h.n = n; h.dim = dim; h.dtype = dtype; h.width = width; h.height = height;
     h.has_xy = (xy != nullptr); h.has_dup = false; h.live = true;
-    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0; h.compact_ready = false;
+    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0; h.hnsw_M = 0; h.compact_ready = false;
     if (dtype == R3DM_BIN) {
         h.words = (dim + 3) / 4;
         const uint32_t n_pad = n + 8;
@@ -281,7 +281,7 @@ extern "C" int r3dm_clear_images(r3dm_ctx* c)
     for (auto& im : c->imgs) {
         if (!im) continue;
         if (im->borrowed) { im->release(); continue; }
-        im->live = false; im->has_K = false; im->ann_K = 0; im->compact_ready = false; im->n = 0;
+        im->live = false; im->has_K = false; im->ann_K = 0; im->hnsw_M = 0; im->compact_ready = false; im->n = 0;
         c->spare.push_back(std::move(im));
     }
     c->imgs.clear();

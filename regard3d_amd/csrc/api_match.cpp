@@ -13,7 +13,7 @@ extern "C" int r3dm_graph_merge(const r3dm_graph* const* parts, uint32_t n_parts
 
 // compaction + ordering + de-duplication of nn_idx[pair][*] (finalize_pairs_kernel), copy back, append the non-empty
 // pairs to `g` in job order.  Shared by the exhaustive and the graph-search drivers.
-static int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_stride, uint32_t sort_cap,
+int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_stride, uint32_t sort_cap,
                           uint64_t n_queries, uint32_t max_nJ, r3dm_graph* g, int32_t* knn_idx_host, float* knn_dist_host)
 {
     const uint32_t P = (uint32_t)jobs.size();
@@ -502,7 +502,7 @@ static int ensure_compact_rows(r3dm_ctx* c, std::vector<uint32_t> slots)
 }
 
 // builds the graph index of every listed slot that does not hold one for this K
-static int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t K)
+int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t K)
 {
     std::sort(slots.begin(), slots.end());
     slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
@@ -776,7 +776,7 @@ extern "C" int r3dm_kgraph_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_da
 extern "C" int r3dm_drop_indices(r3dm_ctx* c)
 {
     if (!c) return R3DM_ERR_INVALID;
-    for (auto& h : c->imgs) if (h) h->ann_K = 0;             // the device pointers stay valid until the rebuild replaces them
+    for (auto& h : c->imgs) if (h) { h->ann_K = 0; h->hnsw_M = 0; }            // the device pointers stay valid until the rebuild replaces them
     return R3DM_OK;
 }
 

@@ -276,6 +276,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         return ctx_ ? r3dm_match_pairs(ctx_, p.data(), p.size() / 2, ratio, squared, out) : r3dm_multi_match_pairs(multi_, p.data(), p.size() / 2, ratio, squared, out); };
     auto match_kgraph = [&](const std::vector<uint32_t>& p, float ratio, const r3dm_kgraph_params* kpp, r3dm_graph** out) {
         return ctx_ ? r3dm_match_pairs_kgraph(ctx_, p.data(), p.size() / 2, ratio, kpp, out) : r3dm_multi_match_pairs_kgraph(multi_, p.data(), p.size() / 2, ratio, kpp, out); };
+    auto match_hnsw = [&](const std::vector<uint32_t>& p, float ratio, const r3dm_hnsw_params* hpp, r3dm_graph** out) {
+        return ctx_ ? r3dm_match_pairs_hnsw(ctx_, p.data(), p.size() / 2, ratio, hpp, out) : r3dm_multi_match_pairs_hnsw(multi_, p.data(), p.size() / 2, ratio, hpp, out); };
     auto filter_F = [&](const r3dm_graph* g, r3dm_graph** out) {
         return ctx_ ? r3dm_filter_F(ctx_, g, 4.0, 2048, seed_, R3DM_ERR_SYMMETRIC_EPIPOLAR, out, nullptr) : r3dm_multi_filter_F(multi_, g, 4.0, 2048, seed_, out, nullptr); };
     auto filter_E = [&](const r3dm_graph* g, r3dm_graph** out) {
@@ -357,7 +359,16 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     // an approximate arm whose job the exhaustive matcher does at least as fast -- and exactly -- is served by it (setApproximateArmsPolicy)
     if (use_kgraph && arms_policy_ == kArmsFastest && r3dm_exhaustive_is_faster(ctx_ ? ctx_ : r3dm_multi_ctx(multi_, 0)) == 1) use_kgraph = false;
     last_exhaustive_ = !use_kgraph;
-    if (use_kgraph) {
+    // arms 6 / 7 / 8 taken literally (kArmsAsRequested) run hnsw_match itself: hnswlib's search on a batch-built HNSW index
+    // (r3dm_match_pairs_hnsw), for the descriptor lengths hnswlib's SIMD16 distance serves; other lengths keep the graph matcher
+    const bool use_hnsw = use_kgraph && arms_policy_ == kArmsAsRequested && matchingAlgorithm >= 6 && matchingAlgorithm <= 8 &&
+                          dtype_ != R3DM_BIN && (dim_ == 64 || dim_ == 128 || dim_ == 144 || dim_ == 256);
+    last_hnsw_ = use_hnsw;
+    if (use_hnsw) {
+        r3dm_hnsw_params hp;
+        (void)r3dm_hnsw_preset(matchingAlgorithm - 6, &hp);
+        rc = match_hnsw(pairs, params.distRatio_, &hp, &putative);
+    } else if (use_kgraph) {
         rc = match_kgraph(pairs, params.distRatio_, &kp, &putative);
     } else {
         rc = match(pairs, params.distRatio_, squared, &putative);

@@ -1,0 +1,389 @@
+// kernels_hnsw.hip -- the HNSW plugin path (matchingAlgorithm 6..8 of /root/reference/src/R3DComputeMatches.cpp:2035-2062;
+// hnsw_match :497-593, ArrayMatcher_hnsw src/utils/matcher_hnsw.h:53-83,150-190, hnswlib src/thirdparty/hnswlib/hnswlib/hnswalg.h).
+//
+//   hnsw_search_kernel   hnswlib's searchKnn(query, 2) with setEf(ef), one wavefront per query: greedy descent through the upper
+//                        layers (hnswalg.h:745-768), then searchBaseLayerST on layer 0 (:214-280).  The two std::priority_queues
+//                        are binary heaps in LDS moved exactly as libstdc++'s push_heap / pop_heap move them (hnswlib compares heap
+//                        entries by distance only, so WHICH of two equally distant rows leaves first is decided by the sift order;
+//                        integer-valued SIFT bins produce such ties all the time).  Distances are L2SqrSIMD16Ext's AVX arm
+//                        (space_l2.h:40-75): eight interleaved partial sums, added left to right, no FMA -- lane l of an 8-lane
+//                        group IS accumulator l, eight rows per wavefront step.  On an index exported from the reference-built
+//                        library the results equal hnswlib's bit for bit (tests/test_gpu_hnsw.py).
+//   hnsw_link_kernel     the batch construction (DESIGN.md "HNSW", CPU model oracle/hnsw.c: orc_hnsw_build_batch): one wavefront
+//                        per (row, layer): candidates (layer 0: the row's list in the exact 32-NN graph of kernels_ann.hip; above:
+//                        its 32 nearest members of the layer by an exact scan), hnswlib's getNeighborsByHeuristic2 (:282-322) over
+//                        them in ascending (distance, row) order, refill with the closest rejected, list written farthest first.
+//
+// The distance evaluations are the same instruction sequence everywhere (hn_dist8), compiled with -ffp-contract=off.
+#include "r3dm_internal.hpp"
+
+namespace r3dm {
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+struct HnPair { float d; uint32_t id; };
+
+// lanes of one wavefront meet here: compiler fence + scheduling barrier (LDS operations of one wavefront execute in program order)
+#define HN_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// bits/stl_heap.h __push_heap with CompareByFirst (a max-heap on d)
+__device__ __forceinline__ void hn_sift_up(HnPair* v, uint32_t hole, float d, uint32_t id)
+{
+    while (hole > 0) {
+        const uint32_t parent = (hole - 1) >> 1;
+        const HnPair p = v[parent];
+        if (!(p.d < d)) break;
+        v[hole] = p; hole = parent;
+    }
+    v[hole] = HnPair{d, id};
+}
+__device__ __forceinline__ void hn_push(HnPair* v, uint32_t& n, float d, uint32_t id) { hn_sift_up(v, n, d, id); n += 1; }
+// pop_heap + pop_back: __pop_heap -> __adjust_heap
+__device__ __forceinline__ void hn_pop(HnPair* v, uint32_t& n)
+{
+    if (n > 1) {
+        const uint32_t len = n - 1;
+        const HnPair value = v[len];
+        uint32_t hole = 0, second = 0;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            const HnPair a = v[second], b = v[second - 1];
+            if (a.d < b.d) { second--; v[hole] = b; } else v[hole] = a;
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            v[hole] = v[second - 1]; hole = second - 1;
+        }
+        hn_sift_up(v, hole, value.d, value.id);
+    }
+    n -= 1;
+}
+
+// accumulator l (= lane & 7) of L2SqrSIMD16Ext over one row: acc_l = sum_i (a[8i + l] - b[8i + l])^2 in increasing i
+template <int NB>
+__device__ __forceinline__ float hn_acc(const float (&q)[NB], const float* __restrict__ row, uint32_t l)
+{
+    float x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) x[i] = row[8 * i + l];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { const float t = q[i] - x[i]; acc = acc + t * t; }
+    return acc;
+}
+// ... and the horizontal sum acc0 + acc1 + ... + acc7, left to right; valid in every lane of the 8-lane group
+__device__ __forceinline__ float hn_hsum8(float acc, uint32_t lane)
+{
+    const int base = (int)(lane & ~7u);
+    float r = __shfl(acc, base);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = r + __shfl(acc, base + k);
+    return r;
+}
+template <int NB>
+__device__ __forceinline__ void hn_load_q(float (&q)[NB], const float* __restrict__ row, uint32_t l)
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) q[i] = row[8 * i + l];
+}
+
+// distances from the row in q to the `size` rows ids[0 .. size): dist[j] (LDS) for every j; skip[j] != 0 leaves dist[j] unset
+template <int NB, typename SKIP>
+__device__ __forceinline__ void hn_dist_list(const float (&q)[NB], const float* __restrict__ rows, uint32_t dim, const int32_t* ids, uint32_t size,
+                                             float* dist, uint32_t lane, SKIP skip)
+{
+    const uint32_t g = lane >> 3, l = lane & 7u;
+    for (uint32_t j0 = 0; j0 < size; j0 += 8) {
+        const uint32_t j = j0 + g;
+        const bool on = j < size;
+        const uint32_t c = on ? (uint32_t)ids[j] : 0u;
+        const bool work = on && !skip(c);
+        float acc = 0.f;
+        if (work) acc = hn_acc<NB>(q, rows + (size_t)c * dim, l);
+        const float d = hn_hsum8(acc, lane);
+        if (work && l == 0) dist[j] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ search
+template <int NB>
+__global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams P)
+{
+    extern __shared__ unsigned char hn_smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const HnswSearchJob job = P.jobs[blockIdx.y];
+    const uint32_t qi = blockIdx.x * 4 + wave;
+    // per-wave LDS: visited bits | top heap (ef + 1) | candidate heap (cand_cap) | dist[64] | ids[64]
+    const uint32_t per_wave = P.flag_words * 4 + (P.ef + 1) * 8 + P.cand_cap * 8 + 64 * 4 + 64 * 4;
+    unsigned char* base = hn_smem + (size_t)wave * per_wave;
+    uint32_t* visited = reinterpret_cast<uint32_t*>(base);
+    HnPair* top = reinterpret_cast<HnPair*>(base + P.flag_words * 4);
+    HnPair* cand = top + (P.ef + 1);
+    float* dist = reinterpret_cast<float*>(cand + P.cand_cap);
+    int32_t* ids = reinterpret_cast<int32_t*>(dist + 64);
+    if (qi >= job.nq) return;                                            // (no workgroup barrier below)
+    const HnswView ix = job.ix;
+    const uint32_t dim = ix.dim, M = ix.M, l = lane & 7u;
+    const size_t o = (size_t)job.out_base + qi;
+
+    float q[NB];
+    hn_load_q<NB>(q, job.query + (size_t)qi * dim, l);
+    for (uint32_t w = lane; w < P.flag_words; w += 64) visited[w] = 0;
+    unsigned long long evals = 1;
+
+    uint32_t cur = (uint32_t)ix.enter;
+    float curdist = hn_hsum8(hn_acc<NB>(q, ix.rows + (size_t)cur * dim, l), lane);
+    curdist = __shfl(curdist, 0);
+    // greedy descent (hnswalg.h:745-768): the list is walked in order, every strictly closer row takes over
+    for (int level = ix.maxlevel; level > 0; --level) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const int32_t* L = ix.up + ((size_t)ix.up_off[cur] + (uint32_t)(level - 1)) * (1 + M);
+            const uint32_t size = (uint32_t)L[0];
+            hn_dist_list<NB>(q, ix.rows, dim, L + 1, size, dist, lane, [](uint32_t) { return false; });
+            HN_SYNC();
+            evals += size;
+            for (uint32_t j = 0; j < size; ++j) {
+                const float d = dist[j];
+                if (d < curdist) { curdist = d; cur = (uint32_t)L[1 + j]; changed = true; }
+            }
+            HN_SYNC();
+        }
+    }
+    // searchBaseLayerST (hnswalg.h:214-280)
+    const uint32_t ef = P.ef;
+    uint32_t n_top = 0, n_cand = 0;
+    bool overflow = false;
+    HN_SYNC();
+    if (lane == 0) visited[cur >> 5] |= 1u << (cur & 31u);
+    hn_push(top, n_top, curdist, cur);
+    hn_push(cand, n_cand, -curdist, cur);
+    float lower = curdist;
+    HN_SYNC();
+    while (n_cand) {
+        const HnPair c0 = cand[0];
+        if ((-c0.d) > lower) break;
+        hn_pop(cand, n_cand);
+        const int32_t* L = ix.l0 + (size_t)c0.id * (1 + 2 * M);
+        const uint32_t size = (uint32_t)L[0];
+        HN_SYNC();
+        if (lane < size) ids[lane] = L[1 + lane];                       // 2M <= 64 links
+        HN_SYNC();
+        hn_dist_list<NB>(q, ix.rows, dim, ids, size, dist, lane, [&](uint32_t c) { return ((visited[c >> 5] >> (c & 31u)) & 1u) != 0; });
+        HN_SYNC();
+        for (uint32_t j = 0; j < size; ++j) {
+            const uint32_t c = (uint32_t)ids[j];
+            const uint32_t w = visited[c >> 5], bit = 1u << (c & 31u);
+            if (w & bit) continue;                                     // seen before this list, or earlier in this list
+            visited[c >> 5] = w | bit;
+            evals += 1;
+            const float d = dist[j];
+            if (top[0].d > d || n_top < ef) {
+                if (n_cand >= P.cand_cap) { overflow = true; break; }
+                hn_push(cand, n_cand, -d, c);
+                hn_push(top, n_top, d, c);
+                if (n_top > ef) hn_pop(top, n_top);
+                lower = top[0].d;
+            }
+        }
+        if (overflow) break;
+    }
+    if (overflow) {                                                     // the host repeats the query with a larger heap
+        if (lane == 0) { atomicAdd(P.n_overflow, 1u); P.nn_idx[o] = kNone - 1u; }
+        return;
+    }
+    while (n_top > 2) hn_pop(top, n_top);
+    // results as ArrayMatcher_hnsw::SearchNeighbours orders them: ascending (distance, row)
+    HnPair r0{0.f, kNone}, r1{0.f, kNone};
+    const uint32_t nr = n_top;
+    if (nr >= 1) { r0 = top[0]; hn_pop(top, n_top); }
+    if (nr == 2) {
+        r1 = top[0];
+        if (r1.d < r0.d || (!(r0.d < r1.d) && r1.id < r0.id)) { const HnPair t = r0; r0 = r1; r1 = t; }
+    }
+    if (lane == 0) {
+        const bool two = nr == 2;
+        P.nn_idx[o] = (two && r0.d < P.ratio_R * r1.d) ? r0.id : kNone;
+        if (P.knn_idx) {
+            P.knn_idx[2 * o] = nr >= 1 ? (int32_t)r0.id : -1; P.knn_idx[2 * o + 1] = two ? (int32_t)r1.id : -1;
+            P.knn_dist[2 * o] = nr >= 1 ? r0.d : R3DM_INF;   P.knn_dist[2 * o + 1] = two ? r1.d : R3DM_INF;
+        }
+        atomicAdd(P.n_comps, evals);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ construction
+__device__ __forceinline__ unsigned long long hn_key(float d, uint32_t id) { return ((unsigned long long)__float_as_uint(d) << 32) | id; }
+__device__ __forceinline__ float hn_key_d(unsigned long long k) { return __uint_as_float((uint32_t)(k >> 32)); }
+
+// one row against one row, all eight accumulators in ONE lane (the heuristic compares a candidate with every kept row: a lane per kept row)
+__device__ __forceinline__ float hn_l2_lane(const float* __restrict__ a, const float* __restrict__ b, uint32_t dim)
+{
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t i = 0; i < dim; i += 8) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a + i), a1 = *reinterpret_cast<const float4*>(a + i + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(b + i), b1 = *reinterpret_cast<const float4*>(b + i + 4);
+        float t;
+        t = a0.x - b0.x; acc[0] = acc[0] + t * t;  t = a0.y - b0.y; acc[1] = acc[1] + t * t;
+        t = a0.z - b0.z; acc[2] = acc[2] + t * t;  t = a0.w - b0.w; acc[3] = acc[3] + t * t;
+        t = a1.x - b1.x; acc[4] = acc[4] + t * t;  t = a1.y - b1.y; acc[5] = acc[5] + t * t;
+        t = a1.z - b1.z; acc[6] = acc[6] + t * t;  t = a1.w - b1.w; acc[7] = acc[7] + t * t;
+    }
+    return acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7];
+}
+
+template <int NB>
+__global__ void __launch_bounds__(256) hnsw_link_kernel(const HnswBuildParams P)
+{
+    __shared__ unsigned long long s_key[4][64];     // candidates (ascending), later the kept rows
+    __shared__ unsigned long long s_ret[4][64];
+    __shared__ unsigned long long s_pruned[4][64];
+    __shared__ float s_dist[4][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, l = lane & 7u, g = lane >> 3;
+    const HnswBuildJob job = P.jobs[blockIdx.y];
+    const uint32_t t = blockIdx.x * 4 + wave;
+    if (t >= job.n + job.up_rows) return;
+    const uint32_t dim = job.dim, M = job.M;
+    unsigned long long* key = s_key[wave];
+    unsigned long long* ret = s_ret[wave];
+    unsigned long long* pruned = s_pruned[wave];
+    float* dist = s_dist[wave];
+
+    uint32_t node, limit, nc;
+    int32_t* out;
+    float q[NB];
+    if (t < job.n) {
+        // layer 0: the row's list in the exact 32-NN graph (+ reverse edges, 64 closest), re-measured with hnswlib's distance
+        node = t; limit = 2 * M; out = job.l0 + (size_t)node * (1 + 2 * M);
+        hn_load_q<NB>(q, job.rows + (size_t)node * dim, l);
+        nc = min(job.adj_deg[node], 64u);
+        const int32_t* ids = reinterpret_cast<const int32_t*>(job.adj + (size_t)node * kAnnDeg);
+        hn_dist_list<NB>(q, job.rows, dim, ids, nc, dist, lane, [](uint32_t) { return false; });
+        HN_SYNC();
+        const unsigned long long mine = lane < nc ? hn_key(dist[lane], (uint32_t)ids[lane]) : ~0ull;
+        key[lane] = mine;
+        HN_SYNC();
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < 64; ++j) rank += key[j] < mine ? 1u : 0u;       // rows are unique, so are the keys
+        HN_SYNC();
+        if (lane < nc) key[rank] = mine;
+        HN_SYNC();
+    } else {
+        // layer L > 0: the 32 nearest members of the layer by (distance, row), exact scan; lanes 0 .. 31 hold the list in order
+        const uint32_t r = t - job.n;
+        node = job.up_node[r];
+        const uint32_t L = job.up_level[r];
+        limit = M; out = job.up + (size_t)r * (1 + M);
+        hn_load_q<NB>(q, job.rows + (size_t)node * dim, l);
+        const uint32_t* mem = job.members + job.mem_off[L - 1];
+        const uint32_t nm = job.mem_off[L] - job.mem_off[L - 1];
+        const uint32_t K = min(32u, nm - 1);
+        unsigned long long mine = ~0ull;
+        for (uint32_t b0 = 0; b0 < nm; b0 += 8) {
+            const uint32_t b = b0 + g;
+            const bool on = b < nm;
+            const uint32_t c = on ? mem[b] : node;
+            const bool work = on && c != node;
+            float acc = 0.f;
+            if (work) acc = hn_acc<NB>(q, job.rows + (size_t)c * dim, l);
+            const float d = hn_hsum8(acc, lane);
+            const unsigned long long e_mine = work ? hn_key(d, c) : ~0ull;
+            for (uint32_t gg = 0; gg < 8; ++gg) {
+                const unsigned long long e = __shfl(e_mine, (int)(gg * 8));
+                const unsigned long long worst = __shfl(mine, (int)(K ? K - 1 : 0));
+                if (K == 0 || e >= worst) continue;                               // wave-uniform
+                const uint32_t pos = (uint32_t)__popcll(__ballot(lane < K && mine < e));
+                const unsigned long long up = __shfl_up(mine, 1);
+                if (lane < K && lane > pos) mine = up;
+                if (lane == pos) mine = e;
+            }
+        }
+        nc = (uint32_t)__popcll(__ballot(lane < K && mine != ~0ull));
+        key[lane] = lane < nc ? mine : ~0ull;
+        HN_SYNC();
+    }
+
+    // getNeighborsByHeuristic2 over key[0 .. nc) (ascending); a list shorter than the limit is kept whole
+    uint32_t nret = 0, npr = 0;
+    if (nc < limit) { if (lane < nc) ret[lane] = key[lane]; nret = nc; }
+    else {
+        for (uint32_t k = 0; k < nc && nret < limit; ++k) {
+            const unsigned long long ck = key[k];
+            const uint32_t cid = __builtin_amdgcn_readfirstlane((uint32_t)ck);
+            const float dq = hn_key_d(ck);
+            bool bad = false;
+            if (lane < nret) bad = hn_l2_lane(job.rows + (size_t)(uint32_t)ret[lane] * dim, job.rows + (size_t)cid * dim, dim) < dq;
+            const bool good = __ballot(bad) == 0ull;
+            HN_SYNC();
+            if (lane == 0) { if (good) ret[nret] = ck; else pruned[npr] = ck; }
+            if (good) ++nret; else ++npr;
+            HN_SYNC();
+        }
+        // free places go to the closest rejected candidates; then ascending order again
+        const uint32_t fill = min(npr, limit - nret);
+        if (lane < fill) ret[nret + lane] = pruned[lane];
+        nret += fill;
+        HN_SYNC();
+        const unsigned long long mine = lane < nret ? ret[lane] : ~0ull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nret; ++j) rank += ret[j] < mine ? 1u : 0u;
+        HN_SYNC();
+        if (lane < nret) ret[rank] = mine;
+        HN_SYNC();
+    }
+    HN_SYNC();
+    if (lane == 0) out[0] = (int32_t)nret;
+    if (lane < nret) out[1 + lane] = (int32_t)(uint32_t)ret[nret - 1 - lane];      // farthest first
+    else if (lane < limit) out[1 + lane] = -1;
+}
+
+}  // namespace
+
+hipError_t launch_hnsw_search(hipStream_t st, const HnswSearchParams& Pin, uint32_t max_nq, uint32_t max_n, uint32_t dim)
+{
+    HnswSearchParams P = Pin;
+    if (P.n_jobs == 0 || max_nq == 0) return hipSuccess;
+    if (P.ef < 2 || P.ef > 512 || P.cand_cap < 16) return hipErrorInvalidValue;
+    P.flag_words = (max_n + 31) / 32;
+    const size_t per_wave = (size_t)P.flag_words * 4 + (size_t)(P.ef + 1) * 8 + (size_t)P.cand_cap * 8 + 512;
+    const size_t lds = per_wave * 4;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((max_nq + 3) / 4, P.n_jobs);
+    if (P.n_jobs > 65535u) return hipErrorInvalidValue;
+#define R3DM_HNSW_SEARCH(NB)                                                                                            \
+    do {                                                                                                               \
+        if (lds > 64 * 1024) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)hnsw_search_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                             \
+        }                                                                                                              \
+        hipLaunchKernelGGL((hnsw_search_kernel<NB>), grid, dim3(256), lds, st, P);                                      \
+    } while (0)
+    switch (dim) {
+        case 64:  R3DM_HNSW_SEARCH(8); break;
+        case 128: R3DM_HNSW_SEARCH(16); break;
+        case 144: R3DM_HNSW_SEARCH(18); break;
+        case 256: R3DM_HNSW_SEARCH(32); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef R3DM_HNSW_SEARCH
+    return hipGetLastError();
+}
+
+hipError_t launch_hnsw_link(hipStream_t st, const HnswBuildParams& P, uint32_t n_jobs, uint32_t max_items, uint32_t dim)
+{
+    if (n_jobs == 0 || max_items == 0) return hipSuccess;
+    if (n_jobs > 65535u) return hipErrorInvalidValue;
+    const dim3 grid((max_items + 3) / 4, n_jobs);
+    switch (dim) {
+        case 64:  hipLaunchKernelGGL((hnsw_link_kernel<8>), grid, dim3(256), 0, st, P); break;
+        case 128: hipLaunchKernelGGL((hnsw_link_kernel<16>), grid, dim3(256), 0, st, P); break;
+        case 144: hipLaunchKernelGGL((hnsw_link_kernel<18>), grid, dim3(256), 0, st, P); break;
+        case 256: hipLaunchKernelGGL((hnsw_link_kernel<32>), grid, dim3(256), 0, st, P); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace r3dm

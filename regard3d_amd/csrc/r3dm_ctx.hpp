@@ -72,6 +72,9 @@ struct HostImage {
     bool compact_ready = false;     // ann_rows16 / ann_rows8 reflect the staged rows (reset by staging)
     DevBuf ann_adj, ann_deg, ann_rows16, ann_rows8;   // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0; compact row copies only for bf16- / u8-exact views
     uint32_t ann_K = 0;
+    // HNSW index (r3dm_match_pairs_hnsw), valid when hnsw_M != 0: hnswlib's arrays (kernels_hnsw.hip: HnswView) + the host-side scalars
+    DevBuf hnsw_l0, hnsw_up_off, hnsw_up;
+    uint32_t hnsw_M = 0, hnsw_seed = 0, hnsw_up_rows = 0; int32_t hnsw_enter = -1, hnsw_maxlevel = -1;
     bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter
     double Kinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     void release()
@@ -79,6 +82,7 @@ struct HostImage {
         if (borrowed) { *this = HostImage(); return; }     // drop the aliases, keep the index's memory
         rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
         ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; compact_ready = false; live = false;
+        hnsw_l0.release(); hnsw_up_off.release(); hnsw_up.release(); hnsw_M = 0;
     }
 };
 
@@ -129,6 +133,7 @@ struct r3dm_ctx {
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
+    DevBuf h_aux, h_jobs;            // HNSW: per-batch layer tables / job records
     DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff, f_order;
     DevBuf m_raw, m_peer;                                   // r3dm_multi_set_image: the one upload of a view / this device's copy of it
     std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size, ak_B planes each
@@ -182,5 +187,8 @@ struct r3dm_index {
 int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3 = nullptr, int32_t split_k = 0);
 int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
                     int32_t* knn_idx_host, float* knn_dist_host);
+int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_stride, uint32_t sort_cap,
+                   uint64_t n_queries, uint32_t max_nJ, r3dm_graph* g, int32_t* knn_idx_host, float* knn_dist_host);
+int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t K);
 int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width, uint32_t height,
                     const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);

@@ -114,6 +114,47 @@ struct AnnSearchParams {
     unsigned long long* n_comps;  // distance evaluations (atomic)
 };
 
+// ---- HNSW plugin path (kernels_hnsw.hip): an index is three arrays in hnswlib's own shape
+struct HnswView {
+    const float*   rows;          // [n][dim] f32, row-major
+    const int32_t* l0;            // [n][1 + 2M]: count, links (farthest first, -1 padded)
+    const int32_t* up_off;        // [n + 1]: first upper-layer row of a node (layer L of node i: row up_off[i] + L - 1)
+    const int32_t* up;            // [rows][1 + M]
+    uint32_t n, dim, M;
+    int32_t enter, maxlevel;
+};
+struct HnswSearchJob {
+    HnswView     ix;
+    const float* query;           // [nq][dim]
+    uint32_t     nq;
+    uint32_t     out_base;        // first slot of the pair in nn_idx / knn_*
+};
+struct HnswSearchParams {
+    const HnswSearchJob* jobs;
+    uint32_t n_jobs, ef, cand_cap, flag_words;
+    float    ratio_R;
+    uint32_t* nn_idx;
+    int32_t*  knn_idx;            // optional
+    float*    knn_dist;           // optional
+    unsigned long long* n_comps;  // distance evaluations (atomic)
+    uint32_t* n_overflow;         // queries whose candidate heap did not fit cand_cap (their nn_idx slot holds 0xFFFFFFFE)
+};
+struct HnswBuildJob {
+    const float*    rows;
+    const uint32_t* adj;          // ImgDev::ann_adj of the view (exact 32-NN graph + reverse edges)
+    const uint32_t* adj_deg;
+    const uint32_t* up_node;      // [up_rows] node of an upper-layer row
+    const uint32_t* up_level;     // [up_rows] its layer (1 ..)
+    const uint32_t* members;      // rows of layer 1, then layer 2, ... each ascending
+    const uint32_t* mem_off;      // [maxlevel + 1] offsets into members
+    int32_t* l0;
+    int32_t* up;
+    uint32_t n, dim, M, up_rows;
+};
+struct HnswBuildParams {
+    const HnswBuildJob* jobs;
+};
+
 struct MatchParams {
     const ImgDev* imgs;
     const uint2*  pairs;          // slot indices (I, J)
@@ -276,6 +317,8 @@ hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_
 // rows_mode: 0 = f32 rows, 1 = ImgDev::ann_rows16 (bf16), 2 = ImgDev::ann_rows8 (u8) -- every indexed view of the batch must hold that copy;
 // 3 = u8 rows on both sides (the query views hold ann_rows8 too): distances as integer dot products
 hipError_t launch_ann_search(hipStream_t st, const AnnSearchParams& P, uint32_t max_nJ, uint32_t max_nI, uint32_t dim, int rows_mode);
+hipError_t launch_hnsw_search(hipStream_t st, const HnswSearchParams& P, uint32_t max_nq, uint32_t max_n, uint32_t dim);
+hipError_t launch_hnsw_link(hipStream_t st, const HnswBuildParams& P, uint32_t n_jobs, uint32_t max_items, uint32_t dim);
 hipError_t launch_ann_rows16(hipStream_t st, const float* rows, uint16_t* rows16, size_t n_elems);
 hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, size_t n_elems);
 // img_of (optional): image of the batch each keypoint belongs to -- its pixels start img_of[k] * w * h floats into `image`

@@ -120,7 +120,7 @@ int main(int argc, char** argv)
         if (arms_env && !strcmp(arms_env, "requested")) stage.setApproximateArmsPolicy(r3d_amd::R3DComputeMatches::kArmsAsRequested);
         const bool ok = stage.computeMatches(params, true, paths, 1, algo);
         if (!ok) { fprintf(stderr, "computeMatches failed: %s\n", stage.errorMessage().c_str()); return 7; }
-        fprintf(stderr, "matcher %s\n", stage.lastMatchWasExhaustive() ? "exhaustive" : "graph");
+        fprintf(stderr, "matcher %s\n", stage.lastMatchWasExhaustive() ? "exhaustive" : (stage.lastMatchWasHnsw() ? "hnsw" : "graph"));
         printf("%zu %zu\n", stage.getStatistics().putativeMatches_.size(), stage.getStatistics().fundamentalMatches_.size());
         return 0;
     }

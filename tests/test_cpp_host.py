@@ -178,12 +178,20 @@ def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
                                                         seed=1998, min_rows=128)
     p, c, m = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
     assert np.array_equal(p, pairs[counts > 0]) and np.array_equal(c, counts[counts > 0]) and np.array_equal(m, matches)
-    # the HNSW / MRPT / FLANN arms are served by the same matcher with the preset of matching recall: 8 ("HNSW precise") == 3
+    # MRPT / FLANN arms (no such index here) are served by the same matcher with the preset of matching recall: 0 ("FLANN") == 3
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
-                       env=dict(os.environ, R3DM_TEST_ALGO="8", R3DM_TEST_ARMS="requested"))
-    assert r.returncode == 0, r.stderr
+                       env=dict(os.environ, R3DM_TEST_ALGO="0", R3DM_TEST_ARMS="requested"))
+    assert r.returncode == 0 and "matcher graph" in r.stderr, r.stderr
     p8, c8, m8 = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
     assert np.array_equal(p8, p) and np.array_equal(c8, c) and np.array_equal(m8, m)
+    # arms 6 / 7 / 8 run hnsw_match itself: hnswlib's search on the batch-built index; putative file == the CPU model
+    for algo, preset in ((6, "fast"), (8, "precise")):
+        r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True,
+                           env=dict(os.environ, R3DM_TEST_ALGO=str(algo), R3DM_TEST_ARMS="requested"))
+        assert r.returncode == 0 and "matcher hnsw" in r.stderr, r.stderr
+        hc, hm = oracle.match_collection_hnsw(sc.descs, sc.xys, pairs, 0.6, preset)
+        ph, ch, mh = oracle.load_matches(str(tmp_path / "matches.putative.txt"))
+        assert np.array_equal(ph, pairs[hc > 0]) and np.array_equal(ch, hc[hc > 0]) and np.array_equal(mh, hm)
     # the default policy serves an approximate arm with whichever matcher is faster for the views: LIOP-144 (real-valued) -> the
     # exhaustive matcher, i.e. arm 0 (the GUI's default, FLANN in the reference) writes exactly what arm 9 writes
     r = subprocess.run([host_exe, "stage", str(tmp_path), "144"] + names, capture_output=True, text=True, env=dict(os.environ, R3DM_TEST_ALGO="0"))

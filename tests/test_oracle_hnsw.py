@@ -85,3 +85,22 @@ def test_live_reference_if_built(oracle):
         assert all(np.array_equal(ex[k], ix[k]) for k in ("levels", "links0", "up_off", "up_links"))
         mi, md = mine.knn2(d1, ef)
         assert np.array_equal(mi, idx) and np.array_equal(md.view(np.uint32), dist.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene", ["sift", "liop"])
+@pytest.mark.parametrize("preset", PRESETS)
+def test_batch_built_index_recall_at_least_the_reference_index(oracle, scene, preset):
+    """the index the HIP path builds (orc_hnsw_build_batch: exact candidates + hnswlib's heuristic, one pass) searched with hnswlib's
+    searchKnn at the reference's ef finds the true nearest row at least as often as the reference-built index does"""
+    d0, d1, ix, idx, dist = load_case(scene, preset)
+    M, _, ef = oracle.HNSW_PRESETS[preset]
+    D = ((d1[:, None, :].astype(np.float64) - d0[None, :, :]) ** 2).sum(-1)
+    o = np.argsort(D, 1)[:, :2]
+    g = oracle.hnsw_build_batch(d0, M)
+    ex = g.export()
+    assert np.array_equal(ex["levels"], ix["levels"]) and ex["maxlevel"] == ix["maxlevel"]          # the same level draw
+    assert ex["links0"][:, 0].max() <= 2 * M and (ex["up_links"][:, 0].max() if len(ex["up_links"]) else 0) <= M
+    mi, md = g.knn2(d1, ef)
+    for k in (0, 1):
+        ours, ref = (mi[:, k] == o[:, k]).mean(), (idx[:, k] == o[:, k]).mean()
+        assert ours >= ref, (k, ours, ref)
