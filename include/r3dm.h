@@ -198,11 +198,14 @@ typedef struct {
 /* preset = matchingAlgorithm of the reference: 0 "KGraph fast", 1 "medium", 2 "precise", anything else its default
  * block (src/R3DComputeMatches.cpp:844-873) */
 int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out);
-/* parameters that serve an approximate arm of the reference's dispatch (matchingAlgorithm, src/R3DComputeMatches.cpp:2035-2062:
- * 0 FLANN kd-trees, 1..3 KGraph, 5 MRPT, 6..8 HNSW) with a recall at least that of the arm; R3DM_ERR_INVALID for the exhaustive
- * arms 4 / 9 and unknown values.  Only the KGraph arms are the reference's algorithm; FLANN, MRPT and HNSW are SUBSTITUTED: no
- * kd-tree, random-projection or HNSW index is built here, the same deterministic graph matcher answers for them and its matches
- * are not those the reference's arm would return (both are approximate).  See the table in api_match.cpp and DESIGN.md section 4.7. */
+/* parameters with which the graph matcher serves an approximate arm of the reference's dispatch (matchingAlgorithm,
+ * src/R3DComputeMatches.cpp:2035-2062: 0 FLANN kd-trees, 1..3 KGraph, 5 MRPT, 6..8 HNSW) with a recall at least that of the arm;
+ * R3DM_ERR_INVALID for the exhaustive arms 4 / 9 and unknown values.  The KGraph arms are the reference's algorithm.  The HNSW
+ * arms have their own entry points (r3dm_match_pairs_hnsw below: hnswlib's search on an HNSW index) -- this mapping is what a host
+ * uses for them only when it wants the FASTEST matcher of at least the arm's recall, or for a descriptor length hnswlib's SIMD16
+ * distance does not serve.  FLANN and MRPT are SUBSTITUTED: no kd-tree or random-projection index is built here, the same
+ * deterministic graph matcher answers for them and its matches are not those the reference's arm would return (both are
+ * approximate).  See the table in api_match.cpp and DESIGN.md section 4.7. */
 int r3dm_ann_params_for_algorithm(int matching_algorithm, r3dm_kgraph_params* out);
 int r3dm_match_pairs_kgraph(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
                             const r3dm_kgraph_params* params, r3dm_graph** out);

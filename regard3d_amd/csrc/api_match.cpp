@@ -416,8 +416,10 @@ extern "C" int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out)
 
 // The approximate arms of the reference's dispatch (src/R3DComputeMatches.cpp:2035-2062) all trade recall for speed with a
 // different index each (FLANN kd-trees, KGraph, MRPT random-projection trees, HNSW); none of them is reproducible bit for bit
-// (random trees / seeds / thread schedules), so parity with any of them is recall.  They are all served by the one deterministic
-// graph matcher here, with the preset whose measured recall is at least that of the reference's arm:
+// (random trees / seeds / thread schedules), so parity with any of them is recall.  The HNSW arms have their own matcher
+// (api_hnsw.cpp: hnswlib's search, bit-exact on a reference-built index); this table is how the one deterministic graph matcher
+// serves an arm when the host asks for the fastest matcher of at least the arm's recall (the facade's default policy), and the
+// arms whose index is not built here at all (FLANN, MRPT):
 //   1..3  kgraph_match presets                        -> fast / medium / precise
 //   6..8  hnsw_match presets (:533-565)               -> fast / medium / precise  (reference-built HNSW on tests/golden/
 //                                                        ann_hnsw_ref.npz: 0.573 / 0.933 / 0.975 recall@1; here 0.851 / 0.947 / 0.980)
