@@ -120,3 +120,16 @@ def test_match_pairs_hnsw_equals_model_neighbours_plus_ratio_rules(ctx, oracle, 
     # the same call again is served by the cached indices
     g2 = ctx.match_pairs_hnsw(pairs, 0.8, hp)
     assert ctx.stats().n_ann_built == 0 and np.array_equal(g2.matches, matches)
+
+
+@pytest.mark.parametrize("scene", ["sift", "liop"])
+def test_recall_at_8k_rows_at_least_the_reference_built_index(ctx, oracle, scene):
+    """VERDICT r2 item 7 (i) at the size of BASELINE's views; the reference-built rows come from tests/golden/hnsw_ref_recall_8k.npz"""
+    from test_oracle_hnsw import load_case_8k
+    d0, d1, exact, ref = load_case_8k(scene)
+    for preset in PRESETS:
+        gi, _ = ctx.hnsw_knn2(d0, d1, api.HnswParams.preset(preset))
+        for k in (0, 1):
+            ours, theirs = (gi[:, k] == exact[:, k]).mean(), (ref[preset][:, k] == exact[:, k]).mean()
+            print(scene, preset, "recall@%d" % (k + 1), "batch-built %.4f" % ours, "reference-built %.4f" % theirs)
+            assert ours >= theirs

@@ -104,3 +104,29 @@ def test_batch_built_index_recall_at_least_the_reference_index(oracle, scene, pr
     for k in (0, 1):
         ours, ref = (mi[:, k] == o[:, k]).mean(), (idx[:, k] == o[:, k]).mean()
         assert ours >= ref, (k, ours, ref)
+
+
+GOLD8 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hnsw_ref_recall_8k.npz")
+
+
+def load_case_8k(scene):
+    """two views x 8,192 rows (the size of BASELINE's views) + the exact 2-NN and the reference-built HNSW's rows per preset"""
+    from regard3d_amd import synth
+    g = np.load(GOLD8)
+    n, seed = (int(v) for v in g[f"{scene}_scene"])
+    sc = synth.make_scene(2, n, scene, seed=seed)
+    d0, d1 = np.ascontiguousarray(sc.descs[0], np.float32), np.ascontiguousarray(sc.descs[1], np.float32)
+    assert [zlib.crc32(d0.tobytes()), zlib.crc32(d1.tobytes())] == g[f"{scene}_crc"].tolist(), "synth.make_scene drifted"
+    return d0, d1, g[f"{scene}_exact"].astype(np.int32), {p: g[f"{scene}_{p}_idx"].astype(np.int32) for p in PRESETS}
+
+
+@pytest.mark.parametrize("scene", ["sift", "liop"])
+def test_batch_built_index_recall_at_8k_rows(oracle, scene):
+    """recall >= the reference-built HierarchicalNSW per preset at 8k rows"""
+    d0, d1, exact, ref = load_case_8k(scene)
+    for preset in PRESETS:
+        M, _, ef = oracle.HNSW_PRESETS[preset]
+        mi, _ = oracle.hnsw_build_batch(d0, M).knn2(d1, ef)
+        for k in (0, 1):
+            ours, theirs = (mi[:, k] == exact[:, k]).mean(), (ref[preset][:, k] == exact[:, k]).mean()
+            assert ours >= theirs, (preset, k, ours, theirs)

@@ -47,3 +47,21 @@ for name, s in SCENES.items():
         print(name, preset, "maxlevel", ix["maxlevel"], "mean degree", ix["links0"][:, 0].mean(), flush=True)
 np.savez_compressed(out, **data)
 print(out, os.path.getsize(out) / 1e3, "kB")
+
+# ---- hnsw_ref_recall_8k.npz: the recall bar at the size of BASELINE's views (8,192 rows per view).  Only what the bar needs is
+# stored: the exact 2-NN (reference-built BruteforceSearch) and the reference-built HierarchicalNSW's searchKnn rows per preset.
+out8 = os.path.join(os.path.dirname(out), "hnsw_ref_recall_8k.npz")
+data = {}
+for name, s in {"sift": dict(kind="sift", seed=81), "liop": dict(kind="liop", seed=82)}.items():
+    sc = synth.make_scene(2, 8192, s["kind"], seed=s["seed"])
+    d0, d1 = np.ascontiguousarray(sc.descs[0], np.float32), np.ascontiguousarray(sc.descs[1], np.float32)
+    data[f"{name}_crc"] = np.array([zlib.crc32(d0.tobytes()), zlib.crc32(d1.tobytes())], np.uint32)
+    data[f"{name}_scene"] = np.array([8192, s["seed"]], np.int32)
+    ei, ed = O.ref_knn(d0, d1, 2)
+    data[f"{name}_exact"] = ei.astype(np.int16)
+    for preset, (M, efc, ef) in O.HNSW_PRESETS.items():
+        ix, idx, dist = O.ref_hnsw_export(d0, d1, M, efc, ef)
+        data[f"{name}_{preset}_idx"] = idx.astype(np.int16)
+        print(name, preset, "reference-built recall@1 %.4f @2 %.4f" % ((idx[:, 0] == ei[:, 0]).mean(), (idx[:, 1] == ei[:, 1]).mean()), flush=True)
+np.savez_compressed(out8, **data)
+print(out8, os.path.getsize(out8) / 1e3, "kB")
