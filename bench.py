@@ -265,13 +265,13 @@ def stage_main(a):
         # the GUI's default arm (matchingAlgorithm 0 = FLANN kd-trees in the reference, src/Regard3DMainFrame.cpp:2405) on the files
         # the step left: no extraction, matching + filters only -- under the facade's default policy (an approximate arm is served by
         # whichever matcher is faster on the views: exhaustive for LIOP-144), as requested (the graph matcher), and arm 9 the same
-        # way for a like-for-like match phase, plain and with the opt-in split-f16 nominator
+        # way for a like-for-like match phase: as the facade runs it (exact fast paths: split-f16 nomination for LIOP) and on plain f32 tiles
         def rerun(algo, **kw):
             wipe(False)
             r = stage.run(d, bare, 0.001, 0.6, algo, **kw).as_dict()
             return r, {x: open(os.path.join(d, f"matches.{x}.bin"), "rb").read() for x in ("putative", "f", "e", "h")}
         r0g, f0g = rerun(0, arms_as_requested=True)
-        r9s, f9s = rerun(9, split_mfma=True)
+        r9t, f9t = rerun(9, f32_tiles=True)
         r0, f0 = rerun(0)
         r9, f9 = rerun(9)                   # last: its files are what the CPU leg below compares with
         # detector roofline: a dedicated pass of the batch entry on B resident images, one context, nothing else on the GPU
@@ -287,7 +287,7 @@ def stage_main(a):
             "vs_baseline": None, "dtype": "f32 (detector, LIOP, L2) / f64 (AC-RANSAC)", "data": "synthetic",
             "config": {"workload": f"stage: {N} synthetic {W}x{H} photographs (one textured plane, 78 % overlap between neighbours) resident in HBM -> "
                                    f"R3DComputeMatches::computeMatches: Fast-A-KAZE + LIOP-144 ({conc} batches of {batch} in flight) -> .feat/.desc -> exhaustive {n_pairs} pairs, "
-                                   "brute-force L2 2-NN + ratio 0.6 (matchingAlgorithm 9) -> F + E + H AC-RANSAC (4 px, 2048 it) -> matches.*.txt/.bin",
+                                   "brute-force L2 2-NN + ratio 0.6 (matchingAlgorithm 9; split-f16 nomination + f32 re-score, bit-identical to f32 tiles) -> F + E + H AC-RANSAC (4 px, 2048 it) -> matches.*.txt/.bin",
                        "name": "stage", "images": N, "pairs": n_pairs, "image_size": [W, H], "parallelism": "1 GPU"},
             "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total")},
             "kernels_ms": {"match": mean("ms_match_kernels"), "F": mean("ms_F_kernels"), "E": mean("ms_E_kernels"), "H": mean("ms_H_kernels"),
@@ -297,8 +297,10 @@ def stage_main(a):
                          "detector_passes": int(last["features"]["n_passes"]), "regrows": int(last["features"]["n_regrows"])},
             "graphs": {k: int(last[k]) for k in ("n_putative_pairs", "n_putative_matches", "n_F_pairs", "n_F_matches", "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches")},
             "arm_9_on_existing_files": {"ms_match": r9["ms_match"], "ms_match_kernels": r9["ms_match_kernels"], "ms_total": r9["ms_total"], "putative_matches": int(r9["n_putative_matches"])},
-            "arm_9_opt_in_split_mfma": {"ms_match": r9s["ms_match"], "ms_match_kernels": r9s["ms_match_kernels"], "ms_total": r9s["ms_total"],
-                                        "all_match_files_identical_to_arm_9": bool(f9s == f9)},
+            "arm_9_on_plain_f32_tiles": {"ms_match": r9t["ms_match"], "ms_match_kernels": r9t["ms_match_kernels"], "ms_total": r9t["ms_total"],
+                                         "all_match_files_identical_to_arm_9": bool(f9t == f9),
+                                         "note": "R3DM_STAGE_F32_TILES: the arithmetic BASELINE's configurations name; the facade's default nominates on split-f16 "
+                                                 "tiles and re-scores in f32 in the reference's order -- bit-identical files (include/r3d_compute_matches.hpp)"},
             "arm_0_gui_default": {"ms_match": r0["ms_match"], "ms_total": r0["ms_total"], "putative_matches": int(r0["n_putative_matches"]),
                                   "served_by": "exhaustive matcher" if r0["match_was_exhaustive"] else "graph matcher",
                                   "all_match_files_identical_to_arm_9": bool(f0 == f9),

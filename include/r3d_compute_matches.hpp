@@ -84,6 +84,14 @@ public:
     void clearViews() { views_.clear(); }                            // a kept-alive stage object between two collections
     void setRegionsType(r3dm_dtype dtype, uint32_t dim);           // default: float x 144 (R3D_AKAZE_LIOP_Regions)
     void setSeed(uint64_t seed) { seed_ = seed; }
+    // The exhaustive matcher's exact MFMA fast paths: split-f16 nomination for real-valued descriptors (LIOP-144, what Regard3D matches:
+    // 2.9x) and bf16 tiles for integer-valued ones (SIFT bins: 7.9x).  Both nominate candidates on narrow tiles and then compute the
+    // distances of the candidates in f32 in the reference's order, with a certificate per query (a query whose certificate fails goes
+    // through the exact scan), so indices, distances and match files are BIT-IDENTICAL to the plain f32-tile path (tests/
+    // test_gpu_split_mfma.py, test_gpu_integer_mfma.py, test_liop_match_ref.py against reference-built code; bench.py --config stage
+    // compares the files on every run).  ON by default in this facade since round 3; the C ABI's r3dm_match_pairs keeps f32 tiles
+    // unless r3dm_set_split_mfma / r3dm_set_integer_mfma are called (BASELINE's configurations name the f32 arithmetic).
+    void setExactFastPaths(bool on) { setIntegerFastPath(on); setSplitFastPath(on); }
     // no reference counterpart: forwards r3dm_set_integer_mfma (bit-identical results, integer-valued descriptors only)
     void setIntegerFastPath(bool on);
     // no reference counterpart: forwards r3dm_set_split_mfma (bit-identical results, real-valued descriptors: LIOP)
@@ -196,8 +204,9 @@ int  r3dm_stage_run(r3dm_stage* s, const char* matches_dir, const r3dm_view_imag
                     r3dm_stage_report* report, char* err, size_t err_cap);
 /* flags of r3dm_compute_matches_stage / r3dm_stage_run */
 #define R3DM_STAGE_ARMS_AS_REQUESTED 1u   /* approximate arms always on the graph matcher (default: the faster matcher, R3DComputeMatches::setApproximateArmsPolicy) */
-#define R3DM_STAGE_SPLIT_MFMA        2u   /* r3dm_set_split_mfma: the opt-in split-f16 nominator for real-valued descriptors (bit-identical results) */
-#define R3DM_STAGE_INTEGER_MFMA      4u   /* r3dm_set_integer_mfma */
+#define R3DM_STAGE_SPLIT_MFMA        2u   /* (implied since round 3: the facade's exact fast paths are on by default) */
+#define R3DM_STAGE_INTEGER_MFMA      4u   /* (implied since round 3) */
+#define R3DM_STAGE_F32_TILES         8u   /* plain f32 MFMA tiles for the exhaustive matcher: R3DComputeMatches::setExactFastPaths(false); same files, slower */
 typedef struct { uint32_t id, width, height; const char* basename; } r3dm_view;
 int r3dm_compute_matches_dir(int device_id, const char* matches_dir, const r3dm_view* views, uint32_t n_views,
                              r3dm_dtype dtype, uint32_t dim, float dist_ratio, int compute_F, uint64_t seed,

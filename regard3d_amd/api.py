@@ -117,13 +117,13 @@ class Stage:
 
     def run(self, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6, matching_algorithm: int = 9, compute_F: bool = True,
             compute_E: bool = True, compute_H: bool = True, seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8,
-            arms_as_requested: bool = False, split_mfma: bool = False, integer_mfma: bool = False) -> StageReport:
+            arms_as_requested: bool = False, split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False) -> StageReport:
         keep = []
         arr = _stage_views(views, keep)
         rep = StageReport(); err = C.create_string_buffer(1024)
         rc = self._L.r3dm_stage_run(self._h, matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm, int(compute_F),
                                     int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
-                                    (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0), C.byref(rep), err, 1024)
+                                    (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0) | (8 if f32_tiles else 0), C.byref(rep), err, 1024)
         if rc != 0:
             raise R3dmError(f"r3dm_stage_run -> {rc}: {err.value.decode()}")
         return rep
@@ -143,7 +143,7 @@ class Stage:
 def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6,
                           matching_algorithm: int = 9, compute_F: bool = True, compute_E: bool = True, compute_H: bool = True,
                           seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8, arms_as_requested: bool = False,
-                          split_mfma: bool = False, integer_mfma: bool = False) -> StageReport:
+                          split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False) -> StageReport:
     """R3DComputeMatches::computeMatches from pixels (r3dm_compute_matches_stage): features stage for the views whose .feat/.desc
     are missing, matching, F / E / H filters, match files.  views: dicts with id, width, height, basename and optionally
     gray ([h, w] float32) or bgr ([h, w, 3] uint8) -- numpy or torch (host or device) -- and focal_px / ppx / ppy."""
@@ -155,7 +155,7 @@ def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float 
     L.r3dm_compute_matches_stage.argtypes = [C.c_void_p, C.c_int] + _STAGE_ARGS
     rc = L.r3dm_compute_matches_stage(ids, len(device_ids), matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm,
                                       int(compute_F), int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
-                                      (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0), C.byref(rep), err, 1024)
+                                      (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0) | (8 if f32_tiles else 0), C.byref(rep), err, 1024)
     if rc != 0:
         raise R3dmError(f"r3dm_compute_matches_stage -> {rc}: {err.value.decode()}")
     return rep

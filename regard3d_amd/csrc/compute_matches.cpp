@@ -133,6 +133,7 @@ R3DComputeMatches::R3DComputeMatches(int device_id)
     devices_.assign(1, device_id);
     const int rc = r3dm_create(device_id, &ctx_);
     if (rc != R3DM_OK) { ctx_ = nullptr; errorMessage_ = "r3dm_create failed (" + std::to_string(rc) + "): no gfx950 GPU"; }
+    setExactFastPaths(true);
 }
 
 R3DComputeMatches::R3DComputeMatches(const std::vector<int>& device_ids)
@@ -141,10 +142,12 @@ R3DComputeMatches::R3DComputeMatches(const std::vector<int>& device_ids)
     if (device_ids.size() == 1) {
         const int rc = r3dm_create(device_ids[0], &ctx_);
         if (rc != R3DM_OK) { ctx_ = nullptr; errorMessage_ = "r3dm_create failed (" + std::to_string(rc) + "): no gfx950 GPU"; }
+        setExactFastPaths(true);
         return;
     }
     const int rc = r3dm_multi_create(device_ids.data(), (int)device_ids.size(), &multi_);
     if (rc != R3DM_OK) { multi_ = nullptr; errorMessage_ = "r3dm_multi_create failed (" + std::to_string(rc) + ")"; }
+    setExactFastPaths(true);
 }
 
 R3DComputeMatches::~R3DComputeMatches()
@@ -498,8 +501,7 @@ extern "C" int r3dm_stage_run(r3dm_stage* sp, const char* matches_dir, const r3d
         stage.setSeed(seed);
         if (features_batches_in_flight > 0 && features_images_per_batch > 0) stage.setFeaturesConcurrency(features_batches_in_flight, features_images_per_batch);
         stage.setApproximateArmsPolicy((flags & R3DM_STAGE_ARMS_AS_REQUESTED) ? r3d_amd::R3DComputeMatches::kArmsAsRequested : r3d_amd::R3DComputeMatches::kArmsFastest);
-        stage.setSplitFastPath((flags & R3DM_STAGE_SPLIT_MFMA) != 0);
-        stage.setIntegerFastPath((flags & R3DM_STAGE_INTEGER_MFMA) != 0);
+        stage.setExactFastPaths((flags & R3DM_STAGE_F32_TILES) == 0);      // (R3DM_STAGE_SPLIT_MFMA / _INTEGER_MFMA: implied since round 3)
         r3d_amd::R3DFParams params;
         params.keypointDetectorList_ = {"Fast-AKAZE"};
         params.threshold_ = threshold;

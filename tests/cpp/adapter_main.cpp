@@ -114,7 +114,7 @@ int main(int argc, char** argv)
         // R3DM_TEST_ALGO selects the dispatch arm (default 9 = GPU brute force; 1..3 = KGraph presets)
         const char* algo_env = getenv("R3DM_TEST_ALGO");
         const int algo = algo_env ? atoi(algo_env) : r3d_amd::R3DComputeMatches::kMatchingAlgorithmGPU;
-        if (getenv("R3DM_TEST_INTEGER_MFMA")) stage.setIntegerFastPath(true);
+        if (getenv("R3DM_TEST_F32_TILES")) stage.setExactFastPaths(false);          // default: on
         // R3DM_TEST_ARMS=requested: approximate arms always on the graph matcher (default: on whichever matcher is faster for the views)
         const char* arms_env = getenv("R3DM_TEST_ARMS");
         if (arms_env && !strcmp(arms_env, "requested")) stage.setApproximateArmsPolicy(r3d_amd::R3DComputeMatches::kArmsAsRequested);

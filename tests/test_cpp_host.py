@@ -205,15 +205,17 @@ def test_stage_facade_kgraph_dispatch(host_exe, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_stage_facade_integer_fast_path_writes_the_same_files(host_exe, oracle, tmp_path):
-    """R3DComputeMatches::setIntegerFastPath on SIFT-like integer descriptors: byte-identical matches.putative / matches.f"""
-    sc = synth.make_scene(5, 1200, "sift", seed=31)
+@pytest.mark.parametrize("kind,dim", [("sift", "128"), ("liop", "144")])
+def test_stage_facade_exact_fast_paths_write_the_same_files(host_exe, oracle, tmp_path, kind, dim):
+    """the facade's exact fast paths (default: on -- bf16 tiles for SIFT-like integer descriptors, split-f16 nomination for
+    real-valued LIOP-144) against R3DComputeMatches::setExactFastPaths(false): byte-identical matches.putative / matches.f"""
+    sc = synth.make_scene(5, 1200, kind, seed=31)
     names = _write_views(oracle, str(tmp_path), sc)
-    r = subprocess.run([host_exe, "stage", str(tmp_path), "128"] + names, capture_output=True, text=True)
+    r = subprocess.run([host_exe, "stage", str(tmp_path), dim] + names, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ref = {f: open(str(tmp_path / f), "rb").read() for f in ("matches.putative.bin", "matches.putative.txt", "matches.f.bin")}
-    r2 = subprocess.run([host_exe, "stage", str(tmp_path), "128"] + names, capture_output=True, text=True,
-                        env=dict(os.environ, R3DM_TEST_INTEGER_MFMA="1"))
+    r2 = subprocess.run([host_exe, "stage", str(tmp_path), dim] + names, capture_output=True, text=True,
+                        env=dict(os.environ, R3DM_TEST_F32_TILES="1"))
     assert r2.returncode == 0, r2.stderr
     assert r2.stdout == r.stdout
     for f, blob in ref.items():
