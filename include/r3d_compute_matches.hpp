@@ -19,6 +19,7 @@
 
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -119,6 +120,9 @@ public:
     using ImageProviderFn = bool (*)(const View& view, Pixels* out, void* user);
     using ImageReleaseFn = void (*)(const View& view, void* user);
     void setImageProvider(ImageProviderFn get, ImageReleaseFn release, void* user) { provider_ = get; provider_release_ = release; provider_user_ = user; }
+    // false: every view goes through its .feat / .desc files, as in the reference (default true: views computed in this call are
+    // registered with the matcher from device memory -- the same values, without the file system and PCIe round trip)
+    void setDirectRegistration(bool on) { direct_registration_ = on; }
     // detector batches in flight per device and images per batch of the features stage (defaults 2 x 8)
     void setFeaturesConcurrency(int batches_in_flight, int images_per_batch) { feat_conc_ = batches_in_flight; feat_batch_ = images_per_batch; }
 
@@ -158,6 +162,14 @@ private:
     int feat_conc_ = 2, feat_batch_ = 8;
     ArmsPolicy arms_policy_ = kArmsFastest;
     bool last_exhaustive_ = true, last_hnsw_ = false;
+    // views registered with the matcher straight from the features stage (r3dm_set_features_sink): descriptors device to device,
+    // positions as a reader of the .feat file would parse them; the load step reads the files of the other views only
+    std::mutex sink_mu_;
+    std::vector<char> registered_;         // per view of views_
+    std::vector<uint32_t> registered_n_;
+    const size_t* sink_need_ = nullptr;    // views of the running features chunk
+    bool direct_registration_ = true;
+    static int features_sink(void* self, uint32_t image_index, uint32_t n_features, const float* desc_device, const float* xy_as_written);
     ImageProviderFn provider_ = nullptr;
     ImageReleaseFn provider_release_ = nullptr;
     void* provider_user_ = nullptr;

@@ -481,6 +481,17 @@ typedef struct {
 } r3dm_features_totals;
 int r3dm_get_features_totals(const r3dm_ctx* ctx, r3dm_features_totals* out);
 
+/* A sink for the features entry points (r3dm_extract_features_batch, r3dm_multi_extract_features*): called once per COMPUTED image
+ * (not for skipped ones), from the thread that computed it, after its two files are written.  desc_device = n_features x 144 floats
+ * in DEVICE memory of the computing context (valid until the sink returns); xy_as_written = n_features x 2 floats exactly as a reader
+ * of the .feat file parses them (the file holds 6 significant digits).  What Regions_Provider::load would read back from the files
+ * (src/R3DComputeMatches.cpp:2040) is thus handed over without the round trip through the file system and the PCIe bus: the facade
+ * registers the view with the matcher straight from it (r3dm_set_image accepts device pointers).  image_index = the index in the
+ * arrays of the call.  A non-zero return fails the features call with R3DM_ERR_INVALID.  NULL removes the sink. */
+typedef int (*r3dm_features_sink)(void* user, uint32_t image_index, uint32_t n_features, const float* desc_device, const float* xy_as_written);
+int r3dm_set_features_sink(r3dm_ctx* ctx, r3dm_features_sink sink, void* user);
+int r3dm_multi_set_features_sink(r3dm_multi* m, r3dm_features_sink sink, void* user);
+
 #ifdef __cplusplus
 }
 #endif

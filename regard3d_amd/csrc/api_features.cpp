@@ -711,13 +711,22 @@ static inline char* put_g(char* p, char* end, float v)
 
 // KeypointSet::saveToBinFile (src/keypointSet.hpp:61-67): .feat = one "x y scale orientation" line per feature
 // (SIOPointFeature::operator<<, default float formatting; scale = size / 2, :835-836), .desc = count + raw rows
-static int write_feat_desc(r3dm_ctx* c, const char* feat_path, const char* desc_path, const float* kps, const float* desc, uint32_t n)
+// xy_as_written (optional, n x 2): the positions as a reader of the file parses them (std::from_chars on the text just written)
+static int write_feat_desc(r3dm_ctx* c, const char* feat_path, const char* desc_path, const float* kps, const float* desc, uint32_t n,
+                           float* xy_as_written = nullptr)
 {
     std::vector<char> txt((size_t)n * 64 + 64);
     char* p = txt.data(); char* const end = p + txt.size();
     for (uint32_t k = 0; k < n; ++k) {
+        char* const x0 = p;
         p = put_g(p, end, kps[4 * (size_t)k]); *p++ = ' ';
+        char* const y0 = p;
         p = put_g(p, end, kps[4 * (size_t)k + 1]); *p++ = ' ';
+        if (xy_as_written) {
+            float vx = kps[4 * (size_t)k], vy = kps[4 * (size_t)k + 1];
+            (void)std::from_chars(x0, y0 - 1, vx); (void)std::from_chars(y0, p - 1, vy);
+            xy_as_written[2 * (size_t)k] = vx; xy_as_written[2 * (size_t)k + 1] = vy;
+        }
         p = put_g(p, end, kps[4 * (size_t)k + 2] / 2.0f); *p++ = ' ';
         p = put_g(p, end, kps[4 * (size_t)k + 3]); *p++ = '\n';
     }
@@ -813,17 +822,30 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     }
     c->stats.ms_liop_wall = now_ms() - t_liop;
     const double t_io = now_ms();
+    double ms_sink = 0.0;
+    std::vector<float> xy_written;
     for (uint32_t b = 0; b < B; ++b) {
         const uint32_t n = (uint32_t)bo.recs[b].size();
         if (feat_paths && desc_paths && feat_paths[b] && desc_paths[b]) {
-            rc = write_feat_desc(c, feat_paths[b], desc_paths[b], kps.data() + 4 * first[b], desc_host ? desc_host + 144 * first[b] : nullptr, n);
+            if (c->feat_sink) xy_written.resize((size_t)n * 2 + 2);
+            rc = write_feat_desc(c, feat_paths[b], desc_paths[b], kps.data() + 4 * first[b], desc_host ? desc_host + 144 * first[b] : nullptr, n,
+                                 c->feat_sink ? xy_written.data() : nullptr);
             if (rc != R3DM_OK) return rc;
+            if (c->feat_sink) {
+                // the descriptors of the batch are still in liop_out (this context's stream is idle: the copy above was waited for)
+                const double t_s = now_ms();
+                const int src = c->feat_sink(c->feat_sink_user, c->feat_sink_ids ? c->feat_sink_ids[b] : b, n,
+                                             n ? c->liop_out.as<float>() + 144 * first[b] : nullptr, xy_written.data());
+                ms_sink += now_ms() - t_s;
+                (void)hipSetDevice(c->device);                 // the sink may have worked on another device from this thread
+                if (src != 0) { c->err = "the features sink refused image " + std::to_string(c->feat_sink_ids ? c->feat_sink_ids[b] : b); return R3DM_ERR_INVALID; }
+            }
         }
         if (n_features) n_features[b] = n;
         if (kps_out) (*kps_out)[b].assign(kps.begin() + 4 * first[b], kps.begin() + 4 * first[b + 1]);
         if (desc_out) { if (n) (*desc_out)[b].assign(desc_host + 144 * first[b], desc_host + 144 * first[b + 1]); else (*desc_out)[b].clear(); }
     }
-    c->stats.ms_feature_files = now_ms() - t_io;
+    c->stats.ms_feature_files = now_ms() - t_io - ms_sink;
     c->feat_totals.ms_liop_kernels += n_total ? c->stats.ms_liop_kernel : 0.0;
     c->feat_totals.ms_wall += c->stats.ms_liop_wall + c->stats.ms_feature_files;
     c->feat_totals.ms_files += c->stats.ms_feature_files;
@@ -950,8 +972,10 @@ int multi_extract_impl(r3dm_multi* m, uint32_t n_images, const float* const* gra
                     std::vector<const char*> fp(B), dp(B); std::vector<uint32_t> nf(B, 0);
                     const bool gk = is_gray(mine[0]);
                     for (uint32_t j = 0; j < B; ++j) { if (gk) g[j] = grays[mine[j]]; else bg[j] = bgrs[mine[j]]; fp[j] = feat_paths[mine[j]]; dp[j] = desc_paths[mine[j]]; }
+                    c->feat_sink_ids = mine.data();                    // the sink (if any) is told the caller's indices
                     const int rc = r3dm_extract_features_batch(c, B, gk ? g.data() : nullptr, gk ? nullptr : bg.data(), widths[mine[0]], heights[mine[0]],
                                                                threshold, fp.data(), dp.data(), nf.data());
+                    c->feat_sink_ids = nullptr;
                     if (n_features) for (uint32_t j = 0; j < B; ++j) n_features[mine[j]] = nf[j];
                     if (rc != R3DM_OK) { rcs[k] = rc; errs[k] = std::string("image ") + std::to_string(mine[0]) + " (batch of " + std::to_string(B) + "): " + r3dm_last_error(c); }
                 }
@@ -974,6 +998,20 @@ int multi_extract_impl(r3dm_multi* m, uint32_t n_images, const float* const* gra
 }
 
 }  // namespace
+
+extern "C" int r3dm_set_features_sink(r3dm_ctx* c, r3dm_features_sink sink, void* user)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    c->feat_sink = sink; c->feat_sink_user = sink ? user : nullptr;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_multi_set_features_sink(r3dm_multi* m, r3dm_features_sink sink, void* user)
+{
+    if (!m) return R3DM_ERR_INVALID;
+    for (int k = 0; k < r3dm_multi_num_devices(m); ++k) (void)r3dm_set_features_sink(r3dm_multi_ctx(m, k), sink, user);
+    return R3DM_OK;
+}
 
 extern "C" int r3dm_multi_extract_features(r3dm_multi* m, uint32_t n_images, const float* const* grays, const uint32_t* widths,
                                            const uint32_t* heights, float threshold, const char* const* feat_paths,

@@ -157,6 +157,21 @@ R3DComputeMatches::~R3DComputeMatches()
     if (multi_) r3dm_multi_destroy(multi_);
 }
 
+// r3dm_features_sink of the features stage: the view is registered with the matcher from the worker thread that computed it
+// (descriptors device to device, positions as written to the .feat file).  A registration that fails is not an error: the view
+// is then read back from its files like any other.
+int R3DComputeMatches::features_sink(void* self_, uint32_t image_index, uint32_t n_features, const float* desc_device, const float* xy_as_written)
+{
+    R3DComputeMatches* self = static_cast<R3DComputeMatches*>(self_);
+    const size_t vi = self->sink_need_[image_index];
+    const View& v = self->views_[vi];
+    std::lock_guard<std::mutex> lk(self->sink_mu_);
+    const int rc = self->ctx_ ? r3dm_set_image(self->ctx_, v.id_view, v.ui_width, v.ui_height, desc_device, n_features, self->dim_, self->dtype_, xy_as_written)
+                              : r3dm_multi_set_image(self->multi_, v.id_view, v.ui_width, v.ui_height, desc_device, n_features, self->dim_, self->dtype_, xy_as_written);
+    if (rc == R3DM_OK) { self->registered_[vi] = 1; self->registered_n_[vi] = n_features; }
+    return 0;
+}
+
 // R3DFeaturesThread::extractFeaturesAndDescriptors(vec_fileNames, sOutDir, params) (/root/reference/src/R3DComputeMatches.cpp:1994-1995,
 // src/threads/R3DFeaturesThread.cpp:38-210) for the views whose two files are not both there.  The reference's worker threads
 // admit one image at a time into the detector; here feat_conc_ batches of feat_batch_ same-size images are in flight per device.
@@ -177,6 +192,7 @@ bool R3DComputeMatches::runFeaturesStage(const R3DFParams& params, const std::st
         if (rc != R3DM_OK) { feat_multi_ = nullptr; errorMessage_ = "r3dm_multi_create (features stage) failed (" + std::to_string(rc) + ")"; return false; }
     }
     const int n_ctx = r3dm_multi_num_devices(feat_multi_);
+    (void)r3dm_multi_set_features_sink(feat_multi_, direct_registration_ ? &R3DComputeMatches::features_sink : nullptr, this);
     r3dm_features_totals before{};
     for (int k = 0; k < n_ctx; ++k) {
         r3dm_features_totals t{};
@@ -213,6 +229,7 @@ bool R3DComputeMatches::runFeaturesStage(const R3DFParams& params, const std::st
         }
         int rc = R3DM_OK;
         char err[512] = {0};
+        sink_need_ = need.data() + c0;
         if (ok) rc = r3dm_multi_extract_features_ex(feat_multi_, (uint32_t)cn, grays.data(), bgrs.data(), ws.data(), hs.data(), params.threshold_,
                                                     fp.data(), dp.data(), nf.data(), sk.data(), (uint32_t)std::max(1, feat_batch_), err, sizeof(err));
         if (provider_release_) for (size_t k = 0; k < cn; ++k) if (provided[k]) provider_release_(views_[need[c0 + k]], provider_user_);
@@ -300,6 +317,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     const size_t row_bytes = dtype_ == R3DM_F32 ? (size_t)dim_ * 4 : (size_t)dim_;
 
     // ---- R3DFeaturesThread::extractFeaturesAndDescriptors(vec_fileNames, sOutDir, params) (:1994-1995)
+    if (clear_images() != R3DM_OK) { errorMessage_ = last_error(); return false; }
+    registered_.assign(views_.size(), 0); registered_n_.assign(views_.size(), 0);
     {
         const double t0 = wall_ms();
         if (!runFeaturesStage(params, dir)) return false;
@@ -307,8 +326,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     }
     const double t_load = wall_ms();
 
-    // ---- Regions_Provider::load + Features_Provider::load (src/R3DComputeMatches.cpp:2040,2094-2095)
-    if (clear_images() != R3DM_OK) { errorMessage_ = last_error(); return false; }
+    // ---- Regions_Provider::load + Features_Provider::load (src/R3DComputeMatches.cpp:2040,2094-2095): the views the features stage
+    // computed in this call are registered already (features_sink); the files of the others are read here
     // files are read and parsed by all host threads, 64 views at a time; registration (device copies) stays in view order
     struct Loaded { std::vector<float> xy; std::vector<unsigned char> desc; uint64_t n = 0; bool ok = false; };
     std::vector<Loaded> chunk;
@@ -320,6 +339,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
             for (long k = 0; k < (long)cn; ++k) {
                 const View& u = views_[vi + (size_t)k];
                 Loaded& L = chunk[(size_t)k];
+                if (registered_[vi + (size_t)k]) { L.ok = true; continue; }
                 // nothing may leave an OpenMP region by exception (std::terminate): a failed allocation is a failed load
                 try { L.ok = load_feat(dir + "/" + u.basename + ".feat", L.xy) && load_desc(dir + "/" + u.basename + ".desc", row_bytes, L.desc, L.n); }
                 catch (...) { L.ok = false; }
@@ -334,10 +354,13 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
             errorMessage_ = "Invalid features: " + v.basename;       // reference: MLOG "Invalid features." + return false (:2096-2097)
             return false;
         }
-        if (xy.size() != 2 * n) { errorMessage_ = "feature/descriptor count mismatch: " + v.basename; return false; }
-        statistics_.numberOfKeypoints_.push_back((int)n);
-        const int rc = set_image(v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, xy.data());
-        if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
+        if (registered_[vi]) statistics_.numberOfKeypoints_.push_back((int)registered_n_[vi]);
+        else {
+            if (xy.size() != 2 * n) { errorMessage_ = "feature/descriptor count mismatch: " + v.basename; return false; }
+            statistics_.numberOfKeypoints_.push_back((int)n);
+            const int rc = set_image(v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, xy.data());
+            if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
+        }
         if (v.focal_px > 0.0) {
             const double K[9] = {v.focal_px, 0.0, v.ppx, 0.0, v.focal_px, v.ppy, 0.0, 0.0, 1.0};      // Pinhole_Intrinsic::K()
             if (set_intrinsics(v.id_view, K) != R3DM_OK) { errorMessage_ = last_error(); return false; }

@@ -148,6 +148,8 @@ struct r3dm_ctx {
     uint32_t liop_npix = 0;
     uint64_t n_views_staged = 0;                            // copies + re-layouts since r3dm_create (never reset)
     r3dm_stats stats{};
+    r3dm_features_sink feat_sink = nullptr; void* feat_sink_user = nullptr;   // r3dm_set_features_sink
+    const uint32_t* feat_sink_ids = nullptr;                 // indices of the running batch in its caller's arrays (r3dm_multi_extract_features*), else 0 .. B-1
     r3dm_features_totals feat_totals{};                      // since r3dm_create (r3dm_get_features_totals)
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
 };
