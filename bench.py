@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS) + ["stage"], default="c2")
     ap.add_argument("--stage-size", default="4000x3000", help="--config stage: image size WxH")
+    ap.add_argument("--stage-features", default="2x8", help="--config stage: detector batches in flight x images per batch")
+    ap.add_argument("--stage-quick", action="store_true", help="--config stage: the timed steps only (no arm re-runs, rooflines or CPU leg): tuning runs")
     ap.add_argument("--images", type=int, default=0, help="override the collection size of the config (stated in config.workload)")
     ap.add_argument("--feat", type=int, default=0, help="override the features per image of the config")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
@@ -239,7 +241,7 @@ def stage_main(a):
     bare = [dict(v, gray=None) for v in views]
     n_pairs = N * (N - 1) // 2
     d = tempfile.mkdtemp(prefix="r3dm_stage_")
-    conc, batch = 2, 8
+    conc, batch = (int(x) for x in a.stage_features.lower().split("x"))
 
     def wipe(all_files=True):
         for f in os.listdir(d):
@@ -262,6 +264,10 @@ def stage_main(a):
         elapsed = time.perf_counter() - t0
         mean = lambda k: sum(r[k] for r in reps) / len(reps)
         last = reps[-1]
+        if a.stage_quick:
+            print(json.dumps({"stage_features": a.stage_features, "ms_per_step": elapsed / a.steps * 1e3,
+                              "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total")}}))
+            return
         # the GUI's default arm (matchingAlgorithm 0 = FLANN kd-trees in the reference, src/Regard3DMainFrame.cpp:2405) on the files
         # the step left: no extraction, matching + filters only -- under the facade's default policy (an approximate arm is served by
         # whichever matcher is faster on the views: exhaustive for LIOP-144), as requested (the graph matcher), and arm 9 the same

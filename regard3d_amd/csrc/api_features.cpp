@@ -712,7 +712,7 @@ static inline char* put_g(char* p, char* end, float v)
 // KeypointSet::saveToBinFile (src/keypointSet.hpp:61-67): .feat = one "x y scale orientation" line per feature
 // (SIOPointFeature::operator<<, default float formatting; scale = size / 2, :835-836), .desc = count + raw rows
 // xy_as_written (optional, n x 2): the positions as a reader of the file parses them (std::from_chars on the text just written)
-static int write_feat_desc(r3dm_ctx* c, const char* feat_path, const char* desc_path, const float* kps, const float* desc, uint32_t n,
+static int write_feat_desc(std::string& err, const char* feat_path, const char* desc_path, const float* kps, const float* desc, uint32_t n,
                            float* xy_as_written = nullptr)
 {
     std::vector<char> txt((size_t)n * 64 + 64);
@@ -731,16 +731,16 @@ static int write_feat_desc(r3dm_ctx* c, const char* feat_path, const char* desc_
         p = put_g(p, end, kps[4 * (size_t)k + 3]); *p++ = '\n';
     }
     FILE* f = fopen(feat_path, "wb");
-    if (!f) { c->err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
+    if (!f) { err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
     bool ok = (p == txt.data()) || fwrite(txt.data(), 1, (size_t)(p - txt.data()), f) == (size_t)(p - txt.data());
     ok = (fclose(f) == 0) && ok;
-    if (!ok) { c->err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
+    if (!ok) { err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
     f = fopen(desc_path, "wb");
-    if (!f) { c->err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
+    if (!f) { err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
     const uint64_t cnt = n;
     ok = fwrite(&cnt, 8, 1, f) == 1 && (n == 0 || fwrite(desc, 144 * 4, n, f) == n);
     ok = (fclose(f) == 0) && ok;
-    if (!ok) { c->err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
+    if (!ok) { err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
     return R3DM_OK;
 }
 
@@ -779,15 +779,21 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     first[B] = n_total;
     std::vector<float> kps(4 * n_total), M6(6 * n_total);
     std::vector<uint32_t> img_of(n_total);
-    for (uint32_t b = 0; b < B; ++b)
-        for (size_t k = 0; k < bo.recs[b].size(); ++k) {
-            const AkKpRec& r = bo.recs[b][k];
-            const size_t g = first[b] + k;
+    // angle (atan2f of the host libm, as the reference) and LIOP patch map of every keypoint: a few host threads share the loop
+    for (uint32_t b = 0; b < B; ++b) {
+        const long nk = (long)bo.recs[b].size();
+        const AkKpRec* recs = bo.recs[b].data();
+        const size_t f0 = first[b];
+#pragma omp parallel for schedule(static) num_threads(8) if (nk > 4096)
+        for (long k = 0; k < nk; ++k) {
+            const AkKpRec& r = recs[k];
+            const size_t g = f0 + (size_t)k;
             float* o = &kps[4 * g];
             o[0] = r.x; o[1] = r.y; o[2] = r.size; o[3] = ak_angle_deg(ak_theta(r));
             liop_patch_map(o[0], o[1], o[2], o[3], 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, &M6[6 * g]);
             img_of[g] = b;
         }
+    }
     const float* desc_host = nullptr;
     if (n_total) {
         rc = liop_prepare(c);
@@ -823,19 +829,35 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     c->stats.ms_liop_wall = now_ms() - t_liop;
     const double t_io = now_ms();
     double ms_sink = 0.0;
-    std::vector<float> xy_written;
+    // the files of the B images are formatted and written by up to 8 host threads (28 k keypoints = 113 k decimal conversions and
+    // 16 MB per image); the sink then sees the images in batch order from this thread
+    const bool to_files = feat_paths && desc_paths;
+    std::vector<std::vector<float>> xy_written(B);
+    std::vector<int> wrc(B, R3DM_OK);
+    std::vector<std::string> werr(B);
+    if (to_files) {
+#pragma omp parallel for schedule(dynamic) num_threads(8) if (B > 1)
+        for (long b = 0; b < (long)B; ++b) {
+            if (!feat_paths[b] || !desc_paths[b]) continue;
+            const uint32_t n = (uint32_t)bo.recs[b].size();
+            try {                                                   // nothing may leave an OpenMP region by exception
+                if (c->feat_sink) xy_written[b].resize((size_t)n * 2 + 2);
+                std::string e;
+                wrc[b] = write_feat_desc(e, feat_paths[b], desc_paths[b], kps.data() + 4 * first[b], desc_host ? desc_host + 144 * first[b] : nullptr, n,
+                                         c->feat_sink ? xy_written[b].data() : nullptr);
+                werr[b] = e;
+            } catch (...) { wrc[b] = R3DM_ERR_NOMEM; }
+        }
+    }
     for (uint32_t b = 0; b < B; ++b) {
         const uint32_t n = (uint32_t)bo.recs[b].size();
-        if (feat_paths && desc_paths && feat_paths[b] && desc_paths[b]) {
-            if (c->feat_sink) xy_written.resize((size_t)n * 2 + 2);
-            rc = write_feat_desc(c, feat_paths[b], desc_paths[b], kps.data() + 4 * first[b], desc_host ? desc_host + 144 * first[b] : nullptr, n,
-                                 c->feat_sink ? xy_written.data() : nullptr);
-            if (rc != R3DM_OK) return rc;
+        if (to_files && feat_paths[b] && desc_paths[b]) {
+            if (wrc[b] != R3DM_OK) { c->err = werr[b].empty() ? "out of host memory" : werr[b]; return wrc[b]; }
             if (c->feat_sink) {
                 // the descriptors of the batch are still in liop_out (this context's stream is idle: the copy above was waited for)
                 const double t_s = now_ms();
                 const int src = c->feat_sink(c->feat_sink_user, c->feat_sink_ids ? c->feat_sink_ids[b] : b, n,
-                                             n ? c->liop_out.as<float>() + 144 * first[b] : nullptr, xy_written.data());
+                                             n ? c->liop_out.as<float>() + 144 * first[b] : nullptr, xy_written[b].data());
                 ms_sink += now_ms() - t_s;
                 (void)hipSetDevice(c->device);                 // the sink may have worked on another device from this thread
                 if (src != 0) { c->err = "the features sink refused image " + std::to_string(c->feat_sink_ids ? c->feat_sink_ids[b] : b); return R3DM_ERR_INVALID; }
