@@ -10,6 +10,8 @@
 #include <fstream>
 #include <sstream>
 #include <algorithm>
+#include <memory>
+#include <thread>
 
 namespace r3d_amd {
 
@@ -56,6 +58,37 @@ bool load_feat(const std::string& path, std::vector<float>& xy)
     }
     return true;
 }
+
+// Save(PairWiseMatches, file) of the .txt and the .bin of a graph on two host threads while the next filter runs on the GPU; the
+// destructor waits for every write and frees the graphs it was given
+struct MatchFileWriter {
+    struct Job { std::thread th; int rc = R3DM_OK; std::string path; };
+    std::vector<std::unique_ptr<Job>> jobs;
+    std::vector<r3dm_graph*> owned;
+    void save(const r3dm_graph* g, const std::string& txt_path, const std::string& bin_path)
+    {
+        for (const std::string& p : {txt_path, bin_path}) {
+            std::unique_ptr<Job> j(new Job());
+            j->path = p;
+            Job* raw = j.get();
+            try { raw->th = std::thread([g, raw]() noexcept { raw->rc = r3dm_save_matches(g, raw->path.c_str()); }); }
+            catch (...) { raw->rc = r3dm_save_matches(g, raw->path.c_str()); }             // no thread to be had: write here
+            jobs.push_back(std::move(j));
+        }
+    }
+    void own(r3dm_graph* g) { owned.push_back(g); }
+    // waits for all writes; the path of the first one that failed, or ""
+    std::string finish()
+    {
+        std::string bad;
+        for (auto& j : jobs) { if (j->th.joinable()) j->th.join(); if (j->rc != R3DM_OK && bad.empty()) bad = j->path; }
+        jobs.clear();
+        for (r3dm_graph* g : owned) r3dm_graph_free(g);
+        owned.clear();
+        return bad;
+    }
+    ~MatchFileWriter() { (void)finish(); }
+};
 
 bool load_desc(const std::string& path, size_t row_bytes, std::vector<unsigned char>& data, uint64_t& n)
 {
@@ -404,13 +437,11 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     t_phase = wall_ms();
     graph_to_map(putative, statistics_.putativeMatches_);
     const std::string put_path = paths.matchesPutitativeFilename_.empty() ? dir + "/matches.putative.txt" : paths.matchesPutitativeFilename_;
-    if (r3dm_save_matches(putative, put_path.c_str()) != R3DM_OK ||
-        r3dm_save_matches(putative, with_ext(put_path, ".bin").c_str()) != R3DM_OK) {
-        // the reference returns EXIT_FAILURE (== true) from a bool function here (:2069); a real failure is reported instead
-        errorMessage_ = "Cannot save computed matches in: " + put_path;
-        r3dm_graph_free(putative);
-        return false;
-    }
+    // the match files are written behind the filters (two host threads per graph); failures are reported at the end -- the reference
+    // returns EXIT_FAILURE (== true) from a bool function there (:2069), a real failure is reported instead
+    MatchFileWriter writer;
+    writer.own(putative);
+    writer.save(putative, put_path, with_ext(put_path, ".bin"));
 
     if (svgOutput) write_adjacency_svg(dir + "/PutativeAdjacencyMatrix.svg", views_.size(), statistics_.putativeMatches_);   // :2074
     phases_.files += wall_ms() - t_phase;
@@ -421,16 +452,14 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         r3dm_graph* geo = nullptr;
         t_phase = wall_ms();
         rc = filter_F(putative, &geo);
-        if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
         phases_.filter_F = wall_ms() - t_phase; phases_.F_kernels = kernel_ms(true);
         t_phase = wall_ms();
         graph_to_map(geo, statistics_.fundamentalMatches_);
         const std::string f_path = paths.matchesFFilename_.empty() ? dir + "/matches.f.txt" : paths.matchesFFilename_;
-        const bool ok = r3dm_save_matches(geo, f_path.c_str()) == R3DM_OK &&
-                        r3dm_save_matches(geo, with_ext(f_path, ".bin").c_str()) == R3DM_OK;
-        r3dm_graph_free(geo);
+        writer.own(geo);
+        writer.save(geo, f_path, with_ext(f_path, ".bin"));
         phases_.files += wall_ms() - t_phase;
-        if (!ok) { errorMessage_ = "Cannot save computed matches in: " + f_path; r3dm_graph_free(putative); return false; }
     }
     // ---- essential-matrix filter (:2130-2204): 5-point solver on K^-1 x, then the overlap rule (>= 50 matches and
     //      >= 30 % of the putative matches, :2175-2192); matches.e.txt feeds the global SfM engine
@@ -439,16 +468,14 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         r3dm_graph* geo = nullptr;
         t_phase = wall_ms();
         rc = filter_E(putative, &geo);
-        if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
         phases_.filter_E = wall_ms() - t_phase; phases_.E_kernels = kernel_ms(true);
         t_phase = wall_ms();
         graph_to_map(geo, statistics_.essentialMatches_);
         const std::string e_path = paths.matchesEFilename_.empty() ? dir + "/matches.e.txt" : paths.matchesEFilename_;
-        const bool ok = r3dm_save_matches(geo, e_path.c_str()) == R3DM_OK &&
-                        r3dm_save_matches(geo, with_ext(e_path, ".bin").c_str()) == R3DM_OK;
-        r3dm_graph_free(geo);
+        writer.own(geo);
+        writer.save(geo, e_path, with_ext(e_path, ".bin"));
         phases_.files += wall_ms() - t_phase;
-        if (!ok) { errorMessage_ = "Cannot save computed matches in: " + e_path; r3dm_graph_free(putative); return false; }
     }
     // ---- homography filter (:2216-2233): same skeleton, 4-point solver; matches.h.txt
     if (params.computeHomographyMatrix_) {
@@ -456,16 +483,14 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         r3dm_graph* geo = nullptr;
         t_phase = wall_ms();
         rc = filter_H(putative, &geo);
-        if (rc != R3DM_OK) { errorMessage_ = last_error(); r3dm_graph_free(putative); return false; }
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
         phases_.filter_H = wall_ms() - t_phase; phases_.H_kernels = kernel_ms(true);
         t_phase = wall_ms();
         graph_to_map(geo, statistics_.homographyMatches_);
         const std::string h_path = paths.matchesHFilename_.empty() ? dir + "/matches.h.txt" : paths.matchesHFilename_;
-        const bool ok = r3dm_save_matches(geo, h_path.c_str()) == R3DM_OK &&
-                        r3dm_save_matches(geo, with_ext(h_path, ".bin").c_str()) == R3DM_OK;
-        r3dm_graph_free(geo);
+        writer.own(geo);
+        writer.save(geo, h_path, with_ext(h_path, ".bin"));
         phases_.files += wall_ms() - t_phase;
-        if (!ok) { errorMessage_ = "Cannot save computed matches in: " + h_path; r3dm_graph_free(putative); return false; }
     }
     // GeometricAdjacencyMatrix.svg (:2238): the reference draws whichever filter ran last (H, else E, else F)
     if (svgOutput) {
@@ -473,7 +498,12 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
                                     : (params.computeEssentialMatrix_ ? statistics_.essentialMatches_ : statistics_.fundamentalMatches_);
         write_adjacency_svg(dir + "/GeometricAdjacencyMatrix.svg", views_.size(), last);
     }
-    r3dm_graph_free(putative);
+    {
+        const double t_w = wall_ms();
+        const std::string bad = writer.finish();
+        phases_.files += wall_ms() - t_w;
+        if (!bad.empty()) { errorMessage_ = "Cannot save computed matches in: " + bad; return false; }
+    }
     phases_.total = wall_ms() - t_begin;
     return true;
 }
