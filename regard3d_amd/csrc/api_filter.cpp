@@ -106,7 +106,11 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     fp.offsets = c->f_offs.as<uint64_t>(); fp.matches = c->f_matches.as<r3dm_match>();
     // LDS sort capacity: 8192 (x 12 B) fits beside the hypothesis buffer; pairs with more putatives sort in global scratch
     // (essential matrix: 4096, so that header + 16 hypotheses + sort buffers stay below 80 KB and two workgroups share a CU)
-    fp.n_items = NI; fp.m_cap = std::min<uint32_t>(model_kind == 2 ? 4096 : 8192, std::max<uint32_t>(64, next_pow2(max_m)));
+    // collections with long match lists (some pair above 4096 putatives: LDS admits one workgroup per CU anyway) run the 512-thread
+    // variant of the kernel -- the same results, every pass over a pair's matches in half the trips
+    const int wide_knob = r3dm_dev_knob("R3DM_FILTER_WIDE", -1);
+    fp.wide = wide_knob >= 0 ? (uint32_t)(wide_knob != 0) : (max_m > 4096 ? 1u : 0u);
+    fp.n_items = NI; fp.m_cap = std::min<uint32_t>((model_kind == 2 && !fp.wide) ? 4096 : 8192, std::max<uint32_t>(64, next_pow2(max_m)));
     fp.spill_keys = nullptr; fp.spill_idx = nullptr; fp.spill_off = nullptr;
     if (max_m > fp.m_cap) {
         std::vector<uint64_t> soff(NI, 0);

@@ -733,10 +733,10 @@ struct FState {
     double cur_nfa;          // scratch: NFA of the model under evaluation
     uint32_t nIter, reserve, iter, pool_size, n_inl, acMode, n_models, iters_done;
     uint32_t cnt, cur_k, flag, chunk_n;
-    uint32_t wave_cnt[4];
-    double   red_v[4];
-    double   red_b[4];       // reduction slots of the sort-skipping bound
-    uint32_t red_k[4];
+    uint32_t wave_cnt[8];    // (up to 8 waves: the wide variant of the kernel runs 512 threads)
+    double   red_v[8];
+    double   red_b[8];       // reduction slots of the sort-skipping bound
+    uint32_t red_k[8];
     uint32_t nm[64];
     uint32_t dbg_smp[64];    // debug trace: first sample index of each hypothesis of the chunk
     uint32_t dbg_pool;       // debug trace: pool size the chunk was drawn from
@@ -840,7 +840,9 @@ __device__ __forceinline__ bool pair_gt(unsigned long long a, uint32_t ai, unsig
     return (a > b) || (a == b && ai > bi);
 }
 
-template <int E>
+// GLOBAL: keys / sidx are the global spill buffers of a pair with more matches than the LDS holds (the register part is the same,
+// the few wave-crossing stages go through global memory with a fence at the barrier).
+template <int E, bool GLOBAL = false>
 __device__ __forceinline__ void wg_sort_regs(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx,
                                              uint32_t cap, uint32_t total, uint32_t tid)
 {
@@ -857,12 +859,12 @@ __device__ __forceinline__ void wg_sort_regs(unsigned long long* __restrict__ ke
     for (uint32_t size = 2; size <= cap; size <<= 1) {
         // ---- distances that cross waves: through LDS (every thread parks its entries, reads the partner's)
         for (uint32_t stride = size >> 1; stride >= 64u * E; stride >>= 1) {
-            r3dm_syncthreads();                                   // earlier readers of keys / sidx are done
+            wg_sync_t<GLOBAL>();                                   // earlier readers of keys / sidx are done
             if (base < cap) {
 #pragma unroll
                 for (int s = 0; s < E; ++s) { keys[base + s] = k[s]; sidx[base + s] = x[s]; }
             }
-            r3dm_syncthreads();
+            wg_sync_t<GLOBAL>();
             if (base < cap) {
 #pragma unroll
                 for (int s = 0; s < E; ++s) {
@@ -912,15 +914,17 @@ __device__ __forceinline__ void wg_sort_regs(unsigned long long* __restrict__ ke
             }
         }
     }
-    r3dm_syncthreads();
+    wg_sync_t<GLOBAL>();
     if (base < cap) {
 #pragma unroll
         for (int s = 0; s < E; ++s) { keys[base + s] = k[s]; sidx[base + s] = x[s]; }
     }
-    r3dm_syncthreads();
+    wg_sync_t<GLOBAL>();
 }
 
-template <int KIND, bool SPILL, class KeyT, class IdxT>
+// NT = threads of the workgroup: 256 (two workgroups per CU), or 512 for collections with long match lists (one workgroup per CU with
+// the same registers per lane; every pass over the matches of a pair -- residuals, bound, sort, NFA scan -- takes half the trips)
+template <int KIND, bool SPILL, int NT, class KeyT, class IdxT>
 __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __restrict__ pts, uint32_t* __restrict__ pool_g,
                                               float* __restrict__ logc_g, unsigned char* smem, KeyT keys, IdxT sidx, uint32_t item)
 {
@@ -933,6 +937,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     constexpr double MAXM = (KIND == 0) ? 3.0 : (KIND == 1 ? 1.0 : 10.0); // Kernel::MAX_MODELS
     constexpr double MULT_ERR = (KIND == 1) ? 1.0 : 0.5;       // multError(): point-to-point vs point-to-line
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t NW = (uint32_t)NT / 64u;
     const uint64_t begin = P.offsets[2 * item], end = P.offsets[2 * item + 1];
     const uint32_t m = (uint32_t)(end - begin);
     const uint2 sl = P.pairs[item];
@@ -958,7 +963,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     const double* K1i = S.kinv;
     const double* K2i = S.kinv + 9;
     if (KIND == 2 && tid < 18) S.kinv[tid] = P.kinv[9 * (size_t)(tid < 9 ? sl.x : sl.y) + (tid < 9 ? tid : tid - 9)];
-    for (uint32_t p = tid; p < m; p += 256) {
+    for (uint32_t p = tid; p < m; p += NT) {
         const r3dm_match q = mm[p];
         const double xi = (double)Ip->xy[2 * (size_t)q.i], yi = (double)Ip->xy[2 * (size_t)q.i + 1];
         const double xj = (double)Jp->xy[2 * (size_t)q.j], yj = (double)Jp->xy[2 * (size_t)q.j + 1];
@@ -996,7 +1001,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         S.cnt = 0u;
     }
 #pragma unroll
-    for (int j = 0; j < kHistBins / 256; ++j) hist[tid + 256 * j] = 0u;
+    for (int j = 0; j < kHistBins / NT; ++j) hist[tid + NT * j] = 0u;
     wg_sync_global();          // points, pool and logcombi table go through global memory
 
 #ifdef R3DM_E_TIMING
@@ -1012,7 +1017,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         constexpr uint32_t CH = (uint32_t)ChunkOf<KIND>::n;
         const uint32_t chunk_n = (nIter0 - iter0 < CH) ? nIter0 - iter0 : CH;
         // the hypothesis of the chunk this lane works on: lane c of wave 0 for F / H, the 16-lane group tid / 16 for E
-        const uint32_t hyp = (KIND == 2) ? (tid >> 4) : tid;
+        const uint32_t hyp = (KIND == 2) ? (tid >> 4) : tid;             // (threads beyond the first 256 of the wide variant draw nothing: hyp >= 16)
         const uint32_t pool_size = S.pool_size;
 
         // ---- draw + solve one chunk of minimal samples (hypothesis c <-> iteration iter0 + c)
@@ -1116,12 +1121,12 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 // barrier that closes it -- one barrier less per model than clearing them here)
                 // four batches of 256 matches per trip: the point loads (global memory, 32 bytes per match) of all four are in
                 // flight before the first residual is needed
-                for (uint32_t base = 0; base < m; base += 1024) {
+                for (uint32_t base = 0; base < m; base += 4u * NT) {
                     double r[4]; bool in[4];
                     double px[4][4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const uint32_t p = base + 256u * (uint32_t)u + tid;
+                        const uint32_t p = base + (uint32_t)NT * (uint32_t)u + tid;
                         const size_t pp = 4 * (size_t)(p < m ? p : 0u);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) px[u][e] = pt[pp + e];
@@ -1130,7 +1135,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     uint32_t n_new = 0;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const uint32_t p = base + 256u * (uint32_t)u + tid;
+                        const uint32_t p = base + (uint32_t)NT * (uint32_t)u + tid;
                         r[u] = (KIND == 0) ? sym_epipolar_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
                              : (KIND == 1) ? h_asym_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
                                            : epipolar_dist_err(FE, px[u][0], px[u][1], px[u][2], px[u][3]);
@@ -1147,7 +1152,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                             const uint32_t pos = woff + (uint32_t)__builtin_popcountll(bal[u] & ((1ull << lane) - 1ull));
                             FCHECK(pos < m || !in[u], 3, pos, m);
                             if (in[u]) {
-                                keys[pos] = (unsigned long long)__double_as_longlong(r[u]); sidx[pos] = base + 256u * (uint32_t)u + tid;
+                                keys[pos] = (unsigned long long)__double_as_longlong(r[u]); sidx[pos] = base + (uint32_t)NT * (uint32_t)u + tid;
                                 long long bin = (__double_as_longlong(r[u]) >> kHistShift) - hist_base;
                                 bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
                                 atomicAdd(&hist[bin], 1u);
@@ -1176,10 +1181,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 bool hopeless = false;
                 if (ac && total > SS && S.minNFA < __builtin_huge_val() && !R3DM_TRACE(P)) {
                     // inclusive running counts, 4 consecutive bins per thread, written back in place
-                    uint32_t cb[kHistBins / 256];
+                    uint32_t cb[kHistBins / NT];
                     uint32_t run = 0;
 #pragma unroll
-                    for (int j = 0; j < kHistBins / 256; ++j) { run += hist[tid * (kHistBins / 256) + j]; cb[j] = run; }
+                    for (int j = 0; j < kHistBins / NT; ++j) { run += hist[tid * (kHistBins / NT) + j]; cb[j] = run; }
                     uint32_t incl = run;
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= (uint32_t)off) incl += o; }
@@ -1187,15 +1192,15 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     wg_sync_t<SPILL>();
                     uint32_t excl = incl - run;
 #pragma unroll
-                    for (uint32_t w = 0; w < 4; ++w) if (w < wave) excl += S.wave_cnt[w];
+                    for (uint32_t w = 0; w < NW; ++w) if (w < wave) excl += S.wave_cnt[w];
 #pragma unroll
-                    for (int j = 0; j < kHistBins / 256; ++j) hist[tid * (kHistBins / 256) + j] = excl + cb[j];
+                    for (int j = 0; j < kHistBins / NT; ++j) hist[tid * (kHistBins / NT) + j] = excl + cb[j];
                     wg_sync_t<SPILL>();
                     // bins tid, tid + 256, ...: neighbouring (equally dense) bins go to different threads
                     double wmin = __builtin_huge_val();
 #pragma unroll
-                    for (int j = 0; j < kHistBins / 256; ++j) {
-                        const uint32_t b = tid + 256u * (uint32_t)j;
+                    for (int j = 0; j < kHistBins / NT; ++j) {
+                        const uint32_t b = tid + (uint32_t)NT * (uint32_t)j;
                         const uint32_t k_hi = hist[b], k_prev = b ? hist[b - 1] : 0u;
                         uint32_t k_lo = k_prev + 1u; if (k_lo < SS + 1u) k_lo = SS + 1u;
                         if (k_hi >= k_lo) {
@@ -1211,32 +1216,34 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wmin, off); wmin = o < wmin ? o : wmin; }
                     if (lane == 0) S.red_b[wave] = wmin;
                     wg_sync_t<SPILL>();
-                    wmin = fmin(fmin(S.red_b[0], S.red_b[1]), fmin(S.red_b[2], S.red_b[3]));      // (own slots: the NFA reduction below uses red_v, no barrier in between)
+                    wmin = S.red_b[0];
+#pragma unroll
+                    for (uint32_t w = 1; w < NW; ++w) wmin = fmin(wmin, S.red_b[w]);      // (own slots: the NFA reduction below uses red_v, no barrier in between)
                     hopeless = !R3DM_DBG(P) && (wmin - 1.0e-6 >= S.minNFA);
                     if (R3DM_DBG(P)) S_bound = wmin;              // developer build: nothing is skipped, the bound is checked against the NFA
                 }
                 if (ac && total > SS && !hopeless) {
                     // sort (residual, index) ascending: residuals are >= 0 so the u64 bit pattern orders them
                     uint32_t cap = 1; while (cap < total) cap <<= 1;
-                    bool sorted = false;
-                    if constexpr (!SPILL) {
-                        sorted = true;
-                        switch (cap >> 8) {
-                            case 0: case 1: wg_sort_regs<1>(keys, sidx, cap, total, tid); break;
-                            case 2: wg_sort_regs<2>(keys, sidx, cap, total, tid); break;
-                            case 4: wg_sort_regs<4>(keys, sidx, cap, total, tid); break;
-                            case 8: wg_sort_regs<8>(keys, sidx, cap, total, tid); break;
-                            case 16: wg_sort_regs<16>(keys, sidx, cap, total, tid); break;
-                            case 32: wg_sort_regs<32>(keys, sidx, cap, total, tid); break;
-                            default: sorted = false; break;
-                        }
+                    // (the 256-thread variant keeps its spilled lists on the plain network, as before: the register sort of a
+                    // global list is instantiated for the wide variant only)
+                    bool sorted = !SPILL || NT == 512;
+                    if constexpr (!SPILL || NT == 512)
+                    switch (cap / (uint32_t)NT) {
+                        case 0: case 1: wg_sort_regs<1, SPILL>(keys, sidx, cap, total, tid); break;
+                        case 2: wg_sort_regs<2, SPILL>(keys, sidx, cap, total, tid); break;
+                        case 4: wg_sort_regs<4, SPILL>(keys, sidx, cap, total, tid); break;
+                        case 8: wg_sort_regs<8, SPILL>(keys, sidx, cap, total, tid); break;
+                        case 16: wg_sort_regs<16, SPILL>(keys, sidx, cap, total, tid); break;
+                        case 32: wg_sort_regs<32, SPILL>(keys, sidx, cap, total, tid); break;
+                        default: sorted = false; break;               // longer lists: the plain network below
                     }
                     if (!sorted) {
-                    for (uint32_t q = total + tid; q < cap; q += 256) { keys[q] = ~0ull; sidx[q] = 0xFFFFFFFFu; }
+                    for (uint32_t q = total + tid; q < cap; q += NT) { keys[q] = ~0ull; sidx[q] = 0xFFFFFFFFu; }
                     wg_sync_t<SPILL>();
                     for (uint32_t size = 2; size <= cap; size <<= 1) {
                         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                            for (uint32_t tI = tid; tI < (cap >> 1); tI += 256) {
+                            for (uint32_t tI = tid; tI < (cap >> 1); tI += NT) {
                                 const uint32_t lo = 2 * tI - (tI & (stride - 1));
                                 const uint32_t hi = lo + stride;
                                 const bool up = ((lo & size) == 0);
@@ -1254,7 +1261,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 #endif
                     // bestNFA: k = 8 .. total, first minimum wins
                     double bv = __builtin_huge_val(); uint32_t bk = 0xFFFFFFFFu;
-                    for (uint32_t kk = SS + 1 + tid; kk <= total; kk += 256) {
+                    for (uint32_t kk = SS + 1 + tid; kk <= total; kk += NT) {
                         const double e = __longlong_as_double((long long)keys[kk - 1]);
                         const double logalpha = logalpha0 + MULT_ERR * log10(e + FLT_EPS_D);
                         const double v = loge0 + logalpha * (double)(kk - SS) + (double)logc_n[kk] + (double)P.logc_k[kk];
@@ -1270,7 +1277,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     if (lane == 0) { S.red_v[wave] = bv; S.red_k[wave] = bk; }
                     wg_sync_t<SPILL>();
 #pragma unroll
-                    for (uint32_t w = 0; w < 4; ++w) {
+                    for (uint32_t w = 0; w < NW; ++w) {
                         const double ov = S.red_v[w]; const uint32_t ok = S.red_k[w];
                         if (w == 0 || ov < nfa || (ov == nfa && ok < kbest)) { nfa = ov; kbest = ok; }
                     }
@@ -1282,7 +1289,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 FCHECK(!improve || (kbest <= total && kbest > SS), 4, kbest, total);
                 FCHECK(S_bound - 1.0e-6 <= nfa, 8, kbest, total);                 // the sort-skipping bound really is one
                 if (improve) {
-                    for (uint32_t q = tid; q < kbest; q += 256) inl[q] = sidx[q];
+                    for (uint32_t q = tid; q < kbest; q += NT) inl[q] = sidx[q];
                     better = true;
                 }
                 wg_sync_t<SPILL>();
@@ -1307,7 +1314,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     S.cnt = 0u;                                   // for the next model (every reader of this model's count is behind the barrier above)
                 }
 #pragma unroll
-                for (int j = 0; j < kHistBins / 256; ++j) hist[tid + 256 * j] = 0u;     // ... and its histogram: last read before the commit barrier
+                for (int j = 0; j < kHistBins / NT; ++j) hist[tid + NT * j] = 0u;     // ... and its histogram: last read before the commit barrier
                 wg_sync_t<SPILL>();
             }
             // ---- end of iteration `it`: ACRANSAC's pool / budget update.  Thread 0 is about to change the loop bounds that
@@ -1334,13 +1341,13 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 // positions must not depend on it -- same rule in oracle/acransac.c.)
                 const uint32_t ni = S.n_inl;
                 IdxT flags = sidx;                                       // sort scratch, free between models
-                for (uint32_t q = tid; q < m; q += 256) flags[q] = 0u;
+                for (uint32_t q = tid; q < m; q += NT) flags[q] = 0u;
                 wg_sync_t<SPILL>();
                 FCHECK(ni <= m, 5, ni, m);
-                for (uint32_t q = tid; q < ni; q += 256) { const uint32_t iq = inl[q]; FCHECK(iq < m, 6, iq, q); if (!R3DM_DBG(P) || iq < m) flags[iq] = 1u; }
+                for (uint32_t q = tid; q < ni; q += NT) { const uint32_t iq = inl[q]; FCHECK(iq < m, 6, iq, q); if (!R3DM_DBG(P) || iq < m) flags[iq] = 1u; }
                 wg_sync_t<SPILL>();
                 uint32_t filled = 0;
-                for (uint32_t base = 0; base < m; base += 256) {
+                for (uint32_t base = 0; base < m; base += NT) {
                     const uint32_t p = base + tid;
                     const bool in = (p < m) && (flags[p] != 0u);
                     const unsigned long long bal = __ballot(in);
@@ -1349,7 +1356,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                     wg_sync_t<SPILL>();
                     uint32_t woff = 0, tot = 0;
 #pragma unroll
-                    for (uint32_t w = 0; w < 4; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
+                    for (uint32_t w = 0; w < NW; ++w) { const uint32_t cw = S.wave_cnt[w]; if (w < wave) woff += cw; tot += cw; }
                     if (in) pool[filled + woff + before] = p;
                     filled += tot;
                     wg_sync_t<SPILL>();
@@ -1412,9 +1419,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 
 // Two workgroups per CU for F and H (256 registers per lane; the F kernel trades 42 spilled VGPRs of its cold solver path
 // for the second workgroup: 40.0 -> 24.8 ms on the 790 pairs of C2, three per CU at 168 registers gains nothing more);
-// the E kernel's 5-point workspace (102 KiB LDS) allows one.
-template <int KIND>
-__global__ __launch_bounds__(256, 2)
+// E likewise since its 5-point solver became a cooperative LDS routine.  The wide variant (NT = 512, one workgroup per CU, the same
+// registers per lane) serves collections with long match lists: FilterParams::wide, set by the host (api_filter.cpp).
+template <int KIND, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1)
 void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
                      uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
 {
@@ -1425,12 +1433,12 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
     if (m <= P.m_cap) {
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + kHdr + ChunkOf<KIND>::n * MS * 8);
         uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
-        acransac_body<KIND, false>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
+        acransac_body<KIND, false, NT>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
     } else {
         // slice of the global spill buffer, sized for the next power of two of m (host: spill_off[item])
         unsigned long long* keys = P.spill_keys + P.spill_off[item];
         uint32_t* sidx = P.spill_idx + P.spill_off[item];
-        acransac_body<KIND, true>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
+        acransac_body<KIND, true, NT>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
     }
 }
 
@@ -1440,13 +1448,18 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
 // gave run-to-run different inlier sets.  The cooperative solver above has no calls and no spills; the option is gone, and
 // tests/test_gpu_fullsize.py::test_filters_are_deterministic_when_workgroups_share_a_cu runs against the default build.)
 hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds);
+template <int KIND, int NT>
+static hipError_t launch_acransac(hipStream_t st, const FilterParams& P, size_t lds)
+{
+    hipError_t e = hipFuncSetAttribute((const void*)acransac_kernel<KIND, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((acransac_kernel<KIND, NT>), dim3(P.n_items), dim3(NT), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+    return hipGetLastError();
+}
 #ifdef R3DM_FILTER_ONLY_E
 hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds)
 {
-    hipError_t e = hipFuncSetAttribute((const void*)acransac_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(acransac_kernel<2>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
-    return hipGetLastError();
+    return P.wide ? launch_acransac<2, 512>(st, P, lds) : launch_acransac<2, 256>(st, P, lds);
 }
 #else
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
@@ -1454,14 +1467,8 @@ hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
     if (P.n_items == 0) return hipSuccess;
     const size_t lds = filter_F_lds_bytes(P.m_cap, P.model_kind);
     if (P.model_kind == 2) return launch_filter_E(st, P, lds);
-    const void* fn = (P.model_kind == 0) ? (const void*)acransac_kernel<0> : (const void*)acransac_kernel<1>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (P.model_kind == 0)
-        hipLaunchKernelGGL(acransac_kernel<0>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
-    else
-        hipLaunchKernelGGL(acransac_kernel<1>, dim3(P.n_items), dim3(256), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
-    return hipGetLastError();
+    if (P.model_kind == 0) return P.wide ? launch_acransac<0, 512>(st, P, lds) : launch_acransac<0, 256>(st, P, lds);
+    return P.wide ? launch_acransac<1, 512>(st, P, lds) : launch_acransac<1, 256>(st, P, lds);
 }
 #endif
 

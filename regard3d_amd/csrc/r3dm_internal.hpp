@@ -203,6 +203,7 @@ struct FilterParams {
     const r3dm_match* matches;
     uint32_t      n_items;
     uint32_t      m_cap;          // LDS sort capacity (power of two); items with more putatives use the spill buffers
+    uint32_t      wide;           // != 0: the 512-thread variant of the kernel (long match lists: one workgroup per CU, half the trips per pass)
     unsigned long long* spill_keys;  // optional global sort buffers for those items
     uint32_t*     spill_idx;
     const uint64_t* spill_off;    // [n_items] element offset of the item's slice (next_pow2(m) elements)

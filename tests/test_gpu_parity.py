@@ -385,6 +385,41 @@ def test_views_beyond_the_lds_sort_budget(ctx, oracle, n, frac):
     assert min(np.linalg.norm(a - b), np.linalg.norm(a + b)) < 1e-9
 
 
+@pytest.mark.parametrize("n,frac", [(11500, 0.95), (7000, 0.9), (22000, 0.95)])
+def test_filters_on_long_match_lists(ctx, oracle, n, frac):
+    """The wide (512-thread) variant of the AC-RANSAC kernel, chosen when a pair has more than 4096 putatives: ~10 k matches
+    (beyond the 8192-entry LDS list: global list, register sort), ~6 k (LDS list) and ~20 k (global list, plain network) --
+    F, E and H inlier sets and models equal to the CPU restatement's, as on the 256-thread variant."""
+    rng = np.random.default_rng(n + 5)
+    A, xyA, B, xyB = _two_view_scene(rng, n, 16, frac)
+    K = np.array([[4800.0, 0, 2000], [0, 4800.0, 1500], [0, 0, 1]])          # the cameras of _two_view_scene
+    ctx.clear_images()
+    ctx.set_image(0, A, xyA, 4000, 3000); ctx.set_image(1, B, xyB, 4000, 3000)
+    ctx.set_intrinsics(0, K); ctx.set_intrinsics(1, K)
+    pairs = np.array([[0, 1]], np.uint32)
+    g = ctx.match_pairs(pairs, 0.6, True)
+    counts = np.diff(g.offsets.astype(np.int64)).astype(np.uint32)
+    assert counts[0] > 0.8 * n * frac
+    xys, W, H = [xyA, xyB], [4000, 4000], [3000, 3000]
+    gf, F = ctx.filter_F(g, 4.0, 2048, seed=5489, want_F=True)
+    oc, om, oF = oracle.filter_F_collection(xys, W, H, pairs, counts, g.matches, 4.0, 2048, 5489, want_F=True)
+    assert oc[0] > 0.5 * counts[0] and set(map(tuple, gf.matches.tolist())) == set(map(tuple, om.tolist()))
+    a = F[0] / np.linalg.norm(F[0]); b = oF[0] / np.linalg.norm(oF[0])
+    assert min(np.linalg.norm(a - b), np.linalg.norm(a + b)) < 1e-9
+    ge, Em = ctx.filter_E(g, 4.0, 2048, seed=5489, min_count=50, min_ratio=0.3, want_E=True)
+    ec, em, oE = oracle.filter_E_collection(xys, W, H, np.stack([K, K]), pairs, counts, g.matches, 4.0, 2048, 5489,
+                                            prune_min_count=50, prune_min_ratio=0.3, want_E=True)
+    assert set(map(tuple, ge.matches.tolist())) == set(map(tuple, em.tolist())) and ec[0] > 0
+    a = Em[0] / np.linalg.norm(Em[0]); b = oE[0] / np.linalg.norm(oE[0])
+    assert min(np.linalg.norm(a - b), np.linalg.norm(a + b)) < 1e-9
+    gh, Hm = ctx.filter_H(g, 4.0, 2048, seed=5489, want_H=True)
+    hc, hm, oH = oracle.filter_H_collection(xys, W, H, pairs, counts, g.matches, 4.0, 2048, 5489, want_F=True)
+    assert set(map(tuple, gh.matches.tolist())) == set(map(tuple, hm.tolist()))
+    if hc[0]:
+        a = Hm[0] / np.linalg.norm(Hm[0]); b = oH[0] / np.linalg.norm(oH[0])
+        assert min(np.linalg.norm(a - b), np.linalg.norm(a + b)) < 1e-9
+
+
 def test_filters_on_degenerate_and_tiny_pairs(ctx, oracle):
     """Hand-made putative graphs that push the solvers into their degenerate branches (NaN / inf residuals, no real roots,
     singular systems, samples as large as the list): collinear points, one repeated point, pure noise, lists of SS+1 .. SS+6
