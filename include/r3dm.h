@@ -160,6 +160,15 @@ typedef struct {
     uint32_t reserved;
 } r3dm_pair_report;
 int r3dm_filter_report(const r3dm_ctx* ctx, r3dm_pair_report* out, uint64_t cap);
+/* The three filters of one putative graph side by side -- what the reference runs one after the other at src/R3DComputeMatches.cpp:
+ * 2113-2120 (F), :2130-2204 (E + overlap rule) and :2216-2233 (H); they only read the putative graph.  which: bit 0 F, bit 1 E, bit 2 H
+ * (the out_* of a requested filter must not be NULL).  Each filter has its own stream and work buffers in the context, the three
+ * AC-RANSAC kernels share the GPU: a collection with few, long pairs (one workgroup per pair, bound by ONE CU's f64 rate) leaves most
+ * CUs idle under a single kernel.  Results are those of r3dm_filter_F / _E / _H.  ms_kernels3 / ms_wall3 (optional): HIP-event time
+ * of the kernel and wall time of each call in the order F, E, H (they overlap).  r3dm_filter_report afterwards: the E call's, else F's. */
+int r3dm_filter_FEH(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter, uint64_t seed, int which,
+                    uint32_t e_min_count, float e_min_ratio, r3dm_graph** out_F, r3dm_graph** out_E, r3dm_graph** out_H,
+                    double* ms_kernels3, double* ms_wall3);
 
 /* ---- ArrayMatcher-shaped low level call: 2-NN of each query row among the dataset rows ----
  * out_idx / out_dist: 2 entries per query, ascending distance (dist: float squared L2 for F32/U8,

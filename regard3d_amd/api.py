@@ -26,7 +26,7 @@ EXPORTS = [
     "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_stage_create", "r3dm_stage_run", "r3dm_stage_destroy", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
     "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
-    "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
+    "r3dm_filter_FEH", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_transfer_counts", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
@@ -69,7 +69,7 @@ class ViewImage(C.Structure):
 class StageReport(C.Structure):
     """r3dm_stage_report: wall time of the phases of R3DComputeMatches::computeMatches (ms), kernel times, counts"""
     _fields_ = [(k, C.c_double) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total",
-                                          "ms_match_kernels", "ms_F_kernels", "ms_E_kernels", "ms_H_kernels")] + \
+                                          "ms_match_kernels", "ms_F_kernels", "ms_E_kernels", "ms_H_kernels", "ms_filters_wall")] + \
                [(k, C.c_uint64) for k in ("images_extracted", "n_keypoints", "n_putative_pairs", "n_putative_matches", "n_F_pairs", "n_F_matches",
                                           "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches", "match_was_exhaustive")] + [("features", FeaturesTotals)]
 
@@ -249,6 +249,7 @@ def load_library():
     L.r3dm_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, C.POINTER(vp), vp]
     L.r3dm_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
     L.r3dm_filter_E.argtypes = [vp, vp, C.c_double, u32, u64, u32, C.c_float, C.POINTER(vp), vp]
+    L.r3dm_filter_FEH.argtypes = [vp, vp, C.c_double, u32, u64, C.c_int, u32, C.c_float, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp]
     L.r3dm_set_intrinsics.argtypes = [vp, u32, vp]
     L.r3dm_liop_describe_patches.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32)]
     L.r3dm_extract_liop.argtypes = [vp, vp, u32, u32, vp, u32, C.c_float, vp, vp]
@@ -589,6 +590,16 @@ class Context:
                                           C.byref(h), _ptr(Ebuf)), "r3dm_filter_E")
         g = Graph(h.value)
         return (g, Ebuf[:g.num_pairs].copy()) if want_E else g
+
+    def filter_FEH(self, putative: Graph, which: str = "FEH", max_residual_px: float = 4.0, max_iter: int = 2048, seed: int = 5489,
+                   min_count: int = 50, min_ratio: float = 0.3):
+        """r3dm_filter_FEH: the requested filters side by side -> ({"F": Graph, ...}, ms_kernels [F, E, H], ms_wall [F, E, H])"""
+        bits = sum({"F": 1, "E": 2, "H": 4}[k] for k in which)
+        hs = {k: C.c_void_p() for k in "FEH"}
+        msk = np.zeros(3); msw = np.zeros(3)
+        self._check(self._L.r3dm_filter_FEH(self._h, putative._h, max_residual_px, max_iter, seed, bits, min_count, min_ratio,
+                                            C.byref(hs["F"]), C.byref(hs["E"]), C.byref(hs["H"]), _ptr(msk), _ptr(msw)), "r3dm_filter_FEH")
+        return {k: Graph(hs[k].value) for k in which}, msk, msw
 
     def knn2(self, dataset: np.ndarray, query: np.ndarray, binary: bool = False):
         dataset = np.ascontiguousarray(dataset); query = np.ascontiguousarray(query)

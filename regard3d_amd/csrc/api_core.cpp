@@ -42,10 +42,10 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto& im : c->imgs) if (im) im->release();
     DevBuf* bufs[] = {&c->d_imgs, &c->d_pairs, &c->d_nn, &c->d_knn_idx, &c->d_knn_dist, &c->d_fb, &c->d_cnt, &c->d_out,
-                      &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->m_raw, &c->m_peer, &c->f_pairs, &c->f_ids, &c->f_offs, &c->f_matches,
-                      &c->f_inl_cnt, &c->f_inl_idx, &c->f_F, &c->f_thr, &c->f_iters, &c->f_log10, &c->f_logck, &c->f_scratch,
+                      &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->m_raw, &c->m_peer,
                       &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
-                      &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->f_kinv, &c->d_spill, &c->f_spill, &c->f_soff, &c->f_order};
+                      &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->d_spill};
+    for (FilterBufs& fb : c->fb) fb.release();
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
     for (auto& im : c->spare) if (im) im->release();

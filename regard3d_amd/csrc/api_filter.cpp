@@ -5,19 +5,44 @@
 // HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
 #include "r3dm_ctx.hpp"
 
+#include <memory>
+#include <thread>
+
 // ------------------------------------------------------------------------------------------------
 // geometric filter
 // ------------------------------------------------------------------------------------------------
 // model_kind 0 = fundamental matrix (GeometricFilter_FMatrix_AC), 1 = homography (GeometricFilter_HMatrix_AC)
 //            2 = essential matrix (GeometricFilter_EMatrix_AC) + Regard3D's overlap rule (min_count / min_ratio)
-static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+// What a filter call leaves behind besides its graph: written by the call's own thread, folded into the context afterwards (three
+// calls of r3dm_filter_FEH run side by side)
+struct FilterCallOut {
+    std::string err;
+    double ms_kernels = 0.0, ms_wall = 0.0;
+    std::vector<r3dm_pair_report> report;
+};
+#define FHIP(call)                                                                     \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            o.err = std::string(#call) + ": " + hipGetErrorString(e__);                \
+            return R3DM_ERR_HIP;                                                       \
+        }                                                                              \
+    } while (0)
+
+static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                          uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out,
                          uint32_t min_count = 0, float min_ratio = 0.f)
 {
     if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
+    FilterBufs& B = c->fb[model_kind];
     const uint32_t SS = model_kind == 0 ? 7u : (model_kind == 1 ? 4u : 5u);          // Kernel::MINIMUM_SAMPLES
     *out = nullptr;
-    R3DM_HIP(c, hipSetDevice(c->device));
+    FHIP(hipSetDevice(c->device));
+    if (!B.stream) {
+        FHIP(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+        FHIP(hipEventCreate(&B.ev0));
+        FHIP(hipEventCreate(&B.ev1));
+    }
     const double t_call = now_ms();
     const uint64_t NP = putative->pairs.size() / 2;
     // work items: pairs with more than SS putatives (ACRANSAC returns nothing for n <= MINIMUM_SAMPLES)
@@ -30,17 +55,17 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         if (m <= SS) continue;
         const uint32_t I = putative->pairs[2 * p], J = putative->pairs[2 * p + 1];
         auto a = c->slot_of.find(I), b = c->slot_of.find(J);
-        if (a == c->slot_of.end() || b == c->slot_of.end()) { c->err = "filter: pair references an unregistered view"; return R3DM_ERR_INVALID; }
+        if (a == c->slot_of.end() || b == c->slot_of.end()) { o.err = "filter: pair references an unregistered view"; return R3DM_ERR_INVALID; }
         const HostImage& A = *c->imgs[a->second];
         const HostImage& B = *c->imgs[b->second];
-        if (!A.has_xy || !B.has_xy) { c->err = "filter: view registered without feature positions"; return R3DM_ERR_INVALID; }
+        if (!A.has_xy || !B.has_xy) { o.err = "filter: view registered without feature positions"; return R3DM_ERR_INVALID; }
         // ACKernelAdaptor normalises with 1 / sqrt(w h) and the NFA scale is D / A of image J: a view registered with a zero
         // width or height would turn every residual into NaN and the filter into a silent "no inliers"
         if (A.width == 0 || A.height == 0 || B.width == 0 || B.height == 0) {
-            c->err = "filter: view " + std::to_string(A.width == 0 || A.height == 0 ? I : J) + " was registered without its image size (width / height = 0)";
+            o.err = "filter: view " + std::to_string(A.width == 0 || A.height == 0 ? I : J) + " was registered without its image size (width / height = 0)";
             return R3DM_ERR_INVALID;
         }
-        if (m > (1u << 22)) { c->err = "filter: more than 4M putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
+        if (m > (1u << 22)) { o.err = "filter: more than 4M putative matches in one pair"; return R3DM_ERR_UNSUPPORTED; }
         // E_ACRobust: a pair whose views lack valid pinhole intrinsics is not estimated (and so not kept)
         if (model_kind == 2 && (!A.has_K || !B.has_K)) continue;
         item_pair.push_back((uint32_t)p);
@@ -52,7 +77,6 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     auto g = std::unique_ptr<r3dm_graph>(new r3dm_graph());
     g->offsets.push_back(0);
     const uint32_t NI = (uint32_t)item_pair.size();
-    c->stats.ms_filter_kernels = 0;
     if (NI == 0) { *out = g.release(); return R3DM_OK; }
     (void)sum_m;
     // [begin, end) of every item's putative list inside the full match array
@@ -62,7 +86,7 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         begin_end[2 * k] = putative->offsets[p];
         begin_end[2 * k + 1] = putative->offsets[p + 1];
     }
-    if (model_kind == 0 && err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { c->err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
+    if (model_kind == 0 && err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { o.err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
     // host tables in the reference's own float arithmetic (glibc log10f), see kernels_filter.hip
     std::vector<float> l10(max_m + 2), lck(max_m + 2);
     for (uint32_t k = 0; k <= max_m + 1; ++k) l10[k] = std::log10((float)k);
@@ -75,35 +99,35 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         lck[n] = r;
     }
     const uint64_t n_match_total = putative->matches.size();
-    R3DM_HIP(c, c->f_pairs.ensure(sizeof(uint2) * NI));
-    R3DM_HIP(c, c->f_ids.ensure(sizeof(uint2) * NI));
-    R3DM_HIP(c, c->f_offs.ensure(sizeof(uint64_t) * 2 * NI));
-    R3DM_HIP(c, c->f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
-    R3DM_HIP(c, c->f_inl_cnt.ensure(4 * (size_t)NI));
+    FHIP(B.f_pairs.ensure(sizeof(uint2) * NI));
+    FHIP(B.f_ids.ensure(sizeof(uint2) * NI));
+    FHIP(B.f_offs.ensure(sizeof(uint64_t) * 2 * NI));
+    FHIP(B.f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
+    FHIP(B.f_inl_cnt.ensure(4 * (size_t)NI));
     // slice offsets of the per-item work arrays: multiples of 32 elements, room for m + 1 (kernels_filter.hip explains why)
     std::vector<uint64_t> soff(NI + 1, 0);
     for (uint32_t k = 0; k < NI; ++k) soff[k + 1] = soff[k] + ((begin_end[2 * k + 1] - begin_end[2 * k] + 1 + 31) / 32) * 32;
     const uint64_t n_slice = soff[NI];
-    R3DM_HIP(c, c->f_inl_idx.ensure(4 * (size_t)n_slice + 64));
-    R3DM_HIP(c, c->f_soff.ensure(8 * (size_t)(NI + 1)));
-    R3DM_HIP(c, hipMemcpyAsync(c->f_soff.p, soff.data(), 8 * (size_t)(NI + 1), hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, c->f_F.ensure(72 * (size_t)NI));
-    R3DM_HIP(c, c->f_thr.ensure(16 * (size_t)NI));
-    R3DM_HIP(c, c->f_iters.ensure(8 * (size_t)NI));
-    R3DM_HIP(c, c->f_log10.ensure(4 * l10.size()));
-    R3DM_HIP(c, c->f_logck.ensure(4 * lck.size()));
-    R3DM_HIP(c, hipMemcpyAsync(c->f_pairs.p, slots.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(c->f_ids.p, ids.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(c->f_offs.p, begin_end.data(), sizeof(uint64_t) * 2 * NI, hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(c->f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(c->f_log10.p, l10.data(), 4 * l10.size(), hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(c->f_logck.p, lck.data(), 4 * lck.size(), hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemsetAsync(c->f_inl_cnt.p, 0, 4 * (size_t)NI, c->stream));
+    FHIP(B.f_inl_idx.ensure(4 * (size_t)n_slice + 64));
+    FHIP(B.f_soff.ensure(8 * (size_t)(NI + 1)));
+    FHIP(hipMemcpyAsync(B.f_soff.p, soff.data(), 8 * (size_t)(NI + 1), hipMemcpyHostToDevice, B.stream));
+    FHIP(B.f_F.ensure(72 * (size_t)NI));
+    FHIP(B.f_thr.ensure(16 * (size_t)NI));
+    FHIP(B.f_iters.ensure(8 * (size_t)NI));
+    FHIP(B.f_log10.ensure(4 * l10.size()));
+    FHIP(B.f_logck.ensure(4 * lck.size()));
+    FHIP(hipMemcpyAsync(B.f_pairs.p, slots.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, B.stream));
+    FHIP(hipMemcpyAsync(B.f_ids.p, ids.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, B.stream));
+    FHIP(hipMemcpyAsync(B.f_offs.p, begin_end.data(), sizeof(uint64_t) * 2 * NI, hipMemcpyHostToDevice, B.stream));
+    FHIP(hipMemcpyAsync(B.f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, B.stream));
+    FHIP(hipMemcpyAsync(B.f_log10.p, l10.data(), 4 * l10.size(), hipMemcpyHostToDevice, B.stream));
+    FHIP(hipMemcpyAsync(B.f_logck.p, lck.data(), 4 * lck.size(), hipMemcpyHostToDevice, B.stream));
+    FHIP(hipMemsetAsync(B.f_inl_cnt.p, 0, 4 * (size_t)NI, B.stream));
 
     FilterParams fp{};
     fp.imgs = c->d_imgs.as<ImgDev>();
-    fp.pairs = c->f_pairs.as<uint2>(); fp.pair_ids = c->f_ids.as<uint2>();
-    fp.offsets = c->f_offs.as<uint64_t>(); fp.matches = c->f_matches.as<r3dm_match>();
+    fp.pairs = B.f_pairs.as<uint2>(); fp.pair_ids = B.f_ids.as<uint2>();
+    fp.offsets = B.f_offs.as<uint64_t>(); fp.matches = B.f_matches.as<r3dm_match>();
     // LDS sort capacity: 8192 (x 12 B) fits beside the hypothesis buffer; pairs with more putatives sort in global scratch
     // (essential matrix: 4096, so that header + 16 hypotheses + sort buffers stay below 80 KB and two workgroups share a CU)
     // collections with long match lists (some pair above 4096 putatives: LDS admits one workgroup per CU anyway) run the 512-thread
@@ -120,9 +144,10 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
             soff[k] = tot;
             if (mk > fp.m_cap) tot += next_pow2((uint32_t)mk);
         }
-        R3DM_HIP(c, c->f_spill.ensure(tot * 12 + NI * 8 + 64));
-        unsigned char* base = c->f_spill.as<unsigned char>();
-        R3DM_HIP(c, hipMemcpy(base + tot * 12, soff.data(), NI * 8, hipMemcpyHostToDevice));
+        FHIP(B.f_spill.ensure(tot * 12 + NI * 8 + 64));
+        unsigned char* base = B.f_spill.as<unsigned char>();
+        FHIP(hipMemcpyAsync(base + tot * 12, soff.data(), NI * 8, hipMemcpyHostToDevice, B.stream));
+        FHIP(hipStreamSynchronize(B.stream));       // `soff` leaves scope
         fp.spill_keys = reinterpret_cast<unsigned long long*>(base);
         fp.spill_idx = reinterpret_cast<uint32_t*>(base + tot * 8);
         fp.spill_off = reinterpret_cast<const uint64_t*>(base + tot * 12);
@@ -134,18 +159,19 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         std::vector<double> kinv(9 * c->imgs.size(), 0.0);
         for (size_t s = 0; s < c->imgs.size(); ++s)
             if (c->imgs[s] && c->imgs[s]->has_K) memcpy(&kinv[9 * s], c->imgs[s]->Kinv, 72);
-        R3DM_HIP(c, c->f_kinv.ensure(kinv.size() * 8));
-        R3DM_HIP(c, hipMemcpy(c->f_kinv.p, kinv.data(), kinv.size() * 8, hipMemcpyHostToDevice));
-        fp.kinv = c->f_kinv.as<double>();
+        FHIP(B.f_kinv.ensure(kinv.size() * 8));
+        FHIP(hipMemcpyAsync(B.f_kinv.p, kinv.data(), kinv.size() * 8, hipMemcpyHostToDevice, B.stream));
+        FHIP(hipStreamSynchronize(B.stream));       // `kinv` leaves scope
+        fp.kinv = B.f_kinv.as<double>();
     }
-    fp.log10_tab = c->f_log10.as<float>(); fp.logc_k = c->f_logck.as<float>();
-    fp.inl_count = c->f_inl_cnt.as<uint32_t>(); fp.inl_idx = c->f_inl_idx.as<uint32_t>();
-    fp.F_out = c->f_F.as<double>(); fp.thr_nfa = c->f_thr.as<double>(); fp.iters = c->f_iters.as<uint32_t>();
-    R3DM_HIP(c, c->f_scratch.ensure(40 * (size_t)n_slice + 256));
-    fp.pts_scratch = c->f_scratch.as<double>();
-    fp.pool_scratch = reinterpret_cast<uint32_t*>(c->f_scratch.as<unsigned char>() + 32 * (size_t)n_slice);
-    fp.scratch_logc = reinterpret_cast<float*>(c->f_scratch.as<unsigned char>() + 36 * (size_t)n_slice);
-    fp.soff = c->f_soff.as<uint64_t>();
+    fp.log10_tab = B.f_log10.as<float>(); fp.logc_k = B.f_logck.as<float>();
+    fp.inl_count = B.f_inl_cnt.as<uint32_t>(); fp.inl_idx = B.f_inl_idx.as<uint32_t>();
+    fp.F_out = B.f_F.as<double>(); fp.thr_nfa = B.f_thr.as<double>(); fp.iters = B.f_iters.as<uint32_t>();
+    FHIP(B.f_scratch.ensure(40 * (size_t)n_slice + 256));
+    fp.pts_scratch = B.f_scratch.as<double>();
+    fp.pool_scratch = reinterpret_cast<uint32_t*>(B.f_scratch.as<unsigned char>() + 32 * (size_t)n_slice);
+    fp.scratch_logc = reinterpret_cast<float*>(B.f_scratch.as<unsigned char>() + 36 * (size_t)n_slice);
+    fp.soff = B.f_soff.as<uint64_t>();
     // launch order: the workgroup of a pair runs for a time roughly proportional to its putative count, and a C2 call has
     // ~1.5 x as many pairs as resident workgroups -- start the long ones first so the tail of the launch is short ones
     {
@@ -156,13 +182,13 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
             std::iota(order.begin(), order.end(), 0u);
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
                 return begin_end[2 * a + 1] - begin_end[2 * a] > begin_end[2 * b + 1] - begin_end[2 * b]; });
-            R3DM_HIP(c, c->f_order.ensure(4 * (size_t)NI));
-            R3DM_HIP(c, hipMemcpyAsync(c->f_order.p, order.data(), 4 * (size_t)NI, hipMemcpyHostToDevice, c->stream));
-            R3DM_HIP(c, hipStreamSynchronize(c->stream));       // `order` leaves scope
-            fp.order = c->f_order.as<uint32_t>();
+            FHIP(B.f_order.ensure(4 * (size_t)NI));
+            FHIP(hipMemcpyAsync(B.f_order.p, order.data(), 4 * (size_t)NI, hipMemcpyHostToDevice, B.stream));
+            FHIP(hipStreamSynchronize(B.stream));       // `order` leaves scope
+            fp.order = B.f_order.as<uint32_t>();
         }
     }
-    if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { c->err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
+    if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { o.err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
     // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
     DevBuf trace_buf;
     const uint32_t trace_cap = 16384;
@@ -176,8 +202,8 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
             for (uint32_t k = 0; k < NI; ++k)
                 if (ids[k].x == tI && ids[k].y == tJ) fp.trace_item = k;
         if (fp.trace_item != 0xFFFFFFFFu) {
-            R3DM_HIP(c, trace_buf.ensure(40 * (size_t)trace_cap + 64));
-            R3DM_HIP(c, hipMemsetAsync(trace_buf.p, 0, 40 * (size_t)trace_cap + 64, c->stream));
+            FHIP(trace_buf.ensure(40 * (size_t)trace_cap + 64));
+            FHIP(hipMemsetAsync(trace_buf.p, 0, 40 * (size_t)trace_cap + 64, B.stream));
             fp.trace = trace_buf.as<double>() + 8;
             fp.trace_rows = trace_buf.as<uint32_t>();
         }
@@ -185,21 +211,21 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     DevBuf dbg_buf;
     fp.dbg = nullptr;
     if (r3dm_dev_knob("R3DM_FILTER_CHECK", 0)) {
-        R3DM_HIP(c, dbg_buf.ensure(64));
-        R3DM_HIP(c, hipMemsetAsync(dbg_buf.p, 0, 64, c->stream));
+        FHIP(dbg_buf.ensure(64));
+        FHIP(hipMemsetAsync(dbg_buf.p, 0, 64, B.stream));
         fp.dbg = dbg_buf.as<uint32_t>();
     }
-    R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
-    R3DM_HIP(c, launch_filter_F(c->stream, fp));
-    R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    FHIP(hipEventRecord(B.ev0, B.stream));
+    FHIP(launch_filter_F(B.stream, fp));
+    FHIP(hipEventRecord(B.ev1, B.stream));
     if (fp.dbg) {                                          // developer build only
         uint32_t d[4] = {0, 0, 0, 0};
-        hipError_t e = hipMemcpyAsync(d, fp.dbg, 16, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the kernel runs on c->stream (non-blocking): wait for it
+        hipError_t e = hipMemcpyAsync(d, fp.dbg, 16, hipMemcpyDeviceToHost, B.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(B.stream);       // the kernel runs on B.stream (non-blocking): wait for it
         dbg_buf.release();
         if (e != hipSuccess || d[0]) {
             trace_buf.release();
-            c->err = e != hipSuccess ? std::string("filter check: ") + hipGetErrorString(e)
+            o.err = e != hipSuccess ? std::string("filter check: ") + hipGetErrorString(e)
                    : "filter invariant " + std::to_string(d[0]) + " violated at item " + std::to_string(d[1]) + " (" + std::to_string(d[2]) + ", " + std::to_string(d[3]) + ")";
             return R3DM_ERR_HIP;
         }
@@ -208,16 +234,16 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     std::vector<uint32_t> h_cnt(NI);
     std::vector<uint32_t> h_idx(n_slice);
     std::vector<double> h_F(9 * (size_t)NI);
-    R3DM_HIP(c, hipMemcpyAsync(h_cnt.data(), c->f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(h_idx.data(), c->f_inl_idx.p, 4 * (size_t)n_slice, hipMemcpyDeviceToHost, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(h_F.data(), c->f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
-    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    FHIP(hipMemcpyAsync(h_cnt.data(), B.f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
+    FHIP(hipMemcpyAsync(h_idx.data(), B.f_inl_idx.p, 4 * (size_t)n_slice, hipMemcpyDeviceToHost, B.stream));
+    FHIP(hipMemcpyAsync(h_F.data(), B.f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
+    FHIP(hipStreamSynchronize(B.stream));
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-    c->stats.ms_filter_kernels = ms;
+    (void)hipEventElapsedTime(&ms, B.ev0, B.ev1);
+    o.ms_kernels = ms;
     if (fp.trace) {
         std::vector<double> tr(5 * (size_t)trace_cap + 8);
-        R3DM_HIP(c, hipMemcpy(tr.data(), trace_buf.p, tr.size() * 8, hipMemcpyDeviceToHost));
+        FHIP(hipMemcpy(tr.data(), trace_buf.p, tr.size() * 8, hipMemcpyDeviceToHost));
         const uint32_t rows = std::min<uint32_t>(*reinterpret_cast<uint32_t*>(tr.data()), trace_cap);
         if (FILE* f = fopen(tf, "w")) {
             for (uint32_t r = 0; r < rows; ++r)
@@ -235,11 +261,12 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
     {
         std::vector<double> h_thr(2 * (size_t)NI);
         std::vector<uint32_t> h_it(2 * (size_t)NI);
-        R3DM_HIP(c, hipMemcpy(h_thr.data(), c->f_thr.p, 16 * (size_t)NI, hipMemcpyDeviceToHost));
-        R3DM_HIP(c, hipMemcpy(h_it.data(), c->f_iters.p, 8 * (size_t)NI, hipMemcpyDeviceToHost));
-        c->report.assign(NP, r3dm_pair_report{});
+        FHIP(hipMemcpyAsync(h_thr.data(), B.f_thr.p, 16 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
+        FHIP(hipMemcpyAsync(h_it.data(), B.f_iters.p, 8 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
+        FHIP(hipStreamSynchronize(B.stream));
+        o.report.assign(NP, r3dm_pair_report{});
         for (uint32_t k = 0; k < NI; ++k) {
-            r3dm_pair_report& r = c->report[item_pair[k]];
+            r3dm_pair_report& r = o.report[item_pair[k]];
             r.threshold_px = h_thr[2 * k]; r.nfa = h_thr[2 * k + 1];
             r.iterations = h_it[2 * k]; r.models = h_it[2 * k + 1]; r.inliers = h_cnt[k];
         }
@@ -260,15 +287,29 @@ static int filter_common(r3dm_ctx* c, const r3dm_graph* putative, double max_res
         if (F_out) memcpy(F_out + 9 * kept, h_F.data() + 9 * (size_t)k, 72);
         ++kept;
     }
-    c->stats.ms_wall_filter = now_ms() - t_call;
+    o.ms_wall = now_ms() - t_call;
     *out = g.release();
     return R3DM_OK;
+}
+
+// one filter call on the context: its outcome folded into the context's error / statistics / report
+static int filter_one(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter, uint64_t seed, r3dm_ferror err_kind,
+                      int model_kind, r3dm_graph** out, double* M_out, uint32_t min_count = 0, float min_ratio = 0.f)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    FilterCallOut o;
+    const int rc = filter_common(c, o, putative, max_residual_px, max_iter, seed, err_kind, model_kind, out, M_out, min_count, min_ratio);
+    if (rc != R3DM_OK && !o.err.empty()) c->err = o.err;
+    c->stats.ms_filter_kernels = o.ms_kernels;
+    c->stats.ms_wall_filter = o.ms_wall;
+    if (rc == R3DM_OK) c->report = std::move(o.report);
+    return rc;
 }
 
 static int r3dm_filter_F_impl(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                              uint64_t seed, r3dm_ferror err_kind, r3dm_graph** out, double* F_out)
 {
-    return filter_common(c, putative, max_residual_px, max_iter, seed, err_kind, 0, out, F_out);
+    return filter_one(c, putative, max_residual_px, max_iter, seed, err_kind, 0, out, F_out);
 }
 
 extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
@@ -280,7 +321,7 @@ extern "C" int r3dm_filter_F(r3dm_ctx* c, const r3dm_graph* putative, double max
 static int r3dm_filter_H_impl(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                              uint64_t seed, r3dm_graph** out, double* H_out)
 {
-    return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 1, out, H_out);
+    return filter_one(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 1, out, H_out);
 }
 
 extern "C" int r3dm_filter_H(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
@@ -311,13 +352,58 @@ extern "C" int r3dm_set_intrinsics(r3dm_ctx* c, uint32_t view_id, const double* 
 static int r3dm_filter_E_impl(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                              uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out)
 {
-    return filter_common(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 2, out, E_out, min_count, min_ratio);
+    return filter_one(c, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, 2, out, E_out, min_count, min_ratio);
 }
 
 extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                              uint64_t seed, uint32_t min_count, float min_ratio, r3dm_graph** out, double* E_out)
 {
     return r3dm_guarded(c, [&]() -> int { return r3dm_filter_E_impl(c, putative, max_residual_px, max_iter, seed, min_count, min_ratio, out, E_out); });
+}
+
+// F, E and H of one putative graph side by side: three host threads, each with the work buffers, stream and events of its model kind.
+// A collection of few, long pairs (24 photographs: 94 putative pairs of 10-20 k matches) occupies a third of the CUs under one
+// AC-RANSAC kernel, and a pair's workgroup is bound by ONE CU's f64 rate; the three kernels together fill the chip.
+extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter, uint64_t seed, int which,
+                               uint32_t e_min_count, float e_min_ratio, r3dm_graph** out_F, r3dm_graph** out_E, r3dm_graph** out_H,
+                               double* ms_kernels3, double* ms_wall3)
+{
+    if (!c || !putative || (which & 7) == 0) return R3DM_ERR_INVALID;
+    if (((which & 1) && !out_F) || ((which & 2) && !out_E) || ((which & 4) && !out_H)) return R3DM_ERR_INVALID;
+    if (out_F) *out_F = nullptr;
+    if (out_E) *out_E = nullptr;
+    if (out_H) *out_H = nullptr;
+    // kinds of the buffer sets: 0 F, 1 H, 2 E
+    struct Call { int kind; r3dm_graph** out; int rc = R3DM_OK; FilterCallOut o; std::thread th; };
+    std::vector<std::unique_ptr<Call>> calls;
+    if (which & 1) { calls.emplace_back(new Call()); calls.back()->kind = 0; calls.back()->out = out_F; }
+    if (which & 2) { calls.emplace_back(new Call()); calls.back()->kind = 2; calls.back()->out = out_E; }
+    if (which & 4) { calls.emplace_back(new Call()); calls.back()->kind = 1; calls.back()->out = out_H; }
+    auto run = [&](Call* k) noexcept {
+        try {
+            k->rc = filter_common(c, k->o, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, k->kind, k->out, nullptr,
+                                  k->kind == 2 ? e_min_count : 0u, k->kind == 2 ? e_min_ratio : 0.f);
+        } catch (...) { k->rc = R3DM_ERR_NOMEM; k->o.err = "out of host memory"; }
+    };
+    for (size_t i = 1; i < calls.size(); ++i) {
+        try { calls[i]->th = std::thread(run, calls[i].get()); }
+        catch (...) { run(calls[i].get()); }                   // no thread to be had: run it here
+    }
+    run(calls[0].get());
+    int rc = R3DM_OK;
+    for (auto& k : calls) {
+        if (k->th.joinable()) k->th.join();
+        const int slot = k->kind == 0 ? 0 : (k->kind == 2 ? 1 : 2);          // F, E, H
+        if (ms_kernels3) ms_kernels3[slot] = k->o.ms_kernels;
+        if (ms_wall3) ms_wall3[slot] = k->o.ms_wall;
+        if (k->rc != R3DM_OK && rc == R3DM_OK) { rc = k->rc; if (!k->o.err.empty()) c->err = k->o.err; }
+        if (k->kind == 2 || calls.size() == 1 || (k->kind == 0 && !(which & 2))) c->report = k->o.report;       // the E call's diagnostics, else F's
+    }
+    (void)hipSetDevice(c->device);
+    if (rc != R3DM_OK) {
+        for (auto& k : calls) if (*k->out) { r3dm_graph_free(*k->out); *k->out = nullptr; }
+    }
+    return rc;
 }
 
 extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint64_t cap)

@@ -446,6 +446,35 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     if (svgOutput) write_adjacency_svg(dir + "/PutativeAdjacencyMatrix.svg", views_.size(), statistics_.putativeMatches_);   // :2074
     phases_.files += wall_ms() - t_phase;
 
+    // ---- the three geometric filters side by side on one device (r3dm_filter_FEH): they only read the putative graph; the files
+    //      and maps follow in the reference's order.  (A device list deals each filter's pairs to the devices instead.)
+    const int which = (params.computeFundalmentalMatrix_ ? 1 : 0) | (params.computeEssentialMatrix_ ? 2 : 0) | (params.computeHomographyMatrix_ ? 4 : 0);
+    const bool side_by_side = ctx_ && (which & (which - 1)) != 0;
+    const double t_filters = wall_ms();
+    if (side_by_side) {
+        if (progress_) progress_(0.8f, "Calculate fundamental matrix", progress_user_);
+        r3dm_graph *gF = nullptr, *gE = nullptr, *gH = nullptr;
+        double msk[3] = {0, 0, 0}, msw[3] = {0, 0, 0};
+        rc = r3dm_filter_FEH(ctx_, putative, 4.0, 2048, seed_, which, 50, 0.3f, &gF, &gE, &gH, msk, msw);
+        if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
+        phases_.filter_F = msw[0]; phases_.filter_E = msw[1]; phases_.filter_H = msw[2];
+        phases_.F_kernels = msk[0]; phases_.E_kernels = msk[1]; phases_.H_kernels = msk[2];
+        phases_.filters_wall = wall_ms() - t_filters;
+        t_phase = wall_ms();
+        struct Out { r3dm_graph* g; PairWiseMatches* map; const std::string* named; const char* def; float frac; const char* msg; };
+        const Out outs[3] = {{gF, &statistics_.fundamentalMatches_, &paths.matchesFFilename_, "/matches.f.txt", 0.9f, "Calculate essential matrix"},
+                             {gE, &statistics_.essentialMatches_, &paths.matchesEFilename_, "/matches.e.txt", 0.95f, "Calculate homography matrix"},
+                             {gH, &statistics_.homographyMatches_, &paths.matchesHFilename_, "/matches.h.txt", 1.0f, nullptr}};
+        for (const Out& o : outs) {
+            if (!o.g) continue;
+            graph_to_map(o.g, *o.map);
+            const std::string path = o.named->empty() ? dir + o.def : *o.named;
+            writer.own(o.g);
+            writer.save(o.g, path, with_ext(path, ".bin"));
+            if (progress_ && o.msg) progress_(o.frac, o.msg, progress_user_);
+        }
+        phases_.files += wall_ms() - t_phase;
+    } else {
     // ---- geometric filtering, fundamental matrix (:2113-2120): AC-RANSAC, 4.0 px upper bound, 2048 iterations
     if (params.computeFundalmentalMatrix_) {
         if (progress_) progress_(0.8f, "Calculate fundamental matrix", progress_user_);
@@ -491,6 +520,8 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         writer.own(geo);
         writer.save(geo, h_path, with_ext(h_path, ".bin"));
         phases_.files += wall_ms() - t_phase;
+    }
+    phases_.filters_wall = wall_ms() - t_filters;
     }
     // GeometricAdjacencyMatrix.svg (:2238): the reference draws whichever filter ran last (H, else E, else F)
     if (svgOutput) {
@@ -572,6 +603,7 @@ extern "C" int r3dm_stage_run(r3dm_stage* sp, const char* matches_dir, const r3d
             *report = r3dm_stage_report{};
             report->ms_features = P.features; report->ms_load = P.load; report->ms_match = P.match; report->ms_filter_F = P.filter_F;
             report->ms_filter_E = P.filter_E; report->ms_filter_H = P.filter_H; report->ms_files = P.files; report->ms_total = P.total;
+            report->ms_filters_wall = P.filters_wall;
             report->ms_match_kernels = P.match_kernels; report->ms_F_kernels = P.F_kernels; report->ms_E_kernels = P.E_kernels; report->ms_H_kernels = P.H_kernels;
             report->images_extracted = P.images_extracted; report->features = P.features_totals;
             report->match_was_exhaustive = stage.lastMatchWasExhaustive() ? 1 : 0;

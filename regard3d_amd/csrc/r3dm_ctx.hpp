@@ -117,6 +117,21 @@ struct r3dm_graph {
     std::vector<r3dm_match> matches;
 };
 
+struct FilterBufs {
+    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch, f_kinv, f_spill, f_soff, f_order;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void release()
+    {
+        DevBuf* b[] = {&f_pairs, &f_ids, &f_offs, &f_matches, &f_inl_cnt, &f_inl_idx, &f_F, &f_thr, &f_iters, &f_log10, &f_logck, &f_scratch, &f_kinv, &f_spill, &f_soff, &f_order};
+        for (DevBuf* x : b) x->release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+        ev0 = ev1 = nullptr; stream = nullptr;
+    }
+};
+
 struct r3dm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -131,10 +146,12 @@ struct r3dm_ctx {
     DevBuf d_imgs;                                           // ImgDev[slots]
     // scratch (grown on demand, reused across calls)
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
-    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch;
+    // geometric filters: one set of work buffers, stream and events per model kind (0 F, 1 H, 2 E), so that r3dm_filter_FEH can run the
+    // three AC-RANSAC kernels of a putative graph side by side (a collection with few, long pairs leaves most CUs idle under one)
+    FilterBufs fb[3];
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf h_aux, h_jobs;            // HNSW: per-batch layer tables / job records
-    DevBuf a_jobs, a_scratch, a_ids, f_kinv, d_spill, f_spill, f_soff, f_order;
+    DevBuf a_jobs, a_scratch, a_ids, d_spill;
     DevBuf m_raw, m_peer;                                   // r3dm_multi_set_image: the one upload of a view / this device's copy of it
     std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size, ak_B planes each
     int ak_w = 0, ak_h = 0, ak_B = 0;

@@ -420,6 +420,25 @@ def test_filters_on_long_match_lists(ctx, oracle, n, frac):
         assert min(np.linalg.norm(a - b), np.linalg.norm(a + b)) < 1e-9
 
 
+def test_filters_side_by_side_equal_the_single_calls(ctx):
+    """r3dm_filter_FEH: F, E and H on three streams at once -> the graphs of r3dm_filter_F / _E / _H, whatever the subset"""
+    sc = synth.make_scene(6, 1500, "liop", seed=91)
+    K = synth.intrinsics()
+    ctx.clear_images()
+    for i in range(sc.n_images):
+        ctx.set_image(i, sc.descs[i], sc.xys[i], 4000, 3000); ctx.set_intrinsics(i, K)
+    g = ctx.match_pairs(sc.exhaustive_pairs(), 0.6, True)
+    one = {"F": ctx.filter_F(g), "E": ctx.filter_E(g), "H": ctx.filter_H(g)}
+    for which in ("FEH", "FH", "E", "EH"):
+        for rep in range(2):
+            got, msk, msw = ctx.filter_FEH(g, which)
+            for k in which:
+                assert np.array_equal(got[k].pairs, one[k].pairs) and np.array_equal(got[k].offsets, one[k].offsets), (which, k)
+                assert np.array_equal(got[k].matches, one[k].matches), (which, k)
+            assert all(msk["FEH".index(k)] > 0 for k in which)
+    assert one["F"].num_pairs >= 5
+
+
 def test_filters_on_degenerate_and_tiny_pairs(ctx, oracle):
     """Hand-made putative graphs that push the solvers into their degenerate branches (NaN / inf residuals, no real roots,
     singular systems, samples as large as the list): collinear points, one repeated point, pure noise, lists of SS+1 .. SS+6
