@@ -5,8 +5,8 @@
 // HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
 #include "r3dm_ctx.hpp"
 
+#include <functional>
 #include <memory>
-#include <thread>
 
 // ------------------------------------------------------------------------------------------------
 // geometric filter
@@ -19,6 +19,8 @@ struct FilterCallOut {
     std::string err;
     double ms_kernels = 0.0, ms_wall = 0.0;
     std::vector<r3dm_pair_report> report;
+    r3dm_graph* pending = nullptr;        // the graph under construction between filter_prepare and its collect
+    ~FilterCallOut() { delete pending; }
 };
 #define FHIP(call)                                                                     \
     do {                                                                               \
@@ -29,20 +31,20 @@ struct FilterCallOut {
         }                                                                              \
     } while (0)
 
-static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
-                         uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out,
-                         uint32_t min_count = 0, float min_ratio = 0.f)
+// Everything in front of the launch (work items, tables, uploads on the context's stream, kernel parameters) and, as `collect`, everything
+// behind it (copy back, per-pair report, acceptance rules, the filtered graph); collect runs once the launch has been waited for and is
+// given its HIP-event time.  launch = false in fp_out.n_items == 0 (nothing to run: collect still delivers the empty graph).
+static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
+                          uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out,
+                          uint32_t min_count, float min_ratio, FilterParams& fp_out, std::function<int(float)>& collect)
 {
+    fp_out = FilterParams{};
     if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
     FilterBufs& B = c->fb[model_kind];
     const uint32_t SS = model_kind == 0 ? 7u : (model_kind == 1 ? 4u : 5u);          // Kernel::MINIMUM_SAMPLES
     *out = nullptr;
     FHIP(hipSetDevice(c->device));
-    if (!B.stream) {
-        FHIP(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-        FHIP(hipEventCreate(&B.ev0));
-        FHIP(hipEventCreate(&B.ev1));
-    }
+
     const double t_call = now_ms();
     const uint64_t NP = putative->pairs.size() / 2;
     // work items: pairs with more than SS putatives (ACRANSAC returns nothing for n <= MINIMUM_SAMPLES)
@@ -77,7 +79,12 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
     auto g = std::unique_ptr<r3dm_graph>(new r3dm_graph());
     g->offsets.push_back(0);
     const uint32_t NI = (uint32_t)item_pair.size();
-    if (NI == 0) { *out = g.release(); return R3DM_OK; }
+    if (NI == 0) {
+        r3dm_graph* empty = g.release();
+        o.pending = empty;
+        collect = [&o, out, empty, t_call](float) -> int { o.pending = nullptr; *out = empty; o.ms_wall = now_ms() - t_call; return R3DM_OK; };
+        return R3DM_OK;
+    }
     (void)sum_m;
     // [begin, end) of every item's putative list inside the full match array
     std::vector<uint64_t> begin_end(2 * (size_t)NI);
@@ -110,19 +117,19 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
     const uint64_t n_slice = soff[NI];
     FHIP(B.f_inl_idx.ensure(4 * (size_t)n_slice + 64));
     FHIP(B.f_soff.ensure(8 * (size_t)(NI + 1)));
-    FHIP(hipMemcpyAsync(B.f_soff.p, soff.data(), 8 * (size_t)(NI + 1), hipMemcpyHostToDevice, B.stream));
+    FHIP(hipMemcpyAsync(B.f_soff.p, soff.data(), 8 * (size_t)(NI + 1), hipMemcpyHostToDevice, c->stream));
     FHIP(B.f_F.ensure(72 * (size_t)NI));
     FHIP(B.f_thr.ensure(16 * (size_t)NI));
     FHIP(B.f_iters.ensure(8 * (size_t)NI));
     FHIP(B.f_log10.ensure(4 * l10.size()));
     FHIP(B.f_logck.ensure(4 * lck.size()));
-    FHIP(hipMemcpyAsync(B.f_pairs.p, slots.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, B.stream));
-    FHIP(hipMemcpyAsync(B.f_ids.p, ids.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, B.stream));
-    FHIP(hipMemcpyAsync(B.f_offs.p, begin_end.data(), sizeof(uint64_t) * 2 * NI, hipMemcpyHostToDevice, B.stream));
-    FHIP(hipMemcpyAsync(B.f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, B.stream));
-    FHIP(hipMemcpyAsync(B.f_log10.p, l10.data(), 4 * l10.size(), hipMemcpyHostToDevice, B.stream));
-    FHIP(hipMemcpyAsync(B.f_logck.p, lck.data(), 4 * lck.size(), hipMemcpyHostToDevice, B.stream));
-    FHIP(hipMemsetAsync(B.f_inl_cnt.p, 0, 4 * (size_t)NI, B.stream));
+    FHIP(hipMemcpyAsync(B.f_pairs.p, slots.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
+    FHIP(hipMemcpyAsync(B.f_ids.p, ids.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
+    FHIP(hipMemcpyAsync(B.f_offs.p, begin_end.data(), sizeof(uint64_t) * 2 * NI, hipMemcpyHostToDevice, c->stream));
+    FHIP(hipMemcpyAsync(B.f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, c->stream));
+    FHIP(hipMemcpyAsync(B.f_log10.p, l10.data(), 4 * l10.size(), hipMemcpyHostToDevice, c->stream));
+    FHIP(hipMemcpyAsync(B.f_logck.p, lck.data(), 4 * lck.size(), hipMemcpyHostToDevice, c->stream));
+    FHIP(hipMemsetAsync(B.f_inl_cnt.p, 0, 4 * (size_t)NI, c->stream));
 
     FilterParams fp{};
     fp.imgs = c->d_imgs.as<ImgDev>();
@@ -146,8 +153,8 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
         }
         FHIP(B.f_spill.ensure(tot * 12 + NI * 8 + 64));
         unsigned char* base = B.f_spill.as<unsigned char>();
-        FHIP(hipMemcpyAsync(base + tot * 12, soff.data(), NI * 8, hipMemcpyHostToDevice, B.stream));
-        FHIP(hipStreamSynchronize(B.stream));       // `soff` leaves scope
+        FHIP(hipMemcpyAsync(base + tot * 12, soff.data(), NI * 8, hipMemcpyHostToDevice, c->stream));
+        FHIP(hipStreamSynchronize(c->stream));       // `soff` leaves scope
         fp.spill_keys = reinterpret_cast<unsigned long long*>(base);
         fp.spill_idx = reinterpret_cast<uint32_t*>(base + tot * 8);
         fp.spill_off = reinterpret_cast<const uint64_t*>(base + tot * 12);
@@ -160,8 +167,8 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
         for (size_t s = 0; s < c->imgs.size(); ++s)
             if (c->imgs[s] && c->imgs[s]->has_K) memcpy(&kinv[9 * s], c->imgs[s]->Kinv, 72);
         FHIP(B.f_kinv.ensure(kinv.size() * 8));
-        FHIP(hipMemcpyAsync(B.f_kinv.p, kinv.data(), kinv.size() * 8, hipMemcpyHostToDevice, B.stream));
-        FHIP(hipStreamSynchronize(B.stream));       // `kinv` leaves scope
+        FHIP(hipMemcpyAsync(B.f_kinv.p, kinv.data(), kinv.size() * 8, hipMemcpyHostToDevice, c->stream));
+        FHIP(hipStreamSynchronize(c->stream));       // `kinv` leaves scope
         fp.kinv = B.f_kinv.as<double>();
     }
     fp.log10_tab = B.f_log10.as<float>(); fp.logc_k = B.f_logck.as<float>();
@@ -183,8 +190,8 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
                 return begin_end[2 * a + 1] - begin_end[2 * a] > begin_end[2 * b + 1] - begin_end[2 * b]; });
             FHIP(B.f_order.ensure(4 * (size_t)NI));
-            FHIP(hipMemcpyAsync(B.f_order.p, order.data(), 4 * (size_t)NI, hipMemcpyHostToDevice, B.stream));
-            FHIP(hipStreamSynchronize(B.stream));       // `order` leaves scope
+            FHIP(hipMemcpyAsync(B.f_order.p, order.data(), 4 * (size_t)NI, hipMemcpyHostToDevice, c->stream));
+            FHIP(hipStreamSynchronize(c->stream));       // `order` leaves scope
             fp.order = B.f_order.as<uint32_t>();
         }
     }
@@ -203,7 +210,7 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
                 if (ids[k].x == tI && ids[k].y == tJ) fp.trace_item = k;
         if (fp.trace_item != 0xFFFFFFFFu) {
             FHIP(trace_buf.ensure(40 * (size_t)trace_cap + 64));
-            FHIP(hipMemsetAsync(trace_buf.p, 0, 40 * (size_t)trace_cap + 64, B.stream));
+            FHIP(hipMemsetAsync(trace_buf.p, 0, 40 * (size_t)trace_cap + 64, c->stream));
             fp.trace = trace_buf.as<double>() + 8;
             fp.trace_rows = trace_buf.as<uint32_t>();
         }
@@ -212,16 +219,19 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
     fp.dbg = nullptr;
     if (r3dm_dev_knob("R3DM_FILTER_CHECK", 0)) {
         FHIP(dbg_buf.ensure(64));
-        FHIP(hipMemsetAsync(dbg_buf.p, 0, 64, B.stream));
+        FHIP(hipMemsetAsync(dbg_buf.p, 0, 64, c->stream));
         fp.dbg = dbg_buf.as<uint32_t>();
     }
-    FHIP(hipEventRecord(B.ev0, B.stream));
-    FHIP(launch_filter_F(B.stream, fp));
-    FHIP(hipEventRecord(B.ev1, B.stream));
+    fp_out = fp;
+    r3dm_graph* graw = g.release();
+    o.pending = graw;
+    collect = [=, &o](float ms) mutable -> int {
+    std::unique_ptr<r3dm_graph> g(graw);
+    o.pending = nullptr;
     if (fp.dbg) {                                          // developer build only
         uint32_t d[4] = {0, 0, 0, 0};
-        hipError_t e = hipMemcpyAsync(d, fp.dbg, 16, hipMemcpyDeviceToHost, B.stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(B.stream);       // the kernel runs on B.stream (non-blocking): wait for it
+        hipError_t e = hipMemcpyAsync(d, fp.dbg, 16, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the kernel runs on c->stream (non-blocking): wait for it
         dbg_buf.release();
         if (e != hipSuccess || d[0]) {
             trace_buf.release();
@@ -234,12 +244,10 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
     std::vector<uint32_t> h_cnt(NI);
     std::vector<uint32_t> h_idx(n_slice);
     std::vector<double> h_F(9 * (size_t)NI);
-    FHIP(hipMemcpyAsync(h_cnt.data(), B.f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
-    FHIP(hipMemcpyAsync(h_idx.data(), B.f_inl_idx.p, 4 * (size_t)n_slice, hipMemcpyDeviceToHost, B.stream));
-    FHIP(hipMemcpyAsync(h_F.data(), B.f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
-    FHIP(hipStreamSynchronize(B.stream));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, B.ev0, B.ev1);
+    FHIP(hipMemcpyAsync(h_cnt.data(), B.f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+    FHIP(hipMemcpyAsync(h_idx.data(), B.f_inl_idx.p, 4 * (size_t)n_slice, hipMemcpyDeviceToHost, c->stream));
+    FHIP(hipMemcpyAsync(h_F.data(), B.f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+    FHIP(hipStreamSynchronize(c->stream));
     o.ms_kernels = ms;
     if (fp.trace) {
         std::vector<double> tr(5 * (size_t)trace_cap + 8);
@@ -261,9 +269,9 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
     {
         std::vector<double> h_thr(2 * (size_t)NI);
         std::vector<uint32_t> h_it(2 * (size_t)NI);
-        FHIP(hipMemcpyAsync(h_thr.data(), B.f_thr.p, 16 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
-        FHIP(hipMemcpyAsync(h_it.data(), B.f_iters.p, 8 * (size_t)NI, hipMemcpyDeviceToHost, B.stream));
-        FHIP(hipStreamSynchronize(B.stream));
+        FHIP(hipMemcpyAsync(h_thr.data(), B.f_thr.p, 16 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+        FHIP(hipMemcpyAsync(h_it.data(), B.f_iters.p, 8 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
+        FHIP(hipStreamSynchronize(c->stream));
         o.report.assign(NP, r3dm_pair_report{});
         for (uint32_t k = 0; k < NI; ++k) {
             r3dm_pair_report& r = o.report[item_pair[k]];
@@ -288,7 +296,26 @@ static int filter_common(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putati
         ++kept;
     }
     o.ms_wall = now_ms() - t_call;
+    o.pending = nullptr;
     *out = g.release();
+    return R3DM_OK;
+    };
+    return R3DM_OK;
+}
+
+// launch + wait + HIP-event time of the kernel(s) of `n` prepared filters (one combined launch when n > 1)
+static int filter_launch(r3dm_ctx* c, FilterCallOut& o, const FilterParams* fps, int n, float* ms)
+{
+    *ms = 0.f;
+    int live = 0;
+    for (int k = 0; k < n; ++k) live += fps[k].n_items ? 1 : 0;
+    if (!live) return R3DM_OK;
+    FHIP(hipEventRecord(c->ev0, c->stream));
+    if (n == 1) FHIP(launch_filter_F(c->stream, fps[0]));
+    else FHIP(launch_filter_all(c->stream, fps, n));
+    FHIP(hipEventRecord(c->ev1, c->stream));
+    FHIP(hipStreamSynchronize(c->stream));
+    (void)hipEventElapsedTime(ms, c->ev0, c->ev1);
     return R3DM_OK;
 }
 
@@ -298,7 +325,12 @@ static int filter_one(r3dm_ctx* c, const r3dm_graph* putative, double max_residu
 {
     if (!c) return R3DM_ERR_INVALID;
     FilterCallOut o;
-    const int rc = filter_common(c, o, putative, max_residual_px, max_iter, seed, err_kind, model_kind, out, M_out, min_count, min_ratio);
+    FilterParams fp{};
+    std::function<int(float)> collect;
+    float ms = 0.f;
+    int rc = filter_prepare(c, o, putative, max_residual_px, max_iter, seed, err_kind, model_kind, out, M_out, min_count, min_ratio, fp, collect);
+    if (rc == R3DM_OK) rc = filter_launch(c, o, &fp, 1, &ms);
+    if (rc == R3DM_OK) rc = collect(ms);
     if (rc != R3DM_OK && !o.err.empty()) c->err = o.err;
     c->stats.ms_filter_kernels = o.ms_kernels;
     c->stats.ms_wall_filter = o.ms_wall;
@@ -361,49 +393,60 @@ extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max
     return r3dm_guarded(c, [&]() -> int { return r3dm_filter_E_impl(c, putative, max_residual_px, max_iter, seed, min_count, min_ratio, out, E_out); });
 }
 
-// F, E and H of one putative graph side by side: three host threads, each with the work buffers, stream and events of its model kind.
+// F, E and H of one putative graph in ONE launch (acransac_all_kernel: the workgroups of the three filters side by side).
 // A collection of few, long pairs (24 photographs: 94 putative pairs of 10-20 k matches) occupies a third of the CUs under one
-// AC-RANSAC kernel, and a pair's workgroup is bound by ONE CU's f64 rate; the three kernels together fill the chip.
+// AC-RANSAC kernel, and a pair's workgroup is bound by ONE CU's f64 rate; the three filters together fill the chip.  (Three streams
+// do not do it: the streams of a process share a handful of hardware queues and the kernels mostly ran one after the other.)
 extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter, uint64_t seed, int which,
                                uint32_t e_min_count, float e_min_ratio, r3dm_graph** out_F, r3dm_graph** out_E, r3dm_graph** out_H,
                                double* ms_kernels3, double* ms_wall3)
 {
     if (!c || !putative || (which & 7) == 0) return R3DM_ERR_INVALID;
     if (((which & 1) && !out_F) || ((which & 2) && !out_E) || ((which & 4) && !out_H)) return R3DM_ERR_INVALID;
-    if (out_F) *out_F = nullptr;
-    if (out_E) *out_E = nullptr;
-    if (out_H) *out_H = nullptr;
-    // kinds of the buffer sets: 0 F, 1 H, 2 E
-    struct Call { int kind; r3dm_graph** out; int rc = R3DM_OK; FilterCallOut o; std::thread th; };
-    std::vector<std::unique_ptr<Call>> calls;
-    if (which & 1) { calls.emplace_back(new Call()); calls.back()->kind = 0; calls.back()->out = out_F; }
-    if (which & 2) { calls.emplace_back(new Call()); calls.back()->kind = 2; calls.back()->out = out_E; }
-    if (which & 4) { calls.emplace_back(new Call()); calls.back()->kind = 1; calls.back()->out = out_H; }
-    auto run = [&](Call* k) noexcept {
-        try {
-            k->rc = filter_common(c, k->o, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, k->kind, k->out, nullptr,
-                                  k->kind == 2 ? e_min_count : 0u, k->kind == 2 ? e_min_ratio : 0.f);
-        } catch (...) { k->rc = R3DM_ERR_NOMEM; k->o.err = "out of host memory"; }
-    };
-    for (size_t i = 1; i < calls.size(); ++i) {
-        try { calls[i]->th = std::thread(run, calls[i].get()); }
-        catch (...) { run(calls[i].get()); }                   // no thread to be had: run it here
-    }
-    run(calls[0].get());
-    int rc = R3DM_OK;
-    for (auto& k : calls) {
-        if (k->th.joinable()) k->th.join();
-        const int slot = k->kind == 0 ? 0 : (k->kind == 2 ? 1 : 2);          // F, E, H
-        if (ms_kernels3) ms_kernels3[slot] = k->o.ms_kernels;
-        if (ms_wall3) ms_wall3[slot] = k->o.ms_wall;
-        if (k->rc != R3DM_OK && rc == R3DM_OK) { rc = k->rc; if (!k->o.err.empty()) c->err = k->o.err; }
-        if (k->kind == 2 || calls.size() == 1 || (k->kind == 0 && !(which & 2))) c->report = k->o.report;       // the E call's diagnostics, else F's
-    }
-    (void)hipSetDevice(c->device);
-    if (rc != R3DM_OK) {
-        for (auto& k : calls) if (*k->out) { r3dm_graph_free(*k->out); *k->out = nullptr; }
-    }
-    return rc;
+    return r3dm_guarded(c, [&]() -> int {
+        if (out_F) *out_F = nullptr;
+        if (out_E) *out_E = nullptr;
+        if (out_H) *out_H = nullptr;
+        if (ms_kernels3) ms_kernels3[0] = ms_kernels3[1] = ms_kernels3[2] = 0.0;
+        if (ms_wall3) ms_wall3[0] = ms_wall3[1] = ms_wall3[2] = 0.0;
+        struct Call { int kind, slot; r3dm_graph** out; FilterCallOut o; std::function<int(float)> collect; };
+        std::vector<std::unique_ptr<Call>> calls;          // in the order F, E, H; kinds of the buffer sets: 0 F, 1 H, 2 E
+        if (which & 1) { calls.emplace_back(new Call()); calls.back()->kind = 0; calls.back()->slot = 0; calls.back()->out = out_F; }
+        if (which & 2) { calls.emplace_back(new Call()); calls.back()->kind = 2; calls.back()->slot = 1; calls.back()->out = out_E; }
+        if (which & 4) { calls.emplace_back(new Call()); calls.back()->kind = 1; calls.back()->slot = 2; calls.back()->out = out_H; }
+        std::vector<FilterParams> fps(calls.size());
+        int rc = R3DM_OK;
+        for (size_t i = 0; i < calls.size() && rc == R3DM_OK; ++i) {
+            Call& k = *calls[i];
+            rc = filter_prepare(c, k.o, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, k.kind, k.out, nullptr,
+                                k.kind == 2 ? e_min_count : 0u, k.kind == 2 ? e_min_ratio : 0.f, fps[i], k.collect);
+            if (rc != R3DM_OK && !k.o.err.empty()) c->err = k.o.err;
+        }
+        float ms = 0.f;
+        if (rc == R3DM_OK) {
+            bool wide = false;
+            for (const FilterParams& f : fps) wide = wide || (f.n_items && f.wide);
+            for (FilterParams& f : fps) f.wide = wide ? 1u : 0u;      // one launch, one workgroup size
+            FilterCallOut lo;
+            rc = filter_launch(c, lo, fps.data(), (int)fps.size(), &ms);
+            if (rc != R3DM_OK && !lo.err.empty()) c->err = lo.err;
+        }
+        for (size_t i = 0; i < calls.size() && rc == R3DM_OK; ++i) {
+            Call& k = *calls[i];
+            rc = k.collect(ms);
+            if (rc != R3DM_OK && !k.o.err.empty()) c->err = k.o.err;
+            if (ms_kernels3) ms_kernels3[k.slot] = ms;                // the one launch serves all requested filters
+            if (ms_wall3) ms_wall3[k.slot] = k.o.ms_wall;
+            if (rc == R3DM_OK && (k.kind == 2 || !(which & 2))) c->report = k.o.report;       // the E call's diagnostics, else the last one's
+        }
+        c->stats.ms_filter_kernels = ms;
+        if (rc != R3DM_OK) {
+            if (out_F && *out_F) { r3dm_graph_free(*out_F); *out_F = nullptr; }
+            if (out_E && *out_E) { r3dm_graph_free(*out_E); *out_E = nullptr; }
+            if (out_H && *out_H) { r3dm_graph_free(*out_H); *out_H = nullptr; }
+        }
+        return rc;
+    });
 }
 
 extern "C" int r3dm_filter_report(const r3dm_ctx* c, r3dm_pair_report* out, uint64_t cap)

@@ -752,7 +752,7 @@ template <int KIND> struct ChunkOf { static constexpr int n = (KIND == 2) ? kE5S
 constexpr int kHistBins = 1024, kHistSub = 5, kHistShift = 52 - kHistSub;
 constexpr int kHdr = 1024 + kHistBins * 4;
 
-#ifdef R3DM_FILTER_ONLY_E
+#if defined(R3DM_FILTER_ONLY_E) || defined(R3DM_FILTER_ALL)
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 static inline size_t filter_F_lds_bytes_unused_(uint32_t m_cap, int model_kind)
 #else
@@ -1422,24 +1422,46 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 // E likewise since its 5-point solver became a cooperative LDS routine.  The wide variant (NT = 512, one workgroup per CU, the same
 // registers per lane) serves collections with long match lists: FilterParams::wide, set by the host (api_filter.cpp).
 template <int KIND, int NT>
-__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1)
-void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4] */,
-                     uint32_t* __restrict__ pool_g /* [sum m] */, float* __restrict__ logc_g /* [sum m + items + 1] */)
+__device__ __forceinline__ void acransac_item(const FilterParams& P, unsigned char* smem, uint32_t block)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MS = (KIND == 2) ? 90 : 27;
-    const uint32_t item = P.order ? P.order[blockIdx.x] : blockIdx.x;
+    const uint32_t item = P.order ? P.order[block] : block;
     const uint32_t m = (uint32_t)(P.offsets[2 * item + 1] - P.offsets[2 * item]);
     if (m <= P.m_cap) {
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + kHdr + ChunkOf<KIND>::n * MS * 8);
         uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
-        acransac_body<KIND, false, NT>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
+        acransac_body<KIND, false, NT>(P, P.pts_scratch, P.pool_scratch, P.scratch_logc, smem, keys, sidx, item);
     } else {
         // slice of the global spill buffer, sized for the next power of two of m (host: spill_off[item])
         unsigned long long* keys = P.spill_keys + P.spill_off[item];
         uint32_t* sidx = P.spill_idx + P.spill_off[item];
-        acransac_body<KIND, true, NT>(P, pts, pool_g, logc_g, smem, keys, sidx, item);
+        acransac_body<KIND, true, NT>(P, P.pts_scratch, P.pool_scratch, P.scratch_logc, smem, keys, sidx, item);
     }
+}
+
+template <int KIND, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1)
+void acransac_kernel(const FilterParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    acransac_item<KIND, NT>(P, smem, blockIdx.x);
+}
+
+// The filters of one putative graph in one launch (r3dm_filter_FEH): blocks [0, first[1]) run the first parameter set, [first[1],
+// first[2]) the second, the rest the third; kinds[] names the model of each set.  Registers and LDS are those of the hungriest kind.
+struct FilterParamsAll { FilterParams p[3]; uint32_t first[4]; int kinds[3]; };
+template <int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1)
+void acransac_all_kernel(const FilterParamsAll A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t b = blockIdx.x;
+    const int s = b < A.first[1] ? 0 : (b < A.first[2] ? 1 : 2);
+    const uint32_t local = b - A.first[s];
+    const int kind = A.kinds[s];
+    if (kind == 0) acransac_item<0, NT>(A.p[s], smem, local);
+    else if (kind == 1) acransac_item<1, NT>(A.p[s], smem, local);
+    else acransac_item<2, NT>(A.p[s], smem, local);
 }
 
 // The essential-matrix instantiation lives in its own translation unit (kernels_filter_e.hip = this file with
@@ -1448,12 +1470,41 @@ void acransac_kernel(const FilterParams P, double* __restrict__ pts /* [sum m][4
 // gave run-to-run different inlier sets.  The cooperative solver above has no calls and no spills; the option is gone, and
 // tests/test_gpu_fullsize.py::test_filters_are_deterministic_when_workgroups_share_a_cu runs against the default build.)
 hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds);
+#if defined(R3DM_FILTER_ALL)
+template <int NT>
+static hipError_t launch_all(hipStream_t st, const FilterParamsAll& A, uint32_t blocks, size_t lds)
+{
+    hipError_t e = hipFuncSetAttribute((const void*)acransac_all_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((acransac_all_kernel<NT>), dim3(blocks), dim3(NT), lds, st, A);
+    return hipGetLastError();
+}
+hipError_t launch_filter_all(hipStream_t st, const FilterParams* P, int n)
+{
+    if (n < 1 || n > 3) return hipErrorInvalidValue;
+    FilterParamsAll A{};
+    size_t lds = 0;
+    uint32_t blocks = 0;
+    bool wide = false;
+    for (int k = 0; k < 3; ++k) {
+        A.first[k] = blocks;
+        if (k < n) {
+            A.p[k] = P[k]; A.kinds[k] = P[k].model_kind;
+            blocks += P[k].n_items;
+            if (P[k].n_items) { lds = std::max(lds, filter_F_lds_bytes(P[k].m_cap, P[k].model_kind)); wide = wide || P[k].wide; }
+        }
+    }
+    A.first[3] = blocks;
+    if (blocks == 0) return hipSuccess;
+    return wide ? launch_all<512>(st, A, blocks, lds) : launch_all<256>(st, A, blocks, lds);
+}
+#else
 template <int KIND, int NT>
 static hipError_t launch_acransac(hipStream_t st, const FilterParams& P, size_t lds)
 {
     hipError_t e = hipFuncSetAttribute((const void*)acransac_kernel<KIND, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((acransac_kernel<KIND, NT>), dim3(P.n_items), dim3(NT), lds, st, P, P.pts_scratch, P.pool_scratch, P.scratch_logc);
+    hipLaunchKernelGGL((acransac_kernel<KIND, NT>), dim3(P.n_items), dim3(NT), lds, st, P);
     return hipGetLastError();
 }
 #ifdef R3DM_FILTER_ONLY_E
@@ -1470,6 +1521,7 @@ hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
     if (P.model_kind == 0) return P.wide ? launch_acransac<0, 512>(st, P, lds) : launch_acransac<0, 256>(st, P, lds);
     return P.wide ? launch_acransac<1, 512>(st, P, lds) : launch_acransac<1, 256>(st, P, lds);
 }
+#endif
 #endif
 
 }  // namespace r3dm

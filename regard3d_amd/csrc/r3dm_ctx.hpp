@@ -119,16 +119,10 @@ struct r3dm_graph {
 
 struct FilterBufs {
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch, f_kinv, f_spill, f_soff, f_order;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void release()
     {
         DevBuf* b[] = {&f_pairs, &f_ids, &f_offs, &f_matches, &f_inl_cnt, &f_inl_idx, &f_F, &f_thr, &f_iters, &f_log10, &f_logck, &f_scratch, &f_kinv, &f_spill, &f_soff, &f_order};
         for (DevBuf* x : b) x->release();
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
-        ev0 = ev1 = nullptr; stream = nullptr;
     }
 };
 
@@ -146,8 +140,8 @@ struct r3dm_ctx {
     DevBuf d_imgs;                                           // ImgDev[slots]
     // scratch (grown on demand, reused across calls)
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
-    // geometric filters: one set of work buffers, stream and events per model kind (0 F, 1 H, 2 E), so that r3dm_filter_FEH can run the
-    // three AC-RANSAC kernels of a putative graph side by side (a collection with few, long pairs leaves most CUs idle under one)
+    // geometric filters: one set of work buffers per model kind (0 F, 1 H, 2 E), so that r3dm_filter_FEH can run the three
+    // AC-RANSAC filters of a putative graph in one launch (a collection with few, long pairs leaves most CUs idle under one)
     FilterBufs fb[3];
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf h_aux, h_jobs;            // HNSW: per-batch layer tables / job records
