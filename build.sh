@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 WHAT=${1:-all}
-SRC="kernels_match.hip kernels_filter.hip kernels_filter_e.hip kernels_filter_all.hip kernels_liop.hip kernels_ann.hip kernels_hnsw.hip kernels_akaze.hip api_core.cpp api_match.cpp api_hnsw.cpp api_filter.cpp api_features.cpp api_multi.cpp compute_matches.cpp"
+SRC="kernels_match.hip kernels_filter.hip kernels_filter_e.hip kernels_liop.hip kernels_ann.hip kernels_hnsw.hip kernels_akaze.hip api_core.cpp api_match.cpp api_hnsw.cpp api_filter.cpp api_features.cpp api_multi.cpp compute_matches.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
 HDRS="regard3d_amd/csrc/*.hpp include/*.h include/*.hpp"
 
@@ -22,8 +22,9 @@ build_one() {   # $1 = variant dir, $2 = extra flags, $3 = output, $4 = extra so
     if [ ! -f $o ]; then stale=1; else
       for d in regard3d_amd/csrc/$f $HDRS build.sh; do [ $d -nt $o ] && stale=1; done
     fi
-    local extra=""      # (no per-file compiler options: the essential-matrix kernel no longer needs -amdgpu-spill-sgpr-to-vgpr=0)
-    { [ $f = kernels_filter_e.hip ] || [ $f = kernels_filter_all.hip ]; } && [ regard3d_amd/csrc/kernels_filter.hip -nt $o ] && stale=1
+    local extra=""
+    # (no per-file compiler options: the essential-matrix kernel no longer needs -amdgpu-spill-sgpr-to-vgpr=0)
+    [ $f = kernels_filter_e.hip ] && [ regard3d_amd/csrc/kernels_filter.hip -nt $o ] && stale=1
     if [ $stale = 1 ]; then ( $HIPCC $FLAGS $2 $extra -x hip -c regard3d_amd/csrc/$f -o $o ) & pids="$pids $!"; fi
   done
   for f in $4; do

@@ -303,19 +303,47 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     return R3DM_OK;
 }
 
-// launch + wait + HIP-event time of the kernel(s) of `n` prepared filters (one combined launch when n > 1)
+// launch + wait + HIP-event time of the kernels of `n` prepared filters.  One filter: on the context's stream.  Several: every kernel
+// on the stream of its kind's priority class (FilterBufs::stream), after the uploads on the context's stream have been waited for.
 static int filter_launch(r3dm_ctx* c, FilterCallOut& o, const FilterParams* fps, int n, float* ms)
 {
-    *ms = 0.f;
+    for (int k = 0; k < n; ++k) ms[k] = 0.f;
     int live = 0;
     for (int k = 0; k < n; ++k) live += fps[k].n_items ? 1 : 0;
     if (!live) return R3DM_OK;
-    FHIP(hipEventRecord(c->ev0, c->stream));
-    if (n == 1) FHIP(launch_filter_F(c->stream, fps[0]));
-    else FHIP(launch_filter_all(c->stream, fps, n));
-    FHIP(hipEventRecord(c->ev1, c->stream));
+    if (n == 1) {
+        FHIP(hipEventRecord(c->ev0, c->stream));
+        FHIP(launch_filter_F(c->stream, fps[0]));
+        FHIP(hipEventRecord(c->ev1, c->stream));
+        FHIP(hipStreamSynchronize(c->stream));
+        (void)hipEventElapsedTime(&ms[0], c->ev0, c->ev1);
+        return R3DM_OK;
+    }
+    int prio_low = 0, prio_high = 0;
+    FHIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));          // numerically: low >= high
     FHIP(hipStreamSynchronize(c->stream));
-    (void)hipEventElapsedTime(ms, c->ev0, c->ev1);
+    for (int k = 0; k < n; ++k) {
+        if (!fps[k].n_items) continue;
+        FilterBufs& B = c->fb[fps[k].model_kind];
+        if (!B.stream) {
+            const int prio = fps[k].model_kind == 2 ? prio_high : (fps[k].model_kind == 0 ? (prio_low + prio_high) / 2 : prio_low);
+            FHIP(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, prio));
+            FHIP(hipEventCreate(&B.ev0));
+            FHIP(hipEventCreate(&B.ev1));
+        }
+        FHIP(hipEventRecord(B.ev0, B.stream));
+        FHIP(launch_filter_F(B.stream, fps[k]));
+        FHIP(hipEventRecord(B.ev1, B.stream));
+    }
+    hipError_t first = hipSuccess;
+    for (int k = 0; k < n; ++k) {
+        if (!fps[k].n_items) continue;
+        FilterBufs& B = c->fb[fps[k].model_kind];
+        const hipError_t e = hipStreamSynchronize(B.stream);              // wait for ALL of them, whatever one of them says
+        if (e != hipSuccess && first == hipSuccess) first = e;
+        if (e == hipSuccess) (void)hipEventElapsedTime(&ms[k], B.ev0, B.ev1);
+    }
+    FHIP(first);
     return R3DM_OK;
 }
 
@@ -393,10 +421,14 @@ extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max
     return r3dm_guarded(c, [&]() -> int { return r3dm_filter_E_impl(c, putative, max_residual_px, max_iter, seed, min_count, min_ratio, out, E_out); });
 }
 
-// F, E and H of one putative graph in ONE launch (acransac_all_kernel: the workgroups of the three filters side by side).
+// F, E and H of one putative graph side by side: the three kernels on streams of three priority classes (filter_launch).
 // A collection of few, long pairs (24 photographs: 94 putative pairs of 10-20 k matches) occupies a third of the CUs under one
-// AC-RANSAC kernel, and a pair's workgroup is bound by ONE CU's f64 rate; the three filters together fill the chip.  (Three streams
-// do not do it: the streams of a process share a handful of hardware queues and the kernels mostly ran one after the other.)
+// AC-RANSAC kernel, and a pair's workgroup is bound by ONE CU's f64 rate; the three filters together fill the chip: 26 ms instead
+// of 14 + 24 + 10 on 30 pairs of 8-12 k matches (tools/filters_side_by_side.py).  What made the kernels overlap at all was taking
+// the agent-scope fences out of their barriers (kernels_filter.hip: wg_fence) -- with them, three kernels at once ran no faster than
+// one after the other, whatever the streams (plain, priority classes, CU masks).  Measured and dropped: one merged kernel with the
+// three model kinds as branches -- hipcc's code for the fundamental-matrix branch faulted as soon as a second kind was compiled
+// into the same kernel (product build only, spilled lists only).
 extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter, uint64_t seed, int which,
                                uint32_t e_min_count, float e_min_ratio, r3dm_graph** out_F, r3dm_graph** out_E, r3dm_graph** out_H,
                                double* ms_kernels3, double* ms_wall3)
@@ -422,24 +454,23 @@ extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double m
                                 k.kind == 2 ? e_min_count : 0u, k.kind == 2 ? e_min_ratio : 0.f, fps[i], k.collect);
             if (rc != R3DM_OK && !k.o.err.empty()) c->err = k.o.err;
         }
-        float ms = 0.f;
+        float ms[3] = {0.f, 0.f, 0.f};
         if (rc == R3DM_OK) {
-            bool wide = false;
-            for (const FilterParams& f : fps) wide = wide || (f.n_items && f.wide);
-            for (FilterParams& f : fps) f.wide = wide ? 1u : 0u;      // one launch, one workgroup size
             FilterCallOut lo;
-            rc = filter_launch(c, lo, fps.data(), (int)fps.size(), &ms);
+            rc = filter_launch(c, lo, fps.data(), (int)fps.size(), ms);
             if (rc != R3DM_OK && !lo.err.empty()) c->err = lo.err;
         }
+        float ms_max = 0.f;
         for (size_t i = 0; i < calls.size() && rc == R3DM_OK; ++i) {
             Call& k = *calls[i];
-            rc = k.collect(ms);
+            rc = k.collect(ms[i]);
             if (rc != R3DM_OK && !k.o.err.empty()) c->err = k.o.err;
-            if (ms_kernels3) ms_kernels3[k.slot] = ms;                // the one launch serves all requested filters
+            ms_max = std::max(ms_max, ms[i]);
+            if (ms_kernels3) ms_kernels3[k.slot] = ms[i];
             if (ms_wall3) ms_wall3[k.slot] = k.o.ms_wall;
             if (rc == R3DM_OK && (k.kind == 2 || !(which & 2))) c->report = k.o.report;       // the E call's diagnostics, else the last one's
         }
-        c->stats.ms_filter_kernels = ms;
+        c->stats.ms_filter_kernels = ms_max;
         if (rc != R3DM_OK) {
             if (out_F && *out_F) { r3dm_graph_free(*out_F); *out_F = nullptr; }
             if (out_E && *out_E) { r3dm_graph_free(*out_E); *out_E = nullptr; }

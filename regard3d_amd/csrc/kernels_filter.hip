@@ -752,7 +752,7 @@ template <int KIND> struct ChunkOf { static constexpr int n = (KIND == 2) ? kE5S
 constexpr int kHistBins = 1024, kHistSub = 5, kHistShift = 52 - kHistSub;
 constexpr int kHdr = 1024 + kHistBins * 4;
 
-#if defined(R3DM_FILTER_ONLY_E) || defined(R3DM_FILTER_ALL)
+#ifdef R3DM_FILTER_ONLY_E
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 static inline size_t filter_F_lds_bytes_unused_(uint32_t m_cap, int model_kind)
 #else
@@ -821,11 +821,16 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 // table written at start-up, the pool rebuilt after an improvement, and -- spill variant only -- the sort buffers.  A
 // workgroup-scope fence compiles to no vmcnt wait on gfx950 (LLVM's memory model relies on same-CU ordering through the L1),
 // so those places use an agent-scope fence (vmcnt(0), L2 write-back, L1 invalidate) before the barrier: they are rare.
-__device__ __forceinline__ void wg_sync_global() { __threadfence(); __syncthreads(); }
+// Waves of ONE workgroup exchange data through global memory here (the pair's points, pool, tables; the spilled sort lists): every
+// slice belongs to one workgroup, whose waves share a CU and its vector L1 -- a WORKGROUP-scope fence (wait for the outstanding
+// stores and loads) is what the exchange needs.  __threadfence() is agent scope: on this chip of eight L2s that is an L2 write-back +
+// invalidate per barrier, ~10 per evaluated model on a spilled pair, and it slows every other workgroup of the device with it.
+__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+__device__ __forceinline__ void wg_sync_global() { wg_fence(); r3dm_syncthreads(); wg_fence(); }
 template <bool GLOBAL_BUFFERS>
 __device__ __forceinline__ void wg_sync_t()
 {
-    if (GLOBAL_BUFFERS) { __threadfence(); __syncthreads(); }
+    if (GLOBAL_BUFFERS) { wg_fence(); r3dm_syncthreads(); wg_fence(); }
     else r3dm_syncthreads();
 }
 
@@ -1363,7 +1368,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 }
                 FCHECK(filled == ni, 7, filled, ni);
                 pool_changed = true;
-                __threadfence();       // the rebuilt pool (global memory) is read by the sampling lanes of the next chunk
+                wg_fence();            // the rebuilt pool (global memory) is read by the sampling lanes of the next chunk (same workgroup)
             }
             wg_sync_t<SPILL>();
             // the chunk was cut from the old budget: stop when the (possibly shrunk) budget is exhausted
@@ -1447,58 +1452,12 @@ void acransac_kernel(const FilterParams P)
     acransac_item<KIND, NT>(P, smem, blockIdx.x);
 }
 
-// The filters of one putative graph in one launch (r3dm_filter_FEH): blocks [0, first[1]) run the first parameter set, [first[1],
-// first[2]) the second, the rest the third; kinds[] names the model of each set.  Registers and LDS are those of the hungriest kind.
-struct FilterParamsAll { FilterParams p[3]; uint32_t first[4]; int kinds[3]; };
-template <int NT>
-__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1)
-void acransac_all_kernel(const FilterParamsAll A)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t b = blockIdx.x;
-    const int s = b < A.first[1] ? 0 : (b < A.first[2] ? 1 : 2);
-    const uint32_t local = b - A.first[s];
-    const int kind = A.kinds[s];
-    if (kind == 0) acransac_item<0, NT>(A.p[s], smem, local);
-    else if (kind == 1) acransac_item<1, NT>(A.p[s], smem, local);
-    else acransac_item<2, NT>(A.p[s], smem, local);
-}
-
 // The essential-matrix instantiation lives in its own translation unit (kernels_filter_e.hip = this file with
 // R3DM_FILTER_ONLY_E) only to compile in parallel with F / H.  (Round 2 needed -mllvm -amdgpu-spill-sgpr-to-vgpr=0 there: the
 // one-lane 5-point solver was called out of line from divergent control flow and SGPRs spilled into VGPR lanes across the calls
 // gave run-to-run different inlier sets.  The cooperative solver above has no calls and no spills; the option is gone, and
 // tests/test_gpu_fullsize.py::test_filters_are_deterministic_when_workgroups_share_a_cu runs against the default build.)
 hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds);
-#if defined(R3DM_FILTER_ALL)
-template <int NT>
-static hipError_t launch_all(hipStream_t st, const FilterParamsAll& A, uint32_t blocks, size_t lds)
-{
-    hipError_t e = hipFuncSetAttribute((const void*)acransac_all_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((acransac_all_kernel<NT>), dim3(blocks), dim3(NT), lds, st, A);
-    return hipGetLastError();
-}
-hipError_t launch_filter_all(hipStream_t st, const FilterParams* P, int n)
-{
-    if (n < 1 || n > 3) return hipErrorInvalidValue;
-    FilterParamsAll A{};
-    size_t lds = 0;
-    uint32_t blocks = 0;
-    bool wide = false;
-    for (int k = 0; k < 3; ++k) {
-        A.first[k] = blocks;
-        if (k < n) {
-            A.p[k] = P[k]; A.kinds[k] = P[k].model_kind;
-            blocks += P[k].n_items;
-            if (P[k].n_items) { lds = std::max(lds, filter_F_lds_bytes(P[k].m_cap, P[k].model_kind)); wide = wide || P[k].wide; }
-        }
-    }
-    A.first[3] = blocks;
-    if (blocks == 0) return hipSuccess;
-    return wide ? launch_all<512>(st, A, blocks, lds) : launch_all<256>(st, A, blocks, lds);
-}
-#else
 template <int KIND, int NT>
 static hipError_t launch_acransac(hipStream_t st, const FilterParams& P, size_t lds)
 {
@@ -1521,7 +1480,6 @@ hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
     if (P.model_kind == 0) return P.wide ? launch_acransac<0, 512>(st, P, lds) : launch_acransac<0, 256>(st, P, lds);
     return P.wide ? launch_acransac<1, 512>(st, P, lds) : launch_acransac<1, 256>(st, P, lds);
 }
-#endif
 #endif
 
 }  // namespace r3dm

@@ -119,8 +119,17 @@ struct r3dm_graph {
 
 struct FilterBufs {
     DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch, f_kinv, f_spill, f_soff, f_order;
+    // r3dm_filter_FEH: the kernel of this kind on a stream of its own PRIORITY class (E high, F normal, H low).  Streams of one
+    // priority share a handful of hardware queues -- three plain streams ran the three kernels mostly one after the other --, streams
+    // of different priorities never do.
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void release()
     {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+        ev0 = ev1 = nullptr; stream = nullptr;
         DevBuf* b[] = {&f_pairs, &f_ids, &f_offs, &f_matches, &f_inl_cnt, &f_inl_idx, &f_F, &f_thr, &f_iters, &f_log10, &f_logck, &f_scratch, &f_kinv, &f_spill, &f_soff, &f_order};
         for (DevBuf* x : b) x->release();
     }
@@ -141,7 +150,7 @@ struct r3dm_ctx {
     // scratch (grown on demand, reused across calls)
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     // geometric filters: one set of work buffers per model kind (0 F, 1 H, 2 E), so that r3dm_filter_FEH can run the three
-    // AC-RANSAC filters of a putative graph in one launch (a collection with few, long pairs leaves most CUs idle under one)
+    // AC-RANSAC kernels of a putative graph side by side (a collection with few, long pairs leaves most CUs idle under one)
     FilterBufs fb[3];
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf h_aux, h_jobs;            // HNSW: per-batch layer tables / job records

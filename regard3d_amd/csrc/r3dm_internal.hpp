@@ -312,7 +312,6 @@ hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t 
 hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_n);
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
-hipError_t launch_filter_all(hipStream_t st, const FilterParams* P, int n);      // 2 or 3 prepared filters (kinds distinct) in one launch
 size_t     filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 // rows8: every job carries byte rows -> the all-pairs scan runs on integer dot products (same keys)
 hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim, bool rows8);
