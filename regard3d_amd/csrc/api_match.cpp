@@ -183,7 +183,22 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         n_fallback = fbt[0];
         if (fbt[0] > 0) {
             bool rescan = fbt[1] > 0;                      // some pair overflowed its list
-            if ((first.dim & 3u) == 0) R3DM_HIP(c, launch_l2_exact_batch(c->stream, mp, first.G));
+            if ((first.dim & 3u) == 0) {
+                // a pair's uncertified queries are scanned by one workgroup per ~4096 rows of image I (at most 16): few pairs with
+                // long views (24 views of 28 k rows: 276 workgroups of 7.7 ms each) otherwise leave the chip idle behind one round
+                uint32_t max_nI = 0;
+                for (const PairJob& j : jobs) max_nI = std::max(max_nI, c->imgs[j.sI]->n);
+                uint32_t S = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (max_nI + 4095u) / 4096u));
+                while (S > 1 && (uint64_t)P * S > 65535ull * 4) --S;
+                mp.fb_slices = S; mp.fb_part = nullptr; mp.fb_done = nullptr;
+                if (S > 1) {
+                    R3DM_HIP(c, c->d_fb2.ensure((size_t)P * kFbPerPair * S * 16 + (size_t)P * 4 + 64));
+                    mp.fb_part = c->d_fb2.as<float4>();
+                    mp.fb_done = reinterpret_cast<uint32_t*>(c->d_fb2.as<unsigned char>() + (size_t)P * kFbPerPair * S * 16);
+                    R3DM_HIP(c, hipMemsetAsync(mp.fb_done, 0, (size_t)P * 4, c->stream));
+                }
+                R3DM_HIP(c, launch_l2_exact_batch(c->stream, mp, first.G));
+            }
             else rescan = true;                            // scalar-tail dims: generic exact kernel
             if (rescan) {
                 if (total_slots > 0xFFFFFFFFull) { c->err = "batch too large for the exact rescan"; return R3DM_ERR_UNSUPPORTED; }

@@ -825,7 +825,12 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 // slice belongs to one workgroup, whose waves share a CU and its vector L1 -- a WORKGROUP-scope fence (wait for the outstanding
 // stores and loads) is what the exchange needs.  __threadfence() is agent scope: on this chip of eight L2s that is an L2 write-back +
 // invalidate per barrier, ~10 per evaluated model on a spilled pair, and it slows every other workgroup of the device with it.
-__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// (The explicit wait is not redundant: hipcc was seen to emit no vmcnt wait for a workgroup-scope fence on gfx950, kernels_match.hip.)
+__device__ __forceinline__ void wg_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): this wave's global stores and loads have completed
+}
 __device__ __forceinline__ void wg_sync_global() { wg_fence(); r3dm_syncthreads(); wg_fence(); }
 template <bool GLOBAL_BUFFERS>
 __device__ __forceinline__ void wg_sync_t()

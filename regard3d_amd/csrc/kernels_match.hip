@@ -1424,7 +1424,9 @@ void l2_exact_batch_kernel(const MatchParams P)
     __shared__ f32x4 tile[32 * D4];                  // 32 rows x Dpad floats
     __shared__ float md0[256], md1[256];
     __shared__ uint32_t mi0[256], mi1[256];
+    __shared__ uint32_t s_ticket;
     const uint32_t pair = blockIdx.x;
+    const uint32_t S = P.fb_slices, slice = blockIdx.y;
     const uint32_t cnt_all = P.fb_cnt[pair];
     if (cnt_all == 0) return;
     const uint32_t cnt = cnt_all < kFbPerPair ? cnt_all : kFbPerPair;
@@ -1434,6 +1436,10 @@ void l2_exact_batch_kernel(const MatchParams P)
     const uint32_t nI = Ip->n, dim = Ip->dim, d4 = dim >> 2;      // dim % 4 == 0 guaranteed by the launcher
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const gf4p irows = (gf4p)Ip->rows;
+    // this workgroup's rows of image I: whole 32-row tiles, slice `slice` of S
+    const uint32_t tiles_per = ((nI + 31u) / 32u + S - 1u) / S;
+    const uint32_t row_beg = slice * tiles_per * 32u;
+    const uint32_t row_end = (row_beg + tiles_per * 32u < nI) ? row_beg + tiles_per * 32u : nI;
     for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
         const bool active = b0 + lane < cnt;
         const uint32_t q = P.fb_q[(size_t)pair * kFbPerPair + (active ? b0 + lane : b0)];
@@ -1442,9 +1448,9 @@ void l2_exact_batch_kernel(const MatchParams P)
 #pragma unroll
         for (int k = 0; k < D4; ++k) qv[k] = (k < (int)d4) ? qrow[k] : f32x4{0.f, 0.f, 0.f, 0.f};
         float d0 = R3DM_INF, d1 = R3DM_INF; uint32_t i0 = kNone, i1 = kNone;
-        for (uint32_t t0 = 0; t0 < nI; t0 += 32) {
+        for (uint32_t t0 = row_beg; t0 < row_end; t0 += 32) {
             r3dm_syncthreads();
-            const uint32_t rows_here = (nI - t0 < 32u) ? nI - t0 : 32u;
+            const uint32_t rows_here = (row_end - t0 < 32u) ? row_end - t0 : 32u;
             for (uint32_t e = threadIdx.x; e < rows_here * d4; e += 256) {
                 const uint32_t r = e / d4, k = e % d4;
                 tile[r * D4 + k] = irows[(size_t)(t0 + r) * d4 + k];
@@ -1486,6 +1492,38 @@ void l2_exact_batch_kernel(const MatchParams P)
                 }
                 a0 = r0; a1 = r1; x0 = j0; x1 = j1;
             }
+            if (S > 1) P.fb_part[((size_t)pair * kFbPerPair + b0 + lane) * S + slice] = make_float4(a0, __uint_as_float(x0), a1, __uint_as_float(x1));
+            else if (nI < 2) emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
+            else emit_result(P, pair, q, a0, x0, a1, x1);
+        }
+    }
+    if (S > 1) {
+        // the last slice of the pair to get here merges the S partial (best, runner-up) of every query under the (distance, row) order
+        __threadfence();
+        r3dm_syncthreads();
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&P.fb_done[pair], 1u);
+        r3dm_syncthreads();
+        if (s_ticket != S - 1u) return;
+        __threadfence();
+        for (uint32_t k = threadIdx.x; k < cnt; k += 256) {
+            const uint32_t q = P.fb_q[(size_t)pair * kFbPerPair + k];
+            const float4* part = P.fb_part + ((size_t)pair * kFbPerPair + k) * S;
+            float4 v = part[0];
+            float a0 = v.x, a1 = v.z; uint32_t x0 = __float_as_uint(v.y), x1 = __float_as_uint(v.w);
+            for (uint32_t w = 1; w < S; ++w) {
+                v = part[w];
+                const float b0_ = v.x, b1_ = v.z;
+                const uint32_t y0 = __float_as_uint(v.y), y1 = __float_as_uint(v.w);
+                float r0, r1; uint32_t j0, j1;
+                if (lex_less(b0_, y0, a0, x0)) {
+                    r0 = b0_; j0 = y0;
+                    if (lex_less(b1_, y1, a0, x0)) { r1 = b1_; j1 = y1; } else { r1 = a0; j1 = x0; }
+                } else {
+                    r0 = a0; j0 = x0;
+                    if (lex_less(b0_, y0, a1, x1)) { r1 = b0_; j1 = y0; } else { r1 = a1; j1 = x1; }
+                }
+                a0 = r0; a1 = r1; x0 = j0; x1 = j1;
+            }
             if (nI < 2) emit_result(P, pair, q, R3DM_INF, kNone, R3DM_INF, kNone);
             else emit_result(P, pair, q, a0, x0, a1, x1);
         }
@@ -1495,12 +1533,13 @@ void l2_exact_batch_kernel(const MatchParams P)
 hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t G)
 {
     if (P.n_pairs == 0) return hipSuccess;
-    if (P.n_pairs > kMaxBlocksOf256) return hipErrorInvalidValue;
+    if (P.n_pairs > kMaxBlocksOf256 || P.fb_slices < 1 || P.fb_slices > 64 || (uint64_t)P.n_pairs * P.fb_slices > kMaxBlocksOf256) return hipErrorInvalidValue;
+    const dim3 grid(P.n_pairs, P.fb_slices);
     switch (G) {
-        case 8:  hipLaunchKernelGGL((l2_exact_batch_kernel<8>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
-        case 16: hipLaunchKernelGGL((l2_exact_batch_kernel<16>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
-        case 18: hipLaunchKernelGGL((l2_exact_batch_kernel<18>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
-        case 32: hipLaunchKernelGGL((l2_exact_batch_kernel<32>), dim3(P.n_pairs), dim3(256), 0, st, P); break;
+        case 8:  hipLaunchKernelGGL((l2_exact_batch_kernel<8>), grid, dim3(256), 0, st, P); break;
+        case 16: hipLaunchKernelGGL((l2_exact_batch_kernel<16>), grid, dim3(256), 0, st, P); break;
+        case 18: hipLaunchKernelGGL((l2_exact_batch_kernel<18>), grid, dim3(256), 0, st, P); break;
+        case 32: hipLaunchKernelGGL((l2_exact_batch_kernel<32>), grid, dim3(256), 0, st, P); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

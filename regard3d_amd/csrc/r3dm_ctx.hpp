@@ -154,7 +154,7 @@ struct r3dm_ctx {
     FilterBufs fb[3];
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf h_aux, h_jobs;            // HNSW: per-batch layer tables / job records
-    DevBuf a_jobs, a_scratch, a_ids, d_spill;
+    DevBuf a_jobs, a_scratch, a_ids, d_spill, d_fb2;
     DevBuf m_raw, m_peer;                                   // r3dm_multi_set_image: the one upload of a view / this device's copy of it
     std::vector<DevBuf> ak_bufs;                            // Fast-A-KAZE work buffers of the last image size, ak_B planes each
     int ak_w = 0, ak_h = 0, ak_B = 0;

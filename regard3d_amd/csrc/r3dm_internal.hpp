@@ -172,6 +172,11 @@ struct MatchParams {
     uint32_t*     fb_q;           // [n_pairs][kFbPerPair] query rows
     uint32_t*     fb_cnt;         // [n_pairs] number collected (may exceed kFbPerPair: overflow -> global rescan)
     uint32_t*     fb_total;       // [2]: total uncertified queries, number that overflowed their pair's list
+    // the exact scan of a pair's uncertified queries split over fb_slices workgroups (row ranges of image I): per-slice results in
+    // fb_part, the last workgroup of a pair to finish merges them (fb_done: tickets, zeroed by the host)
+    float4*       fb_part;        // [n_pairs][kFbPerPair][fb_slices] (d0, bits of i0, d1, bits of i1)
+    uint32_t*     fb_done;        // [n_pairs]
+    uint32_t      fb_slices;      // 1: one workgroup per pair, results emitted directly
 };
 constexpr uint32_t kFbPerPair = 256;
 constexpr uint32_t kFallback = 0xFFFFFFFEu;
