@@ -266,7 +266,7 @@ def stage_main(a):
         last = reps[-1]
         if a.stage_quick:
             print(json.dumps({"stage_features": a.stage_features, "ms_per_step": elapsed / a.steps * 1e3,
-                              "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total")}}))
+                              "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_match_kernels", "ms_match_post", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")}}))
             return
         # the GUI's default arm (matchingAlgorithm 0 = FLANN kd-trees in the reference, src/Regard3DMainFrame.cpp:2405) on the files
         # the step left: no extraction, matching + filters only -- under the facade's default policy (an approximate arm is served by
@@ -295,8 +295,9 @@ def stage_main(a):
                                    f"R3DComputeMatches::computeMatches: Fast-A-KAZE + LIOP-144 ({conc} batches of {batch} in flight) -> .feat/.desc -> exhaustive {n_pairs} pairs, "
                                    "brute-force L2 2-NN + ratio 0.6 (matchingAlgorithm 9; split-f16 nomination + f32 re-score, bit-identical to f32 tiles) -> F + E + H AC-RANSAC (4 px, 2048 it) -> matches.*.txt/.bin",
                        "name": "stage", "images": N, "pairs": n_pairs, "image_size": [W, H], "parallelism": "1 GPU"},
-            "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total")},
-            "kernels_ms": {"match": mean("ms_match_kernels"), "F": mean("ms_F_kernels"), "E": mean("ms_E_kernels"), "H": mean("ms_H_kernels"),
+            "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")},
+            "phases_note": "filter_F / _E / _H run side by side on the one device (r3dm_filter_FEH): they overlap, filters_wall is their sum in the total",
+            "kernels_ms": {"match": mean("ms_match_kernels"), "match_post_wall": mean("ms_match_post"), "F": mean("ms_F_kernels"), "E": mean("ms_E_kernels"), "H": mean("ms_H_kernels"),
                            "detector_sum_over_contexts": last["features"]["ms_detect_kernels"], "liop_sum_over_contexts": last["features"]["ms_liop_kernels"]},
             "features": {"images_per_s": N / (mean("ms_features") * 1e-3), "ms_per_image": mean("ms_features") / N, "keypoints": int(last["n_keypoints"]),
                          "keypoints_per_image": last["n_keypoints"] / N, "file_ms_sum_over_contexts": last["features"]["ms_files"],

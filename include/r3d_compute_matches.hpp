@@ -133,6 +133,7 @@ public:
     struct PhaseTimes {
         double features = 0, load = 0, match = 0, filter_F = 0, filter_E = 0, filter_H = 0, files = 0, total = 0;
         double match_kernels = 0, F_kernels = 0, E_kernels = 0, H_kernels = 0;     // HIP-event time of the dominant kernel of each phase
+        double match_post = 0;                                                      // of `match`: everything behind the nomination kernel (exact scan of uncertified queries, finalisation, copy back)
         double filters_wall = 0;                                                    // F + E + H together: they run side by side on one device (r3dm_filter_FEH), so filter_F / _E / _H overlap
         uint64_t images_extracted = 0;
         r3dm_features_totals features_totals{};                                      // summed over the contexts of the features stage
@@ -197,6 +198,7 @@ typedef struct {
     double ms_features, ms_load, ms_match, ms_filter_F, ms_filter_E, ms_filter_H, ms_files, ms_total;
     double ms_match_kernels, ms_F_kernels, ms_E_kernels, ms_H_kernels;
     double ms_filters_wall;          /* F + E + H together (side by side on one device: ms_filter_F / _E / _H overlap) */
+    double ms_match_post;            /* of ms_match: behind the nomination kernel (exact scan of uncertified queries, finalisation, copy back) */
     uint64_t images_extracted, n_keypoints;
     uint64_t n_putative_pairs, n_putative_matches, n_F_pairs, n_F_matches, n_E_pairs, n_E_matches, n_H_pairs, n_H_matches;
     uint64_t match_was_exhaustive;   /* 1: the exhaustive matcher ran (arm 4 / 9, or an approximate arm routed to it) */

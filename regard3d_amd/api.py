@@ -69,7 +69,7 @@ class ViewImage(C.Structure):
 class StageReport(C.Structure):
     """r3dm_stage_report: wall time of the phases of R3DComputeMatches::computeMatches (ms), kernel times, counts"""
     _fields_ = [(k, C.c_double) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_files", "ms_total",
-                                          "ms_match_kernels", "ms_F_kernels", "ms_E_kernels", "ms_H_kernels", "ms_filters_wall")] + \
+                                          "ms_match_kernels", "ms_F_kernels", "ms_E_kernels", "ms_H_kernels", "ms_filters_wall", "ms_match_post")] + \
                [(k, C.c_uint64) for k in ("images_extracted", "n_keypoints", "n_putative_pairs", "n_putative_matches", "n_F_pairs", "n_F_matches",
                                           "n_E_pairs", "n_E_matches", "n_H_pairs", "n_H_matches", "match_was_exhaustive")] + [("features", FeaturesTotals)]
 

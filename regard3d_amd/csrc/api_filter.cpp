@@ -225,9 +225,11 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     fp_out = fp;
     r3dm_graph* graw = g.release();
     o.pending = graw;
+    FilterBufs* const Bp = &B;
     collect = [=, &o](float ms) mutable -> int {
     std::unique_ptr<r3dm_graph> g(graw);
     o.pending = nullptr;
+    FilterBufs& B = *Bp;                                   // (the context's buffer set itself, not a copy captured with the closure)
     if (fp.dbg) {                                          // developer build only
         uint32_t d[4] = {0, 0, 0, 0};
         hipError_t e = hipMemcpyAsync(d, fp.dbg, 16, hipMemcpyDeviceToHost, c->stream);
@@ -242,10 +244,12 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     }
 
     std::vector<uint32_t> h_cnt(NI);
-    std::vector<uint32_t> h_idx(n_slice);
+    // (inlier indices through the kind's page-locked landing buffer: pageable destinations are pinned on the way by the runtime)
+    if (B.pin_idx.ensure(4 * (size_t)n_slice + 64) != hipSuccess) { o.err = "filter: out of page-locked host memory"; return R3DM_ERR_NOMEM; }
+    uint32_t* h_idx = static_cast<uint32_t*>(B.pin_idx.p);
     std::vector<double> h_F(9 * (size_t)NI);
     FHIP(hipMemcpyAsync(h_cnt.data(), B.f_inl_cnt.p, 4 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
-    FHIP(hipMemcpyAsync(h_idx.data(), B.f_inl_idx.p, 4 * (size_t)n_slice, hipMemcpyDeviceToHost, c->stream));
+    FHIP(hipMemcpyAsync(h_idx, B.f_inl_idx.p, 4 * (size_t)n_slice, hipMemcpyDeviceToHost, c->stream));
     FHIP(hipMemcpyAsync(h_F.data(), B.f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
     FHIP(hipStreamSynchronize(c->stream));
     o.ms_kernels = ms;

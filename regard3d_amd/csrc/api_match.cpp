@@ -48,19 +48,26 @@ int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_str
         if (total <= out_cap) break;
         out_cap = total;                                   // overflow: nothing was lost, run it again with room
     }
-    std::vector<r3dm_match> h_m((size_t)total);
-    if (total) R3DM_HIP(c, hipMemcpy(h_m.data(), c->d_out.p, (size_t)total * sizeof(r3dm_match), hipMemcpyDeviceToHost));
+    // the matches come back through the context's page-locked landing buffer on the context's stream (a synchronous hipMemcpy into a
+    // fresh pageable vector runs on the null stream, pins the pages on the way and was seen to take 80 ms for 7.7 MB every few calls)
+    const r3dm_match* h_m = nullptr;
+    if (total) {
+        R3DM_HIP(c, c->pin_out.ensure((size_t)total * sizeof(r3dm_match)));
+        R3DM_HIP(c, hipMemcpyAsync(c->pin_out.p, c->d_out.p, (size_t)total * sizeof(r3dm_match), hipMemcpyDeviceToHost, c->stream));
+        h_m = static_cast<const r3dm_match*>(c->pin_out.p);
+    }
     if (knn_idx_host) {
         // single-pair use (r3dm_knn2): copy the raw 2-NN of pair 0
-        R3DM_HIP(c, hipMemcpy(knn_idx_host, c->d_knn_idx.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost));
-        R3DM_HIP(c, hipMemcpy(knn_dist_host, c->d_knn_dist.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost));
+        R3DM_HIP(c, hipMemcpyAsync(knn_idx_host, c->d_knn_idx.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(knn_dist_host, c->d_knn_dist.p, (size_t)max_nJ * 8, hipMemcpyDeviceToHost, c->stream));
     }
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
 
     if (g) {
         for (uint32_t p = 0; p < P; ++p) {
             if (h_cnt[p] == 0) continue;                   // empty vectors never enter the map
             g->pairs.push_back(jobs[p].I); g->pairs.push_back(jobs[p].J);
-            g->matches.insert(g->matches.end(), h_m.begin() + h_off[p], h_m.begin() + h_off[p] + h_cnt[p]);
+            g->matches.insert(g->matches.end(), h_m + h_off[p], h_m + h_off[p] + h_cnt[p]);
             g->offsets.push_back(g->matches.size());
         }
     }
@@ -74,6 +81,7 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
 {
     const uint32_t P = (uint32_t)jobs.size();
     if (P == 0) return R3DM_OK;
+    const double t_dbg0 = now_ms();
     const HostImage& first = *c->imgs[jobs[0].sI];
     const r3dm_dtype dtype = first.dtype;
     uint32_t max_nJ = 0, max_tiles = 0;
@@ -159,6 +167,7 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
     mp.fb_cnt = c->d_fb.as<uint32_t>() + 16;
     mp.fb_q = c->d_fb.as<uint32_t>() + 16 + P;
 
+    const double t_dbg1 = now_ms();
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     uint64_t n_fallback = 0;
     if (dtype == R3DM_BIN) {
@@ -217,6 +226,8 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
     int rcf = finalize_batch(c, jobs, q_stride, sort_cap, n_queries, max_nJ, g, knn_idx_host, knn_dist_host);
     if (rcf != R3DM_OK) return rcf;
     c->stats.ms_wall_match_post += now_ms() - t_post;
+    if (r3dm_dev_knob("R3DM_MATCH_TIMING", 0))
+        fprintf(stderr, "run_match_batch: prepare %.2f ms, launch .. exact scan issued %.2f ms, finalize %.2f ms\n", t_dbg1 - t_dbg0, t_post - t_dbg1, now_ms() - t_post);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_match_kernels += ms;

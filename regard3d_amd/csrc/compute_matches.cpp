@@ -434,6 +434,13 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     }
     if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
     phases_.match = wall_ms() - t_phase; phases_.match_kernels = kernel_ms(false);
+#ifdef R3DM_DEVTOOLS
+    { r3dm_stats st{}; if (ctx_ && r3dm_get_stats(ctx_, &st) == R3DM_OK) fprintf(stderr, "facade match phase %.2f ms, r3dm_match_pairs inside %.2f ms\n", phases_.match, st.ms_wall_match); }
+#endif
+    {
+        r3dm_stats st{};
+        if (ctx_ && r3dm_get_stats(ctx_, &st) == R3DM_OK) phases_.match_post = st.ms_wall_match_post;
+    }
     t_phase = wall_ms();
     graph_to_map(putative, statistics_.putativeMatches_);
     const std::string put_path = paths.matchesPutitativeFilename_.empty() ? dir + "/matches.putative.txt" : paths.matchesPutitativeFilename_;
@@ -603,7 +610,7 @@ extern "C" int r3dm_stage_run(r3dm_stage* sp, const char* matches_dir, const r3d
             *report = r3dm_stage_report{};
             report->ms_features = P.features; report->ms_load = P.load; report->ms_match = P.match; report->ms_filter_F = P.filter_F;
             report->ms_filter_E = P.filter_E; report->ms_filter_H = P.filter_H; report->ms_files = P.files; report->ms_total = P.total;
-            report->ms_filters_wall = P.filters_wall;
+            report->ms_filters_wall = P.filters_wall; report->ms_match_post = P.match_post;
             report->ms_match_kernels = P.match_kernels; report->ms_F_kernels = P.F_kernels; report->ms_E_kernels = P.E_kernels; report->ms_H_kernels = P.H_kernels;
             report->images_extracted = P.images_extracted; report->features = P.features_totals;
             report->match_was_exhaustive = stage.lastMatchWasExhaustive() ? 1 : 0;

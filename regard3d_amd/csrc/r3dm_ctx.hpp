@@ -124,8 +124,10 @@ struct FilterBufs {
     // of different priorities never do.
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    PinBuf pin_idx;           // page-locked landing zone of the inlier indices
     void release()
     {
+        pin_idx.release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -161,6 +163,7 @@ struct r3dm_ctx {
     uint32_t ak_cap = 0;                                    // candidate slots per image the detector last needed (grows, never shrinks)
     int ak_n_levels = 0;
     AkLevelDev* ak_levels_dev = nullptr;                    // level table of the last detector pass (inside ak_bufs; read by the MLDB kernel)
+    PinBuf pin_out;                                         // page-locked landing zone of the match lists of a batch (finalize_batch)
     PinBuf pin_desc;                                        // page-locked landing zone of the LIOP descriptors of a batch
     bool integer_mfma = false;                              // r3dm_set_integer_mfma
     bool split_mfma = false;                                // r3dm_set_split_mfma
