@@ -49,7 +49,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
     for (auto& im : c->spare) if (im) im->release();
-    c->pin_desc.release(); c->pin_out.release();
+    c->pin_desc.release(); c->pin_out.release(); c->pin_small.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -41,10 +41,14 @@ int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_str
         fp.total = reinterpret_cast<unsigned long long*>(c->d_cnt.as<uint32_t>() + 8);
         fp.pair_off = c->d_pair_off.as<uint64_t>(); fp.pair_cnt = c->d_pair_cnt.as<uint32_t>();
         R3DM_HIP(c, launch_finalize(c->stream, fp));
-        R3DM_HIP(c, hipMemcpyAsync(&total, fp.total, 8, hipMemcpyDeviceToHost, c->stream));
-        R3DM_HIP(c, hipMemcpyAsync(h_off.data(), fp.pair_off, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
-        R3DM_HIP(c, hipMemcpyAsync(h_cnt.data(), fp.pair_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
+        // (every copy back lands in page-locked memory: pageable destinations go through the runtime's staging path)
+        R3DM_HIP(c, c->pin_small.ensure(64 + (size_t)P * 12));
+        unsigned char* ps = static_cast<unsigned char*>(c->pin_small.p);
+        R3DM_HIP(c, hipMemcpyAsync(ps, fp.total, 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(ps + 64, fp.pair_off, (size_t)P * 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync(ps + 64 + (size_t)P * 8, fp.pair_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(&total, ps, 8); memcpy(h_off.data(), ps + 64, (size_t)P * 8); memcpy(h_cnt.data(), ps + 64 + (size_t)P * 8, (size_t)P * 4);
         if (total <= out_cap) break;
         out_cap = total;                                   // overflow: nothing was lost, run it again with room
     }
@@ -187,8 +191,10 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         }
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         uint32_t fbt[2] = {0, 0};
-        R3DM_HIP(c, hipMemcpyAsync(fbt, mp.fb_total, 8, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, c->pin_small.ensure(64));
+        R3DM_HIP(c, hipMemcpyAsync(c->pin_small.p, mp.fb_total, 8, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(fbt, c->pin_small.p, 8);
         n_fallback = fbt[0];
         if (fbt[0] > 0) {
             bool rescan = fbt[1] > 0;                      // some pair overflowed its list

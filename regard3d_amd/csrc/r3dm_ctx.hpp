@@ -163,6 +163,7 @@ struct r3dm_ctx {
     uint32_t ak_cap = 0;                                    // candidate slots per image the detector last needed (grows, never shrinks)
     int ak_n_levels = 0;
     AkLevelDev* ak_levels_dev = nullptr;                    // level table of the last detector pass (inside ak_bufs; read by the MLDB kernel)
+    PinBuf pin_small;                                       // ... of the counters and per-pair tables that come back with them
     PinBuf pin_out;                                         // page-locked landing zone of the match lists of a batch (finalize_batch)
     PinBuf pin_desc;                                        // page-locked landing zone of the LIOP descriptors of a batch
     bool integer_mfma = false;                              // r3dm_set_integer_mfma
