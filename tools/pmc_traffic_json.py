@@ -23,5 +23,10 @@ for k, v in vals.items():
     out[f"c2:{k}"] = {"kernel": v["kernel"], "from": os.path.relpath(sys.argv[1], ROOT), "source": "kernels_match.hip", "source_sha16": sha16,
                       "fetch_size_kib": v["FETCH_SIZE"], "write_size_kib": v.get("WRITE_SIZE", 0.0), "read_bytes_corrected": rd, "write_bytes": wr,
                       "traffic_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": ALG[k][0], "note": "algorithmic = " + ALG[k][1]}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
-print({k: round(v["traffic_bytes_per_launch"] / 1e9, 1) for k, v in out.items() if k != "_comment"})
+dst = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+if os.path.exists(dst):                      # entries of other configs / kernels (c5: kernels_ann.hip) stay
+    old = json.load(open(dst))
+    old.update(out)
+    out = old
+json.dump(out, open(dst, "w"), indent=1)
+print({k: round(v["traffic_bytes_per_launch"] / 1e9, 1) for k, v in out.items() if k != "_comment" and "traffic_bytes_per_launch" in v})
