@@ -6,6 +6,8 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from regard3d_amd import api, synth
+if any(k.startswith("R3DM_") for k in os.environ):
+    api.use_developer_library()
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "liop"
 n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 24
