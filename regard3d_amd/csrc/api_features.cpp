@@ -584,12 +584,12 @@ static int r3dm_liop_describe_patches_impl(r3dm_ctx* c, const float* patches, ui
     const size_t in_bytes = (size_t)n * 41 * 41 * 4, out_bytes = (size_t)n * 144 * 4;
     R3DM_HIP(c, c->liop_in.ensure(in_bytes));
     R3DM_HIP(c, c->liop_out.ensure(out_bytes));
-    R3DM_HIP(c, c->liop_cnt.ensure(64));
+    R3DM_HIP(c, c->liop_cnt.ensure(64 + (size_t)n * 4));          // [tie count | ...][tie list: n]
     R3DM_HIP(c, hipMemcpyAsync(c->liop_in.p, patches, in_bytes, hipMemcpyDefault, c->stream));
     R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
-                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>()));
+                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
     R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
     R3DM_HIP(c, hipMemcpyAsync(desc_out, c->liop_out.p, out_bytes, hipMemcpyDefault, c->stream));
     uint32_t nt = 0;
@@ -655,7 +655,7 @@ static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t widt
     R3DM_HIP(c, c->liop_kern.ensure(64));
     R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
     R3DM_HIP(c, c->liop_out.ensure(out_bytes));
-    R3DM_HIP(c, c->liop_cnt.ensure(64));
+    R3DM_HIP(c, c->liop_cnt.ensure(64 + (size_t)n * 4));
     if (!resident_image) R3DM_HIP(c, hipMemcpyAsync(c->liop_img.p, image, img_bytes, hipMemcpyDefault, c->stream));
     const float* dev_image = resident_image ? resident_image : c->liop_img.as<float>();
     R3DM_HIP(c, hipMemcpyAsync(c->liop_M.p, M6.data(), M6.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -665,7 +665,7 @@ static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t widt
     R3DM_HIP(c, launch_liop_extract(c->stream, dev_image, (int)width, (int)height, c->liop_M.as<float>(),
                                     c->liop_kern.as<float>(), n, c->liop_in.as<float>()));
     R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
-                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>()));
+                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
     R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
     R3DM_HIP(c, hipMemcpyAsync(desc_out, c->liop_out.p, out_bytes, hipMemcpyDefault, c->stream));
     if (patches_out) R3DM_HIP(c, hipMemcpyAsync(patches_out, c->liop_in.p, patch_bytes, hipMemcpyDefault, c->stream));
@@ -805,7 +805,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         R3DM_HIP(c, c->liop_kern.ensure(64));
         R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
         R3DM_HIP(c, c->liop_out.ensure(out_bytes));
-        R3DM_HIP(c, c->liop_cnt.ensure(64));
+        R3DM_HIP(c, c->liop_cnt.ensure(64 + n_total * 4));
         R3DM_HIP(c, c->pin_desc.ensure(out_bytes));
         uint32_t* d_img_of = reinterpret_cast<uint32_t*>(c->liop_M.as<float>() + M6.size());
         R3DM_HIP(c, hipMemcpyAsync(c->liop_M.p, M6.data(), M6.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -817,7 +817,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         R3DM_HIP(c, launch_liop_extract(c->stream, c->ak_bufs[0].as<float>(), (int)width, (int)height, c->liop_M.as<float>(),
                                         c->liop_kern.as<float>(), (uint32_t)n_total, c->liop_in.as<float>(), d_img_of));
         R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
-                                c->liop_sy.as<double>(), (uint32_t)n_total, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>()));
+                                c->liop_sy.as<double>(), (uint32_t)n_total, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         R3DM_HIP(c, hipMemcpyAsync(c->pin_desc.p, c->liop_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));

@@ -126,23 +126,31 @@ struct LiopParams {
     const double* sy;          // [n_pix][4]
     uint32_t n, n_pix;
     float* desc;               // [n][144]
-    uint32_t* n_tie_patches;   // statistics: patches that needed the exact re-sort
+    uint32_t* n_tie_patches;   // patches with equal intensities in their support: they need the reference's exact re-sort ...
+    uint32_t* tie_list;        // ... and are left to the second pass (their indices, [n])
 };
 
+// TIE_PASS = false: every patch whose support intensities are all distinct (almost all: blurred float images) -- 14 KB of LDS per
+// one-wave workgroup, 11 of them per CU.  A patch with a tie only puts itself on P.tie_list.  TIE_PASS = true: the patches of that
+// list, with the arrays of the reference's quick sort (8 KB more) -- launched right behind the first pass, its workgroups read the
+// count from device memory (no host round trip; a launch over an empty list costs a few microseconds).
+template <bool TIE_PASS>
 __global__ __launch_bounds__(64)
 void liop_kernel(const LiopParams P)
 {
     __shared__ __attribute__((aligned(16))) float patch[kLiopPix + 3 + 128];   // (+ slack: the patch is loaded in float4 pieces)
     __shared__ float inten[kLiopSortCap];            // intensities in scan order (for the exact re-sort)
     __shared__ uint16_t perm[kLiopSortCap];
-    __shared__ uint2 qarr[kLiopMaxPix + 4];          // exact re-sort of patches with equal intensities: (intensity bits, position)
-    __shared__ uint16_t qstack[2 * kLiopMaxPix + 8];
+    __shared__ uint2 qarr[TIE_PASS ? kLiopMaxPix + 4 : 1];          // exact re-sort of patches with equal intensities: (intensity bits, position)
+    __shared__ uint16_t qstack[TIE_PASS ? 2 * kLiopMaxPix + 8 : 1];
     __shared__ uint32_t hist[144];
     __shared__ float s_norm;
 
     const uint32_t lane = threadIdx.x;
     const uint32_t N = P.n_pix;
-    for (uint32_t item = blockIdx.x; item < P.n; item += gridDim.x) {
+    const uint32_t n_items = TIE_PASS ? *P.n_tie_patches : P.n;
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const uint32_t item = TIE_PASS ? P.tie_list[it] : it;
         const float* src = P.patches + (size_t)item * kLiopPix;
         {
             // 1681 floats; a patch starts at a multiple of 4 bytes only, so the vector loads are of single floats, all in flight at once
@@ -187,15 +195,18 @@ void liop_kernel(const LiopParams P)
             continue;
         }
         if (any_tie) {
-            for (uint32_t i = lane; i < N + 4u; i += 64) qarr[i] = make_uint2(i < N ? __float_as_uint(inten[i]) : 0u, i);
-            r3dm_syncthreads();
-            if (lane == 0) {
-                liop_ref_qsort(qarr, (int)N, qstack);
-                atomicAdd(P.n_tie_patches, 1u);
+            if constexpr (!TIE_PASS) {
+                if (lane == 0) P.tie_list[atomicAdd(P.n_tie_patches, 1u)] = item;      // the second pass does this patch
+                r3dm_syncthreads();
+                continue;
+            } else {
+                for (uint32_t i = lane; i < N + 4u; i += 64) qarr[i] = make_uint2(i < N ? __float_as_uint(inten[i]) : 0u, i);
+                r3dm_syncthreads();
+                if (lane == 0) liop_ref_qsort(qarr, (int)N, qstack);
+                r3dm_syncthreads();
+                for (uint32_t i = lane; i < N; i += 64) perm[i] = (uint16_t)qarr[i].y;
+                r3dm_syncthreads();
             }
-            r3dm_syncthreads();
-            for (uint32_t i = lane; i < N; i += 64) perm[i] = (uint16_t)qarr[i].y;
-            r3dm_syncthreads();
         }
         // threshold = -intensityThreshold * (max - min), all float (vl_liop.c:497-503)
         const float thr = (float)(5.0 / 255) * (inten[perm[N - 1]] - inten[perm[0]]);
@@ -343,14 +354,16 @@ hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h,
     return hipGetLastError();
 }
 
+// n_tie_patches: one zeroed word (receives the number of patches that needed the exact re-sort); tie_list: n words of scratch
 hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
-                       uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches)
+                       uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches, uint32_t* tie_list)
 {
     if (n == 0) return hipSuccess;
     if (n_pix < 2 || n_pix > (uint32_t)kLiopMaxPix) return hipErrorInvalidValue;
-    LiopParams P{patches, pix, sx, sy, n, n_pix, desc, n_tie_patches};
+    LiopParams P{patches, pix, sx, sy, n, n_pix, desc, n_tie_patches, tie_list};
     const uint32_t grid = n < 65536u ? n : 65536u;
-    hipLaunchKernelGGL(liop_kernel, dim3(grid), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(liop_kernel<false>, dim3(grid), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(liop_kernel<true>, dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, st, P);
     return hipGetLastError();
 }
 

@@ -331,6 +331,6 @@ hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, s
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
                                uint32_t n, float* patches, const uint32_t* img_of = nullptr);
 hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
-                       uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches);
+                       uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches, uint32_t* tie_list);
 
 }  // namespace r3dm
