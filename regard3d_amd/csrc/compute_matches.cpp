@@ -196,12 +196,14 @@ R3DComputeMatches::~R3DComputeMatches()
 int R3DComputeMatches::features_sink(void* self_, uint32_t image_index, uint32_t n_features, const float* desc_device, const float* xy_as_written)
 {
     R3DComputeMatches* self = static_cast<R3DComputeMatches*>(self_);
-    const size_t vi = self->sink_need_[image_index];
-    const View& v = self->views_[vi];
-    std::lock_guard<std::mutex> lk(self->sink_mu_);
-    const int rc = self->ctx_ ? r3dm_set_image(self->ctx_, v.id_view, v.ui_width, v.ui_height, desc_device, n_features, self->dim_, self->dtype_, xy_as_written)
-                              : r3dm_multi_set_image(self->multi_, v.id_view, v.ui_width, v.ui_height, desc_device, n_features, self->dim_, self->dtype_, xy_as_written);
-    if (rc == R3DM_OK) { self->registered_[vi] = 1; self->registered_n_[vi] = n_features; }
+    try {                                                  // nothing leaves a C callback by exception (the caller is a worker thread of the library)
+        const size_t vi = self->sink_need_[image_index];
+        const View& v = self->views_[vi];
+        std::lock_guard<std::mutex> lk(self->sink_mu_);
+        const int rc = self->ctx_ ? r3dm_set_image(self->ctx_, v.id_view, v.ui_width, v.ui_height, desc_device, n_features, self->dim_, self->dtype_, xy_as_written)
+                                  : r3dm_multi_set_image(self->multi_, v.id_view, v.ui_width, v.ui_height, desc_device, n_features, self->dim_, self->dtype_, xy_as_written);
+        if (rc == R3DM_OK) { self->registered_[vi] = 1; self->registered_n_[vi] = n_features; }
+    } catch (...) {}
     return 0;
 }
 
