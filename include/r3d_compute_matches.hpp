@@ -86,17 +86,19 @@ public:
     void setRegionsType(r3dm_dtype dtype, uint32_t dim);           // default: float x 144 (R3D_AKAZE_LIOP_Regions)
     void setSeed(uint64_t seed) { seed_ = seed; }
     // The exhaustive matcher's exact MFMA fast paths: split-f16 nomination for real-valued descriptors (LIOP-144, what Regard3D matches:
-    // 2.9x) and bf16 tiles for integer-valued ones (SIFT bins: 7.9x).  Both nominate candidates on narrow tiles and then compute the
+    // 2.9x), bf16 tiles for integer-valued ones (SIFT bins: 7.9x) and i8 tiles for binary ones (A-KAZE MLDB: 3.0x, exact integers).  Both nominate candidates on narrow tiles and then compute the
     // distances of the candidates in f32 in the reference's order, with a certificate per query (a query whose certificate fails goes
     // through the exact scan), so indices, distances and match files are BIT-IDENTICAL to the plain f32-tile path (tests/
     // test_gpu_split_mfma.py, test_gpu_integer_mfma.py, test_liop_match_ref.py against reference-built code; bench.py --config stage
     // compares the files on every run).  ON by default in this facade since round 3; the C ABI's r3dm_match_pairs keeps f32 tiles
     // unless r3dm_set_split_mfma / r3dm_set_integer_mfma are called (BASELINE's configurations name the f32 arithmetic).
-    void setExactFastPaths(bool on) { setIntegerFastPath(on); setSplitFastPath(on); }
+    void setExactFastPaths(bool on) { setIntegerFastPath(on); setSplitFastPath(on); setHammingFastPath(on); }
     // no reference counterpart: forwards r3dm_set_integer_mfma (bit-identical results, integer-valued descriptors only)
     void setIntegerFastPath(bool on);
     // no reference counterpart: forwards r3dm_set_split_mfma (bit-identical results, real-valued descriptors: LIOP)
     void setSplitFastPath(bool on);
+    // no reference counterpart: forwards r3dm_set_hamming_mfma (bit-identical results, binary descriptors: A-KAZE MLDB on i8 MFMA tiles, 3.0x)
+    void setHammingFastPath(bool on);
     // How the approximate arms of the dispatch (0 FLANN, 1-3 KGraph, 5 MRPT, 6-8 HNSW) are served.  kArmsFastest (default): by the
     // EXHAUSTIVE matcher whenever r3dm_exhaustive_is_faster says it is not slower on the registered views -- on LIOP-144 every
     // approximate arm is then exact and >= 2x faster than the graph search (the GUI's default arm 0 included); kArmsAsRequested:

@@ -302,6 +302,12 @@ void R3DComputeMatches::setSplitFastPath(bool on)
     if (multi_) for (int k = 0; k < r3dm_multi_num_devices(multi_); ++k) (void)r3dm_set_split_mfma(r3dm_multi_ctx(multi_, k), on ? 1 : 0);
 }
 
+void R3DComputeMatches::setHammingFastPath(bool on)
+{
+    if (ctx_) (void)r3dm_set_hamming_mfma(ctx_, on ? 1 : 0);
+    if (multi_) for (int k = 0; k < r3dm_multi_num_devices(multi_); ++k) (void)r3dm_set_hamming_mfma(r3dm_multi_ctx(multi_, k), on ? 1 : 0);
+}
+
 void R3DComputeMatches::setRegionsType(r3dm_dtype dtype, uint32_t dim) { dtype_ = dtype; dim_ = dim; }
 
 bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,
