@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, help="N = 1 only: run shard 0 of a W-way job")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-leg", action="store_true", help="skip the short pass of the stage leg (pixels -> matches.*) appended to the default line as `stage_leg`")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the extra (untimed-region) pass on the opt-in fast path of the config")
     a = ap.parse_args()
     if a.config == "stage":
@@ -218,6 +219,19 @@ def main():
         attach_traffic(out["roofline"], a.config, out["roofline"]["kernel"].split("<")[0], emu, base_images, n_feat)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.config, cfg, ctx, descs, xys, g, gf, a.cpu_seconds, kp)
+    # Outside the timed region, N = 1, the default leg only: a short pass of the STAGE leg (`--config stage`: 16 photographs of 12 Mpx from
+    # pixels to matches.{putative,f,e,h} through the one facade call), so that the line the driver records also carries what the reference's
+    # default stage costs around the headline kernel.  Never part of `value`.
+    if rank == 0 and world == 1 and a.config == "c2" and not a.no_stage_leg and not emu and not a.images and not a.feat:
+        try:
+            del descs, xys
+            ctx.clear_images()
+            torch.cuda.empty_cache()
+            out["stage_leg"] = stage_main(a, embed={"images": 16, "steps": 2, "warmup": 1})
+            out["stage_leg"]["note"] = ("python bench.py --config stage is the full leg (per-phase ms, detector and E-filter rooflines, CPU baseline, "
+                                        "the GUI's default arm); profiles/r03_end_bench_stage.json")
+        except Exception as e:                    # the headline stands on its own
+            out["stage_leg"] = {"error": str(e)[:300]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -225,8 +239,9 @@ def main():
         td.destroy_process_group()
 
 
-def stage_main(a):
-    """--config stage: the reference's default Compute-matches stage from pixels, through the one facade call."""
+def stage_main(a, embed=None):
+    """--config stage: the reference's default Compute-matches stage from pixels, through the one facade call.
+    embed = {"images", "steps", "warmup"}: the timed steps only, returned as a dict (the `stage_leg` object of the default bench line)."""
     import shutil
     import tempfile
     if int(os.environ.get("WORLD_SIZE", "1")) != 1:
@@ -234,7 +249,9 @@ def stage_main(a):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     W, H = (int(x) for x in a.stage_size.lower().split("x"))
-    N = a.images or 32
+    N = (embed["images"] if embed else a.images) or 32
+    n_steps = embed["steps"] if embed else a.steps
+    n_warm = embed["warmup"] if embed else max(a.warmup, 1)
     imgs, K = synth.make_photo_set(N, H, W, seed=7007, device=dev)          # gray / 255 floats, resident in HBM
     torch.cuda.synchronize()
     views = [dict(id=k, width=W, height=H, basename=f"img{k:04d}", gray=imgs[k], focal_px=K[0, 0], ppx=K[0, 2], ppy=K[1, 2]) for k in range(N)]
@@ -255,18 +272,24 @@ def stage_main(a):
         return stage.run(d, views, 0.001, 0.6, algo, True, True, True, 5489, conc, batch)
 
     try:
-        for _ in range(max(a.warmup, 1)):
+        for _ in range(n_warm):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = [step().as_dict() for _ in range(a.steps)]
+        reps = [step().as_dict() for _ in range(n_steps)]
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         mean = lambda k: sum(r[k] for r in reps) / len(reps)
         last = reps[-1]
-        if a.stage_quick:
-            print(json.dumps({"stage_features": a.stage_features, "ms_per_step": elapsed / a.steps * 1e3,
-                              "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_match_kernels", "ms_match_post", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")}}))
+        if a.stage_quick or embed:
+            quick = {"stage_features": a.stage_features, "images": N, "image_size": [W, H], "pairs": n_pairs, "steps": n_steps,
+                     "ms_per_step": elapsed / n_steps * 1e3, "pairs_per_s": n_pairs * n_steps / elapsed,
+                     "keypoints_per_image": last["n_keypoints"] / N,
+                     "putative_pairs": int(last["n_putative_pairs"]), "putative_matches": int(last["n_putative_matches"]), "F_matches": int(last["n_F_matches"]),
+                     "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_match_kernels", "ms_match_post", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")}}
+            if embed:
+                return quick
+            print(json.dumps(quick))
             return
         # the GUI's default arm (matchingAlgorithm 0 = FLANN kd-trees in the reference, src/Regard3DMainFrame.cpp:2405) on the files
         # the step left: no extraction, matching + filters only -- under the facade's default policy (an approximate arm is served by
