@@ -30,7 +30,7 @@ EXPORTS = [
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_transfer_counts", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
-    "r3dm_multi_match_pairs", "r3dm_multi_match_pairs_kgraph", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
+    "r3dm_multi_match_pairs", "r3dm_multi_match_pairs_kgraph", "r3dm_multi_match_pairs_hnsw", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
 ]
 
 
@@ -297,6 +297,7 @@ def load_library():
     L.r3dm_multi_set_integer_mfma.argtypes = [vp, C.c_int]
     L.r3dm_multi_match_pairs.argtypes = [vp, vp, u64, C.c_float, C.c_int, C.POINTER(vp)]
     L.r3dm_multi_match_pairs_kgraph.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
+    L.r3dm_multi_match_pairs_hnsw.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_multi_filter_F.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
     L.r3dm_multi_filter_H.argtypes = [vp, vp, C.c_double, u32, u64, C.POINTER(vp), vp]
     L.r3dm_multi_filter_E.argtypes = [vp, vp, C.c_double, u32, u64, u32, C.c_float, C.POINTER(vp), vp]
@@ -835,6 +836,14 @@ class MultiContext:
         h = C.c_void_p()
         self._check(self._L.r3dm_multi_match_pairs_kgraph(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0], dist_ratio,
                                                           C.addressof(kp), C.byref(h)), "r3dm_multi_match_pairs_kgraph")
+        return Graph(h.value)
+
+    def match_pairs_hnsw(self, pairs, dist_ratio: float = 0.6, params: "HnswParams" = None) -> Graph:
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        hp = params if params is not None else HnswParams.preset(2)
+        h = C.c_void_p()
+        self._check(self._L.r3dm_multi_match_pairs_hnsw(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0], dist_ratio,
+                                                        C.addressof(hp), C.byref(h)), "r3dm_multi_match_pairs_hnsw")
         return Graph(h.value)
 
     def _filter(self, fn, what, putative, args, want):

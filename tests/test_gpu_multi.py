@@ -66,6 +66,11 @@ def test_two_contexts_reassemble_the_single_context_graphs(ctx, oracle, n_ctx):
         a2 = m.match_pairs_kgraph(pairs, 0.6, kp)
         assert _same(a1, a2) and a1.num_matches > 0
         assert sum(m.device_stats(k).n_ann_built for k in range(n_ctx)) == sc.n_images - 1
+        # ... and the HNSW matcher (hnsw_match): indices per owner of the row, graphs merged
+        hp = api.HnswParams.preset("medium")
+        b1 = ctx.match_pairs_hnsw(pairs, 0.6, hp)
+        b2 = m.match_pairs_hnsw(pairs, 0.6, hp)
+        assert _same(b1, b2) and b1.num_matches > 0
     finally:
         m.close()
         ctx.clear_images()
