@@ -29,6 +29,7 @@ library's stream; `cpu_baseline` times the CPU restatement (oracle/, OpenMP over
 sample of the same workload on the host cores of this box, and doubles as a full-size parity check.
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import math
@@ -239,6 +240,38 @@ def main():
         td.destroy_process_group()
 
 
+def host_cores():
+    """(cores this process may really use, processors it sees): the affinity mask AND the cgroup CPU quota -- a container can show 256
+    processors and own 16 (`cpu.max = 1600000 100000`); OpenMP teams of 256 threads are then throttled, and `cores: 256` would overstate
+    what the CPU baseline ran on."""
+    seen = os.cpu_count() or 1
+    n = seen
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            parts = open(path).read().split()
+            if parts and parts[0].lstrip("-").isdigit() and int(parts[0]) > 0:
+                period = int(parts[1]) if len(parts) > 1 else int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                n = max(1, min(n, int(parts[0]) // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, seen
+
+
+def use_host_cores():
+    """OpenMP teams of the oracle sized to the cores the process owns; -> (cores, processors seen)"""
+    cores, seen = host_cores()
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    return cores, seen
+
+
 def stage_main(a, embed=None):
     """--config stage: the reference's default Compute-matches stage from pixels, through the one facade call.
     embed = {"images", "steps", "warmup"}: the timed steps only, returned as a dict (the `stage_leg` object of the default bench line)."""
@@ -390,7 +423,7 @@ def stage_cpu_baseline(ctx, imgs, d, K, W, H, budget_s):
     The crop also goes through the GPU detector: same keypoints or the leg reports the mismatch."""
     from oracle import pyoracle as O
     O.build()
-    cores = os.cpu_count() or 1
+    cores, seen = use_host_cores()
     cw, ch = W // 2, H // 2
     crop = imgs[0][:ch, :cw].contiguous().cpu().numpy()
     t0 = time.perf_counter()
@@ -421,7 +454,7 @@ def stage_cpu_baseline(ctx, imgs, d, K, W, H, budget_s):
     g = api.Graph.load(os.path.join(d, "matches.putative.bin")).as_dict()
     gf = api.Graph.load(os.path.join(d, "matches.f.bin")).as_dict()
     share = (cw * ch) / float(W * H)
-    return {"value": 1.0 / (t_match + t_filt), "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / (t_match + t_filt), "unit": "pairs/s", "cores": cores, "processors_seen": seen, "kind": "port",
             "sample": f"features: the {cw}x{ch} top-left crop of image 0 through oracle/akaze.c ({t_det:.1f} s) + liop.c ({t_liop:.1f} s), OpenMP on {cores} threads; "
                       f"matching: pair (0,1) of the stage's own descriptors, brute-force L2 2-NN + ratio ({t_match:.1f} s) + F / E / H AC-RANSAC ({t_filt:.2f} s)",
             "features_images_per_s_full_size_equivalent": share / (t_det + t_liop),
@@ -580,7 +613,7 @@ def cpu_baseline(name, cfg, ctx, descs, xys, g, gf, budget_s, kp):
     kgraph_match :808-902 for c5: NN-descent index of image 0 with the reference's parameters, then the searches) + the
     AC-RANSAC F filter of those pairs.  The same pairs are then compared with the GPU result (parity check for free)."""
     from oracle import pyoracle as O
-    cores = os.cpu_count() or 1
+    cores, seen = use_host_cores()
     n_images = descs.shape[0]
     binary = cfg["kind"] == "akaze"
     n = int(descs.shape[1])
@@ -607,7 +640,7 @@ def cpu_baseline(name, cfg, ctx, descs, xys, g, gf, budget_s, kp):
     t_filter = time.perf_counter() - t1
     how = ("NN-descent index of image 0 (K 16, L 24, the reference's default block) + graph searches" if kp is not None
            else ("brute-force Hamming 2-NN + ratio" if binary else "brute-force L2 2-NN + ratio"))
-    out = {"value": S / (t_match + t_filter), "unit": "pairs/s", "cores": cores, "kind": "port",
+    out = {"value": S / (t_match + t_filter), "unit": "pairs/s", "cores": cores, "processors_seen": seen, "kind": "port",
            "sample": f"pairs (0,1..{S}) of the same workload: {how} ({t_match:.1f} s) + AC-RANSAC F filter ({t_filter:.2f} s), "
                      f"OpenMP over J on {cores} threads"}
     # parity of the sampled pairs at full size.  The GPU graph matcher is deterministic where the reference's NN-descent is

@@ -489,6 +489,10 @@ typedef struct {
     double   ms_files;                 /* of which: writing .feat / .desc                                                      */
 } r3dm_features_totals;
 int r3dm_get_features_totals(const r3dm_ctx* ctx, r3dm_features_totals* out);
+/* How many helper threads a host should start beside this library: half of the cores the process may really use -- the affinity mask
+ * AND the cgroup CPU quota (a container can show 256 processors and own 16; more runnable threads than that are throttled for the rest
+ * of the scheduler period, which looks like random 60-100 ms stalls) -- at most `want`.  The library sizes its own teams with it. */
+int r3dm_host_threads(int want);
 
 /* A sink for the features entry points (r3dm_extract_features_batch, r3dm_multi_extract_features*): called once per COMPUTED image
  * (not for skipped ones), from the thread that computed it, after its two files are written.  desc_device = n_features x 144 floats

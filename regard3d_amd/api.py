@@ -26,7 +26,7 @@ EXPORTS = [
     "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_stage_create", "r3dm_stage_run", "r3dm_stage_destroy", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
     "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
-    "r3dm_filter_FEH", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
+    "r3dm_filter_FEH", "r3dm_host_threads", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_transfer_counts", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",

@@ -271,6 +271,9 @@ extern "C" int r3dm_set_image(r3dm_ctx* c, uint32_t view_id, uint32_t width, uin
     return r3dm_guarded(c, [&]() -> int { return r3dm_set_image_impl(c, view_id, width, height, desc, n, dim, dtype, xy); });
 }
 
+// the size of a helper team of host threads that fits the cores this process may use (affinity mask and cgroup CPU quota), at most `want`
+extern "C" int r3dm_host_threads(int want) { return r3dm_host_team(want > 0 ? want : 1, 1); }
+
 extern "C" int r3dm_clear_images(r3dm_ctx* c)
 {
     if (!c) return R3DM_ERR_INVALID;

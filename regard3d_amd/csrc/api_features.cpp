@@ -779,12 +779,14 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     first[B] = n_total;
     std::vector<float> kps(4 * n_total), M6(6 * n_total);
     std::vector<uint32_t> img_of(n_total);
+    const int host_team = r3dm_host_team(8);                 // helper threads of this batch: bounded by the cores the process really owns
+    (void)host_team;
     // angle (atan2f of the host libm, as the reference) and LIOP patch map of every keypoint: a few host threads share the loop
     for (uint32_t b = 0; b < B; ++b) {
         const long nk = (long)bo.recs[b].size();
         const AkKpRec* recs = bo.recs[b].data();
         const size_t f0 = first[b];
-#pragma omp parallel for schedule(static) num_threads(8) if (nk > 4096)
+#pragma omp parallel for schedule(static) num_threads(host_team) if (nk > 4096)
         for (long k = 0; k < nk; ++k) {
             const AkKpRec& r = recs[k];
             const size_t g = f0 + (size_t)k;
@@ -836,7 +838,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     std::vector<int> wrc(B, R3DM_OK);
     std::vector<std::string> werr(B);
     if (to_files) {
-#pragma omp parallel for schedule(dynamic) num_threads(8) if (B > 1)
+#pragma omp parallel for schedule(dynamic) num_threads(host_team) if (B > 1)
         for (long b = 0; b < (long)B; ++b) {
             if (!feat_paths[b] || !desc_paths[b]) continue;
             const uint32_t n = (uint32_t)bo.recs[b].size();

@@ -376,7 +376,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         if (vi % 64 == 0) {
             const size_t cn = std::min<size_t>(64, views_.size() - vi);
             chunk.assign(cn, Loaded());
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(r3dm_host_threads(64))
             for (long k = 0; k < (long)cn; ++k) {
                 const View& u = views_[vi + (size_t)k];
                 Loaded& L = chunk[(size_t)k];

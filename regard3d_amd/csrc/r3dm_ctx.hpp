@@ -7,8 +7,10 @@
 
 #include "r3dm_internal.hpp"
 
+#include <sched.h>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +28,37 @@ using namespace r3dm;
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
+
+// How many host threads a helper team of this library may start: the cores this process may actually use -- the affinity mask AND the
+// cgroup CPU quota (a container with `cpu.max = 1600000 100000` sees 256 processors and owns 16: a burst of more runnable threads than
+// that is throttled until the end of the 100 ms period, which showed as random 60-100 ms stalls of the stage's main thread) -- divided
+// among the workers that may run such a team at the same time, at most `want`.
+inline int r3dm_host_team(int want, int concurrent_teams = 2)
+{
+    static const int cores = [] {
+        int n = (int)std::thread::hardware_concurrency();
+        if (n < 1) n = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a >= 1 && a < n) n = a; }
+        for (const char* path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+            if (FILE* f = fopen(path, "r")) {
+                char a[64] = {0}, b[64] = {0};
+                const int got = fscanf(f, "%63s %63s", a, b);
+                fclose(f);
+                if (got >= 1 && a[0] >= '0' && a[0] <= '9') {
+                    double quota = atof(a), period = got >= 2 ? atof(b) : 100000.0;
+                    if (got < 2) if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%63s", b) == 1) period = atof(b); fclose(g); }
+                    if (quota > 0 && period > 0) { const int q = (int)(quota / period); if (q >= 1 && q < n) n = q; }
+                }
+                break;
+            }
+        }
+        return n;
+    }();
+    int t = cores / (2 * (concurrent_teams > 0 ? concurrent_teams : 1));       // half of the cores for the teams: the rest runs workers, writers, the runtime
+    if (t > want) t = want;
+    return t < 1 ? 1 : t;
+}
 
 struct DevBuf {
     void* p = nullptr;
