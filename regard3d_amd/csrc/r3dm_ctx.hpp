@@ -55,7 +55,7 @@ inline int r3dm_host_team(int want, int concurrent_teams = 2)
         }
         return n;
     }();
-    int t = cores / (2 * (concurrent_teams > 0 ? concurrent_teams : 1));       // half of the cores for the teams: the rest runs workers, writers, the runtime
+    int t = (cores - 4) / (concurrent_teams > 0 ? concurrent_teams : 1);       // four cores stay free for the main thread, writers and the runtime's own threads
     if (t > want) t = want;
     return t < 1 ? 1 : t;
 }
