@@ -495,7 +495,8 @@ int r3dm_get_features_totals(const r3dm_ctx* ctx, r3dm_features_totals* out);
 int r3dm_host_threads(int want);
 
 /* A sink for the features entry points (r3dm_extract_features_batch, r3dm_multi_extract_features*): called once per COMPUTED image
- * (not for skipped ones), from the thread that computed it, after its two files are written.  desc_device = n_features x 144 floats
+ * (not for skipped ones), from a helper thread of the library (several images of a batch may arrive concurrently: the sink must be
+ * thread-safe), after the image's two files are written.  desc_device = n_features x 144 floats
  * in DEVICE memory of the computing context (valid until the sink returns); xy_as_written = n_features x 2 floats exactly as a reader
  * of the .feat file parses them (the file holds 6 significant digits).  What Regions_Provider::load would read back from the files
  * (src/R3DComputeMatches.cpp:2040) is thus handed over without the round trip through the file system and the PCIe bus: the facade

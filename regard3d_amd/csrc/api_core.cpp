@@ -203,8 +203,12 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         std::vector<uint32_t> canon(n);
         bool dup = false;
         {
-            std::unordered_map<uint64_t, uint32_t> first;
-            first.reserve((size_t)n * 2);
+            // open addressing, linear probing, table of >= 2 n slots: a slot holds the first feature index seen at a position
+            uint32_t bits = 4;
+            while ((1u << bits) < 2u * n) ++bits;
+            const uint32_t mask = (1u << bits) - 1u;
+            std::vector<uint64_t> keys((size_t)1 << bits);
+            std::vector<uint32_t> vals((size_t)1 << bits, 0xFFFFFFFFu);
             for (uint32_t k = 0; k < n; ++k) {
                 const float fx = hxy[2 * (size_t)k], fy = hxy[2 * (size_t)k + 1];
                 canon[k] = k;
@@ -212,8 +216,11 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
                 uint32_t bx, by;
                 const float zx = fx == 0.0f ? 0.0f : fx, zy = fy == 0.0f ? 0.0f : fy;
                 std::memcpy(&bx, &zx, 4); std::memcpy(&by, &zy, 4);
-                auto it = first.emplace(((uint64_t)bx << 32) | by, k);
-                if (!it.second) { canon[k] = it.first->second; dup = true; }  // ascending k: the stored index is the smallest of the class
+                const uint64_t key = ((uint64_t)bx << 32) | by;
+                uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - bits)) & mask;
+                while (vals[slot] != 0xFFFFFFFFu && keys[slot] != key) slot = (slot + 1u) & mask;
+                if (vals[slot] == 0xFFFFFFFFu) { keys[slot] = key; vals[slot] = k; }
+                else { canon[k] = vals[slot]; dup = true; }                   // ascending k: the stored index is the smallest of the class
             }
         }
         if (dup) {

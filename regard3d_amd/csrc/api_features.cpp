@@ -830,46 +830,43 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     }
     c->stats.ms_liop_wall = now_ms() - t_liop;
     const double t_io = now_ms();
-    double ms_sink = 0.0;
     // the files of the B images are formatted and written by up to 8 host threads (28 k keypoints = 113 k decimal conversions and
     // 16 MB per image); the sink then sees the images in batch order from this thread
     const bool to_files = feat_paths && desc_paths;
-    std::vector<std::vector<float>> xy_written(B);
     std::vector<int> wrc(B, R3DM_OK);
     std::vector<std::string> werr(B);
     if (to_files) {
+        // ... and each thread hands its image to the sink (if any) as soon as its files are written: the sink of the facade registers the
+        // view with the matcher (position classes, device-to-device copy, re-layout kernels) while the other threads still format theirs.
+        // The descriptors of the batch are still in liop_out (this context's stream is idle: the copy above was waited for).
 #pragma omp parallel for schedule(dynamic) num_threads(host_team) if (B > 1)
         for (long b = 0; b < (long)B; ++b) {
             if (!feat_paths[b] || !desc_paths[b]) continue;
             const uint32_t n = (uint32_t)bo.recs[b].size();
             try {                                                   // nothing may leave an OpenMP region by exception
-                if (c->feat_sink) xy_written[b].resize((size_t)n * 2 + 2);
+                std::vector<float> xy_written;
+                if (c->feat_sink) xy_written.resize((size_t)n * 2 + 2);
                 std::string e;
                 wrc[b] = write_feat_desc(e, feat_paths[b], desc_paths[b], kps.data() + 4 * first[b], desc_host ? desc_host + 144 * first[b] : nullptr, n,
-                                         c->feat_sink ? xy_written[b].data() : nullptr);
+                                         c->feat_sink ? xy_written.data() : nullptr);
                 werr[b] = e;
+                if (wrc[b] == R3DM_OK && c->feat_sink) {
+                    const uint32_t id = c->feat_sink_ids ? c->feat_sink_ids[b] : (uint32_t)b;
+                    const int src = c->feat_sink(c->feat_sink_user, id, n, n ? c->liop_out.as<float>() + 144 * first[b] : nullptr, xy_written.data());
+                    if (src != 0) { wrc[b] = R3DM_ERR_INVALID; werr[b] = "the features sink refused image " + std::to_string(id); }
+                }
             } catch (...) { wrc[b] = R3DM_ERR_NOMEM; }
         }
+        (void)hipSetDevice(c->device);                         // a sink may have worked on another device from this thread
     }
     for (uint32_t b = 0; b < B; ++b) {
         const uint32_t n = (uint32_t)bo.recs[b].size();
-        if (to_files && feat_paths[b] && desc_paths[b]) {
-            if (wrc[b] != R3DM_OK) { c->err = werr[b].empty() ? "out of host memory" : werr[b]; return wrc[b]; }
-            if (c->feat_sink) {
-                // the descriptors of the batch are still in liop_out (this context's stream is idle: the copy above was waited for)
-                const double t_s = now_ms();
-                const int src = c->feat_sink(c->feat_sink_user, c->feat_sink_ids ? c->feat_sink_ids[b] : b, n,
-                                             n ? c->liop_out.as<float>() + 144 * first[b] : nullptr, xy_written[b].data());
-                ms_sink += now_ms() - t_s;
-                (void)hipSetDevice(c->device);                 // the sink may have worked on another device from this thread
-                if (src != 0) { c->err = "the features sink refused image " + std::to_string(c->feat_sink_ids ? c->feat_sink_ids[b] : b); return R3DM_ERR_INVALID; }
-            }
-        }
+        if (to_files && feat_paths[b] && desc_paths[b] && wrc[b] != R3DM_OK) { c->err = werr[b].empty() ? "out of host memory" : werr[b]; return wrc[b]; }
         if (n_features) n_features[b] = n;
         if (kps_out) (*kps_out)[b].assign(kps.begin() + 4 * first[b], kps.begin() + 4 * first[b + 1]);
         if (desc_out) { if (n) (*desc_out)[b].assign(desc_host + 144 * first[b], desc_host + 144 * first[b + 1]); else (*desc_out)[b].clear(); }
     }
-    c->stats.ms_feature_files = now_ms() - t_io - ms_sink;
+    c->stats.ms_feature_files = now_ms() - t_io;            // (the sink's time included)
     c->feat_totals.ms_liop_kernels += n_total ? c->stats.ms_liop_kernel : 0.0;
     c->feat_totals.ms_wall += c->stats.ms_liop_wall + c->stats.ms_feature_files;
     c->feat_totals.ms_files += c->stats.ms_feature_files;
