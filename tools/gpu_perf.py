@@ -50,6 +50,9 @@ for rep in range(a.reps):
         t = time.time(); gh = c.filter_H(g); th = time.time() - t; sh = c.stats()
         print(json.dumps(dict(rep=rep, t_filter_E=te, ms_E_kernel=se.ms_filter_kernels, e_pairs=ge.num_pairs, e_matches=ge.num_matches,
                               t_filter_H=th, ms_H_kernel=sh.ms_filter_kernels, h_pairs=gh.num_pairs)), flush=True)
+        t = time.time(); feh, msk, msw = c.filter_FEH(g, "FEH"); tf = time.time() - t
+        print(json.dumps(dict(rep=rep, side_by_side="r3dm_filter_FEH", wall_ms=tf * 1e3, kernels_ms_F_E_H=msk.tolist(),
+                              same_graphs=bool(np.array_equal(feh["E"].matches, ge.matches) and np.array_equal(feh["H"].matches, gh.matches)))), flush=True)
 if a.check:
     from oracle import pyoracle as O
     sub = pairs[: a.check]
