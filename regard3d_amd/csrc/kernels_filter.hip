@@ -750,7 +750,7 @@ template <int KIND> struct ChunkOf { static constexpr int n = (KIND == 2) ? kE5S
 // residual histogram of the model under evaluation (the sort-skipping bound below): 2^kHistSub bins per octave of the residual,
 // kHistBins bins down from the bound on the residuals; LDS header = FState (padded to 1024) + the histogram
 constexpr int kHistBins = 1024, kHistSub = 5, kHistShift = 52 - kHistSub;
-constexpr int kHdr = 1024 + kHistBins * 4 + kHistBins * 8;          // FState | histogram | per-bin log term of the bound (doubles)
+constexpr int kHdr = 1024 + kHistBins * 4;
 
 #ifdef R3DM_FILTER_ONLY_E
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind);
@@ -942,7 +942,6 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     constexpr int MS = (KIND == 2) ? 90 : 27;                  // doubles per hypothesis: 9 x MAX_MODELS (27 also for H)
     double* Fs = reinterpret_cast<double*>(smem + kHdr);                                   // [64][MS]
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + 1024);                             // [kHistBins]
-    double* la_bin = reinterpret_cast<double*>(smem + 1024 + kHistBins * 4);               // [kHistBins] logalpha term of a bin's lower edge
 
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);    // Kernel::MINIMUM_SAMPLES
     constexpr double MAXM = (KIND == 0) ? 3.0 : (KIND == 1 ? 1.0 : 10.0); // Kernel::MAX_MODELS
@@ -1207,30 +1206,17 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 #pragma unroll
                     for (int j = 0; j < kHistBins / NT; ++j) hist[tid * (kHistBins / NT) + j] = excl + cb[j];
                     wg_sync_t<SPILL>();
-                    // the log term of every non-empty bin once (bins tid, tid + NT, ...), then the k = SS + 1 .. total in equal shares:
-                    // a good model packs thousands of residuals into a few bins, whose owners used to walk them alone
+                    // bins tid, tid + 256, ...: neighbouring (equally dense) bins go to different threads
                     double wmin = __builtin_huge_val();
 #pragma unroll
                     for (int j = 0; j < kHistBins / NT; ++j) {
                         const uint32_t b = tid + (uint32_t)NT * (uint32_t)j;
                         const uint32_t k_hi = hist[b], k_prev = b ? hist[b - 1] : 0u;
-                        if (k_hi > k_prev) {
+                        uint32_t k_lo = k_prev + 1u; if (k_lo < SS + 1u) k_lo = SS + 1u;
+                        if (k_hi >= k_lo) {
                             const double edge = b ? __longlong_as_double(((long long)b + hist_base) << kHistShift) : 0.0;
-                            la_bin[b] = logalpha0 + MULT_ERR * log10(edge + FLT_EPS_D);
-                        }
-                    }
-                    r3dm_syncthreads();
-                    {
-                        const uint32_t per = (total - SS + (uint32_t)NT - 1u) / (uint32_t)NT;       // total > SS here
-                        const uint32_t kk_beg = SS + 1u + tid * per;
-                        uint32_t kk_end = kk_beg + per - 1u; if (kk_end > total) kk_end = total;
-                        if (kk_beg <= kk_end) {
-                            uint32_t lo = 0, hi = kHistBins - 1;                  // first bin whose running count reaches kk_beg
-                            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (hist[mid] >= kk_beg) hi = mid; else lo = mid + 1; }
-                            uint32_t b = lo, b_hi = hist[b];
-                            double la = la_bin[b];
-                            for (uint32_t kk = kk_beg; kk <= kk_end; ++kk) {
-                                if (kk > b_hi) { do { ++b; b_hi = hist[b]; } while (kk > b_hi); la = la_bin[b]; }
+                            const double la = logalpha0 + MULT_ERR * log10(edge + FLT_EPS_D);
+                            for (uint32_t kk = k_lo; kk <= k_hi; ++kk) {
                                 const double w = loge0 + la * (double)(kk - SS) + (double)logc_n[kk] + (double)P.logc_k[kk];
                                 wmin = w < wmin ? w : wmin;
                             }
