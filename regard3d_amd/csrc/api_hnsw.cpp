@@ -143,7 +143,7 @@ static int ensure_hnsw_indices(r3dm_ctx* c, std::vector<uint32_t> slots, const r
 static HnswView view_of(const HostImage& h)
 {
     HnswView v{};
-    v.rows = h.rows.as<float>(); v.l0 = h.hnsw_l0.as<int32_t>(); v.up_off = h.hnsw_up_off.as<int32_t>(); v.up = h.hnsw_up.as<int32_t>();
+    v.rows = h.rows.as<float>(); v.rows8 = h.compact_ready ? h.ann_rows8.as<uint8_t>() : nullptr; v.l0 = h.hnsw_l0.as<int32_t>(); v.up_off = h.hnsw_up_off.as<int32_t>(); v.up = h.hnsw_up.as<int32_t>();
     v.n = h.n; v.dim = h.dim; v.M = h.hnsw_M; v.enter = h.hnsw_enter; v.maxlevel = h.hnsw_maxlevel;
     return v;
 }
@@ -166,12 +166,14 @@ static int run_hnsw_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float r
     const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));
     std::vector<uint2> hp(P);
     std::vector<HnswSearchJob> sj(P);
+    bool rows8 = true;                                        // every index view of the batch holds its byte rows (integers 0 .. 255: SIFT bins)
     for (uint32_t p = 0; p < P; ++p) {
         hp[p] = make_uint2(jobs[p].sI, jobs[p].sJ);
         sj[p].ix = view_of(*c->imgs[jobs[p].sI]);
         sj[p].query = c->imgs[jobs[p].sJ]->rows.as<float>();
         sj[p].nq = c->imgs[jobs[p].sJ]->n;
         sj[p].out_base = p * q_stride;
+        rows8 = rows8 && sj[p].ix.rows8 != nullptr;
     }
     R3DM_HIP(c, c->d_pairs.ensure(sizeof(uint2) * P));
     R3DM_HIP(c, c->h_jobs.ensure(sizeof(HnswSearchJob) * P));
@@ -188,6 +190,7 @@ static int run_hnsw_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float r
     sp.jobs = c->h_jobs.as<HnswSearchJob>(); sp.n_jobs = P;
     sp.ef = std::max(ef, 2u);                                  // searchKnn: max(ef_, k)
     sp.ratio_R = ratio_R;
+    sp.rows8 = rows8 ? 1u : 0u;
     sp.nn_idx = c->d_nn.as<uint32_t>();
     sp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
     sp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;
@@ -220,6 +223,7 @@ static int run_hnsw_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float r
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_ann_search += ms;
     c->stats.n_ann_dist += comps;
+    c->stats.n_ann_rows8 += rows8 ? 1 : 0;
     c->stats.n_match_launches += 1;
     c->stats.n_pairs += P;
     c->stats.n_queries += n_queries;

@@ -61,12 +61,13 @@ __device__ __forceinline__ void hn_pop(HnPair* v, uint32_t& n)
 }
 
 // accumulator l (= lane & 7) of L2SqrSIMD16Ext over one row: acc_l = sum_i (a[8i + l] - b[8i + l])^2 in increasing i
-template <int NB>
-__device__ __forceinline__ float hn_acc(const float (&q)[NB], const float* __restrict__ row, uint32_t l)
+// ROW = float or uint8_t (byte rows of integer-valued views: the conversion is exact, so the sum is the same float)
+template <int NB, typename ROW>
+__device__ __forceinline__ float hn_acc(const float (&q)[NB], const ROW* __restrict__ row, uint32_t l)
 {
     float x[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) x[i] = row[8 * i + l];
+    for (int i = 0; i < NB; ++i) x[i] = (float)row[8 * i + l];
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < NB; ++i) { const float t = q[i] - x[i]; acc = acc + t * t; }
@@ -89,8 +90,8 @@ __device__ __forceinline__ void hn_load_q(float (&q)[NB], const float* __restric
 }
 
 // distances from the row in q to the `size` rows ids[0 .. size): dist[j] (LDS) for every j; skip[j] != 0 leaves dist[j] unset
-template <int NB, typename SKIP>
-__device__ __forceinline__ void hn_dist_list(const float (&q)[NB], const float* __restrict__ rows, uint32_t dim, const int32_t* ids, uint32_t size,
+template <int NB, typename ROW, typename SKIP>
+__device__ __forceinline__ void hn_dist_list(const float (&q)[NB], const ROW* __restrict__ rows, uint32_t dim, const int32_t* ids, uint32_t size,
                                              float* dist, uint32_t lane, SKIP skip)
 {
     const uint32_t g = lane >> 3, l = lane & 7u;
@@ -100,14 +101,14 @@ __device__ __forceinline__ void hn_dist_list(const float (&q)[NB], const float* 
         const uint32_t c = on ? (uint32_t)ids[j] : 0u;
         const bool work = on && !skip(c);
         float acc = 0.f;
-        if (work) acc = hn_acc<NB>(q, rows + (size_t)c * dim, l);
+        if (work) acc = hn_acc<NB, ROW>(q, rows + (size_t)c * dim, l);
         const float d = hn_hsum8(acc, lane);
         if (work && l == 0) dist[j] = d;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------ search
-template <int NB>
+template <int NB, typename ROW>
 __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams P)
 {
     extern __shared__ unsigned char hn_smem[];
@@ -125,6 +126,7 @@ __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams
     if (qi >= job.nq) return;                                            // (no workgroup barrier below)
     const HnswView ix = job.ix;
     const uint32_t dim = ix.dim, M = ix.M, l = lane & 7u;
+    const ROW* __restrict__ xrows = sizeof(ROW) == 1 ? reinterpret_cast<const ROW*>(ix.rows8) : reinterpret_cast<const ROW*>(ix.rows);
     const size_t o = (size_t)job.out_base + qi;
 
     float q[NB];
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams
     unsigned long long evals = 1;
 
     uint32_t cur = (uint32_t)ix.enter;
-    float curdist = hn_hsum8(hn_acc<NB>(q, ix.rows + (size_t)cur * dim, l), lane);
+    float curdist = hn_hsum8(hn_acc<NB, ROW>(q, xrows + (size_t)cur * dim, l), lane);
     curdist = __shfl(curdist, 0);
     // greedy descent (hnswalg.h:745-768): the list is walked in order, every strictly closer row takes over
     for (int level = ix.maxlevel; level > 0; --level) {
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams
             changed = false;
             const int32_t* L = ix.up + ((size_t)ix.up_off[cur] + (uint32_t)(level - 1)) * (1 + M);
             const uint32_t size = (uint32_t)L[0];
-            hn_dist_list<NB>(q, ix.rows, dim, L + 1, size, dist, lane, [](uint32_t) { return false; });
+            hn_dist_list<NB, ROW>(q, xrows, dim, L + 1, size, dist, lane, [](uint32_t) { return false; });
             HN_SYNC();
             evals += size;
             for (uint32_t j = 0; j < size; ++j) {
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams
         HN_SYNC();
         if (lane < size) ids[lane] = L[1 + lane];                       // 2M <= 64 links
         HN_SYNC();
-        hn_dist_list<NB>(q, ix.rows, dim, ids, size, dist, lane, [&](uint32_t c) { return ((visited[c >> 5] >> (c & 31u)) & 1u) != 0; });
+        hn_dist_list<NB, ROW>(q, xrows, dim, ids, size, dist, lane, [&](uint32_t c) { return ((visited[c >> 5] >> (c & 31u)) & 1u) != 0; });
         HN_SYNC();
         for (uint32_t j = 0; j < size; ++j) {
             const uint32_t c = (uint32_t)ids[j];
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(256) hnsw_link_kernel(const HnswBuildParams P)
         hn_load_q<NB>(q, job.rows + (size_t)node * dim, l);
         nc = min(job.adj_deg[node], 64u);
         const int32_t* ids = reinterpret_cast<const int32_t*>(job.adj + (size_t)node * kAnnDeg);
-        hn_dist_list<NB>(q, job.rows, dim, ids, nc, dist, lane, [](uint32_t) { return false; });
+        hn_dist_list<NB, float>(q, job.rows, dim, ids, nc, dist, lane, [](uint32_t) { return false; });
         HN_SYNC();
         const unsigned long long mine = lane < nc ? hn_key(dist[lane], (uint32_t)ids[lane]) : ~0ull;
         key[lane] = mine;
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256) hnsw_link_kernel(const HnswBuildParams P)
             const uint32_t c = on ? mem[b] : node;
             const bool work = on && c != node;
             float acc = 0.f;
-            if (work) acc = hn_acc<NB>(q, job.rows + (size_t)c * dim, l);
+            if (work) acc = hn_acc<NB, float>(q, job.rows + (size_t)c * dim, l);
             const float d = hn_hsum8(acc, lane);
             const unsigned long long e_mine = work ? hn_key(d, c) : ~0ull;
             for (uint32_t gg = 0; gg < 8; ++gg) {
@@ -352,14 +354,15 @@ hipError_t launch_hnsw_search(hipStream_t st, const HnswSearchParams& Pin, uint3
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((max_nq + 3) / 4, P.n_jobs);
     if (P.n_jobs > 65535u) return hipErrorInvalidValue;
-#define R3DM_HNSW_SEARCH(NB)                                                                                            \
+#define R3DM_HNSW_SEARCH_T(NB, ROW)                                                                                     \
     do {                                                                                                               \
         if (lds > 64 * 1024) {                                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)hnsw_search_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e = hipFuncSetAttribute((const void*)hnsw_search_kernel<NB, ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((hnsw_search_kernel<NB>), grid, dim3(256), lds, st, P);                                      \
+        hipLaunchKernelGGL((hnsw_search_kernel<NB, ROW>), grid, dim3(256), lds, st, P);                                 \
     } while (0)
+#define R3DM_HNSW_SEARCH(NB) do { if (P.rows8) R3DM_HNSW_SEARCH_T(NB, uint8_t); else R3DM_HNSW_SEARCH_T(NB, float); } while (0)
     switch (dim) {
         case 64:  R3DM_HNSW_SEARCH(8); break;
         case 128: R3DM_HNSW_SEARCH(16); break;
@@ -368,6 +371,7 @@ hipError_t launch_hnsw_search(hipStream_t st, const HnswSearchParams& Pin, uint3
         default: return hipErrorInvalidValue;
     }
 #undef R3DM_HNSW_SEARCH
+#undef R3DM_HNSW_SEARCH_T
     return hipGetLastError();
 }
 

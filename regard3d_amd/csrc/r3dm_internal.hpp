@@ -117,6 +117,7 @@ struct AnnSearchParams {
 // ---- HNSW plugin path (kernels_hnsw.hip): an index is three arrays in hnswlib's own shape
 struct HnswView {
     const float*   rows;          // [n][dim] f32, row-major
+    const uint8_t* rows8;         // the same rows as bytes when every element is an integer 0 .. 255 (ImgDev::ann_rows8), else nullptr
     const int32_t* l0;            // [n][1 + 2M]: count, links (farthest first, -1 padded)
     const int32_t* up_off;        // [n + 1]: first upper-layer row of a node (layer L of node i: row up_off[i] + L - 1)
     const int32_t* up;            // [rows][1 + M]
@@ -132,6 +133,7 @@ struct HnswSearchJob {
 struct HnswSearchParams {
     const HnswSearchJob* jobs;
     uint32_t n_jobs, ef, cand_cap, flag_words;
+    uint32_t rows8;               // != 0: every job's index view holds its byte rows; the search gathers those (a quarter of the bytes, the same float values)
     float    ratio_R;
     uint32_t* nn_idx;
     int32_t*  knn_idx;            // optional
