@@ -176,3 +176,20 @@ def test_corrupt_match_and_descriptor_files_fail_cleanly(tmp_path):
         with pytest.raises(api.R3dmError):
             api.Graph.load(str(p))
     assert api.Graph.load(str(good)).num_matches == len(MATCHES)
+
+
+def test_host_thread_budget_respects_the_cores_the_process_owns():
+    """r3dm_host_threads (include/r3dm.h): at least 1, at most what was asked for, and never more than the affinity mask / the cgroup
+    CPU quota leave; bench.py's host_cores() reads the same sources"""
+    import ctypes as C
+    from regard3d_amd import api
+    L = api.load_library()
+    L.r3dm_host_threads.argtypes = [C.c_int]; L.r3dm_host_threads.restype = C.c_int
+    assert L.r3dm_host_threads(1) == 1 and L.r3dm_host_threads(0) == 1
+    t = L.r3dm_host_threads(64)
+    assert 1 <= t <= 64 and t <= len(os.sched_getaffinity(0))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    cores, seen = bench.host_cores()
+    assert 1 <= cores <= seen and t <= max(1, cores)
