@@ -288,7 +288,8 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
                 float* Lti = Lt(i) + po; float* lt2i = lt2 + po; float* tmpi = tmp + po; float* smoothi = smooth + po; float* flowi = flow + po;
                 // FED launches of this level: one step per launch on the large levels, up to four steps per launch where a step is
                 // mostly launch latency or the planes thrash the Infinity Cache (<= 3.2 Mpx per image: from the second octave of a 12 Mpx image on; R3DM_AK_FED_MULTI=0 in the developer build keeps one step per launch)
-                static const int multi_px = r3dm_dev_knob("R3DM_AK_FED_MULTI", 1) ? 3200000 : 0;
+                static const int multi_knob = r3dm_dev_knob("R3DM_AK_FED_MULTI", 1);      // developer build: 0 = never, 1 = the product, > 1 = that many pixels
+                static const int multi_px = multi_knob > 1 ? multi_knob : (multi_knob ? 3200000 : 0);
                 const size_t per = n <= (size_t)multi_px ? 4 : 1;
                 const size_t n_launch = (tau.size() + per - 1) / per;
                 const float* start = nullptr;
