@@ -138,11 +138,17 @@ template <bool TIE_PASS>
 __global__ __launch_bounds__(64)
 void liop_kernel(const LiopParams P)
 {
-    __shared__ __attribute__((aligned(16))) float patch[kLiopPix + 3 + 128];   // (+ slack: the patch is loaded in float4 pieces)
+    // the patch -- and, in the second pass, over the same bytes, the arrays of the reference's quick sort (the patch is not needed while
+    // they are: it is read again from global memory behind the sort)
+    constexpr int kPatchFloats = kLiopPix + 3 + 128;                                 // (+ slack: the patch is loaded in float4 pieces)
+    constexpr int kQBytes = (kLiopMaxPix + 4) * 8 + (2 * kLiopMaxPix + 8) * 2;
+    constexpr int kRegionBytes = (TIE_PASS && kQBytes > kPatchFloats * 4) ? kQBytes : kPatchFloats * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char region[kRegionBytes];
+    float* patch = reinterpret_cast<float*>(region);
+    uint2* qarr = reinterpret_cast<uint2*>(region);                                   // exact re-sort: (intensity bits, position)
+    uint16_t* qstack = reinterpret_cast<uint16_t*>(region + (kLiopMaxPix + 4) * 8);
     __shared__ float inten[kLiopSortCap];            // intensities in scan order (for the exact re-sort)
     __shared__ uint16_t perm[kLiopSortCap];
-    __shared__ uint2 qarr[TIE_PASS ? kLiopMaxPix + 4 : 1];          // exact re-sort of patches with equal intensities: (intensity bits, position)
-    __shared__ uint16_t qstack[TIE_PASS ? 2 * kLiopMaxPix + 8 : 1];
     __shared__ uint32_t hist[144];
     __shared__ float s_norm;
 
@@ -205,6 +211,8 @@ void liop_kernel(const LiopParams P)
                 if (lane == 0) liop_ref_qsort(qarr, (int)N, qstack);
                 r3dm_syncthreads();
                 for (uint32_t i = lane; i < N; i += 64) perm[i] = (uint16_t)qarr[i].y;
+                r3dm_syncthreads();
+                for (uint32_t e = lane; e < (uint32_t)kLiopPix; e += 64) patch[e] = src[e];      // the sort's arrays lay over the patch
                 r3dm_syncthreads();
             }
         }
