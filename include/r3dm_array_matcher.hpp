@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "r3dm.h"
+#include "r3dm_context_pool.hpp"     // detail::ContextPool / ContextLease (shared with regard3d_features.hpp)
 
 #ifdef R3DM_WITH_OPENMVG
 #include "openMVG/matching/indMatch.hpp"
@@ -61,70 +62,6 @@ template <typename Scalar> struct DefaultMetric { using ResultType = float; };
 #define R3DM_ARRAY_MATCHER_BASE(Scalar, Metric)
 #define R3DM_OVERRIDE
 #endif
-
-namespace detail {
-
-// Contexts of one device, shared by every adapter of the process.  Created on demand, never destroyed (a static destructor
-// would run after the HIP runtime's own teardown).
-class ContextPool {
-public:
-    static constexpr int kPoolSize = 4;
-    static ContextPool& of(int device)
-    {
-        static std::mutex mu;
-        static std::map<int, ContextPool*> pools;
-        std::lock_guard<std::mutex> lock(mu);
-        ContextPool*& p = pools[device];
-        if (!p) p = new ContextPool(device);
-        return *p;
-    }
-    r3dm_ctx* acquire()
-    {
-        std::unique_lock<std::mutex> lock(mu_);
-        for (;;) {
-            if (!free_.empty()) { r3dm_ctx* c = free_.back(); free_.pop_back(); return c; }
-            if (created_ < kPoolSize) {
-                r3dm_ctx* c = nullptr;
-                if (r3dm_create(device_, &c) == R3DM_OK) { ++created_; all_.push_back(c); return c; }
-                if (created_ == 0) return nullptr;             // no usable GPU: the adapter reports failure, it never falls back
-            }
-            cv_.wait(lock);
-        }
-    }
-    void release(r3dm_ctx* c)
-    {
-        { std::lock_guard<std::mutex> lock(mu_); free_.push_back(c); }
-        cv_.notify_one();
-    }
-    // copies + re-layouts made by all contexts of the pool (r3dm_stats.n_views_staged): Build = 1, every search = 1 (its queries)
-    uint64_t viewsStaged()
-    {
-        std::lock_guard<std::mutex> lock(mu_);
-        uint64_t n = 0;
-        for (r3dm_ctx* c : all_) { r3dm_stats s; if (r3dm_get_stats(c, &s) == R3DM_OK) n += s.n_views_staged; }
-        return n;
-    }
-    int created() { std::lock_guard<std::mutex> lock(mu_); return created_; }
-
-private:
-    explicit ContextPool(int device) : device_(device) {}
-    int device_;
-    int created_ = 0;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::vector<r3dm_ctx*> free_, all_;
-};
-
-struct ContextLease {
-    explicit ContextLease(ContextPool& p) : pool(p), ctx(p.acquire()) {}
-    ~ContextLease() { if (ctx) pool.release(ctx); }
-    ContextLease(const ContextLease&) = delete;
-    ContextLease& operator=(const ContextLease&) = delete;
-    ContextPool& pool;
-    r3dm_ctx* ctx;
-};
-
-}  // namespace detail
 
 template <typename Scalar = float, typename Metric = DefaultMetric<Scalar>>
 class ArrayMatcher_r3dm R3DM_ARRAY_MATCHER_BASE(Scalar, Metric) {

@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "r3d_compute_matches.hpp"
@@ -75,26 +77,58 @@ int main(int argc, char** argv)
         return 0;
     }
     if (!strcmp(argv[1], "features") && argc >= 6) {
-        // features <raw float32 gray image> <width> <height> <out.txt>: Regard3DFeatures::detectAndExtract on the GPU
+        // features <raw float32 gray image> <width> <height> <out.txt> [n_threads]: the reference's use of the feature face
+        // (src/threads/R3DFeaturesThread.cpp:58-77,123-210): initAKAZESemaphore(1), then the static, handle-free
+        // Regard3DFeatures::detectAndExtract(img, feats, descs, params) from n_threads (default CPUs + 1, at most 9) worker
+        // threads at once, uninitializeAKAZESemaphore().  Thread 0's result goes to out.txt; prints
+        // "<threads> <all results equal> <max detector calls in flight>".
+        using r3d_amd::Regard3DFeatures;
         const uint32_t w = (uint32_t)atoi(argv[3]), h = (uint32_t)atoi(argv[4]);
         std::vector<float> img((size_t)w * h);
         FILE* f = fopen(argv[2], "rb");
         if (!f || fread(img.data(), 4, img.size(), f) != img.size()) return 3;
         fclose(f);
-        r3dm_ctx* ctx = nullptr;
-        if (r3dm_create(0, &ctx) != R3DM_OK) { fprintf(stderr, "no gfx950 device\n"); return 7; }
-        r3d_amd::FeatsR3D feats; r3d_amd::DescsR3D descs;
-        r3d_amd::R3DFParams params;
-        const bool ok = r3d_amd::Regard3DFeatures::detectAndExtract(ctx, {img.data(), w, h}, feats, descs, params);
-        if (!ok) { fprintf(stderr, "detectAndExtract failed: %s\n", r3dm_last_error(ctx)); r3dm_destroy(ctx); return 7; }
+        int nthreads = argc >= 7 ? atoi(argv[6]) : (int)std::min(9u, std::thread::hardware_concurrency() + 1);
+        if (nthreads < 1) nthreads = 1;
+        const std::vector<std::string> listed = Regard3DFeatures::getKeypointDetectors();
+        if (listed.size() != 6 || listed[1] != "Fast-AKAZE" || Regard3DFeatures::getFeatureExtractors() != std::vector<std::string>{"LIOP"}) return 8;
+        if (!Regard3DFeatures::initAKAZESemaphore(1)) return 8;
+        Regard3DFeatures::resetMaxDetectorsInFlight();
+        std::vector<Regard3DFeatures::FeatsR3D> feats(nthreads); std::vector<Regard3DFeatures::DescsR3D> descs(nthreads);
+        std::vector<std::string> errors(nthreads);
+        std::vector<std::thread> workers;
+        for (int t = 0; t < nthreads; ++t)
+            workers.emplace_back([&, t] {
+                try {
+                    const r3d_amd::ImageViewF view(img.data(), w, h);
+                    Regard3DFeatures::R3DFParams params;          // keypointDetectorList_ = {"Fast-AKAZE"}, threshold_ = 0.001
+                    Regard3DFeatures::detectAndExtract(view, feats[t], descs[t], params);
+                } catch (const std::exception& e) { errors[t] = e.what(); }
+            });
+        for (std::thread& th : workers) th.join();
+        const int in_flight = Regard3DFeatures::maxDetectorsInFlight();
+        Regard3DFeatures::uninitializeAKAZESemaphore();
+        for (const std::string& e : errors) if (!e.empty()) { fprintf(stderr, "detectAndExtract failed: %s\n", e.c_str()); return 7; }
+        bool same = true;
+        for (int t = 1; t < nthreads; ++t)
+            same = same && feats[t].size() == feats[0].size() && descs[t] == descs[0] &&
+                   !memcmp(feats[t].data(), feats[0].data(), feats[0].size() * sizeof(r3d_amd::FeatureR3D));
+        // an unserved detector of the listed ones fails loudly, it never returns an empty result
+        bool threw = false;
+        try {
+            Regard3DFeatures::R3DFParams params; params.keypointDetectorList_ = {"MSER"};
+            Regard3DFeatures::FeatsR3D f2; Regard3DFeatures::DescsR3D d2;
+            Regard3DFeatures::detectAndExtract(r3d_amd::ImageViewF(img.data(), w, h), f2, d2, params);
+        } catch (const std::runtime_error&) { threw = true; }
+        if (!threw) return 9;
         FILE* o = fopen(argv[5], "w");
-        for (size_t k = 0; k < feats.size(); ++k) {
-            fprintf(o, "%.9g %.9g %.9g %.9g", feats[k].x, feats[k].y, feats[k].scale, feats[k].orientation);
-            for (float v : descs[k]) fprintf(o, " %.9g", v);
+        for (size_t k = 0; k < feats[0].size(); ++k) {
+            fprintf(o, "%.9g %.9g %.9g %.9g", feats[0][k].x, feats[0][k].y, feats[0][k].scale, feats[0][k].orientation);
+            for (float v : descs[0][k]) fprintf(o, " %.9g", v);
             fprintf(o, "\n");
         }
         fclose(o);
-        r3dm_destroy(ctx);
+        printf("%d %d %d\n", nthreads, same ? 1 : 0, in_flight);
         return 0;
     }
     if (!strcmp(argv[1], "stage") && argc >= 5) {

@@ -258,8 +258,10 @@ def test_features_facade_matches_oracle(host_exe, oracle, tmp_path):
     img = np.clip(img, 0, 1).astype(np.float32)
     raw = str(tmp_path / "img.f32"); out = str(tmp_path / "feats.txt")
     img.tofile(raw)
-    r = subprocess.run([host_exe, "features", raw, "560", "400", out], capture_output=True, text=True)
+    # the reference's signatures, from 5 worker threads at once under initAKAZESemaphore(1) (tests/cpp/adapter_main.cpp)
+    r = subprocess.run([host_exe, "features", raw, "560", "400", out, "5"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["5", "1", "1"]             # 5 threads, identical results, one detector call in flight at a time
     got = np.loadtxt(out, dtype=np.float64).astype(np.float32)
     okp = oracle.akaze_detect(img, 0.001)["kps"]
     odesc = oracle.liop_describe(oracle.liop_extract_patches(img, okp, 8.0))
