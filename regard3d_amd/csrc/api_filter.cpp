@@ -8,6 +8,9 @@
 #include <functional>
 #include <memory>
 
+// a device buffer that lives as long as the closure that captured it (the trace / check buffers of the developer build)
+struct SharedDevBuf { DevBuf b; ~SharedDevBuf() { b.release(); } };
+
 // ------------------------------------------------------------------------------------------------
 // geometric filter
 // ------------------------------------------------------------------------------------------------
@@ -93,6 +96,36 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         begin_end[2 * k] = putative->offsets[p];
         begin_end[2 * k + 1] = putative->offsets[p + 1];
     }
+    // ---- long pairs run on the cooperative kernel (kernels_filter_coop.hip): G workgroups per batch of models, slices of the match list.
+    // G follows the pair-length distribution: slices of 2048 .. 8192 matches, short enough that the long pairs of the call fill the
+    // device about one and a half times over; collections of short pairs (C2: every pair below the threshold) keep the one-workgroup
+    // kernel and its launch shape untouched.
+    const uint32_t coop_min = (uint32_t)r3dm_dev_knob("R3DM_FILTER_COOP_MIN", 4096);      // pairs with more putatives; 0 = never
+    const uint32_t coop_g_knob = (uint32_t)r3dm_dev_knob("R3DM_FILTER_COOP_G", 0);        // > 0: this many slices for every such pair
+    std::vector<unsigned char> is_coop(NI, 0);
+    std::vector<uint32_t> coop_items, coop_G, coop_slice, coop_hoff;
+    uint32_t max_m_short = 0, coop_slots = 0;
+    {
+        uint64_t sum_long = 0;
+        for (uint32_t k = 0; k < NI; ++k) {
+            const uint64_t mk = begin_end[2 * k + 1] - begin_end[2 * k];
+            if (coop_min && mk > coop_min && mk <= (uint64_t)kCoopMaxG * 65472u) { is_coop[k] = 1; sum_long += mk; }
+            else max_m_short = std::max<uint32_t>(max_m_short, (uint32_t)mk);
+        }
+        const uint64_t fill = std::max<uint64_t>(1, (uint64_t)std::max(c->n_cu, 1) * 3 / 2);
+        const uint32_t slice_target = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(2048, ((sum_long / fill + 511) / 512) * 512));
+        for (uint32_t k = 0; k < NI; ++k) {
+            if (!is_coop[k]) continue;
+            const uint32_t mk = (uint32_t)(begin_end[2 * k + 1] - begin_end[2 * k]);
+            uint32_t G = coop_g_knob ? coop_g_knob : (mk + slice_target - 1) / slice_target;
+            G = std::max<uint32_t>(G, (mk + 65471u) / 65472u);                              // a slice counts in 16 bits
+            G = std::min<uint32_t>(std::max<uint32_t>(G, 1u), kCoopMaxG);
+            const uint32_t len = (((mk + G - 1) / G + 63) / 64) * 64;
+            coop_items.push_back(k); coop_G.push_back(G); coop_slice.push_back(len); coop_hoff.push_back(coop_slots);
+            coop_slots += G;
+        }
+    }
+    const uint32_t n_coop = (uint32_t)coop_items.size();
     if (model_kind == 0 && err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { o.err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
     // host tables in the reference's own float arithmetic (glibc log10f), see kernels_filter.hip
     std::vector<float> l10(max_m + 2), lck(max_m + 2);
@@ -140,16 +173,16 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     // collections with long match lists (some pair above 4096 putatives: LDS admits one workgroup per CU anyway) run the 512-thread
     // variant of the kernel -- the same results, every pass over a pair's matches in half the trips
     const int wide_knob = r3dm_dev_knob("R3DM_FILTER_WIDE", -1);
-    fp.wide = wide_knob >= 0 ? (uint32_t)(wide_knob != 0) : (max_m > 4096 ? 1u : 0u);
-    fp.n_items = NI; fp.m_cap = std::min<uint32_t>((model_kind == 2 && !fp.wide) ? 4096 : 8192, std::max<uint32_t>(64, next_pow2(max_m)));
+    fp.wide = wide_knob >= 0 ? (uint32_t)(wide_knob != 0) : (max_m_short > 4096 ? 1u : 0u);
+    fp.n_items = NI; fp.m_cap = std::min<uint32_t>((model_kind == 2 && !fp.wide) ? 4096 : 8192, std::max<uint32_t>(64, next_pow2(std::max(max_m_short, 1u))));
     fp.spill_keys = nullptr; fp.spill_idx = nullptr; fp.spill_off = nullptr;
-    if (max_m > fp.m_cap) {
+    if (max_m_short > fp.m_cap || n_coop) {                  // (the cooperative kernel keeps every pair's sort lists in global memory)
         std::vector<uint64_t> soff(NI, 0);
         uint64_t tot = 0;
         for (uint32_t k = 0; k < NI; ++k) {
             const uint64_t mk = begin_end[2 * k + 1] - begin_end[2 * k];
             soff[k] = tot;
-            if (mk > fp.m_cap) tot += next_pow2((uint32_t)mk);
+            if (mk > fp.m_cap || is_coop[k]) tot += next_pow2((uint32_t)mk);
         }
         FHIP(B.f_spill.ensure(tot * 12 + NI * 8 + 64));
         unsigned char* base = B.f_spill.as<unsigned char>();
@@ -184,20 +217,75 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     {
         static const int lpt = r3dm_dev_knob("R3DM_FILTER_LPT", 1);
         fp.order = nullptr;
-        if (lpt && NI > 1) {
-            std::vector<uint32_t> order(NI);
-            std::iota(order.begin(), order.end(), 0u);
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        fp.n_short = NI - n_coop;
+        if ((lpt && NI > 1) || n_coop) {
+            std::vector<uint32_t> order;
+            order.reserve(NI);
+            for (uint32_t k = 0; k < NI; ++k) if (!is_coop[k]) order.push_back(k);
+            if (lpt) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
                 return begin_end[2 * a + 1] - begin_end[2 * a] > begin_end[2 * b + 1] - begin_end[2 * b]; });
             FHIP(B.f_order.ensure(4 * (size_t)NI));
-            FHIP(hipMemcpyAsync(B.f_order.p, order.data(), 4 * (size_t)NI, hipMemcpyHostToDevice, c->stream));
+            if (!order.empty()) FHIP(hipMemcpyAsync(B.f_order.p, order.data(), 4 * order.size(), hipMemcpyHostToDevice, c->stream));
             FHIP(hipStreamSynchronize(c->stream));       // `order` leaves scope
             fp.order = B.f_order.as<uint32_t>();
         }
     }
+    fp.n_coop = n_coop;
+    fp.coop_workers = 0;
+    if (n_coop) {
+        // one allocation: [items | G | slice | hoff] [queue] [state] [models] [batch matrices] [slice counts] [slope tables] [T*] [slice histograms]
+        auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+        uint32_t cap = 64; while (cap < coop_slots + n_coop + 1) cap <<= 1;
+        const size_t o_small = 0, small_bytes = up(16 * (size_t)n_coop);
+        const size_t o_q = o_small + small_bytes, q_bytes = up(4 * (8 + 2 * (size_t)cap));
+        const size_t o_state = o_q + q_bytes, state_bytes = up((size_t)n_coop * kCoopStateBytes);
+        const size_t o_models = o_state + state_bytes, models_bytes = up(8 * (size_t)n_coop * filter_coop_model_doubles(model_kind));
+        const size_t o_bm = o_models + models_bytes, bm_bytes = up(8 * (size_t)n_coop * kCoopB * 9);
+        const size_t o_cnt = o_bm + bm_bytes, cnt_bytes = up(4 * (size_t)coop_slots * kCoopB);
+        const size_t o_la = o_cnt + cnt_bytes, la_bytes = up(8 * (size_t)n_coop * 1024);
+        const size_t o_ts = o_la + la_bytes, ts_bytes = up(8 * (size_t)n_slice + 64);
+        const size_t o_hist = o_ts + ts_bytes, hist_bytes = up(4 * (size_t)coop_slots * kCoopB * 512);
+        FHIP(B.f_coop.ensure(o_hist + hist_bytes));
+        unsigned char* base = B.f_coop.as<unsigned char>();
+        uint32_t workers = 0;
+        for (uint32_t g : coop_G) workers += g;
+        const int workers_knob = r3dm_dev_knob("R3DM_FILTER_COOP_WORKERS", 0);
+        workers = workers_knob > 0 ? (uint32_t)workers_knob : std::min<uint32_t>(workers, (uint32_t)std::max(c->n_cu, 1));
+        std::vector<uint32_t> stage(small_bytes / 4 + q_bytes / 4, 0u);
+        memcpy(&stage[0], coop_items.data(), 4 * (size_t)n_coop);
+        memcpy(&stage[n_coop], coop_G.data(), 4 * (size_t)n_coop);
+        memcpy(&stage[2 * (size_t)n_coop], coop_slice.data(), 4 * (size_t)n_coop);
+        memcpy(&stage[3 * (size_t)n_coop], coop_hoff.data(), 4 * (size_t)n_coop);
+        uint32_t* q = &stage[small_bytes / 4];
+        q[0] = 0; q[1] = n_coop; q[2] = 0; q[3] = coop_slots; q[4] = workers; q[5] = n_coop; q[6] = cap - 1; q[7] = 0;
+        for (uint32_t i = 0; i < cap; ++i) q[8 + i] = i;                               // slot i is free for ticket i
+        // every pair starts with its start-up task, longest pair first
+        std::vector<uint32_t> by_len(n_coop);
+        std::iota(by_len.begin(), by_len.end(), 0u);
+        std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) {
+            const uint32_t ka = coop_items[a], kb = coop_items[b];
+            return begin_end[2 * ka + 1] - begin_end[2 * ka] > begin_end[2 * kb + 1] - begin_end[2 * kb]; });
+        for (uint32_t i = 0; i < n_coop; ++i) { q[8 + i] = i + 1; q[8 + cap + i] = (by_len[i] << 5) | 31u; }
+        FHIP(hipMemcpyAsync(base, stage.data(), 4 * stage.size(), hipMemcpyHostToDevice, c->stream));
+        FHIP(hipMemsetAsync(base + o_state, 0, state_bytes, c->stream));
+        FHIP(hipStreamSynchronize(c->stream));           // `stage` leaves scope
+        fp.coop_items = reinterpret_cast<const uint32_t*>(base);
+        fp.coop_G = fp.coop_items + n_coop; fp.coop_slice = fp.coop_items + 2 * (size_t)n_coop; fp.coop_hoff = fp.coop_items + 3 * (size_t)n_coop;
+        fp.coop_q = reinterpret_cast<uint32_t*>(base + o_q);
+        fp.coop_state = base + o_state;
+        fp.coop_models = reinterpret_cast<double*>(base + o_models);
+        fp.coop_bm = reinterpret_cast<double*>(base + o_bm);
+        fp.coop_cnt = reinterpret_cast<uint32_t*>(base + o_cnt);
+        fp.coop_la = reinterpret_cast<double*>(base + o_la);
+        fp.coop_tstar = reinterpret_cast<double*>(base + o_ts);
+        fp.coop_hist = reinterpret_cast<uint32_t*>(base + o_hist);
+        fp.coop_workers = workers;
+        if (filter_coop_lds_bytes(model_kind) > 160 * 1024) { o.err = "filter: LDS budget exceeded (cooperative kernel)"; return R3DM_ERR_UNSUPPORTED; }
+    }
     if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { o.err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
     // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
-    DevBuf trace_buf;
+    auto trace_own = std::make_shared<SharedDevBuf>();
+    DevBuf& trace_buf = trace_own->b;
     const uint32_t trace_cap = 16384;
     const char* tp = r3dm_dev_str("R3DM_TRACE_PAIR");
     const char* tf = r3dm_dev_str("R3DM_TRACE_FILE");
@@ -215,7 +303,8 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
             fp.trace_rows = trace_buf.as<uint32_t>();
         }
     }
-    DevBuf dbg_buf;
+    auto dbg_own = std::make_shared<SharedDevBuf>();
+    DevBuf& dbg_buf = dbg_own->b;
     fp.dbg = nullptr;
     if (r3dm_dev_knob("R3DM_FILTER_CHECK", 0)) {
         FHIP(dbg_buf.ensure(64));
@@ -223,6 +312,9 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         fp.dbg = dbg_buf.as<uint32_t>();
     }
     fp_out = fp;
+    // the host staging vectors above (slots, ids, begin_end, l10, lck, soff) were handed to asynchronous copies on the context's stream:
+    // they must not leave scope before the copies have read them
+    FHIP(hipStreamSynchronize(c->stream));
     r3dm_graph* graw = g.release();
     o.pending = graw;
     FilterBufs* const Bp = &B;
@@ -230,6 +322,8 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     std::unique_ptr<r3dm_graph> g(graw);
     o.pending = nullptr;
     FilterBufs& B = *Bp;                                   // (the context's buffer set itself, not a copy captured with the closure)
+    DevBuf& trace_buf = trace_own->b;                      // (released with the closure, whether or not it ever runs)
+    DevBuf& dbg_buf = dbg_own->b;
     if (fp.dbg) {                                          // developer build only
         uint32_t d[4] = {0, 0, 0, 0};
         hipError_t e = hipMemcpyAsync(d, fp.dbg, 16, hipMemcpyDeviceToHost, c->stream);
@@ -307,6 +401,34 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     return R3DM_OK;
 }
 
+// The kernels of one prepared filter on `st`, bracketed by (ev0, ev1): the cooperative kernel of the long pairs on the kind's second
+// stream (forked from and joined back into `st` with events, so that the bracket covers both), the one-workgroup-per-pair kernel of
+// the short ones on `st` itself.
+static int filter_enqueue(r3dm_ctx* c, FilterCallOut& o, const FilterParams& fp, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+{
+    FilterBufs& B = c->fb[fp.model_kind];
+    FHIP(hipEventRecord(ev0, st));
+    if (fp.n_coop) {
+        if (!B.stream2 || !B.ev2) {
+            hipStream_t s2 = nullptr; hipEvent_t e2 = nullptr;
+            int prio_low = 0, prio_high = 0;
+            FHIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+            const int prio = fp.model_kind == 2 ? prio_high : (fp.model_kind == 0 ? (prio_low + prio_high) / 2 : prio_low);
+            FHIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio));
+            const hipError_t e = hipEventCreate(&e2);
+            if (e != hipSuccess) { (void)hipStreamDestroy(s2); FHIP(e); }
+            B.stream2 = s2; B.ev2 = e2;
+        }
+        FHIP(hipStreamWaitEvent(B.stream2, ev0, 0));
+        FHIP(launch_filter_coop(B.stream2, fp, fp.coop_workers));
+        FHIP(hipEventRecord(B.ev2, B.stream2));
+    }
+    if (fp.n_short) FHIP(launch_filter_F(st, fp));
+    if (fp.n_coop) FHIP(hipStreamWaitEvent(st, B.ev2, 0));
+    FHIP(hipEventRecord(ev1, st));
+    return R3DM_OK;
+}
+
 // launch + wait + HIP-event time of the kernels of `n` prepared filters.  One filter: on the context's stream.  Several: every kernel
 // on the stream of its kind's priority class (FilterBufs::stream), after the uploads on the context's stream have been waited for.
 static int filter_launch(r3dm_ctx* c, FilterCallOut& o, const FilterParams* fps, int n, float* ms)
@@ -316,9 +438,8 @@ static int filter_launch(r3dm_ctx* c, FilterCallOut& o, const FilterParams* fps,
     for (int k = 0; k < n; ++k) live += fps[k].n_items ? 1 : 0;
     if (!live) return R3DM_OK;
     if (n == 1) {
-        FHIP(hipEventRecord(c->ev0, c->stream));
-        FHIP(launch_filter_F(c->stream, fps[0]));
-        FHIP(hipEventRecord(c->ev1, c->stream));
+        const int rc = filter_enqueue(c, o, fps[0], c->stream, c->ev0, c->ev1);
+        if (rc != R3DM_OK) return rc;
         FHIP(hipStreamSynchronize(c->stream));
         (void)hipEventElapsedTime(&ms[0], c->ev0, c->ev1);
         return R3DM_OK;
@@ -329,15 +450,27 @@ static int filter_launch(r3dm_ctx* c, FilterCallOut& o, const FilterParams* fps,
     for (int k = 0; k < n; ++k) {
         if (!fps[k].n_items) continue;
         FilterBufs& B = c->fb[fps[k].model_kind];
-        if (!B.stream) {
+        if (!B.stream || !B.ev0 || !B.ev1) {
+            // (all three or none: a half-made set would break every later call of the context)
+            if (B.ev0) (void)hipEventDestroy(B.ev0);
+            if (B.ev1) (void)hipEventDestroy(B.ev1);
+            if (B.stream) (void)hipStreamDestroy(B.stream);
+            B.stream = nullptr; B.ev0 = B.ev1 = nullptr;
             const int prio = fps[k].model_kind == 2 ? prio_high : (fps[k].model_kind == 0 ? (prio_low + prio_high) / 2 : prio_low);
-            FHIP(hipStreamCreateWithPriority(&B.stream, hipStreamNonBlocking, prio));
-            FHIP(hipEventCreate(&B.ev0));
-            FHIP(hipEventCreate(&B.ev1));
+            hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+            hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+            if (e == hipSuccess) e = hipEventCreate(&e0);
+            if (e == hipSuccess) e = hipEventCreate(&e1);
+            if (e != hipSuccess) {
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                if (s) (void)hipStreamDestroy(s);
+                FHIP(e);
+            }
+            B.stream = s; B.ev0 = e0; B.ev1 = e1;
         }
-        FHIP(hipEventRecord(B.ev0, B.stream));
-        FHIP(launch_filter_F(B.stream, fps[k]));
-        FHIP(hipEventRecord(B.ev1, B.stream));
+        const int rc = filter_enqueue(c, o, fps[k], B.stream, B.ev0, B.ev1);
+        if (rc != R3DM_OK) return rc;
     }
     hipError_t first = hipSuccess;
     for (int k = 0; k < n; ++k) {

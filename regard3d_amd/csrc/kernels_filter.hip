@@ -752,7 +752,7 @@ template <int KIND> struct ChunkOf { static constexpr int n = (KIND == 2) ? kE5S
 constexpr int kHistBins = 1024, kHistSub = 5, kHistShift = 52 - kHistSub;
 constexpr int kHdr = 1024 + kHistBins * 4;
 
-#ifdef R3DM_FILTER_ONLY_E
+#if defined(R3DM_FILTER_ONLY_E) || defined(R3DM_FILTER_DEVICE_ONLY)
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 static inline size_t filter_F_lds_bytes_unused_(uint32_t m_cap, int model_kind)
 #else
@@ -818,14 +818,19 @@ size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 // explicit lgkmcnt(0), see r3dm_internal.hpp -- the missing wait at the top of the chunk loop below is what made the
 // homography kernel, the only one light enough for two workgroups per CU, return different results from run to run and
 // eventually fault).  Through GLOBAL memory they exchange data in three places: the normalised points / pool / log-combinatorial
-// table written at start-up, the pool rebuilt after an improvement, and -- spill variant only -- the sort buffers.  A
-// workgroup-scope fence compiles to no vmcnt wait on gfx950 (LLVM's memory model relies on same-CU ordering through the L1),
-// so those places use an agent-scope fence (vmcnt(0), L2 write-back, L1 invalidate) before the barrier: they are rare.
-// Waves of ONE workgroup exchange data through global memory here (the pair's points, pool, tables; the spilled sort lists): every
-// slice belongs to one workgroup, whose waves share a CU and its vector L1 -- a WORKGROUP-scope fence (wait for the outstanding
-// stores and loads) is what the exchange needs.  __threadfence() is agent scope: on this chip of eight L2s that is an L2 write-back +
-// invalidate per barrier, ~10 per evaluated model on a spilled pair, and it slows every other workgroup of the device with it.
-// (The explicit wait is not redundant: hipcc was seen to emit no vmcnt wait for a workgroup-scope fence on gfx950, kernels_match.hip.)
+// table written at start-up, the pool rebuilt after an improvement, and -- spill variant only -- the sort buffers.  Every such
+// slice belongs to ONE workgroup, whose waves share a CU and its vector L1 -- a WORKGROUP-scope fence plus a wait for the wave's
+// outstanding stores and loads is what the exchange needs.  __threadfence() is agent scope: on this chip of eight L2s that is an L2
+// write-back + invalidate per barrier, ~10 per evaluated model on a spilled pair, and it slows every other workgroup of the device
+// with it.  (The explicit wait is not redundant: hipcc was seen to emit no vmcnt wait for a workgroup-scope fence on gfx950.)
+// Two conditions the shortcut rests on, both enforced here rather than assumed: the s_waitcnt immediate below is the gfx9 encoding
+// (vmcnt(0) lgkmcnt(0) = 0x0070), and the workgroup's waves must share one L1, i.e. the kernel is NOT compiled in threadgroup-split
+// mode (-mtgsplit: the compiler defines no macro for it, so build.sh refuses the flag instead).
+#if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__) && !defined(__gfx942__)
+#error "wg_fence: the s_waitcnt encoding and the same-CU L1 argument are written for gfx942 / gfx950"
+#endif
+#endif
 __device__ __forceinline__ void wg_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -932,6 +937,7 @@ __device__ __forceinline__ void wg_sort_regs(unsigned long long* __restrict__ ke
     wg_sync_t<GLOBAL>();
 }
 
+#ifndef R3DM_FILTER_DEVICE_ONLY      // (kernels_filter_coop.hip includes this file for the device routines above only)
 // NT = threads of the workgroup: 256 (two workgroups per CU), or 512 for collections with long match lists (one workgroup per CU with
 // the same registers per lane; every pass over the matches of a pair -- residuals, bound, sort, NFA scan -- takes half the trips)
 template <int KIND, bool SPILL, int NT, class KeyT, class IdxT>
@@ -1468,7 +1474,7 @@ static hipError_t launch_acransac(hipStream_t st, const FilterParams& P, size_t 
 {
     hipError_t e = hipFuncSetAttribute((const void*)acransac_kernel<KIND, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((acransac_kernel<KIND, NT>), dim3(P.n_items), dim3(NT), lds, st, P);
+    hipLaunchKernelGGL((acransac_kernel<KIND, NT>), dim3(P.n_short), dim3(NT), lds, st, P);
     return hipGetLastError();
 }
 #ifdef R3DM_FILTER_ONLY_E
@@ -1479,12 +1485,13 @@ hipError_t launch_filter_E(hipStream_t st, const FilterParams& P, size_t lds)
 #else
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P)
 {
-    if (P.n_items == 0) return hipSuccess;
+    if (P.n_short == 0) return hipSuccess;
     const size_t lds = filter_F_lds_bytes(P.m_cap, P.model_kind);
     if (P.model_kind == 2) return launch_filter_E(st, P, lds);
     if (P.model_kind == 0) return P.wide ? launch_acransac<0, 512>(st, P, lds) : launch_acransac<0, 256>(st, P, lds);
     return P.wide ? launch_acransac<1, 512>(st, P, lds) : launch_acransac<1, 256>(st, P, lds);
 }
 #endif
+#endif   // R3DM_FILTER_DEVICE_ONLY
 
 }  // namespace r3dm

@@ -151,12 +151,15 @@ struct r3dm_graph {
 };
 
 struct FilterBufs {
-    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch, f_kinv, f_spill, f_soff, f_order;
+    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch, f_kinv, f_spill, f_soff, f_order, f_coop;
     // r3dm_filter_FEH: the kernel of this kind on a stream of its own PRIORITY class (E high, F normal, H low).  Streams of one
     // priority share a handful of hardware queues -- three plain streams ran the three kernels mostly one after the other --, streams
     // of different priorities never do.
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the cooperative kernel of the kind's long pairs (kernels_filter_coop.hip) runs beside the one-workgroup kernel of its short ones
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev2 = nullptr;
     PinBuf pin_idx;           // page-locked landing zone of the inlier indices
     void release()
     {
@@ -164,8 +167,10 @@ struct FilterBufs {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
-        ev0 = ev1 = nullptr; stream = nullptr;
-        DevBuf* b[] = {&f_pairs, &f_ids, &f_offs, &f_matches, &f_inl_cnt, &f_inl_idx, &f_F, &f_thr, &f_iters, &f_log10, &f_logck, &f_scratch, &f_kinv, &f_spill, &f_soff, &f_order};
+        if (ev2) (void)hipEventDestroy(ev2);
+        if (stream2) (void)hipStreamDestroy(stream2);
+        ev0 = ev1 = ev2 = nullptr; stream = stream2 = nullptr;
+        DevBuf* b[] = {&f_pairs, &f_ids, &f_offs, &f_matches, &f_inl_cnt, &f_inl_idx, &f_F, &f_thr, &f_iters, &f_log10, &f_logck, &f_scratch, &f_kinv, &f_spill, &f_soff, &f_order, &f_coop};
         for (DevBuf* x : b) x->release();
     }
 };

@@ -200,6 +200,10 @@ struct FinalizeParams {
     uint32_t*     pair_cnt;       // [n_pairs]
 };
 
+constexpr int kCoopB = 32;                  // models per batch of the cooperative AC-RANSAC kernel, at most
+constexpr uint32_t kCoopStateBytes = 2048;  // global slot of a pair's state
+constexpr uint32_t kCoopMaxG = 30;          // slices per pair, at most (5-bit slice code of a task, 31 = start-up)
+
 struct FilterParams {
     const ImgDev* imgs;
     const uint2*  pairs;          // slot indices, one per work item
@@ -233,6 +237,23 @@ struct FilterParams {
     double*       pts_scratch;    // [slices][4] normalised (x1, y1, x2, y2)
     uint32_t*     pool_scratch;   // [n_matches]    current sampling pool
     float*        scratch_logc;   // [n_matches + n_items + 1] logcombi(k, m) table of each item
+    // ---- long pairs: the cooperative kernel (kernels_filter_coop.hip).  Items order[0 .. n_short) run on the one-workgroup-per-pair
+    // kernel, the n_coop items of coop_items on a pool of workers over a task queue.
+    uint32_t      n_short;
+    uint32_t      n_coop;
+    uint32_t      coop_workers;   // workgroups of the cooperative launch
+    const uint32_t* coop_items;   // [n_coop] work item of every cooperative pair
+    const uint32_t* coop_G;       // [n_coop] slices (workgroups per batch) of the pair, 1 .. kCoopMaxG
+    const uint32_t* coop_slice;   // [n_coop] matches per slice (< 65536: the slice histograms count in 16 bits)
+    const uint32_t* coop_hoff;    // [n_coop] first histogram slot of the pair
+    unsigned char* coop_state;    // [n_coop][kCoopStateBytes] pair state between batches
+    double*       coop_models;    // [n_coop][chunk x 9 x MAX_MODELS] models of the current chunk of minimal samples
+    double*       coop_bm;        // [n_coop][kCoopB][9] matrices the residuals of the batch in flight are taken with
+    uint32_t*     coop_hist;      // [slots][kCoopB][512] residual histograms of a slice (1024 u16 bins per model)
+    uint32_t*     coop_cnt;       // [slots][kCoopB] matches within the bound
+    double*       coop_tstar;     // [slices] T*(k) of every item (indexed by soff), k = 0 .. m
+    double*       coop_la;        // [n_coop][1024] NFA slope of every histogram bin
+    uint32_t*     coop_q;         // task queue: [head, tail, done, potential, active, n_pairs, cap - 1, -] + seq[cap] + data[cap]
     // debug trace (R3DM_TRACE_PAIR): rows of (iter, model, #<=bound, NFA, improved) for one item
     double*       trace;
     uint32_t      trace_item, trace_cap, trace_iter;
@@ -319,6 +340,9 @@ hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t 
 hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_n);
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
+hipError_t launch_filter_coop(hipStream_t st, const FilterParams& P, uint32_t n_workers);
+size_t     filter_coop_lds_bytes(int model_kind);
+inline size_t filter_coop_model_doubles(int model_kind) { return model_kind == 2 ? 32u * 90u : 64u * 27u; }   // chunk x 9 x MAX_MODELS
 size_t     filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 // rows8: every job carries byte rows -> the all-pairs scan runs on integer dot products (same keys)
 hipError_t launch_ann_build(hipStream_t st, const AnnBuildParams& P, uint32_t n_jobs, uint32_t max_n, uint32_t dim, bool rows8);
