@@ -233,46 +233,78 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     fp.n_coop = n_coop;
     fp.coop_workers = 0;
     if (n_coop) {
-        // one allocation: [items | G | slice | hoff] [queue] [state] [models] [batch matrices] [slice counts] [slope tables] [T*] [slice histograms]
+        // one allocation: [items | G | slice | hoff | start order] [queue] [published records] [models] [batch matrices] [slice counts]
+        // [slope tables] [T*] [slice histograms]
         auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-        uint32_t cap = 64; while (cap < coop_slots + n_coop + 1) cap <<= 1;
-        const size_t o_small = 0, small_bytes = up(16 * (size_t)n_coop);
-        const size_t o_q = o_small + small_bytes, q_bytes = up(4 * (8 + 2 * (size_t)cap));
-        const size_t o_state = o_q + q_bytes, state_bytes = up((size_t)n_coop * kCoopStateBytes);
-        const size_t o_models = o_state + state_bytes, models_bytes = up(8 * (size_t)n_coop * filter_coop_model_doubles(model_kind));
+        uint32_t workers = 0;
+        for (uint32_t g : coop_G) workers += g;
+        const int workers_knob = r3dm_dev_knob("R3DM_FILTER_COOP_WORKERS", 0);
+        workers = workers_knob > 0 ? (uint32_t)workers_knob : std::min<uint32_t>(workers, (uint32_t)std::max(c->n_cu, 1));
+        // scheduling words (kernels_filter_coop.hip): three lines of counters, the overflow ring, the idle ring, one mailbox line per worker
+        uint32_t cap = 64; while (cap < coop_slots + 1) cap <<= 1;
+        uint32_t icap = 64; while (icap < workers + 1) icap <<= 1;
+        const size_t q_words = 96 + 2 * (size_t)cap + 2 * (size_t)icap + 32 * (size_t)workers;
+        const size_t o_small = 0, small_bytes = up(20 * (size_t)n_coop);
+        const size_t o_q = o_small + small_bytes, q_bytes = up(4 * q_words);
+        const size_t o_pub = o_q + q_bytes, pub_bytes = up(64 * (size_t)n_coop);
+        const size_t o_models = o_pub + pub_bytes, models_bytes = up(8 * (size_t)n_coop * filter_coop_model_doubles(model_kind));
         const size_t o_bm = o_models + models_bytes, bm_bytes = up(8 * (size_t)n_coop * kCoopB * 9);
         const size_t o_cnt = o_bm + bm_bytes, cnt_bytes = up(4 * (size_t)coop_slots * kCoopB);
         const size_t o_la = o_cnt + cnt_bytes, la_bytes = up(8 * (size_t)n_coop * 1024);
         const size_t o_ts = o_la + la_bytes, ts_bytes = up(8 * (size_t)n_slice + 64);
         const size_t o_hist = o_ts + ts_bytes, hist_bytes = up(4 * (size_t)coop_slots * kCoopB * 512);
+        // (the kernel addresses the points and the slice histograms through 32-bit buffer offsets)
+        if (32 * (uint64_t)n_slice >= 0x7FFFFFFFull || hist_bytes >= 0x7FFFFFFFull) { o.err = "filter: putative graph too large for the cooperative kernel's buffer offsets"; return R3DM_ERR_UNSUPPORTED; }
         FHIP(B.f_coop.ensure(o_hist + hist_bytes));
         unsigned char* base = B.f_coop.as<unsigned char>();
-        uint32_t workers = 0;
-        for (uint32_t g : coop_G) workers += g;
-        const int workers_knob = r3dm_dev_knob("R3DM_FILTER_COOP_WORKERS", 0);
-        workers = workers_knob > 0 ? (uint32_t)workers_knob : std::min<uint32_t>(workers, (uint32_t)std::max(c->n_cu, 1));
         std::vector<uint32_t> stage(small_bytes / 4 + q_bytes / 4, 0u);
         memcpy(&stage[0], coop_items.data(), 4 * (size_t)n_coop);
         memcpy(&stage[n_coop], coop_G.data(), 4 * (size_t)n_coop);
         memcpy(&stage[2 * (size_t)n_coop], coop_slice.data(), 4 * (size_t)n_coop);
         memcpy(&stage[3 * (size_t)n_coop], coop_hoff.data(), 4 * (size_t)n_coop);
+        // pairs are started longest first
+        {
+            uint32_t* by_len = &stage[4 * (size_t)n_coop];
+            std::iota(by_len, by_len + n_coop, 0u);
+            std::stable_sort(by_len, by_len + n_coop, [&](uint32_t a, uint32_t b) {
+                const uint32_t ka = coop_items[a], kb = coop_items[b];
+                return begin_end[2 * ka + 1] - begin_end[2 * ka] > begin_end[2 * kb + 1] - begin_end[2 * kb]; });
+        }
         uint32_t* q = &stage[small_bytes / 4];
-        q[0] = 0; q[1] = n_coop; q[2] = 0; q[3] = coop_slots; q[4] = workers; q[5] = n_coop; q[6] = cap - 1; q[7] = 0;
-        for (uint32_t i = 0; i < cap; ++i) q[8 + i] = i;                               // slot i is free for ticket i
-        // every pair starts with its start-up task, longest pair first
-        std::vector<uint32_t> by_len(n_coop);
-        std::iota(by_len.begin(), by_len.end(), 0u);
-        std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) {
-            const uint32_t ka = coop_items[a], kb = coop_items[b];
-            return begin_end[2 * ka + 1] - begin_end[2 * ka] > begin_end[2 * kb + 1] - begin_end[2 * kb]; });
-        for (uint32_t i = 0; i < n_coop; ++i) { q[8 + i] = i + 1; q[8 + cap + i] = (by_len[i] << 5) | 31u; }
+        q[5] = n_coop; q[6] = cap - 1; q[20] = workers; q[34] = icap - 1; q[65] = coop_slots; q[66] = workers;
+        for (uint32_t i = 0; i < cap; ++i) q[96 + i] = i;                              // overflow ring: slot i is free for ticket i
+        for (uint32_t i = 0; i < icap; ++i) q[96 + 2 * (size_t)cap + i] = i;           // idle ring likewise
+        for (uint32_t w = 0; w < workers; ++w) q[96 + 2 * (size_t)cap + 2 * (size_t)icap + 32 * (size_t)w] = 0xFFFFFFFEu;   // mailboxes: nobody waits yet
         FHIP(hipMemcpyAsync(base, stage.data(), 4 * stage.size(), hipMemcpyHostToDevice, c->stream));
-        FHIP(hipMemsetAsync(base + o_state, 0, state_bytes, c->stream));
-        FHIP(hipStreamSynchronize(c->stream));           // `stage` leaves scope
+        FHIP(hipMemsetAsync(base + o_pub, 0, pub_bytes, c->stream));
+        // logcombi(k, m) of every cooperative pair as a running prefix in the reference's float accumulation order (makelogcombi_n,
+        // SURVEY.md A.5): pre[i] = pre[i-1] + (l10[m-i+1] - l10[i]), mirrored for k > m/2 -- the same operations, in the same order, as
+        // thread 0 of the one-workgroup kernel performs (this translation unit is compiled with -ffp-contract=off like the kernels)
+        if (B.pin_idx.ensure(4 * (size_t)n_slice + 64) != hipSuccess) { o.err = "filter: out of page-locked host memory"; return R3DM_ERR_NOMEM; }
+        {
+            float* lc = static_cast<float*>(B.pin_idx.p);
+            for (uint32_t qi = 0; qi < n_coop; ++qi) {
+                const uint32_t k = coop_items[qi];
+                const uint32_t m = (uint32_t)(begin_end[2 * k + 1] - begin_end[2 * k]);
+                float* t = lc + soff[k];
+                float pre = 0.0f;
+                t[0] = 0.0f; t[m] = 0.0f;
+                for (uint32_t i = 1; i <= m / 2; ++i) {
+                    pre = pre + (l10[m - i + 1] - l10[i]);
+                    t[i] = pre;
+                    if (m - i > i) t[m - i] = pre;
+                }
+            }
+            // (one copy of the whole table array: the slices of the short pairs carry whatever the buffer held -- the one-workgroup
+            // kernel fills its own tables before it reads them)
+            FHIP(hipMemcpyAsync(fp.scratch_logc, lc, 4 * (size_t)n_slice, hipMemcpyHostToDevice, c->stream));
+        }
+        FHIP(hipStreamSynchronize(c->stream));           // `stage` leaves scope; the landing buffer is reused for the results
         fp.coop_items = reinterpret_cast<const uint32_t*>(base);
         fp.coop_G = fp.coop_items + n_coop; fp.coop_slice = fp.coop_items + 2 * (size_t)n_coop; fp.coop_hoff = fp.coop_items + 3 * (size_t)n_coop;
+        fp.coop_start = fp.coop_items + 4 * (size_t)n_coop;
         fp.coop_q = reinterpret_cast<uint32_t*>(base + o_q);
-        fp.coop_state = base + o_state;
+        fp.coop_pub = base + o_pub;
         fp.coop_models = reinterpret_cast<double*>(base + o_models);
         fp.coop_bm = reinterpret_cast<double*>(base + o_bm);
         fp.coop_cnt = reinterpret_cast<uint32_t*>(base + o_cnt);
@@ -280,6 +312,12 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         fp.coop_tstar = reinterpret_cast<double*>(base + o_ts);
         fp.coop_hist = reinterpret_cast<uint32_t*>(base + o_hist);
         fp.coop_workers = workers;
+        fp.coop_prof = nullptr;
+        if (r3dm_dev_knob("R3DM_COOP_PROF", 0)) {               // developer build: per-pair phase times of the cooperative kernel
+            FHIP(B.f_coop_prof.ensure(128 * (size_t)n_coop));
+            FHIP(hipMemsetAsync(B.f_coop_prof.p, 0, 128 * (size_t)n_coop, c->stream));
+            fp.coop_prof = B.f_coop_prof.as<unsigned long long>();
+        }
         if (filter_coop_lds_bytes(model_kind) > 160 * 1024) { o.err = "filter: LDS budget exceeded (cooperative kernel)"; return R3DM_ERR_UNSUPPORTED; }
     }
     if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { o.err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
@@ -347,6 +385,31 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     FHIP(hipMemcpyAsync(h_F.data(), B.f_F.p, 72 * (size_t)NI, hipMemcpyDeviceToHost, c->stream));
     FHIP(hipStreamSynchronize(c->stream));
     o.ms_kernels = ms;
+    if (fp.n_coop) {
+        uint32_t qh[96];
+        FHIP(hipMemcpy(qh, fp.coop_q, sizeof(qh), hipMemcpyDeviceToHost));
+        qh[2] = qh[64];                                       // pairs finished
+        if (qh[8] != 0u || qh[2] != fp.n_coop) {
+            o.err = "filter: the cooperative kernel (kind " + std::to_string(model_kind) + ") stalled (code " + std::to_string(qh[8]) + ", info " + std::to_string(qh[9]) + ", " +
+                    std::to_string(qh[2]) + " of " + std::to_string(fp.n_coop) + " pairs finished; at the stall: overflow head " + std::to_string(qh[10]) + " tail " +
+                    std::to_string(qh[11]) + " finished " + std::to_string(qh[12]) + " potential " + std::to_string(qh[13]) + " workers " + std::to_string(qh[14]) +
+                    " started " + std::to_string(qh[15]) + ")";
+            return R3DM_ERR_HIP;
+        }
+    }
+    if (fp.n_coop && fp.coop_prof) {
+        std::vector<unsigned long long> pr(16 * (size_t)fp.n_coop);
+        FHIP(hipMemcpy(pr.data(), fp.coop_prof, 8 * pr.size(), hipMemcpyDeviceToHost));
+        static const char* kind_name[3] = {"F", "H", "E"};
+        for (uint32_t q = 0; q < fp.n_coop; ++q) {
+            const unsigned long long* r = &pr[16 * (size_t)q];
+            const uint32_t k = coop_items[q];
+            fprintf(stderr, "coop %s pair %u m %llu G %u: wall %.0f us | init %.0f solve %.0f form+publish %.0f slices %.0f (sum over workgroups) arrive %.0f bounds %.0f "
+                    "full %.0f (%llu) walk %.0f | batches %llu models %llu | task delay sum %.0f max %.0f, longest slice %.0f %u\n", kind_name[model_kind], q,
+                    (unsigned long long)(begin_end[2 * k + 1] - begin_end[2 * k]), coop_G[q], r[10] / 100.0, r[0] / 100.0, r[1] / 100.0, r[2] / 100.0, r[3] / 100.0,
+                    r[4] / 100.0, r[5] / 100.0, r[6] / 100.0, r[7], r[8] / 100.0, r[9], r[11], r[12] / 100.0, r[14] / 100.0, r[13] / 100.0, 0u);
+        }
+    }
     if (fp.trace) {
         std::vector<double> tr(5 * (size_t)trace_cap + 8);
         FHIP(hipMemcpy(tr.data(), trace_buf.p, tr.size() * 8, hipMemcpyDeviceToHost));

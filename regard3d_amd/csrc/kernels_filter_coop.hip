@@ -2,33 +2,38 @@
 //
 // The one-workgroup-per-pair kernel (kernels_filter.hip) binds a pair to one CU: a pair of 10-20 k putative matches is bound by
 // that CU's f64 rate, and a collection of few, long pairs (what Regard3D produces: tens of photographs) leaves most of the chip
-// idle.  Here a pair with more than FilterParams::coop_min_m matches is evaluated by G workgroups:
+// idle.  Here a pair with more than a threshold of matches (api_filter.cpp: 4096) is evaluated by G workgroups:
 //
 //   * ACRANSAC stays sequential where it is sequential (the reference's iteration order, the pool that shrinks on every
 //     meaningful improvement, the budget that is cut once -- SURVEY.md A.5); what is spread is the part that is not: the
 //     residuals of a BATCH of up to 32 models (whole iterations of the current chunk of minimal samples) over the pair's matches.
-//     Workgroup s takes the s-th slice of the match list, loads every point once for all models of the batch, and leaves a
+//     A workgroup takes the s-th slice of the match list, loads every point once for all models of the batch, and leaves a
 //     residual histogram (the 1024 bins of the sort-skipping bound) and a count per model in its global slot.
-//   * The workgroup that arrives last (an atomic ticket) merges the slots and walks the batch in the reference's order.  The NFA
-//     bound of a model comes from the merged histogram alone; only a model whose bound can beat the best NFA so far -- a few per
-//     cent -- is evaluated in full by that one workgroup (residuals of all matches, sort, NFA scan: the routines of the
-//     one-workgroup kernel), so every decision is the one the sequential algorithm takes: same inlier sets, same models, same
-//     iteration and model counts.  Models behind a pool change are discarded like the rest of a chunk always was; the batch size
-//     starts small after a pool change and doubles (12, 24, 32) while nothing changes.
-//   * Workgroups are not bound to pairs.  The kernel is a pool of workers over a queue of (pair, slice) tasks in global memory; the
-//     last arriver of a batch becomes the pair's leader, prepares the next batch (drawing and solving a new chunk when the old one
-//     is used up or void), publishes G - 1 tasks and takes slice 0 itself.  No workgroup ever waits for a particular other
-//     workgroup to be scheduled -- only for the queue -- so nothing depends on co-residency, and F, E and H kernels can share the
-//     device.  A worker that finds the queue empty while fewer tasks can exist than workers are alive retires, leaving its CU to
-//     the other kernels.
+//   * The pair's LEADER (the workgroup that started the pair; its state stays in that workgroup's LDS for the pair's lifetime)
+//     merges the slots and walks the batch in the reference's order.  The NFA bound of a model comes from the merged histogram
+//     alone; only a model whose bound can beat the best NFA so far -- a few per cent -- is evaluated in full by the leader
+//     (residuals of all matches, sort, NFA scan), so every decision is the one the sequential algorithm takes: same inlier sets,
+//     same models, same iteration and model counts.  Models behind a pool change are discarded like the rest of a chunk always
+//     was; the batch size starts small after a pool change and doubles (12, 24, 32) while nothing changes.
+//   * Workgroups are not bound to slices.  The kernel is a pool of workers: a worker runs slice tasks from a queue in global
+//     memory, or starts a pair that has no leader yet.  A leader publishes G - 1 slice tasks per batch, takes slice 0 itself, and
+//     while it waits for the others it runs slice tasks from the queue like any worker (its own pair's or another's: the slice
+//     routine touches none of the leader's LDS state).  No workgroup ever waits on something only a not-yet-scheduled workgroup
+//     could provide, so nothing depends on co-residency and F, E and H kernels share the device.  A worker that finds nothing to
+//     do while fewer tasks can exist than workers are alive retires, leaving its CU to the other kernels.
 //   * The bound: NFA_k >= loge0 + la(bin of the k-th residual) (k - SS) + T[k], T[k] = logc_n[k] + logc_k[k] (float tables).
 //     T*(k) = log10(m! / ((m-k)! SS! (k-SS)!)) is concave in k, so over the k range of a bin la_b (k - SS) + T*(k) takes its minimum
 //     at an end of the range: two evaluations per non-empty bin instead of one per k (the walk over k was half the evaluation time
 //     of a long pair).  eps_T = max_k |T[k] - T*(k)|, computed per pair at start-up, makes the bound rigorous for the float
 //     tables: bound = min over bins and ends - eps_T - 1e-6.
 //
-// Exchange through global memory between workgroups on different XCDs (eight L2s): plain stores, one agent-scope fence
-// (__threadfence: L2 write-back / invalidate) per workgroup and BATCH on each side of the ticket or the queue -- not per model.
+// Hand-offs between workgroups (eight XCDs, private L2s, per-CU L1s that no other CU's store refreshes) follow the write-through
+// form of /opt/skills/guides/cdna_hip_programming.md section 6 Guideline 16: every word another workgroup reads is STORED sc1
+// (16-byte raw-buffer stores with aux = sc1, or 8-byte relaxed agent-scope atomics) and LOADED sc1; the storing waves drain
+// (`s_waitcnt vmcnt(0)`), the workgroup meets at a barrier, one lane bumps a relaxed agent-scope counter; pollers read that one
+// word relaxed with s_sleep between reads.  No agent-scope fence anywhere: the first version fenced (__threadfence, every thread,
+// four times per batch) and polled its queue with acquire loads -- correct, and 15x slower than the work on a collection of 66
+// pairs (every fence a write-back + invalidate that the other 255 workgroups pay for).
 #define R3DM_FILTER_DEVICE_ONLY 1
 #include "kernels_filter.hip"
 
@@ -36,11 +41,50 @@ namespace r3dm {
 
 constexpr int kCoopNT = 512;                // threads per worker
 constexpr uint32_t kCoopNW = kCoopNT / 64;
-constexpr uint32_t kCoopInitSlice = 31u;    // slice code of a pair's first task
-constexpr uint32_t kCoopNoTask = 0xFFFFFFFFu;
+constexpr uint32_t kCoopNoTask = 0xFFFFFFFFu, kCoopDone = 0xFFFFFFFEu, kCoopStall = 0xFFFFFFFDu;
 template <int KIND> struct CoopChunk { static constexpr int n = (KIND == 2) ? 2 * kE5Samples : kChunk; };   // E: 32 groups of 16 lanes
 
-// State of one pair.  Lives in global memory (FilterParams::coop_state) between batches, in LDS while a leader works on it.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long gu64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define QLOAD(p) __hip_atomic_load((p), RLX_AGENT)
+#define DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// Every wait in this kernel is bounded: a poller that has waited kCoopStallTicks of the 100 MHz wall clock (2 s; a whole call takes
+// milliseconds) records a stall code in the queue header, and every loop leaves as soon as that word is set -- the host then reports
+// R3DM_ERR_HIP with the code instead of a device that never comes back.
+constexpr unsigned long long kCoopStallTicks = 200000000ull;
+constexpr int kAuxSc1 = 16;                 // raw-buffer aux bits: sc1 (write-through store / L1-bypassing load)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t coop_rsrc(const void* p)
+{
+    // descriptors from wave-uniform values only (readfirstlane), so no waterfall loop is emitted
+    const uint64_t a = (uint64_t)p;
+    return __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a)),
+        0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ld16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff)
+{
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, kAuxSc1));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff, u32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, kAuxSc1);
+}
+
+// What a slice task reads about its pair.  One 64-byte record per pair in global memory, every word an 8-byte agent-scope atomic.
+struct CoopPub {
+    gu64 pt;             // the pair's normalised points (byte offset into FilterParams::pts_scratch)
+    gu64 max_thr_bits;   // residual bound (bits of the double)
+    gu64 hist_base;      // first histogram bin (bits of the signed value)
+    gu64 m_slice;        // m | slice_len << 32
+    gu64 hoff_bn;        // first slot of the pair | models of the batch in flight << 32
+    gu64 arrived;        // slices of the batch that have been delivered (the leader's own is not counted)
+    gu64 pad[2];
+};
+static_assert(sizeof(CoopPub) == 64, "one record per 64 bytes");
+
+// State of one pair: in the LDS of its leader from start-up to the result.
 struct CoopS {
     double minNFA, errorMax, bestF[9];
     double eps_T;                          // max |T - T*| of the pair's tables
@@ -51,18 +95,16 @@ struct CoopS {
     uint32_t nIter, reserve, iter, pool_size, n_inl, acMode, n_models, iters_done;
     uint32_t chunk_iter0, chunk_n, chunk_c, chunk_valid;      // the chunk of solved samples: first iteration, iterations, next to decide
     uint32_t b_c0, b_c1, b_n, b_cap;       // the batch: iterations [c0, c1) of the chunk, models, slow-start capacity
-    uint32_t cnt, flag, G, slice_len;
+    uint32_t cnt, flag;
     uint32_t wave_cnt[8], red_k[8];
     uint32_t nm[64];                       // models of every hypothesis of the chunk
     uint8_t  bj_c[kCoopB], bj_k[kCoopB];   // model j of the batch = model bj_k[j] of hypothesis bj_c[j]
-    uint32_t copy_end;                     // ---- fields below are not part of the LDS <-> global copy
-    uint32_t arrived;                      // ticket of the batch in flight
+    uint32_t sh_task, sh_aux;              // broadcast slots of thread 0 (all LDS in the one dynamic array: Guideline 17)
 };
-static_assert(sizeof(CoopS) <= kCoopStateBytes, "CoopS must fit its global slot");
 static_assert(sizeof(CoopS) <= 2048, "CoopS must fit the LDS header");
-constexpr int kCoopHdr = 4608;             // LDS: [CoopS | batch models 32 x 9 doubles at 2048 | slice counts at 4352] [region R at 4608]
-constexpr int kCoopBmOff = 2048, kCoopCntOff = 2048 + kCoopB * 72;
-static_assert(kCoopCntOff + kCoopB * 4 <= kCoopHdr, "LDS header");
+// LDS: [CoopS | slice scratch: batch matrices 32 x 9 doubles at 2048, counts at 4352 | slot counts of the merge at 4608 (30 x 32 u32)] [region R at 8704]
+constexpr int kCoopBmOff = 2048, kCoopCntOff = 2048 + kCoopB * 72, kCoopAllCntOff = 4608, kCoopHdr = 4608 + 4096;
+static_assert(kCoopCntOff + kCoopB * 4 <= kCoopAllCntOff && kCoopMaxG * kCoopB * 4 <= 4096, "LDS header");
 
 static inline size_t coop_lds_bytes_(int model_kind)
 {
@@ -71,38 +113,84 @@ static inline size_t coop_lds_bytes_(int model_kind)
     return (size_t)kCoopHdr + (hist > work ? hist : work);
 }
 
-// ---- the task queue (bounded ring, tickets): header words [head, tail, done, potential, active, n_pairs, cap - 1, -] + seq[cap] + data[cap]
-#define QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-__device__ __forceinline__ void coop_push(uint32_t* q, uint32_t v)
+// ---- scheduling state in global memory (FilterParams::coop_q), every access a relaxed agent-scope atomic by ONE lane.
+// Three 128-byte lines of words, then two ticket rings and the workers' mailboxes:
+//   line 0: [0] overflow head [1] overflow tail [5] pairs [6] overflow capacity - 1 [7] next pair to start [8] stall code [9] stall info
+//           [10..15] what the staller saw [20] workers
+//   line 1: [32] idle-ring head [33] idle-ring tail [34] idle-ring capacity - 1
+//   line 2: [64] pairs finished [65] potential (slices of unfinished pairs) [66] workers alive
+//   [96 ..) overflow ring seq[cap], data[cap]; idle ring seq[icap], data[icap]; mailboxes, 32 words (one line) per worker
+// A worker with nothing to do registers in the idle ring and waits at ITS OWN mailbox line; a leader hands a slice to an idle worker by
+// popping an id and writing the task into that mailbox.  Nobody polls a shared word: the first queue (every idle worker polling one
+// head word, ~200 pollers) delayed each task by ~125 us on a collection of 66 pairs and ran 2.3x slower with 256 workers than with 100.
+// Only when no worker is idle does a task go to the overflow ring, which workers look at when they become free.
+constexpr uint32_t kQNextPair = 7, kQStall = 8, kQIdle = 32, kQDone = 64, kQPot = 65, kQActive = 66, kQArrays = 96;
+constexpr uint32_t kMboxEmpty = 0u, kMboxRetired = 0xFFFFFFFEu;
+
+struct CoopRing { uint32_t* head; uint32_t* tail; uint32_t* seq; uint32_t* data; uint32_t mask; };
+struct CoopSched {
+    uint32_t* h;
+    CoopRing ov, idle;
+    uint32_t* mbox;
+};
+__device__ __forceinline__ CoopSched coop_sched(uint32_t* q)
 {
-    const uint32_t mask = q[6];
-    uint32_t* seq = q + 8;
-    uint32_t* data = seq + mask + 1;
-    const uint32_t t = atomicAdd(&q[1], 1u);
-    const uint32_t slot = t & mask;
-    // (capacity >= the tasks that can be outstanding: the slot is free; the wait is defensive)
-    while (__hip_atomic_load(&seq[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != t) __builtin_amdgcn_s_sleep(2);
-    __hip_atomic_store(&data[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&seq[slot], t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    CoopSched Q;
+    Q.h = q;
+    const uint32_t ov_cap = q[6] + 1u, id_cap = q[kQIdle + 2] + 1u;
+    Q.ov = CoopRing{q + 0, q + 1, q + kQArrays, q + kQArrays + ov_cap, ov_cap - 1u};
+    Q.idle = CoopRing{q + kQIdle, q + kQIdle + 1, q + kQArrays + 2u * ov_cap, q + kQArrays + 2u * ov_cap + id_cap, id_cap - 1u};
+    Q.mbox = q + kQArrays + 2u * ov_cap + 2u * id_cap;
+    return Q;
 }
-__device__ __forceinline__ bool coop_pop(uint32_t* q, uint32_t& v)
+__device__ __forceinline__ bool coop_stalled(uint32_t* q) { return QLOAD(&q[kQStall]) != 0u; }
+__device__ __forceinline__ void coop_report_stall(uint32_t* q, uint32_t code, uint32_t info)
 {
-    const uint32_t mask = q[6];
-    uint32_t* seq = q + 8;
-    uint32_t* data = seq + mask + 1;
+    uint32_t expect = 0u;
+    if (__hip_atomic_compare_exchange_strong(&q[kQStall], &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&q[9], info, RLX_AGENT);
+        __hip_atomic_store(&q[10], QLOAD(&q[0]), RLX_AGENT); __hip_atomic_store(&q[11], QLOAD(&q[1]), RLX_AGENT);        // overflow head, tail
+        __hip_atomic_store(&q[12], QLOAD(&q[kQDone]), RLX_AGENT); __hip_atomic_store(&q[13], QLOAD(&q[kQPot]), RLX_AGENT);
+        __hip_atomic_store(&q[14], QLOAD(&q[kQActive]), RLX_AGENT); __hip_atomic_store(&q[15], QLOAD(&q[kQNextPair]), RLX_AGENT);
+    }
+}
+// bounded ring with tickets; a producer drains its data store before it opens the slot
+__device__ __forceinline__ void ring_push(uint32_t* q, const CoopRing& R, uint32_t v)
+{
+    const uint32_t t = __hip_atomic_fetch_add(R.tail, 1u, RLX_AGENT);
+    const uint32_t slot = t & R.mask;
+    // (capacity >= the entries that can be outstanding: the slot is free; the wait is defensive)
+    for (const unsigned long long t0 = wall_clock64(); QLOAD(&R.seq[slot]) != t;) {
+        __builtin_amdgcn_s_sleep(2);
+        if (coop_stalled(q)) return;
+        if ((unsigned long long)wall_clock64() - t0 > kCoopStallTicks) { coop_report_stall(q, 1u, t); return; }
+    }
+    __hip_atomic_store(&R.data[slot], v, RLX_AGENT);
+    DRAIN_VMEM();
+    __hip_atomic_store(&R.seq[slot], t + 1u, RLX_AGENT);
+}
+__device__ __forceinline__ bool ring_pop(const CoopRing& R, uint32_t& v)
+{
     for (;;) {
-        const uint32_t h = QLOAD(&q[0]);
-        const uint32_t slot = h & mask;
-        if (__hip_atomic_load(&seq[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != h + 1u) return false;   // empty, or its producer is still writing
-        if (atomicCAS(&q[0], h, h + 1u) == h) {
-            v = QLOAD(&data[slot]);
-            __hip_atomic_store(&seq[slot], h + mask + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);        // free for the next lap
+        const uint32_t h = QLOAD(R.head);
+        const uint32_t slot = h & R.mask;
+        if (QLOAD(&R.seq[slot]) != h + 1u) return false;               // empty, or its producer is still writing
+        uint32_t expect = h;
+        if (__hip_atomic_compare_exchange_strong(R.head, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            v = QLOAD(&R.data[slot]);
+            DRAIN_VMEM();                                               // (the value has been read before the slot is reopened)
+            __hip_atomic_store(&R.seq[slot], h + R.mask + 1u, RLX_AGENT);  // free for the next lap
             return true;
         }
     }
 }
+__device__ __forceinline__ bool mbox_cas(uint32_t* word, uint32_t from, uint32_t to)
+{
+    uint32_t expect = from;
+    return __hip_atomic_compare_exchange_strong(word, &expect, to, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-// what a worker needs to know about the pair of its task
+// what the leader knows about its pair
 template <int KIND>
 struct CoopCtx {
     uint32_t item, cp, m, G, slice_len, hoff;
@@ -110,7 +198,7 @@ struct CoopCtx {
     double s1, s2, t1x, t1y, t2x, t2y, logalpha0, maxThreshold, loge0;
     long long hist_base;
     double* pt; uint32_t* pool; uint32_t* inl; float* logc_n; double* tstar; double* la_tab;
-    double* models; double* bm; CoopS* gs;
+    double* models; double* bm; CoopPub* pub;
     unsigned long long* keys; uint32_t* sidx;
     const ImgDev* Ip; const ImgDev* Jp; const r3dm_match* mm;
 };
@@ -133,7 +221,7 @@ __device__ __forceinline__ void coop_ctx(const FilterParams& P, uint32_t cp, Coo
     C.tstar = P.coop_tstar + so; C.la_tab = P.coop_la + (size_t)cp * kHistBins;
     C.models = P.coop_models + (size_t)cp * CoopChunk<KIND>::n * MS;
     C.bm = P.coop_bm + (size_t)cp * kCoopB * 9;
-    C.gs = reinterpret_cast<CoopS*>(P.coop_state + (size_t)cp * kCoopStateBytes);
+    C.pub = reinterpret_cast<CoopPub*>(P.coop_pub) + cp;
     C.keys = P.spill_keys + P.spill_off[C.item]; C.sidx = P.spill_idx + P.spill_off[C.item];
     const int wI = (int)C.Ip->width, hI = (int)C.Ip->height, wJ = (int)C.Jp->width, hJ = (int)C.Jp->height;
     C.s1 = (KIND == 2) ? 1.0 : 1.0 / sqrt((double)(wI * hI));
@@ -150,15 +238,29 @@ __device__ __forceinline__ void coop_ctx(const FilterParams& P, uint32_t cp, Coo
     C.hist_base = (__double_as_longlong(fmin(C.maxThreshold, 1.0e6)) >> kHistShift) - (long long)(kHistBins - 1);
 }
 
+// developer build: where a pair's time goes (R3DM_COOP_PROF=1 prints the table; FilterParams::coop_prof is null otherwise).  Ticks of the
+// 100 MHz wall clock: [0] start-up [1] solves [2] batch forming + publishing [3] slice evaluations (all workgroups) [4] the leader
+// waiting for / helping with slices [5] merged bounds [6] full evaluations [7] their number [8] rest of the walk [9] batches
+// [10] start .. finish [11] models in batches
+#ifdef R3DM_DEVTOOLS
+#define PROF_NOW() ((P.coop_prof && threadIdx.x == 0) ? (unsigned long long)wall_clock64() : 0ull)
+#define PROF_PUT(cp_, slot, v) do { if (P.coop_prof && threadIdx.x == 0) atomicAdd(&P.coop_prof[16 * (size_t)(cp_) + (slot)], (unsigned long long)(v)); } while (0)
+#else
+#define PROF_NOW() 0ull
+#define PROF_PUT(cp_, slot, v) do { (void)(cp_); (void)(v); } while (0)
+#endif
+
 template <int KIND>
 __device__ __forceinline__ double coop_residual(const double* M, double x1, double y1, double x2, double y2)
 {
     return (KIND == 0) ? sym_epipolar_err(M, x1, y1, x2, y2) : (KIND == 1) ? h_asym_err(M, x1, y1, x2, y2) : epipolar_dist_err(M, x1, y1, x2, y2);
 }
 
-// ---- start-up of a pair: the prologue of acransac_body + the tables of the concave bound
+// ---- start-up of a pair: the prologue of acransac_body + the tables of the concave bound.  The points go out write-through (slice
+// tasks on other XCDs read them); logc_n comes from the host (api_filter.cpp: its float running sum is order-bound, a serial loop
+// of m / 2 steps was 1.0-1.6 ms of a 12 k pair's start-up here).
 template <int KIND>
-__device__ void coop_init(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, uint32_t tid)
+__device__ __attribute__((noinline)) void coop_init(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, uint32_t tid)
 {
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);
     constexpr double MULT_ERR = (KIND == 1) ? 1.0 : 0.5;
@@ -167,22 +269,25 @@ __device__ void coop_init(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& 
         const uint2 sl = P.pairs[C.item];
         S.kinv[tid] = P.kinv[9 * (size_t)(tid < 9 ? sl.x : sl.y) + (tid < 9 ? tid : tid - 9)];
     }
-    for (uint32_t p = tid; p < m; p += kCoopNT) {
-        const r3dm_match q = C.mm[p];
-        const double xi = (double)C.Ip->xy[2 * (size_t)q.i], yi = (double)C.Ip->xy[2 * (size_t)q.i + 1];
-        const double xj = (double)C.Jp->xy[2 * (size_t)q.j], yj = (double)C.Jp->xy[2 * (size_t)q.j + 1];
-        C.pt[4 * p + 0] = C.s1 * xi + C.t1x; C.pt[4 * p + 1] = C.s1 * yi + C.t1y;
-        C.pt[4 * p + 2] = C.s2 * xj + C.t2x; C.pt[4 * p + 3] = C.s2 * yj + C.t2y;
-        C.pool[p] = p;
+    {
+        const __amdgpu_buffer_rsrc_t rp = coop_rsrc(P.pts_scratch);
+        const uint32_t pt_off = (uint32_t)((const char*)C.pt - (const char*)P.pts_scratch);
+        for (uint32_t p = tid; p < m; p += kCoopNT) {
+            const r3dm_match q = C.mm[p];
+            const double xi = (double)C.Ip->xy[2 * (size_t)q.i], yi = (double)C.Ip->xy[2 * (size_t)q.i + 1];
+            const double xj = (double)C.Jp->xy[2 * (size_t)q.j], yj = (double)C.Jp->xy[2 * (size_t)q.j + 1];
+            const double a0 = C.s1 * xi + C.t1x, a1 = C.s1 * yi + C.t1y, b0 = C.s2 * xj + C.t2x, b1 = C.s2 * yj + C.t2y;
+            const unsigned long long w0 = (unsigned long long)__double_as_longlong(a0), w1 = (unsigned long long)__double_as_longlong(a1);
+            const unsigned long long w2 = (unsigned long long)__double_as_longlong(b0), w3 = (unsigned long long)__double_as_longlong(b1);
+            u32x4 lo4, hi4;
+            lo4.x = (uint32_t)w0; lo4.y = (uint32_t)(w0 >> 32); lo4.z = (uint32_t)w1; lo4.w = (uint32_t)(w1 >> 32);
+            hi4.x = (uint32_t)w2; hi4.y = (uint32_t)(w2 >> 32); hi4.z = (uint32_t)w3; hi4.w = (uint32_t)(w3 >> 32);
+            st16_sc1(rp, pt_off + 32u * p, lo4);
+            st16_sc1(rp, pt_off + 32u * p + 16u, hi4);
+            C.pool[p] = p;
+        }
     }
     if (tid == 0) {
-        float pre = 0.0f;                                      // makelogcombi_n in the reference's float accumulation order (kernels_filter.hip)
-        C.logc_n[0] = 0.0f; C.logc_n[m] = 0.0f;
-        for (uint32_t i = 1; i <= m / 2; ++i) {
-            pre = pre + (P.log10_tab[m - i + 1] - P.log10_tab[i]);
-            C.logc_n[i] = pre;
-            if (m - i > i) C.logc_n[m - i] = pre;
-        }
         S.minNFA = __builtin_huge_val(); S.errorMax = __builtin_huge_val();
         for (int e = 0; e < 9; ++e) S.bestF[e] = 0.0;
         const uint32_t reserve = P.max_iter / 10;
@@ -191,7 +296,13 @@ __device__ void coop_init(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& 
         S.n_models = 0; S.iters_done = 0; S.cnt = 0u; S.flag = 0u;
         S.chunk_iter0 = 0; S.chunk_n = 0; S.chunk_c = 0; S.chunk_valid = 0;
         S.b_c0 = S.b_c1 = S.b_n = 0; S.b_cap = 12;
-        S.G = C.G; S.slice_len = C.slice_len;
+        CoopPub* pub = C.pub;
+        __hip_atomic_store(&pub->pt, (gu64)((const char*)C.pt - (const char*)P.pts_scratch), RLX_AGENT);
+        __hip_atomic_store(&pub->max_thr_bits, (gu64)__double_as_longlong(C.maxThreshold), RLX_AGENT);
+        __hip_atomic_store(&pub->hist_base, (gu64)C.hist_base, RLX_AGENT);
+        __hip_atomic_store(&pub->m_slice, (gu64)m | ((gu64)C.slice_len << 32), RLX_AGENT);
+        __hip_atomic_store(&pub->hoff_bn, (gu64)C.hoff, RLX_AGENT);
+        __hip_atomic_store(&pub->arrived, (gu64)0, RLX_AGENT);
     }
     // T*(k) = log10( m! / ((m - k)! SS! (k - SS)!) ), k >= SS: concave in k
     {
@@ -204,7 +315,7 @@ __device__ void coop_init(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& 
         const double edge = b ? __longlong_as_double(((long long)b + C.hist_base) << kHistShift) : 0.0;
         C.la_tab[b] = C.logalpha0 + MULT_ERR * log10(edge + FLT_EPS_D);
     }
-    wg_sync_global();                                          // logc_n (thread 0) and T* are read by everyone below
+    wg_sync_global();                                          // T* is read by everyone below (and the points are drained)
     double e = 0.0;
     for (uint32_t k = SS + 1 + tid; k <= m; k += kCoopNT) {
         const double d = fabs(((double)C.logc_n[k] + (double)P.logc_k[k]) - C.tstar[k]);
@@ -224,12 +335,16 @@ __device__ void coop_init(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& 
 
 // ---- draw + solve a chunk of minimal samples starting at iteration S.iter (the sampling block of acransac_body)
 template <int KIND>
-__device__ void coop_solve_chunk(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, unsigned char* smem, uint32_t tid)
+__device__ __attribute__((noinline)) void coop_solve_chunk(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, unsigned char* smem, uint32_t tid)
 {
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);
     constexpr int MS = (KIND == 2) ? 90 : 27;
     constexpr uint32_t CH = (uint32_t)CoopChunk<KIND>::n;
-    const uint32_t iter0 = S.iter, nIter0 = S.nIter;
+    // While no model has any inlier yet, ACRANSAC extends its budget by one iteration at a time out of the reserve (nIter++, reserve--
+    // at it + 1 == nIter): those iterations WILL run, from the same pool, unless one of them finds inliers (then the rest of the chunk
+    // is void like behind any pool change).  Sizing the chunk by nIter alone drew them as ~200 chunks of ONE sample each at the end of
+    // every pair without a model (5 ms of a homography filter's 7).
+    const uint32_t iter0 = S.iter, nIter0 = S.nIter + (S.n_inl == 0 ? S.reserve : 0u);
     const uint32_t chunk_n = (nIter0 - iter0 < CH) ? nIter0 - iter0 : CH;
     const uint32_t hyp = (KIND == 2) ? (tid >> 4) : tid;
     const uint32_t pool_size = S.pool_size;
@@ -285,15 +400,18 @@ __device__ void coop_solve_chunk(const FilterParams& P, const CoopCtx<KIND>& C, 
     wg_sync_global();                                          // the models (global memory) are read by this workgroup's other waves
 }
 
-// ---- the next batch: whole iterations of the chunk from chunk_c on, at most b_cap models, inside the iteration budget
+// ---- the next batch: whole iterations of the chunk from chunk_c on, at most b_cap models, inside the iteration budget.  The matrices
+// the residuals are taken with -- the model itself (F, H) or F = K2^-T E K1^-1 -- go to the pair's global array as 8-byte agent
+// atomics (slice tasks elsewhere read them) and to this workgroup's slice scratch.
 template <int KIND>
-__device__ void coop_form_batch(const CoopCtx<KIND>& C, CoopS& S, unsigned char* smem, uint32_t tid)
+__device__ __attribute__((noinline)) void coop_form_batch(const CoopCtx<KIND>& C, CoopS& S, unsigned char* smem, uint32_t tid)
 {
     constexpr int MS = (KIND == 2) ? 90 : 27;
     if (tid == 0) {
         uint32_t c = S.chunk_c, n = 0;
         const uint32_t c0 = c;
-        while (c < S.chunk_n && S.chunk_iter0 + c < S.nIter) {
+        const uint32_t budget = S.nIter + (S.n_inl == 0 ? S.reserve : 0u);       // (see coop_solve_chunk)
+        while (c < S.chunk_n && S.chunk_iter0 + c < budget) {
             const uint32_t nm = S.nm[c];
             if (c > c0 && n + nm > S.b_cap) break;
             for (uint32_t k = 0; k < nm; ++k) { S.bj_c[n + k] = (uint8_t)c; S.bj_k[n + k] = (uint8_t)k; }
@@ -302,8 +420,6 @@ __device__ void coop_form_batch(const CoopCtx<KIND>& C, CoopS& S, unsigned char*
         S.b_c0 = c0; S.b_c1 = c; S.b_n = n;
     }
     r3dm_syncthreads();
-    // the matrices the residuals are taken with: the model itself (F, H) or F = K2^-T E K1^-1 (every thread that needs it derives
-    // the same bits from the same operations)
     if (tid < S.b_n) {
         const double* Mo = C.models + (size_t)S.bj_c[tid] * MS + 9 * (size_t)S.bj_k[tid];
         double M[9], FE[9];
@@ -312,36 +428,46 @@ __device__ void coop_form_batch(const CoopCtx<KIND>& C, CoopS& S, unsigned char*
         if (KIND == 2) f_from_e(M, S.kinv, S.kinv + 9, FE);
         double* bm_l = reinterpret_cast<double*>(smem + kCoopBmOff) + 9 * tid;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) { const double v = (KIND == 2) ? FE[e] : M[e]; bm_l[e] = v; C.bm[9 * tid + e] = v; }
+        for (int e = 0; e < 9; ++e) {
+            const double v = (KIND == 2) ? FE[e] : M[e];
+            bm_l[e] = v;
+            __hip_atomic_store(reinterpret_cast<gu64*>(C.bm + 9 * tid + e), (gu64)__double_as_longlong(v), RLX_AGENT);
+        }
     }
     r3dm_syncthreads();
 }
 
-// ---- one slice of the batch: residuals of the slice's matches for all models, histogram + count per model into the slice's slot
+// ---- one slice of a batch: residuals of the slice's matches for all models, histogram + count per model into the slice's slot.
+// Uses the slice scratch of the LDS only (never CoopS): a leader runs it for other pairs while it waits for its own slices.
+struct CoopSliceArgs { uint32_t pt_off, lo, hi, slot, b_n; double maxThreshold; long long hist_base; const double* bm_g; };
+
 template <int KIND>
-__device__ void coop_eval_slice(const FilterParams& P, const CoopCtx<KIND>& C, unsigned char* smem, uint32_t slice, uint32_t b_n,
-                                bool bm_in_lds, uint32_t tid)
+__device__ __attribute__((noinline)) void coop_eval_slice(const FilterParams& P, const CoopSliceArgs& A, unsigned char* smem, bool bm_in_lds, uint32_t tid)
 {
-    const uint32_t lane = tid & 63u;
+    const uint32_t lane = tid & 63u, b_n = A.b_n;
     double* bm_l = reinterpret_cast<double*>(smem + kCoopBmOff);
     uint32_t* cnt_l = reinterpret_cast<uint32_t*>(smem + kCoopCntOff);
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kCoopHdr);                    // [b_n][512]: bins 2w (low half), 2w + 1 (high half)
-    if (!bm_in_lds) for (uint32_t e = tid; e < 9 * b_n; e += kCoopNT) bm_l[e] = C.bm[e];
+    if (!bm_in_lds)
+        for (uint32_t e = tid; e < 9 * b_n; e += kCoopNT)
+            bm_l[e] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const gu64*>(A.bm_g + e), RLX_AGENT));
     if (tid < (uint32_t)kCoopB) cnt_l[tid] = 0u;
     for (uint32_t e = tid; e < b_n * 512u; e += kCoopNT) hist[e] = 0u;
     r3dm_syncthreads();
-    const uint32_t lo = slice * C.slice_len;
-    uint32_t hi = lo + C.slice_len; if (hi > C.m) hi = C.m;
-    const double maxThreshold = C.maxThreshold;
-    for (uint32_t base = lo; base < hi; base += 2u * kCoopNT) {
+    const __amdgpu_buffer_rsrc_t rp = coop_rsrc(P.pts_scratch);
+    const double maxThreshold = A.maxThreshold;
+    for (uint32_t base = A.lo; base < A.hi; base += 2u * kCoopNT) {
         double px[2][4]; bool valid[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const uint32_t p = base + (uint32_t)kCoopNT * (uint32_t)u + tid;
-            valid[u] = p < hi;
-            const size_t pp = 4 * (size_t)(valid[u] ? p : lo);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) px[u][e] = C.pt[pp + e];
+            valid[u] = p < A.hi;
+            const uint32_t off = A.pt_off + 32u * (valid[u] ? p : A.lo);
+            const u32x4 a = ld16_sc1(rp, off), b = ld16_sc1(rp, off + 16u);
+            px[u][0] = __longlong_as_double((long long)(((unsigned long long)a.y << 32) | a.x));
+            px[u][1] = __longlong_as_double((long long)(((unsigned long long)a.w << 32) | a.z));
+            px[u][2] = __longlong_as_double((long long)(((unsigned long long)b.y << 32) | b.x));
+            px[u][3] = __longlong_as_double((long long)(((unsigned long long)b.w << 32) | b.z));
         }
         for (uint32_t j = 0; j < b_n; ++j) {
             double M[9];
@@ -353,7 +479,7 @@ __device__ void coop_eval_slice(const FilterParams& P, const CoopCtx<KIND>& C, u
                 const double r = coop_residual<KIND>(M, px[u][0], px[u][1], px[u][2], px[u][3]);
                 const bool in = valid[u] && (r <= maxThreshold);
                 if (in) {
-                    long long bin = (__double_as_longlong(r) >> kHistShift) - C.hist_base;
+                    long long bin = (__double_as_longlong(r) >> kHistShift) - A.hist_base;
                     bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
                     atomicAdd(&hist[j * 512u + (uint32_t)(bin >> 1)], (bin & 1) ? 0x10000u : 1u);
                 }
@@ -363,18 +489,166 @@ __device__ void coop_eval_slice(const FilterParams& P, const CoopCtx<KIND>& C, u
         }
     }
     r3dm_syncthreads();
-    uint32_t* gh = P.coop_hist + (size_t)(C.hoff + slice) * kCoopB * 512;
-    uint32_t* gc = P.coop_cnt + (size_t)(C.hoff + slice) * kCoopB;
-    if (tid < b_n) gc[tid] = cnt_l[tid];
-    // (histograms of models without a match inside the bound are never read: their count says so)
-    for (uint32_t j = 0; j < b_n; ++j) {
-        if (cnt_l[j] == 0u) continue;
-        gh[j * 512u + tid] = hist[j * 512u + tid];             // kCoopNT == 512 words per model
+    // the slot, write-through: counts as 8-byte atomics, histograms of the models that have a match inside the bound as 16-byte
+    // sc1 stores (128 threads per model, four models per pass); histograms of the other models are never read
+    gu64* gc = reinterpret_cast<gu64*>(P.coop_cnt + (size_t)A.slot * kCoopB);
+    if (tid < (uint32_t)kCoopB / 2) __hip_atomic_store(&gc[tid], (gu64)cnt_l[2 * tid] | ((gu64)cnt_l[2 * tid + 1] << 32), RLX_AGENT);
+    {
+        const __amdgpu_buffer_rsrc_t rh = coop_rsrc(P.coop_hist + (size_t)A.slot * kCoopB * 512);
+        const uint32_t sub = tid >> 7, w4 = tid & 127u;
+        for (uint32_t j = sub; j < b_n; j += 4u) {
+            if (cnt_l[j] == 0u) continue;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&hist[j * 512u + 4u * w4]);
+            st16_sc1(rh, (j * 512u + 4u * w4) * 4u, v);
+        }
     }
-    static_assert(kCoopNT == 512, "one histogram word per thread");
+    DRAIN_VMEM();                                              // every storing wave, before the barrier in front of the arrival count
+    r3dm_syncthreads();
 }
 
-// ---- full evaluation of ONE model by one workgroup: residuals of all matches, compaction of those within the bound, sort, NFA scan
+// a slice task from the queue: everything about it comes from the pair's published record
+template <int KIND>
+__device__ __attribute__((noinline)) void coop_run_task(const FilterParams& P, unsigned char* smem, uint32_t task, uint32_t tid)
+{
+    const uint32_t cp = task >> 5, slice = task & 31u;
+    CoopPub* pub = reinterpret_cast<CoopPub*>(P.coop_pub) + cp;
+    const unsigned long long t0 = PROF_NOW();
+    CoopSliceArgs A;
+    const gu64 ms = QLOAD(&pub->m_slice), hb = QLOAD(&pub->hoff_bn);
+    const uint32_t m = (uint32_t)ms, slice_len = (uint32_t)(ms >> 32);
+    A.pt_off = (uint32_t)QLOAD(&pub->pt);
+    A.maxThreshold = __longlong_as_double((long long)QLOAD(&pub->max_thr_bits));
+    A.hist_base = (long long)QLOAD(&pub->hist_base);
+    A.lo = slice * slice_len; A.hi = A.lo + slice_len; if (A.hi > m) A.hi = m;
+    A.slot = (uint32_t)hb + slice; A.b_n = (uint32_t)(hb >> 32);
+    A.bm_g = P.coop_bm + (size_t)cp * kCoopB * 9;
+    coop_eval_slice<KIND>(P, A, smem, false, tid);
+    if (tid == 0) __hip_atomic_fetch_add(&pub->arrived, (gu64)1, RLX_AGENT);
+    PROF_PUT(cp, 3, PROF_NOW() - t0);
+#ifdef R3DM_DEVTOOLS
+    if (P.coop_prof && tid == 0) {                             // [12] sum and [14] max of publish -> start, [13] max slice duration
+        const unsigned long long d = t0 - QLOAD(&pub->pad[0]), dur = PROF_NOW() - t0;
+        atomicAdd(&P.coop_prof[16 * (size_t)cp + 12], d);
+        atomicMax(&P.coop_prof[16 * (size_t)cp + 14], d);
+        atomicMax(&P.coop_prof[16 * (size_t)cp + 13], dur);
+    }
+#endif
+}
+
+// ---- bitonic sort of the (residual, index) lists in global memory, blocks of E entries per thread in registers.
+// The stages `size_from .. size_to` of the network on the block of kCoopNT * E entries that starts at entry i0 (directions from the
+// GLOBAL index, so blocks sorted one after the other come out alternately ascending / descending, as the merge stages behind them
+// need).  Strides >= the block are not this routine's business.  Same exchange rules as wg_sort_regs (kernels_filter.hip).
+template <int E>
+__device__ __forceinline__ void coop_sort_block(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx, uint32_t i0,
+                                                uint32_t size_from, uint32_t size_to, uint32_t total, uint32_t tid)
+{
+    constexpr uint32_t BLK = (uint32_t)kCoopNT * (uint32_t)E;
+    unsigned long long k[E];
+    uint32_t x[E];
+    const uint32_t base = tid * (uint32_t)E;
+    unsigned long long* kb = keys + i0;
+    uint32_t* xb = sidx + i0;
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        const uint32_t i = i0 + base + (uint32_t)s;
+        const bool live = i < total || size_from > 2u;          // (merge stages: the padding was materialised by the block sorts)
+        k[s] = live ? kb[base + s] : ~0ull;
+        x[s] = live ? xb[base + s] : 0xFFFFFFFFu;
+    }
+    for (uint32_t size = size_from; size <= size_to; size <<= 1) {
+        uint32_t stride = size >> 1;
+        if (stride >= BLK) stride = BLK >> 1;
+        // ---- distances that cross waves: through memory (every thread parks its entries, reads the partner's)
+        for (; stride >= 64u * E; stride >>= 1) {
+            wg_sync_t<true>();
+#pragma unroll
+            for (int s = 0; s < E; ++s) { kb[base + s] = k[s]; xb[base + s] = x[s]; }
+            wg_sync_t<true>();
+#pragma unroll
+            for (int s = 0; s < E; ++s) {
+                const uint32_t li = base + (uint32_t)s, i = i0 + li;
+                const unsigned long long ok = kb[li ^ stride];
+                const uint32_t ox = xb[li ^ stride];
+                const bool lower = (i & stride) == 0u, up = (i & size) == 0u;
+                const bool mine_gt = pair_gt(k[s], x[s], ok, ox);
+                if (mine_gt == (lower == up)) { k[s] = ok; x[s] = ox; }
+            }
+        }
+        // ---- distances inside the wave
+        for (; stride >= (uint32_t)E; stride >>= 1) {
+            const int lane_xor = (int)(stride / (uint32_t)E);
+#pragma unroll
+            for (int s = 0; s < E; ++s) {
+                const uint32_t i = i0 + base + (uint32_t)s;
+                const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)k[s], lane_xor);
+                const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(k[s] >> 32), lane_xor);
+                const uint32_t ox = (uint32_t)__shfl_xor((int)x[s], lane_xor);
+                const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;
+                const bool lower = (i & stride) == 0u, up = (i & size) == 0u;
+                const bool mine_gt = pair_gt(k[s], x[s], ok, ox);
+                if (mine_gt == (lower == up)) { k[s] = ok; x[s] = ox; }
+            }
+        }
+        // ---- distances inside the thread
+#pragma unroll
+        for (int ST = E / 2; ST >= 1; ST >>= 1) {
+            if ((uint32_t)ST < size) {
+#pragma unroll
+                for (int s = 0; s < E; ++s) {
+                    if ((s & ST) == 0) {
+                        const bool up = ((i0 + base + (uint32_t)s) & size) == 0u;
+                        const bool gt = pair_gt(k[s], x[s], k[s | ST], x[s | ST]);
+                        if (gt == up) {
+                            const unsigned long long tk = k[s]; k[s] = k[s | ST]; k[s | ST] = tk;
+                            const uint32_t tx = x[s]; x[s] = x[s | ST]; x[s | ST] = tx;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    wg_sync_t<true>();
+#pragma unroll
+    for (int s = 0; s < E; ++s) { kb[base + s] = k[s]; xb[base + s] = x[s]; }
+    wg_sync_t<true>();
+}
+
+// the whole list: up to 8192 entries in one block of 1 .. 16 entries per thread; longer lists as blocks of 8192 (16 per thread: the
+// 32-per-thread form of the one-workgroup kernel needs more registers than a 512-thread workgroup leaves without spilling into the
+// loops around it) + merge stages whose block-crossing strides run on the plain network
+__device__ void coop_sort(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx, uint32_t total, uint32_t tid)
+{
+    uint32_t cap = 1; while (cap < total) cap <<= 1;
+    constexpr uint32_t BLK = (uint32_t)kCoopNT * 16u;
+    if (cap <= BLK) {
+        switch (cap / (uint32_t)kCoopNT) {
+            case 0: case 1: wg_sort_regs<1, true>(keys, sidx, cap, total, tid); break;
+            case 2: wg_sort_regs<2, true>(keys, sidx, cap, total, tid); break;
+            case 4: wg_sort_regs<4, true>(keys, sidx, cap, total, tid); break;
+            case 8: wg_sort_regs<8, true>(keys, sidx, cap, total, tid); break;
+            default: wg_sort_regs<16, true>(keys, sidx, cap, total, tid); break;
+        }
+        return;
+    }
+    for (uint32_t i0 = 0; i0 < cap; i0 += BLK) coop_sort_block<16>(keys, sidx, i0, 2u, BLK, total, tid);
+    for (uint32_t size = 2u * BLK; size <= cap; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride >= BLK; stride >>= 1) {
+            for (uint32_t tI = tid; tI < (cap >> 1); tI += kCoopNT) {
+                const uint32_t lo = 2 * tI - (tI & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                const uint32_t ai = sidx[lo], bi = sidx[hi];
+                if (pair_gt(a, ai, b, bi) == up) { keys[lo] = b; keys[hi] = a; sidx[lo] = bi; sidx[hi] = ai; }
+            }
+            wg_sync_t<true>();
+        }
+        for (uint32_t i0 = 0; i0 < cap; i0 += BLK) coop_sort_block<16>(keys, sidx, i0, size, size, total, tid);
+    }
+}
+
+// ---- full evaluation of ONE model by the leader: residuals of all matches, compaction of those within the bound, sort, NFA scan
 // (the evaluation block of acransac_body with its lists in global memory).  Returns the model's NFA and inlier count.
 template <int KIND>
 __device__ void coop_full_eval(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, const double* M /* residual matrix */,
@@ -427,35 +701,7 @@ __device__ void coop_full_eval(const FilterParams& P, const CoopCtx<KIND>& C, Co
     double nfa = __builtin_huge_val();
     uint32_t kbest = SS;
     if (total > SS) {
-        uint32_t cap = 1; while (cap < total) cap <<= 1;
-        bool sorted = true;
-        switch (cap / (uint32_t)NT) {
-            case 0: case 1: wg_sort_regs<1, true>(keys, sidx, cap, total, tid); break;
-            case 2: wg_sort_regs<2, true>(keys, sidx, cap, total, tid); break;
-            case 4: wg_sort_regs<4, true>(keys, sidx, cap, total, tid); break;
-            case 8: wg_sort_regs<8, true>(keys, sidx, cap, total, tid); break;
-            case 16: wg_sort_regs<16, true>(keys, sidx, cap, total, tid); break;
-            case 32: wg_sort_regs<32, true>(keys, sidx, cap, total, tid); break;
-            default: sorted = false; break;
-        }
-        if (!sorted) {                                          // longer lists: the plain network in global memory
-            for (uint32_t q = total + tid; q < cap; q += NT) { keys[q] = ~0ull; sidx[q] = 0xFFFFFFFFu; }
-            wg_sync_t<true>();
-            for (uint32_t size = 2; size <= cap; size <<= 1) {
-                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (uint32_t tI = tid; tI < (cap >> 1); tI += NT) {
-                        const uint32_t lo = 2 * tI - (tI & (stride - 1));
-                        const uint32_t hi = lo + stride;
-                        const bool up = ((lo & size) == 0);
-                        const unsigned long long x = keys[lo], y = keys[hi];
-                        const uint32_t xi = sidx[lo], yi = sidx[hi];
-                        const bool gt = (x > y) || (x == y && xi > yi);
-                        if (gt == up) { keys[lo] = y; keys[hi] = x; sidx[lo] = yi; sidx[hi] = xi; }
-                    }
-                    wg_sync_t<true>();
-                }
-            }
-        }
+        coop_sort(keys, sidx, total, tid);
         // bestNFA: k = SS + 1 .. total, first minimum wins
         double bv = __builtin_huge_val(); uint32_t bk = 0xFFFFFFFFu;
         for (uint32_t kk = SS + 1 + tid; kk <= total; kk += NT) {
@@ -483,29 +729,48 @@ __device__ void coop_full_eval(const FilterParams& P, const CoopCtx<KIND>& C, Co
     nfa_out = nfa; kbest_out = kbest;
 }
 
-// ---- merged histograms -> count and NFA bound of every model of the batch (one wave per model, eight at a time)
+// ---- merged histograms -> count and NFA bound of every model of the batch (one wave per model, eight at a time).  The slot counts
+// of all slices land in LDS first (one pass, every load in flight at once); a model's histograms are then fetched four slices at a
+// time before any of them is used (the first form chained count -> branch -> histogram per slice: ~1.7 us per model in load latency).
 template <int KIND>
-__device__ void coop_batch_bounds(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, uint32_t tid)
+__device__ void coop_batch_bounds(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, unsigned char* smem, uint32_t tid)
 {
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint32_t* gh = P.coop_hist + (size_t)C.hoff * kCoopB * 512;
-    const uint32_t* gc = P.coop_cnt + (size_t)C.hoff * kCoopB;
+    const uint32_t lane = tid & 63u, wave = tid >> 6, G = C.G;
+    uint32_t* cnt_all = reinterpret_cast<uint32_t*>(smem + kCoopAllCntOff);          // [G][kCoopB]
+    {
+        const gu64* gc = reinterpret_cast<const gu64*>(P.coop_cnt + (size_t)C.hoff * kCoopB);
+        for (uint32_t e = tid; e < G * (uint32_t)kCoopB / 2u; e += kCoopNT) {
+            const gu64 v = QLOAD(&gc[e]);
+            cnt_all[2 * e] = (uint32_t)v; cnt_all[2 * e + 1] = (uint32_t)(v >> 32);
+        }
+    }
+    r3dm_syncthreads();
+    const __amdgpu_buffer_rsrc_t rh = coop_rsrc(P.coop_hist + (size_t)C.hoff * kCoopB * 512);
     for (uint32_t j = wave; j < S.b_n; j += kCoopNW) {
         uint32_t total = 0;
-        for (uint32_t s = 0; s < C.G; ++s) total += gc[(size_t)s * kCoopB + j];
+        for (uint32_t s = 0; s < G; ++s) total += cnt_all[s * kCoopB + j];
         double wmin = __builtin_huge_val();
         if (total > SS) {
             uint32_t h[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = 0u;
-            for (uint32_t s = 0; s < C.G; ++s) {
-                if (gc[(size_t)s * kCoopB + j] == 0u) continue;                       // (slot not written)
-                const uint4* src = reinterpret_cast<const uint4*>(gh + ((size_t)s * kCoopB + j) * 512u + 8u * lane);
-                const uint4 a = src[0], b = src[1];
-                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            for (uint32_t s0 = 0; s0 < G; s0 += 4u) {
+                u32x4 a[4], b[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { h[2 * i] += w[i] & 0xFFFFu; h[2 * i + 1] += w[i] >> 16; }
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t s = s0 + u;
+                    const bool have = s < G && cnt_all[(s < G ? s : 0u) * kCoopB + j] != 0u;      // (slot not written otherwise)
+                    const uint32_t off = (((have ? s : 0u) * (uint32_t)kCoopB + j) * 512u + 8u * lane) * 4u;
+                    a[u] = ld16_sc1(rh, off); b[u] = ld16_sc1(rh, off + 16u);
+                    if (!have) { a[u] = u32x4{0u, 0u, 0u, 0u}; b[u] = u32x4{0u, 0u, 0u, 0u}; }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t w[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { h[2 * i] += w[i] & 0xFFFFu; h[2 * i + 1] += w[i] >> 16; }
+                }
             }
             uint32_t run = 0;
 #pragma unroll
@@ -536,85 +801,86 @@ __device__ void coop_batch_bounds(const FilterParams& P, const CoopCtx<KIND>& C,
 }
 
 // ---- walk the batch in the reference's order (the evaluation loop of acransac_body, a model's evaluation replaced by its
-// merged count / bound and, for the few models that can win, coop_full_eval)
+// merged count / bound and, for the few models that can win, coop_full_eval).  Every thread walks with its own copy of the scalars
+// the walk changes (all threads hold the same values: everything comes from LDS that only barriers separate from its writer);
+// a model that is skipped costs no barrier, thread 0 writes the scalars back where the workgroup meets anyway.
 template <int KIND>
-__device__ void coop_decide(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, uint32_t tid)
+__device__ __attribute__((noinline)) void coop_decide(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, unsigned char* smem, uint32_t tid)
 {
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);
     constexpr int MS = (KIND == 2) ? 90 : 27;
     constexpr int NT = kCoopNT;
     const uint32_t lane = tid & 63u, wave = tid >> 6, m = C.m;
     [[maybe_unused]] const uint32_t item = C.item;                 // (FCHECK reports it)
-    if (S.b_n) coop_batch_bounds<KIND>(P, C, S, tid);
+    const unsigned long long pt0 = PROF_NOW();
+    if (S.b_n) coop_batch_bounds<KIND>(P, C, S, smem, tid);
+    const unsigned long long pt1 = PROF_NOW();
+    PROF_PUT(C.cp, 5, pt1 - pt0);
+    [[maybe_unused]] unsigned long long prof_full = 0;
+    // walk-local copies
+    double minNFA = S.minNFA;
+    uint32_t acMode = S.acMode, n_models = S.n_models, n_inl = S.n_inl, nIter = S.nIter, reserve = S.reserve, pool_size = S.pool_size;
+    uint32_t iters_done = S.iters_done;
+    const uint32_t chunk_iter0 = S.chunk_iter0, c1 = S.b_c1;
     bool pool_changed = false;
     uint32_t j = 0;
     uint32_t c = S.b_c0;
-    const uint32_t c1 = S.b_c1;
     for (; c < c1 && !pool_changed; ++c) {
-        const uint32_t it = S.chunk_iter0 + c;
+        const uint32_t it = chunk_iter0 + c;
         const uint32_t nm = S.nm[c];
         bool better = false;
         for (uint32_t k = 0; k < nm; ++k, ++j) {
             const uint32_t total = S.tot[j];
-            bool ac = S.acMode != 0;
+            bool ac = acMode != 0;
             if (!ac && (double)total > 2.5 * SS) ac = true;
-            double nfa = __builtin_huge_val();
-            uint32_t kbest = SS;
-            const double* Mo = C.models + (size_t)c * MS + 9 * (size_t)k;       // the model itself (E for KIND 2)
-            if (ac && total > SS) {
-                const double bound = C.loge0 + S.bnd[j] - S.eps_T;
-                const bool hopeless = !R3DM_DBG(P) && (S.minNFA < __builtin_huge_val()) && (bound - 1.0e-6 >= S.minNFA);
-                if (!hopeless) {
-                    double Mr[9];
-                    const double* bm_g = C.bm + 9 * (size_t)j;
+            acMode = ac ? 1u : 0u;
+            n_models += 1;
+            if (!(ac && total > SS)) continue;
+            const double bound = C.loge0 + S.bnd[j] - S.eps_T;
+            const bool hopeless = !R3DM_DBG(P) && (minNFA < __builtin_huge_val()) && (bound - 1.0e-6 >= minNFA);
+            if (hopeless) continue;
+            // ---- a model that can win: the full evaluation (the workgroup meets here)
+            double Mr[9];
+            const double* bm_g = C.bm + 9 * (size_t)j;
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) Mr[e] = bm_g[e];
-                    uint32_t total2 = 0;
-                    coop_full_eval<KIND>(P, C, S, Mr, tid, nfa, kbest, total2);
-                    FCHECK(total2 == total, 9, total2, total);                     // the slices and the full pass count the same matches
-                    FCHECK(bound - 1.0e-6 <= nfa, 8, kbest, total);               // the sort-skipping bound really is one
-                }
-            }
-            const bool improve = ac && (nfa < S.minNFA);
-            if (improve) {
+            for (int e = 0; e < 9; ++e) Mr[e] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const gu64*>(bm_g + e), RLX_AGENT));
+            double nfa; uint32_t kbest, total2 = 0;
+            const unsigned long long pf0 = PROF_NOW();
+            coop_full_eval<KIND>(P, C, S, Mr, tid, nfa, kbest, total2);
+            prof_full += PROF_NOW() - pf0;
+            PROF_PUT(C.cp, 7, 1);
+            FCHECK(total2 == total, 9, total2, total);                 // the slices and the full pass count the same matches
+            FCHECK(bound - 1.0e-6 <= nfa, 8, kbest, total);           // the sort-skipping bound really is one
+            if (nfa < minNFA) {
                 for (uint32_t q = tid; q < kbest; q += NT) C.inl[q] = C.sidx[q];
                 better = true;
-            }
-            wg_sync_t<true>();
-            if (tid == 0) {
-                S.acMode = ac ? 1u : 0u;
-                S.n_models += 1;
-                if (improve) {
-                    S.minNFA = nfa;
-                    S.n_inl = kbest;
+                minNFA = nfa; n_inl = kbest;
+                wg_sync_t<true>();
+                if (tid == 0) {
+                    const double* Mo = C.models + (size_t)c * MS + 9 * (size_t)k;     // the model itself (E for KIND 2)
                     S.errorMax = __longlong_as_double((long long)C.keys[kbest - 1]);
 #pragma unroll
                     for (int e = 0; e < 9; ++e) S.bestF[e] = Mo[e];
                 }
             }
-            r3dm_syncthreads();
         }
-        // ---- end of iteration `it`: ACRANSAC's pool / budget update.  Thread 0 is about to change the loop bounds the other waves
-        // read right after the previous iteration's last barrier; a sample without real solutions (nm == 0) needs its own.
-        if (nm == 0) r3dm_syncthreads();
-        if (tid == 0) {
-            S.iters_done = it + 1;
-            S.flag = 0;
-            const bool trigger = (better && S.minNFA < 0.0) || (it + 1 == S.nIter && S.reserve != 0);
-            if (trigger) {
-                if (S.n_inl == 0) { S.nIter += 1; S.reserve -= 1; }
-                else {
-                    S.flag = 1;
-                    S.pool_size = S.n_inl;
-                    if (S.reserve) { S.nIter = it + 1 + S.reserve; S.reserve = 0; }
-                }
+        // ---- end of iteration `it`: ACRANSAC's pool / budget update
+        iters_done = it + 1;
+        bool rebuild = false;
+        const bool trigger = (better && minNFA < 0.0) || (it + 1 == nIter && reserve != 0);
+        if (trigger) {
+            if (n_inl == 0) { nIter += 1; reserve -= 1; }
+            else {
+                rebuild = true;
+                pool_size = n_inl;
+                if (reserve) { nIter = it + 1 + reserve; reserve = 0; }
             }
         }
-        r3dm_syncthreads();
-        if (S.flag) {
+        if (rebuild) {
             // new sampling pool = the inlier SET in ascending index order (same rule as acransac_body / oracle/acransac.c)
-            const uint32_t ni = S.n_inl;
+            const uint32_t ni = n_inl;
             uint32_t* flags = C.sidx;                                // sort scratch, free between models
+            wg_sync_t<true>();
             for (uint32_t q = tid; q < m; q += NT) flags[q] = 0u;
             wg_sync_t<true>();
             for (uint32_t q = tid; q < ni; q += NT) flags[C.inl[q]] = 1u;
@@ -635,18 +901,21 @@ __device__ void coop_decide(const FilterParams& P, const CoopCtx<KIND>& C, CoopS
                 r3dm_syncthreads();
             }
             pool_changed = true;
-            wg_fence();
         }
-        r3dm_syncthreads();
-        if (it + 1 >= S.nIter) { ++c; break; }
+        if (it + 1 >= nIter) { ++c; break; }
     }
+    r3dm_syncthreads();                                             // every thread has read the batch's LDS tables
     if (tid == 0) {
-        S.iter = S.chunk_iter0 + c;
+        S.minNFA = minNFA; S.acMode = acMode; S.n_models = n_models; S.n_inl = n_inl; S.nIter = nIter; S.reserve = reserve;
+        S.pool_size = pool_size; S.iters_done = iters_done;
+        S.iter = chunk_iter0 + c;
         S.chunk_c = c;
         if (pool_changed) { S.chunk_valid = 0; S.b_cap = 12; }
         else { const uint32_t nb = S.b_cap * 2; S.b_cap = nb > (uint32_t)kCoopB ? (uint32_t)kCoopB : nb; }
     }
     wg_sync_global();
+    PROF_PUT(C.cp, 6, prof_full);
+    PROF_PUT(C.cp, 8, PROF_NOW() - pt1 - prof_full);
 }
 
 // ---- result of a pair (the epilogue of acransac_body)
@@ -688,11 +957,107 @@ __device__ void coop_finish(const FilterParams& P, const CoopCtx<KIND>& C, CoopS
     P.iters[2 * (size_t)item + 1] = S.n_models;
 }
 
-// LDS <-> global copies of the pair state (everything in front of CoopS::copy_end)
-__device__ __forceinline__ void coop_state_copy(uint32_t* dst, const uint32_t* src, uint32_t tid)
+// ---- a pair from start-up to result, led by this workgroup
+template <int KIND>
+__device__ void coop_lead_pair(const FilterParams& P, unsigned char* smem, uint32_t cp, uint32_t tid)
 {
-    constexpr uint32_t W = (uint32_t)(offsetof(CoopS, copy_end) / 4);
-    for (uint32_t e = tid; e < W; e += kCoopNT) dst[e] = src[e];
+    CoopS& S = *reinterpret_cast<CoopS*>(smem);
+    uint32_t* q = P.coop_q;
+    const CoopSched Q = coop_sched(q);
+    CoopCtx<KIND> C;
+    coop_ctx<KIND>(P, cp, C);
+    const unsigned long long t_start = PROF_NOW();
+    coop_init<KIND>(P, C, S, tid);
+    PROF_PUT(cp, 0, PROF_NOW() - t_start);
+    bool decide_first = false;
+    for (uint32_t turn = 0;; ++turn) {
+        if (decide_first) coop_decide<KIND>(P, C, S, smem, tid);
+        decide_first = true;
+        if (S.iter >= S.nIter) break;
+        if (turn > 4u * P.max_iter + 64u) { if (tid == 0) coop_report_stall(q, 4u, cp); break; }   // (every turn consumes an iteration or draws a chunk)
+        if (!S.chunk_valid || S.chunk_c >= S.chunk_n) {
+            const unsigned long long t0 = PROF_NOW();
+            coop_solve_chunk<KIND>(P, C, S, smem, tid);
+            PROF_PUT(cp, 1, PROF_NOW() - t0);
+        }
+        const unsigned long long t1 = PROF_NOW();
+        coop_form_batch<KIND>(C, S, smem, tid);
+        const uint32_t b_n = S.b_n;
+        if (b_n == 0) continue;                                    // iterations without a model: only their bookkeeping
+        PROF_PUT(cp, 9, 1); PROF_PUT(cp, 11, b_n);
+        if (C.G > 1u) {
+            DRAIN_VMEM();                                          // the batch matrices (and, first batch, the points and the record)
+            r3dm_syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(&C.pub->hoff_bn, (gu64)C.hoff | ((gu64)b_n << 32), RLX_AGENT);
+                __hip_atomic_store(&C.pub->arrived, (gu64)0, RLX_AGENT);
+#ifdef R3DM_DEVTOOLS
+                if (P.coop_prof) __hip_atomic_store(&C.pub->pad[0], (gu64)wall_clock64(), RLX_AGENT);
+#endif
+                DRAIN_VMEM();
+            }
+            r3dm_syncthreads();
+            // lane s - 1 of wave 0 hands slice s to an idle worker (its mailbox), or -- nobody idle -- to the overflow ring
+            if (tid < C.G - 1u) {
+                const uint32_t task = (cp << 5) | (tid + 1u);
+                bool placed = false;
+                for (int tries = 0; tries < 8 && !placed; ++tries) {
+                    uint32_t id;
+                    if (!ring_pop(Q.idle, id)) break;
+                    placed = mbox_cas(&Q.mbox[32u * id], kMboxEmpty, task + 1u);           // (fails on a worker that has retired meanwhile)
+                }
+                if (!placed) ring_push(q, Q.ov, task);
+            }
+        }
+        PROF_PUT(cp, 2, PROF_NOW() - t1);
+        {
+            const unsigned long long t2 = PROF_NOW();
+            CoopSliceArgs A;
+            A.pt_off = (uint32_t)((const char*)C.pt - (const char*)P.pts_scratch);
+            A.lo = 0u; A.hi = C.slice_len < C.m ? C.slice_len : C.m;
+            A.slot = C.hoff; A.b_n = b_n; A.maxThreshold = C.maxThreshold; A.hist_base = C.hist_base; A.bm_g = C.bm;
+            coop_eval_slice<KIND>(P, A, smem, true, tid);
+            PROF_PUT(cp, 3, PROF_NOW() - t2);
+        }
+        if (C.G > 1u) {
+            // wait for the other slices; meanwhile run slice tasks from the queue (this pair's or any other's)
+            const unsigned long long t3 = PROF_NOW();
+            const unsigned long long w0 = tid == 0 ? (unsigned long long)wall_clock64() : 0ull;
+            bool stalled = false;
+            for (;;) {
+                if (tid == 0) {
+                    // the pair's own arrival word is looked at every ~0.4 us, the shared words (overflow ring, stall flag) every ~3 us
+                    uint32_t v = kCoopNoTask;
+                    for (uint32_t spins = 1;; ++spins) {
+                        if (QLOAD(&C.pub->arrived) >= (gu64)(C.G - 1u)) { v = kCoopDone; break; }
+                        if ((spins & 7u) == 0u) {
+                            if (coop_stalled(q)) { v = kCoopStall; break; }
+                            if (ring_pop(Q.ov, v)) break;
+                            v = kCoopNoTask;
+                            if ((unsigned long long)wall_clock64() - w0 > kCoopStallTicks) { coop_report_stall(q, 2u, cp); v = kCoopStall; break; }
+                        }
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                    S.sh_task = v;
+                }
+                r3dm_syncthreads();
+                const uint32_t t = S.sh_task;
+                r3dm_syncthreads();
+                if (t == kCoopDone) break;
+                if (t == kCoopStall) { stalled = true; break; }
+                if (t != kCoopNoTask) coop_run_task<KIND>(P, smem, t, tid);
+            }
+            if (stalled) break;                                    // (the host reports the call as failed)
+            PROF_PUT(cp, 4, PROF_NOW() - t3);
+        }
+    }
+    coop_finish<KIND>(P, C, S, tid);
+    PROF_PUT(cp, 10, PROF_NOW() - t_start);
+    r3dm_syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_sub(&q[kQPot], C.G, RLX_AGENT);
+        __hip_atomic_fetch_add(&q[kQDone], 1u, RLX_AGENT);
+    }
 }
 
 template <int KIND>
@@ -700,86 +1065,53 @@ __global__ __launch_bounds__(kCoopNT, 1)
 void acransac_coop_kernel(const FilterParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t sh_task, sh_last;
     CoopS& S = *reinterpret_cast<CoopS*>(smem);
     const uint32_t tid = threadIdx.x;
     uint32_t* q = P.coop_q;
+    const CoopSched Q = coop_sched(q);
+    const uint32_t me = blockIdx.x;
     for (;;) {
-        // ---- next task
+        // ---- what next: a task nobody could be found for; else a pair nobody leads yet; else wait at the mailbox, retire, or leave
         if (tid == 0) {
-            uint32_t v = kCoopNoTask;
-            for (;;) {
-                if (coop_pop(q, v)) break;
-                v = kCoopNoTask;
-                if (QLOAD(&q[2]) == q[5]) break;                                   // every pair is finished
-                const uint32_t a = QLOAD(&q[4]), pot = QLOAD(&q[3]);
-                if (a > pot && atomicCAS(&q[4], a, a - 1u) == a) break;            // more workers than tasks can exist: retire
-                __builtin_amdgcn_s_sleep(16);
+            uint32_t v = kCoopNoTask, what = 0;
+            const uint32_t n_pairs = q[5];
+            if (coop_stalled(q)) what = 0;
+            else if (ring_pop(Q.ov, v)) what = 1;
+            else {
+                if (QLOAD(&q[kQNextPair]) < n_pairs) {
+                    const uint32_t t = __hip_atomic_fetch_add(&q[kQNextPair], 1u, RLX_AGENT);
+                    if (t < n_pairs) { v = P.coop_start[t]; what = 2; }
+                }
+                if (what == 0 && QLOAD(&q[kQDone]) != n_pairs) {
+                    uint32_t* mine = &Q.mbox[32u * me];
+                    __hip_atomic_store(mine, kMboxEmpty, RLX_AGENT);
+                    DRAIN_VMEM();
+                    ring_push(q, Q.idle, me);
+                    const unsigned long long w0 = wall_clock64();
+                    for (uint32_t spins = 1;; ++spins) {
+                        const uint32_t mb = QLOAD(mine);
+                        if (mb != kMboxEmpty) { v = mb - 1u; what = 1; break; }
+                        __builtin_amdgcn_s_sleep(24);                           // ~0.6 us between looks at the (private) line
+                        if ((spins & 31u) != 0u) continue;
+                        // every ~20 us: has the call ended, are there more workers than tasks can exist, has something stalled?
+                        bool leave = coop_stalled(q) || QLOAD(&q[kQDone]) == n_pairs;
+                        if (!leave) {
+                            const uint32_t a = QLOAD(&q[kQActive]), pot = QLOAD(&q[kQPot]);
+                            if (a > pot && mbox_cas(&q[kQActive], a, a - 1u)) leave = true;
+                            if (!leave && (unsigned long long)wall_clock64() - w0 > kCoopStallTicks) { coop_report_stall(q, 3u, me); leave = true; }
+                        }
+                        if (leave && mbox_cas(mine, kMboxEmpty, kMboxRetired)) break;   // (a task that arrived meanwhile is taken on the next look)
+                    }
+                }
             }
-            sh_task = v;
+            S.sh_task = v; S.sh_aux = what;
         }
         r3dm_syncthreads();
-        const uint32_t task = sh_task;
+        const uint32_t task = S.sh_task, what = S.sh_aux;
         r3dm_syncthreads();
-        if (task == kCoopNoTask) return;
-        const uint32_t cp = task >> 5, slice = task & 31u;
-        __threadfence();                                                           // acquire: what the task's publisher wrote
-        CoopCtx<KIND> C;
-        coop_ctx<KIND>(P, cp, C);
-        bool decide_first;
-        if (slice == kCoopInitSlice) {
-            coop_init<KIND>(P, C, S, tid);
-            decide_first = false;
-        } else {
-            coop_eval_slice<KIND>(P, C, smem, slice, C.gs->b_n, false, tid);
-            __threadfence();                                                       // release: the slot
-            r3dm_syncthreads();
-            if (tid == 0) sh_last = (atomicAdd(&C.gs->arrived, 1u) == C.G - 1u) ? 1u : 0u;
-            r3dm_syncthreads();
-            const bool last = sh_last != 0u;
-            r3dm_syncthreads();
-            if (!last) continue;
-            __threadfence();                                                       // acquire: the other slices' slots, the pair state
-            coop_state_copy(reinterpret_cast<uint32_t*>(&S), reinterpret_cast<const uint32_t*>(C.gs), tid);
-            r3dm_syncthreads();
-            decide_first = true;
-        }
-        // ---- this workgroup leads the pair until it hands a batch to the queue and is not the last to arrive
-        for (;;) {
-            if (decide_first) coop_decide<KIND>(P, C, S, tid);
-            decide_first = true;
-            if (S.iter >= S.nIter) {
-                coop_finish<KIND>(P, C, S, tid);
-                r3dm_syncthreads();
-                if (tid == 0) { __threadfence(); atomicSub(&q[3], C.G); atomicAdd(&q[2], 1u); }
-                break;
-            }
-            if (!S.chunk_valid || S.chunk_c >= S.chunk_n) coop_solve_chunk<KIND>(P, C, S, smem, tid);
-            coop_form_batch<KIND>(C, S, smem, tid);
-            if (S.b_n == 0) continue;                                              // iterations without a model: only their bookkeeping
-            const uint32_t b_n = S.b_n;
-            if (C.G > 1u) {
-                coop_state_copy(reinterpret_cast<uint32_t*>(C.gs), reinterpret_cast<const uint32_t*>(&S), tid);
-                if (tid == 0) C.gs->arrived = 0u;
-                __threadfence();                                                   // release: state, batch models, (first batch) the pair's tables
-                r3dm_syncthreads();
-                if (tid == 0) for (uint32_t s = 1; s < C.G; ++s) coop_push(q, (cp << 5) | s);
-            }
-            coop_eval_slice<KIND>(P, C, smem, 0u, b_n, true, tid);
-            bool last = true;
-            if (C.G > 1u) {
-                __threadfence();
-                r3dm_syncthreads();
-                if (tid == 0) sh_last = (atomicAdd(&C.gs->arrived, 1u) == C.G - 1u) ? 1u : 0u;
-                r3dm_syncthreads();
-                last = sh_last != 0u;
-                r3dm_syncthreads();
-                if (last) __threadfence();
-            } else {
-                wg_sync_global();                                                  // the slot is read back by this workgroup's other waves
-            }
-            if (!last) break;                                                      // another workgroup will lead (S in LDS is dropped)
-        }
+        if (what == 0) return;
+        if (what == 1) coop_run_task<KIND>(P, smem, task, tid);
+        else coop_lead_pair<KIND>(P, smem, task, tid);
     }
 }
 

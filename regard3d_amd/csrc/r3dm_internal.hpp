@@ -201,7 +201,6 @@ struct FinalizeParams {
 };
 
 constexpr int kCoopB = 32;                  // models per batch of the cooperative AC-RANSAC kernel, at most
-constexpr uint32_t kCoopStateBytes = 2048;  // global slot of a pair's state
 constexpr uint32_t kCoopMaxG = 30;          // slices per pair, at most (5-bit slice code of a task, 31 = start-up)
 
 struct FilterParams {
@@ -246,14 +245,16 @@ struct FilterParams {
     const uint32_t* coop_G;       // [n_coop] slices (workgroups per batch) of the pair, 1 .. kCoopMaxG
     const uint32_t* coop_slice;   // [n_coop] matches per slice (< 65536: the slice histograms count in 16 bits)
     const uint32_t* coop_hoff;    // [n_coop] first histogram slot of the pair
-    unsigned char* coop_state;    // [n_coop][kCoopStateBytes] pair state between batches
+    const uint32_t* coop_start;   // [n_coop] the order in which pairs are started (longest first)
+    unsigned char* coop_pub;      // [n_coop] 64-byte records a slice task reads about its pair (kernels_filter_coop.hip: CoopPub)
     double*       coop_models;    // [n_coop][chunk x 9 x MAX_MODELS] models of the current chunk of minimal samples
     double*       coop_bm;        // [n_coop][kCoopB][9] matrices the residuals of the batch in flight are taken with
     uint32_t*     coop_hist;      // [slots][kCoopB][512] residual histograms of a slice (1024 u16 bins per model)
     uint32_t*     coop_cnt;       // [slots][kCoopB] matches within the bound
     double*       coop_tstar;     // [slices] T*(k) of every item (indexed by soff), k = 0 .. m
     double*       coop_la;        // [n_coop][1024] NFA slope of every histogram bin
-    uint32_t*     coop_q;         // task queue: [head, tail, done, potential, active, n_pairs, cap - 1, -] + seq[cap] + data[cap]
+    unsigned long long* coop_prof; // developer build: [n_coop][16] wall-clock ticks per phase (kernels_filter_coop.hip), or nullptr
+    uint32_t*     coop_q;         // task queue: [head, tail, done, potential, active, n_pairs, cap - 1, next pair to start] + seq[cap] + data[cap]
     // debug trace (R3DM_TRACE_PAIR): rows of (iter, model, #<=bound, NFA, improved) for one item
     double*       trace;
     uint32_t      trace_item, trace_cap, trace_iter;
