@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 WHAT=${1:-all}
-SRC="kernels_match.hip kernels_filter.hip kernels_filter_e.hip kernels_filter_coop.hip kernels_filter_coop_e.hip kernels_liop.hip kernels_ann.hip kernels_hnsw.hip kernels_akaze.hip api_core.cpp api_match.cpp api_hnsw.cpp api_filter.cpp api_features.cpp api_multi.cpp compute_matches.cpp"
+SRC="kernels_match.hip kernels_filter.hip kernels_filter_e.hip kernels_filter_coop.hip kernels_liop.hip kernels_ann.hip kernels_hnsw.hip kernels_akaze.hip api_core.cpp api_match.cpp api_hnsw.cpp api_filter.cpp api_features.cpp api_multi.cpp compute_matches.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
 HDRS="regard3d_amd/csrc/*.hpp include/*.h include/*.hpp"
 # kernels_filter.hip (wg_fence) orders global-memory exchanges INSIDE a workgroup with a workgroup-scope fence: valid only while the
@@ -27,7 +27,7 @@ build_one() {   # $1 = variant dir, $2 = extra flags, $3 = output, $4 = extra so
     fi
     local extra=""
     # (no per-file compiler options: the essential-matrix kernel no longer needs -amdgpu-spill-sgpr-to-vgpr=0)
-    case $f in kernels_filter_e.hip|kernels_filter_coop.hip|kernels_filter_coop_e.hip)
+    case $f in kernels_filter_e.hip|kernels_filter_coop.hip)
       [ regard3d_amd/csrc/kernels_filter.hip -nt $o ] && stale=1; [ regard3d_amd/csrc/kernels_filter_coop.hip -nt $o ] && stale=1;; esac
     if [ $stale = 1 ]; then ( $HIPCC $FLAGS $2 $extra -x hip -c regard3d_amd/csrc/$f -o $o ) & pids="$pids $!"; fi
   done

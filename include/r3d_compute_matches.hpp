@@ -30,7 +30,7 @@ namespace r3d_amd {
 
 // Regard3DFeatures::R3DFParams (same member names, same defaults: src/Regard3DFeatures.cpp:128-135)
 struct R3DFParams {
-    std::vector<std::string> keypointDetectorList_;
+    std::vector<std::string> keypointDetectorList_{"Fast-AKAZE"};     // R3DFParams(): src/Regard3DFeatures.cpp:133
     float threshold_ = 0.001f;
     int nFeatures_ = 20000;
     float distRatio_ = 0.6f;

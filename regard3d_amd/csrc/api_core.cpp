@@ -46,6 +46,10 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
                       &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
                       &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->d_spill, &c->d_fb2};
     for (FilterBufs& fb : c->fb) fb.release();
+    c->coop_sched.release();
+    if (c->coop_ev) (void)hipEventDestroy(c->coop_ev);
+    if (c->coop_stream) (void)hipStreamDestroy(c->coop_stream);
+    c->coop_ev = nullptr; c->coop_stream = nullptr;
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
     for (auto& im : c->spare) if (im) im->release();

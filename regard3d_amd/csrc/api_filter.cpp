@@ -8,6 +8,12 @@
 #include <functional>
 #include <memory>
 
+// What filter_prepare leaves for the shared launch of the cooperative kernel (kernels_filter_coop.hip): the long pairs of this kind
+struct CoopPlan {
+    std::vector<uint32_t> G, len;      // slices and putative count of every cooperative pair of the kind, by pair index
+    uint32_t slots = 0;                // sum of G
+};
+
 // a device buffer that lives as long as the closure that captured it (the trace / check buffers of the developer build)
 struct SharedDevBuf { DevBuf b; ~SharedDevBuf() { b.release(); } };
 
@@ -39,9 +45,10 @@ struct FilterCallOut {
 // given its HIP-event time.  launch = false in fp_out.n_items == 0 (nothing to run: collect still delivers the empty graph).
 static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                           uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out,
-                          uint32_t min_count, float min_ratio, FilterParams& fp_out, std::function<int(float)>& collect)
+                          uint32_t min_count, float min_ratio, FilterParams& fp_out, CoopPlan& plan, std::function<int(float)>& collect)
 {
     fp_out = FilterParams{};
+    plan = CoopPlan{};
     if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
     FilterBufs& B = c->fb[model_kind];
     const uint32_t SS = model_kind == 0 ? 7u : (model_kind == 1 ? 4u : 5u);          // Kernel::MINIMUM_SAMPLES
@@ -233,19 +240,11 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     fp.n_coop = n_coop;
     fp.coop_workers = 0;
     if (n_coop) {
-        // one allocation: [items | G | slice | hoff | start order] [queue] [published records] [models] [batch matrices] [slice counts]
+        // one allocation: [items | G | slice | hoff] [published records] [models] [batch matrices] [slice counts]
         // [slope tables] [T*] [slice histograms]
         auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-        uint32_t workers = 0;
-        for (uint32_t g : coop_G) workers += g;
-        const int workers_knob = r3dm_dev_knob("R3DM_FILTER_COOP_WORKERS", 0);
-        workers = workers_knob > 0 ? (uint32_t)workers_knob : std::min<uint32_t>(workers, (uint32_t)std::max(c->n_cu, 1));
-        // scheduling words (kernels_filter_coop.hip): three lines of counters, the overflow ring, the idle ring, one mailbox line per worker
-        uint32_t cap = 64; while (cap < coop_slots + 1) cap <<= 1;
-        uint32_t icap = 64; while (icap < workers + 1) icap <<= 1;
-        const size_t q_words = 96 + 2 * (size_t)cap + 2 * (size_t)icap + 32 * (size_t)workers;
-        const size_t o_small = 0, small_bytes = up(20 * (size_t)n_coop);
-        const size_t o_q = o_small + small_bytes, q_bytes = up(4 * q_words);
+        const size_t small_bytes = up(16 * (size_t)n_coop);
+        const size_t o_q = small_bytes, q_bytes = 0;
         const size_t o_pub = o_q + q_bytes, pub_bytes = up(64 * (size_t)n_coop);
         const size_t o_models = o_pub + pub_bytes, models_bytes = up(8 * (size_t)n_coop * filter_coop_model_doubles(model_kind));
         const size_t o_bm = o_models + models_bytes, bm_bytes = up(8 * (size_t)n_coop * kCoopB * 9);
@@ -257,26 +256,15 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         if (32 * (uint64_t)n_slice >= 0x7FFFFFFFull || hist_bytes >= 0x7FFFFFFFull) { o.err = "filter: putative graph too large for the cooperative kernel's buffer offsets"; return R3DM_ERR_UNSUPPORTED; }
         FHIP(B.f_coop.ensure(o_hist + hist_bytes));
         unsigned char* base = B.f_coop.as<unsigned char>();
-        std::vector<uint32_t> stage(small_bytes / 4 + q_bytes / 4, 0u);
+        std::vector<uint32_t> stage(small_bytes / 4, 0u);
         memcpy(&stage[0], coop_items.data(), 4 * (size_t)n_coop);
         memcpy(&stage[n_coop], coop_G.data(), 4 * (size_t)n_coop);
         memcpy(&stage[2 * (size_t)n_coop], coop_slice.data(), 4 * (size_t)n_coop);
         memcpy(&stage[3 * (size_t)n_coop], coop_hoff.data(), 4 * (size_t)n_coop);
-        // pairs are started longest first
-        {
-            uint32_t* by_len = &stage[4 * (size_t)n_coop];
-            std::iota(by_len, by_len + n_coop, 0u);
-            std::stable_sort(by_len, by_len + n_coop, [&](uint32_t a, uint32_t b) {
-                const uint32_t ka = coop_items[a], kb = coop_items[b];
-                return begin_end[2 * ka + 1] - begin_end[2 * ka] > begin_end[2 * kb + 1] - begin_end[2 * kb]; });
-        }
-        uint32_t* q = &stage[small_bytes / 4];
-        q[5] = n_coop; q[6] = cap - 1; q[20] = workers; q[34] = icap - 1; q[65] = coop_slots; q[66] = workers;
-        for (uint32_t i = 0; i < cap; ++i) q[96 + i] = i;                              // overflow ring: slot i is free for ticket i
-        for (uint32_t i = 0; i < icap; ++i) q[96 + 2 * (size_t)cap + i] = i;           // idle ring likewise
-        for (uint32_t w = 0; w < workers; ++w) q[96 + 2 * (size_t)cap + 2 * (size_t)icap + 32 * (size_t)w] = 0xFFFFFFFEu;   // mailboxes: nobody waits yet
         FHIP(hipMemcpyAsync(base, stage.data(), 4 * stage.size(), hipMemcpyHostToDevice, c->stream));
         FHIP(hipMemsetAsync(base + o_pub, 0, pub_bytes, c->stream));
+        plan.G = coop_G; plan.slots = coop_slots;
+        for (uint32_t qi = 0; qi < n_coop; ++qi) plan.len.push_back((uint32_t)(begin_end[2 * coop_items[qi] + 1] - begin_end[2 * coop_items[qi]]));
         // logcombi(k, m) of every cooperative pair as a running prefix in the reference's float accumulation order (makelogcombi_n,
         // SURVEY.md A.5): pre[i] = pre[i-1] + (l10[m-i+1] - l10[i]), mirrored for k > m/2 -- the same operations, in the same order, as
         // thread 0 of the one-workgroup kernel performs (this translation unit is compiled with -ffp-contract=off like the kernels)
@@ -302,8 +290,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         FHIP(hipStreamSynchronize(c->stream));           // `stage` leaves scope; the landing buffer is reused for the results
         fp.coop_items = reinterpret_cast<const uint32_t*>(base);
         fp.coop_G = fp.coop_items + n_coop; fp.coop_slice = fp.coop_items + 2 * (size_t)n_coop; fp.coop_hoff = fp.coop_items + 3 * (size_t)n_coop;
-        fp.coop_start = fp.coop_items + 4 * (size_t)n_coop;
-        fp.coop_q = reinterpret_cast<uint32_t*>(base + o_q);
+        fp.coop_q = nullptr;                              // (the scheduling words are shared by the kinds of a call: filter_launch)
         fp.coop_pub = base + o_pub;
         fp.coop_models = reinterpret_cast<double*>(base + o_models);
         fp.coop_bm = reinterpret_cast<double*>(base + o_bm);
@@ -311,14 +298,13 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         fp.coop_la = reinterpret_cast<double*>(base + o_la);
         fp.coop_tstar = reinterpret_cast<double*>(base + o_ts);
         fp.coop_hist = reinterpret_cast<uint32_t*>(base + o_hist);
-        fp.coop_workers = workers;
         fp.coop_prof = nullptr;
         if (r3dm_dev_knob("R3DM_COOP_PROF", 0)) {               // developer build: per-pair phase times of the cooperative kernel
             FHIP(B.f_coop_prof.ensure(128 * (size_t)n_coop));
             FHIP(hipMemsetAsync(B.f_coop_prof.p, 0, 128 * (size_t)n_coop, c->stream));
             fp.coop_prof = B.f_coop_prof.as<unsigned long long>();
         }
-        if (filter_coop_lds_bytes(model_kind) > 160 * 1024) { o.err = "filter: LDS budget exceeded (cooperative kernel)"; return R3DM_ERR_UNSUPPORTED; }
+        if (filter_coop_lds_bytes() > 160 * 1024) { o.err = "filter: LDS budget exceeded (cooperative kernel)"; return R3DM_ERR_UNSUPPORTED; }
     }
     if (filter_F_lds_bytes(fp.m_cap, model_kind) > 160 * 1024) { o.err = "filter: LDS budget exceeded"; return R3DM_ERR_UNSUPPORTED; }
     // debug aid: R3DM_TRACE_PAIR="I,J" + R3DM_TRACE_FILE=path dump the per-model trace of one pair
@@ -387,11 +373,11 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     o.ms_kernels = ms;
     if (fp.n_coop) {
         uint32_t qh[96];
-        FHIP(hipMemcpy(qh, fp.coop_q, sizeof(qh), hipMemcpyDeviceToHost));
-        qh[2] = qh[64];                                       // pairs finished
-        if (qh[8] != 0u || qh[2] != fp.n_coop) {
+        FHIP(hipMemcpy(qh, c->coop_sched.p, sizeof(qh), hipMemcpyDeviceToHost));
+        qh[2] = qh[64];                                       // pairs finished (of all kinds of the call)
+        if (qh[8] != 0u || qh[2] != qh[5]) {
             o.err = "filter: the cooperative kernel (kind " + std::to_string(model_kind) + ") stalled (code " + std::to_string(qh[8]) + ", info " + std::to_string(qh[9]) + ", " +
-                    std::to_string(qh[2]) + " of " + std::to_string(fp.n_coop) + " pairs finished; at the stall: overflow head " + std::to_string(qh[10]) + " tail " +
+                    std::to_string(qh[2]) + " of " + std::to_string(qh[5]) + " pairs finished; at the stall: overflow head " + std::to_string(qh[10]) + " tail " +
                     std::to_string(qh[11]) + " finished " + std::to_string(qh[12]) + " potential " + std::to_string(qh[13]) + " workers " + std::to_string(qh[14]) +
                     " started " + std::to_string(qh[15]) + ")";
             return R3DM_ERR_HIP;
@@ -464,54 +450,79 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     return R3DM_OK;
 }
 
-// The kernels of one prepared filter on `st`, bracketed by (ev0, ev1): the cooperative kernel of the long pairs on the kind's second
-// stream (forked from and joined back into `st` with events, so that the bracket covers both), the one-workgroup-per-pair kernel of
-// the short ones on `st` itself.
-static int filter_enqueue(r3dm_ctx* c, FilterCallOut& o, const FilterParams& fp, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+// The cooperative kernel of a call: ONE pool of workers for the long pairs of all its filters (kernels_filter_coop.hip).  Builds the
+// scheduling words (counters, overflow ring, idle ring, a mailbox line per worker), the start order (kind << 30 | pair, most work
+// first) and the device copy of the FilterParams, and launches on the context's cooperative stream; c->coop_ev is recorded behind it.
+static int coop_launch_shared(r3dm_ctx* c, FilterCallOut& o, FilterParams* fps, const CoopPlan* plans, int n, bool& launched)
 {
-    FilterBufs& B = c->fb[fp.model_kind];
-    FHIP(hipEventRecord(ev0, st));
-    if (fp.n_coop) {
-        if (!B.stream2 || !B.ev2) {
-            hipStream_t s2 = nullptr; hipEvent_t e2 = nullptr;
-            int prio_low = 0, prio_high = 0;
-            FHIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-            const int prio = fp.model_kind == 2 ? prio_high : (fp.model_kind == 0 ? (prio_low + prio_high) / 2 : prio_low);
-            FHIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio));
-            const hipError_t e = hipEventCreate(&e2);
-            if (e != hipSuccess) { (void)hipStreamDestroy(s2); FHIP(e); }
-            B.stream2 = s2; B.ev2 = e2;
-        }
-        FHIP(hipStreamWaitEvent(B.stream2, ev0, 0));
-        FHIP(launch_filter_coop(B.stream2, fp, fp.coop_workers));
-        FHIP(hipEventRecord(B.ev2, B.stream2));
+    launched = false;
+    uint32_t n_pairs = 0, slots = 0;
+    for (int k = 0; k < n; ++k) { n_pairs += fps[k].n_coop; slots += plans[k].slots; }
+    if (!n_pairs) return R3DM_OK;
+    const int workers_knob = r3dm_dev_knob("R3DM_FILTER_COOP_WORKERS", 0);
+    const uint32_t workers = std::min<uint32_t>(256u, workers_knob > 0 ? (uint32_t)workers_knob : std::min<uint32_t>(slots, (uint32_t)std::max(c->n_cu, 1)));   // (the idle bitmap has 256 bits)
+    uint32_t cap = 64; while (cap < slots + 1) cap <<= 1;
+    const size_t q_words = 96 + 2 * (size_t)cap + 32 * (size_t)workers;
+    const size_t start_off = (q_words + 63) / 64 * 64, params_off = ((start_off + n_pairs) * 4 + 255) / 256 * 256;
+    std::vector<unsigned char> stage(params_off + 3 * sizeof(FilterParams), 0);
+    uint32_t* q = reinterpret_cast<uint32_t*>(stage.data());
+    const int leaders_knob = r3dm_dev_knob("R3DM_FILTER_COOP_LEADERS", 0);
+    q[5] = n_pairs; q[6] = cap - 1; q[20] = workers; q[65] = slots; q[66] = workers;
+    q[21] = leaders_knob > 0 ? (uint32_t)leaders_knob : std::max<uint32_t>(1u, (workers * 55u + 99u) / 100u);     // pairs led at a time
+    for (uint32_t i = 0; i < cap; ++i) q[96 + i] = i;                              // overflow ring: slot i is free for ticket i
+    for (uint32_t w = 0; w < workers; ++w) q[96 + 2 * (size_t)cap + 32 * (size_t)w] = 0xFFFFFFFEu;   // mailboxes: nobody waits yet
+    // start order: the pair with the most work first.  Work ~ putatives x models per iteration (E ~4.5, F ~2.6, H ~1) + E's solves.
+    struct Ent { double w; uint32_t v; };
+    std::vector<Ent> ents;
+    for (int k = 0; k < n; ++k) {
+        const int kind = fps[k].model_kind;
+        const double per = kind == 2 ? 6.0 : (kind == 0 ? 2.6 : 1.0);
+        for (uint32_t p = 0; p < fps[k].n_coop; ++p) ents.push_back({per * plans[k].len[p], ((uint32_t)kind << 30) | p});
     }
-    if (fp.n_short) FHIP(launch_filter_F(st, fp));
-    if (fp.n_coop) FHIP(hipStreamWaitEvent(st, B.ev2, 0));
-    FHIP(hipEventRecord(ev1, st));
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.w > b.w; });
+    for (uint32_t i = 0; i < n_pairs; ++i) q[start_off + i] = ents[i].v;
+    FHIP(c->coop_sched.ensure(stage.size()));
+    unsigned char* base = c->coop_sched.as<unsigned char>();
+    FilterParams* hp = reinterpret_cast<FilterParams*>(stage.data() + params_off);
+    for (int k = 0; k < n; ++k) {
+        fps[k].coop_q = reinterpret_cast<uint32_t*>(base);
+        fps[k].coop_workers = workers;
+        hp[fps[k].model_kind] = fps[k];
+    }
+    if (!c->coop_stream || !c->coop_ev) {
+        hipStream_t s2 = nullptr; hipEvent_t e2 = nullptr;
+        FHIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        const hipError_t e = hipEventCreate(&e2);
+        if (e != hipSuccess) { (void)hipStreamDestroy(s2); FHIP(e); }
+        c->coop_stream = s2; c->coop_ev = e2;
+    }
+    FHIP(hipMemcpyAsync(base, stage.data(), stage.size(), hipMemcpyHostToDevice, c->coop_stream));
+    FHIP(launch_filter_coop(c->coop_stream, reinterpret_cast<const FilterParams*>(base + params_off), reinterpret_cast<uint32_t*>(base),
+                            reinterpret_cast<const uint32_t*>(base) + start_off, workers));
+    FHIP(hipEventRecord(c->coop_ev, c->coop_stream));
+    FHIP(hipStreamSynchronize(c->coop_stream));          // `stage` leaves scope (and the kernels below are waited for anyway)
+    launched = true;
     return R3DM_OK;
 }
 
-// launch + wait + HIP-event time of the kernels of `n` prepared filters.  One filter: on the context's stream.  Several: every kernel
-// on the stream of its kind's priority class (FilterBufs::stream), after the uploads on the context's stream have been waited for.
-static int filter_launch(r3dm_ctx* c, FilterCallOut& o, const FilterParams* fps, int n, float* ms)
+// launch + wait + HIP-event time of the kernels of `n` prepared filters: the one-workgroup-per-pair kernel of every kind's short pairs
+// on a stream of its own (one filter: the context's stream; several: the kinds' priority streams), the cooperative kernel of all long
+// pairs once for the call.  ms[k] = HIP-event time from the first launch to the end of kind k's short-pair kernel, or to the end of the
+// cooperative kernel if that came later.
+static int filter_launch(r3dm_ctx* c, FilterCallOut& o, FilterParams* fps, const CoopPlan* plans, int n, float* ms)
 {
     for (int k = 0; k < n; ++k) ms[k] = 0.f;
     int live = 0;
     for (int k = 0; k < n; ++k) live += fps[k].n_items ? 1 : 0;
     if (!live) return R3DM_OK;
-    if (n == 1) {
-        const int rc = filter_enqueue(c, o, fps[0], c->stream, c->ev0, c->ev1);
-        if (rc != R3DM_OK) return rc;
-        FHIP(hipStreamSynchronize(c->stream));
-        (void)hipEventElapsedTime(&ms[0], c->ev0, c->ev1);
-        return R3DM_OK;
-    }
+    FHIP(hipStreamSynchronize(c->stream));                // every upload of the prepare steps has landed
     int prio_low = 0, prio_high = 0;
     FHIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));          // numerically: low >= high
-    FHIP(hipStreamSynchronize(c->stream));
+    std::vector<hipStream_t> st(n, nullptr);
+    std::vector<hipEvent_t> e0(n, nullptr), e1(n, nullptr);
     for (int k = 0; k < n; ++k) {
         if (!fps[k].n_items) continue;
+        if (n == 1) { st[k] = c->stream; e0[k] = c->ev0; e1[k] = c->ev1; continue; }
         FilterBufs& B = c->fb[fps[k].model_kind];
         if (!B.stream || !B.ev0 || !B.ev1) {
             // (all three or none: a half-made set would break every later call of the context)
@@ -520,29 +531,40 @@ static int filter_launch(r3dm_ctx* c, FilterCallOut& o, const FilterParams* fps,
             if (B.stream) (void)hipStreamDestroy(B.stream);
             B.stream = nullptr; B.ev0 = B.ev1 = nullptr;
             const int prio = fps[k].model_kind == 2 ? prio_high : (fps[k].model_kind == 0 ? (prio_low + prio_high) / 2 : prio_low);
-            hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+            hipStream_t s = nullptr; hipEvent_t a = nullptr, b = nullptr;
             hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
-            if (e == hipSuccess) e = hipEventCreate(&e0);
-            if (e == hipSuccess) e = hipEventCreate(&e1);
+            if (e == hipSuccess) e = hipEventCreate(&a);
+            if (e == hipSuccess) e = hipEventCreate(&b);
             if (e != hipSuccess) {
-                if (e0) (void)hipEventDestroy(e0);
-                if (e1) (void)hipEventDestroy(e1);
+                if (a) (void)hipEventDestroy(a);
+                if (b) (void)hipEventDestroy(b);
                 if (s) (void)hipStreamDestroy(s);
                 FHIP(e);
             }
-            B.stream = s; B.ev0 = e0; B.ev1 = e1;
+            B.stream = s; B.ev0 = a; B.ev1 = b;
         }
-        const int rc = filter_enqueue(c, o, fps[k], B.stream, B.ev0, B.ev1);
-        if (rc != R3DM_OK) return rc;
+        st[k] = B.stream; e0[k] = B.ev0; e1[k] = B.ev1;
     }
+    // the short pairs of every kind first (cheap to launch), then the shared cooperative kernel; every bracket closes behind both
+    for (int k = 0; k < n; ++k) {
+        if (!fps[k].n_items) continue;
+        FHIP(hipEventRecord(e0[k], st[k]));
+        if (fps[k].n_short) FHIP(launch_filter_F(st[k], fps[k]));
+    }
+    bool coop = false;
+    const int rc = coop_launch_shared(c, o, fps, plans, n, coop);
     hipError_t first = hipSuccess;
     for (int k = 0; k < n; ++k) {
         if (!fps[k].n_items) continue;
-        FilterBufs& B = c->fb[fps[k].model_kind];
-        const hipError_t e = hipStreamSynchronize(B.stream);              // wait for ALL of them, whatever one of them says
+        if (rc == R3DM_OK) {
+            if (coop && fps[k].n_coop) (void)hipStreamWaitEvent(st[k], c->coop_ev, 0);
+            (void)hipEventRecord(e1[k], st[k]);
+        }
+        const hipError_t e = hipStreamSynchronize(st[k]);                 // wait for ALL of them, whatever one of them says
         if (e != hipSuccess && first == hipSuccess) first = e;
-        if (e == hipSuccess) (void)hipEventElapsedTime(&ms[k], B.ev0, B.ev1);
+        if (e == hipSuccess && rc == R3DM_OK) (void)hipEventElapsedTime(&ms[k], e0[k], e1[k]);
     }
+    if (rc != R3DM_OK) return rc;
     FHIP(first);
     return R3DM_OK;
 }
@@ -554,10 +576,11 @@ static int filter_one(r3dm_ctx* c, const r3dm_graph* putative, double max_residu
     if (!c) return R3DM_ERR_INVALID;
     FilterCallOut o;
     FilterParams fp{};
+    CoopPlan plan;
     std::function<int(float)> collect;
     float ms = 0.f;
-    int rc = filter_prepare(c, o, putative, max_residual_px, max_iter, seed, err_kind, model_kind, out, M_out, min_count, min_ratio, fp, collect);
-    if (rc == R3DM_OK) rc = filter_launch(c, o, &fp, 1, &ms);
+    int rc = filter_prepare(c, o, putative, max_residual_px, max_iter, seed, err_kind, model_kind, out, M_out, min_count, min_ratio, fp, plan, collect);
+    if (rc == R3DM_OK) rc = filter_launch(c, o, &fp, &plan, 1, &ms);
     if (rc == R3DM_OK) rc = collect(ms);
     if (rc != R3DM_OK && !o.err.empty()) c->err = o.err;
     c->stats.ms_filter_kernels = o.ms_kernels;
@@ -647,17 +670,18 @@ extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double m
         if (which & 2) { calls.emplace_back(new Call()); calls.back()->kind = 2; calls.back()->slot = 1; calls.back()->out = out_E; }
         if (which & 4) { calls.emplace_back(new Call()); calls.back()->kind = 1; calls.back()->slot = 2; calls.back()->out = out_H; }
         std::vector<FilterParams> fps(calls.size());
+        std::vector<CoopPlan> plans(calls.size());
         int rc = R3DM_OK;
         for (size_t i = 0; i < calls.size() && rc == R3DM_OK; ++i) {
             Call& k = *calls[i];
             rc = filter_prepare(c, k.o, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, k.kind, k.out, nullptr,
-                                k.kind == 2 ? e_min_count : 0u, k.kind == 2 ? e_min_ratio : 0.f, fps[i], k.collect);
+                                k.kind == 2 ? e_min_count : 0u, k.kind == 2 ? e_min_ratio : 0.f, fps[i], plans[i], k.collect);
             if (rc != R3DM_OK && !k.o.err.empty()) c->err = k.o.err;
         }
         float ms[3] = {0.f, 0.f, 0.f};
         if (rc == R3DM_OK) {
             FilterCallOut lo;
-            rc = filter_launch(c, lo, fps.data(), (int)fps.size(), ms);
+            rc = filter_launch(c, lo, fps.data(), plans.data(), (int)fps.size(), ms);
             if (rc != R3DM_OK && !lo.err.empty()) c->err = lo.err;
         }
         float ms_max = 0.f;

@@ -100,6 +100,8 @@ struct CoopS {
     uint32_t nm[64];                       // models of every hypothesis of the chunk
     uint8_t  bj_c[kCoopB], bj_k[kCoopB];   // model j of the batch = model bj_k[j] of hypothesis bj_c[j]
     uint32_t sh_task, sh_aux;              // broadcast slots of thread 0 (all LDS in the one dynamic array: Guideline 17)
+    uint32_t n_claim, kept;                // idle workers thread 0 claimed for the batch's slices; bitmask of the slices nobody took
+    uint8_t  claim[32];
 };
 static_assert(sizeof(CoopS) <= 2048, "CoopS must fit the LDS header");
 // LDS: [CoopS | slice scratch: batch matrices 32 x 9 doubles at 2048, counts at 4352 | slot counts of the merge at 4608 (30 x 32 u32)] [region R at 8704]
@@ -108,39 +110,44 @@ static_assert(kCoopCntOff + kCoopB * 4 <= kCoopAllCntOff && kCoopMaxG * kCoopB *
 
 static inline size_t coop_lds_bytes_(int model_kind)
 {
-    const size_t hist = (size_t)kCoopB * 512 * 4;                                   // 1024 u16 bins per model
-    const size_t work = model_kind == 2 ? (size_t)CoopChunk<2>::n * kE5Stride * 8 : 0;   // 5-point workspaces
-    return (size_t)kCoopHdr + (hist > work ? hist : work);
+    // region R serves, one at a time: the slice histograms (32 x 1024 u16 bins), the 5-point workspaces, the sort's image of a block
+    const size_t hist = (size_t)kCoopB * 512 * 4;
+    const size_t work = model_kind == 2 ? (size_t)CoopChunk<2>::n * kE5Stride * 8 : 0;
+    const size_t sort = (size_t)8192 * 12;
+    return (size_t)kCoopHdr + std::max(std::max(hist, work), sort);
 }
 
 // ---- scheduling state in global memory (FilterParams::coop_q), every access a relaxed agent-scope atomic by ONE lane.
 // Three 128-byte lines of words, then two ticket rings and the workers' mailboxes:
 //   line 0: [0] overflow head [1] overflow tail [5] pairs [6] overflow capacity - 1 [7] next pair to start [8] stall code [9] stall info
 //           [10..15] what the staller saw [20] workers
-//   line 1: [32] idle-ring head [33] idle-ring tail [34] idle-ring capacity - 1
+//   line 1: [32 .. 39] idle bitmap, four 64-bit words: bit w = worker w waits at its mailbox
 //   line 2: [64] pairs finished [65] potential (slices of unfinished pairs) [66] workers alive
-//   [96 ..) overflow ring seq[cap], data[cap]; idle ring seq[icap], data[icap]; mailboxes, 32 words (one line) per worker
-// A worker with nothing to do registers in the idle ring and waits at ITS OWN mailbox line; a leader hands a slice to an idle worker by
-// popping an id and writing the task into that mailbox.  Nobody polls a shared word: the first queue (every idle worker polling one
-// head word, ~200 pollers) delayed each task by ~125 us on a collection of 66 pairs and ran 2.3x slower with 256 workers than with 100.
-// Only when no worker is idle does a task go to the overflow ring, which workers look at when they become free.
+//   [96 ..) overflow ring seq[cap], data[cap]; mailboxes, 32 words (one line) per worker (at most 256 workers)
+// A worker with nothing to do sets its bit in the idle bitmap and waits at ITS OWN mailbox line; a leader claims as many idle workers as
+// its batch has slices with ONE fetch-and on a bitmap word and writes the tasks into their mailboxes.  Nobody polls a shared word: the
+// first queue (every idle worker polling one head word, ~200 pollers) delayed each task by ~125 us on a collection of 66 pairs and ran
+// 2.3x slower with 256 workers than with 100; an idle RING popped entry by entry (six lanes of a leader fighting over one head word)
+// still cost 55 us per batch.  Only when no worker is idle does a task go to the overflow ring, which workers look at when they
+// become free.
 constexpr uint32_t kQNextPair = 7, kQStall = 8, kQIdle = 32, kQDone = 64, kQPot = 65, kQActive = 66, kQArrays = 96;
 constexpr uint32_t kMboxEmpty = 0u, kMboxRetired = 0xFFFFFFFEu;
 
 struct CoopRing { uint32_t* head; uint32_t* tail; uint32_t* seq; uint32_t* data; uint32_t mask; };
 struct CoopSched {
     uint32_t* h;
-    CoopRing ov, idle;
+    CoopRing ov;
+    gu64* idle;          // [4]
     uint32_t* mbox;
 };
 __device__ __forceinline__ CoopSched coop_sched(uint32_t* q)
 {
     CoopSched Q;
     Q.h = q;
-    const uint32_t ov_cap = q[6] + 1u, id_cap = q[kQIdle + 2] + 1u;
+    const uint32_t ov_cap = q[6] + 1u;
     Q.ov = CoopRing{q + 0, q + 1, q + kQArrays, q + kQArrays + ov_cap, ov_cap - 1u};
-    Q.idle = CoopRing{q + kQIdle, q + kQIdle + 1, q + kQArrays + 2u * ov_cap, q + kQArrays + 2u * ov_cap + id_cap, id_cap - 1u};
-    Q.mbox = q + kQArrays + 2u * ov_cap + 2u * id_cap;
+    Q.idle = reinterpret_cast<gu64*>(q + kQIdle);
+    Q.mbox = q + kQArrays + 2u * ov_cap;
     return Q;
 }
 __device__ __forceinline__ bool coop_stalled(uint32_t* q) { return QLOAD(&q[kQStall]) != 0u; }
@@ -506,11 +513,11 @@ __device__ __attribute__((noinline)) void coop_eval_slice(const FilterParams& P,
     r3dm_syncthreads();
 }
 
-// a slice task from the queue: everything about it comes from the pair's published record
+// a slice task: kind << 30 | pair << 5 | slice; everything else about it comes from the pair's published record
 template <int KIND>
-__device__ __attribute__((noinline)) void coop_run_task(const FilterParams& P, unsigned char* smem, uint32_t task, uint32_t tid)
+__device__ __attribute__((noinline)) void coop_run_task_k(const FilterParams& P, unsigned char* smem, uint32_t task, uint32_t tid)
 {
-    const uint32_t cp = task >> 5, slice = task & 31u;
+    const uint32_t cp = (task & 0x3FFFFFFFu) >> 5, slice = task & 31u;
     CoopPub* pub = reinterpret_cast<CoopPub*>(P.coop_pub) + cp;
     const unsigned long long t0 = PROF_NOW();
     CoopSliceArgs A;
@@ -522,54 +529,71 @@ __device__ __attribute__((noinline)) void coop_run_task(const FilterParams& P, u
     A.lo = slice * slice_len; A.hi = A.lo + slice_len; if (A.hi > m) A.hi = m;
     A.slot = (uint32_t)hb + slice; A.b_n = (uint32_t)(hb >> 32);
     A.bm_g = P.coop_bm + (size_t)cp * kCoopB * 9;
+#ifdef R3DM_DEVTOOLS
+    const unsigned long long t_pub = (P.coop_prof && tid == 0) ? QLOAD(&pub->pad[0]) : 0ull;      // (before the arrival: the next batch overwrites it)
+#endif
     coop_eval_slice<KIND>(P, A, smem, false, tid);
     if (tid == 0) __hip_atomic_fetch_add(&pub->arrived, (gu64)1, RLX_AGENT);
     PROF_PUT(cp, 3, PROF_NOW() - t0);
 #ifdef R3DM_DEVTOOLS
     if (P.coop_prof && tid == 0) {                             // [12] sum and [14] max of publish -> start, [13] max slice duration
-        const unsigned long long d = t0 - QLOAD(&pub->pad[0]), dur = PROF_NOW() - t0;
+        const unsigned long long d = t0 > t_pub ? t0 - t_pub : 0ull, dur = PROF_NOW() - t0;
         atomicAdd(&P.coop_prof[16 * (size_t)cp + 12], d);
         atomicMax(&P.coop_prof[16 * (size_t)cp + 14], d);
         atomicMax(&P.coop_prof[16 * (size_t)cp + 13], dur);
     }
 #endif
 }
+// (params: the three FilterParams of the call in global memory, indexed by model kind -- one pool of workers serves the F, E and H
+// filters of a putative graph: with a kernel per kind, the first one launched held every CU with mostly idle helpers while the
+// other two waited for its workers to retire)
+__device__ __forceinline__ void coop_run_task(const FilterParams* params, unsigned char* smem, uint32_t task, uint32_t tid)
+{
+    switch (task >> 30) {
+        case 0: coop_run_task_k<0>(params[0], smem, task, tid); break;
+        case 1: coop_run_task_k<1>(params[1], smem, task, tid); break;
+        default: coop_run_task_k<2>(params[2], smem, task, tid); break;
+    }
+}
 
-// ---- bitonic sort of the (residual, index) lists in global memory, blocks of E entries per thread in registers.
-// The stages `size_from .. size_to` of the network on the block of kCoopNT * E entries that starts at entry i0 (directions from the
-// GLOBAL index, so blocks sorted one after the other come out alternately ascending / descending, as the merge stages behind them
-// need).  Strides >= the block are not this routine's business.  Same exchange rules as wg_sort_regs (kernels_filter.hip).
+// ---- bitonic sort of the (residual, index) lists (global memory), blocks of kCoopNT * E entries: E entries per thread in registers,
+// exchanges between waves through an LDS image of the block (region R of the workgroup's LDS: 8192 x 12 bytes), global memory touched
+// once to load the block and once to store it.  (The first form exchanged through the global lists themselves: ~20 round trips per
+// sort, 150 us per full evaluation on an idle device and 3-4x that with the other 255 workgroups loading the memory system.)
+// The stages `size_from .. size_to` of the network on the block that starts at entry i0 (directions from the GLOBAL index, so blocks
+// sorted one after the other come out alternately ascending / descending, as the merge stages behind them need).  Strides >= the
+// block are not this routine's business.  Same exchange rules as wg_sort_regs (kernels_filter.hip).  The caller has made the
+// lists visible to the workgroup (wg_sync_t<true>) and finds them visible again on return.
 template <int E>
-__device__ __forceinline__ void coop_sort_block(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx, uint32_t i0,
+__device__ __forceinline__ void coop_sort_block(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx,
+                                                unsigned long long* __restrict__ lk, uint32_t* __restrict__ lx, uint32_t i0,
                                                 uint32_t size_from, uint32_t size_to, uint32_t total, uint32_t tid)
 {
     constexpr uint32_t BLK = (uint32_t)kCoopNT * (uint32_t)E;
     unsigned long long k[E];
     uint32_t x[E];
     const uint32_t base = tid * (uint32_t)E;
-    unsigned long long* kb = keys + i0;
-    uint32_t* xb = sidx + i0;
 #pragma unroll
     for (int s = 0; s < E; ++s) {
         const uint32_t i = i0 + base + (uint32_t)s;
         const bool live = i < total || size_from > 2u;          // (merge stages: the padding was materialised by the block sorts)
-        k[s] = live ? kb[base + s] : ~0ull;
-        x[s] = live ? xb[base + s] : 0xFFFFFFFFu;
+        k[s] = live ? keys[i] : ~0ull;
+        x[s] = live ? sidx[i] : 0xFFFFFFFFu;
     }
     for (uint32_t size = size_from; size <= size_to; size <<= 1) {
         uint32_t stride = size >> 1;
         if (stride >= BLK) stride = BLK >> 1;
-        // ---- distances that cross waves: through memory (every thread parks its entries, reads the partner's)
+        // ---- distances that cross waves: every thread parks its entries in the LDS image, reads the partner's
         for (; stride >= 64u * E; stride >>= 1) {
-            wg_sync_t<true>();
+            r3dm_syncthreads();                                    // earlier readers of the image are done
 #pragma unroll
-            for (int s = 0; s < E; ++s) { kb[base + s] = k[s]; xb[base + s] = x[s]; }
-            wg_sync_t<true>();
+            for (int s = 0; s < E; ++s) { lk[base + s] = k[s]; lx[base + s] = x[s]; }
+            r3dm_syncthreads();
 #pragma unroll
             for (int s = 0; s < E; ++s) {
                 const uint32_t li = base + (uint32_t)s, i = i0 + li;
-                const unsigned long long ok = kb[li ^ stride];
-                const uint32_t ox = xb[li ^ stride];
+                const unsigned long long ok = lk[li ^ stride];
+                const uint32_t ox = lx[li ^ stride];
                 const bool lower = (i & stride) == 0u, up = (i & size) == 0u;
                 const bool mine_gt = pair_gt(k[s], x[s], ok, ox);
                 if (mine_gt == (lower == up)) { k[s] = ok; x[s] = ox; }
@@ -608,30 +632,32 @@ __device__ __forceinline__ void coop_sort_block(unsigned long long* __restrict__
             }
         }
     }
-    wg_sync_t<true>();
 #pragma unroll
-    for (int s = 0; s < E; ++s) { kb[base + s] = k[s]; xb[base + s] = x[s]; }
+    for (int s = 0; s < E; ++s) { keys[i0 + base + s] = k[s]; sidx[i0 + base + s] = x[s]; }
     wg_sync_t<true>();
 }
 
-// the whole list: up to 8192 entries in one block of 1 .. 16 entries per thread; longer lists as blocks of 8192 (16 per thread: the
+// the whole list: up to 8192 entries as one block of 1 .. 16 entries per thread; longer lists as blocks of 8192 (16 per thread: the
 // 32-per-thread form of the one-workgroup kernel needs more registers than a 512-thread workgroup leaves without spilling into the
-// loops around it) + merge stages whose block-crossing strides run on the plain network
-__device__ void coop_sort(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx, uint32_t total, uint32_t tid)
+// loops around it) + merge stages whose block-crossing strides run on the plain network in global memory
+__device__ __attribute__((noinline)) void coop_sort(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx, unsigned char* smem,
+                                                    uint32_t total, uint32_t tid)
 {
+    unsigned long long* lk = reinterpret_cast<unsigned long long*>(smem + kCoopHdr);          // [8192]
+    uint32_t* lx = reinterpret_cast<uint32_t*>(smem + kCoopHdr + 8192 * 8);                    // [8192]
     uint32_t cap = 1; while (cap < total) cap <<= 1;
     constexpr uint32_t BLK = (uint32_t)kCoopNT * 16u;
     if (cap <= BLK) {
         switch (cap / (uint32_t)kCoopNT) {
-            case 0: case 1: wg_sort_regs<1, true>(keys, sidx, cap, total, tid); break;
-            case 2: wg_sort_regs<2, true>(keys, sidx, cap, total, tid); break;
-            case 4: wg_sort_regs<4, true>(keys, sidx, cap, total, tid); break;
-            case 8: wg_sort_regs<8, true>(keys, sidx, cap, total, tid); break;
-            default: wg_sort_regs<16, true>(keys, sidx, cap, total, tid); break;
+            case 0: case 1: coop_sort_block<1>(keys, sidx, lk, lx, 0u, 2u, cap, total, tid); break;
+            case 2: coop_sort_block<2>(keys, sidx, lk, lx, 0u, 2u, cap, total, tid); break;
+            case 4: coop_sort_block<4>(keys, sidx, lk, lx, 0u, 2u, cap, total, tid); break;
+            case 8: coop_sort_block<8>(keys, sidx, lk, lx, 0u, 2u, cap, total, tid); break;
+            default: coop_sort_block<16>(keys, sidx, lk, lx, 0u, 2u, cap, total, tid); break;
         }
         return;
     }
-    for (uint32_t i0 = 0; i0 < cap; i0 += BLK) coop_sort_block<16>(keys, sidx, i0, 2u, BLK, total, tid);
+    for (uint32_t i0 = 0; i0 < cap; i0 += BLK) coop_sort_block<16>(keys, sidx, lk, lx, i0, 2u, BLK, total, tid);
     for (uint32_t size = 2u * BLK; size <= cap; size <<= 1) {
         for (uint32_t stride = size >> 1; stride >= BLK; stride >>= 1) {
             for (uint32_t tI = tid; tI < (cap >> 1); tI += kCoopNT) {
@@ -644,14 +670,14 @@ __device__ void coop_sort(unsigned long long* __restrict__ keys, uint32_t* __res
             }
             wg_sync_t<true>();
         }
-        for (uint32_t i0 = 0; i0 < cap; i0 += BLK) coop_sort_block<16>(keys, sidx, i0, size, size, total, tid);
+        for (uint32_t i0 = 0; i0 < cap; i0 += BLK) coop_sort_block<16>(keys, sidx, lk, lx, i0, size, size, total, tid);
     }
 }
 
 // ---- full evaluation of ONE model by the leader: residuals of all matches, compaction of those within the bound, sort, NFA scan
 // (the evaluation block of acransac_body with its lists in global memory).  Returns the model's NFA and inlier count.
 template <int KIND>
-__device__ void coop_full_eval(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, const double* M /* residual matrix */,
+__device__ void coop_full_eval(const FilterParams& P, const CoopCtx<KIND>& C, CoopS& S, unsigned char* smem, const double* M /* residual matrix */,
                                uint32_t tid, double& nfa_out, uint32_t& kbest_out, uint32_t& total_out)
 {
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);
@@ -701,7 +727,7 @@ __device__ void coop_full_eval(const FilterParams& P, const CoopCtx<KIND>& C, Co
     double nfa = __builtin_huge_val();
     uint32_t kbest = SS;
     if (total > SS) {
-        coop_sort(keys, sidx, total, tid);
+        coop_sort(keys, sidx, smem, total, tid);
         // bestNFA: k = SS + 1 .. total, first minimum wins
         double bv = __builtin_huge_val(); uint32_t bk = 0xFFFFFFFFu;
         for (uint32_t kk = SS + 1 + tid; kk <= total; kk += NT) {
@@ -778,15 +804,32 @@ __device__ void coop_batch_bounds(const FilterParams& P, const CoopCtx<KIND>& C,
             uint32_t incl = run;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= (uint32_t)off) incl += o; }
-            uint32_t k_prev = incl - run;
+            // every table read of the lane's 16 bins is issued before the first one is used (clamped indices, no branch around a load:
+            // sixteen dependent trips to memory per model were most of this routine's time)
+            const uint32_t k0 = incl - run;
+            double la[16], tl[16], th[16];
+            {
+                const double2* lp = reinterpret_cast<const double2*>(C.la_tab + 16u * lane);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const double2 v = lp[i]; la[2 * i] = v.x; la[2 * i + 1] = v.y; }
+                uint32_t k_prev = k0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t k_hi = k_prev + h[i];
+                    uint32_t k_lo = k_prev + 1u; if (k_lo < SS + 1u) k_lo = SS + 1u;
+                    tl[i] = C.tstar[k_lo <= C.m ? k_lo : C.m];
+                    th[i] = C.tstar[k_hi <= C.m ? k_hi : C.m];
+                    k_prev = k_hi;
+                }
+            }
+            uint32_t k_prev = k0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const uint32_t k_hi = k_prev + h[i];
                 uint32_t k_lo = k_prev + 1u; if (k_lo < SS + 1u) k_lo = SS + 1u;
                 if (h[i] != 0u && k_hi >= k_lo) {
-                    const double la = C.la_tab[16u * lane + (uint32_t)i];
-                    const double v_lo = la * (double)(k_lo - SS) + C.tstar[k_lo];
-                    const double v_hi = la * (double)(k_hi - SS) + C.tstar[k_hi];
+                    const double v_lo = la[i] * (double)(k_lo - SS) + tl[i];
+                    const double v_hi = la[i] * (double)(k_hi - SS) + th[i];
                     const double v = v_lo < v_hi ? v_lo : v_hi;
                     wmin = v < wmin ? v : wmin;
                 }
@@ -846,7 +889,7 @@ __device__ __attribute__((noinline)) void coop_decide(const FilterParams& P, con
             for (int e = 0; e < 9; ++e) Mr[e] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const gu64*>(bm_g + e), RLX_AGENT));
             double nfa; uint32_t kbest, total2 = 0;
             const unsigned long long pf0 = PROF_NOW();
-            coop_full_eval<KIND>(P, C, S, Mr, tid, nfa, kbest, total2);
+            coop_full_eval<KIND>(P, C, S, smem, Mr, tid, nfa, kbest, total2);
             prof_full += PROF_NOW() - pf0;
             PROF_PUT(C.cp, 7, 1);
             FCHECK(total2 == total, 9, total2, total);                 // the slices and the full pass count the same matches
@@ -957,10 +1000,35 @@ __device__ void coop_finish(const FilterParams& P, const CoopCtx<KIND>& C, CoopS
     P.iters[2 * (size_t)item + 1] = S.n_models;
 }
 
+// claim up to `need` idle workers (their bits leave the bitmap): one load + one fetch-and per bitmap word that has candidates
+__device__ __forceinline__ uint32_t coop_claim_idle(const CoopSched& Q, uint32_t first_word, uint32_t need, uint8_t* ids)
+{
+    uint32_t got_n = 0;
+    for (uint32_t k = 0; k < 4u && need; ++k) {
+        const uint32_t w = (first_word + k) & 3u;
+        gu64* word = &Q.idle[w];
+        for (int tries = 0; tries < 2 && need; ++tries) {
+            gu64 avail = QLOAD(word);
+            if (!avail) break;
+            gu64 mask = 0;
+            for (uint32_t n = 0; n < need && avail; ++n) { const gu64 low = avail & (~avail + 1ull); mask |= low; avail ^= low; }
+            gu64 mine = __hip_atomic_fetch_and(word, ~mask, RLX_AGENT) & mask;
+            while (mine) {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(mine);
+                mine &= mine - 1ull;
+                ids[got_n++] = (uint8_t)(64u * w + bit);
+                --need;
+            }
+        }
+    }
+    return got_n;
+}
+
 // ---- a pair from start-up to result, led by this workgroup
 template <int KIND>
-__device__ void coop_lead_pair(const FilterParams& P, unsigned char* smem, uint32_t cp, uint32_t tid)
+__device__ __attribute__((noinline)) void coop_lead_pair(const FilterParams* params, unsigned char* smem, uint32_t cp, uint32_t tid)
 {
+    const FilterParams& P = params[KIND];
     CoopS& S = *reinterpret_cast<CoopS*>(smem);
     uint32_t* q = P.coop_q;
     const CoopSched Q = coop_sched(q);
@@ -985,6 +1053,10 @@ __device__ void coop_lead_pair(const FilterParams& P, unsigned char* smem, uint3
         const uint32_t b_n = S.b_n;
         if (b_n == 0) continue;                                    // iterations without a model: only their bookkeeping
         PROF_PUT(cp, 9, 1); PROF_PUT(cp, 11, b_n);
+        // ---- the batch's slices: those that an idle worker can be found for are handed to those workers' mailboxes; the leader runs
+        // slice 0 and every slice nobody is idle for (then every CU has work anyway).  Nothing ever waits in a queue, and a leader
+        // waits only for slices that ARE running on some worker.
+        uint32_t n_handed = 0;
         if (C.G > 1u) {
             DRAIN_VMEM();                                          // the batch matrices (and, first batch, the points and the record)
             r3dm_syncthreads();
@@ -995,60 +1067,72 @@ __device__ void coop_lead_pair(const FilterParams& P, unsigned char* smem, uint3
                 if (P.coop_prof) __hip_atomic_store(&C.pub->pad[0], (gu64)wall_clock64(), RLX_AGENT);
 #endif
                 DRAIN_VMEM();
+                S.n_claim = coop_claim_idle(Q, cp, C.G - 1u, S.claim);
+                S.kept = ((1u << C.G) - 1u) & ~1u;                  // slices 1 .. G - 1 (bit s), cleared as they are handed over
             }
             r3dm_syncthreads();
-            // lane s - 1 of wave 0 hands slice s to an idle worker (its mailbox), or -- nobody idle -- to the overflow ring
-            if (tid < C.G - 1u) {
-                const uint32_t task = (cp << 5) | (tid + 1u);
-                bool placed = false;
-                for (int tries = 0; tries < 8 && !placed; ++tries) {
-                    uint32_t id;
-                    if (!ring_pop(Q.idle, id)) break;
-                    placed = mbox_cas(&Q.mbox[32u * id], kMboxEmpty, task + 1u);           // (fails on a worker that has retired meanwhile)
-                }
-                if (!placed) ring_push(q, Q.ov, task);
+            if (tid < S.n_claim) {
+                const uint32_t slice = tid + 1u;
+                const uint32_t task = ((uint32_t)KIND << 30) | (cp << 5) | slice;
+                if (mbox_cas(&Q.mbox[32u * S.claim[tid]], kMboxEmpty, task + 1u)) atomicAnd(&S.kept, ~(1u << slice));   // (fails on a worker that has just retired)
             }
+            r3dm_syncthreads();
         }
         PROF_PUT(cp, 2, PROF_NOW() - t1);
+        const uint32_t pt_off = (uint32_t)((const char*)C.pt - (const char*)P.pts_scratch);
         {
             const unsigned long long t2 = PROF_NOW();
             CoopSliceArgs A;
-            A.pt_off = (uint32_t)((const char*)C.pt - (const char*)P.pts_scratch);
+            A.pt_off = pt_off;
             A.lo = 0u; A.hi = C.slice_len < C.m ? C.slice_len : C.m;
             A.slot = C.hoff; A.b_n = b_n; A.maxThreshold = C.maxThreshold; A.hist_base = C.hist_base; A.bm_g = C.bm;
             coop_eval_slice<KIND>(P, A, smem, true, tid);
             PROF_PUT(cp, 3, PROF_NOW() - t2);
         }
         if (C.G > 1u) {
-            // wait for the other slices; meanwhile run slice tasks from the queue (this pair's or any other's)
-            const unsigned long long t3 = PROF_NOW();
-            const unsigned long long w0 = tid == 0 ? (unsigned long long)wall_clock64() : 0ull;
-            bool stalled = false;
-            for (;;) {
+            uint32_t kept = S.kept;
+            n_handed = C.G - 1u - (uint32_t)__builtin_popcount(kept);
+            // the kept slices, one after the other; before each, one more look for a worker that has become idle meanwhile
+            while (kept) {
+                const uint32_t slice = (uint32_t)__builtin_ctz(kept);
+                kept &= kept - 1u;
+                r3dm_syncthreads();
                 if (tid == 0) {
-                    // the pair's own arrival word is looked at every ~0.4 us, the shared words (overflow ring, stall flag) every ~3 us
-                    uint32_t v = kCoopNoTask;
-                    for (uint32_t spins = 1;; ++spins) {
-                        if (QLOAD(&C.pub->arrived) >= (gu64)(C.G - 1u)) { v = kCoopDone; break; }
-                        if ((spins & 7u) == 0u) {
-                            if (coop_stalled(q)) { v = kCoopStall; break; }
-                            if (ring_pop(Q.ov, v)) break;
-                            v = kCoopNoTask;
-                            if ((unsigned long long)wall_clock64() - w0 > kCoopStallTicks) { coop_report_stall(q, 2u, cp); v = kCoopStall; break; }
-                        }
-                        __builtin_amdgcn_s_sleep(16);
-                    }
-                    S.sh_task = v;
+                    uint8_t id;
+                    uint32_t handed = 0;
+                    if (coop_claim_idle(Q, cp + slice, 1u, &id) == 1u)
+                        handed = mbox_cas(&Q.mbox[32u * id], kMboxEmpty, (((uint32_t)KIND << 30) | (cp << 5) | slice) + 1u) ? 1u : 0u;
+                    S.sh_aux = handed;
                 }
                 r3dm_syncthreads();
-                const uint32_t t = S.sh_task;
-                r3dm_syncthreads();
-                if (t == kCoopDone) break;
-                if (t == kCoopStall) { stalled = true; break; }
-                if (t != kCoopNoTask) coop_run_task<KIND>(P, smem, t, tid);
+                if (S.sh_aux) { ++n_handed; continue; }
+                const unsigned long long t2 = PROF_NOW();
+                CoopSliceArgs A;
+                A.pt_off = pt_off;
+                A.lo = slice * C.slice_len; A.hi = A.lo + C.slice_len; if (A.hi > C.m) A.hi = C.m;
+                A.slot = C.hoff + slice; A.b_n = b_n; A.maxThreshold = C.maxThreshold; A.hist_base = C.hist_base; A.bm_g = C.bm;
+                coop_eval_slice<KIND>(P, A, smem, true, tid);
+                PROF_PUT(cp, 3, PROF_NOW() - t2);
             }
-            if (stalled) break;                                    // (the host reports the call as failed)
+            // wait for the slices that were handed over (each is running on a worker): only the pair's own arrival word is polled
+            const unsigned long long t3 = PROF_NOW();
+            if (tid == 0) {
+                uint32_t v = kCoopDone;
+                const unsigned long long w0 = wall_clock64();
+                for (uint32_t spins = 1; QLOAD(&C.pub->arrived) < (gu64)n_handed; ++spins) {
+                    __builtin_amdgcn_s_sleep(12);
+                    if ((spins & 63u) == 0u) {
+                        if (coop_stalled(q)) { v = kCoopStall; break; }
+                        if ((unsigned long long)wall_clock64() - w0 > kCoopStallTicks) { coop_report_stall(q, 2u, cp); v = kCoopStall; break; }
+                    }
+                }
+                S.sh_task = v;
+            }
+            r3dm_syncthreads();
+            const uint32_t t = S.sh_task;
+            r3dm_syncthreads();
             PROF_PUT(cp, 4, PROF_NOW() - t3);
+            if (t == kCoopStall) break;                            // (the host reports the call as failed)
         }
     }
     coop_finish<KIND>(P, C, S, tid);
@@ -1060,33 +1144,33 @@ __device__ void coop_lead_pair(const FilterParams& P, unsigned char* smem, uint3
     }
 }
 
-template <int KIND>
 __global__ __launch_bounds__(kCoopNT, 1)
-void acransac_coop_kernel(const FilterParams P)
+void acransac_coop_kernel(const FilterParams* __restrict__ params /* [3], by model kind */, uint32_t* q, const uint32_t* __restrict__ start)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     CoopS& S = *reinterpret_cast<CoopS*>(smem);
     const uint32_t tid = threadIdx.x;
-    uint32_t* q = P.coop_q;
     const CoopSched Q = coop_sched(q);
     const uint32_t me = blockIdx.x;
     for (;;) {
-        // ---- what next: a task nobody could be found for; else a pair nobody leads yet; else wait at the mailbox, retire, or leave
+        // ---- what next: a pair nobody leads yet; else wait at the mailbox for a slice, retire, or leave
         if (tid == 0) {
             uint32_t v = kCoopNoTask, what = 0;
             const uint32_t n_pairs = q[5];
             if (coop_stalled(q)) what = 0;
-            else if (ring_pop(Q.ov, v)) what = 1;
             else {
-                if (QLOAD(&q[kQNextPair]) < n_pairs) {
+                // a new pair, unless enough pairs are being led already: q[21] = pairs in flight at most (about half of the workers, so
+                // that the other half is there to take slices)
+                const uint32_t started = QLOAD(&q[kQNextPair]);
+                if (started < n_pairs && started - QLOAD(&q[kQDone]) < q[21]) {
                     const uint32_t t = __hip_atomic_fetch_add(&q[kQNextPair], 1u, RLX_AGENT);
-                    if (t < n_pairs) { v = P.coop_start[t]; what = 2; }
+                    if (t < n_pairs) { v = start[t]; what = 2; }
                 }
                 if (what == 0 && QLOAD(&q[kQDone]) != n_pairs) {
                     uint32_t* mine = &Q.mbox[32u * me];
                     __hip_atomic_store(mine, kMboxEmpty, RLX_AGENT);
                     DRAIN_VMEM();
-                    ring_push(q, Q.idle, me);
+                    __hip_atomic_fetch_or(&Q.idle[me >> 6], 1ull << (me & 63u), RLX_AGENT);
                     const unsigned long long w0 = wall_clock64();
                     for (uint32_t spins = 1;; ++spins) {
                         const uint32_t mb = QLOAD(mine);
@@ -1096,11 +1180,22 @@ void acransac_coop_kernel(const FilterParams P)
                         // every ~20 us: has the call ended, are there more workers than tasks can exist, has something stalled?
                         bool leave = coop_stalled(q) || QLOAD(&q[kQDone]) == n_pairs;
                         if (!leave) {
+                            const uint32_t st = QLOAD(&q[kQNextPair]);
+                            if (st < n_pairs && st - QLOAD(&q[kQDone]) < q[21] && mbox_cas(mine, kMboxEmpty, kMboxRetired)) {
+                                // a pair can be started (one has finished since this worker went idle): back to the top
+                                __hip_atomic_fetch_and(&Q.idle[me >> 6], ~(1ull << (me & 63u)), RLX_AGENT);
+                                what = 3; break;
+                            }
+                        }
+                        if (!leave) {
                             const uint32_t a = QLOAD(&q[kQActive]), pot = QLOAD(&q[kQPot]);
                             if (a > pot && mbox_cas(&q[kQActive], a, a - 1u)) leave = true;
                             if (!leave && (unsigned long long)wall_clock64() - w0 > kCoopStallTicks) { coop_report_stall(q, 3u, me); leave = true; }
                         }
-                        if (leave && mbox_cas(mine, kMboxEmpty, kMboxRetired)) break;   // (a task that arrived meanwhile is taken on the next look)
+                        if (leave && mbox_cas(mine, kMboxEmpty, kMboxRetired)) {       // (a task that arrived meanwhile is taken on the next look)
+                            __hip_atomic_fetch_and(&Q.idle[me >> 6], ~(1ull << (me & 63u)), RLX_AGENT);
+                            break;
+                        }
                     }
                 }
             }
@@ -1110,32 +1205,28 @@ void acransac_coop_kernel(const FilterParams P)
         const uint32_t task = S.sh_task, what = S.sh_aux;
         r3dm_syncthreads();
         if (what == 0) return;
-        if (what == 1) coop_run_task<KIND>(P, smem, task, tid);
-        else coop_lead_pair<KIND>(P, smem, task, tid);
+        if (what == 3) continue;
+        if (what == 1) coop_run_task(params, smem, task, tid);
+        else {
+            const uint32_t cp = task & 0x3FFFFFFFu;
+            switch (task >> 30) {
+                case 0: coop_lead_pair<0>(params, smem, cp, tid); break;
+                case 1: coop_lead_pair<1>(params, smem, cp, tid); break;
+                default: coop_lead_pair<2>(params, smem, cp, tid); break;
+            }
+        }
     }
 }
 
-template <int KIND>
-static hipError_t launch_coop(hipStream_t st, const FilterParams& P, uint32_t n_workers)
+size_t filter_coop_lds_bytes() { return std::max(std::max(coop_lds_bytes_(0), coop_lds_bytes_(1)), coop_lds_bytes_(2)); }
+hipError_t launch_filter_coop(hipStream_t st, const FilterParams* dev_params, uint32_t* q, const uint32_t* start, uint32_t n_workers)
 {
-    const size_t lds = coop_lds_bytes_(KIND);
-    hipError_t e = hipFuncSetAttribute((const void*)acransac_coop_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (n_workers == 0) return hipSuccess;
+    const size_t lds = filter_coop_lds_bytes();
+    hipError_t e = hipFuncSetAttribute((const void*)acransac_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((acransac_coop_kernel<KIND>), dim3(n_workers), dim3(kCoopNT), lds, st, P);
+    hipLaunchKernelGGL(acransac_coop_kernel, dim3(n_workers), dim3(kCoopNT), lds, st, dev_params, q, start);
     return hipGetLastError();
 }
-
-hipError_t launch_filter_coop_E(hipStream_t st, const FilterParams& P, uint32_t n_workers);
-#ifdef R3DM_FILTER_COOP_ONLY_E
-hipError_t launch_filter_coop_E(hipStream_t st, const FilterParams& P, uint32_t n_workers) { return launch_coop<2>(st, P, n_workers); }
-#else
-size_t filter_coop_lds_bytes(int model_kind) { return coop_lds_bytes_(model_kind); }
-hipError_t launch_filter_coop(hipStream_t st, const FilterParams& P, uint32_t n_workers)
-{
-    if (P.n_coop == 0 || n_workers == 0) return hipSuccess;
-    if (P.model_kind == 2) return launch_filter_coop_E(st, P, n_workers);
-    return P.model_kind == 0 ? launch_coop<0>(st, P, n_workers) : launch_coop<1>(st, P, n_workers);
-}
-#endif
 
 }  // namespace r3dm

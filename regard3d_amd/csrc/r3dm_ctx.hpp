@@ -192,6 +192,11 @@ struct r3dm_ctx {
     // geometric filters: one set of work buffers per model kind (0 F, 1 H, 2 E), so that r3dm_filter_FEH can run the three
     // AC-RANSAC kernels of a putative graph side by side (a collection with few, long pairs leaves most CUs idle under one)
     FilterBufs fb[3];
+    // the cooperative AC-RANSAC kernel of a call (long pairs of all its filters, one pool of workers): scheduling words + start order +
+    // device copy of the kinds' parameters; its stream and the event recorded behind it
+    DevBuf coop_sched;
+    hipStream_t coop_stream = nullptr;
+    hipEvent_t coop_ev = nullptr;
     DevBuf liop_pix, liop_sx, liop_sy, liop_in, liop_out, liop_cnt, liop_img, liop_M, liop_kern;
     DevBuf h_aux, h_jobs;            // HNSW: per-batch layer tables / job records
     DevBuf a_jobs, a_scratch, a_ids, d_spill, d_fb2;

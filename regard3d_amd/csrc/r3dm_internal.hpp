@@ -245,7 +245,6 @@ struct FilterParams {
     const uint32_t* coop_G;       // [n_coop] slices (workgroups per batch) of the pair, 1 .. kCoopMaxG
     const uint32_t* coop_slice;   // [n_coop] matches per slice (< 65536: the slice histograms count in 16 bits)
     const uint32_t* coop_hoff;    // [n_coop] first histogram slot of the pair
-    const uint32_t* coop_start;   // [n_coop] the order in which pairs are started (longest first)
     unsigned char* coop_pub;      // [n_coop] 64-byte records a slice task reads about its pair (kernels_filter_coop.hip: CoopPub)
     double*       coop_models;    // [n_coop][chunk x 9 x MAX_MODELS] models of the current chunk of minimal samples
     double*       coop_bm;        // [n_coop][kCoopB][9] matrices the residuals of the batch in flight are taken with
@@ -341,8 +340,10 @@ hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t 
 hipError_t launch_hamming_knn2(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_n);
 hipError_t launch_finalize(hipStream_t st, const FinalizeParams& P);
 hipError_t launch_filter_F(hipStream_t st, const FilterParams& P);
-hipError_t launch_filter_coop(hipStream_t st, const FilterParams& P, uint32_t n_workers);
-size_t     filter_coop_lds_bytes(int model_kind);
+// one pool of workers for the long pairs of up to three filters: dev_params = FilterParams[3] in device memory indexed by model kind,
+// q = the scheduling words, start = kind << 30 | pair in the order pairs are started
+hipError_t launch_filter_coop(hipStream_t st, const FilterParams* dev_params, uint32_t* q, const uint32_t* start, uint32_t n_workers);
+size_t     filter_coop_lds_bytes();
 inline size_t filter_coop_model_doubles(int model_kind) { return model_kind == 2 ? 32u * 90u : 64u * 27u; }   // chunk x 9 x MAX_MODELS
 size_t     filter_F_lds_bytes(uint32_t m_cap, int model_kind);
 // rows8: every job carries byte rows -> the all-pairs scan runs on integer dot products (same keys)
