@@ -45,7 +45,8 @@ struct FilterCallOut {
 // given its HIP-event time.  launch = false in fp_out.n_items == 0 (nothing to run: collect still delivers the empty graph).
 static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                           uint64_t seed, r3dm_ferror err_kind, int model_kind, r3dm_graph** out, double* F_out,
-                          uint32_t min_count, float min_ratio, FilterParams& fp_out, CoopPlan& plan, std::function<int(float)>& collect)
+                          uint32_t min_count, float min_ratio, FilterParams& fp_out, CoopPlan& plan, std::function<int(float)>& collect,
+                          const r3dm_match* dev_matches = nullptr /* the putative matches already uploaded by another kind of the call */)
 {
     fp_out = FilterParams{};
     plan = CoopPlan{};
@@ -149,7 +150,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     FHIP(B.f_pairs.ensure(sizeof(uint2) * NI));
     FHIP(B.f_ids.ensure(sizeof(uint2) * NI));
     FHIP(B.f_offs.ensure(sizeof(uint64_t) * 2 * NI));
-    FHIP(B.f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
+    if (!dev_matches) FHIP(B.f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
     FHIP(B.f_inl_cnt.ensure(4 * (size_t)NI));
     // slice offsets of the per-item work arrays: multiples of 32 elements, room for m + 1 (kernels_filter.hip explains why)
     std::vector<uint64_t> soff(NI + 1, 0);
@@ -166,7 +167,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     FHIP(hipMemcpyAsync(B.f_pairs.p, slots.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
     FHIP(hipMemcpyAsync(B.f_ids.p, ids.data(), sizeof(uint2) * NI, hipMemcpyHostToDevice, c->stream));
     FHIP(hipMemcpyAsync(B.f_offs.p, begin_end.data(), sizeof(uint64_t) * 2 * NI, hipMemcpyHostToDevice, c->stream));
-    FHIP(hipMemcpyAsync(B.f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, c->stream));
+    if (!dev_matches) FHIP(hipMemcpyAsync(B.f_matches.p, putative->matches.data(), sizeof(r3dm_match) * n_match_total, hipMemcpyHostToDevice, c->stream));
     FHIP(hipMemcpyAsync(B.f_log10.p, l10.data(), 4 * l10.size(), hipMemcpyHostToDevice, c->stream));
     FHIP(hipMemcpyAsync(B.f_logck.p, lck.data(), 4 * lck.size(), hipMemcpyHostToDevice, c->stream));
     FHIP(hipMemsetAsync(B.f_inl_cnt.p, 0, 4 * (size_t)NI, c->stream));
@@ -174,7 +175,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     FilterParams fp{};
     fp.imgs = c->d_imgs.as<ImgDev>();
     fp.pairs = B.f_pairs.as<uint2>(); fp.pair_ids = B.f_ids.as<uint2>();
-    fp.offsets = B.f_offs.as<uint64_t>(); fp.matches = B.f_matches.as<r3dm_match>();
+    fp.offsets = B.f_offs.as<uint64_t>(); fp.matches = dev_matches ? dev_matches : B.f_matches.as<r3dm_match>();
     // LDS sort capacity: 8192 (x 12 B) fits beside the hypothesis buffer; pairs with more putatives sort in global scratch
     // (essential matrix: 4096, so that header + 16 hypotheses + sort buffers stay below 80 KB and two workgroups share a CU)
     // collections with long match lists (some pair above 4096 putatives: LDS admits one workgroup per CU anyway) run the 512-thread
@@ -377,7 +378,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         qh[2] = qh[64];                                       // pairs finished (of all kinds of the call)
         if (qh[8] != 0u || qh[2] != qh[5]) {
             o.err = "filter: the cooperative kernel (kind " + std::to_string(model_kind) + ") stalled (code " + std::to_string(qh[8]) + ", info " + std::to_string(qh[9]) + ", " +
-                    std::to_string(qh[2]) + " of " + std::to_string(qh[5]) + " pairs finished; at the stall: overflow head " + std::to_string(qh[10]) + " tail " +
+                    std::to_string(qh[2]) + " of " + std::to_string(qh[5]) + " pairs finished; at the stall: idle bits " + std::to_string(qh[10]) + " / " +
                     std::to_string(qh[11]) + " finished " + std::to_string(qh[12]) + " potential " + std::to_string(qh[13]) + " workers " + std::to_string(qh[14]) +
                     " started " + std::to_string(qh[15]) + ")";
             return R3DM_ERR_HIP;
@@ -428,6 +429,11 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     }
 
     uint64_t kept = 0;
+    {
+        uint64_t total_kept = 0;
+        for (uint32_t k = 0; k < NI; ++k) total_kept += h_cnt[k];
+        g->matches.reserve(total_kept);
+    }
     for (uint32_t k = 0; k < NI; ++k) {
         // GeometricFilter_{F,H}Matrix_AC: accept iff #inliers > 2.5 * MINIMUM_SAMPLES
         if ((double)h_cnt[k] <= 2.5 * SS) continue;
@@ -437,7 +443,14 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         if (model_kind == 2 && (h_cnt[k] < min_count ||
                                 (float)h_cnt[k] / (float)(putative->offsets[p + 1] - base) < min_ratio)) continue;
         g->pairs.push_back(putative->pairs[2 * p]); g->pairs.push_back(putative->pairs[2 * p + 1]);
-        for (uint32_t q = 0; q < h_cnt[k]; ++q) g->matches.push_back(putative->matches[base + h_idx[soff[k] + q]]);
+        {
+            const size_t at = g->matches.size();
+            g->matches.resize(at + h_cnt[k]);
+            r3dm_match* dst = g->matches.data() + at;
+            const r3dm_match* src = putative->matches.data() + base;
+            const uint32_t* ix = h_idx + soff[k];
+            for (uint32_t q = 0; q < h_cnt[k]; ++q) dst[q] = src[ix[q]];
+        }
         g->offsets.push_back(g->matches.size());
         if (F_out) memcpy(F_out + 9 * kept, h_F.data() + 9 * (size_t)k, 72);
         ++kept;
@@ -451,7 +464,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
 }
 
 // The cooperative kernel of a call: ONE pool of workers for the long pairs of all its filters (kernels_filter_coop.hip).  Builds the
-// scheduling words (counters, overflow ring, idle ring, a mailbox line per worker), the start order (kind << 30 | pair, most work
+// scheduling words (counters, idle bitmap, a mailbox line per worker), the start order (kind << 30 | pair, most work
 // first) and the device copy of the FilterParams, and launches on the context's cooperative stream; c->coop_ev is recorded behind it.
 static int coop_launch_shared(r3dm_ctx* c, FilterCallOut& o, FilterParams* fps, const CoopPlan* plans, int n, bool& launched)
 {
@@ -461,16 +474,14 @@ static int coop_launch_shared(r3dm_ctx* c, FilterCallOut& o, FilterParams* fps, 
     if (!n_pairs) return R3DM_OK;
     const int workers_knob = r3dm_dev_knob("R3DM_FILTER_COOP_WORKERS", 0);
     const uint32_t workers = std::min<uint32_t>(256u, workers_knob > 0 ? (uint32_t)workers_knob : std::min<uint32_t>(slots, (uint32_t)std::max(c->n_cu, 1)));   // (the idle bitmap has 256 bits)
-    uint32_t cap = 64; while (cap < slots + 1) cap <<= 1;
-    const size_t q_words = 96 + 2 * (size_t)cap + 32 * (size_t)workers;
+    const size_t q_words = 96 + 32 * (size_t)workers;          // three lines of counters + one mailbox line per worker (kernels_filter_coop.hip)
     const size_t start_off = (q_words + 63) / 64 * 64, params_off = ((start_off + n_pairs) * 4 + 255) / 256 * 256;
     std::vector<unsigned char> stage(params_off + 3 * sizeof(FilterParams), 0);
     uint32_t* q = reinterpret_cast<uint32_t*>(stage.data());
     const int leaders_knob = r3dm_dev_knob("R3DM_FILTER_COOP_LEADERS", 0);
-    q[5] = n_pairs; q[6] = cap - 1; q[20] = workers; q[65] = slots; q[66] = workers;
+    q[5] = n_pairs; q[20] = workers; q[65] = slots; q[66] = workers;
     q[21] = leaders_knob > 0 ? (uint32_t)leaders_knob : std::max<uint32_t>(1u, (workers * 55u + 99u) / 100u);     // pairs led at a time
-    for (uint32_t i = 0; i < cap; ++i) q[96 + i] = i;                              // overflow ring: slot i is free for ticket i
-    for (uint32_t w = 0; w < workers; ++w) q[96 + 2 * (size_t)cap + 32 * (size_t)w] = 0xFFFFFFFEu;   // mailboxes: nobody waits yet
+    for (uint32_t w = 0; w < workers; ++w) q[96 + 32 * (size_t)w] = 0xFFFFFFFEu;   // mailboxes: nobody waits yet
     // start order: the pair with the most work first.  Work ~ putatives x models per iteration (E ~4.5, F ~2.6, H ~1) + E's solves.
     struct Ent { double w; uint32_t v; };
     std::vector<Ent> ents;
@@ -664,6 +675,7 @@ extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double m
         if (out_H) *out_H = nullptr;
         if (ms_kernels3) ms_kernels3[0] = ms_kernels3[1] = ms_kernels3[2] = 0.0;
         if (ms_wall3) ms_wall3[0] = ms_wall3[1] = ms_wall3[2] = 0.0;
+        const double t_feh0 = now_ms();
         struct Call { int kind, slot; r3dm_graph** out; FilterCallOut o; std::function<int(float)> collect; };
         std::vector<std::unique_ptr<Call>> calls;          // in the order F, E, H; kinds of the buffer sets: 0 F, 1 H, 2 E
         if (which & 1) { calls.emplace_back(new Call()); calls.back()->kind = 0; calls.back()->slot = 0; calls.back()->out = out_F; }
@@ -675,15 +687,18 @@ extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double m
         for (size_t i = 0; i < calls.size() && rc == R3DM_OK; ++i) {
             Call& k = *calls[i];
             rc = filter_prepare(c, k.o, putative, max_residual_px, max_iter, seed, R3DM_ERR_SYMMETRIC_EPIPOLAR, k.kind, k.out, nullptr,
-                                k.kind == 2 ? e_min_count : 0u, k.kind == 2 ? e_min_ratio : 0.f, fps[i], plans[i], k.collect);
+                                k.kind == 2 ? e_min_count : 0u, k.kind == 2 ? e_min_ratio : 0.f, fps[i], plans[i], k.collect,
+                                i > 0 && fps[0].n_items ? fps[0].matches : nullptr);
             if (rc != R3DM_OK && !k.o.err.empty()) c->err = k.o.err;
         }
+        const double t_prep = now_ms();
         float ms[3] = {0.f, 0.f, 0.f};
         if (rc == R3DM_OK) {
             FilterCallOut lo;
             rc = filter_launch(c, lo, fps.data(), plans.data(), (int)fps.size(), ms);
             if (rc != R3DM_OK && !lo.err.empty()) c->err = lo.err;
         }
+        const double t_launch = now_ms();
         float ms_max = 0.f;
         for (size_t i = 0; i < calls.size() && rc == R3DM_OK; ++i) {
             Call& k = *calls[i];
@@ -695,6 +710,9 @@ extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double m
             if (rc == R3DM_OK && (k.kind == 2 || !(which & 2))) c->report = k.o.report;       // the E call's diagnostics, else the last one's
         }
         c->stats.ms_filter_kernels = ms_max;
+        if (r3dm_dev_knob("R3DM_FILTER_TIMING", 0))
+            fprintf(stderr, "r3dm_filter_FEH: prepare %.2f ms, launch + wait %.2f ms (kernels %.2f), collect %.2f ms\n", t_prep - t_feh0, t_launch - t_prep, ms_max,
+                    now_ms() - t_launch);
         if (rc != R3DM_OK) {
             if (out_F && *out_F) { r3dm_graph_free(*out_F); *out_F = nullptr; }
             if (out_E && *out_E) { r3dm_graph_free(*out_E); *out_E = nullptr; }

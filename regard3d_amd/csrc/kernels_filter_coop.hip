@@ -15,12 +15,12 @@
 //     (residuals of all matches, sort, NFA scan), so every decision is the one the sequential algorithm takes: same inlier sets,
 //     same models, same iteration and model counts.  Models behind a pool change are discarded like the rest of a chunk always
 //     was; the batch size starts small after a pool change and doubles (12, 24, 32) while nothing changes.
-//   * Workgroups are not bound to slices.  The kernel is a pool of workers: a worker runs slice tasks from a queue in global
-//     memory, or starts a pair that has no leader yet.  A leader publishes G - 1 slice tasks per batch, takes slice 0 itself, and
-//     while it waits for the others it runs slice tasks from the queue like any worker (its own pair's or another's: the slice
-//     routine touches none of the leader's LDS state).  No workgroup ever waits on something only a not-yet-scheduled workgroup
-//     could provide, so nothing depends on co-residency and F, E and H kernels share the device.  A worker that finds nothing to
-//     do while fewer tasks can exist than workers are alive retires, leaving its CU to the other kernels.
+//   * Workgroups are not bound to slices, and ONE kernel serves the F, E and H filters of a call.  The kernel is a pool of workers: a
+//     worker starts a pair that has no leader yet, or waits at its own mailbox for a slice.  A leader hands the slices of a batch to
+//     the workers that are idle at that moment (one fetch-and on the idle bitmap claims them, one store each delivers the task), runs
+//     slice 0 and every slice nobody was idle for itself, and then waits only for slices that ARE running somewhere.  No workgroup
+//     ever waits on something a not-yet-scheduled workgroup would have to provide, so nothing depends on co-residency.  A worker that
+//     waits while fewer slices can exist than workers are alive retires.
 //   * The bound: NFA_k >= loge0 + la(bin of the k-th residual) (k - SS) + T[k], T[k] = logc_n[k] + logc_k[k] (float tables).
 //     T*(k) = log10(m! / ((m-k)! SS! (k-SS)!)) is concave in k, so over the k range of a bin la_b (k - SS) + T*(k) takes its minimum
 //     at an end of the range: two evaluations per non-empty bin instead of one per k (the walk over k was half the evaluation time
@@ -118,36 +118,30 @@ static inline size_t coop_lds_bytes_(int model_kind)
 }
 
 // ---- scheduling state in global memory (FilterParams::coop_q), every access a relaxed agent-scope atomic by ONE lane.
-// Three 128-byte lines of words, then two ticket rings and the workers' mailboxes:
-//   line 0: [0] overflow head [1] overflow tail [5] pairs [6] overflow capacity - 1 [7] next pair to start [8] stall code [9] stall info
-//           [10..15] what the staller saw [20] workers
+// Three 128-byte lines of words, then the workers' mailboxes:
+//   line 0: [5] pairs [7] next pair to start [8] stall code [9] stall info [10..15] what the staller saw [20] workers [21] pairs led at a time
 //   line 1: [32 .. 39] idle bitmap, four 64-bit words: bit w = worker w waits at its mailbox
 //   line 2: [64] pairs finished [65] potential (slices of unfinished pairs) [66] workers alive
-//   [96 ..) overflow ring seq[cap], data[cap]; mailboxes, 32 words (one line) per worker (at most 256 workers)
+//   [96 ..) mailboxes, 32 words (one line) per worker (at most 256 workers)
 // A worker with nothing to do sets its bit in the idle bitmap and waits at ITS OWN mailbox line; a leader claims as many idle workers as
-// its batch has slices with ONE fetch-and on a bitmap word and writes the tasks into their mailboxes.  Nobody polls a shared word: the
-// first queue (every idle worker polling one head word, ~200 pollers) delayed each task by ~125 us on a collection of 66 pairs and ran
-// 2.3x slower with 256 workers than with 100; an idle RING popped entry by entry (six lanes of a leader fighting over one head word)
-// still cost 55 us per batch.  Only when no worker is idle does a task go to the overflow ring, which workers look at when they
-// become free.
+// its batch has slices with ONE fetch-and on a bitmap word and writes the tasks into their mailboxes; the slices nobody is idle for it
+// runs itself (looking once more for an idle worker before each).  Nobody polls a shared word, and no task ever waits in a queue.
+// What this replaced, on a collection of 66 pairs x 3 filters: a shared task ring that every idle worker polled (~200 pollers on one
+// head word: each task delayed by ~125 us, 2.3x slower with 256 workers than with 100); an idle RING popped entry by entry (six
+// lanes of a leader fighting over one head word: 55 us per batch); an overflow ring for the slices nobody was idle for, polled by
+// the waiting leaders (tasks waited 0.7 ms on average: 62 ms for the call against 14 now).
 constexpr uint32_t kQNextPair = 7, kQStall = 8, kQIdle = 32, kQDone = 64, kQPot = 65, kQActive = 66, kQArrays = 96;
 constexpr uint32_t kMboxEmpty = 0u, kMboxRetired = 0xFFFFFFFEu;
 
-struct CoopRing { uint32_t* head; uint32_t* tail; uint32_t* seq; uint32_t* data; uint32_t mask; };
 struct CoopSched {
-    uint32_t* h;
-    CoopRing ov;
     gu64* idle;          // [4]
     uint32_t* mbox;
 };
 __device__ __forceinline__ CoopSched coop_sched(uint32_t* q)
 {
     CoopSched Q;
-    Q.h = q;
-    const uint32_t ov_cap = q[6] + 1u;
-    Q.ov = CoopRing{q + 0, q + 1, q + kQArrays, q + kQArrays + ov_cap, ov_cap - 1u};
     Q.idle = reinterpret_cast<gu64*>(q + kQIdle);
-    Q.mbox = q + kQArrays + 2u * ov_cap;
+    Q.mbox = q + kQArrays;
     return Q;
 }
 __device__ __forceinline__ bool coop_stalled(uint32_t* q) { return QLOAD(&q[kQStall]) != 0u; }
@@ -156,39 +150,10 @@ __device__ __forceinline__ void coop_report_stall(uint32_t* q, uint32_t code, ui
     uint32_t expect = 0u;
     if (__hip_atomic_compare_exchange_strong(&q[kQStall], &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_store(&q[9], info, RLX_AGENT);
-        __hip_atomic_store(&q[10], QLOAD(&q[0]), RLX_AGENT); __hip_atomic_store(&q[11], QLOAD(&q[1]), RLX_AGENT);        // overflow head, tail
+        __hip_atomic_store(&q[10], (uint32_t)QLOAD(reinterpret_cast<gu64*>(q + kQIdle)), RLX_AGENT);                      // idle workers 0 .. 31
+        __hip_atomic_store(&q[11], (uint32_t)(QLOAD(reinterpret_cast<gu64*>(q + kQIdle)) >> 32), RLX_AGENT);              // 32 .. 63
         __hip_atomic_store(&q[12], QLOAD(&q[kQDone]), RLX_AGENT); __hip_atomic_store(&q[13], QLOAD(&q[kQPot]), RLX_AGENT);
         __hip_atomic_store(&q[14], QLOAD(&q[kQActive]), RLX_AGENT); __hip_atomic_store(&q[15], QLOAD(&q[kQNextPair]), RLX_AGENT);
-    }
-}
-// bounded ring with tickets; a producer drains its data store before it opens the slot
-__device__ __forceinline__ void ring_push(uint32_t* q, const CoopRing& R, uint32_t v)
-{
-    const uint32_t t = __hip_atomic_fetch_add(R.tail, 1u, RLX_AGENT);
-    const uint32_t slot = t & R.mask;
-    // (capacity >= the entries that can be outstanding: the slot is free; the wait is defensive)
-    for (const unsigned long long t0 = wall_clock64(); QLOAD(&R.seq[slot]) != t;) {
-        __builtin_amdgcn_s_sleep(2);
-        if (coop_stalled(q)) return;
-        if ((unsigned long long)wall_clock64() - t0 > kCoopStallTicks) { coop_report_stall(q, 1u, t); return; }
-    }
-    __hip_atomic_store(&R.data[slot], v, RLX_AGENT);
-    DRAIN_VMEM();
-    __hip_atomic_store(&R.seq[slot], t + 1u, RLX_AGENT);
-}
-__device__ __forceinline__ bool ring_pop(const CoopRing& R, uint32_t& v)
-{
-    for (;;) {
-        const uint32_t h = QLOAD(R.head);
-        const uint32_t slot = h & R.mask;
-        if (QLOAD(&R.seq[slot]) != h + 1u) return false;               // empty, or its producer is still writing
-        uint32_t expect = h;
-        if (__hip_atomic_compare_exchange_strong(R.head, &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            v = QLOAD(&R.data[slot]);
-            DRAIN_VMEM();                                               // (the value has been read before the slot is reopened)
-            __hip_atomic_store(&R.seq[slot], h + R.mask + 1u, RLX_AGENT);  // free for the next lap
-            return true;
-        }
     }
 }
 __device__ __forceinline__ bool mbox_cas(uint32_t* word, uint32_t from, uint32_t to)
