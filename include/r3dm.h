@@ -472,6 +472,7 @@ typedef struct {
     /* r3dm_match_pairs_hnsw (ms_ann_build / ms_ann_search / n_ann_built / n_ann_dist are shared with the KGraph path) */
     uint64_t n_hnsw_launches;      /* launches of the HNSW search kernel                                                                */
     uint64_t n_hnsw_retries;       /* ... of those, repeats because a query's candidate heap outgrew its LDS room                       */
+    uint64_t n_counts_mfma;        /* launches of the split nominator that ran on COUNT tiles (rows = small integers x a row scale: LIOP; one f16 MFMA per 16 dimensions instead of three) */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

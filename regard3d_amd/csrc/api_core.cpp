@@ -91,7 +91,7 @@ extern "C" int r3dm_get_features_totals(const r3dm_ctx* c, r3dm_features_totals*
 // ------------------------------------------------------------------------------------------------
 // writes the table entry of `slot`; stat_bits3 / split_k are given when the slot mounts an already staged r3dm_index (the
 // staging kernels fill them otherwise)
-int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_t split_k)
+int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_t split_k, bool counts_ok)
 {
     const size_t need = sizeof(ImgDev) * c->imgs.size();
     if (need > c->d_imgs.cap) {
@@ -122,6 +122,7 @@ int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_
     d.ann_adj = nullptr; d.ann_deg = nullptr; d.ann_rows16 = nullptr; d.ann_rows8 = nullptr;          // staging invalidates the graph index
     d.tiled16 = h.tiled16.as<uint16_t>();
     d.tiledh = h.tiledh.as<uint16_t>(); d.split_k = split_k;
+    d.tiledc = h.tiledc.as<uint16_t>(); d.cscale = h.cscale.as<float>(); d.counts_fail = counts_ok ? 0u : 1u;
     d.tiled8 = h.tiled8.as<uint8_t>();
     R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
@@ -167,6 +168,12 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         const size_t tiledh_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 2048 + kSlackBytes;      // f16 hi | lo planes (split nominator)
         R3DM_HIP(c, h.tiledh.ensure(tiledh_bytes));
         R3DM_HIP(c, hipMemsetAsync(h.tiledh.p, 0, tiledh_bytes, c->stream));
+        // count tiles (rows = small integers x a row scale: LIOP): f16 integers, half the bytes of the split planes, + a scale per row
+        const size_t tiledc_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 1024 + kSlackBytes;
+        R3DM_HIP(c, h.tiledc.ensure(tiledc_bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiledc.p, 0, tiledc_bytes, c->stream));
+        R3DM_HIP(c, h.cscale.ensure((size_t)h.n_tiles * 32 * 4 + kSlackBytes));
+        R3DM_HIP(c, hipMemsetAsync(h.cscale.p, 0, (size_t)h.n_tiles * 32 * 4 + kSlackBytes, c->stream));
         R3DM_HIP(c, h.norms.ensure(norm_bytes));
         R3DM_HIP(c, hipMemsetAsync(h.tiled.p, 0, tiled_bytes, c->stream));
         R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0, norm_bytes, c->stream));
@@ -242,10 +249,20 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
                                      h.tiled.as<float>(), h.tiled16.as<uint16_t>(), h.norms.as<float>(), h.G, h.n_tiles, mx));
         int32_t* sk = &(c->d_imgs.as<ImgDev>() + slot)->split_k;
         R3DM_HIP(c, launch_stage_split(c->stream, h.rows.as<float>(), n, dim, (h.G + 1) / 2, h.n_tiles, h.tiledh.as<uint16_t>(), mx, sk));
+        // count tiles: the staging kernel sets counts_fail when some row is not integers x a scale (the table entry starts at "fails";
+        // clear it first: upload_imgdev wrote 1)
+        uint32_t* cf = &(c->d_imgs.as<ImgDev>() + slot)->counts_fail;
+        uint32_t cfail = 1;
+        if (dtype == R3DM_F32 && n && dim <= 256) {
+            R3DM_HIP(c, hipMemsetAsync(cf, 0, 4, c->stream));
+            R3DM_HIP(c, launch_stage_counts(c->stream, h.rows.as<float>(), n, dim, (h.G + 1) / 2, h.n_tiles, h.tiledc.as<uint16_t>(), h.cscale.as<float>(), cf));
+            R3DM_HIP(c, hipMemcpyAsync(&cfail, cf, 4, hipMemcpyDeviceToHost, c->stream));
+        }
         uint32_t st3[3] = {0, 0, 1};
         R3DM_HIP(c, hipMemcpyAsync(st3, mx, 12, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipMemcpyAsync(&h.split_k, sk, 4, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        h.counts_ok = cfail == 0;
         std::memcpy(&h.max_abs, &st3[1], 4);
         h.not_integer = (st3[2] & 1u) != 0;
         h.has_negative = (st3[2] & 2u) != 0;

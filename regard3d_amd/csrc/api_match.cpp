@@ -132,6 +132,13 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         }
         split = split && any_real;
     }
+    // ... and its cheaper form for views whose rows are small integers x a row scale (LIOP: one f16 MFMA per 16 dimensions on the
+    // count tiles instead of three on the split planes): every view of the batch must have passed the staging check
+    bool counts = split;
+    if (counts)
+        for (const PairJob& j : jobs)
+            if (!c->imgs[j.sI]->counts_ok || !c->imgs[j.sJ]->counts_ok) { counts = false; break; }
+    if (counts && r3dm_dev_knob("R3DM_NO_COUNT_TILES", 0)) counts = false;          // developer build: A/B against the split planes
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
     const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
 
@@ -182,7 +189,10 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));      // (the finaliser would wait here anyway; keeps the wall breakdown honest)
     } else if (has_tensor_kernel(first.G)) {
-        if (split) {
+        if (counts) {
+            R3DM_HIP(c, launch_l2_knn2_counts(c->stream, mp, first.G, max_tiles));
+            c->stats.n_split_mfma += 1; c->stats.n_counts_mfma += 1;
+        } else if (split) {
             R3DM_HIP(c, launch_l2_knn2_split(c->stream, mp, first.G, max_tiles));
             c->stats.n_split_mfma += 1;
         } else {
@@ -326,11 +336,12 @@ static int r3dm_knn2_impl(r3dm_ctx* c, const void* dataset, uint32_t n_dataset, 
         rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
         const uint64_t int_launches = c->stats.n_integer_mfma - keep.n_integer_mfma;
         const uint64_t split_launches = c->stats.n_split_mfma - keep.n_split_mfma;
+        const uint64_t counts_launches = c->stats.n_counts_mfma - keep.n_counts_mfma;
         const uint64_t ham_launches = c->stats.n_hamming_mfma - keep.n_hamming_mfma;
         const uint64_t fb = c->stats.n_exact_fallback - keep.n_exact_fallback;
         c->stats = keep;
         c->stats.n_integer_mfma = int_launches;           // which tiles this call ran on (r3dm_set_integer_mfma / r3dm_set_split_mfma)
-        c->stats.n_split_mfma = split_launches; c->stats.n_hamming_mfma = ham_launches;
+        c->stats.n_split_mfma = split_launches; c->stats.n_hamming_mfma = ham_launches; c->stats.n_counts_mfma = counts_launches;
         c->stats.n_exact_fallback = fb;                   // ... and how many of its queries went through the exact scan
     }
     (void)hipStreamSynchronize(c->stream);
@@ -402,7 +413,7 @@ static int r3dm_index_knn2_impl(r3dm_ctx* c, const r3dm_index* ix, const void* q
     c->imgs.emplace_back(new HostImage());
     *c->imgs[s0] = ix->img;                       // aliases of the index's buffers: mounted for this call only
     c->imgs[s0]->borrowed = true;
-    int rc = upload_imgdev(c, s0, ix->stat_bits, ix->img.split_k);
+    int rc = upload_imgdev(c, s0, ix->stat_bits, ix->img.split_k, ix->img.counts_ok);
     if (rc == R3DM_OK) rc = stage_into_slot(c, s0 + 1, 0, 0, 0, query, n_query, ix->img.dim, ix->img.dtype, nullptr);
     if (rc == R3DM_OK) {
         std::vector<PairJob> jobs{{0, 1, s0, s0 + 1}};
@@ -410,9 +421,10 @@ static int r3dm_index_knn2_impl(r3dm_ctx* c, const r3dm_index* ix, const void* q
         rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
         const uint64_t int_launches = c->stats.n_integer_mfma - keep.n_integer_mfma;
         const uint64_t split_launches = c->stats.n_split_mfma - keep.n_split_mfma;
+        const uint64_t counts_launches = c->stats.n_counts_mfma - keep.n_counts_mfma;
         const uint64_t ham_launches = c->stats.n_hamming_mfma - keep.n_hamming_mfma;
         c->stats = keep;
-        c->stats.n_integer_mfma = int_launches; c->stats.n_split_mfma = split_launches; c->stats.n_hamming_mfma = ham_launches;
+        c->stats.n_integer_mfma = int_launches; c->stats.n_split_mfma = split_launches; c->stats.n_hamming_mfma = ham_launches; c->stats.n_counts_mfma = counts_launches;
     }
     (void)hipStreamSynchronize(c->stream);
     c->imgs[s0]->release(); c->imgs[s0 + 1]->release();

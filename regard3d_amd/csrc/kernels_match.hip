@@ -301,11 +301,13 @@ __device__ __forceinline__ void lex_push(Top2& s, float key, uint32_t idx)
 // SPLIT: the keys come from the split-f16 nominator (l2_knn2_split_kernel) in units of key_inv^-1; a query whose merged
 //        top-2 cannot be certified gets a second chance with all four nominees of its two lane halves before it is sent to
 //        the exact scan
+// lane_key_inv (count tiles, l2_knn2_counts_kernel): the keys of query tile nj are in units of lane_key_inv[nj]^-1, a value per QUERY
+//        (both lane halves of a column hold the same one)
 template <int NJ, bool LEX = false, bool SPLIT = false>
 __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t pair, const ImgDev* __restrict__ Ip,
                                                   const ImgDev* __restrict__ Jp, const Top2 (&st)[NJ], uint32_t qt0,
                                                   uint32_t h, uint32_t c, float dpad, bool bf16_tiles,
-                                                  float key_inv = 1.0f, float slack_abs = 0.0f)
+                                                  float key_inv = 1.0f, float slack_abs = 0.0f, const float* lane_key_inv = nullptr)
 {
     const uint32_t nI = Ip->n, nJ = Jp->n, ntJ = Jp->n_tiles;
     const float maxnorm = __uint_as_float(Ip->max_norm_bits);
@@ -326,7 +328,10 @@ __device__ __forceinline__ void l2_finish_queries(const MatchParams& P, uint32_t
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         Top2 s = st[nj];
-        if constexpr (SPLIT) { s.d0 *= key_inv; s.d1 *= key_inv; s.d2 *= key_inv; }     // power-of-two scale: order unchanged
+        if constexpr (SPLIT) {
+            const float ki = lane_key_inv ? lane_key_inv[nj] : key_inv;                 // positive scale: order unchanged
+            s.d0 *= ki; s.d1 *= ki; s.d2 *= ki;
+        }
         const Top2 own = s;                              // this lane half's list (rows 8 qd + 4 h + k of every tile)
         // partner half (same query column, the other 16 rows of every tile)
         const float pd0 = __shfl_xor(s.d0, 32), pd1 = __shfl_xor(s.d1, 32), pd2 = __shfl_xor(s.d2, 32);
@@ -956,6 +961,278 @@ hipError_t launch_l2_knn2_split(hipStream_t st, const MatchParams& P, uint32_t G
         case 16: return launch_l2_split_t<8, 2, 4>(st, P, max_nj_tiles);
         case 18: return launch_l2_split_t<9, 2, 3>(st, P, max_nj_tiles);
         case 32: return launch_l2_split_t<16, 1, 4>(st, P, max_nj_tiles);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Count tiles: nomination for rows that are SMALL INTEGERS TIMES A PER-ROW SCALE (round 4).  That is what a LIOP descriptor is --
+// the vector Regard3D matches (/root/reference/src/Regard3DFeatures.h:44-48): vl_liop accumulates integer votes per bin and divides
+// by their norm (/root/reference/src/thirdparty/liop/vl_liop.c:553-575), a_i = c_i / n with c_i an integer of a few hundred at most.
+// Integers up to 2048 ARE f16 values, their products are exact in the matrix unit's f32, so
+//     a.b = (c_a . c_b) s_a s_b
+// needs ONE v_mfma_f32_32x32x16_f16 per 16 dimensions on the count tiles, where the split nominator above spends three on hi / lo
+// pieces of the float values: a third of the matrix cycles for the path the product runs by default.  The scales enter afterwards,
+// in the test-and-skip epilogue, and only where a key can matter:
+//     key_q(a) = ||a||^2 / (2 s_q) - (c_a . c_q) s_a        [ = reference key (||a||^2 - 2 a.q) / (2 s_q): per query a positive scale ]
+// with B = -c_q the accumulator holds D' = -(c_a . c_q) <= 0, and for the four keys of a lane's accumulator quad
+//     min key >= min(||a||^2) / (2 s_q) + min(D') max(s_a):
+// one min3 + min + mul + fma + compare per four keys; the per-key mul + fma run only for a quad that passes (rare once the lists
+// have warmed up).  Everything behind the nomination is the split path's: the nominees are re-scored in the reference's own f32
+// summation order, certified against the rounding slack (the key error here -- f32 accumulation of exact products, the 2^-21
+// representation tolerance checked at staging, three roundings in the epilogue -- is below the split residue the slack was sized
+// for), uncertified queries take the four-nominee second chance and then the exact scan.  Results are bit-identical to every other path.
+// Eligibility is decided per view at staging (stage_counts_kernel): every row must satisfy |a_i - c_i s| <= 2^-21 max|a| with integers
+// 0 <= c_i <= 2047; a view with one row that does not (any descriptor that is not of this form) keeps the split tiles.
+// ------------------------------------------------------------------------------------------------
+// one workgroup per 32-row tile, a wave per row (eight rows each): recover (c, s) of the row, verify, write the f16 counts in
+// fragment order [tile][16-dim block][lane half][32 rows][8 f16] and the row's scale; *fail is set when a row is not of the form
+__global__ __launch_bounds__(256)
+void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim, uint32_t GB, uint16_t* __restrict__ tiledc,
+                         float* __restrict__ cscale, uint32_t* __restrict__ fail)
+{
+    const uint32_t t = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint16_t* dst = tiledc + (size_t)t * GB * 512;
+    for (uint32_t r = wave; r < 32u; r += 4u) {
+        const uint32_t row = t * 32u + r;
+        if (row >= n) { if (lane == 0) cscale[row] = 1.0f; continue; }     // (padding rows: counts stay zero, norms are +inf)
+        const float* a = rows + (size_t)row * dim;
+        float v[4];
+        float amax = 0.0f, amin = R3DM_INF;
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = lane + 64u * (uint32_t)e;
+            v[e] = k < dim ? a[k] : 0.0f;
+            if (!(v[e] >= 0.0f) || !(v[e] < R3DM_INF)) bad = true;              // negative, NaN, inf: not a count row
+            amax = fmaxf(amax, v[e]);
+            if (v[e] > 0.0f) amin = fminf(amin, v[e]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, off)); amin = fminf(amin, __shfl_xor(amin, off)); }
+        bad = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+        float cnt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float sc = 1.0f;
+        bool ok = !bad;
+        if (ok && amax > 0.0f) {
+            // the smallest positive element is k x s for a small integer k: try k = 1, 2, ...
+            ok = false;
+            for (uint32_t k = 1; k <= 64u && !ok; ++k) {
+                const float s_try = amin / (float)k;
+                if (!(amax / s_try <= 2047.5f)) break;
+                bool fits = true;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float q = v[e] / s_try;
+                    cnt[e] = rintf(q);
+                    fits = fits && fabsf(q - cnt[e]) <= 0.0625f;                  // coarse: the fit below is what counts
+                }
+                if (__builtin_amdgcn_ballot_w64(!fits) != 0ull) continue;
+                // least-squares scale of the row, then the tolerance every element must meet
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += v[e] * cnt[e]; s2 += cnt[e] * cnt[e]; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+                sc = s1 / s2;
+                bool tol = true;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tol = tol && fabsf(v[e] - cnt[e] * sc) <= 4.76837158203125e-07f * amax;    // 2^-21
+                ok = __builtin_amdgcn_ballot_w64(!tol) == 0ull;
+            }
+        } else if (ok) {
+            sc = 1.0f;                                       // a zero row: counts 0, any scale
+        }
+        if (!ok) { if (lane == 0) atomicOr(fail, 1u); continue; }
+        if (lane == 0) cscale[row] = sc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t kk = lane + 64u * (uint32_t)e;
+            if (kk < GB * 16u) {
+                const uint32_t c8 = kk & 7u, hh = (kk >> 3) & 1u, kb = kk >> 4;
+                dst[kb * 512u + (hh * 32u + r) * 8u + c8] = __builtin_bit_cast(uint16_t, (_Float16)cnt[e]);
+            }
+        }
+    }
+}
+
+hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
+                               uint16_t* tiledc, float* cscale, uint32_t* fail_dev)
+{
+    if (n_tiles == 0 || dim > 256u) return hipSuccess;
+    hipLaunchKernelGGL(stage_counts_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, GB, tiledc, cscale, fail_dev);
+    return hipGetLastError();
+}
+
+template <int GB, int NJ, int PF>
+__device__ __forceinline__ void counts_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rn, __amdgpu_buffer_rsrc_t rs,
+                                                 uint32_t voffA, uint32_t voffN, uint32_t soffA, uint32_t soffN, f32x4 (&abuf)[PF],
+                                                 f32x16& n2_load, f32x16& sa_load, const f32x16& n2_prev, const f32x16& sa_prev,
+                                                 const f32x4 (&bq)[NJ][GB], const float (&cq)[NJ], f32x16 (&cur)[NJ], const f32x16 (&prev)[NJ],
+                                                 Top2 (&st)[NJ], uint32_t prev_rowbase)
+{
+    constexpr int NG = 4 * NJ;                             // (list, quad) groups of four keys per tile
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const f32x4 a = abuf[g % PF];
+        abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
+        if (g == (GB > 2 ? 2 : GB - 1)) {   // THIS tile's ||a||^2 and scales (tested in the next step), element 4 qd + k = row 8 qd + 4 h + k: the accumulator layout
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const f32x4 v = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
+                const f32x4 w = bload16(rs, voffN, soffN + (uint32_t)qd * 32u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { n2_load[4 * qd + k] = v[k]; sa_load[4 * qd + k] = w[k]; }
+            }
+        }
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+            cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq[nj][g]),
+                                                             g == 0 ? zero : cur[nj], 0, 0, 0);
+#pragma unroll
+        for (int gi = (g * NG) / GB; gi < ((g + 1) * NG) / GB; ++gi) {
+            const int nj = gi % NJ, qd = gi / NJ;
+            const float p0 = prev[nj][4 * qd], p1 = prev[nj][4 * qd + 1], p2 = prev[nj][4 * qd + 2], p3 = prev[nj][4 * qd + 3];
+            const float s0 = sa_prev[4 * qd], s1 = sa_prev[4 * qd + 1], s2 = sa_prev[4 * qd + 2], s3 = sa_prev[4 * qd + 3];
+            const float m0 = n2_prev[4 * qd], m1 = n2_prev[4 * qd + 1], m2 = n2_prev[4 * qd + 2], m3 = n2_prev[4 * qd + 3];
+            // lower bound of the quad's four keys (padding rows: ||a||^2 = +inf, count 0 -> key +inf, never below a bound)
+            const float pmin = __builtin_fminf(__builtin_fminf(p0, p1), __builtin_fminf(p2, p3));
+            const float smax = __builtin_fmaxf(__builtin_fmaxf(s0, s1), __builtin_fmaxf(s2, s3));
+            const float nmin = __builtin_fminf(__builtin_fminf(m0, m1), __builtin_fminf(m2, m3));
+            const float lb = __builtin_fmaf(nmin, cq[nj], pmin * smax);
+            if (__builtin_amdgcn_ballot_w64(lb < st[nj].d2) != 0ull) {
+                const uint32_t rb = prev_rowbase + 8u * (uint32_t)qd;
+                top2_push(st[nj], __builtin_fmaf(m0, cq[nj], p0 * s0), rb);
+                top2_push(st[nj], __builtin_fmaf(m1, cq[nj], p1 * s1), rb + 1u);
+                top2_push(st[nj], __builtin_fmaf(m2, cq[nj], p2 * s2), rb + 2u);
+                top2_push(st[nj], __builtin_fmaf(m3, cq[nj], p3 * s3), rb + 3u);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int GB, int NJ, int PF>
+__global__ __launch_bounds__(256, 2)
+void l2_knn2_counts_kernel(const MatchParams P)
+{
+    static_assert(GB % PF == 0, "prefetch window must divide the block count");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t h = lane >> 5, c = lane & 31u;
+    uint32_t pair, qb;
+    if (P.xcd_map) {                                       // pair p on XCD p % 8 (see l2_knn2_mfma_kernel)
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        pair = (j / P.qb_per_pair) * 8u + xcd;
+        qb = j % P.qb_per_pair;
+        if (pair >= P.n_pairs) return;
+    } else {
+        pair = blockIdx.x / P.qb_per_pair;
+        qb = blockIdx.x % P.qb_per_pair;
+    }
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles, nJ = Jp->n;
+    const uint32_t qt0 = (qb * 4u + wave) * NJ;
+    if (qt0 >= ntJ) return;                                // wave-uniform; no barriers in this kernel
+
+    // ---- query fragments (B operand): the NEGATED counts (a sign flip of an f16 integer), and per query 1 / (2 s_q), 2 s_q
+    f32x4 bq[NJ][GB];
+    float cq[NJ], kinv[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
+        const gf4p src = (gf4p)(const void*)Jp->tiledc + (size_t)qt * (GB * 64) + lane;
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] ^= 0x80008000u;
+            bq[nj][g] = __builtin_bit_cast(f32x4, w);
+        }
+        const uint32_t q = qt * 32u + c;
+        const float sq = q < nJ ? Jp->cscale[q] : 1.0f;
+        kinv[nj] = 2.0f * sq;
+        cq[nj] = 1.0f / kinv[nj];
+    }
+    Top2 st[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);
+
+    if (nI >= 2) {
+        const uint64_t pa = (uint64_t)Ip->tiledc, pn = (uint64_t)Ip->norms, ps = (uint64_t)Ip->cscale;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pn >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pn)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ps >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ps)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const uint32_t voffA = lane * 16u, voffN = h * 16u;
+        constexpr uint32_t tileB = (uint32_t)GB * 1024u;
+        const uint32_t hb = 4u * h;
+        f32x4 abuf[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) abuf[s] = bload16(ra, voffA, (uint32_t)s * 1024u);
+        // (||a||^2, scale) per accumulator element, two sets: step t loads tile t's (its keys are tested in step t + 1) while it tests the
+        // keys of tile t - 1 against the other set
+        f32x16 n2A, saA, n2B, saB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { n2B[r] = R3DM_INF; saB[r] = 1.0f; }   // "tile -1": ||a||^2 = +inf keeps it out of every list
+        f32x16 accA[NJ], accB[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[nj][r] = 0.0f;
+        uint32_t t = 0;
+        for (; t + 1 < ntI; t += 2) {
+            counts_tile_step<GB, NJ, PF>(ra, rn, rs, voffA, voffN, t * tileB + PF * 1024u, t * 128u, abuf, n2A, saA, n2B, saB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
+            counts_tile_step<GB, NJ, PF>(ra, rn, rs, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 1) * 128u, abuf, n2B, saB, n2A, saA, bq, cq, accB, accA, st, t * 32u + hb);
+        }
+        if (t < ntI) {
+            counts_tile_step<GB, NJ, PF>(ra, rn, rs, voffA, voffN, t * tileB + PF * 1024u, t * 128u, abuf, n2A, saA, n2B, saB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    top2_push(st[nj], __builtin_fmaf(n2A[r], cq[nj], accA[nj][r] * saA[r]), t * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        } else {
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    top2_push(st[nj], __builtin_fmaf(n2B[r], cq[nj], accB[nj][r] * saB[r]), (ntI - 1) * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        }
+    }
+    l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
+}
+
+template <int GB, int NJ, int PF>
+static hipError_t launch_l2_counts_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
+{
+    MatchParams P = Pin;
+    const uint32_t tiles_per_wg = 4u * NJ;
+    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
+    P.xcd_map = 1u;
+    const uint64_t grid64 = (uint64_t)((P.n_pairs + 7u) / 8u * 8u) * P.qb_per_pair;
+    if (grid64 == 0) return hipSuccess;
+    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((l2_knn2_counts_kernel<GB, NJ, PF>), dim3((uint32_t)grid64), dim3(256), 0, st, P);
+    return hipGetLastError();
+}
+
+// G = padded dim / 8 of the views (8, 16, 18, 32); hipErrorInvalidValue -> no count kernel, caller keeps the split tiles
+hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles)
+{
+    switch (G) {
+        case 8:  return launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles);
+        case 16: return launch_l2_counts_t<8, 2, 4>(st, P, max_nj_tiles);
+        case 18: return launch_l2_counts_t<9, 2, 3>(st, P, max_nj_tiles);
+        case 32: return launch_l2_counts_t<16, 1, 4>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }
 }

@@ -99,9 +99,10 @@ struct HostImage {
     uint32_t G = 0, n_tiles = 0, words = 0;
     bool has_xy = false, has_dup = false, live = false;
     bool borrowed = false;            // the buffers belong to an r3dm_index mounted into this slot for one call: never freed here
-    DevBuf rows, tiled, tiled16, tiledh, tiled8, norms, bin, xy, canon;
+    DevBuf rows, tiled, tiled16, tiledh, tiledc, cscale, tiled8, norms, bin, xy, canon;
     float max_abs = 0.0f; bool not_integer = true, has_negative = true;     // staging statistics (read back after the staging kernel)
     int32_t split_k = 0;                                                    // scale exponent of the f16 split tiles
+    bool counts_ok = false;                                                 // every row is small integers x a row scale: the count tiles are valid
     bool compact_ready = false;     // ann_rows16 / ann_rows8 reflect the staged rows (reset by staging)
     DevBuf ann_adj, ann_deg, ann_rows16, ann_rows8;   // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0; compact row copies only for bf16- / u8-exact views
     uint32_t ann_K = 0;
@@ -113,7 +114,7 @@ struct HostImage {
     void release()
     {
         if (borrowed) { *this = HostImage(); return; }     // drop the aliases, keep the index's memory
-        rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
+        rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiledc.release(); cscale.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
         ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; compact_ready = false; live = false;
         hnsw_l0.release(); hnsw_up_off.release(); hnsw_up.release(); hnsw_M = 0;
     }
@@ -253,7 +254,7 @@ struct r3dm_index {
 };
 
 // shared between the translation units
-int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3 = nullptr, int32_t split_k = 0);
+int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3 = nullptr, int32_t split_k = 0, bool counts_ok = false);
 int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
                     int32_t* knn_idx_host, float* knn_dist_host);
 int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_stride, uint32_t sort_cap,
