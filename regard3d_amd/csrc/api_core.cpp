@@ -122,7 +122,7 @@ int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_
     d.ann_adj = nullptr; d.ann_deg = nullptr; d.ann_rows16 = nullptr; d.ann_rows8 = nullptr;          // staging invalidates the graph index
     d.tiled16 = h.tiled16.as<uint16_t>();
     d.tiledh = h.tiledh.as<uint16_t>(); d.split_k = split_k;
-    d.tiledc = h.tiledc.as<uint16_t>(); d.cscale = h.cscale.as<float>(); d.counts_fail = counts_ok ? 0u : 1u;
+    d.tiledc = h.tiledc.as<uint16_t>(); d.cscale = h.cscale.as<float>(); d.cquad = h.cquad.as<float>(); d.tiledp = h.tiledp.as<uint16_t>(); d.cperm = h.cperm.as<uint32_t>(); d.counts_fail = counts_ok ? 0u : 1u;
     d.tiled8 = h.tiled8.as<uint8_t>();
     R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
@@ -174,6 +174,9 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         R3DM_HIP(c, hipMemsetAsync(h.tiledc.p, 0, tiledc_bytes, c->stream));
         R3DM_HIP(c, h.cscale.ensure((size_t)h.n_tiles * 32 * 4 + kSlackBytes));
         R3DM_HIP(c, hipMemsetAsync(h.cscale.p, 0, (size_t)h.n_tiles * 32 * 4 + kSlackBytes, c->stream));
+        R3DM_HIP(c, h.cquad.ensure((size_t)h.n_tiles * 256 + kSlackBytes));
+        R3DM_HIP(c, h.tiledp.ensure(tiledc_bytes));
+        R3DM_HIP(c, h.cperm.ensure((size_t)h.n_tiles * 32 * 4 + 256));
         R3DM_HIP(c, h.norms.ensure(norm_bytes));
         R3DM_HIP(c, hipMemsetAsync(h.tiled.p, 0, tiled_bytes, c->stream));
         R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0, norm_bytes, c->stream));
@@ -255,7 +258,8 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         uint32_t cfail = 1;
         if (dtype == R3DM_F32 && n && dim <= 256) {
             R3DM_HIP(c, hipMemsetAsync(cf, 0, 4, c->stream));
-            R3DM_HIP(c, launch_stage_counts(c->stream, h.rows.as<float>(), n, dim, (h.G + 1) / 2, h.n_tiles, h.tiledc.as<uint16_t>(), h.cscale.as<float>(), cf));
+            R3DM_HIP(c, launch_stage_counts(c->stream, h.rows.as<float>(), n, dim, (h.G + 1) / 2, h.n_tiles, h.tiledc.as<uint16_t>(), h.cscale.as<float>(), h.norms.as<float>(),
+                                            h.tiledp.as<uint16_t>(), h.cquad.as<float>(), h.cperm.as<uint32_t>(), cf));
             R3DM_HIP(c, hipMemcpyAsync(&cfail, cf, 4, hipMemcpyDeviceToHost, c->stream));
         }
         uint32_t st3[3] = {0, 0, 1};

@@ -1056,18 +1056,92 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
     }
 }
 
+// The DATASET side of the nominator reads the rows in the order of their scales (32 classes per binary order, i.e. scales within
+// 2.2 % of one another inside a class): the quad test of the kernel bounds four keys with the largest scale of their four rows, and
+// with rows in keypoint order (scales 30 % apart) that bound let a large share of the quads through to the per-key path.
+// One workgroup: counting sort of the rows by scale class -> cperm[position] = row (kNone behind the last row).
+__global__ __launch_bounds__(1024)
+void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm)
+{
+    __shared__ uint32_t hist[8192];
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < 8192u; b += 1024u) hist[b] = 0u;
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += 1024u) atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u);    // sign 0: exponent + 5 mantissa bits
+    __syncthreads();
+    uint32_t loc[8], run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { loc[k] = run; run += hist[tid * 8u + (uint32_t)k]; }
+    part[tid] = run;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t base = part[tid] - run;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hist[tid * 8u + (uint32_t)k] = base + loc[k];          // cursors
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += 1024u) cperm[atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u)] = r;
+    for (uint32_t r = n + tid; r < n_pad; r += 1024u) cperm[r] = kNone;
+}
+
+// one workgroup per tile of the ORDERED image: gather the rows cperm names from the keypoint-order count tiles, write their fragments
+// and the tile's 256-byte row line (||a||^2 of the 32 rows, then their negated scales)
+__global__ __launch_bounds__(256)
+void stage_counts_gather_kernel(const uint16_t* __restrict__ tiledc, const float* __restrict__ cscale, const float* __restrict__ norms,
+                                const uint32_t* __restrict__ cperm, uint32_t GB, uint16_t* __restrict__ tiledp, float* __restrict__ crow)
+{
+    const uint32_t t = blockIdx.x;
+    __shared__ uint32_t src[32];
+    if (threadIdx.x < 32u) src[threadIdx.x] = cperm[t * 32u + threadIdx.x];
+    __syncthreads();
+    uint16_t* dst = tiledp + (size_t)t * GB * 512;
+    for (uint32_t e = threadIdx.x; e < GB * 512u; e += 256u) {
+        const uint32_t c8 = e & 7u, r = (e >> 3) & 31u, hh = (e >> 8) & 1u, kb = e >> 9;
+        const uint32_t sr = src[r];
+        dst[e] = sr == kNone ? (uint16_t)0 : tiledc[(size_t)(sr >> 5) * GB * 512 + kb * 512u + (hh * 32u + (sr & 31u)) * 8u + c8];
+    }
+    if (threadIdx.x < 64u) {
+        const uint32_t sr = src[threadIdx.x & 31u];
+        crow[(size_t)t * 64u + threadIdx.x] = threadIdx.x < 32u ? (sr == kNone ? R3DM_INF : norms[sr]) : -(sr == kNone ? 1.0f : cscale[sr]);
+    }
+}
+
 hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
-                               uint16_t* tiledc, float* cscale, uint32_t* fail_dev)
+                               uint16_t* tiledc, float* cscale, const float* norms, uint16_t* tiledp, float* crow, uint32_t* cperm,
+                               uint32_t* fail_dev)
 {
     if (n_tiles == 0 || dim > 256u) return hipSuccess;
     hipLaunchKernelGGL(stage_counts_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, GB, tiledc, cscale, fail_dev);
+    hipLaunchKernelGGL(stage_counts_order_kernel, dim3(1), dim3(1024), 0, st, cscale, n, n_tiles * 32u, cperm);
+    hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow);
     return hipGetLastError();
 }
 
+// Per tile the wave loads ONE 256-byte line beside the nine fragment loads: lane l < 32 holds ||a||^2 of row l, lane 32 + l the negated
+// scale of row l.  A min over aligned groups of four lanes (two DPP steps) turns that into the quad summaries -- min ||a||^2 and
+// -max scale of rows 4 g .. 4 g + 3 in every lane of group g -- and a lane picks the eight numbers of its own accumulator quads
+// (rows 8 qd + 4 h + k: group 2 qd + h) with v_readlane + v_cndmask.  The per-row values are only looked at, through the lane crossbar,
+// for a quad that passes the test.  (Measured dead ends: both arrays as 16 values per lane -- eight more 1-KiB wave loads per tile:
+// 91 ms on the stage's 276 pairs; summaries read through `h ? p[a] : p[b]` -- the compiler selects the ADDRESS and emits flat loads
+// with a vmcnt(0) behind them that drains the fragment prefetch: 126 ms.)
+__device__ __forceinline__ float quad_min4(float v)
+{
+    // min over the aligned group of four lanes: xor-1 then xor-2 inside the DPP quad
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v = __builtin_fminf(v, a);
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return __builtin_fminf(v, b);
+}
+
 template <int GB, int NJ, int PF>
-__device__ __forceinline__ void counts_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rn, __amdgpu_buffer_rsrc_t rs,
-                                                 uint32_t voffA, uint32_t voffN, uint32_t soffA, uint32_t soffN, f32x4 (&abuf)[PF],
-                                                 f32x16& n2_load, f32x16& sa_load, const f32x16& n2_prev, const f32x16& sa_prev,
+__device__ __forceinline__ void counts_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rr, uint32_t voffA, uint32_t voffR,
+                                                 uint32_t soffA, uint32_t soffR, f32x4 (&abuf)[PF], uint32_t h,
+                                                 float& rowv_load, const float (&qs_prev)[8], float rowv_prev,
                                                  const f32x4 (&bq)[NJ][GB], const float (&cq)[NJ], f32x16 (&cur)[NJ], const f32x16 (&prev)[NJ],
                                                  Top2 (&st)[NJ], uint32_t prev_rowbase)
 {
@@ -1077,15 +1151,8 @@ __device__ __forceinline__ void counts_tile_step(__amdgpu_buffer_rsrc_t ra, __am
     for (int g = 0; g < GB; ++g) {
         const f32x4 a = abuf[g % PF];
         abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
-        if (g == (GB > 2 ? 2 : GB - 1)) {   // THIS tile's ||a||^2 and scales (tested in the next step), element 4 qd + k = row 8 qd + 4 h + k: the accumulator layout
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const f32x4 v = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
-                const f32x4 w = bload16(rs, voffN, soffN + (uint32_t)qd * 32u);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { n2_load[4 * qd + k] = v[k]; sa_load[4 * qd + k] = w[k]; }
-            }
-        }
+        if (g == (GB > 2 ? 2 : GB - 1))                    // THIS tile's row values (its keys are tested in the next step)
+            rowv_load = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)voffR, (int)soffR, 0));
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
             cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq[nj][g]),
@@ -1094,22 +1161,34 @@ __device__ __forceinline__ void counts_tile_step(__amdgpu_buffer_rsrc_t ra, __am
         for (int gi = (g * NG) / GB; gi < ((g + 1) * NG) / GB; ++gi) {
             const int nj = gi % NJ, qd = gi / NJ;
             const float p0 = prev[nj][4 * qd], p1 = prev[nj][4 * qd + 1], p2 = prev[nj][4 * qd + 2], p3 = prev[nj][4 * qd + 3];
-            const float s0 = sa_prev[4 * qd], s1 = sa_prev[4 * qd + 1], s2 = sa_prev[4 * qd + 2], s3 = sa_prev[4 * qd + 3];
-            const float m0 = n2_prev[4 * qd], m1 = n2_prev[4 * qd + 1], m2 = n2_prev[4 * qd + 2], m3 = n2_prev[4 * qd + 3];
             // lower bound of the quad's four keys (padding rows: ||a||^2 = +inf, count 0 -> key +inf, never below a bound)
-            const float pmin = __builtin_fminf(__builtin_fminf(p0, p1), __builtin_fminf(p2, p3));
-            const float smax = __builtin_fmaxf(__builtin_fmaxf(s0, s1), __builtin_fmaxf(s2, s3));
-            const float nmin = __builtin_fminf(__builtin_fminf(m0, m1), __builtin_fminf(m2, m3));
-            const float lb = __builtin_fmaf(nmin, cq[nj], pmin * smax);
+            const float pmin = g == 0 ? __builtin_fminf(__builtin_fminf(p0, p1), __builtin_fminf(p2, p3)) : vmin2(vmin3(p0, p1, p2), p3);
+            const float lb = __builtin_fmaf(qs_prev[4 + qd], cq[nj], pmin * qs_prev[qd]);
             if (__builtin_amdgcn_ballot_w64(lb < st[nj].d2) != 0ull) {
                 const uint32_t rb = prev_rowbase + 8u * (uint32_t)qd;
-                top2_push(st[nj], __builtin_fmaf(m0, cq[nj], p0 * s0), rb);
-                top2_push(st[nj], __builtin_fmaf(m1, cq[nj], p1 * s1), rb + 1u);
-                top2_push(st[nj], __builtin_fmaf(m2, cq[nj], p2 * s2), rb + 2u);
-                top2_push(st[nj], __builtin_fmaf(m3, cq[nj], p3 * s3), rb + 3u);
+                const uint32_t r0 = 8u * (uint32_t)qd + 4u * h;               // the quad's first row within its tile
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float n2 = __shfl(rowv_prev, (int)(r0 + (uint32_t)k)), sa = -__shfl(rowv_prev, (int)(32u + r0 + (uint32_t)k));
+                    const float pk = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
+                    top2_push(st[nj], __builtin_fmaf(n2, cq[nj], pk * sa), rb + (uint32_t)k);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the eight summary numbers of a lane's accumulator quads from the tile's row line: [qd] = max scale, [4 + qd] = min ||a||^2
+__device__ __forceinline__ void counts_quad_summaries(float rowv, uint32_t h, float (&qs)[8])
+{
+    const int g = __builtin_bit_cast(int, quad_min4(rowv));
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 8 * qd)), n1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 8 * qd + 4));
+        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 32 + 8 * qd)), s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 36 + 8 * qd));
+        qs[4 + qd] = h ? n1 : n0;
+        qs[qd] = -(h ? s1 : s0);
     }
 }
 
@@ -1162,27 +1241,24 @@ void l2_knn2_counts_kernel(const MatchParams P)
     for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);
 
     if (nI >= 2) {
-        const uint64_t pa = (uint64_t)Ip->tiledc, pn = (uint64_t)Ip->norms, ps = (uint64_t)Ip->cscale;
+        const uint64_t pa = (uint64_t)Ip->tiledp;         // rows in the order of their scales (stage_counts_order_kernel)
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
             0, 0x7FFFFFFF, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pn >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pn)),
-            0, 0x7FFFFFFF, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ps >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ps)),
-            0, 0x7FFFFFFF, 0x00020000);
-        const uint32_t voffA = lane * 16u, voffN = h * 16u;
+        const uint32_t voffA = lane * 16u;
         constexpr uint32_t tileB = (uint32_t)GB * 1024u;
         const uint32_t hb = 4u * h;
+        const uint64_t prw = (uint64_t)Ip->cquad;
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(prw >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)prw)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const uint32_t voffR = lane * 4u;
         f32x4 abuf[PF];
 #pragma unroll
         for (int s = 0; s < PF; ++s) abuf[s] = bload16(ra, voffA, (uint32_t)s * 1024u);
-        // (||a||^2, scale) per accumulator element, two sets: step t loads tile t's (its keys are tested in step t + 1) while it tests the
-        // keys of tile t - 1 against the other set
-        f32x16 n2A, saA, n2B, saB;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { n2B[r] = R3DM_INF; saB[r] = 1.0f; }   // "tile -1": ||a||^2 = +inf keeps it out of every list
+        // the row line of tile t is loaded in step t and used in step t + 1 (the keys of tile t are tested while tile t + 1 is multiplied)
+        float rvA = 0.0f, rvB = h ? -1.0f : R3DM_INF;      // "tile -1": ||a||^2 = +inf keeps it out of every list
+        float qsA[8], qsB[8];
         f32x16 accA[NJ], accB[NJ];
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
@@ -1190,22 +1266,38 @@ void l2_knn2_counts_kernel(const MatchParams P)
             for (int r = 0; r < 16; ++r) accB[nj][r] = 0.0f;
         uint32_t t = 0;
         for (; t + 1 < ntI; t += 2) {
-            counts_tile_step<GB, NJ, PF>(ra, rn, rs, voffA, voffN, t * tileB + PF * 1024u, t * 128u, abuf, n2A, saA, n2B, saB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
-            counts_tile_step<GB, NJ, PF>(ra, rn, rs, voffA, voffN, (t + 1) * tileB + PF * 1024u, (t + 1) * 128u, abuf, n2B, saB, n2A, saA, bq, cq, accB, accA, st, t * 32u + hb);
+            counts_quad_summaries(rvB, h, qsB);
+            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
+            counts_quad_summaries(rvA, h, qsA);
+            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, h, rvB, qsA, rvA, bq, cq, accB, accA, st, t * 32u + hb);
         }
         if (t < ntI) {
-            counts_tile_step<GB, NJ, PF>(ra, rn, rs, voffA, voffN, t * tileB + PF * 1024u, t * 128u, abuf, n2A, saA, n2B, saB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
+            counts_quad_summaries(rvB, h, qsB);
+            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    top2_push(st[nj], __builtin_fmaf(n2A[r], cq[nj], accA[nj][r] * saA[r]), t * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2)) + hb;
+                    top2_push(st[nj], __builtin_fmaf(__shfl(rvA, (int)row), cq[nj], accA[nj][r] * -__shfl(rvA, (int)(32u + row))), t * 32u + row);
+                }
         } else {
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    top2_push(st[nj], __builtin_fmaf(n2B[r], cq[nj], accB[nj][r] * saB[r]), (ntI - 1) * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2)) + hb;
+                    top2_push(st[nj], __builtin_fmaf(__shfl(rvB, (int)row), cq[nj], accB[nj][r] * -__shfl(rvB, (int)(32u + row))), (ntI - 1) * 32u + row);
+                }
+        }
+    }
+    // the lists name rows of the ordered image: back to keypoint order before the tail re-scores and certifies them
+    {
+        const uint32_t* __restrict__ perm = Ip->cperm;
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+            if (st[nj].i0 != kNone) st[nj].i0 = perm[st[nj].i0];
+            if (st[nj].i1 != kNone) st[nj].i1 = perm[st[nj].i1];
         }
     }
     l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);

@@ -99,7 +99,7 @@ struct HostImage {
     uint32_t G = 0, n_tiles = 0, words = 0;
     bool has_xy = false, has_dup = false, live = false;
     bool borrowed = false;            // the buffers belong to an r3dm_index mounted into this slot for one call: never freed here
-    DevBuf rows, tiled, tiled16, tiledh, tiledc, cscale, tiled8, norms, bin, xy, canon;
+    DevBuf rows, tiled, tiled16, tiledh, tiledc, tiledp, cscale, cquad, cperm, tiled8, norms, bin, xy, canon;
     float max_abs = 0.0f; bool not_integer = true, has_negative = true;     // staging statistics (read back after the staging kernel)
     int32_t split_k = 0;                                                    // scale exponent of the f16 split tiles
     bool counts_ok = false;                                                 // every row is small integers x a row scale: the count tiles are valid
@@ -114,7 +114,7 @@ struct HostImage {
     void release()
     {
         if (borrowed) { *this = HostImage(); return; }     // drop the aliases, keep the index's memory
-        rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiledc.release(); cscale.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
+        rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiledc.release(); tiledp.release(); cscale.release(); cquad.release(); cperm.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
         ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; compact_ready = false; live = false;
         hnsw_l0.release(); hnsw_up_off.release(); hnsw_up.release(); hnsw_M = 0;
     }

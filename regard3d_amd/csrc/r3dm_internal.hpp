@@ -72,8 +72,11 @@ struct ImgDev {
     int32_t split_k;
     // count tiles (kernels_match.hip, l2_knn2_counts_kernel): rows that are small integers times a per-row scale (LIOP) as f16 integers
     // in fragment order [n_tiles][G/2][2][32][8], the row scales, and whether EVERY row of the view is of that form
-    const uint16_t* tiledc;
-    const float* cscale;
+    const uint16_t* tiledc;    // keypoint order: the QUERY side of the nominator
+    const float* cscale;       // [n] row scales, keypoint order
+    const uint16_t* tiledp;    // the same tiles with the rows in the order of their scales: the DATASET side
+    const float* cquad;        // [n_tiles][64] the row line of an ordered tile: ||a||^2 of its 32 rows, then their negated scales
+    const uint32_t* cperm;     // [n_tiles * 32] row of the ordered image -> keypoint index (kNone on padding)
     uint32_t counts_fail;      // != 0: some row is not (filled by the staging kernel)
     // binary views, opt-in MFMA Hamming (r3dm_set_hamming_mfma): one byte (0 / 1) per bit in i8 fragment order,
     // [n_tiles][words][2][32][16]; `norms` then holds popcount + 0x3F800000 as float bits
@@ -339,7 +342,8 @@ hipError_t launch_stage_bin8(hipStream_t st, const uint32_t* bin, uint32_t n, ui
 hipError_t launch_l2_knn2_split(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
 hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
 hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
-                               uint16_t* tiledc, float* cscale, uint32_t* fail_dev);
+                               uint16_t* tiledc, float* cscale, const float* norms, uint16_t* tiledp, float* crow, uint32_t* cperm,
+                               uint32_t* fail_dev);
 hipError_t launch_stage_split(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
                               uint16_t* tiledh, const uint32_t* img_stats_dev, int32_t* split_k_dev);
 hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t count, int scan_all);
