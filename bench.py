@@ -14,6 +14,8 @@ them out).
   c4       configs[3]: 1000 x 8192 SIFT-128, 499,500 pairs, sharded over the GPUs + one all-gather.
   c5       configs[4]: 1000 x 16384 SIFT-128, KGraph-style approximate 2-NN (graph index + graph search) + F filter.
   liop144  what Regard3D actually matches (src/Regard3DFeatures.h:44-48): 200 x 8192 x f32[144], real-valued, unit length.
+  liop144c the same collection in the form vl_liop.c EMITS its rows (integer votes divided by their norm, vl_liop.c:553-575): the opt-in
+           leg then nominates on count tiles (one f16 MFMA per 16 dimensions instead of the split nominator's three).
   stage    the reference's DEFAULT stage end to end, one facade call per step (R3DComputeMatches::computeMatches): N synthetic
            4000 x 3000 photographs resident in HBM -> Fast-A-KAZE + LIOP -> .feat/.desc -> LIOP-144 matching (arm 9, and arm 0 =
            the GUI default) -> F + E + H AC-RANSAC -> matches.*.txt/.bin; per-phase times, a roofline for the detector and one
@@ -63,6 +65,8 @@ CONFIGS = {
                what="SIFT-128 f32 descriptors (integer-valued bins)", how="KGraph-style approximate 2-NN (graph index K 24 + pool search P 10 S 10)"),
     "liop144": dict(kind="liop", images=200, feat=8192, seed=2002, matcher="brute", ratio=0.6, squared=True,
                     what="LIOP-like f32[144] descriptors (real-valued, unit length)", how="brute-force L2 2-NN"),
+    "liop144c": dict(kind="liopc", images=200, feat=8192, seed=2002, matcher="brute", ratio=0.6, squared=True,
+                     what="LIOP-144 f32 descriptors in the form vl_liop emits (integer votes over their norm, unit length)", how="brute-force L2 2-NN"),
 }
 
 
@@ -214,7 +218,7 @@ def main():
         attach_traffic(out["opt_in_integer_mfma"]["roofline"], a.config, "l2_knn2_int_kernel", emu, base_images, n_feat)
     if world == 1 and not a.no_opt_in and kp is None and kind == "akaze":
         out["opt_in_hamming_mfma"] = opt_in_hamming(ctx, step, fence, g, gf, job_pairs)
-    if world == 1 and not a.no_opt_in and kp is None and kind == "liop":
+    if world == 1 and not a.no_opt_in and kp is None and kind in ("liop", "liopc"):
         out["opt_in_split_mfma"] = opt_in_split(ctx, step, fence, g, gf, job_pairs)
     if world == 1:
         attach_traffic(out["roofline"], a.config, out["roofline"]["kernel"].split("<")[0], emu, base_images, n_feat)
@@ -580,15 +584,20 @@ def opt_in_split(ctx, step, fence, g, gf, job_pairs):
     finally:
         ctx.set_split_mfma(False)
     same = all(np.array_equal(getattr(x, f), getattr(y, f)) for x, y in ((g, g2), (gf, gf2)) for f in ("pairs", "offsets", "matches"))
-    # matrix work of the split kernel: 3 f16 MFMAs per 16 dims = 3 x the algorithmic 2 n^2 D flops
-    ach = 3.0 * sm2.algorithmic_flops / (sm2.ms_match_kernels * 1e-3) / 1e12 if sm2.ms_match_kernels > 0 else 0.0
+    # matrix work: the split kernel runs 3 f16 MFMAs per 16 dims (3 x the algorithmic 2 n^2 D flops); on COUNT tiles (rows = integer votes
+    # x a row scale: what LIOP is) the nominator runs ONE (l2_knn2_counts_kernel: executed = algorithmic)
+    counts = int(getattr(sm2, "n_counts_mfma", 0)) > 0
+    mult = 1.0 if counts else 3.0
+    ach = mult * sm2.algorithmic_flops / (sm2.ms_match_kernels * 1e-3) / 1e12 if sm2.ms_match_kernels > 0 else 0.0
     return {"value": job_pairs / el2, "unit": "pairs/s", "ms_per_step": el2 * 1e3, "steps": 1,
-            "identical_to_headline_graphs": bool(same), "split_mfma_launches": int(sm2.n_split_mfma),
-            "dtype": "f16 hi/lo pieces nominate (3 MFMAs per 16 dims, f32 accumulate); distances re-scored in f32 as in the headline",
+            "identical_to_headline_graphs": bool(same), "split_mfma_launches": int(sm2.n_split_mfma), "count_tile_launches": int(getattr(sm2, "n_counts_mfma", 0)),
+            "dtype": ("f16 integer votes nominate (1 MFMA per 16 dims, f32 accumulate), row scales in the epilogue" if counts else
+                      "f16 hi/lo pieces nominate (3 MFMAs per 16 dims, f32 accumulate)") + "; distances re-scored in f32 as in the headline",
             "exact_fallback_fraction": sm2.n_exact_fallback / max(sm2.n_queries, 1),
-            "roofline": {"bound": "mfma", "kernel": "l2_knn2_split_kernel<GB=9,NJ=2>", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s (executed f16 matrix flops = 3 x algorithmic)", "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "algorithmic_tflops": ach / 3.0, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
+            "roofline": {"bound": "mfma", "kernel": "l2_knn2_counts_kernel<GB=9,NJ=2>" if counts else "l2_knn2_split_kernel<GB=9,NJ=2>", "achieved": ach,
+                         "peak": BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s (executed f16 matrix flops = %d x algorithmic)" % int(mult), "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_tflops": ach / mult, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
             "filter_kernel_ms": sa2.ms_filter_kernels,
             "wall_ms": {"match": sa2.ms_wall_match, "match_post": sa2.ms_wall_match_post, "filter": sa2.ms_wall_filter}}
 
@@ -629,7 +638,7 @@ def cpu_baseline(name, cfg, ctx, descs, xys, g, gf, budget_s, kp):
     binary = cfg["kind"] == "akaze"
     n = int(descs.shape[1])
     # seconds per pair on one core, scalar code like OpenMVG's metrics: 8192^2 x 128 f32 ~ 9 s, Hamming 16 words ~ 0.7 s, graph search ~ 0.1 s
-    per_pair = {"sift": 9.0, "liop": 10.0, "akaze": 0.7}[cfg["kind"]] * (n / 8192.0) ** 2
+    per_pair = {"sift": 9.0, "liop": 10.0, "liopc": 10.0, "akaze": 0.7}[cfg["kind"]] * (n / 8192.0) ** 2
     if kp is not None:
         per_pair = 0.12 * (n / 16384.0)
     S = int(min(n_images - 1, max(min(cores, 16), int(cores * budget_s / per_pair))))

@@ -78,9 +78,9 @@ def intrinsics() -> np.ndarray:
 
 def make_scene(n_images: int, n_feat: int, kind: str = "sift", seed: int = 2002,
                dtype: str = "f32", outlier_frac: float = 0.15, dim: int | None = None) -> Scene:
-    assert kind in ("sift", "liop", "akaze")
+    assert kind in ("sift", "liop", "liopc", "akaze")
     if dim is None:
-        dim = {"sift": 128, "liop": 144, "akaze": 64}[kind]
+        dim = {"sift": 128, "liop": 144, "liopc": 144, "akaze": 64}[kind]
     n_shared = int(round(0.6 * n_feat))
     step = max(n_shared // 4, 1)
     n_world = (n_images - 1) * step + n_shared
@@ -133,13 +133,13 @@ def make_scene(n_images: int, n_feat: int, kind: str = "sift", seed: int = 2002,
             packed = np.packbits(padded, axis=1, bitorder="little")          # 61 bytes, LSB first
             d = np.zeros((n_feat, dim), np.uint8); d[:, :61] = packed
         else:
-            integer = (kind == "sift")
+            integer = kind in ("sift", "liopc")          # "liopc": integer votes over their norm -- the form vl_liop emits (vl_liop.c:553-575)
             sigma = 6.0
             d = np.empty((n_feat, dim), np.float32)
             d[:n_shared] = _sift_from_base(wbase[ids], r, sigma, integer)
             d[n_shared:] = _sift_from_base(_sift_base(r, n_dis, dim), r, sigma, integer)
-            if kind == "liop":
-                d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12)
+            if kind in ("liop", "liopc"):
+                d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12).astype(np.float32)
             if dtype == "u8":
                 assert integer
                 d = d.astype(np.uint8)
@@ -153,16 +153,16 @@ def make_scene(n_images: int, n_feat: int, kind: str = "sift", seed: int = 2002,
 
 def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda", dim: int | None = None,
                      outlier_frac: float = 0.15, kind: str = "sift"):
-    """The scenes of make_scene() ("sift": integer-valued f32 bins; "liop": the same real-valued, unit length, 144-D;
+    """The scenes of make_scene() ("sift": integer-valued f32 bins; "liop": the same real-valued, unit length, 144-D; "liopc": the same rounded to integer votes BEFORE the normalisation, the form vl_liop.c emits;
     "akaze": 486 random bits with 8 % flips per observation, packed LSB-first into 61 of 64 bytes), sampled with torch's
     device RNG so that bench.py can build the 200 x 8192 workloads (and the 1000-view ones) in seconds, directly in HBM.
     Every rank that calls it with the same seed on the same GPU model gets the same tensors.
     Returns (descs [N, n, dim] f32 -- uint8 for "akaze" --, xys [N, n, 2] f32, world_ids [N, n] int64) on `device`."""
     import torch
 
-    assert kind in ("sift", "liop", "akaze")
+    assert kind in ("sift", "liop", "liopc", "akaze")
     if dim is None:
-        dim = {"sift": 128, "liop": 144, "akaze": 64}[kind]
+        dim = {"sift": 128, "liop": 144, "liopc": 144, "akaze": 64}[kind]
 
     g = torch.Generator(device=device); g.manual_seed(seed)
     n_shared = int(round(0.6 * n_feat)); step = max(n_shared // 4, 1)
@@ -229,9 +229,9 @@ def make_scene_torch(n_images: int, n_feat: int, seed: int = 2002, device="cuda"
             d[:n_shared] = wbase[ids]; d[n_shared:] = sift_base(n_dis)
             d += 6.0 * torch.randn((n_feat, dim), generator=g, device=device, dtype=torch.float32)
             d.clamp_(0.0, 255.0)
-            if kind == "sift":
+            if kind in ("sift", "liopc"):
                 d.round_()
-            else:
+            if kind in ("liop", "liopc"):                # "liopc": integer votes over their norm, as vl_liop emits them
                 d /= d.norm(dim=1, keepdim=True).clamp_min(1e-12)
         perm = torch.randperm(n_feat, generator=g, device=device)
         descs[i] = d[perm]; xys[i] = xy[perm].float()
