@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--images", type=int, default=0, help="override the collection size of the config (stated in config.workload)")
     ap.add_argument("--feat", type=int, default=0, help="override the features per image of the config")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--via-c-abi", action="store_true",
+                    help="reassemble the graphs through the library's own RCCL entry (r3dm_allgather_graphs) instead of torch.distributed; same graphs_sha16")
     ap.add_argument("--emulate-world", type=int, default=0, help="N = 1 only: run shard 0 of a W-way job")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,6 +141,15 @@ def main():
     job_pairs = mine.shape[0] if emu else pairs.shape[0]          # pairs the whole (measured) job processes per step
     kp = api.KGraphParams.preset(3) if cfg["matcher"] == "kgraph" else None
 
+    comm = None
+    if a.via_c_abi:
+        # RCCL communicator of the library itself: rank 0 draws the id, the other ranks receive its 128 bytes (here through the
+        # torch.distributed group that exists anyway; a C++ host would use MPI_Bcast or a file)
+        uid = [api.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            td.broadcast_object_list(uid, src=0)
+        comm = api.Comm(uid[0], rank, world, local_rank)
+
     def match(p):
         if kp is not None:
             ctx.drop_indices()       # every pass builds the index of each image I again, as kgraph_match does (the build is inside the timed step)
@@ -150,7 +161,9 @@ def main():
         s_match = ctx.stats()
         gf = ctx.filter_F(g, 4.0, 2048, seed=5489)
         s_all = ctx.stats()
-        full = r3dist.all_gather_graphs([g, gf], device=xdev)
+        # the one exchange of the path: through torch.distributed (default), or through the library's own RCCL entry (--via-c-abi:
+        # r3dm_allgather_graphs, what a C++ host with one process per GPU calls)
+        full = comm.allgather_graphs([g, gf]) if comm is not None else r3dist.all_gather_graphs([g, gf], device=xdev)
         return g, gf, full, s_match, s_all
 
     def fence():
@@ -203,6 +216,8 @@ def main():
                      "match_only_pairs_per_s_this_rank": (mine.shape[0] * a.steps / (wall["match"] * 1e-3)) if wall["match"] > 0 else None,
                      "exact_fallback_queries_per_step": acc["fallback"] / a.steps, "queries_per_step": acc["queries"] / a.steps,
                      "exact_fallback_fraction": acc["fallback"] / max(acc["queries"], 1),
+                     "exchange": ("r3dm_allgather_graphs: the library's RCCL entry (C ABI), sizes + padded payload" if comm is not None else
+                                  "torch.distributed all_gather of sizes + padded payload (" + (backend if world > 1 else "one rank: nothing to exchange") + ")"),
                      "putative_pairs": int(full[0].num_pairs), "putative_matches": int(full[0].num_matches),
                      "F_pairs": int(full[1].num_pairs), "F_matches": int(full[1].num_matches),
                      # identity of the reassembled graphs (pairs, offsets, matches of both): equal across N for the same collection

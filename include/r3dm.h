@@ -431,6 +431,30 @@ int r3dm_multi_extract_features_ex(r3dm_multi* m, uint32_t n_images, const float
 /* owner_out[p] = the device / rank (0..world-1) that the snake deal gives pair p.  Pure host code (no GPU needed). */
 int r3dm_shard_pairs(const uint32_t* pairs_ij, uint64_t n_pairs, uint32_t world, uint32_t* owner_out);
 
+/* ---- multi-GPU, one process per GPU: the ONE collective of the path ----
+ * Every rank matches and filters its share of the pair list (r3dm_shard_pairs) and then calls r3dm_allgather_graphs: one
+ * ncclAllGather of the per-rank sizes (8 bytes each) and one of the packed graphs padded to the largest rank, over RCCL (xGMI between
+ * the GPUs of a node); every rank ends up with the graphs of the whole collection, ordered by (I, J) -- the std::map the reference's
+ * OpenMP threads fill under `omp critical` (/root/reference/src/R3DComputeMatches.cpp:465,481-487).  The communicator is RCCL's own:
+ * rank 0 draws an id (r3dm_comm_unique_id, 128 bytes) and hands it to the other ranks by whatever the host has (MPI_Bcast, a file,
+ * torch.distributed), every rank calls r3dm_comm_create(id, rank, world, device).  RCCL is bound at run time (dlopen): without
+ * librccl.so these calls return R3DM_ERR_UNSUPPORTED, they never fall back to another transport.
+ * r3dm_graphs_pack / r3dm_graphs_unpack_merge expose the wire format (uint32 words: [n_graphs, len_k ..] then per graph
+ * [P, M_lo, M_hi, pairs, counts, matches]) for hosts that bring their own transport; words from r3dm_graphs_pack are released with
+ * r3dm_words_free. */
+typedef struct r3dm_comm r3dm_comm;
+int  r3dm_comm_unique_id(void* id_out_128);
+int  r3dm_comm_create(const void* id_128, int rank, int world, int device_id, r3dm_comm** out);
+void r3dm_comm_destroy(r3dm_comm* comm);
+int  r3dm_comm_rank(const r3dm_comm* comm);
+int  r3dm_comm_world(const r3dm_comm* comm);
+const char* r3dm_comm_last_error(const r3dm_comm* comm);
+int  r3dm_allgather_graphs(r3dm_comm* comm, const r3dm_graph* const* local, uint32_t n_graphs, r3dm_graph** merged_out /* [n_graphs] */);
+int  r3dm_graphs_pack(const r3dm_graph* const* local, uint32_t n_graphs, uint32_t** words_out, uint64_t* n_words_out);
+void r3dm_words_free(uint32_t* words);
+int  r3dm_graphs_unpack_merge(const uint32_t* const* rank_words, const uint64_t* rank_n_words, uint32_t world, uint32_t n_graphs,
+                              r3dm_graph** merged_out /* [n_graphs] */);
+
 /* ---- files: ".txt" (what Regard3D's consumers read) or ".bin" (cereal portable binary) ---- */
 int r3dm_save_matches(const r3dm_graph* g, const char* path);
 int r3dm_load_matches(const char* path, r3dm_graph** out);

@@ -31,6 +31,8 @@ EXPORTS = [
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_transfer_counts", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
     "r3dm_multi_match_pairs", "r3dm_multi_match_pairs_kgraph", "r3dm_multi_match_pairs_hnsw", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
+    "r3dm_comm_unique_id", "r3dm_comm_create", "r3dm_comm_destroy", "r3dm_comm_rank", "r3dm_comm_world", "r3dm_comm_last_error",
+    "r3dm_allgather_graphs", "r3dm_graphs_pack", "r3dm_words_free", "r3dm_graphs_unpack_merge",
 ]
 
 
@@ -282,6 +284,15 @@ def load_library():
     L.r3dm_graph_free.argtypes = [vp]; L.r3dm_graph_free.restype = None
     L.r3dm_graph_from_csr.argtypes = [vp, u64, vp, vp, C.POINTER(vp)]
     L.r3dm_graph_merge.argtypes = [vp, u32, C.POINTER(vp)]
+    L.r3dm_comm_unique_id.argtypes = [vp]
+    L.r3dm_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.r3dm_comm_destroy.argtypes = [vp]; L.r3dm_comm_destroy.restype = None
+    L.r3dm_comm_rank.argtypes = [vp]; L.r3dm_comm_world.argtypes = [vp]
+    L.r3dm_comm_last_error.argtypes = [vp]; L.r3dm_comm_last_error.restype = C.c_char_p
+    L.r3dm_allgather_graphs.argtypes = [vp, vp, u32, vp]
+    L.r3dm_graphs_pack.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+    L.r3dm_words_free.argtypes = [vp]; L.r3dm_words_free.restype = None
+    L.r3dm_graphs_unpack_merge.argtypes = [vp, vp, u32, u32, vp]
     L.r3dm_save_matches.argtypes = [vp, C.c_char_p]
     L.r3dm_load_matches.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.r3dm_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -396,6 +407,80 @@ class Graph:
         if rc != 0:
             raise R3dmError(f"r3dm_graph_merge -> {rc}")
         return Graph(h.value)
+
+
+def graphs_pack(graphs: Sequence["Graph"]) -> np.ndarray:
+    """r3dm_graphs_pack: the wire format of a rank's graphs (uint32 words), for a transport of the caller's own"""
+    L = load_library()
+    arr = (C.c_void_p * len(graphs))(*[g._h for g in graphs])
+    words = C.c_void_p(); n = C.c_uint64()
+    rc = L.r3dm_graphs_pack(arr, len(graphs), C.byref(words), C.byref(n))
+    if rc != 0:
+        raise R3dmError(f"r3dm_graphs_pack -> {rc}")
+    try:
+        return np.ctypeslib.as_array(C.cast(words, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+    finally:
+        L.r3dm_words_free(words)
+
+
+def graphs_unpack_merge(rank_words: Sequence[np.ndarray], n_graphs: int) -> List["Graph"]:
+    """r3dm_graphs_unpack_merge: the packed graphs of every rank -> the graphs of the whole collection, ordered by (I, J)"""
+    L = load_library()
+    bufs = [np.ascontiguousarray(w, np.uint32) for w in rank_words]
+    ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    lens = (C.c_uint64 * len(bufs))(*[b.size for b in bufs])
+    out = (C.c_void_p * max(n_graphs, 1))()
+    rc = L.r3dm_graphs_unpack_merge(ptrs, lens, len(bufs), n_graphs, out)
+    if rc != 0:
+        raise R3dmError(f"r3dm_graphs_unpack_merge -> {rc}")
+    return [Graph(out[k]) for k in range(n_graphs)]
+
+
+class Comm:
+    """r3dm_comm: the RCCL communicator of the one-process-per-GPU route (r3dm_allgather_graphs).  Rank 0 draws the id
+    (Comm.unique_id()) and hands its 128 bytes to the other ranks; every rank then creates its end."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = 0):
+        L = load_library()
+        h = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        rc = L.r3dm_comm_create(buf, rank, world, device, C.byref(h))
+        if rc != 0:
+            raise R3dmError(f"r3dm_comm_create -> {rc}")
+        self._h = h.value
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * 128)()
+        rc = load_library().r3dm_comm_unique_id(buf)
+        if rc != 0:
+            raise R3dmError(f"r3dm_comm_unique_id -> {rc}" + (" (librccl.so not found)" if rc == -5 else ""))
+        return bytes(buf)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                load_library().r3dm_comm_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def rank(self) -> int:
+        return load_library().r3dm_comm_rank(self._h)
+
+    @property
+    def world(self) -> int:
+        return load_library().r3dm_comm_world(self._h)
+
+    def allgather_graphs(self, local: Sequence["Graph"]) -> List["Graph"]:
+        L = load_library()
+        arr = (C.c_void_p * len(local))(*[g._h for g in local])
+        out = (C.c_void_p * max(len(local), 1))()
+        rc = L.r3dm_allgather_graphs(self._h, arr, len(local), out)
+        if rc != 0:
+            raise R3dmError(f"r3dm_allgather_graphs -> {rc}: {L.r3dm_comm_last_error(self._h).decode()}")
+        return [Graph(out[k]) for k in range(len(local))]
 
 
 class Index:
