@@ -132,6 +132,7 @@ extern "C" int r3dm_graphs_unpack_merge(const uint32_t* const* rank_words, const
                 parts[k].push_back(std::move(g));
                 at += len;
             }
+            if (at != n) return R3DM_ERR_INVALID;                   // (words behind the last graph: not a buffer of this format)
         }
         for (uint32_t k = 0; k < n_graphs; ++k) {
             std::vector<const r3dm_graph*> ptrs;
