@@ -80,6 +80,6 @@ def test_bench_via_c_abi_reassembles_the_same_graphs():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--images", "24", "--feat", "1024", "--steps", "1", "--warmup", "0",
                             "--no-cpu-baseline", "--no-opt-in", "--no-stage-leg"] + extra, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
-        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        out[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])      # (RCCL prints a version banner on stdout)
     assert out["torch"]["detail"]["graphs_sha16"] == out["c_abi"]["detail"]["graphs_sha16"]
     assert "r3dm_allgather_graphs" in out["c_abi"]["detail"]["exchange"]
