@@ -67,6 +67,50 @@ __device__ void liop_ref_qsort(uint2* __restrict__ arr, int n, uint16_t* __restr
     }
 }
 
+// The same quick sort run by the whole wave, level by level: the partitions of disjoint ranges commute, so the segments of one
+// recursion depth are partitioned side by side, a lane each (exactly the reference's Lomuto pass per segment), and their children
+// form the next depth's list.  Same final arrangement as the depth-first original; the serial work drops from ~n log n element steps
+// to the longest segment of every depth (~2 n): the tie pass of a batch of 226 k keypoints took 5.9 ms with one lane per patch.
+// seg: two lists of (begin, end) pairs, 340 pairs each (a depth has at most n / 2 segments of two or more elements); cnt[2]: their lengths.
+__device__ void liop_ref_qsort_wave(uint2* __restrict__ arr, int n, uint16_t* __restrict__ seg, uint32_t* __restrict__ cnt, uint32_t lane)
+{
+    constexpr int kListPairs = (kLiopMaxPix + 4) / 2;
+    if (lane == 0) { seg[0] = 0; seg[1] = (uint16_t)(n - 1); cnt[0] = n >= 2 ? 1u : 0u; cnt[1] = 0u; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int ci = 0;; ci ^= 1) {
+        const uint32_t nseg = cnt[ci];
+        if (nseg == 0u) break;
+        const uint16_t* cur = seg + 2 * kListPairs * ci;
+        uint16_t* nxt = seg + 2 * kListPairs * (ci ^ 1);
+        for (uint32_t sg = lane; sg < nseg; sg += 64u) {
+            const int begin = cur[2 * sg], end = cur[2 * sg + 1];
+            const int pivot = (end + begin) / 2;
+            uint2 t = arr[pivot]; arr[pivot] = arr[end]; arr[end] = t;
+            const float pv = __uint_as_float(arr[end].x);
+            int low = begin;
+            for (int i = begin; i < end; i += 4) {
+                uint2 e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = arr[i + j];                 // (arr carries 4 entries of slack; positions >= end are not used)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (i + j < end && __uint_as_float(e[j].x) - pv <= 0.0f) {
+                        if (low != i + j) { const uint2 o = arr[low]; arr[i + j] = o; arr[low] = e[j]; }
+                        ++low;
+                    }
+                }
+            }
+            t = arr[low]; arr[low] = arr[end]; arr[end] = t;
+            // children of two or more elements (a one-element range is a no-op in the reference too)
+            if (low + 1 < end) { const uint32_t k = atomicAdd(&cnt[ci ^ 1], 1u); nxt[2 * k] = (uint16_t)(low + 1); nxt[2 * k + 1] = (uint16_t)end; }
+            if (begin < low - 1) { const uint32_t k = atomicAdd(&cnt[ci ^ 1], 1u); nxt[2 * k] = (uint16_t)begin; nxt[2 * k + 1] = (uint16_t)(low - 1); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) cnt[ci] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // 4-element version of the same quick sort (neighbour samples with equal intensities)
 __device__ void liop_ref_qsort4(const float (&v)[4], int (&p)[4])
 {
@@ -151,6 +195,7 @@ void liop_kernel(const LiopParams P)
     __shared__ uint16_t perm[kLiopSortCap];
     __shared__ uint32_t hist[144];
     __shared__ float s_norm;
+    __shared__ uint32_t qcnt[2];
 
     const uint32_t lane = threadIdx.x;
     const uint32_t N = P.n_pix;
@@ -208,7 +253,7 @@ void liop_kernel(const LiopParams P)
             } else {
                 for (uint32_t i = lane; i < N + 4u; i += 64) qarr[i] = make_uint2(i < N ? __float_as_uint(inten[i]) : 0u, i);
                 r3dm_syncthreads();
-                if (lane == 0) liop_ref_qsort(qarr, (int)N, qstack);
+                liop_ref_qsort_wave(qarr, (int)N, qstack, qcnt, lane);
                 r3dm_syncthreads();
                 for (uint32_t i = lane; i < N; i += 64) perm[i] = (uint16_t)qarr[i].y;
                 r3dm_syncthreads();
