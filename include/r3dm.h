@@ -81,6 +81,9 @@ int  r3dm_device_info(const r3dm_ctx* ctx, char* arch, size_t arch_cap, int* n_c
 int r3dm_set_image(r3dm_ctx* ctx, uint32_t view_id, uint32_t width, uint32_t height,
                    const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);
 int r3dm_clear_images(r3dm_ctx* ctx);
+/* r3dm_clear_images keeps the staging buffers of up to 256 cleared views for the next collection (the index buffers of a view are
+ * always released); r3dm_trim gives those spares back to the device as well. */
+int r3dm_trim(r3dm_ctx* ctx);
 
 /* Opt-in integer fast path of the L2 matcher (default off; no reference counterpart -- the reference has one L2 loop,
  * openMVG/matching/metric.hpp L2_Vectorized via ArrayMatcherBruteForce).  When every view of a batch holds

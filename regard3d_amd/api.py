@@ -19,7 +19,7 @@ F32, U8, BIN = 0, 1, 2
 NONE = 0xFFFFFFFF
 
 EXPORTS = [
-    "r3dm_create", "r3dm_destroy", "r3dm_last_error", "r3dm_device_info", "r3dm_set_image", "r3dm_clear_images",
+    "r3dm_create", "r3dm_destroy", "r3dm_last_error", "r3dm_device_info", "r3dm_set_image", "r3dm_clear_images", "r3dm_trim",
     "r3dm_match_pairs", "r3dm_filter_F", "r3dm_filter_H", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
@@ -555,6 +555,10 @@ class Context:
 
     def clear_images(self):
         self._check(self._L.r3dm_clear_images(self._h), "r3dm_clear_images")
+
+    def trim(self):
+        """give the staging buffers kept by clear_images() back to the device"""
+        self._check(self._L.r3dm_trim(self._h), "r3dm_trim")
 
     def match_pairs(self, pairs, dist_ratio: float = 0.6, squared_metric: bool = True) -> Graph:
         pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)

@@ -313,14 +313,32 @@ extern "C" int r3dm_clear_images(r3dm_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     // the views are forgotten, their device buffers are kept for the next collection (a stage object that lives across runs, or a
     // bench loop, registers views of the same sizes again and again: six hipMalloc per view were most of the registration time)
+    // Kept: the staging buffers of at most kSpareViews views (a collection larger than that gives the rest back at once).  Never kept:
+    // the per-view INDEX buffers (graph adjacency, compact row copies, HNSW arrays) -- they are rebuilt per collection and nothing
+    // reuses them as they stand, so a context that once held a 1000-view collection does not sit on their gigabytes.
+    constexpr size_t kSpareViews = 256;
     for (auto& im : c->imgs) {
         if (!im) continue;
         if (im->borrowed) { im->release(); continue; }
-        im->live = false; im->has_K = false; im->ann_K = 0; im->hnsw_M = 0; im->compact_ready = false; im->n = 0;
+        if (c->spare.size() >= kSpareViews) { im->release(); continue; }
+        im->ann_adj.release(); im->ann_deg.release(); im->ann_rows16.release(); im->ann_rows8.release();
+        im->hnsw_l0.release(); im->hnsw_up_off.release(); im->hnsw_up.release();
+        im->live = false; im->has_K = false; im->ann_K = 0; im->hnsw_M = 0; im->compact_ready = false; im->n = 0; im->counts_ok = false;
         c->spare.push_back(std::move(im));
     }
     c->imgs.clear();
     c->slot_of.clear();
+    return R3DM_OK;
+}
+
+// give the spare staging buffers back to the device (a long-lived context between two collections of very different sizes)
+extern "C" int r3dm_trim(r3dm_ctx* c)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& im : c->spare) if (im) im->release();
+    c->spare.clear();
     return R3DM_OK;
 }
 
