@@ -235,6 +235,7 @@ def main():
         out["opt_in_hamming_mfma"] = opt_in_hamming(ctx, step, fence, g, gf, job_pairs)
     if world == 1 and not a.no_opt_in and kp is None and kind in ("liop", "liopc"):
         out["opt_in_split_mfma"] = opt_in_split(ctx, step, fence, g, gf, job_pairs)
+        attach_traffic(out["opt_in_split_mfma"]["roofline"], a.config, out["opt_in_split_mfma"]["roofline"]["kernel"].split("<")[0], emu, base_images, n_feat)
     if world == 1:
         attach_traffic(out["roofline"], a.config, out["roofline"]["kernel"].split("<")[0], emu, base_images, n_feat)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -372,6 +373,7 @@ def stage_main(a, embed=None):
         ctx.detect_akaze_batch(imgs[:B], 0.001)
         sd = ctx.stats()
         det_gbs = sd.detect_algorithmic_bytes / (sd.ms_detect_kernels * 1e-3) / 1e9
+        det_cmp_gbs = sd.detect_compulsory_bytes / (sd.ms_detect_kernels * 1e-3) / 1e9
         out = {
             "metric": "image-pairs matched/sec (+ F-inlier filter)", "value": n_pairs * a.steps / elapsed, "unit": "pairs/s", "n_gpus": 1,
             "steps": a.steps, "warmup": max(a.warmup, 1), "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -403,14 +405,20 @@ def stage_main(a, embed=None):
                                                  "served_by": "exhaustive matcher" if r0g["match_was_exhaustive"] else "graph matcher",
                                                  "putative_matches_recovered_vs_arm_9": r0g["n_putative_matches"] / max(r9["n_putative_matches"], 1)},
             "roofline": {"bound": "hbm", "kernel": f"Fast-A-KAZE detector pass, B = {B} images (ak_* kernels, first scale-space launch .. keypoint compaction)",
-                         "achieved": det_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": det_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_image": sd.detect_algorithmic_bytes / B, "ms_per_image": sd.ms_detect_kernels / B,
-                         "note": "algorithmic bytes = every stencil pass of the launch sequence reads / writes whole image planes once (DESIGN.md section 4.8); "
-                                 "measured in a dedicated pass (one context, HIP events on the library's stream), the stage itself keeps "
-                                 f"{conc} such passes in flight"},
+                         "achieved": det_cmp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": det_cmp_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_counted": "compulsory",
+                         "compulsory_bytes_per_image": sd.detect_compulsory_bytes / B, "as_structured_bytes_per_image": sd.detect_algorithmic_bytes / B,
+                         "achieved_as_structured": det_gbs, "frac_as_structured": det_gbs / HBM_PEAK_GBS,
+                         "ms_per_image": sd.ms_detect_kernels / B,
+                         "note": "compulsory bytes = what a perfectly fused level would still move (smoothed plane in + out, determinant out, conductivity out, "
+                                 "8 B per pixel and FED step: round 2's count); as-structured bytes = every stencil pass of the launch sequence reads / writes "
+                                 "whole planes once (round 3's count; PMC FETCH_SIZE agrees with it).  `frac` is on the compulsory count -- fusing passes raises it, "
+                                 "the as-structured fraction only says how fast the passes that exist run (DESIGN.md section 4.8).  Measured in a dedicated pass "
+                                 f"(one context, HIP events on the library's stream); the stage itself keeps {conc} such passes in flight"},
         }
-        # essential-matrix kernel: f64 vector work of the models it evaluated (r3dm_filter_report) over its HIP-event time
-        out["roofline_E"] = stage_E_roofline(d, views, last)
+        out["roofline_liop"] = stage_liop_roofline(ctx, dev, last, N)
+        # the AC-RANSAC kernels: counted f64 flops of the residual passes over the HIP-event time of the side-by-side call + CU occupancy
+        out["roofline_filters"] = stage_filter_roofline(d, views)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = stage_cpu_baseline(ctx, imgs, d, K, W, H, a.cpu_seconds)
         print(json.dumps(out))
@@ -419,14 +427,60 @@ def stage_main(a, embed=None):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def stage_E_roofline(d, views, last):
-    """achieved f64 flop/s of acransac_kernel<2> on the putative graph of the stage: per evaluated model m x 30 flops of residuals
-    (F = K2^-T E K1^-1 applied to every putative, SURVEY 8d's per-model figure) + per 5-point sample ~8e4 flops (null space, 10 x 20
-    elimination, degree-10 Sturm chain with 64 bisection steps: an estimate, stated as such)."""
+# liop_kernel<false>, one wavefront per 41 x 41 patch: VALU instructions per patch, SQ_INSTS_VALU / SQ_WAVES of a rocprofv3 --pmc pass of
+# tools/liop_perf.py (profiles/r04_pmc_liop.txt; + 1,642 SALU, 984 LDS instructions per patch).  A wave64 VALU instruction occupies its
+# SIMD16 for 4 cycles: the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 = 614.4 G wave-instructions/s.
+LIOP_VALU_PER_PATCH = 9688.0
+VALU_ISSUE_PEAK_G = 256 * 4 * 2.4e9 / 4 / 1e9
+
+
+def stage_liop_roofline(ctx, dev, last, n_images):
+    """LIOP descriptor kernel in a dedicated pass (65,536 blurred random patches resident in HBM, the probe of tools/liop_perf.py): bound by
+    VALU issue -- the 1,024-key bitonic network on (intensity, position) keys and the f64 bilinear samples; its HBM traffic (6.7 KB in,
+    576 B out per patch) is 2 % of the HBM roof.  The stage's own LIOP time (extraction + descriptor + tie pass) is reported beside it."""
+    n = 65536
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    img = torch.rand((n, 1, 41, 41), generator=g, device=dev)
+    k = torch.tensor([1, 4, 6, 4, 1], device=dev, dtype=torch.float32); k = (k[:, None] * k[None, :]); k /= k.sum()
+    P = torch.nn.functional.conv2d(img, k[None, None], padding=2)[:, 0].contiguous()
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(3):
+        ctx.liop_describe_patches(P)
+        ms.append(ctx.stats().ms_liop_kernel)
+    m = sorted(ms)[1]
+    rate = n / (m * 1e-3)
+    ach = rate * LIOP_VALU_PER_PATCH / 1e9
+    kp = float(last["n_keypoints"])
+    return {"bound": "valu", "kernel": "liop_kernel<false> (one wavefront per patch; 65,536 patches, dedicated pass)", "achieved": ach, "peak": VALU_ISSUE_PEAK_G,
+            "unit": "G wave-instructions/s (VALU issue)", "frac": ach / VALU_ISSUE_PEAK_G, "traffic": None,
+            "valu_instructions_per_patch": LIOP_VALU_PER_PATCH, "patches_per_s": rate, "kernel_ms": m,
+            "hbm_GB_per_s": n * (6724 + 576) / (m * 1e-3) / 1e9,
+            "in_stage": {"liop_kernels_ms_per_image_sum_over_contexts": last["features"]["ms_liop_kernels"] / n_images,
+                         "keypoints_per_image": kp / n_images,
+                         "patches_per_s_all_three_kernels": kp / (last["features"]["ms_liop_kernels"] * 1e-3) if last["features"]["ms_liop_kernels"] > 0 else None},
+            "note": "instructions per patch from PMC (profiles/r04_pmc_liop.txt: SQ_INSTS_VALU / SQ_WAVES of this kernel, same source) x patches / "
+                    "HIP-event time.  in_stage: patch extraction (warp + blur), descriptor and tie pass of all images, as the contexts' events time them "
+                    "(two contexts share the GPU, so their sum exceeds the wall time of the features phase)"}
+
+
+# f64 operations of ONE residual (one model applied to one putative match), counted on the source (kernels_filter.hip; + - * / one each):
+#   F  sym_epipolar_err:   F x1 12, F^T x2 8, x2.(F x1) 4, squares + sums + two reciprocals + the product 12          = 36
+#   E  epipolar_dist_err:  l = F x1 12, l.x2 4, d^2 1, l0^2 + l1^2 3, the quotient 1                                 = 21
+#   H  h_asym_err:         w 4, two numerators 8, two quotients 2, two differences 2, squares + sum 3               = 19
+RESIDUAL_F64_FLOPS = {"F": 36.0, "E": 21.0, "H": 19.0}
+F64_VECTOR_PEAK_T = 78.6          # MI355X_MICROARCH.md: FP64 vector = 256 CU x 64 FMA lanes/clk x 2 x 2.4 GHz
+
+
+def stage_filter_roofline(d, views):
+    """The AC-RANSAC kernels of the stage (acransac_coop_kernel for pairs of >= 4096 putatives + acransac_kernel<kind> for the rest), F, E
+    and H side by side as the facade runs them: counted f64 flops of the residual passes = sum over pairs of
+    (models evaluated, r3dm_filter_report) x (putative matches of the pair) x RESIDUAL_F64_FLOPS[kind], over the HIP-event time of
+    the side-by-side call, against the f64 vector peak; CU occupancy = workgroups of the call / 256.  Every input of the fraction is
+    in the object: flops = sum(per_kind[k].model_match_evaluations x flops_per_residual[k])."""
     g = api.Graph.load(os.path.join(d, "matches.putative.bin"))
     ctx = api.Context(0)
     import numpy as _np
-    kps = []
     for v in views:
         raw = _np.fromfile(os.path.join(d, v["basename"] + ".desc"), _np.uint8)
         n = int(_np.frombuffer(raw[:8].tobytes(), _np.uint64)[0])
@@ -434,17 +488,35 @@ def stage_E_roofline(d, views, last):
         xy = _np.loadtxt(os.path.join(d, v["basename"] + ".feat"), dtype=_np.float32).reshape(-1, 4)[:, :2].copy()
         ctx.set_image(v["id"], desc, xy, v["width"], v["height"])
         ctx.set_intrinsics(v["id"], _np.array([[v["focal_px"], 0, v["ppx"]], [0, v["focal_px"], v["ppy"]], [0, 0, 1.0]]))
-    ge = ctx.filter_E(g, 4.0, 2048, seed=5489)
-    ms = ctx.stats().ms_filter_kernels
-    rep = ctx.filter_report()
-    counts = _np.diff(g.offsets.astype(_np.int64))
-    flops = sum(r[3] * float(m) * 30.0 + r[2] * 8.0e4 for r, m in zip(rep, counts))
+    counts = _np.diff(g.offsets.astype(_np.int64)).astype(_np.float64)
+    ctx.filter_FEH(g, "FEH", 4.0, 2048, seed=5489)                       # warm: buffers, streams
+    ms3 = []
+    for _ in range(3):
+        _, msk, _ = ctx.filter_FEH(g, "FEH", 4.0, 2048, seed=5489)
+        ms3.append(float(max(msk)))
+    st = ctx.stats()
+    wgs, coop_items = int(st.n_filter_workgroups), int(st.n_filter_coop_pairs)
+    ms = sorted(ms3)[1]
+    per_kind, flops = {}, 0.0
+    for kind, call in (("F", ctx.filter_F), ("E", ctx.filter_E), ("H", ctx.filter_H)):
+        call(g, 4.0, 2048, seed=5489)
+        alone_ms = ctx.stats().ms_filter_kernels
+        rep = ctx.filter_report()
+        ev = float(sum(r[3] * m for r, m in zip(rep, counts)))
+        per_kind[kind] = {"models_evaluated": int(sum(r[3] for r in rep)), "iterations": int(sum(r[2] for r in rep)),
+                          "model_match_evaluations": ev, "flops_per_residual": RESIDUAL_F64_FLOPS[kind], "kernel_ms_alone": alone_ms}
+        flops += ev * RESIDUAL_F64_FLOPS[kind]
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     ctx.close()
-    return {"bound": "valu", "kernel": "acransac_kernel<2> (essential matrix, 5-point)", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s (f64 vector)",
-            "frac": ach / 78.6, "traffic": None, "kernel_ms": ms, "pairs": int(g.num_pairs), "kept_pairs": int(ge.num_pairs),
-            "models_evaluated": int(sum(r[3] for r in rep)), "iterations": int(sum(r[2] for r in rep)),
-            "note": "latency-bound by construction (one workgroup per pair, sequential AC-RANSAC iterations): the f64 roof is the stated bound, the useful numbers are kernel_ms and iterations"}
+    return {"bound": "valu", "kernel": "acransac_coop_kernel (pairs of >= 4096 putatives, F + E + H in one pool of workgroups) + acransac_kernel<kind> (shorter pairs)",
+            "achieved": ach, "peak": F64_VECTOR_PEAK_T, "unit": "TFLOP/s (f64 vector)", "frac": ach / F64_VECTOR_PEAK_T, "traffic": None,
+            "kernel_ms": ms, "kernel_ms_runs": ms3, "flops": flops, "per_kind": per_kind,
+            "pairs": int(g.num_pairs), "putative_matches": int(counts.sum()),
+            "workgroups": wgs, "items_on_cooperative_kernel": coop_items, "cu_occupancy": min(wgs, 256) / 256.0,
+            "note": "residual passes only (the minimal solvers, the NFA walk and the rare sorts are not counted: this is a lower bound of the f64 work). "
+                    "The algorithm is a chain of dependent iterations per pair (sample -> models -> residuals of all matches -> NFA -> pool), "
+                    "so the f64 roof is an upper bound no schedule reaches; round 3's one-workgroup-per-pair shape ran the same stage at "
+                    "75 ms with 94 of 256 CUs busy (profiles/r03_end_bench_stage_kernel_stats.txt)"}
 
 
 def stage_cpu_baseline(ctx, imgs, d, K, W, H, budget_s):
@@ -517,9 +589,10 @@ def roofline(name, cfg, acc, dim, world):
                        "HIP-event time of the launches; the gathers (evaluations x %d B rows) are 99.3 %% cache hits" % int(row_bytes),
                "evaluations": int(acc["ann_dist"]), "evaluations_per_query": acc["ann_dist"] / max(acc["queries"], 1), "row_bytes": int(row_bytes),
                "gathered_GB_per_s": acc["ann_dist"] * row_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "search_ms_total": ms}
-        ent_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        ent_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if VALU_PER_QUERY and os.path.exists(ent_path):
             ent = json.load(open(ent_path)).get("c5:ann_search_kernel")
+            # (this entry predates the machine-code fingerprints: keyed by the hash of kernels_ann.hip, which has not changed since)
             if ent and ent.get("source_sha16") == _sha16(os.path.join(ROOT, "regard3d_amd", "csrc", "kernels_ann.hip")):
                 out["traffic"] = ent["traffic_bytes_per_pair"] * acc.get("pairs", 0) / max(acc["launches"], 1)
                 out["traffic_source"] = f"{ent['from']}: FETCH_SIZE + WRITE_SIZE of the search launches of a 96-image step, per pair ({ent['traffic_bytes_per_pair'] / 1e6:.2f} MB) x the pairs of a launch"
@@ -544,24 +617,32 @@ def _sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def _kernel_code_sha16(kernel):
+    from regard3d_amd.codeobj import kernel_hash, mangled_needle
+    return kernel_hash(os.path.join(ROOT, "regard3d_amd", "libr3dm.so"), mangled_needle(kernel))
+
+
 def attach_traffic(roof, config, kernel, emu, images, feat):
-    """HBM traffic of one launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (a
-    process cannot profile itself; tools/pmc_bench.sh): profiles/r02_pmc_traffic.json, keyed by config + kernel and by the
-    hash of the kernel source it was measured on -- a stale entry is reported as null, never silently."""
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    """HBM traffic of one launch of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command (a process
+    cannot profile itself): profiles/pmc_traffic.json (tools/pmc_traffic_json.py), keyed by config + kernel and by the fingerprint
+    of the kernel's MACHINE CODE in the library that was profiled (regard3d_amd/codeobj.py).  An entry is printed only while the
+    library this process runs holds that very code -- edits elsewhere in the source file do not stale it, and the same library
+    state gives the same answer in every run; otherwise traffic stays null and traffic_source says why."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(tpath) or emu or images != CONFIGS[config]["images"] or feat != CONFIGS[config]["feat"]:
         return
     ent = json.load(open(tpath)).get(f"{config}:{kernel}")
     if not ent:
         return
-    cur = _sha16(os.path.join(ROOT, "regard3d_amd", "csrc", ent.get("source", "kernels_match.hip")))
-    if ent.get("source_sha16") != cur:
-        roof["traffic_source"] = f"profiles/r02_pmc_traffic.json is stale for {kernel} (kernel source changed since the PMC run)"
+    cur = _kernel_code_sha16(ent["kernel"])
+    if not ent.get("code_sha16") or ent.get("code_sha16") != cur:
+        roof["traffic_source"] = (f"profiles/pmc_traffic.json: the entry for {ent['kernel']} was measured on other machine code "
+                                  f"(entry {ent.get('code_sha16')}, this library {cur}): not reported")
         return
     roof["traffic"] = ent["traffic_bytes_per_launch"]
-    roof["traffic_source"] = (f"profiles/r02_pmc_traffic.json <- {ent.get('from', '?')}: separate rocprofv3 --pmc passes of this command on the same "
-                              "kernel source (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured inside this process; "
-                              "algorithmic %.4g bytes/launch" % ent["algorithmic_bytes_per_launch"])
+    roof["traffic_source"] = (f"profiles/pmc_traffic.json <- {ent.get('from', '?')}: separate rocprofv3 --pmc passes of this command on the same "
+                              f"kernel machine code (code_sha16 {cur}; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured inside this process"
+                              + ("; algorithmic %.4g bytes/launch" % ent["algorithmic_bytes_per_launch"] if "algorithmic_bytes_per_launch" in ent else ""))
 
 
 def opt_in_integer(ctx, step, fence, g, gf, job_pairs):
@@ -612,7 +693,8 @@ def opt_in_split(ctx, step, fence, g, gf, job_pairs):
             "roofline": {"bound": "mfma", "kernel": "l2_knn2_counts_kernel<GB=9,NJ=2>" if counts else "l2_knn2_split_kernel<GB=9,NJ=2>", "achieved": ach,
                          "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s (executed f16 matrix flops = %d x algorithmic)" % int(mult), "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "algorithmic_tflops": ach / mult, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
+                         "algorithmic_tflops": ach / mult, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1),
+                         "algorithmic_bytes_per_launch": sm2.algorithmic_bytes / max(sm2.n_match_launches, 1)},
             "filter_kernel_ms": sa2.ms_filter_kernels,
             "wall_ms": {"match": sa2.ms_wall_match, "match_post": sa2.ms_wall_match_post, "filter": sa2.ms_wall_filter}}
 

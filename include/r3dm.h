@@ -165,10 +165,13 @@ typedef struct {
 int r3dm_filter_report(const r3dm_ctx* ctx, r3dm_pair_report* out, uint64_t cap);
 /* The three filters of one putative graph side by side -- what the reference runs one after the other at src/R3DComputeMatches.cpp:
  * 2113-2120 (F), :2130-2204 (E + overlap rule) and :2216-2233 (H); they only read the putative graph.  which: bit 0 F, bit 1 E, bit 2 H
- * (the out_* of a requested filter must not be NULL).  Each filter has its own stream and work buffers in the context, the three
- * AC-RANSAC kernels share the GPU: a collection with few, long pairs (one workgroup per pair, bound by ONE CU's f64 rate) leaves most
- * CUs idle under a single kernel.  Results are those of r3dm_filter_F / _E / _H.  ms_kernels3 / ms_wall3 (optional): HIP-event time
- * of the kernel and wall time of each call in the order F, E, H (they overlap).  r3dm_filter_report afterwards: the E call's, else F's. */
+ * (the out_* of a requested filter must not be NULL).  Pairs with >= 4096 putatives of all requested filters share ONE cooperative
+ * kernel (a pool of persistent workgroups; a pair's residual passes are row slices run by idle workers), shorter pairs run one
+ * workgroup per pair on a stream per filter; one filter alone is served the same way (r3dm_filter_F / _E / _H).  Results are those of
+ * r3dm_filter_F / _E / _H whatever the split (inlier sets, models, iteration counts: tests/test_gpu_filter_coop.py).  ms_kernels3 /
+ * ms_wall3 (optional): HIP-event time of the kernels and wall time of each call in the order F, E, H (they overlap; a filter with
+ * long pairs ends when the cooperative kernel does).  r3dm_filter_report afterwards: the E call's, else F's.  r3dm_stats:
+ * n_filter_workgroups / n_filter_coop_pairs. */
 int r3dm_filter_FEH(r3dm_ctx* ctx, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter, uint64_t seed, int which,
                     uint32_t e_min_count, float e_min_ratio, r3dm_graph** out_F, r3dm_graph** out_E, r3dm_graph** out_H,
                     double* ms_kernels3, double* ms_wall3);
@@ -500,6 +503,10 @@ typedef struct {
     uint64_t n_hnsw_launches;      /* launches of the HNSW search kernel                                                                */
     uint64_t n_hnsw_retries;       /* ... of those, repeats because a query's candidate heap outgrew its LDS room                       */
     uint64_t n_counts_mfma;        /* launches of the split nominator that ran on COUNT tiles (rows = small integers x a row scale: LIOP; one f16 MFMA per 16 dimensions instead of three) */
+    double   detect_compulsory_bytes; /* the last detector pass: bytes a perfectly fused level would still move (smoothed plane in + out, determinant out,
+                                       * conductivity out, 8 bytes per pixel and FED step); detect_algorithmic_bytes is the as-structured count            */
+    uint64_t n_filter_workgroups;  /* workgroups of the last AC-RANSAC call (all its filters): pool workers of the cooperative kernel + one per short pair */
+    uint64_t n_filter_coop_pairs;  /* ... (pair, filter) items that ran on the cooperative kernel                                                          */
 } r3dm_stats;
 int r3dm_get_stats(const r3dm_ctx* ctx, r3dm_stats* out);
 

@@ -52,7 +52,8 @@ class Stats(C.Structure):
                 ("n_hamming_mfma", C.c_uint64), ("n_detect_images", C.c_uint64), ("n_ann_rows16", C.c_uint64), ("n_ann_rows8", C.c_uint64), ("n_ann_dot8", C.c_uint64),
                 ("ms_detect_kernels", C.c_double), ("detect_algorithmic_bytes", C.c_double),
                 ("ms_liop_wall", C.c_double), ("ms_feature_files", C.c_double),
-                ("n_hnsw_launches", C.c_uint64), ("n_hnsw_retries", C.c_uint64), ("n_counts_mfma", C.c_uint64)]
+                ("n_hnsw_launches", C.c_uint64), ("n_hnsw_retries", C.c_uint64), ("n_counts_mfma", C.c_uint64),
+                ("detect_compulsory_bytes", C.c_double), ("n_filter_workgroups", C.c_uint64), ("n_filter_coop_pairs", C.c_uint64)]
 
 
 class FeaturesTotals(C.Structure):

@@ -169,7 +169,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     out.lv = ak_levels(w, h);
     const std::vector<AkLevelHost>& lv = out.lv;
     const int nl = (int)lv.size();
-    c->stats.n_detect_images = B; c->stats.ms_detect_kernels = 0.0; c->stats.detect_algorithmic_bytes = 0.0;
+    c->stats.n_detect_images = B; c->stats.ms_detect_kernels = 0.0; c->stats.detect_algorithmic_bytes = 0.0; c->stats.detect_compulsory_bytes = 0.0;
     if (nl == 0) { c->stats.ms_detect = now_ms() - t_call; return R3DM_OK; }     // image too small for a single evolution level
     hipStream_t st = c->stream;
     const size_t n0 = (size_t)w * h;
@@ -243,8 +243,12 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     float* inv_k2 = reinterpret_cast<float*>(small + 1024);
 
     // algorithmic HBM bytes of the launch sequence: every pass reads / writes whole image planes once
-    double planes_px = 0.0;
-    auto tally = [&](int lw, int lh, int n_planes) { planes_px += (double)lw * lh * n_planes; };
+    // Beside it the COMPULSORY count: the planes a perfectly fused level would still move -- a smoothed plane in and out, the determinant
+    // out, the conductivity out, and per FED step the evolving plane in and out (a step needs its neighbours' previous step, so steps do
+    // not fuse across a plane without halo recomputation); the k-contrast statistics ride on the Gaussian.  This is round 2's 8 bytes per
+    // pixel and pass; a roofline fraction on it falls when launches are fused, the as-structured one does not.
+    double planes_px = 0.0, compulsory_px = 0.0;
+    auto tally = [&](int lw, int lh, int n_planes, int n_compulsory) { planes_px += (double)lw * lh * n_planes; compulsory_px += (double)lw * lh * n_compulsory; };
 
     // Compute_Determinant_Hessian_Response_Single (AKAZEFeatures.cpp:389-410)
     auto hessian = [&](int i, const float* src) -> hipError_t {
@@ -252,7 +256,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
         hipError_t e;
         // two launches: smooth -> (Lx, Ly);  (Lx, Ly) -> Lxx, Lxy, Lyy on the spot -> the determinant
         if ((e = ak_scaled_deriv_xy(st, src, Lx(i), Ly(i), lw, lh, iB, s)) != hipSuccess) return e;
-        tally(lw, lh, 3 + 3);
+        tally(lw, lh, 3 + 3, 1);
         return ak_scaled_deriv_det(st, Lx(i), Ly(i), Ldet(i), lw, lh, iB, s);
     };
 
@@ -264,15 +268,15 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
         hipError_t e;
 #define AK_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
         // (the base level's smoothed image IS evolution level 0: written straight into Lt(0), no copy)
-        AK_TRY(ak_gaussian(st, img, tmp, Lt(0), w, h, iB, taps_off)); tally(w, h, 2);
+        AK_TRY(ak_gaussian(st, img, tmp, Lt(0), w, h, iB, taps_off)); tally(w, h, 2, 2);
         AK_TRY(hessian(0, Lt(0)));
         AK_TRY(hipMemsetAsync(small, 0, (size_t)B * 4096 * 4, st));
         const int nbins = 300;
         if (nl > 1) {
-            AK_TRY(ak_gaussian(st, img, tmp, flow, w, h, iB, taps_one)); tally(w, h, 2);
+            AK_TRY(ak_gaussian(st, img, tmp, flow, w, h, iB, taps_one)); tally(w, h, 2, 1);
             // (the Scharr derivative images of the reference exist only inside these two kernels: DESIGN.md section 4.8)
-            AK_TRY(ak_modg_max(st, flow, w, h, iB, hmax_bits)); tally(w, h, 1);
-            AK_TRY(ak_modg_hist(st, flow, w, h, iB, hmax_bits, nbins, hist)); tally(w, h, 1);
+            AK_TRY(ak_modg_max(st, flow, w, h, iB, hmax_bits)); tally(w, h, 1, 0);
+            AK_TRY(ak_modg_hist(st, flow, w, h, iB, hmax_bits, nbins, hist)); tally(w, h, 1, 0);
         }
         AK_TRY(ak_kcontrast(st, hmax_bits, hist, nbins, (uint32_t)((size_t)(w - 2) * (h - 2)), nl > 1 ? 1 : 0, inv_k2, iB));
         for (int i = 1; i < nl; ++i) {
@@ -324,8 +328,8 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
                     cur = o;
                 }
             }
-            if (lv[i].octave > lv[i - 1].octave) { tally(lv[i - 1].w, lv[i - 1].h, 1); tally(lw, lh, 1); }
-            tally(lw, lh, 2 + 6 + 2 + 3 * (int)tau.size());       // Gaussian (fused row + column pass) 2, derivatives + determinant 6, conductivity 2, 3 per FED step
+            if (lv[i].octave > lv[i - 1].octave) { tally(lv[i - 1].w, lv[i - 1].h, 1, 1); tally(lw, lh, 1, 1); }
+            tally(lw, lh, 2 + 6 + 2 + 3 * (int)tau.size(), 2 + 1 + 1 + 2 * (int)tau.size());       // Gaussian (fused row + column pass) 2, derivatives + determinant 6, conductivity 2, 3 per FED step
         }
 #undef AK_TRY
         return hipSuccess;
@@ -429,7 +433,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     c->stats.ms_detect_kernels = ms;
-    c->stats.detect_algorithmic_bytes = planes_px * 4.0 * B;
+    c->stats.detect_algorithmic_bytes = planes_px * 4.0 * B; c->stats.detect_compulsory_bytes = compulsory_px * 4.0 * B;
     c->stats.ms_detect = now_ms() - t_call;
     r3dm_features_totals& T = c->feat_totals;
     T.n_images += B; T.n_passes += 1; T.ms_detect_kernels += ms; T.detect_algorithmic_bytes += planes_px * 4.0 * B; T.ms_wall += c->stats.ms_detect;

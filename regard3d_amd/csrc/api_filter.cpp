@@ -564,6 +564,12 @@ static int filter_launch(r3dm_ctx* c, FilterCallOut& o, FilterParams* fps, const
     }
     bool coop = false;
     const int rc = coop_launch_shared(c, o, fps, plans, n, coop);
+    {   // occupancy bookkeeping of the call (r3dm_stats): workgroups launched, items on the cooperative kernel
+        uint64_t wgs = 0, items = 0;
+        for (int k = 0; k < n; ++k) { wgs += fps[k].n_short; items += fps[k].n_coop; }
+        for (int k = 0; k < n; ++k) if (coop && fps[k].n_coop) { wgs += fps[k].coop_workers; break; }
+        c->stats.n_filter_workgroups = wgs; c->stats.n_filter_coop_pairs = coop ? items : 0;
+    }
     hipError_t first = hipSuccess;
     for (int k = 0; k < n; ++k) {
         if (!fps[k].n_items) continue;
@@ -655,14 +661,15 @@ extern "C" int r3dm_filter_E(r3dm_ctx* c, const r3dm_graph* putative, double max
     return r3dm_guarded(c, [&]() -> int { return r3dm_filter_E_impl(c, putative, max_residual_px, max_iter, seed, min_count, min_ratio, out, E_out); });
 }
 
-// F, E and H of one putative graph side by side: the three kernels on streams of three priority classes (filter_launch).
-// A collection of few, long pairs (24 photographs: 94 putative pairs of 10-20 k matches) occupies a third of the CUs under one
-// AC-RANSAC kernel, and a pair's workgroup is bound by ONE CU's f64 rate; the three filters together fill the chip: 26 ms instead
-// of 14 + 24 + 10 on 30 pairs of 8-12 k matches (tools/filters_side_by_side.py).  What made the kernels overlap at all was taking
-// the agent-scope fences out of their barriers (kernels_filter.hip: wg_fence) -- with them, three kernels at once ran no faster than
-// one after the other, whatever the streams (plain, priority classes, CU masks).  Measured and dropped: one merged kernel with the
-// three model kinds as branches -- hipcc's code for the fundamental-matrix branch faulted as soon as a second kind was compiled
-// into the same kernel (product build only, spilled lists only).
+// F, E and H of one putative graph side by side.  Long pairs (>= R3DM_FILTER_COOP_MIN putatives, 4096) of ALL requested filters run on
+// ONE cooperative kernel -- a pool of <= 256 persistent workgroups in which a pair's residual passes are row slices handed to idle
+// workers (kernels_filter_coop.hip) -- so a collection of few, long pairs (24 photographs: 94 putative pairs of
+// 10-20 k matches) fills the chip instead of a third of it, and a pair is no longer bound by one CU's f64 rate.  Short pairs keep the
+// one-workgroup-per-pair kernels, one launch per kind on streams of three priority classes, beside the cooperative kernel.  What lets
+// kernels overlap at all was taking the agent-scope fences out of their barriers (kernels_filter.hip: wg_fence).  Measured and
+// dropped in round 3: one merged one-workgroup-per-pair kernel with the three model kinds as branches (hipcc's code for the
+// fundamental-matrix branch faulted, product build only, spilled lists only); the cooperative kernel keeps its phases out of line
+// (noinline) for the same family of reasons.
 extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter, uint64_t seed, int which,
                                uint32_t e_min_count, float e_min_ratio, r3dm_graph** out_F, r3dm_graph** out_E, r3dm_graph** out_H,
                                double* ms_kernels3, double* ms_wall3)

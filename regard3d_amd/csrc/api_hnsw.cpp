@@ -191,6 +191,8 @@ static int run_hnsw_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float r
     sp.ef = std::max(ef, 2u);                                  // searchKnn: max(ef_, k)
     sp.ratio_R = ratio_R;
     sp.rows8 = rows8 ? 1u : 0u;
+    sp.dense_steps = r3dm_dev_knob("R3DM_HNSW_DENSE_STEPS", 0) ? 1u : 0u;                // developer build: the round-3 stepping, for A/B runs
+    sp.queries_per_wave = (uint32_t)r3dm_dev_knob("R3DM_HNSW_QW", 0);                    // developer build: 1 / 2 / 4 / 8 queries per wavefront
     sp.nn_idx = c->d_nn.as<uint32_t>();
     sp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
     sp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;

@@ -107,6 +107,35 @@ __device__ __forceinline__ void hn_dist_list(const float (&q)[NB], const ROW* __
     }
 }
 
+// The base layer's variant: only the links that are not marked visited get a distance, and they are packed first -- eight unvisited
+// rows per wavefront step instead of eight LINKS of which most are already visited (a hop of the precise preset has 38 links and
+// ~6 new rows: one or two steps instead of five; the kernel is bound by the instructions it issues, and the distance steps were
+// four fifths of them).  dist[j] still belongs to link j, so the sequential pass below reads what it read before.
+// `dense_steps` (developer build, R3DM_HNSW_DENSE_STEPS): the round-3 stepping over all links, for A/B runs.
+template <int NB, typename ROW>
+__device__ __forceinline__ uint32_t hn_dist_list_unvisited(const float (&q)[NB], const ROW* __restrict__ rows, uint32_t dim, const int32_t* ids, uint32_t size,
+                                                       float* dist, int32_t* todo, const uint32_t* visited, uint32_t lane)
+{
+    const uint32_t g = lane >> 3, l = lane & 7u;
+    const bool on = lane < size;                                          // size <= 2M <= 64: a lane per link
+    const uint32_t mine = on ? (uint32_t)ids[lane] : 0u;
+    const bool need = on && ((visited[mine >> 5] >> (mine & 31u)) & 1u) == 0u;
+    const unsigned long long m = __ballot(need);
+    const uint32_t n_need = (uint32_t)__popcll(m);
+    if (need) todo[__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)lane;
+    HN_SYNC();
+    for (uint32_t k0 = 0; k0 < n_need; k0 += 8) {
+        const uint32_t k = k0 + g;
+        const bool work = k < n_need;
+        const uint32_t j = work ? (uint32_t)todo[k] : 0u;
+        float acc = 0.f;
+        if (work) acc = hn_acc<NB, ROW>(q, rows + (size_t)(uint32_t)ids[j] * dim, l);
+        const float d = hn_hsum8(acc, lane);
+        if (work && l == 0) dist[j] = d;
+    }
+    return n_need;
+}
+
 // ------------------------------------------------------------------------------------------------------------ search
 template <int NB, typename ROW>
 __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams P)
@@ -115,14 +144,15 @@ __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const HnswSearchJob job = P.jobs[blockIdx.y];
     const uint32_t qi = blockIdx.x * 4 + wave;
-    // per-wave LDS: visited bits | top heap (ef + 1) | candidate heap (cand_cap) | dist[64] | ids[64]
-    const uint32_t per_wave = P.flag_words * 4 + (P.ef + 1) * 8 + P.cand_cap * 8 + 64 * 4 + 64 * 4;
+    // per-wave LDS: visited bits | top heap (ef + 1) | candidate heap (cand_cap) | dist[64] | ids[64] | todo[64]
+    const uint32_t per_wave = P.flag_words * 4 + (P.ef + 1) * 8 + P.cand_cap * 8 + 64 * 4 + 64 * 4 + 64 * 4;
     unsigned char* base = hn_smem + (size_t)wave * per_wave;
     uint32_t* visited = reinterpret_cast<uint32_t*>(base);
     HnPair* top = reinterpret_cast<HnPair*>(base + P.flag_words * 4);
     HnPair* cand = top + (P.ef + 1);
     float* dist = reinterpret_cast<float*>(cand + P.cand_cap);
     int32_t* ids = reinterpret_cast<int32_t*>(dist + 64);
+    int32_t* todo = ids + 64;
     if (qi >= job.nq) return;                                            // (no workgroup barrier below)
     const HnswView ix = job.ix;
     const uint32_t dim = ix.dim, M = ix.M, l = lane & 7u;
@@ -173,9 +203,14 @@ __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams
         HN_SYNC();
         if (lane < size) ids[lane] = L[1 + lane];                       // 2M <= 64 links
         HN_SYNC();
-        hn_dist_list<NB, ROW>(q, xrows, dim, ids, size, dist, lane, [&](uint32_t c) { return ((visited[c >> 5] >> (c & 31u)) & 1u) != 0; });
+        uint32_t n_walk = size;
+        if (P.dense_steps) hn_dist_list<NB, ROW>(q, xrows, dim, ids, size, dist, lane, [&](uint32_t c) { return ((visited[c >> 5] >> (c & 31u)) & 1u) != 0; });
+        else n_walk = hn_dist_list_unvisited<NB, ROW>(q, xrows, dim, ids, size, dist, todo, visited, lane);
         HN_SYNC();
-        for (uint32_t j = 0; j < size; ++j) {
+        // the walk over the list in link order; links that were visited before the hop are no-ops in hnswlib's loop, so only the others
+        // (todo, ascending) are walked -- a row that occurs twice in a list is in todo twice and the second visit finds it marked
+        for (uint32_t k = 0; k < n_walk; ++k) {
+            const uint32_t j = P.dense_steps ? k : (uint32_t)todo[k];
             const uint32_t c = (uint32_t)ids[j];
             const uint32_t w = visited[c >> 5], bit = 1u << (c & 31u);
             if (w & bit) continue;                                     // seen before this list, or earlier in this list
@@ -215,6 +250,163 @@ __global__ void __launch_bounds__(256) hnsw_search_kernel(const HnswSearchParams
         atomicAdd(P.n_comps, evals);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------ search, QW queries per wavefront
+// The same procedure with a GROUP of 64 / QW lanes per query (QW = 2, 4, 8): lane l of an 8-lane subgroup is accumulator l of
+// L2SqrSIMD16Ext as before, a group measures 8 / QW rows per step, and the sequential part -- the walk over the unvisited links, the
+// two heaps -- is issued once per WAVEFRONT for QW queries instead of once per query.  Every query performs exactly the operations
+// it performs in hnsw_search_kernel, in the same order, so the results are the same bits; the groups of a wavefront diverge (different
+// list lengths and hop counts) and the hardware masks them.  State per query in LDS as above; the stride between queries is 8 bytes
+// off a multiple of 128 so that the groups' accesses to the same offset (the heap roots) fall into different banks.  Eight queries
+// per workgroup whatever QW (8 / QW wavefronts): the LDS of a workgroup bounds the queries in flight on a CU either way.
+//
+// DEVELOPER BUILD ONLY (R3DM_HNSW_QW): measured and not adopted.  ms of search per pair, precise preset (M 19, ef 15), round 4:
+//                                        QW = 1     2      4      8
+//     12 views x 8,192 LIOP-144 rows      0.455   0.429  0.577  0.829
+//     16 views x 16,384 SIFT byte rows    0.910   1.008  1.360  1.923
+// A query is a chain of dependent steps (pop -> link list -> rows -> heap moves in LDS) and the LDS state (3.9 KB) caps the queries in
+// flight on a CU at ~40 however they are spread over wavefronts; packing them into fewer wavefronts removes the redundant issue slots
+// but also the wavefronts that hid each other's latency.  The search is latency-bound per query, not issue-bound.
+#ifdef R3DM_DEVTOOLS
+template <int NB, typename ROW, int QW>
+__global__ void __launch_bounds__(64 * (8 / QW)) hnsw_search_group_kernel(const HnswSearchParams P)
+{
+    constexpr uint32_t GL = 64 / QW, RS = GL / 8;                        // lanes per query, rows per step of a group
+    extern __shared__ unsigned char hn_smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t grp = lane / GL, gl = lane % GL, sub = gl >> 3, l = gl & 7u;
+    const HnswSearchJob job = P.jobs[blockIdx.y];
+    const uint32_t slot = wave * QW + grp;
+    const uint32_t qi = blockIdx.x * 8 + slot;
+    unsigned char* base = hn_smem + (size_t)slot * P.per_query;
+    uint32_t* visited = reinterpret_cast<uint32_t*>(base);
+    HnPair* top = reinterpret_cast<HnPair*>(base + P.flag_words * 4);
+    HnPair* cand = top + (P.ef + 1);
+    float* dist = reinterpret_cast<float*>(cand + P.cand_cap);
+    int32_t* ids = reinterpret_cast<int32_t*>(dist + 64);
+    int32_t* todo = ids + 64;
+    if (qi >= job.nq) return;                                            // (no workgroup barrier below; a group leaves as a whole)
+    const HnswView ix = job.ix;
+    const uint32_t dim = ix.dim, M = ix.M;
+    const ROW* __restrict__ xrows = sizeof(ROW) == 1 ? reinterpret_cast<const ROW*>(ix.rows8) : reinterpret_cast<const ROW*>(ix.rows);
+    const size_t o = (size_t)job.out_base + qi;
+    const unsigned long long gmask = GL == 64 ? ~0ull : ((1ull << GL) - 1ull);
+
+    float q[NB];
+    hn_load_q<NB>(q, job.query + (size_t)qi * dim, l);
+    for (uint32_t w = gl; w < P.flag_words; w += GL) visited[w] = 0;
+    unsigned long long evals = 1;
+
+    uint32_t cur = (uint32_t)ix.enter;
+    float curdist = hn_hsum8(hn_acc<NB, ROW>(q, xrows + (size_t)cur * dim, l), lane);
+    // greedy descent (hnswalg.h:745-768)
+    for (int level = ix.maxlevel; level > 0; --level) {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            const int32_t* L = ix.up + ((size_t)ix.up_off[cur] + (uint32_t)(level - 1)) * (1 + M);
+            const uint32_t size = (uint32_t)L[0];
+            HN_SYNC();
+            for (uint32_t j = gl; j < size; j += GL) ids[j] = L[1 + j];
+            HN_SYNC();
+            for (uint32_t j0 = 0; j0 < size; j0 += RS) {
+                const uint32_t j = j0 + sub;
+                const bool on = j < size;
+                float acc = 0.f;
+                if (on) acc = hn_acc<NB, ROW>(q, xrows + (size_t)(uint32_t)ids[j] * dim, l);
+                const float d = hn_hsum8(acc, lane);
+                if (on && l == 0) dist[j] = d;
+            }
+            HN_SYNC();
+            evals += size;
+            for (uint32_t j = 0; j < size; ++j) {
+                const float d = dist[j];
+                if (d < curdist) { curdist = d; cur = (uint32_t)ids[j]; changed = true; }
+            }
+        }
+    }
+    // searchBaseLayerST (hnswalg.h:214-280)
+    const uint32_t ef = P.ef;
+    uint32_t n_top = 0, n_cand = 0;
+    bool overflow = false;
+    HN_SYNC();
+    visited[cur >> 5] |= 1u << (cur & 31u);                              // (the group's lanes write the same word)
+    hn_push(top, n_top, curdist, cur);
+    hn_push(cand, n_cand, -curdist, cur);
+    float lower = curdist;
+    HN_SYNC();
+    while (n_cand) {
+        const HnPair c0 = cand[0];
+        if ((-c0.d) > lower) break;
+        hn_pop(cand, n_cand);
+        const int32_t* L = ix.l0 + (size_t)c0.id * (1 + 2 * M);
+        const uint32_t size = (uint32_t)L[0];
+        HN_SYNC();
+        for (uint32_t j = gl; j < size; j += GL) ids[j] = L[1 + j];       // 2M <= 64 links
+        HN_SYNC();
+        // the unvisited links, packed (hn_dist_list_unvisited, per group)
+        uint32_t n_walk = 0;
+        for (uint32_t j0 = 0; j0 < size; j0 += GL) {
+            const uint32_t j = j0 + gl;
+            const bool on = j < size;
+            const uint32_t mine = on ? (uint32_t)ids[j] : 0u;
+            const bool need = on && ((visited[mine >> 5] >> (mine & 31u)) & 1u) == 0u;
+            const unsigned long long m = (__ballot(need) >> (grp * GL)) & gmask;
+            if (need) todo[n_walk + (uint32_t)__popcll(m & ((1ull << gl) - 1ull))] = (int32_t)j;
+            n_walk += (uint32_t)__popcll(m);
+        }
+        HN_SYNC();
+        for (uint32_t k0 = 0; k0 < n_walk; k0 += RS) {
+            const uint32_t k = k0 + sub;
+            const bool work = k < n_walk;
+            const uint32_t j = work ? (uint32_t)todo[k] : 0u;
+            float acc = 0.f;
+            if (work) acc = hn_acc<NB, ROW>(q, xrows + (size_t)(uint32_t)ids[j] * dim, l);
+            const float d = hn_hsum8(acc, lane);
+            if (work && l == 0) dist[j] = d;
+        }
+        HN_SYNC();
+        for (uint32_t k = 0; k < n_walk; ++k) {
+            const uint32_t j = (uint32_t)todo[k];
+            const uint32_t c = (uint32_t)ids[j];
+            const uint32_t w = visited[c >> 5], bit = 1u << (c & 31u);
+            if (w & bit) continue;                                     // earlier in this list
+            visited[c >> 5] = w | bit;
+            evals += 1;
+            const float d = dist[j];
+            if (top[0].d > d || n_top < ef) {
+                if (n_cand >= P.cand_cap) { overflow = true; break; }
+                hn_push(cand, n_cand, -d, c);
+                hn_push(top, n_top, d, c);
+                if (n_top > ef) hn_pop(top, n_top);
+                lower = top[0].d;
+            }
+        }
+        if (overflow) break;
+    }
+    if (overflow) {                                                     // the host repeats the launch with a larger heap
+        if (gl == 0) { atomicAdd(P.n_overflow, 1u); P.nn_idx[o] = kNone - 1u; }
+        return;
+    }
+    while (n_top > 2) hn_pop(top, n_top);
+    HnPair r0{0.f, kNone}, r1{0.f, kNone};
+    const uint32_t nr = n_top;
+    if (nr >= 1) { r0 = top[0]; hn_pop(top, n_top); }
+    if (nr == 2) {
+        r1 = top[0];
+        if (r1.d < r0.d || (!(r0.d < r1.d) && r1.id < r0.id)) { const HnPair t = r0; r0 = r1; r1 = t; }
+    }
+    if (gl == 0) {
+        const bool two = nr == 2;
+        P.nn_idx[o] = (two && r0.d < P.ratio_R * r1.d) ? r0.id : kNone;
+        if (P.knn_idx) {
+            P.knn_idx[2 * o] = nr >= 1 ? (int32_t)r0.id : -1; P.knn_idx[2 * o + 1] = two ? (int32_t)r1.id : -1;
+            P.knn_dist[2 * o] = nr >= 1 ? r0.d : R3DM_INF;   P.knn_dist[2 * o + 1] = two ? r1.d : R3DM_INF;
+        }
+        atomicAdd(P.n_comps, evals);
+    }
+}
+#endif  // R3DM_DEVTOOLS
 
 // ------------------------------------------------------------------------------------------------------------ construction
 __device__ __forceinline__ unsigned long long hn_key(float d, uint32_t id) { return ((unsigned long long)__float_as_uint(d) << 32) | id; }
@@ -348,20 +540,38 @@ hipError_t launch_hnsw_search(hipStream_t st, const HnswSearchParams& Pin, uint3
     HnswSearchParams P = Pin;
     if (P.n_jobs == 0 || max_nq == 0) return hipSuccess;
     if (P.ef < 2 || P.ef > 512 || P.cand_cap < 16) return hipErrorInvalidValue;
-    P.flag_words = (max_n + 31) / 32;
-    const size_t per_wave = (size_t)P.flag_words * 4 + (size_t)(P.ef + 1) * 8 + (size_t)P.cand_cap * 8 + 512;
-    const size_t lds = per_wave * 4;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const dim3 grid((max_nq + 3) / 4, P.n_jobs);
     if (P.n_jobs > 65535u) return hipErrorInvalidValue;
-#define R3DM_HNSW_SEARCH_T(NB, ROW)                                                                                     \
+    P.flag_words = (max_n + 31) / 32;
+    const size_t state = (size_t)P.flag_words * 4 + (size_t)(P.ef + 1) * 8 + (size_t)P.cand_cap * 8 + 768;
+    const size_t per_query = (state + 127) / 128 * 128 + 8;
+    uint32_t qw = 1;                                                     // a wavefront per query, four per workgroup
+#ifdef R3DM_DEVTOOLS
+    if (P.queries_per_wave == 2 || P.queries_per_wave == 4 || P.queries_per_wave == 8) qw = P.queries_per_wave;   // groups, eight queries per workgroup
+    if (qw > 1 && per_query * 8 > 160 * 1024) qw = 1;
+#endif
+    P.per_query = (uint32_t)per_query;
+    const size_t lds = qw > 1 ? per_query * 8 : state * 4;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const dim3 grid(qw > 1 ? (max_nq + 7) / 8 : (max_nq + 3) / 4, P.n_jobs);
+#define R3DM_HNSW_LAUNCH(KERNEL, THREADS)                                                                              \
     do {                                                                                                               \
         if (lds > 64 * 1024) {                                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)hnsw_search_kernel<NB, ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipError_t e = hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                             \
         }                                                                                                              \
-        hipLaunchKernelGGL((hnsw_search_kernel<NB, ROW>), grid, dim3(256), lds, st, P);                                 \
+        hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), lds, st, P);                                                    \
     } while (0)
+#ifdef R3DM_DEVTOOLS
+#define R3DM_HNSW_SEARCH_T(NB, ROW)                                                                                     \
+    do {                                                                                                               \
+        if (qw == 2) R3DM_HNSW_LAUNCH((hnsw_search_group_kernel<NB, ROW, 2>), 256);                                     \
+        else if (qw == 4) R3DM_HNSW_LAUNCH((hnsw_search_group_kernel<NB, ROW, 4>), 128);                                \
+        else if (qw == 8) R3DM_HNSW_LAUNCH((hnsw_search_group_kernel<NB, ROW, 8>), 64);                                 \
+        else R3DM_HNSW_LAUNCH((hnsw_search_kernel<NB, ROW>), 256);                                                      \
+    } while (0)
+#else
+#define R3DM_HNSW_SEARCH_T(NB, ROW) R3DM_HNSW_LAUNCH((hnsw_search_kernel<NB, ROW>), 256)
+#endif
 #define R3DM_HNSW_SEARCH(NB) do { if (P.rows8) R3DM_HNSW_SEARCH_T(NB, uint8_t); else R3DM_HNSW_SEARCH_T(NB, float); } while (0)
     switch (dim) {
         case 64:  R3DM_HNSW_SEARCH(8); break;
@@ -372,6 +582,7 @@ hipError_t launch_hnsw_search(hipStream_t st, const HnswSearchParams& Pin, uint3
     }
 #undef R3DM_HNSW_SEARCH
 #undef R3DM_HNSW_SEARCH_T
+#undef R3DM_HNSW_LAUNCH
     return hipGetLastError();
 }
 

@@ -148,6 +148,9 @@ struct HnswSearchParams {
     float*    knn_dist;           // optional
     unsigned long long* n_comps;  // distance evaluations (atomic)
     uint32_t* n_overflow;         // queries whose candidate heap did not fit cand_cap (their nn_idx slot holds 0xFFFFFFFE)
+    uint32_t dense_steps;         // developer build: != 0 measures every link of a hop, visited or not, eight LINKS per step (the round-3 stepping; wavefront-per-query kernel only)
+    uint32_t queries_per_wave;    // developer build: 2 / 4 / 8 run hnsw_search_group_kernel (measured, not adopted); else a wavefront per query
+    uint32_t per_query;           // set by the launcher: LDS bytes of one query's state
 };
 struct HnswBuildJob {
     const float*    rows;

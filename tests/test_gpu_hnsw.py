@@ -133,3 +133,37 @@ def test_recall_at_8k_rows_at_least_the_reference_built_index(ctx, oracle, scene
             ours, theirs = (gi[:, k] == exact[:, k]).mean(), (ref[preset][:, k] == exact[:, k]).mean()
             print(scene, preset, "recall@%d" % (k + 1), "batch-built %.4f" % ours, "reference-built %.4f" % theirs)
             assert ours >= theirs
+
+
+@pytest.mark.parametrize("nq", [1, 7, 9, 63])
+def test_search_ragged_query_counts(ctx, oracle, nq):
+    """four queries share a workgroup (a wavefront each): counts that leave wavefronts of the last workgroup empty"""
+    d0, d1, ix, _, _ = load_case("sift", "precise")
+    M, _, ef = oracle.HNSW_PRESETS["precise"]
+    ei, ed = oracle.hnsw_from_arrays(d0, M, ix).knn2(d1[:nq], ef)
+    gi, gd = ctx.hnsw_knn2_on_index(d0, ix, M, d1[:nq], ef)
+    assert np.array_equal(gi, ei)
+    assert np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
+
+
+@pytest.mark.parametrize("knob", ["R3DM_HNSW_DENSE_STEPS=1", "R3DM_HNSW_QW=1", "R3DM_HNSW_QW=2", "R3DM_HNSW_QW=4", "R3DM_HNSW_QW=8"])
+def test_search_kernel_variants_agree(ctx, oracle, tmp_path, knob):
+    """developer build: R3DM_HNSW_DENSE_STEPS=1 measures every link of a hop eight links at a time, as round 3 did (the product packs
+    the unvisited links first); R3DM_HNSW_QW = queries per wavefront (1: a wavefront per query; 2 / 4 / 8: a group of 32 / 16 / 8 lanes
+    per query).  Every variant returns the product's rows and distances and counts the same distance evaluations"""
+    import os, subprocess, sys
+    d0, d1, ix, _, _ = load_case("liop", "precise")
+    M, _, ef = oracle.HNSW_PRESETS["precise"]
+    gi, gd = ctx.hnsw_knn2_on_index(d0, ix, M, d1, ef)
+    evals = ctx.stats().n_ann_dist
+    np.savez(str(tmp_path / "case.npz"), d0=d0, d1=d1, **{"ix_" + k: v for k, v in ix.items()})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np; from regard3d_amd import api; api.use_developer_library(); "
+            f"z = np.load({str(tmp_path / 'case.npz')!r}); ix = {{k[3:]: z[k] for k in z.files if k.startswith('ix_')}}; "
+            f"c = api.Context(0); i, d = c.hnsw_knn2_on_index(z['d0'], ix, {M}, z['d1'], {ef}); "
+            f"np.save({str(tmp_path / 'i.npy')!r}, i); np.save({str(tmp_path / 'd.npy')!r}, d); print(c.stats().n_ann_dist)")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **dict([knob.split("=")])), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(str(tmp_path / "i.npy")), gi)
+    assert np.array_equal(np.load(str(tmp_path / "d.npy")).view(np.uint32), gd.view(np.uint32))
+    assert int(r.stdout.strip().splitlines()[-1]) == evals

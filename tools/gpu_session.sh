@@ -13,6 +13,7 @@
 #   tool:<script.py>[:<args>]       python tools/<script.py> <args>                   -> <tag>_<script>.txt
 #   proftool:<script.py>[:<args>]   the same under rocprofv3 --kernel-trace --stats    -> <tag>_<script>.txt + _<script>_kernel_stats.txt
 #   gridtrace:<script.py>[:<args>] rocprofv3 --kernel-trace CSV of python tools/<script.py>, durations bucketed by (kernel, grid)
+#   exe:<binary>[:<args>]           a prebuilt binary of the tree (tools/ubench/*.bin)   -> <tag>_<name>.txt
 #   pmc:<counters>:<config>[:<extra args>]   separate rocprofv3 --pmc passes (one per comma-separated counter, --kernel-trace only)
 #                                                                                        -> <tag>_pmc_<config>.txt
 # Every step runs under its own `timeout`; nothing here kills by pattern.
@@ -69,6 +70,9 @@ for step in "$@"; do
         timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- python bench.py --config $a2 $a3 --no-cpu-baseline > /tmp/pmc_$ctr.log 2>&1
         echo "## pass: $ctr (rc=$?)"; python tools/pmc_summary.py /tmp/pmc_$ctr 2>&1 | grep -v "stage_" | head -${PMC_HEAD:-8}
       done | tee gpurun_out/${T}_pmc_$a2.txt ;;
+    exe)   # exe:<path of a prebuilt binary in the tree>[:<args>]                      -> <tag>_<name>.txt
+      n=$(basename $a1 .bin)
+      timeout ${TOOL_TIMEOUT:-300} $a1 $a2 2>&1 | tail -${TOOL_TAIL:-40} | cut -c1-300 | tee gpurun_out/${T}_$n.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
