@@ -51,8 +51,17 @@ from regard3d_amd import api, dist as r3dist, synth
 FP32_MFMA_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_bf16, dense (opt-in paths only)
 HBM_PEAK_GBS = 8000.0
-VALU_LANE_OPS_PEAK_T = 78.6        # 256 CU x 128 lanes/clk x 2.4 GHz (SURVEY 8d's stated roof for the xor+popcount pair)
-VALU_INT_MEASURED_T = 41.5         # profiles/r01_ubench_valu_int.txt: what v_xor_b32 + v_bcnt_u32_b32 sustain on this chip
+# The roof of the popcount Hamming kernel (2 lane-ops per 32-bit word: v_xor_b32, v_bcnt_u32_b32 with its accumulate).  SURVEY 8d priced
+# it at 78.6 T lane-op/s = 256 CU x 128 lanes/clk x 2.4 GHz, which is the rate of PACKED f32 (v_pk_fma_f32: two values per lane) -- the
+# 157.3 TFLOP/s vector peak.  Issue rates by instruction, tools/ubench/valu_issue.hip on this chip (profiles/r04_ubench_valu_issue.txt;
+# s_memtime = the 2.4 GHz shader clock; one wavefront alone: 4 cycles per wave64 instruction for all of them):
+#     whole chip, wave64 instructions per SIMD and ns:  v_xor_b32 0.99   v_fma_f32 0.97   v_pk_fma_f32 0.55   v_bcnt_u32_b32 0.57
+#     the alternating pair v_xor_b32 + v_bcnt_u32_b32:  0.64  = 41.7-42.2 T lane-op/s
+# v_bcnt_u32_b32 (VOP3) does not get the second issue slot v_xor_b32 / v_fma_f32 get from other wavefronts; the pair the kernel is made
+# of sustains 42.2 T lane-op/s in registers, with nothing else to do.  That is the roof; the stated 78.6 T stays in the line beside it.
+VALU_LANE_OPS_STATED_T = 78.6      # SURVEY 8d's figure (packed-f32 lane rate)
+VALU_LANE_OPS_PEAK_T = 42.2        # measured ceiling of the v_xor_b32 + v_bcnt_u32_b32 pair (profiles/r04_ubench_valu_issue.txt)
+HAMMING_ALGORITHMIC_VALU_SHARE = 256.0 / 284.0   # hamming_knn2_kernel<16,4> inner loop: 128 xor + 128 bcnt of 284 VALU instructions (ISA)
 
 CONFIGS = {
     "c2": dict(kind="sift", images=200, feat=8192, seed=2002, matcher="brute", ratio=0.6, squared=True,
@@ -602,9 +611,13 @@ def roofline(name, cfg, acc, dim, world):
         t_ops = acc["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0     # lane-ops: 2 per 32-bit word (xor, popcount-accumulate)
         return {"bound": "valu", "kernel": "hamming_knn2_kernel<W=16,QL=4>", "achieved": t_ops, "peak": VALU_LANE_OPS_PEAK_T,
                 "unit": "T lane-op/s", "frac": t_ops / VALU_LANE_OPS_PEAK_T, "traffic": None,
-                "peak_measured_int_valu": VALU_INT_MEASURED_T, "frac_of_measured_int_valu": t_ops / VALU_INT_MEASURED_T,
-                "note": "integer VALU issue bound (neither MFMA nor HBM); v_xor_b32 + v_bcnt_u32_b32 sustain 41.5 T lane-op/s in a "
-                        "register-only micro-benchmark on this chip (profiles/r01_ubench_valu_int.txt), half the f32 FMA lane rate",
+                "peak_source": "measured issue ceiling of the v_xor_b32 + v_bcnt_u32_b32 pair on this chip (tools/ubench/valu_issue.hip, profiles/r04_ubench_valu_issue.txt)",
+                "stated_roof_survey_8d": VALU_LANE_OPS_STATED_T, "frac_of_stated_roof": t_ops / VALU_LANE_OPS_STATED_T,
+                "algorithmic_share_of_valu_instructions": HAMMING_ALGORITHMIC_VALU_SHARE,
+                "frac_counting_every_valu_instruction": t_ops / HAMMING_ALGORITHMIC_VALU_SHARE / VALU_LANE_OPS_PEAK_T,
+                "note": "integer VALU issue bound (neither MFMA nor HBM).  78.6 T lane-op/s is the packed-f32 lane rate; v_bcnt_u32_b32 issues once per "
+                        "~4.2 cycles per SIMD (37.9 T lane-op/s alone) and the xor + popcount pair sustains 42.2 T in registers.  The kernel's inner loop "
+                        "spends 28 of 284 VALU instructions on the two-smallest tracking (ISA count), so 0.90 x 42.2 = 38.0 T is what this loop can reach",
                 "avg_launch_ms": ms / L, "lane_ops_per_launch": acc["flops"] / L, "launches": int(acc["launches"])}
     tf = acc["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     G = 18 if dim == 144 else dim // 8

@@ -70,7 +70,8 @@ public:
     // matchingAlgorithm value of the new dispatch arm next to src/R3DComputeMatches.cpp:2054-2062;
     // 4 ("Brute Force", src/Regard3DMainFrameBase.cpp:1020) is served by the same GPU path; the approximate arms (0 FLANN,
     // 1..3 KGraph, 5 MRPT, 6..8 HNSW) run the graph-based approximate matcher with a preset of at least the arm's recall
-    // (FLANN / MRPT / HNSW are substituted by it, not reimplemented: r3dm.h, r3dm_ann_params_for_algorithm).
+    // (FLANN and MRPT are permanently substituted by it, not reimplemented: r3dm.h, r3dm_ann_params_for_algorithm, DESIGN.md section 7;
+    // the HNSW arms run hnswlib's own search on a batch-built index, r3dm_match_pairs_hnsw).
     static constexpr int kMatchingAlgorithmGPU = 9;
 
     explicit R3DComputeMatches(int device_id = 0);

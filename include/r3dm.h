@@ -218,9 +218,13 @@ int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out);
  * R3DM_ERR_INVALID for the exhaustive arms 4 / 9 and unknown values.  The KGraph arms are the reference's algorithm.  The HNSW
  * arms have their own entry points (r3dm_match_pairs_hnsw below: hnswlib's search on an HNSW index) -- this mapping is what a host
  * uses for them only when it wants the FASTEST matcher of at least the arm's recall, or for a descriptor length hnswlib's SIMD16
- * distance does not serve.  FLANN and MRPT are SUBSTITUTED: no kd-tree or random-projection index is built here, the same
- * deterministic graph matcher answers for them and its matches are not those the reference's arm would return (both are
- * approximate).  See the table in api_match.cpp and DESIGN.md section 4.7. */
+ * distance does not serve.  FLANN (arm 0) and MRPT (arm 5) are PERMANENTLY SUBSTITUTED: no kd-tree or random-projection index is
+ * built here, the same deterministic graph matcher answers for them and its matches are not those the reference's arm would return
+ * (both are approximate).  Decided and closed in round 4: neither FLANN nor Eigen (mrpt.h) exists in the build
+ * image, so neither index could be pinned to the reference; MRPT's projections draw from implementation-defined libstdc++
+ * distributions; and every approximate arm measured on this GPU is slower than the exact fast paths, under which the facade's
+ * default policy serves these arms at recall 1.  The arm numbers and their parameters are accepted and mapped, never rejected.
+ * See the table in api_match.cpp and DESIGN.md sections 4.7 and 7. */
 int r3dm_ann_params_for_algorithm(int matching_algorithm, r3dm_kgraph_params* out);
 int r3dm_match_pairs_kgraph(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
                             const r3dm_kgraph_params* params, r3dm_graph** out);

@@ -14,7 +14,7 @@
 #   proftool:<script.py>[:<args>]   the same under rocprofv3 --kernel-trace --stats    -> <tag>_<script>.txt + _<script>_kernel_stats.txt
 #   gridtrace:<script.py>[:<args>] rocprofv3 --kernel-trace CSV of python tools/<script.py>, durations bucketed by (kernel, grid)
 #   exe:<binary>[:<args>]           a prebuilt binary of the tree (tools/ubench/*.bin)   -> <tag>_<name>.txt
-#   pmc:<counters>:<config>[:<extra args>]   separate rocprofv3 --pmc passes (one per comma-separated counter, --kernel-trace only)
+#   pmc:<group+group>:<config>[:<extra args>]   separate rocprofv3 --pmc passes, one per '+'-separated group of comma-separated counters (--kernel-trace only)
 #                                                                                        -> <tag>_pmc_<config>.txt
 # Every step runs under its own `timeout`; nothing here kills by pattern.
 cd /tmp && export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
@@ -64,11 +64,11 @@ for step in "$@"; do
         timeout ${TOOL_TIMEOUT:-600} rocprofv3 --pmc ${grp//,/ } --kernel-trace --output-format csv -d /tmp/pmt_$n -- python tools/$a2 $a3 > /tmp/pmt_$n.log 2>&1
         echo "## pass: ${grp//,/ } (rc=$?)"; python tools/pmc_summary.py /tmp/pmt_$n ${PMC_BY_GRID:+--by-grid} 2>&1 | grep -E "${PMC_FILTER:-r3dm}" | head -${PMC_HEAD:-12}
       done | tee gpurun_out/${T}_pmc_$n.txt ;;
-    pmc)
-      for ctr in ${a1//,/ }; do
-        rm -rf /tmp/pmc_$ctr
-        timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- python bench.py --config $a2 $a3 --no-cpu-baseline > /tmp/pmc_$ctr.log 2>&1
-        echo "## pass: $ctr (rc=$?)"; python tools/pmc_summary.py /tmp/pmc_$ctr 2>&1 | grep -v "stage_" | head -${PMC_HEAD:-8}
+    pmc)   # pmc:<group+group+...>:<config>[:<extra args>]: one rocprofv3 --pmc pass per group (counters of a group comma-separated)
+      for grp in ${a1//+/ }; do
+        rm -rf /tmp/pmc_pass
+        timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc ${grp//,/ } --kernel-trace --output-format csv -d /tmp/pmc_pass -- python bench.py --config $a2 $a3 --no-cpu-baseline > /tmp/pmc_pass.log 2>&1
+        echo "## pass: ${grp//,/ } (rc=$?)"; python tools/pmc_summary.py /tmp/pmc_pass 2>&1 | grep -v "stage_" | head -${PMC_HEAD:-8}
       done | tee gpurun_out/${T}_pmc_$a2.txt ;;
     exe)   # exe:<path of a prebuilt binary in the tree>[:<args>]                      -> <tag>_<name>.txt
       n=$(basename $a1 .bin)
