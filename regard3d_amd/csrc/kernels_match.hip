@@ -1164,8 +1164,8 @@ __device__ __forceinline__ void counts_tile_step(__amdgpu_buffer_rsrc_t ra, __am
             // lower bound of the quad's four keys (padding rows: ||a||^2 = +inf, count 0 -> key +inf, never below a bound)
             const float pmin = g == 0 ? __builtin_fminf(__builtin_fminf(p0, p1), __builtin_fminf(p2, p3)) : vmin2(vmin3(p0, p1, p2), p3);
             const float lb = __builtin_fmaf(qs_prev[4 + qd], cq[nj], pmin * qs_prev[qd]);
-            if (__builtin_amdgcn_ballot_w64(lb < st[nj].d2) != 0ull) {
-                const uint32_t rb = prev_rowbase + 8u * (uint32_t)qd;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(lb < st[nj].d2) != 0ull, 0)) {
+                const uint32_t rb = prev_rowbase + 8u * (uint32_t)qd;       // wave-uniform: the lists hold rows WITHOUT the lane half's + 4 h (added once, at the end)
                 const uint32_t r0 = 8u * (uint32_t)qd + 4u * h;               // the quad's first row within its tile
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1180,15 +1180,16 @@ __device__ __forceinline__ void counts_tile_step(__amdgpu_buffer_rsrc_t ra, __am
 }
 
 // the eight summary numbers of a lane's accumulator quads from the tile's row line: [qd] = max scale, [4 + qd] = min ||a||^2
+// (lane exchanges, ds_bpermute with the lane half folded into the address: 8 LDS instructions per tile where sixteen v_readlane +
+// sixteen v_mov + eight v_cndmask stood -- the loop is bound by the VALU instructions it issues between the MFMAs)
 __device__ __forceinline__ void counts_quad_summaries(float rowv, uint32_t h, float (&qs)[8])
 {
     const int g = __builtin_bit_cast(int, quad_min4(rowv));
+    const int a0 = (int)(16u * h);                         // byte address of lane 4 h
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-        const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 8 * qd)), n1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 8 * qd + 4));
-        const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 32 + 8 * qd)), s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g, 36 + 8 * qd));
-        qs[4 + qd] = h ? n1 : n0;
-        qs[qd] = -(h ? s1 : s0);
+        qs[4 + qd] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a0 + 32 * qd, g));
+        qs[qd] = -__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a0 + 128 + 32 * qd, g));
     }
 }
 
@@ -1267,37 +1268,38 @@ void l2_knn2_counts_kernel(const MatchParams P)
         uint32_t t = 0;
         for (; t + 1 < ntI; t += 2) {
             counts_quad_summaries(rvB, h, qsB);
-            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
+            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u);
             counts_quad_summaries(rvA, h, qsA);
-            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, h, rvB, qsA, rvA, bq, cq, accB, accA, st, t * 32u + hb);
+            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, h, rvB, qsA, rvA, bq, cq, accB, accA, st, t * 32u);
         }
         if (t < ntI) {
             counts_quad_summaries(rvB, h, qsB);
-            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u + hb);
+            counts_tile_step<GB, NJ, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u);
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2)) + hb;
-                    top2_push(st[nj], __builtin_fmaf(__shfl(rvA, (int)row), cq[nj], accA[nj][r] * -__shfl(rvA, (int)(32u + row))), t * 32u + row);
+                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2));
+                    top2_push(st[nj], __builtin_fmaf(__shfl(rvA, (int)(row + hb)), cq[nj], accA[nj][r] * -__shfl(rvA, (int)(32u + row + hb))), t * 32u + row);
                 }
         } else {
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2)) + hb;
-                    top2_push(st[nj], __builtin_fmaf(__shfl(rvB, (int)row), cq[nj], accB[nj][r] * -__shfl(rvB, (int)(32u + row))), (ntI - 1) * 32u + row);
+                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2));
+                    top2_push(st[nj], __builtin_fmaf(__shfl(rvB, (int)(row + hb)), cq[nj], accB[nj][r] * -__shfl(rvB, (int)(32u + row + hb))), (ntI - 1) * 32u + row);
                 }
         }
     }
     // the lists name rows of the ordered image: back to keypoint order before the tail re-scores and certifies them
     {
         const uint32_t* __restrict__ perm = Ip->cperm;
+        const uint32_t hb2 = 4u * h;                       // the lane half's rows: + 4 within every group of eight
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) {
-            if (st[nj].i0 != kNone) st[nj].i0 = perm[st[nj].i0];
-            if (st[nj].i1 != kNone) st[nj].i1 = perm[st[nj].i1];
+            if (st[nj].i0 != kNone) st[nj].i0 = perm[st[nj].i0 + hb2];
+            if (st[nj].i1 != kNone) st[nj].i1 = perm[st[nj].i1 + hb2];
         }
     }
     l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
