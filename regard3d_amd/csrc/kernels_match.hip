@@ -1600,225 +1600,6 @@ hipError_t launch_hamming_mfma(hipStream_t st, const MatchParams& P, uint32_t wo
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Count tiles with the dataset stream SHARED by the four waves of a workgroup through LDS (round 4, second form).
-// l2_knn2_counts_kernel lets every wave stream the ordered dataset image itself: at one MFMA per 16 dimensions that is a 1 KiB
-// buffer_load_dwordx4 per wave and 64 matrix cycles, and PMC shows the L1 address path 0.73 busy with the matrix pipe 0.33
-// (profiles/r04_final_pmc_liop144c.txt) -- the bound of every 16-bit nominator here (the bf16 kernel: TA 0.94).  The four waves of a
-// workgroup read the SAME tiles, so this kernel fetches a tile once per workgroup: LDS-DMA (global_load_lds) into a ring of three
-// buffers, the pipeline of l2_knn2_int_lds_kernel above (one barrier per tile; a wave orders its own DMA with vmcnt(0) before the
-// barrier), every wave then reads its fragments with lane-linear ds_read_b128.  A buffer = the tile (GB KiB) + its 256-byte row
-// line (||a||^2 of the 32 rows, then their negated scales).  Epilogue, lists, index translation and tail: those of
-// l2_knn2_counts_kernel, unchanged -- the keys are the same numbers, so are the results.
-// ------------------------------------------------------------------------------------------------
-template <int GB, int NJ, int PF>
-__device__ __forceinline__ void counts_tile_step_lds(const unsigned char* __restrict__ lds_cur, const unsigned char* __restrict__ lds_nxt,
-                                                     const unsigned char* __restrict__ row_cur, f32x4 (&abuf)[PF], uint32_t h,
-                                                     float& rowv_load, const float (&qs_prev)[8], float rowv_prev,
-                                                     const f32x4 (&bq)[NJ][GB], const float (&cq)[NJ], f32x16 (&cur)[NJ], const f32x16 (&prev)[NJ],
-                                                     Top2 (&st)[NJ], uint32_t prev_rowbase)
-{
-    constexpr int NG = 4 * NJ;
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int g = 0; g < GB; ++g) {
-        const f32x4 a = abuf[g % PF];
-        abuf[g % PF] = (g + PF < GB) ? *reinterpret_cast<const f32x4*>(lds_cur + (g + PF) * 1024)
-                                     : *reinterpret_cast<const f32x4*>(lds_nxt + (g + PF - GB) * 1024);
-        if (g == (GB > 2 ? 2 : GB - 1)) rowv_load = *reinterpret_cast<const float*>(row_cur);   // THIS tile's row values (tested in the next step)
-#pragma unroll
-        for (int nj = 0; nj < NJ; ++nj)
-            cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq[nj][g]),
-                                                             g == 0 ? zero : cur[nj], 0, 0, 0);
-#pragma unroll
-        for (int gi = (g * NG) / GB; gi < ((g + 1) * NG) / GB; ++gi) {
-            const int nj = gi % NJ, qd = gi / NJ;
-            const float p0 = prev[nj][4 * qd], p1 = prev[nj][4 * qd + 1], p2 = prev[nj][4 * qd + 2], p3 = prev[nj][4 * qd + 3];
-            const float pmin = g == 0 ? __builtin_fminf(__builtin_fminf(p0, p1), __builtin_fminf(p2, p3)) : vmin2(vmin3(p0, p1, p2), p3);
-            const float lb = __builtin_fmaf(qs_prev[4 + qd], cq[nj], pmin * qs_prev[qd]);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(lb < st[nj].d2) != 0ull, 0)) {
-                const uint32_t rb = prev_rowbase + 8u * (uint32_t)qd;       // wave-uniform (+ 4 h is added once, at the end)
-                const uint32_t r0 = 8u * (uint32_t)qd + 4u * h;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float n2 = __shfl(rowv_prev, (int)(r0 + (uint32_t)k)), sa = -__shfl(rowv_prev, (int)(32u + r0 + (uint32_t)k));
-                    const float pk = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
-                    top2_push(st[nj], __builtin_fmaf(n2, cq[nj], pk * sa), rb + (uint32_t)k);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int GB, int NJ, int PF>
-__global__ __launch_bounds__(256, 2)
-void l2_knn2_counts_lds_kernel(const MatchParams P)
-{
-    static_assert(PF <= GB, "the prefetch window is shorter than a tile");
-    // ONE LDS array: [3 buffers][GB KiB tile] then [3 buffers][256 B row line]
-    extern __shared__ __attribute__((aligned(16))) unsigned char cnt_smem[];
-    constexpr uint32_t tileB = (uint32_t)GB * 1024u;
-    constexpr uint32_t row0 = 3u * tileB;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t h = lane >> 5, c = lane & 31u;
-    uint32_t pair, qb;
-    if (P.xcd_map) {
-        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        pair = (j / P.qb_per_pair) * 8u + xcd;
-        qb = j % P.qb_per_pair;
-        if (pair >= P.n_pairs) return;                     // whole workgroup
-    } else {
-        pair = blockIdx.x / P.qb_per_pair;
-        qb = blockIdx.x % P.qb_per_pair;
-    }
-    const uint2 pr = P.pairs[pair];
-    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
-    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
-    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles, nJ = Jp->n;
-    const uint32_t qt0 = (qb * 4u + wave) * NJ;
-    // a wave without query tiles still takes part in the loads and barriers of its workgroup; its results are discarded
-    const bool has_queries = qt0 < ntJ;
-
-    f32x4 bq[NJ][GB];
-    float cq[NJ], kinv[NJ];
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
-        const gf4p src = (gf4p)(const void*)Jp->tiledc + (size_t)qt * (GB * 64) + lane;
-#pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] ^= 0x80008000u;
-            bq[nj][g] = __builtin_bit_cast(f32x4, w);
-        }
-        const uint32_t q = qt * 32u + c;
-        const float sq = q < nJ ? Jp->cscale[q] : 1.0f;
-        kinv[nj] = 2.0f * sq;
-        cq[nj] = 1.0f / kinv[nj];
-    }
-    Top2 st[NJ];
-#pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);
-
-    if (nI >= 2) {                                         // workgroup-uniform
-        // this wave's share of a tile: blocks wave, wave + 4, ...; wave 0 also brings the row line
-        const unsigned char* gA = reinterpret_cast<const unsigned char*>(Ip->tiledp) + lane * 16u;
-        const unsigned char* gR = reinterpret_cast<const unsigned char*>(Ip->cquad) + lane * 4u;
-        auto issue = [&](uint32_t tile, uint32_t buf) {
-            if (tile >= ntI) return;                                          // workgroup-uniform
-#pragma unroll
-            for (int i = 0; i < (GB + 3) / 4; ++i) {
-                const uint32_t blk = wave + 4u * (uint32_t)i;
-                if (blk < (uint32_t)GB)                                       // wave-uniform
-                    __builtin_amdgcn_global_load_lds((glb_vp)(gA + (size_t)tile * tileB + blk * 1024u), (lds_vp)(cnt_smem + buf * tileB + blk * 1024u), 16, 0, 0);
-            }
-            if (wave == 0) __builtin_amdgcn_global_load_lds((glb_vp)(gR + (size_t)tile * 256u), (lds_vp)(cnt_smem + row0 + buf * 256u), 4, 0, 0);
-        };
-        issue(0, 0);
-        issue(1, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue(2, 2);
-        const unsigned char* lane_lds = cnt_smem + lane * 16u;               // fragment of block g of buffer b: + b * tileB + g * 1024
-        const unsigned char* lane_row = cnt_smem + row0 + lane * 4u;         // row line of buffer b: + b * 256
-        f32x4 abuf[PF];
-#pragma unroll
-        for (int s = 0; s < PF; ++s) abuf[s] = *reinterpret_cast<const f32x4*>(lane_lds + s * 1024);
-        float rvA = 0.0f, rvB = h ? -1.0f : R3DM_INF;      // "tile -1": ||a||^2 = +inf keeps it out of every list
-        float qsA[8], qsB[8];
-        f32x16 accA[NJ], accB[NJ];
-#pragma unroll
-        for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accB[nj][r] = 0.0f;
-        const uint32_t hb = 4u * h;
-        uint32_t bc = 0, bn = 1;                                             // buffers of tile t and tile t + 1
-        uint32_t t = 0;
-        for (; t + 1 < ntI; t += 2) {
-            if (t != 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                issue(t + 2, bc == 0 ? 2u : bc - 1u);                        // the buffer tile t - 1 occupied
-            }
-            counts_quad_summaries(rvB, h, qsB);
-            counts_tile_step_lds<GB, NJ, PF>(lane_lds + bc * tileB, lane_lds + bn * tileB, lane_row + bc * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u);
-            bc = bn; bn = bn == 2 ? 0u : bn + 1u;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(t + 3, bc == 0 ? 2u : bc - 1u);
-            counts_quad_summaries(rvA, h, qsA);
-            counts_tile_step_lds<GB, NJ, PF>(lane_lds + bc * tileB, lane_lds + bn * tileB, lane_row + bc * 256u, abuf, h, rvB, qsA, rvA, bq, cq, accB, accA, st, t * 32u);
-            bc = bn; bn = bn == 2 ? 0u : bn + 1u;
-        }
-        if (t < ntI) {
-            if (t != 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            counts_quad_summaries(rvB, h, qsB);
-            counts_tile_step_lds<GB, NJ, PF>(lane_lds + bc * tileB, lane_lds + bn * tileB, lane_row + bc * 256u, abuf, h, rvA, qsB, rvB, bq, cq, accA, accB, st, (t - 1) * 32u);
-#pragma unroll
-            for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2));
-                    top2_push(st[nj], __builtin_fmaf(__shfl(rvA, (int)(row + hb)), cq[nj], accA[nj][r] * -__shfl(rvA, (int)(32u + row + hb))), t * 32u + row);
-                }
-        } else {
-#pragma unroll
-            for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2));
-                    top2_push(st[nj], __builtin_fmaf(__shfl(rvB, (int)(row + hb)), cq[nj], accB[nj][r] * -__shfl(rvB, (int)(32u + row + hb))), (ntI - 1) * 32u + row);
-                }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // drain the look-ahead loads before ordinary loads follow
-    }
-    if (!has_queries) return;                              // (no barrier below)
-    {
-        const uint32_t* __restrict__ perm = Ip->cperm;
-        const uint32_t hb2 = 4u * h;
-#pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) {
-            if (st[nj].i0 != kNone) st[nj].i0 = perm[st[nj].i0 + hb2];
-            if (st[nj].i1 != kNone) st[nj].i1 = perm[st[nj].i1 + hb2];
-        }
-    }
-    l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
-}
-
-template <int GB, int NJ, int PF>
-static hipError_t launch_l2_counts_lds_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
-{
-    MatchParams P = Pin;
-    const uint32_t tiles_per_wg = 4u * NJ;
-    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    P.xcd_map = 1u;
-    const uint64_t grid64 = (uint64_t)((P.n_pairs + 7u) / 8u * 8u) * P.qb_per_pair;
-    if (grid64 == 0) return hipSuccess;
-    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
-    const size_t lds = 3 * (size_t)GB * 1024 + 3 * 256;
-    hipLaunchKernelGGL((l2_knn2_counts_lds_kernel<GB, NJ, PF>), dim3((uint32_t)grid64), dim3(256), lds, st, P);
-    return hipGetLastError();
-}
-
-// the count-tile nominator, dataset tiles shared through LDS (variant != 0) or streamed per wave (0: l2_knn2_counts_kernel)
-hipError_t launch_l2_knn2_counts_v(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, int variant)
-{
-    if (variant == 0) return launch_l2_knn2_counts(st, P, G, max_nj_tiles);
-    switch (G) {
-        case 8:  return launch_l2_counts_lds_t<4, 2, 4>(st, P, max_nj_tiles);
-        case 16: return launch_l2_counts_lds_t<8, 2, 4>(st, P, max_nj_tiles);
-        case 18: return launch_l2_counts_lds_t<9, 2, 3>(st, P, max_nj_tiles);
-        case 32: return launch_l2_counts_lds_t<16, 1, 4>(st, P, max_nj_tiles);
-        default: return hipErrorInvalidValue;
-    }
-}
-
 // binary rows -> i8 fragment tiles [tile][32-bit block kb][lane half h][32 rows][16 bytes] (lane half h of block kb holds bits
 // 32 kb + 16 h .. + 15 of row 32 t + r, one bit per byte) + popcount(row) + kHamBias as the bits of a float (0x7F000000 for the
 // padding rows: a key that never wins).  One workgroup per 32-row tile.
