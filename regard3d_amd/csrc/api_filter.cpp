@@ -190,7 +190,8 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         for (uint32_t k = 0; k < NI; ++k) {
             const uint64_t mk = begin_end[2 * k + 1] - begin_end[2 * k];
             soff[k] = tot;
-            if (mk > fp.m_cap || is_coop[k]) tot += next_pow2((uint32_t)mk);
+            if (is_coop[k]) tot += 2 * (uint64_t)next_pow2((uint32_t)mk);      // [sort | spare]: the bucket pass of the cooperative kernel's full evaluation
+            else if (mk > fp.m_cap) tot += next_pow2((uint32_t)mk);
         }
         FHIP(B.f_spill.ensure(tot * 12 + NI * 8 + 64));
         unsigned char* base = B.f_spill.as<unsigned char>();

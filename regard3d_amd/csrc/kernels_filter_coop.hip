@@ -639,6 +639,79 @@ __device__ __attribute__((noinline)) void coop_sort(unsigned long long* __restri
     }
 }
 
+// ---- the same ascending (residual, index) order by BUCKETS: residuals are >= 0, so their IEEE bit patterns order them; the top 17
+// bits (exponent + 6 mantissa bits: 64 bins per octave) counted down from the pattern of the bound give 2048 bins that cover 32
+// octaves below it (everything smaller shares bin 0).  Count, prefix, scatter into the spare half of the pair's sort arrays grouped
+// by bin, then every entry ranks itself among the members of its own bin and goes to its final place.  ~12 entries per bin on a
+// 12 k-match pair: three passes over the list and ~30 reads per entry where the bitonic network above makes 105 passes of which the
+// block-crossing ones run through global memory -- 270 -> ~60 us per evaluation, and a long pair's AC-RANSAC spends half its time in
+// its ~13 full evaluations.  The order is a pure function of the (key, index) pairs (distinct: the index breaks ties), so the
+// result is the network's.  Returns false -- nothing moved -- when the residuals crowd few bins (sum of squared bin counts above
+// 64 per entry: e.g. an exact synthetic scene whose inliers all have residual 0); the caller then runs the network.
+constexpr uint32_t kBktBins = 2048;
+__device__ __forceinline__ uint32_t coop_bkt_bin(unsigned long long key, uint32_t thr_top)
+{
+    const uint32_t top = (uint32_t)(key >> 46);
+    const uint32_t lo = thr_top >= (kBktBins - 1u) ? thr_top - (kBktBins - 1u) : 0u;
+    const uint32_t b = top > lo ? top - lo : 0u;
+    return b < kBktBins ? b : kBktBins - 1u;
+}
+__device__ __attribute__((noinline)) bool coop_bucket_sort(unsigned long long* __restrict__ keys, uint32_t* __restrict__ sidx,
+                                                           unsigned long long* __restrict__ tk, uint32_t* __restrict__ ti, unsigned char* smem,
+                                                           CoopS& S, uint32_t total, double maxThreshold, uint32_t tid)
+{
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem + kCoopHdr);            // [kBktBins]
+    uint32_t* start = cnt + kBktBins;                                         // [kBktBins]
+    uint32_t* fill = start + kBktBins;                                        // [kBktBins]
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t thr_top = (uint32_t)((unsigned long long)__double_as_longlong(maxThreshold) >> 46);
+    for (uint32_t b = tid; b < kBktBins; b += kCoopNT) { cnt[b] = 0u; fill[b] = 0u; }
+    r3dm_syncthreads();
+    for (uint32_t i = tid; i < total; i += kCoopNT) atomicAdd(&cnt[coop_bkt_bin(keys[i], thr_top)], 1u);
+    r3dm_syncthreads();
+    // exclusive prefix over the bins (kBktBins / kCoopNT consecutive bins per thread) + the crowding measure
+    constexpr uint32_t PER = kBktBins / (uint32_t)kCoopNT;
+    uint32_t c[PER], mine = 0u;
+    double sq = 0.0;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) { c[u] = cnt[tid * PER + u]; mine += c[u]; sq += (double)c[u] * (double)c[u]; }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 63u) S.red_k[wave] = incl;
+    if (lane == 0u) S.red_v[wave] = sq;
+    r3dm_syncthreads();
+    uint32_t wbase = 0u; double sq_all = 0.0;
+#pragma unroll
+    for (uint32_t w = 0; w < kCoopNW; ++w) { if (w < wave) wbase += S.red_k[w]; sq_all += S.red_v[w]; }
+    r3dm_syncthreads();                                                       // red_v / red_k are reused by the caller
+    if (sq_all > 64.0 * (double)total) return false;                          // workgroup-uniform
+    uint32_t run = wbase + incl - mine;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) { start[tid * PER + u] = run; run += c[u]; }
+    r3dm_syncthreads();
+    for (uint32_t i = tid; i < total; i += kCoopNT) {
+        const unsigned long long k = keys[i];
+        const uint32_t b = coop_bkt_bin(k, thr_top);
+        const uint32_t pos = start[b] + atomicAdd(&fill[b], 1u);
+        tk[pos] = k; ti[pos] = sidx[i];
+    }
+    wg_sync_t<true>();
+    for (uint32_t i = tid; i < total; i += kCoopNT) {
+        const unsigned long long k = tk[i];
+        const uint32_t x = ti[i];
+        const uint32_t b = coop_bkt_bin(k, thr_top);
+        const uint32_t s0 = start[b], e0 = s0 + cnt[b];
+        uint32_t r = 0u;
+        for (uint32_t j = s0; j < e0; ++j) r += pair_gt(k, x, tk[j], ti[j]) ? 1u : 0u;
+        keys[s0 + r] = k; sidx[s0 + r] = x;
+    }
+    wg_sync_t<true>();
+    return true;
+}
+
 // ---- full evaluation of ONE model by the leader: residuals of all matches, compaction of those within the bound, sort, NFA scan
 // (the evaluation block of acransac_body with its lists in global memory).  Returns the model's NFA and inlier count.
 template <int KIND>
@@ -692,7 +765,9 @@ __device__ void coop_full_eval(const FilterParams& P, const CoopCtx<KIND>& C, Co
     double nfa = __builtin_huge_val();
     uint32_t kbest = SS;
     if (total > SS) {
-        coop_sort(keys, sidx, smem, total, tid);
+        uint32_t cap2 = 1u; while (cap2 < m) cap2 <<= 1;                     // the pair's arrays hold 2 x next_pow2(m) entries: [sort | spare]
+        if (!coop_bucket_sort(keys, sidx, keys + cap2, sidx + cap2, smem, S, total, maxThreshold, tid))
+            coop_sort(keys, sidx, smem, total, tid);
         // bestNFA: k = SS + 1 .. total, first minimum wins
         double bv = __builtin_huge_val(); uint32_t bk = 0xFFFFFFFFu;
         for (uint32_t kk = SS + 1 + tid; kk <= total; kk += NT) {

@@ -193,3 +193,26 @@ def test_host_thread_budget_respects_the_cores_the_process_owns():
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     cores, seen = bench.host_cores()
     assert 1 <= cores <= seen and t <= max(1, cores)
+
+
+def test_kernel_fingerprints_of_the_built_library():
+    """bench.py keys profiles/pmc_traffic.json to the machine code of the kernel that was profiled (regard3d_amd/codeobj.py): the
+    built library must expose the kernels the entries name, a fingerprint must not depend on anything but the kernel's bytes
+    (two reads agree; another kernel differs), and an entry carries either a fingerprint or the older source hash"""
+    import json
+    from regard3d_amd.codeobj import kernel_code_hashes, kernel_hash, mangled_needle
+    lib = os.path.join(ROOT, "regard3d_amd", "libr3dm.so")
+    hs = kernel_code_hashes(lib)
+    assert len(hs) > 50 and any("l2_knn2_mfma_kernel" in k for k in hs) and any("acransac_coop_kernel" in k for k in hs)
+    n = mangled_needle("l2_knn2_mfma_kernel<16, 2, 4, 3, 2>")
+    assert n == "l2_knn2_mfma_kernelILi16ELi2ELi4ELi3ELi2EE"
+    a, b = kernel_hash(lib, n), kernel_hash(lib, n)
+    assert a is not None and a == b and a != kernel_hash(lib, mangled_needle("l2_knn2_mfma_kernel<18, 2, 3, 3, 2>"))
+    assert kernel_hash(lib, "no_such_kernel") is None
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for key, ent in t.items():
+        if key.startswith("_"):
+            continue
+        assert ent.get("code_sha16") or ent.get("source_sha16"), key
+        if ent.get("code_sha16"):
+            assert kernel_hash(lib, mangled_needle(ent["kernel"])) is not None, key      # the kernel exists in today's library
