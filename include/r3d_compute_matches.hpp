@@ -70,8 +70,8 @@ public:
     // matchingAlgorithm value of the new dispatch arm next to src/R3DComputeMatches.cpp:2054-2062;
     // 4 ("Brute Force", src/Regard3DMainFrameBase.cpp:1020) is served by the same GPU path; the approximate arms (0 FLANN,
     // 1..3 KGraph, 5 MRPT, 6..8 HNSW) run the graph-based approximate matcher with a preset of at least the arm's recall
-    // (FLANN and MRPT are permanently substituted by it, not reimplemented: r3dm.h, r3dm_ann_params_for_algorithm, DESIGN.md section 7;
-    // the HNSW arms run hnswlib's own search on a batch-built index, r3dm_match_pairs_hnsw).
+    // (FLANN is permanently substituted by it, not reimplemented: r3dm.h, r3dm_ann_params_for_algorithm, DESIGN.md section 7;
+    // the HNSW arms run hnswlib's own search on a batch-built index, r3dm_match_pairs_hnsw; the MRPT arm its own trees, r3dm_match_pairs_mrpt).
     static constexpr int kMatchingAlgorithmGPU = 9;
 
     explicit R3DComputeMatches(int device_id = 0);
@@ -104,14 +104,17 @@ public:
     // EXHAUSTIVE matcher whenever r3dm_exhaustive_is_faster says it is not slower on the registered views -- on LIOP-144 every
     // approximate arm is then exact and >= 2x faster than the graph search (the GUI's default arm 0 included); kArmsAsRequested:
     // arms 6-8 by hnsw_match itself (hnswlib's searchKnn on a batch-built HNSW index, r3dm_match_pairs_hnsw; descriptor lengths 64 /
-    // 128 / 144 / 256), arms 1-3 by kgraph_match, and the arms whose index is not built here (0 FLANN kd-trees, 5 MRPT, HNSW on other
-    // lengths) by the graph matcher with a preset of at least the arm's recall (r3dm_ann_params_for_algorithm).
+    // 128 / 144 / 256), arm 5 by mrpt_match itself (random projection trees on the device, r3dm_match_pairs_mrpt), arms 1-3 by
+    // kgraph_match, and the arms whose index is not built here (0 FLANN kd-trees, HNSW on other lengths) by the graph matcher with a
+    // preset of at least the arm's recall (r3dm_ann_params_for_algorithm).
     enum ArmsPolicy { kArmsFastest = 0, kArmsAsRequested = 1 };
     void setApproximateArmsPolicy(ArmsPolicy p) { arms_policy_ = p; }
     // which matcher the last computeMatches call ran: true = exhaustive (arm 4 / 9, or an approximate arm routed to it)
     bool lastMatchWasExhaustive() const { return last_exhaustive_; }
     // ... true = hnsw_match (arms 6-8 under kArmsAsRequested)
     bool lastMatchWasHnsw() const { return last_hnsw_; }
+    // ... true = mrpt_match (arm 5 under kArmsAsRequested)
+    bool lastMatchWasMrpt() const { return last_mrpt_; }
     // updateProgress(float, const wxString&) (src/R3DComputeMatches.cpp:2664): the GUI hook, called with the reference's own
     // fractions and messages (0.7 "Find putative matches", 0.8 / 0.9 / 0.95 "Calculate ... matrix", :2000,2107,2133,2209)
     using ProgressFn = void (*)(float progress, const char* msg, void* user);
@@ -166,7 +169,7 @@ private:
     r3dm_multi* feat_multi_ = nullptr;     // contexts of the features stage (feat_conc_ per device), created on first use
     int feat_conc_ = 2, feat_batch_ = 8;
     ArmsPolicy arms_policy_ = kArmsFastest;
-    bool last_exhaustive_ = true, last_hnsw_ = false;
+    bool last_exhaustive_ = true, last_hnsw_ = false, last_mrpt_ = false;
     // views registered with the matcher straight from the features stage (r3dm_set_features_sink): descriptors device to device,
     // positions as a reader of the .feat file would parse them; the load step reads the files of the other views only
     std::mutex sink_mu_;

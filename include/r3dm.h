@@ -218,12 +218,12 @@ int r3dm_kgraph_preset(int preset, r3dm_kgraph_params* out);
  * R3DM_ERR_INVALID for the exhaustive arms 4 / 9 and unknown values.  The KGraph arms are the reference's algorithm.  The HNSW
  * arms have their own entry points (r3dm_match_pairs_hnsw below: hnswlib's search on an HNSW index) -- this mapping is what a host
  * uses for them only when it wants the FASTEST matcher of at least the arm's recall, or for a descriptor length hnswlib's SIMD16
- * distance does not serve.  FLANN (arm 0) and MRPT (arm 5) are PERMANENTLY SUBSTITUTED: no kd-tree or random-projection index is
- * built here, the same deterministic graph matcher answers for them and its matches are not those the reference's arm would return
- * (both are approximate).  Decided and closed in round 4: neither FLANN nor Eigen (mrpt.h) exists in the build
- * image, so neither index could be pinned to the reference; MRPT's projections draw from implementation-defined libstdc++
- * distributions; and every approximate arm measured on this GPU is slower than the exact fast paths, under which the facade's
- * default policy serves these arms at recall 1.  The arm numbers and their parameters are accepted and mapped, never rejected.
+ * distance does not serve.  The MRPT arm (5) has its own entry points too since round 4 (r3dm_match_pairs_mrpt below: random
+ * projection trees built and queried on the device); this mapping serves it only under the fastest-matcher policy.  FLANN (arm 0)
+ * is PERMANENTLY SUBSTITUTED: no kd-tree index is built here, the deterministic graph matcher answers for it and its matches are not
+ * those the reference's arm would return (both are approximate) -- FLANN is an external library that is not in the reference tree,
+ * so there is nothing to restate or pin, and every approximate arm measured on this GPU is slower than the exact fast paths, under
+ * which the facade's default policy serves these arms at recall 1.  The arm numbers are accepted and mapped, never rejected.
  * See the table in api_match.cpp and DESIGN.md sections 4.7 and 7. */
 int r3dm_ann_params_for_algorithm(int matching_algorithm, r3dm_kgraph_params* out);
 int r3dm_match_pairs_kgraph(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
@@ -298,6 +298,40 @@ int r3dm_hnsw_knn2_on_index(r3dm_ctx* ctx, const float* dataset, uint32_t n_data
 /* the index of a registered view (built if necessary) in that shape; up_links holds up_cap rows, *up_rows receives the number needed */
 int r3dm_hnsw_index(r3dm_ctx* ctx, uint32_t view_id, const r3dm_hnsw_params* params, int32_t* links0, int32_t* up_off,
                     int32_t* up_links, uint32_t up_cap, uint32_t* up_rows, int32_t* enterpoint, int32_t* maxlevel);
+
+/* ---- MRPT plugin path (matchingAlgorithm 5) ----
+ * mrpt_match (src/R3DComputeMatches.cpp:423-491): per first view I an index of n_trees random projection trees of depth `depth` over
+ * its descriptors (ArrayMatcher_mrpt::Build, src/utils/matcher_mrpt.h:76-128 -> Mrpt::grow, src/thirdparty/mrpt/mrpt.h:84-137: sparse
+ * random vectors of density 1 / sqrt(dim), every tree level splits its nodes at the median projection), per query row of J
+ * Mrpt::query(row, 2, votes) (mrpt.h:661-728: one leaf per tree, the rows that collect >= votes votes are measured exactly, the two
+ * nearest kept; once more with votes - 1 when fewer than two rows were elected, matcher_mrpt.h:224-232; a query that still has none is
+ * dropped), then the ratio test ON THE SQUARE ROOTS the index returns with the un-squared ratio (RegionsMatcherT(regions, false),
+ * src/R3DComputeMatches.cpp:461) and the de-duplication / pair rules every arm shares.  The index is built on the device
+ * (kernels_mrpt.hip); parity is with the CPU model oracle/mrpt.c bit for bit.  What cannot match a reference build -- and could not
+ * be pinned to one, mrpt.h being Eigen code: the random vectors are drawn from a counter-based stream instead of std::mt19937 with
+ * implementation-defined distributions (same density, same N(0, 1) values), rows whose projection EQUALS a node's median go left in
+ * (projection, row) order where std::nth_element leaves them anywhere, candidates are measured with the reference's brute-force
+ * metric in its summation order.  Views with fewer than 128 rows are scanned exhaustively; descriptor lengths: any multiple of 4
+ * up to 512; at most 131,072 rows per indexed view. */
+typedef struct {
+    uint32_t n_trees;          /* 1..255                                   (reference: 26)                                         */
+    uint32_t depth;            /* 1..6; clamped per view to max(2, min(depth, floor(log2 n) - 1)) as ArrayMatcher_mrpt::Build does   (6) */
+    uint32_t votes;            /* rows with at least this many of the n_trees votes are candidates, 1..n_trees   (5)               */
+    float    density;          /* share of non-zero entries of a random vector; <= 0: 1 / sqrt(dim), mrpt.h's default   (0.088: set but never passed on by the reference) */
+    uint64_t seed;             /* of the counter-based stream the random vectors are drawn from                                     */
+} r3dm_mrpt_params;
+int r3dm_mrpt_preset(r3dm_mrpt_params* out);               /* 26 / 6 / 5 / default density / seed 0 */
+int r3dm_match_pairs_mrpt(r3dm_ctx* ctx, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                          const r3dm_mrpt_params* params, r3dm_graph** out);
+/* ArrayMatcher_mrpt-shaped call: index `dataset` (>= 128 rows), the two nearest elected rows of every query row.  out_dist = the
+ * SQUARE ROOTS of the squared L2 distances, as Mrpt::query returns them; out_idx -1 / out_dist -1 for a query the reference drops. */
+int r3dm_mrpt_knn2(r3dm_ctx* ctx, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
+                   uint32_t dim, const r3dm_mrpt_params* params, int32_t* out_idx, float* out_dist);
+/* the index of a registered view (built if necessary): R = n_trees * depth x dim (zeros where the sparse matrix has no entry),
+ * splits = n_trees x (2^depth - 1) in heap order, leaves = n_trees x n rows leaf after leaf, leaf_first = 2^depth + 1 offsets;
+ * *depth_out = the clamped depth.  Any output may be NULL.  The arrays must hold the sizes of depth = params->depth. */
+int r3dm_mrpt_index(r3dm_ctx* ctx, uint32_t view_id, const r3dm_mrpt_params* params, float* R, float* splits, int32_t* leaves,
+                    int32_t* leaf_first, uint32_t* depth_out);
 
 /* ---- keypoint detection: Fast-A-KAZE ----
  * The "Fast-AKAZE" arm of Regard3DFeatures::detectKeypoints (src/Regard3DFeatures.cpp:596-617): cv::AKAZE2::create() with its
@@ -413,6 +447,9 @@ int r3dm_multi_match_pairs_kgraph(r3dm_multi* m, const uint32_t* pairs_ij, uint6
 /* ... and for the HNSW matcher (hnsw_match, matchingAlgorithm 6..8) */
 int r3dm_multi_match_pairs_hnsw(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
                                 const r3dm_hnsw_params* params, r3dm_graph** out);
+/* ... and for the MRPT matcher (mrpt_match, matchingAlgorithm 5) */
+int r3dm_multi_match_pairs_mrpt(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                                const r3dm_mrpt_params* params, r3dm_graph** out);
 int r3dm_multi_filter_F(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,
                         uint64_t seed, r3dm_graph** out, double* F_out);
 int r3dm_multi_filter_H(r3dm_multi* m, const r3dm_graph* putative, double max_residual_px, uint32_t max_iter,

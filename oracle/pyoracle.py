@@ -29,7 +29,7 @@ class FResult(C.Structure):
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "kgraph.c", "essential.c", "akaze.c", "r3d_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("matching.c", "acransac.c", "io.c", "liop.c", "kgraph.c", "essential.c", "akaze.c", "hnsw.c", "mrpt.c", "r3d_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -643,3 +643,98 @@ def ref_hnsw_export(dataset, query, M, ef_construction, ef):
     if rc != 0:
         raise RuntimeError(f"ref_hnsw_export failed ({rc})")
     return dict(levels=levels, links0=links0, up_off=up_off, up_links=up[:up_off[n]], enterpoint=ep.value, maxlevel=ml.value), idx, dist
+
+
+# ---- MRPT plugin path (matchingAlgorithm 5): the CPU model (mrpt.c) ----
+MRPT_PRESET = dict(n_trees=26, depth=6, votes=5, density=0.088)      # src/R3DComputeMatches.cpp:453-456
+
+
+class MrptIndex:
+    def __init__(self, handle, data, n_trees, depth):
+        self._h, self._data, self.n_trees, self.depth = handle, data, n_trees, depth
+
+    def __del__(self):
+        try:
+            lib().orc_mrpt_free(C.c_void_p(self._h))
+        except Exception:
+            pass
+
+    def export(self):
+        n, dim = self._data.shape
+        nl = 1 << self.depth
+        R = np.zeros((self.n_trees * self.depth, dim), np.float32); sp = np.zeros((self.n_trees, nl - 1), np.float32)
+        lv = np.zeros((self.n_trees, n), np.int32); lf = np.zeros(nl + 1, np.int32)
+        lib().orc_mrpt_export(C.c_void_p(self._h), _p(R), _p(sp), _p(lv), _p(lf))
+        return dict(R=R, splits=sp, leaves=lv, leaf_first=lf)
+
+    def knn2(self, query, votes):
+        query = np.ascontiguousarray(query, np.float32)
+        idx = np.zeros((len(query), 2), np.int32); dist = np.zeros((len(query), 2), np.float32); ne = np.zeros(len(query), np.uint32)
+        rc = lib().orc_mrpt_knn2(C.c_void_p(self._h), _p(query), len(query), votes, _p(idx), _p(dist), _p(ne))
+        if rc != 0:
+            raise ValueError("orc_mrpt_knn2 failed")
+        return idx, dist, ne
+
+
+def mrpt_depth_for(n, depth):
+    L = lib(); L.orc_mrpt_depth_for.restype = C.c_uint32
+    return int(L.orc_mrpt_depth_for(n, depth))
+
+
+def mrpt_build(data, n_trees=26, depth=6, density=0.088, seed=0) -> MrptIndex:
+    """Mrpt::grow(n_trees, depth clamped as ArrayMatcher_mrpt::Build clamps it, density)"""
+    data = np.ascontiguousarray(data, np.float32)
+    L = lib(); L.orc_mrpt_build.restype = C.c_void_p
+    L.orc_mrpt_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64]
+    d = mrpt_depth_for(data.shape[0], depth)
+    h = L.orc_mrpt_build(_p(data), data.shape[0], data.shape[1], n_trees, d, density, seed)
+    return MrptIndex(h, data, n_trees, d)
+
+
+def mrpt_random_matrix(n_pool, dim, density, seed=0):
+    R = np.zeros((n_pool, dim), np.float32)
+    L = lib(); L.orc_mrpt_random_matrix.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, C.c_void_p]
+    L.orc_mrpt_random_matrix(n_pool, dim, density, seed, _p(R))
+    return R
+
+
+def ratio_dedup(idx, dist, xyI, xyJ, ratio, squared_metric=True):
+    """NNdistanceRatio + both de-duplications on a 2-NN table (matching.c: orc_ratio_dedup_f32) -> matches [m, 2] (i_, j_)"""
+    idx = np.ascontiguousarray(idx, np.int32); dist = np.ascontiguousarray(dist, np.float32)
+    nJ = idx.shape[0]
+    out = np.zeros((max(nJ, 1), 2), np.uint32)
+    xi = np.ascontiguousarray(xyI, np.float32) if xyI is not None else None
+    xj = np.ascontiguousarray(xyJ, np.float32) if xyJ is not None else None
+    m = lib().orc_ratio_dedup_f32(_p(idx), _p(dist), nJ, _p(xi) if xi is not None else None, _p(xj) if xj is not None else None,
+                                  C.c_float(ratio), 1 if squared_metric else 0, _p(out))
+    return out[:m].copy()
+
+
+def match_collection_mrpt(descs, xys, pairs, ratio, n_trees=26, depth=6, votes=5, density=None, seed=0, min_rows=128):
+    """mrpt_match over a collection with the CPU model: per pair (counts, matches) as the GPU path must produce them.  Views below
+    min_rows are scanned exactly with the squared ratio (the exhaustive arm), the others answer through their forest with the
+    un-squared ratio on square-root distances; dropped queries (-1) match nothing."""
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    descs = [np.ascontiguousarray(d, np.float32) for d in descs]
+    index = {}
+    counts = np.zeros(len(pairs), np.uint32); out = []
+    for k, (I, J) in enumerate(pairs):
+        dI, dJ = descs[I], descs[J]
+        if len(dI) == 0 or len(dJ) == 0:
+            continue
+        if len(dI) < min_rows:
+            if len(dI) < 2:
+                continue
+            idx, dist = knn2(dI, dJ)
+            m = ratio_dedup(idx, dist, xys[I], xys[J], ratio, True)
+        else:
+            if I not in index:
+                dens = density if density and density > 0 else float(np.float32(1.0 / np.sqrt(np.float64(dI.shape[1]))))
+                index[I] = mrpt_build(dI, n_trees, depth, dens, seed)
+            idx, dist, _ = index[I].knn2(dJ, votes)
+            dropped = idx[:, 0] < 0
+            idx = idx.copy(); dist = dist.copy()
+            idx[dropped] = 0; dist[dropped] = (1.0, 0.0)
+            m = ratio_dedup(idx, dist, xys[I], xys[J], ratio, False)
+        counts[k] = len(m); out.append(m)
+    return counts, (np.concatenate(out) if out else np.zeros((0, 2), np.uint32))

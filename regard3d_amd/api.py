@@ -27,6 +27,7 @@ EXPORTS = [
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
     "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
     "r3dm_filter_FEH", "r3dm_host_threads", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
+    "r3dm_mrpt_preset", "r3dm_match_pairs_mrpt", "r3dm_mrpt_knn2", "r3dm_mrpt_index", "r3dm_multi_match_pairs_mrpt",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
     "r3dm_multi_set_image", "r3dm_multi_transfer_counts", "r3dm_multi_set_intrinsics", "r3dm_multi_clear_images", "r3dm_multi_set_integer_mfma",
@@ -193,6 +194,18 @@ class HnswParams(C.Structure):
         return hp
 
 
+class MrptParams(C.Structure):
+    """r3dm_mrpt_params: n_trees, depth (clamped per view), votes, density (<= 0: 1 / sqrt(dim)), seed of the random vectors"""
+    _fields_ = [("n_trees", C.c_uint32), ("depth", C.c_uint32), ("votes", C.c_uint32), ("density", C.c_float), ("seed", C.c_uint64)]
+
+    @staticmethod
+    def preset() -> "MrptParams":
+        mp = MrptParams()
+        if load_library().r3dm_mrpt_preset(C.byref(mp)) != 0:
+            raise R3dmError("r3dm_mrpt_preset failed")
+        return mp
+
+
 class HnswArrays(C.Structure):
     """r3dm_hnsw_arrays: an HNSW index in hnswlib's own shape"""
     _fields_ = [("M", C.c_uint32), ("links0", C.c_void_p), ("up_off", C.c_void_p), ("up_links", C.c_void_p), ("up_rows", C.c_uint32),
@@ -272,6 +285,11 @@ def load_library():
     L.r3dm_kgraph_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, u32, u32, vp, vp]
     L.r3dm_kgraph_index.argtypes = [vp, u32, u32, vp, vp]
     L.r3dm_hnsw_preset.argtypes = [C.c_int, vp]
+    L.r3dm_mrpt_preset.argtypes = [vp]
+    L.r3dm_match_pairs_mrpt.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
+    L.r3dm_mrpt_knn2.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.r3dm_mrpt_index.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    L.r3dm_multi_match_pairs_mrpt.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_match_pairs_hnsw.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(vp)]
     L.r3dm_hnsw_knn2.argtypes = [vp, vp, u32, vp, u32, u32, vp, vp, vp]
     L.r3dm_hnsw_knn2_on_index.argtypes = [vp, vp, u32, u32, vp, vp, u32, u32, vp, vp]
@@ -604,6 +622,36 @@ class Context:
         self._check(self._L.r3dm_match_pairs_hnsw(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0], dist_ratio,
                                                   C.addressof(hp), C.byref(h)), "r3dm_match_pairs_hnsw")
         return Graph(h.value)
+
+    def match_pairs_mrpt(self, pairs, dist_ratio: float = 0.6, params: "MrptParams" = None) -> Graph:
+        """mrpt_match (matchingAlgorithm 5): random projection trees per first view, vote, exact re-rank (r3dm_match_pairs_mrpt)"""
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        mp = params if params is not None else MrptParams.preset()
+        h = C.c_void_p()
+        self._check(self._L.r3dm_match_pairs_mrpt(self._h, _ptr(pairs) if pairs.size else None, pairs.shape[0], dist_ratio,
+                                                  C.addressof(mp), C.byref(h)), "r3dm_match_pairs_mrpt")
+        return Graph(h.value)
+
+    def mrpt_knn2(self, dataset, query, params: "MrptParams" = None):
+        """ArrayMatcher_mrpt-shaped: (idx [nq, 2] int32 (-1: dropped), dist [nq, 2] float32 = SQUARE ROOTS of the squared L2 distances)"""
+        dataset = np.ascontiguousarray(dataset, np.float32); query = np.ascontiguousarray(query, np.float32)
+        mp = params if params is not None else MrptParams.preset()
+        nq = query.shape[0]
+        idx = np.full((max(nq, 1), 2), -1, np.int32); dist = np.zeros((max(nq, 1), 2), np.float32)
+        self._check(self._L.r3dm_mrpt_knn2(self._h, _ptr(dataset), dataset.shape[0], _ptr(query), nq, dataset.shape[1],
+                                           C.addressof(mp), _ptr(idx), _ptr(dist)), "r3dm_mrpt_knn2")
+        return idx[:nq], dist[:nq]
+
+    def mrpt_index(self, view_id: int, n_rows: int, dim: int, params: "MrptParams" = None) -> dict:
+        """the MRPT index of a registered view as arrays (r3dm_mrpt_index), cut to the view's clamped depth"""
+        mp = params if params is not None else MrptParams.preset()
+        nl = 1 << mp.depth
+        R = np.zeros((mp.n_trees * mp.depth, dim), np.float32); sp = np.zeros((mp.n_trees, nl - 1), np.float32)
+        lv = np.zeros((mp.n_trees, n_rows), np.int32); lf = np.zeros(nl + 1, np.int32); d = C.c_uint32(0)
+        self._check(self._L.r3dm_mrpt_index(self._h, view_id, C.addressof(mp), _ptr(R), _ptr(sp), _ptr(lv), _ptr(lf), C.byref(d)), "r3dm_mrpt_index")
+        d = d.value; nl = 1 << d
+        return dict(R=R.reshape(-1)[:mp.n_trees * d * dim].reshape(mp.n_trees * d, dim).copy(), splits=sp.reshape(-1)[:mp.n_trees * (nl - 1)].reshape(mp.n_trees, nl - 1).copy(),
+                    leaves=lv, leaf_first=lf[:nl + 1].copy(), depth=d)
 
     def hnsw_knn2(self, dataset, query, params: "HnswParams" = None):
         dataset = np.ascontiguousarray(dataset, np.float32); query = np.ascontiguousarray(query, np.float32)

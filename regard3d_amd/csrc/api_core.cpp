@@ -136,7 +136,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
     HostImage& h = *c->imgs[slot];
     h.view_id = view_id; h.n = n; h.dim = dim; h.dtype = dtype; h.width = width; h.height = height;
     h.has_xy = (xy != nullptr); h.has_dup = false; h.live = true;
-    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0; h.hnsw_M = 0; h.compact_ready = false;
+    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0; h.hnsw_M = 0; h.mrpt_trees = 0; h.compact_ready = false;
     if (dtype == R3DM_BIN) {
         h.words = (dim + 3) / 4;
         const uint32_t n_pad = n + 8;
@@ -323,7 +323,8 @@ extern "C" int r3dm_clear_images(r3dm_ctx* c)
         if (c->spare.size() >= kSpareViews) { im->release(); continue; }
         im->ann_adj.release(); im->ann_deg.release(); im->ann_rows16.release(); im->ann_rows8.release();
         im->hnsw_l0.release(); im->hnsw_up_off.release(); im->hnsw_up.release();
-        im->live = false; im->has_K = false; im->ann_K = 0; im->hnsw_M = 0; im->compact_ready = false; im->n = 0; im->counts_ok = false;
+        im->mrpt_R.release(); im->mrpt_RT.release(); im->mrpt_splits.release(); im->mrpt_leaves.release(); im->mrpt_lf.release();
+        im->live = false; im->has_K = false; im->ann_K = 0; im->hnsw_M = 0; im->mrpt_trees = 0; im->compact_ready = false; im->n = 0; im->counts_ok = false;
         c->spare.push_back(std::move(im));
     }
     c->imgs.clear();

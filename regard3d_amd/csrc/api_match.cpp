@@ -822,7 +822,7 @@ extern "C" int r3dm_kgraph_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_da
 extern "C" int r3dm_drop_indices(r3dm_ctx* c)
 {
     if (!c) return R3DM_ERR_INVALID;
-    for (auto& h : c->imgs) if (h) { h->ann_K = 0; h->hnsw_M = 0; }            // the device pointers stay valid until the rebuild replaces them
+    for (auto& h : c->imgs) if (h) { h->ann_K = 0; h->hnsw_M = 0; h->mrpt_trees = 0; }            // the device pointers stay valid until the rebuild replaces them
     return R3DM_OK;
 }
 

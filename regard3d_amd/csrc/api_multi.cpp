@@ -268,6 +268,29 @@ extern "C" int r3dm_multi_match_pairs_hnsw(r3dm_multi* m, const uint32_t* pairs_
     } catch (...) { m->err = "out of host memory"; return R3DM_ERR_NOMEM; }
 }
 
+// ... and for the MRPT matcher (mrpt_match, matchingAlgorithm 5)
+extern "C" int r3dm_multi_match_pairs_mrpt(r3dm_multi* m, const uint32_t* pairs_ij, uint64_t n_pairs, float dist_ratio,
+                                           const r3dm_mrpt_params* params, r3dm_graph** out)
+{
+    if (!m || !out || !params || (n_pairs && !pairs_ij)) return R3DM_ERR_INVALID;
+    *out = nullptr;
+    const uint32_t W = (uint32_t)m->ctx.size();
+    try {
+        std::vector<uint32_t> owner(n_pairs);
+        int rc = r3dm_shard_pairs(pairs_ij, n_pairs, W, owner.data());
+        if (rc != R3DM_OK) return rc;
+        std::vector<std::vector<uint32_t>> mine(W);
+        for (uint64_t p = 0; p < n_pairs; ++p) { mine[owner[p]].push_back(pairs_ij[2 * p]); mine[owner[p]].push_back(pairs_ij[2 * p + 1]); }
+        std::vector<r3dm_graph*> parts(W, nullptr);
+        rc = for_each_device(m, [&](uint32_t k, r3dm_ctx* c) {
+            return r3dm_match_pairs_mrpt(c, mine[k].data(), mine[k].size() / 2, dist_ratio, params, &parts[k]);
+        });
+        if (rc == R3DM_OK) rc = r3dm_graph_merge(parts.data(), W, out);
+        for (r3dm_graph* g : parts) r3dm_graph_free(g);
+        return rc;
+    } catch (...) { m->err = "out of host memory"; return R3DM_ERR_NOMEM; }
+}
+
 // model_kind as in api_filter.cpp: 0 F, 1 H, 2 E.  Putative pairs are dealt longest list first (the AC-RANSAC of a pair
 // costs about as much as it has putatives) round-robin in snake order; the models of the kept pairs are re-ordered with
 // the merged graph.

@@ -431,7 +431,16 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     const bool use_hnsw = use_kgraph && arms_policy_ == kArmsAsRequested && matchingAlgorithm >= 6 && matchingAlgorithm <= 8 &&
                           dtype_ != R3DM_BIN && (dim_ == 64 || dim_ == 128 || dim_ == 144 || dim_ == 256);
     last_hnsw_ = use_hnsw;
-    if (use_hnsw) {
+    // arm 5 taken literally runs mrpt_match itself: random projection trees on the device (r3dm_match_pairs_mrpt), the reference's
+    // parameters (src/R3DComputeMatches.cpp:453-456); the index takes float rows of any length that is a multiple of 4
+    const bool use_mrpt = use_kgraph && arms_policy_ == kArmsAsRequested && matchingAlgorithm == 5 && dtype_ != R3DM_BIN && (dim_ & 3u) == 0 && dim_ <= 512;
+    last_mrpt_ = use_mrpt;
+    if (use_mrpt) {
+        r3dm_mrpt_params mp;
+        (void)r3dm_mrpt_preset(&mp);
+        rc = ctx_ ? r3dm_match_pairs_mrpt(ctx_, pairs.data(), pairs.size() / 2, params.distRatio_, &mp, &putative)
+                  : r3dm_multi_match_pairs_mrpt(multi_, pairs.data(), pairs.size() / 2, params.distRatio_, &mp, &putative);
+    } else if (use_hnsw) {
         r3dm_hnsw_params hp;
         (void)r3dm_hnsw_preset(matchingAlgorithm - 6, &hp);
         rc = match_hnsw(pairs, params.distRatio_, &hp, &putative);

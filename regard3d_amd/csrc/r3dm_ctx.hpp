@@ -109,6 +109,9 @@ struct HostImage {
     // HNSW index (r3dm_match_pairs_hnsw), valid when hnsw_M != 0: hnswlib's arrays (kernels_hnsw.hip: HnswView) + the host-side scalars
     DevBuf hnsw_l0, hnsw_up_off, hnsw_up;
     uint32_t hnsw_M = 0, hnsw_seed = 0, hnsw_up_rows = 0; int32_t hnsw_enter = -1, hnsw_maxlevel = -1;
+    // MRPT index (r3dm_match_pairs_mrpt), valid when mrpt_trees != 0: kernels_mrpt.hip: MrptView
+    DevBuf mrpt_R, mrpt_RT, mrpt_splits, mrpt_leaves, mrpt_lf;
+    uint32_t mrpt_trees = 0, mrpt_depth = 0; float mrpt_density = 0.0f; uint64_t mrpt_seed = 0;
     bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter
     double Kinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     void release()
@@ -117,6 +120,7 @@ struct HostImage {
         rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiledc.release(); tiledp.release(); cscale.release(); cquad.release(); cperm.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
         ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; compact_ready = false; live = false;
         hnsw_l0.release(); hnsw_up_off.release(); hnsw_up.release(); hnsw_M = 0;
+        mrpt_R.release(); mrpt_RT.release(); mrpt_splits.release(); mrpt_leaves.release(); mrpt_lf.release(); mrpt_trees = 0;
     }
 };
 

@@ -152,6 +152,36 @@ struct HnswSearchParams {
     uint32_t queries_per_wave;    // developer build: 2 / 4 / 8 run hnsw_search_group_kernel (measured, not adopted); else a wavefront per query
     uint32_t per_query;           // set by the launcher: LDS bytes of one query's state
 };
+// ---- MRPT plugin path (kernels_mrpt.hip): random projection trees of a view in the shape of /root/reference/src/thirdparty/mrpt/mrpt.h
+struct MrptView {
+    const float*   rows;          // [n][dim] f32, row-major
+    const float*   RT;            // [dim][n_trees * depth]: the random matrix, transposed (zeros where the sparse matrix has no entry)
+    const float*   splits;        // [n_trees][2^depth - 1], heap order
+    const int32_t* leaves;        // [n_trees][n]: rows of a tree, leaf after leaf
+    const int32_t* leaf_first;    // [2^depth + 1]
+    uint32_t n, dim, n_trees, depth;
+};
+struct MrptQueryJob {
+    MrptView     ix;
+    const float* query;           // [nq][dim]
+    uint32_t     nq;
+    uint32_t     out_base;        // first slot of the pair in nn_idx / knn_*
+};
+struct MrptQueryParams {
+    const MrptQueryJob* jobs;
+    uint32_t n_jobs, votes, elected_cap;
+    uint32_t max_n, pool_pad, per_wave, waves;   // set by the launcher
+    float    ratio;               // UN-squared: the test runs on sqrt distances (RegionsMatcherT(regions, false))
+    uint32_t* nn_idx;
+    int32_t*  knn_idx;            // optional
+    float*    knn_dist;           // optional: sqrtf of the squared L2 distances, -1 for a query without two elected rows
+    unsigned long long* n_comps;  // distance evaluations (atomic)
+};
+hipError_t launch_mrpt_project(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, const float* R, uint32_t n_trees, uint32_t depth, float* proj);
+hipError_t launch_mrpt_trees(hipStream_t st, const float* proj, uint32_t n, uint32_t n_trees, uint32_t depth, uint32_t cap, unsigned long long* keys,
+                             int32_t* leaves, float* splits);
+hipError_t launch_mrpt_query(hipStream_t st, const MrptQueryParams& P, uint32_t max_nq, uint32_t max_n, uint32_t max_pool);
+
 struct HnswBuildJob {
     const float*    rows;
     const uint32_t* adj;          // ImgDev::ann_adj of the view (exact 32-NN graph + reverse edges)

@@ -188,4 +188,7 @@ def test_stage_from_pixels_equals_the_cpu_restatement(oracle, tmp_path, kind):
     assert r5.images_extracted == 0 and r5.match_was_exhaustive == 1 and open(os.path.join(d, "matches.f.bin"), "rb").read() == blob
     r6 = st.run(d, [dict(v, gray=None, bgr=None) for v in views], 0.001, 0.6, 0, True, False, False, arms_as_requested=True)
     assert r6.match_was_exhaustive == 0 and r6.n_putative_pairs >= 4
+    # arm 5 taken literally: mrpt_match on the device (random projection trees per first view, r3dm_match_pairs_mrpt)
+    r7 = st.run(d, [dict(v, gray=None, bgr=None) for v in views], 0.001, 0.6, 5, True, False, False, arms_as_requested=True)
+    assert r7.match_was_exhaustive == 0 and r7.n_putative_pairs >= 4 and 0 < r7.n_putative_matches <= r5.n_putative_matches
     st.close()

@@ -14,6 +14,7 @@ ap.add_argument("--feat", type=int, default=16384)
 ap.add_argument("--kind", default="sift")
 ap.add_argument("--presets", default="fast,medium,precise,default")
 ap.add_argument("--hnsw", default="fast,medium,precise", help="HNSW presets to time as well (matchingAlgorithm 6 / 7 / 8); '' = none")
+ap.add_argument("--mrpt", type=int, default=1, help="time the MRPT arm (matchingAlgorithm 5) as well")
 ap.add_argument("--S", type=int, default=0, help="override search_S (0 = preset)")
 ap.add_argument("--K", type=int, default=0, help="override index_K (0 = preset)")
 a = ap.parse_args()
@@ -72,5 +73,21 @@ for name in [x for x in a.hnsw.split(",") if x]:
                           ms_build=s1.ms_ann_build, ms_build_per_view=s1.ms_ann_build / max(s1.n_ann_built, 1),
                           ms_search=s2.ms_ann_search, ms_search_per_pair=s2.ms_ann_search / len(pairs),
                           evals_per_query=s2.n_ann_dist / max(s2.n_queries, 1), retries=s2.n_hnsw_retries, matches=g.num_matches,
+                          match_recall=hit / max(nb, 1), match_precision=hit / max(g.num_matches, 1),
+                          speedup_vs_exhaustive=sb.ms_match_kernels / s2.ms_ann_search)), flush=True)
+if a.mrpt:
+    mp = api.MrptParams.preset()
+    c.drop_indices()
+    t = time.time(); g = c.match_pairs_mrpt(pairs, 0.6, mp); t1 = time.time() - t
+    s1 = c.stats(); first = (g.pairs.tobytes(), g.matches.tobytes())
+    t = time.time(); g = c.match_pairs_mrpt(pairs, 0.6, mp); t2 = time.time() - t
+    assert first == (g.pairs.tobytes(), g.matches.tobytes()), "MRPT matcher is not deterministic"
+    s2 = c.stats()
+    d = g.as_dict()
+    hit = sum(len(set(map(tuple, d[k].tolist())) & set(map(tuple, bd[k].tolist()))) for k in d if k in bd)
+    print(json.dumps(dict(method="mrpt", n_trees=mp.n_trees, depth=mp.depth, votes=mp.votes, s_first=t1, s_cached=t2, pairs_per_s=len(pairs) / t2,
+                          ms_build=s1.ms_ann_build, ms_build_per_view=s1.ms_ann_build / max(s1.n_ann_built, 1),
+                          ms_search=s2.ms_ann_search, ms_search_per_pair=s2.ms_ann_search / len(pairs),
+                          evals_per_query=s2.n_ann_dist / max(s2.n_queries, 1), matches=g.num_matches,
                           match_recall=hit / max(nb, 1), match_precision=hit / max(g.num_matches, 1),
                           speedup_vs_exhaustive=sb.ms_match_kernels / s2.ms_ann_search)), flush=True)
