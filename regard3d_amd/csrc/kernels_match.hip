@@ -1324,9 +1324,9 @@ hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t 
 {
     switch (G) {
         case 8:  return launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles);
-        case 16: return launch_l2_counts_t<8, 2, 4>(st, P, max_nj_tiles);
-        case 18: return launch_l2_counts_t<9, 2, 3>(st, P, max_nj_tiles);
-        case 32: return launch_l2_counts_t<16, 1, 4>(st, P, max_nj_tiles);
+        case 16: return launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles);
+        case 18: return launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles);
+        case 32: return launch_l2_counts_t<16, 1, 8>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }
 }
