@@ -1305,6 +1305,216 @@ void l2_knn2_counts_kernel(const MatchParams P)
     l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
 }
 
+#ifdef R3DM_DEVTOOLS
+// ------------------------------------------------------------------------------------------------
+// Count tiles, ONE list per query (round 4, third form; NJ = 2 only).  In the 32 x 32 accumulator layout lane (c, h) holds rows
+// 8 j + 4 h + i of query column c, so l2_knn2_counts_kernel keeps TWO lists per query (one per lane half) and per query tile -- 128
+// lists per wave, and the wave-wide test-and-skip takes its slow path whenever any of them can change: ~3.3 of the 8 quad tests of
+// a tile step (PMC: 238 VALU instructions per step where the fast path has 47).  v_permlane32_swap_b32 exchanges the upper lane half
+// of one register with the lower half of another (tools/ubench/permlane_probe.hip): swapping the accumulators of the two query tiles
+// register by register leaves lane c < 32 with ALL 32 rows of query (tile 0, c) and lane 32 + c with all rows of (tile 1, c) --
+// 64 lists per wave, each over all rows, so half as many list changes -- and makes every row quantity of a quad wave-uniform (scalar
+// operands from v_readlane instead of per-lane exchanges).  The keys, and so the results, are those of l2_knn2_counts_kernel.
+//
+// DEVELOPER BUILD ONLY (R3DM_COUNTS_ONE_LIST=1): measured and not adopted.  The kernel is 13 % faster (476 -> 415 ms per launch on
+// liop144c, stage match 74 -> 65 ms) with identical files -- but with one list per query the tail's second chance has two nominees
+// where the two half-lists gave it four, so it certifies fewer near-ties: 4 x the queries in the exact scan (stage: 2,665 -> 10,318 of
+// 7.8 M, +5.7 ms, most of the gain; the reference-built LIOP fixture: 2.3 % of its queries, which would cost far more than the kernel
+// saves).  Tracking a third nominee brings the list changes back up.  (hipcc 7.2 also folds repeated __builtin_amdgcn_permlane32_swap
+// calls into one -- wrong code -- hence the inline assembly with its own wait states below.)
+// ------------------------------------------------------------------------------------------------
+// v_permlane32_swap_b32: the upper lane half of `a` <-> the lower lane half of `b`   (a' = [a.lo | b.lo], b' = [a.hi | b.hi])
+// (s_nop 1 first: the instruction needs two wait states behind a VALU write of either operand -- the compiler inserts them for its
+//  own builtin and cannot for an asm statement)
+__device__ __forceinline__ void swap_lane_halves(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+template <int GB, int PF>
+__device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rr, uint32_t voffA, uint32_t voffR,
+                                                   uint32_t soffA, uint32_t soffR, f32x4 (&abuf)[PF], float& rowv_load, float rowv_prev,
+                                                   const f32x4 (&bq)[2][GB], float cql, f32x16 (&cur)[2], f32x16 (&prev)[2], Top2& st, uint32_t prev_rowbase)
+{
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int gq = __builtin_bit_cast(int, quad_min4(rowv_prev));      // lane 4 m: min of ||a||^2 over rows 4 m .. 4 m + 3; lane 32 + 4 m: min of the negated scales
+    const int rv = __builtin_bit_cast(int, rowv_prev);
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const f32x4 a = abuf[g % PF];
+        abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
+        if (g == (GB > 2 ? 2 : GB - 1))
+            rowv_load = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)voffR, (int)soffR, 0));
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+            cur[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bq[nj][g]),
+                                                             g == 0 ? zero : cur[nj], 0, 0, 0);
+        // eight quad tests per tile (slot = 2 qd + hp: rows 8 qd + 4 hp + k), spread over the GB blocks
+#pragma unroll
+        for (int gi = (g * 8) / GB; gi < ((g + 1) * 8) / GB; ++gi) {
+            const int qd = gi >> 1, hp = gi & 1;
+            if (hp == 0) {                                  // the quad's four registers of both query tiles: one list per lane from here on
+                // (inline assembly: hipcc 7.2 folds several __builtin_amdgcn_permlane32_swap calls into one -- tools/ubench/permlane_probe.hip;
+                //  the wait states an MFMA result needs before a VALU reads it are the compiler's to insert, and it cannot see into the asm)
+                if (gi == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float lo = prev[0][4 * qd + k], hi = prev[1][4 * qd + k];
+                    swap_lane_halves(lo, hi);
+                    prev[0][4 * qd + k] = lo;               // rows 8 qd + k      (lane half 0 of both tiles)
+                    prev[1][4 * qd + k] = hi;               // rows 8 qd + 4 + k  (lane half 1 of both tiles)
+                }
+            }
+            const float p0 = prev[hp][4 * qd], p1 = prev[hp][4 * qd + 1], p2 = prev[hp][4 * qd + 2], p3 = prev[hp][4 * qd + 3];
+            const float pmin = vmin2(vmin3(p0, p1, p2), p3);
+            const int r0 = 8 * qd + 4 * hp;
+            const float n2min = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gq, r0));
+            const float smax = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(gq, 32 + r0));
+            const float lb = __builtin_fmaf(n2min, cql, pmin * smax);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(lb < st.d2) != 0ull, 0)) {
+                const uint32_t rb = prev_rowbase + (uint32_t)r0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, r0 + k));
+                    const float sa = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, 32 + r0 + k));
+                    const float pk = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
+                    top2_push(st, __builtin_fmaf(n2, cql, pk * sa), rb + (uint32_t)k);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the keys of the last tile (nothing multiplies behind it): all 32 rows of the lane's query
+__device__ __forceinline__ void counts_last_tile_m(f32x16 (&acc)[2], float rowv, float cql, Top2& st, uint32_t rowbase)
+{
+    const int rvi = __builtin_bit_cast(int, rowv);
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float lo = acc[0][r], hi = acc[1][r];
+        swap_lane_halves(lo, hi);
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hp;
+            const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rvi, row));
+            const float sa = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(rvi, 32 + row));
+            top2_push(st, __builtin_fmaf(n2, cql, (hp ? hi : lo) * sa), rowbase + (uint32_t)row);
+        }
+    }
+}
+
+template <int GB, int PF>
+__global__ __launch_bounds__(256, 2)
+void l2_knn2_counts2_kernel(const MatchParams P)
+{
+    static_assert(GB % PF == 0, "prefetch window must divide the block count");
+    constexpr int NJ = 2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t h = lane >> 5, c = lane & 31u;
+    uint32_t pair, qb;
+    if (P.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        pair = (j / P.qb_per_pair) * 8u + xcd;
+        qb = j % P.qb_per_pair;
+        if (pair >= P.n_pairs) return;
+    } else {
+        pair = blockIdx.x / P.qb_per_pair;
+        qb = blockIdx.x % P.qb_per_pair;
+    }
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles, nJ = Jp->n;
+    const uint32_t qt0 = (qb * 4u + wave) * NJ;
+    if (qt0 >= ntJ) return;                                // wave-uniform; no barriers in this kernel
+
+    f32x4 bq[NJ][GB];
+    float cq[NJ], kinv[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
+        const gf4p src = (gf4p)(const void*)Jp->tiledc + (size_t)qt * (GB * 64) + lane;
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] ^= 0x80008000u;
+            bq[nj][g] = __builtin_bit_cast(f32x4, w);
+        }
+        const uint32_t q = qt * 32u + c;
+        const float sq = q < nJ ? Jp->cscale[q] : 1.0f;
+        kinv[nj] = 2.0f * sq;
+        cq[nj] = 1.0f / kinv[nj];
+    }
+    const float cql = h ? cq[1] : cq[0];                   // this lane's query after the swap: (tile h, column c)
+    Top2 st;
+    top2_init(st);
+
+    if (nI >= 2) {
+        const uint64_t pa = (uint64_t)Ip->tiledp;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const uint32_t voffA = lane * 16u;
+        constexpr uint32_t tileB = (uint32_t)GB * 1024u;
+        const uint64_t prw = (uint64_t)Ip->cquad;
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(prw >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)prw)),
+            0, 0x7FFFFFFF, 0x00020000);
+        const uint32_t voffR = lane * 4u;
+        f32x4 abuf[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) abuf[s] = bload16(ra, voffA, (uint32_t)s * 1024u);
+        float rvA = 0.0f, rvB = h ? -1.0f : R3DM_INF;      // "tile -1": ||a||^2 = +inf keeps it out of every list
+        f32x16 accA[NJ], accB[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[nj][r] = 0.0f;
+        uint32_t t = 0;
+        for (; t + 1 < ntI; t += 2) {
+            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, bq, cql, accA, accB, st, (t - 1) * 32u);
+            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, rvB, rvA, bq, cql, accB, accA, st, t * 32u);
+        }
+        // the last tile's keys (and one more multiply step when the tile count is odd)
+        if (t < ntI) {
+            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, bq, cql, accA, accB, st, (t - 1) * 32u);
+            counts_last_tile_m(accA, rvA, cql, st, t * 32u);
+        } else {
+            counts_last_tile_m(accB, rvB, cql, st, (ntI - 1) * 32u);
+        }
+    }
+    // the list names rows of the ordered image: back to keypoint order; then hand it to the shared tail in the layout it expects
+    // (a list per lane half and query tile): this lane's list for its own tile, an empty one for the other
+    {
+        const uint32_t* __restrict__ perm = Ip->cperm;
+        if (st.i0 != kNone) st.i0 = perm[st.i0];
+        if (st.i1 != kNone) st.i1 = perm[st.i1];
+    }
+    Top2 st2[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        top2_init(st2[nj]);
+        if ((uint32_t)nj == h) st2[nj] = st;
+    }
+    l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st2, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
+}
+
+template <int GB, int PF>
+static hipError_t launch_l2_counts2_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
+{
+    MatchParams P = Pin;
+    const uint32_t tiles_per_wg = 4u * 2u;
+    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
+    P.xcd_map = 1u;
+    const uint64_t grid64 = (uint64_t)((P.n_pairs + 7u) / 8u * 8u) * P.qb_per_pair;
+    if (grid64 == 0) return hipSuccess;
+    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((l2_knn2_counts2_kernel<GB, PF>), dim3((uint32_t)grid64), dim3(256), 0, st, P);
+    return hipGetLastError();
+}
+#endif  // R3DM_DEVTOOLS
+
 template <int GB, int NJ, int PF>
 static hipError_t launch_l2_counts_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
@@ -1320,12 +1530,19 @@ static hipError_t launch_l2_counts_t(hipStream_t st, const MatchParams& Pin, uin
 }
 
 // G = padded dim / 8 of the views (8, 16, 18, 32); hipErrorInvalidValue -> no count kernel, caller keeps the split tiles
-hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles)
+hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, int variant)
 {
+    (void)variant;
     switch (G) {
+#ifdef R3DM_DEVTOOLS
+        case 8:  return variant ? launch_l2_counts2_t<4, 4>(st, P, max_nj_tiles) : launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles);
+        case 16: return variant ? launch_l2_counts2_t<8, 8>(st, P, max_nj_tiles) : launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles);
+        case 18: return variant ? launch_l2_counts2_t<9, 9>(st, P, max_nj_tiles) : launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles);
+#else
         case 8:  return launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles);
         case 16: return launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles);
         case 18: return launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles);
+#endif
         case 32: return launch_l2_counts_t<16, 1, 8>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }
