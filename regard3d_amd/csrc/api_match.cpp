@@ -190,7 +190,7 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         R3DM_HIP(c, hipStreamSynchronize(c->stream));      // (the finaliser would wait here anyway; keeps the wall breakdown honest)
     } else if (has_tensor_kernel(first.G)) {
         if (counts) {
-            R3DM_HIP(c, launch_l2_knn2_counts(c->stream, mp, first.G, max_tiles, r3dm_dev_knob("R3DM_COUNTS_ONE_LIST", 0)));
+            R3DM_HIP(c, launch_l2_knn2_counts(c->stream, mp, first.G, max_tiles, r3dm_dev_knob("R3DM_COUNTS_TWO_LISTS", 0)));
             c->stats.n_split_mfma += 1; c->stats.n_counts_mfma += 1;
         } else if (split) {
             R3DM_HIP(c, launch_l2_knn2_split(c->stream, mp, first.G, max_tiles));

@@ -1305,7 +1305,6 @@ void l2_knn2_counts_kernel(const MatchParams P)
     l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
 }
 
-#ifdef R3DM_DEVTOOLS
 // ------------------------------------------------------------------------------------------------
 // Count tiles, ONE list per query (round 4, third form; NJ = 2 only).  In the 32 x 32 accumulator layout lane (c, h) holds rows
 // 8 j + 4 h + i of query column c, so l2_knn2_counts_kernel keeps TWO lists per query (one per lane half) and per query tile -- 128
@@ -1316,13 +1315,36 @@ void l2_knn2_counts_kernel(const MatchParams P)
 // 64 lists per wave, each over all rows, so half as many list changes -- and makes every row quantity of a quad wave-uniform (scalar
 // operands from v_readlane instead of per-lane exchanges).  The keys, and so the results, are those of l2_knn2_counts_kernel.
 //
-// DEVELOPER BUILD ONLY (R3DM_COUNTS_ONE_LIST=1): measured and not adopted.  The kernel is 13 % faster (476 -> 415 ms per launch on
-// liop144c, stage match 74 -> 65 ms) with identical files -- but with one list per query the tail's second chance has two nominees
-// where the two half-lists gave it four, so it certifies fewer near-ties: 4 x the queries in the exact scan (stage: 2,665 -> 10,318 of
-// 7.8 M, +5.7 ms, most of the gain; the reference-built LIOP fixture: 2.3 % of its queries, which would cost far more than the kernel
-// saves).  Tracking a third nominee brings the list changes back up.  (hipcc 7.2 also folds repeated __builtin_amdgcn_permlane32_swap
-// calls into one -- wrong code -- hence the inline assembly with its own wait states below.)
+// With one list per query the shared tail's second chance would have two nominees where the two half-lists gave it four (measured:
+// 4 x the queries in the exact scan).  So the list here also carries the THIRD-best row and a lower bound d3 of every key that is
+// none of the three (Top3m below): the tail re-scores three rows and certifies against d3 -- a handful of exact scans where the
+// two-list kernel needs hundreds (reference-built LIOP fixture: 6 of 8,192 queries against 45; 80 views x 8,192 rows: 22 of 25.9 M
+// against 850), and the kernel itself is 5 % faster (13 % without the third row's bookkeeping).  R3DM_COUNTS_TWO_LISTS=1 in the
+// developer build runs l2_knn2_counts_kernel instead (tools/counts_one_list_probe.py).  (hipcc 7.2 folds repeated
+// __builtin_amdgcn_permlane32_swap calls with different operands into one -- wrong code -- hence the inline assembly with its own
+// wait states below.)
 // ------------------------------------------------------------------------------------------------
+// the list of a query in this kernel: the two nominees and the third-best key (d2: the bound of the first certification, as in Top2)
+// PLUS the third-best row (i2) and a lower bound of every key that is none of the three (d3): the tail's second chance re-scores
+// three rows and certifies against d3.  d3 = min over (a) the keys pushed out of, or never into, the three -- exactly -- and (b) the
+// lower bounds of the quads that were skipped (>= d2 at the time, so >= every d2 since).
+struct Top3m { float d0, d1, d2, d3; uint32_t i0, i1, i2; };
+__device__ __forceinline__ void top3m_init(Top3m& s) { s.d0 = s.d1 = s.d2 = s.d3 = R3DM_INF; s.i0 = s.i1 = s.i2 = kNone; }
+__device__ __forceinline__ void top3m_push(Top3m& s, float key, uint32_t idx)
+{
+    const float od0 = s.d0, od1 = s.d1, od2 = s.d2, od3 = s.d3;
+    const uint32_t oi0 = s.i0, oi1 = s.i1, oi2 = s.i2;
+    const bool c0 = key < od0, c1 = key < od1, c2 = key < od2;
+    s.d3 = __builtin_amdgcn_fmed3f(od2, od3, key);         // min(d3, max(d2, key)): what falls out of the three (d2 <= d3 always)
+    s.d2 = __builtin_amdgcn_fmed3f(od1, od2, key);
+    s.d1 = __builtin_amdgcn_fmed3f(od0, od1, key);
+    s.d0 = __builtin_amdgcn_fmed3f(-R3DM_INF, od0, key);
+    const uint32_t t2 = c2 ? idx : oi2, t1 = c1 ? idx : oi1;
+    s.i2 = c1 ? oi1 : t2;
+    s.i1 = c0 ? oi0 : t1;
+    s.i0 = c0 ? idx : oi0;
+}
+
 // v_permlane32_swap_b32: the upper lane half of `a` <-> the lower lane half of `b`   (a' = [a.lo | b.lo], b' = [a.hi | b.hi])
 // (s_nop 1 first: the instruction needs two wait states behind a VALU write of either operand -- the compiler inserts them for its
 //  own builtin and cannot for an asm statement)
@@ -1331,7 +1353,7 @@ __device__ __forceinline__ void swap_lane_halves(float& a, float& b) { asm volat
 template <int GB, int PF>
 __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rr, uint32_t voffA, uint32_t voffR,
                                                    uint32_t soffA, uint32_t soffR, f32x4 (&abuf)[PF], float& rowv_load, float rowv_prev,
-                                                   const f32x4 (&bq)[2][GB], float cql, f32x16 (&cur)[2], f32x16 (&prev)[2], Top2& st, uint32_t prev_rowbase)
+                                                   const f32x4 (&bq)[2][GB], float cql, f32x16 (&cur)[2], f32x16 (&prev)[2], Top3m& st, uint32_t prev_rowbase)
 {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int gq = __builtin_bit_cast(int, quad_min4(rowv_prev));      // lane 4 m: min of ||a||^2 over rows 4 m .. 4 m + 3; lane 32 + 4 m: min of the negated scales
@@ -1368,23 +1390,26 @@ __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __
             const float n2min = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gq, r0));
             const float smax = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(gq, 32 + r0));
             const float lb = __builtin_fmaf(n2min, cql, pmin * smax);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(lb < st.d2) != 0ull, 0)) {
+            const bool mine = lb < st.d2;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine) != 0ull, 0)) {
                 const uint32_t rb = prev_rowbase + (uint32_t)r0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, r0 + k));
                     const float sa = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, 32 + r0 + k));
                     const float pk = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
-                    top2_push(st, __builtin_fmaf(n2, cql, pk * sa), rb + (uint32_t)k);
+                    top3m_push(st, __builtin_fmaf(n2, cql, pk * sa), rb + (uint32_t)k);
                 }
             }
+            // a lane whose own bound did not pass: its four keys are >= lb >= d2 (then and since), whether or not the wave pushed them
+            st.d3 = vmin2(st.d3, mine ? R3DM_INF : lb);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // the keys of the last tile (nothing multiplies behind it): all 32 rows of the lane's query
-__device__ __forceinline__ void counts_last_tile_m(f32x16 (&acc)[2], float rowv, float cql, Top2& st, uint32_t rowbase)
+__device__ __forceinline__ void counts_last_tile_m(f32x16 (&acc)[2], float rowv, float cql, Top3m& st, uint32_t rowbase)
 {
     const int rvi = __builtin_bit_cast(int, rowv);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
@@ -1397,7 +1422,7 @@ __device__ __forceinline__ void counts_last_tile_m(f32x16 (&acc)[2], float rowv,
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hp;
             const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rvi, row));
             const float sa = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(rvi, 32 + row));
-            top2_push(st, __builtin_fmaf(n2, cql, (hp ? hi : lo) * sa), rowbase + (uint32_t)row);
+            top3m_push(st, __builtin_fmaf(n2, cql, (hp ? hi : lo) * sa), rowbase + (uint32_t)row);
         }
     }
 }
@@ -1447,8 +1472,8 @@ void l2_knn2_counts2_kernel(const MatchParams P)
         cq[nj] = 1.0f / kinv[nj];
     }
     const float cql = h ? cq[1] : cq[0];                   // this lane's query after the swap: (tile h, column c)
-    Top2 st;
-    top2_init(st);
+    Top3m st;
+    top3m_init(st);
 
     if (nI >= 2) {
         const uint64_t pa = (uint64_t)Ip->tiledp;
@@ -1484,18 +1509,26 @@ void l2_knn2_counts2_kernel(const MatchParams P)
             counts_last_tile_m(accB, rvB, cql, st, (ntI - 1) * 32u);
         }
     }
-    // the list names rows of the ordered image: back to keypoint order; then hand it to the shared tail in the layout it expects
-    // (a list per lane half and query tile): this lane's list for its own tile, an empty one for the other
+    // the list names rows of the ordered image: back to keypoint order; then hand it to the shared tail in the layout it expects (a
+    // list per lane half and query tile).  This lane's half carries the two nominees with the bound d3; the other half's slot carries
+    // the third-best row as a one-row list with the same bound: the tail's merge then sees the third-best key as the smallest
+    // un-nominated one (first certification, as before), and its second chance re-scores the three rows against d3.
     {
         const uint32_t* __restrict__ perm = Ip->cperm;
         if (st.i0 != kNone) st.i0 = perm[st.i0];
         if (st.i1 != kNone) st.i1 = perm[st.i1];
+        if (st.i2 != kNone) st.i2 = perm[st.i2];
     }
     Top2 st2[NJ];
+    {
+        // the partner lane (c, 1 - h) holds the list of the OTHER query tile: fetch what it has for my tile's partner slot
+        const float pd2 = __shfl_xor(st.d2, 32), pd3 = __shfl_xor(st.d3, 32);
+        const uint32_t pi2 = __shfl_xor(st.i2, 32);
 #pragma unroll
-    for (int nj = 0; nj < NJ; ++nj) {
-        top2_init(st2[nj]);
-        if ((uint32_t)nj == h) st2[nj] = st;
+        for (int nj = 0; nj < NJ; ++nj) {
+            if ((uint32_t)nj == h) { st2[nj].d0 = st.d0; st2[nj].d1 = st.d1; st2[nj].d2 = st.i2 != kNone ? st.d3 : st.d2; st2[nj].i0 = st.i0; st2[nj].i1 = st.i1; }
+            else { st2[nj].d0 = pd2; st2[nj].d1 = R3DM_INF; st2[nj].d2 = pd3; st2[nj].i0 = pi2; st2[nj].i1 = kNone; if (pi2 == kNone) { st2[nj].d0 = R3DM_INF; st2[nj].d2 = pd2; } }
+        }
     }
     l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st2, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
 }
@@ -1513,8 +1546,6 @@ static hipError_t launch_l2_counts2_t(hipStream_t st, const MatchParams& Pin, ui
     hipLaunchKernelGGL((l2_knn2_counts2_kernel<GB, PF>), dim3((uint32_t)grid64), dim3(256), 0, st, P);
     return hipGetLastError();
 }
-#endif  // R3DM_DEVTOOLS
-
 template <int GB, int NJ, int PF>
 static hipError_t launch_l2_counts_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
@@ -1532,17 +1563,11 @@ static hipError_t launch_l2_counts_t(hipStream_t st, const MatchParams& Pin, uin
 // G = padded dim / 8 of the views (8, 16, 18, 32); hipErrorInvalidValue -> no count kernel, caller keeps the split tiles
 hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, int variant)
 {
-    (void)variant;
     switch (G) {
-#ifdef R3DM_DEVTOOLS
-        case 8:  return variant ? launch_l2_counts2_t<4, 4>(st, P, max_nj_tiles) : launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles);
-        case 16: return variant ? launch_l2_counts2_t<8, 8>(st, P, max_nj_tiles) : launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles);
-        case 18: return variant ? launch_l2_counts2_t<9, 9>(st, P, max_nj_tiles) : launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles);
-#else
-        case 8:  return launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles);
-        case 16: return launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles);
-        case 18: return launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles);
-#endif
+        // two query tiles per wave: one list per query (l2_knn2_counts2_kernel); variant != 0 (developer build): the two-list kernel
+        case 8:  return variant ? launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles) : launch_l2_counts2_t<4, 4>(st, P, max_nj_tiles);
+        case 16: return variant ? launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles) : launch_l2_counts2_t<8, 8>(st, P, max_nj_tiles);
+        case 18: return variant ? launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles) : launch_l2_counts2_t<9, 9>(st, P, max_nj_tiles);
         case 32: return launch_l2_counts_t<16, 1, 8>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }
