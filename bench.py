@@ -694,7 +694,7 @@ def opt_in_split(ctx, step, fence, g, gf, job_pairs):
         ctx.set_split_mfma(False)
     same = all(np.array_equal(getattr(x, f), getattr(y, f)) for x, y in ((g, g2), (gf, gf2)) for f in ("pairs", "offsets", "matches"))
     # matrix work: the split kernel runs 3 f16 MFMAs per 16 dims (3 x the algorithmic 2 n^2 D flops); on COUNT tiles (rows = integer votes
-    # x a row scale: what LIOP is) the nominator runs ONE (l2_knn2_counts_kernel: executed = algorithmic)
+    # x a row scale: what LIOP is) the nominator runs ONE (l2_knn2_counts2_kernel: executed = algorithmic)
     counts = int(getattr(sm2, "n_counts_mfma", 0)) > 0
     mult = 1.0 if counts else 3.0
     ach = mult * sm2.algorithmic_flops / (sm2.ms_match_kernels * 1e-3) / 1e12 if sm2.ms_match_kernels > 0 else 0.0
@@ -703,7 +703,7 @@ def opt_in_split(ctx, step, fence, g, gf, job_pairs):
             "dtype": ("f16 integer votes nominate (1 MFMA per 16 dims, f32 accumulate), row scales in the epilogue" if counts else
                       "f16 hi/lo pieces nominate (3 MFMAs per 16 dims, f32 accumulate)") + "; distances re-scored in f32 as in the headline",
             "exact_fallback_fraction": sm2.n_exact_fallback / max(sm2.n_queries, 1),
-            "roofline": {"bound": "mfma", "kernel": "l2_knn2_counts_kernel<GB=9,NJ=2>" if counts else "l2_knn2_split_kernel<GB=9,NJ=2>", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "l2_knn2_counts2_kernel<GB=9,PF=9>" if counts else "l2_knn2_split_kernel<GB=9,NJ=2>", "achieved": ach,
                          "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s (executed f16 matrix flops = %d x algorithmic)" % int(mult), "frac": ach / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                          "algorithmic_tflops": ach / mult, "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1),

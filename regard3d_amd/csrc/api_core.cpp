@@ -174,7 +174,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
         R3DM_HIP(c, hipMemsetAsync(h.tiledc.p, 0, tiledc_bytes, c->stream));
         R3DM_HIP(c, h.cscale.ensure((size_t)h.n_tiles * 32 * 4 + kSlackBytes));
         R3DM_HIP(c, hipMemsetAsync(h.cscale.p, 0, (size_t)h.n_tiles * 32 * 4 + kSlackBytes, c->stream));
-        R3DM_HIP(c, h.cquad.ensure((size_t)h.n_tiles * 256 + kSlackBytes));
+        R3DM_HIP(c, h.cquad.ensure((counts_summary_offset(h.n_tiles) + ((size_t)h.n_tiles + 1) * 16) * 4 + kSlackBytes));
         R3DM_HIP(c, h.tiledp.ensure(tiledc_bytes));
         R3DM_HIP(c, h.cperm.ensure((size_t)h.n_tiles * 32 * 4 + 256));
         R3DM_HIP(c, h.norms.ensure(norm_bytes));

@@ -1089,11 +1089,13 @@ void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uin
     for (uint32_t r = n + tid; r < n_pad; r += 1024u) cperm[r] = kNone;
 }
 
+// (the quad summaries of the ordered tiles live behind the row lines in the same allocation: r3dm_internal.hpp counts_summary_offset)
 // one workgroup per tile of the ORDERED image: gather the rows cperm names from the keypoint-order count tiles, write their fragments
 // and the tile's 256-byte row line (||a||^2 of the 32 rows, then their negated scales)
 __global__ __launch_bounds__(256)
 void stage_counts_gather_kernel(const uint16_t* __restrict__ tiledc, const float* __restrict__ cscale, const float* __restrict__ norms,
-                                const uint32_t* __restrict__ cperm, uint32_t GB, uint16_t* __restrict__ tiledp, float* __restrict__ crow)
+                                const uint32_t* __restrict__ cperm, uint32_t GB, uint16_t* __restrict__ tiledp, float* __restrict__ crow,
+                                float* __restrict__ csum)
 {
     const uint32_t t = blockIdx.x;
     __shared__ uint32_t src[32];
@@ -1109,6 +1111,18 @@ void stage_counts_gather_kernel(const uint16_t* __restrict__ tiledc, const float
         const uint32_t sr = src[threadIdx.x & 31u];
         crow[(size_t)t * 64u + threadIdx.x] = threadIdx.x < 32u ? (sr == kNone ? R3DM_INF : norms[sr]) : -(sr == kNone ? 1.0f : cscale[sr]);
     }
+    // the sixteen numbers l2_knn2_counts2_kernel tests a tile's keys with: min ||a||^2 ([m]) and max scale ([8 + m]) of rows 4 m .. 4 m + 3
+    if (threadIdx.x < 16u && csum) {
+        const uint32_t m = threadIdx.x & 7u;
+        float v = threadIdx.x < 8u ? R3DM_INF : 0.0f;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t sr = src[4u * m + k];
+            if (threadIdx.x < 8u) v = fminf(v, sr == kNone ? R3DM_INF : norms[sr]);
+            else v = fmaxf(v, sr == kNone ? 1.0f : cscale[sr]);
+        }
+        csum[(size_t)t * 16u + threadIdx.x] = v;
+        if (t == 0) csum[(size_t)gridDim.x * 16u + threadIdx.x] = threadIdx.x < 8u ? R3DM_INF : 1.0f;      // the line of "the tile before the first"
+    }
 }
 
 hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
@@ -1118,7 +1132,8 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
     if (n_tiles == 0 || dim > 256u) return hipSuccess;
     hipLaunchKernelGGL(stage_counts_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, GB, tiledc, cscale, fail_dev);
     hipLaunchKernelGGL(stage_counts_order_kernel, dim3(1), dim3(1024), 0, st, cscale, n, n_tiles * 32u, cperm);
-    hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow);
+    hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow,
+                       crow + counts_summary_offset(n_tiles));
     return hipGetLastError();
 }
 
@@ -1345,6 +1360,8 @@ __device__ __forceinline__ void top3m_push(Top3m& s, float key, uint32_t idx)
     s.i0 = c0 ? idx : oi0;
 }
 
+typedef const __attribute__((address_space(4))) float* cf32p;         // constant address space -> SMEM loads (a tile's sixteen quad summaries)
+
 // v_permlane32_swap_b32: the upper lane half of `a` <-> the lower lane half of `b`   (a' = [a.lo | b.lo], b' = [a.hi | b.hi])
 // (s_nop 1 first: the instruction needs two wait states behind a VALU write of either operand -- the compiler inserts them for its
 //  own builtin and cannot for an asm statement)
@@ -1352,12 +1369,14 @@ __device__ __forceinline__ void swap_lane_halves(float& a, float& b) { asm volat
 
 template <int GB, int PF>
 __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rr, uint32_t voffA, uint32_t voffR,
-                                                   uint32_t soffA, uint32_t soffR, f32x4 (&abuf)[PF], float& rowv_load, float rowv_prev,
+                                                   uint32_t soffA, uint32_t soffR, f32x4 (&abuf)[PF], float& rowv_load, float rowv_prev, cf32p sum_prev,
                                                    const f32x4 (&bq)[2][GB], float cql, f32x16 (&cur)[2], f32x16 (&prev)[2], Top3m& st, uint32_t prev_rowbase)
 {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int gq = __builtin_bit_cast(int, quad_min4(rowv_prev));      // lane 4 m: min of ||a||^2 over rows 4 m .. 4 m + 3; lane 32 + 4 m: min of the negated scales
     const int rv = __builtin_bit_cast(int, rowv_prev);
+    float sm[16];                                          // one s_load_dwordx16 at the top of the step: in flight behind the first MFMAs
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sm[k] = sum_prev[k];
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
         const f32x4 a = abuf[g % PF];
@@ -1387,8 +1406,7 @@ __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __
             const float p0 = prev[hp][4 * qd], p1 = prev[hp][4 * qd + 1], p2 = prev[hp][4 * qd + 2], p3 = prev[hp][4 * qd + 3];
             const float pmin = vmin2(vmin3(p0, p1, p2), p3);
             const int r0 = 8 * qd + 4 * hp;
-            const float n2min = __builtin_bit_cast(float, __builtin_amdgcn_readlane(gq, r0));
-            const float smax = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(gq, 32 + r0));
+            const float n2min = sm[2 * qd + hp], smax = sm[8 + 2 * qd + hp];      // scalars (SMEM): rows r0 .. r0 + 3
             const float lb = __builtin_fmaf(n2min, cql, pmin * smax);
             const bool mine = lb < st.d2;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine) != 0ull, 0)) {
@@ -1487,6 +1505,8 @@ void l2_knn2_counts2_kernel(const MatchParams P)
             (void*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(prw >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)prw)),
             0, 0x7FFFFFFF, 0x00020000);
         const uint32_t voffR = lane * 4u;
+        // the quad summaries of tile t: sixteen floats behind the row lines; "tile -1" reads the line one past the last tile (+inf, 1)
+        const cf32p sums = (cf32p)(uintptr_t)(Ip->cquad + counts_summary_offset(ntI));
         f32x4 abuf[PF];
 #pragma unroll
         for (int s = 0; s < PF; ++s) abuf[s] = bload16(ra, voffA, (uint32_t)s * 1024u);
@@ -1498,12 +1518,12 @@ void l2_knn2_counts2_kernel(const MatchParams P)
             for (int r = 0; r < 16; ++r) accB[nj][r] = 0.0f;
         uint32_t t = 0;
         for (; t + 1 < ntI; t += 2) {
-            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, bq, cql, accA, accB, st, (t - 1) * 32u);
-            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, rvB, rvA, bq, cql, accB, accA, st, t * 32u);
+            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, sums + (size_t)(t == 0 ? ntI : t - 1) * 16u, bq, cql, accA, accB, st, (t - 1) * 32u);
+            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, rvB, rvA, sums + (size_t)t * 16u, bq, cql, accB, accA, st, t * 32u);
         }
         // the last tile's keys (and one more multiply step when the tile count is odd)
         if (t < ntI) {
-            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, bq, cql, accA, accB, st, (t - 1) * 32u);
+            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, sums + (size_t)(t == 0 ? ntI : t - 1) * 16u, bq, cql, accA, accB, st, (t - 1) * 32u);
             counts_last_tile_m(accA, rvA, cql, st, t * 32u);
         } else {
             counts_last_tile_m(accB, rvB, cql, st, (ntI - 1) * 32u);

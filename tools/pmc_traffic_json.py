@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from regard3d_amd.codeobj import kernel_hash, mangled_needle
 LIB = os.path.join(ROOT, "regard3d_amd", "libr3dm.so")
-KERNELS = "l2_knn2_mfma_kernel|l2_knn2_int_kernel|l2_knn2_int_lds_kernel|l2_knn2_split_kernel|l2_knn2_counts_kernel|hamming_knn2_kernel|hamming_knn2_mfma_kernel"
+KERNELS = "l2_knn2_mfma_kernel|l2_knn2_int_kernel|l2_knn2_int_lds_kernel|l2_knn2_split_kernel|l2_knn2_counts2_kernel|l2_knn2_counts_kernel|hamming_knn2_kernel|hamming_knn2_mfma_kernel"
 config = sys.argv[2] if len(sys.argv) > 2 else "c2"
 txt = open(sys.argv[1]).read()
 vals = {}
