@@ -554,26 +554,41 @@ static int liop_prepare(r3dm_ctx* c)
             if (x == 0 && y == 0) continue;
             if (dx * dx + dy * dy <= t2) pix.push_back(x + y * side);
         }
-    std::vector<double> sx(4 * pix.size()), sy(4 * pix.size());
+    if (pix.size() > 1024) { c->err = "liop: support larger than the sort capacity"; return R3DM_ERR_UNSUPPORTED; }
+    // per support pixel: the four sample positions as (offset of the top-left tap, fractional parts).  The kernel keeps the patch with
+    // a ring of zeros (43 x 43), so vl_liop's guarded taps (:516-535: `if (ix >= 0 && iy >= 0) a = ...`) are plain reads; floor and
+    // fraction are the reference's own double operations, done once here instead of once per sample and keypoint
+    std::vector<double> sw(8 * pix.size());
+    std::vector<int> so(4 * pix.size()), pixr(pix.size());
     const double dangle = 2 * M_PI / 4.0;
     for (size_t i = 0; i < pix.size(); ++i) {
         const double x = (pix[i] % side) - center, y = (pix[i] / side) - center;
         const double angle0 = std::atan2(y, x);
+        pixr[i] = (pix[i] % side + 1) + (pix[i] / side + 1) * 43;
         for (int k = 0; k < 4; ++k) {
-            sx[4 * i + k] = x + radius * std::cos(angle0 + dangle * k) + center;
-            sy[4 * i + k] = y + radius * std::sin(angle0 + dangle * k) + center;
+            const double sx = x + radius * std::cos(angle0 + dangle * k) + center;
+            const double sy = y + radius * std::sin(angle0 + dangle * k) + center;
+            const long xi = (long)sx, yi = (long)sy;
+            const long ix = (sx >= 0 || (double)xi == sx) ? xi : xi - 1;          // vl_floor_d
+            const long iy = (sy >= 0 || (double)yi == sy) ? yi : yi - 1;
+            if (ix < -1 || ix > side - 1 || iy < -1 || iy > side - 1) { c->err = "liop: a sample leaves the ringed patch"; return R3DM_ERR_UNSUPPORTED; }
+            sw[8 * i + 2 * k] = sx - ix; sw[8 * i + 2 * k + 1] = sy - iy;
+            so[4 * i + k] = (int)((ix + 1) + (iy + 1) * 43);
         }
     }
-    if (pix.size() > 1024) { c->err = "liop: support larger than the sort capacity"; return R3DM_ERR_UNSUPPORTED; }
-    R3DM_HIP(c, c->liop_pix.ensure(pix.size() * 4));
-    R3DM_HIP(c, c->liop_sx.ensure(sx.size() * 8));
-    R3DM_HIP(c, c->liop_sy.ensure(sy.size() * 8));
-    R3DM_HIP(c, hipMemcpyAsync(c->liop_pix.p, pix.data(), pix.size() * 4, hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(c->liop_sx.p, sx.data(), sx.size() * 8, hipMemcpyHostToDevice, c->stream));
-    R3DM_HIP(c, hipMemcpyAsync(c->liop_sy.p, sy.data(), sy.size() * 8, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, c->liop_pix.ensure(pixr.size() * 4));
+    R3DM_HIP(c, c->liop_sx.ensure(sw.size() * 8));
+    R3DM_HIP(c, c->liop_sy.ensure(so.size() * 4));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_pix.p, pixr.data(), pixr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_sx.p, sw.data(), sw.size() * 8, hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipMemcpyAsync(c->liop_sy.p, so.data(), so.size() * 4, hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
     c->liop_npix = (uint32_t)pix.size();
     return R3DM_OK;
+}
+static inline LiopTables liop_tables(const r3dm_ctx* c)
+{
+    return LiopTables{c->liop_pix.as<int>(), c->liop_sx.as<double>(), c->liop_sy.as<int>(), c->liop_npix};
 }
 
 static int r3dm_liop_describe_patches_impl(r3dm_ctx* c, const float* patches, uint32_t n, uint32_t side, float* desc_out,
@@ -593,8 +608,7 @@ static int r3dm_liop_describe_patches_impl(r3dm_ctx* c, const float* patches, ui
     R3DM_HIP(c, hipMemcpyAsync(c->liop_in.p, patches, in_bytes, hipMemcpyDefault, c->stream));
     R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
-    R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
-                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
+    R3DM_HIP(c, launch_liop(c->stream, liop_tables(c), c->liop_in.as<float>(), n, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
     R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
     R3DM_HIP(c, hipMemcpyAsync(desc_out, c->liop_out.p, out_bytes, hipMemcpyDefault, c->stream));
     uint32_t nt = 0;
@@ -658,7 +672,9 @@ static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t widt
     if (!resident_image) R3DM_HIP(c, c->liop_img.ensure(img_bytes));
     R3DM_HIP(c, c->liop_M.ensure(M6.size() * 4));
     R3DM_HIP(c, c->liop_kern.ensure(64));
-    R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
+    static const int fused_knob = r3dm_dev_knob("R3DM_LIOP_FUSED", 1);
+    const bool via_patches = patches_out || !fused_knob;
+    if (via_patches) R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
     R3DM_HIP(c, c->liop_out.ensure(out_bytes));
     R3DM_HIP(c, c->liop_cnt.ensure(64 + (size_t)n * 4));
     if (!resident_image) R3DM_HIP(c, hipMemcpyAsync(c->liop_img.p, image, img_bytes, hipMemcpyDefault, c->stream));
@@ -667,10 +683,16 @@ static int r3dm_extract_liop_impl(r3dm_ctx* c, const float* image, uint32_t widt
     R3DM_HIP(c, hipMemcpyAsync(c->liop_kern.p, kern, sizeof(kern), hipMemcpyHostToDevice, c->stream));
     R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
-    R3DM_HIP(c, launch_liop_extract(c->stream, dev_image, (int)width, (int)height, c->liop_M.as<float>(),
-                                    c->liop_kern.as<float>(), n, c->liop_in.as<float>()));
-    R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
-                            c->liop_sy.as<double>(), n, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
+    // the patches only exist in HBM when the caller asks for them (or the developer build's R3DM_LIOP_FUSED=0): otherwise the warp + blur
+    // runs inside the descriptor kernel's wavefront
+    if (via_patches) {
+        R3DM_HIP(c, launch_liop_extract(c->stream, dev_image, (int)width, (int)height, c->liop_M.as<float>(),
+                                        c->liop_kern.as<float>(), n, c->liop_in.as<float>()));
+        R3DM_HIP(c, launch_liop(c->stream, liop_tables(c), c->liop_in.as<float>(), n, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
+    } else {
+        R3DM_HIP(c, launch_liop_fused(c->stream, liop_tables(c), dev_image, (int)width, (int)height, c->liop_M.as<float>(), c->liop_kern.as<float>(), nullptr,
+                                      n, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
+    }
     R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
     R3DM_HIP(c, hipMemcpyAsync(desc_out, c->liop_out.p, out_bytes, hipMemcpyDefault, c->stream));
     if (patches_out) R3DM_HIP(c, hipMemcpyAsync(patches_out, c->liop_in.p, patch_bytes, hipMemcpyDefault, c->stream));
@@ -810,7 +832,6 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         const size_t patch_bytes = n_total * 41 * 41 * 4, out_bytes = n_total * 144 * 4;
         R3DM_HIP(c, c->liop_M.ensure(M6.size() * 4 + img_of.size() * 4));
         R3DM_HIP(c, c->liop_kern.ensure(64));
-        R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
         R3DM_HIP(c, c->liop_out.ensure(out_bytes));
         R3DM_HIP(c, c->liop_cnt.ensure(64 + n_total * 4));
         R3DM_HIP(c, c->pin_desc.ensure(out_bytes));
@@ -821,10 +842,16 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         R3DM_HIP(c, hipMemsetAsync(c->liop_cnt.p, 0, 64, c->stream));
         R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
         // the detector has left the B gray images in its image buffer (ak_bufs[0], B planes, read-only for it)
-        R3DM_HIP(c, launch_liop_extract(c->stream, c->ak_bufs[0].as<float>(), (int)width, (int)height, c->liop_M.as<float>(),
-                                        c->liop_kern.as<float>(), (uint32_t)n_total, c->liop_in.as<float>(), d_img_of));
-        R3DM_HIP(c, launch_liop(c->stream, c->liop_in.as<float>(), c->liop_pix.as<int>(), c->liop_sx.as<double>(),
-                                c->liop_sy.as<double>(), (uint32_t)n_total, c->liop_npix, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
+        static const int fused_knob = r3dm_dev_knob("R3DM_LIOP_FUSED", 1);     // developer build: 0 = patches through HBM (two kernels)
+        if (!fused_knob) {
+            R3DM_HIP(c, c->liop_in.ensure(patch_bytes));
+            R3DM_HIP(c, launch_liop_extract(c->stream, c->ak_bufs[0].as<float>(), (int)width, (int)height, c->liop_M.as<float>(),
+                                            c->liop_kern.as<float>(), (uint32_t)n_total, c->liop_in.as<float>(), d_img_of));
+            R3DM_HIP(c, launch_liop(c->stream, liop_tables(c), c->liop_in.as<float>(), (uint32_t)n_total, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
+        } else {
+            R3DM_HIP(c, launch_liop_fused(c->stream, liop_tables(c), c->ak_bufs[0].as<float>(), (int)width, (int)height, c->liop_M.as<float>(), c->liop_kern.as<float>(),
+                                          d_img_of, (uint32_t)n_total, c->liop_out.as<float>(), c->liop_cnt.as<uint32_t>(), c->liop_cnt.as<uint32_t>() + 16));
+        }
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         R3DM_HIP(c, hipMemcpyAsync(c->pin_desc.p, c->liop_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));

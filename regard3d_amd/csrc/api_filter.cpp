@@ -49,6 +49,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
                           const r3dm_match* dev_matches = nullptr /* the putative matches already uploaded by another kind of the call */)
 {
     fp_out = FilterParams{};
+    fp_out.model_kind = model_kind;                       // (also on the early returns: coop_launch_shared files the parameter blocks by kind)
     plan = CoopPlan{};
     if (!c || !putative || !out || max_iter == 0) return R3DM_ERR_INVALID;
     FilterBufs& B = c->fb[model_kind];
@@ -133,7 +134,21 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
             coop_slots += G;
         }
     }
-    const uint32_t n_coop = (uint32_t)coop_items.size();
+    uint32_t n_coop = (uint32_t)coop_items.size();
+    // slice offsets of the per-item work arrays: multiples of 32 elements, room for m + 1 (kernels_filter.hip explains why)
+    std::vector<uint64_t> soff(NI + 1, 0);
+    for (uint32_t k = 0; k < NI; ++k) soff[k + 1] = soff[k] + ((begin_end[2 * k + 1] - begin_end[2 * k] + 1 + 31) / 32) * 32;
+    const uint64_t n_slice = soff[NI];
+    // the cooperative kernel addresses the points and the slice histograms through 32-bit buffer offsets: a call beyond them (about 67 M
+    // putatives) runs every pair on the one-workgroup kernel, as every call did before the cooperative kernel existed
+    if (n_coop && (32 * (uint64_t)n_slice >= 0x7FFFFFFFull || 4 * (uint64_t)coop_slots * kCoopB * 512 + 256 >= 0x7FFFFFFFull)) {
+        for (uint32_t k = 0; k < NI; ++k) {
+            is_coop[k] = 0;
+            max_m_short = std::max<uint32_t>(max_m_short, (uint32_t)(begin_end[2 * k + 1] - begin_end[2 * k]));
+        }
+        coop_items.clear(); coop_G.clear(); coop_slice.clear(); coop_hoff.clear();
+        coop_slots = 0; n_coop = 0;
+    }
     if (model_kind == 0 && err_kind != R3DM_ERR_SYMMETRIC_EPIPOLAR) { o.err = "filter: only the symmetric epipolar error is implemented"; return R3DM_ERR_UNSUPPORTED; }
     // host tables in the reference's own float arithmetic (glibc log10f), see kernels_filter.hip
     std::vector<float> l10(max_m + 2), lck(max_m + 2);
@@ -152,10 +167,6 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     FHIP(B.f_offs.ensure(sizeof(uint64_t) * 2 * NI));
     if (!dev_matches) FHIP(B.f_matches.ensure(sizeof(r3dm_match) * std::max<uint64_t>(n_match_total, 1)));
     FHIP(B.f_inl_cnt.ensure(4 * (size_t)NI));
-    // slice offsets of the per-item work arrays: multiples of 32 elements, room for m + 1 (kernels_filter.hip explains why)
-    std::vector<uint64_t> soff(NI + 1, 0);
-    for (uint32_t k = 0; k < NI; ++k) soff[k + 1] = soff[k] + ((begin_end[2 * k + 1] - begin_end[2 * k] + 1 + 31) / 32) * 32;
-    const uint64_t n_slice = soff[NI];
     FHIP(B.f_inl_idx.ensure(4 * (size_t)n_slice + 64));
     FHIP(B.f_soff.ensure(8 * (size_t)(NI + 1)));
     FHIP(hipMemcpyAsync(B.f_soff.p, soff.data(), 8 * (size_t)(NI + 1), hipMemcpyHostToDevice, c->stream));
@@ -254,7 +265,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         const size_t o_la = o_cnt + cnt_bytes, la_bytes = up(8 * (size_t)n_coop * 1024);
         const size_t o_ts = o_la + la_bytes, ts_bytes = up(8 * (size_t)n_slice + 64);
         const size_t o_hist = o_ts + ts_bytes, hist_bytes = up(4 * (size_t)coop_slots * kCoopB * 512);
-        // (the kernel addresses the points and the slice histograms through 32-bit buffer offsets)
+        // (the kernel addresses the points and the slice histograms through 32-bit buffer offsets: checked above, kept as a guard)
         if (32 * (uint64_t)n_slice >= 0x7FFFFFFFull || hist_bytes >= 0x7FFFFFFFull) { o.err = "filter: putative graph too large for the cooperative kernel's buffer offsets"; return R3DM_ERR_UNSUPPORTED; }
         FHIP(B.f_coop.ensure(o_hist + hist_bytes));
         unsigned char* base = B.f_coop.as<unsigned char>();
@@ -497,6 +508,9 @@ static int coop_launch_shared(r3dm_ctx* c, FilterCallOut& o, FilterParams* fps, 
     unsigned char* base = c->coop_sched.as<unsigned char>();
     FilterParams* hp = reinterpret_cast<FilterParams*>(stage.data() + params_off);
     for (int k = 0; k < n; ++k) {
+        // a kind without long pairs (none of its pairs is long, or it has no work items at all: E on views without intrinsics) leaves
+        // its block zeroed -- the start order never names it -- and must not overwrite another kind's block
+        if (!fps[k].n_coop) continue;
         fps[k].coop_q = reinterpret_cast<uint32_t*>(base);
         fps[k].coop_workers = workers;
         hp[fps[k].model_kind] = fps[k];

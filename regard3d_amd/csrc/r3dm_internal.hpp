@@ -406,7 +406,16 @@ hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, s
 // img_of (optional): image of the batch each keypoint belongs to -- its pixels start img_of[k] * w * h floats into `image`
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
                                uint32_t n, float* patches, const uint32_t* img_of = nullptr);
-hipError_t launch_liop(hipStream_t st, const float* patches, const int* pix, const double* sx, const double* sy,
-                       uint32_t n, uint32_t n_pix, float* desc, uint32_t* n_tie_patches, uint32_t* tie_list);
+// geometry tables of the 41 x 41 LIOP patch (api_features.cpp: liop_prepare), all in device memory
+struct LiopTables {
+    const int* pix;            // [n_pix] support pixels in scan order, as offsets into the zero-ringed 43 x 43 patch
+    const double* samp_w;      // [n_pix][4][2] fractional parts (wx, wy) of the four sample positions
+    const int* samp_off;       // [n_pix][4] ringed-patch offset of every sample's top-left tap
+    uint32_t n_pix;
+};
+hipError_t launch_liop(hipStream_t st, const LiopTables& T, const float* patches, uint32_t n, float* desc, uint32_t* n_tie_patches, uint32_t* tie_list);
+// keypoints -> descriptors without the patches ever reaching HBM (the warp + blur runs inside the descriptor's wavefront)
+hipError_t launch_liop_fused(hipStream_t st, const LiopTables& T, const float* image, int w, int h, const float* M6, const float* kern,
+                             const uint32_t* img_of, uint32_t n, float* desc, uint32_t* n_tie_patches, uint32_t* tie_list);
 
 }  // namespace r3dm
