@@ -21,6 +21,7 @@
 // HBM traffic: 6.7 KB patch in, 576 B out per keypoint -> bound by LDS latency / sort, not HBM.
 
 #include "r3dm_internal.hpp"
+#include <type_traits>
 
 namespace r3dm {
 
@@ -35,44 +36,16 @@ __device__ __forceinline__ uint32_t float_order_bits(float v)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// exact emulation of the reference's quick sort (lane 0 only) over arr[0..n) = (intensity bits, scan position), ordered by
-// intensity.  One LDS array of pairs instead of perm[] + val[perm[]] (no dependent second load), and the Lomuto pass reads four
-// positions ahead: a swap writes positions `low` <= i and i only, never one that is still to be read, so the look-ahead is exact.
-__device__ void liop_ref_qsort(uint2* __restrict__ arr, int n, uint16_t* __restrict__ stack)
-{
-    int sp = 0;
-    stack[sp++] = 0; stack[sp++] = (uint16_t)(n - 1);
-    while (sp > 0) {
-        const int end = stack[--sp], begin = stack[--sp];
-        const int pivot = (end + begin) / 2;
-        uint2 t = arr[pivot]; arr[pivot] = arr[end]; arr[end] = t;
-        const float pv = __uint_as_float(arr[end].x);
-        int low = begin;
-        for (int i = begin; i < end; i += 4) {
-            uint2 e[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = arr[i + j];                     // (arr carries 4 entries of slack)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (i + j < end && __uint_as_float(e[j].x) - pv <= 0.0f) {
-                    if (low != i + j) { const uint2 o = arr[low]; arr[i + j] = o; arr[low] = e[j]; }
-                    ++low;
-                }
-            }
-        }
-        t = arr[low]; arr[low] = arr[end]; arr[end] = t;
-        // the reference recurses into the low part first, then the high part: push high first (LIFO)
-        if (low < end) { stack[sp++] = (uint16_t)(low + 1); stack[sp++] = (uint16_t)end; }
-        if (low > begin) { stack[sp++] = (uint16_t)begin; stack[sp++] = (uint16_t)(low - 1); }
-    }
-}
-
-// The same quick sort run by the whole wave, level by level: the partitions of disjoint ranges commute, so the segments of one
-// recursion depth are partitioned side by side, a lane each (exactly the reference's Lomuto pass per segment), and their children
-// form the next depth's list.  Same final arrangement as the depth-first original; the serial work drops from ~n log n element steps
-// to the longest segment of every depth (~2 n): the tie pass of a batch of 226 k keypoints took 5.9 ms with one lane per patch.
+// The reference's quick sort (vl_liop.c:84-120: middle pivot, Lomuto pass, "value - pivot <= 0", low part first) decides the order of
+// EQUAL intensities, and with it ordinal bins.  It is run by the whole wave, one recursion depth at a time: the partitions of disjoint
+// ranges commute, so the segments of a depth are partitioned side by side, a lane each (exactly the reference's pass per segment), and
+// their children form the next depth's list.  Same final arrangement as the depth-first original; the serial work drops from
+// ~n log n element steps to the longest segment of every depth (~2 n).
+// arr[i] = (class << 16) | scan position, class = rank of the pixel's intensity among the DISTINCT intensities of the patch (the sort
+// only ever asks "value <= pivot value", which the classes answer exactly; 4 bytes per entry instead of 8).  arr carries 4 entries of
+// slack: the Lomuto pass reads four positions ahead -- a swap writes positions `low` <= i and i only, never one still to be read.
 // seg: two lists of (begin, end) pairs, 340 pairs each (a depth has at most n / 2 segments of two or more elements); cnt[2]: their lengths.
-__device__ void liop_ref_qsort_wave(uint2* __restrict__ arr, int n, uint16_t* __restrict__ seg, uint32_t* __restrict__ cnt, uint32_t lane)
+__device__ void liop_ref_qsort_wave(uint32_t* __restrict__ arr, int n, uint16_t* __restrict__ seg, uint32_t* __restrict__ cnt, uint32_t lane)
 {
     constexpr int kListPairs = (kLiopMaxPix + 4) / 2;
     if (lane == 0) { seg[0] = 0; seg[1] = (uint16_t)(n - 1); cnt[0] = n >= 2 ? 1u : 0u; cnt[1] = 0u; }
@@ -85,17 +58,17 @@ __device__ void liop_ref_qsort_wave(uint2* __restrict__ arr, int n, uint16_t* __
         for (uint32_t sg = lane; sg < nseg; sg += 64u) {
             const int begin = cur[2 * sg], end = cur[2 * sg + 1];
             const int pivot = (end + begin) / 2;
-            uint2 t = arr[pivot]; arr[pivot] = arr[end]; arr[end] = t;
-            const float pv = __uint_as_float(arr[end].x);
+            uint32_t t = arr[pivot]; arr[pivot] = arr[end]; arr[end] = t;
+            const uint32_t pv = arr[end] >> 16;
             int low = begin;
             for (int i = begin; i < end; i += 4) {
-                uint2 e[4];
+                uint32_t e[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = arr[i + j];                 // (arr carries 4 entries of slack; positions >= end are not used)
+                for (int j = 0; j < 4; ++j) e[j] = arr[i + j];                 // (positions >= end are not used)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (i + j < end && __uint_as_float(e[j].x) - pv <= 0.0f) {
-                        if (low != i + j) { const uint2 o = arr[low]; arr[i + j] = o; arr[low] = e[j]; }
+                    if (i + j < end && (e[j] >> 16) <= pv) {
+                        if (low != i + j) { const uint32_t o = arr[low]; arr[i + j] = o; arr[low] = e[j]; }
                         ++low;
                     }
                 }
@@ -214,42 +187,65 @@ __device__ __forceinline__ void liop_make_patch(const float* __restrict__ image,
         L.tx[t] = make_int2((int)rint(M[0] * t * 1024), (int)rint(M[3] * t * 1024));
     }
     LIOP_WAVE_SYNC();
-    // ---- warp: 3 groups of 9 pixels per lane, the 36 loads of a group issued before the first is used
+    // ---- warp: kWarpGroups groups of kWarpPer pixels per lane, the loads of a group (4 per pixel) issued before the first is used.  X and Y are monotone in the
+    // row and in the column (sums of two rounded monotone terms), so their extremes over the patch are at its four corners: when all
+    // four lie inside the image (almost every keypoint) no tap of the patch needs a border test or a clamp.
+    bool inside;
     {
+        const int2 y0 = L.ty[0], y1 = L.ty[S - 1], x0 = L.tx[0], x1 = L.tx[S - 1];
+        inside = w <= 32768 && h <= 32768;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int2 a = (c & 2) ? y1 : y0, b = (c & 1) ? x1 : x0;
+            const int sx = ((a.x + b.x) >> 5) >> 5, sy = ((a.y + b.y) >> 5) >> 5;
+            inside = inside && sx >= 0 && sx + 1 < w && sy >= 0 && sy + 1 < h;
+        }
+    }
+    constexpr int kWarpGroups = 2, kWarpPer = 14;          // 28 >= 27 steps; 56 gathers in flight per lane
+    auto warp = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         const uint32_t ln = liop_opaque(lane);
         LIOP_FIRST(y, x, ln);
 #pragma unroll 1
-        for (int g = 0; g < 3; ++g) {
-            float v0[9], v1[9], v2[9], v3[9], wt[9][4];
-            int at[9];
+        for (int g = 0; g < kWarpGroups; ++g) {
+            float v0[kWarpPer], v1[kWarpPer], v2[kWarpPer], v3[kWarpPer], fxy[kWarpPer][2];
+            int at[kWarpPer];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const bool live = y < (uint32_t)S;                                  // e < 1681
+            for (int q = 0; q < kWarpPer; ++q) {
+                const bool live = y < (uint32_t)S;                      // e < 1681 (the last steps of a lane can leave the patch)
                 const uint32_t yc = live ? y : 0u;
                 const int2 a = L.ty[yc], b = L.tx[x];
                 const int X = (a.x + b.x) >> 5, Y = (a.y + b.y) >> 5;
                 int sx = X >> 5, sy = Y >> 5;
-                sx = sx > 32767 ? 32767 : (sx < -32768 ? -32768 : sx);
-                sy = sy > 32767 ? 32767 : (sy < -32768 ? -32768 : sy);
-                const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
-                wt[q][0] = (1.f - fy) * (1.f - fx); wt[q][1] = (1.f - fy) * fx; wt[q][2] = fy * (1.f - fx); wt[q][3] = fy * fx;
-                const bool x0 = (unsigned)sx < (unsigned)w, x1 = (unsigned)(sx + 1) < (unsigned)w;
-                const bool y0 = (unsigned)sy < (unsigned)h, y1 = (unsigned)(sy + 1) < (unsigned)h;
-                const uint32_t cx0 = x0 ? (uint32_t)sx : 0u, cx1 = x1 ? (uint32_t)(sx + 1) : 0u;
-                const uint32_t r0 = (y0 ? (uint32_t)sy : 0u) * (uint32_t)w, r1 = (y1 ? (uint32_t)(sy + 1) : 0u) * (uint32_t)w;
-                const float a0 = image[r0 + cx0], a1 = image[r0 + cx1], a2 = image[r1 + cx0], a3 = image[r1 + cx1];
-                v0[q] = (x0 && y0) ? a0 : 0.f; v1[q] = (x1 && y0) ? a1 : 0.f; v2[q] = (x0 && y1) ? a2 : 0.f; v3[q] = (x1 && y1) ? a3 : 0.f;
+                fxy[q][0] = (float)(X & 31) * (1.f / 32); fxy[q][1] = (float)(Y & 31) * (1.f / 32);
+                if (FAST) {
+                    const float* __restrict__ p0 = image + ((uint32_t)sy * (uint32_t)w + (uint32_t)sx);
+                    const float* __restrict__ p1 = p0 + w;
+                    v0[q] = p0[0]; v1[q] = p0[1]; v2[q] = p1[0]; v3[q] = p1[1];
+                } else {
+                    sx = sx > 32767 ? 32767 : (sx < -32768 ? -32768 : sx);
+                    sy = sy > 32767 ? 32767 : (sy < -32768 ? -32768 : sy);
+                    const bool x0 = (unsigned)sx < (unsigned)w, x1 = (unsigned)(sx + 1) < (unsigned)w;
+                    const bool y0 = (unsigned)sy < (unsigned)h, y1 = (unsigned)(sy + 1) < (unsigned)h;
+                    const uint32_t cx0 = x0 ? (uint32_t)sx : 0u, cx1 = x1 ? (uint32_t)(sx + 1) : 0u;
+                    const uint32_t r0 = (y0 ? (uint32_t)sy : 0u) * (uint32_t)w, r1 = (y1 ? (uint32_t)(sy + 1) : 0u) * (uint32_t)w;
+                    const float a0 = image[r0 + cx0], a1 = image[r0 + cx1], a2 = image[r1 + cx0], a3 = image[r1 + cx1];
+                    v0[q] = (x0 && y0) ? a0 : 0.f; v1[q] = (x1 && y0) ? a1 : 0.f; v2[q] = (x0 && y1) ? a2 : 0.f; v3[q] = (x1 && y1) ? a3 : 0.f;
+                }
                 at[q] = live ? (int)(y * (uint32_t)kLiopWS + x) : -1;
                 LIOP_NEXT(y, x);
             }
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 0; q < kWarpPer; ++q) {
                 if (at[q] < 0) continue;
-                const float v = v0[q] * wt[q][0] + v1[q] * wt[q][1] + v2[q] * wt[q][2] + v3[q] * wt[q][3];
+                const float fx = fxy[q][0], fy = fxy[q][1];
+                const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+                const float v = v0[q] * w0 + v1[q] * w1 + v2[q] * w2 + v3[q] * w3;
                 L.buf[at[q] + 5] = v;
             }
         }
-    }
+    };
+    if (inside) warp(std::true_type{}); else warp(std::false_type{});
     LIOP_WAVE_SYNC();
     // BORDER_REFLECT_101 of the row filter, materialised: column -k of a row holds its column k, column 40 + k its column 40 - k
     // (41 rows x 10 pad cells, copied inside LDS)
@@ -324,6 +320,28 @@ __device__ __forceinline__ void liop_make_patch(const float* __restrict__ image,
     }
 }
 
+// lexicographic index of a permutation of (0, 1, 2, 3) (Lehmer code), as vl_liop.c:541-551 counts it
+__device__ __forceinline__ uint32_t liop_lehmer(const int (&np)[4])
+{
+    const int c0 = (np[1] < np[0]) + (np[2] < np[0]) + (np[3] < np[0]);
+    const int c1 = (np[2] < np[1]) + (np[3] < np[1]);
+    const int c2 = (np[3] < np[2]);
+    return (uint32_t)(c0 * 6 + c1 * 2 + c2);
+}
+// the permutation index of four DISTINCT samples from their six comparisons: bit 0 = v0 < v1, 1 = v0 < v2, 2 = v0 < v3, 3 = v1 < v2,
+// 4 = v1 < v3, 5 = v2 < v3.  rank(k) = number of samples below sample k; np[r] = the sample of rank r (the unique ascending order).
+// Patterns no four numbers produce (cycles) map to 0 and are never looked up.
+__device__ __forceinline__ uint32_t liop_perm_index(uint32_t key)
+{
+    const int b01 = key & 1, b02 = (key >> 1) & 1, b03 = (key >> 2) & 1, b12 = (key >> 3) & 1, b13 = (key >> 4) & 1, b23 = (key >> 5) & 1;
+    const int rk[4] = {(1 - b01) + (1 - b02) + (1 - b03), b01 + (1 - b12) + (1 - b13), b02 + b12 + (1 - b23), b03 + b13 + b23};
+    if ((1 << rk[0] | 1 << rk[1] | 1 << rk[2] | 1 << rk[3]) != 15) return 0u;
+    int np[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) np[r] = (rk[0] == r) ? 0 : (rk[1] == r) ? 1 : (rk[2] == r) ? 2 : 3;
+    return liop_lehmer(np);
+}
+
 struct LiopParams {
     const float* patches;      // [n][41*41] (FUSED = false)
     const int*   pix;          // [n_pix] offsets of the circular support (scan order) in the ZERO-RINGED patch: (x + 1) + (y + 1) * 43
@@ -331,8 +349,8 @@ struct LiopParams {
     const int4*  samp_off;     // [n_pix]    offsets of their top-left taps in the ringed patch: (floor(x) + 1) + (floor(y) + 1) * 43
     uint32_t n, n_pix;
     float* desc;               // [n][144]
-    uint32_t* n_tie_patches;   // patches with equal intensities in their support: they need the reference's exact re-sort ...
-    uint32_t* tie_list;        // ... and are left to the second pass (their indices, [n])
+    uint32_t* n_tie_patches;   // counts the patches with equal intensities in their support (they took the reference's exact re-sort)
+    uint32_t* tie_list;        // (unused since the exact sort runs inside the patch's own wavefront)
     // FUSED = true: the patch is warped + blurred from the image by the wavefront itself (liop_make_patch) and never exists in HBM
     const float* image0; int w, h;
     const float* M6;           // [n][6] inverse maps
@@ -340,43 +358,50 @@ struct LiopParams {
     const uint32_t* img_of;    // [n] image plane of every keypoint (or nullptr: plane 0)
 };
 
-// TIE_PASS = false: every patch whose support intensities are all distinct (almost all: blurred float images) -- 16 KB of LDS per
-// one-wave workgroup, 10 of them per CU.  A patch with a tie only puts itself on P.tie_list.  TIE_PASS = true: the patches of that
-// list, with the arrays of the reference's quick sort (8 KB more) -- launched right behind the first pass, its workgroups read the
-// count from device memory (no host round trip; a launch over an empty list costs a few microseconds).
+// One wavefront per patch; 13.5 KB of LDS per one-wave workgroup, 11 of them per CU.
 // The patch lives in LDS with a ring of zeros around it (43 x 43): the four taps of a bilinear sample are then always readable --
 // vl_liop's `if (ix >= 0 && ...)` guards become reads of a 0.0f -- and the floor / fraction of every sample position, which depend
 // on the support pixel only, come from host tables (computed with the reference's double operations) instead of f64 -> i64
 // conversions per sample.
-template <bool TIE_PASS, bool FUSED>
-__global__ __launch_bounds__(64, 3)                  // (three waves per SIMD = what 16 KB of LDS per wavefront admits: 168 VGPRs, not the 512 a lone wave may take)
+// A patch with equal intensities in its support is re-ordered by the reference's own quick sort right here, by its own wavefront (a
+// wavefront IS a patch: nothing diverges).  Until round 5 such patches went to a second launch that extracted and sorted them again
+// (a third of the LIOP time on the stage's photographs); the exact sort now works on intensity CLASSES, 4 bytes per entry, in LDS the
+// patch phase has finished with -- no extra LDS, no second pass.
+// LDS map in 32-bit words: [0, 2132) warp / filter image, then the ringed patch [0, 1849); [2132, 2296) coordinate tables;
+// [2296, 2634) perm (u16); [2634, 3209) spare.  Exact sort (ties only): entries [1849, 2529), segment lists [2529, 3209).
+constexpr int kLiopLdsWords = 3209;
+constexpr int kLiopPermWord = 2296, kLiopQArrWord = 1849, kLiopQSegWord = 2529;
+static_assert(sizeof(LiopWaveLds) == 4 * kLiopPermWord, "LDS map of liop_kernel");
+static_assert(kLiopQArrWord >= kLiopPS * kLiopPS && kLiopQArrWord + kLiopMaxPix + 4 <= kLiopQSegWord && kLiopQSegWord + (kLiopMaxPix + 4) <= kLiopLdsWords, "LDS map of liop_kernel");
+__device__ __forceinline__ float liop_from_order_bits(uint32_t b) { return __uint_as_float((b & 0x80000000u) ? (b ^ 0x80000000u) : ~b); }
+
+template <bool FUSED>
+__global__ __launch_bounds__(64, 3)                  // (three waves per SIMD = what 13.5 KB of LDS per wavefront admits: 168 VGPRs, not the 512 a lone wave may take)
 void liop_kernel(const LiopParams P)
 {
-    __shared__ __attribute__((aligned(16))) LiopWaveLds W;
-    constexpr int kQPairs = TIE_PASS ? (kLiopMaxPix + 4) : 1;
-    constexpr int kQStack = TIE_PASS ? (2 * kLiopMaxPix + 8) : 1;
-    __shared__ uint2 qarr[kQPairs];                  // exact re-sort: (intensity bits, position)
-    __shared__ uint16_t qstack[kQStack];
-    __shared__ float inten[kLiopSortCap];            // intensities in scan order (for the exact re-sort)
-    __shared__ uint16_t perm[kLiopSortCap];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLiopLdsWords];
     __shared__ uint32_t hist[144];
     __shared__ float s_norm;
     __shared__ uint32_t qcnt[2];
+    __shared__ unsigned char perm_lut[64];
+    LiopWaveLds& W = *reinterpret_cast<LiopWaveLds*>(lds);
     float* patch = W.buf;
+    uint16_t* perm = reinterpret_cast<uint16_t*>(lds + kLiopPermWord);
+    uint32_t* qarr = lds + kLiopQArrWord;
+    uint16_t* qseg = reinterpret_cast<uint16_t*>(lds + kLiopQSegWord);
+    perm_lut[threadIdx.x] = (unsigned char)liop_perm_index(threadIdx.x);       // (read behind the barriers of the first patch)
 
     const uint32_t lane0 = threadIdx.x;
     const uint32_t N = P.n_pix;
-    const uint32_t n_items = TIE_PASS ? *P.n_tie_patches : P.n;
     float kern[11];
     if (FUSED) {
 #pragma unroll
         for (int k = 0; k < 11; ++k) kern[k] = P.kern[k];
     }
-    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    for (uint32_t item = blockIdx.x; item < P.n; item += gridDim.x) {
         // (a laundered lane id per patch: nothing that depends on the lane alone -- a few hundred registers of index arithmetic over
         // the phases below -- is worth keeping alive across a whole patch, and the compiler would)
-        const uint32_t lane = FUSED ? liop_opaque(lane0) : lane0;
-        const uint32_t item = TIE_PASS ? P.tie_list[it] : it;
+        const uint32_t lane = liop_opaque(lane0);
         {
             float v[27];
             if (FUSED) {
@@ -408,30 +433,32 @@ void liop_kernel(const LiopParams P)
         for (uint32_t e = lane; e < 144; e += 64) hist[e] = 0;
         r3dm_syncthreads();
 
-        // ---- 1. rank the support pixels by intensity (key i: lane i / 16, slot i % 16)
+        // ---- 1. rank the support pixels by intensity (key i: lane i / 16, slot i % 16).  -0.0f and 0.0f are one intensity to the
+        // reference's comparison: v + 0.0f brings both to +0 before the order bits are taken.
         unsigned long long keys[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const uint32_t i = lane * 16u + (uint32_t)s;
-            if (i < N) { const float v = patch[P.pix[i]]; inten[i] = v; keys[s] = ((unsigned long long)float_order_bits(v) << 32) | i; }
+            if (i < N) { const float v = patch[P.pix[i]] + 0.0f; keys[s] = ((unsigned long long)float_order_bits(v) << 32) | i; }
             else keys[s] = ~0ull;
         }
         liop_sort1024(keys, lane);
         bool tie = false;
-        {
-            // the first key of the next lane, for the pair that straddles two lanes
-            const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(keys[0] >> 32), 1);
+        uint32_t hi_last = 0u;                           // order bits of the largest intensity, in the lane that holds sorted position N - 1
+        // the first key of the next lane, for the pair that straddles two lanes
+        const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(keys[0] >> 32), 1);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const uint32_t i = lane * 16u + (uint32_t)s;
-                if (i < N) perm[i] = (uint16_t)(keys[s] & 0xFFFFu);
-                const uint32_t next_hi = (s < 15) ? (uint32_t)(keys[s < 15 ? s + 1 : 15] >> 32) : nhi;
-                if (i + 1 < N) tie |= ((uint32_t)(keys[s] >> 32) == next_hi);
-            }
+        for (int s = 0; s < 16; ++s) {
+            const uint32_t i = lane * 16u + (uint32_t)s;
+            if (i < N) perm[i] = (uint16_t)(keys[s] & 0xFFFFu);
+            if (i == N - 1u) hi_last = (uint32_t)(keys[s] >> 32);
+            const uint32_t next_hi = (s < 15) ? (uint32_t)(keys[s < 15 ? s + 1 : 15] >> 32) : nhi;
+            if (i + 1 < N) tie |= ((uint32_t)(keys[s] >> 32) == next_hi);
         }
         const bool any_tie = __ballot(tie) != 0ull;
+        const float vmin = liop_from_order_bits((uint32_t)__shfl((int)(uint32_t)(keys[0] >> 32), 0));
+        const float vmax = liop_from_order_bits((uint32_t)__shfl((int)hi_last, (int)((N - 1u) >> 4)));
         r3dm_syncthreads();
-        const float vmin = inten[perm[0]], vmax = inten[perm[N - 1]];
         if (vmin == vmax) {
             // constant support: every weight is 0, the descriptor is 0 / max(0, 1e-12) = 0
             for (uint32_t e = lane; e < 144; e += 64) P.desc[(size_t)item * 144 + e] = 0.0f;
@@ -439,32 +466,69 @@ void liop_kernel(const LiopParams P)
             continue;
         }
         if (any_tie) {
-            if constexpr (!TIE_PASS) {
-                if (lane == 0) P.tie_list[atomicAdd(P.n_tie_patches, 1u)] = item;      // the second pass does this patch
-                r3dm_syncthreads();
-                continue;
-            } else {
-                for (uint32_t i = lane; i < N + 4u; i += 64) qarr[i] = make_uint2(i < N ? __float_as_uint(inten[i]) : 0u, i);
-                r3dm_syncthreads();
-                liop_ref_qsort_wave(qarr, (int)N, qstack, qcnt, lane);
-                r3dm_syncthreads();
-                for (uint32_t i = lane; i < N; i += 64) perm[i] = (uint16_t)qarr[i].y;
-                r3dm_syncthreads();
+            if (lane == 0) atomicAdd(P.n_tie_patches, 1u);
+            // class of sorted position j = number of positions k <= j whose intensity differs from its predecessor's
+            uint32_t cls[16];
+            uint32_t run = 0;
+            const uint32_t phi = (uint32_t)__shfl_up((int)(uint32_t)(keys[15] >> 32), 1);      // last key of the previous lane
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const uint32_t prev = s ? (uint32_t)(keys[s ? s - 1 : 0] >> 32) : phi;
+                const bool first = (lane == 0u && s == 0);
+                run += (!first && (uint32_t)(keys[s] >> 32) != prev) ? 1u : 0u;
+                cls[s] = run;
             }
+            uint32_t incl = run;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= (uint32_t)off) incl += o; }
+            const uint32_t base = incl - run;
+            // entries in SCAN order: position i holds (class of pixel i, i) -- the array the reference sorts is the scan order
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const uint32_t j = lane * 16u + (uint32_t)s;
+                const uint32_t pos = (uint32_t)(keys[s] & 0xFFFFu);
+                if (j < N) qarr[pos] = ((base + cls[s]) << 16) | pos;
+            }
+            if (lane < 4u) qarr[N + lane] = 0u;
+            r3dm_syncthreads();
+            liop_ref_qsort_wave(qarr, (int)N, qseg, qcnt, lane);
+            r3dm_syncthreads();
+            uint32_t q[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { const uint32_t i = lane + 64u * (uint32_t)k; q[k] = i < N ? qarr[i] : 0u; }
+            r3dm_syncthreads();                          // perm lies inside the sort's arrays
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { const uint32_t i = lane + 64u * (uint32_t)k; if (i < N) perm[i] = (uint16_t)(q[k] & 0xFFFFu); }
+            r3dm_syncthreads();
         }
         // threshold = -intensityThreshold * (max - min), all float (vl_liop.c:497-503)
-        const float thr = (float)(5.0 / 255) * (inten[perm[N - 1]] - inten[perm[0]]);
+        const float thr = (float)(5.0 / 255) * (vmax - vmin);
 
-        // ---- 2. per rank: bin, 4 bilinear samples, permutation index, weight
+        // ---- 2. per rank: bin, 4 bilinear samples, permutation index, weight.  The sample tables of the NEXT rank of a lane are
+        // requested before the current one is worked on (the kernel is latency-bound: an L2 round trip per rank otherwise).
+        // bin = min(i / area, 5) by five comparisons (a runtime division costs more than the four samples' arithmetic)
         const uint32_t area = N / 6u;
-        for (uint32_t i = lane; i < N; i += 64) {
-            uint32_t bin = i / area; if (bin > 5u) bin = 5u;
+        uint32_t i = lane;
+        int4 so = make_int4(0, 0, 0, 0);
+        double2 sw[4] = {};
+        if (i < N) {
             const uint32_t p = perm[i];
-            const int4 so = P.samp_off[p];
-            const int offs[4] = {so.x, so.y, so.z, so.w};
-            double2 sw[4];
+            so = P.samp_off[p];
 #pragma unroll
             for (int k = 0; k < 4; ++k) sw[k] = P.samp_w[4 * p + k];
+        }
+        while (i < N) {
+            const uint32_t i2 = i + 64u;
+            int4 so2 = make_int4(0, 0, 0, 0);
+            double2 sw2[4] = {};
+            if (i2 < N) {
+                const uint32_t p2 = perm[i2];
+                so2 = P.samp_off[p2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sw2[k] = P.samp_w[4 * p2 + k];
+            }
+            const uint32_t bin = (uint32_t)(i >= area) + (uint32_t)(i >= 2u * area) + (uint32_t)(i >= 3u * area) + (uint32_t)(i >= 4u * area) + (uint32_t)(i >= 5u * area);
+            const int offs[4] = {so.x, so.y, so.z, so.w};
             float nv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -473,35 +537,24 @@ void liop_kernel(const LiopParams P)
                 const double a = q[0], b = q[1], c = q[kLiopPS], d = q[kLiopPS + 1];
                 nv[k] = (float)((1.0 - wy) * (a + (b - a) * wx) + wy * (c + (d - c) * wx));
             }
-            // order of the 4 samples; without ties it is the unique ascending order
-            int np[4];
-            const bool ntie = nv[0] == nv[1] || nv[0] == nv[2] || nv[0] == nv[3] || nv[1] == nv[2] || nv[1] == nv[3] || nv[2] == nv[3];
-            if (!ntie) {
-                int rk[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int r = 0;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) r += (nv[u] < nv[k]);
-                    rk[k] = r;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) np[r] = (rk[0] == r) ? 0 : (rk[1] == r) ? 1 : (rk[2] == r) ? 2 : 3;
-            } else {
-                np[0] = 0; np[1] = 1; np[2] = 2; np[3] = 3;
+            // order of the 4 samples: without ties the six comparisons name the permutation; its lexicographic index comes from the table
+            // the lanes built at kernel start (liop_perm_index on every pattern).  Equal samples (rare) go through the reference's quick sort.
+            const uint32_t key = (uint32_t)(nv[0] < nv[1]) | ((uint32_t)(nv[0] < nv[2]) << 1) | ((uint32_t)(nv[0] < nv[3]) << 2) |
+                                 ((uint32_t)(nv[1] < nv[2]) << 3) | ((uint32_t)(nv[1] < nv[3]) << 4) | ((uint32_t)(nv[2] < nv[3]) << 5);
+            const bool ntie = (nv[0] == nv[1]) | (nv[0] == nv[2]) | (nv[0] == nv[3]) | (nv[1] == nv[2]) | (nv[1] == nv[3]) | (nv[2] == nv[3]);
+            uint32_t index = perm_lut[key];
+            if (ntie) {
+                int np[4] = {0, 1, 2, 3};
                 liop_ref_qsort4(nv, np);
+                index = liop_lehmer(np);
             }
-            // lexicographic index of the permutation (Lehmer code)
-            const int c0 = (np[1] < np[0]) + (np[2] < np[0]) + (np[3] < np[0]);
-            const int c1 = (np[2] < np[1]) + (np[3] < np[1]);
-            const int c2 = (np[3] < np[2]);
-            const int index = c0 * 6 + c1 * 2 + c2;
-            uint32_t weight = 0;
+            const float t0 = nv[0] + thr, t1 = nv[1] + thr, t2 = nv[2] + thr, t3 = nv[3] + thr;
+            const uint32_t weight = (uint32_t)((nv[0] > t1) | (nv[1] > t0)) + (uint32_t)((nv[0] > t2) | (nv[2] > t0)) + (uint32_t)((nv[0] > t3) | (nv[3] > t0)) +
+                                    (uint32_t)((nv[1] > t2) | (nv[2] > t1)) + (uint32_t)((nv[1] > t3) | (nv[3] > t1)) + (uint32_t)((nv[2] > t3) | (nv[3] > t2));
+            if (weight) atomicAdd(&hist[bin * 24u + index], weight);
+            i = i2; so = so2;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a + 1; b < 4; ++b) weight += (nv[a] > nv[b] + thr || nv[b] > nv[a] + thr) ? 1u : 0u;
-            if (weight) atomicAdd(&hist[bin * 24u + (uint32_t)index], weight);
+            for (int k = 0; k < 4; ++k) sw[k] = sw2[k];
         }
         r3dm_syncthreads();
 
@@ -520,7 +573,7 @@ void liop_kernel(const LiopParams P)
 }
 
 // the patches alone (r3dm_extract_liop with patches_out, tools): four wavefronts per workgroup, a patch each, no barrier
-__global__ __launch_bounds__(256, 4)
+__global__ __launch_bounds__(256, 3)
 void liop_extract_patches_kernel(const float* __restrict__ image0, int w, int h, const float* __restrict__ M6,
                                  const float* __restrict__ kern_g /* 11 taps */, uint32_t n, float* __restrict__ patches,
                                  const uint32_t* __restrict__ img_of)
@@ -563,8 +616,7 @@ hipError_t launch_liop(hipStream_t st, const LiopTables& T, const float* patches
     P.patches = patches; P.pix = T.pix; P.samp_w = reinterpret_cast<const double2*>(T.samp_w); P.samp_off = reinterpret_cast<const int4*>(T.samp_off);
     P.n = n; P.n_pix = T.n_pix; P.desc = desc; P.n_tie_patches = n_tie_patches; P.tie_list = tie_list;
     const uint32_t grid = n < 65536u ? n : 65536u;
-    hipLaunchKernelGGL((liop_kernel<false, false>), dim3(grid), dim3(64), 0, st, P);
-    hipLaunchKernelGGL((liop_kernel<true, false>), dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, st, P);
+    hipLaunchKernelGGL((liop_kernel<false>), dim3(grid), dim3(64), 0, st, P);
     return hipGetLastError();
 }
 
@@ -580,8 +632,7 @@ hipError_t launch_liop_fused(hipStream_t st, const LiopTables& T, const float* i
     P.n = n; P.n_pix = T.n_pix; P.desc = desc; P.n_tie_patches = n_tie_patches; P.tie_list = tie_list;
     P.image0 = image; P.w = w; P.h = h; P.M6 = M6; P.kern = kern; P.img_of = img_of;
     const uint32_t grid = n < 65536u ? n : 65536u;
-    hipLaunchKernelGGL((liop_kernel<false, true>), dim3(grid), dim3(64), 0, st, P);
-    hipLaunchKernelGGL((liop_kernel<true, true>), dim3(grid < 2048u ? grid : 2048u), dim3(64), 0, st, P);
+    hipLaunchKernelGGL((liop_kernel<true>), dim3(grid), dim3(64), 0, st, P);
     return hipGetLastError();
 }
 

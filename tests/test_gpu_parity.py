@@ -283,6 +283,8 @@ def test_extract_liop_patches_and_descriptors(ctx, oracle):
     assert np.array_equal(patches, exp_p)
     exp_d = oracle.ref_liop(exp_p) if oracle.ref_liop_lib() is not None else oracle.liop_describe(exp_p)
     assert np.array_equal(desc, exp_d)
+    # without patches_out the warp + blur runs inside the descriptor kernel (the features stage's path): the same descriptors
+    assert np.array_equal(ctx.extract_liop(img, kps, 8.0), exp_d)
     nrm = np.linalg.norm(desc.astype(np.float64), axis=1)
     assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))
 
