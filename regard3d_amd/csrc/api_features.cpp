@@ -286,16 +286,32 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
             // (Splitting the launches of the 3 Mpx octave into sub-batches whose planes fit the Infinity Cache was measured: 2.31-2.34 ms
             // per image against 2.36 -- not worth a second launch order; profiles/r03_f_*.)
             const uint32_t SUB = B;
+            size_t fed_launches = tau.size();                           // plane passes of the FED part (3 planes each): launches, not steps
             for (uint32_t b0 = 0; b0 < B; b0 += SUB) {
                 const int nb = (int)std::min<uint32_t>(SUB, B - b0);
                 const size_t po = (size_t)b0 * n;                       // every plane of this level's launches is n floats
                 float* Lti = Lt(i) + po; float* lt2i = lt2 + po; float* tmpi = tmp + po; float* smoothi = smooth + po; float* flowi = flow + po;
-                // FED launches of this level: one step per launch on the large levels, up to four steps per launch where a step is
-                // mostly launch latency or the planes thrash the Infinity Cache (<= 3.2 Mpx per image: from the second octave of a 12 Mpx image on; R3DM_AK_FED_MULTI=0 in the developer build keeps one step per launch)
+                // FED launches of this level.  Product: up to four steps per launch in registers (ak_fed_march_kernel: a wavefront marches a
+                // strip of columns down the rows, every step level three rows deep in registers -- 12 bytes of HBM traffic per pixel and
+                // LAUNCH instead of per step).  The older forms stay for the developer build's A/B runs: one step per launch
+                // (R3DM_AK_FED_MARCH=0 R3DM_AK_FED_MULTI=0), four steps through LDS on the levels of <= 3.2 Mpx (R3DM_AK_FED_MARCH=0).
+                static const int march_knob = r3dm_dev_knob("R3DM_AK_FED_MARCH", 1);      // 0 = never, 1 = every level, > 1 = levels of at least that many pixels
+                static const int march_kmax = std::min(4, std::max(1, r3dm_dev_knob("R3DM_AK_FED_KMAX", 4)));
+                static const int march_waves = std::max(256, r3dm_dev_knob("R3DM_AK_FED_WAVES", 12000));
+                const bool march = march_knob && lw >= 3 && lh >= 3 && (march_knob == 1 || n >= (size_t)march_knob);
                 static const int multi_knob = r3dm_dev_knob("R3DM_AK_FED_MULTI", 1);      // developer build: 0 = never, 1 = the product, > 1 = that many pixels
                 static const int multi_px = multi_knob > 1 ? multi_knob : (multi_knob ? 3200000 : 0);
-                const size_t per = n <= (size_t)multi_px ? 4 : 1;
-                const size_t n_launch = (tau.size() + per - 1) / per;
+                // chunk[m] = steps of launch m
+                std::vector<int> chunk;
+                if (march) {
+                    const int q = ((int)tau.size() + march_kmax - 1) / march_kmax;         // launches, steps spread evenly over them
+                    for (int m = 0; m < q; ++m) chunk.push_back(((int)tau.size() * (m + 1)) / q - ((int)tau.size() * m) / q);
+                } else {
+                    const int per = n <= (size_t)multi_px ? 4 : 1;
+                    for (size_t k0 = 0; k0 < tau.size(); k0 += (size_t)per) chunk.push_back((int)std::min<size_t>((size_t)per, tau.size() - k0));
+                }
+                const size_t n_launch = chunk.size();
+                fed_launches = n_launch;
                 const float* start = nullptr;
                 if (lv[i].octave > lv[i - 1].octave) {
                     // the FED launches ping-pong between Lt(i) and the work image and must END in Lt(i): the half-sampled start image
@@ -320,16 +336,23 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
                 AK_TRY(ak_scharr_g2(st, smoothi, flowi, lw, lh, nb, inv_k2 + (size_t)b0 * 4096 + lv[i].octave));     // kcontrast * 0.75^octave
                 // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; launch m of M writes Lt(i) when M - m is even, else the work image
                 const float* cur = start;
+                size_t k0 = 0;
                 for (size_t m = 1; m <= n_launch; ++m) {
                     float* o = ((n_launch - m) % 2 == 0) ? Lti : lt2i;
-                    const size_t k0 = (m - 1) * per, kn = std::min(per, tau.size() - k0);
-                    if (per == 1) AK_TRY(ak_fed_step(st, cur, flowi, o, lw, lh, nb, tau[k0]));
-                    else AK_TRY(ak_fed_multi(st, cur, flowi, o, lw, lh, nb, tau.data() + k0, (int)kn));
-                    cur = o;
+                    const int kn = chunk[m - 1];
+                    if (march) {
+                        // rows per band: enough wavefronts to fill the chip (strips x bands x images >= march_waves), at most 128 rows
+                        const int vw = 64 - 2 * kn, strips = (lw + vw - 1) / vw;
+                        int rows = (int)(((int64_t)lh * strips * nb + march_waves - 1) / march_waves);
+                        rows = std::max(16, std::min(128, (rows + 7) / 8 * 8));
+                        AK_TRY(ak_fed_march(st, cur, flowi, o, lw, lh, nb, tau.data() + k0, kn, rows));
+                    } else if (kn == 1 && n > (size_t)multi_px) AK_TRY(ak_fed_step(st, cur, flowi, o, lw, lh, nb, tau[k0]));
+                    else AK_TRY(ak_fed_multi(st, cur, flowi, o, lw, lh, nb, tau.data() + k0, kn));
+                    cur = o; k0 += (size_t)kn;
                 }
             }
             if (lv[i].octave > lv[i - 1].octave) { tally(lv[i - 1].w, lv[i - 1].h, 1, 1); tally(lw, lh, 1, 1); }
-            tally(lw, lh, 2 + 6 + 2 + 3 * (int)tau.size(), 2 + 1 + 1 + 2 * (int)tau.size());       // Gaussian (fused row + column pass) 2, derivatives + determinant 6, conductivity 2, 3 per FED step
+            tally(lw, lh, 2 + 6 + 2 + 3 * (int)fed_launches, 2 + 1 + 1 + 2 * (int)tau.size());       // Gaussian (fused row + column pass) 2, derivatives + determinant 6, conductivity 2, 3 per FED launch (as structured); compulsory: 2 per FED step, the round-2 count
         }
 #undef AK_TRY
         return hipSuccess;

@@ -577,6 +577,50 @@ void ak_fed_multi_kernel(const float* __restrict__ Lt, const float* __restrict__
     }
 }
 
+// ---- up to 4 FED steps in ONE pass over the image, in registers: fed_march.inc (the control flow is shared with a CPU emulation,
+// tests/cpp/fed_march_emul.cpp).  A wavefront = a strip of 64 columns marching down a band of rows; four strips per workgroup.
+}  // namespace r3dm
+#define FED_HD __device__ __forceinline__
+#include "fed_march.inc"
+namespace r3dm {
+struct AkWaveOps {
+    using VF = float; using VM = bool; using VI = int;
+    static __device__ __forceinline__ VF zero() { return 0.0f; }
+    static __device__ __forceinline__ VI lane_plus(int b) { return b + (int)(threadIdx.x & 63u); }
+    static __device__ __forceinline__ VM gt(VI a, int b) { return a > b; }
+    static __device__ __forceinline__ VM lt(VI a, int b) { return a < b; }
+    static __device__ __forceinline__ VM land(VM a, VM b) { return a && b; }
+    static __device__ __forceinline__ VM core_lanes(int k) { const int l = (int)(threadIdx.x & 63u); return l >= k && l < 64 - k; }
+    static __device__ __forceinline__ VI clampi(VI a, int lo, int hi) { return ak_clamp(a, lo, hi); }
+    static __device__ __forceinline__ VF load(const float* __restrict__ p, int row, int w, VI xc) { return p[(uint32_t)row * (uint32_t)w + (uint32_t)xc]; }
+    static __device__ __forceinline__ void store(float* __restrict__ p, int row, int w, VI x, VF v, VM m) { if (m) p[(uint32_t)row * (uint32_t)w + (uint32_t)x] = v; }
+    static __device__ __forceinline__ VF add(VF a, VF b) { return a + b; }
+    static __device__ __forceinline__ VF sub(VF a, VF b) { return a - b; }
+    static __device__ __forceinline__ VF mul(VF a, VF b) { return a * b; }
+    static __device__ __forceinline__ VF muls(VF a, float b) { return a * b; }
+    static __device__ __forceinline__ VF sel(VM m, VF a, VF b) { return m ? a : b; }
+    // DPP wavefront shifts: lane i reads lane i - 1 (wave_shr:1) / lane i + 1 (wave_shl:1); the end lanes read 0 -- garbage by design
+    static __device__ __forceinline__ VF shr(VF a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x138, 0xF, 0xF, false)); }
+    static __device__ __forceinline__ VF shl(VF a) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x130, 0xF, 0xF, false)); }
+};
+template <int K>
+__global__ __launch_bounds__(256)
+void ak_fed_march_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, AkFedSteps st, int rows_per_band)
+{
+    constexpr int VW = 64 - 2 * K;                         // columns a strip stores
+    Lt = AK_PLANE(Lt, w, h); Lf = AK_PLANE(Lf, w, h); out = AK_PLANE(out, w, h);
+    const int strip = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (strip * VW >= w) return;                           // (wave-uniform: no barrier anywhere in this kernel)
+    const int x_first = strip * VW - K;
+    const int y0 = (int)blockIdx.y * rows_per_band, y1 = y0 + rows_per_band < h ? y0 + rows_per_band : h;
+    float tau[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) tau[k] = st.tau[k];
+    const bool edge = x_first < 1 || x_first + 63 > w - 2;
+    if (edge) fed_march_strip<K, true, AkWaveOps>(Lt, Lf, out, w, h, tau, x_first, y0, y1);
+    else fed_march_strip<K, false, AkWaveOps>(Lt, Lf, out, w, h, tau, x_first, y0, y1);
+}
+
 // ---- halfsample: INTER_AREA, exact 2x (resizeAreaFast_) or fractional cells (ResizeArea_, tables from the host)
 __global__ __launch_bounds__(256)
 void ak_half_fast_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int sh, int dw, int dh)
@@ -1314,6 +1358,24 @@ hipError_t ak_fed_multi(hipStream_t st, const float* Lt, const float* Lf, float*
     for (int k = 0; k < n_steps; ++k) fs.tau[k] = tau[k];
     fs.n = n_steps;
     hipLaunchKernelGGL(ak_fed_multi_kernel, dim3((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32), (unsigned)B), dim3(256), 0, st, Lt, Lf, out, w, h, fs);
+    return hipGetLastError();
+}
+// n_steps <= 4 FED steps tau[0..n) in one register-marching pass (any level of at least 3 x 3 pixels); n_waves_hint = wavefronts the
+// launch should at least have (rows per band are chosen for it: fewer rows per band = more wavefronts, more halo rows per output row)
+hipError_t ak_fed_march(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps, int rows_per_band)
+{
+    if (n_steps < 1 || n_steps > 4 || w < 3 || h < 3 || rows_per_band < 1) return hipErrorInvalidValue;
+    AkFedSteps fs{};
+    for (int k = 0; k < n_steps; ++k) fs.tau[k] = tau[k];
+    fs.n = n_steps;
+    const int vw = 64 - 2 * n_steps, strips = (w + vw - 1) / vw;
+    const dim3 grid((unsigned)((strips + 3) / 4), (unsigned)((h + rows_per_band - 1) / rows_per_band), (unsigned)B);
+    switch (n_steps) {
+        case 1: hipLaunchKernelGGL(ak_fed_march_kernel<1>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
+        case 2: hipLaunchKernelGGL(ak_fed_march_kernel<2>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
+        case 3: hipLaunchKernelGGL(ak_fed_march_kernel<3>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
+        default: hipLaunchKernelGGL(ak_fed_march_kernel<4>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
+    }
     return hipGetLastError();
 }
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,

@@ -348,6 +348,7 @@ hipError_t ak_modg_max(hipStream_t st, const float* src, int w, int h, int B, ui
 hipError_t ak_modg_hist(hipStream_t st, const float* src, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, float step_size);
 hipError_t ak_fed_multi(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps);
+hipError_t ak_fed_march(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps, int rows_per_band);
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);
 hipError_t ak_extrema(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, int max_rows, float thr, int pass);
