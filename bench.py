@@ -158,6 +158,7 @@ def main():
         if world > 1:
             td.broadcast_object_list(uid, src=0)
         comm = api.Comm(uid[0], rank, world, local_rank)
+        ctx.set_device_graphs(True)      # the graphs of a step keep a device mirror: r3dm_allgather_graphs sends them from device memory
 
     def match(p):
         if kp is not None:
@@ -225,7 +226,7 @@ def main():
                      "match_only_pairs_per_s_this_rank": (mine.shape[0] * a.steps / (wall["match"] * 1e-3)) if wall["match"] > 0 else None,
                      "exact_fallback_queries_per_step": acc["fallback"] / a.steps, "queries_per_step": acc["queries"] / a.steps,
                      "exact_fallback_fraction": acc["fallback"] / max(acc["queries"], 1),
-                     "exchange": ("r3dm_allgather_graphs: the library's RCCL entry (C ABI), sizes + padded payload" if comm is not None else
+                     "exchange": (f"r3dm_allgather_graphs: the library's RCCL entry (C ABI), sizes + padded payload; {comm.last_device_graphs} of 2 local graphs sent from their device mirror" if comm is not None else
                                   "torch.distributed all_gather of sizes + padded payload (" + (backend if world > 1 else "one rank: nothing to exchange") + ")"),
                      "putative_pairs": int(full[0].num_pairs), "putative_matches": int(full[0].num_matches),
                      "F_pairs": int(full[1].num_pairs), "F_matches": int(full[1].num_matches),

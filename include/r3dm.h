@@ -242,6 +242,11 @@ int r3dm_exhaustive_is_faster(const r3dm_ctx* ctx);
 int r3dm_kgraph_knn2(r3dm_ctx* ctx, const float* dataset, uint32_t n_dataset, const float* query, uint32_t n_query,
                      uint32_t dim, const r3dm_kgraph_params* params, uint32_t pair_i, uint32_t pair_j,
                      int32_t* out_idx, float* out_dist);
+/* Rows per view the graph matcher indexes: its index is the exact K-NN graph, built by an all-pairs scan of the view (quadratic in the
+ * rows: 1-4 ms at 16 k rows, ~0.3 s at this bound).  r3dm_kgraph_index / r3dm_match_pairs_kgraph / r3dm_kgraph_knn2 return
+ * R3DM_ERR_UNSUPPORTED for a larger view instead of indexing it in quadratic time (the reference's NN-descent builder,
+ * src/thirdparty/kgraph/kgraph.cpp:703-999, is not built); the exhaustive matcher has no such bound. */
+#define R3DM_KGRAPH_MAX_ROWS 131072u
 /* the index of a registered view (built if necessary): adj_out = n x 64 rows (0xFFFFFFFF padded), deg_out = n */
 int r3dm_kgraph_index(r3dm_ctx* ctx, uint32_t view_id, uint32_t index_K, uint32_t* adj_out, uint32_t* deg_out);
 /* forget the graph indices of all registered views (they are rebuilt on the next r3dm_match_pairs_kgraph); the reference builds
@@ -497,6 +502,17 @@ int  r3dm_comm_rank(const r3dm_comm* comm);
 int  r3dm_comm_world(const r3dm_comm* comm);
 const char* r3dm_comm_last_error(const r3dm_comm* comm);
 int  r3dm_allgather_graphs(r3dm_comm* comm, const r3dm_graph* const* local, uint32_t n_graphs, r3dm_graph** merged_out /* [n_graphs] */);
+/* Device-resident graphs for that exchange.  With r3dm_set_device_graphs(ctx, 1) every graph the context produces from then on
+ * (r3dm_match_pairs*, r3dm_filter_F / _E / _H / _FEH) keeps, beside its host vectors, the same CSR in the memory of the context's GPU,
+ * laid out by gather kernels where the matches already are (the finalisation's output array; the putative matches through the filters'
+ * inlier indices).  r3dm_allgather_graphs sends such a graph from device memory -- its payload does not cross PCIe on the way out --
+ * when the mirror lives on the communicator's device; other graphs are packed on the host as before (r3dm_graph_from_csr, loaded or
+ * merged graphs have no mirror).  r3dm_graph_on_device: the device id of a graph's mirror, -1 without one;
+ * r3dm_comm_last_device_graphs: how many local graphs of the last exchange went out that way.  Every rank takes part in every
+ * collective of an exchange even when it fails locally (it says so in the words it contributes), so all ranks return together. */
+int  r3dm_set_device_graphs(r3dm_ctx* ctx, int enable);
+int  r3dm_graph_on_device(const r3dm_graph* g);
+int  r3dm_comm_last_device_graphs(const r3dm_comm* comm);
 int  r3dm_graphs_pack(const r3dm_graph* const* local, uint32_t n_graphs, uint32_t** words_out, uint64_t* n_words_out);
 void r3dm_words_free(uint32_t* words);
 int  r3dm_graphs_unpack_merge(const uint32_t* const* rank_words, const uint64_t* rank_n_words, uint32_t world, uint32_t n_graphs,

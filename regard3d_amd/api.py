@@ -34,6 +34,7 @@ EXPORTS = [
     "r3dm_multi_match_pairs", "r3dm_multi_match_pairs_kgraph", "r3dm_multi_match_pairs_hnsw", "r3dm_multi_filter_F", "r3dm_multi_filter_H", "r3dm_multi_filter_E", "r3dm_shard_pairs",
     "r3dm_comm_unique_id", "r3dm_comm_create", "r3dm_comm_destroy", "r3dm_comm_rank", "r3dm_comm_world", "r3dm_comm_last_error",
     "r3dm_allgather_graphs", "r3dm_graphs_pack", "r3dm_words_free", "r3dm_graphs_unpack_merge",
+    "r3dm_set_device_graphs", "r3dm_graph_on_device", "r3dm_comm_last_device_graphs",
 ]
 
 
@@ -309,6 +310,9 @@ def load_library():
     L.r3dm_comm_rank.argtypes = [vp]; L.r3dm_comm_world.argtypes = [vp]
     L.r3dm_comm_last_error.argtypes = [vp]; L.r3dm_comm_last_error.restype = C.c_char_p
     L.r3dm_allgather_graphs.argtypes = [vp, vp, u32, vp]
+    L.r3dm_set_device_graphs.argtypes = [vp, C.c_int]
+    L.r3dm_graph_on_device.argtypes = [vp]
+    L.r3dm_comm_last_device_graphs.argtypes = [vp]
     L.r3dm_graphs_pack.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
     L.r3dm_words_free.argtypes = [vp]; L.r3dm_words_free.restype = None
     L.r3dm_graphs_unpack_merge.argtypes = [vp, vp, u32, u32, vp]
@@ -350,6 +354,11 @@ class Graph:
 
     def __init__(self, handle: int):
         self._h = handle
+
+    @property
+    def on_device(self) -> int:
+        """device id of the graph's device mirror, -1 without one"""
+        return load_library().r3dm_graph_on_device(self._h)
 
     def __del__(self):
         try:
@@ -491,6 +500,11 @@ class Comm:
     @property
     def world(self) -> int:
         return load_library().r3dm_comm_world(self._h)
+
+    @property
+    def last_device_graphs(self) -> int:
+        """local graphs of the last exchange that went on the wire from their device mirror (Context.set_device_graphs)"""
+        return load_library().r3dm_comm_last_device_graphs(self._h)
 
     def allgather_graphs(self, local: Sequence["Graph"]) -> List["Graph"]:
         L = load_library()
@@ -704,6 +718,10 @@ class Context:
                     "r3dm_filter_H")
         g = Graph(h.value)
         return (g, Hbuf[:g.num_pairs].copy()) if want_H else g
+
+    def set_device_graphs(self, enable: bool = True):
+        """r3dm_set_device_graphs: graphs produced from now on keep a device mirror (sent by Comm.allgather_graphs without a host round trip)"""
+        self._check(self._L.r3dm_set_device_graphs(self._h, int(bool(enable))), "r3dm_set_device_graphs")
 
     def set_integer_mfma(self, enable: bool = True):
         """opt-in bf16-exact MFMA path for integer-valued descriptors (include/r3dm.h: r3dm_set_integer_mfma)"""

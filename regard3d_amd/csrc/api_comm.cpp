@@ -86,6 +86,7 @@ struct r3dm_comm {
     DevBuf d_send, d_recv, d_sizes;
     PinBuf h_send, h_recv;
     std::string err;
+    uint32_t last_device_graphs = 0;      // graphs of the last exchange whose payload was sent from their device mirror
 };
 
 extern "C" int r3dm_graphs_pack(const r3dm_graph* const* local, uint32_t n_graphs, uint32_t** words_out, uint64_t* n_words_out)
@@ -97,6 +98,7 @@ extern "C" int r3dm_graphs_pack(const r3dm_graph* const* local, uint32_t n_graph
         buf[0] = n_graphs;
         for (uint32_t k = 0; k < n_graphs; ++k) {
             if (!local[k]) return R3DM_ERR_INVALID;
+            if (local[k]->pairs.size() / 2 > 0xFFFFFFFFull) return R3DM_ERR_UNSUPPORTED;     // (the pair count travels as one word)
             const size_t at = buf.size();
             pack_graph(*local[k], buf);
             if (buf.size() - at > 0xFFFFFFFFull) return R3DM_ERR_UNSUPPORTED;
@@ -200,43 +202,101 @@ extern "C" const char* r3dm_comm_last_error(const r3dm_comm* c) { return c ? c->
         if (e__ != ncclSuccess) { c->err = std::string(#call) + ": " + rccl().GetErrorString(e__); return R3DM_ERR_HIP; } \
     } while (0)
 
+extern "C" int r3dm_comm_last_device_graphs(const r3dm_comm* c) { return c ? (int)c->last_device_graphs : -1; }
+
+// The exchange.  Every rank takes part in every collective of the call whatever happened to it locally: a rank that cannot pack or
+// allocate says so in the words it contributes (size ~0 / status 1) and ALL ranks return an error together -- a rank that left early
+// would leave the others blocked inside RCCL.
+// A local graph with a device mirror on this communicator's GPU (r3dm_set_device_graphs; GraphDev) goes on the wire from device memory:
+// three device-to-device copies behind a 12-byte header -- its payload never visits the host on the way out.  A graph without one is
+// packed on the host and uploaded, as before.  The gathered payload comes back to the host either way: the merged graphs are host
+// objects (PairWiseMatches feeds files and the SfM stage).
 extern "C" int r3dm_allgather_graphs(r3dm_comm* c, const r3dm_graph* const* local, uint32_t n_graphs, r3dm_graph** merged_out)
 {
     if (!c || !merged_out || (n_graphs && !local)) return R3DM_ERR_INVALID;
     for (uint32_t k = 0; k < n_graphs; ++k) merged_out[k] = nullptr;
     try {
         CHIP(hipSetDevice(c->device));
-        uint32_t* words = nullptr; uint64_t n_words = 0;
-        int rc = r3dm_graphs_pack(local, n_graphs, &words, &n_words);
-        if (rc != R3DM_OK) { c->err = "r3dm_allgather_graphs: packing failed"; return rc; }
-        std::unique_ptr<uint32_t, void (*)(uint32_t*)> words_own(words, r3dm_words_free);
         const uint32_t W = (uint32_t)c->world;
+        constexpr unsigned long long kFailed = ~0ull;
+        // ---- what this rank sends: per graph the word count, and whether the device mirror serves it
+        int local_rc = R3DM_OK;
+        std::vector<uint64_t> len(n_graphs, 0);
+        std::vector<unsigned char> on_dev(n_graphs, 0);
+        unsigned long long n_words = 1ull + n_graphs;
+        for (uint32_t k = 0; k < n_graphs && local_rc == R3DM_OK; ++k) {
+            const r3dm_graph* g = local[k];
+            if (!g) { local_rc = R3DM_ERR_INVALID; break; }
+            const uint64_t P = g->pairs.size() / 2, M = g->matches.size();
+            if (P > 0xFFFFFFFFull || 3 + 3 * P + 2 * M > 0xFFFFFFFFull) { local_rc = R3DM_ERR_UNSUPPORTED; break; }
+            len[k] = 3 + 3 * P + 2 * M;
+            on_dev[k] = g->dev.valid && g->dev.device == c->device && g->dev.P == P && g->dev.M == M;
+            n_words += len[k];
+        }
         // ---- sizes: 8 bytes per rank
-        CHIP(c->d_sizes.ensure(8 * (size_t)(W + 1)));
-        unsigned long long* d_all = c->d_sizes.as<unsigned long long>();        // [W] gathered, [W] = mine
-        const unsigned long long mine = n_words;
-        CHIP(hipMemcpyAsync(d_all + W, &mine, 8, hipMemcpyHostToDevice, c->stream));
-        CNCCL(rccl().AllGather(d_all + W, d_all, 1, ncclUint64, c->comm, c->stream));
+        CHIP(c->d_sizes.ensure(8 * (size_t)(2 * W + 2)));
+        unsigned long long* d_all = c->d_sizes.as<unsigned long long>();        // [W] gathered sizes, [W] gathered status, then mine x 2
+        const unsigned long long mine = local_rc == R3DM_OK ? n_words : kFailed;
+        CHIP(hipMemcpyAsync(d_all + 2 * W, &mine, 8, hipMemcpyHostToDevice, c->stream));
+        CNCCL(rccl().AllGather(d_all + 2 * W, d_all, 1, ncclUint64, c->comm, c->stream));
         std::vector<unsigned long long> sizes(W);
         CHIP(hipMemcpyAsync(sizes.data(), d_all, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
         CHIP(hipStreamSynchronize(c->stream));
         unsigned long long mx = 1;
-        for (unsigned long long s : sizes) mx = std::max(mx, s);
+        for (uint32_t r = 0; r < W; ++r) {
+            if (sizes[r] == kFailed) { c->err = "r3dm_allgather_graphs: rank " + std::to_string(r) + " could not pack its graphs (null graph, or more than 2^32 words in one)"; return local_rc != R3DM_OK ? local_rc : R3DM_ERR_INVALID; }
+            mx = std::max(mx, sizes[r]);
+        }
+        // ---- buffers, then a status word per rank: nobody enters the payload collective unless everybody can
+        unsigned long long status = 0;
+        if (c->d_send.ensure(4 * (size_t)mx) != hipSuccess || c->d_recv.ensure(4 * (size_t)mx * W) != hipSuccess ||
+            c->h_send.ensure(4 * (size_t)mx) != hipSuccess || c->h_recv.ensure(4 * (size_t)mx * W) != hipSuccess) { status = 1; (void)hipGetLastError(); }
+        CHIP(hipMemcpyAsync(d_all + 2 * W + 1, &status, 8, hipMemcpyHostToDevice, c->stream));
+        CNCCL(rccl().AllGather(d_all + 2 * W + 1, d_all + W, 1, ncclUint64, c->comm, c->stream));
+        std::vector<unsigned long long> stat(W);
+        CHIP(hipMemcpyAsync(stat.data(), d_all + W, 8 * (size_t)W, hipMemcpyDeviceToHost, c->stream));
+        CHIP(hipStreamSynchronize(c->stream));
+        for (uint32_t r = 0; r < W; ++r)
+            if (stat[r]) { c->err = "r3dm_allgather_graphs: rank " + std::to_string(r) + " is out of memory for the exchange buffers"; return R3DM_ERR_NOMEM; }
+        // ---- my words in d_send: the host writes headers (and whole graphs without a mirror) into the pinned image, uploads them in
+        // runs, and the mirrors fill their places device to device
+        uint32_t* hs = static_cast<uint32_t*>(c->h_send.p);
+        uint32_t* ds = c->d_send.as<uint32_t>();
+        hs[0] = n_graphs;
+        for (uint32_t k = 0; k < n_graphs; ++k) hs[1 + k] = (uint32_t)len[k];
+        size_t at = 1 + (size_t)n_graphs, run0 = 0;                              // [run0, at) = host words not yet uploaded
+        c->last_device_graphs = 0;
+        for (uint32_t k = 0; k < n_graphs; ++k) {
+            const r3dm_graph& g = *local[k];
+            const uint64_t P = g.pairs.size() / 2, M = g.matches.size();
+            hs[at] = (uint32_t)P; hs[at + 1] = (uint32_t)(M & 0xFFFFFFFFull); hs[at + 2] = (uint32_t)(M >> 32);
+            if (on_dev[k]) {
+                CHIP(hipMemcpyAsync(ds + run0, hs + run0, 4 * (at + 3 - run0), hipMemcpyHostToDevice, c->stream));
+                uint32_t* d = ds + at + 3;
+                if (P) CHIP(hipMemcpyAsync(d, g.dev.pairs.p, 8 * (size_t)P, hipMemcpyDeviceToDevice, c->stream));
+                if (P) CHIP(hipMemcpyAsync(d + 2 * P, g.dev.counts.p, 4 * (size_t)P, hipMemcpyDeviceToDevice, c->stream));
+                if (M) CHIP(hipMemcpyAsync(d + 3 * P, g.dev.matches.p, 8 * (size_t)M, hipMemcpyDeviceToDevice, c->stream));
+                at += (size_t)len[k];
+                run0 = at;
+                c->last_device_graphs += 1;
+            } else {
+                uint32_t* o = hs + at + 3;
+                if (P) memcpy(o, g.pairs.data(), 8 * (size_t)P);
+                for (uint64_t p = 0; p < P; ++p) o[2 * P + p] = (uint32_t)(g.offsets[p + 1] - g.offsets[p]);
+                if (M) memcpy(o + 3 * P, g.matches.data(), 8 * (size_t)M);
+                at += (size_t)len[k];
+            }
+        }
+        if (mx > at) memset(hs + at, 0, 4 * (size_t)(mx - at));                   // padding up to the largest rank
+        if (mx > run0) CHIP(hipMemcpyAsync(ds + run0, hs + run0, 4 * (size_t)(mx - run0), hipMemcpyHostToDevice, c->stream));
         // ---- payload, padded to the largest rank: the one exchange (RCCL over xGMI)
-        CHIP(c->d_send.ensure(4 * (size_t)mx));
-        CHIP(c->d_recv.ensure(4 * (size_t)mx * W));
-        CHIP(c->h_send.ensure(4 * (size_t)mx));
-        CHIP(c->h_recv.ensure(4 * (size_t)mx * W));
-        memcpy(c->h_send.p, words, 4 * (size_t)n_words);
-        if (mx > n_words) memset(static_cast<uint32_t*>(c->h_send.p) + n_words, 0, 4 * (size_t)(mx - n_words));
-        CHIP(hipMemcpyAsync(c->d_send.p, c->h_send.p, 4 * (size_t)mx, hipMemcpyHostToDevice, c->stream));
         CNCCL(rccl().AllGather(c->d_send.p, c->d_recv.p, (size_t)mx, ncclUint32, c->comm, c->stream));
         CHIP(hipMemcpyAsync(c->h_recv.p, c->d_recv.p, 4 * (size_t)mx * W, hipMemcpyDeviceToHost, c->stream));
         CHIP(hipStreamSynchronize(c->stream));
         std::vector<const uint32_t*> ptrs(W);
         std::vector<uint64_t> lens(W);
         for (uint32_t r = 0; r < W; ++r) { ptrs[r] = static_cast<const uint32_t*>(c->h_recv.p) + (size_t)r * mx; lens[r] = sizes[r]; }
-        rc = r3dm_graphs_unpack_merge(ptrs.data(), lens.data(), W, n_graphs, merged_out);
+        const int rc = r3dm_graphs_unpack_merge(ptrs.data(), lens.data(), W, n_graphs, merged_out);
         if (rc != R3DM_OK) c->err = "r3dm_allgather_graphs: a rank sent a malformed buffer";
         return rc;
     } catch (...) { c->err = "out of host memory"; return R3DM_ERR_NOMEM; }

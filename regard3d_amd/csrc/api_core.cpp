@@ -44,7 +44,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     DevBuf* bufs[] = {&c->d_imgs, &c->d_pairs, &c->d_nn, &c->d_knn_idx, &c->d_knn_dist, &c->d_fb, &c->d_cnt, &c->d_out,
                       &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->m_raw, &c->m_peer,
                       &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
-                      &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->d_spill, &c->d_fb2};
+                      &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->d_spill, &c->d_fb2, &c->g_segs};
     for (FilterBufs& fb : c->fb) fb.release();
     c->coop_sched.release();
     if (c->coop_ev) (void)hipEventDestroy(c->coop_ev);
@@ -373,6 +373,57 @@ extern "C" const uint32_t* r3dm_graph_pairs(const r3dm_graph* g) { return g ? g-
 extern "C" const uint64_t* r3dm_graph_offsets(const r3dm_graph* g) { return g ? g->offsets.data() : nullptr; }
 extern "C" const r3dm_match* r3dm_graph_matches(const r3dm_graph* g) { return g ? g->matches.data() : nullptr; }
 extern "C" void r3dm_graph_free(r3dm_graph* g) { delete g; }
+
+// ---- the device mirror of a graph (GraphDev): appended to where the matches already are in device memory
+extern "C" int r3dm_set_device_graphs(r3dm_ctx* c, int enable)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    c->device_graphs = enable != 0;
+    return R3DM_OK;
+}
+extern "C" int r3dm_graph_on_device(const r3dm_graph* g) { return g && g->dev.valid ? g->dev.device : -1; }
+
+// grows `b` to hold `need` bytes keeping its first `used` bytes
+static hipError_t dev_grow(DevBuf& b, size_t used, size_t need, hipStream_t st)
+{
+    if (need <= b.cap) return hipSuccess;
+    DevBuf n;
+    hipError_t e = n.ensure(need + need / 2);
+    if (e != hipSuccess) return e;
+    if (used) e = hipMemcpyAsync(n.p, b.p, used, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { n.release(); return e; }
+    b.release();
+    b = n;
+    return hipSuccess;
+}
+
+// Appends segs.size() kept pairs to the mirror of g: their view ids (2 per pair), their counts, and their matches gathered on the device
+// from `src` (through the index list `idx` when given).  segs[k].dst counts from the start of the appended block.  A failure only
+// invalidates the mirror (the host vectors of the graph are the product either way).
+int graph_dev_append(r3dm_ctx* c, r3dm_graph* g, const std::vector<uint32_t>& pair_ids, const std::vector<uint32_t>& counts, std::vector<GraphSeg>& segs,
+                     const r3dm_match* src, const uint32_t* idx)
+{
+    GraphDev& d = g->dev;
+    if (!d.valid) return R3DM_OK;
+    const size_t n = segs.size();
+    if (n == 0) return R3DM_OK;
+    uint64_t add = 0;
+    for (uint32_t v : counts) add += v;
+    for (GraphSeg& sgm : segs) sgm.dst += d.M;
+    hipError_t e = dev_grow(d.pairs, d.P * 8, (d.P + n) * 8, c->stream);
+    if (e == hipSuccess) e = dev_grow(d.counts, d.P * 4, (d.P + n) * 4, c->stream);
+    if (e == hipSuccess) e = dev_grow(d.matches, d.M * sizeof(r3dm_match), (d.M + add) * sizeof(r3dm_match) + 16, c->stream);
+    if (e == hipSuccess) e = c->g_segs.ensure(n * sizeof(GraphSeg));
+    if (e == hipSuccess) e = hipMemcpyAsync(d.pairs.as<uint32_t>() + 2 * d.P, pair_ids.data(), n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d.counts.as<uint32_t>() + d.P, counts.data(), n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->g_segs.p, segs.data(), n * sizeof(GraphSeg), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_graph_gather(c->stream, src, idx, c->g_segs.as<GraphSeg>(), (uint32_t)n, d.matches.as<r3dm_match>());
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // the host arrays above leave scope with the caller
+    if (e != hipSuccess) { d.release(); (void)hipGetLastError(); return R3DM_OK; }
+    d.P += n; d.M += add;
+    return R3DM_OK;
+}
 
 static int r3dm_graph_from_csr_impl(const uint32_t* pairs_ij, uint64_t n_pairs, const uint64_t* offsets,
                                    const r3dm_match* matches, r3dm_graph** out)

@@ -286,6 +286,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
             // (Splitting the launches of the 3 Mpx octave into sub-batches whose planes fit the Infinity Cache was measured: 2.31-2.34 ms
             // per image against 2.36 -- not worth a second launch order; profiles/r03_f_*.)
             const uint32_t SUB = B;
+            bool head_used = false;
             size_t fed_launches = tau.size();                           // plane passes of the FED part (3 planes each): launches, not steps
             for (uint32_t b0 = 0; b0 < B; b0 += SUB) {
                 const int nb = (int)std::min<uint32_t>(SUB, B - b0);
@@ -327,13 +328,31 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
                     if (start != Lti) AK_TRY(hipMemcpyAsync(Lti, start, (size_t)nb * n * 4, hipMemcpyDeviceToDevice, st));
                     start = Lti;
                 }
-                AK_TRY(ak_gaussian(st, start, tmpi, smoothi, lw, lh, nb, taps_one));
-                {
-                    const int s_i = lv[i].sigma_size;
+                // Gaussian -> derivatives -> determinant -> conductivity.  Product: four HBM-bound launches (10 plane moves).  The one-pass form
+                // (ak_level_head_kernel: a marching wavefront with the intermediates in LDS rings, 5 plane moves, bit-identical -- level_head.inc,
+                // tests/cpp/level_head_emul.cpp) is built and MEASURED SLOWER, twice: 1,369 us (stages chained inside an iteration) and 1,573 us
+                // (stages one iteration apart) against 1,083 us for the four launches at 8 x 12 Mpx.  PMC (profiles/r05_pmc_level_head.txt):
+                // 271 scalar + 138 vector + 28 LDS instructions per 48 stored pixels -- the per-row bookkeeping of a marching wavefront
+                // (ring slots, border rows, stage predicates) is paid once per 64 lanes and row, where a thread-per-pixel kernel pays it
+                // once per four rows of loads; at ~620 G wave instructions/s the fused form is instruction-bound above the four launches'
+                // HBM time.  It stays behind the developer knob R3DM_AK_HEAD=1 (tests/test_gpu_akaze.py runs it for bit-identity).
+                static const int head_knob = r3dm_dev_knob("R3DM_AK_HEAD", 0);
+                static const int head_waves = std::max(256, r3dm_dev_knob("R3DM_AK_HEAD_WAVES", 8000));
+                const int s_i = lv[i].sigma_size;
+                const bool head = head_knob && taps_one.n == 5 && s_i >= 2 && s_i <= 4 && lw >= 16 && lh >= 16;
+                head_used = head;
+                if (head) {
+                    const int vw = 64 - 2 * (2 + 2 * s_i), strips = (lw + vw - 1) / vw;
+                    int rows = (int)(((int64_t)lh * strips * nb + head_waves - 1) / head_waves);
+                    rows = std::max(32, std::min(256, (rows + 15) / 16 * 16));
+                    AK_TRY(ak_level_head(st, start, Lx(i) + po, Ly(i) + po, Ldet(i) + po, flowi, lw, lh, nb, taps_one, s_i,
+                                         inv_k2 + (size_t)b0 * 4096 + lv[i].octave, rows));
+                } else {
+                    AK_TRY(ak_gaussian(st, start, tmpi, smoothi, lw, lh, nb, taps_one));
                     AK_TRY(ak_scaled_deriv_xy(st, smoothi, Lx(i) + po, Ly(i) + po, lw, lh, nb, s_i));
                     AK_TRY(ak_scaled_deriv_det(st, Lx(i) + po, Ly(i) + po, Ldet(i) + po, lw, lh, nb, s_i));
+                    AK_TRY(ak_scharr_g2(st, smoothi, flowi, lw, lh, nb, inv_k2 + (size_t)b0 * 4096 + lv[i].octave));     // kcontrast * 0.75^octave
                 }
-                AK_TRY(ak_scharr_g2(st, smoothi, flowi, lw, lh, nb, inv_k2 + (size_t)b0 * 4096 + lv[i].octave));     // kcontrast * 0.75^octave
                 // Fast Explicit Diffusion: lt += lstep * 0.5 * tau_j; launch m of M writes Lt(i) when M - m is even, else the work image
                 const float* cur = start;
                 size_t k0 = 0;
@@ -352,7 +371,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
                 }
             }
             if (lv[i].octave > lv[i - 1].octave) { tally(lv[i - 1].w, lv[i - 1].h, 1, 1); tally(lw, lh, 1, 1); }
-            tally(lw, lh, 2 + 6 + 2 + 3 * (int)fed_launches, 2 + 1 + 1 + 2 * (int)tau.size());       // Gaussian (fused row + column pass) 2, derivatives + determinant 6, conductivity 2, 3 per FED launch (as structured); compulsory: 2 per FED step, the round-2 count
+            tally(lw, lh, (head_used ? 5 : 2 + 6 + 2) + 3 * (int)fed_launches, 2 + 1 + 1 + 2 * (int)tau.size());       // Gaussian (fused row + column pass) 2, derivatives + determinant 6, conductivity 2, 3 per FED launch (as structured); compulsory: 2 per FED step, the round-2 count
         }
 #undef AK_TRY
         return hipSuccess;
@@ -398,7 +417,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     }
     int max_rows = 0;
     for (int i = 0; i < nl; ++i) max_rows = std::max(max_rows, lv[i].h - 2 * lv[i].border);
-    // tiles of the extremum count pass: 64 columns x 16 rows of a level's interior, the levels one after another
+    // tiles of the extremum count pass: 64 columns x 64 rows of a level's interior (kernels_akaze.hip kAkMaskRows = 16 rows per wave), the levels one after another
     AkTileTable tiles;
     uint32_t n_tiles = 0;
     for (int i = 0; i < 17; ++i) tiles.begin[i] = 0xFFFFFFFFu;
@@ -406,7 +425,7 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
     for (int i = 0; i < nl; ++i) {
         tiles.begin[i] = n_tiles;
         const int rows_i = std::max(0, lv[i].h - 2 * lv[i].border), words_i = std::max(0, (lv[i].w - 2 * lv[i].border + 63) / 64);
-        n_tiles += (uint32_t)words_i * (uint32_t)((rows_i + 15) / 16);
+        n_tiles += (uint32_t)words_i * (uint32_t)((rows_i + 63) / 64);
     }
     // slot capacity per image: a strict 3x3 maximum excludes its eight neighbours, so a level holds at most ceil(w/2) ceil(h/2)
     // candidates; start from min(that bound, 256 k) and grow only if an image reports more (the bound itself never overflows)

@@ -446,6 +446,10 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
         for (uint32_t k = 0; k < NI; ++k) total_kept += h_cnt[k];
         g->matches.reserve(total_kept);
     }
+    const bool mirror = c->device_graphs;
+    if (mirror) { g->dev.valid = true; g->dev.device = c->device; }
+    std::vector<uint32_t> m_ids, m_cnts;
+    std::vector<GraphSeg> m_segs;
     for (uint32_t k = 0; k < NI; ++k) {
         // GeometricFilter_{F,H}Matrix_AC: accept iff #inliers > 2.5 * MINIMUM_SAMPLES
         if ((double)h_cnt[k] <= 2.5 * SS) continue;
@@ -464,9 +468,14 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
             for (uint32_t q = 0; q < h_cnt[k]; ++q) dst[q] = src[ix[q]];
         }
         g->offsets.push_back(g->matches.size());
+        if (mirror) {      // r3dm_set_device_graphs: the same inliers gathered on the device (putative matches through the inlier indices)
+            m_ids.push_back(putative->pairs[2 * p]); m_ids.push_back(putative->pairs[2 * p + 1]); m_cnts.push_back(h_cnt[k]);
+            m_segs.push_back(GraphSeg{base, soff[k], g->offsets[g->offsets.size() - 2], h_cnt[k], 0});
+        }
         if (F_out) memcpy(F_out + 9 * kept, h_F.data() + 9 * (size_t)k, 72);
         ++kept;
     }
+    if (mirror) (void)graph_dev_append(c, g.get(), m_ids, m_cnts, m_segs, fp.matches, B.f_inl_idx.as<uint32_t>());
     o.ms_wall = now_ms() - t_call;
     o.pending = nullptr;
     *out = g.release();

@@ -68,12 +68,21 @@ int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_str
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
 
     if (g) {
+        // r3dm_set_device_graphs: the same pairs, in the same order, into the graph's device mirror straight from d_out (no payload byte
+        // of the mirror crosses PCIe: ids and counts are 12 bytes per pair of host-side bookkeeping)
+        const bool mirror = c->device_graphs && (g->dev.valid || (g->pairs.empty() && g->dev.P == 0));
+        if (mirror && !g->dev.valid) { g->dev.valid = true; g->dev.device = c->device; }
+        std::vector<uint32_t> ids, cnts;
+        std::vector<GraphSeg> segs;
+        uint64_t dst = 0;
         for (uint32_t p = 0; p < P; ++p) {
             if (h_cnt[p] == 0) continue;                   // empty vectors never enter the map
             g->pairs.push_back(jobs[p].I); g->pairs.push_back(jobs[p].J);
             g->matches.insert(g->matches.end(), h_m + h_off[p], h_m + h_off[p] + h_cnt[p]);
             g->offsets.push_back(g->matches.size());
+            if (mirror) { ids.push_back(jobs[p].I); ids.push_back(jobs[p].J); cnts.push_back(h_cnt[p]); segs.push_back(GraphSeg{h_off[p], 0, dst, h_cnt[p], 0}); dst += h_cnt[p]; }
         }
+        if (mirror) (void)graph_dev_append(c, g, ids, cnts, segs, c->d_out.as<r3dm_match>(), nullptr);
     }
     return R3DM_OK;
 }
@@ -189,9 +198,16 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         R3DM_HIP(c, hipStreamSynchronize(c->stream));      // (the finaliser would wait here anyway; keeps the wall breakdown honest)
     } else if (has_tensor_kernel(first.G)) {
+        bool counts_ran = false;
         if (counts) {
-            R3DM_HIP(c, launch_l2_knn2_counts(c->stream, mp, first.G, max_tiles, r3dm_dev_knob("R3DM_COUNTS_TWO_LISTS", 0)));
-            c->stats.n_split_mfma += 1; c->stats.n_counts_mfma += 1;
+            // hipErrorInvalidValue = no count kernel for this launch (descriptor length, or a grid beyond the launcher's bound): the split
+            // tiles, which every such view also holds, serve the batch
+            const hipError_t ec = launch_l2_knn2_counts(c->stream, mp, first.G, max_tiles, r3dm_dev_knob("R3DM_COUNTS_TWO_LISTS", 0));
+            if (ec == hipErrorInvalidValue) (void)hipGetLastError();
+            else { R3DM_HIP(c, ec); counts_ran = true; c->stats.n_split_mfma += 1; c->stats.n_counts_mfma += 1; }
+        }
+        if (counts_ran) {
+            // (launched above)
         } else if (split) {
             R3DM_HIP(c, launch_l2_knn2_split(c->stream, mp, first.G, max_tiles));
             c->stats.n_split_mfma += 1;
@@ -555,6 +571,16 @@ int ensure_ann_indices(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t K)
     std::vector<uint32_t> todo;
     for (uint32_t s : slots) if (c->imgs[s]->ann_K != K) todo.push_back(s);
     if (todo.empty()) return R3DM_OK;
+    // The index is the EXACT K-NN graph (+ reverse edges): an all-pairs scan of the view against itself, O(n^2 dim) -- 1.1-4.4 ms per
+    // 16 k-row view, the right builder at every size BASELINE names, and the wrong one far beyond: at R3DM_KGRAPH_MAX_ROWS rows it is
+    // ~0.3 s per view and grows fourfold per doubling.  The reference's NN-descent (kgraph.cpp:703-999) is not built here; a larger view
+    // is refused by name rather than indexed silently in quadratic time (the exhaustive matcher serves it: r3dm_match_pairs).
+    for (uint32_t s : todo)
+        if (c->imgs[s]->n > R3DM_KGRAPH_MAX_ROWS) {
+            c->err = "kgraph index: view of " + std::to_string(c->imgs[s]->n) + " rows exceeds R3DM_KGRAPH_MAX_ROWS (" + std::to_string(R3DM_KGRAPH_MAX_ROWS) +
+                     "): the exact K-NN graph build is quadratic in the rows";
+            return R3DM_ERR_UNSUPPORTED;
+        }
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     size_t start = 0;
     while (start < todo.size()) {

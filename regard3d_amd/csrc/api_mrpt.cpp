@@ -72,6 +72,25 @@ static void mrpt_random_matrix(uint32_t n_pool, uint32_t dim, float density, uin
         }
 }
 // count_first_leaf_indices (mrpt.h:1664-1672)
+// rows the query kernel may elect for an index view of n rows (run_mrpt_batch sizes the elected list with it)
+static uint32_t mrpt_elected_cap(uint32_t n, uint32_t n_trees, uint32_t depth, uint32_t votes)
+{
+    // rows that can reach the lowest threshold used (votes, then votes - 1): every elected row holds that many of the n_trees x max_leaf votes
+    const uint64_t max_leaf = n / (1u << depth) + 1u;
+    const uint64_t bound = std::min<uint64_t>(n, (uint64_t)n_trees * max_leaf / std::max<uint32_t>(votes > 1 ? votes - 1 : 1, 1u));
+    return (uint32_t)bound + 64u;
+}
+// LDS one wavefront of mrpt_query_kernel needs for such a view (kernels_mrpt.hip: launch_mrpt_query, the same formula): the vote bytes
+// (n) and the elected list do not fit the CU's 160 KB for every view the index itself admits -- with the reference's preset from
+// ~115 k rows on, with votes <= 2 much sooner.  Views beyond it are matched exhaustively (recall 1), like views too small for a forest.
+static bool mrpt_query_fits_lds(uint32_t n, const r3dm_mrpt_params& mp)
+{
+    const uint32_t depth = mrpt_depth_for(n, mp.depth);
+    const size_t pool_pad = ((size_t)mp.n_trees * depth + 63u) / 64u * 64u;
+    const size_t per_wave = (pool_pad * 4 + 256 * 4 + 8 + (size_t)mrpt_elected_cap(n, mp.n_trees, depth, mp.votes) * 4 + (size_t)((n + 3u) / 4u) * 4 + 15) / 16 * 16;
+    return per_wave <= 160u * 1024u;
+}
+
 static void mrpt_leaf_sizes(uint32_t n, uint32_t level, uint32_t depth, std::vector<int32_t>& out)
 {
     if (level == depth) { out.push_back((int32_t)n); return; }
@@ -157,10 +176,7 @@ static int run_mrpt_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float r
         max_nJ = std::max(max_nJ, c->imgs[j.sJ]->n);
         n_queries += c->imgs[j.sJ]->n;
         max_pool = std::max(max_pool, I.mrpt_trees * I.mrpt_depth);
-        // rows that can reach the lowest threshold used (votes, then votes - 1): every elected row holds that many of the n_trees x max_leaf votes
-        const uint64_t max_leaf = I.n / (1u << I.mrpt_depth) + 1u;
-        const uint64_t bound = std::min<uint64_t>(I.n, (uint64_t)I.mrpt_trees * max_leaf / std::max<uint32_t>(votes > 1 ? votes - 1 : 1, 1u));
-        elected_cap = std::max<uint32_t>(elected_cap, (uint32_t)bound + 64u);
+        elected_cap = std::max<uint32_t>(elected_cap, mrpt_elected_cap(I.n, I.mrpt_trees, I.mrpt_depth, votes));
     }
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
     const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));
@@ -194,7 +210,7 @@ static int run_mrpt_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float r
     R3DM_HIP(c, hipEventRecord(c->ev0, c->stream));
     R3DM_HIP(c, hipMemsetAsync(c->d_cnt.p, 0, 64, c->stream));
     hipError_t e = launch_mrpt_query(c->stream, qp, max_nJ, max_nI, max_pool);
-    if (e == hipErrorInvalidValue) { c->err = "MRPT query: the view's vote table exceeds the LDS (more than 131,072 rows?)"; return R3DM_ERR_UNSUPPORTED; }
+    if (e == hipErrorInvalidValue) { c->err = "MRPT query: vote bytes + elected list of the largest index view of the batch exceed the 160 KB of LDS a wavefront can have"; return R3DM_ERR_UNSUPPORTED; }
     R3DM_HIP(c, e);
     unsigned long long comps = 0;
     R3DM_HIP(c, hipMemcpyAsync(&comps, qp.n_comps, 8, hipMemcpyDeviceToHost, c->stream));
@@ -234,7 +250,7 @@ static int r3dm_match_pairs_mrpt_impl(r3dm_ctx* c, const uint32_t* pairs_ij, uin
         if (A.n == 0 || B.n == 0 || A.dtype != B.dtype || A.dim != B.dim) continue;
         if (A.dtype == R3DM_BIN || !mrpt_dim_ok(A.dim)) { c->err = "MRPT matching needs F32/U8 descriptors of a length that is a multiple of 4, at most 512"; return R3DM_ERR_UNSUPPORTED; }
         if (A.n > (1u << 17)) { c->err = "MRPT matching: more than 131,072 rows in one view"; return R3DM_ERR_UNSUPPORTED; }
-        if (A.n < kAnnMinRows) small_jobs.push_back({I, J, a->second, b->second});    // a forest over a handful of rows: such views are scanned
+        if (A.n < kAnnMinRows || !mrpt_query_fits_lds(A.n, *mp)) small_jobs.push_back({I, J, a->second, b->second});    // a forest over a handful of rows, or a view whose vote table no wavefront's LDS holds: such views are scanned
         else ann_jobs.push_back({I, J, a->second, b->second});
     }
     auto by_pair = [](const PairJob& x, const PairJob& y) { return x.I != y.I ? x.I < y.I : x.J < y.J; };
@@ -297,6 +313,7 @@ extern "C" int r3dm_mrpt_knn2(r3dm_ctx* c, const float* dataset, uint32_t n_data
         if (!mrpt_dim_ok(dim)) { c->err = "MRPT matching needs descriptors of a length that is a multiple of 4, at most 512"; return R3DM_ERR_UNSUPPORTED; }
         if (n_dataset < kAnnMinRows) { c->err = "r3dm_mrpt_knn2: fewer than 128 rows (such views are scanned: r3dm_knn2)"; return R3DM_ERR_UNSUPPORTED; }
         if (n_dataset > (1u << 17)) { c->err = "MRPT matching: more than 131,072 rows in one view"; return R3DM_ERR_UNSUPPORTED; }
+        if (!mrpt_query_fits_lds(n_dataset, *mp)) { c->err = "r3dm_mrpt_knn2: the vote table of this many rows exceeds a wavefront's LDS with these parameters (such views are scanned: r3dm_knn2)"; return R3DM_ERR_UNSUPPORTED; }
         R3DM_HIP(c, hipSetDevice(c->device));
         const uint32_t s0 = (uint32_t)c->imgs.size();
         c->imgs.emplace_back(new HostImage());

@@ -621,6 +621,46 @@ void ak_fed_march_kernel(const float* __restrict__ Lt, const float* __restrict__
     else fed_march_strip<K, false, AkWaveOps>(Lt, Lf, out, w, h, tau, x_first, y0, y1);
 }
 
+// ---- Gaussian + both derivative images + determinant + conductivity of a level in ONE pass: level_head.inc (control flow shared with
+// the CPU emulation tests/cpp/level_head_emul.cpp).  A wavefront = a strip of 64 columns marching down a band of rows with its
+// intermediate rows in LDS rings; four strips per workgroup, no workgroup barrier.
+}  // namespace r3dm
+#include "level_head.inc"
+namespace r3dm {
+struct AkHeadOps : AkWaveOps {
+    using Lds = float*;
+    static __device__ __forceinline__ VI col_clamp(VI x, int off, int w, int x_first) { return ak_clamp(ak_clamp(x + off, 0, w - 1) - x_first, -16, 79); }
+    static __device__ __forceinline__ VI col_refl(VI x, int off, int w, int x_first) { return ak_clamp(ak_refl101(x + off, w) - x_first, -16, 79); }
+    static __device__ __forceinline__ void lds_store(Lds l, int at, VF v) { l[at + (int)(threadIdx.x & 63u)] = v; }
+    static __device__ __forceinline__ VF lds_load(Lds l, int at, VI idx) { return l[at + idx]; }
+    static __device__ __forceinline__ VF lds_load_off(Lds l, int at, int off) { return l[at + (int)(threadIdx.x & 63u) + off]; }
+    static __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    static __device__ __forceinline__ VF adds(VF a, float b) { return a + b; }
+    static __device__ __forceinline__ VF neg(VF a) { return -a; }
+    static __device__ __forceinline__ VF rcp_div(float a, VF b) { return a / b; }
+};
+template <int S>
+__global__ __launch_bounds__(256)
+void ak_level_head_kernel(const float* __restrict__ src, float* __restrict__ Lx, float* __restrict__ Ly, float* __restrict__ Ldet, float* __restrict__ flow,
+                          int w, int h, AkTaps kf, const float* __restrict__ inv_k2_p, int rows_per_band)
+{
+    using G = LevelHeadGeom<S>;
+    __shared__ float rings[4][G::FLOATS];
+    src = AK_PLANE(src, w, h); Lx = AK_PLANE(Lx, w, h); Ly = AK_PLANE(Ly, w, h); Ldet = AK_PLANE(Ldet, w, h); flow = AK_PLANE(flow, w, h);
+    const float inv_k2 = inv_k2_p[(size_t)blockIdx.z * kAkSmallWords];        // 1 / k^2 of this octave, left on the device by ak_kcontrast_kernel
+    const int wave = (int)(threadIdx.x >> 6);
+    const int strip = (int)blockIdx.x * 4 + wave;
+    if (strip * G::VW >= w) return;                        // (wave-uniform: no workgroup barrier in this kernel)
+    const int x_first = strip * G::VW - G::H;
+    const int y0 = (int)blockIdx.y * rows_per_band, y1 = y0 + rows_per_band < h ? y0 + rows_per_band : h;
+    float k5[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) k5[k] = kf.k[k];
+    const bool edge = x_first < 0 || x_first + 63 > w - 1;
+    if (edge) level_head_strip<S, true, AkHeadOps>(src, Lx, Ly, Ldet, flow, w, h, k5, inv_k2, x_first, y0, y1, rings[wave]);
+    else level_head_strip<S, false, AkHeadOps>(src, Lx, Ly, Ldet, flow, w, h, k5, inv_k2, x_first, y0, y1, rings[wave]);
+}
+
 // ---- halfsample: INTER_AREA, exact 2x (resizeAreaFast_) or fractional cells (ResizeArea_, tables from the host)
 __global__ __launch_bounds__(256)
 void ak_half_fast_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int sh, int dw, int dh)
@@ -660,15 +700,19 @@ __device__ __forceinline__ bool ak_is_extremum(const float* __restrict__ ldet, i
     if (v <= next[x - 1] || v <= next[x] || v <= next[x + 1]) return false;
     return true;
 }
-// The count pass: a workgroup owns a tile of 64 columns x 16 rows of ONE level's interior (every lane a column, every wave 4 rows;
+// The count pass: a workgroup owns a tile of 64 columns x 64 rows of ONE level's interior (every lane a column, every wave 16 rows;
 // the 18 values a lane needs are loaded before anything is compared), blockIdx.x = tile over all levels (AkTileTable: where the
 // tiles of each level begin), blockIdx.y = image.  The outcome of the 3 x 3 test is kept as one bit per pixel (a 64-bit ballot per
 // 64 pixels, L.mask: 1/32 of the image) next to the per-row counts; after the scan of the counts and the device-side slot layout the
 // emit pass reads only the bit masks and the determinant at the set bits -- no second sweep over the image, no barrier anywhere
 // (the two-sweep, two-barriers-per-256-pixels form took 1.4 ms per call for eight 12 Mpx images, a wave-per-row sweep 1.0 ms).
+// (Tile = 64 columns x 64 rows since round 5: a wave owns 16 rows and has the 54 loads of its 18 input rows in flight at once.  With
+// 16-row tiles the launch was 471 k workgroups of two dependent memory round trips each -- bound by workgroup turnover at 1 TB/s.)
+constexpr int kAkMaskRows = 16;                         // rows per wavefront of the extremum count pass (tile = 4 x that)
 __global__ __launch_bounds__(256)
 void ak_extrema_mask_kernel(const AkLevelDev* __restrict__ levels, int n_levels, AkTileTable tt, float thr)
 {
+    constexpr int RW = kAkMaskRows;
     const uint32_t t = blockIdx.x;
     int li = 0;
 #pragma unroll
@@ -677,22 +721,22 @@ void ak_extrema_mask_kernel(const AkLevelDev* __restrict__ levels, int n_levels,
     const uint32_t local = t - tt.begin[li];
     const int tx = (int)(local % L.mask_words), ty = (int)(local / L.mask_words);
     const int rows = L.h - 2 * L.border, lane = threadIdx.x & 63;
-    const int row0 = ty * 16 + (int)(threadIdx.x >> 6) * 4;
+    const int row0 = ty * (4 * RW) + (int)(threadIdx.x >> 6) * RW;
     if (row0 >= rows) return;                                              // wave-uniform
     const int x = L.border + tx * 64 + lane;
     const bool valid_x = x < L.w - L.border;
     const int xc = valid_x ? x : L.border;
     const float* __restrict__ ldet = L.Ldet;
-    float v[6][3];
+    float v[RW + 2][3];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < RW + 2; ++j) {
         int yy = L.border + row0 - 1 + j;
         yy = yy < L.h - 1 ? yy : L.h - 1;
         const float* __restrict__ P = ldet + ((uint32_t)yy * (uint32_t)L.w + (uint32_t)xc);
         v[j][0] = P[-1]; v[j][1] = P[0]; v[j][2] = P[1];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RW; ++j) {
         const int row = row0 + j;
         const float c = v[j + 1][1];
         // ak_is_extremum: `if (v <= n) return false` for the threshold and the eight neighbours
@@ -1376,6 +1420,18 @@ hipError_t ak_fed_march(hipStream_t st, const float* Lt, const float* Lf, float*
         case 3: hipLaunchKernelGGL(ak_fed_march_kernel<3>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
         default: hipLaunchKernelGGL(ak_fed_march_kernel<4>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
     }
+    return hipGetLastError();
+}
+// start image -> Lx, Ly, Ldet, conductivity of a level (5-tap Gaussian, derivative scale s in 2 .. 4, at least 16 x 16 pixels)
+hipError_t ak_level_head(hipStream_t st, const float* src, float* Lx, float* Ly, float* Ldet, float* flow, int w, int h, int B, const AkTaps& kf, int s,
+                         const float* inv_k2, int rows_per_band)
+{
+    if (kf.n != 5 || s < 2 || s > 4 || w < 16 || h < 16 || rows_per_band < 1) return hipErrorInvalidValue;
+    const int vw = 64 - 2 * (2 + 2 * s), strips = (w + vw - 1) / vw;
+    const dim3 grid((unsigned)((strips + 3) / 4), (unsigned)((h + rows_per_band - 1) / rows_per_band), (unsigned)B);
+    if (s == 2) hipLaunchKernelGGL(ak_level_head_kernel<2>, grid, dim3(256), 0, st, src, Lx, Ly, Ldet, flow, w, h, kf, inv_k2, rows_per_band);
+    else if (s == 3) hipLaunchKernelGGL(ak_level_head_kernel<3>, grid, dim3(256), 0, st, src, Lx, Ly, Ldet, flow, w, h, kf, inv_k2, rows_per_band);
+    else hipLaunchKernelGGL(ak_level_head_kernel<4>, grid, dim3(256), 0, st, src, Lx, Ly, Ldet, flow, w, h, kf, inv_k2, rows_per_band);
     return hipGetLastError();
 }
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,

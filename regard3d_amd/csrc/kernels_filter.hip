@@ -965,7 +965,11 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     // array): workgroups that share a CU -- and with it the vector L1 -- never share a cache line of data one of them is
     // still writing
     const uint64_t so = P.soff[item];
-    double* __restrict__ pt = pts + 4 * so;
+    // The positions of a pair's matches as the four FLOATS the views hold, 16 bytes per match (the first half of the slot a match has in
+    // the points scratch): every reader re-forms the normalised f64 coordinates with the two operations that used to fill a 32-byte
+    // record of doubles (bit-identical).  Round 4's PMC had this kernel fetch 7.4 GB per launch for 47 MB of input: two workgroups per
+    // CU, 64 per XCD, each re-reading ~59 KB per model = the 4 MiB of an XCD's L2.  Half the footprint stays inside it.
+    float4* __restrict__ pt = reinterpret_cast<float4*>(pts + 4 * so);
     uint32_t* __restrict__ pool = pool_g + so;
     uint32_t* __restrict__ inl = P.inl_idx + so;
     float* __restrict__ logc_n = logc_g + so;                 // m + 1 entries
@@ -981,10 +985,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     if (KIND == 2 && tid < 18) S.kinv[tid] = P.kinv[9 * (size_t)(tid < 9 ? sl.x : sl.y) + (tid < 9 ? tid : tid - 9)];
     for (uint32_t p = tid; p < m; p += NT) {
         const r3dm_match q = mm[p];
-        const double xi = (double)Ip->xy[2 * (size_t)q.i], yi = (double)Ip->xy[2 * (size_t)q.i + 1];
-        const double xj = (double)Jp->xy[2 * (size_t)q.j], yj = (double)Jp->xy[2 * (size_t)q.j + 1];
-        pt[4 * p + 0] = s1 * xi + t1x; pt[4 * p + 1] = s1 * yi + t1y;
-        pt[4 * p + 2] = s2 * xj + t2x; pt[4 * p + 3] = s2 * yj + t2y;
+        pt[p] = make_float4(Ip->xy[2 * (size_t)q.i], Ip->xy[2 * (size_t)q.i + 1], Jp->xy[2 * (size_t)q.j], Jp->xy[2 * (size_t)q.j + 1]);
         pool[p] = p;
     }
     const double Dd = sqrt((double)wJ * (double)wJ + (double)hJ * (double)hJ);
@@ -1059,8 +1060,9 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 FCHECK(pos[k < (int)SS ? k : 0] < pool_size, 1, pos[k < (int)SS ? k : 0], pool_size);
                 FCHECK(sidx_ < m, 2, sidx_, m);
                 if (R3DM_DBG(P) && sidx_ >= m) sidx_ = 0;
-                px1[k][0] = pt[4 * (size_t)sidx_ + 0]; px1[k][1] = pt[4 * (size_t)sidx_ + 1];
-                px2[k][0] = pt[4 * (size_t)sidx_ + 2]; px2[k][1] = pt[4 * (size_t)sidx_ + 3];
+                const float4 f4 = pt[sidx_];
+                px1[k][0] = s1 * (double)f4.x + t1x; px1[k][1] = s1 * (double)f4.y + t1y;
+                px2[k][0] = s2 * (double)f4.z + t2x; px2[k][1] = s2 * (double)f4.w + t2y;
                 if (KIND == 2) {                 // camera coordinates: hnormalized(K^-1 (x, y, 1))
                     const double xa = px1[k][0], ya = px1[k][1], xb = px2[k][0], yb = px2[k][1];
                     const double w1 = K1i[6] * xa + K1i[7] * ya + K1i[8];
@@ -1135,7 +1137,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 // set do not depend on it)
                 // (S.cnt and the histogram are zero here: cleared once at kernel start and again at the end of every model, behind the
                 // barrier that closes it -- one barrier less per model than clearing them here)
-                // four batches of 256 matches per trip: the point loads (global memory, 32 bytes per match) of all four are in
+                // four batches of 256 matches per trip: the point loads (global memory, 16 bytes per match) of all four are in
                 // flight before the first residual is needed
                 for (uint32_t base = 0; base < m; base += 4u * NT) {
                     double r[4]; bool in[4];
@@ -1143,9 +1145,9 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const uint32_t p = base + (uint32_t)NT * (uint32_t)u + tid;
-                        const size_t pp = 4 * (size_t)(p < m ? p : 0u);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) px[u][e] = pt[pp + e];
+                        const float4 f4 = pt[p < m ? p : 0u];
+                        px[u][0] = s1 * (double)f4.x + t1x; px[u][1] = s1 * (double)f4.y + t1y;
+                        px[u][2] = s2 * (double)f4.z + t2x; px[u][3] = s2 * (double)f4.w + t2y;
                     }
                     unsigned long long bal[4];
                     uint32_t n_new = 0;

@@ -1060,10 +1060,14 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
 // 2.2 % of one another inside a class): the quad test of the kernel bounds four keys with the largest scale of their four rows, and
 // with rows in keypoint order (scales 30 % apart) that bound let a large share of the quads through to the per-key path.
 // One workgroup: counting sort of the rows by scale class -> cperm[position] = row (kNone behind the last row).
+// The rows of a class keep their keypoint order (a stable sort): the atomic cursors place them in whatever order the waves arrive, so a
+// second sweep ranks every row inside its class segment by row index -- which rows share a tile, and with it which queries the epilogue
+// sends to the exact scan, is then the same from run to run (the results are exact either way).  `tmp`: n_pad words of scratch.
 __global__ __launch_bounds__(1024)
-void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm)
+void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm, uint32_t* __restrict__ tmp)
 {
     __shared__ uint32_t hist[8192];
+    __shared__ uint32_t start[8192];
     __shared__ uint32_t part[1024];
     const uint32_t tid = threadIdx.x;
     for (uint32_t b = tid; b < 8192u; b += 1024u) hist[b] = 0u;
@@ -1083,9 +1087,18 @@ void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uin
     }
     const uint32_t base = part[tid] - run;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) hist[tid * 8u + (uint32_t)k] = base + loc[k];          // cursors
+    for (int k = 0; k < 8; ++k) { hist[tid * 8u + (uint32_t)k] = base + loc[k]; start[tid * 8u + (uint32_t)k] = base + loc[k]; }          // cursors
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024u) cperm[atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u)] = r;
+    for (uint32_t r = tid; r < n; r += 1024u) tmp[atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u)] = r;
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += 1024u) {
+        const uint32_t cls = (__float_as_uint(cscale[r]) >> 18) & 8191u;
+        const uint32_t s0 = start[cls], s1 = hist[cls];
+        uint32_t rank = 0;
+        for (uint32_t q = s0; q < s1; ++q) rank += tmp[q] < r ? 1u : 0u;
+        cperm[s0 + rank] = r;
+    }
     for (uint32_t r = n + tid; r < n_pad; r += 1024u) cperm[r] = kNone;
 }
 
@@ -1131,7 +1144,8 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
 {
     if (n_tiles == 0 || dim > 256u) return hipSuccess;
     hipLaunchKernelGGL(stage_counts_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, GB, tiledc, cscale, fail_dev);
-    hipLaunchKernelGGL(stage_counts_order_kernel, dim3(1), dim3(1024), 0, st, cscale, n, n_tiles * 32u, cperm);
+    // (the ordered tiles are written by the gather kernel behind this one: until then their first n_pad words are the order kernel's scratch)
+    hipLaunchKernelGGL(stage_counts_order_kernel, dim3(1), dim3(1024), 0, st, cscale, n, n_tiles * 32u, cperm, reinterpret_cast<uint32_t*>(tiledp));
     hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow,
                        crow + counts_summary_offset(n_tiles));
     return hipGetLastError();

@@ -124,6 +124,9 @@ struct HostImage {
     }
 };
 
+int graph_dev_append(r3dm_ctx* c, r3dm_graph* g, const std::vector<uint32_t>& pair_ids, const std::vector<uint32_t>& counts, std::vector<GraphSeg>& segs,
+                     const r3dm_match* src, const uint32_t* idx);      // api_core.cpp
+
 inline uint32_t kernel_G_for(uint32_t dim)
 {
     const uint32_t g = (dim + 7) / 8;
@@ -149,10 +152,26 @@ inline bool has_ext(const char* path, const char* ext)
 }
 
 
+// The same CSR in device memory, kept beside the host vectors when the context was asked to (r3dm_set_device_graphs): what
+// r3dm_allgather_graphs puts on the wire without a host round trip of the payload (api_comm.cpp).  Filled where the data already is
+// on the device: by the gather kernels behind the match finalisation and the filters (kernels_graph.hip).
+struct GraphDev {
+    DevBuf pairs, counts, matches;    // u32 [2 P], u32 [P], r3dm_match [M]
+    uint64_t P = 0, M = 0;
+    int device = -1;
+    bool valid = false;
+    void release() { pairs.release(); counts.release(); matches.release(); P = M = 0; valid = false; device = -1; }
+};
+
 struct r3dm_graph {
     std::vector<uint32_t> pairs;      // 2 per pair
     std::vector<uint64_t> offsets;    // n_pairs + 1
     std::vector<r3dm_match> matches;
+    GraphDev dev;                     // optional device mirror (never copied with the graph)
+    r3dm_graph() = default;
+    r3dm_graph(const r3dm_graph&) = delete;
+    r3dm_graph& operator=(const r3dm_graph&) = delete;
+    ~r3dm_graph() { dev.release(); }
 };
 
 struct FilterBufs {
@@ -217,6 +236,8 @@ struct r3dm_ctx {
     bool integer_mfma = false;                              // r3dm_set_integer_mfma
     bool split_mfma = false;                                // r3dm_set_split_mfma
     bool hamming_mfma = false;                              // r3dm_set_hamming_mfma
+    bool device_graphs = false;                             // r3dm_set_device_graphs: match / filter results keep a device mirror (GraphDev)
+    DevBuf g_segs;                                          // segment table of the graph gather kernel (kernels_graph.hip)
     uint32_t liop_npix = 0;
     uint64_t n_views_staged = 0;                            // copies + re-layouts since r3dm_create (never reset)
     r3dm_stats stats{};

@@ -348,6 +348,8 @@ hipError_t ak_modg_max(hipStream_t st, const float* src, int w, int h, int B, ui
 hipError_t ak_modg_hist(hipStream_t st, const float* src, int w, int h, int B, const uint32_t* hmax_bits, int nbins, uint32_t* hist);
 hipError_t ak_fed_step(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, float step_size);
 hipError_t ak_fed_multi(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps);
+hipError_t ak_level_head(hipStream_t st, const float* src, float* Lx, float* Ly, float* Ldet, float* flow, int w, int h, int B, const AkTaps& kf, int s,
+                         const float* inv_k2, int rows_per_band);
 hipError_t ak_fed_march(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps, int rows_per_band);
 hipError_t ak_halfsample(hipStream_t st, const float* src, float* dst, int w, int h, int B, const AkAreaTab* xt, const int* xb,
                          const AkAreaTab* yt, const int* yb);
@@ -407,6 +409,10 @@ hipError_t launch_ann_rows8(hipStream_t st, const float* rows, uint8_t* rows8, s
 // img_of (optional): image of the batch each keypoint belongs to -- its pixels start img_of[k] * w * h floats into `image`
 hipError_t launch_liop_extract(hipStream_t st, const float* image, int w, int h, const float* M6, const float* kern,
                                uint32_t n, float* patches, const uint32_t* img_of = nullptr);
+// one contiguous run of matches of the graph gather kernel (kernels_graph.hip): element offsets into src / idx / dst
+struct GraphSeg { uint64_t src, idx, dst; uint32_t cnt, pad; };
+hipError_t launch_graph_gather(hipStream_t st, const r3dm_match* src, const uint32_t* idx, const GraphSeg* segs, uint32_t n_segs, r3dm_match* dst);
+
 // geometry tables of the 41 x 41 LIOP patch (api_features.cpp: liop_prepare), all in device memory
 struct LiopTables {
     const int* pix;            // [n_pix] support pixels in scan order, as offsets into the zero-ringed 43 x 43 patch

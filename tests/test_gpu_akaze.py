@@ -76,6 +76,27 @@ def test_live_set_overflow_falls_back_to_scratch(ctx, tmp_path):
     assert np.array_equal(np.load(str(tmp_path / "k.npy")), kps) and np.array_equal(np.load(str(tmp_path / "r.npy")), resp)
 
 
+@pytest.mark.parametrize("env", [{"R3DM_AK_HEAD": "1"}, {"R3DM_AK_FED_MARCH": "0"}, {"R3DM_AK_FED_MARCH": "0", "R3DM_AK_FED_MULTI": "0"},
+                                 {"R3DM_AK_FED_KMAX": "2", "R3DM_AK_FED_WAVES": "300"}])
+def test_alternative_launch_forms_of_the_scale_space_are_bit_identical(ctx, tmp_path, env):
+    """The scale space has several launch forms of the same arithmetic: FED steps riding one pass in registers (the product), one step per
+    launch, four steps through LDS; the level head as four launches (the product) or as one marching pass with LDS rings
+    (R3DM_AK_HEAD=1, measured slower).  The developer build selects them by environment; keypoints and responses must not move."""
+    import os, subprocess, sys
+    img = _scene(700, 900, 5)
+    kps, resp = ctx.detect_akaze(img, 1e-5)
+    assert len(kps) > 1000
+    np.save(str(tmp_path / "img.npy"), img)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np; from regard3d_amd import api; api.use_developer_library(); "
+            f"c = api.Context(0); k, r = c.detect_akaze(np.load({str(tmp_path / 'img.npy')!r}), 1e-5); "
+            f"np.save({str(tmp_path / 'k.npy')!r}, k); np.save({str(tmp_path / 'r.npy')!r}, r)")
+    r = subprocess.run([sys.executable, "-c", code], env=dict({k: v for k, v in os.environ.items() if not k.startswith("R3DM_")}, **env),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(str(tmp_path / "k.npy")), kps) and np.array_equal(np.load(str(tmp_path / "r.npy")), resp)
+
+
 def test_blank_and_tiny_images(ctx):
     kps, _ = ctx.detect_akaze(np.full((300, 400), 0.3, np.float32))
     assert len(kps) == 0

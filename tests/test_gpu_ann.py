@@ -216,3 +216,25 @@ def test_drop_indices_forces_a_rebuild_with_the_same_result(ctx):
     assert (built0, built1, built2) == (3, 0, 3)
     for g in (g1, g2):
         assert np.array_equal(g.pairs, g0.pairs) and np.array_equal(g.offsets, g0.offsets) and np.array_equal(g.matches, g0.matches)
+
+
+def test_graph_index_refuses_views_beyond_its_row_bound(ctx):
+    """The index is the exact K-NN graph, quadratic in the rows of a view: beyond R3DM_KGRAPH_MAX_ROWS (131,072) the library says
+    so instead of indexing silently (the reference's NN-descent builder, src/thirdparty/kgraph/kgraph.cpp:703-999, is not built);
+    the exhaustive matcher still serves such a view."""
+    n = 131072 + 32
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 255, (n, 8)).astype(np.float32)
+    small = big[:256].copy()
+    xy = rng.uniform(0, 3000, (n, 2)).astype(np.float32)      # (distinct positions: matches at one position are one match to the reference)
+    ctx.clear_images()
+    ctx.set_image(0, big, xy, 4000, 3000); ctx.set_image(1, small, xy[:256], 4000, 3000)
+    with pytest.raises(api.R3dmError, match="R3DM_KGRAPH_MAX_ROWS"):
+        ctx.kgraph_index(0, n)
+    with pytest.raises(api.R3dmError, match="R3DM_KGRAPH_MAX_ROWS"):
+        ctx.match_pairs_kgraph(np.array([[0, 1]], np.uint32), 0.6, api.KGraphParams.preset("default"))
+    adj, deg = ctx.kgraph_index(1, 256)                    # a view inside the bound next to it is indexed as ever
+    assert deg.min() >= 1
+    g = ctx.match_pairs(np.array([[0, 1]], np.uint32), 0.6, True)
+    assert g.num_pairs == 1 and g.num_matches >= 200      # rows 0..255 of the big view are the small view's own rows
+    ctx.clear_images()
