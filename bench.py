@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS) + ["stage"], default="c2")
     ap.add_argument("--stage-size", default="4000x3000", help="--config stage: image size WxH")
-    ap.add_argument("--stage-features", default="2x8", help="--config stage: detector batches in flight x images per batch")
+    ap.add_argument("--stage-features", default="3x8", help="--config stage: detector batches in flight x images per batch")
     ap.add_argument("--stage-quick", action="store_true", help="--config stage: the timed steps only (no arm re-runs, rooflines or CPU leg): tuning runs")
     ap.add_argument("--images", type=int, default=0, help="override the collection size of the config (stated in config.workload)")
     ap.add_argument("--feat", type=int, default=0, help="override the features per image of the config")

@@ -129,7 +129,7 @@ public:
     // false: every view goes through its .feat / .desc files, as in the reference (default true: views computed in this call are
     // registered with the matcher from device memory -- the same values, without the file system and PCIe round trip)
     void setDirectRegistration(bool on) { direct_registration_ = on; }
-    // detector batches in flight per device and images per batch of the features stage (defaults 2 x 8)
+    // detector batches in flight per device and images per batch of the features stage (defaults 3 x 8)
     void setFeaturesConcurrency(int batches_in_flight, int images_per_batch) { feat_conc_ = batches_in_flight; feat_batch_ = images_per_batch; }
 
     bool computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,
@@ -167,7 +167,7 @@ private:
     uint64_t seed_ = 5489;
     std::vector<int> devices_;             // the device list this facade was built with
     r3dm_multi* feat_multi_ = nullptr;     // contexts of the features stage (feat_conc_ per device), created on first use
-    int feat_conc_ = 2, feat_batch_ = 8;
+    int feat_conc_ = 3, feat_batch_ = 8;      // (round 5: with the detector and LIOP kernels at 59 ms per 24 images the host part of a batch is no longer hidden by two)
     ArmsPolicy arms_policy_ = kArmsFastest;
     bool last_exhaustive_ = true, last_hnsw_ = false, last_mrpt_ = false;
     // views registered with the matcher straight from the features stage (r3dm_set_features_sink): descriptors device to device,

@@ -121,7 +121,7 @@ class Stage:
         self._h, self._L = h.value, L
 
     def run(self, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6, matching_algorithm: int = 9, compute_F: bool = True,
-            compute_E: bool = True, compute_H: bool = True, seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8,
+            compute_E: bool = True, compute_H: bool = True, seed: int = 5489, batches_in_flight: int = 3, images_per_batch: int = 8,
             arms_as_requested: bool = False, split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False) -> StageReport:
         keep = []
         arr = _stage_views(views, keep)
@@ -147,7 +147,7 @@ class Stage:
 
 def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6,
                           matching_algorithm: int = 9, compute_F: bool = True, compute_E: bool = True, compute_H: bool = True,
-                          seed: int = 5489, batches_in_flight: int = 2, images_per_batch: int = 8, arms_as_requested: bool = False,
+                          seed: int = 5489, batches_in_flight: int = 3, images_per_batch: int = 8, arms_as_requested: bool = False,
                           split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False) -> StageReport:
     """R3DComputeMatches::computeMatches from pixels (r3dm_compute_matches_stage): features stage for the views whose .feat/.desc
     are missing, matching, F / E / H filters, match files.  views: dicts with id, width, height, basename and optionally

@@ -1061,15 +1061,20 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
 // with rows in keypoint order (scales 30 % apart) that bound let a large share of the quads through to the per-key path.
 // One workgroup: counting sort of the rows by scale class -> cperm[position] = row (kNone behind the last row).
 // The rows of a class keep their keypoint order (a stable sort): the atomic cursors place them in whatever order the waves arrive, so a
-// second sweep ranks every row inside its class segment by row index -- which rows share a tile, and with it which queries the epilogue
-// sends to the exact scan, is then the same from run to run (the results are exact either way).  `tmp`: n_pad words of scratch.
+// second kernel ranks every row inside its class segment by row index, one thread per row over the whole chip -- which rows share a
+// tile, and with it which queries the epilogue sends to the exact scan, is then the same from run to run (the results are exact
+// either way).  scratch: n_pad words (rows of a class, unordered) + 2 n_pad words (every row's class segment).
+// (Ranking inside this one-workgroup kernel was tried first: a view's rows fall into a few hundred classes, 14 M serial reads per view,
+// +115 ms on the stage's 24 views.)
 __global__ __launch_bounds__(1024)
-void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm, uint32_t* __restrict__ tmp)
+void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm, uint32_t* __restrict__ scratch)
 {
     __shared__ uint32_t hist[8192];
     __shared__ uint32_t start[8192];
     __shared__ uint32_t part[1024];
     const uint32_t tid = threadIdx.x;
+    uint32_t* __restrict__ tmp = scratch;
+    uint2* __restrict__ seg = reinterpret_cast<uint2*>(scratch + n_pad);
     for (uint32_t b = tid; b < 8192u; b += 1024u) hist[b] = 0u;
     __syncthreads();
     for (uint32_t r = tid; r < n; r += 1024u) atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u);    // sign 0: exponent + 5 mantissa bits
@@ -1090,16 +1095,20 @@ void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uin
     for (int k = 0; k < 8; ++k) { hist[tid * 8u + (uint32_t)k] = base + loc[k]; start[tid * 8u + (uint32_t)k] = base + loc[k]; }          // cursors
     __syncthreads();
     for (uint32_t r = tid; r < n; r += 1024u) tmp[atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u)] = r;
-    __threadfence_block();
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024u) {
-        const uint32_t cls = (__float_as_uint(cscale[r]) >> 18) & 8191u;
-        const uint32_t s0 = start[cls], s1 = hist[cls];
-        uint32_t rank = 0;
-        for (uint32_t q = s0; q < s1; ++q) rank += tmp[q] < r ? 1u : 0u;
-        cperm[s0 + rank] = r;
-    }
+    for (uint32_t r = tid; r < n; r += 1024u) { const uint32_t cls = (__float_as_uint(cscale[r]) >> 18) & 8191u; seg[r] = make_uint2(start[cls], hist[cls]); }
     for (uint32_t r = n + tid; r < n_pad; r += 1024u) cperm[r] = kNone;
+}
+__global__ __launch_bounds__(256)
+void stage_counts_rank_kernel(uint32_t n, uint32_t n_pad, const uint32_t* __restrict__ scratch, uint32_t* __restrict__ cperm)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t* __restrict__ tmp = scratch;
+    const uint2 sg = reinterpret_cast<const uint2*>(scratch + n_pad)[r];
+    uint32_t rank = 0;
+    for (uint32_t q = sg.x; q < sg.y; ++q) rank += tmp[q] < r ? 1u : 0u;
+    cperm[sg.x + rank] = r;
 }
 
 // (the quad summaries of the ordered tiles live behind the row lines in the same allocation: r3dm_internal.hpp counts_summary_offset)
@@ -1144,8 +1153,10 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
 {
     if (n_tiles == 0 || dim > 256u) return hipSuccess;
     hipLaunchKernelGGL(stage_counts_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, GB, tiledc, cscale, fail_dev);
-    // (the ordered tiles are written by the gather kernel behind this one: until then their first n_pad words are the order kernel's scratch)
+    // (the ordered tiles are written by the gather kernel behind these two: until then their first 3 n_pad words -- 12 of the >= 128 bytes a
+    // row has there -- are the order kernels' scratch)
     hipLaunchKernelGGL(stage_counts_order_kernel, dim3(1), dim3(1024), 0, st, cscale, n, n_tiles * 32u, cperm, reinterpret_cast<uint32_t*>(tiledp));
+    hipLaunchKernelGGL(stage_counts_rank_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, n, n_tiles * 32u, reinterpret_cast<const uint32_t*>(tiledp), cperm);
     hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow,
                        crow + counts_summary_offset(n_tiles));
     return hipGetLastError();
@@ -1602,6 +1613,8 @@ hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t 
         case 8:  return variant ? launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles) : launch_l2_counts2_t<4, 4>(st, P, max_nj_tiles);
         case 16: return variant ? launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles) : launch_l2_counts2_t<8, 8>(st, P, max_nj_tiles);
         case 18: return variant ? launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles) : launch_l2_counts2_t<9, 9>(st, P, max_nj_tiles);
+        // (256 dimensions stay on the two-list kernel, one query tile per wave: l2_knn2_counts2_kernel<16, 8> -- 128 registers of query
+        //  fragments -- compiles with its fragment array indexed through scratch memory, 528 bytes per lane, round 5)
         case 32: return launch_l2_counts_t<16, 1, 8>(st, P, max_nj_tiles);
         default: return hipErrorInvalidValue;
     }
