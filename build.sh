@@ -8,9 +8,9 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 WHAT=${1:-all}
-SRC="kernels_match.hip kernels_filter.hip kernels_filter_e.hip kernels_filter_coop.hip kernels_liop.hip kernels_ann.hip kernels_hnsw.hip kernels_mrpt.hip kernels_akaze.hip kernels_graph.hip api_core.cpp api_match.cpp api_hnsw.cpp api_mrpt.cpp api_filter.cpp api_features.cpp api_multi.cpp api_comm.cpp compute_matches.cpp"
+SRC="kernels_match.hip kernels_match_16bit.hip kernels_match_hamming.hip kernels_match_exact.hip kernels_filter.hip kernels_filter_e.hip kernels_filter_coop.hip kernels_liop.hip kernels_ann.hip kernels_hnsw.hip kernels_mrpt.hip kernels_akaze.hip kernels_graph.hip api_core.cpp api_match.cpp api_hnsw.cpp api_mrpt.cpp api_filter.cpp api_features.cpp api_multi.cpp api_comm.cpp compute_matches.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fopenmp -Wall -Wno-unused-result -Iinclude"
-HDRS="regard3d_amd/csrc/*.hpp include/*.h include/*.hpp"
+HDRS="regard3d_amd/csrc/*.hpp regard3d_amd/csrc/*.inc include/*.h include/*.hpp"
 # kernels_filter.hip (wg_fence) orders global-memory exchanges INSIDE a workgroup with a workgroup-scope fence: valid only while the
 # waves of a workgroup share a CU and its L1, i.e. never in threadgroup-split mode
 case " $HIPCC $FLAGS $HIPCC_FLAGS $CXXFLAGS " in *tgsplit*) echo "build.sh: -mtgsplit is not supported (kernels_filter.hip: wg_fence)"; exit 1;; esac

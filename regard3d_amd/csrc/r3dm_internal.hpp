@@ -373,6 +373,9 @@ hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint
                             uint32_t* bin, uint32_t words, uint32_t n_pad);
 // returns hipErrorInvalidValue when (G, dtype) has no tensor kernel; caller falls back to the exact scan
 hipError_t launch_l2_knn2(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, bool integer_mfma = false);
+// (between the translation units of the matcher: the bf16 launcher, hipErrorNotSupported = no such kernel for this G; the LDS-shared developer variants)
+hipError_t launch_l2_knn2_int(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
+hipError_t launch_l2_int_lds_variant(hipStream_t st, const MatchParams& P, uint32_t max_nj_tiles, int iv);
 hipError_t launch_hamming_mfma(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_nj_tiles);
 hipError_t launch_stage_bin8(hipStream_t st, const uint32_t* bin, uint32_t n, uint32_t words, uint32_t n_tiles, uint8_t* tiled8, float* norms);
 hipError_t launch_l2_knn2_split(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles);
