@@ -93,7 +93,11 @@ def stage_main(a, embed=None, cpu_baseline_fn=None):
                      "housekeeping_ms_per_step": housekeeping / n_steps * 1e3,
                      "keypoints_per_image": last["n_keypoints"] / N,
                      "putative_pairs": int(last["n_putative_pairs"]), "putative_matches": int(last["n_putative_matches"]), "F_matches": int(last["n_F_matches"]),
-                     "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_match_kernels", "ms_match_post", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")}}
+                     "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_match_kernels", "ms_match_post", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")},
+                     # in situ = inside the timed step, with the other batches in flight beside them: HIP-event time per image, summed over the features contexts
+                     "features_in_situ": {"detector_kernels_ms_per_image": last["features"]["ms_detect_kernels"] / N, "liop_kernels_ms_per_image": last["features"]["ms_liop_kernels"] / N,
+                                          "liop_kernels_ms_per_28k_keypoints": last["features"]["ms_liop_kernels"] / max(last["n_keypoints"], 1) * 28000.0,
+                                          "kernel_sum_ms": last["features"]["ms_detect_kernels"] + last["features"]["ms_liop_kernels"], "wall_ms": mean("ms_features")}}
             if embed:
                 return quick
             print(json.dumps(quick))
@@ -131,6 +135,10 @@ def stage_main(a, embed=None, cpu_baseline_fn=None):
             "phases_note": "filter_F / _E / _H run side by side on the one device (r3dm_filter_FEH): they overlap, filters_wall is their sum in the total",
             "kernels_ms": {"match": mean("ms_match_kernels"), "match_post_wall": mean("ms_match_post"), "F": mean("ms_F_kernels"), "E": mean("ms_E_kernels"), "H": mean("ms_H_kernels"),
                            "detector_sum_over_contexts": last["features"]["ms_detect_kernels"], "liop_sum_over_contexts": last["features"]["ms_liop_kernels"]},
+            "features_in_situ": {"detector_kernels_ms_per_image": last["features"]["ms_detect_kernels"] / N, "liop_kernels_ms_per_image": last["features"]["ms_liop_kernels"] / N,
+                                 "liop_kernels_ms_per_28k_keypoints": last["features"]["ms_liop_kernels"] / max(last["n_keypoints"], 1) * 28000.0,
+                                 "kernel_sum_ms": last["features"]["ms_detect_kernels"] + last["features"]["ms_liop_kernels"], "wall_ms": mean("ms_features"),
+                                 "note": "HIP-event time inside the timed step with the other batches in flight beside them, summed over the features contexts"},
             "features": {"images_per_s": N / (mean("ms_features") * 1e-3), "ms_per_image": mean("ms_features") / N, "keypoints": int(last["n_keypoints"]),
                          "keypoints_per_image": last["n_keypoints"] / N, "file_ms_sum_over_contexts": last["features"]["ms_files"],
                          "detector_passes": int(last["features"]["n_passes"]), "regrows": int(last["features"]["n_regrows"])},

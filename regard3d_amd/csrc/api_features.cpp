@@ -297,7 +297,10 @@ static int ak_detect_batch(r3dm_ctx* c, uint32_t B, const float* const* images, 
                 // LAUNCH instead of per step).  The older forms stay for the developer build's A/B runs: one step per launch
                 // (R3DM_AK_FED_MARCH=0 R3DM_AK_FED_MULTI=0), four steps through LDS on the levels of <= 3.2 Mpx (R3DM_AK_FED_MARCH=0).
                 static const int march_knob = r3dm_dev_knob("R3DM_AK_FED_MARCH", 1);      // 0 = never, 1 = every level, > 1 = levels of at least that many pixels
-                static const int march_kmax = std::min(4, std::max(1, r3dm_dev_knob("R3DM_AK_FED_KMAX", 4)));
+                // steps per launch: up to 4 on the large levels (a step there is bound by the arithmetic of its cells, more per pass only
+                // widens the halo), up to 6 below 1 Mpx per image, where a launch is mostly its own latency and fewer launches is the gain
+                static const int kmax_knob = r3dm_dev_knob("R3DM_AK_FED_KMAX", 0);
+                const int march_kmax = kmax_knob > 0 ? std::min(6, kmax_knob) : (n < (size_t)1000000 ? 6 : 4);
                 static const int march_waves = std::max(256, r3dm_dev_knob("R3DM_AK_FED_WAVES", 12000));
                 const bool march = march_knob && lw >= 3 && lh >= 3 && (march_knob == 1 || n >= (size_t)march_knob);
                 static const int multi_knob = r3dm_dev_knob("R3DM_AK_FED_MULTI", 1);      // developer build: 0 = never, 1 = the product, > 1 = that many pixels

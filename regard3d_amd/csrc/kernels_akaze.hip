@@ -515,7 +515,7 @@ void ak_fed_step_kernel(const float* __restrict__ Lt, const float* __restrict__ 
 // cells at least s from the halo's edge are exact -- and writes its tile.  Every cell update is the expression of
 // ak_fed_step_kernel with the same border cases (decided by the cell's position in the IMAGE), so the result is bit-identical;
 // the halo cells are simply updated twice (here and by the neighbouring tile).
-struct AkFedSteps { float tau[4]; int n; };
+struct AkFedSteps { float tau[6]; int n; };
 __global__ __launch_bounds__(256)
 void ak_fed_multi_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ out, int w, int h, AkFedSteps st)
 {
@@ -727,6 +727,9 @@ void ak_extrema_mask_kernel(const AkLevelDev* __restrict__ levels, int n_levels,
     const bool valid_x = x < L.w - L.border;
     const int xc = valid_x ? x : L.border;
     const float* __restrict__ ldet = L.Ldet;
+    // (the neighbours' columns from the adjacent lanes by DPP wave shifts -- two loads per pixel row instead of three -- measured the
+    // same 519 us, and a third form that loaded the outer column under `if (lane == 0 || lane == 63)` 926 us: the pass is bound by
+    // the latency of its ~77 rounds of workgroups over 0.68 GB of cold determinant planes, not by its load instructions)
     float v[RW + 2][3];
 #pragma unroll
     for (int j = 0; j < RW + 2; ++j) {
@@ -1114,6 +1117,8 @@ __global__ __launch_bounds__(64)
 void ak_refine_kernel(const AkLevelDev* __restrict__ levels, int n_levels)
 {
     __shared__ float resX[112], resY[112];
+    __shared__ uint32_t scnt[48], sstart[48];
+    __shared__ unsigned char sinv[128];
     const AkLevelDev* __restrict__ Lb = levels + (size_t)blockIdx.y * n_levels;
     const int lane = threadIdx.x;
     uint32_t pre[17];
@@ -1173,19 +1178,51 @@ void ak_refine_kernel(const AkLevelDev* __restrict__ levels, int n_levels)
             rxs[q] = wgt * L.Lx[p]; rys[q] = wgt * L.Ly[p];
             key[q] = k < 109 ? (int)(ak_fast_atan2(rys[q], rxs[q]) / ang_step) : -1;
         }
-        // counting sort by angle slice without touching LDS: for every slice one ballot per sample row gives its population, the
-        // start of the slice (running sum) and, for the lanes holding one of its samples, the sample's slot
-        // start + count - 1 - #{earlier samples of the slice} -- what the reference's "--slice[key]" loop produces
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        uint32_t pos0 = 0, pos1 = 0, my_start = 109, running = 0;
-        for (int kk = 0; kk <= slices; ++kk) {
-            const unsigned long long b0 = __ballot(key[0] == kk), b1 = __ballot(key[1] == kk);
-            const uint32_t c0 = (uint32_t)__builtin_popcountll(b0), c1 = (uint32_t)__builtin_popcountll(b1);
-            if (key[0] == kk) pos0 = running + (c0 + c1) - 1u - (uint32_t)__builtin_popcountll(b0 & lt);
-            if (key[1] == kk) pos1 = running + (c0 + c1) - 1u - (c0 + (uint32_t)__builtin_popcountll(b1 & lt));
-            if (lane == kk) my_start = running;
-            running += c0 + c1;
+        // counting sort by angle slice: sample i goes to start[key] + count[key] - 1 - #{j < i with the same key} (what the reference's
+        // "--slice[key]" loop produces).  #{j < i, same key} = the sample's place inside its slice in the order (key, i): a bitonic
+        // sort of the 128 composite keys (key << 8 | i), two per lane -- 28 compare-exchange steps, where one ballot pair per slice was 43
+        // rounds of scalar bookkeeping (half of this kernel's instructions); slice populations by LDS atomics, their prefix by a lane scan.
+        if (lane < 48) scnt[lane] = 0u;
+        r3dm_syncthreads();
+        uint32_t e0 = ((uint32_t)key[0] << 8) | (uint32_t)lane;                                   // sample lane (always one of the 109)
+        uint32_t e1 = key[1] >= 0 ? (((uint32_t)key[1] << 8) | (uint32_t)(lane + 64)) : (0xFF00u | (uint32_t)(lane + 64));
+        atomicAdd(&scnt[key[0]], 1u);
+        if (key[1] >= 0) atomicAdd(&scnt[key[1]], 1u);
+#pragma unroll
+        for (int size = 2; size <= 128; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                if (stride == 64) {                                  // (size 128: the lane's own pair, ascending)
+                    const uint32_t lo = e0 < e1 ? e0 : e1, hi = e0 < e1 ? e1 : e0;
+                    e0 = lo; e1 = hi;
+                } else {
+                    const bool lower = (lane & stride) == 0;
+                    const uint32_t o0 = (uint32_t)__shfl_xor((int)e0, stride), o1 = (uint32_t)__shfl_xor((int)e1, stride);
+                    // element index = lane + 64 q: bit `size` of it decides the direction (size 64: q itself; size 128: always up)
+                    const bool up0 = size >= 64 ? true : (lane & size) == 0;
+                    const bool up1 = size == 64 ? false : (size == 128 ? true : (lane & size) == 0);
+                    const uint32_t mn0 = e0 < o0 ? e0 : o0, mx0 = e0 < o0 ? o0 : e0, mn1 = e1 < o1 ? e1 : o1, mx1 = e1 < o1 ? o1 : e1;
+                    e0 = (lower == up0) ? mn0 : mx0;
+                    e1 = (lower == up1) ? mn1 : mx1;
+                }
+            }
         }
+        // sorted position p = lane + 64 q holds sample (e & 0xFF): tell that sample where it stands
+        sinv[e0 & 0xFFu] = (unsigned char)lane;
+        sinv[e1 & 0xFFu] = (unsigned char)(lane + 64);
+        r3dm_syncthreads();
+        uint32_t my_start = 109;
+        {
+            const uint32_t c = lane <= (uint32_t)slices ? scnt[lane] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += o; }
+            if (lane <= (uint32_t)slices) { my_start = incl - c; sstart[lane] = incl - c; }
+        }
+        r3dm_syncthreads();
+        const uint32_t pos0 = 2u * sstart[key[0]] + scnt[key[0]] - 1u - (uint32_t)sinv[lane];
+        const uint32_t k1 = key[1] >= 0 ? (uint32_t)key[1] : 0u;
+        const uint32_t pos1 = 2u * sstart[k1] + scnt[k1] - 1u - (uint32_t)sinv[lane + 64];
         resX[pos0] = rxs[0]; resY[pos0] = rys[0];
         if (key[1] >= 0) { resX[pos1] = rxs[1]; resY[pos1] = rys[1]; }
         r3dm_syncthreads();
@@ -1404,11 +1441,11 @@ hipError_t ak_fed_multi(hipStream_t st, const float* Lt, const float* Lf, float*
     hipLaunchKernelGGL(ak_fed_multi_kernel, dim3((unsigned)((w + 31) / 32), (unsigned)((h + 31) / 32), (unsigned)B), dim3(256), 0, st, Lt, Lf, out, w, h, fs);
     return hipGetLastError();
 }
-// n_steps <= 4 FED steps tau[0..n) in one register-marching pass (any level of at least 3 x 3 pixels); n_waves_hint = wavefronts the
+// n_steps <= 6 FED steps tau[0..n) in one register-marching pass (any level of at least 3 x 3 pixels); n_waves_hint = wavefronts the
 // launch should at least have (rows per band are chosen for it: fewer rows per band = more wavefronts, more halo rows per output row)
 hipError_t ak_fed_march(hipStream_t st, const float* Lt, const float* Lf, float* out, int w, int h, int B, const float* tau, int n_steps, int rows_per_band)
 {
-    if (n_steps < 1 || n_steps > 4 || w < 3 || h < 3 || rows_per_band < 1) return hipErrorInvalidValue;
+    if (n_steps < 1 || n_steps > 6 || w < 3 || h < 3 || rows_per_band < 1) return hipErrorInvalidValue;
     AkFedSteps fs{};
     for (int k = 0; k < n_steps; ++k) fs.tau[k] = tau[k];
     fs.n = n_steps;
@@ -1418,7 +1455,9 @@ hipError_t ak_fed_march(hipStream_t st, const float* Lt, const float* Lf, float*
         case 1: hipLaunchKernelGGL(ak_fed_march_kernel<1>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
         case 2: hipLaunchKernelGGL(ak_fed_march_kernel<2>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
         case 3: hipLaunchKernelGGL(ak_fed_march_kernel<3>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
-        default: hipLaunchKernelGGL(ak_fed_march_kernel<4>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
+        case 4: hipLaunchKernelGGL(ak_fed_march_kernel<4>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
+        case 5: hipLaunchKernelGGL(ak_fed_march_kernel<5>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
+        default: hipLaunchKernelGGL(ak_fed_march_kernel<6>, grid, dim3(256), 0, st, Lt, Lf, out, w, h, fs, rows_per_band); break;
     }
     return hipGetLastError();
 }

@@ -916,12 +916,10 @@ __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __
                     const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, r0 + k));
                     const float sa = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, 32 + r0 + k));
                     const float pk = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
-                    const float key = __builtin_fmaf(n2, cql, pk * sa);
-                    // usually ONE of the four keys of a quad that passed its bound changes a list: test each before its 12-instruction push.
-                    // A key that is >= d2 in every lane leaves (d0, d1, d2) and the rows alone and lowers d3 to min(d3, key) -- exactly what
-                    // the push would do with it (med3(d2, d3, key) for key >= d2), in one instruction.
-                    if (__builtin_amdgcn_ballot_w64(key < st.d2) != 0ull) top3m_push(st, key, rb + (uint32_t)k);
-                    else st.d3 = vmin2(st.d3, key);
+                    // (a per-key test before the push -- push only a key that some lane's list wants, else d3 = min(d3, key) -- was measured
+                    //  slower: 465 against 434-447 ms on liop144c, 70.0 against 66.6 ms on the stage's 276 pairs, round 5: the extra
+                    //  ballots and branches cost more than the 12-instruction pushes they skip)
+                    top3m_push(st, __builtin_fmaf(n2, cql, pk * sa), rb + (uint32_t)k);
                 }
             }
             // a lane whose own bound did not pass: its four keys are >= lb >= d2 (then and since), whether or not the wave pushed them

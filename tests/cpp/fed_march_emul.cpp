@@ -106,7 +106,7 @@ int main()
     for (auto& s : sizes)
         for (int R : {1, 5, 16, 64}) {
             bad += check<1>(s[0], s[1], R); bad += check<2>(s[0], s[1], R); bad += check<3>(s[0], s[1], R);
-            bad += check<4>(s[0], s[1], R); bad += check<5>(s[0], s[1], R);
+            bad += check<4>(s[0], s[1], R); bad += check<5>(s[0], s[1], R); bad += check<6>(s[0], s[1], R);
         }
     printf(bad ? "DIFFERENT (%d configurations)\n" : "identical\n", bad);
     return bad ? 1 : 0;
