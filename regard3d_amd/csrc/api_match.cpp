@@ -178,8 +178,8 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
     mp.err_scale = 4.25f * (float)(first.G * 8) * 5.9604645e-08f;
     // split-f16 keys: residue of the two-piece split 3 x 2^-22 ||a|| ||b|| <= 1.5 x 2^-22 (||a||^2 + ||b||^2), f32 accumulation of
     // 3 Dpad products + one C operand per MFMA with a one-sided 2^-23 per addition on partial sums <= 2 (||a||^2 + ||b||^2), plus the
-    // reference sum's own (D/2 + 12) 2^-24 -- together below (3 Dpad + 34) 2^-22 (kernels_match.hip, l2_knn2_split_kernel)
-    if (split) mp.err_scale = (3.0f * (float)(first.G * 8) + 34.0f) * 2.3841858e-07f;
+    // reference sum's own (D/2 + 12) 2^-24 -- together below (3 Dpad + 34) 2^-22, + 2 for the count kernel's bias (kernels_match.hip, l2_knn2_split_kernel)
+    if (split) mp.err_scale = (3.0f * (float)(first.G * 8) + 36.0f) * 2.3841858e-07f;      // (+ 2: the count kernel's keys carry ||b||^2 / (2 s_b) and drop it again)
     mp.nn_idx = c->d_nn.as<uint32_t>();
     mp.knn_idx = knn_idx_host ? c->d_knn_idx.as<int32_t>() : nullptr;
     mp.knn_dist = knn_idx_host ? c->d_knn_dist.as<float>() : nullptr;

@@ -220,7 +220,7 @@ hipError_t launch_l2_knn2_int(hipStream_t st, const MatchParams& P, uint32_t G, 
 // runs as three v_mfma_f32_32x32x16_f16 per 16 dimensions: 96 matrix cycles against 512 on the f32 tiles.  Products of f16
 // values are exact in f32, so the key differs from the exact one by the split residue (3 x 2^-22 ||a|| ||b||) plus the
 // f32 accumulation of 3 D products (bounded with a one-sided 2^-23 per addition, i.e. without assuming round-to-nearest
-// inside the matrix unit); host: MatchParams::err_scale = (3 Dpad + 34) 2^-22.  That is 3x the slack of the f32 tiles, which
+// inside the matrix unit); host: MatchParams::err_scale = (3 Dpad + 36) 2^-22.  That is 3x the slack of the f32 tiles, which
 // is why the tail (l2_finish_queries<SPLIT>) gives an uncertified query a second chance with the four nominees of its two
 // lane halves.  Results stay bit-identical to the oracle: certification or exact scan, as on the f32 tiles.
 // Layout: ImgDev::tiledh = [tile][16-dim block][hi | lo][lane half][32 rows][8 f16] -- 2 KiB per block, one contiguous
@@ -536,7 +536,7 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
 // with rows in keypoint order (scales 30 % apart) that bound let a large share of the quads through to the per-key path.
 // One workgroup: counting sort of the rows by scale class -> cperm[position] = row (kNone behind the last row).
 // The rows of a class keep their keypoint order (a stable sort): the atomic cursors place them in whatever order the waves arrive, so a
-// second kernel ranks every row inside its class segment by row index, one thread per row over the whole chip -- which rows share a
+// second kernel ranks every row inside its class segment by row index, one wavefront per row over the whole chip -- which rows share a
 // tile, and with it which queries the epilogue sends to the exact scan, is then the same from run to run (the results are exact
 // either way).  scratch: n_pad words (rows of a class, unordered) + 2 n_pad words (every row's class segment).
 // (Ranking inside this one-workgroup kernel was tried first: a view's rows fall into a few hundred classes, 14 M serial reads per view,
@@ -577,13 +577,16 @@ void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uin
 __global__ __launch_bounds__(256)
 void stage_counts_rank_kernel(uint32_t n, uint32_t n_pad, const uint32_t* __restrict__ scratch, uint32_t* __restrict__ cperm)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    // a wavefront per row: its lanes stride the class segment (one class can hold the whole view -- rows of one common scale)
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (r >= n) return;
     const uint32_t* __restrict__ tmp = scratch;
     const uint2 sg = reinterpret_cast<const uint2*>(scratch + n_pad)[r];
     uint32_t rank = 0;
-    for (uint32_t q = sg.x; q < sg.y; ++q) rank += tmp[q] < r ? 1u : 0u;
-    cperm[sg.x + rank] = r;
+    for (uint32_t q = sg.x + lane; q < sg.y; q += 64u) rank += tmp[q] < r ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) rank += (uint32_t)__shfl_xor((int)rank, o);
+    if (lane == 0) cperm[sg.x + rank] = r;
 }
 
 // (the quad summaries of the ordered tiles live behind the row lines in the same allocation: r3dm_internal.hpp counts_summary_offset)
@@ -631,7 +634,7 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
     // (the ordered tiles are written by the gather kernel behind these two: until then their first 3 n_pad words -- 12 of the >= 128 bytes a
     // row has there -- are the order kernels' scratch)
     hipLaunchKernelGGL(stage_counts_order_kernel, dim3(1), dim3(1024), 0, st, cscale, n, n_tiles * 32u, cperm, reinterpret_cast<uint32_t*>(tiledp));
-    hipLaunchKernelGGL(stage_counts_rank_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, n, n_tiles * 32u, reinterpret_cast<const uint32_t*>(tiledp), cperm);
+    hipLaunchKernelGGL(stage_counts_rank_kernel, dim3((n + 3u) / 4u), dim3(256), 0, st, n, n_tiles * 32u, reinterpret_cast<const uint32_t*>(tiledp), cperm);
     hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow,
                        crow + counts_summary_offset(n_tiles));
     return hipGetLastError();
@@ -832,34 +835,13 @@ void l2_knn2_counts_kernel(const MatchParams P)
 //
 // With one list per query the shared tail's second chance would have two nominees where the two half-lists gave it four (measured:
 // 4 x the queries in the exact scan).  So the list here also carries the THIRD-best row and a lower bound d3 of every key that is
-// none of the three (Top3m below): the tail re-scores three rows and certifies against d3 -- a handful of exact scans where the
-// two-list kernel needs hundreds (reference-built LIOP fixture: 6 of 8,192 queries against 45; 80 views x 8,192 rows: 22 of 25.9 M
-// against 850), and the kernel itself is 5 % faster (13 % without the third row's bookkeeping).  R3DM_COUNTS_TWO_LISTS=1 in the
-// developer build runs l2_knn2_counts_kernel instead (tools/counts_one_list_probe.py).  (hipcc 7.2 folds repeated
-// __builtin_amdgcn_permlane32_swap calls with different operands into one -- wrong code -- hence the inline assembly with its own
-// wait states below.)
-// ------------------------------------------------------------------------------------------------
-// the list of a query in this kernel: the two nominees and the third-best key (d2: the bound of the first certification, as in Top2)
-// PLUS the third-best row (i2) and a lower bound of every key that is none of the three (d3): the tail's second chance re-scores
-// three rows and certifies against d3.  d3 = min over (a) the keys pushed out of, or never into, the three -- exactly -- and (b) the
-// lower bounds of the quads that were skipped (>= d2 at the time, so >= every d2 since).
-struct Top3m { float d0, d1, d2, d3; uint32_t i0, i1, i2; };
-__device__ __forceinline__ void top3m_init(Top3m& s) { s.d0 = s.d1 = s.d2 = s.d3 = R3DM_INF; s.i0 = s.i1 = s.i2 = kNone; }
-__device__ __forceinline__ void top3m_push(Top3m& s, float key, uint32_t idx)
-{
-    const float od0 = s.d0, od1 = s.d1, od2 = s.d2, od3 = s.d3;
-    const uint32_t oi0 = s.i0, oi1 = s.i1, oi2 = s.i2;
-    const bool c0 = key < od0, c1 = key < od1, c2 = key < od2;
-    s.d3 = __builtin_amdgcn_fmed3f(od2, od3, key);         // min(d3, max(d2, key)): what falls out of the three (d2 <= d3 always)
-    s.d2 = __builtin_amdgcn_fmed3f(od1, od2, key);
-    s.d1 = __builtin_amdgcn_fmed3f(od0, od1, key);
-    s.d0 = __builtin_amdgcn_fmed3f(-R3DM_INF, od0, key);
-    const uint32_t t2 = c2 ? idx : oi2, t1 = c1 ? idx : oi1;
-    s.i2 = c1 ? oi1 : t2;
-    s.i1 = c0 ? oi0 : t1;
-    s.i0 = c0 ? idx : oi0;
-}
-
+// none of the three: the tail re-scores three rows and certifies against d3 -- a handful of exact scans where the two-list kernel
+// needs hundreds.  R3DM_COUNTS_TWO_LISTS=1 in the developer build runs l2_knn2_counts_kernel instead
+// (tools/counts_one_list_probe.py).  (hipcc 7.2 folds repeated __builtin_amdgcn_permlane32_swap calls with different operands into
+// one -- wrong code -- hence the inline assembly with its own wait states below.)
+// d3 = min over (a) the keys pushed out of, or never into, the three -- exactly -- and (b) the lower bounds of the quads that were
+// skipped (>= d2 at the time, so >= every d2 since).
+//
 typedef const __attribute__((address_space(4))) float* cf32p;         // constant address space -> SMEM loads (a tile's sixteen quad summaries)
 
 // v_permlane32_swap_b32: the upper lane half of `a` <-> the lower lane half of `b`   (a' = [a.lo | b.lo], b' = [a.hi | b.hi])
@@ -867,10 +849,53 @@ typedef const __attribute__((address_space(4))) float* cf32p;         // constan
 //  own builtin and cannot for an asm statement)
 __device__ __forceinline__ void swap_lane_halves(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 
+// The list is held as PACKED words (round 5; round 4 kept four float keys and three row indices per query: thirteen VALU
+// instructions per push -- four medians, three comparisons, six selects -- and 72.3 ms where this form takes 63.6 on 3,160 pairs of
+// 8,192 rows).  A wave of 64 lists takes the push path for
+// ~3 of the 8 quads of every tile -- 64 queries x a top-3 list change with probability 3 / (rows seen) per row: the share is the
+// statistics of the problem, not a loose bound.  Here a key carries its row in its own low bits: key' = key + ||b||^2 / (2 s_b) is
+// the squared distance in key units (>= 0 up to rounding, so its float bits order like integers), the low B = ceil(log2(padded
+// rows)) mantissa bits are replaced by the row index (v_and_or_b32), and the list is four v_med3_i32 / v_min_i32 on such words:
+// five instructions per key instead of thirteen, no index registers.  What the truncation costs is resolution between keys closer
+// than 2^(B-23) relative (2^-10 at 8,192 rows): which of two such rows is nominated is then decided by their indices, and the bounds
+// handed to the tail are the words with the index bits cleared -- truncated DOWN, so every certification stays a proof; a query
+// whose runner-up is that close to its third- and fourth-best rows goes to the exact scan as before, just more often
+// (tests/test_gpu_count_tiles.py counts them).
+struct Top3p { int d0, d1, d2, d3; };
+__device__ __forceinline__ int imed3(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int imin2(int a, int b) { int r; asm("v_min_i32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void top3p_push(Top3p& s, float key, uint32_t idx, int nmask)
+{
+    int k;                                                  // (key & nmask) | (idx & ~nmask): one v_bfi_b32 ("tile -1" has rows below zero: +inf keys, any index)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(k) : "v"(nmask), "v"(key), "s"(idx));
+    s.d3 = imed3(s.d2, s.d3, k);                            // what falls out of the three (d2 <= d3 always)
+    s.d2 = imed3(s.d1, s.d2, k);
+    s.d1 = imed3(s.d0, s.d1, k);
+    s.d0 = imin2(s.d0, k);
+}
+
+// the four registers of an accumulator quad of both query tiles -> one query per lane: four v_permlane32_swap_b32 behind ONE
+// pair of wait states (the swaps touch disjoint registers; what the wait covers is a VALU write of an operand just before
+//  -- as four statements, the first with the wait states: one statement with eight in-out operands makes the register allocator
+//  shuffle the accumulator registers through copies; tests/test_build_hazards.py checks in the built code that no swap has a VALU
+//  write of one of its operands in the two instructions before it)
+__device__ __forceinline__ void swap_lane_halves_first(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_lane_halves_next(float& a, float& b) { asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// min of four products that are all <= +0 (counts are non-negative and the query fragments carry the sign): on such floats the
+// UNSIGNED integer order is the reversed float order (+0 < -0 < ... < -inf), so the minimum is one v_max3_u32 + one v_max_u32 --
+// integer instructions, which the compiler emits itself (a float minimum of matrix results costs a canonicalising v_max each, and the
+// inline-assembly v_min3_f32 that avoids those is followed by a wait state the hazard recogniser adds behind every asm statement)
+__device__ __forceinline__ float min4_nonpositive(float p0, float p1, float p2, float p3)
+{
+    const uint32_t a = __builtin_bit_cast(uint32_t, p0), b = __builtin_bit_cast(uint32_t, p1), c = __builtin_bit_cast(uint32_t, p2), d = __builtin_bit_cast(uint32_t, p3);
+    return __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(a, b), c), d));
+}
+
 template <int GB, int PF>
-__device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rr, uint32_t voffA, uint32_t voffR,
+__device__ __forceinline__ void counts_tile_step_p(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rr, uint32_t voffA, uint32_t voffR,
                                                    uint32_t soffA, uint32_t soffR, f32x4 (&abuf)[PF], float& rowv_load, float rowv_prev, cf32p sum_prev,
-                                                   const f32x4 (&bq)[2][GB], float cql, f32x16 (&cur)[2], f32x16 (&prev)[2], Top3m& st, uint32_t prev_rowbase)
+                                                   const f32x4 (&bq)[2][GB], float cql, float cbl, int nmask,
+                                                   f32x16 (&cur)[2], f32x16 (&prev)[2], Top3p& st, uint32_t prev_rowbase)
 {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int rv = __builtin_bit_cast(int, rowv_prev);
@@ -880,7 +905,8 @@ __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
         const f32x4 a = abuf[g % PF];
-        abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
+        // block g + PF of the stream: 1 KiB each; three of four offsets ride in the instruction's immediate field
+        abuf[g % PF] = bload16(ra, voffA + (uint32_t)(g & 3) * 1024u, soffA + (uint32_t)(g >> 2) * 4096u);
         if (g == (GB > 2 ? 2 : GB - 1))
             rowv_load = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)voffR, (int)soffR, 0));
 #pragma unroll
@@ -898,17 +924,17 @@ __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float lo = prev[0][4 * qd + k], hi = prev[1][4 * qd + k];
-                    swap_lane_halves(lo, hi);
+                    if (k == 0) swap_lane_halves_first(lo, hi); else swap_lane_halves_next(lo, hi);
                     prev[0][4 * qd + k] = lo;               // rows 8 qd + k      (lane half 0 of both tiles)
                     prev[1][4 * qd + k] = hi;               // rows 8 qd + 4 + k  (lane half 1 of both tiles)
                 }
             }
             const float p0 = prev[hp][4 * qd], p1 = prev[hp][4 * qd + 1], p2 = prev[hp][4 * qd + 2], p3 = prev[hp][4 * qd + 3];
-            const float pmin = vmin2(vmin3(p0, p1, p2), p3);
+            const float pmin = min4_nonpositive(p0, p1, p2, p3);
             const int r0 = 8 * qd + 4 * hp;
             const float n2min = sm[2 * qd + hp], smax = sm[8 + 2 * qd + hp];      // scalars (SMEM): rows r0 .. r0 + 3
-            const float lb = __builtin_fmaf(n2min, cql, pmin * smax);
-            const bool mine = lb < st.d2;
+            const int lb = __builtin_bit_cast(int, __builtin_fmaf(n2min, cql, __builtin_fmaf(pmin, smax, cbl)));
+            const bool mine = lb < st.d2;                   // (integer order = float order from 0 up; a rounding-negative bound passes)
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine) != 0ull, 0)) {
                 const uint32_t rb = prev_rowbase + (uint32_t)r0;
 #pragma unroll
@@ -916,21 +942,20 @@ __device__ __forceinline__ void counts_tile_step_m(__amdgpu_buffer_rsrc_t ra, __
                     const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, r0 + k));
                     const float sa = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(rv, 32 + r0 + k));
                     const float pk = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));
-                    // (a per-key test before the push -- push only a key that some lane's list wants, else d3 = min(d3, key) -- was measured
-                    //  slower: 465 against 434-447 ms on liop144c, 70.0 against 66.6 ms on the stage's 276 pairs, round 5: the extra
-                    //  ballots and branches cost more than the 12-instruction pushes they skip)
-                    top3m_push(st, __builtin_fmaf(n2, cql, pk * sa), rb + (uint32_t)k);
+                    top3p_push(st, __builtin_fmaf(n2, cql, __builtin_fmaf(pk, sa, cbl)), rb + (uint32_t)k, nmask);
                 }
             }
-            // a lane whose own bound did not pass: its four keys are >= lb >= d2 (then and since), whether or not the wave pushed them
-            st.d3 = vmin2(st.d3, mine ? R3DM_INF : lb);
+            // a lane whose own bound did not pass: its four keys are >= lb >= d2 (then and since), whether or not the wave pushed them.
+            // (One v_med3_i32(lb, d2, d3) instead -- d3 = d2 for a lane whose bound passed, which is what d3 becomes anyway when one
+            //  of the keys enters -- weakens d3 whenever a loose bound passes without an entry: 60 x the exact scans, measured.)
+            st.d3 = imin2(st.d3, mine ? 0x7F800000 : lb);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // the keys of the last tile (nothing multiplies behind it): all 32 rows of the lane's query
-__device__ __forceinline__ void counts_last_tile_m(f32x16 (&acc)[2], float rowv, float cql, Top3m& st, uint32_t rowbase)
+__device__ __forceinline__ void counts_last_tile_p(f32x16 (&acc)[2], float rowv, float cql, float cbl, int nmask, Top3p& st, uint32_t rowbase)
 {
     const int rvi = __builtin_bit_cast(int, rowv);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
@@ -943,7 +968,7 @@ __device__ __forceinline__ void counts_last_tile_m(f32x16 (&acc)[2], float rowv,
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hp;
             const float n2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(rvi, row));
             const float sa = -__builtin_bit_cast(float, __builtin_amdgcn_readlane(rvi, 32 + row));
-            top3m_push(st, __builtin_fmaf(n2, cql, (hp ? hi : lo) * sa), rowbase + (uint32_t)row);
+            top3p_push(st, __builtin_fmaf(n2, cql, __builtin_fmaf(hp ? hi : lo, sa, cbl)), rowbase + (uint32_t)row, nmask);
         }
     }
 }
@@ -975,7 +1000,13 @@ void l2_knn2_counts2_kernel(const MatchParams P)
     if (qt0 >= ntJ) return;                                // wave-uniform; no barriers in this kernel
 
     f32x4 bq[NJ][GB];
-    float cq[NJ], kinv[NJ];
+    float cql, cbl;                                        // this lane's query after the swap: (tile h, column c)
+    {
+        uint32_t qt = qt0 + h; if (qt >= ntJ) qt = ntJ - 1;
+        const uint32_t q = qt * 32u + c;
+        cql = 0.5f / (q < nJ ? Jp->cscale[q] : 1.0f);      // keys are in units of 2 s_b
+        cbl = (q < nJ ? Jp->norms[q] : 0.0f) * cql;         // ||b||^2 in key units: key + cb = the squared distance / (2 s_b)
+    }
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
@@ -987,14 +1018,12 @@ void l2_knn2_counts2_kernel(const MatchParams P)
             for (int k = 0; k < 4; ++k) w[k] ^= 0x80008000u;
             bq[nj][g] = __builtin_bit_cast(f32x4, w);
         }
-        const uint32_t q = qt * 32u + c;
-        const float sq = q < nJ ? Jp->cscale[q] : 1.0f;
-        kinv[nj] = 2.0f * sq;
-        cq[nj] = 1.0f / kinv[nj];
     }
-    const float cql = h ? cq[1] : cq[0];                   // this lane's query after the swap: (tile h, column c)
-    Top3m st;
-    top3m_init(st);
+    // the row index of a key lives in its low B bits; B from the padded row count of the dataset image (wave-uniform)
+    const uint32_t idx_mask = (2u << (31u - (uint32_t)__builtin_clz((ntI * 32u - 1u) | 1u))) - 1u;
+    const int nmask = (int)~idx_mask;
+    Top3p st;
+    st.d0 = st.d1 = st.d2 = 0x7FFFFFFF; st.d3 = 0x7F800000;
 
     if (nI >= 2) {
         const uint64_t pa = (uint64_t)Ip->tiledp;
@@ -1021,36 +1050,44 @@ void l2_knn2_counts2_kernel(const MatchParams P)
             for (int r = 0; r < 16; ++r) accB[nj][r] = 0.0f;
         uint32_t t = 0;
         for (; t + 1 < ntI; t += 2) {
-            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, sums + (size_t)(t == 0 ? ntI : t - 1) * 16u, bq, cql, accA, accB, st, (t - 1) * 32u);
-            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, rvB, rvA, sums + (size_t)t * 16u, bq, cql, accB, accA, st, t * 32u);
+            counts_tile_step_p<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, sums + (size_t)(t == 0 ? ntI : t - 1) * 16u, bq, cql, cbl, nmask, accA, accB, st, (t - 1) * 32u);
+            counts_tile_step_p<GB, PF>(ra, rr, voffA, voffR, (t + 1) * tileB + PF * 1024u, (t + 1) * 256u, abuf, rvB, rvA, sums + (size_t)t * 16u, bq, cql, cbl, nmask, accB, accA, st, t * 32u);
         }
         // the last tile's keys (and one more multiply step when the tile count is odd)
         if (t < ntI) {
-            counts_tile_step_m<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, sums + (size_t)(t == 0 ? ntI : t - 1) * 16u, bq, cql, accA, accB, st, (t - 1) * 32u);
-            counts_last_tile_m(accA, rvA, cql, st, t * 32u);
+            counts_tile_step_p<GB, PF>(ra, rr, voffA, voffR, t * tileB + PF * 1024u, t * 256u, abuf, rvA, rvB, sums + (size_t)(t == 0 ? ntI : t - 1) * 16u, bq, cql, cbl, nmask, accA, accB, st, (t - 1) * 32u);
+            counts_last_tile_p(accA, rvA, cql, cbl, nmask, st, t * 32u);
         } else {
-            counts_last_tile_m(accB, rvB, cql, st, (ntI - 1) * 32u);
+            counts_last_tile_p(accB, rvB, cql, cbl, nmask, st, (ntI - 1) * 32u);
         }
     }
-    // the list names rows of the ordered image: back to keypoint order; then hand it to the shared tail in the layout it expects (a
-    // list per lane half and query tile).  This lane's half carries the two nominees with the bound d3; the other half's slot carries
-    // the third-best row as a one-row list with the same bound: the tail's merge then sees the third-best key as the smallest
-    // un-nominated one (first certification, as before), and its second chance re-scores the three rows against d3.
-    {
-        const uint32_t* __restrict__ perm = Ip->cperm;
-        if (st.i0 != kNone) st.i0 = perm[st.i0];
-        if (st.i1 != kNone) st.i1 = perm[st.i1];
-        if (st.i2 != kNone) st.i2 = perm[st.i2];
-    }
+    // unpack: a word below +inf names a row of the ORDERED image in its low bits (back to keypoint order through cperm; a padding
+    // row maps to kNone there) and, with those bits cleared, a lower bound of its key'; the tail works in key units without ||b||^2.
+    // The tail's layout is a list per lane half and query tile: this lane's half carries the two nominees with the bound d3; the
+    // other half's slot carries the third-best row as a one-row list with the same bound -- its merge then sees the third-best key
+    // as the smallest un-nominated one (first certification), and its second chance re-scores the three rows against d3.
+    const uint32_t* __restrict__ perm = Ip->cperm;
+    auto key_of = [&](int w) -> float { return w >= 0x7F800000 ? R3DM_INF : __builtin_bit_cast(float, w & nmask) - cbl; };
+    auto row_of = [&](int w) -> uint32_t { return w >= 0x7F800000 ? kNone : perm[(uint32_t)w & idx_mask]; };
+    const float f0 = key_of(st.d0), f1 = key_of(st.d1), f2 = key_of(st.d2), f3 = key_of(st.d3);
+    const uint32_t i0 = row_of(st.d0), i1 = row_of(st.d1), i2 = row_of(st.d2);
     Top2 st2[NJ];
+    float kinv[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
+        const uint32_t q = qt * 32u + c;
+        kinv[nj] = 2.0f * (q < nJ ? Jp->cscale[q] : 1.0f);
+    }
     {
         // the partner lane (c, 1 - h) holds the list of the OTHER query tile: fetch what it has for my tile's partner slot
-        const float pd2 = __shfl_xor(st.d2, 32), pd3 = __shfl_xor(st.d3, 32);
-        const uint32_t pi2 = __shfl_xor(st.i2, 32);
+        const float pd2 = __shfl_xor(f2, 32), pd3 = __shfl_xor(f3, 32);
+        const uint32_t pi2 = __shfl_xor(i2, 32);
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) {
-            if ((uint32_t)nj == h) { st2[nj].d0 = st.d0; st2[nj].d1 = st.d1; st2[nj].d2 = st.i2 != kNone ? st.d3 : st.d2; st2[nj].i0 = st.i0; st2[nj].i1 = st.i1; }
-            else { st2[nj].d0 = pd2; st2[nj].d1 = R3DM_INF; st2[nj].d2 = pd3; st2[nj].i0 = pi2; st2[nj].i1 = kNone; if (pi2 == kNone) { st2[nj].d0 = R3DM_INF; st2[nj].d2 = pd2; } }
+            Top2& o = st2[nj];
+            if ((uint32_t)nj == h) { o.d0 = f0; o.d1 = f1; o.d2 = i2 != kNone ? f3 : f2; o.i0 = i0; o.i1 = i1; }
+            else { o.d0 = pd2; o.d1 = R3DM_INF; o.d2 = pd3; o.i0 = pi2; o.i1 = kNone; if (pi2 == kNone) { o.d0 = R3DM_INF; o.d2 = pd2; } }
         }
     }
     l2_finish_queries<NJ, false, true>(P, pair, Ip, Jp, st2, qt0, h, c, (float)(GB * 16), false, 1.0f, 0.0f, kinv);
@@ -1069,6 +1106,7 @@ static hipError_t launch_l2_counts2_t(hipStream_t st, const MatchParams& Pin, ui
     hipLaunchKernelGGL((l2_knn2_counts2_kernel<GB, PF>), dim3((uint32_t)grid64), dim3(256), 0, st, P);
     return hipGetLastError();
 }
+
 template <int GB, int NJ, int PF>
 static hipError_t launch_l2_counts_t(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
