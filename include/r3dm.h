@@ -598,6 +598,19 @@ typedef int (*r3dm_features_sink)(void* user, uint32_t image_index, uint32_t n_f
 int r3dm_set_features_sink(r3dm_ctx* ctx, r3dm_features_sink sink, void* user);
 int r3dm_multi_set_features_sink(r3dm_multi* m, r3dm_features_sink sink, void* user);
 
+/* Deferred feature files.  The reference's feature thread returns when KeypointSet::saveToBinFile has written the image's .feat /
+ * .desc (src/threads/R3DFeaturesThread.cpp:139-170, src/keypointSet.hpp:61-67); with on != 0 a features call of this context returns
+ * when the images are COMPUTED and handed to the sink -- the two fwrites of every image of a batch (16 MB of descriptors per 28 k
+ * keypoints) run on a writer thread of the context, beside the caller's next step (the facade: the match phase) and beside the
+ * context's next batch.  r3dm_features_files_wait joins the writer and reports its I/O error, if any (R3DM_ERR_IO; the message in
+ * r3dm_last_error); a context joins its writer by itself before it needs the landing buffer again, when the mode is switched
+ * off, and in r3dm_destroy.  The files are complete when the wait returns R3DM_OK -- call it before anything reads them.
+ * Off by default: without it every features entry point returns with its files written, as before. */
+int r3dm_set_deferred_feature_files(r3dm_ctx* ctx, int on);
+int r3dm_features_files_wait(r3dm_ctx* ctx);
+int r3dm_multi_set_deferred_feature_files(r3dm_multi* m, int on);
+int r3dm_multi_features_files_wait(r3dm_multi* m, char* err, size_t err_cap);
+
 #ifdef __cplusplus
 }
 #endif

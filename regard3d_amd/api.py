@@ -26,7 +26,7 @@ EXPORTS = [
     "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_stage_create", "r3dm_stage_run", "r3dm_stage_destroy", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
     "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
-    "r3dm_filter_FEH", "r3dm_host_threads", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
+    "r3dm_filter_FEH", "r3dm_host_threads", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_set_deferred_feature_files", "r3dm_features_files_wait", "r3dm_multi_set_deferred_feature_files", "r3dm_multi_features_files_wait", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
     "r3dm_mrpt_preset", "r3dm_match_pairs_mrpt", "r3dm_mrpt_knn2", "r3dm_mrpt_index", "r3dm_multi_match_pairs_mrpt",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
@@ -312,6 +312,10 @@ def load_library():
     L.r3dm_allgather_graphs.argtypes = [vp, vp, u32, vp]
     L.r3dm_set_device_graphs.argtypes = [vp, C.c_int]
     L.r3dm_graph_on_device.argtypes = [vp]
+    L.r3dm_set_deferred_feature_files.argtypes = [vp, C.c_int]
+    L.r3dm_features_files_wait.argtypes = [vp]
+    L.r3dm_multi_set_deferred_feature_files.argtypes = [vp, C.c_int]
+    L.r3dm_multi_features_files_wait.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.r3dm_comm_last_device_graphs.argtypes = [vp]
     L.r3dm_graphs_pack.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
     L.r3dm_words_free.argtypes = [vp]; L.r3dm_words_free.restype = None
@@ -856,6 +860,14 @@ class Context:
         self._check(self._L.r3dm_extract_features_batch(self._h, B, None if bgr else ip, ip if bgr else None, w, h, threshold, fp, dp, _ptr(nf)),
                     "r3dm_extract_features_batch")
         return nf
+
+    def set_deferred_feature_files(self, on: bool = True):
+        """r3dm_set_deferred_feature_files: features calls return when the images are computed; their files are written on the
+        context's writer thread (features_files_wait joins it and reports its I/O error)"""
+        self._check(self._L.r3dm_set_deferred_feature_files(self._h, 1 if on else 0), "r3dm_set_deferred_feature_files")
+
+    def features_files_wait(self):
+        self._check(self._L.r3dm_features_files_wait(self._h), "r3dm_features_files_wait")
 
     def gray_from_bgr8(self, bgr: np.ndarray) -> np.ndarray:
         bgr = np.ascontiguousarray(bgr, np.uint8)

@@ -38,6 +38,7 @@ extern "C" int r3dm_create(int device_id, r3dm_ctx** out)
 extern "C" void r3dm_destroy(r3dm_ctx* c)
 {
     if (!c) return;
+    if (c->file_writer.joinable()) c->file_writer.join();       // deferred feature files: the writer reads pin_desc
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& im : c->imgs) if (im) im->release();
@@ -56,6 +57,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     c->pin_desc.release(); c->pin_out.release(); c->pin_small.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_desc) (void)hipEventDestroy(c->ev_desc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -3,6 +3,7 @@
 // Mirrors, for the compute-matches hot path only, what the reference does in
 // /root/reference/src/R3DComputeMatches.cpp:2035-2129 and src/Regard3DFeatures.cpp -- with every arithmetic stage running as
 // HIP kernels on one MI355X.  There is no CPU fallback in this file: when HIP fails, the call fails.
+#include "fmt_g6.hpp"
 #include "r3dm_ctx.hpp"
 
 #include <charconv>
@@ -773,38 +774,34 @@ extern "C" int r3dm_gray_from_bgr8(r3dm_ctx* c, const unsigned char* bgr, uint32
     return R3DM_OK;
 }
 
-// "%g" of one float, locale-independent (the host application runs under setlocale(LC_ALL, "")): std::to_chars with the
-// general format and precision 6 is defined as printf("%.6g") in the "C" locale
-static inline char* put_g(char* p, char* end, float v)
-{
-    const std::to_chars_result r = std::to_chars(p, end, v, std::chars_format::general, 6);
-    return r.ptr;
-}
+// "%g" of one float, locale-independent (the host application runs under setlocale(LC_ALL, "")): printf("%.6g") in the "C" locale,
+// i.e. std::to_chars(general, 6) -- through the exact fast path of fmt_g6.hpp for the magnitudes a .feat file holds
+static inline char* put_g(char* p, char* end, float v, float* as_parsed = nullptr) { return r3dm_fmt::put_g6(p, end, v, as_parsed); }
 
 // KeypointSet::saveToBinFile (src/keypointSet.hpp:61-67): .feat = one "x y scale orientation" line per feature
 // (SIOPointFeature::operator<<, default float formatting; scale = size / 2, :835-836), .desc = count + raw rows
 // xy_as_written (optional, n x 2): the positions as a reader of the file parses them (std::from_chars on the text just written)
-static int write_feat_desc(std::string& err, const char* feat_path, const char* desc_path, const float* kps, const float* desc, uint32_t n,
-                           float* xy_as_written = nullptr)
+// (two halves: the text of the .feat file -- and with it the positions as a reader parses them -- and the two fwrites, which a context
+//  with r3dm_set_deferred_feature_files leaves to its writer thread)
+static size_t format_feat(std::vector<char>& txt, const float* kps, uint32_t n, float* xy_as_written)
 {
-    std::vector<char> txt((size_t)n * 64 + 64);
+    txt.resize((size_t)n * 64 + 64);
     char* p = txt.data(); char* const end = p + txt.size();
     for (uint32_t k = 0; k < n; ++k) {
-        char* const x0 = p;
-        p = put_g(p, end, kps[4 * (size_t)k]); *p++ = ' ';
-        char* const y0 = p;
-        p = put_g(p, end, kps[4 * (size_t)k + 1]); *p++ = ' ';
-        if (xy_as_written) {
-            float vx = kps[4 * (size_t)k], vy = kps[4 * (size_t)k + 1];
-            (void)std::from_chars(x0, y0 - 1, vx); (void)std::from_chars(y0, p - 1, vy);
-            xy_as_written[2 * (size_t)k] = vx; xy_as_written[2 * (size_t)k + 1] = vy;
-        }
+        float* const back = xy_as_written ? xy_as_written + 2 * (size_t)k : nullptr;
+        p = put_g(p, end, kps[4 * (size_t)k], back); *p++ = ' ';
+        p = put_g(p, end, kps[4 * (size_t)k + 1], back ? back + 1 : nullptr); *p++ = ' ';
         p = put_g(p, end, kps[4 * (size_t)k + 2] / 2.0f); *p++ = ' ';
         p = put_g(p, end, kps[4 * (size_t)k + 3]); *p++ = '\n';
     }
+    return (size_t)(p - txt.data());
+}
+
+static int write_feat_desc_files(std::string& err, const char* feat_path, const char* desc_path, const char* txt, size_t txt_len, const float* desc, uint32_t n)
+{
     FILE* f = fopen(feat_path, "wb");
     if (!f) { err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
-    bool ok = (p == txt.data()) || fwrite(txt.data(), 1, (size_t)(p - txt.data()), f) == (size_t)(p - txt.data());
+    bool ok = txt_len == 0 || fwrite(txt, 1, txt_len, f) == txt_len;
     ok = (fclose(f) == 0) && ok;
     if (!ok) { err = std::string("cannot write ") + feat_path; return R3DM_ERR_IO; }
     f = fopen(desc_path, "wb");
@@ -814,6 +811,24 @@ static int write_feat_desc(std::string& err, const char* feat_path, const char* 
     ok = (fclose(f) == 0) && ok;
     if (!ok) { err = std::string("cannot write ") + desc_path; return R3DM_ERR_IO; }
     return R3DM_OK;
+}
+
+static int write_feat_desc(std::string& err, const char* feat_path, const char* desc_path, const float* kps, const float* desc, uint32_t n,
+                           float* xy_as_written = nullptr)
+{
+    std::vector<char> txt;
+    const size_t len = format_feat(txt, kps, n, xy_as_written);
+    return write_feat_desc_files(err, feat_path, desc_path, txt.data(), len, desc, n);
+}
+
+// the writer thread of a context with deferred feature files: joined before pin_desc is filled again and by the wait entry
+static int features_files_join(r3dm_ctx* c)
+{
+    if (c->file_writer.joinable()) c->file_writer.join();
+    const int rc = c->file_writer_rc;
+    if (rc != R3DM_OK) c->err = c->file_writer_err.empty() ? "writing the feature files failed" : c->file_writer_err;
+    c->file_writer_rc = R3DM_OK; c->file_writer_err.clear();
+    return rc;
 }
 
 static bool both_files_exist(const char* feat_path, const char* desc_path, uint32_t* n_rows)
@@ -869,6 +884,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         }
     }
     const float* desc_host = nullptr;
+    const bool deferred = c->defer_files && feat_paths && desc_paths;
     if (n_total) {
         rc = liop_prepare(c);
         if (rc != R3DM_OK) return rc;
@@ -879,6 +895,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         R3DM_HIP(c, c->liop_kern.ensure(64));
         R3DM_HIP(c, c->liop_out.ensure(out_bytes));
         R3DM_HIP(c, c->liop_cnt.ensure(64 + n_total * 4));
+        { const int wrc_prev = features_files_join(c); if (wrc_prev != R3DM_OK) return wrc_prev; }      // the previous batch's writer still reads pin_desc
         R3DM_HIP(c, c->pin_desc.ensure(out_bytes));
         uint32_t* d_img_of = reinterpret_cast<uint32_t*>(c->liop_M.as<float>() + M6.size());
         R3DM_HIP(c, hipMemcpyAsync(c->liop_M.p, M6.data(), M6.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -899,20 +916,85 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         }
         R3DM_HIP(c, hipEventRecord(c->ev1, c->stream));
         R3DM_HIP(c, hipMemcpyAsync(c->pin_desc.p, c->liop_out.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
-        R3DM_HIP(c, hipStreamSynchronize(c->stream));
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        c->stats.ms_liop_kernel = ms;
         desc_host = c->pin_desc.as<float>();
+        if (deferred) {
+            // the descriptors travel to the host behind the kernel; only the writer thread waits for them (ev_desc)
+            if (!c->ev_desc) R3DM_HIP(c, hipEventCreateWithFlags(&c->ev_desc, hipEventDisableTiming));
+            R3DM_HIP(c, hipEventRecord(c->ev_desc, c->stream));
+        } else {
+            R3DM_HIP(c, hipStreamSynchronize(c->stream));
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->stats.ms_liop_kernel = ms;
+        }
     }
-    c->stats.ms_liop_wall = now_ms() - t_liop;
+    if (!deferred) c->stats.ms_liop_wall = now_ms() - t_liop;
     const double t_io = now_ms();
     // the files of the B images are formatted and written by up to 8 host threads (28 k keypoints = 113 k decimal conversions and
     // 16 MB per image); the sink then sees the images in batch order from this thread
     const bool to_files = feat_paths && desc_paths;
     std::vector<int> wrc(B, R3DM_OK);
     std::vector<std::string> werr(B);
-    if (to_files) {
+    if (to_files && deferred) {
+        // deferred files (r3dm_set_deferred_feature_files): the text of the .feat files is formatted while the LIOP kernel runs (it needs
+        // the keypoints only); when the kernel is done the images go to the sink (which reads the descriptors on the device); the
+        // fwrites -- 16 MB of descriptors per 28 k keypoints, still on their way to pin_desc -- are left to the context's writer thread,
+        // which runs beside whatever the caller does next
+        struct Job { std::string feat, desc; std::vector<char> txt; size_t len; const float* rows; uint32_t n; std::vector<float> xy; };
+        auto jobs = std::make_shared<std::vector<Job>>(B);
+#pragma omp parallel for schedule(dynamic) num_threads(host_team) if (B > 1)
+        for (long b = 0; b < (long)B; ++b) {
+            if (!feat_paths[b] || !desc_paths[b]) continue;
+            const uint32_t n = (uint32_t)bo.recs[b].size();
+            try {
+                Job& j = (*jobs)[(size_t)b];
+                if (c->feat_sink) j.xy.resize((size_t)n * 2 + 2);
+                j.feat = feat_paths[b]; j.desc = desc_paths[b]; j.n = n; j.rows = desc_host ? desc_host + 144 * first[b] : nullptr;
+                j.len = format_feat(j.txt, kps.data() + 4 * first[b], n, c->feat_sink ? j.xy.data() : nullptr);
+            } catch (...) { wrc[b] = R3DM_ERR_NOMEM; }
+        }
+        if (n_total) {
+            R3DM_HIP(c, hipEventSynchronize(c->ev1));            // the LIOP kernel (the copy to the host is still running)
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->stats.ms_liop_kernel = ms;
+        }
+        c->stats.ms_liop_wall = now_ms() - t_liop;
+        if (c->feat_sink) {
+#pragma omp parallel for schedule(dynamic) num_threads(host_team) if (B > 1)
+            for (long b = 0; b < (long)B; ++b) {
+                if (!feat_paths[b] || !desc_paths[b] || wrc[b] != R3DM_OK) continue;
+                const uint32_t n = (uint32_t)bo.recs[b].size();
+                const uint32_t id = c->feat_sink_ids ? c->feat_sink_ids[b] : (uint32_t)b;
+                int src = 1;
+                try { src = c->feat_sink(c->feat_sink_user, id, n, n ? c->liop_out.as<float>() + 144 * first[b] : nullptr, (*jobs)[(size_t)b].xy.data()); } catch (...) {}
+                if (src != 0) { wrc[b] = R3DM_ERR_INVALID; werr[b] = "the features sink refused image " + std::to_string(id); }
+                std::vector<float>().swap((*jobs)[(size_t)b].xy);
+            }
+            (void)hipSetDevice(c->device);
+        }
+        { const int wrc_prev = features_files_join(c); if (wrc_prev != R3DM_OK) return wrc_prev; }      // (a batch without keypoints has not joined it above)
+        try {
+            // (two threads per context: the writes have the caller's next phase to hide behind and must not take its cores)
+            c->file_writer = std::thread([c, jobs, writer_team = std::min(host_team, 2), wait_desc = n_total != 0]() {
+                const double t0 = now_ms();
+                if (wait_desc && (hipSetDevice(c->device) != hipSuccess || hipEventSynchronize(c->ev_desc) != hipSuccess)) {
+                    c->file_writer_rc = R3DM_ERR_HIP; c->file_writer_err = "the descriptors did not reach the host";
+                    return;
+                }
+                std::vector<int> rcs(jobs->size(), R3DM_OK); std::vector<std::string> errs(jobs->size());
+#pragma omp parallel for schedule(dynamic) num_threads(writer_team) if (jobs->size() > 1)
+                for (long b = 0; b < (long)jobs->size(); ++b) {
+                    const Job& j = (*jobs)[(size_t)b];
+                    if (j.feat.empty()) continue;
+                    try { rcs[(size_t)b] = write_feat_desc_files(errs[(size_t)b], j.feat.c_str(), j.desc.c_str(), j.txt.data(), j.len, j.rows, j.n); }
+                    catch (...) { rcs[(size_t)b] = R3DM_ERR_NOMEM; }
+                }
+                for (size_t b = 0; b < rcs.size(); ++b) if (rcs[b] != R3DM_OK && c->file_writer_rc == R3DM_OK) { c->file_writer_rc = rcs[b]; c->file_writer_err = errs[b]; }
+                c->file_writer_ms += now_ms() - t0;
+            });
+        } catch (...) { c->err = "cannot start the feature-file writer"; return R3DM_ERR_NOMEM; }
+    } else if (to_files) {
         // ... and each thread hands its image to the sink (if any) as soon as its files are written: the sink of the facade registers the
         // view with the matcher (position classes, device-to-device copy, re-layout kernels) while the other threads still format theirs.
         // The descriptors of the batch are still in liop_out (this context's stream is idle: the copy above was waited for).
@@ -936,6 +1018,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         }
         (void)hipSetDevice(c->device);                         // a sink may have worked on another device from this thread
     }
+    if (deferred && desc_out && n_total) R3DM_HIP(c, hipEventSynchronize(c->ev_desc));
     for (uint32_t b = 0; b < B; ++b) {
         const uint32_t n = (uint32_t)bo.recs[b].size();
         if (to_files && feat_paths[b] && desc_paths[b] && wrc[b] != R3DM_OK) { c->err = werr[b].empty() ? "out of host memory" : werr[b]; return wrc[b]; }
@@ -1102,6 +1185,40 @@ extern "C" int r3dm_set_features_sink(r3dm_ctx* c, r3dm_features_sink sink, void
     if (!c) return R3DM_ERR_INVALID;
     c->feat_sink = sink; c->feat_sink_user = sink ? user : nullptr;
     return R3DM_OK;
+}
+
+extern "C" int r3dm_set_deferred_feature_files(r3dm_ctx* c, int on)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    c->defer_files = on != 0;
+    return on ? R3DM_OK : features_files_join(c);
+}
+
+extern "C" int r3dm_features_files_wait(r3dm_ctx* c)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    return features_files_join(c);
+}
+
+extern "C" int r3dm_multi_set_deferred_feature_files(r3dm_multi* m, int on)
+{
+    if (!m) return R3DM_ERR_INVALID;
+    int rc = R3DM_OK;
+    for (int k = 0; k < r3dm_multi_num_devices(m); ++k) { const int r = r3dm_set_deferred_feature_files(r3dm_multi_ctx(m, k), on); if (r != R3DM_OK && rc == R3DM_OK) rc = r; }
+    return rc;
+}
+
+extern "C" int r3dm_multi_features_files_wait(r3dm_multi* m, char* err, size_t err_cap)
+{
+    if (!m) return R3DM_ERR_INVALID;
+    if (err && err_cap) err[0] = 0;
+    int rc = R3DM_OK;
+    for (int k = 0; k < r3dm_multi_num_devices(m); ++k) {
+        r3dm_ctx* c = r3dm_multi_ctx(m, k);
+        const int r = features_files_join(c);
+        if (r != R3DM_OK && rc == R3DM_OK) { rc = r; if (err && err_cap) { strncpy(err, r3dm_last_error(c), err_cap - 1); err[err_cap - 1] = 0; } }
+    }
+    return rc;
 }
 
 extern "C" int r3dm_multi_set_features_sink(r3dm_multi* m, r3dm_features_sink sink, void* user)

@@ -228,6 +228,9 @@ bool R3DComputeMatches::runFeaturesStage(const R3DFParams& params, const std::st
     }
     const int n_ctx = r3dm_multi_num_devices(feat_multi_);
     (void)r3dm_multi_set_features_sink(feat_multi_, direct_registration_ ? &R3DComputeMatches::features_sink : nullptr, this);
+    // the .feat / .desc of a batch are written behind the sink calls, beside the match phase (computeMatches waits for them before it
+    // returns): only when the views are registered straight from the device, else Regions_Provider::load reads those files next
+    (void)r3dm_multi_set_deferred_feature_files(feat_multi_, direct_registration_ ? 1 : 0);
     r3dm_features_totals before{};
     for (int k = 0; k < n_ctx; ++k) {
         r3dm_features_totals t{};
@@ -317,6 +320,11 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     phases_ = PhaseTimes();
     if (!ctx_ && !multi_) return false;
     const double t_begin = wall_ms();
+    // the feature files of this call are complete when it returns, however it returns (r3dm_set_deferred_feature_files)
+    struct FeatureFilesGuard {
+        R3DComputeMatches* self;
+        ~FeatureFilesGuard() { if (self->feat_multi_) (void)r3dm_multi_features_files_wait(self->feat_multi_, nullptr, 0); }
+    } feature_files_guard{this};
     // HIP-event time of the dominant kernel of the last match / filter call (the slowest device of a multi-device deal)
     auto kernel_ms = [&](bool filter) -> double {
         double ms = 0;
@@ -556,8 +564,11 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     {
         const double t_w = wall_ms();
         const std::string bad = writer.finish();
+        char ferr[512] = {0};
+        const int frc = feat_multi_ ? r3dm_multi_features_files_wait(feat_multi_, ferr, sizeof(ferr)) : R3DM_OK;
         phases_.files += wall_ms() - t_w;
         if (!bad.empty()) { errorMessage_ = "Cannot save computed matches in: " + bad; return false; }
+        if (frc != R3DM_OK) { errorMessage_ = std::string("features stage failed: ") + ferr; return false; }
     }
     phases_.total = wall_ms() - t_begin;
     return true;

@@ -244,6 +244,13 @@ struct r3dm_ctx {
     r3dm_features_sink feat_sink = nullptr; void* feat_sink_user = nullptr;   // r3dm_set_features_sink
     const uint32_t* feat_sink_ids = nullptr;                 // indices of the running batch in its caller's arrays (r3dm_multi_extract_features*), else 0 .. B-1
     r3dm_features_totals feat_totals{};                      // since r3dm_create (r3dm_get_features_totals)
+    // r3dm_set_deferred_feature_files: the fwrite of a batch's .feat / .desc runs on `file_writer` behind the sink calls; the thread
+    // reads pin_desc, so it is joined before that buffer is filled again, by r3dm_features_files_wait and by r3dm_destroy
+    bool defer_files = false;
+    hipEvent_t ev_desc = nullptr;                            // the descriptors of the batch have landed in pin_desc (created on first use)
+    std::thread file_writer;
+    int file_writer_rc = 0; std::string file_writer_err;
+    double file_writer_ms = 0.0;                             // wall time the writer threads spent (sum since the last wait)
     std::vector<r3dm_pair_report> report;                    // last r3dm_filter_F call, one per putative pair
 };
 

@@ -154,6 +154,31 @@ def test_features_stage_over_an_image_list_runs_images_concurrently_and_skips_ex
     assert [__import__("os").path.getmtime(p) for p in feats[:3]] == os_mtime[:3]
 
 
+def test_deferred_feature_files_are_the_same_files(ctx, tmp_path):
+    """r3dm_set_deferred_feature_files: the batch call returns with the images computed and the fwrites on the context's writer thread;
+    after r3dm_features_files_wait the files are byte for byte those of the immediate mode -- also when a second batch follows at once
+    (the context joins its writer before it reuses the landing buffer) -- and an unwritable path is reported by the wait"""
+    from regard3d_amd import api
+    imgs = [_scene(420, 560, 70 + k) for k in range(6)]
+    now = tmp_path / "now"; later = tmp_path / "later"; now.mkdir(); later.mkdir()
+    def paths(d, ks): return [str(d / f"i{k}.feat") for k in ks], [str(d / f"i{k}.desc") for k in ks]
+    n_now = list(ctx.extract_features_batch(imgs[:3], *paths(now, range(3)))) + list(ctx.extract_features_batch(imgs[3:], *paths(now, range(3, 6))))
+    ctx.set_deferred_feature_files(True)
+    try:
+        n_later = list(ctx.extract_features_batch(imgs[:3], *paths(later, range(3)))) + list(ctx.extract_features_batch(imgs[3:], *paths(later, range(3, 6))))
+        ctx.features_files_wait()
+        assert n_later == n_now and min(n_now) > 10
+        for k in range(6):
+            for ext in ("feat", "desc"):
+                assert open(str(later / f"i{k}.{ext}"), "rb").read() == open(str(now / f"i{k}.{ext}"), "rb").read(), (k, ext)
+        ctx.extract_features_batch(imgs[:1], [str(tmp_path / "no_such_dir" / "a.feat")], [str(tmp_path / "no_such_dir" / "a.desc")])
+        with pytest.raises(api.R3dmError):
+            ctx.features_files_wait()
+        ctx.features_files_wait()                                      # the error was consumed
+    finally:
+        ctx.set_deferred_feature_files(False)
+
+
 def test_mldb_descriptors_equal_the_cpu_restatement_and_match_across_noise(ctx, oracle):
     """detectAndCompute(DESCRIPTOR_MLDB): 61-byte descriptors bit-equal; then the config-C3 chain detect -> MLDB -> Hamming matcher"""
     img = _scene(600, 800, 31)
