@@ -41,8 +41,8 @@ __device__ __forceinline__ void int_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgp
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
         const f32x4 a = abuf[g % PF];
-        abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
-        if (g == (GB > 2 ? 2 : GB - 1)) {   // next tile's norms, element 4 qd + k = row 8 qd + 4 h + k: the accumulator layout
+        if (ABL < 2) abuf[g % PF] = bload16(ra, voffA, soffA + (uint32_t)g * 1024u);
+        if (ABL < 2 && g == (GB > 2 ? 2 : GB - 1)) {   // next tile's norms, element 4 qd + k = row 8 qd + 4 h + k: the accumulator layout
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const f32x4 v = bload16(rn, voffN, soffN + (uint32_t)qd * 32u);
@@ -58,7 +58,7 @@ __device__ __forceinline__ void int_tile_step(__amdgpu_buffer_rsrc_t ra, __amdgp
         for (int gi = (g * NG) / GB; gi < ((g + 1) * NG) / GB; ++gi) {
             const int nj = gi % NJ, qd = gi / NJ;
             const float p0 = prev[nj][4 * qd], p1 = prev[nj][4 * qd + 1], p2 = prev[nj][4 * qd + 2], p3 = prev[nj][4 * qd + 3];
-            if constexpr (ABL != 0) {
+            if constexpr ((ABL & 1) != 0) {
                 asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(p3));
             } else {
                 // Step 0 may follow the previous tile's last MFMAs (the writers of p0..p3) closely: its minimum goes through
@@ -195,11 +195,16 @@ hipError_t launch_l2_knn2_int(hipStream_t st, const MatchParams& P, uint32_t G, 
     // R3DM_L2_INT_VARIANT (A/B measurements on 780 pairs of 8192 x 8192 rows, D = 128; the f32 tiles take 95.0 ms):
     //   2 = NJ 2 x 2 waves/SIMD (default, 12.4 ms) | 8 = same with a whole-tile prefetch window (12.95 ms) |
     //   4 = NJ 4 x 1 wave/SIMD (17.6 ms) | 9 = 2 without the epilogue (timing only, 11.4 ms) | 5 / 59 / 6: tiles shared through LDS (kernels_match_hamming.hip)
+    //   round 5, same workload (2 = 11.67 ms): 9 = no epilogue 10.52 | 10 = no tile / norm loads 7.57 | 11 = neither 7.26 (timing only);
+    //   5 = LDS-shared 12.16 | 59 = LDS-shared without the epilogue 9.36.  The loads are the bound: with two query tiles per wave a CU's
+    //   four SIMDs consume 4 KiB of fragments per 64 matrix cycles = 64 B/clk, the whole rate of its L1 address path
     static const int iv = r3dm_dev_knob("R3DM_L2_INT_VARIANT", 2);
     if (G == 16 && (iv == 5 || iv == 59 || iv == 6)) return launch_l2_int_lds_variant(st, P, max_nj_tiles, iv);
     if (G == 16 && iv == 4) return launch_l2_int<8, 4, 4, 1>(st, P, max_nj_tiles);
     if (G == 16 && iv == 9) return launch_l2_int<8, 2, 4, 2, 1>(st, P, max_nj_tiles);
     if (G == 16 && iv == 8) return launch_l2_int<8, 2, 8, 2>(st, P, max_nj_tiles);
+    if (G == 16 && iv == 10) return launch_l2_int<8, 2, 4, 2, 2>(st, P, max_nj_tiles);
+    if (G == 16 && iv == 11) return launch_l2_int<8, 2, 4, 2, 3>(st, P, max_nj_tiles);
 #endif
     switch (G) {
         case 8:  return launch_l2_int<4, 2, 4, 2>(st, P, max_nj_tiles);
