@@ -168,7 +168,7 @@ def stage_main(a, embed=None, cpu_baseline_fn=None):
                                  "the as-structured fraction only says how fast the passes that exist run (DESIGN.md section 4.8).  Measured in a dedicated pass "
                                  f"(one context, HIP events on the library's stream); the stage itself keeps {conc} such passes in flight"},
         }
-        out["roofline_liop"] = stage_liop_roofline(ctx, dev, last, N)
+        out["roofline_liop"] = stage_liop_roofline(ctx, dev, last, N, imgs[0])
         # the AC-RANSAC kernels: counted f64 flops of the residual passes over the HIP-event time of the side-by-side call + CU occupancy
         out["roofline_filters"] = stage_filter_roofline(d, views)
         if not a.no_cpu_baseline:
@@ -179,41 +179,43 @@ def stage_main(a, embed=None, cpu_baseline_fn=None):
         shutil.rmtree(d, ignore_errors=True)
 
 
-# liop_kernel<false>, one wavefront per 41 x 41 patch: VALU instructions per patch, SQ_INSTS_VALU / SQ_WAVES of a rocprofv3 --pmc pass of
-# tools/liop_perf.py (profiles/r04_pmc_liop.txt; + 1,642 SALU, 984 LDS instructions per patch).  A wave64 VALU instruction occupies its
-# SIMD16 for 4 cycles: the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 = 614.4 G wave-instructions/s.
-LIOP_VALU_PER_PATCH = 9688.0
+# liop_kernel<true> (the product path of the features stage since round 5: warp + blur of the 41 x 41 patch inside the descriptor's
+# wavefront, one wavefront per keypoint): VALU instructions per keypoint = SQ_INSTS_VALU of a rocprofv3 --pmc pass of
+# tools/liop_fused_perf.py 120000 over its 120,000 keypoints (profiles/r05_final_pmc_liop.txt: 1.37918e9 per launch; + 1,914 SALU and
+# 1,675 LDS instructions per keypoint; the two-kernel form it replaced: 8,351 + 3,319).  A wave64 VALU instruction occupies its SIMD16
+# for 4 cycles: the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 = 614.4 G wave-instructions/s.
+LIOP_VALU_PER_PATCH = 11493.0
 VALU_ISSUE_PEAK_G = 256 * 4 * 2.4e9 / 4 / 1e9
 
 
-def stage_liop_roofline(ctx, dev, last, n_images):
-    """LIOP descriptor kernel in a dedicated pass (65,536 blurred random patches resident in HBM, the probe of tools/liop_perf.py): bound by
-    VALU issue -- the 1,024-key bitonic network on (intensity, position) keys and the f64 bilinear samples; its HBM traffic (6.7 KB in,
-    576 B out per patch) is 2 % of the HBM roof.  The stage's own LIOP time (extraction + descriptor + tie pass) is reported beside it."""
+def stage_liop_roofline(ctx, dev, last, n_images, image):
+    """The fused LIOP kernel in a dedicated pass: the keypoints the detector finds on one of the stage's photographs (resident in HBM),
+    repeated to 65,536, through r3dm_extract_liop -- bound by VALU issue (the bilinear warp, the 1,024-key bitonic network on
+    (intensity, position) keys and the f64 bilinear samples); its HBM traffic is a few per cent of the HBM roof.  The stage's own LIOP
+    time is reported beside it."""
     n = 65536
-    g = torch.Generator(device=dev); g.manual_seed(1)
-    img = torch.rand((n, 1, 41, 41), generator=g, device=dev)
-    k = torch.tensor([1, 4, 6, 4, 1], device=dev, dtype=torch.float32); k = (k[:, None] * k[None, :]); k /= k.sum()
-    P = torch.nn.functional.conv2d(img, k[None, None], padding=2)[:, 0].contiguous()
-    torch.cuda.synchronize()
+    kps, _ = ctx.detect_akaze(image, 0.001)
+    if len(kps) == 0:
+        return None
+    K = np.tile(kps, ((n + len(kps) - 1) // len(kps), 1))[:n].copy()
     ms = []
     for _ in range(3):
-        ctx.liop_describe_patches(P)
+        ctx.extract_liop(image, K, 8.0)
         ms.append(ctx.stats().ms_liop_kernel)
     m = sorted(ms)[1]
     rate = n / (m * 1e-3)
     ach = rate * LIOP_VALU_PER_PATCH / 1e9
     kp = float(last["n_keypoints"])
-    return {"bound": "valu", "kernel": "liop_kernel<false> (one wavefront per patch; 65,536 patches, dedicated pass)", "achieved": ach, "peak": VALU_ISSUE_PEAK_G,
+    return {"bound": "valu", "kernel": "liop_kernel<true> (patch warp + blur + descriptor, one wavefront per keypoint; 65,536 keypoints of one photograph, dedicated pass)",
+            "achieved": ach, "peak": VALU_ISSUE_PEAK_G,
             "unit": "G wave-instructions/s (VALU issue)", "frac": ach / VALU_ISSUE_PEAK_G, "traffic": None,
-            "valu_instructions_per_patch": LIOP_VALU_PER_PATCH, "patches_per_s": rate, "kernel_ms": m,
-            "hbm_GB_per_s": n * (6724 + 576) / (m * 1e-3) / 1e9,
+            "valu_instructions_per_patch": LIOP_VALU_PER_PATCH, "patches_per_s": rate, "kernel_ms": m, "ms_per_28k_keypoints": m / n * 28000.0,
             "in_stage": {"liop_kernels_ms_per_image_sum_over_contexts": last["features"]["ms_liop_kernels"] / n_images,
                          "keypoints_per_image": kp / n_images,
-                         "patches_per_s_all_three_kernels": kp / (last["features"]["ms_liop_kernels"] * 1e-3) if last["features"]["ms_liop_kernels"] > 0 else None},
-            "note": "instructions per patch from PMC (profiles/r04_pmc_liop.txt: SQ_INSTS_VALU / SQ_WAVES of this kernel, same source) x patches / "
-                    "HIP-event time.  in_stage: patch extraction (warp + blur), descriptor and tie pass of all images, as the contexts' events time them "
-                    "(two contexts share the GPU, so their sum exceeds the wall time of the features phase)"}
+                         "patches_per_s": kp / (last["features"]["ms_liop_kernels"] * 1e-3) if last["features"]["ms_liop_kernels"] > 0 else None},
+            "note": "instructions per keypoint from PMC (profiles/r05_final_pmc_liop.txt: SQ_INSTS_VALU of this kernel over its keypoints, same source) x keypoints / "
+                    "HIP-event time.  in_stage: the same kernel over the keypoints of all images, as the contexts' events time it with the other "
+                    "batches in flight beside it (their sum exceeds the wall time of the features phase)"}
 
 
 # f64 operations of ONE residual (one model applied to one putative match), counted on the source (kernels_filter.hip; + - * / one each):

@@ -546,6 +546,8 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
 // either way).  scratch: n_pad words (rows of a class, unordered) + 2 n_pad words (every row's class segment).
 // (Ranking inside this one-workgroup kernel was tried first: a view's rows fall into a few hundred classes, 14 M serial reads per view,
 // +115 ms on the stage's 24 views.)
+// (210-230 us per view of 28 k LIOP rows: their scales fall into a few dozen classes, so the LDS atomics of a wavefront mostly hit
+//  one address and serialise; issuing the loads of the three passes eight at a time changed nothing, round 5.)
 __global__ __launch_bounds__(1024)
 void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm, uint32_t* __restrict__ scratch)
 {
