@@ -279,31 +279,41 @@ def roofline(name, cfg, acc, dim, world):
     L = max(acc["launches"], 1)
     if cfg["matcher"] == "kgraph":
         ms = acc["ann_ms"]
-        # The search is VALU-ISSUE-bound, not gather-bound (PMC: profiles/r02_r_pmc_ann_search_dot8_prefilter.txt):
-        # one wavefront per query executes 6.04 k VALU (+ 5.21 k SALU) instructions on the byte-row / v_dot4 path, and a wave64 VALU
+        # The search is VALU-ISSUE-bound, not gather-bound (PMC: profiles/r05_final_pmc_c5.txt):
+        # one wavefront per query executes 5.6 k VALU (+ 5.3 k SALU) instructions on the byte-row / v_dot4 path, and a wave64 VALU
         # instruction occupies its SIMD16 for 4 cycles -> the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 = 614.4 G wave-instructions/s.
         # 99.3 % of the row gathers are served by L1 / L2; what reaches the fabric is reported as `traffic` (PMC, scaled per pair).
         rows8 = acc.get("ann_rows8", 0) > 0 and acc.get("ann_rows8", 0) == acc.get("ann_launches", -1)
         rows16 = acc.get("ann_rows16", 0) > 0 and acc.get("ann_rows16", 0) == acc.get("ann_launches", -1)
         dot8 = acc.get("ann_dot8", 0) == acc.get("ann_launches", -1)
         row_bytes = dim * (1.0 if rows8 else 2.0 if rows16 else 4.0)
-        VALU_PER_QUERY = 6038.0 if (rows8 and dot8) else None          # SQ_INSTS_VALU / SQ_WAVES of ann_search_kernel<8, 3>
+        # instructions per query and HBM-side bytes per pair: PMC passes of `bench.py --config c5 --images 96`, reported only while the
+        # library holds the very machine code of ann_search_kernel<8, 3> that was profiled (profiles/pmc_traffic.json, tools/pmc_traffic_json.py)
+        ent, ent_why = None, "no PMC entry for this kernel"
+        ent_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if rows8 and dot8 and os.path.exists(ent_path):
+            e = json.load(open(ent_path)).get("c5:ann_search_kernel")
+            if e and e.get("code_sha16"):
+                cur = _kernel_code_sha16(e["kernel"])
+                if cur == e["code_sha16"]:
+                    ent = e
+                else:
+                    ent_why = f"profiles/pmc_traffic.json: the entry for {e['kernel']} was measured on other machine code (entry {e['code_sha16']}, this library {cur})"
+        VALU_PER_QUERY = ent["valu_instructions_per_query"] if ent else None
         peak = 256 * 4 * 2.4e9 / 4 / 1e9
         ach = acc["queries"] * VALU_PER_QUERY / (ms * 1e-3) / 1e9 if (ms > 0 and VALU_PER_QUERY) else 0.0
         out = {"bound": "valu", "kernel": ("ann_search_kernel<u8 rows, v_dot4>" if dot8 else "ann_search_kernel<u8 rows>") if rows8 else "ann_search_kernel<bf16 rows>" if rows16 else "ann_search_kernel",
                "achieved": ach, "peak": peak, "unit": "G wave-instructions/s (VALU issue)", "frac": ach / peak, "traffic": None,
-               "valu_instructions_per_query": VALU_PER_QUERY, "salu_instructions_per_query": 5212.0 if VALU_PER_QUERY else None,
-               "note": "VALU-issue-bound: instructions per query from PMC (profiles/r02_r_pmc_ann_search_dot8_prefilter.txt, same kernel source) x queries / "
-                       "HIP-event time of the launches; the gathers (evaluations x %d B rows) are 99.3 %% cache hits" % int(row_bytes),
+               "valu_instructions_per_query": VALU_PER_QUERY, "salu_instructions_per_query": ent["salu_instructions_per_query"] if ent else None,
+               "note": ("VALU-issue-bound: instructions per query from PMC (%s: SQ_INSTS_VALU / SQ_WAVES of this kernel, one wavefront per query; same machine code, "
+                        "code_sha16 %s) x queries / HIP-event time of the launches; the gathers (evaluations x %d B rows) are 99 %% cache hits"
+                        % (ent["from"], ent["code_sha16"], int(row_bytes))) if ent else ("instructions per query not reported: " + ent_why),
                "evaluations": int(acc["ann_dist"]), "evaluations_per_query": acc["ann_dist"] / max(acc["queries"], 1), "row_bytes": int(row_bytes),
                "gathered_GB_per_s": acc["ann_dist"] * row_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "search_ms_total": ms}
-        ent_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if VALU_PER_QUERY and os.path.exists(ent_path):
-            ent = json.load(open(ent_path)).get("c5:ann_search_kernel")
-            # (this entry predates the machine-code fingerprints: keyed by the hash of kernels_ann.hip, which has not changed since)
-            if ent and ent.get("source_sha16") == _sha16(os.path.join(ROOT, "regard3d_amd", "csrc", "kernels_ann.hip")):
-                out["traffic"] = ent["traffic_bytes_per_pair"] * acc.get("pairs", 0) / max(acc["launches"], 1)
-                out["traffic_source"] = f"{ent['from']}: FETCH_SIZE + WRITE_SIZE of the search launches of a 96-image step, per pair ({ent['traffic_bytes_per_pair'] / 1e6:.2f} MB) x the pairs of a launch"
+        if ent:
+            out["traffic"] = ent["traffic_bytes_per_pair"] * acc.get("pairs", 0) / max(acc["launches"], 1)
+            out["traffic_source"] = (f"{ent['from']}: FETCH_SIZE + WRITE_SIZE of the search launch of a 96-image step, per pair "
+                                     f"({ent['traffic_bytes_per_pair'] / 1e6:.2f} MB) x the pairs of a launch")
         return out
     ms = acc["kernel_ms"]
     if cfg["kind"] == "akaze":
