@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--via-c-abi", action="store_true",
                     help="reassemble the graphs through the library's own RCCL entry (r3dm_allgather_graphs) instead of torch.distributed; same graphs_sha16")
     ap.add_argument("--emulate-world", type=int, default=0, help="N = 1 only: run shard 0 of a W-way job")
+    ap.add_argument("--views-from", choices=["rank0", "each"], default="rank0",
+                    help="N > 1: rank 0 generates the synthetic collection and broadcasts it (default), or every rank generates it from the seed")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="rough budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-leg", action="store_true", help="skip the short pass of the stage leg (pixels -> matches.*) appended to the default line as `stage_leg`")
@@ -124,7 +126,30 @@ def main():
     n_feat = cfg["feat"]
     kind = cfg["kind"]
     binary = kind == "akaze"
-    descs, xys, _ = synth.make_scene_torch(n_images, n_feat, seed=cfg["seed"], device=dev, kind=kind)
+    if world > 1 and a.views_from == "rank0":
+        # the collection exists ONCE: rank 0 generates it and every other rank receives the same bytes (each GPU matches its rows of I
+        # against all later views, so every rank needs (nearly) every view: descriptors are replicated by design) -- one
+        # broadcast over the fabric instead of N generations, and no reliance on N devices drawing identical random streams
+        import torch.distributed as td
+        meta = [None]
+        if rank == 0:
+            descs, xys, _ = synth.make_scene_torch(n_images, n_feat, seed=cfg["seed"], device=dev, kind=kind)
+            meta = [(tuple(descs.shape), str(descs.dtype), tuple(xys.shape), str(xys.dtype))]
+        td.broadcast_object_list(meta, src=0)
+        if rank != 0:
+            dsh, ddt, xsh, xdt = meta[0]
+            descs = torch.empty(dsh, dtype=getattr(torch, ddt.split(".")[-1]), device=dev)
+            xys = torch.empty(xsh, dtype=getattr(torch, xdt.split(".")[-1]), device=dev)
+        for t in (descs, xys):
+            if xdev.type == "cpu":                          # (the gloo test hook: through host memory)
+                h = t.cpu()
+                td.broadcast(h, src=0)
+                if rank != 0:
+                    t.copy_(h)
+            else:
+                td.broadcast(t, src=0)
+    else:
+        descs, xys, _ = synth.make_scene_torch(n_images, n_feat, seed=cfg["seed"], device=dev, kind=kind)
     dim = int(descs.shape[2])
     torch.cuda.synchronize()
     ctx = api.Context(local_rank)
