@@ -225,11 +225,12 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         if (fbt[0] > 0) {
             bool rescan = fbt[1] > 0;                      // some pair overflowed its list
             if ((first.dim & 3u) == 0) {
-                // a pair's uncertified queries are scanned by one workgroup per ~4096 rows of image I (at most 16): few pairs with
-                // long views (24 views of 28 k rows: 276 workgroups of 7.7 ms each) otherwise leave the chip idle behind one round
+                // a pair's uncertified queries are scanned by one workgroup per ~1024 rows of image I (at most 64): few pairs with
+                // long views (24 views of 28 k rows: 276 workgroups of 7.7 ms each) otherwise leave the chip idle behind one round,
+                // and a workgroup walks its rows tile by tile behind two barriers each (4096 rows per workgroup: 3.9 ms on those views)
                 uint32_t max_nI = 0;
                 for (const PairJob& j : jobs) max_nI = std::max(max_nI, c->imgs[j.sI]->n);
-                uint32_t S = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (max_nI + 4095u) / 4096u));
+                uint32_t S = std::min<uint32_t>(64u, std::max<uint32_t>(1u, (max_nI + 1023u) / 1024u));
                 while (S > 1 && (uint64_t)P * S > 65535ull * 4) --S;
                 mp.fb_slices = S; mp.fb_part = nullptr; mp.fb_done = nullptr;
                 if (S > 1) {
