@@ -467,15 +467,23 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         if (ctx_ && r3dm_get_stats(ctx_, &st) == R3DM_OK) phases_.match_post = st.ms_wall_match_post;
     }
     t_phase = wall_ms();
-    graph_to_map(putative, statistics_.putativeMatches_);
     const std::string put_path = paths.matchesPutitativeFilename_.empty() ? dir + "/matches.putative.txt" : paths.matchesPutitativeFilename_;
     // the match files are written behind the filters (two host threads per graph); failures are reported at the end -- the reference
     // returns EXIT_FAILURE (== true) from a bool function there (:2069), a real failure is reported instead
     MatchFileWriter writer;
     writer.own(putative);
     writer.save(putative, put_path, with_ext(put_path, ".bin"));
-
-    if (svgOutput) write_adjacency_svg(dir + "/PutativeAdjacencyMatrix.svg", views_.size(), statistics_.putativeMatches_);   // :2074
+    // statistics_.putativeMatches_ (the PairWiseMatches map the reference keeps, :2040-2069) is filled beside the filters as well: a
+    // million matches into per-pair vectors is host work nothing on the device waits for
+    struct MapJob {
+        std::thread th;
+        void start(const r3dm_graph* g, PairWiseMatches* out) { th = std::thread([g, out]() { try { graph_to_map(g, *out); } catch (...) { out->clear(); } }); }
+        void join() { if (th.joinable()) th.join(); }
+        ~MapJob() { join(); }
+    };
+    MapJob put_map;
+    try { put_map.start(putative, &statistics_.putativeMatches_); } catch (...) { graph_to_map(putative, statistics_.putativeMatches_); }
+    if (svgOutput) { put_map.join(); write_adjacency_svg(dir + "/PutativeAdjacencyMatrix.svg", views_.size(), statistics_.putativeMatches_); }   // :2074
     phases_.files += wall_ms() - t_phase;
 
     // ---- the three geometric filters side by side on one device (r3dm_filter_FEH): they only read the putative graph; the files
@@ -497,14 +505,18 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         const Out outs[3] = {{gF, &statistics_.fundamentalMatches_, &paths.matchesFFilename_, "/matches.f.txt", 0.9f, "Calculate essential matrix"},
                              {gE, &statistics_.essentialMatches_, &paths.matchesEFilename_, "/matches.e.txt", 0.95f, "Calculate homography matrix"},
                              {gH, &statistics_.homographyMatches_, &paths.matchesHFilename_, "/matches.h.txt", 1.0f, nullptr}};
-        for (const Out& o : outs) {
+        MapJob maps[3];
+        for (int k = 0; k < 3; ++k) {
+            const Out& o = outs[k];
             if (!o.g) continue;
-            graph_to_map(o.g, *o.map);
+            try { maps[k].start(o.g, o.map); } catch (...) { graph_to_map(o.g, *o.map); }      // the three maps side by side
             const std::string path = o.named->empty() ? dir + o.def : *o.named;
             writer.own(o.g);
             writer.save(o.g, path, with_ext(path, ".bin"));
             if (progress_ && o.msg) progress_(o.frac, o.msg, progress_user_);
         }
+        for (MapJob& mj : maps) mj.join();
+        put_map.join();
         phases_.files += wall_ms() - t_phase;
     } else {
     // ---- geometric filtering, fundamental matrix (:2113-2120): AC-RANSAC, 4.0 px upper bound, 2048 iterations
