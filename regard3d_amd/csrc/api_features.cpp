@@ -977,6 +977,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         try {
             // (two threads per context: the writes have the caller's next phase to hide behind and must not take its cores)
             c->file_writer = std::thread([c, jobs, writer_team = std::min(host_team, 2), wait_desc = n_total != 0]() {
+                r3dm_background_thread();
                 const double t0 = now_ms();
                 if (wait_desc && (hipSetDevice(c->device) != hipSuccess || hipEventSynchronize(c->ev_desc) != hipSuccess)) {
                     c->file_writer_rc = R3DM_ERR_HIP; c->file_writer_err = "the descriptors did not reach the host";

@@ -12,6 +12,9 @@
 #include <algorithm>
 #include <memory>
 #include <thread>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace r3d_amd {
 
@@ -59,6 +62,10 @@ bool load_feat(const std::string& path, std::vector<float>& xy)
     return true;
 }
 
+// first thing in a background writer thread: its work has a whole phase to hide behind, so under contention for the host's cores it
+// stands back (Linux: a per-thread nice value, inherited by the helpers it starts)
+static inline void stand_back() { (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10); }
+
 // Save(PairWiseMatches, file) of the .txt and the .bin of a graph on two host threads while the next filter runs on the GPU; the
 // destructor waits for every write and frees the graphs it was given
 struct MatchFileWriter {
@@ -71,7 +78,7 @@ struct MatchFileWriter {
             std::unique_ptr<Job> j(new Job());
             j->path = p;
             Job* raw = j.get();
-            try { raw->th = std::thread([g, raw]() noexcept { raw->rc = r3dm_save_matches(g, raw->path.c_str()); }); }
+            try { raw->th = std::thread([g, raw]() noexcept { stand_back(); raw->rc = r3dm_save_matches(g, raw->path.c_str()); }); }
             catch (...) { raw->rc = r3dm_save_matches(g, raw->path.c_str()); }             // no thread to be had: write here
             jobs.push_back(std::move(j));
         }
@@ -477,7 +484,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     // million matches into per-pair vectors is host work nothing on the device waits for
     struct MapJob {
         std::thread th;
-        void start(const r3dm_graph* g, PairWiseMatches* out) { th = std::thread([g, out]() { try { graph_to_map(g, *out); } catch (...) { out->clear(); } }); }
+        void start(const r3dm_graph* g, PairWiseMatches* out) { th = std::thread([g, out]() { stand_back(); try { graph_to_map(g, *out); } catch (...) { out->clear(); } }); }
         void join() { if (th.joinable()) th.join(); }
         ~MapJob() { join(); }
     };

@@ -8,6 +8,9 @@
 #include "r3dm_internal.hpp"
 
 #include <sched.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <algorithm>
 #include <chrono>
 #include <thread>
@@ -33,6 +36,14 @@ using namespace r3dm;
 // cgroup CPU quota (a container with `cpu.max = 1600000 100000` sees 256 processors and owns 16: a burst of more runnable threads than
 // that is throttled until the end of the 100 ms period, which showed as random 60-100 ms stalls of the stage's main thread) -- divided
 // among the workers that may run such a team at the same time, at most `want`.
+// called first thing by the library's background writer threads (feature files, match files): their work has a whole phase of the
+// caller's to hide behind, so under contention for the host's cores they stand back (Linux: a per-thread nice value, inherited
+// by the OpenMP helpers they start)
+inline void r3dm_background_thread()
+{
+    (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+}
+
 inline int r3dm_host_team(int want, int concurrent_teams = 2)
 {
     static const int cores = [] {
