@@ -535,11 +535,10 @@ extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
         std::vector<std::vector<char>> bufs((size_t)T);
         std::vector<size_t> lens((size_t)T, 0);
         std::vector<int> failed((size_t)T, 0);
-#pragma omp parallel for schedule(static, 1) num_threads(T) if (T > 1)
-        for (int c = 0; c < T; ++c) {
+        r3dm_parallel_for((long)T, T, [&](long c) {
             try {
                 const uint64_t p0 = cut[c], p1 = cut[c + 1];
-                if (p1 <= p0) continue;
+                if (p1 <= p0) return;
                 const uint64_t mcount = g->offsets[p1] - g->offsets[p0];
                 bufs[(size_t)c].resize((size_t)(mcount * 22 + (p1 - p0) * 44 + 64));        // a line <= 22 bytes, a pair header <= 11 + 11 + 21
                 char* o = bufs[(size_t)c].data();
@@ -549,7 +548,7 @@ extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
                 }
                 lens[(size_t)c] = (size_t)(o - bufs[(size_t)c].data());
             } catch (...) { failed[(size_t)c] = 1; }
-        }
+        });
         for (int c = 0; c < T && ok; ++c) {
             if (failed[(size_t)c]) { ok = false; break; }
             if (lens[(size_t)c]) ok &= fwrite(bufs[(size_t)c].data(), 1, lens[(size_t)c], f) == lens[(size_t)c];

@@ -869,19 +869,27 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     const int host_team = r3dm_host_team(8);                 // helper threads of this batch: bounded by the cores the process really owns
     (void)host_team;
     // angle (atan2f of the host libm, as the reference) and LIOP patch map of every keypoint: a few host threads share the loop
-    for (uint32_t b = 0; b < B; ++b) {
-        const long nk = (long)bo.recs[b].size();
-        const AkKpRec* recs = bo.recs[b].data();
-        const size_t f0 = first[b];
-#pragma omp parallel for schedule(static) num_threads(host_team) if (nk > 4096)
-        for (long k = 0; k < nk; ++k) {
-            const AkKpRec& r = recs[k];
-            const size_t g = f0 + (size_t)k;
-            float* o = &kps[4 * g];
-            o[0] = r.x; o[1] = r.y; o[2] = r.size; o[3] = ak_angle_deg(ak_theta(r));
-            liop_patch_map(o[0], o[1], o[2], o[3], 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, &M6[6 * g]);
-            img_of[g] = b;
+    {
+        // chunks of 4,096 keypoints over all images of the batch
+        struct Chunk { uint32_t b; long k0, k1; };
+        std::vector<Chunk> chunks;
+        for (uint32_t b = 0; b < B; ++b) {
+            const long nk = (long)bo.recs[b].size();
+            for (long k0 = 0; k0 < nk; k0 += 4096) chunks.push_back({b, k0, std::min(nk, k0 + 4096)});
         }
+        r3dm_parallel_for((long)chunks.size(), host_team, [&](long ci) {
+            const Chunk& ch = chunks[(size_t)ci];
+            const AkKpRec* recs = bo.recs[ch.b].data();
+            const size_t f0 = first[ch.b];
+            for (long k = ch.k0; k < ch.k1; ++k) {
+                const AkKpRec& r = recs[k];
+                const size_t g = f0 + (size_t)k;
+                float* o = &kps[4 * g];
+                o[0] = r.x; o[1] = r.y; o[2] = r.size; o[3] = ak_angle_deg(ak_theta(r));
+                liop_patch_map(o[0], o[1], o[2], o[3], 8.0f /* getKpSizeFactor("Fast-AKAZE"), :703-704 */, &M6[6 * g]);
+                img_of[g] = ch.b;
+            }
+        });
     }
     const float* desc_host = nullptr;
     const bool deferred = c->defer_files && feat_paths && desc_paths;
@@ -942,9 +950,8 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         // which runs beside whatever the caller does next
         struct Job { std::string feat, desc; std::vector<char> txt; size_t len; const float* rows; uint32_t n; std::vector<float> xy; };
         auto jobs = std::make_shared<std::vector<Job>>(B);
-#pragma omp parallel for schedule(dynamic) num_threads(host_team) if (B > 1)
-        for (long b = 0; b < (long)B; ++b) {
-            if (!feat_paths[b] || !desc_paths[b]) continue;
+        r3dm_parallel_for((long)B, host_team, [&](long b) {
+            if (!feat_paths[b] || !desc_paths[b]) return;
             const uint32_t n = (uint32_t)bo.recs[b].size();
             try {
                 Job& j = (*jobs)[(size_t)b];
@@ -952,7 +959,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
                 j.feat = feat_paths[b]; j.desc = desc_paths[b]; j.n = n; j.rows = desc_host ? desc_host + 144 * first[b] : nullptr;
                 j.len = format_feat(j.txt, kps.data() + 4 * first[b], n, c->feat_sink ? j.xy.data() : nullptr);
             } catch (...) { wrc[b] = R3DM_ERR_NOMEM; }
-        }
+        });
         if (n_total) {
             R3DM_HIP(c, hipEventSynchronize(c->ev1));            // the LIOP kernel (the copy to the host is still running)
             float ms = 0.f;
@@ -961,16 +968,15 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         }
         c->stats.ms_liop_wall = now_ms() - t_liop;
         if (c->feat_sink) {
-#pragma omp parallel for schedule(dynamic) num_threads(host_team) if (B > 1)
-            for (long b = 0; b < (long)B; ++b) {
-                if (!feat_paths[b] || !desc_paths[b] || wrc[b] != R3DM_OK) continue;
+            r3dm_parallel_for((long)B, host_team, [&](long b) {
+                if (!feat_paths[b] || !desc_paths[b] || wrc[b] != R3DM_OK) return;
                 const uint32_t n = (uint32_t)bo.recs[b].size();
                 const uint32_t id = c->feat_sink_ids ? c->feat_sink_ids[b] : (uint32_t)b;
                 int src = 1;
                 try { src = c->feat_sink(c->feat_sink_user, id, n, n ? c->liop_out.as<float>() + 144 * first[b] : nullptr, (*jobs)[(size_t)b].xy.data()); } catch (...) {}
                 if (src != 0) { wrc[b] = R3DM_ERR_INVALID; werr[b] = "the features sink refused image " + std::to_string(id); }
                 std::vector<float>().swap((*jobs)[(size_t)b].xy);
-            }
+            });
             (void)hipSetDevice(c->device);
         }
         { const int wrc_prev = features_files_join(c); if (wrc_prev != R3DM_OK) return wrc_prev; }      // (a batch without keypoints has not joined it above)
@@ -984,13 +990,12 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
                     return;
                 }
                 std::vector<int> rcs(jobs->size(), R3DM_OK); std::vector<std::string> errs(jobs->size());
-#pragma omp parallel for schedule(dynamic) num_threads(writer_team) if (jobs->size() > 1)
-                for (long b = 0; b < (long)jobs->size(); ++b) {
+                r3dm_parallel_for((long)jobs->size(), writer_team, [&](long b) {
                     const Job& j = (*jobs)[(size_t)b];
-                    if (j.feat.empty()) continue;
+                    if (j.feat.empty()) return;
                     try { rcs[(size_t)b] = write_feat_desc_files(errs[(size_t)b], j.feat.c_str(), j.desc.c_str(), j.txt.data(), j.len, j.rows, j.n); }
                     catch (...) { rcs[(size_t)b] = R3DM_ERR_NOMEM; }
-                }
+                });
                 for (size_t b = 0; b < rcs.size(); ++b) if (rcs[b] != R3DM_OK && c->file_writer_rc == R3DM_OK) { c->file_writer_rc = rcs[b]; c->file_writer_err = errs[b]; }
                 c->file_writer_ms += now_ms() - t0;
             });
@@ -999,9 +1004,8 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
         // ... and each thread hands its image to the sink (if any) as soon as its files are written: the sink of the facade registers the
         // view with the matcher (position classes, device-to-device copy, re-layout kernels) while the other threads still format theirs.
         // The descriptors of the batch are still in liop_out (this context's stream is idle: the copy above was waited for).
-#pragma omp parallel for schedule(dynamic) num_threads(host_team) if (B > 1)
-        for (long b = 0; b < (long)B; ++b) {
-            if (!feat_paths[b] || !desc_paths[b]) continue;
+        r3dm_parallel_for((long)B, host_team, [&](long b) {
+            if (!feat_paths[b] || !desc_paths[b]) return;
             const uint32_t n = (uint32_t)bo.recs[b].size();
             try {                                                   // nothing may leave an OpenMP region by exception
                 std::vector<float> xy_written;
@@ -1016,7 +1020,7 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
                     if (src != 0) { wrc[b] = R3DM_ERR_INVALID; werr[b] = "the features sink refused image " + std::to_string(id); }
                 }
             } catch (...) { wrc[b] = R3DM_ERR_NOMEM; }
-        }
+        });
         (void)hipSetDevice(c->device);                         // a sink may have worked on another device from this thread
     }
     if (deferred && desc_out && n_total) R3DM_HIP(c, hipEventSynchronize(c->ev_desc));

@@ -12,6 +12,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <cmath>
@@ -42,6 +43,26 @@ using namespace r3dm;
 inline void r3dm_background_thread()
 {
     (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+}
+
+// fn(i) for i in [0, n) on up to `threads` host threads that EXIT when the work is done.  (An OpenMP team keeps spinning for
+// work for milliseconds after every region -- libgomp sizes that spin by the CPUs it can see, not by the cgroup quota the process
+// lives under -- and several such teams at once ran a 16-core quota dry: CFS then stalls the whole process for the rest of its
+// period.  These regions are a few milliseconds long and few; six thread starts per region cost less than that.)
+// fn must not throw.
+template <class F>
+inline void r3dm_parallel_for(long n, int threads, F&& fn)
+{
+    if (n <= 0) return;
+    if (threads > n) threads = (int)n;
+    if (threads <= 1) { for (long i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<long> next{0};
+    auto worker = [&]() { for (;;) { const long i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) break; fn(i); } };
+    std::vector<std::thread> th;
+    th.reserve((size_t)threads - 1);
+    try { for (int t = 1; t < threads; ++t) th.emplace_back(worker); } catch (...) {}      // fewer helpers: the work is still done
+    worker();
+    for (std::thread& t : th) t.join();
 }
 
 inline int r3dm_host_team(int want, int concurrent_teams = 2)
