@@ -866,8 +866,10 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
     first[B] = n_total;
     std::vector<float> kps(4 * n_total), M6(6 * n_total);
     std::vector<uint32_t> img_of(n_total);
-    const int host_team = r3dm_host_team(8);                 // helper threads of this batch: bounded by the cores the process really owns
-    (void)host_team;
+    // helper threads of this batch: the cores the process really owns (its cgroup quota), shared with the other batches in flight
+    static std::atomic<int> batches_in_flight{0};
+    struct InFlight { std::atomic<int>& n; int mine; InFlight(std::atomic<int>& a) : n(a), mine(a.fetch_add(1) + 1) {} ~InFlight() { n.fetch_sub(1); } } in_flight(batches_in_flight);
+    const int host_team = r3dm_host_team(8, std::max(2, in_flight.mine));
     // angle (atan2f of the host libm, as the reference) and LIOP patch map of every keypoint: a few host threads share the loop
     {
         // chunks of 4,096 keypoints over all images of the batch
