@@ -536,8 +536,8 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
     }
 }
 
-// The DATASET side of the nominator reads the rows in the order of their scales (32 classes per binary order, i.e. scales within
-// 2.2 % of one another inside a class): the quad test of the kernel bounds four keys with the largest scale of their four rows, and
+// The DATASET side of the nominator reads the rows in the order of their scales (512 classes per binary order, i.e. scales within
+// 0.2 % of one another inside a class): the quad test of the kernel bounds four keys with the largest scale of their four rows, and
 // with rows in keypoint order (scales 30 % apart) that bound let a large share of the quads through to the per-key path.
 // One workgroup: counting sort of the rows by scale class -> cperm[position] = row (kNone behind the last row).
 // The rows of a class keep their keypoint order (a stable sort): the atomic cursors place them in whatever order the waves arrive, so a
@@ -554,12 +554,33 @@ void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uin
     __shared__ uint32_t hist[8192];
     __shared__ uint32_t start[8192];
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t s_emin;
     const uint32_t tid = threadIdx.x;
     uint32_t* __restrict__ tmp = scratch;
     uint2* __restrict__ seg = reinterpret_cast<uint2*>(scratch + n_pad);
     for (uint32_t b = tid; b < 8192u; b += 1024u) hist[b] = 0u;
+    if (tid == 0) s_emin = 255u;
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024u) atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u);    // sign 0: exponent + 5 mantissa bits
+    // class of a scale: 4 bits of binary order above the view's smallest + 9 mantissa bits (0.2 % steps; round 5 -- 8 exponent + 5
+    // mantissa bits before: 2.2 % steps put the few dozen scales of a LIOP view into a few dozen classes, loose quad bounds in the
+    // kernel and LDS atomics that all hit the same counters here).  A scale of 0 (an all-zero row) is class 0; orders beyond fifteen
+    // above the smallest share the top one (the order is a heuristic: results are exact whatever it is).
+    {
+        uint32_t e = 255u;
+        for (uint32_t r = tid; r < n; r += 1024u) { const uint32_t x = (__float_as_uint(cscale[r]) >> 23) & 255u; if (x != 0u && x < e) e = x; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)e, o); e = y < e ? y : e; }
+        if ((tid & 63u) == 0u) atomicMin(&s_emin, e);
+    }
+    __syncthreads();
+    const uint32_t emin = s_emin;
+    auto cls_of = [emin](float s) -> uint32_t {
+        const uint32_t bits = __float_as_uint(s), x = (bits >> 23) & 255u;
+        if (x == 0u) return 0u;
+        const uint32_t d = x - emin + 1u;
+        return ((d < 15u ? d : 15u) << 9) | ((bits >> 14) & 511u);
+    };
+    for (uint32_t r = tid; r < n; r += 1024u) atomicAdd(&hist[cls_of(cscale[r])], 1u);
     __syncthreads();
     uint32_t loc[8], run = 0;
 #pragma unroll
@@ -576,9 +597,9 @@ void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uin
 #pragma unroll
     for (int k = 0; k < 8; ++k) { hist[tid * 8u + (uint32_t)k] = base + loc[k]; start[tid * 8u + (uint32_t)k] = base + loc[k]; }          // cursors
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024u) tmp[atomicAdd(&hist[(__float_as_uint(cscale[r]) >> 18) & 8191u], 1u)] = r;
+    for (uint32_t r = tid; r < n; r += 1024u) tmp[atomicAdd(&hist[cls_of(cscale[r])], 1u)] = r;
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024u) { const uint32_t cls = (__float_as_uint(cscale[r]) >> 18) & 8191u; seg[r] = make_uint2(start[cls], hist[cls]); }
+    for (uint32_t r = tid; r < n; r += 1024u) { const uint32_t cls = cls_of(cscale[r]); seg[r] = make_uint2(start[cls], hist[cls]); }
     for (uint32_t r = n + tid; r < n_pad; r += 1024u) cperm[r] = kNone;
 }
 __global__ __launch_bounds__(256)
