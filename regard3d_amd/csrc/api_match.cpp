@@ -202,7 +202,12 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         if (counts) {
             // hipErrorInvalidValue = no count kernel for this launch (descriptor length, or a grid beyond the launcher's bound): the split
             // tiles, which every such view also holds, serve the batch
-            const hipError_t ec = launch_l2_knn2_counts(c->stream, mp, first.G, max_tiles, r3dm_dev_knob("R3DM_COUNTS_TWO_LISTS", 0));
+            // (the one-list kernel packs a key and its row into 32 bits: views beyond 65,536 rows would leave its keys fewer than seven
+            //  mantissa bits and send a growing share of their queries to the exact scan -- they take the two-list kernel, float keys)
+            uint32_t max_nI_rows = 0;
+            for (const PairJob& j : jobs) max_nI_rows = std::max(max_nI_rows, c->imgs[j.sI]->n);
+            const int two_lists = (max_nI_rows > 65536u || r3dm_dev_knob("R3DM_COUNTS_TWO_LISTS", 0)) ? 1 : 0;
+            const hipError_t ec = launch_l2_knn2_counts(c->stream, mp, first.G, max_tiles, two_lists);
             if (ec == hipErrorInvalidValue) (void)hipGetLastError();
             else { R3DM_HIP(c, ec); counts_ran = true; c->stats.n_split_mfma += 1; c->stats.n_counts_mfma += 1; }
         }

@@ -1153,7 +1153,7 @@ static hipError_t launch_l2_counts_t(hipStream_t st, const MatchParams& Pin, uin
 hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, int variant)
 {
     switch (G) {
-        // two query tiles per wave: one list per query (l2_knn2_counts2_kernel); variant != 0 (developer build): the two-list kernel
+        // two query tiles per wave: one list per query (l2_knn2_counts2_kernel); variant != 0 (dataset views beyond 65,536 rows; developer knob): the two-list kernel
         case 8:  return variant ? launch_l2_counts_t<4, 2, 4>(st, P, max_nj_tiles) : launch_l2_counts2_t<4, 4>(st, P, max_nj_tiles);
         case 16: return variant ? launch_l2_counts_t<8, 2, 8>(st, P, max_nj_tiles) : launch_l2_counts2_t<8, 8>(st, P, max_nj_tiles);
         case 18: return variant ? launch_l2_counts_t<9, 2, 9>(st, P, max_nj_tiles) : launch_l2_counts2_t<9, 9>(st, P, max_nj_tiles);

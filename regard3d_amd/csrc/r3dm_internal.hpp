@@ -382,7 +382,7 @@ hipError_t launch_l2_knn2_split(hipStream_t st, const MatchParams& P, uint32_t G
 // ImgDev::cquad holds [n_tiles][64] row-line floats, slack, then [n_tiles + 1][16] quad summaries (the extra line: +inf / scale 1, the
 // "tile before the first"): offset of the summaries in floats
 __host__ __device__ inline size_t counts_summary_offset(uint32_t n_tiles) { return (size_t)n_tiles * 64u + 8192u; }
-hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, int variant = 0);   // variant 1 (developer build): the two-list kernel for every G (l2_knn2_counts_kernel)
+hipError_t launch_l2_knn2_counts(hipStream_t st, const MatchParams& P, uint32_t G, uint32_t max_nj_tiles, int variant = 0);   // variant 1: the two-list kernel for every G (l2_knn2_counts_kernel: float keys -- dataset views beyond 65,536 rows, and R3DM_COUNTS_TWO_LISTS in the developer build)
 hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, uint32_t dim, uint32_t GB, uint32_t n_tiles,
                                uint16_t* tiledc, float* cscale, const float* norms, uint16_t* tiledp, float* crow, uint32_t* cperm,
                                uint32_t* fail_dev);

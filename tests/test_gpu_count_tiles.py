@@ -41,7 +41,8 @@ def _liop_like(rng, n, dim, top=40, heavy=0.02):
 
 
 @pytest.mark.parametrize("nI,nJ,dim", [(700, 900, 144), (1500, 1200, 128), (300, 100, 37), (2100, 2050, 144), (97, 33, 64),
-                                       (640, 500, 256), (2, 9, 144), (4100, 130, 100)])
+                                       (640, 500, 256), (2, 9, 144), (4100, 130, 100),
+                                       (66000, 70, 144)])       # a dataset view beyond 65,536 rows: the two-list kernel (float keys)
 def test_knn2_bit_exact_on_the_count_tiles(sctx, oracle, nI, nJ, dim):
     rng = np.random.default_rng(dim * 104729 + nI)
     a, ca = _liop_like(rng, nI, dim)
