@@ -214,6 +214,22 @@ hipError_t launch_l2_exact_batch(hipStream_t st, const MatchParams& P, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // body shared by the two storage classes of the sort buffer: `keys` / `drop` point into LDS (fast path) or into a
 // per-pair slice of global scratch (pairs that keep more matches than the LDS budget holds: views with > 16k features)
+// a pair that keeps more matches than the LDS sort holds works in its own slice of global scratch: what one wave stored must be
+// visible to the other waves of the SAME workgroup after a barrier.  They share one CU and its L1, so a workgroup-scope fence and
+// the completion of this wave's own memory operations is all that takes (an agent-scope fence -- what __threadfence() is -- writes
+// the L2 back on this eight-L2 part: ~20 us per sorting stage, 2.5 ms for a pair of 20 k matches; same shortcut and the same two
+// conditions as wg_fence in kernels_filter.hip: gfx9 s_waitcnt encoding, no threadgroup-split mode -- build.sh refuses -mtgsplit)
+#if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__) && !defined(__gfx942__)
+#error "fin_fence: the s_waitcnt encoding and the same-CU L1 argument are written for gfx942 / gfx950"
+#endif
+#endif
+__device__ __forceinline__ void fin_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): this wave's global stores and loads have completed
+}
+
 template <bool GLOBAL_BUFFERS, class KeyT, class DropT>
 __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys, DropT drop, unsigned long long* s_off_p,
                                               uint32_t* wave_cnt, uint32_t* s_total_p, uint32_t pair)
@@ -246,7 +262,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
         // pad to a power of two and bitonic-sort ascending
         uint32_t cap = 1; while (cap < m) cap <<= 1;
         for (uint32_t k = m + threadIdx.x; k < cap; k += 256) keys[k] = ~0ull;
-        if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
+        if (GLOBAL_BUFFERS) fin_fence();
         r3dm_syncthreads();
         for (uint32_t size = 2; size <= cap; size <<= 1) {
             for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -257,7 +273,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
                     const unsigned long long x = keys[lo], y = keys[hi];
                     if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
                 }
-                if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
+                if (GLOBAL_BUFFERS) fin_fence();
                 r3dm_syncthreads();
             }
         }
@@ -276,7 +292,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
                     d = (Ip->canon[(uint32_t)(keys[e] >> 32)] == ci) && (Jp->canon[(uint32_t)keys[e]] == cj);
                 drop[k] = d;
             }
-            if (GLOBAL_BUFFERS) __threadfence();        // agent scope: a workgroup-scope fence emits no vmcnt wait on gfx950
+            if (GLOBAL_BUFFERS) fin_fence();
             r3dm_syncthreads();
             // stable in-place compaction, 256 elements per round: every element moves to a position <= its own, and a round
             // reads its 256 keys before the barrier that precedes its writes
@@ -288,14 +304,14 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
                 const unsigned long long bal = __ballot(keep);
                 const uint32_t before = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
                 if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-                if (GLOBAL_BUFFERS) __threadfence();
+                if (GLOBAL_BUFFERS) fin_fence();
                 r3dm_syncthreads();
                 uint32_t woff = 0, tot = 0;
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) { const uint32_t cw = wave_cnt[q]; if (q < wave) woff += cw; tot += cw; }
                 if (keep) keys[w + woff + before] = kk;
                 w += tot;
-                if (GLOBAL_BUFFERS) __threadfence();
+                if (GLOBAL_BUFFERS) fin_fence();
                 r3dm_syncthreads();
             }
             m = w;
