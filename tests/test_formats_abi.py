@@ -53,6 +53,30 @@ def test_library_writer_reader_match_the_goldens(tmp_path):
         api.Graph.load(str(tmp_path / "missing.txt"))
 
 
+def test_large_match_files_are_the_oracle_writers_bytes(oracle, tmp_path):
+    """r3dm_save_matches formats a long .txt on several host threads (runs of pairs of about equal match counts, each into its own
+    buffer, written out in order): the bytes are those of the restatement's writer -- 300 k matches over 700 pairs, some of them
+    empty, numbers of one to ten digits -- and the file reads back to the same graph"""
+    from regard3d_amd import api
+    rng = np.random.default_rng(11)
+    P = 700
+    pairs = np.array([(i, j) for i in range(60) for j in range(i + 1, 60)][:P], np.uint32)
+    counts = rng.integers(0, 900, P).astype(np.uint32)
+    counts[[3, 4, 250, 699]] = 0
+    counts[17] = 9000
+    n = int(counts.sum())
+    mag = rng.integers(0, 10, n)                                                   # digits per number, uniformly
+    matches = np.stack([(rng.random(n) * 10.0 ** mag).astype(np.uint64) % (1 << 32), rng.integers(0, 1 << 32, n, dtype=np.uint64)], 1).astype(np.uint32)
+    g = api.Graph.from_csr(pairs, np.r_[0, np.cumsum(counts.astype(np.uint64))].astype(np.uint64), matches)
+    t_lib, t_orc = str(tmp_path / "lib.txt"), str(tmp_path / "orc.txt")
+    g.save(t_lib)
+    keep = counts > 0                                                              # (a graph holds no empty pairs: from_csr drops them)
+    oracle.save_matches(t_orc, pairs[keep], counts[keep], matches)
+    assert n > 250000 and open(t_lib, "rb").read() == open(t_orc, "rb").read()
+    back = api.Graph.load(t_lib)
+    assert np.array_equal(back.pairs, g.pairs) and np.array_equal(back.offsets, g.offsets) and np.array_equal(back.matches, g.matches)
+
+
 def test_graph_from_csr_orders_pairs_and_merge():
     from regard3d_amd import api
     a = api.Graph.from_csr(np.array([[2, 5], [0, 1]], np.uint32), np.array([0, 3, 5], np.uint64),
