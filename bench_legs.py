@@ -70,7 +70,7 @@ def stage_main(a, embed=None, cpu_baseline_fn=None):
         wipe()                                  # bench housekeeping (deleting the previous step's 400 MB of files): outside the step's clock
         torch.cuda.synchronize()
         t = time.perf_counter()
-        r = stage.run(d, views, 0.001, 0.6, algo, True, True, True, 5489, conc, batch)
+        r = stage.run(d, views, 0.001, 0.6, algo, True, True, True, 5489, conc, batch, background_nice=True)
         torch.cuda.synchronize()
         timed[0] += time.perf_counter() - t
         return r
@@ -91,6 +91,7 @@ def stage_main(a, embed=None, cpu_baseline_fn=None):
             quick = {"stage_features": a.stage_features, "images": N, "image_size": [W, H], "pairs": n_pairs, "steps": n_steps,
                      "ms_per_step": elapsed / n_steps * 1e3, "pairs_per_s": n_pairs * n_steps / elapsed,
                      "housekeeping_ms_per_step": housekeeping / n_steps * 1e3,
+                     "step_ms": [r["ms_total"] for r in reps], "step_features_ms": [r["ms_features"] for r in reps],
                      "keypoints_per_image": last["n_keypoints"] / N,
                      "putative_pairs": int(last["n_putative_pairs"]), "putative_matches": int(last["n_putative_matches"]), "F_matches": int(last["n_F_matches"]),
                      "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_match_kernels", "ms_match_post", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")},
@@ -130,7 +131,9 @@ def stage_main(a, embed=None, cpu_baseline_fn=None):
             "config": {"workload": f"stage: {N} synthetic {W}x{H} photographs (one textured plane, 78 % overlap between neighbours) resident in HBM -> "
                                    f"R3DComputeMatches::computeMatches: Fast-A-KAZE + LIOP-144 ({conc} batches of {batch} in flight) -> .feat/.desc -> exhaustive {n_pairs} pairs, "
                                    "brute-force L2 2-NN + ratio 0.6 (matchingAlgorithm 9; split-f16 nomination + f32 re-score, bit-identical to f32 tiles) -> F + E + H AC-RANSAC (4 px, 2048 it) -> matches.*.txt/.bin",
-                       "name": "stage", "images": N, "pairs": n_pairs, "image_size": [W, H], "parallelism": "1 GPU"},
+                       "name": "stage", "images": N, "pairs": n_pairs, "image_size": [W, H], "parallelism": "1 GPU",
+                       "host_options": "R3DM_STAGE_BACKGROUND_NICE (R3DComputeMatches::setBackgroundThreadsNice(10)): this host asks the stage's background "
+                                       "writer threads to stand back -- the box's container owns 16 cores; off by default in the library"},
             "phases_ms": {k[3:]: mean(k) for k in ("ms_features", "ms_load", "ms_match", "ms_filter_F", "ms_filter_E", "ms_filter_H", "ms_filters_wall", "ms_files", "ms_total")},
             "phases_note": "filter_F / _E / _H run side by side on the one device (r3dm_filter_FEH): they overlap, filters_wall is their sum in the total",
             "kernels_ms": {"match": mean("ms_match_kernels"), "match_post_wall": mean("ms_match_post"), "F": mean("ms_F_kernels"), "E": mean("ms_E_kernels"), "H": mean("ms_H_kernels"),

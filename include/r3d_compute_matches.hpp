@@ -131,6 +131,10 @@ public:
     void setDirectRegistration(bool on) { direct_registration_ = on; }
     // detector batches in flight per device and images per batch of the features stage (defaults 3 x 8)
     void setFeaturesConcurrency(int batches_in_flight, int images_per_batch) { feat_conc_ = batches_in_flight; feat_batch_ = images_per_batch; }
+    // nice value (1 .. 19) of the stage's background host threads -- match-file writers, PairWiseMatches map builders, the deferred
+    // feature-file writers of its contexts -- so that they stand back behind the caller's threads when the process lives under a CPU
+    // quota; 0 (default): the library leaves thread priorities alone
+    void setBackgroundThreadsNice(int nice_value) { background_nice_ = nice_value < 0 ? 0 : (nice_value > 19 ? 19 : nice_value); }
 
     bool computeMatches(R3DFParams& params, bool svgOutput, const R3DProjectPaths& paths,
                         int cameraModel, int matchingAlgorithm);
@@ -177,6 +181,7 @@ private:
     std::vector<uint32_t> registered_n_;
     const size_t* sink_need_ = nullptr;    // views of the running features chunk
     bool direct_registration_ = true;
+    int background_nice_ = 0;
     static int features_sink(void* self, uint32_t image_index, uint32_t n_features, const float* desc_device, const float* xy_as_written);
     ImageProviderFn provider_ = nullptr;
     ImageReleaseFn provider_release_ = nullptr;
@@ -228,6 +233,7 @@ int  r3dm_stage_run(r3dm_stage* s, const char* matches_dir, const r3dm_view_imag
 #define R3DM_STAGE_ARMS_AS_REQUESTED 1u   /* approximate arms always on the graph matcher (default: the faster matcher, R3DComputeMatches::setApproximateArmsPolicy) */
 #define R3DM_STAGE_SPLIT_MFMA        2u   /* (implied since round 3: the facade's exact fast paths are on by default) */
 #define R3DM_STAGE_INTEGER_MFMA      4u   /* (implied since round 3) */
+#define R3DM_STAGE_BACKGROUND_NICE  16u   /* background writer threads at nice 10 (R3DComputeMatches::setBackgroundThreadsNice(10)); default: priorities untouched */
 #define R3DM_STAGE_F32_TILES         8u   /* plain f32 MFMA tiles for the exhaustive matcher: R3DComputeMatches::setExactFastPaths(false); same files, slower */
 typedef struct { uint32_t id, width, height; const char* basename; } r3dm_view;
 int r3dm_compute_matches_dir(int device_id, const char* matches_dir, const r3dm_view* views, uint32_t n_views,

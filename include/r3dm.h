@@ -77,9 +77,39 @@ int  r3dm_device_info(const r3dm_ctx* ctx, char* arch, size_t arch_cap, int* n_c
  * Register (or replace) view `view_id`: n descriptors of `dim` elements (floats for F32, bytes for
  * U8/BIN), row-major, plus optional feature positions xy (n x 2 floats, pixel coordinates; NULL if
  * no coordinate de-duplication / geometric filter is wanted).  The data is copied to HBM and
- * re-laid-out there (MFMA fragment-order tiles + row norms). */
+ * re-laid-out there (MFMA fragment-order tiles + row norms).
+ * What the reference does before it matches (Regions_Provider::load / Features_Provider::load, src/R3DComputeMatches.cpp:2040,2094-2095).
+ * The call returns when the caller's buffers are consumed, NOT when the view is laid out: rows in pageable host memory are copied
+ * into a ring of page-locked slots and travel from there (one DMA + one kernel per view, queued on the context's stream); device
+ * pointers and page-locked host pointers are read in place and waited for.  Every later call of the context is ordered behind
+ * the registration; r3dm_images_wait waits for it explicitly.  A view costs its f32 tiles + norms in HBM (1.0 x its f32 size); the
+ * layouts only some paths read (row-major rows for real-valued views and the approximate matchers, bf16 / split-f16 / count /
+ * byte tiles of the opt-in paths) are made by the first call that needs them, or here when the path's switch is already on. */
 int r3dm_set_image(r3dm_ctx* ctx, uint32_t view_id, uint32_t width, uint32_t height,
                    const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy);
+/* ... a whole collection in one call (the reference loads all regions in one Regions_Provider::load): helper threads of the host
+ * fill the ring with the next views while the DMA and the kernels of the previous ones run.  dtype: r3dm_dtype. */
+typedef struct r3dm_view_desc {
+    uint32_t view_id, width, height;
+    uint32_t n, dim;
+    int32_t dtype;
+    const void* desc;
+    const float* xy;
+} r3dm_view_desc;
+int r3dm_set_images(r3dm_ctx* ctx, const r3dm_view_desc* views, uint32_t n_views);
+int r3dm_images_wait(r3dm_ctx* ctx);
+/* What a registered view holds in HBM (reports, tests): *layouts = the on-demand layouts staged so far, bits R3DM_LAYOUT_*;
+ * *bytes = device memory of every layout and index of the view; *ring_uploads / *direct_uploads (context-wide, may be NULL) = views that
+ * travelled through the page-locked ring / were read where the caller had them, since r3dm_create. */
+#define R3DM_LAYOUT_ROWS   1u   /* row-major f32 rows */
+#define R3DM_LAYOUT_BF16   2u   /* bf16 tiles (r3dm_set_integer_mfma) */
+#define R3DM_LAYOUT_SPLIT  4u   /* split-f16 planes (r3dm_set_split_mfma) */
+#define R3DM_LAYOUT_COUNTS 8u   /* count tiles + scale order (r3dm_set_split_mfma, votes x scale rows) */
+#define R3DM_LAYOUT_BIN8   16u  /* byte-per-bit tiles (r3dm_set_hamming_mfma) */
+int r3dm_view_info(r3dm_ctx* ctx, uint32_t view_id, uint32_t* layouts, uint64_t* bytes, uint64_t* ring_uploads, uint64_t* direct_uploads);
+/* device memory the context holds for its registered views (the slabs their layouts are cut from, live and recycled blocks alike),
+ * for the upload ring (device slots + position-class tables), and the ring's page-locked host memory; any pointer may be NULL */
+int r3dm_memory_info(const r3dm_ctx* ctx, uint64_t* views_device_bytes, uint64_t* ring_device_bytes, uint64_t* ring_host_bytes);
 int r3dm_clear_images(r3dm_ctx* ctx);
 /* r3dm_clear_images keeps the staging buffers of up to 256 cleared views for the next collection (the index buffers of a view are
  * always released); r3dm_trim gives those spares back to the device as well. */
@@ -508,8 +538,12 @@ int  r3dm_allgather_graphs(r3dm_comm* comm, const r3dm_graph* const* local, uint
  * inlier indices).  r3dm_allgather_graphs sends such a graph from device memory -- its payload does not cross PCIe on the way out --
  * when the mirror lives on the communicator's device; other graphs are packed on the host as before (r3dm_graph_from_csr, loaded or
  * merged graphs have no mirror).  r3dm_graph_on_device: the device id of a graph's mirror, -1 without one;
- * r3dm_comm_last_device_graphs: how many local graphs of the last exchange went out that way.  Every rank takes part in every
- * collective of an exchange even when it fails locally (it says so in the words it contributes), so all ranks return together. */
+ * r3dm_comm_last_device_graphs: how many local graphs of the last exchange went out that way.  The approximate matchers
+ * (r3dm_match_pairs_kgraph / _hnsw / _mrpt) merge two part graphs on the host -- graph-searched pairs and exhaustively scanned small
+ * ones: their result keeps a mirror when all of its pairs are of one kind (the usual case), none otherwise.
+ * A rank takes part in every collective of an exchange whatever happened while it prepared its share -- graphs it cannot pack, buffers
+ * it cannot allocate, copies into its send buffer that fail are reported in the words it contributes -- so all ranks return together;
+ * not covered: a device that is gone (hipSetDevice, the size collective's own 16 (W + 1) bytes, a failing collective). */
 int  r3dm_set_device_graphs(r3dm_ctx* ctx, int enable);
 int  r3dm_graph_on_device(const r3dm_graph* g);
 int  r3dm_comm_last_device_graphs(const r3dm_comm* comm);
@@ -607,6 +641,11 @@ int r3dm_multi_set_features_sink(r3dm_multi* m, r3dm_features_sink sink, void* u
  * off, and in r3dm_destroy.  The files are complete when the wait returns R3DM_OK -- call it before anything reads them.
  * Off by default: without it every features entry point returns with its files written, as before. */
 int r3dm_set_deferred_feature_files(r3dm_ctx* ctx, int on);
+/* The library's background host threads (the deferred feature-file writers of a context; the facade's match-file writers and map
+ * builders) run at the host's default priority unless asked: nice_value 1 .. 19 makes them stand back behind the caller's own threads
+ * (Linux per-thread nice; useful when the process lives under a CPU quota it can exhaust), 0 (default) leaves priorities alone. */
+int r3dm_set_background_nice(r3dm_ctx* ctx, int nice_value);
+int r3dm_multi_set_background_nice(r3dm_multi* m, int nice_value);
 int r3dm_features_files_wait(r3dm_ctx* ctx);
 int r3dm_multi_set_deferred_feature_files(r3dm_multi* m, int on);
 int r3dm_multi_features_files_wait(r3dm_multi* m, char* err, size_t err_cap);

@@ -16,17 +16,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libr3dm.so")
 
 F32, U8, BIN = 0, 1, 2
+LAYOUT_ROWS, LAYOUT_BF16, LAYOUT_SPLIT, LAYOUT_COUNTS, LAYOUT_BIN8 = 1, 2, 4, 8, 16
 NONE = 0xFFFFFFFF
 
 EXPORTS = [
-    "r3dm_create", "r3dm_destroy", "r3dm_last_error", "r3dm_device_info", "r3dm_set_image", "r3dm_clear_images", "r3dm_trim",
+    "r3dm_create", "r3dm_destroy", "r3dm_last_error", "r3dm_device_info", "r3dm_set_image", "r3dm_set_images", "r3dm_images_wait", "r3dm_view_info", "r3dm_memory_info", "r3dm_clear_images", "r3dm_trim",
     "r3dm_match_pairs", "r3dm_filter_F", "r3dm_filter_H", "r3dm_knn2", "r3dm_graph_num_pairs", "r3dm_graph_num_matches",
     "r3dm_graph_pairs", "r3dm_graph_offsets", "r3dm_graph_matches", "r3dm_graph_free", "r3dm_graph_from_csr",
     "r3dm_graph_merge", "r3dm_save_matches", "r3dm_load_matches", "r3dm_get_stats", "r3dm_filter_report",
     "r3dm_compute_matches_dir", "r3dm_compute_matches_stage", "r3dm_stage_create", "r3dm_stage_run", "r3dm_stage_destroy", "r3dm_liop_describe_patches", "r3dm_extract_liop",
     "r3dm_set_intrinsics", "r3dm_filter_E", "r3dm_ann_params_for_algorithm", "r3dm_detect_akaze", "r3dm_detect_akaze_mldb", "r3dm_gray_from_bgr8", "r3dm_extract_features_to_files", "r3dm_multi_extract_features",
     "r3dm_detect_akaze_batch", "r3dm_extract_features_batch", "r3dm_multi_extract_features_ex", "r3dm_get_features_totals", "r3dm_kgraph_preset", "r3dm_match_pairs_kgraph", "r3dm_exhaustive_is_faster", "r3dm_kgraph_knn2", "r3dm_kgraph_index", "r3dm_drop_indices",
-    "r3dm_filter_FEH", "r3dm_host_threads", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_set_deferred_feature_files", "r3dm_features_files_wait", "r3dm_multi_set_deferred_feature_files", "r3dm_multi_features_files_wait", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
+    "r3dm_filter_FEH", "r3dm_host_threads", "r3dm_set_features_sink", "r3dm_multi_set_features_sink", "r3dm_set_deferred_feature_files", "r3dm_set_background_nice", "r3dm_multi_set_background_nice", "r3dm_features_files_wait", "r3dm_multi_set_deferred_feature_files", "r3dm_multi_features_files_wait", "r3dm_hnsw_preset", "r3dm_match_pairs_hnsw", "r3dm_hnsw_knn2", "r3dm_hnsw_knn2_on_index", "r3dm_hnsw_index",
     "r3dm_mrpt_preset", "r3dm_match_pairs_mrpt", "r3dm_mrpt_knn2", "r3dm_mrpt_index", "r3dm_multi_match_pairs_mrpt",
     "r3dm_set_integer_mfma", "r3dm_set_split_mfma", "r3dm_set_hamming_mfma", "r3dm_index_create", "r3dm_index_knn2", "r3dm_index_destroy",
     "r3dm_multi_create", "r3dm_multi_destroy", "r3dm_multi_num_devices", "r3dm_multi_ctx", "r3dm_multi_last_error",
@@ -40,6 +41,12 @@ EXPORTS = [
 
 class R3dmError(RuntimeError):
     pass
+
+
+class ViewDesc(C.Structure):
+    """r3dm_view_desc (include/r3dm.h): one view of an r3dm_set_images batch"""
+    _fields_ = [("view_id", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("n", C.c_uint32), ("dim", C.c_uint32),
+                ("dtype", C.c_int32), ("desc", C.c_void_p), ("xy", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -122,13 +129,13 @@ class Stage:
 
     def run(self, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6, matching_algorithm: int = 9, compute_F: bool = True,
             compute_E: bool = True, compute_H: bool = True, seed: int = 5489, batches_in_flight: int = 3, images_per_batch: int = 8,
-            arms_as_requested: bool = False, split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False) -> StageReport:
+            arms_as_requested: bool = False, split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False, background_nice: bool = False) -> StageReport:
         keep = []
         arr = _stage_views(views, keep)
         rep = StageReport(); err = C.create_string_buffer(1024)
         rc = self._L.r3dm_stage_run(self._h, matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm, int(compute_F),
                                     int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
-                                    (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0) | (8 if f32_tiles else 0), C.byref(rep), err, 1024)
+                                    (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0) | (8 if f32_tiles else 0) | (16 if background_nice else 0), C.byref(rep), err, 1024)
         if rc != 0:
             raise R3dmError(f"r3dm_stage_run -> {rc}: {err.value.decode()}")
         return rep
@@ -148,7 +155,7 @@ class Stage:
 def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float = 0.001, dist_ratio: float = 0.6,
                           matching_algorithm: int = 9, compute_F: bool = True, compute_E: bool = True, compute_H: bool = True,
                           seed: int = 5489, batches_in_flight: int = 3, images_per_batch: int = 8, arms_as_requested: bool = False,
-                          split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False) -> StageReport:
+                          split_mfma: bool = False, integer_mfma: bool = False, f32_tiles: bool = False, background_nice: bool = False) -> StageReport:
     """R3DComputeMatches::computeMatches from pixels (r3dm_compute_matches_stage): features stage for the views whose .feat/.desc
     are missing, matching, F / E / H filters, match files.  views: dicts with id, width, height, basename and optionally
     gray ([h, w] float32) or bgr ([h, w, 3] uint8) -- numpy or torch (host or device) -- and focal_px / ppx / ppy."""
@@ -160,7 +167,7 @@ def compute_matches_stage(device_ids, matches_dir: str, views, threshold: float 
     L.r3dm_compute_matches_stage.argtypes = [C.c_void_p, C.c_int] + _STAGE_ARGS
     rc = L.r3dm_compute_matches_stage(ids, len(device_ids), matches_dir.encode(), arr, len(views), threshold, dist_ratio, matching_algorithm,
                                       int(compute_F), int(compute_E), int(compute_H), seed, batches_in_flight, images_per_batch,
-                                      (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0) | (8 if f32_tiles else 0), C.byref(rep), err, 1024)
+                                      (1 if arms_as_requested else 0) | (2 if split_mfma else 0) | (4 if integer_mfma else 0) | (8 if f32_tiles else 0) | (16 if background_nice else 0), C.byref(rep), err, 1024)
     if rc != 0:
         raise R3dmError(f"r3dm_compute_matches_stage -> {rc}: {err.value.decode()}")
     return rep
@@ -255,7 +262,12 @@ def load_library():
     L.r3dm_last_error.argtypes = [vp]; L.r3dm_last_error.restype = C.c_char_p
     L.r3dm_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(u64)]
     L.r3dm_set_image.argtypes = [vp, u32, u32, u32, vp, u32, u32, C.c_int, vp]
+    L.r3dm_set_images.argtypes = [vp, vp, u32]
+    L.r3dm_images_wait.argtypes = [vp]
+    L.r3dm_view_info.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.r3dm_memory_info.argtypes = [vp, vp, vp, vp]
     L.r3dm_clear_images.argtypes = [vp]
+    L.r3dm_trim.argtypes = [vp]
     L.r3dm_set_integer_mfma.argtypes = [vp, C.c_int]
     L.r3dm_set_split_mfma.argtypes = [vp, C.c_int]
     L.r3dm_set_hamming_mfma.argtypes = [vp, C.c_int]
@@ -589,6 +601,49 @@ class Context:
             xy = np.ascontiguousarray(xy, np.float32) if isinstance(xy, np.ndarray) else xy.contiguous().float()
         self._check(self._L.r3dm_set_image(self._h, view_id, width, height, _ptr(desc), n, dim, dt, _ptr(xy)),
                     "r3dm_set_image")
+
+    def set_images(self, view_ids, descs, xys=None, width: int = 0, height: int = 0, binary: bool = False, wait: bool = False):
+        """a whole collection in one call (r3dm_set_images): descs / xys are sequences of [n, dim] / [n, 2] arrays (numpy: host memory,
+        copied through the library's page-locked ring by helper threads; torch: read where they are).  wait: return when every view is
+        resident and laid out (r3dm_images_wait) instead of when the caller's buffers are consumed."""
+        keep = []
+        arr = (ViewDesc * len(view_ids))()
+        for k, vid in enumerate(view_ids):
+            d = descs[k]
+            if isinstance(d, np.ndarray):
+                d = np.ascontiguousarray(d)
+                is_f32 = d.dtype == np.float32
+                if not is_f32 and d.dtype != np.uint8:
+                    raise TypeError(d.dtype)
+            else:
+                import torch
+                d = d.contiguous()
+                is_f32 = d.dtype == torch.float32
+                if not is_f32 and d.dtype != torch.uint8:
+                    raise TypeError(d.dtype)
+            x = None if xys is None else xys[k]
+            if x is not None:
+                x = np.ascontiguousarray(x, np.float32) if isinstance(x, np.ndarray) else x.contiguous().float()
+            keep.append((d, x))
+            arr[k] = ViewDesc(int(vid), width, height, int(d.shape[0]), int(d.shape[1]), F32 if is_f32 else (BIN if binary else U8), _ptr(d), _ptr(x))
+        self._check(self._L.r3dm_set_images(self._h, C.cast(arr, C.c_void_p), len(view_ids)), "r3dm_set_images")
+        if wait:
+            self.images_wait()
+
+    def images_wait(self):
+        self._check(self._L.r3dm_images_wait(self._h), "r3dm_images_wait")
+
+    def memory_info(self):
+        """-> (device bytes of the slabs the registered views' layouts are cut from, device bytes of the upload ring, its page-locked host bytes)"""
+        a = C.c_uint64(); b = C.c_uint64(); h = C.c_uint64()
+        self._check(self._L.r3dm_memory_info(self._h, C.byref(a), C.byref(b), C.byref(h)), "r3dm_memory_info")
+        return a.value, b.value, h.value
+
+    def view_info(self, view_id: int):
+        """-> (layout bits LAYOUT_*, bytes of HBM the view's layouts and indices occupy, views uploaded through the ring, views read in place)"""
+        lay = C.c_uint32(); b = C.c_uint64(); ru = C.c_uint64(); du = C.c_uint64()
+        self._check(self._L.r3dm_view_info(self._h, view_id, C.byref(lay), C.byref(b), C.byref(ru), C.byref(du)), "r3dm_view_info")
+        return lay.value, b.value, ru.value, du.value
 
     def clear_images(self):
         self._check(self._L.r3dm_clear_images(self._h), "r3dm_clear_images")

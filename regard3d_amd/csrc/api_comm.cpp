@@ -204,9 +204,11 @@ extern "C" const char* r3dm_comm_last_error(const r3dm_comm* c) { return c ? c->
 
 extern "C" int r3dm_comm_last_device_graphs(const r3dm_comm* c) { return c ? (int)c->last_device_graphs : -1; }
 
-// The exchange.  Every rank takes part in every collective of the call whatever happened to it locally: a rank that cannot pack or
-// allocate says so in the words it contributes (size ~0 / status 1) and ALL ranks return an error together -- a rank that left early
-// would leave the others blocked inside RCCL.
+// The exchange.  A rank takes part in every collective of the call whatever happened to it while it PREPARED its share: a rank that
+// cannot pack its graphs or allocate the exchange buffers says so in the words it contributes (size ~0 / status 1), a rank whose
+// copies into the send buffer fail poisons the first word of what it sends, and ALL ranks return an error together -- a rank that
+// left early would leave the others blocked inside RCCL.  What is NOT covered (nothing a rank could contribute): hipSetDevice, the
+// 16 (W + 1)-byte buffer of the size collective, and a failing collective or stream itself -- a device that is gone.
 // A local graph with a device mirror on this communicator's GPU (r3dm_set_device_graphs; GraphDev) goes on the wire from device memory:
 // three device-to-device copies behind a 12-byte header -- its payload never visits the host on the way out.  A graph without one is
 // packed on the host and uploaded, as before.  The gathered payload comes back to the host either way: the merged graphs are host
@@ -260,6 +262,9 @@ extern "C" int r3dm_allgather_graphs(r3dm_comm* c, const r3dm_graph* const* loca
             if (stat[r]) { c->err = "r3dm_allgather_graphs: rank " + std::to_string(r) + " is out of memory for the exchange buffers"; return R3DM_ERR_NOMEM; }
         // ---- my words in d_send: the host writes headers (and whole graphs without a mirror) into the pinned image, uploads them in
         // runs, and the mirrors fill their places device to device
+        // (from here to the payload collective a failed copy is remembered, not returned: the collective is entered either way)
+        hipError_t late = hipSuccess; const char* late_what = "";
+#define CSOFT(call) do { if (late == hipSuccess) { late = (call); if (late != hipSuccess) late_what = #call; } } while (0)
         uint32_t* hs = static_cast<uint32_t*>(c->h_send.p);
         uint32_t* ds = c->d_send.as<uint32_t>();
         hs[0] = n_graphs;
@@ -271,11 +276,11 @@ extern "C" int r3dm_allgather_graphs(r3dm_comm* c, const r3dm_graph* const* loca
             const uint64_t P = g.pairs.size() / 2, M = g.matches.size();
             hs[at] = (uint32_t)P; hs[at + 1] = (uint32_t)(M & 0xFFFFFFFFull); hs[at + 2] = (uint32_t)(M >> 32);
             if (on_dev[k]) {
-                CHIP(hipMemcpyAsync(ds + run0, hs + run0, 4 * (at + 3 - run0), hipMemcpyHostToDevice, c->stream));
+                CSOFT(hipMemcpyAsync(ds + run0, hs + run0, 4 * (at + 3 - run0), hipMemcpyHostToDevice, c->stream));
                 uint32_t* d = ds + at + 3;
-                if (P) CHIP(hipMemcpyAsync(d, g.dev.pairs.p, 8 * (size_t)P, hipMemcpyDeviceToDevice, c->stream));
-                if (P) CHIP(hipMemcpyAsync(d + 2 * P, g.dev.counts.p, 4 * (size_t)P, hipMemcpyDeviceToDevice, c->stream));
-                if (M) CHIP(hipMemcpyAsync(d + 3 * P, g.dev.matches.p, 8 * (size_t)M, hipMemcpyDeviceToDevice, c->stream));
+                if (P) CSOFT(hipMemcpyAsync(d, g.dev.pairs.p, 8 * (size_t)P, hipMemcpyDeviceToDevice, c->stream));
+                if (P) CSOFT(hipMemcpyAsync(d + 2 * P, g.dev.counts.p, 4 * (size_t)P, hipMemcpyDeviceToDevice, c->stream));
+                if (M) CSOFT(hipMemcpyAsync(d + 3 * P, g.dev.matches.p, 8 * (size_t)M, hipMemcpyDeviceToDevice, c->stream));
                 at += (size_t)len[k];
                 run0 = at;
                 c->last_device_graphs += 1;
@@ -288,9 +293,17 @@ extern "C" int r3dm_allgather_graphs(r3dm_comm* c, const r3dm_graph* const* loca
             }
         }
         if (mx > at) memset(hs + at, 0, 4 * (size_t)(mx - at));                   // padding up to the largest rank
-        if (mx > run0) CHIP(hipMemcpyAsync(ds + run0, hs + run0, 4 * (size_t)(mx - run0), hipMemcpyHostToDevice, c->stream));
+        if (mx > run0) CSOFT(hipMemcpyAsync(ds + run0, hs + run0, 4 * (size_t)(mx - run0), hipMemcpyHostToDevice, c->stream));
         // ---- payload, padded to the largest rank: the one exchange (RCCL over xGMI)
+        if (late != hipSuccess) {
+            // my send buffer is not what its header says: poison its first word (the unpacker checks it against n_graphs on every rank)
+            static const uint32_t kPoison = 0xFFFFFFFFu;
+            (void)hipGetLastError();
+            (void)hipMemcpyAsync(ds, &kPoison, 4, hipMemcpyHostToDevice, c->stream);
+        }
+#undef CSOFT
         CNCCL(rccl().AllGather(c->d_send.p, c->d_recv.p, (size_t)mx, ncclUint32, c->comm, c->stream));
+        if (late != hipSuccess) { (void)hipStreamSynchronize(c->stream); c->err = std::string(late_what) + ": " + hipGetErrorString(late); return R3DM_ERR_HIP; }
         CHIP(hipMemcpyAsync(c->h_recv.p, c->d_recv.p, 4 * (size_t)mx * W, hipMemcpyDeviceToHost, c->stream));
         CHIP(hipStreamSynchronize(c->stream));
         std::vector<const uint32_t*> ptrs(W);

@@ -45,7 +45,7 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     DevBuf* bufs[] = {&c->d_imgs, &c->d_pairs, &c->d_nn, &c->d_knn_idx, &c->d_knn_dist, &c->d_fb, &c->d_cnt, &c->d_out,
                       &c->d_pair_off, &c->d_pair_cnt, &c->d_raw, &c->m_raw, &c->m_peer,
                       &c->liop_pix, &c->liop_sx, &c->liop_sy, &c->liop_in, &c->liop_out, &c->liop_cnt, &c->liop_img, &c->liop_M, &c->liop_kern,
-                      &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->d_spill, &c->d_fb2, &c->g_segs};
+                      &c->a_jobs, &c->h_aux, &c->h_jobs, &c->a_scratch, &c->a_ids, &c->d_spill, &c->d_fb2, &c->g_segs, &c->d_verdict};
     for (FilterBufs& fb : c->fb) fb.release();
     c->coop_sched.release();
     if (c->coop_ev) (void)hipEventDestroy(c->coop_ev);
@@ -54,7 +54,9 @@ extern "C" void r3dm_destroy(r3dm_ctx* c)
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : c->ak_bufs) b.release();
     for (auto& im : c->spare) if (im) im->release();
-    c->pin_desc.release(); c->pin_out.release(); c->pin_small.release();
+    c->pin_desc.release(); c->pin_out.release(); c->pin_small.release(); c->tab_host.release(); c->tab_back.release();
+    c->ring.release();
+    c->arena.release_all();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_desc) (void)hipEventDestroy(c->ev_desc);
@@ -89,220 +91,582 @@ extern "C" int r3dm_get_features_totals(const r3dm_ctx* c, r3dm_features_totals*
 }
 
 // ------------------------------------------------------------------------------------------------
-// views
+// views: registration (the reference loads every view's regions before it matches: Regions_Provider::load,
+// /root/reference/src/R3DComputeMatches.cpp:2040,2094-2095)
 // ------------------------------------------------------------------------------------------------
-// writes the table entry of `slot`; stat_bits3 / split_k are given when the slot mounts an already staged r3dm_index (the
-// staging kernels fill them otherwise)
-int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3, int32_t split_k, bool counts_ok)
+// A view costs ONE pass over its descriptors: host rows -> page-locked ring slot (the caller's pageable memory is consumed when the call
+// returns) -> one DMA -> one kernel that writes the fragment-order tiles, the norms, the statistics and the table entry.  No
+// synchronisation per view: the statistics the host needs to choose a matching path (integer-valued? largest element? votes x scale?)
+// stay in the table until the first call that asks (sync_view_stats), and the layouts only some paths read -- row-major rows, bf16
+// tiles, split planes, count tiles, byte tiles -- are staged by that path's first call (ensure_layouts).
+static void fill_entry(const HostImage& h, ImgDev& d)
 {
-    const size_t need = sizeof(ImgDev) * c->imgs.size();
-    if (need > c->d_imgs.cap) {
-        // grow and re-upload every live slot; max_norm_bits must survive -> read the old table back first
-        std::vector<ImgDev> old(c->d_imgs.cap / sizeof(ImgDev));
-        R3DM_HIP(c, hipStreamSynchronize(c->stream));
-        if (!old.empty()) {
-            R3DM_HIP(c, hipMemcpyAsync(old.data(), c->d_imgs.p, old.size() * sizeof(ImgDev), hipMemcpyDeviceToHost, c->stream));
-            R3DM_HIP(c, hipStreamSynchronize(c->stream));
-        }
-        DevBuf nb;
-        R3DM_HIP(c, nb.ensure(sizeof(ImgDev) * std::max<size_t>(64, c->imgs.size() * 2)));
-        R3DM_HIP(c, hipMemsetAsync(nb.p, 0, nb.cap, c->stream));
-        const size_t keep = std::min(old.size(), c->imgs.size());
-        if (keep) R3DM_HIP(c, hipMemcpyAsync(nb.p, old.data(), keep * sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
-        R3DM_HIP(c, hipStreamSynchronize(c->stream));
-        c->d_imgs.release();
-        c->d_imgs = nb;
-    }
-    const HostImage& h = *c->imgs[slot];
-    ImgDev d{};
-    d.rows = h.rows.as<float>(); d.tiled = h.tiled.as<float>(); d.norms = h.norms.as<float>();
+    d = ImgDev{};
+    d.rows = (h.have & kLayRows) ? h.rows.as<float>() : nullptr;
+    d.tiled = h.tiled.as<float>(); d.norms = h.norms.as<float>();
     d.bin = h.bin.as<uint32_t>(); d.xy = h.has_xy ? h.xy.as<float>() : nullptr;
-    d.canon = h.has_dup ? h.canon.as<uint32_t>() : nullptr;
+    d.canon = h.has_xy ? h.canon.as<uint32_t>() : nullptr;
+    d.has_dup = h.has_dup ? 1u : 0u;
     d.n = h.n; d.n_tiles = h.n_tiles; d.dim = h.dim; d.G = h.G; d.words = h.words;
     d.width = h.width; d.height = h.height;
-    d.max_norm_bits = stat_bits3 ? stat_bits3[0] : 0; d.max_abs_bits = stat_bits3 ? stat_bits3[1] : 0; d.not_integer = stat_bits3 ? stat_bits3[2] : 0;
-    d.ann_adj = nullptr; d.ann_deg = nullptr; d.ann_rows16 = nullptr; d.ann_rows8 = nullptr;          // staging invalidates the graph index
-    d.tiled16 = h.tiled16.as<uint16_t>();
-    d.tiledh = h.tiledh.as<uint16_t>(); d.split_k = split_k;
-    d.tiledc = h.tiledc.as<uint16_t>(); d.cscale = h.cscale.as<float>(); d.cquad = h.cquad.as<float>(); d.tiledp = h.tiledp.as<uint16_t>(); d.cperm = h.cperm.as<uint32_t>(); d.counts_fail = counts_ok ? 0u : 1u;
-    d.tiled8 = h.tiled8.as<uint8_t>();
-    R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, &d, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+    d.max_norm_bits = h.stats_valid ? h.stat_bits[0] : 0u; d.max_abs_bits = h.stats_valid ? h.stat_bits[1] : 0u; d.not_integer = h.stats_valid ? h.stat_bits[2] : 0u;
+    d.ann_adj = h.ann_K ? h.ann_adj.as<uint32_t>() : nullptr; d.ann_deg = h.ann_K ? h.ann_deg.as<uint32_t>() : nullptr;
+    d.ann_rows16 = h.compact_ready ? h.ann_rows16.as<uint16_t>() : nullptr; d.ann_rows8 = h.compact_ready ? h.ann_rows8.as<uint8_t>() : nullptr;
+    d.tiled16 = (h.have & kLayBf16) ? h.tiled16.as<uint16_t>() : nullptr;
+    d.tiledh = (h.have & kLaySplit) ? h.tiledh.as<uint16_t>() : nullptr; d.split_k = h.split_k;
+    const bool cn = (h.have & kLayCounts) != 0;
+    d.tiledc = cn ? h.tiledc.as<uint16_t>() : nullptr; d.cscale = cn ? h.cscale.as<float>() : nullptr; d.cquad = cn ? h.cquad.as<float>() : nullptr;
+    d.tiledp = cn ? h.tiledp.as<uint16_t>() : nullptr; d.cperm = cn ? h.cperm.as<uint32_t>() : nullptr; d.counts_fail = (cn && h.counts_ok) ? 0u : 1u;
+    d.tiled8 = (h.have & kLayBin8) ? h.tiled8.as<uint8_t>() : nullptr;
+}
+
+// room for `slots` entries in the device table and its page-locked mirror.  Growing re-uploads every live entry: the statistics of
+// views staged since the last read live only in the old table, so they are read back first.
+static int table_reserve(r3dm_ctx* c, size_t slots)
+{
+    const size_t need = sizeof(ImgDev) * slots;
+    if (need <= c->d_imgs.cap && need <= c->tab_host.cap) return R3DM_OK;
+    int rc = sync_view_stats(c);
+    if (rc != R3DM_OK) return rc;
     R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t cap_slots = std::max<size_t>(256, slots * 2);
+    DevBuf nb;
+    R3DM_HIP(c, nb.ensure(sizeof(ImgDev) * cap_slots));
+    R3DM_HIP(c, hipMemsetAsync(nb.p, 0, nb.cap, c->stream));
+    PinBuf np;
+    R3DM_HIP(c, np.ensure(sizeof(ImgDev) * cap_slots));
+    std::memset(np.p, 0, np.cap);
+    const size_t live = std::min(c->imgs.size(), cap_slots);
+    for (size_t k = 0; k < live; ++k) if (c->imgs[k]) fill_entry(*c->imgs[k], np.as<ImgDev>()[k]);
+    if (live) R3DM_HIP(c, hipMemcpyAsync(nb.p, np.p, live * sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    c->d_imgs.release(); c->d_imgs = nb;
+    c->tab_host.release(); c->tab_host = np;
     return R3DM_OK;
 }
 
-// copy + re-layout one view into slot `slot`
-int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width, uint32_t height,
-                    const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
+int publish_entry(r3dm_ctx* c, uint32_t slot)
 {
-    HostImage& h = *c->imgs[slot];
-    h.view_id = view_id; h.n = n; h.dim = dim; h.dtype = dtype; h.width = width; h.height = height;
-    h.has_xy = (xy != nullptr); h.has_dup = false; h.live = true;
-    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0; h.hnsw_M = 0; h.mrpt_trees = 0; h.compact_ready = false;
-    if (dtype == R3DM_BIN) {
-        h.words = (dim + 3) / 4;
-        const uint32_t n_pad = n + 8;
-        R3DM_HIP(c, h.bin.ensure((size_t)n_pad * h.words * 4 + kSlackBytes));
-        if (n) {
-            R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
-            R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
+    int rc = table_reserve(c, c->imgs.size());
+    if (rc != R3DM_OK) return rc;
+    ImgDev* m = c->tab_host.as<ImgDev>() + slot;
+    fill_entry(*c->imgs[slot], *m);
+    R3DM_HIP(c, hipMemcpyAsync(c->d_imgs.as<ImgDev>() + slot, m, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+    return R3DM_OK;
+}
+
+static inline int32_t split_k_of(float mx)
+{
+    // the same function of max|x| as stage_split_kernel's: max|x| 2^k in [2^13, 2^14)
+    int k = 0;
+    if (mx > 0.0f && std::isfinite(mx)) {
+        uint32_t b; std::memcpy(&b, &mx, 4);
+        k = 13 - ((int)((b >> 23) & 0xFFu) - 127);
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    }
+    return k;
+}
+
+int sync_view_stats(r3dm_ctx* c)
+{
+    if (c->pending_stats.empty()) return R3DM_OK;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (uint32_t s : c->pending_stats) if (s < c->imgs.size()) { lo = std::min(lo, s); hi = std::max(hi, s); }
+    if (lo <= hi) {
+        const size_t cnt = (size_t)hi - lo + 1;
+        R3DM_HIP(c, c->tab_back.ensure(cnt * sizeof(ImgDev)));
+        R3DM_HIP(c, hipMemcpyAsync(c->tab_back.p, c->d_imgs.as<ImgDev>() + lo, cnt * sizeof(ImgDev), hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        const ImgDev* t = c->tab_back.as<ImgDev>();
+        for (uint32_t s : c->pending_stats) {
+            if (s >= c->imgs.size() || !c->imgs[s]) continue;
+            HostImage& h = *c->imgs[s];
+            if (h.stats_valid) continue;
+            const ImgDev& d = t[s - lo];
+            h.stat_bits[0] = d.max_norm_bits; h.stat_bits[1] = d.max_abs_bits; h.stat_bits[2] = d.not_integer;
+            std::memcpy(&h.max_abs, &h.stat_bits[1], 4);
+            h.not_integer = (d.not_integer & 1u) != 0;
+            h.has_negative = (d.not_integer & 2u) != 0;
+            h.has_dup = d.has_dup != 0;
+            h.split_k = split_k_of(h.max_abs);
+            if (h.have & kLayCounts) h.counts_ok = d.counts_fail == 0;
+            h.stats_valid = true;
+            if (h.dtype == R3DM_BIN) { h.not_integer = true; h.has_negative = true; }
+            // (the table entry itself already holds all of this: the kernels wrote it there)
+            ImgDev* m = c->tab_host.as<ImgDev>() + s;
+            m->max_norm_bits = d.max_norm_bits; m->max_abs_bits = d.max_abs_bits; m->not_integer = d.not_integer; m->has_dup = d.has_dup; m->counts_fail = d.counts_fail;
         }
-        R3DM_HIP(c, launch_stage_bin(c->stream, c->d_raw.as<uint8_t>(), n, dim, h.bin.as<uint32_t>(), h.words, n_pad));
-        // one byte per bit in i8 MFMA fragment order + biased popcounts: the tiles of the opt-in MFMA Hamming (r3dm_set_hamming_mfma)
-        h.n_tiles = (n + kTileRows - 1) / kTileRows;
-        const size_t t8_bytes = (size_t)h.n_tiles * h.words * 1024 + 2 * kSlackBytes;
-        const size_t nrm_bytes = (size_t)h.n_tiles * 32 * 4 + kSlackBytes;
-        R3DM_HIP(c, h.tiled8.ensure(t8_bytes));
-        R3DM_HIP(c, h.norms.ensure(nrm_bytes));
-        R3DM_HIP(c, hipMemsetAsync(h.tiled8.p, 0, t8_bytes, c->stream));
-        R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0x7F, nrm_bytes, c->stream));
-        R3DM_HIP(c, launch_stage_bin8(c->stream, h.bin.as<uint32_t>(), n, h.words, h.n_tiles, h.tiled8.as<uint8_t>(), h.norms.as<float>()));
-    } else {
-        h.G = kernel_G_for(dim);
-        h.n_tiles = (n + kTileRows - 1) / kTileRows;
-        const size_t tiled_bytes = (size_t)h.n_tiles * h.G * 1024 + kSlackBytes;
-        const size_t norm_bytes = (size_t)h.n_tiles * 32 * 4 + kSlackBytes;
-        R3DM_HIP(c, h.rows.ensure((size_t)std::max<uint32_t>(n, 1) * dim * 4 + 256));
-        R3DM_HIP(c, h.tiled.ensure(tiled_bytes));
-        const size_t tiled16_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 1024 + kSlackBytes;
-        R3DM_HIP(c, h.tiled16.ensure(tiled16_bytes));
-        R3DM_HIP(c, hipMemsetAsync(h.tiled16.p, 0, tiled16_bytes, c->stream));
-        const size_t tiledh_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 2048 + kSlackBytes;      // f16 hi | lo planes (split nominator)
-        R3DM_HIP(c, h.tiledh.ensure(tiledh_bytes));
-        R3DM_HIP(c, hipMemsetAsync(h.tiledh.p, 0, tiledh_bytes, c->stream));
+    }
+    c->pending_stats.clear();
+    return R3DM_OK;
+}
+
+// ---- on-demand layouts
+// launches the staging kernels of the layouts in `want` the image does not hold (allocating their buffers); the caller publishes the entry
+int ensure_layouts_image(r3dm_ctx* c, HostImage& h, uint32_t want)
+{
+    if (h.dtype == R3DM_BIN) {
+        want &= kLayBin8;
+        if ((want & ~h.have) & kLayBin8) {
+            const size_t t8_bytes = (size_t)h.n_tiles * h.words * 1024 + 2 * kSlackBytes;
+            const size_t nrm_bytes = (size_t)h.n_tiles * 32 * 4 + kSlackBytes;
+            R3DM_HIP(c, h.tiled8.ensure(t8_bytes));
+            R3DM_HIP(c, h.norms.ensure(nrm_bytes));
+            R3DM_HIP(c, hipMemsetAsync(h.tiled8.p, 0, t8_bytes, c->stream));
+            R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0x7F, nrm_bytes, c->stream));
+            R3DM_HIP(c, launch_stage_bin8(c->stream, h.bin.as<uint32_t>(), h.n, h.words, h.n_tiles, h.tiled8.as<uint8_t>(), h.norms.as<float>()));
+            h.have |= kLayBin8;
+        }
+        return R3DM_OK;
+    }
+    want &= (kLayRows | kLayBf16 | kLaySplit | kLayCounts);
+    if (want & (kLayCounts | kLaySplit)) want |= kLayRows;
+    if ((want & kLayCounts) && !(h.dtype == R3DM_F32 && h.n && h.dim <= 256)) want &= ~kLayCounts;      // never votes x scale: counts_ok stays false
+    const uint32_t todo = want & ~h.have;
+    if (!todo) return R3DM_OK;
+    const uint32_t GB = (h.G + 1) / 2;
+    if (todo & kLayRows) {
+        R3DM_HIP(c, h.rows.ensure((size_t)std::max<uint32_t>(h.n, 1) * h.dim * 4 + 256));
+        R3DM_HIP(c, launch_untile_rows(c->stream, h.tiled.as<float>(), h.n, h.dim, h.G, h.n_tiles, h.rows.as<float>()));
+        h.have |= kLayRows;
+    }
+    if (todo & kLayBf16) {
+        const size_t bytes = (size_t)h.n_tiles * GB * 1024 + kSlackBytes;
+        R3DM_HIP(c, h.tiled16.ensure(bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiled16.p, 0, bytes, c->stream));
+        R3DM_HIP(c, launch_stage_bf16(c->stream, h.tiled.as<float>(), h.G, h.n_tiles, h.tiled16.as<uint16_t>()));
+        h.have |= kLayBf16;
+    }
+    if (todo & kLaySplit) {
+        // f16 hi | lo planes of the values scaled by 2^split_k; the kernel derives split_k from max|x| in `stats` exactly as split_k_of does
+        const size_t bytes = (size_t)h.n_tiles * GB * 2048 + kSlackBytes;
+        R3DM_HIP(c, h.tiledh.ensure(bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiledh.p, 0, bytes, c->stream));
+        R3DM_HIP(c, c->d_cnt.ensure(64));
+        uint32_t* st3 = c->d_cnt.as<uint32_t>() + 12;             // (words 12 .. 15 of the counter block: statistics in, split_k out)
+        R3DM_HIP(c, hipMemcpyAsync(st3, h.stat_bits, 12, hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, launch_stage_split(c->stream, h.rows.as<float>(), h.n, h.dim, GB, h.n_tiles, h.tiledh.as<uint16_t>(), st3, reinterpret_cast<int32_t*>(st3 + 3)));
+        h.have |= kLaySplit;
+    }
+    if (todo & kLayCounts) {
         // count tiles (rows = small integers x a row scale: LIOP): f16 integers, half the bytes of the split planes, + a scale per row
-        const size_t tiledc_bytes = (size_t)h.n_tiles * ((h.G + 1) / 2) * 1024 + kSlackBytes;
-        R3DM_HIP(c, h.tiledc.ensure(tiledc_bytes));
-        R3DM_HIP(c, hipMemsetAsync(h.tiledc.p, 0, tiledc_bytes, c->stream));
+        const size_t bytes = (size_t)h.n_tiles * GB * 1024 + kSlackBytes;
+        R3DM_HIP(c, h.tiledc.ensure(bytes));
+        R3DM_HIP(c, hipMemsetAsync(h.tiledc.p, 0, bytes, c->stream));
         R3DM_HIP(c, h.cscale.ensure((size_t)h.n_tiles * 32 * 4 + kSlackBytes));
         R3DM_HIP(c, hipMemsetAsync(h.cscale.p, 0, (size_t)h.n_tiles * 32 * 4 + kSlackBytes, c->stream));
         R3DM_HIP(c, h.cquad.ensure((counts_summary_offset(h.n_tiles) + ((size_t)h.n_tiles + 1) * 16) * 4 + kSlackBytes));
-        R3DM_HIP(c, h.tiledp.ensure(tiledc_bytes));
+        R3DM_HIP(c, h.tiledp.ensure(bytes));
         R3DM_HIP(c, h.cperm.ensure((size_t)h.n_tiles * 32 * 4 + 256));
-        R3DM_HIP(c, h.norms.ensure(norm_bytes));
-        R3DM_HIP(c, hipMemsetAsync(h.tiled.p, 0, tiled_bytes, c->stream));
-        R3DM_HIP(c, hipMemsetAsync(h.norms.p, 0, norm_bytes, c->stream));
-        const void* raw = nullptr;
-        if (n) {
-            if (dtype == R3DM_F32) {
-                R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim * 4));
-                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim * 4, hipMemcpyDefault, c->stream));
-            } else {
-                R3DM_HIP(c, c->d_raw.ensure((size_t)n * dim));
-                R3DM_HIP(c, hipMemcpyAsync(c->d_raw.p, desc, (size_t)n * dim, hipMemcpyDefault, c->stream));
-            }
-            raw = c->d_raw.p;
-        }
-        (void)raw;
+        h.have |= kLayCounts;
+        h.counts_ok = false;                                      // until the check's verdict is read (ensure_layouts)
     }
-    if (xy && n) {
-        R3DM_HIP(c, h.xy.ensure((size_t)n * 8));
-        R3DM_HIP(c, hipMemcpyAsync(h.xy.p, xy, (size_t)n * 8, hipMemcpyDefault, c->stream));
-    }
-    // position classes (IndMatchDecorator de-duplication needs to know which features share a position): canon[k] = the smallest
-    // index among the features at k's position.  One hash pass (equal floats <-> equal bit patterns once -0 is folded into +0; a NaN
-    // equals nothing, itself included); host positions are read where they are.
-    if (xy && n > 1) {
-        std::vector<float> hxy_copy;
-        const float* hxy = xy;
-        {
-            hipPointerAttribute_t at{};
-            const bool on_device = hipPointerGetAttributes(&at, xy) == hipSuccess && (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged);
-            (void)hipGetLastError();
-            if (on_device) {
-                hxy_copy.resize((size_t)n * 2);
-                R3DM_HIP(c, hipMemcpyAsync(hxy_copy.data(), h.xy.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-                R3DM_HIP(c, hipStreamSynchronize(c->stream));
-                hxy = hxy_copy.data();
-            }
+    return R3DM_OK;
+}
+
+// the count tiles' kernels write their verdict into a word the caller names (the table entry's counts_fail, or scratch)
+static int launch_counts_of(r3dm_ctx* c, HostImage& h, uint32_t* fail_dev)
+{
+    R3DM_HIP(c, hipMemsetAsync(fail_dev, 0, 4, c->stream));
+    R3DM_HIP(c, launch_stage_counts(c->stream, h.rows.as<float>(), h.n, h.dim, (h.G + 1) / 2, h.n_tiles, h.tiledc.as<uint16_t>(), h.cscale.as<float>(), h.norms.as<float>(),
+                                    h.tiledp.as<uint16_t>(), h.cquad.as<float>(), h.cperm.as<uint32_t>(), fail_dev));
+    return R3DM_OK;
+}
+
+int ensure_layouts(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t want, bool* counts_all_ok)
+{
+    std::sort(slots.begin(), slots.end());
+    slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+    int rc = sync_view_stats(c);                               // entries are republished below: the host must hold their statistics
+    if (rc != R3DM_OK) return rc;
+    // verdict words of count-tile checks launched here: one per slot, in scratch (an entry republished behind the kernel would overwrite its own)
+    std::vector<uint32_t> checked;
+    std::vector<std::unique_lock<std::mutex>> locks;
+    for (uint32_t s : slots) {
+        HostImage& m = *c->imgs[s];
+        HostImage* h = &m;
+        if (m.borrowed && m.owner) {
+            // a mounted index: its layouts belong to the index and are added there, under its lock (searches from other contexts run
+            // on the buffers it already holds)
+            uint32_t w = want;
+            if (m.dtype != R3DM_BIN && (w & (kLayCounts | kLaySplit))) w |= kLayRows;
+            if ((w & ~m.owner->img.have) == 0 && (w & ~m.have) == 0) continue;
+            locks.emplace_back(m.owner->mu);
+            h = &m.owner->img;
         }
-        std::vector<uint32_t> canon(n);
-        bool dup = false;
-        {
-            // open addressing, linear probing, table of >= 2 n slots: a slot holds the first feature index seen at a position
+        const uint32_t before = h->have;
+        rc = ensure_layouts_image(c, *h, want);
+        if (rc != R3DM_OK) return rc;
+        if ((h->have & ~before) & kLayCounts) checked.push_back(s);
+        if (h != &m) {
+            m.rows = h->rows; m.tiled16 = h->tiled16; m.tiledh = h->tiledh; m.tiledc = h->tiledc; m.tiledp = h->tiledp; m.cscale = h->cscale; m.cquad = h->cquad;
+            m.cperm = h->cperm; m.tiled8 = h->tiled8; m.norms = h->norms; m.have = h->have; m.counts_ok = h->counts_ok;
+        }
+        if (h->have != before || h != &m) { rc = publish_entry(c, s); if (rc != R3DM_OK) return rc; }
+    }
+    if (!checked.empty()) {
+        R3DM_HIP(c, c->d_verdict.ensure(checked.size() * 4 + 64));
+        R3DM_HIP(c, c->pin_small.ensure(checked.size() * 4 + 64));
+        for (size_t k = 0; k < checked.size(); ++k) {
+            HostImage& m = *c->imgs[checked[k]];
+            rc = launch_counts_of(c, (m.borrowed && m.owner) ? m.owner->img : m, c->d_verdict.as<uint32_t>() + k);
+            if (rc != R3DM_OK) return rc;
+        }
+        R3DM_HIP(c, hipMemcpyAsync(c->pin_small.p, c->d_verdict.p, checked.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        R3DM_HIP(c, hipStreamSynchronize(c->stream));
+        const uint32_t* v = c->pin_small.as<uint32_t>();
+        for (size_t k = 0; k < checked.size(); ++k) {
+            HostImage& m = *c->imgs[checked[k]];
+            m.counts_ok = v[k] == 0;
+            if (m.borrowed && m.owner) m.owner->img.counts_ok = m.counts_ok;
+        }
+    }
+    if (!locks.empty()) R3DM_HIP(c, hipStreamSynchronize(c->stream));     // other contexts may read the index's new layouts once the locks are gone
+    if (counts_all_ok) {
+        *counts_all_ok = true;
+        for (uint32_t s : slots) if (!((c->imgs[s]->have & kLayCounts) && c->imgs[s]->counts_ok)) { *counts_all_ok = false; break; }
+    }
+    return R3DM_OK;
+}
+
+// ---- the upload ring
+enum { kSrcPageable = 0, kSrcPinned = 1, kSrcDevice = 2 };
+static int source_kind(const void* p, const void** dev_ptr)
+{
+    *dev_ptr = p;
+    if (!p) return kSrcPageable;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return kSrcPageable; }
+    if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) return kSrcDevice;
+    if (at.type == hipMemoryTypeHost && at.devicePointer) { *dev_ptr = at.devicePointer; return kSrcPinned; }
+    return kSrcPageable;
+}
+
+// next ring slot, free to be overwritten (its last view's kernels have run)
+static int ring_acquire(r3dm_ctx* c, int* slot_out)
+{
+    UploadRing& r = c->ring;
+    const int s = (int)(r.next++ % UploadRing::kSlots);
+    if (!r.ev[s]) R3DM_HIP(c, hipEventCreateWithFlags(&r.ev[s], hipEventDisableTiming));
+    if (r.busy[s]) { R3DM_HIP(c, hipEventSynchronize(r.ev[s])); r.busy[s] = false; }
+    *slot_out = s;
+    return R3DM_OK;
+}
+
+struct ViewSrc {
+    uint32_t view_id, width, height;
+    const void* desc; uint32_t n, dim; r3dm_dtype dtype; const float* xy;
+};
+
+static inline size_t desc_bytes_of(const ViewSrc& v) { return (size_t)v.n * v.dim * (v.dtype == R3DM_F32 ? 4 : 1); }
+static inline size_t ring_xy_offset(const ViewSrc& v) { return (desc_bytes_of(v) + 255) / 256 * 256; }
+
+// host rows -> the ring slot's page-locked buffer (callable from helper threads: touches nothing but the slot)
+static void ring_fill(const UploadRing& r, int s, const ViewSrc& v, bool desc_from_host, bool xy_from_host)
+{
+    unsigned char* dst = r.pin[s].as<unsigned char>();
+    if (desc_from_host && v.n) std::memcpy(dst, v.desc, desc_bytes_of(v));
+    if (xy_from_host && v.xy && v.n) std::memcpy(dst + ring_xy_offset(v), v.xy, (size_t)v.n * 8);
+}
+
+// Stage one view into `slot`.  `s` = its ring slot (acquired; the page-locked buffer already holds the host rows when filled = true).
+// Leaves the stream with: [DMA of the slot] -> staging kernel(s) -> the slot's event.  Nothing is waited for.
+static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, int kind_desc, const void* dev_desc, int kind_xy, const void* dev_xy, bool filled)
+{
+    HostImage& h = *c->imgs[slot];
+    UploadRing& r = c->ring;
+    h.view_id = v.view_id; h.n = v.n; h.dim = v.dim; h.dtype = v.dtype; h.width = v.width; h.height = v.height;
+    h.has_xy = (v.xy != nullptr); h.has_dup = false; h.live = true;
+    h.G = 0; h.n_tiles = 0; h.words = 0; h.ann_K = 0; h.hnsw_M = 0; h.mrpt_trees = 0; h.compact_ready = false;
+    h.have = 0; h.stats_valid = false; h.counts_ok = false; h.split_k = 0; h.max_abs = 0.0f; h.not_integer = true; h.has_negative = true;
+    const uint32_t n = v.n, dim = v.dim;
+    const size_t dbytes = desc_bytes_of(v), xy_off = ring_xy_offset(v), xy_bytes = v.xy ? (size_t)n * 8 : 0;
+    const bool desc_ring = kind_desc == kSrcPageable && n, xy_ring = v.xy && kind_xy == kSrcPageable && n;
+    const int zero_copy = r3dm_dev_knob("R3DM_UPLOAD_ZEROCOPY", 0);
+    // ---- where the kernel reads the raw rows / the positions
+    const void* raw = dev_desc; const float* xy_src = (const float*)dev_xy;
+    if (desc_ring || xy_ring) {
+        if (!filled) {
+            R3DM_HIP(c, r.pin[s].ensure(xy_off + xy_bytes + 256));
+            ring_fill(r, s, v, desc_ring, xy_ring);
+        }
+        const unsigned char* base;
+        if (zero_copy) base = r.pin[s].as<unsigned char>();               // the kernel reads the page-locked slot over the link
+        else {
+            R3DM_HIP(c, r.raw[s].ensure(xy_off + xy_bytes + 256));
+            // one DMA for rows + positions when both are in the slot, else the part that is
+            const size_t from = desc_ring ? 0 : xy_off, to = xy_ring ? xy_off + xy_bytes : dbytes;
+            R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + from, r.pin[s].as<unsigned char>() + from, to - from, hipMemcpyHostToDevice, c->stream));
+            base = r.raw[s].as<unsigned char>();
+        }
+        if (desc_ring) raw = base;
+        if (xy_ring) xy_src = (const float*)(base + xy_off);
+        c->n_ring_uploads += 1;
+    } else c->n_direct_uploads += 1;
+
+    int rc = table_reserve(c, c->imgs.size());
+    if (rc != R3DM_OK) return rc;
+    ImgDev* entry_dev = c->d_imgs.as<ImgDev>() + slot;
+    StageViewArgs A{};
+    A.n = n; A.dim = dim;
+    if (v.xy) {
+        R3DM_HIP(c, h.xy.ensure((size_t)std::max<uint32_t>(n, 1) * 8));
+        R3DM_HIP(c, h.canon.ensure((size_t)std::max<uint32_t>(n, 1) * 4));
+        A.xy_src = n ? xy_src : nullptr; A.xy_dst = h.xy.as<float>(); A.canon_dst = h.canon.as<uint32_t>(); A.has_dup = &entry_dev->has_dup;
+        if (n > 1) {
+            // position classes: a hash table of >= 2 n slots per view in flight
             uint32_t bits = 4;
             while ((1u << bits) < 2u * n) ++bits;
-            const uint32_t mask = (1u << bits) - 1u;
-            std::vector<uint64_t> keys((size_t)1 << bits);
-            std::vector<uint32_t> vals((size_t)1 << bits, 0xFFFFFFFFu);
-            for (uint32_t k = 0; k < n; ++k) {
-                const float fx = hxy[2 * (size_t)k], fy = hxy[2 * (size_t)k + 1];
-                canon[k] = k;
-                if (fx != fx || fy != fy) continue;                           // NaN: a class of its own
-                uint32_t bx, by;
-                const float zx = fx == 0.0f ? 0.0f : fx, zy = fy == 0.0f ? 0.0f : fy;
-                std::memcpy(&bx, &zx, 4); std::memcpy(&by, &zy, 4);
-                const uint64_t key = ((uint64_t)bx << 32) | by;
-                uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - bits)) & mask;
-                while (vals[slot] != 0xFFFFFFFFu && keys[slot] != key) slot = (slot + 1u) & mask;
-                if (vals[slot] == 0xFFFFFFFFu) { keys[slot] = key; vals[slot] = k; }
-                else { canon[k] = vals[slot]; dup = true; }                   // ascending k: the stored index is the smallest of the class
-            }
-        }
-        if (dup) {
-            h.has_dup = true;
-            R3DM_HIP(c, h.canon.ensure((size_t)n * 4));
-            R3DM_HIP(c, hipMemcpyAsync(h.canon.p, canon.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-            R3DM_HIP(c, hipStreamSynchronize(c->stream));
+            const size_t tab_bytes = ((size_t)12) << bits;
+            R3DM_HIP(c, r.ctab[s].ensure(tab_bytes));
+            R3DM_HIP(c, hipMemsetAsync(r.ctab[s].p, 0xFF, tab_bytes, c->stream));
+            A.canon_keys = r.ctab[s].as<unsigned long long>(); A.canon_vals = reinterpret_cast<uint32_t*>(r.ctab[s].as<unsigned char>() + ((size_t)8 << bits)); A.canon_bits = bits;
         }
     }
-    int rc = upload_imgdev(c, slot);
-    if (rc != R3DM_OK) return rc;
-    if (dtype != R3DM_BIN) {
-        uint32_t* mx = &(c->d_imgs.as<ImgDev>() + slot)->max_norm_bits;
-        R3DM_HIP(c, launch_stage_f32(c->stream, n ? c->d_raw.p : nullptr, dtype == R3DM_U8, n, dim, h.rows.as<float>(),
-                                     h.tiled.as<float>(), h.tiled16.as<uint16_t>(), h.norms.as<float>(), h.G, h.n_tiles, mx));
-        int32_t* sk = &(c->d_imgs.as<ImgDev>() + slot)->split_k;
-        R3DM_HIP(c, launch_stage_split(c->stream, h.rows.as<float>(), n, dim, (h.G + 1) / 2, h.n_tiles, h.tiledh.as<uint16_t>(), mx, sk));
-        // count tiles: the staging kernel sets counts_fail when some row is not integers x a scale (the table entry starts at "fails";
-        // clear it first: upload_imgdev wrote 1)
-        uint32_t* cf = &(c->d_imgs.as<ImgDev>() + slot)->counts_fail;
-        uint32_t cfail = 1;
-        if (dtype == R3DM_F32 && n && dim <= 256) {
-            R3DM_HIP(c, hipMemsetAsync(cf, 0, 4, c->stream));
-            R3DM_HIP(c, launch_stage_counts(c->stream, h.rows.as<float>(), n, dim, (h.G + 1) / 2, h.n_tiles, h.tiledc.as<uint16_t>(), h.cscale.as<float>(), h.norms.as<float>(),
-                                            h.tiledp.as<uint16_t>(), h.cquad.as<float>(), h.cperm.as<uint32_t>(), cf));
-            R3DM_HIP(c, hipMemcpyAsync(&cfail, cf, 4, hipMemcpyDeviceToHost, c->stream));
-        }
-        uint32_t st3[3] = {0, 0, 1};
-        R3DM_HIP(c, hipMemcpyAsync(st3, mx, 12, hipMemcpyDeviceToHost, c->stream));
-        R3DM_HIP(c, hipMemcpyAsync(&h.split_k, sk, 4, hipMemcpyDeviceToHost, c->stream));
-        R3DM_HIP(c, hipStreamSynchronize(c->stream));
-        h.counts_ok = cfail == 0;
-        std::memcpy(&h.max_abs, &st3[1], 4);
-        h.not_integer = (st3[2] & 1u) != 0;
-        h.has_negative = (st3[2] & 2u) != 0;
+    // layouts of the paths that are switched on already are staged behind the view (else: their first call stages them)
+    uint32_t eager = 0;
+    if (v.dtype == R3DM_BIN) { if (c->hamming_mfma) eager |= kLayBin8; }
+    else {
+        if (c->integer_mfma) eager |= kLayBf16;
+        if (c->split_mfma) eager |= kLayRows | ((v.dtype == R3DM_F32 && n && dim <= 256) ? kLayCounts : 0u);
     }
-    R3DM_HIP(c, hipStreamSynchronize(c->stream));     // d_raw is reused by the next call
+    if (v.dtype == R3DM_BIN) {
+        h.words = (dim + 3) / 4;
+        R3DM_HIP(c, h.bin.ensure((size_t)(n + 8) * h.words * 4 + kSlackBytes));
+        h.n_tiles = (n + kTileRows - 1) / kTileRows;
+    } else {
+        h.G = kernel_G_for(dim);
+        h.n_tiles = (n + kTileRows - 1) / kTileRows;
+        R3DM_HIP(c, h.tiled.ensure((size_t)h.n_tiles * h.G * 1024 + kSlackBytes));
+        R3DM_HIP(c, h.norms.ensure((size_t)h.n_tiles * 32 * 4 + kSlackBytes));
+        if (eager & kLayRows) {                                   // written by the staging kernel itself, from the tile it holds in LDS
+            R3DM_HIP(c, h.rows.ensure((size_t)std::max<uint32_t>(n, 1) * dim * 4 + 256));
+            h.have |= kLayRows;
+        }
+    }
+    // the table entry: written once from the mirror with the statistics zeroed; the kernels accumulate into it
+    ImgDev* m = c->tab_host.as<ImgDev>() + slot;
+    fill_entry(h, *m);
+    R3DM_HIP(c, hipMemcpyAsync(entry_dev, m, sizeof(ImgDev), hipMemcpyHostToDevice, c->stream));
+    if (v.xy && n == 1) R3DM_HIP(c, hipMemsetAsync(h.canon.p, 0, 4, c->stream));          // one feature: its own class
+    if (v.dtype == R3DM_BIN) {
+        R3DM_HIP(c, launch_stage_bin(c->stream, (const uint8_t*)raw, n, dim, h.bin.as<uint32_t>(), h.words, n + 8));
+        R3DM_HIP(c, launch_stage_positions(c->stream, A));
+    } else {
+        A.raw = raw; A.raw_is_u8 = v.dtype == R3DM_U8; A.G = h.G; A.n_tiles = h.n_tiles;
+        A.tiled = h.tiled.as<float>(); A.norms = h.norms.as<float>(); A.rows = (h.have & kLayRows) ? h.rows.as<float>() : nullptr;
+        A.img_stats = &entry_dev->max_norm_bits;
+        R3DM_HIP(c, launch_stage_view(c->stream, A));
+    }
+    if (eager & ~h.have) {
+        rc = ensure_layouts_image(c, h, eager);
+        if (rc != R3DM_OK) return rc;
+        // pointer fields only: the statistics words of the entry belong to the kernels until sync_view_stats
+        ImgDev e; fill_entry(h, e);
+        m->tiled16 = e.tiled16; m->tiledc = e.tiledc; m->cscale = e.cscale; m->cquad = e.cquad; m->tiledp = e.tiledp; m->cperm = e.cperm; m->tiled8 = e.tiled8;
+        if (v.dtype == R3DM_BIN) { m->norms = e.norms; R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->norms, &m->norms, sizeof(void*), hipMemcpyHostToDevice, c->stream)); }
+        R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->tiled16, &m->tiled16, sizeof(void*), hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->tiledc, &m->tiledc, offsetof(ImgDev, counts_fail) - offsetof(ImgDev, tiledc), hipMemcpyHostToDevice, c->stream));
+        R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->tiled8, &m->tiled8, sizeof(void*), hipMemcpyHostToDevice, c->stream));
+        if (h.have & kLayCounts) { rc = launch_counts_of(c, h, &entry_dev->counts_fail); if (rc != R3DM_OK) return rc; }
+    }
+    R3DM_HIP(c, hipEventRecord(r.ev[s], c->stream));
+    r.busy[s] = true;
+    c->pending_stats.push_back(slot);
     c->n_views_staged += 1;
     return R3DM_OK;
+}
+
+static int check_view(r3dm_ctx* c, const ViewSrc& v)
+{
+    if (v.dim == 0 || (v.n && !v.desc)) return R3DM_ERR_INVALID;
+    if (v.dtype != R3DM_F32 && v.dtype != R3DM_U8 && v.dtype != R3DM_BIN) return R3DM_ERR_INVALID;
+    if (v.n >= (1u << 22)) { c->err = "more than 4M features in one view"; return R3DM_ERR_UNSUPPORTED; }
+    if (v.dtype == R3DM_BIN && !(((v.dim + 3) / 4) == 8 || ((v.dim + 3) / 4) == 16)) {
+        c->err = "binary descriptors must be 29..32 or 61..64 bytes"; return R3DM_ERR_UNSUPPORTED;
+    }
+    return R3DM_OK;
+}
+
+// copy + re-layout one view into slot `slot`.  Returns with the caller's buffers consumed: host rows sit in the ring; device (or
+// page-locked) buffers the kernel reads in place are waited for.
+int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width, uint32_t height,
+                    const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
+{
+    const ViewSrc v{view_id, width, height, desc, n, dim, dtype, xy};
+    const void *dd = nullptr, *dx = nullptr;
+    const int kd = source_kind(desc, &dd), kx = source_kind(xy, &dx);
+    int s = 0;
+    int rc = ring_acquire(c, &s);
+    if (rc != R3DM_OK) return rc;
+    rc = stage_enqueue(c, slot, v, s, kd, dd, kx, dx, false);
+    if (rc != R3DM_OK) return rc;
+    if ((n && kd != kSrcPageable) || (xy && n && kx != kSrcPageable)) R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    return R3DM_OK;
+}
+
+static uint32_t slot_for_view(r3dm_ctx* c, uint32_t view_id)
+{
+    auto it = c->slot_of.find(view_id);
+    if (it != c->slot_of.end()) return it->second;
+    const uint32_t slot = (uint32_t)c->imgs.size();
+    if (!c->spare.empty()) { c->imgs.emplace_back(std::move(c->spare.back())); c->spare.pop_back(); }      // buffers of a cleared view
+    else { c->imgs.emplace_back(new HostImage()); c->imgs.back()->use_arena(&c->arena); }
+    c->slot_of[view_id] = slot;
+    return slot;
 }
 
 static int r3dm_set_image_impl(r3dm_ctx* c, uint32_t view_id, uint32_t width, uint32_t height,
                               const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
 {
-    if (!c || dim == 0 || (n && !desc)) return R3DM_ERR_INVALID;
-    if (dtype != R3DM_F32 && dtype != R3DM_U8 && dtype != R3DM_BIN) return R3DM_ERR_INVALID;
-    if (n >= (1u << 22)) { c->err = "more than 4M features in one view"; return R3DM_ERR_UNSUPPORTED; }
-    if (dtype == R3DM_BIN && !(((dim + 3) / 4) == 8 || ((dim + 3) / 4) == 16)) {
-        c->err = "binary descriptors must be 29..32 or 61..64 bytes"; return R3DM_ERR_UNSUPPORTED;
-    }
+    if (!c) return R3DM_ERR_INVALID;
+    const ViewSrc v{view_id, width, height, desc, n, dim, dtype, xy};
+    int rc = check_view(c, v);
+    if (rc != R3DM_OK) return rc;
     R3DM_HIP(c, hipSetDevice(c->device));
-    uint32_t slot;
-    auto it = c->slot_of.find(view_id);
-    if (it == c->slot_of.end()) {
-        slot = (uint32_t)c->imgs.size();
-        if (!c->spare.empty()) { c->imgs.emplace_back(std::move(c->spare.back())); c->spare.pop_back(); }      // buffers of a cleared view
-        else c->imgs.emplace_back(new HostImage());
-        c->slot_of[view_id] = slot;
-    } else slot = it->second;
-    return stage_into_slot(c, slot, view_id, width, height, desc, n, dim, dtype, xy);
+    return stage_into_slot(c, slot_for_view(c, view_id), view_id, width, height, desc, n, dim, dtype, xy);
 }
 
 extern "C" int r3dm_set_image(r3dm_ctx* c, uint32_t view_id, uint32_t width, uint32_t height,
                               const void* desc, uint32_t n, uint32_t dim, r3dm_dtype dtype, const float* xy)
 {
     return r3dm_guarded(c, [&]() -> int { return r3dm_set_image_impl(c, view_id, width, height, desc, n, dim, dtype, xy); });
+}
+
+// A whole collection in one call: helper threads copy the pageable rows of the next views into ring slots while the DMA and the kernels
+// of the previous ones run; one synchronisation at the end, and only when some view was read where the caller keeps it.
+static int r3dm_set_images_impl(r3dm_ctx* c, const r3dm_view_desc* views, uint32_t n_views)
+{
+    if (!c || (n_views && !views)) return R3DM_ERR_INVALID;
+    if (n_views == 0) return R3DM_OK;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    std::vector<ViewSrc> vs(n_views);
+    std::vector<int> kd(n_views), kx(n_views);
+    std::vector<const void*> dd(n_views), dx(n_views);
+    std::vector<uint32_t> slots(n_views);
+    for (uint32_t k = 0; k < n_views; ++k) {
+        const r3dm_view_desc& w = views[k];
+        vs[k] = ViewSrc{w.view_id, w.width, w.height, w.desc, w.n, w.dim, (r3dm_dtype)w.dtype, w.xy};
+        int rc = check_view(c, vs[k]);
+        if (rc != R3DM_OK) return rc;
+        kd[k] = source_kind(w.desc, &dd[k]); kx[k] = source_kind(w.xy, &dx[k]);
+    }
+    for (uint32_t k = 0; k < n_views; ++k) slots[k] = slot_for_view(c, vs[k].view_id);
+    int rc = table_reserve(c, c->imgs.size());
+    if (rc != R3DM_OK) return rc;
+    UploadRing& r = c->ring;
+    constexpr int S = UploadRing::kSlots;
+    // every slot's page-locked buffer sized for the largest view before the helpers start (they only memcpy)
+    size_t max_slot = 0;
+    bool any_host = false, any_inplace = false;
+    for (uint32_t k = 0; k < n_views; ++k) {
+        const bool dh = kd[k] == kSrcPageable && vs[k].n, xh = vs[k].xy && kx[k] == kSrcPageable && vs[k].n;
+        if (dh || xh) { any_host = true; max_slot = std::max(max_slot, ring_xy_offset(vs[k]) + (size_t)vs[k].n * 8 + 256); }
+        if ((vs[k].n && kd[k] != kSrcPageable) || (vs[k].xy && vs[k].n && kx[k] != kSrcPageable)) any_inplace = true;
+    }
+    if (any_host) {
+        for (int s = 0; s < S; ++s) {
+            if (r.busy[s]) { R3DM_HIP(c, hipEventSynchronize(r.ev[s])); r.busy[s] = false; }
+            R3DM_HIP(c, r.pin[s].ensure(max_slot));
+        }
+    }
+    // view k uses ring slot (base + k) % S.  state[k]: 0 waiting, 1 filled by a helper, 2 enqueued (its event is recorded)
+    const uint64_t base = r.next;
+    std::vector<std::atomic<int>> state(n_views);
+    for (auto& a : state) a.store(0, std::memory_order_relaxed);
+    std::atomic<uint32_t> next_fill{0};
+    std::atomic<bool> abort{false};
+    const int T = any_host ? r3dm_host_team(4, 1) : 0;
+    auto helper = [&]() {
+        (void)hipSetDevice(c->device);
+        for (;;) {
+            const uint32_t k = next_fill.fetch_add(1, std::memory_order_relaxed);
+            if (k >= n_views || abort.load(std::memory_order_relaxed)) break;
+            const int s = (int)((base + k) % S);
+            // the slot's previous user in this batch must have been enqueued, and its kernels done
+            if (k >= (uint32_t)S) {
+                while (state[k - S].load(std::memory_order_acquire) != 2) { if (abort.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
+                (void)hipEventSynchronize(r.ev[s]);
+            }
+            ring_fill(r, s, vs[k], kd[k] == kSrcPageable, kx[k] == kSrcPageable);
+            state[k].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    try { for (int t = 0; t < T; ++t) th.emplace_back(helper); } catch (...) {}
+    const bool helpers = !th.empty();
+    rc = R3DM_OK;
+    for (uint32_t k = 0; k < n_views && rc == R3DM_OK; ++k) {
+        const int s = (int)((base + k) % S);
+        if (!r.ev[s]) { hipError_t e = hipEventCreateWithFlags(&r.ev[s], hipEventDisableTiming); if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = R3DM_ERR_HIP; break; } }
+        bool filled = false;
+        if (helpers) { while (state[k].load(std::memory_order_acquire) != 1) std::this_thread::yield(); filled = true; }
+        else if (r.busy[s]) { if (hipEventSynchronize(r.ev[s]) != hipSuccess) { c->err = "hipEventSynchronize"; rc = R3DM_ERR_HIP; break; } r.busy[s] = false; }
+        rc = stage_enqueue(c, slots[k], vs[k], s, kd[k], dd[k], kx[k], dx[k], filled);
+        state[k].store(2, std::memory_order_release);
+    }
+    if (rc != R3DM_OK) { abort.store(true); for (auto& a : state) a.store(2, std::memory_order_release); }
+    for (std::thread& t : th) t.join();
+    r.next = base + n_views;
+    if (rc != R3DM_OK) return rc;
+    if (any_inplace) R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_set_images(r3dm_ctx* c, const r3dm_view_desc* views, uint32_t n_views)
+{
+    return r3dm_guarded(c, [&]() -> int { return r3dm_set_images_impl(c, views, n_views); });
+}
+
+extern "C" int r3dm_view_info(r3dm_ctx* c, uint32_t view_id, uint32_t* layouts, uint64_t* bytes, uint64_t* ring_uploads, uint64_t* direct_uploads)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    auto it = c->slot_of.find(view_id);
+    if (it == c->slot_of.end()) { c->err = "unregistered view"; return R3DM_ERR_INVALID; }
+    const HostImage& h = *c->imgs[it->second];
+    static_assert(kLayRows == R3DM_LAYOUT_ROWS && kLayBf16 == R3DM_LAYOUT_BF16 && kLaySplit == R3DM_LAYOUT_SPLIT && kLayCounts == R3DM_LAYOUT_COUNTS &&
+                  kLayBin8 == R3DM_LAYOUT_BIN8, "public layout bits");
+    if (layouts) *layouts = h.have;
+    if (bytes) {
+        // what the view's live layouts occupy (a recycled buffer may be larger than its present tenant; buffers of layouts the view
+        // does not hold -- kept from an earlier tenant -- are not counted)
+        uint64_t b = 0;
+        if (h.dtype == R3DM_BIN) b += h.bin.cap; else b += h.tiled.cap + h.norms.cap;
+        if (h.has_xy) b += h.xy.cap + h.canon.cap;
+        if (h.have & kLayRows) b += h.rows.cap;
+        if (h.have & kLayBf16) b += h.tiled16.cap;
+        if (h.have & kLaySplit) b += h.tiledh.cap;
+        if (h.have & kLayCounts) b += h.tiledc.cap + h.tiledp.cap + h.cscale.cap + h.cquad.cap + h.cperm.cap;
+        if (h.have & kLayBin8) b += h.tiled8.cap + h.norms.cap;
+        if (h.ann_K) b += h.ann_adj.cap + h.ann_deg.cap;
+        if (h.compact_ready) b += h.ann_rows16.cap + h.ann_rows8.cap;
+        if (h.hnsw_M) b += h.hnsw_l0.cap + h.hnsw_up_off.cap + h.hnsw_up.cap;
+        if (h.mrpt_trees) b += h.mrpt_R.cap + h.mrpt_RT.cap + h.mrpt_splits.cap + h.mrpt_leaves.cap + h.mrpt_lf.cap;
+        *bytes = b;
+    }
+    if (ring_uploads) *ring_uploads = c->n_ring_uploads;
+    if (direct_uploads) *direct_uploads = c->n_direct_uploads;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_memory_info(const r3dm_ctx* c, uint64_t* views_device_bytes, uint64_t* ring_device_bytes, uint64_t* ring_host_bytes)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    if (views_device_bytes) *views_device_bytes = c->arena.bytes_held();
+    uint64_t rd = 0, rh = 0;
+    for (int k = 0; k < UploadRing::kSlots; ++k) { rd += c->ring.raw[k].cap + c->ring.ctab[k].cap; rh += c->ring.pin[k].cap; }
+    if (ring_device_bytes) *ring_device_bytes = rd;
+    if (ring_host_bytes) *ring_host_bytes = rh;
+    return R3DM_OK;
+}
+
+// everything registered so far is resident and laid out (the registration calls return with work still queued on the context's stream)
+extern "C" int r3dm_images_wait(r3dm_ctx* c)
+{
+    if (!c) return R3DM_ERR_INVALID;
+    R3DM_HIP(c, hipSetDevice(c->device));
+    R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    return R3DM_OK;
 }
 
 // the size of a helper team of host threads that fits the cores this process may use (affinity mask and cgroup CPU quota), at most `want`
@@ -326,11 +690,12 @@ extern "C" int r3dm_clear_images(r3dm_ctx* c)
         im->ann_adj.release(); im->ann_deg.release(); im->ann_rows16.release(); im->ann_rows8.release();
         im->hnsw_l0.release(); im->hnsw_up_off.release(); im->hnsw_up.release();
         im->mrpt_R.release(); im->mrpt_RT.release(); im->mrpt_splits.release(); im->mrpt_leaves.release(); im->mrpt_lf.release();
-        im->live = false; im->has_K = false; im->ann_K = 0; im->hnsw_M = 0; im->mrpt_trees = 0; im->compact_ready = false; im->n = 0; im->counts_ok = false;
+        im->live = false; im->has_K = false; im->ann_K = 0; im->hnsw_M = 0; im->mrpt_trees = 0; im->compact_ready = false; im->n = 0; im->counts_ok = false; im->have = 0; im->stats_valid = false;
         c->spare.push_back(std::move(im));
     }
     c->imgs.clear();
     c->slot_of.clear();
+    c->pending_stats.clear();
     return R3DM_OK;
 }
 
@@ -523,35 +888,47 @@ extern "C" int r3dm_save_matches(const r3dm_graph* g, const char* path)
         const uint64_t total = g->matches.size();
         int T = total > 200000 ? r3dm_host_team(4, 4) : 1;
         if (T < 1) T = 1;
-        // chunk c = pairs [cut[c], cut[c + 1]): boundaries where the running match count passes c / T of the total
-        std::vector<uint64_t> cut((size_t)T + 1, np);
-        cut[0] = 0;
-        for (int c = 1; c < T; ++c) {
-            const uint64_t want = total / (uint64_t)T * (uint64_t)c;
-            cut[c] = (uint64_t)(std::upper_bound(g->offsets.begin(), g->offsets.begin() + (ptrdiff_t)np, want) - g->offsets.begin());
-            if (cut[c] > np) cut[c] = np;
-            if (cut[c] < cut[c - 1]) cut[c] = cut[c - 1];
-        }
+        // rounds of at most ~64 MiB of text (a graph of 1e8 matches is 2 GB of text: it is never held whole): a round = a run of pairs,
+        // split among the T threads where the running match count passes c / T of the round's, written in order, buffers reused
+        constexpr uint64_t kRoundMatches = (64ull << 20) / 22;
         std::vector<std::vector<char>> bufs((size_t)T);
         std::vector<size_t> lens((size_t)T, 0);
         std::vector<int> failed((size_t)T, 0);
-        r3dm_parallel_for((long)T, T, [&](long c) {
-            try {
-                const uint64_t p0 = cut[c], p1 = cut[c + 1];
-                if (p1 <= p0) return;
-                const uint64_t mcount = g->offsets[p1] - g->offsets[p0];
-                bufs[(size_t)c].resize((size_t)(mcount * 22 + (p1 - p0) * 44 + 64));        // a line <= 22 bytes, a pair header <= 11 + 11 + 21
-                char* o = bufs[(size_t)c].data();
-                for (uint64_t p = p0; p < p1; ++p) {
-                    o = put_u64(o, g->pairs[2 * p], ' '); o = put_u64(o, g->pairs[2 * p + 1], '\n'); o = put_u64(o, g->offsets[p + 1] - g->offsets[p], '\n');
-                    for (uint64_t k = g->offsets[p]; k < g->offsets[p + 1]; ++k) { o = put_u64(o, g->matches[k].i, ' '); o = put_u64(o, g->matches[k].j, '\n'); }
-                }
-                lens[(size_t)c] = (size_t)(o - bufs[(size_t)c].data());
-            } catch (...) { failed[(size_t)c] = 1; }
-        });
-        for (int c = 0; c < T && ok; ++c) {
-            if (failed[(size_t)c]) { ok = false; break; }
-            if (lens[(size_t)c]) ok &= fwrite(bufs[(size_t)c].data(), 1, lens[(size_t)c], f) == lens[(size_t)c];
+        std::vector<uint64_t> cut((size_t)T + 1, 0);
+        uint64_t r0 = 0;
+        while (r0 < np && ok) {
+            uint64_t r1 = (uint64_t)(std::upper_bound(g->offsets.begin() + (ptrdiff_t)r0, g->offsets.begin() + (ptrdiff_t)np, g->offsets[r0] + kRoundMatches) - g->offsets.begin());
+            if (r1 <= r0) r1 = r0 + 1;                     // (one pair longer than a round: a round of its own)
+            if (r1 > np) r1 = np;
+            const uint64_t rtotal = g->offsets[r1] - g->offsets[r0];
+            cut[0] = r0; cut[(size_t)T] = r1;
+            for (int c = 1; c < T; ++c) {
+                const uint64_t want = g->offsets[r0] + rtotal / (uint64_t)T * (uint64_t)c;
+                cut[c] = (uint64_t)(std::upper_bound(g->offsets.begin() + (ptrdiff_t)r0, g->offsets.begin() + (ptrdiff_t)r1, want) - g->offsets.begin());
+                if (cut[c] > r1) cut[c] = r1;
+                if (cut[c] < cut[c - 1]) cut[c] = cut[c - 1];
+            }
+            r3dm_parallel_for((long)T, T, [&](long c) {
+                lens[(size_t)c] = 0;
+                try {
+                    const uint64_t p0 = cut[c], p1 = cut[c + 1];
+                    if (p1 <= p0) return;
+                    const uint64_t mcount = g->offsets[p1] - g->offsets[p0];
+                    const size_t need = (size_t)(mcount * 22 + (p1 - p0) * 44 + 64);        // a line <= 22 bytes, a pair header <= 11 + 11 + 21
+                    if (bufs[(size_t)c].size() < need) bufs[(size_t)c].resize(need);
+                    char* o = bufs[(size_t)c].data();
+                    for (uint64_t p = p0; p < p1; ++p) {
+                        o = put_u64(o, g->pairs[2 * p], ' '); o = put_u64(o, g->pairs[2 * p + 1], '\n'); o = put_u64(o, g->offsets[p + 1] - g->offsets[p], '\n');
+                        for (uint64_t k = g->offsets[p]; k < g->offsets[p + 1]; ++k) { o = put_u64(o, g->matches[k].i, ' '); o = put_u64(o, g->matches[k].j, '\n'); }
+                    }
+                    lens[(size_t)c] = (size_t)(o - bufs[(size_t)c].data());
+                } catch (...) { failed[(size_t)c] = 1; }
+            });
+            for (int c = 0; c < T && ok; ++c) {
+                if (failed[(size_t)c]) { fclose(f); return R3DM_ERR_NOMEM; }        // (a formatting buffer could not be allocated: not an I/O failure)
+                if (lens[(size_t)c]) ok &= fwrite(bufs[(size_t)c].data(), 1, lens[(size_t)c], f) == lens[(size_t)c];
+            }
+            r0 = r1;
         }
     }
     ok &= (fclose(f) == 0);

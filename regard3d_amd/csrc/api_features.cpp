@@ -982,10 +982,15 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
             (void)hipSetDevice(c->device);
         }
         { const int wrc_prev = features_files_join(c); if (wrc_prev != R3DM_OK) return wrc_prev; }      // (a batch without keypoints has not joined it above)
-        try {
+        // a batch that failed here (text formatting, a sink that refused an image) is reported now and writes NO files: a writer started
+        // for it would make the files of a failed call appear later, in the background
+        bool batch_ok = true;
+        for (uint32_t b = 0; b < B; ++b) if (feat_paths[b] && desc_paths[b] && wrc[b] != R3DM_OK) batch_ok = false;
+        const int nice_value = c->background_nice;
+        if (batch_ok) try {
             // (two threads per context: the writes have the caller's next phase to hide behind and must not take its cores)
-            c->file_writer = std::thread([c, jobs, writer_team = std::min(host_team, 2), wait_desc = n_total != 0]() {
-                r3dm_background_thread();
+            c->file_writer = std::thread([c, jobs, nice_value, writer_team = std::min(host_team, 2), wait_desc = n_total != 0]() {
+                r3dm_background_thread(nice_value);
                 const double t0 = now_ms();
                 if (wait_desc && (hipSetDevice(c->device) != hipSuccess || hipEventSynchronize(c->ev_desc) != hipSuccess)) {
                     c->file_writer_rc = R3DM_ERR_HIP; c->file_writer_err = "the descriptors did not reach the host";
@@ -998,7 +1003,12 @@ static int extract_features_batch_impl(r3dm_ctx* c, uint32_t B, const float* con
                     try { rcs[(size_t)b] = write_feat_desc_files(errs[(size_t)b], j.feat.c_str(), j.desc.c_str(), j.txt.data(), j.len, j.rows, j.n); }
                     catch (...) { rcs[(size_t)b] = R3DM_ERR_NOMEM; }
                 });
-                for (size_t b = 0; b < rcs.size(); ++b) if (rcs[b] != R3DM_OK && c->file_writer_rc == R3DM_OK) { c->file_writer_rc = rcs[b]; c->file_writer_err = errs[b]; }
+                // (the report comes late -- at the wait, or at this context's next batch: it names the file so that it can be traced to its batch)
+                for (size_t b = 0; b < rcs.size(); ++b)
+                    if (rcs[b] != R3DM_OK && c->file_writer_rc == R3DM_OK) {
+                        c->file_writer_rc = rcs[b];
+                        c->file_writer_err = "deferred feature files of " + (*jobs)[b].feat + ": " + (errs[b].empty() ? std::string("write failed") : errs[b]);
+                    }
                 c->file_writer_ms += now_ms() - t0;
             });
         } catch (...) { c->err = "cannot start the feature-file writer"; return R3DM_ERR_NOMEM; }
@@ -1199,6 +1209,21 @@ extern "C" int r3dm_set_deferred_feature_files(r3dm_ctx* c, int on)
     if (!c) return R3DM_ERR_INVALID;
     c->defer_files = on != 0;
     return on ? R3DM_OK : features_files_join(c);
+}
+
+extern "C" int r3dm_set_background_nice(r3dm_ctx* c, int nice_value)
+{
+    if (!c || nice_value < 0 || nice_value > 19) return R3DM_ERR_INVALID;
+    c->background_nice = nice_value;
+    return R3DM_OK;
+}
+
+extern "C" int r3dm_multi_set_background_nice(r3dm_multi* m, int nice_value)
+{
+    if (!m) return R3DM_ERR_INVALID;
+    int rc = R3DM_OK;
+    for (int k = 0; k < r3dm_multi_num_devices(m); ++k) { const int r = r3dm_set_background_nice(r3dm_multi_ctx(m, k), nice_value); if (r != R3DM_OK && rc == R3DM_OK) rc = r; }
+    return rc;
 }
 
 extern "C" int r3dm_features_files_wait(r3dm_ctx* c)

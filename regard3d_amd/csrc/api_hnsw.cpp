@@ -53,6 +53,8 @@ static void hnsw_levels(uint32_t n, uint32_t M, uint32_t seed, std::vector<int32
 // builds the HNSW index of every listed slot that does not hold one for this (M, seed)
 static int ensure_hnsw_indices(r3dm_ctx* c, std::vector<uint32_t> slots, const r3dm_hnsw_params& hp)
 {
+    { const int rcl = ensure_layouts(c, slots, kLayRows); if (rcl != R3DM_OK) return rcl; }      // the index is built from (and searched on) row-major rows
+
     std::sort(slots.begin(), slots.end());
     slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
     std::vector<uint32_t> todo;
@@ -154,6 +156,12 @@ static int run_hnsw_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float r
 {
     const uint32_t P = (uint32_t)jobs.size();
     if (P == 0) return R3DM_OK;
+    {   // queries and index rows are gathered from the row-major rows
+        std::vector<uint32_t> slots;
+        for (const PairJob& j : jobs) { slots.push_back(j.sI); slots.push_back(j.sJ); }
+        const int rcl = ensure_layouts(c, slots, kLayRows);
+        if (rcl != R3DM_OK) return rcl;
+    }
     uint32_t max_nJ = 0, max_nI = 0;
     uint64_t n_queries = 0;
     for (const PairJob& j : jobs) {
@@ -263,6 +271,9 @@ static int r3dm_match_pairs_hnsw_impl(r3dm_ctx* c, const uint32_t* pairs_ij, uin
 
     r3dm_graph ga, gs;
     ga.offsets.push_back(0); gs.offsets.push_back(0);
+    // (r3dm_set_device_graphs) the two part graphs are merged on the host: a device mirror survives that only when one part is the whole
+    // result -- then it is built and handed over; with both kinds of pairs present no mirror is built at all (it would be dropped)
+    PartMirrorGuard mirror_guard(c, !ann_jobs.empty() && !small_jobs.empty());
     if (!ann_jobs.empty()) {
         std::vector<uint32_t> slots;
         for (const PairJob& j : ann_jobs) slots.push_back(j.sI);
@@ -296,8 +307,7 @@ static int r3dm_match_pairs_hnsw_impl(r3dm_ctx* c, const uint32_t* pairs_ij, uin
         if (rc != R3DM_OK) return rc;
         start = end;
     }
-    const r3dm_graph* parts[2] = {&ga, &gs};
-    rc = r3dm_graph_merge(parts, 2, out);
+    rc = merge_parts_keep_mirror(ga, gs, out);
     c->stats.ms_wall_match = now_ms() - t_call;
     return rc;
 }

@@ -87,6 +87,24 @@ int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_str
     return R3DM_OK;
 }
 
+PartMirrorGuard::PartMirrorGuard(r3dm_ctx* c_, bool suppress) : c(c_), keep(c_->device_graphs) { if (suppress) c->device_graphs = false; }
+PartMirrorGuard::~PartMirrorGuard() { c->device_graphs = keep; }
+
+// merged = ga + gs ordered by (I, J).  When one part is empty the other one IS the result (its batches appended pairs in (I, J) order):
+// its device mirror moves to the merged graph instead of being dropped with the part.
+int merge_parts_keep_mirror(r3dm_graph& ga, r3dm_graph& gs, r3dm_graph** out)
+{
+    const r3dm_graph* parts[2] = {&ga, &gs};
+    const int rc = r3dm_graph_merge(parts, 2, out);
+    if (rc != R3DM_OK || !*out) return rc;
+    r3dm_graph* whole = ga.pairs.empty() ? &gs : (gs.pairs.empty() ? &ga : nullptr);
+    if (whole && whole->dev.valid && whole->dev.P == (*out)->pairs.size() / 2 && whole->dev.M == (*out)->matches.size() && (*out)->pairs == whole->pairs) {
+        (*out)->dev = whole->dev;                 // (plain handles: the part forgets them, the merged graph frees them)
+        whole->dev = GraphDev();
+    }
+    return rc;
+}
+
 // runs the 2-NN + ratio kernels over `jobs` (slot pairs, all of one dtype/dim) and appends the
 // non-empty results to `g` in job order.  knn_idx/knn_dist (host, optional) receive the raw 2-NN.
 int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
@@ -95,6 +113,7 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
     const uint32_t P = (uint32_t)jobs.size();
     if (P == 0) return R3DM_OK;
     const double t_dbg0 = now_ms();
+    { const int rcs = sync_view_stats(c); if (rcs != R3DM_OK) return rcs; }      // which path a batch takes depends on its views' statistics
     const HostImage& first = *c->imgs[jobs[0].sI];
     const r3dm_dtype dtype = first.dtype;
     uint32_t max_nJ = 0, max_tiles = 0;
@@ -114,19 +133,26 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
             bytes += ((double)A.n + B.n) * A.dim * 4 + (double)B.n * 16;
         }
     }
+    // the views of the batch (layouts are staged per view, on first use)
+    std::vector<uint32_t> batch_slots;
+    batch_slots.reserve(2 * (size_t)P);
+    for (const PairJob& j : jobs) { batch_slots.push_back(j.sI); batch_slots.push_back(j.sJ); }
+    std::sort(batch_slots.begin(), batch_slots.end());
+    batch_slots.erase(std::unique(batch_slots.begin(), batch_slots.end()), batch_slots.end());
+    // same test as the kernels' exact_pair (kernels_match_common.hpp): key + ||q||^2 IS the reference distance, bit for bit
+    auto exact_pair = [&](const HostImage& A, const HostImage& B, bool bf16) {
+        const float dpad = (float)(first.G * 8), mI = A.max_abs, mJ = B.max_abs;
+        return !A.not_integer && !B.not_integer &&
+               ((A.has_negative || B.has_negative)
+                    ? dpad * (mI + mJ) * (mI + mJ) < 16777216.0f
+                    : (2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f)) &&
+               (!bf16 || (mI <= 256.0f && mJ <= 256.0f));
+    };
     // integer fast path (r3dm_set_integer_mfma): every view of the batch must hold bf16-exact integers
     bool int_mfma = c->integer_mfma && dtype != R3DM_BIN && first.G != 18;
     if (int_mfma)
-        for (const PairJob& j : jobs) {
-            const HostImage& A = *c->imgs[j.sI];
-            const HostImage& B = *c->imgs[j.sJ];
-            const float dpad = (float)(first.G * 8), mI = A.max_abs, mJ = B.max_abs;      // same test as the kernel's exact_pair
-            const bool exact = !A.not_integer && !B.not_integer && mI <= 256.0f && mJ <= 256.0f &&
-                               ((A.has_negative || B.has_negative)
-                                    ? dpad * (mI + mJ) * (mI + mJ) < 16777216.0f
-                                    : (2.0f * dpad * mI * mJ < 16777216.0f && dpad * mI * mI < 16777216.0f && dpad * mJ * mJ < 16777216.0f));
-            if (!exact) { int_mfma = false; break; }
-        }
+        for (const PairJob& j : jobs)
+            if (!exact_pair(*c->imgs[j.sI], *c->imgs[j.sJ], true)) { int_mfma = false; break; }
     // split-f16 nominator (r3dm_set_split_mfma): batches with at least one real-valued view (integer-valued batches are exact
     // on the f32 tiles already and have their own fast path); every view finite, scales within reach of one another
     bool split = c->split_mfma && !int_mfma && dtype != R3DM_BIN && has_tensor_kernel(first.G);
@@ -142,12 +168,27 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         split = split && any_real;
     }
     // ... and its cheaper form for views whose rows are small integers x a row scale (LIOP: one f16 MFMA per 16 dimensions on the
-    // count tiles instead of three on the split planes): every view of the batch must have passed the staging check
-    bool counts = split;
+    // count tiles instead of three on the split planes): every view of the batch must pass the staging check
+    bool counts = split && !r3dm_dev_knob("R3DM_NO_COUNT_TILES", 0);          // (developer build: A/B against the split planes)
     if (counts)
-        for (const PairJob& j : jobs)
-            if (!c->imgs[j.sI]->counts_ok || !c->imgs[j.sJ]->counts_ok) { counts = false; break; }
-    if (counts && r3dm_dev_knob("R3DM_NO_COUNT_TILES", 0)) counts = false;          // developer build: A/B against the split planes
+        for (uint32_t s : batch_slots) { const HostImage& h = *c->imgs[s]; if (!(h.dtype == R3DM_F32 && h.n && h.dim <= 256)) { counts = false; break; } }
+    // ---- the layouts this batch reads that its views do not hold yet (staged once per view; kernels_match.hip, kernels_match_16bit.hip)
+    {
+        int rcl = R3DM_OK;
+        if (dtype == R3DM_BIN) { if (c->hamming_mfma) rcl = ensure_layouts(c, batch_slots, kLayBin8); }
+        else if (int_mfma) rcl = ensure_layouts(c, batch_slots, kLayBf16);
+        else if (split) {
+            if (counts) { bool all_ok = false; rcl = ensure_layouts(c, batch_slots, kLayRows | kLayCounts, &all_ok); counts = all_ok; }
+            if (rcl == R3DM_OK && !counts) rcl = ensure_layouts(c, batch_slots, kLayRows | kLaySplit);
+        } else if (has_tensor_kernel(first.G)) {
+            // the f32 tiles: a pair of integer-valued views never re-reads a row (exact_pair); any other pair re-scores its nominees from
+            // the row-major rows
+            bool all_exact = true;
+            for (const PairJob& j : jobs) if (!exact_pair(*c->imgs[j.sI], *c->imgs[j.sJ], false)) { all_exact = false; break; }
+            if (!all_exact) rcl = ensure_layouts(c, batch_slots, kLayRows);
+        } else rcl = ensure_layouts(c, batch_slots, kLayRows);             // no tensor kernel: the exact scan of every query reads the rows
+        if (rcl != R3DM_OK) return rcl;
+    }
     const uint32_t q_stride = std::max<uint32_t>(32, (max_nJ + 31) / 32 * 32);
     const uint32_t sort_cap = std::min<uint32_t>(16384, std::max<uint32_t>(8, next_pow2(q_stride)));   // LDS budget; larger views may spill
 
@@ -214,6 +255,7 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
         if (counts_ran) {
             // (launched above)
         } else if (split) {
+            if (counts) { const int rcl = ensure_layouts(c, batch_slots, kLayRows | kLaySplit); if (rcl != R3DM_OK) return rcl; }      // (no count kernel for this launch: the split planes after all)
             R3DM_HIP(c, launch_l2_knn2_split(c->stream, mp, first.G, max_tiles));
             c->stats.n_split_mfma += 1;
         } else {
@@ -249,6 +291,7 @@ int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R
             else rescan = true;                            // scalar-tail dims: generic exact kernel
             if (rescan) {
                 if (total_slots > 0xFFFFFFFFull) { c->err = "batch too large for the exact rescan"; return R3DM_ERR_UNSUPPORTED; }
+                { const int rcl = ensure_layouts(c, batch_slots, kLayRows); if (rcl != R3DM_OK) return rcl; }      // the per-query scan reads row-major rows
                 R3DM_HIP(c, launch_l2_exact_items(c->stream, mp, (uint32_t)total_slots, 2));
             }
         }
@@ -395,9 +438,13 @@ static int r3dm_index_create_impl(r3dm_ctx* c, const void* dataset, uint32_t n_d
     const uint32_t s0 = (uint32_t)c->imgs.size();
     c->imgs.emplace_back(new HostImage());
     int rc = stage_into_slot(c, s0, 0, 0, 0, dataset, n_dataset, dim, dtype, nullptr);
-    if (rc == R3DM_OK && dtype != R3DM_BIN) {
-        hipError_t e = hipMemcpyAsync(ix->stat_bits, &(c->d_imgs.as<ImgDev>() + s0)->max_norm_bits, 12, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    // Build stages what searches will read: the row-major rows beside the tiles (an index is one dataset: memory is not the concern,
+    // a search from any context must not have to add to it) and the layouts of the paths that are switched on; a path switched on
+    // later adds its layout on first use, under the index's lock
+    if (rc == R3DM_OK) rc = ensure_layouts(c, {s0}, dtype == R3DM_BIN ? (c->hamming_mfma ? kLayBin8 : 0u)
+                                                                     : (kLayRows | (c->integer_mfma ? kLayBf16 : 0u) | (c->split_mfma ? (kLayCounts | kLaySplit) : 0u)));
+    if (rc == R3DM_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { c->err = std::string("r3dm_index_create: ") + hipGetErrorString(e); rc = R3DM_ERR_HIP; }
     }
     if (rc == R3DM_OK) {
@@ -433,9 +480,13 @@ static int r3dm_index_knn2_impl(r3dm_ctx* c, const r3dm_index* ix, const void* q
     const uint32_t s0 = (uint32_t)c->imgs.size();
     c->imgs.emplace_back(new HostImage());
     c->imgs.emplace_back(new HostImage());
-    *c->imgs[s0] = ix->img;                       // aliases of the index's buffers: mounted for this call only
+    {
+        std::lock_guard<std::mutex> lk(const_cast<r3dm_index*>(ix)->mu);
+        *c->imgs[s0] = ix->img;                   // aliases of the index's buffers: mounted for this call only
+    }
     c->imgs[s0]->borrowed = true;
-    int rc = upload_imgdev(c, s0, ix->stat_bits, ix->img.split_k, ix->img.counts_ok);
+    c->imgs[s0]->owner = const_cast<r3dm_index*>(ix);
+    int rc = publish_entry(c, s0);
     if (rc == R3DM_OK) rc = stage_into_slot(c, s0 + 1, 0, 0, 0, query, n_query, ix->img.dim, ix->img.dtype, nullptr);
     if (rc == R3DM_OK) {
         std::vector<PairJob> jobs{{0, 1, s0, s0 + 1}};
@@ -515,6 +566,7 @@ static int check_kgraph_params(r3dm_ctx* c, const r3dm_kgraph_params* kp)
 extern "C" int r3dm_exhaustive_is_faster(const r3dm_ctx* c)
 {
     if (!c) return 0;
+    if (sync_view_stats(const_cast<r3dm_ctx*>(c)) != R3DM_OK) return 0;        // (integer-valued? is a statistic of the staging kernel)
     bool any = false;
     for (const auto& up : c->imgs) {
         if (!up || !up->live) continue;
@@ -759,8 +811,16 @@ static int r3dm_match_pairs_kgraph_impl(r3dm_ctx* c, const uint32_t* pairs_ij, u
 
     r3dm_graph ga, gs;
     ga.offsets.push_back(0); gs.offsets.push_back(0);
+    // (r3dm_set_device_graphs) the two part graphs are merged on the host: a device mirror survives that only when one part is the whole
+    // result -- then it is built and handed over; with both kinds of pairs present no mirror is built at all (it would be dropped)
+    PartMirrorGuard mirror_guard(c, !ann_jobs.empty() && !small_jobs.empty());
     if (!ann_jobs.empty()) {
         std::vector<uint32_t> slots;
+        // the graph build and the graph search gather row-major rows (f32, or the compact copies made from them)
+        for (const PairJob& j : ann_jobs) { slots.push_back(j.sI); slots.push_back(j.sJ); }
+        rc = ensure_layouts(c, slots, kLayRows);
+        if (rc != R3DM_OK) return rc;
+        slots.clear();
         for (const PairJob& j : ann_jobs) slots.push_back(j.sI);
         rc = ensure_ann_indices(c, slots, kp->index_K);
         if (rc != R3DM_OK) return rc;
@@ -797,8 +857,7 @@ static int r3dm_match_pairs_kgraph_impl(r3dm_ctx* c, const uint32_t* pairs_ij, u
         if (rc != R3DM_OK) return rc;
         start = end;
     }
-    const r3dm_graph* parts[2] = {&ga, &gs};
-    rc = r3dm_graph_merge(parts, 2, out);
+    rc = merge_parts_keep_mirror(ga, gs, out);
     c->stats.ms_wall_match = now_ms() - t_call;
     return rc;
 }
@@ -829,7 +888,8 @@ static int r3dm_kgraph_knn2_impl(r3dm_ctx* c, const float* dataset, uint32_t n_d
         std::vector<PairJob> jobs{{pair_i, pair_j, s0, s0 + 1}};
         if (n_dataset < kAnnMinRows || kp->search_P >= n_dataset) rc = run_match_batch(c, jobs, 1.0f, nullptr, out_idx, out_dist);
         else {
-            rc = ensure_ann_indices(c, {s0}, kp->index_K);
+            rc = ensure_layouts(c, {s0, s0 + 1}, kLayRows);
+            if (rc == R3DM_OK) rc = ensure_ann_indices(c, {s0}, kp->index_K);
             if (rc == R3DM_OK) rc = ensure_compact_rows(c, {s0 + 1});
             if (rc == R3DM_OK) rc = run_ann_batch(c, jobs, 1.0f, *kp, nullptr, out_idx, out_dist);
         }
@@ -867,7 +927,8 @@ extern "C" int r3dm_kgraph_index(r3dm_ctx* c, uint32_t view_id, uint32_t index_K
     HostImage& h = *c->imgs[it->second];
     if (h.dtype == R3DM_BIN || (h.dim & 3u) || h.n < 2) { c->err = "kgraph index needs >= 2 F32/U8 rows with dim % 4 == 0"; return R3DM_ERR_UNSUPPORTED; }
     R3DM_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_ann_indices(c, {it->second}, index_K);
+    int rc = ensure_layouts(c, {it->second}, kLayRows);
+    if (rc == R3DM_OK) rc = ensure_ann_indices(c, {it->second}, index_K);
     if (rc != R3DM_OK) return rc;
     R3DM_HIP(c, hipMemcpy(adj_out, h.ann_adj.p, (size_t)h.n * kAnnDeg * 4, hipMemcpyDeviceToHost));
     R3DM_HIP(c, hipMemcpy(deg_out, h.ann_deg.p, (size_t)h.n * 4, hipMemcpyDeviceToHost));

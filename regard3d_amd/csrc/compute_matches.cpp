@@ -10,6 +10,7 @@
 #include <fstream>
 #include <sstream>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <thread>
 #include <sys/resource.h>
@@ -64,7 +65,8 @@ bool load_feat(const std::string& path, std::vector<float>& xy)
 
 // first thing in a background writer thread: its work has a whole phase to hide behind, so under contention for the host's cores it
 // stands back (Linux: a per-thread nice value, inherited by the helpers it starts)
-static inline void stand_back() { (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10); }
+// (only when the host asked for it: R3DComputeMatches::setBackgroundThreadsNice)
+static inline void stand_back(int nice_value) { if (nice_value > 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_value); }
 
 // Save(PairWiseMatches, file) of the .txt and the .bin of a graph on two host threads while the next filter runs on the GPU; the
 // destructor waits for every write and frees the graphs it was given
@@ -72,13 +74,15 @@ struct MatchFileWriter {
     struct Job { std::thread th; int rc = R3DM_OK; std::string path; };
     std::vector<std::unique_ptr<Job>> jobs;
     std::vector<r3dm_graph*> owned;
+    int nice_value = 0;
     void save(const r3dm_graph* g, const std::string& txt_path, const std::string& bin_path)
     {
+        const int nv = nice_value;
         for (const std::string& p : {txt_path, bin_path}) {
             std::unique_ptr<Job> j(new Job());
             j->path = p;
             Job* raw = j.get();
-            try { raw->th = std::thread([g, raw]() noexcept { stand_back(); raw->rc = r3dm_save_matches(g, raw->path.c_str()); }); }
+            try { raw->th = std::thread([g, raw, nv]() noexcept { stand_back(nv); raw->rc = r3dm_save_matches(g, raw->path.c_str()); }); }
             catch (...) { raw->rc = r3dm_save_matches(g, raw->path.c_str()); }             // no thread to be had: write here
             jobs.push_back(std::move(j));
         }
@@ -238,6 +242,7 @@ bool R3DComputeMatches::runFeaturesStage(const R3DFParams& params, const std::st
     // the .feat / .desc of a batch are written behind the sink calls, beside the match phase (computeMatches waits for them before it
     // returns): only when the views are registered straight from the device, else Regions_Provider::load reads those files next
     (void)r3dm_multi_set_deferred_feature_files(feat_multi_, direct_registration_ ? 1 : 0);
+    (void)r3dm_multi_set_background_nice(feat_multi_, background_nice_);
     r3dm_features_totals before{};
     for (int k = 0; k < n_ctx; ++k) {
         r3dm_features_totals t{};
@@ -478,18 +483,27 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     // the match files are written behind the filters (two host threads per graph); failures are reported at the end -- the reference
     // returns EXIT_FAILURE (== true) from a bool function there (:2069), a real failure is reported instead
     MatchFileWriter writer;
+    writer.nice_value = background_nice_;
     writer.own(putative);
     writer.save(putative, put_path, with_ext(put_path, ".bin"));
     // statistics_.putativeMatches_ (the PairWiseMatches map the reference keeps, :2040-2069) is filled beside the filters as well: a
     // million matches into per-pair vectors is host work nothing on the device waits for
     struct MapJob {
         std::thread th;
-        void start(const r3dm_graph* g, PairWiseMatches* out) { th = std::thread([g, out]() { stand_back(); try { graph_to_map(g, *out); } catch (...) { out->clear(); } }); }
-        void join() { if (th.joinable()) th.join(); }
-        ~MapJob() { join(); }
+        const r3dm_graph* g = nullptr; PairWiseMatches* out = nullptr;
+        std::atomic<bool> failed{false};
+        void start(const r3dm_graph* g_, PairWiseMatches* out_, int nv)
+        {
+            g = g_; out = out_;
+            th = std::thread([this, nv]() { stand_back(nv); try { graph_to_map(g, *out); } catch (...) { failed.store(true); } });
+        }
+        // a map the background thread could not build (out of memory) is built again HERE, where a second failure reaches the caller
+        // as the exception it is -- never an empty map behind a `true` from computeMatches
+        void join() { if (th.joinable()) th.join(); if (failed.exchange(false)) { out->clear(); graph_to_map(g, *out); } }
+        ~MapJob() { if (th.joinable()) th.join(); }
     };
     MapJob put_map;
-    try { put_map.start(putative, &statistics_.putativeMatches_); } catch (...) { graph_to_map(putative, statistics_.putativeMatches_); }
+    try { put_map.start(putative, &statistics_.putativeMatches_, background_nice_); } catch (...) { graph_to_map(putative, statistics_.putativeMatches_); }
     if (svgOutput) { put_map.join(); write_adjacency_svg(dir + "/PutativeAdjacencyMatrix.svg", views_.size(), statistics_.putativeMatches_); }   // :2074
     phases_.files += wall_ms() - t_phase;
 
@@ -516,7 +530,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         for (int k = 0; k < 3; ++k) {
             const Out& o = outs[k];
             if (!o.g) continue;
-            try { maps[k].start(o.g, o.map); } catch (...) { graph_to_map(o.g, *o.map); }      // the three maps side by side
+            try { maps[k].start(o.g, o.map, background_nice_); } catch (...) { graph_to_map(o.g, *o.map); }      // the three maps side by side
             const std::string path = o.named->empty() ? dir + o.def : *o.named;
             writer.own(o.g);
             writer.save(o.g, path, with_ext(path, ".bin"));
@@ -639,6 +653,7 @@ extern "C" int r3dm_stage_run(r3dm_stage* sp, const char* matches_dir, const r3d
         stage.setSeed(seed);
         if (features_batches_in_flight > 0 && features_images_per_batch > 0) stage.setFeaturesConcurrency(features_batches_in_flight, features_images_per_batch);
         stage.setApproximateArmsPolicy((flags & R3DM_STAGE_ARMS_AS_REQUESTED) ? r3d_amd::R3DComputeMatches::kArmsAsRequested : r3d_amd::R3DComputeMatches::kArmsFastest);
+        stage.setBackgroundThreadsNice((flags & R3DM_STAGE_BACKGROUND_NICE) ? 10 : 0);
         stage.setExactFastPaths((flags & R3DM_STAGE_F32_TILES) == 0);      // (R3DM_STAGE_SPLIT_MFMA / _INTEGER_MFMA: implied since round 3)
         r3d_amd::R3DFParams params;
         params.keypointDetectorList_ = {"Fast-AKAZE"};

@@ -21,75 +21,227 @@
 namespace r3dm {
 
 // ------------------------------------------------------------------------------------------------
-// staging: raw row-major descriptors -> rows (f32) + MFMA fragment-order tiles + norms
+// staging (registration of a view: what Regions_Provider::load is to the reference, /root/reference/src/R3DComputeMatches.cpp:2040,2094)
+// ONE kernel per view on the default path: the raw row-major descriptors (f32, or u8 converted on the way) are read ONCE -- from the
+// upload ring's device slot, from the caller's device buffer, or straight from page-locked host memory over the link -- and leave as
+// the MFMA fragment-order tiles + norms + the view's statistics; the row-major f32 copy (`rows`) is written only when asked for
+// (a view of integer-valued bins never needs it: its MFMA keys ARE the reference distances, and the exact scan reads the tiles).
+// Every other layout (bf16 tiles, split-f16 planes, count tiles, byte tiles) is staged on first use by the path that reads it
+// (api_core.cpp: ensure_layouts).
 // ------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256)
-void stage_rows_kernel(const void* __restrict__ raw, int raw_is_u8, uint32_t n, uint32_t dim,
-                       float* __restrict__ rows)
+// role blocks behind the n_tiles tile blocks: kStageAuxBlocks blocks copy the positions, enter them into the position-class hash
+// table (IndMatchDecorator's coordinate de-duplication needs to know which features share a position) and zero the slack
+constexpr uint32_t kStageAuxBlocks = 8;
+
+__device__ __forceinline__ bool canon_key_of(float fx, float fy, unsigned long long& key)
 {
-    const size_t total = (size_t)n * dim;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256)
-        rows[e] = raw_is_u8 ? (float)((const uint8_t*)raw)[e] : ((const float*)raw)[e];
+    if (fx != fx || fy != fy) return false;                          // NaN: equals nothing, itself included -> a class of its own
+    const float zx = fx == 0.0f ? 0.0f : fx, zy = fy == 0.0f ? 0.0f : fy;      // -0 folded into +0: equal floats <-> equal bit patterns
+    key = ((unsigned long long)__float_as_uint(zx) << 32) | __float_as_uint(zy);
+    return true;
+}
+__device__ __forceinline__ uint32_t canon_hash(unsigned long long key, uint32_t bits)
+{
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - bits));
 }
 
-// one workgroup per 32-row tile
-__global__ __launch_bounds__(256)
-void stage_tiles_kernel(const float* __restrict__ rows, uint32_t n, uint32_t dim, uint32_t G,
-                        float* __restrict__ tiled, uint16_t* __restrict__ tiled16, float* __restrict__ norms,
-                        uint32_t* __restrict__ img_stats)
+__device__ __forceinline__ void stage_aux_role(const StageViewArgs& A, uint32_t rb)
 {
+    const uint32_t n = A.n, G = A.G;
+    const uint32_t nthr = kStageAuxBlocks * 256u, tid = rb * 256u + threadIdx.x;
+    if (A.xy_src) {
+        const unsigned long long kEmpty = ~0ull;
+        const uint32_t mask = (1u << A.canon_bits) - 1u;
+        for (uint32_t k = tid; k < n; k += nthr) {
+            const float fx = A.xy_src[2 * (size_t)k], fy = A.xy_src[2 * (size_t)k + 1];
+            if (A.xy_dst != A.xy_src) { A.xy_dst[2 * (size_t)k] = fx; A.xy_dst[2 * (size_t)k + 1] = fy; }
+            unsigned long long key;
+            if (A.canon_keys && canon_key_of(fx, fy, key)) {
+                uint32_t slot = canon_hash(key, A.canon_bits) & mask;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(A.canon_keys + slot, kEmpty, key);
+                    if (old == kEmpty || old == key) { atomicMin(A.canon_vals + slot, k); break; }
+                    slot = (slot + 1u) & mask;
+                }
+            }
+        }
+    }
+    // zero slack behind the tiles and the norms (prefetches run past the end; a recycled buffer holds an older view there)
+    if (A.tiled) {
+        float* ts = A.tiled + (size_t)A.n_tiles * G * 256u;
+        for (uint32_t e = tid; e < kSlackBytes / 4u; e += nthr) ts[e] = 0.0f;
+        float* ns = A.norms + (size_t)A.n_tiles * 32u;
+        for (uint32_t e = tid; e < kSlackBytes / 4u; e += nthr) ns[e] = 0.0f;
+    }
+}
+
+// one workgroup per 32-row tile (+ the role blocks)
+__global__ __launch_bounds__(256)
+void stage_view_kernel(const StageViewArgs A)
+{
+    __shared__ float sm[32 * 260];                     // the tile's rows, row stride dim + 4 floats (dim <= 256 staged through LDS)
+    const uint32_t n = A.n, dim = A.dim, G = A.G;
+    if (blockIdx.x >= A.n_tiles) { stage_aux_role(A, blockIdx.x - A.n_tiles); return; }
     const uint32_t t = blockIdx.x;
-    const uint32_t per_tile = G * 256;                 // floats per tile = G * 2 * 32 * 4
-    float* dst = tiled + (size_t)t * per_tile;
-    for (uint32_t e = threadIdx.x; e < per_tile; e += 256) {
-        const uint32_t c = e & 3, r = (e >> 2) & 31, h = (e >> 7) & 1, g = e >> 8;
-        const uint32_t row = t * 32 + r, k = 8 * g + 4 * h + c;
-        dst[e] = (row < n && k < dim) ? rows[(size_t)row * dim + k] : 0.0f;
+    const uint32_t rows_here = (n - t * 32u < 32u) ? n - t * 32u : 32u;
+    const uint32_t per_tile = G * 256u;                // floats per tile = G * 2 * 32 * 4
+    float* dst = A.tiled + (size_t)t * per_tile;
+    const bool lds = dim <= 256u && (dim & 3u) == 0u && (((uintptr_t)A.raw) & (A.raw_is_u8 ? 3u : 15u)) == 0u;
+    const uint32_t stride = dim + 4u;
+    if (lds) {
+        // coalesced read of the tile's rows_here x dim values (contiguous in the raw image), converted, into LDS
+        const uint32_t total = rows_here * dim;
+        if (A.raw_is_u8) {
+            const uint8_t* src = (const uint8_t*)A.raw + (size_t)t * 32u * dim;
+            for (uint32_t e = threadIdx.x * 4u; e < total; e += 1024u) {
+                const uint32_t w = *(const uint32_t*)(src + e);              // dim % 4 == 0: 4-byte aligned
+                const uint32_t r = e / dim, k = e - r * dim;
+                float* o = sm + r * stride + k;
+                o[0] = (float)(w & 255u); o[1] = (float)((w >> 8) & 255u); o[2] = (float)((w >> 16) & 255u); o[3] = (float)(w >> 24);
+            }
+        } else {
+            const f32x4* src = (const f32x4*)((const float*)A.raw + (size_t)t * 32u * dim);
+            for (uint32_t e = threadIdx.x; e < total / 4u; e += 256u) {
+                const f32x4 v = src[e];
+                const uint32_t r = (e * 4u) / dim, k = e * 4u - r * dim;
+                *(f32x4*)(sm + r * stride + k) = v;
+            }
+        }
+        __syncthreads();
+        if (A.rows) {
+            f32x4* ro = (f32x4*)(A.rows + (size_t)t * 32u * dim);
+            for (uint32_t e = threadIdx.x; e < total / 4u; e += 256u) {
+                const uint32_t r = (e * 4u) / dim, k = e * 4u - r * dim;
+                ro[e] = *(const f32x4*)(sm + r * stride + k);
+            }
+        }
+        // fragment order: float4 (g, h, r) = row 32 t + r, dims 8 g + 4 h .. + 3
+        for (uint32_t e4 = threadIdx.x; e4 < per_tile / 4u; e4 += 256u) {
+            const uint32_t r = e4 & 31u, h = (e4 >> 5) & 1u, g = e4 >> 6;
+            const uint32_t k = 8u * g + 4u * h;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < rows_here && k < dim) v = *(const f32x4*)(sm + r * stride + k);
+            ((f32x4*)dst)[e4] = v;
+        }
+    } else {
+        // any other descriptor length: element by element from the raw image
+        for (uint32_t e = threadIdx.x; e < per_tile; e += 256u) {
+            const uint32_t c = e & 3u, r = (e >> 2) & 31u, h = (e >> 7) & 1u, g = e >> 8;
+            const uint32_t row = t * 32u + r, k = 8u * g + 4u * h + c;
+            float v = 0.0f;
+            if (row < n && k < dim) v = A.raw_is_u8 ? (float)((const uint8_t*)A.raw)[(size_t)row * dim + k] : ((const float*)A.raw)[(size_t)row * dim + k];
+            dst[e] = v;
+            if (A.rows && row < n && k < dim) A.rows[(size_t)row * dim + k] = v;
+        }
     }
-    // bf16 tiles of the integer fast path: the upper 16 bits of the float ARE the value when it is an integer of
-    // magnitude <= 256 (8 significant bits); for any other view these tiles are never read (kernel-side check)
-    const uint32_t GB = (G + 1) / 2, per_tile16 = GB * 512;
-    uint16_t* dst16 = tiled16 + (size_t)t * per_tile16;
-    for (uint32_t e = threadIdx.x; e < per_tile16; e += 256) {
-        const uint32_t c8 = e & 7, r = (e >> 3) & 31, h = (e >> 8) & 1, kb = e >> 9;
-        const uint32_t row = t * 32 + r, k = 16 * kb + 8 * h + c8;
-        const float v = (row < n && k < dim) ? rows[(size_t)row * dim + k] : 0.0f;
-        dst16[e] = (uint16_t)(__float_as_uint(v) >> 16);
-    }
-    if (threadIdx.x < 32) {
-        const uint32_t row = t * 32 + threadIdx.x;
+    if (threadIdx.x < 32u) {
+        const uint32_t row = t * 32u + threadIdx.x;
         float s = R3DM_INF;
         if (row < n) {
             s = 0.0f;
-            const float* p = rows + (size_t)row * dim;
             float mx = 0.0f; bool nonint = false, neg = false;
             for (uint32_t k = 0; k < dim; ++k) {
-                const float v = p[k];
+                float v;
+                if (lds) v = sm[threadIdx.x * stride + k];
+                else v = A.raw_is_u8 ? (float)((const uint8_t*)A.raw)[(size_t)row * dim + k] : ((const float*)A.raw)[(size_t)row * dim + k];
                 s = fmaf(v, v, s);
                 mx = fmaxf(mx, fabsf(v));
                 nonint |= !(v == rintf(v));                  // also true for NaN
                 neg |= v < 0.0f;
             }
             // img_stats = &ImgDev::max_norm_bits, max_abs_bits, not_integer (non-negative floats order like uints)
-            atomicMax(img_stats + 0, __float_as_uint(s));
-            atomicMax(img_stats + 1, __float_as_uint(mx));
-            if (nonint) atomicOr(img_stats + 2, 1u);       // ImgDev::not_integer: bit 0 = some non-integer, bit 1 = some negative
-            if (neg) atomicOr(img_stats + 2, 2u);
+            atomicMax(A.img_stats + 0, __float_as_uint(s));
+            atomicMax(A.img_stats + 1, __float_as_uint(mx));
+            if (nonint) atomicOr(A.img_stats + 2, 1u);     // ImgDev::not_integer: bit 0 = some non-integer, bit 1 = some negative
+            if (neg) atomicOr(A.img_stats + 2, 2u);
         }
-        norms[(size_t)t * 32 + threadIdx.x] = s;
+        A.norms[(size_t)t * 32u + threadIdx.x] = s;
     }
 }
 
-hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
-                            float* rows, float* tiled, uint16_t* tiled16, float* norms, uint32_t G, uint32_t n_tiles,
-                            uint32_t* img_stats_dev)
+// position classes, second pass (behind stage_view_kernel's inserts): canon[k] = the smallest feature index at k's position;
+// *has_dup is set when some feature is not the first of its class
+__global__ __launch_bounds__(256)
+void canon_lookup_kernel(const float* __restrict__ xy, uint32_t n, const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                         uint32_t bits, uint32_t* __restrict__ canon, uint32_t* __restrict__ has_dup)
 {
-    if (n == 0) return hipSuccess;
-    const size_t total = (size_t)n * dim;
-    uint32_t grid = (uint32_t)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(stage_rows_kernel, dim3(grid), dim3(256), 0, st, raw, raw_is_u8, n, dim, rows);
-    hipLaunchKernelGGL(stage_tiles_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, G, tiled, tiled16, norms, img_stats_dev);
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    uint32_t cls = k;
+    unsigned long long key;
+    if (canon_key_of(xy[2 * (size_t)k], xy[2 * (size_t)k + 1], key)) {
+        const uint32_t mask = (1u << bits) - 1u;
+        uint32_t slot = canon_hash(key, bits) & mask;
+        while (keys[slot] != key) slot = (slot + 1u) & mask;          // the key was entered by the pass before
+        cls = vals[slot];
+    }
+    canon[k] = cls;
+    if (cls != k) atomicOr(has_dup, 1u);
+}
+
+__global__ __launch_bounds__(256)
+void stage_positions_kernel(const StageViewArgs A) { stage_aux_role(A, blockIdx.x); }
+
+hipError_t launch_stage_positions(hipStream_t st, const StageViewArgs& A)
+{
+    if (!A.xy_src || A.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_positions_kernel, dim3(kStageAuxBlocks), dim3(256), 0, st, A);
+    if (A.canon_keys)
+        hipLaunchKernelGGL(canon_lookup_kernel, dim3((A.n + 255u) / 256u), dim3(256), 0, st, A.xy_dst, A.n, A.canon_keys, A.canon_vals, A.canon_bits,
+                           A.canon_dst, A.has_dup);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_view(hipStream_t st, const StageViewArgs& A)
+{
+    hipLaunchKernelGGL(stage_view_kernel, dim3(A.n_tiles + kStageAuxBlocks), dim3(256), 0, st, A);
+    if (A.xy_src && A.canon_keys && A.n)
+        hipLaunchKernelGGL(canon_lookup_kernel, dim3((A.n + 255u) / 256u), dim3(256), 0, st, A.xy_dst, A.n, A.canon_keys, A.canon_vals, A.canon_bits,
+                           A.canon_dst, A.has_dup);
+    return hipGetLastError();
+}
+
+// ---- layouts staged on first use, from the fragment-order tiles (which hold the view's f32 values verbatim)
+// row-major f32 rows: float4 chunk k4 of row q is tiled float4 ((q >> 5) 2G + k4) 32 + (q & 31)
+__global__ __launch_bounds__(256)
+void untile_rows_kernel(const float* __restrict__ tiled, uint32_t n, uint32_t dim, uint32_t G, float* __restrict__ rows)
+{
+    const uint32_t t = blockIdx.x;
+    const float* src = tiled + (size_t)t * G * 256u;
+    for (uint32_t e = threadIdx.x; e < G * 256u; e += 256u) {
+        const uint32_t c = e & 3u, r = (e >> 2) & 31u, h = (e >> 7) & 1u, g = e >> 8;
+        const uint32_t row = t * 32u + r, k = 8u * g + 4u * h + c;
+        if (row < n && k < dim) rows[(size_t)row * dim + k] = src[e];
+    }
+}
+hipError_t launch_untile_rows(hipStream_t st, const float* tiled, uint32_t n, uint32_t dim, uint32_t G, uint32_t n_tiles, float* rows)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(untile_rows_kernel, dim3(n_tiles), dim3(256), 0, st, tiled, n, dim, G, rows);
+    return hipGetLastError();
+}
+
+// bf16 tiles of the integer fast path: the upper 16 bits of the float ARE the value when it is an integer of magnitude <= 256 (8
+// significant bits); for any other view these tiles are never read (kernel-side check).  [tile][16-dim block][lane half][32 rows][8]
+__global__ __launch_bounds__(256)
+void stage_bf16_kernel(const float* __restrict__ tiled, uint32_t G, uint16_t* __restrict__ tiled16)
+{
+    const uint32_t t = blockIdx.x, GB = (G + 1u) / 2u;
+    const float* src = tiled + (size_t)t * G * 256u;
+    uint16_t* dst16 = tiled16 + (size_t)t * GB * 512u;
+    for (uint32_t e = threadIdx.x; e < GB * 512u; e += 256u) {
+        const uint32_t c8 = e & 7u, r = (e >> 3) & 31u, h = (e >> 8) & 1u, kb = e >> 9;
+        const uint32_t k = 16u * kb + 8u * h + c8;                   // dimension; in the f32 tiles: g = k / 8, half (k / 4) & 1, lane k & 3
+        const uint32_t g = k >> 3;
+        const float v = g < G ? src[g * 256u + ((k >> 2) & 1u) * 128u + r * 4u + (k & 3u)] : 0.0f;
+        dst16[e] = (uint16_t)(__float_as_uint(v) >> 16);
+    }
+}
+hipError_t launch_stage_bf16(hipStream_t st, const float* tiled, uint32_t G, uint32_t n_tiles, uint16_t* tiled16)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_bf16_kernel, dim3(n_tiles), dim3(256), 0, st, tiled, G, tiled16);
     return hipGetLastError();
 }
 

@@ -539,82 +539,65 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
 // The DATASET side of the nominator reads the rows in the order of their scales (512 classes per binary order, i.e. scales within
 // 0.2 % of one another inside a class): the quad test of the kernel bounds four keys with the largest scale of their four rows, and
 // with rows in keypoint order (scales 30 % apart) that bound let a large share of the quads through to the per-key path.
-// One workgroup: counting sort of the rows by scale class -> cperm[position] = row (kNone behind the last row).
-// The rows of a class keep their keypoint order (a stable sort): the atomic cursors place them in whatever order the waves arrive, so a
-// second kernel ranks every row inside its class segment by row index, one wavefront per row over the whole chip -- which rows share a
-// tile, and with it which queries the epilogue sends to the exact scan, is then the same from run to run (the results are exact
-// either way).  scratch: n_pad words (rows of a class, unordered) + 2 n_pad words (every row's class segment).
-// (Ranking inside this one-workgroup kernel was tried first: a view's rows fall into a few hundred classes, 14 M serial reads per view,
-// +115 ms on the stage's 24 views.)
-// (210-230 us per view of 28 k LIOP rows: their scales fall into a few dozen classes, so the LDS atomics of a wavefront mostly hit
-//  one address and serialise; issuing the loads of the three passes eight at a time changed nothing, round 5.)
-__global__ __launch_bounds__(1024)
-void stage_counts_order_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm, uint32_t* __restrict__ scratch)
+// cperm[position] = row, rows ordered by (scale class, row index), kNone behind the last row: a SORT of 64-bit keys class << 32 | row
+// -- a bitonic network, chunks of <= 16,384 keys in LDS by one workgroup of 1,024 threads each, chunk-crossing strides through
+// global memory -- so the order is the same from run to run by construction (which rows share a tile decides which queries the
+// epilogue sends to the exact scan; the results are exact either way), and its cost does not depend on how the scales are
+// distributed: 8,192 rows are ONE launch of one workgroup.  (Rounds 4-5: a one-workgroup counting sort on LDS atomics -- 210-265 us
+// per 28 k-row view whose scales fall into a few dozen classes, the atomics of a wavefront serialising on them -- plus a ranking
+// kernel of O(rows x class size): 413 us per 8 k-row view of one class.)
+// class of a scale: its sign-free exponent and 9 mantissa bits (0.2 % steps); a scale of 0 or a denormal (an all-zero row) is class 0
+constexpr uint32_t kOrdNT = 1024;
+__device__ __forceinline__ unsigned long long order_key(float s, uint32_t row)
 {
-    __shared__ uint32_t hist[8192];
-    __shared__ uint32_t start[8192];
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t s_emin;
-    const uint32_t tid = threadIdx.x;
-    uint32_t* __restrict__ tmp = scratch;
-    uint2* __restrict__ seg = reinterpret_cast<uint2*>(scratch + n_pad);
-    for (uint32_t b = tid; b < 8192u; b += 1024u) hist[b] = 0u;
-    if (tid == 0) s_emin = 255u;
-    __syncthreads();
-    // class of a scale: 4 bits of binary order above the view's smallest + 9 mantissa bits (0.2 % steps; round 5 -- 8 exponent + 5
-    // mantissa bits before: 2.2 % steps put the few dozen scales of a LIOP view into a few dozen classes, loose quad bounds in the
-    // kernel and LDS atomics that all hit the same counters here).  A scale of 0 (an all-zero row) is class 0; orders beyond fifteen
-    // above the smallest share the top one (the order is a heuristic: results are exact whatever it is).
-    {
-        uint32_t e = 255u;
-        for (uint32_t r = tid; r < n; r += 1024u) { const uint32_t x = (__float_as_uint(cscale[r]) >> 23) & 255u; if (x != 0u && x < e) e = x; }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)e, o); e = y < e ? y : e; }
-        if ((tid & 63u) == 0u) atomicMin(&s_emin, e);
-    }
-    __syncthreads();
-    const uint32_t emin = s_emin;
-    auto cls_of = [emin](float s) -> uint32_t {
-        const uint32_t bits = __float_as_uint(s), x = (bits >> 23) & 255u;
-        if (x == 0u) return 0u;
-        const uint32_t d = x - emin + 1u;
-        return ((d < 15u ? d : 15u) << 9) | ((bits >> 14) & 511u);
-    };
-    for (uint32_t r = tid; r < n; r += 1024u) atomicAdd(&hist[cls_of(cscale[r])], 1u);
-    __syncthreads();
-    uint32_t loc[8], run = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { loc[k] = run; run += hist[tid * 8u + (uint32_t)k]; }
-    part[tid] = run;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t v = tid >= off ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    const uint32_t base = part[tid] - run;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { hist[tid * 8u + (uint32_t)k] = base + loc[k]; start[tid * 8u + (uint32_t)k] = base + loc[k]; }          // cursors
-    __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024u) tmp[atomicAdd(&hist[cls_of(cscale[r])], 1u)] = r;
-    __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024u) { const uint32_t cls = cls_of(cscale[r]); seg[r] = make_uint2(start[cls], hist[cls]); }
-    for (uint32_t r = n + tid; r < n_pad; r += 1024u) cperm[r] = kNone;
+    const uint32_t bits = __float_as_uint(s);
+    const uint32_t cls = ((bits >> 23) & 255u) == 0u ? 0u : (bits >> 14) & 0x1FFFFu;
+    return ((unsigned long long)cls << 32) | row;
 }
-__global__ __launch_bounds__(256)
-void stage_counts_rank_kernel(uint32_t n, uint32_t n_pad, const uint32_t* __restrict__ scratch, uint32_t* __restrict__ cperm)
+// compare-exchange passes of the bitonic network on a chunk of C keys in LDS: strides first .. 1 of merge step `size` (global index = base + local)
+__device__ __forceinline__ void order_lds_passes(unsigned long long* lk, uint32_t C, uint32_t base, uint32_t size, uint32_t first_stride)
 {
-    // a wavefront per row: its lanes stride the class segment (one class can hold the whole view -- rows of one common scale)
-    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (r >= n) return;
-    const uint32_t* __restrict__ tmp = scratch;
-    const uint2 sg = reinterpret_cast<const uint2*>(scratch + n_pad)[r];
-    uint32_t rank = 0;
-    for (uint32_t q = sg.x + lane; q < sg.y; q += 64u) rank += tmp[q] < r ? 1u : 0u;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) rank += (uint32_t)__shfl_xor((int)rank, o);
-    if (lane == 0) cperm[sg.x + rank] = r;
+    for (uint32_t stride = first_stride; stride >= 1u; stride >>= 1) {
+        for (uint32_t e = threadIdx.x; e < C / 2u; e += kOrdNT) {
+            const uint32_t lo = 2u * e - (e & (stride - 1u)), hi = lo + stride;
+            const bool up = (((base + lo) & size) == 0u);
+            const unsigned long long a = lk[lo], b = lk[hi];
+            if ((a > b) == up) { lk[lo] = b; lk[hi] = a; }
+        }
+        __syncthreads();
+    }
+}
+// MODE 0: make the keys of chunk blockIdx.x and sort it (merge steps 2 .. C); MODE 1: the in-chunk strides (C / 2 .. 1) of merge step `size`.
+// `last`: the chunk is in its final order -> cperm; else -> keys (global scratch)
+template <int MODE>
+__global__ __launch_bounds__(kOrdNT)
+void stage_counts_sort_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t n_pad, uint32_t C, uint32_t size, int last,
+                              unsigned long long* __restrict__ keys, uint32_t* __restrict__ cperm)
+{
+    extern __shared__ unsigned long long ord_lk[];
+    const uint32_t base = blockIdx.x * C;
+    if (MODE == 0) {
+        for (uint32_t e = threadIdx.x; e < C; e += kOrdNT) { const uint32_t r = base + e; ord_lk[e] = r < n ? order_key(cscale[r], r) : ~0ull; }
+        __syncthreads();
+        for (uint32_t sz = 2u; sz <= C; sz <<= 1) order_lds_passes(ord_lk, C, base, sz, sz >> 1);
+    } else {
+        for (uint32_t e = threadIdx.x; e < C; e += kOrdNT) ord_lk[e] = keys[base + e];
+        __syncthreads();
+        order_lds_passes(ord_lk, C, base, size, C >> 1);
+    }
+    if (last) { for (uint32_t e = threadIdx.x; e < C; e += kOrdNT) if (base + e < n_pad) cperm[base + e] = (uint32_t)ord_lk[e]; }     // (padding keys: low word = kNone)
+    else for (uint32_t e = threadIdx.x; e < C; e += kOrdNT) keys[base + e] = ord_lk[e];
+}
+// one chunk-crossing stride of merge step `size`
+__global__ __launch_bounds__(256)
+void stage_counts_sort_global_kernel(unsigned long long* __restrict__ keys, uint32_t half, uint32_t size, uint32_t stride)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= half) return;
+    const uint32_t lo = 2u * e - (e & (stride - 1u)), hi = lo + stride;
+    const bool up = ((lo & size) == 0u);
+    const unsigned long long a = keys[lo], b = keys[hi];
+    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
 }
 
 // (the quad summaries of the ordered tiles live behind the row lines in the same allocation: r3dm_internal.hpp counts_summary_offset)
@@ -659,10 +642,27 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
 {
     if (n_tiles == 0 || dim > 256u) return hipSuccess;
     hipLaunchKernelGGL(stage_counts_kernel, dim3(n_tiles), dim3(256), 0, st, rows, n, dim, GB, tiledc, cscale, fail_dev);
-    // (the ordered tiles are written by the gather kernel behind these two: until then their first 3 n_pad words -- 12 of the >= 128 bytes a
-    // row has there -- are the order kernels' scratch)
-    hipLaunchKernelGGL(stage_counts_order_kernel, dim3(1), dim3(1024), 0, st, cscale, n, n_tiles * 32u, cperm, reinterpret_cast<uint32_t*>(tiledp));
-    hipLaunchKernelGGL(stage_counts_rank_kernel, dim3((n + 3u) / 4u), dim3(256), 0, st, n, n_tiles * 32u, reinterpret_cast<const uint32_t*>(tiledp), cperm);
+    // (the ordered tiles are written by the gather kernel behind the sort: until then their first 16 of the >= 128 bytes a row has there
+    // are the sort's key scratch)
+    {
+        const uint32_t n_pad = n_tiles * 32u;
+        uint32_t N2 = 64u; while (N2 < n_pad) N2 <<= 1;
+        const uint32_t C = N2 < 16384u ? N2 : 16384u;
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(tiledp);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)stage_counts_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stage_counts_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(stage_counts_sort_kernel<0>, dim3(N2 / C), dim3(kOrdNT), C * 8u, st, cscale, n, n_pad, C, 0u, N2 == C ? 1 : 0, keys, cperm);
+        for (uint32_t size = 2u * C; size <= N2 && size > C; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride >= C; stride >>= 1)
+                hipLaunchKernelGGL(stage_counts_sort_global_kernel, dim3((N2 / 2u + 255u) / 256u), dim3(256), 0, st, keys, N2 / 2u, size, stride);
+            hipLaunchKernelGGL(stage_counts_sort_kernel<1>, dim3(N2 / C), dim3(kOrdNT), C * 8u, st, cscale, n, n_pad, C, size, size == N2 ? 1 : 0, keys, cperm);
+        }
+    }
     hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow,
                        crow + counts_summary_offset(n_tiles));
     return hipGetLastError();

@@ -77,13 +77,16 @@ hipError_t launch_l2_exact_items(hipStream_t st, const MatchParams& P, uint32_t 
 // exact scan of the per-pair fallback lists: one workgroup per pair, lane = one uncertified query
 // (its row in registers), wave w = rows {8w .. 8w+7} of every 32-row tile of image I staged through
 // LDS (row reads are wave-uniform -> LDS broadcast).  Reference arithmetic, (distance, row) order.
+// Both operands come from the fragment-order tiles (ImgDev::tiled: the f32 values verbatim; float4 chunk k4 of row q is float4
+// ((q >> 5) 2G + k4) 32 + (q & 31)): a tile of image I is one contiguous G-KiB copy into LDS, and a view needs no row-major copy
+// for this scan (integer-valued views -- SIFT bins -- are registered without one).
 // ------------------------------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(256)
 void l2_exact_batch_kernel(const MatchParams P)
 {
     constexpr int D4 = G * 2;                        // float4 per (padded) row
-    __shared__ f32x4 tile[32 * D4];                  // 32 rows x Dpad floats
+    __shared__ f32x4 tile[32 * D4];                  // 32 rows x Dpad floats, fragment order: [chunk k][row r]
     __shared__ float md0[256], md1[256];
     __shared__ uint32_t mi0[256], mi1[256];
     __shared__ uint32_t s_ticket;
@@ -97,7 +100,7 @@ void l2_exact_batch_kernel(const MatchParams P)
     const ImgDev* __restrict__ Jp = P.imgs + pr.y;
     const uint32_t nI = Ip->n, dim = Ip->dim, d4 = dim >> 2;      // dim % 4 == 0 guaranteed by the launcher
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const gf4p irows = (gf4p)Ip->rows;
+    const gf4p itiles = (gf4p)Ip->tiled;
     // this workgroup's rows of image I: whole 32-row tiles, slice `slice` of S
     const uint32_t tiles_per = ((nI + 31u) / 32u + S - 1u) / S;
     const uint32_t row_beg = slice * tiles_per * 32u;
@@ -106,16 +109,16 @@ void l2_exact_batch_kernel(const MatchParams P)
         const bool active = b0 + lane < cnt;
         const uint32_t q = P.fb_q[(size_t)pair * kFbPerPair + (active ? b0 + lane : b0)];
         f32x4 qv[D4];
-        const gf4p qrow = (gf4p)Jp->rows + (size_t)q * d4;
+        const gf4p qrow = (gf4p)Jp->tiled + (size_t)(q >> 5) * (D4 * 32) + (q & 31u);
 #pragma unroll
-        for (int k = 0; k < D4; ++k) qv[k] = (k < (int)d4) ? qrow[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < D4; ++k) qv[k] = (k < (int)d4) ? qrow[k * 32] : f32x4{0.f, 0.f, 0.f, 0.f};
         float d0 = R3DM_INF, d1 = R3DM_INF; uint32_t i0 = kNone, i1 = kNone;
         for (uint32_t t0 = row_beg; t0 < row_end; t0 += 32) {
             r3dm_syncthreads();
             const uint32_t rows_here = (row_end - t0 < 32u) ? row_end - t0 : 32u;
-            for (uint32_t e = threadIdx.x; e < rows_here * d4; e += 256) {
-                const uint32_t r = e / d4, k = e % d4;
-                tile[r * D4 + k] = irows[(size_t)(t0 + r) * d4 + k];
+            {
+                const gf4p src = itiles + (size_t)(t0 >> 5) * (D4 * 32);
+                for (uint32_t e = threadIdx.x; e < 32u * D4; e += 256) tile[e] = src[e];
             }
             r3dm_syncthreads();
             for (uint32_t rr = 0; rr < 8; ++rr) {
@@ -125,7 +128,7 @@ void l2_exact_batch_kernel(const MatchParams P)
 #pragma unroll
                 for (int k = 0; k < D4; ++k) {
                     if (k < (int)d4) {
-                        const f32x4 a = tile[r * D4 + k];
+                        const f32x4 a = tile[k * 32 + r];
                         const float e0 = a[0] - qv[k][0], e1 = a[1] - qv[k][1], e2 = a[2] - qv[k][2], e3 = a[3] - qv[k][3];
                         result += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
                     }
@@ -277,11 +280,14 @@ __device__ __forceinline__ void finalize_body(const FinalizeParams& P, KeyT keys
                 r3dm_syncthreads();
             }
         }
-        // coordinate de-duplication: only possible when both views contain repeated positions.  Element k is dropped when an
+        // coordinate de-duplication: only possible when the QUERY view J repeats positions -- two of its features at one position that
+        // matched the same row of I, or two rows of I at one position (a query has one match, so repeated positions in I alone never
+        // produce two matches with equal coordinates).  Element k is dropped when an
         // EARLIER element of the (i, j)-sorted list has the same position classes (ci, cj).  canon[] is the smallest index of a
         // class, so such an element has i >= ci: the scan starts at the first key with i >= ci (binary search) -- for a feature
         // that is its own class representative (the usual case) that is the handful of earlier matches of the same i.
-        if (Ip->canon && Jp->canon) {
+        // (Until round 6 the test was "both views repeat positions": a pair whose I had none kept both matches of a repeated J position.)
+        if (Ip->canon && Jp->canon && Jp->has_dup) {
             for (uint32_t k = threadIdx.x; k < m; k += 256) {
                 const uint32_t ci = Ip->canon[(uint32_t)(keys[k] >> 32)], cj = Jp->canon[(uint32_t)keys[k]];
                 uint32_t lo = 0, hi = k;

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -28,6 +29,8 @@
 #include <vector>
 
 using namespace r3dm;
+
+struct r3dm_index;
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -40,9 +43,11 @@ using namespace r3dm;
 // called first thing by the library's background writer threads (feature files, match files): their work has a whole phase of the
 // caller's to hide behind, so under contention for the host's cores they stand back (Linux: a per-thread nice value, inherited
 // by the OpenMP helpers they start)
-inline void r3dm_background_thread()
+// (only when the host asked for it -- r3dm_set_background_nice, R3DComputeMatches::setBackgroundThreadsNice: a library does not
+// change thread priorities on its own)
+inline void r3dm_background_thread(int nice_value)
 {
-    (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+    if (nice_value > 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_value);
 }
 
 // fn(i) for i in [0, n) on up to `threads` host threads that EXIT when the work is done.  (An OpenMP team keeps spinning for
@@ -92,19 +97,87 @@ inline int r3dm_host_team(int want, int concurrent_teams = 2)
     return t < 1 ? 1 : t;
 }
 
+// Device memory of the views of a context: blocks cut from large slabs instead of one hipMalloc per buffer.  A view of 8,192 x 128
+// floats is a 4 MiB tile image + 32 KiB of slack + three small arrays: hipMalloc rounds each of them up to its page size (the tile
+// image alone occupied 6 MiB), which made a registered collection 1.5 x its own bytes; cut from 64 MiB slabs at 256-byte granularity
+// it is 1.05 x.  Blocks freed by a view (replaced, trimmed) go to a free list and serve later requests of at most 1.25 x their size; a
+// slab whose blocks are all free goes back to the device.  Not thread-safe: a context is used by one thread at a time.
+struct DevArena {
+    struct Slab { unsigned char* p = nullptr; size_t cap = 0, used = 0; uint32_t live = 0; };
+    std::vector<Slab> slabs;
+    std::multimap<size_t, std::pair<uint32_t, size_t>> free_blocks;       // size -> (slab, offset)
+    int bump[2] = {-1, -1};                                               // the slabs new blocks are cut from: the newest and the one before
+    static constexpr size_t kSlab = (size_t)64 << 20, kAlign = 256;
+    hipError_t alloc(size_t bytes, void** out, size_t* got)
+    {
+        bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4) {
+            const auto blk = it->second;
+            *out = slabs[blk.first].p + blk.second; *got = it->first;
+            slabs[blk.first].live += 1;
+            free_blocks.erase(it);
+            return hipSuccess;
+        }
+        for (int b : bump) {                                                     // the two newest slabs are bumped
+            if (b < 0 || (size_t)b >= slabs.size()) continue;
+            Slab& sl = slabs[(size_t)b];
+            if (sl.p && sl.cap - sl.used >= bytes) { *out = sl.p + sl.used; *got = bytes; sl.used += bytes; sl.live += 1; return hipSuccess; }
+        }
+        Slab sl;
+        sl.cap = std::max(kSlab, bytes);
+        hipError_t e = hipMalloc((void**)&sl.p, sl.cap);
+        if (e != hipSuccess) return e;
+        sl.used = bytes; sl.live = 1;
+        *out = sl.p; *got = bytes;
+        uint32_t at = (uint32_t)slabs.size();
+        for (uint32_t k = 0; k < slabs.size(); ++k) if (!slabs[k].p) { at = k; break; }      // reuse a dead entry: indices in free_blocks stay valid
+        bump[1] = bump[0]; bump[0] = (int)at;
+        if (at == slabs.size()) slabs.push_back(sl); else slabs[at] = sl;
+        return hipSuccess;
+    }
+    void free(void* p, size_t bytes)
+    {
+        unsigned char* q = static_cast<unsigned char*>(p);
+        for (uint32_t k = 0; k < slabs.size(); ++k) {
+            Slab& sl = slabs[k];
+            if (!sl.p || q < sl.p || q >= sl.p + sl.cap) continue;
+            sl.live -= 1;
+            if (sl.live == 0) {
+                for (auto it = free_blocks.begin(); it != free_blocks.end();) it = it->second.first == k ? free_blocks.erase(it) : std::next(it);
+                (void)hipFree(sl.p);
+                sl = Slab();
+            } else free_blocks.insert({bytes, {k, (size_t)(q - sl.p)}});
+            return;
+        }
+    }
+    size_t bytes_held() const { size_t b = 0; for (const Slab& sl : slabs) b += sl.p ? sl.cap : 0; return b; }
+    void release_all() { for (Slab& sl : slabs) if (sl.p) (void)hipFree(sl.p); slabs.clear(); free_blocks.clear(); bump[0] = bump[1] = -1; }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevArena* arena = nullptr;        // set: the buffer is a block of this arena (per-view layouts of a context), else its own hipMalloc
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        release();
+        if (arena) {
+            hipError_t e = arena->alloc(bytes, &p, &cap);
+            if (e != hipSuccess) { p = nullptr; cap = 0; }
+            return e;
+        }
         const size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p) { if (arena) arena->free(p, cap); else (void)hipFree(p); }
+        p = nullptr; cap = 0;
+    }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -125,15 +198,32 @@ struct PinBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Layouts of a view beyond the ones every view holds from registration on (float views: fragment-order f32 tiles + norms + statistics;
+// binary views: padded word rows): staged on FIRST USE by the path that reads them (api_core.cpp: ensure_layouts), or at registration
+// when the path's flag (r3dm_set_integer_mfma / _split_mfma / _hamming_mfma) is already on.
+enum : uint32_t {
+    kLayRows   = 1u,     // row-major f32 rows: exact re-scoring of real-valued pairs, the generic exact scan, the approximate matchers
+    kLayBf16   = 2u,     // bf16 tiles (r3dm_set_integer_mfma)
+    kLaySplit  = 4u,     // split-f16 planes (r3dm_set_split_mfma)
+    kLayCounts = 8u,     // count tiles + scale order (r3dm_set_split_mfma, rows = integer votes x a row scale); needs kLayRows
+    kLayBin8   = 16u,    // one byte per bit in i8 fragment order (r3dm_set_hamming_mfma)
+};
+
 struct HostImage {
     uint32_t view_id = 0, n = 0, dim = 0, width = 0, height = 0;
     r3dm_dtype dtype = R3DM_F32;
     uint32_t G = 0, n_tiles = 0, words = 0;
     bool has_xy = false, has_dup = false, live = false;
     bool borrowed = false;            // the buffers belong to an r3dm_index mounted into this slot for one call: never freed here
+    struct r3dm_index* owner = nullptr;   // ... that index (layouts staged on first use are added to IT, under its lock)
     DevBuf rows, tiled, tiled16, tiledh, tiledc, tiledp, cscale, cquad, cperm, tiled8, norms, bin, xy, canon;
-    float max_abs = 0.0f; bool not_integer = true, has_negative = true;     // staging statistics (read back after the staging kernel)
-    int32_t split_k = 0;                                                    // scale exponent of the f16 split tiles
+    uint32_t have = 0;                // kLay* bits: which on-demand layouts reflect the staged view
+    // staging statistics: accumulated by the staging kernel in the view's table entry, read back -- for all views staged since the last
+    // read -- by sync_view_stats() at the first call that needs them (no per-view synchronisation at registration)
+    bool stats_valid = false;
+    uint32_t stat_bits[3] = {0, 0, 1};                                      // ImgDev::max_norm_bits, max_abs_bits, not_integer
+    float max_abs = 0.0f; bool not_integer = true, has_negative = true;
+    int32_t split_k = 0;                                                    // scale exponent of the f16 split tiles (a function of max_abs)
     bool counts_ok = false;                                                 // every row is small integers x a row scale: the count tiles are valid
     bool compact_ready = false;     // ann_rows16 / ann_rows8 reflect the staged rows (reset by staging)
     DevBuf ann_adj, ann_deg, ann_rows16, ann_rows8;   // graph index (r3dm_match_pairs_kgraph), valid when ann_K != 0; compact row copies only for bf16- / u8-exact views
@@ -146,11 +236,18 @@ struct HostImage {
     uint32_t mrpt_trees = 0, mrpt_depth = 0; float mrpt_density = 0.0f; uint64_t mrpt_seed = 0;
     bool has_K = false;               // pinhole intrinsics (r3dm_set_intrinsics), needed by the essential-matrix filter
     double Kinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the layout buffers of a view registered with a context are blocks of the context's arena (an r3dm_index owns plain allocations:
+    // it outlives contexts)
+    void use_arena(DevArena* a)
+    {
+        DevBuf* b[] = {&rows, &tiled, &tiled16, &tiledh, &tiledc, &tiledp, &cscale, &cquad, &cperm, &tiled8, &norms, &bin, &xy, &canon};
+        for (DevBuf* x : b) x->arena = a;
+    }
     void release()
     {
         if (borrowed) { *this = HostImage(); return; }     // drop the aliases, keep the index's memory
         rows.release(); tiled.release(); tiled16.release(); tiledh.release(); tiledc.release(); tiledp.release(); cscale.release(); cquad.release(); cperm.release(); tiled8.release(); norms.release(); bin.release(); xy.release(); canon.release();
-        ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; compact_ready = false; live = false;
+        ann_adj.release(); ann_deg.release(); ann_rows16.release(); ann_rows8.release(); ann_K = 0; compact_ready = false; live = false; have = 0; stats_valid = false;
         hnsw_l0.release(); hnsw_up_off.release(); hnsw_up.release(); hnsw_M = 0;
         mrpt_R.release(); mrpt_RT.release(); mrpt_splits.release(); mrpt_leaves.release(); mrpt_lf.release(); mrpt_trees = 0;
     }
@@ -231,6 +328,28 @@ struct FilterBufs {
     }
 };
 
+// The way of a view from host memory to HBM (r3dm_set_image / r3dm_set_images): a ring of page-locked slots the caller's pageable rows
+// are copied into by the host (several threads for a batch of views), one asynchronous DMA per view from there into the slot's
+// device buffer, the staging kernel behind it, an event behind that -- a slot is reused when its event has passed; nothing waits
+// per view.  Every view in flight also owns the slot's position-class hash table.
+struct UploadRing {
+    static constexpr int kSlots = 8;
+    PinBuf pin[kSlots];
+    DevBuf raw[kSlots];
+    DevBuf ctab[kSlots];                 // position-class hash table: u64 keys [2^bits] then u32 values [2^bits]
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool busy[kSlots] = {false, false, false, false, false, false, false, false};
+    uint64_t next = 0;
+    void release()
+    {
+        for (int k = 0; k < kSlots; ++k) {
+            pin[k].release(); raw[k].release(); ctab[k].release();
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            ev[k] = nullptr; busy[k] = false;
+        }
+    }
+};
+
 struct r3dm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -243,6 +362,13 @@ struct r3dm_ctx {
     std::vector<std::unique_ptr<HostImage>> spare;          // views dropped by r3dm_clear_images: their device buffers serve the next ones
     std::unordered_map<uint32_t, uint32_t> slot_of;         // view id -> slot
     DevBuf d_imgs;                                           // ImgDev[slots]
+    PinBuf tab_host;                                         // page-locked mirror of the table's entries as the host last published them
+    PinBuf tab_back;                                         // landing zone of the table read back by sync_view_stats()
+    std::vector<uint32_t> pending_stats;                     // slots staged since the last sync_view_stats()
+    UploadRing ring;
+    DevArena arena;                                          // device memory of the registered views' layouts
+    DevBuf d_verdict;                                        // verdict words of count-tile checks launched by ensure_layouts
+    uint64_t n_ring_uploads = 0, n_direct_uploads = 0;       // views that went through the ring / were read where the caller had them
     // scratch (grown on demand, reused across calls)
     DevBuf d_pairs, d_nn, d_knn_idx, d_knn_dist, d_fb, d_cnt, d_out, d_pair_off, d_pair_cnt, d_raw;
     // geometric filters: one set of work buffers per model kind (0 F, 1 H, 2 E), so that r3dm_filter_FEH can run the three
@@ -279,6 +405,7 @@ struct r3dm_ctx {
     // r3dm_set_deferred_feature_files: the fwrite of a batch's .feat / .desc runs on `file_writer` behind the sink calls; the thread
     // reads pin_desc, so it is joined before that buffer is filled again, by r3dm_features_files_wait and by r3dm_destroy
     bool defer_files = false;
+    int background_nice = 0;                                  // r3dm_set_background_nice: nice value of this context's background writer threads (0 = unchanged)
     hipEvent_t ev_desc = nullptr;                            // the descriptors of the batch have landed in pin_desc (created on first use)
     std::thread file_writer;
     int file_writer_rc = 0; std::string file_writer_err;
@@ -313,12 +440,26 @@ struct PairJob { uint32_t I, J, sI, sJ; };
 // A dataset staged once for many queries (ArrayMatcher::Build): owns its device buffers, belongs to a device, not to a context
 struct r3dm_index {
     int device = 0;
-    HostImage img;
-    uint32_t stat_bits[3] = {0, 0, 0};          // ImgDev::max_norm_bits, max_abs_bits, not_integer as the staging kernel left them
+    HostImage img;                              // (statistics included: HostImage::stat_bits)
+    std::mutex mu;                              // layouts staged after Build (a flag switched on later) are added under this lock
 };
 
 // shared between the translation units
-int upload_imgdev(r3dm_ctx* c, uint32_t slot, const uint32_t* stat_bits3 = nullptr, int32_t split_k = 0, bool counts_ok = false);
+// part graphs of the approximate matchers (graph-searched pairs + exhaustively scanned small pairs): see their use
+struct PartMirrorGuard {
+    r3dm_ctx* c; bool keep;
+    PartMirrorGuard(r3dm_ctx* c_, bool suppress);
+    ~PartMirrorGuard();
+};
+int merge_parts_keep_mirror(r3dm_graph& ga, r3dm_graph& gs, r3dm_graph** out);
+// (re)writes the table entry of `slot` from its HostImage, statistics included: only for views whose statistics the host holds
+int publish_entry(r3dm_ctx* c, uint32_t slot);
+// the statistics of every view staged since the last call -> HostImage (one read of the table, one synchronisation)
+int sync_view_stats(r3dm_ctx* c);
+// stages the layouts `want` (kLay* bits) of every listed slot that does not hold them; kLayCounts: *counts_all_ok = every listed view
+// passed the votes-x-scale check.  Slots that mount an r3dm_index are staged under the index's lock.
+int ensure_layouts(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t want, bool* counts_all_ok = nullptr);
+int ensure_layouts_image(r3dm_ctx* c, HostImage& h, uint32_t want);        // (no table entry involved; the caller publishes)
 int run_match_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, float ratio_R, r3dm_graph* g,
                     int32_t* knn_idx_host, float* knn_dist_host);
 int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_stride, uint32_t sort_cap,

@@ -70,6 +70,9 @@ struct ImgDev {
     // values scaled by 2^split_k (max|x| 2^split_k in [2^13, 2^14); both filled by stage_split_kernel)
     const uint16_t* tiledh;
     int32_t split_k;
+    // (in the 4 bytes of padding that followed split_k: the size of the entry and the offsets of its other fields stay what the
+    // profiled machine code of the matching kernels was compiled with, profiles/pmc_traffic.json)
+    uint32_t has_dup;          // != 0: some feature of the view shares its position with an earlier one (filled by the staging kernel)
     // count tiles (kernels_match.hip, l2_knn2_counts_kernel): rows that are small integers times a per-row scale (LIOP) as f16 integers
     // in fragment order [n_tiles][G/2][2][32][8], the row scales, and whether EVERY row of the view is of that form
     const uint16_t* tiledc;    // keypoint order: the QUERY side of the nominator
@@ -366,9 +369,24 @@ hipError_t ak_compact(hipStream_t st, const AkLevelDev* levels, int n_levels, in
 constexpr uint32_t kAkSlotBytes = 80;                  // per candidate slot: cand 16 + list 16 + live 16 + out0 16 + out1 8 + valid 4 + dead 2 (+ 2 spare)
 
 // ---- launchers implemented in the .hip files (host side) ----
-hipError_t launch_stage_f32(hipStream_t st, const void* raw, int raw_is_u8, uint32_t n, uint32_t dim,
-                            float* rows, float* tiled, uint16_t* tiled16, float* norms, uint32_t G, uint32_t n_tiles,
-                            uint32_t* img_stats_dev /* &ImgDev::max_norm_bits: 3 consecutive words */);
+// registration of one float view (kernels_match.hip: stage_view_kernel): raw descriptors -> fragment-order tiles + norms + statistics
+// (+ the row-major f32 copy when `rows` is given), the positions copied / entered into the position-class table by role blocks of the
+// same launch, the classes read back by a second small launch
+struct StageViewArgs {
+    const void* raw;               // [n][dim] f32 or u8, row-major: device memory, or page-locked host memory read over the link
+    int raw_is_u8;
+    uint32_t n, dim, G, n_tiles;
+    float* tiled; float* norms;
+    float* rows;                   // optional
+    uint32_t* img_stats;           // &ImgDev::max_norm_bits: 3 consecutive words (zeroed by the table entry's upload)
+    const float* xy_src; float* xy_dst;         // optional positions (xy_src == xy_dst: already in place)
+    unsigned long long* canon_keys; uint32_t* canon_vals; uint32_t canon_bits;     // hash table of 2^bits slots, all bytes 0xFF
+    uint32_t* canon_dst; uint32_t* has_dup;     // -> ImgDev::canon's array, &ImgDev::has_dup
+};
+hipError_t launch_stage_view(hipStream_t st, const StageViewArgs& A);
+hipError_t launch_stage_positions(hipStream_t st, const StageViewArgs& A);      // the position part alone (binary views)
+hipError_t launch_untile_rows(hipStream_t st, const float* tiled, uint32_t n, uint32_t dim, uint32_t G, uint32_t n_tiles, float* rows);
+hipError_t launch_stage_bf16(hipStream_t st, const float* tiled, uint32_t G, uint32_t n_tiles, uint16_t* tiled16);
 hipError_t launch_stage_bin(hipStream_t st, const uint8_t* raw, uint32_t n, uint32_t nbytes,
                             uint32_t* bin, uint32_t words, uint32_t n_pad);
 // returns hipErrorInvalidValue when (G, dtype) has no tensor kernel; caller falls back to the exact scan

@@ -77,6 +77,23 @@ def test_large_match_files_are_the_oracle_writers_bytes(oracle, tmp_path):
     assert np.array_equal(back.pairs, g.pairs) and np.array_equal(back.offsets, g.offsets) and np.array_equal(back.matches, g.matches)
 
 
+def test_match_files_longer_than_one_writer_round(oracle, tmp_path):
+    """the .txt writer formats at most ~64 MiB of text at a time (rounds of pairs; a graph of 1e8 matches must not be held as text):
+    7 M matches -- three rounds, one of them a single pair longer than a round -- give the restatement's bytes"""
+    from regard3d_amd import api
+    rng = np.random.default_rng(12)
+    counts = np.array([1500000, 200000, 3300000, 5, 900000, 1100000], np.uint32)
+    pairs = np.array([(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)], np.uint32)
+    n = int(counts.sum())
+    matches = rng.integers(0, 1 << 20, (n, 2), dtype=np.uint64).astype(np.uint32)
+    g = api.Graph.from_csr(pairs, np.r_[0, np.cumsum(counts.astype(np.uint64))].astype(np.uint64), matches)
+    t_lib, t_orc = str(tmp_path / "lib.txt"), str(tmp_path / "orc.txt")
+    g.save(t_lib)
+    oracle.save_matches(t_orc, pairs, counts, matches)
+    import filecmp
+    assert filecmp.cmp(t_lib, t_orc, shallow=False)
+
+
 def test_graph_from_csr_orders_pairs_and_merge():
     from regard3d_amd import api
     a = api.Graph.from_csr(np.array([[2, 5], [0, 1]], np.uint32), np.array([0, 3, 5], np.uint64),

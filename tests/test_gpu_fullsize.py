@@ -225,6 +225,16 @@ def test_bench_config_legs(config, extra):
     cb = j["cpu_baseline"]
     assert cb["parity_pairs_checked"] >= 1 and cb["putative_mismatches"] == 0 and cb["F_inlier_set_mismatches"] == 0, cb
     assert j["detail"]["putative_matches"] > 0
+    # the clock of SURVEY 8(d) starts at host memory: the line carries what registration costs and one measured pass from there
+    assert j["detail"]["register_ms"] > 0 and 0 < j["detail"]["value_from_host"] <= j["value"] * 1.05
+    if config == "c5":
+        # what the config exists to report: ANN vs brute force, recall and throughput, and both bounds of the search
+        d = j["detail"]
+        assert 0.5 < d["recall_at_1"] <= 1.0 and 0.5 < d["recall_at_2"] <= 1.0                    # (over all queries, strangers included)
+        assert 0.99 < d["recall_at_1_of_queries_with_a_match"] <= 1.0 and 0.99 < d["match_set_f1"] <= 1.0 and 0.99 < d["match_set_recall"] <= 1.0
+        assert d["exhaustive_pairs_per_s"]["f32_tiles"] > 0 and d["exhaustive_pairs_per_s"]["integer_tiles_opt_in"] > 0
+        assert d["exhaustive_pairs_per_s"]["integer_graphs_identical_to_f32"] is True
+        assert set(j["roofline"]["bounds"]) == {"valu_issue", "gathered_bytes_over_hbm"}
     if config == "c4":
         assert "shard 0 of 8" in j["config"]["workload"] and j["config"]["pairs"] < 24 * 23 // 2
         assert cb["optimised_cpu"]["reference_built_index_mismatches"] == 0 and cb["optimised_cpu"]["reference_built_distance_mismatches"] == 0
