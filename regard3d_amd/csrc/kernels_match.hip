@@ -30,9 +30,10 @@ namespace r3dm {
 // (api_core.cpp: ensure_layouts).
 // ------------------------------------------------------------------------------------------------
 
-// role blocks behind the n_tiles tile blocks: kStageAuxBlocks blocks copy the positions, enter them into the position-class hash
-// table (IndMatchDecorator's coordinate de-duplication needs to know which features share a position) and zero the slack
-constexpr uint32_t kStageAuxBlocks = 8;
+// role blocks behind the n_tiles tile blocks -- one per 256 features, at least 8: they copy the positions, enter them into the
+// position-class hash table (IndMatchDecorator's coordinate de-duplication needs to know which features share a position; one
+// compare-and-swap + one minimum per feature, a thread each) and zero the slack
+__host__ __device__ inline uint32_t stage_aux_blocks(uint32_t n) { const uint32_t b = (n + 255u) / 256u; return b < 8u ? 8u : (b > 1024u ? 1024u : b); }
 
 __device__ __forceinline__ bool canon_key_of(float fx, float fy, unsigned long long& key)
 {
@@ -46,10 +47,10 @@ __device__ __forceinline__ uint32_t canon_hash(unsigned long long key, uint32_t 
     return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - bits));
 }
 
-__device__ __forceinline__ void stage_aux_role(const StageViewArgs& A, uint32_t rb)
+__device__ __forceinline__ void stage_aux_role(const StageViewArgs& A, uint32_t rb, uint32_t n_role_blocks)
 {
     const uint32_t n = A.n, G = A.G;
-    const uint32_t nthr = kStageAuxBlocks * 256u, tid = rb * 256u + threadIdx.x;
+    const uint32_t nthr = n_role_blocks * 256u, tid = rb * 256u + threadIdx.x;
     if (A.xy_src) {
         const unsigned long long kEmpty = ~0ull;
         const uint32_t mask = (1u << A.canon_bits) - 1u;
@@ -82,44 +83,40 @@ void stage_view_kernel(const StageViewArgs A)
 {
     __shared__ float sm[32 * 260];                     // the tile's rows, row stride dim + 4 floats (dim <= 256 staged through LDS)
     const uint32_t n = A.n, dim = A.dim, G = A.G;
-    if (blockIdx.x >= A.n_tiles) { stage_aux_role(A, blockIdx.x - A.n_tiles); return; }
-    const uint32_t t = blockIdx.x;
+    // (the role blocks come first: their atomics' round trips run beside the tile blocks' copies)
+    const uint32_t n_role = gridDim.x - A.n_tiles;
+    if (blockIdx.x < n_role) { stage_aux_role(A, blockIdx.x, n_role); return; }
+    const uint32_t t = blockIdx.x - n_role;
     const uint32_t rows_here = (n - t * 32u < 32u) ? n - t * 32u : 32u;
     const uint32_t per_tile = G * 256u;                // floats per tile = G * 2 * 32 * 4
     float* dst = A.tiled + (size_t)t * per_tile;
     const bool lds = dim <= 256u && (dim & 3u) == 0u && (((uintptr_t)A.raw) & (A.raw_is_u8 ? 3u : 15u)) == 0u;
     const uint32_t stride = dim + 4u;
     if (lds) {
-        // coalesced read of the tile's rows_here x dim values (contiguous in the raw image), converted, into LDS
-        const uint32_t total = rows_here * dim;
+        // coalesced read of the tile's rows_here x dim values (contiguous in the raw image), converted, into LDS: thread (ty, tx) walks
+        // rows ty, ty + 8, ... and the 4-element chunks tx, tx + 32, ... of a row
+        const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5, d4 = dim >> 2;
         if (A.raw_is_u8) {
-            const uint8_t* src = (const uint8_t*)A.raw + (size_t)t * 32u * dim;
-            for (uint32_t e = threadIdx.x * 4u; e < total; e += 1024u) {
-                const uint32_t w = *(const uint32_t*)(src + e);              // dim % 4 == 0: 4-byte aligned
-                const uint32_t r = e / dim, k = e - r * dim;
-                float* o = sm + r * stride + k;
-                o[0] = (float)(w & 255u); o[1] = (float)((w >> 8) & 255u); o[2] = (float)((w >> 16) & 255u); o[3] = (float)(w >> 24);
-            }
+            const uint32_t* src = (const uint32_t*)((const uint8_t*)A.raw + (size_t)t * 32u * dim);     // dim % 4 == 0: 4-byte aligned
+            for (uint32_t r = ty; r < rows_here; r += 8u)
+                for (uint32_t k4 = tx; k4 < d4; k4 += 32u) {
+                    const uint32_t w = src[r * d4 + k4];
+                    *(f32x4*)(sm + r * stride + 4u * k4) = f32x4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
+                }
         } else {
             const f32x4* src = (const f32x4*)((const float*)A.raw + (size_t)t * 32u * dim);
-            for (uint32_t e = threadIdx.x; e < total / 4u; e += 256u) {
-                const f32x4 v = src[e];
-                const uint32_t r = (e * 4u) / dim, k = e * 4u - r * dim;
-                *(f32x4*)(sm + r * stride + k) = v;
-            }
+            for (uint32_t r = ty; r < rows_here; r += 8u)
+                for (uint32_t k4 = tx; k4 < d4; k4 += 32u) *(f32x4*)(sm + r * stride + 4u * k4) = src[r * d4 + k4];
         }
         __syncthreads();
         if (A.rows) {
             f32x4* ro = (f32x4*)(A.rows + (size_t)t * 32u * dim);
-            for (uint32_t e = threadIdx.x; e < total / 4u; e += 256u) {
-                const uint32_t r = (e * 4u) / dim, k = e * 4u - r * dim;
-                ro[e] = *(const f32x4*)(sm + r * stride + k);
-            }
+            for (uint32_t r = ty; r < rows_here; r += 8u)
+                for (uint32_t k4 = tx; k4 < d4; k4 += 32u) ro[r * d4 + k4] = *(const f32x4*)(sm + r * stride + 4u * k4);
         }
         // fragment order: float4 (g, h, r) = row 32 t + r, dims 8 g + 4 h .. + 3
         for (uint32_t e4 = threadIdx.x; e4 < per_tile / 4u; e4 += 256u) {
-            const uint32_t r = e4 & 31u, h = (e4 >> 5) & 1u, g = e4 >> 6;
-            const uint32_t k = 8u * g + 4u * h;
+            const uint32_t r = e4 & 31u, k = (e4 >> 5) * 4u;            // (g, h) = e4 >> 5: dims 8 g + 4 h = 4 (e4 >> 5)
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < rows_here && k < dim) v = *(const f32x4*)(sm + r * stride + k);
             ((f32x4*)dst)[e4] = v;
@@ -141,14 +138,19 @@ void stage_view_kernel(const StageViewArgs A)
         if (row < n) {
             s = 0.0f;
             float mx = 0.0f; bool nonint = false, neg = false;
-            for (uint32_t k = 0; k < dim; ++k) {
-                float v;
-                if (lds) v = sm[threadIdx.x * stride + k];
-                else v = A.raw_is_u8 ? (float)((const uint8_t*)A.raw)[(size_t)row * dim + k] : ((const float*)A.raw)[(size_t)row * dim + k];
+            // ||row||^2 as ONE fma chain in element order (the accumulators' C operand; what rounds 1-5 computed), four elements per LDS read
+            auto take = [&](float v) {
                 s = fmaf(v, v, s);
                 mx = fmaxf(mx, fabsf(v));
                 nonint |= !(v == rintf(v));                  // also true for NaN
                 neg |= v < 0.0f;
+            };
+            if (lds) {
+                const float* p = sm + threadIdx.x * stride;
+                for (uint32_t k = 0; k < dim; k += 4u) { const f32x4 v = *(const f32x4*)(p + k); take(v[0]); take(v[1]); take(v[2]); take(v[3]); }
+            } else {
+                for (uint32_t k = 0; k < dim; ++k)
+                    take(A.raw_is_u8 ? (float)((const uint8_t*)A.raw)[(size_t)row * dim + k] : ((const float*)A.raw)[(size_t)row * dim + k]);
             }
             // img_stats = &ImgDev::max_norm_bits, max_abs_bits, not_integer (non-negative floats order like uints)
             atomicMax(A.img_stats + 0, __float_as_uint(s));
@@ -181,12 +183,12 @@ void canon_lookup_kernel(const float* __restrict__ xy, uint32_t n, const unsigne
 }
 
 __global__ __launch_bounds__(256)
-void stage_positions_kernel(const StageViewArgs A) { stage_aux_role(A, blockIdx.x); }
+void stage_positions_kernel(const StageViewArgs A) { stage_aux_role(A, blockIdx.x, gridDim.x); }
 
 hipError_t launch_stage_positions(hipStream_t st, const StageViewArgs& A)
 {
     if (!A.xy_src || A.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(stage_positions_kernel, dim3(kStageAuxBlocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(stage_positions_kernel, dim3(stage_aux_blocks(A.n)), dim3(256), 0, st, A);
     if (A.canon_keys)
         hipLaunchKernelGGL(canon_lookup_kernel, dim3((A.n + 255u) / 256u), dim3(256), 0, st, A.xy_dst, A.n, A.canon_keys, A.canon_vals, A.canon_bits,
                            A.canon_dst, A.has_dup);
@@ -195,7 +197,7 @@ hipError_t launch_stage_positions(hipStream_t st, const StageViewArgs& A)
 
 hipError_t launch_stage_view(hipStream_t st, const StageViewArgs& A)
 {
-    hipLaunchKernelGGL(stage_view_kernel, dim3(A.n_tiles + kStageAuxBlocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(stage_view_kernel, dim3(A.n_tiles + stage_aux_blocks(A.n)), dim3(256), 0, st, A);
     if (A.xy_src && A.canon_keys && A.n)
         hipLaunchKernelGGL(canon_lookup_kernel, dim3((A.n + 255u) / 256u), dim3(256), 0, st, A.xy_dst, A.n, A.canon_keys, A.canon_vals, A.canon_bits,
                            A.canon_dst, A.has_dup);

@@ -539,21 +539,22 @@ void stage_counts_kernel(const float* __restrict__ rows, uint32_t n, uint32_t di
 // The DATASET side of the nominator reads the rows in the order of their scales (512 classes per binary order, i.e. scales within
 // 0.2 % of one another inside a class): the quad test of the kernel bounds four keys with the largest scale of their four rows, and
 // with rows in keypoint order (scales 30 % apart) that bound let a large share of the quads through to the per-key path.
-// cperm[position] = row, rows ordered by (scale class, row index), kNone behind the last row: a SORT of 64-bit keys class << 32 | row
-// -- a bitonic network, chunks of <= 16,384 keys in LDS by one workgroup of 1,024 threads each, chunk-crossing strides through
-// global memory -- so the order is the same from run to run by construction (which rows share a tile decides which queries the
-// epilogue sends to the exact scan; the results are exact either way), and its cost does not depend on how the scales are
-// distributed: 8,192 rows are ONE launch of one workgroup.  (Rounds 4-5: a one-workgroup counting sort on LDS atomics -- 210-265 us
-// per 28 k-row view whose scales fall into a few dozen classes, the atomics of a wavefront serialising on them -- plus a ranking
-// kernel of O(rows x class size): 413 us per 8 k-row view of one class.)
+// cperm[position] = row, rows ordered by (scale class, row index), kNone behind the last row -- a STABLE SORT by class, so the order
+// is the same from run to run by construction (which rows share a tile decides which queries the epilogue sends to the exact scan;
+// the results are exact either way), at a cost that does not depend on how the scales are distributed.  Two launches for views of up
+// to 65,536 rows: (1) every workgroup orders a RUN of 1,024 consecutive rows by (class, row) -- a bitonic network on 32-bit keys
+// class << 10 | row-in-run in 4 KiB of LDS; (2) every row finds its place among all runs by counting, in each other run, the keys
+// that sort before it (two binary searches per run: rows of earlier runs win ties, rows of later runs lose them) -- the runs are
+// 4 KiB each and stay in L2.  8,192 rows: 8 workgroups twice, ~10 us; 28 k rows: ~30 us.  Larger views take a bitonic network over
+// 64-bit keys class << 32 | row, chunks of 16,384 keys in LDS, chunk-crossing strides through global memory.
+// (Rounds 4-5: a one-workgroup counting sort on LDS atomics -- 210-265 us per 28 k-row view whose scales fall into a few dozen classes,
+// the atomics of a wavefront serialising on them -- plus a ranking kernel of O(rows x class size): 413 us per 8 k-row view of one
+// class.  Round 6 first tried the one-workgroup LDS bitonic sort for every size: 16,384 64-bit keys through 105 stages are LDS
+// bandwidth, ~300 us.)
 // class of a scale: its sign-free exponent and 9 mantissa bits (0.2 % steps); a scale of 0 or a denormal (an all-zero row) is class 0
 constexpr uint32_t kOrdNT = 1024;
-__device__ __forceinline__ unsigned long long order_key(float s, uint32_t row)
-{
-    const uint32_t bits = __float_as_uint(s);
-    const uint32_t cls = ((bits >> 23) & 255u) == 0u ? 0u : (bits >> 14) & 0x1FFFFu;
-    return ((unsigned long long)cls << 32) | row;
-}
+__device__ __forceinline__ uint32_t order_class(float s);
+__device__ __forceinline__ unsigned long long order_key(float s, uint32_t row) { return ((unsigned long long)order_class(s) << 32) | row; }
 // compare-exchange passes of the bitonic network on a chunk of C keys in LDS: strides first .. 1 of merge step `size` (global index = base + local)
 __device__ __forceinline__ void order_lds_passes(unsigned long long* lk, uint32_t C, uint32_t base, uint32_t size, uint32_t first_stride)
 {
@@ -567,6 +568,74 @@ __device__ __forceinline__ void order_lds_passes(unsigned long long* lk, uint32_
         __syncthreads();
     }
 }
+__device__ __forceinline__ uint32_t order_class(float s)
+{
+    const uint32_t bits = __float_as_uint(s);
+    return ((bits >> 23) & 255u) == 0u ? 0u : (bits >> 14) & 0x1FFFFu;
+}
+constexpr uint32_t kRun = 1024;
+// (1) one workgroup of 512 threads per run of 1,024 consecutive rows: keys class << 10 | row-in-run (rows beyond n: all ones), sorted
+__global__ __launch_bounds__(512)
+void stage_counts_runs_kernel(const float* __restrict__ cscale, uint32_t n, uint32_t* __restrict__ runs)
+{
+    __shared__ uint32_t lk[kRun];
+    const uint32_t base = blockIdx.x * kRun;
+    for (uint32_t e = threadIdx.x; e < kRun; e += 512u) { const uint32_t r = base + e; lk[e] = r < n ? (order_class(cscale[r]) << 10) | e : 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t size = 2u; size <= kRun; size <<= 1)
+        for (uint32_t stride = size >> 1; stride >= 1u; stride >>= 1) {
+            const uint32_t e = threadIdx.x;
+            const uint32_t lo = 2u * e - (e & (stride - 1u)), hi = lo + stride;
+            const bool up = ((lo & size) == 0u);
+            const uint32_t a = lk[lo], b = lk[hi];
+            if ((a > b) == up) { lk[lo] = b; lk[hi] = a; }
+            __syncthreads();
+        }
+    for (uint32_t e = threadIdx.x; e < kRun; e += 512u) runs[base + e] = lk[e];
+}
+// (2) one thread per element of a sorted run: its place = its index in its own run + the keys of the other runs that sort before it.
+// The other runs are searched in LDS, 32 runs (128 KiB) at a time: a binary search is ten dependent reads, and 28 runs x 10 reads from
+// L2 were 61 us per 28 k-row view.
+constexpr uint32_t kPlaceGroup = 32;
+__global__ __launch_bounds__(1024)
+void stage_counts_place_kernel(const uint32_t* __restrict__ runs, uint32_t n_runs, uint32_t n, uint32_t n_pad, uint32_t* __restrict__ cperm)
+{
+    extern __shared__ uint32_t place_lds[];                     // [min(n_runs, kPlaceGroup)][kRun]
+    const uint32_t r = blockIdx.x, e = threadIdx.x;
+    const uint32_t key = runs[r * kRun + e];
+    const bool pad = key == 0xFFFFFFFFu;
+    const uint32_t cls_lo = key & ~1023u, cls_hi = key | 1023u;   // keys of the same class: [cls_lo, cls_hi]
+    uint32_t pos = e;
+    for (uint32_t q0 = 0; q0 < n_runs; q0 += kPlaceGroup) {
+        const uint32_t qn = n_runs - q0 < kPlaceGroup ? n_runs - q0 : kPlaceGroup;
+        __syncthreads();
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(runs + q0 * kRun);
+            uint4* dst = reinterpret_cast<uint4*>(place_lds);
+            for (uint32_t i = e; i < qn * (kRun / 4u); i += 1024u) dst[i] = src[i];
+        }
+        __syncthreads();
+        if (pad) continue;
+        for (uint32_t qq = 0; qq < qn; ++qq) {
+            const uint32_t q = q0 + qq;
+            if (q == r) continue;
+            const uint32_t* run = place_lds + qq * kRun;
+            // earlier runs: keys <= cls_hi sort before mine (same class, smaller row); later runs: keys < cls_lo
+            if (q > r && cls_lo == 0u) continue;                   // nothing sorts before class 0
+            const uint32_t bound = q < r ? cls_hi : cls_lo - 1u;   // count keys <= bound
+            uint32_t lo = 0, hi = kRun;
+#pragma unroll
+            for (int it = 0; it < 11; ++it)                        // (eleven halvings empty a range of 1,024)
+                if (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (run[mid] <= bound) lo = mid + 1u; else hi = mid; }
+            pos += lo;
+        }
+    }
+    if (pad) {                                                     // padding: kNone behind the last row (as many padding keys in the run as rows >= n)
+        const uint32_t row = r * kRun + e;
+        if (row >= n && row < n_pad) cperm[row] = kNone;
+    } else cperm[pos] = r * kRun + (key & 1023u);
+}
+
 // MODE 0: make the keys of chunk blockIdx.x and sort it (merge steps 2 .. C); MODE 1: the in-chunk strides (C / 2 .. 1) of merge step `size`.
 // `last`: the chunk is in its final order -> cperm; else -> keys (global scratch)
 template <int MODE>
@@ -646,6 +715,19 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
     // are the sort's key scratch)
     {
         const uint32_t n_pad = n_tiles * 32u;
+        if (n_pad <= 65536u) {
+            // runs of 1,024 rows + placement by counting (scratch: 4 bytes per row of the padded runs)
+            const uint32_t n_runs = (n_pad + kRun - 1u) / kRun;
+            uint32_t* runs = reinterpret_cast<uint32_t*>(tiledp);
+            hipLaunchKernelGGL(stage_counts_runs_kernel, dim3(n_runs), dim3(512), 0, st, cscale, n, runs);
+            static bool place_attr = false;
+            if (!place_attr) {
+                const hipError_t e = hipFuncSetAttribute((const void*)stage_counts_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPlaceGroup * kRun * 4u));
+                if (e != hipSuccess) return e;
+                place_attr = true;
+            }
+            hipLaunchKernelGGL(stage_counts_place_kernel, dim3(n_runs), dim3(1024), (n_runs < kPlaceGroup ? n_runs : kPlaceGroup) * kRun * 4u, st, runs, n_runs, n, n_pad, cperm);
+        } else {
         uint32_t N2 = 64u; while (N2 < n_pad) N2 <<= 1;
         const uint32_t C = N2 < 16384u ? N2 : 16384u;
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(tiledp);
@@ -661,6 +743,7 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
             for (uint32_t stride = size >> 1; stride >= C; stride >>= 1)
                 hipLaunchKernelGGL(stage_counts_sort_global_kernel, dim3((N2 / 2u + 255u) / 256u), dim3(256), 0, st, keys, N2 / 2u, size, stride);
             hipLaunchKernelGGL(stage_counts_sort_kernel<1>, dim3(N2 / C), dim3(kOrdNT), C * 8u, st, cscale, n, n_pad, C, size, size == N2 ? 1 : 0, keys, cperm);
+        }
         }
     }
     hipLaunchKernelGGL(stage_counts_gather_kernel, dim3(n_tiles), dim3(256), 0, st, tiledc, cscale, norms, cperm, GB, tiledp, crow,

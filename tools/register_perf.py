@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--kind", default="sift")
     ap.add_argument("--dev", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--split", action="store_true", help="r3dm_set_split_mfma on before the views are registered: rows + count tiles are staged behind every view")
+    ap.add_argument("--integer", action="store_true", help="r3dm_set_integer_mfma on before the views are registered: bf16 tiles are staged behind every view")
     a = ap.parse_args()
     if a.dev:
         api.use_developer_library()
@@ -47,6 +49,10 @@ def main():
     raw_bytes = sum(d.nbytes for d in hd)
     ids = list(range(a.images))
     ctx = api.Context(0)
+    if a.split:
+        ctx.set_split_mfma(True)
+    if a.integer:
+        ctx.set_integer_mfma(True)
 
     def free_hbm():
         return torch.cuda.mem_get_info(0)[0]
