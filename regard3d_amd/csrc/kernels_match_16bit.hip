@@ -199,7 +199,7 @@ hipError_t launch_l2_knn2_int(hipStream_t st, const MatchParams& P, uint32_t G, 
     //   5 = LDS-shared 12.16 | 59 = LDS-shared without the epilogue 9.36.  The loads are the bound: with two query tiles per wave a CU's
     //   four SIMDs consume 4 KiB of fragments per 64 matrix cycles = 64 B/clk, the whole rate of its L1 address path
     static const int iv = r3dm_dev_knob("R3DM_L2_INT_VARIANT", 2);
-    if (G == 16 && (iv == 5 || iv == 59 || iv == 6)) return launch_l2_int_lds_variant(st, P, max_nj_tiles, iv);
+    if (G == 16 && (iv == 5 || iv == 59 || iv == 6 || iv == 7 || iv == 79)) return launch_l2_int_lds_variant(st, P, max_nj_tiles, iv);
     if (G == 16 && iv == 4) return launch_l2_int<8, 4, 4, 1>(st, P, max_nj_tiles);
     if (G == 16 && iv == 9) return launch_l2_int<8, 2, 4, 2, 1>(st, P, max_nj_tiles);
     if (G == 16 && iv == 8) return launch_l2_int<8, 2, 8, 2>(st, P, max_nj_tiles);

@@ -278,6 +278,216 @@ void l2_knn2_int_lds_kernel(const MatchParams P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same workgroup-shared tiles WITHOUT a barrier in the loop (round 6): a ring of kRingK LDS slots, a sequence word and a release
+// counter per slot.  The barrier version lost to the per-wave loads not by its LDS traffic (9.36 ms against 10.52 without the
+// epilogue, 780 pairs) but because one s_barrier per tile makes every wave wait for the one whose lists changed (12.16 against
+// 11.67 with it): here a wave in its push path stalls nobody until it is kRingK - 1 tiles behind.
+//   * tile T lives in slot T % kRingK and is FETCHED by wave T % 4 of the workgroup (all of it: GB LDS-DMA blocks + the 32 norms),
+//     as early as the slot is free -- i.e. when all four waves have released tile T - kRingK (rel[slot] == 4 x generation) -- and the
+//     fetching wave is within kRingK - 1 tiles of it;
+//   * a wave publishes a tile it fetched at the start of a LATER step of its own, behind a counted s_waitcnt vmcnt that covers the
+//     tile's DMAs (the only vector-memory operations of the loop), by writing T + 1 into seq[slot]; LDS instructions of a wave execute
+//     in order, so a reader that sees the word sees the tile (the rule of the guide: LDS-DMA data is ordered by the issuing wave's
+//     vmcnt; the sequence word takes the place of the barrier the reader would pass);
+//   * a wave reads tile t (and, through its fragment window, the first blocks of tile t + 1) after it has seen seq of tile t + 1, and
+//     releases tile t with one ds_add behind its last read of it.
+// Waves without query tiles fetch and release like the others; their results are discarded.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kRingK = 8;
+__device__ __forceinline__ uint32_t lds_read_u32(const uint32_t* p)
+{
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+
+template <int GB, int NJ, int PF, int WPS, int ABL = 0, int OPS = 0>
+__global__ __launch_bounds__(256, WPS)
+void l2_knn2_int_ring_kernel(const MatchParams P)
+{
+    static_assert(PF <= GB, "the fragment window runs at most one tile ahead");
+    // ONE LDS array: [kRingK slots][GB KiB tile | 256 B norms], then seq[kRingK], rel[kRingK]
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
+    constexpr uint32_t tileB = (uint32_t)GB * 1024u, slotB = tileB + 256u;
+    uint32_t* seq = reinterpret_cast<uint32_t*>(ring_smem + kRingK * slotB);
+    uint32_t* rel = seq + kRingK;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t h = lane >> 5, c = lane & 31u;
+    uint32_t pair, qb;
+    if (P.xcd_map) {                                       // pair p on XCD p % 8 (see l2_knn2_mfma_kernel)
+        const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        pair = (j / P.qb_per_pair) * 8u + xcd;
+        qb = j % P.qb_per_pair;
+        if (pair >= P.n_pairs) return;                     // whole workgroup
+    } else {
+        pair = blockIdx.x / P.qb_per_pair;
+        qb = blockIdx.x % P.qb_per_pair;
+    }
+    const uint2 pr = P.pairs[pair];
+    const ImgDev* __restrict__ Ip = P.imgs + pr.x;
+    const ImgDev* __restrict__ Jp = P.imgs + pr.y;
+    const uint32_t nI = Ip->n, ntI = Ip->n_tiles, ntJ = Jp->n_tiles;
+    const uint32_t qt0 = (qb * 4u + wave) * NJ;
+    const bool has_queries = qt0 < ntJ;
+
+    if (threadIdx.x < 2u * kRingK) seq[threadIdx.x] = 0u;  // (seq and rel are adjacent)
+    const void* tilesJ = OPS == 0 ? (const void*)Jp->tiled16 : (const void*)Jp->tiled8;
+    const void* tilesI = OPS == 0 ? (const void*)Ip->tiled16 : (const void*)Ip->tiled8;
+    f32x4 bq[NJ][GB];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t qt = qt0 + nj; if (qt >= ntJ) qt = ntJ - 1;
+        const gf4p src = (gf4p)tilesJ + (size_t)qt * (GB * 64) + lane;
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const u32x4 w = __builtin_bit_cast(u32x4, src[g * 64]);
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (OPS == 0) {                  // -2 x (integer, |x| <= 256) is a bf16 again
+                    const float lo = __uint_as_float(w[k] << 16) * -2.0f, hi = __uint_as_float(w[k] & 0xFFFF0000u) * -2.0f;
+                    o[k] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+                } else o[k] = w[k] * 0xFEu;                // bytes 0 / 1 -> 0 / -2 as i8 (no carries between bytes)
+            }
+            bq[nj][g] = __builtin_bit_cast(f32x4, o);
+        }
+    }
+    Top2 st[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) top2_init(st[nj]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the query fragments: from here on this wave's vmcnt counts its LDS-DMAs only
+    __syncthreads();                                       // seq / rel are zero for everybody (the only barrier of the kernel)
+
+    if (nI >= 2) {                                         // workgroup-uniform
+        const unsigned char* gA = reinterpret_cast<const unsigned char*>(tilesI) + lane * 16u;
+        const unsigned char* gN = reinterpret_cast<const unsigned char*>(Ip->norms) + (lane & 31u) * 4u;
+        // fetch tile T into its slot: GB + 1 LDS-DMA instructions (the DMA adds lane x 16 / lane x 4 itself)
+        auto fetch = [&](uint32_t T) {
+            unsigned char* slot = ring_smem + (T % kRingK) * slotB;
+#pragma unroll
+            for (int i = 0; i < GB; ++i)
+                __builtin_amdgcn_global_load_lds((glb_vp)(gA + (size_t)T * tileB + i * 1024u), (lds_vp)(slot + i * 1024u), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)(gN + (size_t)T * 128u), (lds_vp)(slot + tileB), 4, 0, 0);
+        };
+        // ---- prologue: the first kRingK - 1 tiles, each by its wave; published when landed
+        uint32_t next_fetch = wave;                        // smallest tile = wave (mod 4) this wave has not fetched
+        while (next_fetch < kRingK - 1u && next_fetch < ntI) { fetch(next_fetch); next_fetch += 4u; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            for (uint32_t T = wave; T < kRingK - 1u && T < ntI; T += 4u) __atomic_store_n(seq + T % kRingK, T + 1u, __ATOMIC_RELAXED);
+        uint32_t pend = 0xFFFFFFFFu;                       // tile fetched in an earlier step and not yet published
+
+        const unsigned char* lane_lds = ring_smem + lane * 16u;            // fragment of block g of slot s: + s * slotB + g * 1024
+        const unsigned char* lane_nrm = ring_smem + tileB + h * 16u;       // quad qd of slot s: + s * slotB + qd * 32
+        // wait until tile T is published (T < ntI)
+        auto wait_tile = [&](uint32_t T) {
+            const uint32_t* w = seq + T % kRingK;
+            while (lds_read_u32(w) != T + 1u) __builtin_amdgcn_s_sleep(1);
+        };
+        wait_tile(0);
+        if (ntI > 1) wait_tile(1);
+        f32x4 abuf[PF];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) abuf[s] = *reinterpret_cast<const f32x4*>(lane_lds + s * 1024);
+        f32x16 nrmA, nrmB;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lane_nrm + qd * 32);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nrmA[4 * qd + k] = v[k];
+        }
+        f32x16 accA[NJ], accB[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[nj][r] = R3DM_INF;              // "tile -1": keys that never win
+        const uint32_t hb = 4u * h;
+        // this wave's duties towards the ring, at the head of step t and again in every round of a wait: publish the tile an earlier
+        // call fetched (its DMAs are then a step old: the wait is a formality unless HBM served them), fetch the next tile of this
+        // wave when its slot has been released by all four waves and it is within kRingK - 1 tiles.  A wave that waits keeps doing
+        // both, or two waves could wait for tiles the other one holds back.
+        auto service = [&](uint32_t t) {
+            if (pend != 0xFFFFFFFFu) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __atomic_store_n(seq + pend % kRingK, pend + 1u, __ATOMIC_RELAXED);
+                pend = 0xFFFFFFFFu;
+            }
+            if (next_fetch < ntI && next_fetch <= t + kRingK - 1u && lds_read_u32(rel + next_fetch % kRingK) == 4u * (next_fetch / kRingK)) {
+                fetch(next_fetch);
+                pend = next_fetch; next_fetch += 4u;
+            }
+        };
+        // head of step t: tiles t and, for the fragment window, t + 1 are about to be read
+        auto step_head = [&](uint32_t t) {
+            service(t);
+            if (t + 1u < ntI) {
+                const uint32_t* w = seq + (t + 1u) % kRingK;
+                while (lds_read_u32(w) != t + 2u) { __builtin_amdgcn_s_sleep(1); service(t); }
+            }
+        };
+        auto release = [&](uint32_t t) {                   // behind this wave's last ds_read of tile t (LDS instructions execute in order)
+            if (lane == 0) __atomic_fetch_add(rel + t % kRingK, 1u, __ATOMIC_RELAXED);
+        };
+        uint32_t t = 0;
+        for (; t + 1 < ntI; t += 2) {
+            step_head(t);
+            int_tile_step_lds<GB, NJ, PF, ABL, OPS>(lane_lds + (t % kRingK) * slotB, lane_lds + ((t + 1u) % kRingK) * slotB, lane_nrm + ((t + 1u) % kRingK) * slotB,
+                                                    abuf, nrmA, nrmB, bq, accA, accB, st, (t - 1) * 32u + hb);
+            release(t);
+            step_head(t + 1u);
+            int_tile_step_lds<GB, NJ, PF, ABL, OPS>(lane_lds + ((t + 1u) % kRingK) * slotB, lane_lds + ((t + 2u) % kRingK) * slotB, lane_nrm + ((t + 2u) % kRingK) * slotB,
+                                                    abuf, nrmB, nrmA, bq, accB, accA, st, t * 32u + hb);
+            release(t + 1u);
+        }
+        if (t < ntI) {
+            step_head(t);
+            int_tile_step_lds<GB, NJ, PF, ABL, OPS>(lane_lds + (t % kRingK) * slotB, lane_lds + ((t + 1u) % kRingK) * slotB, lane_nrm + ((t + 1u) % kRingK) * slotB,
+                                                    abuf, nrmA, nrmB, bq, accA, accB, st, (t - 1) * 32u + hb);
+            release(t);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tope_push(st[nj], accA[nj][r], t * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        } else {
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tope_push(st[nj], accB[nj][r], (ntI - 1) * 32u + hb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        }
+        // a tile this wave fetched and nobody waited for yet is still published: other waves may be behind
+        if (pend != 0xFFFFFFFFu) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __atomic_store_n(seq + pend % kRingK, pend + 1u, __ATOMIC_RELAXED);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // drain before ordinary loads follow
+    }
+    if (has_queries) {
+        if constexpr (OPS == 0) l2_finish_queries<NJ, true>(P, pair, Ip, Jp, st, qt0, h, c, (float)(GB * 16), true);
+        else hamming_finish_queries<NJ>(P, pair, Ip, Jp, st, qt0, h, c);
+    }
+}
+
+template <int GB, int NJ, int PF, int WPS, int ABL = 0, int OPS = 0>
+static hipError_t launch_l2_int_ring(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
+{
+    MatchParams P = Pin;
+    const uint32_t tiles_per_wg = 4u * NJ;
+    P.qb_per_pair = (max_nj_tiles + tiles_per_wg - 1) / tiles_per_wg;
+    P.xcd_map = 1u;
+    const uint64_t grid64 = (uint64_t)((P.n_pairs + 7u) / 8u * 8u) * P.qb_per_pair;
+    if (grid64 == 0) return hipSuccess;
+    if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
+    const size_t lds = kRingK * ((size_t)GB * 1024 + 256) + 2 * kRingK * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)l2_knn2_int_ring_kernel<GB, NJ, PF, WPS, ABL, OPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((l2_knn2_int_ring_kernel<GB, NJ, PF, WPS, ABL, OPS>), dim3((uint32_t)grid64), dim3(256), lds, st, P);
+    return hipGetLastError();
+}
+
 template <int GB, int NJ, int PF, int WPS, int ABL = 0, int OPS = 0>
 static hipError_t launch_l2_int_lds(hipStream_t st, const MatchParams& Pin, uint32_t max_nj_tiles)
 {
@@ -297,6 +507,12 @@ static hipError_t launch_l2_int_lds(hipStream_t st, const MatchParams& Pin, uint
 // biased popcounts in ImgDev::norms; 8 words = 256 bits = 8 blocks, 16 words = 512 bits = 16 blocks of 32
 hipError_t launch_hamming_mfma(hipStream_t st, const MatchParams& P, uint32_t words, uint32_t max_nj_tiles)
 {
+#ifdef R3DM_DEVTOOLS
+    // A/B (tools/int_ring_ab.py ... akaze): the barrier-free ring against the barrier per tile (the product)
+    static const int ring = r3dm_dev_knob("R3DM_HAMMING_RING", 0);
+    if (ring && words == 16) return launch_l2_int_ring<16, 2, 4, 2, 0, 1>(st, P, max_nj_tiles);
+    if (ring && words == 8) return launch_l2_int_ring<8, 2, 4, 2, 0, 1>(st, P, max_nj_tiles);
+#endif
     switch (words) {
         case 8:  return launch_l2_int_lds<8, 2, 4, 2, 0, 1>(st, P, max_nj_tiles);
         case 16: return launch_l2_int_lds<16, 2, 4, 2, 0, 1>(st, P, max_nj_tiles);
@@ -340,6 +556,8 @@ hipError_t launch_stage_bin8(hipStream_t st, const uint32_t* bin, uint32_t n, ui
 // the bf16 integer kernel's LDS-shared variants (developer A/B of kernels_match_16bit.hip: R3DM_L2_INT_VARIANT 5 / 59 / 6)
 hipError_t launch_l2_int_lds_variant(hipStream_t st, const MatchParams& P, uint32_t max_nj_tiles, int iv)
 {
+    if (iv == 7) return launch_l2_int_ring<8, 2, 4, 2>(st, P, max_nj_tiles);       // ... through a barrier-free ring of LDS slots
+    if (iv == 79) return launch_l2_int_ring<8, 2, 4, 2, 1>(st, P, max_nj_tiles);   // ... without the epilogue (timing only)
     if (iv == 5) return launch_l2_int_lds<8, 2, 4, 2>(st, P, max_nj_tiles);        // workgroup-shared tiles through LDS-DMA
     if (iv == 59) return launch_l2_int_lds<8, 2, 4, 2, 1>(st, P, max_nj_tiles);    // ... without the epilogue (timing only)
     return launch_l2_int_lds<8, 2, 8, 2>(st, P, max_nj_tiles);                     // ... whole-tile fragment window

@@ -176,3 +176,39 @@ def test_collection_graphs_of_every_descriptor_kind(ictx, oracle):
 
 def test_views_beyond_the_lds_sort_budget(ictx, oracle):
     _parity_module().test_views_beyond_the_lds_sort_budget(ictx, oracle, 20000, 1.0)
+
+
+@pytest.mark.parametrize("env,kind", [({"R3DM_L2_INT_VARIANT": "7"}, "sift"), ({"R3DM_L2_INT_VARIANT": "5"}, "sift"), ({"R3DM_HAMMING_RING": "1"}, "akaze")])
+def test_lds_shared_variants_of_the_developer_build_give_the_products_graph(env, kind):
+    """The workgroup-shared forms of the bf16 / i8 nominators -- dataset tiles through LDS-DMA, with a barrier per tile (5) or through the
+    barrier-free ring of slots with sequence words and release counters (7; measured on a par with the per-wave loads and kept in
+    the developer build) -- must produce the graph the product's kernels produce: views of ragged sizes (workgroups with
+    waves that hold no queries, fewer tiles than ring slots, more tiles than ring slots)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, json, hashlib; sys.path.insert(0, {root!r})
+import numpy as np
+from regard3d_amd import api, synth
+if {bool(env)!r} and sys.argv[1] == "dev":
+    api.use_developer_library()
+sc = synth.make_scene(6, 2300, {kind!r}, seed=77)
+for k, n in ((1, 37), (2, 200), (3, 1), (4, 1025)):
+    sc.descs[k] = sc.descs[k][:n]; sc.xys[k] = sc.xys[k][:n]
+binary = {kind!r} == "akaze"
+c = api.Context(0)
+c.set_images(list(range(6)), sc.descs, sc.xys, 4000, 3000, binary=binary)
+(c.set_hamming_mfma if binary else c.set_integer_mfma)(True)
+g = c.match_pairs(sc.exhaustive_pairs(), 0.8 if binary else 0.7, not binary)
+s = c.stats()
+print(json.dumps(dict(sha=hashlib.sha256(b"".join(np.ascontiguousarray(getattr(g, f)).tobytes() for f in ("pairs", "offsets", "matches"))).hexdigest(),
+                      matches=int(g.num_matches), fast=int(s.n_hamming_mfma if binary else s.n_integer_mfma))))
+"""
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("R3DM_")}
+    out = {}
+    for which, e in (("product", clean), ("dev", dict(clean, **env))):
+        r = subprocess.run([sys.executable, "-c", code, which], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[which] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["product"]["fast"] >= 1 and out["dev"]["fast"] >= 1 and out["product"]["matches"] > 0
+    assert out["dev"] == out["product"]
