@@ -427,7 +427,9 @@ static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, in
     uint32_t eager = 0;
     if (v.dtype == R3DM_BIN) { if (c->hamming_mfma) eager |= kLayBin8; }
     else {
-        if (c->integer_mfma) eager |= kLayBf16;
+        // (the bf16 tiles of r3dm_set_integer_mfma are never staged here: whether a view is integer-valued is a statistic of the very
+        //  kernel this call queues -- the facade switches every exact path on and registers LIOP rows -- so they wait for a first match call
+        //  that can use them, 12 us per view)
         if (c->split_mfma) eager |= kLayRows | ((v.dtype == R3DM_F32 && n && dim <= 256) ? kLayCounts : 0u);
     }
     if (v.dtype == R3DM_BIN) {

@@ -232,6 +232,9 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     fp.pool_scratch = reinterpret_cast<uint32_t*>(B.f_scratch.as<unsigned char>() + 32 * (size_t)n_slice);
     fp.scratch_logc = reinterpret_cast<float*>(B.f_scratch.as<unsigned char>() + 36 * (size_t)n_slice);
     fp.soff = B.f_soff.as<uint64_t>();
+    FHIP(B.f_la.ensure((size_t)NI * 1024 * 8 + 64));
+    fp.la_tab = B.f_la.as<double>();
+    fp.scout = (uint32_t)(r3dm_dev_knob("R3DM_FILTER_SCOUT", 1) != 0);      // (developer build: 0 = every model through the full evaluation, for A/B and parity)
     // launch order: the workgroup of a pair runs for a time roughly proportional to its putative count, and a C2 call has
     // ~1.5 x as many pairs as resident workgroups -- start the long ones first so the tail of the launch is short ones
     {

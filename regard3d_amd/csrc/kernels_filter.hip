@@ -751,6 +751,11 @@ template <int KIND> struct ChunkOf { static constexpr int n = (KIND == 2) ? kE5S
 // kHistBins bins down from the bound on the residuals; LDS header = FState (padded to 1024) + the histogram
 constexpr int kHistBins = 1024, kHistSub = 5, kHistShift = 52 - kHistSub;
 constexpr int kHdr = 1024 + kHistBins * 4;
+// the scout pass (round 6, acransac_body): per chunk the flat offsets of the hypotheses' models, and per scouted model the number of
+// matches within the bound and the lower bound of its NFA; the per-wave histograms of the pass live in the (then idle) sort buffers
+constexpr int kScoutModels = 192;                   // 64 x 3 (F), 64 x 1 (H), 16 x 10 (E)
+constexpr int kScoutBytes = kScoutModels * 4 + kScoutModels * 8 + 80 * 4;      // totals, bounds, offsets [65] padded: 2624 bytes (16-byte multiple)
+constexpr int kScoutHistBytes = 8 * kHistBins * 4;  // eight waves (the 512-thread variant) x 1024 u32 bins
 
 #if defined(R3DM_FILTER_ONLY_E) || defined(R3DM_FILTER_DEVICE_ONLY)
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind);
@@ -759,12 +764,13 @@ static inline size_t filter_F_lds_bytes_unused_(uint32_t m_cap, int model_kind)
 size_t filter_F_lds_bytes(uint32_t m_cap, int model_kind)
 #endif
 {
-    // [FState, padded to 1024][histogram: 1024 x u32][Fs: chunk x (9 x MAX_MODELS) doubles][keys: m_cap x u64][idx: m_cap x u32]
+    // [FState, padded to 1024][histogram: 1024 x u32][Fs: chunk x (9 x MAX_MODELS) doubles][scout: totals, bounds, offsets][keys: m_cap x u64][idx: m_cap x u32]
     const size_t ms = model_kind == 2 ? 90 : 27;
     const size_t chunk = model_kind == 2 ? kE5Samples : kChunk;
     size_t sort_bytes = (size_t)m_cap * 12;
     if (model_kind == 2 && sort_bytes < (size_t)kE5Samples * kE5Stride * 8) sort_bytes = (size_t)kE5Samples * kE5Stride * 8;   // 5-point workspaces
-    return (size_t)kHdr + chunk * ms * 8 + sort_bytes;
+    if (sort_bytes < (size_t)kScoutHistBytes) sort_bytes = (size_t)kScoutHistBytes;                                                // the scout pass's per-wave histograms
+    return (size_t)kHdr + chunk * ms * 8 + kScoutBytes + sort_bytes;
 }
 
 // KIND 0: fundamental matrix (7-point, <= 3 models, symmetric epipolar error, point-to-line NFA scale)
@@ -938,6 +944,96 @@ __device__ __forceinline__ void wg_sort_regs(unsigned long long* __restrict__ ke
 }
 
 #ifndef R3DM_FILTER_DEVICE_ONLY      // (kernels_filter_coop.hip includes this file for the device routines above only)
+// ------------------------------------------------------------------------------------------------
+// The scout pass (round 6).  AC-RANSAC walks its models in order, but all a model needs from the matches to be passed over is how many of
+// them lie within the bound and -- once some model has been accepted -- a lower bound of the NFA it could reach (the histogram bound
+// of the full evaluation below).  Neither depends on the state of the walk, so the models of a chunk are scouted ahead of it, ONE
+// WAVEFRONT PER MODEL (a workgroup scouts 4 or 8 models at a time): one sweep over the pair's matches, count by ballot, histogram in the
+// wave's own 4 KiB of LDS, prefix and bound inside the wave -- no workgroup barrier, no compaction, no global atomics.  The walk then
+// passes over a model without a barrier when the scout says it cannot be accepted (98 % of them), and runs the full
+// evaluation -- unchanged -- on the others.  What was ~6 barriers + one pass per model becomes one barrier per sub-batch of models;
+// inlier sets, models, iteration and model counts are those of the sequential rule (and of oracle/acransac.c): a skipped model is
+// exactly one the full evaluation would have found hopeless or short of AC mode.
+// la_g: per-bin NFA slope logalpha0 + mult log10(edge + eps) of the pair (filled once per pair, same expression as the full evaluation)
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __noinline__ void scout_model(const float4* __restrict__ pt, uint32_t m, const double* __restrict__ Fm, const double* __restrict__ kinv,
+                                         double s1, double t1x, double t1y, double s2, double t2x, double t2y, double maxThreshold,
+                                         long long hist_base, bool want_bound, const double* __restrict__ la_g, const float* __restrict__ logc_n,
+                                         const float* __restrict__ logc_k, double loge0, uint32_t* __restrict__ whist, uint32_t lane,
+                                         uint32_t* __restrict__ out_total, double* __restrict__ out_bound)
+{
+    constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);
+    double F[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) F[e] = Fm[e];
+    if (KIND == 2) { double FE[9]; f_from_e(F, kinv, kinv + 9, FE);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) F[e] = FE[e]; }
+    if (want_bound) {
+        uint4* z = reinterpret_cast<uint4*>(whist + 16u * lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < m; base += 256u) {
+        double px[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t p = base + 64u * (uint32_t)u + lane;
+            const float4 f4 = pt[p < m ? p : 0u];
+            px[u][0] = s1 * (double)f4.x + t1x; px[u][1] = s1 * (double)f4.y + t1y;
+            px[u][2] = s2 * (double)f4.z + t2x; px[u][3] = s2 * (double)f4.w + t2y;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t p = base + 64u * (uint32_t)u + lane;
+            const double r = (KIND == 0) ? sym_epipolar_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
+                           : (KIND == 1) ? h_asym_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
+                                         : epipolar_dist_err(F, px[u][0], px[u][1], px[u][2], px[u][3]);
+            const bool in = (p < m) && (r <= maxThreshold);
+            total += (uint32_t)__builtin_popcountll(__ballot(in));
+            if (want_bound && in) {
+                long long bin = (__double_as_longlong(r) >> kHistShift) - hist_base;
+                bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
+                atomicAdd(&whist[bin], 1u);
+            }
+        }
+    }
+    double bound = -__builtin_huge_val();                  // "no bound": the walk then takes the full evaluation
+    if (want_bound && total > SS) {
+        // inclusive running counts over the bins: 16 consecutive bins per lane, written back in place
+        uint32_t cb[16];
+        uint32_t run = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { run += whist[16u * lane + (uint32_t)j]; cb[j] = run; }
+        uint32_t incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= (uint32_t)off) incl += o; }
+        const uint32_t excl = incl - run;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) whist[16u * lane + (uint32_t)j] = excl + cb[j];
+        // bins lane, lane + 64, ...: neighbouring (equally dense) bins go to different lanes
+        double wmin = __builtin_huge_val();
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t b = lane + 64u * (uint32_t)j;
+            const uint32_t k_hi = whist[b], k_prev = b ? whist[b - 1] : 0u;
+            uint32_t k_lo = k_prev + 1u; if (k_lo < SS + 1u) k_lo = SS + 1u;
+            if (k_hi >= k_lo) {
+                const double la = la_g[b];
+                for (uint32_t kk = k_lo; kk <= k_hi; ++kk) {
+                    const double w = loge0 + la * (double)(kk - SS) + (double)logc_n[kk] + (double)logc_k[kk];
+                    wmin = w < wmin ? w : wmin;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wmin, off); wmin = o < wmin ? o : wmin; }
+        bound = wmin;
+    }
+    if (lane == 0) { *out_total = total; *out_bound = bound; }
+}
+
 // NT = threads of the workgroup: 256 (two workgroups per CU), or 512 for collections with long match lists (one workgroup per CU with
 // the same registers per lane; every pass over the matches of a pair -- residuals, bound, sort, NFA scan -- takes half the trips)
 template <int KIND, bool SPILL, int NT, class KeyT, class IdxT>
@@ -1019,7 +1115,23 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     }
 #pragma unroll
     for (int j = 0; j < kHistBins / NT; ++j) hist[tid + NT * j] = 0u;
-    wg_sync_global();          // points, pool and logcombi table go through global memory
+    // the scout pass (scout_model above): on in the product; the developer build can switch it off (A/B, parity of the two walks) and
+    // its traces / invariant checks take the full evaluation for every model
+    const bool scout_on = P.scout != 0u && P.la_tab != nullptr && !R3DM_TRACE(P) && !R3DM_DBG(P);
+    double* __restrict__ la_g = P.la_tab ? P.la_tab + (size_t)item * kHistBins : nullptr;
+    if (scout_on) {
+#pragma unroll
+        for (int j = 0; j < kHistBins / NT; ++j) {
+            const uint32_t b = tid + (uint32_t)NT * (uint32_t)j;
+            const double edge = b ? __longlong_as_double(((long long)b + hist_base) << kHistShift) : 0.0;
+            la_g[b] = logalpha0 + MULT_ERR * log10(edge + FLT_EPS_D);
+        }
+    }
+    // walk state every thread keeps for itself (all threads take the same decisions on the same shared values): AC mode, models walked,
+    // iterations done -- the full evaluation used to keep them in LDS behind a barrier per model
+    bool ac_reg = !(P.precision_px < __builtin_huge_val());
+    uint32_t nmod_reg = 0, iters_done_reg = 0;
+    wg_sync_global();          // points, pool, logcombi and slope tables go through global memory
 
 #ifdef R3DM_E_TIMING
     unsigned long long cyc_solve = 0, cyc_eval = 0, cyc_t0 = 0, cyc_res = 0, cyc_sort = 0;
@@ -1030,6 +1142,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         cyc_t0 = __builtin_readcyclecounter();
 #endif
         const uint32_t iter0 = S.iter, nIter0 = S.nIter;
+        uint32_t nIter_reg = nIter0, reserve_reg = S.reserve;
         if (iter0 >= nIter0) break;
         constexpr uint32_t CH = (uint32_t)ChunkOf<KIND>::n;
         const uint32_t chunk_n = (nIter0 - iter0 < CH) ? nIter0 - iter0 : CH;
@@ -1116,6 +1229,17 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         { const unsigned long long now = __builtin_readcyclecounter(); cyc_solve += now - cyc_t0; cyc_t0 = now; }
 #endif
 
+        // ---- flat offsets of the chunk's models (scout pass): moff[c] = models of the hypotheses before c
+        uint32_t* __restrict__ sc_total = reinterpret_cast<uint32_t*>(smem + kHdr + CH * MS * 8);
+        double* __restrict__ sc_bound = reinterpret_cast<double*>(sc_total + kScoutModels);
+        uint32_t* __restrict__ moff = reinterpret_cast<uint32_t*>(sc_bound + kScoutModels);
+        uint32_t* __restrict__ whist = reinterpret_cast<uint32_t*>(smem + kHdr + CH * MS * 8 + kScoutBytes) + wave * (uint32_t)kHistBins;   // (the idle LDS sort buffers)
+        if (scout_on) {
+            if (tid <= chunk_n) { uint32_t o = 0; for (uint32_t j = 0; j < tid; ++j) o += S.nm[j]; moff[tid] = o; }
+            wg_sync_t<SPILL>();
+        }
+        uint32_t scouted = 0;                          // models [0, scouted) of the chunk hold scout results
+
         // ---- evaluate the chunk's iterations in order
         bool pool_changed = false;
         uint32_t c = 0;
@@ -1124,6 +1248,32 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
             const uint32_t nm = S.nm[c];
             bool better = false;
             for (uint32_t k = 0; k < nm; ++k) {
+                if (scout_on) {
+                    const uint32_t f = moff[c] + k;
+                    if (f >= scouted) {
+                        // scout the next sub-batch of models, four per wavefront at most (a pool change discards what lies behind it)
+                        const uint32_t n_chunk_models = moff[chunk_n];
+                        const uint32_t end_f = scouted + 4u * NW < n_chunk_models ? scouted + 4u * NW : n_chunk_models;
+                        const bool want_bound = S.minNFA < __builtin_huge_val();
+                        for (uint32_t fi = scouted + wave; fi < end_f; fi += NW) {
+                            const bool hit = lane < chunk_n && moff[lane] <= fi && fi < moff[lane + 1u];
+                            const uint32_t cc = (uint32_t)__builtin_ctzll(__ballot(hit));
+                            const uint32_t kk = fi - moff[cc];
+                            scout_model<KIND>(pt, m, Fs + cc * MS + kk * 9, S.kinv, s1, t1x, t1y, s2, t2x, t2y, maxThreshold, hist_base, want_bound,
+                                              la_g, logc_n, P.logc_k, loge0, whist, lane, sc_total + fi, sc_bound + fi);
+                        }
+                        wg_sync_t<SPILL>();
+                        scouted = end_f;
+                    }
+                    // can the full evaluation accept this model?  Not below AC mode's 2.5 x sample size, not with SS or fewer matches
+                    // within the bound, not when the best NFA its residual histogram allows is above the best so far
+                    const uint32_t tot_f = sc_total[f];
+                    const double bound_f = sc_bound[f], minNFA_f = S.minNFA;
+                    const bool ac_f = ac_reg || ((double)tot_f > 2.5 * SS);
+                    const bool skip = !(ac_f && tot_f > SS) ||
+                                      (bound_f > -__builtin_huge_val() && minNFA_f < __builtin_huge_val() && bound_f - 1.0e-6 >= minNFA_f);
+                    if (skip) { ac_reg = ac_f; nmod_reg += 1; continue; }
+                }
                 double F[9];
 #pragma unroll
                 for (int e = 0; e < 9; ++e) F[e] = Fs[c * MS + k * 9 + e];
@@ -1186,7 +1336,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 cyc_res += cyc_m1 - cyc_m0;
 #endif
                 // AC mode switches on with the first model that has > 2.5*7 points within the bound
-                bool ac = S.acMode != 0;
+                bool ac = ac_reg;
                 if (!ac && (double)total > 2.5 * SS) ac = true;
                 double nfa = __builtin_huge_val();
                 uint32_t kbest = SS;
@@ -1321,7 +1471,6 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                         }
                     }
                     S.acMode = ac ? 1u : 0u;
-                    S.n_models += 1;
                     if (improve) {
                         S.minNFA = nfa;
                         S.n_inl = kbest;
@@ -1333,7 +1482,15 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 }
 #pragma unroll
                 for (int j = 0; j < kHistBins / NT; ++j) hist[tid + NT * j] = 0u;     // ... and its histogram: last read before the commit barrier
+                ac_reg = ac; nmod_reg += 1;
                 wg_sync_t<SPILL>();
+            }
+            // ---- end of iteration `it`, the common case: no model of it was accepted and the iteration budget does not end here --
+            // nothing shared changes (ACRANSAC's pool / budget update below cannot trigger)
+            if (scout_on && !better && !(it + 1 == nIter_reg && reserve_reg != 0u)) {
+                iters_done_reg = it + 1;
+                if (it + 1 >= nIter_reg) { ++c; break; }
+                continue;
             }
             // ---- end of iteration `it`: ACRANSAC's pool / budget update.  Thread 0 is about to change the loop bounds that
             // the other waves read right after the previous iteration's last barrier; every evaluated model ends with a
@@ -1384,6 +1541,8 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 wg_fence();            // the rebuilt pool (global memory) is read by the sampling lanes of the next chunk (same workgroup)
             }
             wg_sync_t<SPILL>();
+            iters_done_reg = it + 1;
+            nIter_reg = S.nIter; reserve_reg = S.reserve;
             // the chunk was cut from the old budget: stop when the (possibly shrunk) budget is exhausted
             if (it + 1 >= S.nIter) { ++c; break; }
         }
@@ -1430,8 +1589,8 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
         P.thr_nfa[2 * (size_t)item] = (double)cyc_solve + 1e-12 * (double)cyc_res;      // (integers below 2^40: both survive in one double pair)
         P.thr_nfa[2 * (size_t)item + 1] = (double)cyc_eval + 1e-12 * (double)cyc_sort;
 #endif
-        P.iters[2 * (size_t)item] = S.iters_done;
-        P.iters[2 * (size_t)item + 1] = S.n_models;
+        P.iters[2 * (size_t)item] = iters_done_reg;
+        P.iters[2 * (size_t)item + 1] = nmod_reg;
     }
 }
 
@@ -1446,7 +1605,7 @@ __device__ __forceinline__ void acransac_item(const FilterParams& P, unsigned ch
     const uint32_t item = P.order ? P.order[block] : block;
     const uint32_t m = (uint32_t)(P.offsets[2 * item + 1] - P.offsets[2 * item]);
     if (m <= P.m_cap) {
-        unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + kHdr + ChunkOf<KIND>::n * MS * 8);
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem + kHdr + ChunkOf<KIND>::n * MS * 8 + kScoutBytes);
         uint32_t* sidx = reinterpret_cast<uint32_t*>(keys + P.m_cap);
         acransac_body<KIND, false, NT>(P, P.pts_scratch, P.pool_scratch, P.scratch_logc, smem, keys, sidx, item);
     } else {

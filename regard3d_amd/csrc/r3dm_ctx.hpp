@@ -304,7 +304,7 @@ struct r3dm_graph {
 };
 
 struct FilterBufs {
-    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch, f_kinv, f_spill, f_soff, f_order, f_coop, f_coop_prof;
+    DevBuf f_pairs, f_ids, f_offs, f_matches, f_inl_cnt, f_inl_idx, f_F, f_thr, f_iters, f_log10, f_logck, f_scratch, f_kinv, f_spill, f_soff, f_order, f_coop, f_coop_prof, f_la;
     // r3dm_filter_FEH: the kernel of this kind on a stream of its own PRIORITY class (E high, F normal, H low).  Streams of one
     // priority share a handful of hardware queues -- three plain streams ran the three kernels mostly one after the other --, streams
     // of different priorities never do.
@@ -323,7 +323,7 @@ struct FilterBufs {
         if (ev2) (void)hipEventDestroy(ev2);
         if (stream2) (void)hipStreamDestroy(stream2);
         ev0 = ev1 = ev2 = nullptr; stream = stream2 = nullptr;
-        DevBuf* b[] = {&f_pairs, &f_ids, &f_offs, &f_matches, &f_inl_cnt, &f_inl_idx, &f_F, &f_thr, &f_iters, &f_log10, &f_logck, &f_scratch, &f_kinv, &f_spill, &f_soff, &f_order, &f_coop, &f_coop_prof};
+        DevBuf* b[] = {&f_pairs, &f_ids, &f_offs, &f_matches, &f_inl_cnt, &f_inl_idx, &f_F, &f_thr, &f_iters, &f_log10, &f_logck, &f_scratch, &f_kinv, &f_spill, &f_soff, &f_order, &f_coop, &f_coop_prof, &f_la};
         for (DevBuf* x : b) x->release();
     }
 };

@@ -280,6 +280,8 @@ struct FilterParams {
     double*       pts_scratch;    // [slices][4] normalised (x1, y1, x2, y2)
     uint32_t*     pool_scratch;   // [n_matches]    current sampling pool
     float*        scratch_logc;   // [n_matches + n_items + 1] logcombi(k, m) table of each item
+    double*       la_tab;         // [n_items][1024] NFA slope of every residual-histogram bin of the item (the one-workgroup kernel's scout pass)
+    uint32_t      scout;          // != 0: the one-workgroup kernel scouts its models a wavefront each ahead of the walk (kernels_filter.hip)
     // ---- long pairs: the cooperative kernel (kernels_filter_coop.hip).  Items order[0 .. n_short) run on the one-workgroup-per-pair
     // kernel, the n_coop items of coop_items on a pool of workers over a task queue.
     uint32_t      n_short;

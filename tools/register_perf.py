@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--dev", action="store_true")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--split", action="store_true", help="r3dm_set_split_mfma on before the views are registered: rows + count tiles are staged behind every view")
-    ap.add_argument("--integer", action="store_true", help="r3dm_set_integer_mfma on before the views are registered: bf16 tiles are staged behind every view")
+    ap.add_argument("--integer", action="store_true", help="r3dm_set_integer_mfma on before the views are registered (its bf16 tiles wait for the first match call all the same)")
     a = ap.parse_args()
     if a.dev:
         api.use_developer_library()
