@@ -396,7 +396,17 @@ static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, in
             R3DM_HIP(c, r.raw[s].ensure(xy_off + xy_bytes + 256));
             // one DMA for rows + positions when both are in the slot, else the part that is
             const size_t from = desc_ring ? 0 : xy_off, to = xy_ring ? xy_off + xy_bytes : dbytes;
-            R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + from, r.pin[s].as<unsigned char>() + from, to - from, hipMemcpyHostToDevice, c->stream));
+            if (r3dm_dev_knob("R3DM_UPLOAD_ONE_STREAM", 0)) {
+                R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + from, r.pin[s].as<unsigned char>() + from, to - from, hipMemcpyHostToDevice, c->stream));
+            } else {
+                // on the ring's copy stream; the kernels of this view (context's stream) wait for its event.  The slot's previous DMA and
+                // the kernel that read it are done: the host waited for the slot's event before it refilled the page-locked buffer.
+                if (!r.copy_stream) R3DM_HIP(c, hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
+                if (!r.ev_copy[s]) R3DM_HIP(c, hipEventCreateWithFlags(&r.ev_copy[s], hipEventDisableTiming));
+                R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + from, r.pin[s].as<unsigned char>() + from, to - from, hipMemcpyHostToDevice, r.copy_stream));
+                R3DM_HIP(c, hipEventRecord(r.ev_copy[s], r.copy_stream));
+                R3DM_HIP(c, hipStreamWaitEvent(c->stream, r.ev_copy[s], 0));
+            }
             base = r.raw[s].as<unsigned char>();
         }
         if (desc_ring) raw = base;

@@ -340,13 +340,20 @@ struct UploadRing {
     hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool busy[kSlots] = {false, false, false, false, false, false, false, false};
     uint64_t next = 0;
+    // the DMAs run on a stream of their own, each followed by an event the view's staging kernel waits for on the context's stream: the
+    // DMA of view k + 1 then runs beside the kernel of view k instead of behind it (one stream: 85 us + 29 us per 8,192 x 128 view)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void release()
     {
         for (int k = 0; k < kSlots; ++k) {
             pin[k].release(); raw[k].release(); ctab[k].release();
             if (ev[k]) (void)hipEventDestroy(ev[k]);
-            ev[k] = nullptr; busy[k] = false;
+            if (ev_copy[k]) (void)hipEventDestroy(ev_copy[k]);
+            ev[k] = nullptr; ev_copy[k] = nullptr; busy[k] = false;
         }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        copy_stream = nullptr;
     }
 };
 

@@ -320,3 +320,96 @@ def test_c3_binary_collection_of_24_views(ctx, oracle):
     # images more than three steps apart share nothing: every kept pair is a neighbouring one
     assert gf.num_pairs >= 60 and all(int(J) - int(I) <= 3 for I, J in gf.pairs)
     ctx.clear_images()
+
+
+def _collection_1000(feat, seed):
+    """the 1000-view collections of BASELINE configs C4 / C5 as host arrays (generated on the device in blocks of 100 views)"""
+    import torch
+    descs, xys = [], []
+    d, x, _ = synth.make_scene_torch(1000, feat, seed=seed, device="cuda", kind="sift")
+    for i in range(1000):
+        descs.append(d[i].cpu().numpy()); xys.append(x[i].cpu().numpy())
+    del d, x
+    torch.cuda.empty_cache()
+    return descs, xys
+
+
+def _sample_pairs(rng, n_views, n):
+    pairs = {(0, 1), (0, n_views - 1), (n_views - 2, n_views - 1), (499, 500)}
+    while len(pairs) < n:
+        a, b = sorted(rng.choice(n_views, 2, replace=False).tolist())
+        pairs.add((a, b))
+    return np.array(sorted(pairs), np.uint32)
+
+
+def test_c4_resident_collection_of_1000_views(oracle):
+    """BASELINE config C4's collection -- 1000 views x 8,192 SIFT-128 f32, registered from host memory in one r3dm_set_images call --
+    stays within 1.3 x its raw rows in HBM on the default path; pairs sampled across the whole index range match exactly as they do in
+    a context that holds only their two views (nothing a view's 999 neighbours do to the table, the slabs or the ring leaks into a pair's
+    result), two of them equal the CPU restatement, and the F filter keeps the overlapping ones."""
+    from regard3d_amd import api
+    descs, xys = _collection_1000(8192, 4004)
+    raw = sum(d.nbytes for d in descs)
+    c = api.Context(0)
+    try:
+        c.set_images(list(range(1000)), descs, xys, synth.WIDTH, synth.HEIGHT, wait=True)
+        views_bytes, ring_bytes, _ = c.memory_info()
+        assert raw <= views_bytes <= 1.3 * raw, (views_bytes / raw)
+        assert all(c.view_info(v)[0] == 0 for v in (0, 499, 999))
+        pairs = _sample_pairs(np.random.default_rng(44), 1000, 160)
+        g = c.match_pairs(pairs, 0.6, True)
+        assert c.memory_info()[0] <= 1.3 * raw                     # integer-valued views: the default path added no layout
+        d = g.as_dict()
+        assert len(d) > 0
+        gf = c.filter_F(g, 4.0, 2048, seed=5489)
+        assert 0 < gf.num_pairs <= g.num_pairs
+        c2 = api.Context(0)
+        try:
+            for (I, J) in pairs[::16].tolist():
+                c2.clear_images()
+                c2.set_image(I, descs[I], xys[I], synth.WIDTH, synth.HEIGHT); c2.set_image(J, descs[J], xys[J], synth.WIDTH, synth.HEIGHT)
+                one = c2.match_pairs(np.array([[I, J]], np.uint32), 0.6, True).as_dict()
+                assert np.array_equal(one.get((I, J), np.zeros((0, 2), np.uint32)), d.get((I, J), np.zeros((0, 2), np.uint32))), (I, J)
+        finally:
+            c2.close()
+        sub = np.array([[0, 999], [499, 500]], np.uint32)
+        counts, matches = oracle.match_collection([descs[0], descs[999], descs[499], descs[500]], [xys[0], xys[999], xys[499], xys[500]],
+                                                  np.array([[0, 1], [2, 3]], np.uint32), 0.6, True)
+        off = 0
+        for p, key in enumerate(((0, 999), (499, 500))):
+            assert np.array_equal(d.get(key, np.zeros((0, 2), np.uint32)), matches[off:off + counts[p]]), key
+            off += counts[p]
+    finally:
+        c.close()
+
+
+def test_c5_resident_collection_of_1000_views_graph_matcher():
+    """BASELINE config C5's collection -- 1000 views x 16,384 SIFT-128 -- resident at once: the graph matcher (index of every sampled
+    first view built on first use, rows staged on first use) gives every sampled pair the graph it gives in a context holding only that
+    pair's views; the views the sample never touched hold nothing beyond their tiles."""
+    from regard3d_amd import api
+    descs, xys = _collection_1000(16384, 5005)
+    raw = sum(d.nbytes for d in descs)
+    kp = api.KGraphParams.preset(3)
+    c = api.Context(0)
+    try:
+        c.set_images(list(range(1000)), descs, xys, synth.WIDTH, synth.HEIGHT, wait=True)
+        assert c.memory_info()[0] <= 1.3 * raw
+        pairs = _sample_pairs(np.random.default_rng(55), 1000, 48)
+        g = c.match_pairs_kgraph(pairs, 0.6, kp)
+        d = g.as_dict()
+        assert len(d) > 0 and c.stats().n_ann_built == len(set(pairs[:, 0].tolist()))
+        used = set(pairs.reshape(-1).tolist())
+        untouched = next(v for v in range(1000) if v not in used)
+        assert c.view_info(untouched)[0] == 0 and c.view_info(int(pairs[0, 0]))[0] == api.LAYOUT_ROWS
+        c2 = api.Context(0)
+        try:
+            for (I, J) in pairs[::8].tolist():
+                c2.clear_images()
+                c2.set_image(I, descs[I], xys[I], synth.WIDTH, synth.HEIGHT); c2.set_image(J, descs[J], xys[J], synth.WIDTH, synth.HEIGHT)
+                one = c2.match_pairs_kgraph(np.array([[I, J]], np.uint32), 0.6, kp).as_dict()
+                assert np.array_equal(one.get((I, J), np.zeros((0, 2), np.uint32)), d.get((I, J), np.zeros((0, 2), np.uint32))), (I, J)
+        finally:
+            c2.close()
+    finally:
+        c.close()
