@@ -572,6 +572,11 @@ __device__ __forceinline__ int five_point_coop(const double (&px1)[7][2], const 
     int d = 10;
     while (d > 0 && W[kE5P + d] == 0.0) --d;
     if (d <= 0) return 0;
+    // (the chain's 11 x 11 slots start as zeros: every coefficient above a polynomial's degree then IS zero -- copies, eliminations and
+    //  normalisations below only write up to the degree and zero what they eliminate -- so the bisection can run Horner over fixed
+    //  lengths: leading zeros change no bit of the value)
+    for (int e = l; e < 121; e += kE5Lanes) W[kE5A + e] = 0.0;
+    E5_SYNC();
     {
         const double lead = W[kE5P + d];
         if (l <= d) W[kE5A + l] = W[kE5P + l] / lead;
@@ -643,10 +648,17 @@ __device__ __forceinline__ int five_point_coop(const double (&px1)[7][2], const 
         for (int it = 0; it < 64; ++it) {
             const double mid = 0.5 * (lo + hi);
             int changes = 0, last = 0;
-            for (int k = 0; k < nf; ++k) {
-                const int dk = (int)W[kE5Deg + k];
-                double v = W[kE5A + 11 * k + dk];
-                for (int c = dk - 1; c >= 0; --c) v = v * mid + W[kE5A + 11 * k + c];
+            // f[k] has degree <= 10 - k (the chain's degrees fall by at least one per step) and zeros above its own: eleven Horner
+            // chains of FIXED length, independent of one another, their 66 coefficients read from LDS at constant offsets -- the
+            // reads pipeline and the chains interleave.  (With the degrees read from LDS the 66 reads and multiply-adds of a step were
+            // one dependent sequence: 64 steps x ~66 LDS round trips per root, most of a chunk's 170 us.)  A polynomial beyond the
+            // chain's end is all zeros: its sign 0 is skipped like any vanishing value.
+            asm volatile("" ::: "memory");              // (the coefficients stay in LDS: 132 registers of them would spill)
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                double v = W[kE5A + 11 * k + (10 - k)];
+#pragma unroll
+                for (int c = 9 - k; c >= 0; --c) v = v * mid + W[kE5A + 11 * k + c];
                 const int sg = (v > 0.0) - (v < 0.0);
                 if (sg != 0) { if (last != 0 && sg != last) ++changes; last = sg; }
             }
