@@ -330,14 +330,18 @@ int ensure_layouts(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t want, bool
 }
 
 // ---- the upload ring
-enum { kSrcPageable = 0, kSrcPinned = 1, kSrcDevice = 2 };
-static int source_kind(const void* p, const void** dev_ptr)
+enum { kSrcPageable = 0, kSrcPinned = 1, kSrcDevice = 2, kSrcPeer = 3 };
+// where a caller's buffer lives: pageable host memory (copied into the ring by the host), page-locked host memory and memory of THIS
+// device (read in place by the staging kernel), memory of another device (copied into the ring's device slot by the runtime: a kernel
+// may not assume peer access)
+static int source_kind(const void* p, const void** dev_ptr, int this_device)
 {
     *dev_ptr = p;
     if (!p) return kSrcPageable;
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return kSrcPageable; }
-    if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) return kSrcDevice;
+    if (at.type == hipMemoryTypeDevice) return at.device == this_device ? kSrcDevice : kSrcPeer;
+    if (at.type == hipMemoryTypeManaged) return kSrcDevice;
     if (at.type == hipMemoryTypeHost && at.devicePointer) { *dev_ptr = at.devicePointer; return kSrcPinned; }
     return kSrcPageable;
 }
@@ -413,6 +417,18 @@ static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, in
         if (xy_ring) xy_src = (const float*)(base + xy_off);
         c->n_ring_uploads += 1;
     } else c->n_direct_uploads += 1;
+    if ((kind_desc == kSrcPeer && n) || (v.xy && kind_xy == kSrcPeer && n)) {
+        // rows on another device: the runtime copies them into this slot's device buffer (peer-to-peer where the devices allow it)
+        R3DM_HIP(c, r.raw[s].ensure(xy_off + xy_bytes + 256));
+        if (kind_desc == kSrcPeer && n) {
+            R3DM_HIP(c, hipMemcpyAsync(r.raw[s].p, v.desc, dbytes, hipMemcpyDefault, c->stream));
+            raw = r.raw[s].p;
+        }
+        if (v.xy && kind_xy == kSrcPeer && n) {
+            R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + xy_off, v.xy, xy_bytes, hipMemcpyDefault, c->stream));
+            xy_src = (const float*)(r.raw[s].as<unsigned char>() + xy_off);
+        }
+    }
 
     int rc = table_reserve(c, c->imgs.size());
     if (rc != R3DM_OK) return rc;
@@ -507,7 +523,7 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
 {
     const ViewSrc v{view_id, width, height, desc, n, dim, dtype, xy};
     const void *dd = nullptr, *dx = nullptr;
-    const int kd = source_kind(desc, &dd), kx = source_kind(xy, &dx);
+    const int kd = source_kind(desc, &dd, c->device), kx = source_kind(xy, &dx, c->device);
     int s = 0;
     int rc = ring_acquire(c, &s);
     if (rc != R3DM_OK) return rc;
@@ -561,7 +577,7 @@ static int r3dm_set_images_impl(r3dm_ctx* c, const r3dm_view_desc* views, uint32
         vs[k] = ViewSrc{w.view_id, w.width, w.height, w.desc, w.n, w.dim, (r3dm_dtype)w.dtype, w.xy};
         int rc = check_view(c, vs[k]);
         if (rc != R3DM_OK) return rc;
-        kd[k] = source_kind(w.desc, &dd[k]); kx[k] = source_kind(w.xy, &dx[k]);
+        kd[k] = source_kind(w.desc, &dd[k], c->device); kx[k] = source_kind(w.xy, &dx[k], c->device);
     }
     for (uint32_t k = 0; k < n_views; ++k) slots[k] = slot_for_view(c, vs[k].view_id);
     int rc = table_reserve(c, c->imgs.size());
