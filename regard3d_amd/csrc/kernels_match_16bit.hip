@@ -720,23 +720,19 @@ hipError_t launch_stage_counts(hipStream_t st, const float* rows, uint32_t n, ui
             const uint32_t n_runs = (n_pad + kRun - 1u) / kRun;
             uint32_t* runs = reinterpret_cast<uint32_t*>(tiledp);
             hipLaunchKernelGGL(stage_counts_runs_kernel, dim3(n_runs), dim3(512), 0, st, cscale, n, runs);
-            static bool place_attr = false;
-            if (!place_attr) {
+            {   // (per launch: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive several)
                 const hipError_t e = hipFuncSetAttribute((const void*)stage_counts_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kPlaceGroup * kRun * 4u));
                 if (e != hipSuccess) return e;
-                place_attr = true;
             }
             hipLaunchKernelGGL(stage_counts_place_kernel, dim3(n_runs), dim3(1024), (n_runs < kPlaceGroup ? n_runs : kPlaceGroup) * kRun * 4u, st, runs, n_runs, n, n_pad, cperm);
         } else {
         uint32_t N2 = 64u; while (N2 < n_pad) N2 <<= 1;
         const uint32_t C = N2 < 16384u ? N2 : 16384u;
         unsigned long long* keys = reinterpret_cast<unsigned long long*>(tiledp);
-        static bool attr_set = false;
-        if (!attr_set) {
+        {
             hipError_t e = hipFuncSetAttribute((const void*)stage_counts_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stage_counts_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             if (e != hipSuccess) return e;
-            attr_set = true;
         }
         hipLaunchKernelGGL(stage_counts_sort_kernel<0>, dim3(N2 / C), dim3(kOrdNT), C * 8u, st, cscale, n, n_pad, C, 0u, N2 == C ? 1 : 0, keys, cperm);
         for (uint32_t size = 2u * C; size <= N2 && size > C; size <<= 1) {

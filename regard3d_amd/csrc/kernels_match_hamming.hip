@@ -478,11 +478,9 @@ static hipError_t launch_l2_int_ring(hipStream_t st, const MatchParams& Pin, uin
     if (grid64 == 0) return hipSuccess;
     if (grid64 > kMaxBlocksOf256) return hipErrorInvalidValue;
     const size_t lds = kRingK * ((size_t)GB * 1024 + 256) + 2 * kRingK * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         const hipError_t e = hipFuncSetAttribute((const void*)l2_knn2_int_ring_kernel<GB, NJ, PF, WPS, ABL, OPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((l2_knn2_int_ring_kernel<GB, NJ, PF, WPS, ABL, OPS>), dim3((uint32_t)grid64), dim3(256), lds, st, P);
     return hipGetLastError();
