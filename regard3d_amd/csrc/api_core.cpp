@@ -471,6 +471,8 @@ static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, in
             R3DM_HIP(c, h.rows.ensure((size_t)std::max<uint32_t>(n, 1) * dim * 4 + 256));
             h.have |= kLayRows;
         }
+        // the count tiles' buffers exist before the entry goes up (one upload carries every pointer); their kernels follow the staging kernel
+        if (eager & kLayCounts) { rc = ensure_layouts_image(c, h, kLayCounts); if (rc != R3DM_OK) return rc; }
     }
     // the table entry: written once from the mirror with the statistics zeroed; the kernels accumulate into it
     ImgDev* m = c->tab_host.as<ImgDev>() + slot;
@@ -486,18 +488,17 @@ static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, in
         A.img_stats = &entry_dev->max_norm_bits;
         R3DM_HIP(c, launch_stage_view(c->stream, A));
     }
-    if (eager & ~h.have) {
+    if (v.dtype == R3DM_BIN && (eager & ~h.have)) {
+        // byte tiles are made from the word rows the kernel above wrote: staged behind it, their two pointers patched into the entry
+        // (pointer fields only: the statistics words of the entry belong to the kernels until sync_view_stats)
         rc = ensure_layouts_image(c, h, eager);
         if (rc != R3DM_OK) return rc;
-        // pointer fields only: the statistics words of the entry belong to the kernels until sync_view_stats
         ImgDev e; fill_entry(h, e);
-        m->tiled16 = e.tiled16; m->tiledc = e.tiledc; m->cscale = e.cscale; m->cquad = e.cquad; m->tiledp = e.tiledp; m->cperm = e.cperm; m->tiled8 = e.tiled8;
-        if (v.dtype == R3DM_BIN) { m->norms = e.norms; R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->norms, &m->norms, sizeof(void*), hipMemcpyHostToDevice, c->stream)); }
-        R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->tiled16, &m->tiled16, sizeof(void*), hipMemcpyHostToDevice, c->stream));
-        R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->tiledc, &m->tiledc, offsetof(ImgDev, counts_fail) - offsetof(ImgDev, tiledc), hipMemcpyHostToDevice, c->stream));
+        m->tiled8 = e.tiled8; m->norms = e.norms;
+        R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->norms, &m->norms, sizeof(void*), hipMemcpyHostToDevice, c->stream));
         R3DM_HIP(c, hipMemcpyAsync((void*)&entry_dev->tiled8, &m->tiled8, sizeof(void*), hipMemcpyHostToDevice, c->stream));
-        if (h.have & kLayCounts) { rc = launch_counts_of(c, h, &entry_dev->counts_fail); if (rc != R3DM_OK) return rc; }
     }
+    if (v.dtype != R3DM_BIN && (h.have & kLayCounts)) { rc = launch_counts_of(c, h, &entry_dev->counts_fail); if (rc != R3DM_OK) return rc; }
     R3DM_HIP(c, hipEventRecord(r.ev[s], c->stream));
     r.busy[s] = true;
     c->pending_stats.push_back(slot);
