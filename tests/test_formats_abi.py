@@ -151,6 +151,21 @@ def test_no_cpu_fallback_without_gpu():
         api.Context(0)
 
 
+def test_registration_entries_reject_null_handles_without_a_gpu():
+    """the registration entries of round 6 validate their arguments before they touch the device: a null context (what a host holds
+    after a failed r3dm_create) is R3DM_ERR_INVALID = 1, never a crash -- callable without a GPU"""
+    import ctypes as C
+    from regard3d_amd import api
+    L = api.load_library()
+    view = api.ViewDesc(0, 0, 0, 0, 128, api.F32, None, None)
+    assert L.r3dm_set_images(None, C.byref(view), 1) != 0
+    assert L.r3dm_images_wait(None) != 0
+    assert L.r3dm_view_info(None, 0, None, None, None, None) != 0
+    assert L.r3dm_memory_info(None, None, None, None) != 0
+    L.r3dm_set_background_nice.argtypes = [C.c_void_p, C.c_int]
+    assert L.r3dm_set_background_nice(None, 10) != 0
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "regard3d_amd")
     for dirpath, _, files in os.walk(pkg):
