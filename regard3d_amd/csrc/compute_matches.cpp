@@ -392,6 +392,7 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
     // files are read and parsed by all host threads, 64 views at a time; registration (device copies) stays in view order
     struct Loaded { std::vector<float> xy; std::vector<unsigned char> desc; uint64_t n = 0; bool ok = false; };
     std::vector<Loaded> chunk;
+    std::vector<char> batch_done;
     for (size_t vi = 0; vi < views_.size(); ++vi) {
         if (vi % 64 == 0) {
             const size_t cn = std::min<size_t>(64, views_.size() - vi);
@@ -404,6 +405,27 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
                 // nothing may leave an OpenMP region by exception (std::terminate): a failed allocation is a failed load
                 try { L.ok = load_feat(dir + "/" + u.basename + ".feat", L.xy) && load_desc(dir + "/" + u.basename + ".desc", row_bytes, L.desc, L.n); }
                 catch (...) { L.ok = false; }
+            }
+            // one device: the chunk's views go to the matcher in ONE call (r3dm_set_images: helper threads fill the page-locked ring beside
+            // the DMAs) -- up to the first view the per-view pass below will refuse, so that its error is the one reported
+            batch_done.assign(cn, 0);
+            if (ctx_) {
+                std::vector<r3dm_view_desc> vd;
+                std::vector<size_t> which;
+                for (size_t k = 0; k < cn; ++k) {
+                    const Loaded& L = chunk[k];
+                    if (!L.ok) break;
+                    if (registered_[vi + k]) continue;
+                    if (L.xy.size() != 2 * L.n) break;
+                    const View& u = views_[vi + k];
+                    vd.push_back(r3dm_view_desc{u.id_view, u.ui_width, u.ui_height, (uint32_t)L.n, dim_, (int32_t)dtype_, L.desc.data(), L.xy.data()});
+                    which.push_back(k);
+                }
+                if (!vd.empty()) {
+                    const int rcb = r3dm_set_images(ctx_, vd.data(), (uint32_t)vd.size());
+                    if (rcb != R3DM_OK) { errorMessage_ = last_error(); return false; }
+                    for (size_t k : which) batch_done[k] = 1;
+                }
             }
         }
         const View& v = views_[vi];
@@ -419,8 +441,10 @@ bool R3DComputeMatches::computeMatches(R3DFParams& params, bool svgOutput, const
         else {
             if (xy.size() != 2 * n) { errorMessage_ = "feature/descriptor count mismatch: " + v.basename; return false; }
             statistics_.numberOfKeypoints_.push_back((int)n);
-            const int rc = set_image(v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, xy.data());
-            if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
+            if (!batch_done[vi % 64]) {
+                const int rc = set_image(v.id_view, v.ui_width, v.ui_height, desc.data(), (uint32_t)n, xy.data());
+                if (rc != R3DM_OK) { errorMessage_ = last_error(); return false; }
+            }
         }
         if (v.focal_px > 0.0) {
             const double K[9] = {v.focal_px, 0.0, v.ppx, 0.0, v.focal_px, v.ppy, 0.0, 0.0, 1.0};      // Pinhole_Intrinsic::K()
