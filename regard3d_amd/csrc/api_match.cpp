@@ -75,6 +75,8 @@ int finalize_batch(r3dm_ctx* c, const std::vector<PairJob>& jobs, uint32_t q_str
         std::vector<uint32_t> ids, cnts;
         std::vector<GraphSeg> segs;
         uint64_t dst = 0;
+        g->matches.reserve(g->matches.size() + (size_t)total);     // (one allocation: a graph of millions of matches otherwise re-grows a dozen times)
+        g->pairs.reserve(g->pairs.size() + 2 * (size_t)P); g->offsets.reserve(g->offsets.size() + P);
         for (uint32_t p = 0; p < P; ++p) {
             if (h_cnt[p] == 0) continue;                   // empty vectors never enter the map
             g->pairs.push_back(jobs[p].I); g->pairs.push_back(jobs[p].J);
