@@ -734,9 +734,32 @@ extern "C" int r3dm_filter_FEH(r3dm_ctx* c, const r3dm_graph* putative, double m
         }
         const double t_launch = now_ms();
         float ms_max = 0.f;
+        // the kinds' results come back side by side as well: each collect is a few copies into its own page-locked buffer and the host-side
+        // assembly of its graph (inlier indices -> matches), 1.5-2 ms per kind on a stage's graph; a thread per kind.  (Not with device
+        // mirrors -- they share the context's gather scratch -- and not in the developer build, whose traces and checks are written
+        // for one collect at a time.)
+        std::vector<int> rcs(calls.size(), R3DM_OK);
+        bool collected = false;
+#ifndef R3DM_DEVTOOLS
+        if (rc == R3DM_OK && calls.size() > 1 && !c->device_graphs) {
+            std::vector<std::thread> th;
+            try {
+                for (size_t i = 1; i < calls.size(); ++i)
+                    th.emplace_back([&, i]() {
+                        (void)hipSetDevice(c->device);
+                        try { rcs[i] = calls[i]->collect(ms[i]); } catch (...) { rcs[i] = R3DM_ERR_NOMEM; }
+                    });
+            } catch (...) {}                                   // fewer threads than kinds: the rest is collected below
+            try { rcs[0] = calls[0]->collect(ms[0]); } catch (...) { rcs[0] = R3DM_ERR_NOMEM; }
+            const size_t started = th.size();
+            for (std::thread& t : th) t.join();
+            for (size_t i = 1 + started; i < calls.size(); ++i) { try { rcs[i] = calls[i]->collect(ms[i]); } catch (...) { rcs[i] = R3DM_ERR_NOMEM; } }
+            collected = true;
+        }
+#endif
         for (size_t i = 0; i < calls.size() && rc == R3DM_OK; ++i) {
             Call& k = *calls[i];
-            rc = k.collect(ms[i]);
+            rc = collected ? rcs[i] : k.collect(ms[i]);
             if (rc != R3DM_OK && !k.o.err.empty()) c->err = k.o.err;
             ms_max = std::max(ms_max, ms[i]);
             if (ms_kernels3) ms_kernels3[k.slot] = ms[i];
