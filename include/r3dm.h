@@ -80,8 +80,9 @@ int  r3dm_device_info(const r3dm_ctx* ctx, char* arch, size_t arch_cap, int* n_c
  * re-laid-out there (MFMA fragment-order tiles + row norms).
  * What the reference does before it matches (Regions_Provider::load / Features_Provider::load, src/R3DComputeMatches.cpp:2040,2094-2095).
  * The call returns when the caller's buffers are consumed, NOT when the view is laid out: rows in pageable host memory are copied
- * into a ring of page-locked slots and travel from there (one DMA + one kernel per view, queued on the context's stream); device
- * pointers and page-locked host pointers are read in place and waited for.  Every later call of the context is ordered behind
+ * into a ring of page-locked slots and travel from there (one DMA + one kernel per view, queued on the context's streams); rows
+ * behind device pointers (this device's or a peer's) and page-locked host pointers are copied by the copy engine into the ring's
+ * device slot, and only that copy is waited for.  Every later call of the context is ordered behind
  * the registration; r3dm_images_wait waits for it explicitly.  A view costs its f32 tiles + norms in HBM (1.0 x its f32 size); the
  * layouts only some paths read (row-major rows for real-valued views and the approximate matchers, bf16 / split-f16 / count /
  * byte tiles of the opt-in paths) are made by the first call that needs them, or here when the path's switch is already on. */
@@ -100,7 +101,8 @@ int r3dm_set_images(r3dm_ctx* ctx, const r3dm_view_desc* views, uint32_t n_views
 int r3dm_images_wait(r3dm_ctx* ctx);
 /* What a registered view holds in HBM (reports, tests): *layouts = the on-demand layouts staged so far, bits R3DM_LAYOUT_*;
  * *bytes = device memory of every layout and index of the view; *ring_uploads / *direct_uploads (context-wide, may be NULL) = views that
- * travelled through the page-locked ring / were read where the caller had them, since r3dm_create. */
+ * travelled through the page-locked ring / were copied straight from the caller's device or page-locked buffers (and empty views),
+ * since r3dm_create. */
 #define R3DM_LAYOUT_ROWS   1u   /* row-major f32 rows */
 #define R3DM_LAYOUT_BF16   2u   /* bf16 tiles (r3dm_set_integer_mfma) */
 #define R3DM_LAYOUT_SPLIT  4u   /* split-f16 planes (r3dm_set_split_mfma) */

@@ -640,7 +640,7 @@ class Context:
         return a.value, b.value, h.value
 
     def view_info(self, view_id: int):
-        """-> (layout bits LAYOUT_*, bytes of HBM the view's layouts and indices occupy, views uploaded through the ring, views read in place)"""
+        """-> (layout bits LAYOUT_*, bytes of HBM the view's layouts and indices occupy, views whose rows went through the page-locked ring, views copied straight from the caller's device / page-locked buffers)"""
         lay = C.c_uint32(); b = C.c_uint64(); ru = C.c_uint64(); du = C.c_uint64()
         self._check(self._L.r3dm_view_info(self._h, view_id, C.byref(lay), C.byref(b), C.byref(ru), C.byref(du)), "r3dm_view_info")
         return lay.value, b.value, ru.value, du.value

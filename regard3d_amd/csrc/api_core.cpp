@@ -331,9 +331,8 @@ int ensure_layouts(r3dm_ctx* c, std::vector<uint32_t> slots, uint32_t want, bool
 
 // ---- the upload ring
 enum { kSrcPageable = 0, kSrcPinned = 1, kSrcDevice = 2, kSrcPeer = 3 };
-// where a caller's buffer lives: pageable host memory (copied into the ring by the host), page-locked host memory and memory of THIS
-// device (read in place by the staging kernel), memory of another device (copied into the ring's device slot by the runtime: a kernel
-// may not assume peer access)
+// where a caller's buffer lives: pageable host memory (copied into the ring's page-locked slot by the host first); page-locked host
+// memory, memory of THIS device, memory of another device (all three copied by the runtime straight into the ring's device slot)
 static int source_kind(const void* p, const void** dev_ptr, int this_device)
 {
     *dev_ptr = p;
@@ -375,7 +374,7 @@ static void ring_fill(const UploadRing& r, int s, const ViewSrc& v, bool desc_fr
 
 // Stage one view into `slot`.  `s` = its ring slot (acquired; the page-locked buffer already holds the host rows when filled = true).
 // Leaves the stream with: [DMA of the slot] -> staging kernel(s) -> the slot's event.  Nothing is waited for.
-static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, int kind_desc, const void* dev_desc, int kind_xy, const void* dev_xy, bool filled)
+static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, int kind_desc, const void* dev_desc, int kind_xy, const void* dev_xy, bool filled, bool* copy_wait_out)
 {
     HostImage& h = *c->imgs[slot];
     UploadRing& r = c->ring;
@@ -386,49 +385,37 @@ static int stage_enqueue(r3dm_ctx* c, uint32_t slot, const ViewSrc& v, int s, in
     const uint32_t n = v.n, dim = v.dim;
     const size_t dbytes = desc_bytes_of(v), xy_off = ring_xy_offset(v), xy_bytes = v.xy ? (size_t)n * 8 : 0;
     const bool desc_ring = kind_desc == kSrcPageable && n, xy_ring = v.xy && kind_xy == kSrcPageable && n;
-    const int zero_copy = r3dm_dev_knob("R3DM_UPLOAD_ZEROCOPY", 0);
-    // ---- where the kernel reads the raw rows / the positions
-    const void* raw = dev_desc; const float* xy_src = (const float*)dev_xy;
-    if (desc_ring || xy_ring) {
-        if (!filled) {
-            R3DM_HIP(c, r.pin[s].ensure(xy_off + xy_bytes + 256));
-            ring_fill(r, s, v, desc_ring, xy_ring);
-        }
-        const unsigned char* base;
-        if (zero_copy) base = r.pin[s].as<unsigned char>();               // the kernel reads the page-locked slot over the link
-        else {
-            R3DM_HIP(c, r.raw[s].ensure(xy_off + xy_bytes + 256));
+    // ---- every source ends in the slot's device buffer, by a copy on the ring's copy stream: pageable rows from the page-locked slot
+    // the host filled, anything else (device memory of this or another GPU, page-locked host memory) straight from where the caller
+    // keeps it -- the caller's buffers are consumed when THAT copy is done (copy_event_out), not when the staging kernels are; the
+    // kernels of this view (context's stream) wait for the slot's copy event.  The slot's previous copies and the kernel that read
+    // them are done: the host waited for the slot's event before the slot was handed out.  (Round 6 first read device sources in
+    // place and waited for the kernels: 0.3-0.5 ms per view of a features worker's time in the stage.)
+    const void* raw = nullptr; const float* xy_src = nullptr;
+    (void)dev_desc; (void)dev_xy;
+    *copy_wait_out = false;
+    if (n) {
+        R3DM_HIP(c, r.raw[s].ensure(xy_off + xy_bytes + 256));
+        if (!r.copy_stream) R3DM_HIP(c, hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
+        if (!r.ev_copy[s]) R3DM_HIP(c, hipEventCreateWithFlags(&r.ev_copy[s], hipEventDisableTiming));
+        unsigned char* base = r.raw[s].as<unsigned char>();
+        if (desc_ring || xy_ring) {
+            if (!filled) {
+                R3DM_HIP(c, r.pin[s].ensure(xy_off + xy_bytes + 256));
+                ring_fill(r, s, v, desc_ring, xy_ring);
+            }
             // one DMA for rows + positions when both are in the slot, else the part that is
             const size_t from = desc_ring ? 0 : xy_off, to = xy_ring ? xy_off + xy_bytes : dbytes;
-            if (r3dm_dev_knob("R3DM_UPLOAD_ONE_STREAM", 0)) {
-                R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + from, r.pin[s].as<unsigned char>() + from, to - from, hipMemcpyHostToDevice, c->stream));
-            } else {
-                // on the ring's copy stream; the kernels of this view (context's stream) wait for its event.  The slot's previous DMA and
-                // the kernel that read it are done: the host waited for the slot's event before it refilled the page-locked buffer.
-                if (!r.copy_stream) R3DM_HIP(c, hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
-                if (!r.ev_copy[s]) R3DM_HIP(c, hipEventCreateWithFlags(&r.ev_copy[s], hipEventDisableTiming));
-                R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + from, r.pin[s].as<unsigned char>() + from, to - from, hipMemcpyHostToDevice, r.copy_stream));
-                R3DM_HIP(c, hipEventRecord(r.ev_copy[s], r.copy_stream));
-                R3DM_HIP(c, hipStreamWaitEvent(c->stream, r.ev_copy[s], 0));
-            }
-            base = r.raw[s].as<unsigned char>();
-        }
-        if (desc_ring) raw = base;
-        if (xy_ring) xy_src = (const float*)(base + xy_off);
-        c->n_ring_uploads += 1;
+            R3DM_HIP(c, hipMemcpyAsync(base + from, r.pin[s].as<unsigned char>() + from, to - from, hipMemcpyHostToDevice, r.copy_stream));
+            c->n_ring_uploads += 1;
+        } else c->n_direct_uploads += 1;
+        if (!desc_ring) { R3DM_HIP(c, hipMemcpyAsync(base, v.desc, dbytes, hipMemcpyDefault, r.copy_stream)); *copy_wait_out = true; }
+        if (v.xy && !xy_ring) { R3DM_HIP(c, hipMemcpyAsync(base + xy_off, v.xy, xy_bytes, hipMemcpyDefault, r.copy_stream)); *copy_wait_out = true; }
+        R3DM_HIP(c, hipEventRecord(r.ev_copy[s], r.copy_stream));
+        R3DM_HIP(c, hipStreamWaitEvent(c->stream, r.ev_copy[s], 0));
+        raw = base;
+        if (v.xy) xy_src = (const float*)(base + xy_off);
     } else c->n_direct_uploads += 1;
-    if ((kind_desc == kSrcPeer && n) || (v.xy && kind_xy == kSrcPeer && n)) {
-        // rows on another device: the runtime copies them into this slot's device buffer (peer-to-peer where the devices allow it)
-        R3DM_HIP(c, r.raw[s].ensure(xy_off + xy_bytes + 256));
-        if (kind_desc == kSrcPeer && n) {
-            R3DM_HIP(c, hipMemcpyAsync(r.raw[s].p, v.desc, dbytes, hipMemcpyDefault, c->stream));
-            raw = r.raw[s].p;
-        }
-        if (v.xy && kind_xy == kSrcPeer && n) {
-            R3DM_HIP(c, hipMemcpyAsync(r.raw[s].as<unsigned char>() + xy_off, v.xy, xy_bytes, hipMemcpyDefault, c->stream));
-            xy_src = (const float*)(r.raw[s].as<unsigned char>() + xy_off);
-        }
-    }
 
     int rc = table_reserve(c, c->imgs.size());
     if (rc != R3DM_OK) return rc;
@@ -528,9 +515,10 @@ int stage_into_slot(r3dm_ctx* c, uint32_t slot, uint32_t view_id, uint32_t width
     int s = 0;
     int rc = ring_acquire(c, &s);
     if (rc != R3DM_OK) return rc;
-    rc = stage_enqueue(c, slot, v, s, kd, dd, kx, dx, false);
+    bool wait_copy = false;
+    rc = stage_enqueue(c, slot, v, s, kd, dd, kx, dx, false, &wait_copy);
     if (rc != R3DM_OK) return rc;
-    if ((n && kd != kSrcPageable) || (xy && n && kx != kSrcPageable)) R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    if (wait_copy) R3DM_HIP(c, hipEventSynchronize(c->ring.ev_copy[s]));      // the caller's device / page-locked buffers have been read
     return R3DM_OK;
 }
 
@@ -624,6 +612,7 @@ static int r3dm_set_images_impl(r3dm_ctx* c, const r3dm_view_desc* views, uint32
     std::vector<std::thread> th;
     try { for (int t = 0; t < T; ++t) th.emplace_back(helper); } catch (...) {}
     const bool helpers = !th.empty();
+    int last_copy_slot = -1;
     rc = R3DM_OK;
     for (uint32_t k = 0; k < n_views && rc == R3DM_OK; ++k) {
         const int s = (int)((base + k) % S);
@@ -631,14 +620,17 @@ static int r3dm_set_images_impl(r3dm_ctx* c, const r3dm_view_desc* views, uint32
         bool filled = false;
         if (helpers) { while (state[k].load(std::memory_order_acquire) != 1) std::this_thread::yield(); filled = true; }
         else if (r.busy[s]) { if (hipEventSynchronize(r.ev[s]) != hipSuccess) { c->err = "hipEventSynchronize"; rc = R3DM_ERR_HIP; break; } r.busy[s] = false; }
-        rc = stage_enqueue(c, slots[k], vs[k], s, kd[k], dd[k], kx[k], dx[k], filled);
+        bool wc = false;
+        rc = stage_enqueue(c, slots[k], vs[k], s, kd[k], dd[k], kx[k], dx[k], filled, &wc);
+        if (wc) last_copy_slot = s;
         state[k].store(2, std::memory_order_release);
     }
     if (rc != R3DM_OK) { abort.store(true); for (auto& a : state) a.store(2, std::memory_order_release); }
     for (std::thread& t : th) t.join();
     r.next = base + n_views;
     if (rc != R3DM_OK) return rc;
-    if (any_inplace) R3DM_HIP(c, hipStreamSynchronize(c->stream));
+    // buffers the copy stream read where the caller keeps them: consumed when the last such copy is done (the stream runs in order)
+    if (any_inplace && last_copy_slot >= 0) R3DM_HIP(c, hipEventSynchronize(r.ev_copy[last_copy_slot]));
     return R3DM_OK;
 }
 

@@ -6,8 +6,7 @@ SURVEY.md section 8(d) starts the metric's clock at "descriptors resident in hos
 first match call (the reference: Regions_Provider::load, /root/reference/src/R3DComputeMatches.cpp:2040,2094-2095).
 
   python tools/register_perf.py [--images 200] [--feat 8192] [--kind sift|siftu8|liopc|akaze] [--dev] [--reps 5]
---dev loads the developer build (R3DM_UPLOAD_ZEROCOPY=1: the staging kernel reads the page-locked ring over the link instead of
-a DMA into a device slot first).  Prints one line per (source, entry point) with ms per collection, GB/s and the HBM the
+--dev loads the developer build.  Prints one line per (source, entry point) with ms per collection, GB/s and the HBM the
 collection holds afterwards.
 """
 import argparse
