@@ -762,6 +762,9 @@ void ak_extrema_emit_kernel(const AkLevelDev* __restrict__ levels)
     const int y = L.border + row, lane = threadIdx.x & 63;
     const unsigned long long* __restrict__ mrow = L.mask + (size_t)row * L.mask_words;
     uint32_t base = L.row_off[row];
+    // (the parallel in-level pruning below: every candidate starts as its own component, opens no slot yet; its row rides in .w)
+    uint32_t* __restrict__ par = reinterpret_cast<uint32_t*>(L.live);
+    const uint32_t n_cand = L.counts[0];
     for (uint32_t c0 = 0; c0 < L.mask_words; c0 += 64) {
         const uint32_t c = c0 + (uint32_t)lane;
         unsigned long long m = c < L.mask_words ? mrow[c] : 0ull;
@@ -774,7 +777,9 @@ void ak_extrema_emit_kernel(const AkLevelDev* __restrict__ levels)
             const int bit = __builtin_ctzll(m);
             m &= m - 1ull;
             const int x = L.border + (int)c * 64 + bit;
-            L.cand[o++] = make_float4((float)(x * L.ratio), (float)(y * L.ratio), L.Ldet[(size_t)y * L.w + x], 0.0f);
+            L.cand[o] = make_float4((float)(x * L.ratio), (float)(y * L.ratio), L.Ldet[(size_t)y * L.w + x], __int_as_float(row));
+            par[o] = o; par[n_cand + o] = 0u; par[2u * n_cand + o] = 0u; L.out_valid[o] = 0u;
+            ++o;
         }
         base += (uint32_t)__shfl((int)incl, 63);
     }
@@ -902,9 +907,14 @@ __device__ __forceinline__ bool ak_prune_body(const AkLevelDev& L, uint32_t n_ca
 // 64 candidates instead of one per candidate); the outcomes of the candidates without a close earlier batch-mate are final
 // and are applied block-wise (appends keep raster order through a prefix count); the few candidates WITH a close earlier
 // batch-mate are evaluated one by one, in order, exactly like ak_prune_body does.  Identical list, identical order.
-__device__ __forceinline__ bool ak_prune_body_batched(const AkLevelDev& L, uint32_t n_cand, float* lx, float* ly, float* lr, uint32_t* lslot, uint32_t live_cap)
+// BYCAND (the parallel form below, one large component at a time): the candidates are cand[mem[0 .. n_cand)], a slot is known by the
+// candidate that opened it and lives in out0[that candidate] (out_valid = 1) until ak_prune_emit_kernel numbers the slots.
+__device__ __forceinline__ uint32_t ak_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool BYCAND>
+__device__ __forceinline__ bool ak_prune_body_batched(const AkLevelDev& L, uint32_t n_cand, const uint32_t* mem, float* lx, float* ly, float* lr, uint32_t* lslot, uint32_t live_cap)
 {
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    float4* __restrict__ out = BYCAND ? L.out0 : L.list;
     // the dependency box is a little wider than 2 size: the keep / replace rule compares dx*dx + dy*dy with size*size in floats, so
     // a candidate may be `within size` of a slot at an axis distance a few ulps beyond size; classifying a few more candidates as
     // dependent only sends them through the one-by-one path
@@ -913,7 +923,8 @@ __device__ __forceinline__ bool ak_prune_body_batched(const AkLevelDev& L, uint3
     for (uint32_t c0 = 0; c0 < n_cand; c0 += 64) {
         const uint32_t nb = (n_cand - c0 < 64u) ? n_cand - c0 : 64u;
         const bool have = lane < nb;
-        const float4 mine = have ? L.cand[c0 + lane] : make_float4(0, 0, 0, 0);
+        const uint32_t ci = BYCAND ? (have ? ak_ld(mem + c0 + lane) : 0u) : c0 + lane;
+        const float4 mine = have ? L.cand[ci] : make_float4(0, 0, 0, 0);
         const float px = mine.x, py = mine.y, pr = mine.z;
         // ---- drop the live entries that no candidate from this batch on can reach (rows more than one radius behind the
         // batch's first row; candidates come in raster order)
@@ -957,11 +968,13 @@ __device__ __forceinline__ bool ak_prune_body_batched(const AkLevelDev& L, uint3
             const bool app = in_blk && found == 0xFFFFFFFFu;
             const bool rep = in_blk && found != 0xFFFFFFFFu && pr > lr[found];
             const unsigned long long amask = __ballot(app);
-            if (rep) { lx[found] = px; ly[found] = py; lr[found] = pr; L.list[lslot[found]] = make_float4(px, py, pr, 1.0f); }
+            if (rep) { lx[found] = px; ly[found] = py; lr[found] = pr; out[lslot[found]] = make_float4(px, py, pr, 1.0f); }
             if (app) {
                 const uint32_t r = (uint32_t)__builtin_popcountll(amask & ((1ull << lane) - 1ull));
-                lx[n_live + r] = px; ly[n_live + r] = py; lr[n_live + r] = pr; lslot[n_live + r] = n_list + r;
-                L.list[n_list + r] = make_float4(px, py, pr, 1.0f);
+                const uint32_t slot = BYCAND ? ci : n_list + r;
+                lx[n_live + r] = px; ly[n_live + r] = py; lr[n_live + r] = pr; lslot[n_live + r] = slot;
+                out[slot] = make_float4(px, py, pr, 1.0f);
+                if (BYCAND) L.out_valid[slot] = 1u;
             }
             { const uint32_t na = (uint32_t)__builtin_popcountll(amask); n_live += na; n_list += na; }
             p = q;
@@ -977,30 +990,213 @@ __device__ __forceinline__ bool ak_prune_body_batched(const AkLevelDev& L, uint3
                     if (bal) f = (int)b + __builtin_ctzll(bal);
                 }
                 if (f >= 0) {
-                    if (qr > lr[f]) { if (lane == 0) { lx[f] = qx; ly[f] = qy; lr[f] = qr; L.list[lslot[f]] = make_float4(qx, qy, qr, 1.0f); } }
+                    if (qr > lr[f]) { if (lane == 0) { lx[f] = qx; ly[f] = qy; lr[f] = qr; out[lslot[f]] = make_float4(qx, qy, qr, 1.0f); } }
                 } else {
-                    if (lane == 0) { lx[n_live] = qx; ly[n_live] = qy; lr[n_live] = qr; lslot[n_live] = n_list; L.list[n_list] = make_float4(qx, qy, qr, 1.0f); }
+                    const uint32_t slot = BYCAND ? (uint32_t)__shfl((int)ci, (int)q) : n_list;
+                    if (lane == 0) { lx[n_live] = qx; ly[n_live] = qy; lr[n_live] = qr; lslot[n_live] = slot; out[slot] = make_float4(qx, qy, qr, 1.0f);
+                                     if (BYCAND) L.out_valid[slot] = 1u; }
                     ++n_live; ++n_list;
                 }
                 p = q + 1;
             }
         }
     }
-    if (lane == 0) L.counts[1] = n_list;
+    if (!BYCAND && lane == 0) L.counts[1] = n_list;
     return true;
 }
 
+constexpr uint32_t kAkHandBack = 0x80000000u;          // counts[3]: this level goes back to the one-wavefront form
+// The whole level by one wavefront (rounds 2-5; since round 6 the levels the parallel form below hands back -- counts[3] set: a large
+// component whose live set outgrew LDS -- and, in the developer build, every level when R3DM_AK_PRUNE=0).
 __global__ __launch_bounds__(64)
-void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels, uint32_t live_cap)
+void ak_prune_level_kernel(const AkLevelDev* __restrict__ levels, uint32_t live_cap, int only_flagged)
 {
     __shared__ float lx[kAkLive], ly[kAkLive], lr[kAkLive];
     __shared__ uint32_t lslot[kAkLive];
     const AkLevelDev L = levels[blockIdx.x];
+    if (only_flagged && !(L.counts[3] & kAkHandBack)) return;
     const uint32_t n_cand = L.counts[0];
     // The live set holds the kept points within one radius of the scan line: a few dozen in practice, so it lives in LDS;
     // only if it ever outgrows kAkLive slots (bounded by the candidate count alone) is the level redone with it in scratch.
-    if (!ak_prune_body_batched(L, n_cand, lx, ly, lr, lslot, live_cap))
+    if (!ak_prune_body_batched<false>(L, n_cand, nullptr, lx, ly, lr, lslot, live_cap))
         ak_prune_body<true>(L, n_cand, L.live, L.live + n_cand, L.live + 2 * (size_t)n_cand, (uint32_t*)(L.live + 3 * (size_t)n_cand), 0u);
+}
+
+// ---- The same rule, in parallel (round 6).  A candidate only ever meets slots within `size` of it, and a slot only ever stands where
+// some candidate stood (its opener, or a stronger candidate within `size` of where it stood before).  So the candidates fall into the
+// connected components of "within size of each other" (the very float predicate of the rule), and nothing one component does is seen
+// by another: first slot in list order within the radius = first slot OF THE COMPONENT in the order its candidates opened them.
+//   link     one lane per candidate, union-find over the earlier candidates of the rows within the radius (a wave reads them uniformly)
+//   flatten  root, member count and last member of every component
+//   small    a component of <= 64 candidates by one wavefront with its slots in registers (lane = slot, in opening order); a lone
+//            candidate opens its slot on the spot; larger components are queued
+//   large    a queued component by one wavefront: members gathered in raster order, then the batched rule above with the live set in LDS
+//            (a live set that outgrows LDS hands the level back to ak_prune_level_kernel)
+//   emit     slots numbered by a running count of the openers in raster order = the order the sequential rule appends them
+// Scratch (n = candidates of the level; all of it idle until the refinement): live[0..n) parent, [n..2n) member count (at roots),
+// [2n..3n) last member (at roots), [3n..4n) queue of (root, where its members are gathered) pairs; out0[i] / out_valid[i] = the slot
+// candidate i opened; out1 = the gathered members of the queued components; counts[2] = queued components, counts[3] = gather cursor
+// (< n) with the hand-back flag as its top bit.
+__device__ __forceinline__ uint32_t ak_uf_find(uint32_t* par, uint32_t x)
+{
+    for (;;) {
+        const uint32_t p = ak_ld(par + x);
+        if (p == x) return x;
+        const uint32_t g = ak_ld(par + p);
+        if (g == p) return p;
+        __hip_atomic_store(par + x, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // path halving: g is an ancestor of x whatever else happens
+        x = g;
+    }
+}
+__device__ __forceinline__ void ak_uf_union(uint32_t* par, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = ak_uf_find(par, a); b = ak_uf_find(par, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }                                // the later root goes under the earlier one: links point backwards, no cycle
+        if (atomicCAS(par + a, a, b) == a) return;
+    }
+}
+__global__ __launch_bounds__(256)
+void ak_prune_link_kernel(const AkLevelDev* __restrict__ levels)
+{
+    const AkLevelDev L = levels[blockIdx.y];
+    const uint32_t n = L.counts[0];
+    uint32_t* par = reinterpret_cast<uint32_t*>(L.live);
+    const float size = L.psize, size2 = size * size;
+    const int reach = (int)(size / L.ratio) + 1;                     // rows: dy = rows x ratio exactly
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
+    for (uint32_t c0 = wave * 64u; c0 < n; c0 += n_waves * 64u) {
+        const uint32_t i = c0 + lane;
+        const bool have = i < n;
+        const float4 me = L.cand[have ? i : c0];
+        int row_lo = __builtin_amdgcn_readfirstlane(__float_as_int(me.w)) - reach;     // lane 0 holds the wave's first (lowest) row
+        row_lo = row_lo < 0 ? 0 : row_lo;
+        const uint32_t lo = L.row_off[row_lo];
+        const uint32_t hi = c0 + 64u < n ? c0 + 64u : n;
+        for (uint32_t j = lo; j + 1u < hi; ++j) {
+            const float4 o = L.cand[j];                                                 // (wave-uniform address)
+            const float dx = me.x - o.x, dy = me.y - o.y;
+            if (have && j < i && dx * dx + dy * dy <= size2) ak_uf_union(par, i, j);
+        }
+    }
+}
+__global__ __launch_bounds__(256)
+void ak_prune_flatten_kernel(const AkLevelDev* __restrict__ levels)
+{
+    const AkLevelDev L = levels[blockIdx.y];
+    const uint32_t n = L.counts[0];
+    uint32_t* par = reinterpret_cast<uint32_t*>(L.live);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t r = ak_uf_find(par, i);
+        if (r != i) __hip_atomic_store(par + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(par + n + r, 1u);
+        atomicMax(par + 2u * n + r, i);
+    }
+}
+constexpr uint32_t kAkSmallComp = 64;
+__global__ __launch_bounds__(256)
+void ak_prune_small_kernel(const AkLevelDev* __restrict__ levels)
+{
+    const AkLevelDev L = levels[blockIdx.y];
+    const uint32_t n = L.counts[0];
+    const uint32_t* __restrict__ par = reinterpret_cast<const uint32_t*>(L.live);
+    uint32_t* __restrict__ queue = reinterpret_cast<uint32_t*>(L.live) + 3u * (size_t)n;
+    const float size = L.psize, size2 = size * size;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = gridDim.x * 4u;
+    for (uint32_t c0 = wave * 64u; c0 < n; c0 += n_waves * 64u) {
+        const uint32_t i = c0 + lane;
+        const bool have = i < n;
+        const bool root = have && par[i] == i;
+        const uint32_t sz = root ? par[n + i] : 0u, last = root ? par[2u * n + i] : 0u;
+        if (sz == 1u) { const float4 c = L.cand[i]; L.out0[i] = make_float4(c.x, c.y, c.z, 1.0f); L.out_valid[i] = 1u; }
+        if (sz > kAkSmallComp) {
+            const uint32_t at = atomicAdd(L.counts + 2, 1u), first = atomicAdd(L.counts + 3, sz);     // (counts[3]: gather cursor until the large pass; then the hand-back flag)
+            queue[2u * at] = i; queue[2u * at + 1u] = first;
+        }
+        unsigned long long todo = __ballot(sz >= 2u && sz <= kAkSmallComp);
+        while (todo) {
+            const int bit = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t r = c0 + (uint32_t)bit, r_last = (uint32_t)__shfl((int)last, bit);
+            // the slots of this component: lane = slot, in opening order
+            float sx = 0.f, sy = 0.f, sr = 0.f; uint32_t sidx = 0u, n_slots = 0u;
+            for (uint32_t b = r; b <= r_last; b += 64u) {
+                const uint32_t j = b + lane;
+                const bool in = j <= r_last;
+                const uint32_t rt = in ? par[j] : 0xFFFFFFFFu;
+                const float4 cj = in ? L.cand[j] : make_float4(0, 0, 0, 0);
+                unsigned long long mm = __ballot(rt == r);
+                while (mm) {
+                    const int k = __builtin_ctzll(mm);
+                    mm &= mm - 1ull;
+                    const float px = __shfl(cj.x, k), py = __shfl(cj.y, k), pr = __shfl(cj.z, k);
+                    const float dx = px - sx, dy = py - sy;
+                    const unsigned long long bal = __ballot(lane < n_slots && dx * dx + dy * dy <= size2);
+                    if (bal) {
+                        const int f = __builtin_ctzll(bal);
+                        if (pr > __shfl(sr, f) && (int)lane == f) { sx = px; sy = py; sr = pr; }
+                    } else {
+                        if (lane == n_slots) { sx = px; sy = py; sr = pr; sidx = b + (uint32_t)k; }
+                        ++n_slots;
+                    }
+                }
+            }
+            if (lane < n_slots) { L.out0[sidx] = make_float4(sx, sy, sr, 1.0f); L.out_valid[sidx] = 1u; }
+        }
+    }
+}
+__global__ __launch_bounds__(64)
+void ak_prune_large_kernel(const AkLevelDev* __restrict__ levels, uint32_t live_cap)
+{
+    __shared__ float lx[kAkLive], ly[kAkLive], lr[kAkLive];
+    __shared__ uint32_t lslot[kAkLive];
+    const AkLevelDev L = levels[blockIdx.y];
+    const uint32_t n = L.counts[0], n_queued = L.counts[2];
+    const uint32_t* __restrict__ par = reinterpret_cast<const uint32_t*>(L.live);
+    const uint32_t* __restrict__ queue = par + 3u * (size_t)n;
+    uint32_t* __restrict__ members = reinterpret_cast<uint32_t*>(L.out1);
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t q = blockIdx.x; q < n_queued; q += gridDim.x) {
+        const uint32_t r = queue[2u * q], first = queue[2u * q + 1u], r_last = par[2u * n + r], sz = par[n + r];
+        uint32_t w = 0;
+        for (uint32_t b = r; b <= r_last; b += 64u) {
+            const uint32_t j = b + lane;
+            const bool is = j <= r_last && par[j] == r;
+            const unsigned long long bal = __ballot(is);
+            if (is) members[first + w + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = j;
+            w += (uint32_t)__builtin_popcountll(bal);
+        }
+        __threadfence();                                     // the wave's own stores, before it reads them back (ak_ld: past the L1)
+        if (!ak_prune_body_batched<true>(L, sz, members + first, lx, ly, lr, lslot, live_cap)) {
+            if (lane == 0) atomicOr(L.counts + 3, kAkHandBack);
+            return;
+        }
+    }
+}
+__global__ __launch_bounds__(1024)
+void ak_prune_emit_kernel(const AkLevelDev* __restrict__ levels)
+{
+    __shared__ uint32_t wsum[16];
+    const AkLevelDev L = levels[blockIdx.x];
+    const uint32_t n = L.counts[0];
+    if (L.counts[3] & kAkHandBack) return;                  // ak_prune_level_kernel rebuilds this level's list
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 1024u) {
+        const uint32_t i = c0 + tid;
+        const bool open = i < n && L.out_valid[i] != 0u;
+        const unsigned long long bal = __ballot(open);
+        if (lane == 0) wsum[wave] = (uint32_t)__builtin_popcountll(bal);
+        r3dm_syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) { const uint32_t v = wsum[k]; before += k < wave ? v : 0u; all += v; }
+        if (open) L.list[base + before + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = L.out0[i];
+        base += all;
+        r3dm_syncthreads();
+    }
+    if (tid == 0) L.counts[1] = base;
 }
 
 // ---- cross-level pruning.  mode 0 ("lower"): a point q of level i-1 dies when some point p of level i lies within
@@ -1254,38 +1450,52 @@ void ak_refine_kernel(const AkLevelDev* __restrict__ levels, int n_levels)
 
 // ---- the surviving keypoints of every image, compacted in the reference's order (evolution level, then list order) into one
 // record array per image: what crosses to the host for the angle (getAngleV2 = atan2 of the host libm, utils.h of fast-akaze)
-// and comes back as the LIOP warp -- 32 bytes per keypoint, one copy each way.  One workgroup per image.
-__global__ __launch_bounds__(256)
+// and comes back as the LIOP warp -- 32 bytes per keypoint, one copy each way.  One workgroup per (level, image): it counts the
+// survivors of the levels before its own (4 bytes per list entry, a few hundred KB at most), then writes its level's records behind
+// them.  (Rounds 2-5: one workgroup of 256 per image walking all levels, two barriers per 256 entries: 184 us per batch of eight.)
+__global__ __launch_bounds__(1024)
 void ak_compact_kernel(const AkLevelDev* __restrict__ levels, int n_levels, AkKpRec* __restrict__ recs, uint32_t cap,
                        AkBatchMeta* __restrict__ meta)
 {
-    __shared__ uint32_t wave_cnt[4];
-    const uint32_t b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t wave_cnt[16];
+    const uint32_t b = blockIdx.y;
+    const int mine = (int)blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     AkKpRec* out = recs + (size_t)b * cap;
-    uint32_t base = 0;
-    for (int i = 0; i < n_levels; ++i) {
+    uint32_t before = 0;
+    for (int i = 0; i < mine; ++i) {
         const AkLevelDev L = levels[(size_t)b * n_levels + i];
         const uint32_t n = L.counts[1];
-        for (uint32_t j0 = 0; j0 < n; j0 += 256) {
-            const uint32_t j = j0 + threadIdx.x;
-            const bool v = j < n && L.out_valid[j] != 0;
-            const unsigned long long bal = __ballot(v);
-            if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
-            r3dm_syncthreads();
-            uint32_t woff = 0, tot = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const uint32_t cw = wave_cnt[q]; if (q < wave) woff += cw; tot += cw; }
-            if (v) {
-                const float4 o0 = L.out0[j]; const float2 o1 = L.out1[j];
-                AkKpRec r; r.x = o0.x; r.y = o0.y; r.size = o0.z; r.response = o0.w; r.max_x = o1.x; r.max_y = o1.y; r.level = (uint32_t)i; r.pad = 0;
-                out[base + woff + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = r;
-            }
-            base += tot;
-            r3dm_syncthreads();
-        }
+        for (uint32_t j = tid; j < n; j += 1024u) before += L.out_valid[j] != 0 ? 1u : 0u;
     }
-    if (threadIdx.x == 0) meta[b].n_kp = base;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off);
+    if (lane == 0) wave_cnt[wave] = before;
+    r3dm_syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) base += wave_cnt[q];
+    r3dm_syncthreads();
+    const AkLevelDev L = levels[(size_t)b * n_levels + mine];
+    const uint32_t n = L.counts[1];
+    for (uint32_t j0 = 0; j0 < n; j0 += 1024u) {
+        const uint32_t j = j0 + tid;
+        const bool v = j < n && L.out_valid[j] != 0;
+        const unsigned long long bal = __ballot(v);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__builtin_popcountll(bal);
+        r3dm_syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 16u; ++q) { const uint32_t cw = wave_cnt[q]; woff += q < wave ? cw : 0u; tot += cw; }
+        if (v) {
+            const float4 o0 = L.out0[j]; const float2 o1 = L.out1[j];
+            AkKpRec r; r.x = o0.x; r.y = o0.y; r.size = o0.z; r.response = o0.w; r.max_x = o1.x; r.max_y = o1.y; r.level = (uint32_t)mine; r.pad = 0;
+            out[base + woff + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = r;
+        }
+        base += tot;
+        r3dm_syncthreads();
+    }
+    if (mine == n_levels - 1 && tid == 0) meta[b].n_kp = base;
 }
 
 // ---- MLDB-486 descriptor (MLDB_Full_Descriptor_InvokerV2, AKAZEFeatures.cpp:1790-1909): 2 keypoints per wavefront, one lane per
@@ -1511,7 +1721,17 @@ hipError_t ak_prune_levels(hipStream_t st, const AkLevelDev* levels, int n_level
 {
     // R3DM_AK_LIVE_CAP (test hook): a small LDS capacity forces the global-scratch fallback of the in-level pruning
     static const uint32_t live_cap = [] { const int c = r3dm_dev_knob("R3DM_AK_LIVE_CAP", kAkLive); return (uint32_t)(c < 1 ? 1 : c > kAkLive ? kAkLive : c); }();
-    hipLaunchKernelGGL(ak_prune_level_kernel, dim3((unsigned)(n_levels * B)), dim3(64), 0, st, levels, live_cap);
+    // R3DM_AK_PRUNE=0 (developer build): every level by one wavefront, the form of rounds 2-5
+    static const bool parallel = r3dm_dev_knob("R3DM_AK_PRUNE", 1) != 0;
+    const unsigned nl = (unsigned)(n_levels * B);
+    if (parallel) {
+        hipLaunchKernelGGL(ak_prune_link_kernel, dim3(32, nl), dim3(256), 0, st, levels);
+        hipLaunchKernelGGL(ak_prune_flatten_kernel, dim3(16, nl), dim3(256), 0, st, levels);
+        hipLaunchKernelGGL(ak_prune_small_kernel, dim3(32, nl), dim3(256), 0, st, levels);
+        hipLaunchKernelGGL(ak_prune_large_kernel, dim3(8, nl), dim3(64), 0, st, levels, live_cap);
+        hipLaunchKernelGGL(ak_prune_emit_kernel, dim3(nl), dim3(1024), 0, st, levels);
+    }
+    hipLaunchKernelGGL(ak_prune_level_kernel, dim3(nl), dim3(64), 0, st, levels, live_cap, parallel ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t ak_list_ranges(hipStream_t st, const AkLevelDev* levels, int n_levels, int B)
@@ -1535,7 +1755,8 @@ hipError_t ak_refine(hipStream_t st, const AkLevelDev* levels, int n_levels, int
 }
 hipError_t ak_compact(hipStream_t st, const AkLevelDev* levels, int n_levels, int B, AkKpRec* recs, uint32_t cap, AkBatchMeta* meta)
 {
-    hipLaunchKernelGGL(ak_compact_kernel, dim3((unsigned)B), dim3(256), 0, st, levels, n_levels, recs, cap, meta);
+    if (n_levels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ak_compact_kernel, dim3((unsigned)n_levels, (unsigned)B), dim3(1024), 0, st, levels, n_levels, recs, cap, meta);
     return hipGetLastError();
 }
 

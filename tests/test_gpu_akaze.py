@@ -76,6 +76,37 @@ def test_live_set_overflow_falls_back_to_scratch(ctx, tmp_path):
     assert np.array_equal(np.load(str(tmp_path / "k.npy")), kps) and np.array_equal(np.load(str(tmp_path / "r.npy")), resp)
 
 
+@pytest.mark.parametrize("env", [{"R3DM_AK_PRUNE": "0"}, {"R3DM_AK_LIVE_CAP": "8"}, {"R3DM_AK_PRUNE": "0", "R3DM_AK_LIVE_CAP": "8"}])
+@pytest.mark.parametrize("kind", ["scene", "noise", "dense"])
+def test_in_level_pruning_in_parallel_equals_the_one_wavefront_form(ctx, tmp_path, env, kind):
+    """Round 6: the in-level pruning resolves the connected components of `within size of each other` side by side (lone candidates on
+    the spot, components of <= 64 by a wavefront with the slots in registers, larger ones with the live set in LDS, a live set that
+    outgrows LDS handing the level back).  R3DM_AK_PRUNE=0 (developer build) is the one-wavefront form of rounds 2-5, R3DM_AK_LIVE_CAP=8
+    forces the hand-back: keypoints, their order and responses must not move.  noise / dense: thousands of candidates per level,
+    components of hundreds of candidates."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(21)
+    if kind == "scene":
+        img, thr = _scene(700, 900, 9, n_blobs=120, noise=0.02), 1e-5
+    elif kind == "noise":
+        img, thr = np.clip(0.5 + rng.normal(0, 0.2, (500, 700)), 0, 1).astype(np.float32), 1e-7
+    else:
+        # smooth noise: extrema a few pixels apart everywhere -> chains of candidates within each other's radius
+        from scipy.ndimage import gaussian_filter
+        img, thr = np.clip(0.5 + 4.0 * gaussian_filter(rng.normal(0, 0.2, (600, 800)), 1.2), 0, 1).astype(np.float32), 1e-8
+    kps, resp = ctx.detect_akaze(img, thr)
+    assert len(kps) > 1000
+    np.save(str(tmp_path / "img.npy"), img)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np; from regard3d_amd import api; api.use_developer_library(); "
+            f"c = api.Context(0); k, r = c.detect_akaze(np.load({str(tmp_path / 'img.npy')!r}), {thr!r}); "
+            f"np.save({str(tmp_path / 'k.npy')!r}, k); np.save({str(tmp_path / 'r.npy')!r}, r)")
+    r = subprocess.run([sys.executable, "-c", code], env=dict({k: v for k, v in os.environ.items() if not k.startswith("R3DM_")}, **env),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(str(tmp_path / "k.npy")), kps) and np.array_equal(np.load(str(tmp_path / "r.npy")), resp)
+
+
 @pytest.mark.parametrize("env", [{"R3DM_AK_HEAD": "1"}, {"R3DM_AK_FED_MARCH": "0"}, {"R3DM_AK_FED_MARCH": "0", "R3DM_AK_FED_MULTI": "0"},
                                  {"R3DM_AK_FED_KMAX": "2", "R3DM_AK_FED_WAVES": "300"}])
 def test_alternative_launch_forms_of_the_scale_space_are_bit_identical(ctx, tmp_path, env):
