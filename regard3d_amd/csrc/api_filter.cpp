@@ -234,7 +234,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     fp.soff = B.f_soff.as<uint64_t>();
     FHIP(B.f_la.ensure((size_t)NI * 1024 * 8 + 64));
     fp.la_tab = B.f_la.as<double>();
-    fp.scout = (uint32_t)(r3dm_dev_knob("R3DM_FILTER_SCOUT", 1) != 0);      // (developer build: 0 = every model through the full evaluation, for A/B and parity)
+    { const int sc = r3dm_dev_knob("R3DM_FILTER_SCOUT", 1); fp.scout = (uint32_t)(sc < 0 ? 0 : sc > 5 ? 1 : sc); }   // (developer build: 0 = every model through the full evaluation, 2 = the scout divides exactly, 3 = check mode with R3DM_FILTER_CHECK=1; A/B and parity)
     // launch order: the workgroup of a pair runs for a time roughly proportional to its putative count, and a C2 call has
     // ~1.5 x as many pairs as resident workgroups -- start the long ones first so the tail of the launch is short ones
     {
@@ -373,6 +373,10 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
             trace_buf.release();
             o.err = e != hipSuccess ? std::string("filter check: ") + hipGetErrorString(e)
                    : "filter invariant " + std::to_string(d[0]) + " violated at item " + std::to_string(d[1]) + " (" + std::to_string(d[2]) + ", " + std::to_string(d[3]) + ")";
+            if (e == hipSuccess && (d[0] == 10u || d[0] == 11u)) {     // (the scout's bound, and the NFA / the full evaluation's bound it exceeds, as float bits)
+                float fa, fb; memcpy(&fa, &d[2], 4); memcpy(&fb, &d[3], 4);
+                char b[96]; snprintf(b, sizeof b, " = (%.7g, %.7g)", (double)fa, (double)fb); o.err += b;
+            }
             return R3DM_ERR_HIP;
         }
     }

@@ -968,12 +968,60 @@ __device__ __forceinline__ void wg_sort_regs(unsigned long long* __restrict__ ke
 // exactly one the full evaluation would have found hopeless or short of AC mode.
 // la_g: per-bin NFA slope logalpha0 + mult log10(edge + eps) of the pair (filled once per pair, same expression as the full evaluation)
 // ------------------------------------------------------------------------------------------------
+// The scout only needs to know on which side of the bound a residual lies and in which histogram bin -- never the value -- so it
+// trades the sweep's IEEE divisions (two per residual for F and H, ~11 dependent f64 instructions each) for v_rcp_f64 + one Newton step
+// and carries an interval [lo, hi] that contains the residual the full evaluation would compute: v_rcp_f64 is good to 2^-23 (measured:
+// tools/ubench/rcp_f64_accuracy.hip), one step squares that; the margins below are 2^-32 where the quotient enters as a factor and
+// 2^-40 of the quotient where a difference follows it (H).  `hi <= bound` is surely within, `lo <= bound` possibly; the histogram takes
+// `lo` of the possible ones, which can only lower the NFA bound.  Counts that the interval leaves open on either side of a threshold
+// of the walk (SS, 2.5 SS) send the model to the full evaluation.  NaN / inf (a degenerate model) fail every comparison, as they do there.
+__device__ __forceinline__ double rcp_newton(double a)
+{
+    const double r = __builtin_amdgcn_rcp(a);
+    return __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+}
+template <int KIND>
+__device__ __forceinline__ void scout_residual(const double* F, double x1, double y1, double x2, double y2, double& lo, double& hi)
+{
+    if (KIND == 1) {
+        const double rw = rcp_newton(F[6] * x1 + F[7] * y1 + F[8]);
+        const double qx = (F[0] * x1 + F[1] * y1 + F[2]) * rw, qy = (F[3] * x1 + F[4] * y1 + F[5]) * rw;
+        const double ex = __builtin_fabs(x2 - qx), ey = __builtin_fabs(y2 - qy);
+        const double mx = 0x1p-40 * (__builtin_fabs(qx) + ex), my = 0x1p-40 * (__builtin_fabs(qy) + ey);
+        const double lx = __builtin_fmax(ex - mx, 0.0), ly = __builtin_fmax(ey - my, 0.0), hx = ex + mx, hy = ey + my;
+        lo = (lx * lx + ly * ly) * (1.0 - 0x1p-40);
+        hi = (hx * hx + hy * hy) * (1.0 + 0x1p-40);
+    } else {
+        const double l0 = F[0] * x1 + F[1] * y1 + F[2];
+        const double l1 = F[3] * x1 + F[4] * y1 + F[5];
+        const double l2 = F[6] * x1 + F[7] * y1 + F[8];
+        const double d = x2 * l0 + y2 * l1 + l2;
+        double r;
+        if (KIND == 0) {
+            const double t0 = F[0] * x2 + F[3] * y2 + F[6];
+            const double t1 = F[1] * x2 + F[4] * y2 + F[7];
+            r = (d * d) * (rcp_newton(l0 * l0 + l1 * l1) + rcp_newton(t0 * t0 + t1 * t1)) * 0.25;
+        } else {
+            r = (d * d) * rcp_newton(l0 * l0 + l1 * l1);
+        }
+        lo = r * (1.0 - 0x1p-32);
+        hi = r * (1.0 + 0x1p-32);
+    }
+}
+constexpr uint32_t kScoutOpen = 0x80000000u;        // sc_total: the count is open on one side of a threshold of the walk
+// lanes of a wavefront that hand values to each other through LDS: to the compiler they are separate threads, so the store of one and the
+// load of another need an order it has to respect (found by the scout's check mode: the cross-lane reads of the running counts below had
+// been scheduled ahead of the write-back and saw raw bin counts -- a bound that was not one)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <int KIND>
 __device__ __noinline__ void scout_model(const float4* __restrict__ pt, uint32_t m, const double* __restrict__ Fm, const double* __restrict__ kinv,
                                          double s1, double t1x, double t1y, double s2, double t2x, double t2y, double maxThreshold,
                                          long long hist_base, bool want_bound, const double* __restrict__ la_g, const float* __restrict__ logc_n,
                                          const float* __restrict__ logc_k, double loge0, uint32_t* __restrict__ whist, uint32_t lane,
-                                         uint32_t* __restrict__ out_total, double* __restrict__ out_bound)
+                                         uint32_t* __restrict__ out_total, double* __restrict__ out_bound, bool exact, double slack)
 {
     constexpr uint32_t SS = (KIND == 0) ? 7u : (KIND == 1 ? 4u : 5u);
     double F[9];
@@ -986,8 +1034,9 @@ __device__ __noinline__ void scout_model(const float4* __restrict__ pt, uint32_t
         uint4* z = reinterpret_cast<uint4*>(whist + 16u * lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) z[j] = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_sync();
     }
-    uint32_t total = 0;
+    uint32_t total = 0, total_sure = 0;
     for (uint32_t base = 0; base < m; base += 256u) {
         double px[4][4];
 #pragma unroll
@@ -1000,21 +1049,30 @@ __device__ __noinline__ void scout_model(const float4* __restrict__ pt, uint32_t
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t p = base + 64u * (uint32_t)u + lane;
-            const double r = (KIND == 0) ? sym_epipolar_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
-                           : (KIND == 1) ? h_asym_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
-                                         : epipolar_dist_err(F, px[u][0], px[u][1], px[u][2], px[u][3]);
-            const bool in = (p < m) && (r <= maxThreshold);
+            double r_lo, r_hi;
+            if (exact || KIND == 1) {           // (H: the interval costs what the two divisions by one denominator do -- measured 10.1 -> 11.0 ms; it keeps them)
+                r_lo = (KIND == 0) ? sym_epipolar_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
+                     : (KIND == 1) ? h_asym_err(F, px[u][0], px[u][1], px[u][2], px[u][3])
+                                   : epipolar_dist_err(F, px[u][0], px[u][1], px[u][2], px[u][3]);
+                r_hi = r_lo;
+            } else {
+                scout_residual<KIND>(F, px[u][0], px[u][1], px[u][2], px[u][3], r_lo, r_hi);
+            }
+            const bool in = (p < m) && (r_lo <= maxThreshold);
             total += (uint32_t)__builtin_popcountll(__ballot(in));
+            total_sure += (uint32_t)__builtin_popcountll(__ballot((p < m) && (r_hi <= maxThreshold)));
             if (want_bound && in) {
-                long long bin = (__double_as_longlong(r) >> kHistShift) - hist_base;
+                long long bin = (__double_as_longlong(r_lo) >> kHistShift) - hist_base;
                 bin = bin < 0 ? 0 : (bin > kHistBins - 1 ? kHistBins - 1 : bin);
                 atomicAdd(&whist[bin], 1u);
             }
         }
     }
+    const bool open = ((double)total > 2.5 * SS) != ((double)total_sure > 2.5 * SS) || (total > SS) != (total_sure > SS);
     double bound = -__builtin_huge_val();                  // "no bound": the walk then takes the full evaluation
     if (want_bound && total > SS) {
         // inclusive running counts over the bins: 16 consecutive bins per lane, written back in place
+        wave_lds_sync();
         uint32_t cb[16];
         uint32_t run = 0;
 #pragma unroll
@@ -1025,25 +1083,31 @@ __device__ __noinline__ void scout_model(const float4* __restrict__ pt, uint32_t
         const uint32_t excl = incl - run;
 #pragma unroll
         for (int j = 0; j < 16; ++j) whist[16u * lane + (uint32_t)j] = excl + cb[j];
-        // bins lane, lane + 64, ...: neighbouring (equally dense) bins go to different lanes
+        wave_lds_sync();
+        // bins lane, lane + 64, ...: neighbouring (equally dense) bins go to different lanes.  Within a bin the NFA term of k is
+        // la k + g(k) + const with g = logc_n + logc_k; g is concave in k (log-binomials) up to the rounding drift of its float
+        // tables, so over the k of a bin the term is smallest at one END of the range, less `slack` (scout_slack below bounds twice the
+        // drift): two table reads per bin, all of a lane's in flight at once, where one read pair per k made this loop -- a chain of
+        // dependent global loads, up to the bin's whole count long -- the larger part of a model's cost (the scout's first form).
         double wmin = __builtin_huge_val();
+#pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t b = lane + 64u * (uint32_t)j;
             const uint32_t k_hi = whist[b], k_prev = b ? whist[b - 1] : 0u;
             uint32_t k_lo = k_prev + 1u; if (k_lo < SS + 1u) k_lo = SS + 1u;
-            if (k_hi >= k_lo) {
-                const double la = la_g[b];
-                for (uint32_t kk = k_lo; kk <= k_hi; ++kk) {
-                    const double w = loge0 + la * (double)(kk - SS) + (double)logc_n[kk] + (double)logc_k[kk];
-                    wmin = w < wmin ? w : wmin;
-                }
-            }
+            const bool some = k_hi >= k_lo;
+            const uint32_t ka = some ? k_lo : 0u, kb = some ? k_hi : 0u;
+            const double la = la_g[b];
+            const double wa = loge0 + la * (double)(ka - SS) + (double)logc_n[ka] + (double)logc_k[ka];
+            const double wb = loge0 + la * (double)(kb - SS) + (double)logc_n[kb] + (double)logc_k[kb];
+            const double w = wa < wb ? wa : wb;
+            wmin = (some && w < wmin) ? w : wmin;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wmin, off); wmin = o < wmin ? o : wmin; }
-        bound = wmin;
+        bound = wmin - slack;
     }
-    if (lane == 0) { *out_total = total; *out_bound = bound; }
+    if (lane == 0) { *out_total = total | (open ? kScoutOpen : 0u); *out_bound = bound; }
 }
 
 // NT = threads of the workgroup: 256 (two workgroups per CU), or 512 for collections with long match lists (one workgroup per CU with
@@ -1129,7 +1193,11 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     for (int j = 0; j < kHistBins / NT; ++j) hist[tid + NT * j] = 0u;
     // the scout pass (scout_model above): on in the product; the developer build can switch it off (A/B, parity of the two walks) and
     // its traces / invariant checks take the full evaluation for every model
-    const bool scout_on = P.scout != 0u && P.la_tab != nullptr && !R3DM_TRACE(P) && !R3DM_DBG(P);
+    // (developer build: R3DM_FILTER_SCOUT=2 -- the scout divides like the full evaluation; =3 with R3DM_FILTER_CHECK=1 -- the scout runs,
+    // nothing is skipped, and every model's count and NFA are checked against what the scout promised: invariants 9 and 10)
+    const bool scout_check = P.scout >= 3u && R3DM_DBG(P) && !R3DM_TRACE(P);
+    const bool scout_on = P.scout != 0u && P.la_tab != nullptr && !R3DM_TRACE(P) && (!R3DM_DBG(P) || scout_check);
+    const bool scout_exact = P.scout == 2u || P.scout == 5u;
     double* __restrict__ la_g = P.la_tab ? P.la_tab + (size_t)item * kHistBins : nullptr;
     if (scout_on) {
 #pragma unroll
@@ -1144,6 +1212,9 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     bool ac_reg = !(P.precision_px < __builtin_huge_val());
     uint32_t nmod_reg = 0, iters_done_reg = 0;
     wg_sync_global();          // points, pool, logcombi and slope tables go through global memory
+    // what the float accumulation of the log-binomial tables (orc_logcombi_tables: <= m / 2 additions of float log10 differences, each
+    // rounded at the running sum's ulp) can move them away from a concave sequence, twice: drift <= (m / 2) (2^-25 max + 2^-21)
+    const double scout_slack = scout_on ? 0x1p-24 * (double)m * ((double)logc_n[m / 2u] + 32.0) + 1.0e-4 : 0.0;
 
 #ifdef R3DM_E_TIMING
     unsigned long long cyc_solve = 0, cyc_eval = 0, cyc_t0 = 0, cyc_res = 0, cyc_sort = 0;
@@ -1260,6 +1331,7 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
             const uint32_t nm = S.nm[c];
             bool better = false;
             for (uint32_t k = 0; k < nm; ++k) {
+                [[maybe_unused]] uint32_t chk_tot = 0u; [[maybe_unused]] double chk_bound = -__builtin_huge_val();
                 if (scout_on) {
                     const uint32_t f = moff[c] + k;
                     if (f >= scouted) {
@@ -1272,19 +1344,21 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                             const uint32_t cc = (uint32_t)__builtin_ctzll(__ballot(hit));
                             const uint32_t kk = fi - moff[cc];
                             scout_model<KIND>(pt, m, Fs + cc * MS + kk * 9, S.kinv, s1, t1x, t1y, s2, t2x, t2y, maxThreshold, hist_base, want_bound,
-                                              la_g, logc_n, P.logc_k, loge0, whist, lane, sc_total + fi, sc_bound + fi);
+                                              la_g, logc_n, P.logc_k, loge0, whist, lane, sc_total + fi, sc_bound + fi, scout_exact, scout_slack);
                         }
                         wg_sync_t<SPILL>();
                         scouted = end_f;
                     }
                     // can the full evaluation accept this model?  Not below AC mode's 2.5 x sample size, not with SS or fewer matches
                     // within the bound, not when the best NFA its residual histogram allows is above the best so far
-                    const uint32_t tot_f = sc_total[f];
+                    const uint32_t tot_w = sc_total[f], tot_f = tot_w & ~kScoutOpen;
                     const double bound_f = sc_bound[f], minNFA_f = S.minNFA;
                     const bool ac_f = ac_reg || ((double)tot_f > 2.5 * SS);
-                    const bool skip = !(ac_f && tot_f > SS) ||
-                                      (bound_f > -__builtin_huge_val() && minNFA_f < __builtin_huge_val() && bound_f - 1.0e-6 >= minNFA_f);
-                    if (skip) { ac_reg = ac_f; nmod_reg += 1; continue; }
+                    const bool skip = !(tot_w & kScoutOpen) &&
+                                      (!(ac_f && tot_f > SS) ||
+                                       (bound_f > -__builtin_huge_val() && minNFA_f < __builtin_huge_val() && bound_f - 1.0e-6 >= minNFA_f));
+                    if (skip && !scout_check) { ac_reg = ac_f; nmod_reg += 1; continue; }
+                    chk_tot = tot_w; chk_bound = bound_f;
                 }
                 double F[9];
 #pragma unroll
@@ -1468,6 +1542,12 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 const bool improve = ac && (nfa < minNFA);
                 FCHECK(!improve || (kbest <= total && kbest > SS), 4, kbest, total);
                 FCHECK(S_bound - 1.0e-6 <= nfa, 8, kbest, total);                 // the sort-skipping bound really is one
+                if (scout_check) {
+                    const uint32_t ct = chk_tot & ~kScoutOpen;
+                    FCHECK(ct >= total && ((chk_tot & kScoutOpen) || (((double)ct > 2.5 * SS) == ((double)total > 2.5 * SS) && (ct > SS) == (total > SS))), 9, ct, total);
+                    FCHECK(!(ac && total > SS) || !(S_bound > -__builtin_huge_val()) || chk_bound <= S_bound + 1.0e-9, 11, __float_as_uint((float)chk_bound), __float_as_uint((float)S_bound));   // ... the scout's bound is the full evaluation's, or below it
+                    FCHECK(!(ac && total > SS) || chk_bound - 1.0e-6 <= nfa, 10, __float_as_uint((float)chk_bound), __float_as_uint((float)nfa));     // ... and so is the scout's
+                }
                 if (improve) {
                     for (uint32_t q = tid; q < kbest; q += NT) inl[q] = sidx[q];
                     better = true;

@@ -496,10 +496,13 @@ def test_filters_on_degenerate_and_tiny_pairs(ctx, oracle):
 
 
 @pytest.mark.gpu
-def test_filters_skip_no_model_that_could_win(ctx):
+@pytest.mark.parametrize("scout", ["0", "3"])
+def test_filters_skip_no_model_that_could_win(ctx, scout):
     """The AC-RANSAC kernels skip the sort of a model whose histogram bound on the NFA stays above the best NFA so far
     (kernels_filter.hip).  The developer build with R3DM_FILTER_CHECK=1 skips nothing and checks `bound <= NFA` on every model it
-    evaluates (invariant 8 -> error); its inlier sets and models must equal the product's."""
+    evaluates (invariant 8 -> error); its inlier sets and models must equal the product's.  R3DM_FILTER_SCOUT=3 beside it: the scout
+    pass runs too (reciprocal intervals instead of divisions, the NFA bound from the two ends of every bin's count range less the
+    tables' drift) and every model's exact count and NFA are checked against what the scout promised (invariants 9, 10)."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sc = synth.make_scene(7, 4000, "sift", seed=612)
@@ -533,7 +536,7 @@ def test_filters_skip_no_model_that_could_win(ctx):
     """)
     import tempfile
     with tempfile.TemporaryDirectory() as d:
-        r = subprocess.run([sys.executable, "-c", code, d + "/"], env=dict(os.environ, R3DM_FILTER_CHECK="1"), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code, d + "/"], env=dict(os.environ, R3DM_FILTER_CHECK="1", R3DM_FILTER_SCOUT=scout), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "checked" in r.stdout, r.stdout[-800:] + r.stderr[-2500:]
         for name in ("F", "H", "E"):
             z = np.load(d + "/" + name + ".npz")
