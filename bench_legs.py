@@ -364,6 +364,8 @@ def attach_traffic(roof, config, kernel, at_named_size):
         roof["traffic_source"] = (f"profiles/pmc_traffic.json: the entry for {ent['kernel']} was measured on other machine code "
                                   f"(entry {ent.get('code_sha16')}, this library {cur}): not reported")
         return
+    if "traffic_bytes_per_launch" not in ent:                   # (an entry counted per pair -- c5's graph search -- is reported by its own leg)
+        return
     roof["traffic"] = ent["traffic_bytes_per_launch"]
     roof["traffic_source"] = (f"profiles/pmc_traffic.json <- {ent.get('from', '?')}: separate rocprofv3 --pmc passes of this command on the same "
                               f"kernel machine code (code_sha16 {cur}; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured inside this process"
