@@ -604,7 +604,8 @@ class Context:
 
     def set_images(self, view_ids, descs, xys=None, width: int = 0, height: int = 0, binary: bool = False, wait: bool = False):
         """a whole collection in one call (r3dm_set_images): descs / xys are sequences of [n, dim] / [n, 2] arrays (numpy: host memory,
-        copied through the library's page-locked ring by helper threads; torch: read where they are).  wait: return when every view is
+        copied through the library's page-locked ring by helper threads; torch: device or page-locked tensors, copied by the copy engine straight
+        into the ring's device slot).  wait: return when every view is
         resident and laid out (r3dm_images_wait) instead of when the caller's buffers are consumed."""
         keep = []
         arr = (ViewDesc * len(view_ids))()

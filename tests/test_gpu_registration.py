@@ -45,7 +45,8 @@ def _scene(kind, n_img=7, n_feat=900, seed=4242):
 
 
 @pytest.mark.parametrize("kind", ["sift", "liop", "akaze"])
-@pytest.mark.parametrize("source", ["numpy_batch", "numpy_single", "pinned_batch", "device_batch", "device_single"])
+@pytest.mark.parametrize("source", ["numpy_batch", "numpy_single", "pinned_batch", "device_batch", "device_single",
+                                    "mixed_batch", "mixed_single"])
 def test_every_source_and_entry_registers_the_same_collection(oracle, kind, source):
     import torch
     sc = _scene(kind)
@@ -59,6 +60,13 @@ def test_every_source_and_entry_registers_the_same_collection(oracle, kind, sour
     elif source.startswith("pinned"):
         D = [torch.from_numpy(np.ascontiguousarray(d)).pin_memory() for d in sc.descs]
         X = [torch.from_numpy(np.ascontiguousarray(x)).pin_memory() for x in sc.xys]
+    elif source.startswith("mixed"):
+        # rows and positions of one view in different kinds of memory, changing from view to view: pageable rows + device positions,
+        # device rows + pageable positions, page-locked rows + device positions
+        pick = lambda a, how: (a if how == 0 else torch.from_numpy(np.ascontiguousarray(a)).pin_memory() if how == 1
+                               else torch.from_numpy(np.ascontiguousarray(a)).cuda())
+        D = [pick(d, (0, 2, 1)[i % 3]) for i, d in enumerate(sc.descs)]
+        X = [pick(x, (2, 0, 2)[i % 3]) for i, x in enumerate(sc.xys)]
     else:
         D = [torch.from_numpy(np.ascontiguousarray(d)).cuda() for d in sc.descs]
         X = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in sc.xys]
@@ -77,6 +85,8 @@ def test_every_source_and_entry_registers_the_same_collection(oracle, kind, sour
         _, _, ring, direct = c.view_info(0)
         if source.startswith("numpy"):
             assert ring == 2 * 6 and direct == 2              # (the empty view has nothing to send through the ring)
+        elif source.startswith("mixed"):
+            assert ring + direct == 2 * 7 and ring > 0 and direct > 0
         else:
             assert ring == 0 and direct == 2 * 7
     finally:
