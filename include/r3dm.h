@@ -82,7 +82,9 @@ int  r3dm_device_info(const r3dm_ctx* ctx, char* arch, size_t arch_cap, int* n_c
  * The call returns when the caller's buffers are consumed, NOT when the view is laid out: rows in pageable host memory are copied
  * into a ring of page-locked slots and travel from there (one DMA + one kernel per view, queued on the context's streams); rows
  * behind device pointers (this device's or a peer's) and page-locked host pointers are copied by the copy engine into the ring's
- * device slot, and only that copy is waited for.  Every later call of the context is ordered behind
+ * device slot, and only that copy is waited for.  A device buffer must be COMPLETE when the call is made: the library's streams are
+ * not ordered behind the caller's, so the stream that produced the buffer has to be synchronised first (the features workers of
+ * r3dm_multi_extract_features hand their batches over that way).  Every later call of the context is ordered behind
  * the registration; r3dm_images_wait waits for it explicitly.  A view costs its f32 tiles + norms in HBM (1.0 x its f32 size); the
  * layouts only some paths read (row-major rows for real-valued views and the approximate matchers, bf16 / split-f16 / count /
  * byte tiles of the opt-in paths) are made by the first call that needs them, or here when the path's switch is already on. */
