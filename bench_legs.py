@@ -387,7 +387,7 @@ def opt_in_integer(ctx, step, fence, g, gf, job_pairs):
     return {"value": job_pairs / el2, "unit": "pairs/s", "ms_per_step": el2 * 1e3, "steps": 1,
             "identical_to_headline_graphs": bool(same), "integer_mfma_launches": int(sm2.n_integer_mfma),
             "dtype": "bf16 operands holding exact integers, f32 accumulate (exact below 2^24)",
-            "roofline": {"bound": "mfma", "kernel": "l2_knn2_int_kernel<GB=8,NJ=2>", "achieved": ach2, "peak": BF16_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "l2_knn2_int_kernel<GB=8,NJ=3>", "achieved": ach2, "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach2 / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": sm2.ms_match_kernels / max(sm2.n_match_launches, 1)},
             "filter_kernel_ms": sa2.ms_filter_kernels,

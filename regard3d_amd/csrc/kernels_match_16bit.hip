@@ -193,7 +193,7 @@ hipError_t launch_l2_knn2_int(hipStream_t st, const MatchParams& P, uint32_t G, 
 {
 #ifdef R3DM_DEVTOOLS
     // R3DM_L2_INT_VARIANT (A/B measurements on 780 pairs of 8192 x 8192 rows, D = 128; the f32 tiles take 95.0 ms):
-    //   2 = NJ 2 x 2 waves/SIMD (default, 12.4 ms) | 8 = same with a whole-tile prefetch window (12.95 ms) |
+    //   2 = the product | 22 = NJ 2 x 2 waves/SIMD (the product until round 6, 12.4 ms) | 8 = same with a whole-tile prefetch window (12.95 ms) |
     //   4 = NJ 4 x 1 wave/SIMD (17.6 ms) | 9 = 2 without the epilogue (timing only, 11.4 ms) | 5 / 59 / 6: tiles shared through LDS (kernels_match_hamming.hip)
     //   round 5, same workload (2 = 11.67 ms): 9 = no epilogue 10.52 | 10 = no tile / norm loads 7.57 | 11 = neither 7.26 (timing only);
     //   5 = LDS-shared 12.16 | 59 = LDS-shared without the epilogue 9.36.  The loads are the bound: with two query tiles per wave a CU's
@@ -201,6 +201,7 @@ hipError_t launch_l2_knn2_int(hipStream_t st, const MatchParams& P, uint32_t G, 
     static const int iv = r3dm_dev_knob("R3DM_L2_INT_VARIANT", 2);
     if (G == 16 && (iv == 5 || iv == 59 || iv == 6 || iv == 7 || iv == 79)) return launch_l2_int_lds_variant(st, P, max_nj_tiles, iv);
     if (G == 16 && iv == 4) return launch_l2_int<8, 4, 4, 1>(st, P, max_nj_tiles);
+    if (G == 16 && iv == 22) return launch_l2_int<8, 2, 4, 2>(st, P, max_nj_tiles);     // two query tiles per wave (the product of rounds 3-5)
     if (G == 16 && iv == 9) return launch_l2_int<8, 2, 4, 2, 1>(st, P, max_nj_tiles);
     if (G == 16 && iv == 8) return launch_l2_int<8, 2, 8, 2>(st, P, max_nj_tiles);
     if (G == 16 && iv == 10) return launch_l2_int<8, 2, 4, 2, 2>(st, P, max_nj_tiles);
@@ -208,7 +209,9 @@ hipError_t launch_l2_knn2_int(hipStream_t st, const MatchParams& P, uint32_t G, 
 #endif
     switch (G) {
         case 8:  return launch_l2_int<4, 2, 4, 2>(st, P, max_nj_tiles);
-        case 16: return launch_l2_int<8, 2, 4, 2>(st, P, max_nj_tiles);
+        // (128 dimensions: THREE query tiles per wave still fit two waves per SIMD -- 251 registers, no spills -- and a fragment block
+        //  then feeds three MFMAs instead of two: 10.40 ms against 10.80 on 780 pairs of 8,192 rows, same graphs; round 6)
+        case 16: return launch_l2_int<8, 3, 4, 2>(st, P, max_nj_tiles);
         case 32: return launch_l2_int<16, 2, 4, 2>(st, P, max_nj_tiles);
         default: return hipErrorNotSupported;
     }
