@@ -234,7 +234,7 @@ static int filter_prepare(r3dm_ctx* c, FilterCallOut& o, const r3dm_graph* putat
     fp.soff = B.f_soff.as<uint64_t>();
     FHIP(B.f_la.ensure((size_t)NI * 1024 * 8 + 64));
     fp.la_tab = B.f_la.as<double>();
-    { const int sc = r3dm_dev_knob("R3DM_FILTER_SCOUT", 1); fp.scout = (uint32_t)(sc < 0 ? 0 : sc > 5 ? 1 : sc); }   // (developer build: 0 = every model through the full evaluation, 2 = the scout divides exactly, 3 = check mode with R3DM_FILTER_CHECK=1; A/B and parity)
+    { const int sc = r3dm_dev_knob("R3DM_FILTER_SCOUT", 1); fp.scout = (uint32_t)(sc < 0 ? 0 : sc > 5 ? 1 : sc) | ((uint32_t)r3dm_dev_knob("R3DM_FILTER_SCOUT_SUB", 0) << 8); }   // (developer build: 0 = every model through the full evaluation, 2 = the scout divides exactly, 3 = check mode with R3DM_FILTER_CHECK=1; A/B and parity)
     // launch order: the workgroup of a pair runs for a time roughly proportional to its putative count, and a C2 call has
     // ~1.5 x as many pairs as resident workgroups -- start the long ones first so the tail of the launch is short ones
     {

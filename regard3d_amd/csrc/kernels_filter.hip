@@ -1195,9 +1195,10 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
     // its traces / invariant checks take the full evaluation for every model
     // (developer build: R3DM_FILTER_SCOUT=2 -- the scout divides like the full evaluation; =3 with R3DM_FILTER_CHECK=1 -- the scout runs,
     // nothing is skipped, and every model's count and NFA are checked against what the scout promised: invariants 9 and 10)
-    const bool scout_check = P.scout >= 3u && R3DM_DBG(P) && !R3DM_TRACE(P);
-    const bool scout_on = P.scout != 0u && P.la_tab != nullptr && !R3DM_TRACE(P) && (!R3DM_DBG(P) || scout_check);
-    const bool scout_exact = P.scout == 2u || P.scout == 5u;
+    const uint32_t scout_mode = P.scout & 0xFFu;
+    const bool scout_check = scout_mode >= 3u && R3DM_DBG(P) && !R3DM_TRACE(P);
+    const bool scout_on = scout_mode != 0u && P.la_tab != nullptr && !R3DM_TRACE(P) && (!R3DM_DBG(P) || scout_check);
+    const bool scout_exact = scout_mode == 2u || scout_mode == 5u;
     double* __restrict__ la_g = P.la_tab ? P.la_tab + (size_t)item * kHistBins : nullptr;
     if (scout_on) {
 #pragma unroll
@@ -1335,9 +1336,12 @@ __device__ __forceinline__ void acransac_body(const FilterParams& P, double* __r
                 if (scout_on) {
                     const uint32_t f = moff[c] + k;
                     if (f >= scouted) {
-                        // scout the next sub-batch of models, four per wavefront at most (a pool change discards what lies behind it)
+                        // scout the next sub-batch of models (a pool change discards what lies behind it)
                         const uint32_t n_chunk_models = moff[chunk_n];
-                        const uint32_t end_f = scouted + 4u * NW < n_chunk_models ? scouted + 4u * NW : n_chunk_models;
+                        // (two per wavefront: what lies behind an accepted model is scouted for nothing -- 16 per wavefront cost F 10.2 ms where 2 cost 6.9;
+                        //  developer build: R3DM_FILTER_SCOUT_SUB)
+                        const uint32_t sub_n = (P.scout >> 8) ? (P.scout >> 8) * NW : 2u * NW;
+                        const uint32_t end_f = scouted + sub_n < n_chunk_models ? scouted + sub_n : n_chunk_models;
                         const bool want_bound = S.minNFA < __builtin_huge_val();
                         for (uint32_t fi = scouted + wave; fi < end_f; fi += NW) {
                             const bool hit = lane < chunk_n && moff[lane] <= fi && fi < moff[lane + 1u];
