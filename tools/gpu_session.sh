@@ -28,8 +28,11 @@ for step in "$@"; do
   echo "=== [$T] $step"
   case $kind in
     pytest)
-      if [ -n "$a1" ]; then timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q -x -k "$a1" 2>&1 | tail -${PYTEST_TAIL:-15} | tee gpurun_out/${T}_pytest.txt
-      else timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q 2>&1 | tail -${PYTEST_TAIL:-15} | tee gpurun_out/${T}_pytest.txt; fi ;;
+      # (the whole log is kept beside the tail: a run that dies with a signal says which test it was in only at the top of its dump)
+      if [ -n "$a1" ]; then timeout ${PYTEST_TIMEOUT:-1500} python -X faulthandler -m pytest tests -m gpu -q -x -v -k "$a1" > gpurun_out/${T}_pytest_full.txt 2>&1
+      else timeout ${PYTEST_TIMEOUT:-1500} python -X faulthandler -m pytest tests -m gpu -q -v > gpurun_out/${T}_pytest_full.txt 2>&1; fi
+      echo "rc=$?" >> gpurun_out/${T}_pytest_full.txt
+      grep -v "PASSED\|^$" gpurun_out/${T}_pytest_full.txt | tail -${PYTEST_TAIL:-15} | tee gpurun_out/${T}_pytest.txt ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/${T}_smoke.txt ;;
     bench)
